@@ -1,0 +1,213 @@
+// TEST INFRASTRUCTURE ONLY — runtime for the fake hip_runtime.h (tests/hostemu/README.md).
+// One OS thread; every HIP thread of the running block is a ucontext fiber.
+#include <hip/hip_runtime.h>
+#undef threadIdx
+#undef blockIdx
+#undef blockDim
+#undef gridDim
+
+#include <ucontext.h>
+#include <chrono>
+#include <vector>
+
+namespace hipemu {
+
+Idx g_threadIdx, g_blockIdx;
+dim3 g_blockDim, g_gridDim;
+
+namespace {
+constexpr size_t kStack = 256 * 1024;
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool done = false;
+    Idx tid;
+    int lin = 0;
+};
+
+ucontext_t g_sched;
+std::vector<Fiber> g_fibers;
+Fiber* g_cur = nullptr;
+const std::function<void()>* g_body = nullptr;
+std::vector<char> g_dyn;
+void* g_dyn_aligned = nullptr;
+long g_launches = 0;
+
+int g_nthreads = 0;      // threads per block of the running launch
+int g_live = 0;          // fibers of the block not yet finished
+int g_bar_count = 0;
+unsigned g_bar_gen = 0;
+
+struct WaveState {
+    int live = 0;
+    int count = 0;
+    unsigned gen = 0;
+    alignas(64) unsigned char xchg[64][64];
+};
+std::vector<WaveState> g_waves;
+
+void yield() { swapcontext(&g_cur->ctx, &g_sched); }
+
+void trampoline() {
+    (*g_body)();
+    Fiber* f = g_cur;
+    f->done = true;
+    --g_live;
+    WaveState& w = g_waves[f->lin >> 6];
+    --w.live;
+    // a finished thread must not strand its peers at a barrier
+    if (g_bar_count > 0 && g_bar_count == g_live) { g_bar_count = 0; ++g_bar_gen; }
+    if (w.count > 0 && w.count == w.live) { w.count = 0; ++w.gen; }
+    swapcontext(&f->ctx, &g_sched);
+}
+
+void wave_barrier(WaveState& w) {
+    unsigned gen = w.gen;
+    if (++w.count == w.live) { w.count = 0; ++w.gen; return; }
+    while (w.gen == gen) yield();
+}
+}  // namespace
+
+void* dyn_smem() { return g_dyn_aligned; }
+int lane_id() { return g_cur->lin & 63; }
+long launches() { return g_launches; }
+
+void block_barrier() {
+    unsigned gen = g_bar_gen;
+    if (++g_bar_count == g_live) { g_bar_count = 0; ++g_bar_gen; return; }
+    while (g_bar_gen == gen) yield();
+}
+
+void wave_exchange(const void* in, void* out, size_t bytes, int src_lane) {
+    if (bytes > 64) { fprintf(stderr, "hipemu: shuffle payload too large\n"); abort(); }
+    WaveState& w = g_waves[g_cur->lin >> 6];
+    int lane = g_cur->lin & 63;
+    memcpy(w.xchg[lane], in, bytes);
+    wave_barrier(w);
+    int nlanes = 64;
+    int total = g_nthreads;
+    int wave_base = (g_cur->lin >> 6) << 6;
+    if (wave_base + nlanes > total) nlanes = total - wave_base;
+    if (src_lane < 0 || src_lane >= nlanes) src_lane = lane;
+    memcpy(out, w.xchg[src_lane], bytes);
+    wave_barrier(w);
+}
+
+void wave_gather64(const void* in, size_t bytes, void* all64) {
+    WaveState& w = g_waves[g_cur->lin >> 6];
+    int lane = g_cur->lin & 63;
+    memcpy(w.xchg[lane], in, bytes);
+    wave_barrier(w);
+    for (int l = 0; l < 64; ++l) memcpy((char*)all64 + l * bytes, w.xchg[l], bytes);
+    wave_barrier(w);
+}
+
+void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+    ++g_launches;
+    const int nthreads = (int)(block.x * block.y * block.z);
+    if (nthreads <= 0 || nthreads > 1024) { fprintf(stderr, "hipemu: bad block size %d\n", nthreads); abort(); }
+    if (shmem > 160 * 1024) { fprintf(stderr, "hipemu: %zu B of LDS requested (> 160 KiB)\n", shmem); abort(); }
+    g_nthreads = nthreads;
+    g_blockDim = block;
+    g_gridDim = grid;
+    g_body = &body;
+    g_dyn.assign(shmem + 64, 0);
+    g_dyn_aligned = (void*)(((uintptr_t)g_dyn.data() + 63) & ~(uintptr_t)63);
+    if ((int)g_fibers.size() < nthreads) {
+        size_t old = g_fibers.size();
+        g_fibers.resize(nthreads);
+        for (size_t i = old; i < g_fibers.size(); ++i) g_fibers[i].stack = (char*)malloc(kStack);
+    }
+    const int nwaves = (nthreads + 63) / 64;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                g_blockIdx = Idx{bx, by, bz};
+                g_waves.assign(nwaves, WaveState());
+                g_live = nthreads;
+                g_bar_count = 0;
+                for (int t = 0; t < nthreads; ++t) {
+                    Fiber& f = g_fibers[t];
+                    f.done = false;
+                    f.lin = t;
+                    f.tid = Idx{(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y),
+                                (unsigned)(t / (block.x * block.y))};
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = f.stack;
+                    f.ctx.uc_stack.ss_size = kStack;
+                    f.ctx.uc_link = &g_sched;
+                    makecontext(&f.ctx, (void (*)())trampoline, 0);
+                    g_waves[t >> 6].live++;
+                }
+                int remaining = nthreads;
+                while (remaining > 0) {
+                    int progressed = 0;
+                    for (int t = 0; t < nthreads; ++t) {
+                        Fiber& f = g_fibers[t];
+                        if (f.done) continue;
+                        g_cur = &f;
+                        g_threadIdx = f.tid;
+                        swapcontext(&g_sched, &f.ctx);
+                        ++progressed;
+                        if (f.done) --remaining;
+                    }
+                    if (!progressed) break;
+                }
+            }
+    g_body = nullptr;
+}
+}  // namespace hipemu
+
+// ----------------------------------------------------------- host API shim --
+struct hipemu_event_t { std::chrono::steady_clock::time_point t; };
+struct hipemu_stream_t { int dummy; };
+
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    memset(p, 0, sizeof(*p));
+    snprintf(p->name, sizeof(p->name), "hostemu (CPU fibers, tests only)");
+    snprintf(p->gcnArchName, sizeof(p->gcnArchName), "hostemu");
+    p->totalGlobalMem = (size_t)8 << 30;
+    p->multiProcessorCount = 256;
+    p->clockRate = 2400000;
+    p->sharedMemPerBlock = 160 * 1024;
+    p->warpSize = 64;
+    return hipSuccess;
+}
+hipError_t hipMalloc(void** p, size_t bytes) {
+    // guard bytes on both sides so small overruns are caught by the tests' canaries
+    *p = aligned_alloc(256, ((bytes + 255) / 256 + 1) * 256);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
+hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t b, hipMemcpyKind) { memmove(d, s, b); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t b, hipMemcpyKind, hipStream_t) { memmove(d, s, b); return hipSuccess; }
+hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width,
+                            size_t height, hipMemcpyKind, hipStream_t) {
+    for (size_t r = 0; r < height; ++r) memmove((char*)dst + r * dpitch, (const char*)src + r * spitch, width);
+    return hipSuccess;
+}
+hipError_t hipMemset(void* d, int v, size_t b) { memset(d, v, b); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t b, hipStream_t) { memset(d, v, b); return hipSuccess; }
+hipError_t hipStreamCreate(hipStream_t* s) { *s = new hipemu_stream_t{0}; return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event_t; return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+hipError_t hipGetLastError() { return hipSuccess; }
+hipError_t hipPeekAtLastError() { return hipSuccess; }
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)4 << 30; *t = (size_t)8 << 30; return hipSuccess; }

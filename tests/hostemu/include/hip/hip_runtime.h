@@ -1,0 +1,187 @@
+// TEST INFRASTRUCTURE ONLY — fake HIP runtime header for CPU-side CI.
+// See tests/hostemu/README.md.  Compiled with clang++ -x c++ (host only).
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+// ----------------------------------------------------------------- basics --
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef int hipError_t;
+enum : int {
+    hipSuccess = 0,
+    hipErrorInvalidValue = 1,
+    hipErrorOutOfMemory = 2,
+    hipErrorNotReady = 600,
+    hipErrorNoDevice = 100,
+};
+typedef struct hipemu_stream_t* hipStream_t;
+typedef struct hipemu_event_t* hipEvent_t;
+enum hipMemcpyKind {
+    hipMemcpyHostToHost = 0,
+    hipMemcpyHostToDevice = 1,
+    hipMemcpyDeviceToHost = 2,
+    hipMemcpyDeviceToDevice = 3,
+    hipMemcpyDefault = 4
+};
+struct hipDeviceProp_t {
+    char name[256];
+    char gcnArchName[256];
+    size_t totalGlobalMem;
+    int multiProcessorCount;
+    int clockRate;
+    size_t sharedMemPerBlock;
+    int warpSize;
+    int l2CacheSize;
+};
+#define hipHostMallocDefault 0
+#define hipStreamNonBlocking 1
+#define hipEventDefault 0
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)hipemu::dyn_smem();
+
+struct double2 { double x, y; };
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+struct double4 { double x, y, z, w; };
+static inline double4 make_double4(double x, double y, double z, double w) { return double4{x, y, z, w}; }
+struct int2 { int x, y; };
+
+// ---------------------------------------------------------------- runtime --
+namespace hipemu {
+struct Idx { unsigned x, y, z; };
+extern Idx g_threadIdx, g_blockIdx;
+extern dim3 g_blockDim, g_gridDim;
+void* dyn_smem();
+void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void block_barrier();
+void wave_exchange(const void* in, void* out, size_t bytes, int src_lane);
+void wave_gather64(const void* in, size_t bytes, void* all64);  // every lane gets all 64 values
+int lane_id();
+long launches();
+
+template <class K, class... A>
+static inline void launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t, A... args) {
+    std::function<void()> body = [=]() { kernel(args...); };
+    run_grid(grid, block, shmem, body);
+}
+}  // namespace hipemu
+
+#define threadIdx hipemu::g_threadIdx
+#define blockIdx hipemu::g_blockIdx
+#define blockDim hipemu::g_blockDim
+#define gridDim hipemu::g_gridDim
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), stream, ##__VA_ARGS__)
+
+static inline void __syncthreads() { hipemu::block_barrier(); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+template <class T>
+static inline T __shfl(T v, int src, int width = 64) {
+    int lane = hipemu::lane_id();
+    int base = (lane / width) * width;
+    T out;
+    hipemu::wave_exchange(&v, &out, sizeof(T), base + (src % width + width) % width);
+    return out;
+}
+template <class T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+    int lane = hipemu::lane_id();
+    int src = lane ^ mask;
+    if (src / width != lane / width) src = lane;
+    T out;
+    hipemu::wave_exchange(&v, &out, sizeof(T), src);
+    return out;
+}
+template <class T>
+static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    int lane = hipemu::lane_id();
+    int src = lane + (int)delta;
+    if (src / width != lane / width) src = lane;
+    T out;
+    hipemu::wave_exchange(&v, &out, sizeof(T), src);
+    return out;
+}
+template <class T>
+static inline T __shfl_up(T v, unsigned delta, int width = 64) {
+    int lane = hipemu::lane_id();
+    int src = lane - (int)delta;
+    if (src < 0 || src / width != lane / width) src = lane;
+    T out;
+    hipemu::wave_exchange(&v, &out, sizeof(T), src);
+    return out;
+}
+
+static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+
+// f64 MFMA 16x16x4, gfx950 layout (cdna_hip_programming.md §3):
+//   A: lane l holds A[i = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][j = l & 15]
+//   C/D: 4 values per lane, col = l & 15, row = (l >> 4) + 4 * reg
+typedef double hipemu_f64x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_f64x4 hipemu_mfma_f64_16x16x4(double a, double b, hipemu_f64x4 c, int, int, int) {
+    double A[64], B[64];
+    hipemu::wave_gather64(&a, sizeof(double), A);
+    hipemu::wave_gather64(&b, sizeof(double), B);
+    int l = hipemu::lane_id();
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) + 4 * r;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = std::fma(A[k * 16 + row], B[k * 16 + col], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f64_16x16x4f64 hipemu_mfma_f64_16x16x4
+
+// ------------------------------------------------------------- host "API" --
+hipError_t hipGetDeviceCount(int* n);
+hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int* d);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
+hipError_t hipMalloc(void** p, size_t bytes);
+template <class T> static inline hipError_t hipMalloc(T** p, size_t bytes) { return hipMalloc((void**)p, bytes); }
+hipError_t hipFree(void* p);
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags = 0);
+template <class T> static inline hipError_t hipHostMalloc(T** p, size_t bytes, unsigned flags = 0) { return hipHostMalloc((void**)p, bytes, flags); }
+hipError_t hipHostFree(void* p);
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s = nullptr);
+hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width,
+                            size_t height, hipMemcpyKind kind, hipStream_t s = nullptr);
+hipError_t hipMemset(void* dst, int value, size_t bytes);
+hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t s = nullptr);
+hipError_t hipStreamCreate(hipStream_t* s);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipDeviceSynchronize();
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipGetLastError();
+hipError_t hipPeekAtLastError();
+const char* hipGetErrorString(hipError_t e);
+hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b);

@@ -1,0 +1,163 @@
+/*
+ * sella_hip.h — C ABI of libsella_hip.so, the MI355X (gfx950) implementation of the
+ * inner saddle-point linear-algebra loop of Sella.
+ *
+ * This is the drop-in boundary.  The reference has no FFI; the seam it
+ * offers for exactly this path is sella/_gpu.py (numpy-in / numpy-out helpers backed by
+ * torch.cuda) plus the function-level seams one level up.  Each entry point below names
+ * the reference interface it replaces (path:line under /root/reference).  INTEGRATION.md
+ * shows the ctypes stub a Sella maintainer would add.
+ *
+ * Conventions
+ *   - all matrices are fp64, C-contiguous row-major; host pointers are borrowed for the
+ *     duration of the call only and are never written unless documented as outputs;
+ *   - device memory is owned by the context and addressed through integer handles;
+ *   - every function returns 0 on success or a negative SELLA_E_* code, the message is
+ *     available from sella_last_error(); no exceptions cross the boundary;
+ *   - one host thread per context, one HIP stream per context; calls are synchronous at
+ *     the boundary (outputs are valid on return);
+ *   - there is NO CPU fallback: without a usable HIP device sella_ctx_create fails.
+ */
+#ifndef SELLA_HIP_H
+#define SELLA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sella_ctx sella_ctx;
+typedef int sella_mat;            /* handle of a device-resident row-major matrix */
+#define SELLA_NO_MAT (-1)
+
+enum {
+    SELLA_OK = 0,
+    SELLA_E_INVALID = -1,         /* bad argument / shape mismatch                       */
+    SELLA_E_HIP = -2,             /* HIP runtime error (message has the HIP string)      */
+    SELLA_E_NOMEM = -3,           /* device allocation failed (cf. _gpu.py:44-52 OOM)    */
+    SELLA_E_NOCONV = -4,          /* iteration limit hit (MGS sweeps, secular solver..)  */
+    SELLA_E_CALLBACK = -5,        /* host matvec callback reported failure               */
+    SELLA_E_NODEVICE = -6,        /* no HIP device visible                               */
+    SELLA_E_UNSUPPORTED = -7
+};
+
+const char* sella_last_error(void);
+const char* sella_version(void);
+
+/* ---- device / context ------------------------------------------------------------ */
+/* replaces the implicit torch.cuda device + availability probe, sella/_gpu.py:17-41    */
+int sella_device_count(int* count);
+int sella_ctx_create(int device, sella_ctx** ctx);
+int sella_ctx_destroy(sella_ctx* ctx);
+int sella_ctx_sync(sella_ctx* ctx);
+int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
+/* integer tuning knobs (kernel variant selection for benchmarking); unknown key -> -1  */
+int sella_ctx_set_option(sella_ctx* ctx, const char* key, long value);
+
+/* ---- device matrices --------------------------------------------------------------- */
+/* to_gpu(A): sella/_gpu.py:55-67 (upload, cached by ApproximateHessian linalg.py:197-207) */
+int sella_mat_upload(sella_ctx* ctx, const double* A, int rows, int cols, sella_mat* h);
+int sella_mat_alloc(sella_ctx* ctx, int rows, int cols, sella_mat* h);
+int sella_mat_set(sella_ctx* ctx, sella_mat h, const double* A);        /* overwrite    */
+int sella_mat_download(sella_ctx* ctx, sella_mat h, double* out);       /* .cpu().numpy() */
+int sella_mat_shape(sella_ctx* ctx, sella_mat h, int* rows, int* cols);
+int sella_mat_copy(sella_ctx* ctx, sella_mat src, sella_mat* dst);
+int sella_mat_transpose(sella_ctx* ctx, sella_mat src, sella_mat* dst);
+int sella_mat_free(sella_ctx* ctx, sella_mat h);
+/* C = alpha * A + beta * B (same shapes; B may be SELLA_NO_MAT with beta ignored)       */
+int sella_mat_axpby(sella_ctx* ctx, double alpha, sella_mat A, double beta, sella_mat B,
+                    sella_mat* C);
+
+/* ---- dense products ------------------------------------------------------------------ */
+/* Y = A X, A (n x n) resident, X and Y host (n x k row-major).
+ * ApproximateHessian._matvec/_matmat  sella/linalg.py:324-335; dense A.dot(t) in
+ * sella/eigensolvers.py:52,112; B@S in sella/hessian_update.py:119,160-176.             */
+int sella_symm_mm(sella_ctx* ctx, sella_mat A, const double* X, int k, double* Y);
+/* Y = A^T X for a general resident A (rows x cols), X host (rows x k), Y (cols x k)     */
+int sella_gemm_tn_host(sella_ctx* ctx, sella_mat A, const double* X, int k, double* Y);
+/* out (m x m) = U^T H U, H (n x n) resident, U host (n x m).
+ * gpu_project  sella/_gpu.py:114-132 (peswrapper.py:374,382; linalg.py:306-317)         */
+int sella_project(sella_ctx* ctx, sella_mat H, const double* U, int m, double* out);
+/* same, result stays on the device as a new handle (and optionally on the host)        */
+int sella_project_dev(sella_ctx* ctx, sella_mat H, sella_mat U, sella_mat* out);
+/* general C = op(A) op(B) on resident matrices (test / building block)                 */
+int sella_gemm(sella_ctx* ctx, int transA, int transB, double alpha, sella_mat A,
+               sella_mat B, double beta, sella_mat C);
+
+/* ---- symmetric eigensolver ------------------------------------------------------------ */
+/* gpu_eigh / gpu_eigh_t  sella/_gpu.py:70-97 (torch.linalg.eigh).  w (n) ascending.
+ * V: new handle holding the eigenvectors as COLUMNS (V[i][j] = component i of vector j),
+ * Vt: new handle with the eigenvectors as ROWS.  Either pointer may be NULL.             */
+int sella_eigh(sella_ctx* ctx, sella_mat A, double* w, sella_mat* V, sella_mat* Vt);
+
+/* ---- thin QR ---------------------------------------------------------------------------- */
+/* gpu_qr(A) economy mode  sella/_gpu.py:100-111 (peswrapper.py:691).  A host (m x n),
+ * m >= n; Q (m x n), R (n x n) host outputs.                                             */
+int sella_qr_thin(sella_ctx* ctx, const double* A, int m, int n, double* Q, double* R);
+
+/* ---- Gram-Schmidt --------------------------------------------------------------------- */
+/* modified_gram_schmidt(X, Y)  sella/utilities/math.pyx:143-159 (mgs :74-140).
+ * X host (n x nx), Y host (n x ny) or NULL; out host (n x nx); *kept = columns kept.
+ * Returns SELLA_E_NOCONV where the reference raises RuntimeError("MGS failed.").         */
+int sella_mgs(sella_ctx* ctx, const double* X, int n, int nx, const double* Y, int ny,
+              double eps1, double eps2, int maxiter, double* out, int* kept);
+
+/* ---- Davidson / Rayleigh-Ritz ----------------------------------------------------------- */
+/* rayleigh_ritz(A, gamma, P, B=None, v0, vref, vreftol, method, maxiter)
+ *   sella/eigensolvers.py:31-112, expand :115-153.
+ * A: resident dense matrix, or SELLA_NO_MAT with a host callback (the finite-difference
+ *    operator NumericalHessian, sella/linalg.py:39-95, lives behind the calculator boundary
+ *    and therefore stays a host callback).
+ * P: given by its eigendecomposition P = Q diag(pevals) Q^T with Q resident both as columns
+ *    (Pvecs) and as rows (PvecsT) — exactly what sella_eigh returns — or Pvecs = SELLA_NO_MAT
+ *    for P = pscale * I.
+ * v0: host (n x nv0) start block (nv0 >= 1).  vref may be NULL.
+ * Outputs (host): lams (kmax), V and AV (n x k row-major, Ritz vectors as columns), *k.     */
+typedef int (*sella_matvec_fn)(void* user, const double* v, double* Av, int n);
+enum { SELLA_DAV_LANCZOS = 0, SELLA_DAV_GD = 1, SELLA_DAV_JD0 = 2, SELLA_DAV_JD0_ALT = 3,
+       SELLA_DAV_MJD0 = 4, SELLA_DAV_MJD0_ALT = 5 };
+int sella_davidson(sella_ctx* ctx, sella_mat A, sella_matvec_fn matvec, void* user,
+                   sella_mat Pvecs, sella_mat PvecsT, const double* pevals, double pscale,
+                   int n, const double* v0, int nv0, double gamma, int method, int maxiter,
+                   const double* vref, double vreftol,
+                   double* lams, double* V, double* AV, int* k, int* nmatvec);
+
+/* ---- quasi-Newton update ------------------------------------------------------------------ */
+/* update_H(B, S, Y, method, symm, lams, vecs, B_gpu, evals_gpu, evecs_gpu)
+ *   sella/hessian_update.py:40-111, formulas :114-157, torch variant :160-203.
+ * B resident (n x n) is updated IN PLACE and symmetrised in the same pass.
+ * evecs/evals: eigendecomposition of B (columns), needed by TS-BFGS / BFGS_auto only.
+ * S, Y host (n x k).  symm in {-1 (None), 0, 1, 2}.                                          */
+enum { SELLA_UPD_TS_BFGS = 0, SELLA_UPD_BFGS = 1, SELLA_UPD_PSB = 2, SELLA_UPD_DFP = 3,
+       SELLA_UPD_SR1 = 4, SELLA_UPD_GREENSTADT = 5, SELLA_UPD_BFGS_AUTO = 6 };
+int sella_update_h(sella_ctx* ctx, sella_mat B, sella_mat evecs, sella_mat evecsT,
+                   const double* evals, const double* S, const double* Y, int n, int k,
+                   int method, int symm);
+/* symmetrize_Y(S, Y, symm)  sella/hessian_update.py:12-37; out host (n x k)                   */
+int sella_symmetrize_y(sella_ctx* ctx, const double* S, const double* Y, int n, int k,
+                       int symm, double* out);
+
+/* ---- step solve -------------------------------------------------------------------------- */
+/* One evaluation of Stepper.get_s(alpha)  sella/optimize/stepper.py:82-96 (QN), :128-157
+ * (RFO), :179-185 (P-RFO) in the eigenbasis of the (projected) Hessian:
+ *   evecs (m x m resident, columns) / evecsT (rows), evals (m), g (m) host.
+ * kind: 0 = qn, 1 = rfo, 2 = prfo.  Outputs s, dsda (m) host.                               */
+enum { SELLA_STEP_QN = 0, SELLA_STEP_RFO = 1, SELLA_STEP_PRFO = 2 };
+typedef struct sella_stepper sella_stepper;
+int sella_stepper_create(sella_ctx* ctx, int kind, sella_mat evecs, sella_mat evecsT,
+                         const double* evals, const double* g, int m, int order,
+                         sella_stepper** st);
+int sella_stepper_get_s(sella_stepper* st, double alpha, double* s, double* dsda);
+int sella_stepper_destroy(sella_stepper* st);
+
+/* ---- profiling hooks (bench.py roofline leg) ---------------------------------------------- */
+/* When enabled, every launch of the big streaming kernels is bracketed by hipEvents on the
+ * context stream.  kind: 0 = gemv (row-panel matvec), 1 = gemm, 2 = update, 3 = other.       */
+int sella_prof_enable(sella_ctx* ctx, int on);
+int sella_prof_reset(sella_ctx* ctx);
+int sella_prof_get(sella_ctx* ctx, int kind, long* launches, double* total_ms,
+                   double* total_bytes, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SELLA_HIP_H */

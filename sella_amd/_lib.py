@@ -1,0 +1,124 @@
+"""ctypes binding of libsella_hip.so (include/sella_hip.h).
+
+There is deliberately no CPU fallback here: if the shared object is missing or no HIP
+device is visible, importing the accelerated path fails loudly.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, byref, c_char_p, c_double, c_int, c_long,  # noqa: F401
+                    c_void_p)
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsella_hip.so')
+
+_lib = None
+
+c_double_p = POINTER(c_double)
+c_int_p = POINTER(c_int)
+MATVEC_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_double_p, c_double_p, c_int)
+
+# name -> (restype, argtypes); mirrors include/sella_hip.h one to one
+SIGNATURES = {
+    'sella_last_error': (c_char_p, []),
+    'sella_version': (c_char_p, []),
+    'sella_device_count': (c_int, [c_int_p]),
+    'sella_ctx_create': (c_int, [c_int, POINTER(c_void_p)]),
+    'sella_ctx_destroy': (c_int, [c_void_p]),
+    'sella_ctx_sync': (c_int, [c_void_p]),
+    'sella_ctx_device_name': (c_int, [c_void_p, c_char_p, c_int]),
+    'sella_ctx_set_option': (c_int, [c_void_p, c_char_p, c_long]),
+    'sella_mat_upload': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int_p]),
+    'sella_mat_alloc': (c_int, [c_void_p, c_int, c_int, c_int_p]),
+    'sella_mat_set': (c_int, [c_void_p, c_int, c_void_p]),
+    'sella_mat_download': (c_int, [c_void_p, c_int, c_void_p]),
+    'sella_mat_shape': (c_int, [c_void_p, c_int, c_int_p, c_int_p]),
+    'sella_mat_copy': (c_int, [c_void_p, c_int, c_int_p]),
+    'sella_mat_transpose': (c_int, [c_void_p, c_int, c_int_p]),
+    'sella_mat_free': (c_int, [c_void_p, c_int]),
+    'sella_mat_axpby': (c_int, [c_void_p, c_double, c_int, c_double, c_int, c_int_p]),
+    'sella_symm_mm': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    'sella_gemm_tn_host': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    'sella_project': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    'sella_project_dev': (c_int, [c_void_p, c_int, c_int, c_int_p]),
+    'sella_gemm': (c_int, [c_void_p, c_int, c_int, c_double, c_int, c_int, c_double, c_int]),
+    'sella_eigh': (c_int, [c_void_p, c_int, c_void_p, c_int_p, c_int_p]),
+    'sella_qr_thin': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'sella_mgs': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_double, c_double,
+                          c_int, c_void_p, c_int_p]),
+    'sella_davidson': (c_int, [c_void_p, c_int, MATVEC_FN, c_void_p, c_int, c_int, c_void_p,
+                               c_double, c_int, c_void_p, c_int, c_double, c_int, c_int, c_void_p,
+                               c_double, c_void_p, c_void_p, c_void_p, c_int_p, c_int_p]),
+    'sella_update_h': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                               c_int, c_int, c_int]),
+    'sella_symmetrize_y': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'sella_stepper_create': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                     POINTER(c_void_p)]),
+    'sella_stepper_get_s': (c_int, [c_void_p, c_double, c_void_p, c_void_p]),
+    'sella_stepper_destroy': (c_int, [c_void_p]),
+    'sella_prof_enable': (c_int, [c_void_p, c_int]),
+    'sella_prof_reset': (c_int, [c_void_p]),
+    'sella_prof_get': (c_int, [c_void_p, c_int, POINTER(c_long), c_double_p, c_double_p, c_double_p]),
+}
+
+SELLA_NO_MAT = -1
+
+
+class SellaHipError(RuntimeError):
+    """Raised for any non-zero status of the C ABI (carries sella_last_error())."""
+
+    def __init__(self, status, message):
+        super().__init__(f'libsella_hip status {status}: {message}')
+        self.status = status
+
+
+missing_symbols = []
+
+
+def _declare(lib):
+    del missing_symbols[:]
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:           # reported by tests/test_abi.py; using it raises
+            missing_symbols.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def lib():
+    """The loaded library.  Raises if libsella_hip.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `python -m sella_amd.build` '
+                '(hipcc --offload-arch=gfx950). sella_amd has no CPU fallback.')
+        _lib = _declare(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+def _set_library_for_tests(cdll):
+    """TEST HOOK: bind a different build of the same sources (tests/hostemu)."""
+    global _lib
+    _lib = _declare(cdll) if cdll is not None else None
+
+
+def check(status):
+    if status != 0:
+        raise SellaHipError(status, lib().sella_last_error().decode(errors='replace'))
+
+
+def as_f64(a, shape=None):
+    """C-contiguous float64 view/copy (inputs are never mutated, cf. _gpu.py:64)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f'expected shape {shape}, got {a.shape}')
+    return a
+
+
+def ptr(a):
+    return a.ctypes.data_as(c_void_p) if a is not None else None

@@ -1,0 +1,446 @@
+// context.hip — context, device matrices, scratch pool, profiling hooks and the simple
+// C-ABI entry points (uploads, products, projection).  See include/sella_hip.h.
+#include "internal.h"
+
+namespace sella {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int mat_new(sella_ctx* c, int rows, int cols, sella_mat* h) {
+    if (rows < 0 || cols < 0) {
+        set_error("mat_new: negative shape %d x %d", rows, cols);
+        return SELLA_E_INVALID;
+    }
+    Mat m;
+    m.rows = rows;
+    m.cols = cols;
+    m.ld = round_up(cols > 0 ? cols : 1, 8);
+    // two spare rows so 16-byte reads that start inside the last row never leave the buffer
+    const size_t bytes = ((size_t)(rows > 0 ? rows : 1) + 2) * m.ld * sizeof(double);
+    hipError_t e = hipMalloc((void**)&m.d, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return SELLA_E_NOMEM;
+    }
+    HIPCHK(hipMemsetAsync(m.d, 0, bytes, c->stream));
+    m.live = true;
+    for (size_t i = 0; i < c->mats.size(); ++i)
+        if (!c->mats[i].live) {
+            c->mats[i] = m;
+            *h = (int)i;
+            return SELLA_OK;
+        }
+    c->mats.push_back(m);
+    *h = (int)c->mats.size() - 1;
+    return SELLA_OK;
+}
+
+Mat* mat_get(sella_ctx* c, sella_mat h) {
+    if (c == nullptr || h < 0 || h >= (int)c->mats.size() || !c->mats[h].live) {
+        set_error("invalid matrix handle %d", h);
+        return nullptr;
+    }
+    return &c->mats[h];
+}
+
+int scratch_get(sella_ctx* c, int slot, size_t bytes, double** p) {
+    if (slot < 0 || slot >= SCR_NSLOTS) {
+        set_error("bad scratch slot %d", slot);
+        return SELLA_E_INVALID;
+    }
+    if ((int)c->scratch.size() < SCR_NSLOTS) c->scratch.resize(SCR_NSLOTS, {nullptr, 0});
+    auto& s = c->scratch[slot];
+    bytes = round_up_l((long)bytes + 64, 256);
+    if (s.second < bytes) {
+        if (s.first) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipFree(s.first));
+            s.first = nullptr;
+            s.second = 0;
+        }
+        size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc((void**)&s.first, want);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu bytes) for scratch failed: %s", want, hipGetErrorString(e));
+            return SELLA_E_NOMEM;
+        }
+        s.second = want;
+        HIPCHK(hipMemsetAsync(s.first, 0, want, c->stream));
+    }
+    *p = s.first;
+    return SELLA_OK;
+}
+
+// Host (n x k) row-major  <->  device panel of k rows (vector-major).  The transposition is
+// done on the host side of the copy (n*k doubles, negligible next to the n^2 streams).
+int upload_panel(sella_ctx* c, const double* X, int n, int k, double* dpanel, int ldp) {
+    std::vector<double> tmp((size_t)k * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < k; ++j) tmp[(size_t)j * n + i] = X[(size_t)i * k + j];
+    HIPCHK(hipMemcpy2DAsync(dpanel, (size_t)ldp * sizeof(double), tmp.data(), (size_t)n * sizeof(double),
+                            (size_t)n * sizeof(double), k, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SELLA_OK;
+}
+
+int download_panel(sella_ctx* c, const double* dpanel, int ldp, int n, int k, double* X) {
+    std::vector<double> tmp((size_t)k * n);
+    HIPCHK(hipMemcpy2DAsync(tmp.data(), (size_t)n * sizeof(double), dpanel, (size_t)ldp * sizeof(double),
+                            (size_t)n * sizeof(double), k, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < k; ++j) X[(size_t)i * k + j] = tmp[(size_t)j * n + i];
+    return SELLA_OK;
+}
+
+int read_scalars(sella_ctx* c, int offset, int count) {
+    if (offset < 0 || offset + count > c->nscal) {
+        set_error("read_scalars: range [%d, %d) outside the exchange buffer", offset, offset + count);
+        return SELLA_E_INVALID;
+    }
+    HIPCHK(hipMemcpyAsync(c->hscal + offset, c->dscal + offset, (size_t)count * sizeof(double),
+                          hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SELLA_OK;
+}
+
+void prof_begin(sella_ctx* c, int kind, double bytes, double flops) {
+    if (!c->prof) return;
+    ProfPending p;
+    p.kind = kind;
+    p.bytes = bytes;
+    p.flops = flops;
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+    (void)hipEventRecord(p.a, c->stream);
+    c->pending.push_back(p);
+}
+
+void prof_end(sella_ctx* c) {
+    if (!c->prof || c->pending.empty()) return;
+    (void)hipEventRecord(c->pending.back().b, c->stream);
+    if (c->pending.size() >= 4096) (void)prof_flush(c);
+}
+
+int prof_flush(sella_ctx* c) {
+    if (c->pending.empty()) return SELLA_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ProfSlot& s = c->slots[p.kind];
+            s.launches += 1;
+            s.ms += ms;
+            s.bytes += p.bytes;
+            s.flops += p.flops;
+        }
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    c->pending.clear();
+    return SELLA_OK;
+}
+
+}  // namespace sella
+
+using namespace sella;
+
+extern "C" {
+
+const char* sella_last_error(void) { return g_err; }
+const char* sella_version(void) { return "sella_hip 0.1 (gfx950, fp64)"; }
+
+int sella_device_count(int* count) {
+    if (!count) return SELLA_E_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return SELLA_E_NODEVICE;
+    }
+    *count = n;
+    return SELLA_OK;
+}
+
+int sella_ctx_create(int device, sella_ctx** out) {
+    if (!out) return SELLA_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible: libsella_hip has no CPU fallback");
+        return SELLA_E_NODEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (%d visible)", device, n);
+        return SELLA_E_INVALID;
+    }
+    HIPCHK(hipSetDevice(device));
+    sella_ctx* c = new sella_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+        c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    hipError_t e = hipStreamCreate(&c->stream);
+    if (e != hipSuccess) {
+        set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete c;
+        return SELLA_E_HIP;
+    }
+    c->nscal = DS_TOTAL;
+    if (hipMalloc((void**)&c->dscal, (size_t)c->nscal * sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void**)&c->hscal, (size_t)c->nscal * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        set_error("allocating the scalar exchange buffers failed");
+        delete c;
+        return SELLA_E_NOMEM;
+    }
+    (void)hipMemsetAsync(c->dscal, 0, (size_t)c->nscal * sizeof(double), c->stream);
+    c->scratch.resize(SCR_NSLOTS, {nullptr, 0});
+    *out = c;
+    return SELLA_OK;
+}
+
+int sella_ctx_destroy(sella_ctx* c) {
+    if (!c) return SELLA_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)prof_flush(c);
+    for (auto& m : c->mats)
+        if (m.live && m.d) (void)hipFree(m.d);
+    for (auto& s : c->scratch)
+        if (s.first) (void)hipFree(s.first);
+    if (c->dscal) (void)hipFree(c->dscal);
+    if (c->hscal) (void)hipHostFree(c->hscal);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SELLA_OK;
+}
+
+int sella_ctx_sync(sella_ctx* c) {
+    if (!c) return SELLA_E_INVALID;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SELLA_OK;
+}
+
+int sella_ctx_device_name(sella_ctx* c, char* buf, int buflen) {
+    if (!c || !buf || buflen <= 0) return SELLA_E_INVALID;
+    snprintf(buf, buflen, "%s", c->name);
+    return SELLA_OK;
+}
+
+int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
+    if (!c || !key) return SELLA_E_INVALID;
+    if (!strcmp(key, "gemv_rw")) {
+        if (value != 1 && value != 2 && value != 4) { set_error("gemv_rw must be 1, 2 or 4"); return SELLA_E_INVALID; }
+        c->opt.gemv_rw = value;
+    } else if (!strcmp(key, "gemm_mfma")) c->opt.gemm_mfma = value ? 1 : 0;
+    else if (!strcmp(key, "dav_reorth")) c->opt.dav_reorth = value ? 1 : 0;
+    else if (!strcmp(key, "eigh_leaf")) {
+        if (value < 2 || value > 64) { set_error("eigh_leaf must be in [2, 64]"); return SELLA_E_INVALID; }
+        c->opt.eigh_leaf = value;
+    } else if (!strcmp(key, "eigh_nb")) {
+        if (value < 1 || value > 64) { set_error("eigh_nb must be in [1, 64]"); return SELLA_E_INVALID; }
+        c->opt.eigh_nb = value;
+    } else {
+        set_error("unknown option '%s'", key);
+        return SELLA_E_INVALID;
+    }
+    return SELLA_OK;
+}
+
+// ---- matrices ---------------------------------------------------------------------------
+int sella_mat_alloc(sella_ctx* c, int rows, int cols, sella_mat* h) {
+    if (!c || !h) return SELLA_E_INVALID;
+    return mat_new(c, rows, cols, h);
+}
+
+int sella_mat_set(sella_ctx* c, sella_mat h, const double* A) {
+    Mat* m = mat_get(c, h);
+    if (!m || !A) return SELLA_E_INVALID;
+    if (m->rows == 0 || m->cols == 0) return SELLA_OK;
+    HIPCHK(hipMemcpy2DAsync(m->d, (size_t)m->ld * sizeof(double), A, (size_t)m->cols * sizeof(double),
+                            (size_t)m->cols * sizeof(double), m->rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SELLA_OK;
+}
+
+int sella_mat_upload(sella_ctx* c, const double* A, int rows, int cols, sella_mat* h) {
+    if (!c || !A || !h) return SELLA_E_INVALID;
+    SCHK(mat_new(c, rows, cols, h));
+    int st = sella_mat_set(c, *h, A);
+    if (st != SELLA_OK) { sella_mat_free(c, *h); *h = SELLA_NO_MAT; }
+    return st;
+}
+
+int sella_mat_download(sella_ctx* c, sella_mat h, double* out) {
+    Mat* m = mat_get(c, h);
+    if (!m || !out) return SELLA_E_INVALID;
+    if (m->rows == 0 || m->cols == 0) return SELLA_OK;
+    HIPCHK(hipMemcpy2DAsync(out, (size_t)m->cols * sizeof(double), m->d, (size_t)m->ld * sizeof(double),
+                            (size_t)m->cols * sizeof(double), m->rows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SELLA_OK;
+}
+
+int sella_mat_shape(sella_ctx* c, sella_mat h, int* rows, int* cols) {
+    Mat* m = mat_get(c, h);
+    if (!m) return SELLA_E_INVALID;
+    if (rows) *rows = m->rows;
+    if (cols) *cols = m->cols;
+    return SELLA_OK;
+}
+
+int sella_mat_free(sella_ctx* c, sella_mat h) {
+    Mat* m = mat_get(c, h);
+    if (!m) return SELLA_E_INVALID;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(m->d));
+    *m = Mat();
+    return SELLA_OK;
+}
+
+int sella_mat_copy(sella_ctx* c, sella_mat src, sella_mat* dst) {
+    Mat* s = mat_get(c, src);
+    if (!s || !dst) return SELLA_E_INVALID;
+    const int rows = s->rows, cols = s->cols;
+    SCHK(mat_new(c, rows, cols, dst));
+    s = mat_get(c, src);
+    Mat* d = mat_get(c, *dst);
+    return launch_axpby2d(c, rows, cols, 1.0, s->d, s->ld, 0.0, nullptr, 0, d->d, d->ld);
+}
+
+int sella_mat_transpose(sella_ctx* c, sella_mat src, sella_mat* dst) {
+    Mat* s = mat_get(c, src);
+    if (!s || !dst) return SELLA_E_INVALID;
+    const int rows = s->rows, cols = s->cols;
+    SCHK(mat_new(c, cols, rows, dst));
+    s = mat_get(c, src);
+    Mat* d = mat_get(c, *dst);
+    return launch_transpose(c, s->d, rows, cols, s->ld, d->d, d->ld);
+}
+
+int sella_mat_axpby(sella_ctx* c, double alpha, sella_mat A, double beta, sella_mat B, sella_mat* C) {
+    Mat* a = mat_get(c, A);
+    if (!a || !C) return SELLA_E_INVALID;
+    const int rows = a->rows, cols = a->cols;
+    if (B != SELLA_NO_MAT) {
+        Mat* b = mat_get(c, B);
+        if (!b) return SELLA_E_INVALID;
+        if (b->rows != rows || b->cols != cols) { set_error("axpby: shape mismatch"); return SELLA_E_INVALID; }
+    }
+    SCHK(mat_new(c, rows, cols, C));
+    a = mat_get(c, A);
+    Mat* b = (B != SELLA_NO_MAT) ? mat_get(c, B) : nullptr;
+    Mat* o = mat_get(c, *C);
+    return launch_axpby2d(c, rows, cols, alpha, a->d, a->ld, beta, b ? b->d : nullptr, b ? b->ld : 0,
+                          o->d, o->ld);
+}
+
+// ---- products ---------------------------------------------------------------------------
+int sella_symm_mm(sella_ctx* c, sella_mat A, const double* X, int k, double* Y) {
+    Mat* a = mat_get(c, A);
+    if (!a || !X || !Y || k <= 0) return SELLA_E_INVALID;
+    const int rows = a->rows, cols = a->cols;
+    const int ldx = round_up(cols, 8), ldy = round_up(rows, 8);
+    double *dx, *dy;
+    SCHK(scratch_get(c, SCR_X, (size_t)k * ldx * sizeof(double), &dx));
+    SCHK(scratch_get(c, SCR_Y, (size_t)k * ldy * sizeof(double), &dy));
+    SCHK(upload_panel(c, X, cols, k, dx, ldx));
+    a = mat_get(c, A);
+    SCHK(launch_gemv_rows(c, a->d, rows, cols, a->ld, dx, ldx, k, dy, ldy, GemvEpi()));
+    return download_panel(c, dy, ldy, rows, k, Y);
+}
+
+int sella_gemm_tn_host(sella_ctx* c, sella_mat A, const double* X, int k, double* Y) {
+    Mat* a = mat_get(c, A);
+    if (!a || !X || !Y || k <= 0) return SELLA_E_INVALID;
+    const int rows = a->rows, cols = a->cols;
+    const int ldx = round_up(rows, 8), ldy = round_up(cols, 8);
+    double *dx, *dy;
+    SCHK(scratch_get(c, SCR_X, (size_t)k * ldx * sizeof(double), &dx));
+    SCHK(scratch_get(c, SCR_Y, (size_t)k * ldy * sizeof(double), &dy));
+    SCHK(upload_panel(c, X, rows, k, dx, ldx));
+    a = mat_get(c, A);
+    SCHK(launch_gemv_cols(c, a->d, rows, cols, a->ld, dx, ldx, k, dy, ldy));
+    return download_panel(c, dy, ldy, cols, k, Y);
+}
+
+int sella_gemm(sella_ctx* c, int transA, int transB, double alpha, sella_mat A, sella_mat B, double beta,
+               sella_mat C) {
+    Mat *a = mat_get(c, A), *b = mat_get(c, B), *o = mat_get(c, C);
+    if (!a || !b || !o) return SELLA_E_INVALID;
+    const int M = transA ? a->cols : a->rows, K = transA ? a->rows : a->cols;
+    const int Kb = transB ? b->cols : b->rows, N = transB ? b->rows : b->cols;
+    if (K != Kb || o->rows != M || o->cols != N) {
+        set_error("gemm: shape mismatch (%d x %d)(%d x %d) -> %d x %d", M, K, Kb, N, o->rows, o->cols);
+        return SELLA_E_INVALID;
+    }
+    return launch_gemm(c, transA, transB, M, N, K, alpha, a->d, a->ld, b->d, b->ld, beta, o->d, o->ld);
+}
+
+int sella_project_dev(sella_ctx* c, sella_mat H, sella_mat U, sella_mat* out) {
+    Mat *h = mat_get(c, H), *u = mat_get(c, U);
+    if (!h || !u || !out) return SELLA_E_INVALID;
+    const int n = h->rows, m = u->cols;
+    if (h->cols != n || u->rows != n) { set_error("project: H must be n x n and U n x m"); return SELLA_E_INVALID; }
+    // T = H U (n x m), out = U^T T (m x m)
+    double* T;
+    const int ldt = round_up(m, 8);
+    SCHK(scratch_get(c, SCR_MISC0, (size_t)n * ldt * sizeof(double), &T));
+    SCHK(mat_new(c, m, m, out));
+    h = mat_get(c, H);
+    u = mat_get(c, U);
+    Mat* o = mat_get(c, *out);
+    SCHK(launch_gemm(c, 0, 0, n, m, n, 1.0, h->d, h->ld, u->d, u->ld, 0.0, T, ldt));
+    SCHK(launch_gemm(c, 1, 0, m, m, n, 1.0, u->d, u->ld, T, ldt, 0.0, o->d, o->ld));
+    return SELLA_OK;
+}
+
+int sella_project(sella_ctx* c, sella_mat H, const double* U, int m, double* out) {
+    Mat* h = mat_get(c, H);
+    if (!h || !U || !out || m <= 0) return SELLA_E_INVALID;
+    sella_mat hU = SELLA_NO_MAT, hO = SELLA_NO_MAT;
+    SCHK(sella_mat_upload(c, U, h->rows, m, &hU));
+    int st = sella_project_dev(c, H, hU, &hO);
+    if (st == SELLA_OK) st = sella_mat_download(c, hO, out);
+    sella_mat_free(c, hU);
+    if (hO != SELLA_NO_MAT) sella_mat_free(c, hO);
+    return st;
+}
+
+// ---- profiling ----------------------------------------------------------------------------
+int sella_prof_enable(sella_ctx* c, int on) {
+    if (!c) return SELLA_E_INVALID;
+    if (!on) SCHK(prof_flush(c));
+    c->prof = on != 0;
+    return SELLA_OK;
+}
+
+int sella_prof_reset(sella_ctx* c) {
+    if (!c) return SELLA_E_INVALID;
+    SCHK(prof_flush(c));
+    for (int k = 0; k < PROF_NKIND; ++k) c->slots[k] = ProfSlot();
+    return SELLA_OK;
+}
+
+int sella_prof_get(sella_ctx* c, int kind, long* launches, double* total_ms, double* total_bytes,
+                   double* total_flops) {
+    if (!c || kind < 0 || kind >= PROF_NKIND) return SELLA_E_INVALID;
+    SCHK(prof_flush(c));
+    const ProfSlot& s = c->slots[kind];
+    if (launches) *launches = s.launches;
+    if (total_ms) *total_ms = s.ms;
+    if (total_bytes) *total_bytes = s.bytes;
+    if (total_flops) *total_flops = s.flops;
+    return SELLA_OK;
+}
+
+}  // extern "C"

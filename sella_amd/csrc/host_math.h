@@ -1,0 +1,149 @@
+// host_math.h — k x k host-side algebra shared by the Davidson driver and the quasi-Newton
+// update (k = number of secant pairs / subspace size, tens at most).  The O(n k) and O(n^2)
+// work they parametrise runs on the device; these are the O(k^3) coefficient computations
+// that sit between two kernel launches.
+#pragma once
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "small_linalg.h"
+
+namespace sella {
+namespace hostm {
+
+typedef std::vector<double> vec;
+
+// x = pinv(M) b for a symmetric M (lower triangle read), minimum-norm like
+// numpy.linalg.lstsq(M, b, rcond=None): singular values below eps*k*max are dropped.
+inline void sym_pinv_solve(int m, const double* M, int ldm, const double* b, double* x) {
+    if (m == 0) return;
+    vec w(m), Z((size_t)m * m), work(m);
+    small::sym_eig(m, M, ldm, w.data(), Z.data(), m, work.data());
+    double wmax = 0.0;
+    for (int i = 0; i < m; ++i) wmax = std::max(wmax, fabs(w[i]));
+    const double cut = 2.220446049250313e-16 * m * wmax;
+    for (int i = 0; i < m; ++i) x[i] = 0.0;
+    for (int j = 0; j < m; ++j) {
+        if (fabs(w[j]) <= cut) continue;
+        double p = 0.0;
+        for (int i = 0; i < m; ++i) p += Z[(size_t)i * m + j] * b[i];
+        p /= w[j];
+        for (int i = 0; i < m; ++i) x[i] += Z[(size_t)i * m + j] * p;
+    }
+}
+
+// Coefficients of the secant symmetrisation (sella/hessian_update.py:12-37):
+//   Ytilde = Y + Pn X   with Pn = S (symm 0 and 2) or Pn = Y (symm 1), X (k x k).
+// Inputs: STS[a][b] = S_a.S_b,  STY[a][b] = S_a.Y_b   (k x k row-major).
+// Returns which panel multiplies X: 0 -> S, 1 -> Y, -1 -> identity (X untouched, no correction).
+inline int symm_coeffs(int k, const double* STS, const double* STY, int symm, double* X) {
+    for (int i = 0; i < k * k; ++i) X[i] = 0.0;
+    if (symm < 0 || k == 1) return -1;
+    if (symm == 2) {
+        // sequential: column i corrected inside span(S[:, :i])          (hessian_update.py:12-24)
+        vec L((size_t)k * k), dYTS((size_t)k * k, 0.0), rhs(k), coef(k);
+        const bool spd = small::cholesky(k, STS, k, L.data(), k) == 0;
+        for (int i = 1; i < k; ++i) {
+            // YTS[i, l] = Y_i.S_l = STY[l][i];  YTS[l, i] = Y_l.S_i = STY[i][l]
+            for (int l = 0; l < i; ++l)
+                rhs[l] = STY[(size_t)l * k + i] - STY[(size_t)i * k + l] - dYTS[(size_t)l * k + i];
+            if (spd) {
+                for (int l = 0; l < i; ++l) coef[l] = rhs[l];
+                small::cholesky_solve_leading(i, L.data(), k, coef.data());
+            } else {
+                sym_pinv_solve(i, STS, k, rhs.data(), coef.data());
+            }
+            for (int l = 0; l < i; ++l) X[(size_t)l * k + i] = -coef[l];      // dY_i = -S[:, :i] coef
+            for (int c = 0; c < k; ++c) {
+                double s = 0.0;
+                for (int l = 0; l < i; ++l) s += STS[(size_t)c * k + l] * coef[l];
+                dYTS[(size_t)i * k + c] = -s;
+            }
+        }
+        return 0;
+    }
+    // symm 0 / 1: X = lstsq(G, tril(S^T Y - Y^T S, -1)^T),  G = S^T S (0) or S^T Y (1)
+    vec K((size_t)k * k, 0.0);            // K = tril(..., -1)^T  -> strictly upper
+    for (int a = 0; a < k; ++a)
+        for (int b = 0; b < a; ++b)
+            K[(size_t)b * k + a] = STY[(size_t)a * k + b] - STY[(size_t)b * k + a];
+    if (symm == 0) {
+        vec col(k), sol(k);
+        for (int c = 0; c < k; ++c) {
+            for (int r = 0; r < k; ++r) col[r] = K[(size_t)r * k + c];
+            sym_pinv_solve(k, STS, k, col.data(), sol.data());
+            for (int r = 0; r < k; ++r) X[(size_t)r * k + c] = sol[r];
+        }
+        return 0;
+    }
+    // symm == 1: general (non-symmetric) k x k system, LU with partial pivoting
+    vec G(STY, STY + (size_t)k * k);
+    std::vector<int> piv(k);
+    for (int i = 0; i < k * k; ++i) X[i] = K[i];
+    if (small::lu_factor(k, G.data(), k, piv.data()) == 0) small::lu_solve(k, G.data(), k, piv.data(), X, k, k);
+    return 1;
+}
+
+// Generalised symmetric-definite eigenproblem A x = lam M x (lower triangles of both are
+// read, like scipy.linalg.eigh(A, M)): Cholesky M = L L^T, C = L^-1 A L^-T, eig(C), x = L^-T y.
+// W (k x k) gets the eigenvectors as columns (W^T M W = I), lams ascending.  Returns 0 on success.
+inline int gen_sym_eig(int k, const double* A, const double* M, double* lams, double* W) {
+    vec L((size_t)k * k), C((size_t)k * k), Yv((size_t)k * k), work(k);
+    if (small::cholesky(k, M, k, L.data(), k) != 0) return 1;
+    // As = symmetric matrix from the lower triangle of A
+    vec As((size_t)k * k);
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j <= i; ++j) As[(size_t)i * k + j] = As[(size_t)j * k + i] = A[(size_t)i * k + j];
+    // T = L^-1 As  (forward substitution on each column)
+    vec T((size_t)k * k);
+    for (int c = 0; c < k; ++c)
+        for (int i = 0; i < k; ++i) {
+            double s = As[(size_t)i * k + c];
+            for (int l = 0; l < i; ++l) s -= L[(size_t)i * k + l] * T[(size_t)l * k + c];
+            T[(size_t)i * k + c] = s / L[(size_t)i * k + i];
+        }
+    // C = T L^-T  : C^T = L^-1 T^T  -> solve per row of T
+    for (int r = 0; r < k; ++r)
+        for (int i = 0; i < k; ++i) {
+            double s = T[(size_t)r * k + i];
+            for (int l = 0; l < i; ++l) s -= L[(size_t)i * k + l] * C[(size_t)r * k + l];
+            C[(size_t)r * k + i] = s / L[(size_t)i * k + i];
+        }
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < i; ++j) {
+            const double v = 0.5 * (C[(size_t)i * k + j] + C[(size_t)j * k + i]);
+            C[(size_t)i * k + j] = C[(size_t)j * k + i] = v;
+        }
+    if (small::sym_eig(k, C.data(), k, lams, Yv.data(), k, work.data()) != 0) return 2;
+    // W = L^-T Yv (back substitution per column)
+    for (int c = 0; c < k; ++c)
+        for (int i = k - 1; i >= 0; --i) {
+            double s = Yv[(size_t)i * k + c];
+            for (int l = i + 1; l < k; ++l) s -= L[(size_t)l * k + i] * W[(size_t)l * k + c];
+            W[(size_t)i * k + c] = s / L[(size_t)i * k + i];
+        }
+    return 0;
+}
+
+// C = A^T B A style helpers on k x k row-major matrices
+inline void congruence(int k, const double* W, const double* G, double* out) {
+    // out = W^T G W
+    vec T((size_t)k * k);
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) {
+            double s = 0.0;
+            for (int l = 0; l < k; ++l) s += G[(size_t)i * k + l] * W[(size_t)l * k + j];
+            T[(size_t)i * k + j] = s;
+        }
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) {
+            double s = 0.0;
+            for (int l = 0; l < k; ++l) s += W[(size_t)l * k + i] * T[(size_t)l * k + j];
+            out[(size_t)i * k + j] = s;
+        }
+}
+
+}  // namespace hostm
+}  // namespace sella

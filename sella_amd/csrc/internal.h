@@ -1,0 +1,155 @@
+// internal.h — shared declarations of libsella_hip (context, device matrices, kernel launchers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/sella_hip.h"
+
+#define SELLA_HD __host__ __device__
+#include "small_linalg.h"
+
+namespace sella {
+
+void set_error(const char* fmt, ...);
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            sella::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),        \
+                             __FILE__, __LINE__);                                          \
+            return SELLA_E_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define SCHK(expr)                                                                         \
+    do {                                                                                   \
+        int s_ = (expr);                                                                   \
+        if (s_ != SELLA_OK) return s_;                                                     \
+    } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline long round_up_l(long x, long m) { return (x + m - 1) / m * m; }
+
+// Device matrix, row-major, leading dimension padded to a multiple of 8 doubles (64 B) with
+// the padding kept at zero, so 16-byte vector loads never straddle a row and never see NaNs.
+struct Mat {
+    double* d = nullptr;
+    int rows = 0, cols = 0, ld = 0;
+    bool live = false;
+};
+
+enum ProfKind { PROF_GEMV = 0, PROF_GEMM = 1, PROF_UPDATE = 2, PROF_OTHER = 3, PROF_NKIND = 4 };
+
+struct ProfPending {
+    hipEvent_t a, b;
+    int kind;
+    double bytes, flops;
+};
+
+struct ProfSlot {
+    long launches = 0;
+    double ms = 0, bytes = 0, flops = 0;
+};
+
+struct Options {
+    long gemv_rw = 2;        // rows per wavefront in the row-panel matvec (1, 2 or 4)
+    long gemm_mfma = 1;      // 1: MFMA f64 16x16x4 GEMM tiles, 0: VALU register tiles
+    long dav_reorth = 0;     // 1: re-orthonormalise V before each MGS like math.pyx:148-151
+    long eigh_leaf = 32;     // leaf size of the divide-and-conquer tree
+    long eigh_nb = 32;       // panel width of the blocked tridiagonalisation
+};
+
+}  // namespace sella
+
+struct sella_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<sella::Mat> mats;
+    // small exchange buffers: device scalars + pinned host mirror
+    double* dscal = nullptr;
+    double* hscal = nullptr;
+    int nscal = 0;
+    // pooled scratch (grown on demand, never shrunk)
+    std::vector<std::pair<double*, size_t>> scratch;   // slot -> (ptr, bytes)
+    sella::Options opt;
+    bool prof = false;
+    std::vector<sella::ProfPending> pending;
+    sella::ProfSlot slots[sella::PROF_NKIND];
+    char name[256] = {0};
+    int num_cu = 256;
+};
+
+namespace sella {
+
+// ---- context helpers (context.hip) ------------------------------------------------------
+int mat_new(sella_ctx* c, int rows, int cols, sella_mat* h);       // zero-initialised
+Mat* mat_get(sella_ctx* c, sella_mat h);
+int scratch_get(sella_ctx* c, int slot, size_t bytes, double** p); // persistent scratch slot
+int upload_panel(sella_ctx* c, const double* X, int n, int k, double* dpanel, int ldp);   // (n x k) host -> k rows
+int download_panel(sella_ctx* c, const double* dpanel, int ldp, int n, int k, double* X); // k rows -> (n x k) host
+int read_scalars(sella_ctx* c, int offset, int count);             // dscal -> hscal (sync)
+// layout of the scalar exchange buffer (doubles)
+enum { DS_MISC = 0, DS_CVEC = 16384, DS_STAGE = 32768, DS_GRAM = 65536, DS_TOTAL = 131072 };
+void prof_begin(sella_ctx* c, int kind, double bytes, double flops);
+void prof_end(sella_ctx* c);
+int prof_flush(sella_ctx* c);
+
+enum ScratchSlot {
+    SCR_X = 0, SCR_Y, SCR_PART, SCR_V, SCR_AV, SCR_V2, SCR_AV2, SCR_R, SCR_T, SCR_W, SCR_C,
+    SCR_EIG0, SCR_EIG1, SCR_EIG2, SCR_EIG3, SCR_EIG4, SCR_EIG5, SCR_UPD0, SCR_UPD1, SCR_UPD2,
+    SCR_UPD3, SCR_QR0, SCR_QR1, SCR_STEP0, SCR_STEP1, SCR_MISC0, SCR_MISC1, SCR_NSLOTS
+};
+
+// ---- kernel launchers (kernels.hip) -------------------------------------------------------
+// Epilogue of the row-panel matvec.
+struct GemvEpi {
+    int mode = 0;            // 0: y = alpha*acc; 1: y = alpha*acc/(dvec[i]-theta); 2: y = alpha*acc + beta*y
+    const double* dvec = nullptr;
+    double theta = 0, alpha = 1, beta = 0;
+};
+// Y[h*ldy + i] = epi(sum_j A[i*lda + j] * X[h*ldx + j]),  i < rows, j < cols, h < nrhs (<= 8).
+// A must be 16-byte aligned with even lda; X rows must be readable up to round_up(cols, 2).
+int launch_gemv_rows(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* X,
+                     int ldx, int nrhs, double* Y, int ldy, const GemvEpi& epi);
+// Y[h*ldy + j] = sum_i A[i*lda + j] * X[h*ldx + i]   (transposed product, deterministic 2-pass)
+int launch_gemv_cols(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* X,
+                     int ldx, int nrhs, double* Y, int ldy);
+// out[cidx*ldo + i] = beta * out[..] + sum_j W1[j*ldw1 + cidx] P1[j*ldp1 + i]
+//                                   + sum_j W2[j*ldw2 + cidx] P2[j*ldp2 + i]
+// W1/W2 are DEVICE pointers (k1 x nout, k2 x nout); P2 may be null.
+int launch_lincomb(sella_ctx* c, int n, int nout, const double* P1, int ldp1, int k1,
+                   const double* W1, int ldw1, const double* P2, int ldp2, int k2,
+                   const double* W2, int ldw2, double beta, double* out, int ldo);
+// out[r] = sum_i P[r*ldp + i]^2
+int launch_rows_sumsq(sella_ctx* c, const double* P, int ldp, int nrows, int n, double* out);
+// x[i] *= f(scal[0]) : mode 0 -> 1/sqrt(s), 1 -> 1/s, 2 -> s
+int launch_scale_by(sella_ctx* c, double* x, int n, const double* scal, int mode);
+// t = -x + y * (dots[0]/dots[1])  (|dots[1]| < 1e-12 -> t = x), eigensolvers.py:123-139
+int launch_jd_combine(sella_ctx* c, const double* x, const double* y, const double* dots,
+                      double* t, int n);
+// generic elementwise z = a*x + b*y (y may be null)
+int launch_axpby(sella_ctx* c, int n, double a, const double* x, double b, const double* y,
+                 double* z);
+// 2-D: C[i*ldc + j] = a*A[i*lda + j] + b*B[i*ldb + j]
+int launch_axpby2d(sella_ctx* c, int rows, int cols, double a, const double* A, int lda, double b,
+                   const double* B, int ldb, double* C, int ldc);
+int launch_transpose(sella_ctx* c, const double* A, int rows, int cols, int lda, double* At,
+                     int ldat);
+// C = alpha * op(A) op(B) + beta * C ; op(X) = X or X^T; M,N,K are the product dimensions.
+int launch_gemm(sella_ctx* c, int transA, int transB, int M, int N, int K, double alpha,
+                const double* A, int lda, const double* B, int ldb, double beta, double* C,
+                int ldc);
+// B[i][j] = 0.5*(B[i][j] + B[j][i]) in place (square)
+int launch_symmetrize(sella_ctx* c, double* B, int n, int ld);
+// gather rows: out[r*ldo + j] = in[idx[r]*ldi + j] (idx device int array)
+int launch_gather_rows(sella_ctx* c, const double* in, int ldi, const int* idx, int nrows,
+                       int ncols, double* out, int ldo);
+
+}  // namespace sella

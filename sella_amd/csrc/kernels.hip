@@ -1,0 +1,639 @@
+// kernels.hip — streaming kernels of libsella_hip for gfx950 (CDNA4, wave64).
+//
+// Everything on the Sella hot path is fp64 and, at 3N ~ 3072, HBM/L2-bandwidth bound
+// (SURVEY.md §8d): the work-horse is a row-panel matvec that streams a row-major matrix
+// once with 16-byte coalesced loads, keeps the right-hand sides in LDS and reduces each row
+// inside one 64-lane wavefront.  Panels of Krylov vectors are stored vector-major
+// (k rows x n), so the same kernel computes V^T t, and all O(n k) updates are coalesced.
+#include "internal.h"
+
+namespace sella {
+
+// ------------------------------------------------------------------------------------
+// wave64 butterfly sum
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------
+// K1: row-panel matvec.  One wavefront owns RW consecutive rows; lanes stride the row in
+// 16-byte pieces (1 KiB per wave-instruction, fully coalesced); the NRHS right-hand sides
+// are staged through LDS in column tiles of GEMV_TC doubles so arbitrarily long rows work
+// with <= NRHS*16 KiB of LDS.  Algorithmic traffic: 8*rows*cols bytes (matrix read once).
+// ------------------------------------------------------------------------------------
+constexpr int GEMV_TC = 2048;
+
+template <int NRHS, int RW>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ A, int rows,
+                                                        int cols, int lda,
+                                                        const double* __restrict__ X, int ldx,
+                                                        double* __restrict__ Y, int ldy,
+                                                        GemvEpi epi) {
+    HIP_DYNAMIC_SHARED(double, xs)
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + wave) * RW;
+
+    const double* arow[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        int rr = row0 + r;
+        if (rr > rows - 1) rr = rows - 1;
+        arow[r] = A + (size_t)rr * lda;
+    }
+    double acc[RW][NRHS];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int h = 0; h < NRHS; ++h) acc[r][h] = 0.0;
+
+    const int cols2 = (cols + 1) & ~1;
+    for (int c0 = 0; c0 < cols2; c0 += GEMV_TC) {
+        const int tc = (cols2 - c0 < GEMV_TC) ? (cols2 - c0) : GEMV_TC;
+#pragma unroll
+        for (int h = 0; h < NRHS; ++h)
+            for (int j = threadIdx.x; j < tc; j += 256) {
+                const int col = c0 + j;
+                xs[h * GEMV_TC + j] = (col < cols) ? X[(size_t)h * ldx + col] : 0.0;
+            }
+        __syncthreads();
+        const int tc2 = tc >> 1;
+        const double2* xs2 = reinterpret_cast<const double2*>(xs);
+#pragma unroll 4
+        for (int j = lane; j < tc2; j += 64) {
+            double2 av[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+                av[r] = *reinterpret_cast<const double2*>(arow[r] + c0 + 2 * j);
+#pragma unroll
+            for (int h = 0; h < NRHS; ++h) {
+                const double2 xv = xs2[h * (GEMV_TC / 2) + j];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) acc[r][h] += av[r].x * xv.x + av[r].y * xv.y;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int h = 0; h < NRHS; ++h) acc[r][h] = wave_sum(acc[r][h]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int rr = row0 + r;
+            if (rr < rows) {
+#pragma unroll
+                for (int h = 0; h < NRHS; ++h) {
+                    double v = epi.alpha * acc[r][h];
+                    if (epi.mode == 1) v = v / (epi.dvec[rr] - epi.theta);
+                    else if (epi.mode == 2) v += epi.beta * Y[(size_t)h * ldy + rr];
+                    Y[(size_t)h * ldy + rr] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int NRHS>
+static int gemv_rows_dispatch_rw(sella_ctx* c, int rw, const double* A, int rows, int cols, int lda,
+                                 const double* X, int ldx, double* Y, int ldy, const GemvEpi& epi) {
+    const size_t shmem = (size_t)NRHS * GEMV_TC * sizeof(double);
+    if (rw == 4) {
+        int grid = (rows + 15) / 16;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 4>), dim3(grid), dim3(256), shmem,
+                           c->stream, A, rows, cols, lda, X, ldx, Y, ldy, epi);
+    } else if (rw == 2) {
+        int grid = (rows + 7) / 8;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 2>), dim3(grid), dim3(256), shmem,
+                           c->stream, A, rows, cols, lda, X, ldx, Y, ldy, epi);
+    } else {
+        int grid = (rows + 3) / 4;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 1>), dim3(grid), dim3(256), shmem,
+                           c->stream, A, rows, cols, lda, X, ldx, Y, ldy, epi);
+    }
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+int launch_gemv_rows(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* X,
+                     int ldx, int nrhs, double* Y, int ldy, const GemvEpi& epi) {
+    if (rows <= 0 || cols <= 0 || nrhs <= 0) return SELLA_OK;
+    if ((lda & 1) || (((uintptr_t)A) & 15)) {
+        set_error("gemv_rows: matrix must be 16-byte aligned with even leading dimension");
+        return SELLA_E_INVALID;
+    }
+    int rw = (int)c->opt.gemv_rw;
+    // few rows (panel dots): one row per wavefront keeps more wavefronts in flight
+    if (rows < 1024) rw = 1;
+    for (int h0 = 0; h0 < nrhs; h0 += 8) {
+        const int nh = (nrhs - h0 < 8) ? (nrhs - h0) : 8;
+        const double* Xh = X + (size_t)h0 * ldx;
+        double* Yh = Y + (size_t)h0 * ldy;
+        prof_begin(c, PROF_GEMV, 8.0 * rows * (double)cols, 2.0 * rows * (double)cols * nh);
+        int st;
+        switch (nh) {
+            case 1: st = gemv_rows_dispatch_rw<1>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
+            case 2: st = gemv_rows_dispatch_rw<2>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
+            case 3: st = gemv_rows_dispatch_rw<3>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
+            case 4: st = gemv_rows_dispatch_rw<4>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
+            case 5: st = gemv_rows_dispatch_rw<5>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
+            case 6: st = gemv_rows_dispatch_rw<6>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
+            case 7: st = gemv_rows_dispatch_rw<7>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
+            default: st = gemv_rows_dispatch_rw<8>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
+        }
+        prof_end(c);
+        SCHK(st);
+    }
+    return SELLA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// K1t: transposed product Y = A^T X without a transposed copy.  Each thread owns two
+// adjacent columns (16-byte coalesced loads along the row), row blocks are split over
+// blockIdx.y into a partial buffer that a second kernel sums in a fixed order
+// (deterministic; no atomics).
+// ------------------------------------------------------------------------------------
+constexpr int GEMVT_ROWS = 32;
+
+template <int NRHS>
+__global__ __launch_bounds__(256) void gemv_cols_partial_kernel(const double* __restrict__ A,
+                                                                int rows, int cols, int lda,
+                                                                const double* __restrict__ X,
+                                                                int ldx, double* __restrict__ part,
+                                                                int ldpart) {
+    __shared__ double xs[NRHS * GEMVT_ROWS];
+    const int r0 = blockIdx.y * GEMVT_ROWS;
+    const int nr = (rows - r0 < GEMVT_ROWS) ? (rows - r0) : GEMVT_ROWS;
+    for (int t = threadIdx.x; t < NRHS * GEMVT_ROWS; t += 256) {
+        const int h = t / GEMVT_ROWS, r = t % GEMVT_ROWS;
+        xs[t] = (r < nr) ? X[(size_t)h * ldx + r0 + r] : 0.0;
+    }
+    __syncthreads();
+    const int cp = blockIdx.x * 256 + threadIdx.x;
+    const int cols2 = (cols + 1) & ~1;
+    if (2 * cp >= cols2) return;
+    double2 acc[NRHS];
+#pragma unroll
+    for (int h = 0; h < NRHS; ++h) acc[h] = make_double2(0.0, 0.0);
+    const double* ap = A + (size_t)r0 * lda + 2 * cp;
+#pragma unroll 4
+    for (int r = 0; r < nr; ++r) {
+        const double2 a = *reinterpret_cast<const double2*>(ap + (size_t)r * lda);
+#pragma unroll
+        for (int h = 0; h < NRHS; ++h) {
+            const double x = xs[h * GEMVT_ROWS + r];
+            acc[h].x += a.x * x;
+            acc[h].y += a.y * x;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < NRHS; ++h)
+        *reinterpret_cast<double2*>(part + ((size_t)blockIdx.y * NRHS + h) * ldpart + 2 * cp) = acc[h];
+}
+
+__global__ __launch_bounds__(256) void gemv_cols_reduce_kernel(const double* __restrict__ part,
+                                                               int ldpart, int nsplit, int nrhs,
+                                                               int cols, double* __restrict__ Y,
+                                                               int ldy) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int h = blockIdx.y;
+    if (j >= cols) return;
+    double s = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[((size_t)sp * nrhs + h) * ldpart + j];
+    Y[(size_t)h * ldy + j] = s;
+}
+
+template <int NRHS>
+static int gemv_cols_run(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* X,
+                         int ldx, double* Y, int ldy) {
+    const int cols2 = (cols + 1) & ~1;
+    const int ldpart = round_up(cols2, 8);
+    const int nsplit = (rows + GEMVT_ROWS - 1) / GEMVT_ROWS;
+    double* part;
+    SCHK(scratch_get(c, SCR_PART, (size_t)nsplit * NRHS * ldpart * sizeof(double), &part));
+    dim3 grid((cols2 / 2 + 255) / 256, nsplit);
+    prof_begin(c, PROF_GEMV, 8.0 * rows * (double)cols, 2.0 * rows * (double)cols * NRHS);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_cols_partial_kernel<NRHS>), grid, dim3(256), 0, c->stream,
+                       A, rows, cols, lda, X, ldx, part, ldpart);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(gemv_cols_reduce_kernel, dim3((cols + 255) / 256, NRHS), dim3(256), 0, c->stream,
+                       part, ldpart, nsplit, NRHS, cols, Y, ldy);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+int launch_gemv_cols(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* X,
+                     int ldx, int nrhs, double* Y, int ldy) {
+    if (rows <= 0 || cols <= 0 || nrhs <= 0) return SELLA_OK;
+    if ((lda & 1) || (((uintptr_t)A) & 15)) {
+        set_error("gemv_cols: matrix must be 16-byte aligned with even leading dimension");
+        return SELLA_E_INVALID;
+    }
+    for (int h0 = 0; h0 < nrhs; h0 += 4) {
+        const int nh = (nrhs - h0 < 4) ? (nrhs - h0) : 4;
+        const double* Xh = X + (size_t)h0 * ldx;
+        double* Yh = Y + (size_t)h0 * ldy;
+        switch (nh) {
+            case 1: SCHK(gemv_cols_run<1>(c, A, rows, cols, lda, Xh, ldx, Yh, ldy)); break;
+            case 2: SCHK(gemv_cols_run<2>(c, A, rows, cols, lda, Xh, ldx, Yh, ldy)); break;
+            case 3: SCHK(gemv_cols_run<3>(c, A, rows, cols, lda, Xh, ldx, Yh, ldy)); break;
+            default: SCHK(gemv_cols_run<4>(c, A, rows, cols, lda, Xh, ldx, Yh, ldy)); break;
+        }
+    }
+    return SELLA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// K2: linear combinations of panel rows (basis rotation V <- V W, residuals, Gram-Schmidt
+// updates).  Thread i owns element i of every vector: all loads/stores are coalesced.
+// ------------------------------------------------------------------------------------
+constexpr int LC_NT = 8;     // outputs per thread
+constexpr int LC_JT = 128;   // panel rows per LDS tile of coefficients
+
+__global__ __launch_bounds__(256) void lincomb_kernel(int n, int nout, const double* __restrict__ P1,
+                                                      int ldp1, int k1,
+                                                      const double* __restrict__ W1, int ldw1,
+                                                      const double* __restrict__ P2, int ldp2,
+                                                      int k2, const double* __restrict__ W2,
+                                                      int ldw2, double beta,
+                                                      double* __restrict__ out, int ldo) {
+    __shared__ double ws[LC_JT * LC_NT];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int c0 = blockIdx.y * LC_NT;
+    double acc[LC_NT];
+#pragma unroll
+    for (int c = 0; c < LC_NT; ++c) acc[c] = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const double* P = pass ? P2 : P1;
+        const double* W = pass ? W2 : W1;
+        const int ldp = pass ? ldp2 : ldp1;
+        const int ldw = pass ? ldw2 : ldw1;
+        const int k = pass ? k2 : k1;
+        if (P == nullptr || k <= 0) continue;
+        for (int j0 = 0; j0 < k; j0 += LC_JT) {
+            const int jt = (k - j0 < LC_JT) ? (k - j0) : LC_JT;
+            __syncthreads();
+            for (int t = threadIdx.x; t < jt * LC_NT; t += 256) {
+                const int j = t / LC_NT, cc = t % LC_NT;
+                ws[t] = (c0 + cc < nout) ? W[(size_t)(j0 + j) * ldw + c0 + cc] : 0.0;
+            }
+            __syncthreads();
+            if (i < n) {
+#pragma unroll 4
+                for (int j = 0; j < jt; ++j) {
+                    const double p = P[(size_t)(j0 + j) * ldp + i];
+#pragma unroll
+                    for (int c = 0; c < LC_NT; ++c) acc[c] += ws[j * LC_NT + c] * p;
+                }
+            }
+        }
+    }
+    if (i < n) {
+#pragma unroll
+        for (int c = 0; c < LC_NT; ++c) {
+            if (c0 + c < nout) {
+                double* o = out + (size_t)(c0 + c) * ldo + i;
+                *o = (beta == 0.0) ? acc[c] : (beta * (*o) + acc[c]);
+            }
+        }
+    }
+}
+
+int launch_lincomb(sella_ctx* c, int n, int nout, const double* P1, int ldp1, int k1,
+                   const double* W1, int ldw1, const double* P2, int ldp2, int k2,
+                   const double* W2, int ldw2, double beta, double* out, int ldo) {
+    if (n <= 0 || nout <= 0) return SELLA_OK;
+    dim3 grid((n + 255) / 256, (nout + LC_NT - 1) / LC_NT);
+    hipLaunchKernelGGL(lincomb_kernel, grid, dim3(256), 0, c->stream, n, nout, P1, ldp1, k1, W1, ldw1,
+                       P2, ldp2, k2, W2, ldw2, beta, out, ldo);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// small vector kernels
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restrict__ P, int ldp,
+                                                         int nrows, int n, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;   // whole wavefront leaves together
+    const double* p = P + (size_t)r * ldp;
+    double s = 0.0;
+    for (int i = lane; i < n; i += 64) s += p[i] * p[i];
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s;
+}
+
+int launch_rows_sumsq(sella_ctx* c, const double* P, int ldp, int nrows, int n, double* out) {
+    if (nrows <= 0) return SELLA_OK;
+    hipLaunchKernelGGL(rows_sumsq_kernel, dim3((nrows + 3) / 4), dim3(256), 0, c->stream, P, ldp, nrows,
+                       n, out);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+__global__ __launch_bounds__(256) void scale_by_kernel(double* __restrict__ x, int n,
+                                                       const double* __restrict__ scal, int mode) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double s = scal[0];
+    double f;
+    if (mode == 0) f = 1.0 / sqrt(s);
+    else if (mode == 1) f = 1.0 / s;
+    else f = s;
+    x[i] *= f;
+}
+
+int launch_scale_by(sella_ctx* c, double* x, int n, const double* scal, int mode) {
+    hipLaunchKernelGGL(scale_by_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, x, n, scal, mode);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+__global__ __launch_bounds__(256) void jd_combine_kernel(const double* __restrict__ x,
+                                                         const double* __restrict__ y,
+                                                         const double* __restrict__ dots,
+                                                         double* __restrict__ t, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double num = dots[0], den = dots[1];
+    // eigensolvers.py:127-132: t = y*(v.x / v.y) - x, or x itself when v.y ~ 0
+    t[i] = (fabs(den) < 1e-12) ? x[i] : (y[i] * (num / den) - x[i]);
+}
+
+int launch_jd_combine(sella_ctx* c, const double* x, const double* y, const double* dots, double* t,
+                      int n) {
+    hipLaunchKernelGGL(jd_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, x, y, dots, t, n);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+// (no __restrict__: callers may update in place)
+__global__ __launch_bounds__(256) void axpby_kernel(int n, double a, const double* x, double b,
+                                                    const double* y, double* z) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v = a * x[i];
+    if (y != nullptr) v += b * y[i];
+    z[i] = v;
+}
+
+int launch_axpby(sella_ctx* c, int n, double a, const double* x, double b, const double* y, double* z) {
+    if (n <= 0) return SELLA_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, a, x, b, y, z);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+__global__ __launch_bounds__(256) void axpby2d_kernel(int rows, int cols, double a,
+                                                      const double* __restrict__ A, int lda, double b,
+                                                      const double* __restrict__ B, int ldb,
+                                                      double* __restrict__ C, int ldc) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= cols || i >= rows) return;
+    double v = a * A[(size_t)i * lda + j];
+    if (B != nullptr) v += b * B[(size_t)i * ldb + j];
+    C[(size_t)i * ldc + j] = v;
+}
+
+int launch_axpby2d(sella_ctx* c, int rows, int cols, double a, const double* A, int lda, double b,
+                   const double* B, int ldb, double* C, int ldc) {
+    if (rows <= 0 || cols <= 0) return SELLA_OK;
+    hipLaunchKernelGGL(axpby2d_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, c->stream, rows,
+                       cols, a, A, lda, b, B, ldb, C, ldc);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+// 32x32 tiles through LDS (+1 padding), coalesced on both sides.
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ A, int rows,
+                                                        int cols, int lda, double* __restrict__ At,
+                                                        int ldat) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, cc = c0 + tx;
+        tile[k][tx] = (r < rows && cc < cols) ? A[(size_t)r * lda + cc] : 0.0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int cc = c0 + k, r = r0 + tx;   // At[cc][r]
+        if (cc < cols && r < rows) At[(size_t)cc * ldat + r] = tile[tx][k];
+    }
+}
+
+int launch_transpose(sella_ctx* c, const double* A, int rows, int cols, int lda, double* At, int ldat) {
+    if (rows <= 0 || cols <= 0) return SELLA_OK;
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
+                       c->stream, A, rows, cols, lda, At, ldat);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+// In-place symmetrisation B <- (B + B^T)/2: block (bi, bj) with bi <= bj handles both tiles.
+__global__ __launch_bounds__(256) void symmetrize_kernel(double* __restrict__ B, int n, int ld) {
+    if (blockIdx.x < blockIdx.y) return;   // uniform per block
+    __shared__ double t1[32][33];
+    __shared__ double t2[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;     // tile (r0, c0), mirror (c0, r0)
+    for (int k = ty; k < 32; k += 8) {
+        int r = r0 + k, cc = c0 + tx;
+        t1[k][tx] = (r < n && cc < n) ? B[(size_t)r * ld + cc] : 0.0;
+        r = c0 + k; cc = r0 + tx;
+        t2[k][tx] = (r < n && cc < n) ? B[(size_t)r * ld + cc] : 0.0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        int r = r0 + k, cc = c0 + tx;
+        if (r < n && cc < n) B[(size_t)r * ld + cc] = 0.5 * (t1[k][tx] + t2[tx][k]);
+        r = c0 + k; cc = r0 + tx;
+        if (r < n && cc < n) B[(size_t)r * ld + cc] = 0.5 * (t2[k][tx] + t1[tx][k]);
+    }
+}
+
+int launch_symmetrize(sella_ctx* c, double* B, int n, int ld) {
+    if (n <= 0) return SELLA_OK;
+    const int nb = (n + 31) / 32;
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(nb, nb), dim3(256), 0, c->stream, B, n, ld);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const double* __restrict__ in, int ldi,
+                                                          const int* __restrict__ idx, int nrows,
+                                                          int ncols, double* __restrict__ out,
+                                                          int ldo) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (j >= ncols || r >= nrows) return;
+    out[(size_t)r * ldo + j] = in[(size_t)idx[r] * ldi + j];
+}
+
+int launch_gather_rows(sella_ctx* c, const double* in, int ldi, const int* idx, int nrows, int ncols,
+                       double* out, int ldo) {
+    if (nrows <= 0 || ncols <= 0) return SELLA_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((ncols + 255) / 256, nrows), dim3(256), 0, c->stream, in,
+                       ldi, idx, nrows, ncols, out, ldo);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// GEMM, fp64.  C (M x N) = alpha * op(A) op(B) + beta * C, everything row-major.
+// 64x64 output tile per 256-thread workgroup, K stepped by 16 through LDS (k-major tiles,
+// row stride 80 doubles so the two 16-lane halves of a 32-lane LDS group hit disjoint banks).
+//   MFMA variant : each wavefront owns a 32x32 quadrant = 2x2 v_mfma_f64_16x16x4_f64 tiles
+//                  (A frag: lane l holds A[l&15][l>>4]; B frag: B[l>>4][l&15];
+//                   C/D: col = l&15, row = (l>>4) + 4*reg).
+//   VALU variant : each thread owns a 4x4 register tile.
+// Edge tiles are zero-filled on load and masked on store, so any M, N, K, ld are accepted.
+// ------------------------------------------------------------------------------------
+constexpr int GM_BM = 64, GM_BN = 64, GM_BK = 16, GM_LD = 80;
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void gemm_load_tiles(const double* __restrict__ A, int lda, int transA,
+                                                const double* __restrict__ B, int ldb, int transB,
+                                                int M, int N, int K, int m0, int n0, int k0,
+                                                double (*As)[GM_LD], double (*Bs)[GM_LD]) {
+    // As[k][m] = op(A)[m0+m][k0+k];  Bs[k][n] = op(B)[k0+k][n0+n];  1024 elements each
+    for (int t = threadIdx.x; t < GM_BM * GM_BK; t += 256) {
+        int m, k;
+        if (transA) { m = t & 63; k = t >> 6; }     // contiguous along m in memory
+        else { k = t & 15; m = t >> 4; }            // contiguous along k in memory
+        const int gm = m0 + m, gk = k0 + k;
+        double v = 0.0;
+        if (gm < M && gk < K) v = transA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
+        As[k][m] = v;
+    }
+    for (int t = threadIdx.x; t < GM_BN * GM_BK; t += 256) {
+        int n, k;
+        if (transB) { k = t & 15; n = t >> 4; }     // B is N x K: contiguous along k
+        else { n = t & 63; k = t >> 6; }            // B is K x N: contiguous along n
+        const int gn = n0 + n, gk = k0 + k;
+        double v = 0.0;
+        if (gn < N && gk < K) v = transB ? B[(size_t)gn * ldb + gk] : B[(size_t)gk * ldb + gn];
+        Bs[k][n] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(int transA, int transB, int M, int N, int K,
+                                                        double alpha, const double* __restrict__ A,
+                                                        int lda, const double* __restrict__ B,
+                                                        int ldb, double beta, double* __restrict__ C,
+                                                        int ldc) {
+    __shared__ double As[GM_BK][GM_LD];
+    __shared__ double Bs[GM_BK][GM_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int li = lane & 15, lk = lane >> 4;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += GM_BK) {
+        __syncthreads();
+        gemm_load_tiles(A, lda, transA, B, ldb, transB, M, N, K, m0, n0, k0, As, Bs);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GM_BK; kk += 4) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = As[kk + lk][wm + a * 16 + li];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = Bs[kk + lk][wn + b * 16 + li];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm + a * 16 + lk + 4 * r;
+                const int gn = n0 + wn + b * 16 + li;
+                if (gm < M && gn < N) {
+                    double* cp = C + (size_t)gm * ldc + gn;
+                    const double v = alpha * acc[a][b][r];
+                    *cp = (beta == 0.0) ? v : (v + beta * (*cp));
+                }
+            }
+}
+
+__global__ __launch_bounds__(256) void gemm_valu_kernel(int transA, int transB, int M, int N, int K,
+                                                        double alpha, const double* __restrict__ A,
+                                                        int lda, const double* __restrict__ B,
+                                                        int ldb, double beta, double* __restrict__ C,
+                                                        int ldc) {
+    __shared__ double As[GM_BK][GM_LD];
+    __shared__ double Bs[GM_BK][GM_LD];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // 16 x 16 threads, 4x4 each
+    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k0 = 0; k0 < K; k0 += GM_BK) {
+        __syncthreads();
+        gemm_load_tiles(A, lda, transA, B, ldb, transB, M, N, K, m0, n0, k0, As, Bs);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GM_BK; ++kk) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[a] = As[kk][ty * 4 + a];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf[b] = Bs[kk][tx * 4 + b];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += af[a] * bf[b];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int gm = m0 + ty * 4 + a, gn = n0 + tx * 4 + b;
+            if (gm < M && gn < N) {
+                double* cp = C + (size_t)gm * ldc + gn;
+                const double v = alpha * acc[a][b];
+                *cp = (beta == 0.0) ? v : (v + beta * (*cp));
+            }
+        }
+}
+
+int launch_gemm(sella_ctx* c, int transA, int transB, int M, int N, int K, double alpha,
+                const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc) {
+    if (M <= 0 || N <= 0) return SELLA_OK;
+    dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM);
+    prof_begin(c, PROF_GEMM, 8.0 * ((double)M * K + (double)K * N + 2.0 * M * N), 2.0 * M * (double)N * K);
+    if (c->opt.gemm_mfma)
+        hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, c->stream, transA, transB, M, N, K, alpha,
+                           A, lda, B, ldb, beta, C, ldc);
+    else
+        hipLaunchKernelGGL(gemm_valu_kernel, grid, dim3(256), 0, c->stream, transA, transB, M, N, K, alpha,
+                           A, lda, B, ldb, beta, C, ldc);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+}  // namespace sella

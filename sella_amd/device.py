@@ -1,0 +1,289 @@
+"""Python face of the C ABI: a `Context` (one HIP device + stream) and `DeviceMatrix`
+handles.  numpy in / numpy out, fp64, like the reference's accelerator seam
+(sella/_gpu.py:55-132) — but the device side is libsella_hip, not torch.
+"""
+import os
+import weakref
+from ctypes import byref, c_char_p, c_double, c_int, c_long, c_void_p, create_string_buffer
+
+import numpy as np
+
+from . import _lib
+from ._lib import SELLA_NO_MAT, as_f64, check, ptr
+
+DAVIDSON_METHODS = {'lanczos': 0, 'gd': 1, 'jd0': 2, 'jd0_alt': 3, 'mjd0': 4, 'mjd0_alt': 5}
+UPDATE_METHODS = {'TS-BFGS': 0, 'BFGS': 1, 'PSB': 2, 'DFP': 3, 'SR1': 4, 'Greenstadt': 5,
+                  'BFGS_auto': 6}
+
+
+class DeviceMatrix:
+    """Row-major fp64 matrix resident in HBM (opaque handle owned by a Context)."""
+
+    def __init__(self, ctx, handle, shape):
+        self.ctx = ctx
+        self.handle = handle
+        self.shape = tuple(shape)
+        self._fin = weakref.finalize(self, DeviceMatrix._release, ctx, handle)
+
+    @staticmethod
+    def _release(ctx, handle):
+        if ctx._h is not None:
+            _lib.lib().sella_mat_free(ctx._h, handle)
+
+    def free(self):
+        self._fin()
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        check(_lib.lib().sella_mat_download(self.ctx._h, self.handle, ptr(out)))
+        return out
+
+    def set(self, A):
+        A = as_f64(A, self.shape)
+        check(_lib.lib().sella_mat_set(self.ctx._h, self.handle, ptr(A)))
+
+    def copy(self):
+        h = c_int(-1)
+        check(_lib.lib().sella_mat_copy(self.ctx._h, self.handle, byref(h)))
+        return DeviceMatrix(self.ctx, h.value, self.shape)
+
+    def transpose(self):
+        h = c_int(-1)
+        check(_lib.lib().sella_mat_transpose(self.ctx._h, self.handle, byref(h)))
+        return DeviceMatrix(self.ctx, h.value, self.shape[::-1])
+
+
+class Context:
+    def __init__(self, device=None):
+        L = _lib.lib()
+        if device is None:
+            device = int(os.environ.get('SELLA_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+            n = c_int(0)
+            check(L.sella_device_count(byref(n)))
+            if n.value > 0:
+                device %= n.value
+        h = c_void_p()
+        check(L.sella_ctx_create(int(device), byref(h)))
+        self._h = h
+        self.device = int(device)
+        self._fin = weakref.finalize(self, Context._destroy, self, L)
+
+    @staticmethod
+    def _destroy(self, L):
+        if self._h is not None:
+            L.sella_ctx_destroy(self._h)
+            self._h = None
+
+    def close(self):
+        self._fin()
+
+    # ---- misc -------------------------------------------------------------------------
+    @property
+    def name(self):
+        buf = create_string_buffer(256)
+        check(_lib.lib().sella_ctx_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    def sync(self):
+        check(_lib.lib().sella_ctx_sync(self._h))
+
+    def set_option(self, key, value):
+        check(_lib.lib().sella_ctx_set_option(self._h, key.encode(), int(value)))
+
+    # ---- matrices ---------------------------------------------------------------------
+    def upload(self, A):
+        A = as_f64(A)
+        if A.ndim == 1:
+            A = A[:, None]
+        h = c_int(-1)
+        check(_lib.lib().sella_mat_upload(self._h, ptr(A), A.shape[0], A.shape[1], byref(h)))
+        return DeviceMatrix(self, h.value, A.shape)
+
+    def zeros(self, rows, cols):
+        h = c_int(-1)
+        check(_lib.lib().sella_mat_alloc(self._h, rows, cols, byref(h)))
+        return DeviceMatrix(self, h.value, (rows, cols))
+
+    def axpby(self, alpha, A, beta=0.0, B=None):
+        h = c_int(-1)
+        check(_lib.lib().sella_mat_axpby(self._h, float(alpha), A.handle, float(beta),
+                                         SELLA_NO_MAT if B is None else B.handle, byref(h)))
+        return DeviceMatrix(self, h.value, A.shape)
+
+    # ---- products -----------------------------------------------------------------------
+    def symm_mm(self, A, X):
+        """A @ X with A resident; X (n,) or (n, k) host."""
+        X = as_f64(X)
+        one_d = X.ndim == 1
+        X2 = X[:, None] if one_d else X
+        X2 = np.ascontiguousarray(X2)
+        if X2.shape[0] != A.shape[1]:
+            raise ValueError(f'dimension mismatch: {A.shape} @ {X.shape}')
+        Y = np.empty((A.shape[0], X2.shape[1]))
+        check(_lib.lib().sella_symm_mm(self._h, A.handle, ptr(X2), X2.shape[1], ptr(Y)))
+        return Y[:, 0] if one_d else Y
+
+    def tmatmul(self, A, X):
+        """A.T @ X with A resident."""
+        X = as_f64(X)
+        one_d = X.ndim == 1
+        X2 = np.ascontiguousarray(X[:, None] if one_d else X)
+        if X2.shape[0] != A.shape[0]:
+            raise ValueError(f'dimension mismatch: {A.shape}.T @ {X.shape}')
+        Y = np.empty((A.shape[1], X2.shape[1]))
+        check(_lib.lib().sella_gemm_tn_host(self._h, A.handle, ptr(X2), X2.shape[1], ptr(Y)))
+        return Y[:, 0] if one_d else Y
+
+    def project(self, H, U):
+        """U.T @ H @ U (numpy result), H resident, U host (n, m)."""
+        U = as_f64(U)
+        out = np.empty((U.shape[1], U.shape[1]))
+        check(_lib.lib().sella_project(self._h, H.handle, ptr(U), U.shape[1], ptr(out)))
+        return out
+
+    def project_dev(self, H, U):
+        h = c_int(-1)
+        check(_lib.lib().sella_project_dev(self._h, H.handle, U.handle, byref(h)))
+        return DeviceMatrix(self, h.value, (U.shape[1], U.shape[1]))
+
+    def gemm(self, A, B, C, transA=False, transB=False, alpha=1.0, beta=0.0):
+        check(_lib.lib().sella_gemm(self._h, int(transA), int(transB), float(alpha), A.handle,
+                                    B.handle, float(beta), C.handle))
+        return C
+
+    # ---- factorizations -------------------------------------------------------------------
+    def eigh(self, A, vectors=True):
+        """(w, V, Vt): eigenvalues ascending (numpy), eigenvectors as columns / rows (device)."""
+        n = A.shape[0]
+        w = np.empty(n)
+        hv, hvt = c_int(-1), c_int(-1)
+        check(_lib.lib().sella_eigh(self._h, A.handle, ptr(w), byref(hv) if vectors else None,
+                                    byref(hvt) if vectors else None))
+        if not vectors:
+            return w, None, None
+        return w, DeviceMatrix(self, hv.value, (n, n)), DeviceMatrix(self, hvt.value, (n, n))
+
+    def qr_thin(self, A):
+        A = as_f64(A)
+        m, n = A.shape
+        Q = np.empty((m, n))
+        R = np.empty((n, n))
+        check(_lib.lib().sella_qr_thin(self._h, ptr(A), m, n, ptr(Q), ptr(R)))
+        return Q, R
+
+    def mgs(self, X, Y=None, eps1=1e-15, eps2=1e-6, maxiter=100):
+        X = as_f64(X)
+        n, nx = X.shape
+        ny = 0
+        if Y is not None:
+            Y = as_f64(Y)
+            ny = Y.shape[1]
+        out = np.zeros((n, nx))
+        kept = c_int(0)
+        check(_lib.lib().sella_mgs(self._h, ptr(X), n, nx, ptr(Y) if ny else None, ny, eps1, eps2,
+                                   maxiter, ptr(out), byref(kept)))
+        return np.ascontiguousarray(out[:, :kept.value])
+
+    # ---- Davidson -------------------------------------------------------------------------
+    def davidson(self, A, n, v0, gamma, method='jd0', maxiter=None, Pvecs=None, PvecsT=None,
+                 pevals=None, pscale=1.0, vref=None, vreftol=0.99):
+        """A: DeviceMatrix or a python callable v -> A v.  Returns (lams, V, AV, nmatvec)."""
+        if method not in DAVIDSON_METHODS:
+            raise ValueError("Unknown diagonalization method {}".format(method))
+        v0 = as_f64(v0)
+        if v0.ndim == 1:
+            v0 = v0[:, None]
+        v0 = np.ascontiguousarray(v0)
+        nv0 = v0.shape[1]
+        if maxiter is None:
+            maxiter = 2 * n + 1
+        kmax = min(n, max(int(maxiter), nv0))
+        lams = np.zeros(kmax + 1)
+        V = np.zeros((n * (kmax + 1),))
+        AV = np.zeros((n * (kmax + 1),))
+        k = c_int(0)
+        nmv = c_int(0)
+        err = []
+        if isinstance(A, DeviceMatrix):
+            hA, cb = A.handle, _lib.MATVEC_FN()
+        else:
+            hA = SELLA_NO_MAT
+
+            def _cb(user, vp, avp, nn):
+                try:
+                    v = np.ctypeslib.as_array(vp, shape=(nn,)).copy()
+                    out = np.asarray(A(v), dtype=np.float64).ravel()
+                    np.ctypeslib.as_array(avp, shape=(nn,))[:] = out
+                    return 0
+                except BaseException as e:      # noqa: B902 — must not unwind through C
+                    err.append(e)
+                    return 1
+            cb = _lib.MATVEC_FN(_cb)
+        pe = as_f64(pevals) if pevals is not None else None
+        vr = as_f64(vref) if vref is not None else None
+        st = _lib.lib().sella_davidson(
+            self._h, hA, cb, None,
+            SELLA_NO_MAT if Pvecs is None else Pvecs.handle,
+            SELLA_NO_MAT if PvecsT is None else PvecsT.handle,
+            ptr(pe), float(pscale), int(n), ptr(v0), nv0, float(gamma),
+            DAVIDSON_METHODS[method], int(maxiter), ptr(vr), float(vreftol),
+            ptr(lams), ptr(V), ptr(AV), byref(k), byref(nmv))
+        if err:
+            raise err[0]
+        check(st)
+        kk = k.value
+        return (lams[:kk].copy(), V[:n * kk].reshape(n, kk).copy(),
+                AV[:n * kk].reshape(n, kk).copy(), nmv.value)
+
+    # ---- quasi-Newton -----------------------------------------------------------------------
+    def update_h(self, B, S, Y, method='TS-BFGS', symm=2, evals=None, evecs=None, evecsT=None):
+        """In-place update of the resident B (n x n)."""
+        if method not in UPDATE_METHODS:
+            raise ValueError('Unknown update method {}'.format(method))
+        S = as_f64(S)
+        Y = as_f64(Y)
+        n, k = S.shape
+        ev = as_f64(evals) if evals is not None else None
+        check(_lib.lib().sella_update_h(
+            self._h, B.handle, SELLA_NO_MAT if evecs is None else evecs.handle,
+            SELLA_NO_MAT if evecsT is None else evecsT.handle, ptr(ev), ptr(S), ptr(Y), n, k,
+            UPDATE_METHODS[method], -1 if symm is None else int(symm)))
+
+    def symmetrize_y(self, S, Y, symm):
+        S = as_f64(S)
+        Y = as_f64(Y)
+        n, k = S.shape
+        out = np.empty((n, k))
+        check(_lib.lib().sella_symmetrize_y(self._h, ptr(S), ptr(Y), n, k,
+                                            -1 if symm is None else int(symm), ptr(out)))
+        return out
+
+    # ---- profiling ---------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        check(_lib.lib().sella_prof_enable(self._h, int(bool(on))))
+
+    def prof_reset(self):
+        check(_lib.lib().sella_prof_reset(self._h))
+
+    def prof_get(self, kind):
+        n, ms, b, f = c_long(0), c_double(0), c_double(0), c_double(0)
+        check(_lib.lib().sella_prof_get(self._h, int(kind), byref(n), byref(ms), byref(b), byref(f)))
+        return dict(launches=n.value, ms=ms.value, bytes=b.value, flops=f.value)
+
+
+_default = None
+
+
+def get_context():
+    """Process-wide default context (one process per GPU)."""
+    global _default
+    if _default is None:
+        _default = Context()
+    return _default
+
+
+def _reset_default_context():
+    global _default
+    if _default is not None:
+        _default.close()
+    _default = None

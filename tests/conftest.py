@@ -1,0 +1,71 @@
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLD = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+BACKENDS = [pytest.param('emu', id='emu'), pytest.param('hip', marks=pytest.mark.gpu, id='hip')]
+
+
+@pytest.fixture(scope='session')
+def emu_library():
+    """tests/hostemu build of the kernel sources (CPU fibers) — test infrastructure."""
+    sys.path.insert(0, os.path.join(REPO, 'tests', 'hostemu'))
+    import build_emu
+    return ctypes.CDLL(build_emu.build())
+
+
+@pytest.fixture(scope='module', params=BACKENDS)
+def ctx(request):
+    """A sella_amd Context on the real HIP library ('hip', gpu-marked) or on the host
+    emulation of the same sources ('emu', CPU CI)."""
+    from sella_amd import _lib, device
+    device._reset_default_context()
+    if request.param == 'emu':
+        _lib._set_library_for_tests(request.getfixturevalue('emu_library'))
+    else:
+        _lib._set_library_for_tests(None)
+    c = device.Context(0)
+    c.backend = request.param
+    device._default = c
+    yield c
+    device._default = None
+    c.close()
+    _lib._set_library_for_tests(None)
+
+
+@pytest.fixture(scope='session')
+def manifest():
+    with open(os.path.join(GOLD, 'manifest.json')) as f:
+        return json.load(f)
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLD, name + '.npz'))
+
+
+def hessian_like(n, seed, eps=5e-3, nneg=1):
+    """SURVEY.md §8(d) synthetic Hessian / preconditioner / gradient (same recipe as
+    oracle/make_golden.py, so the big-size digests in tests/golden apply)."""
+    rng = np.random.RandomState(seed)
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    lam = np.exp(rng.uniform(np.log(0.05), np.log(50.0), n))
+    lam[:nneg] = -np.linspace(1.0, 0.5, nneg)
+    A = (Q * lam) @ Q.T
+    A = 0.5 * (A + A.T)
+    N = rng.normal(size=(n, n))
+    P = A + eps * 0.5 * (N + N.T)
+    g = rng.normal(size=n)
+    return A, P, g

@@ -1,0 +1,56 @@
+"""TEST INFRASTRUCTURE: compile sella_amd/csrc/*.hip against the fake HIP runtime header
+(tests/hostemu/include) into tests/hostemu/_build/libsella_hostemu.so with host clang++.
+See tests/hostemu/README.md.  Never loaded by the product."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(REPO, 'sella_amd', 'csrc')
+OUT = os.path.join(HERE, '_build')
+LIB = os.path.join(OUT, 'libsella_hostemu.so')
+CXX = os.environ.get('HOSTEMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')
+FLAGS = ['-x', 'c++', '-std=c++17', '-O2', '-g', '-fPIC', '-I', os.path.join(HERE, 'include'),
+         '-Wall', '-Wno-unused-function', '-Wno-unused-result', '-Wno-unknown-pragmas',
+         '-Wno-pass-failed']
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OUT, exist_ok=True)
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.hip')]
+    srcs.append(os.path.join(HERE, 'hostemu.cpp'))
+    hooks = os.path.join(HERE, 'hooks.cpp')
+    if os.path.exists(hooks):
+        srcs.append(hooks)
+    deps = list(srcs) + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    deps += [os.path.join(HERE, 'include', 'hip', 'hip_runtime.h'),
+             os.path.join(REPO, 'include', 'sella_hip.h')]
+    newest = max(os.path.getmtime(d) for d in deps)
+    objs, procs = [], []
+    for s in srcs:
+        o = os.path.join(OUT, os.path.basename(s) + '.o')
+        objs.append(o)
+        if not force and os.path.exists(o) and os.path.getmtime(o) > newest:
+            continue
+        cmd = [CXX, *FLAGS, '-c', s, '-o', o]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    bad = False
+    for s, p in procs:
+        out = p.communicate()[0].decode()
+        if p.returncode != 0:
+            bad = True
+            sys.stderr.write(f'--- {s} ---\n{out}\n')
+        elif verbose and out.strip():
+            print(out)
+    if bad:
+        raise RuntimeError('hostemu build failed')
+    if procs or not os.path.exists(LIB):
+        subprocess.check_call([CXX, '-shared', '-fPIC', *objs, '-o', LIB])
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -142,52 +142,9 @@ int apply_pinv(Dav& s, double theta, const double* in, int m, double* mid, doubl
     return launch_gemv_rows(c, s.Q->d, s.n, s.n, s.Q->ld, mid, s.ld, m, out, s.ld, GemvEpi());
 }
 
-// One classical Gram-Schmidt sweep of t against the first k panel rows, then normalise:
-//   cvec = V t ; t -= V^T cvec ; norm2 -> dscal[slot] ; t /= sqrt(norm2)
-int gs_sweep(Dav& s, double* t, int k, int slot) {
-    sella_ctx* c = s.c;
-    double* cvec = c->dscal + DS_CVEC;  // k coefficients, already negated by the epilogue
-    if (k > 0) {
-        GemvEpi neg;
-        neg.alpha = -1.0;
-        SCHK(launch_gemv_rows(c, s.Vp, k, s.n, s.ld, t, s.ld, 1, cvec, s.cap, neg));
-        // t <- t + sum_j cvec[j] V_j  (coefficient "matrix" is k x 1, ldw = 1)
-        SCHK(launch_lincomb(c, s.n, 1, s.Vp, s.ld, k, cvec, 1, nullptr, 0, 0, nullptr, 0, 1.0, t, s.ld));
-    }
-    SCHK(launch_rows_sumsq(c, t, s.ld, 1, s.n, c->dscal + slot));
-    return launch_scale_by(c, t, s.n, c->dscal + slot, 0);
-}
-
-int normalise(Dav& s, double* t, int slot) {
-    SCHK(launch_rows_sumsq(s.c, t, s.ld, 1, s.n, s.c->dscal + slot));
-    return launch_scale_by(s.c, t, s.n, s.c->dscal + slot, 0);
-}
-
-// Orthonormalise t against V[0:k) with the reference's accept / drop rules (math.pyx:105-133):
-// drop (return kept=0) when one sweep shrinks the vector below eps2 = 1e-6; accept when a
-// sweep leaves the norm within eps1 = 1e-15 of one.  first_norm returns the norm after the
-// first sweep (= ||t - V V^T t|| for a unit t, the quantity tested at eigensolvers.py:93).
+// Orthonormalise t against V[0:k) with the reference's accept / drop rules (gs.hip).
 int orthonormalise(Dav& s, double* t, int k, int* kept, double* first_norm) {
-    sella_ctx* c = s.c;
-    const double eps1 = 1e-15, eps2 = 1e-6;
-    *kept = 0;
-    SCHK(normalise(s, t, 8));
-    SCHK(gs_sweep(s, t, k, 9));
-    SCHK(gs_sweep(s, t, k, 10));
-    SCHK(read_scalars(c, 8, 3));
-    double n1 = sqrt(c->hscal[9]), n2 = sqrt(c->hscal[10]);
-    if (first_norm) *first_norm = n1;
-    if (!(c->hscal[8] > 0.0) || !(n1 == n1)) return SELLA_OK;          // zero / NaN input: dropped
-    if (n1 < eps2) return SELLA_OK;
-    for (int it = 0; it < 100; ++it) {
-        if (n2 < eps2) return SELLA_OK;
-        if (fabs(1.0 - n2) <= eps1) { *kept = 1; return SELLA_OK; }
-        SCHK(gs_sweep(s, t, k, 10));
-        SCHK(read_scalars(c, 10, 1));
-        n2 = sqrt(c->hscal[10]);
-    }
-    set_error("MGS failed.");
-    return SELLA_E_NOCONV;
+    return gs_orthonormalise(s.c, s.Vp, s.ld, k, t, s.n, 1e-15, 1e-6, 100, kept, first_norm);
 }
 
 // Append the unit vector in panel slot k (already orthonormalised) and its image A t; update

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
                     double v = epi.alpha * acc[r][h];
                     if (epi.mode == 1) v = v / (epi.dvec[rr] - epi.theta);
                     else if (epi.mode == 2) v += epi.beta * Y[(size_t)h * ldy + rr];
+                    else if (epi.mode == 3) v *= fabs(epi.dvec[rr]);
                     Y[(size_t)h * ldy + rr] = v;
                 }
             }

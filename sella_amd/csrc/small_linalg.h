@@ -28,7 +28,7 @@ SELLA_HD inline double sign_of(double a, double b) { return b >= 0.0 ? fabs(a) :
 // Returns 0, or l+1 if eigenvalue l failed to converge in 60 iterations.
 // ---------------------------------------------------------------------------------------
 SELLA_HD inline int tridiag_ql(int n, double* d, double* e, double* Z, int ldz, int n_rows,
-                               int row0 = 0, int row_step = 1) {
+                               int row0 = 0, int row_step = 1, long cs = 1) {
     if (n <= 1) return 0;
     e[n - 1] = 0.0;
     for (int l = 0; l < n; ++l) {
@@ -66,9 +66,9 @@ SELLA_HD inline int tridiag_ql(int n, double* d, double* e, double* Z, int ldz, 
                     if (Z) {
                         for (int k = row0; k < n_rows; k += row_step) {
                             double* zr = Z + (long)k * ldz;
-                            double f2 = zr[i + 1];
-                            zr[i + 1] = s * zr[i] + c * f2;
-                            zr[i] = c * zr[i] - s * f2;
+                            double f2 = zr[(i + 1) * cs];
+                            zr[(i + 1) * cs] = s * zr[i * cs] + c * f2;
+                            zr[i * cs] = c * zr[i * cs] - s * f2;
                         }
                     }
                 }

@@ -1,0 +1,344 @@
+// update.hip — secant symmetrisation and multi-secant quasi-Newton updates of the resident
+// approximate Hessian (sella/hessian_update.py:12-157; torch formulation :160-203).
+//
+// Every update of the reference family can be written, after the final symmetrisation
+// B+ = (B + Delta + (B + Delta)^T)/2 (hessian_update.py:104-109), as
+//       B+ = sym(B) + sum_a (U_a Z_a^T + Z_a U_a^T)
+// with two vector-major panels U, Z of kk <= 2k rows (k = number of secant pairs):
+//   TS-BFGS / PSB / DFP / Greenstadt : Delta = U J^T + J U^T - U (J^T S) U^T
+//                                      ->  Z = J - 1/2 sym(J^T S) U
+//   SR1                              : Delta = J (J^T S)^-1 J^T      -> U = J, Z = 1/2 sym(C^-1) J
+//   BFGS                             : two such terms (Y and B S panels).
+// The n x n work is therefore: k-column panel products B S, Q^T S, Q (|lam| Q^T S) (row-panel
+// matvecs) and ONE fused pass over B that symmetrises and applies the rank-2kk update
+// (reads and writes B once: 16 n^2 bytes).  All k x k algebra is host code (host_math.h).
+#include "internal.h"
+#include "host_math.h"
+
+namespace sella {
+
+// ------------------------------------------------------------------------------------------
+// fused symmetrise + symmetric rank-2kk update.  Workgroup (bx >= by) owns the 32x32 tile
+// T1 = B[by*32.., bx*32..] and its mirror T2; both are read once and written once.
+// ------------------------------------------------------------------------------------------
+constexpr int R2K_KT = 16;
+
+__global__ __launch_bounds__(256) void sym_rank2k_kernel(double* __restrict__ B, int n, int ld,
+                                                         const double* __restrict__ Up,
+                                                         const double* __restrict__ Zp, int ldp, int kk) {
+    if (blockIdx.x < blockIdx.y) return;
+    __shared__ double t1[32][33];
+    __shared__ double t2[32][33];
+    __shared__ double ur[R2K_KT][32], zr[R2K_KT][32], uc[R2K_KT][32], zc[R2K_KT][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int k = ty; k < 32; k += 8) {
+        int r = r0 + k, cc = c0 + tx;
+        t1[k][tx] = (r < n && cc < n) ? B[(size_t)r * ld + cc] : 0.0;
+        r = c0 + k; cc = r0 + tx;
+        t2[k][tx] = (r < n && cc < n) ? B[(size_t)r * ld + cc] : 0.0;
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};     // rows ty, ty+8, ty+16, ty+24 ; column tx
+    for (int a0 = 0; a0 < kk; a0 += R2K_KT) {
+        const int at = (kk - a0 < R2K_KT) ? (kk - a0) : R2K_KT;
+        __syncthreads();
+        for (int t = threadIdx.x; t < R2K_KT * 32; t += 256) {
+            const int a = t >> 5, i = t & 31;
+            const bool ok = a < at;
+            const int gr = r0 + i, gc = c0 + i;
+            ur[a][i] = (ok && gr < n) ? Up[(size_t)(a0 + a) * ldp + gr] : 0.0;
+            zr[a][i] = (ok && gr < n) ? Zp[(size_t)(a0 + a) * ldp + gr] : 0.0;
+            uc[a][i] = (ok && gc < n) ? Up[(size_t)(a0 + a) * ldp + gc] : 0.0;
+            zc[a][i] = (ok && gc < n) ? Zp[(size_t)(a0 + a) * ldp + gc] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < R2K_KT; ++a) {
+            const double ucx = uc[a][tx], zcx = zc[a][tx];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += ur[a][ty + 8 * q] * zcx + zr[a][ty + 8 * q] * ucx;
+        }
+    }
+    __syncthreads();
+    // new value of element (r0 + k, c0 + tx), k = ty + 8q; mirror element gets the same value
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = ty + 8 * q;
+        const double v = 0.5 * (t1[k][tx] + t2[tx][k]) + acc[q];
+        t1[k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        int r = r0 + k, cc = c0 + tx;
+        if (r < n && cc < n) B[(size_t)r * ld + cc] = t1[k][tx];
+        r = c0 + k; cc = r0 + tx;
+        if (r < n && cc < n) B[(size_t)r * ld + cc] = t1[tx][k];
+    }
+}
+
+int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, const double* Zp, int ldp,
+                      int kk) {
+    const int nb = (n + 31) / 32;
+    prof_begin(c, PROF_UPDATE, 16.0 * n * (double)n, 4.0 * kk * (double)n * n);
+    hipLaunchKernelGGL(sym_rank2k_kernel, dim3(nb, nb), dim3(256), 0, c->stream, B, n, ld, Up, Zp, ldp, kk);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+namespace {
+
+using hostm::vec;
+
+// G[a][b] = P_a . Q_b for two vector-major panels (ka x kb), one sync
+int gram(sella_ctx* c, const double* P, int ka, const double* Q, int kb, int n, int ld, vec& G) {
+    G.assign((size_t)ka * kb, 0.0);
+    if (ka * kb > DS_STAGE - DS_CVEC) { set_error("update: too many secant pairs"); return SELLA_E_UNSUPPORTED; }
+    double* d = c->dscal + DS_CVEC;
+    // Y[h*ldy + i] = P_i . Q_h
+    SCHK(launch_gemv_rows(c, P, ka, n, ld, Q, ld, kb, d, ka, GemvEpi()));
+    SCHK(read_scalars(c, DS_CVEC, ka * kb));
+    for (int a = 0; a < ka; ++a)
+        for (int b = 0; b < kb; ++b) G[(size_t)a * kb + b] = c->hscal[DS_CVEC + (size_t)b * ka + a];
+    return SELLA_OK;
+}
+
+// device copy of a small host matrix in the SCR_W scratch (synchronous; k x k only)
+int put_k(sella_ctx* c, const vec& h, size_t offset, double** d) {
+    double* base;
+    SCHK(scratch_get(c, SCR_W, (size_t)(1 << 16) * sizeof(double), &base));
+    if (offset + h.size() > (size_t)(1 << 16)) { set_error("update: coefficient buffer overflow"); return SELLA_E_UNSUPPORTED; }
+    HIPCHK(hipMemcpyAsync(base + offset, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *d = base + offset;
+    return SELLA_OK;
+}
+
+// Ytilde panel from S, Y panels (symmetrize_Y, hessian_update.py:27-37)
+int symmetrize_panels(sella_ctx* c, const double* Sp, const double* Yp, int n, int k, int ld, int symm,
+                      double* Ytp) {
+    SCHK(launch_axpby2d(c, k, n, 1.0, Yp, ld, 0.0, nullptr, 0, Ytp, ld));
+    if (symm < 0 || k == 1) return SELLA_OK;
+    if (symm > 2) { set_error("Unknown symmetrization method %d", symm); return SELLA_E_INVALID; }
+    vec STS, STY, X((size_t)k * k);
+    SCHK(gram(c, Sp, k, Sp, k, n, ld, STS));
+    SCHK(gram(c, Sp, k, Yp, k, n, ld, STY));
+    const int which = hostm::symm_coeffs(k, STS.data(), STY.data(), symm, X.data());
+    if (which < 0) return SELLA_OK;
+    double* dX;
+    SCHK(put_k(c, X, 0, &dX));
+    return launch_lincomb(c, n, k, which == 0 ? Sp : Yp, ld, k, dX, k, nullptr, 0, 0, nullptr, 0, 1.0, Ytp, ld);
+}
+
+// inverse of a general k x k matrix (LU); returns false if singular
+bool invert(int k, const vec& M, vec& Minv) {
+    vec LU(M);
+    std::vector<int> piv(k);
+    if (small::lu_factor(k, LU.data(), k, piv.data()) != 0) return false;
+    Minv.assign((size_t)k * k, 0.0);
+    for (int i = 0; i < k; ++i) Minv[(size_t)i * k + i] = 1.0;
+    small::lu_solve(k, LU.data(), k, piv.data(), Minv.data(), k, k);
+    return true;
+}
+
+// symmetric pseudo-inverse (minimum norm, like lstsq) of a symmetric k x k matrix
+void sym_pinv(int k, const vec& M, vec& Mp) {
+    Mp.assign((size_t)k * k, 0.0);
+    vec e(k), x(k);
+    for (int col = 0; col < k; ++col) {
+        for (int i = 0; i < k; ++i) e[i] = (i == col) ? 1.0 : 0.0;
+        hostm::sym_pinv_solve(k, M.data(), k, e.data(), x.data());
+        for (int i = 0; i < k; ++i) Mp[(size_t)i * k + col] = x[i];
+    }
+}
+
+}  // namespace
+}  // namespace sella
+
+using namespace sella;
+
+extern "C" int sella_symmetrize_y(sella_ctx* c, const double* S, const double* Y, int n, int k, int symm,
+                                  double* out) {
+    if (!c || !S || !Y || !out || n <= 0 || k <= 0) return SELLA_E_INVALID;
+    const int ld = round_up(n, 8);
+    double *Sp, *Yp, *Ytp;
+    SCHK(scratch_get(c, SCR_UPD0, (size_t)k * ld * sizeof(double), &Sp));
+    SCHK(scratch_get(c, SCR_UPD1, (size_t)k * ld * sizeof(double), &Yp));
+    SCHK(scratch_get(c, SCR_UPD2, (size_t)k * ld * sizeof(double), &Ytp));
+    SCHK(upload_panel(c, S, n, k, Sp, ld));
+    SCHK(upload_panel(c, Y, n, k, Yp, ld));
+    SCHK(symmetrize_panels(c, Sp, Yp, n, k, ld, symm, Ytp));
+    return download_panel(c, Ytp, ld, n, k, out);
+}
+
+extern "C" int sella_update_h(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt, const double* evals,
+                              const double* S, const double* Y, int n, int k, int method, int symm) {
+    Mat* B = mat_get(c, hB);
+    if (!B || !S || !Y || k <= 0) return SELLA_E_INVALID;
+    if (B->rows != n || B->cols != n) { set_error("update_H: B must be %d x %d", n, n); return SELLA_E_INVALID; }
+    if (method < SELLA_UPD_TS_BFGS || method > SELLA_UPD_BFGS_AUTO) {
+        set_error("Unknown update method %d", method);
+        return SELLA_E_INVALID;
+    }
+    const int ld = round_up(n, 8);
+    double *Sp, *Yp, *Ytp, *BSp, *wk;
+    SCHK(scratch_get(c, SCR_UPD0, (size_t)k * ld * sizeof(double), &Sp));
+    SCHK(scratch_get(c, SCR_UPD1, (size_t)k * ld * sizeof(double), &Yp));
+    SCHK(scratch_get(c, SCR_UPD2, (size_t)k * ld * sizeof(double), &Ytp));
+    SCHK(scratch_get(c, SCR_UPD3, (size_t)6 * k * ld * sizeof(double), &wk));
+    BSp = wk;                                    // k rows
+    double* Jp = wk + (size_t)k * ld;            // k rows
+    double* Up = wk + 2 * (size_t)k * ld;        // up to 2k rows
+    double* Zp = wk + 4 * (size_t)k * ld;        // up to 2k rows
+    SCHK(upload_panel(c, S, n, k, Sp, ld));
+    SCHK(upload_panel(c, Y, n, k, Yp, ld));
+    SCHK(symmetrize_panels(c, Sp, Yp, n, k, ld, symm, Ytp));
+    B = mat_get(c, hB);
+    // B S (k right-hand sides through the row-panel matvec) and J = Ytilde - B S
+    SCHK(launch_gemv_rows(c, B->d, n, n, B->ld, Sp, ld, k, BSp, ld, GemvEpi()));
+    SCHK(launch_axpby2d(c, k, n, 1.0, Ytp, ld, -1.0, BSp, ld, Jp, ld));
+
+    hostm::vec STY, STS, C, tmp, Minv;
+    if (method == SELLA_UPD_BFGS_AUTO) {                                   // hessian_update.py:80-87
+        method = SELLA_UPD_TS_BFGS;
+        bool pd = evals != nullptr;
+        if (pd) {
+            if (hV == SELLA_NO_MAT) pd = evals[0] > 0.0;
+            else for (int i = 0; i < n; ++i) if (!(evals[i] > 0.0)) { pd = false; break; }
+        }
+        if (pd) {
+            SCHK(gram(c, Sp, k, Ytp, k, n, ld, STY));
+            SCHK(gram(c, Sp, k, Sp, k, n, ld, STS));
+            hostm::vec lam(k), Wv((size_t)k * k);
+            if (hostm::gen_sym_eig(k, STY.data(), STS.data(), lam.data(), Wv.data()) == 0) {
+                bool allpos = true;
+                for (int i = 0; i < k; ++i) allpos = allpos && lam[i] > 0.0;
+                if (allpos) method = SELLA_UPD_BFGS;
+            }
+        }
+    }
+
+    int kk = k;
+    auto panel_times = [&](const hostm::vec& M, const double* P, double* out, size_t off) -> int {
+        // out_a = sum_b M[a][b] P_b   (k x k times a k-row panel)
+        hostm::vec Mt((size_t)k * k);
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) Mt[(size_t)b * k + a] = M[(size_t)a * k + b];
+        double* dM;
+        SCHK(put_k(c, Mt, off, &dM));
+        return launch_lincomb(c, n, k, P, ld, k, dM, k, nullptr, 0, 0, nullptr, 0, 0.0, out, ld);
+    };
+
+    if (method == SELLA_UPD_SR1) {
+        // Delta = J (J^T S)^-1 J^T ;  U = J, Z = 1/2 sym(C^-1) J
+        SCHK(gram(c, Jp, k, Sp, k, n, ld, C));
+        if (!invert(k, C, Minv)) { set_error("SR1 update: singular J^T S"); return SELLA_E_NOCONV; }
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b <= a; ++b) {
+                const double v = 0.25 * (Minv[(size_t)a * k + b] + Minv[(size_t)b * k + a]);
+                Minv[(size_t)a * k + b] = Minv[(size_t)b * k + a] = v;
+            }
+        SCHK(launch_axpby2d(c, k, n, 1.0, Jp, ld, 0.0, nullptr, 0, Up, ld));
+        SCHK(panel_times(Minv, Jp, Zp, 0));
+    } else if (method == SELLA_UPD_BFGS) {
+        // Delta = Y (Y^T S)^-1 Y^T - BS (S^T B S)^-1 (BS)^T
+        hostm::vec YTS, SBS, I1, I2;
+        SCHK(gram(c, Ytp, k, Sp, k, n, ld, YTS));
+        SCHK(gram(c, Sp, k, BSp, k, n, ld, SBS));
+        if (!invert(k, YTS, I1) || !invert(k, SBS, I2)) { set_error("BFGS update: singular curvature matrix"); return SELLA_E_NOCONV; }
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b <= a; ++b) {
+                double v = 0.25 * (I1[(size_t)a * k + b] + I1[(size_t)b * k + a]);
+                I1[(size_t)a * k + b] = I1[(size_t)b * k + a] = v;
+                v = -0.25 * (I2[(size_t)a * k + b] + I2[(size_t)b * k + a]);
+                I2[(size_t)a * k + b] = I2[(size_t)b * k + a] = v;
+            }
+        SCHK(launch_axpby2d(c, k, n, 1.0, Ytp, ld, 0.0, nullptr, 0, Up, ld));
+        SCHK(launch_axpby2d(c, k, n, 1.0, BSp, ld, 0.0, nullptr, 0, Up + (size_t)k * ld, ld));
+        SCHK(panel_times(I1, Ytp, Zp, 0));
+        SCHK(panel_times(I2, BSp, Zp + (size_t)k * ld, (size_t)k * k));
+        kk = 2 * k;
+    } else {
+        // U-family: Delta = U J^T + J U^T - U (J^T S) U^T
+        if (method == SELLA_UPD_TS_BFGS) {
+            // |B| S = Q (|lam| * (Q^T S))                                      hessian_update.py:121
+            double* absBS = Zp;                  // temporary use of the Z rows
+            double* mid = Up;
+            if (hV == SELLA_NO_MAT) {
+                if (!evals) { set_error("TS-BFGS needs the eigendecomposition of B"); return SELLA_E_INVALID; }
+                SCHK(launch_axpby2d(c, k, n, fabs(evals[0]), Sp, ld, 0.0, nullptr, 0, absBS, ld));
+            } else {
+                Mat *V = mat_get(c, hV), *Vt = mat_get(c, hVt);
+                if (!V || !Vt || !evals) { set_error("TS-BFGS needs evecs, evecsT and evals"); return SELLA_E_INVALID; }
+                double* dev;
+                SCHK(scratch_get(c, SCR_C, (size_t)ld * sizeof(double), &dev));
+                HIPCHK(hipMemcpyAsync(dev, evals, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                GemvEpi e;
+                e.mode = 3;
+                e.dvec = dev;
+                SCHK(launch_gemv_rows(c, Vt->d, n, n, Vt->ld, Sp, ld, k, mid, ld, e));
+                SCHK(launch_gemv_rows(c, V->d, n, n, V->ld, mid, ld, k, absBS, ld, GemvEpi()));
+            }
+            // X = X1 + X2 = M1 Ytilde^T + M2 absBS^T with M1 = S^T Ytilde, M2 = S^T absBS  (k x n)
+            // G = X S = M1 M1^T + M2 M2^T ;  U^T = pinv(G) X                  hessian_update.py:120-123
+            hostm::vec M1, M2, G((size_t)k * k, 0.0), Gp, C1((size_t)k * k), C2((size_t)k * k);
+            SCHK(gram(c, Sp, k, Ytp, k, n, ld, M1));
+            SCHK(gram(c, Sp, k, absBS, k, n, ld, M2));
+            for (int a = 0; a < k; ++a)
+                for (int b = 0; b < k; ++b) {
+                    double s = 0.0;
+                    for (int l = 0; l < k; ++l)
+                        s += M1[(size_t)a * k + l] * M1[(size_t)b * k + l] + M2[(size_t)a * k + l] * M2[(size_t)b * k + l];
+                    G[(size_t)a * k + b] = s;
+                }
+            sym_pinv(k, G, Gp);
+            for (int a = 0; a < k; ++a)
+                for (int b = 0; b < k; ++b) {
+                    double s1 = 0.0, s2 = 0.0;
+                    for (int l = 0; l < k; ++l) {
+                        s1 += Gp[(size_t)a * k + l] * M1[(size_t)l * k + b];
+                        s2 += Gp[(size_t)a * k + l] * M2[(size_t)l * k + b];
+                    }
+                    // lincomb wants W[j][c] = coefficient of panel row j in output row c
+                    C1[(size_t)b * k + a] = s1;
+                    C2[(size_t)b * k + a] = s2;
+                }
+            double *d1, *d2;
+            SCHK(put_k(c, C1, 0, &d1));
+            SCHK(put_k(c, C2, (size_t)k * k, &d2));
+            // Up cannot alias its inputs: absBS lives in Zp, Ytp is separate; write U into Up
+            SCHK(launch_lincomb(c, n, k, Ytp, ld, k, d1, k, absBS, ld, k, d2, k, 0.0, Up, ld));
+        } else if (method == SELLA_UPD_PSB) {                                   // U = S (S^T S)^-1
+            SCHK(gram(c, Sp, k, Sp, k, n, ld, STS));
+            if (!invert(k, STS, Minv)) { set_error("PSB update: singular S^T S"); return SELLA_E_NOCONV; }
+            SCHK(panel_times(Minv, Sp, Up, 0));
+        } else if (method == SELLA_UPD_DFP) {                                   // U^T = (S^T Y)^-1 Y^T
+            SCHK(gram(c, Sp, k, Ytp, k, n, ld, STY));
+            if (!invert(k, STY, Minv)) { set_error("DFP update: singular S^T Y"); return SELLA_E_NOCONV; }
+            SCHK(panel_times(Minv, Ytp, Up, 0));
+        } else {                                                                // Greenstadt
+            hostm::vec SBS;
+            SCHK(gram(c, Sp, k, BSp, k, n, ld, SBS));
+            if (!invert(k, SBS, Minv)) { set_error("Greenstadt update: singular S^T B S"); return SELLA_E_NOCONV; }
+            SCHK(panel_times(Minv, BSp, Up, 0));
+        }
+        // Z = J - 1/2 sym(J^T S) U
+        SCHK(gram(c, Jp, k, Sp, k, n, ld, C));
+        hostm::vec Cs((size_t)k * k);
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) Cs[(size_t)a * k + b] = -0.25 * (C[(size_t)a * k + b] + C[(size_t)b * k + a]);
+        // Z_a = J_a + sum_b Cs[a][b] U_b
+        SCHK(launch_axpby2d(c, k, n, 1.0, Jp, ld, 0.0, nullptr, 0, Zp, ld));
+        hostm::vec CsT((size_t)k * k);
+        for (int a = 0; a < k; ++a)
+            for (int b = 0; b < k; ++b) CsT[(size_t)b * k + a] = Cs[(size_t)a * k + b];
+        double* dC;
+        SCHK(put_k(c, CsT, 2 * (size_t)k * k, &dC));
+        SCHK(launch_lincomb(c, n, k, Up, ld, k, dC, k, nullptr, 0, 0, nullptr, 0, 1.0, Zp, ld));
+    }
+    B = mat_get(c, hB);
+    SCHK(launch_sym_rank2k(c, B->d, n, B->ld, Up, Zp, ld, kk));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SELLA_OK;
+}

@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the Sella inner saddle-point linear-algebra loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Metric (BASELINE.json): Davidson iterations per second on the synthetic 3N = 3072 Hessian of
+SURVEY.md §8(d).  One *step* = one complete `rayleigh_ritz(A, gamma=0.1, P, v0=g, 'jd0',
+maxiter=40)` call of the HIP path with A and P already resident in HBM — including the device
+eigendecomposition of the preconditioner P that the eigenbasis form of the JD correction needs
+once per call (the reference pays a dense LU per iteration instead).  `value` = Davidson
+iterations (vectors added to the subspace, the unit BASELINE.md quotes) summed over all ranks,
+divided by the slowest rank's time for the K steps.  Ranks are independent replicas (the path has
+no exchange step), so scaling is weak.
+
+Extra objects on the JSON line:
+  roofline      row-panel matvec (`gemv_rows_kernel`, the dominant kernel): algorithmic bytes per
+                launch (8*rows*cols) / mean launch time from hipEvents on the library's own stream,
+                collected in a separate instrumented pass over the same K steps.
+  cpu_baseline  the NumPy/SciPy oracle port of the reference algorithm (dense LU per iteration)
+                timed on this box's host cores on the same inputs (one call), rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable copy)
+
+
+def hessian_like(n, seed, eps=5e-3):
+    """one negative mode, log-uniform positive spectrum, noisy preconditioner."""
+    rng = np.random.RandomState(seed)
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    lam = np.exp(rng.uniform(np.log(0.05), np.log(50.0), n))
+    lam[0] = -1.0
+    A = (Q * lam) @ Q.T
+    A = 0.5 * (A + A.T)
+    N = rng.normal(size=(n, n))
+    P = A + eps * 0.5 * (N + N.T)
+    g = rng.normal(size=n)
+    return A, P, g
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--n', type=int, default=3072)
+    ap.add_argument('--maxiter', type=int, default=40)
+    ap.add_argument('--gamma', type=float, default=0.1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+
+    from sella_amd.device import Context
+    ctx = Context(local_rank)
+    n = args.n
+    A, P, g = hessian_like(n, seed=rank)            # one independent replica per rank
+    dA = ctx.upload(A)
+    dP = ctx.upload(P)
+
+    def one_step():
+        w, V, Vt = ctx.eigh(dP)
+        lams, Vr, AVr, nmv = ctx.davidson(dA, n, g, args.gamma, method='jd0', maxiter=args.maxiter,
+                                          Pvecs=V, PvecsT=Vt, pevals=w)
+        V.free()
+        Vt.free()
+        return lams, Vr, AVr, nmv
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(args.steps):
+        lams, Vr, AVr, nmv = one_step()
+        iters += Vr.shape[1]
+    ctx.sync()
+    if dist is not None and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+
+    # Davidson loop alone (P's eigendecomposition kept from a previous optimizer phase)
+    w, V, Vt = ctx.eigh(dP)
+    ctx.sync()
+    t1 = time.perf_counter()
+    it2 = 0
+    for _ in range(args.steps):
+        _, Vr2, _, _ = ctx.davidson(dA, n, g, args.gamma, method='jd0', maxiter=args.maxiter,
+                                    Pvecs=V, PvecsT=Vt, pevals=w)
+        it2 += Vr2.shape[1]
+    ctx.sync()
+    t_loop = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    for _ in range(3):
+        w_, V_, Vt_ = ctx.eigh(dP)
+        V_.free()
+        Vt_.free()
+    ctx.sync()
+    t_eigh = (time.perf_counter() - t2) / 3
+
+    # parity evidence carried on the line: lowest Ritz pair vs LAPACK on the host
+    resid = float(np.linalg.norm(A @ Vr[:, 0] - lams[0] * Vr[:, 0]))
+    av_err = float(np.abs(AVr - A @ Vr).max())
+
+    # ---- roofline of the dominant kernel: instrumented pass (hipEvents on the library stream) ----
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(max(1, min(args.steps, 5))):
+        ctx.davidson(dA, n, g, args.gamma, method='jd0', maxiter=args.maxiter, Pvecs=V, PvecsT=Vt, pevals=w)
+    ctx.prof_enable(False)
+    pg = ctx.prof_get(0)
+    roof = None
+    if pg['launches'] > 0 and pg['ms'] > 0:
+        # only the n x n streams matter for the roofline; panel dots are tiny launches of the
+        # same kernel, so report bytes/time over all launches (dominated by the n x n ones)
+        achieved = pg['bytes'] / (pg['ms'] * 1e-3) / 1e9
+        roof = dict(bound='hbm', kernel='gemv_rows_kernel', achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                    unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    launches=pg['launches'], mean_us=round(1e3 * pg['ms'] / pg['launches'], 2),
+                    bytes_per_launch=round(pg['bytes'] / pg['launches']))
+
+    times = [elapsed]
+    total_iters = iters
+    if dist is not None:
+        dev = 'cuda' if torch.cuda.is_available() else 'cpu'
+        t = torch.tensor([elapsed, float(iters)], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)                 # RCCL all-gather of the per-replica results
+        times = [float(x[0]) for x in gathered]
+        total_iters = int(sum(float(x[1]) for x in gathered))
+    tmax = max(times)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle.sella_oracle as orc        # checker / baseline only (oracle/README.md)
+        threads = os.cpu_count()
+        try:
+            from threadpoolctl import threadpool_info
+            info = threadpool_info()
+            if info:
+                threads = info[0].get('num_threads', threads)
+        except Exception:
+            pass
+        tc = time.perf_counter()
+        lc, Vc, AVc = orc.rayleigh_ritz(A, args.gamma, P, v0=g, method='jd0', maxiter=args.maxiter)
+        tcpu = time.perf_counter() - tc
+        cpu = dict(value=round(Vc.shape[1] / tcpu, 4), unit='davidson_iter/s', cores=int(threads), kind='port',
+                   sample=f'1 call of oracle rayleigh_ritz (reference algorithm: dense LU per iteration), '
+                          f'n={n}, k={Vc.shape[1]} vectors, {tcpu:.1f} s',
+                   lam0_abs_diff_vs_hip=float(abs(lc[0] - lams[0])), k=int(Vc.shape[1]))
+
+    if rank == 0:
+        value = total_iters / tmax
+        line = {
+            'metric': 'Davidson iterations/s (3N=3072 synthetic Hessian, jd0, gamma=0.1, maxiter=40; '
+                      'whole rayleigh_ritz call incl. device eigh of the preconditioner)',
+            'value': round(value, 2), 'unit': 'davidson_iter/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * tmax / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': f'1024-atom-equivalent 3N={n} fp64 Davidson (BASELINE configs[1]), '
+                                   f'one independent replica per GPU', 'n': n, 'maxiter': args.maxiter,
+                       'gamma': args.gamma, 'method': 'jd0', 'vectors_per_call': int(Vr.shape[1])},
+            'davidson_loop_only_iter_per_s': round(it2 / t_loop, 1),
+            'eigh_ms': round(1e3 * t_eigh, 2),
+            'parity': {'lowest_ritz_value': float(lams[0]), 'ritz_residual_norm': resid, 'max_abs_AV_minus_A_V': av_err},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

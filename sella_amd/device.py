@@ -271,6 +271,33 @@ class Context:
         return dict(launches=n.value, ms=ms.value, bytes=b.value, flops=f.value)
 
 
+STEPPER_KINDS = {'qn': 0, 'rfo': 1, 'prfo': 2}
+
+
+class DeviceStepper:
+    """One (g, H, order) step-family instance evaluated in the eigenbasis of H
+    (sella_amd/csrc/stepper.hip).  V is (nout x m) with the eigenvectors (optionally already
+    multiplied by a projection basis) as columns, Vt its transpose; g has Vt.shape[1] entries."""
+
+    def __init__(self, ctx, kind, V, Vt, evals, g, order):
+        self.ctx = ctx
+        self.nout = V.shape[0]
+        self._keep = (V, Vt)
+        evals = as_f64(evals)
+        g = as_f64(g)
+        h = c_void_p()
+        check(_lib.lib().sella_stepper_create(ctx._h, STEPPER_KINDS[kind], V.handle, Vt.handle,
+                                              ptr(evals), ptr(g), len(evals), int(order), byref(h)))
+        self._h = h
+        self._fin = weakref.finalize(self, _lib.lib().sella_stepper_destroy, h)
+
+    def get_s(self, alpha):
+        s = np.empty(self.nout)
+        dsda = np.empty(self.nout)
+        check(_lib.lib().sella_stepper_get_s(self._h, float(alpha), ptr(s), ptr(dsda)))
+        return s, dsda
+
+
 _default = None
 
 

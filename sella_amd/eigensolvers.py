@@ -1,0 +1,110 @@
+"""Davidson / Rayleigh-Ritz partial diagonalisation — drop-in for sella/eigensolvers.py
+(`exact` :9-28, `rayleigh_ritz` :31-112; the correction methods of `expand` :115-153 are
+selected by the same `method` strings).  The whole loop runs inside libsella_hip
+(sella_amd/csrc/davidson.hip); only the operator A may call back into Python, because the
+finite-difference Hessian lives behind the calculator boundary.
+"""
+import numpy as np
+
+from .device import DeviceMatrix, get_context
+from .linalg import ApproximateHessian
+
+
+def _is_identity(P):
+    n = P.shape[0]
+    if P.shape != (n, n) or P[0, 0] != 1.0:
+        return False
+    return np.count_nonzero(P) == n and bool(np.all(P.diagonal() == 1.0))
+
+
+def _dense_from_operator(A, probes):
+    """B = sum_i p_i (A p_i)^T over the ROWS p_i of `probes`, symmetrised (eigensolvers.py:22-26)."""
+    n = A.shape[0]
+    B = np.zeros((n, n))
+    for i in range(n):
+        p = probes[i]
+        B += np.outer(p, np.asarray(A.dot(p)).ravel())
+    return 0.5 * (B + B.T)
+
+
+def exact(A, gamma=None, P=None):
+    """Full diagonalisation on the device; returns (lams, vecs, lams * vecs)."""
+    ctx = get_context()
+    if isinstance(A, DeviceMatrix):
+        dA, own = A, False
+    elif isinstance(A, np.ndarray):
+        dA, own = ctx.upload(A), True
+    else:
+        probes = np.eye(A.shape[0]) if P is None else exact(P)[1]
+        dA, own = ctx.upload(_dense_from_operator(A, probes)), True
+    lams, V, Vt = ctx.eigh(dA)
+    vecs = V.numpy()
+    V.free()
+    Vt.free()
+    if own:
+        dA.free()
+    return lams, vecs, lams[np.newaxis, :] * vecs
+
+
+def _preconditioner(P):
+    """-> dict(Pvecs, PvecsT, pevals, pscale), owned handles to free afterwards."""
+    ctx = get_context()
+    if P is None:
+        return dict(pscale=1.0), []
+    if isinstance(P, ApproximateHessian):
+        if P.B is None:
+            return dict(pscale=1.0), []
+        w, V, Vt = P.device_eig()
+        return dict(Pvecs=V, PvecsT=Vt, pevals=w), []
+    P = np.asarray(P, dtype=np.float64)
+    if _is_identity(P):
+        return dict(pscale=1.0), []
+    dP = ctx.upload(P)
+    w, V, Vt = ctx.eigh(dP)
+    dP.free()
+    return dict(Pvecs=V, PvecsT=Vt, pevals=w), [V, Vt]
+
+
+def rayleigh_ritz(A, gamma, P, B=None, v0=None, vref=None, vreftol=0.99,
+                  method='jd0', maxiter=None):
+    """Same contract as the reference: returns (lams, V, AV) with the columns of V rotated
+    into the Ritz basis.  `A` may be a numpy array, a DeviceMatrix or any object with
+    `.shape` and `.dot(v)` (e.g. NumericalHessian); `P` a numpy array or an
+    ApproximateHessian (whose cached device eigendecomposition is then reused)."""
+    n, _ = A.shape
+    if B is not None and not _is_identity(np.asarray(B)):
+        raise NotImplementedError('a non-identity metric B is not supported by the HIP path')
+    if maxiter is None:
+        maxiter = 2 * n + 1
+    if gamma <= 0:
+        return exact(A, gamma, P)
+
+    ctx = get_context()
+    pre, owned = _preconditioner(P)
+    try:
+        if v0 is not None:
+            start = np.asarray(v0, dtype=np.float64).reshape((n, -1))
+        else:
+            # leading eigenvectors of P span the start block (eigensolvers.py:46-50)
+            if 'Pvecs' in pre:
+                P_lams = pre['pevals']
+                nneg = max(1, int(np.sum(P_lams < 0)))
+                start = pre['PvecsT'].numpy()[:nneg].T
+            else:
+                start = np.eye(n)[:, :1]
+        own_A = False
+        if isinstance(A, np.ndarray):
+            op, own_A = ctx.upload(A), True
+        elif isinstance(A, DeviceMatrix):
+            op = A
+        else:
+            def op(v, _A=A):
+                return np.asarray(_A.dot(v)).ravel()
+        lams, V, AV, _ = ctx.davidson(op, n, np.ascontiguousarray(start), gamma, method=method,
+                                      maxiter=maxiter, vref=vref, vreftol=vreftol, **pre)
+        if own_A:
+            op.free()
+    finally:
+        for h in owned:
+            h.free()
+    return lams, V, AV

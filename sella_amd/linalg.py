@@ -1,0 +1,299 @@
+"""Operators of the hot path — drop-in for sella/linalg.py:14-353.
+
+  NumericalHessian   finite-difference Hessian-vector products through the calculator
+                     boundary (linalg.py:14-101); the projection products U v / U^T Av run on
+                     the device when the basis is large.
+  MatrixSum          operator sum (linalg.py:104-140)
+  ApproximateHessian owner of the n x n approximate Hessian B (linalg.py:143-353).  B lives in
+                     HBM (`_B_gpu`); its eigenvectors stay on the device both as columns and as
+                     rows, ready for the Davidson preconditioner, the TS-BFGS |B| term and the
+                     P-RFO step; numpy copies are produced lazily.
+"""
+import numpy as np
+from scipy.sparse.linalg import LinearOperator
+
+from .device import DeviceMatrix, get_context
+from .hessian_update import update_H
+
+_DEVICE_MIN = 64        # below this a projection basis is not worth a device round trip
+
+
+class NumericalHessian(LinearOperator):
+    dtype = np.dtype('float64')
+
+    def __init__(self, func, x0, g0, eta, threepoint=False, Uproj=None):
+        self.func = func
+        self.x0 = x0.copy()
+        self.g0 = g0.copy()
+        self.eta = eta
+        self.threepoint = threepoint
+        self.calls = 0
+        self.Uproj = Uproj
+        self.ntrue = len(self.x0)
+        if Uproj is not None:
+            ntrue, n = Uproj.shape
+            assert ntrue == self.ntrue
+        else:
+            n = self.ntrue
+        super().__init__(self.dtype, (n, n))
+        self.Vs = np.empty((self.ntrue, 0), dtype=self.dtype)
+        self.AVs = np.empty((self.ntrue, 0), dtype=self.dtype)
+        self._U_gpu = None
+        if Uproj is not None and min(Uproj.shape) >= _DEVICE_MIN:
+            self._U_gpu = get_context().upload(Uproj)
+
+    def _lift(self, v):
+        if self._U_gpu is not None:
+            return get_context().symm_mm(self._U_gpu, v)
+        return self.Uproj @ v
+
+    def _restrict(self, w):
+        if self._U_gpu is not None:
+            return get_context().tmatmul(self._U_gpu, w)
+        return self.Uproj.T @ w
+
+    def _matvec(self, v):
+        self.calls += 1
+        v = np.asarray(v, dtype=np.float64).ravel()
+        if self.Uproj is not None:
+            v = self._lift(v)
+        # canonical displacement direction (linalg.py:45-73): downhill, else towards the
+        # origin, else first significant component positive
+        vdotg = v @ self.g0
+        vdotx = v @ self.x0
+        sign = 1.
+        if abs(vdotg) > 1e-4:
+            sign = 2. * (vdotg < 0) - 1.
+        elif abs(vdotx) > 1e-4:
+            sign = 2. * (vdotx < 0) - 1.
+        else:
+            big = np.flatnonzero(np.abs(v) > 1e-4)
+            if big.size:
+                sign = 1. if v[big[0]] > 0 else -1.
+        vnorm = np.linalg.norm(v)
+        if vnorm < 1e-12:
+            return np.zeros(self.shape[0])
+        vnorm *= sign
+        _, gplus = self.func(self.x0 + self.eta * v / vnorm)
+        if self.threepoint:
+            _, gminus = self.func(self.x0 - self.eta * v / vnorm)
+            Av = vnorm * (gplus - gminus) / (2 * self.eta)
+        else:
+            Av = vnorm * (gplus - self.g0) / self.eta
+        self.Vs = np.hstack((self.Vs, v.reshape((self.ntrue, -1))))
+        self.AVs = np.hstack((self.AVs, Av.reshape((self.ntrue, -1))))
+        if self.Uproj is not None:
+            Av = self._restrict(Av)
+        return Av
+
+    def __add__(self, other):
+        return MatrixSum(self, other)
+
+    def _transpose(self):
+        return self
+
+
+class MatrixSum(LinearOperator):
+    def __init__(self, *matrices):
+        dtype = sorted([mat.dtype for mat in matrices], reverse=True)[0]
+        super().__init__(dtype, matrices[0].shape)
+        dense = None
+        self.matrices = []
+        for matrix in matrices:
+            assert matrix.shape == self.shape, (matrix.shape, self.shape)
+            if isinstance(matrix, np.ndarray):
+                dense = matrix.astype(self.dtype) if dense is None else dense + matrix
+            else:
+                self.matrices.append(matrix)
+        if dense is not None:
+            self.matrices.append(dense)
+
+    def _matvec(self, v):
+        w = np.zeros(self.shape[0], dtype=self.dtype)
+        for matrix in self.matrices:
+            w += np.asarray(matrix.dot(v)).ravel()
+        return w
+
+    def _transpose(self):
+        return MatrixSum(*[mat.T for mat in self.matrices])
+
+    def __add__(self, other):
+        return MatrixSum(*self.matrices, other)
+
+
+class ApproximateHessian(LinearOperator):
+    def __init__(self, dim, ncart, B0=None, update_method='TS-BFGS', symm=2,
+                 initialized=False):
+        self.dim = dim
+        self.ncart = ncart
+        super().__init__(np.float64, (dim, dim))
+        self.update_method = update_method
+        self.symm = symm
+        self.initialized = initialized
+        self._B = None             # numpy copy (None while stale)
+        self._B_gpu = None         # DeviceMatrix (None while not uploaded)
+        self._is_none = True
+        self._drop_eig()
+        self.set_B(B0)
+
+    # ---- storage -------------------------------------------------------------------------
+    def _drop_eig(self):
+        self._evals = None
+        self._evecs = None
+        for name in ('_evecs_gpu', '_evecsT_gpu'):
+            old = getattr(self, name, None)
+            if old is not None:
+                old.free()
+            setattr(self, name, None)
+        self._evals_gpu = None
+
+    @property
+    def B(self):
+        if self._is_none:
+            return None
+        if self._B is None:
+            self._B = self._B_gpu.numpy()
+        return self._B
+
+    @B.setter
+    def B(self, value):
+        self.set_B(value)
+
+    def _get_B_gpu(self):
+        """Device mirror of B, uploaded lazily (linalg.py:197-207)."""
+        if self._is_none:
+            return None
+        if self._B_gpu is None:
+            self._B_gpu = get_context().upload(self._B)
+        return self._B_gpu
+
+    def set_B(self, target):
+        self._drop_eig()
+        if self._B_gpu is not None:
+            self._B_gpu.free()
+        self._B_gpu = None
+        if target is None:
+            self._B = None
+            self._is_none = True
+            self.initialized = False
+            return
+        if isinstance(target, DeviceMatrix):
+            assert target.shape == self.shape
+            self._B, self._B_gpu = None, target
+            self.initialized = True
+        else:
+            if np.isscalar(target):
+                target = target * np.eye(self.dim)
+            else:
+                self.initialized = True
+            target = np.asarray(target, dtype=np.float64)
+            assert target.shape == self.shape
+            self._B = target
+        self._is_none = False
+
+    # ---- eigendecomposition (lazy, device-resident) -------------------------------------------
+    def _ensure_eigen_computed(self):
+        if self._evals is not None or self._is_none:
+            return
+        w, V, Vt = get_context().eigh(self._get_B_gpu())
+        self._evals = w
+        self._evals_gpu = w
+        self._evecs_gpu = V
+        self._evecsT_gpu = Vt
+
+    @property
+    def evals(self):
+        self._ensure_eigen_computed()
+        return self._evals
+
+    @evals.setter
+    def evals(self, value):
+        self._evals = value
+
+    @property
+    def evecs(self):
+        self._ensure_eigen_computed()
+        if self._evecs is None and self._evecs_gpu is not None:
+            self._evecs = self._evecs_gpu.numpy()
+        return self._evecs
+
+    @evecs.setter
+    def evecs(self, value):
+        self._evecs = value
+
+    def device_eig(self):
+        """(evals numpy, evecs DeviceMatrix [columns], evecsT DeviceMatrix [rows]) or None."""
+        self._ensure_eigen_computed()
+        if self._evals is None:
+            return None
+        return self._evals, self._evecs_gpu, self._evecsT_gpu
+
+    # ---- quasi-Newton update ----------------------------------------------------------------
+    def update(self, dx, dg):
+        """Perform a quasi-Newton update on B (linalg.py:274-304)."""
+        if not self.initialized:
+            self.initialized = True
+            nc = self.ncart
+            B = np.zeros(self.shape) if self._is_none else self.B.copy()
+            B[:nc, :nc] = update_H(None, dx[:nc], dg[:nc], method=self.update_method,
+                                   symm=self.symm)
+            self.set_B(B)
+            return
+        if np.ndim(dx) == 1 and np.linalg.norm(dx) < 1e-8:
+            return                                           # update_H returns B itself
+        eig = self.device_eig() if self.update_method in ('TS-BFGS', 'BFGS_auto') else None
+        dB = self._get_B_gpu()
+        kw = {}
+        if eig is not None:
+            kw = dict(evals_gpu=eig[0], evecs_gpu=eig[1], evecsT_gpu=eig[2])
+        # (B itself is only inspected for None-ness when a device mirror is supplied)
+        update_H(False, dx, dg, method=self.update_method, symm=self.symm, B_gpu=dB,
+                 download=False, **kw)
+        # the device matrix was updated in place: host copy and eigenpairs are stale
+        self._B = None
+        self._drop_eig()
+        self.initialized = True
+
+    def project(self, U):
+        """Project B into the subspace spanned by the columns of U (linalg.py:306-317)."""
+        m, n = U.shape
+        assert m == self.dim
+        if self._is_none:
+            Bproj = None
+        else:
+            Bproj = get_context().project(self._get_B_gpu(), U)
+        return ApproximateHessian(n, 0, Bproj, self.update_method, self.symm)
+
+    def asarray(self):
+        if not self._is_none:
+            return self.B
+        return np.eye(self.dim)
+
+    def _matvec(self, v):
+        if self._is_none:
+            return v
+        return get_context().symm_mm(self._get_B_gpu(), np.asarray(v, dtype=np.float64).ravel())
+
+    def _rmatvec(self, v):
+        return self.matvec(v)
+
+    def _matmat(self, X):
+        if self._is_none:
+            return X
+        return get_context().symm_mm(self._get_B_gpu(), X)
+
+    def _rmatmat(self, X):
+        return self.matmat(X)
+
+    def __add__(self, other):
+        initialized = self.initialized
+        if isinstance(other, ApproximateHessian):
+            initialized = initialized and other.initialized
+            other = other.B
+        if not self.initialized or other is None:
+            tot = None
+            initialized = False
+        else:
+            tot = self.B + other
+        return ApproximateHessian(self.dim, self.ncart, tot, self.update_method, self.symm,
+                                  initialized=initialized)

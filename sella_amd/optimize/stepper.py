@@ -1,0 +1,123 @@
+"""Step families — drop-in for sella/optimize/stepper.py:20-199 (same class names, synonyms,
+alpha ranges and `get_s(alpha) -> (s, dsda)` contract).
+
+MI355X formulation: every family is evaluated in the eigenbasis of the (projected) approximate
+Hessian that `ApproximateHessian` keeps on the device.  RFO / P-RFO therefore never form or
+diagonalise the (m+1) x (m+1) augmented matrix the reference rebuilds for every trial alpha
+(stepper.py:128-131): it is a bordered diagonal matrix there, solved by a secular equation in
+O(m) (sella_amd/csrc/stepper.hip), followed by one 2-right-hand-side device matvec.
+
+Extension: `U` (optional, numpy (n, m)) — an orthonormal basis the Hessian was projected with.
+When given, `g` is the unprojected gradient and `get_s` returns vectors in the unprojected
+space (U @ s, U @ dsda), saving the caller two n x m host products per trial alpha.
+"""
+from typing import List, Optional, Tuple, Type
+
+import numpy as np
+
+from ..device import DeviceStepper, get_context
+from ..linalg import ApproximateHessian
+
+
+class BaseStepper:
+    alpha0: Optional[float] = None
+    alphamin: Optional[float] = None
+    alphamax: Optional[float] = None
+    slope: Optional[float] = None          # sign of d|s|/dalpha
+    newton_safe: bool = True
+    synonyms: List[str] = []
+    _kind: Optional[str] = None
+
+    def __init__(self, g: np.ndarray, H: ApproximateHessian, order: int = 0,
+                 d1: Optional[np.ndarray] = None, U: Optional[np.ndarray] = None) -> None:
+        self.g = g
+        self.H = H
+        self.order = order
+        self.d1 = d1
+        self.U = U
+        self._stepper_init()
+
+    @classmethod
+    def match(cls, name: str) -> bool:
+        return name in cls.synonyms
+
+    def _device_eig(self):
+        """(evals, V, Vt) of H on the device; an uninitialised H is the identity
+        (stepper.py:62-64 falls back to eigh(H.asarray()))."""
+        ctx = get_context()
+        eig = self.H.device_eig()
+        if eig is None:
+            m = self.H.shape[0]
+            V = ctx.upload(np.eye(m))
+            return np.ones(m), V, V.transpose()
+        return eig
+
+    def _stepper_init(self) -> None:
+        ctx = get_context()
+        evals, V, Vt = self._device_eig()
+        if self.U is not None:
+            # compose the projection with the eigenbasis once: (U V) is n x m
+            dU = ctx.upload(self.U)
+            VU = ctx.zeros(self.U.shape[0], V.shape[1])
+            ctx.gemm(dU, V, VU)
+            dU.free()
+            V, Vt = VU, VU.transpose()
+        self._dev = DeviceStepper(ctx, self._kind, V, Vt, evals, self.g, self.order)
+
+    def get_s(self, alpha: float) -> Tuple[np.ndarray, np.ndarray]:
+        return self._dev.get_s(alpha)
+
+
+class NaiveStepper(BaseStepper):
+    synonyms = []
+    alpha0 = 0.5
+    alphamin = 0.
+    alphamax = 1.
+    slope = 1.
+
+    def __init__(self, dx: np.ndarray) -> None:
+        self.dx = dx
+
+    def get_s(self, alpha: float) -> Tuple[np.ndarray, np.ndarray]:
+        return alpha * self.dx, self.dx
+
+
+class QuasiNewton(BaseStepper):
+    alpha0 = 0.
+    alphamin = 0.
+    alphamax = np.inf
+    slope = -1
+    _kind = 'qn'
+    synonyms = [
+        'qn', 'quasi-newton', 'quasi newton', 'quasi-newton', 'newton', 'mmf',
+        'minimum mode following', 'minimum-mode following', 'dimer',
+    ]
+
+
+class RationalFunctionOptimization(BaseStepper):
+    alpha0 = 1.
+    alphamin = 0.
+    alphamax = 1.
+    slope = 1.
+    newton_safe = False
+    _kind = 'rfo'
+    synonyms = ['rfo', 'rational function optimization']
+
+
+class PartitionedRationalFunctionOptimization(RationalFunctionOptimization):
+    _kind = 'prfo'
+    synonyms = ['prfo', 'p-rfo', 'partitioned rational function optimization']
+
+
+_all_steppers = [
+    QuasiNewton,
+    RationalFunctionOptimization,
+    PartitionedRationalFunctionOptimization,
+]
+
+
+def get_stepper(name: str) -> Type[BaseStepper]:
+    for stepper in _all_steppers:
+        if stepper.match(name):
+            return stepper
+    raise ValueError("Unknown stepper name: {}".format(name))

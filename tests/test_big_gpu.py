@@ -1,0 +1,110 @@
+"""Full-size checks on the MI355X (BASELINE.json sizes): parity against the scalar digests the
+real reference produced at n = 300 / 768 / 3072 (tests/golden/big_digests.json, matrices are
+regenerated from the seeded recipe), plus size-independent properties at 3N = 3072."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, hessian_like
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def digests():
+    with open(os.path.join(GOLD, 'big_digests.json')) as f:
+        return json.load(f)
+
+
+def ritz_of_span(A, V):
+    Q, _ = np.linalg.qr(V)
+    return np.linalg.eigvalsh(Q.T @ A @ Q)
+
+
+@pytest.mark.parametrize('n', [300, 768, 3072])
+def test_davidson_digest(ctx, digests, n):
+    if ctx.backend != 'hip':
+        pytest.skip('hardware only')
+    from sella_amd.eigensolvers import rayleigh_ritz
+    d = digests[str(n)]
+    A, P, g = hessian_like(n, 0, eps=5e-3)
+    lams, V, AV = rayleigh_ritz(A, 0.1, P, v0=g, method='jd0', maxiter=40)
+    assert V.shape[1] == d['k']
+    # north_star tolerance: eigenpairs within 1e-10 of the reference
+    assert abs(lams[0] - d['lams'][0]) < 1e-10 * max(1, abs(d['lams'][0]))
+    np.testing.assert_allclose(lams, d['lams'], atol=1e-8)
+    np.testing.assert_allclose(AV, A @ V, atol=1e-10)
+    np.testing.assert_allclose(V.T @ V, np.eye(V.shape[1]), atol=1e-12)
+    # per-iteration parity: lowest Ritz value of the growing Krylov space (variational)
+    np.testing.assert_allclose(ritz_of_span(A, V)[0], d['ritz'][-1], atol=1e-9)
+    # the projection of a fixed probe vector on the final Krylov space is basis-independent
+    probe = np.cos(np.arange(n) * 0.37)
+    ref_proj = np.linalg.norm(np.array(d['t_probe']))       # T is orthonormal: |T^T probe|
+    assert abs(np.linalg.norm(V.T @ probe) - ref_proj) < 1e-7 * max(1.0, ref_proj)
+
+
+@pytest.mark.parametrize('n', [300, 768, 3072])
+def test_update_digest(ctx, digests, n):
+    if ctx.backend != 'hip':
+        pytest.skip('hardware only')
+    from sella_amd.linalg import ApproximateHessian
+    d = digests[str(n)]
+    A, P, g = hessian_like(n, 0, eps=5e-3)
+    H = ApproximateHessian(n, n, P)
+    S = np.random.RandomState(1).normal(size=(n, 3))
+    Y = A @ S
+    H.update(S, Y)
+    B = H.B
+    assert abs(np.linalg.norm(B) - d['update_fro']) < 1e-9 * d['update_fro']
+    assert abs(np.trace(B) - d['update_trace']) < 1e-9 * abs(d['update_trace'])
+    # secant condition (tests/test_hessian_update.py:33-37) and exact symmetry
+    np.testing.assert_allclose(B @ S, Y, atol=1e-8 * np.abs(Y).max())
+    np.testing.assert_array_equal(B, B.T)
+
+
+@pytest.mark.parametrize('n', [300, 768])
+def test_prfo_digest(ctx, digests, n):
+    if ctx.backend != 'hip':
+        pytest.skip('hardware only')
+    from helpers import FakePES
+    from sella_amd.linalg import ApproximateHessian
+    from sella_amd.optimize.restricted_step import get_restricted_step
+    d = digests[str(n)]
+    A, P, g = hessian_like(n, 0, eps=5e-3)
+    s, smag = get_restricted_step('tr')(FakePES(ApproximateHessian, P, g, 0, seed=0), 1, 0.1, 'prfo').get_s()
+    probe = np.cos(np.arange(n) * 0.37)
+    assert abs(np.linalg.norm(s) - d['prfo_tr_s_norm']) < 1e-10
+    assert abs(probe @ s - d['prfo_tr_s_probe']) < 1e-9
+
+
+def test_eigh_properties_3072(ctx):
+    if ctx.backend != 'hip':
+        pytest.skip('hardware only')
+    n = 3072
+    A, P, g = hessian_like(n, 1)
+    dP = ctx.upload(P)
+    w, V, Vt = ctx.eigh(dP)
+    Vn = V.numpy()
+    assert np.all(np.diff(w) >= 0)
+    np.testing.assert_allclose(w, np.linalg.eigvalsh(P), atol=1e-10)
+    assert np.abs(P @ Vn - Vn * w).max() < 1e-10
+    assert np.abs(Vn.T @ Vn - np.eye(n)).max() < 1e-11
+    # trace / Frobenius invariants (size-independent checks)
+    assert abs(w.sum() - np.trace(P)) < 1e-8
+    assert abs(np.sqrt((w ** 2).sum()) - np.linalg.norm(P)) < 1e-8
+
+
+def test_matvec_linearity_3072(ctx):
+    if ctx.backend != 'hip':
+        pytest.skip('hardware only')
+    n = 3072
+    rng = np.random.RandomState(5)
+    A = rng.normal(size=(n, n))
+    dA = ctx.upload(A)
+    x, y = rng.normal(size=n), rng.normal(size=n)
+    lhs = ctx.symm_mm(dA, 2.0 * x - 3.0 * y)
+    rhs = 2.0 * ctx.symm_mm(dA, x) - 3.0 * ctx.symm_mm(dA, y)
+    np.testing.assert_allclose(lhs, rhs, atol=1e-9)
+    np.testing.assert_allclose(ctx.symm_mm(dA, x), A @ x, atol=1e-9)

@@ -1,0 +1,89 @@
+"""Streaming kernels through the C ABI against numpy (the oracle for a matvec is the matvec):
+row-panel matvec for every right-hand-side count and rows-per-wave variant, transposed product,
+fp64 GEMM (MFMA and VALU tiles, all transpose combinations, ragged shapes), projection."""
+import numpy as np
+import pytest
+
+
+def sizes(ctx):
+    return [(37, 1), (64, 2), (130, 3), (200, 8), (70, 11)] if ctx.backend == 'emu' else \
+        [(37, 1), (64, 2), (130, 3), (1000, 8), (3072, 1), (3072, 2), (777, 11), (4099, 2)]
+
+
+def test_symm_mm(ctx):
+    rng = np.random.RandomState(0)
+    for n, k in sizes(ctx):
+        A = rng.normal(size=(n, n))
+        X = rng.normal(size=(n, k))
+        dA = ctx.upload(A)
+        ref = A @ X
+        for rw in (1, 2, 4):
+            ctx.set_option('gemv_rw', rw)
+            np.testing.assert_allclose(ctx.symm_mm(dA, X), ref, atol=1e-13 * n * np.abs(ref).max())
+        np.testing.assert_allclose(ctx.symm_mm(dA, X[:, 0]), ref[:, 0], atol=1e-13 * n * np.abs(ref).max())
+        np.testing.assert_array_equal(dA.numpy(), A)
+        np.testing.assert_array_equal(dA.transpose().numpy(), A.T)
+        dA.free()
+    ctx.set_option('gemv_rw', 2)
+
+
+def test_rectangular_and_transposed_products(ctx):
+    rng = np.random.RandomState(1)
+    for rows, cols, k in [(50, 83, 2), (83, 50, 3), (1, 40, 1), (300, 7, 5)]:
+        A = rng.normal(size=(rows, cols))
+        dA = ctx.upload(A)
+        X = rng.normal(size=(cols, k))
+        Z = rng.normal(size=(rows, k))
+        np.testing.assert_allclose(ctx.symm_mm(dA, X), A @ X, atol=1e-12)
+        np.testing.assert_allclose(ctx.tmatmul(dA, Z), A.T @ Z, atol=1e-12)
+
+
+@pytest.mark.parametrize('mfma', [0, 1])
+def test_gemm(ctx, mfma):
+    rng = np.random.RandomState(2)
+    ctx.set_option('gemm_mfma', mfma)
+    shapes = [(64, 64, 16), (70, 45, 33), (130, 64, 100), (5, 3, 2)]
+    if ctx.backend == 'hip':
+        shapes += [(512, 384, 256), (1000, 1000, 64), (33, 2000, 1500)]
+    for M, N, K in shapes:
+        for tA in (0, 1):
+            for tB in (0, 1):
+                a = rng.normal(size=(K, M) if tA else (M, K))
+                b = rng.normal(size=(N, K) if tB else (K, N))
+                c0 = rng.normal(size=(M, N))
+                dC = ctx.upload(c0)
+                ctx.gemm(ctx.upload(a), ctx.upload(b), dC, tA, tB, 0.7, 0.3)
+                ref = 0.7 * (a.T if tA else a) @ (b.T if tB else b) + 0.3 * c0
+                np.testing.assert_allclose(dC.numpy(), ref, atol=1e-13 * K * max(1, np.abs(ref).max()))
+    ctx.set_option('gemm_mfma', 1)
+
+
+def test_gemm_identity_with_asymmetric_operand(ctx):
+    """A = I against an asymmetric B catches a transposed accumulator layout."""
+    n = 48
+    B = np.arange(n * n, dtype=float).reshape(n, n)
+    dC = ctx.zeros(n, n)
+    ctx.gemm(ctx.upload(np.eye(n)), ctx.upload(B), dC)
+    np.testing.assert_array_equal(dC.numpy(), B)
+
+
+def test_project(ctx):
+    rng = np.random.RandomState(3)
+    n, m = (90, 17) if ctx.backend == 'emu' else (1500, 400)
+    H = rng.normal(size=(n, n))
+    H = H + H.T
+    U = np.linalg.qr(rng.normal(size=(n, m)))[0]
+    ref = U.T @ H @ U
+    np.testing.assert_allclose(ctx.project(ctx.upload(H), U), ref, atol=1e-12 * n)
+
+
+def test_error_reporting(ctx):
+    from sella_amd._lib import SellaHipError
+    dA = ctx.upload(np.eye(4))
+    with pytest.raises(ValueError):
+        ctx.symm_mm(dA, np.zeros(5))
+    dA.free()
+    with pytest.raises(SellaHipError):
+        dA.numpy()
+    with pytest.raises(SellaHipError):
+        ctx.set_option('no_such_option', 1)

@@ -1,0 +1,145 @@
+"""Davidson / Rayleigh-Ritz on the device.
+
+* golden parity: every case of tests/golden/g1_davidson.npz (generated from the real reference)
+  — subspace size, Ritz values, Ritz vectors up to sign, and AV = A V;
+* the reference's own property tests (tests/test_eigensolvers.py:11-71) re-stated on
+  sella_amd.eigensolvers with the finite-difference operator as a host callback."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from helpers import colsign, get_matrix, poly_factory
+
+STRICT = ('jd0', 'jd0_alt', 'lanczos')
+
+
+def run_case(ctx, g, case):
+    i = case['id']
+    A, P, n = g[f'c{i}_A'], g[f'c{i}_P'], case['n']
+    maxiter = None if case['maxiter'] < 0 else case['maxiter']
+    dA = ctx.upload(A)
+    kw = {}
+    w = Q = None
+    if case['P'] != 'eye':
+        w, Q = np.linalg.eigh(P)          # inputs of the kernel under test, not its result
+        kw = dict(Pvecs=ctx.upload(Q), PvecsT=ctx.upload(Q.T.copy()), pevals=w)
+    if case['start'] == 'v0':
+        v0 = g[f'c{i}_v0']
+    else:
+        v0 = Q[:, :max(1, int((w < 0).sum()))]
+    lams, V, AV, nmv = ctx.davidson(dA, n, v0, case['gamma'], method=case['method'],
+                                    maxiter=maxiter, **kw)
+    rl, rV = g[f'c{i}_lams'], g[f'c{i}_V']
+    assert V.shape == rV.shape, (case, V.shape, rV.shape)
+    strict = case['method'] in STRICT
+    # Krylov processes amplify roundoff; bounds scale with the oracle-vs-reference deviation
+    # recorded when the goldens were generated (manifest dev_*), floor = north_star's 1e-10
+    assert abs(lams[0] - rl[0]) <= max(1e-10 if strict else 1e-8, 50 * case['dev_lam0'])
+    assert np.abs(lams - rl).max() <= max(1e-8 if strict else 1e-5, 100 * case['dev_lams'])
+    assert np.abs(colsign(V, rV) - rV).max() <= max(1e-7 if strict else 1e-4, 100 * case['dev_V'])
+    np.testing.assert_allclose(AV, A @ V, atol=1e-11)
+    np.testing.assert_allclose(V.T @ V, np.eye(V.shape[1]), atol=1e-12)
+    assert nmv == V.shape[1]
+
+
+def test_golden_davidson(ctx, manifest):
+    g = load_golden('g1_davidson')
+    cases = manifest['g1_davidson']
+    if ctx.backend == 'emu':          # the emulator is slow: default method in full, one of each other
+        cases = [c for c in cases if c['method'] == 'jd0' or (c['P'] == 'noisy' and c['gamma'] == 1e-32)
+                 or (c['start'] == 'P')]
+    for case in cases:
+        run_case(ctx, g, case)
+
+
+def test_golden_expand_through_one_iteration(ctx, manifest):
+    """One correction vector per method (g2_expand): drive the device loop for exactly one
+    expansion from the golden Ritz basis and compare span(V, t)."""
+    g = load_golden('g2_expand')
+    for case in manifest['g2_expand']:
+        if case['seeking'] != 0:
+            continue
+        i = case['id']
+        V, P, lams, t = g[f'c{i}_V'], g[f'c{i}_P'], g[f'c{i}_lams'], g[f'c{i}_t']
+        n, k = V.shape
+        # a symmetric operator whose action on span(V) is the golden Y
+        Y = g[f'c{i}_Y']
+        w, Q = np.linalg.eigh(P)
+        A = Y @ V.T + V @ Y.T - V @ (V.T @ Y) @ V.T
+        lam_dev, Vd, AVd, _ = ctx.davidson(ctx.upload(A), n, V, 1e-32, method=case['method'],
+                                            maxiter=k + 1, Pvecs=ctx.upload(Q),
+                                            PvecsT=ctx.upload(Q.T.copy()), pevals=w)
+        assert Vd.shape[1] == k + 1
+        # the new direction must be the golden t orthogonalised against V
+        tperp = t - V @ (V.T @ t)
+        tperp /= np.linalg.norm(tperp)
+        resid = tperp - Vd @ (Vd.T @ tperp)
+        assert np.linalg.norm(resid) < 1e-8, case
+
+
+@pytest.mark.parametrize("dim,order,eta,threepoint", [(10, 4, 1e-6, True), (10, 4, 1e-6, False)])
+def test_exact(ctx, dim, order, eta, threepoint):
+    from sella_amd.eigensolvers import exact
+    from sella_amd.linalg import NumericalHessian
+    rng = np.random.RandomState(1)
+    tol = dict(atol=1e-4, rtol=eta ** 2)
+    poly = poly_factory(dim, order, rng=rng)
+    x = rng.normal(size=dim)
+    _, g, h = poly(x)
+    H = NumericalHessian(lambda x: poly(x)[:2], g0=g, x0=x, eta=eta, threepoint=threepoint)
+    l1, V1, AV1 = exact(h)
+    l2, V2, AV2 = exact(H)
+    np.testing.assert_allclose(l1, l2, **tol)
+    np.testing.assert_allclose(np.abs(V1.T @ V2), np.eye(dim), **tol)
+    np.testing.assert_allclose(h @ V1, AV1, **tol)
+    np.testing.assert_allclose(h @ V2, AV2, **tol)
+    P = h + get_matrix(dim, dim, rng=rng) * 1e-3
+    l3, V3, AV3 = exact(H, P=P)
+    np.testing.assert_allclose(l1, l3, **tol)
+
+
+@pytest.mark.parametrize("dim,order,eta,threepoint,gamma,method,maxiter",
+                         [(10, 4, 1e-6, False, 0., 'jd0', None),
+                          (10, 4, 1e-6, False, 1e-32, 'jd0', 3),
+                          (10, 4, 1e-6, True, 1e-1, 'jd0', None),
+                          (10, 4, 1e-6, False, 1e-1, 'jd0', None),
+                          (10, 4, 1e-6, False, 1e-1, 'lanczos', None),
+                          (10, 4, 1e-6, False, 1e-1, 'gd', None),
+                          (10, 4, 1e-6, False, 1e-1, 'jd0_alt', None),
+                          (10, 4, 1e-6, False, 1e-1, 'mjd0_alt', None),
+                          (10, 4, 1e-6, False, 1e-1, 'mjd0', None)])
+def test_rayleigh_ritz(ctx, dim, order, eta, threepoint, gamma, method, maxiter):
+    from sella_amd.eigensolvers import rayleigh_ritz
+    from sella_amd.linalg import NumericalHessian
+    rng = np.random.RandomState(1)
+    tol = dict(atol=1e-4, rtol=eta ** 2)
+    poly = poly_factory(dim, order, rng=rng)
+    x = rng.normal(size=dim)
+    _, g, h = poly(x)
+    H = NumericalHessian(lambda x: poly(x)[:2], g0=g, x0=x, eta=eta, threepoint=threepoint)
+    l1, V1, AV1 = rayleigh_ritz(H, gamma, np.eye(dim), method=method, maxiter=maxiter)
+    np.testing.assert_allclose(l1, np.linalg.eigh(V1.T @ AV1)[0], **tol)
+    v0 = rng.normal(size=dim)
+    rayleigh_ritz(H, gamma, np.eye(dim), method=method, v0=v0, maxiter=maxiter,
+                  vref=np.linalg.eigh(h)[1][:, 0])
+
+
+def test_unknown_method_and_metric(ctx):
+    from sella_amd.eigensolvers import rayleigh_ritz
+    A = np.diag(np.arange(1., 9.))
+    with pytest.raises(ValueError):
+        rayleigh_ritz(A, 0.1, np.eye(8), v0=np.ones(8), method='nope')
+    with pytest.raises(NotImplementedError):
+        rayleigh_ritz(A, 0.1, np.eye(8), B=2 * np.eye(8), v0=np.ones(8))
+
+
+def test_callback_failure_propagates(ctx):
+    from sella_amd.eigensolvers import rayleigh_ritz
+
+    class Boom:
+        shape = (8, 8)
+
+        def dot(self, v):
+            raise RuntimeError('calculator failed')
+    with pytest.raises(RuntimeError, match='calculator failed'):
+        rayleigh_ritz(Boom(), 0.1, np.eye(8), v0=np.ones(8))

@@ -1,0 +1,89 @@
+"""Quasi-Newton updates on the device: the reference's secant-condition tests
+(tests/test_hessian_update.py:9-45) re-stated on sella_amd.hessian_update, plus golden parity
+against the real reference for every method / B kind / k / symm (g4, g5)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from helpers import get_matrix
+
+
+@pytest.mark.parametrize("dim,subdim,method,symm, pd",
+                         [(10, 1, 'TS-BFGS', 2, False),
+                          (10, 2, 'TS-BFGS', 0, False),
+                          (10, 2, 'TS-BFGS', 1, False),
+                          (10, 2, 'TS-BFGS', 2, False),
+                          (10, 2, 'BFGS', 2, False),
+                          (10, 2, 'PSB', 2, False),
+                          (10, 2, 'DFP', 2, False),
+                          (10, 2, 'SR1', 2, False),
+                          (10, 2, 'Greenstadt', 2, False),
+                          (10, 2, 'BFGS_auto', 2, False),
+                          (10, 2, 'BFGS_auto', 2, True)])
+def test_update_H(ctx, dim, subdim, method, symm, pd):
+    from sella_amd.hessian_update import update_H
+    rng = np.random.RandomState(1)
+    tol = dict(atol=1e-6, rtol=1e-6)
+    B = get_matrix(dim, dim, pd, True, rng=rng)
+    H = get_matrix(dim, dim, pd, True, rng=rng)
+    S = get_matrix(dim, subdim, rng=rng)
+    Y = H @ S
+    B1 = update_H(None, S, Y, method=method, symm=symm)
+    np.testing.assert_allclose(B1 @ S, Y, **tol)
+    B2 = update_H(B, S, Y, method=method, symm=symm)
+    np.testing.assert_allclose(B2 @ S, Y, **tol)
+    np.testing.assert_array_equal(B2, B2.T)
+    if subdim == 1:
+        B3 = update_H(B, S.ravel(), Y.ravel(), method=method, symm=symm)
+        np.testing.assert_allclose(B2, B3, **tol)
+        B4 = update_H(B, S.ravel() / 1e12, Y.ravel() / 1e12, method=method, symm=symm)
+        np.testing.assert_allclose(B, B4, atol=0, rtol=0)
+        assert B4 is B
+
+
+def test_unknown_method(ctx):
+    from sella_amd.hessian_update import update_H
+    with pytest.raises(ValueError):
+        update_H(np.eye(4), np.ones((4, 1)), np.ones((4, 1)), method='nope')
+
+
+def test_golden_symmetrize(ctx, manifest):
+    from sella_amd.hessian_update import symmetrize_Y
+    g = load_golden('g4_symmetrize')
+    for case in manifest['g4_symmetrize']:
+        i = case['id']
+        symm = None if case['symm'] < 0 else case['symm']
+        out = symmetrize_Y(g[f'c{i}_S'], g[f'c{i}_Y'], symm)
+        np.testing.assert_allclose(out, g[f'c{i}_out'], atol=1e-11, rtol=1e-11)
+
+
+def test_golden_update(ctx, manifest):
+    from sella_amd.hessian_update import update_H
+    g = load_golden('g5_update_h')
+    cases = manifest['g5_update_h']
+    if ctx.backend == 'emu':
+        cases = [c for c in cases if c['k'] != 8 or c['method'] in ('TS-BFGS', 'SR1')]
+    for case in cases:
+        i = case['id']
+        B = None if case['B'] == 'none' else g[f'c{i}_B']
+        out = update_H(B, g[f'c{i}_S'], g[f'c{i}_Y'], method=case['method'], symm=case['symm'])
+        ref = g[f'c{i}_out']
+        np.testing.assert_allclose(out, ref, atol=1e-10 * np.abs(ref).max(), rtol=0, err_msg=str(case))
+    out = update_H(g['oned_B'], g['oned_s'], g['oned_y'])
+    np.testing.assert_allclose(out, g['oned_out'], atol=1e-11)
+
+
+def test_device_resident_update_returns_handle(ctx):
+    """B_gpu branch (hessian_update.py:70-75): in-place on the device, (numpy, handle) returned."""
+    from sella_amd.hessian_update import update_H
+    rng = np.random.RandomState(7)
+    n = 24
+    B = get_matrix(n, n, False, True, rng=rng)
+    S = rng.normal(size=(n, 3))
+    Y = get_matrix(n, n, False, True, rng=rng) @ S
+    ref = update_H(B, S, Y)
+    dB = ctx.upload(B)
+    out, handle = update_H(B, S, Y, B_gpu=dB)
+    assert handle is dB
+    np.testing.assert_allclose(out, ref, atol=1e-12)
+    np.testing.assert_allclose(dB.numpy(), ref, atol=1e-12)

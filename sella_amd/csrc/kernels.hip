@@ -24,7 +24,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 // are staged through LDS in column tiles of GEMV_TC doubles so arbitrarily long rows work
 // with <= NRHS*16 KiB of LDS.  Algorithmic traffic: 8*rows*cols bytes (matrix read once).
 // ------------------------------------------------------------------------------------
-constexpr int GEMV_TC = 2048;
+// column tile per right-hand side: the LDS footprint stays at 32 KiB for any NRHS (>= 5 blocks per CU)
+constexpr int gemv_tc(int nrhs) { return nrhs <= 2 ? 2048 : (nrhs <= 4 ? 1024 : 512); }
 
 template <int NRHS, int RW>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ A, int rows,
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
                                                         double* __restrict__ Y, int ldy,
                                                         GemvEpi epi) {
     HIP_DYNAMIC_SHARED(double, xs)
+    constexpr int GEMV_TC = gemv_tc(NRHS);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int row0 = (blockIdx.x * 4 + wave) * RW;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
 template <int NRHS>
 static int gemv_rows_dispatch_rw(sella_ctx* c, int rw, const double* A, int rows, int cols, int lda,
                                  const double* X, int ldx, double* Y, int ldy, const GemvEpi& epi) {
-    const size_t shmem = (size_t)NRHS * GEMV_TC * sizeof(double);
+    const size_t shmem = (size_t)NRHS * gemv_tc(NRHS) * sizeof(double);
     if (rw == 4) {
         int grid = (rows + 15) / 16;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 4>), dim3(grid), dim3(256), shmem,

@@ -68,11 +68,17 @@ __global__ __launch_bounds__(256) void sym_rank2k_kernel(double* __restrict__ B,
         t1[k][tx] = v;
     }
     __syncthreads();
+    const bool diag = (blockIdx.x == blockIdx.y);
     for (int k = ty; k < 32; k += 8) {
         int r = r0 + k, cc = c0 + tx;
-        if (r < n && cc < n) B[(size_t)r * ld + cc] = t1[k][tx];
-        r = c0 + k; cc = r0 + tx;
-        if (r < n && cc < n) B[(size_t)r * ld + cc] = t1[tx][k];
+        // inside a diagonal tile both (k, tx) and (tx, k) are computed (in different summation
+        // orders): publish the upper-triangle value for both so B+ is exactly symmetric
+        const double v = (diag && k > tx) ? t1[tx][k] : t1[k][tx];
+        if (r < n && cc < n) B[(size_t)r * ld + cc] = v;
+        if (!diag) {
+            r = c0 + k; cc = r0 + tx;
+            if (r < n && cc < n) B[(size_t)r * ld + cc] = t1[tx][k];
+        }
     }
 }
 

@@ -179,28 +179,46 @@ __global__ __launch_bounds__(256) void rot_rows_kernel(double* __restrict__ Zb, 
     }
 }
 
-__global__ __launch_bounds__(64) void secular_kernel(int K, const double* __restrict__ D,
-                                                     const double* __restrict__ w, double rho,
-                                                     double* __restrict__ tau, int* __restrict__ org,
-                                                     double* __restrict__ lam, int* __restrict__ info) {
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= K) return;
+struct WaveSum {
+    __device__ double operator()(double v) const { return wave_sum_e(v); }
+};
+struct WaveProd {
+    __device__ double operator()(double v) const {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v *= __shfl_xor(v, m, 64);
+        return v;
+    }
+};
+
+// one WAVEFRONT per root: the 64 lanes split every O(K) sum of the iteration (K wavefronts in
+// flight instead of K/64), all lanes follow the same control flow on wave-reduced values
+__global__ __launch_bounds__(256) void secular_kernel(int K, const double* __restrict__ D,
+                                                      const double* __restrict__ w, double rho,
+                                                      double* __restrict__ tau, int* __restrict__ org,
+                                                      double* __restrict__ lam, int* __restrict__ info) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= K) return;            // whole wavefront leaves together
     int o;
     double t;
-    const int it = secular::solve_root(K, D, w, rho, j, &o, &t);
-    tau[j] = t;
-    org[j] = o;
-    lam[j] = D[o] + t;
-    if (it < 0) info[1] = j + 1;
+    const int it = secular::solve_root(K, D, w, rho, j, &o, &t, lane, 64, WaveSum());
+    if (lane == 0) {
+        tau[j] = t;
+        org[j] = o;
+        lam[j] = D[o] + t;
+        if (it < 0) info[1] = j + 1;
+    }
 }
 
-__global__ __launch_bounds__(64) void zhat_kernel(int K, const double* __restrict__ D,
-                                                  const double* __restrict__ w,
-                                                  const double* __restrict__ tau,
-                                                  const int* __restrict__ org, double* __restrict__ zh) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void zhat_kernel(int K, const double* __restrict__ D,
+                                                   const double* __restrict__ w,
+                                                   const double* __restrict__ tau,
+                                                   const int* __restrict__ org, double* __restrict__ zh) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i >= K) return;
-    zh[i] = secular::zhat(K, D, w, tau, org, i);
+    const double z = secular::zhat(K, D, w, tau, org, i, lane, 64, WaveProd());
+    if (lane == 0) zh[i] = z;
 }
 
 // Ut[j][i] = zhat_i / ((D_i - D_org_j) - tau_j), row j normalised
@@ -431,9 +449,9 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
                 int* orgd = W.ibuf + 16 + 2 * (int)leaves.size() + 16 + 3 * n;
                 HIPCHK(hipMemcpyAsync(Dd, Dn.data(), (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
                 HIPCHK(hipMemcpyAsync(wd, wn.data(), (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-                hipLaunchKernelGGL(secular_kernel, dim3((K + 63) / 64), dim3(64), 0, c->stream, K, Dd, wd, rho, taud,
+                hipLaunchKernelGGL(secular_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd, wd, rho, taud,
                                    orgd, lamd, info);
-                hipLaunchKernelGGL(zhat_kernel, dim3((K + 63) / 64), dim3(64), 0, c->stream, K, Dd, wd, taud, orgd, zhd);
+                hipLaunchKernelGGL(zhat_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd, wd, taud, orgd, zhd);
                 const int ldu = round_up(K, 8);
                 hipLaunchKernelGGL(build_u_kernel, dim3(K), dim3(256), 0, c->stream, K, Dd, zhd, taud, orgd, W.Ut, ldu);
                 HIPCHK(hipGetLastError());

@@ -2,5 +2,22 @@
 
 Host code is plain Python over a ctypes C ABI (include/sella_hip.h); all O(n^2)/O(n^3) work
 runs in hand-written HIP kernels for gfx950 (libsella_hip.so).  There is no CPU fallback.
+
+    from sella_amd import Sella, Constraints        # same entry points as `from sella import ...`
 """
 __version__ = '0.1.0'
+
+_LAZY = {
+    'Sella': ('sella_amd.optimize.optimize', 'Sella'),
+    'PES': ('sella_amd.peswrapper', 'PES'),
+    'Constraints': ('sella_amd.internal', 'Constraints'),
+    'Atoms': ('sella_amd.atoms', 'Atoms'),
+}
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+        mod, attr = _LAZY[name]
+        return getattr(importlib.import_module(mod), attr)
+    raise AttributeError(name)

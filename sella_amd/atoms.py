@@ -1,0 +1,232 @@
+"""Minimal stand-ins for the parts of ASE the path touches (ASE is not installable in the build
+image; when `ase` imports, its own classes are used instead and these are bypassed).
+
+  Atoms       positions / cell / pbc / calc, get_potential_energy(), get_forces()  — exactly the
+              attributes `PES` reads (sella/peswrapper.py:294-303,332-338,413-418)
+  Optimizer   the run()/irun()/log()/converged() loop `Sella` inherits from
+              ase.optimize.optimize.Optimizer (sella/optimize/optimize.py:10,177)
+  calculators on the far side of the calculator boundary, for tests and benchmarks:
+              QuadraticCubicModel (SURVEY.md §8d model PES), MorseCluster
+              (tests/integration/test_morse_cluster.py), PairLJ.
+"""
+import sys
+import time
+
+import numpy as np
+
+try:                                                        # pragma: no cover - depends on the host
+    from ase import Atoms as _AseAtoms                      # noqa: F401
+    from ase.optimize.optimize import Optimizer as _AseOptimizer
+    HAVE_ASE = True
+except Exception:                                           # noqa: BLE001
+    HAVE_ASE = False
+
+
+class Atoms:
+    def __init__(self, symbols=None, positions=None, cell=None, pbc=False, calculator=None,
+                 numbers=None):
+        self.positions = np.array(positions, dtype=np.float64).reshape((-1, 3))
+        n = len(self.positions)
+        self.symbols = list(symbols) if symbols is not None else ['X'] * n
+        self.numbers = np.array(numbers if numbers is not None else np.zeros(n, dtype=int))
+        self.cell = np.zeros((3, 3)) if cell is None else np.array(cell, dtype=np.float64).reshape(3, 3)
+        self.pbc = np.array([pbc] * 3 if np.isscalar(pbc) else pbc, dtype=bool)
+        self.calc = calculator
+        self.constraints = []
+
+    def __len__(self):
+        return len(self.positions)
+
+    def copy(self):
+        new = Atoms(self.symbols, self.positions.copy(), self.cell.copy(), self.pbc.copy(), self.calc,
+                    self.numbers.copy())
+        return new
+
+    def get_positions(self):
+        return self.positions.copy()
+
+    def set_positions(self, pos):
+        self.positions = np.array(pos, dtype=np.float64).reshape((-1, 3))
+
+    def get_potential_energy(self):
+        return float(self.calc.get_potential_energy(self))
+
+    def get_forces(self):
+        return np.asarray(self.calc.get_forces(self), dtype=np.float64).reshape((-1, 3))
+
+
+class Calculator:
+    """energy_and_gradient(positions (N,3)) -> (E, dE/dx (N,3)); results cached per geometry."""
+
+    def __init__(self):
+        self._key = None
+        self._res = None
+        self.ncalls = 0
+
+    def energy_and_gradient(self, pos):
+        raise NotImplementedError
+
+    def _get(self, atoms):
+        key = atoms.positions.tobytes()
+        if key != self._key:
+            self.ncalls += 1
+            self._res = self.energy_and_gradient(atoms.positions)
+            self._key = key
+        return self._res
+
+    def get_potential_energy(self, atoms):
+        return self._get(atoms)[0]
+
+    def get_forces(self, atoms):
+        return -self._get(atoms)[1]
+
+
+class QuadraticCubicModel(Calculator):
+    """f(x) = 1/2 x^T A x + c/3 sum_j (u_j . x)^3 — gradient = one matvec + a few dots, so an
+    optimizer step on it is linear-algebra bound.  `A` may be given as a numpy
+    array (host matvec) or as a callable v -> A v (e.g. a device-resident matrix)."""
+
+    def __init__(self, A, U, c=0.05):
+        super().__init__()
+        self.A = A
+        self.U = np.asarray(U, dtype=np.float64)
+        self.c = c
+
+    def energy_and_gradient(self, pos):
+        x = pos.ravel()
+        Ax = self.A(x) if callable(self.A) else self.A @ x
+        p = self.U @ x
+        e = 0.5 * x @ Ax + self.c / 3.0 * np.sum(p ** 3)
+        g = Ax + self.U.T @ (self.c * p ** 2)
+        return e, g.reshape(pos.shape)
+
+
+class MorseCluster(Calculator):
+    """Pairwise Morse potential, D (1 - exp(-a (r - r0)))^2 - D."""
+
+    def __init__(self, D=1.0, a=1.0, r0=1.0):
+        super().__init__()
+        self.D, self.a, self.r0 = D, a, r0
+
+    def energy_and_gradient(self, pos):
+        n = len(pos)
+        d = pos[:, None, :] - pos[None, :, :]
+        r = np.linalg.norm(d, axis=2)
+        iu = np.triu_indices(n, 1)
+        rr = r[iu]
+        ex = np.exp(-self.a * (rr - self.r0))
+        e = np.sum(self.D * (1 - ex) ** 2 - self.D)
+        de = 2 * self.D * self.a * (1 - ex) * ex
+        g = np.zeros_like(pos)
+        u = d[iu] / rr[:, None]
+        np.add.at(g, iu[0], de[:, None] * u)
+        np.add.at(g, iu[1], -de[:, None] * u)
+        return e, g
+
+
+class PairLJ(Calculator):
+    def __init__(self, eps=1.0, sigma=1.0):
+        super().__init__()
+        self.eps, self.sigma = eps, sigma
+
+    def energy_and_gradient(self, pos):
+        n = len(pos)
+        d = pos[:, None, :] - pos[None, :, :]
+        iu = np.triu_indices(n, 1)
+        rr = np.linalg.norm(d[iu], axis=1)
+        s6 = (self.sigma / rr) ** 6
+        e = np.sum(4 * self.eps * (s6 ** 2 - s6))
+        de = 4 * self.eps * (-12 * s6 ** 2 + 6 * s6) / rr
+        g = np.zeros_like(pos)
+        u = d[iu] / rr[:, None]
+        np.add.at(g, iu[0], de[:, None] * u)
+        np.add.at(g, iu[1], -de[:, None] * u)
+        return e, g
+
+
+class _MiniOptimizer:
+    """The subset of ase.optimize.optimize.Optimizer that `Sella` relies on."""
+
+    def __init__(self, atoms, restart=None, logfile='-', trajectory=None, master=None):
+        self.atoms = atoms
+        self.optimizable = atoms
+        self.restart = restart
+        if logfile == '-':
+            self.logfile = sys.stdout
+            self._own_log = False
+        elif logfile is None:
+            self.logfile = None
+            self._own_log = False
+        elif isinstance(logfile, str):
+            self.logfile = open(logfile, 'a')
+            self._own_log = True
+        else:
+            self.logfile = logfile
+            self._own_log = False
+        self.nsteps = 0
+        self.max_steps = 0
+        self.fmax = None
+        self.observers = []
+        self._closers = []
+
+    def closelater(self, obj):
+        self._closers.append(obj)
+        return obj
+
+    def attach(self, function, interval=1, *args, **kwargs):
+        self.observers.append((function, interval, args, kwargs))
+
+    def call_observers(self):
+        for function, interval, args, kwargs in self.observers:
+            if interval > 0 and self.nsteps % interval == 0:
+                function(*args, **kwargs)
+
+    def irun(self, fmax=0.05, steps=100000000):
+        self.fmax = fmax
+        self.max_steps = self.nsteps + steps
+        self.log()
+        self.call_observers()
+        if self.converged():
+            yield True
+            return
+        while self.nsteps < self.max_steps:
+            self.step()
+            self.nsteps += 1
+            self.log()
+            self.call_observers()
+            if self.converged():
+                yield True
+                return
+            yield False
+
+    def run(self, fmax=0.05, steps=100000000):
+        conv = False
+        for conv in self.irun(fmax=fmax, steps=steps):
+            pass
+        return conv
+
+    def close(self):
+        for obj in self._closers:
+            if hasattr(obj, 'close'):
+                obj.close()
+        if self._own_log and self.logfile is not None:
+            self.logfile.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def converged(self, forces=None):
+        raise NotImplementedError
+
+    def log(self, forces=None):
+        raise NotImplementedError
+
+    def step(self):
+        raise NotImplementedError
+
+
+Optimizer = _AseOptimizer if HAVE_ASE else _MiniOptimizer

@@ -1,0 +1,460 @@
+"""Internal-coordinate primitives and the `Constraints` container — the subset of
+sella/internal.py the saddle-point path needs:
+
+  * value / gradient / Hessian of translations, bonds, angles and dihedrals with periodic shift
+    vectors, same definitions as internal.py:58-80 (`_bond_value`, `_angle_value`,
+    `_dihedral_value`) and internal.py:466-470 (`_translation`);
+  * `Constraints`: fix_translation / fix_bond / fix_angle / fix_dihedral with eq / lt / gt kinds,
+    `residual()`, `jacobian()` (dense, internal.py:1780-1902), `hessian().ldot(L)`
+    (internal.py:2189-2305, linalg.py:601-618), inequality bookkeeping (internal.py:2788-2823).
+
+The reference differentiates these functions with JAX (CPU).  Here the derivatives are exact
+too, but come from a small hyper-dual-number (second-order forward-mode) arithmetic vectorised
+over all coordinates of one kind — no JAX.  Out of scope here: TRIC rotations,
+cell derivatives, dummy atoms, automatic topology search.
+"""
+from functools import partialmethod
+
+import numpy as np
+
+
+class DuplicateInternalError(ValueError):
+    pass
+
+
+class DuplicateConstraintError(DuplicateInternalError):
+    pass
+
+
+# ------------------------------------------------------------------------------------------
+# hyper-dual numbers: value v (nc,), gradient g (nc, m), Hessian H (nc, m, m)
+# ------------------------------------------------------------------------------------------
+class HD:
+    __slots__ = ('v', 'g', 'H')
+
+    def __init__(self, v, g, H):
+        self.v, self.g, self.H = v, g, H
+
+    @staticmethod
+    def variables(x):
+        """x (nc, m) -> list of m independent variables."""
+        nc, m = x.shape
+        out = []
+        for i in range(m):
+            g = np.zeros((nc, m))
+            g[:, i] = 1.0
+            out.append(HD(x[:, i].copy(), g, np.zeros((nc, m, m))))
+        return out
+
+    @staticmethod
+    def _lift(o, like):
+        if isinstance(o, HD):
+            return o
+        v = np.broadcast_to(np.asarray(o, dtype=float), like.v.shape)
+        return HD(v, np.zeros_like(like.g), np.zeros_like(like.H))
+
+    def __add__(self, o):
+        o = HD._lift(o, self)
+        return HD(self.v + o.v, self.g + o.g, self.H + o.H)
+
+    __radd__ = __add__
+
+    def __neg__(self):
+        return HD(-self.v, -self.g, -self.H)
+
+    def __sub__(self, o):
+        return self + (-HD._lift(o, self))
+
+    def __rsub__(self, o):
+        return HD._lift(o, self) - self
+
+    def __mul__(self, o):
+        o = HD._lift(o, self)
+        gg = self.g[:, :, None] * o.g[:, None, :]
+        return HD(self.v * o.v, self.v[:, None] * o.g + o.v[:, None] * self.g,
+                  self.v[:, None, None] * o.H + o.v[:, None, None] * self.H + gg + gg.transpose(0, 2, 1))
+
+    __rmul__ = __mul__
+
+    def apply(self, f, df, d2f):
+        """Elementwise function with first and second derivative values."""
+        return HD(f, df[:, None] * self.g,
+                  df[:, None, None] * self.H + d2f[:, None, None] * (self.g[:, :, None] * self.g[:, None, :]))
+
+    def recip(self):
+        return self.apply(1.0 / self.v, -1.0 / self.v ** 2, 2.0 / self.v ** 3)
+
+    def __truediv__(self, o):
+        return self * HD._lift(o, self).recip()
+
+    def sqrt(self):
+        s = np.sqrt(self.v)
+        return self.apply(s, 0.5 / s, -0.25 / s ** 3)
+
+    def arccos(self):
+        c = np.clip(self.v, -1.0, 1.0)
+        om = np.maximum(1.0 - c * c, 1e-300)
+        return self.apply(np.arccos(c), -1.0 / np.sqrt(om), -c / om ** 1.5)
+
+
+def hd_arctan2(y, x):
+    r2 = x * x + y * y
+    U = x / r2
+    W = -(y / r2)
+    g = U.v[:, None] * y.g + W.v[:, None] * x.g
+    H = (U.v[:, None, None] * y.H + W.v[:, None, None] * x.H
+         + U.g[:, :, None] * y.g[:, None, :] + W.g[:, :, None] * x.g[:, None, :])
+    return HD(np.arctan2(y.v, x.v), g, 0.5 * (H + H.transpose(0, 2, 1)))
+
+
+def _dot(a, b):
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+
+
+def _cross(a, b):
+    return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+
+
+def _sub(a, b, t=None):
+    out = [a[i] - b[i] for i in range(3)]
+    if t is not None:
+        out = [out[i] + t[:, i] for i in range(3)]
+    return out
+
+
+def _norm(a):
+    return _dot(a, a).sqrt()
+
+
+# value functions on hyper-dual inputs; p = list of atoms, each a list of 3 HD; t (nc, nvec, 3)
+def _bond_hd(p, t):                                           # internal.py:58-60
+    return _norm(_sub(p[1], p[0], t[:, 0]))
+
+
+def _angle_hd(p, t):                                          # internal.py:63-70
+    dx1 = [-c for c in _sub(p[1], p[0], t[:, 0])]
+    dx2 = _sub(p[2], p[1], t[:, 1])
+    return (_dot(dx1, dx2) / (_norm(dx1) * _norm(dx2))).arccos()
+
+
+def _dihedral_hd(p, t):                                       # internal.py:73-80
+    dx1 = _sub(p[1], p[0], t[:, 0])
+    dx2 = _sub(p[2], p[1], t[:, 1])
+    dx3 = _sub(p[3], p[2], t[:, 2])
+    c12, c23 = _cross(dx1, dx2), _cross(dx2, dx3)
+    numer = _dot(dx2, _cross(c12, c23))
+    denom = _norm(dx2) * _dot(c12, c23)
+    return hd_arctan2(numer, denom)
+
+
+_KINDS = {'bonds': (2, _bond_hd), 'angles': (3, _angle_hd), 'dihedrals': (4, _dihedral_hd)}
+
+
+def evaluate_kind(kind, pos, tvec):
+    """pos (nc, natoms, 3), tvec (nc, natoms-1, 3) -> value (nc,), grad (nc, natoms, 3),
+    hess (nc, natoms, 3, natoms, 3)."""
+    na, fn = _KINDS[kind]
+    nc = pos.shape[0]
+    if nc == 0:
+        return np.zeros(0), np.zeros((0, na, 3)), np.zeros((0, na, 3, na, 3))
+    vars_ = HD.variables(pos.reshape(nc, 3 * na))
+    p = [[vars_[3 * a + d] for d in range(3)] for a in range(na)]
+    out = fn(p, tvec)
+    return out.v, out.g.reshape(nc, na, 3), out.H.reshape(nc, na, 3, na, 3)
+
+
+# ------------------------------------------------------------------------------------------
+# coordinate objects (identity / bookkeeping only; numerics are batched per kind)
+# ------------------------------------------------------------------------------------------
+class Coordinate:
+    nindices = None
+    kind = None
+
+    def __init__(self, indices, ncvecs=None, **kwargs):
+        self.indices = np.array(indices, dtype=np.int64)
+        if self.nindices is not None and len(self.indices) != self.nindices:
+            raise ValueError(f'{self.__class__.__name__} needs {self.nindices} atom indices')
+        n = max(len(self.indices) - 1, 0)
+        self.ncvecs = np.zeros((n, 3), dtype=np.int64) if ncvecs is None else np.array(ncvecs, dtype=np.int64).reshape((n, 3))
+        self.kwargs = kwargs
+
+    def reverse(self):
+        return self.__class__(self.indices[::-1], -self.ncvecs[::-1], **self.kwargs)
+
+    def __eq__(self, other):
+        if not isinstance(other, self.__class__):
+            return NotImplemented
+        for cand in (other, other.reverse()):
+            if np.array_equal(self.indices, cand.indices) and np.array_equal(self.ncvecs, cand.ncvecs):
+                return True
+        return False
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}({self.indices.tolist()})'
+
+    def calc(self, atoms):
+        pos = atoms.positions[self.indices][None]
+        tv = (self.ncvecs @ np.asarray(atoms.cell, dtype=float))[None]
+        return float(evaluate_kind(self.kind, pos, tv)[0][0])
+
+
+class Bond(Coordinate):
+    nindices, kind = 2, 'bonds'
+
+
+class Angle(Coordinate):
+    nindices, kind = 3, 'angles'
+
+
+class Dihedral(Coordinate):
+    nindices, kind = 4, 'dihedrals'
+
+
+class Translation(Coordinate):
+    """Mean position of a set of atoms along one Cartesian axis (internal.py:466-493)."""
+    kind = 'translations'
+
+    def __init__(self, indices, dim, ncvecs=None):
+        Coordinate.__init__(self, np.atleast_1d(indices))
+        self.kwargs['dim'] = int(dim)
+        self.ncvecs = np.zeros((0, 3), dtype=np.int64)
+
+    def reverse(self):
+        return self
+
+    def __eq__(self, other):
+        if not isinstance(other, self.__class__):
+            return NotImplemented
+        return self.kwargs['dim'] == other.kwargs['dim'] and set(self.indices.tolist()) == set(other.indices.tolist())
+
+    def calc(self, atoms):
+        return float(atoms.positions[self.indices, self.kwargs['dim']].mean())
+
+
+class _HessianStack:
+    """Per-coordinate Hessians with the `ldot` contraction of SparseInternalHessians
+    (sella/linalg.py:601-618): ldot(v) = sum_i v_i H_i as a dense (ndof, ndof) matrix."""
+
+    def __init__(self, ndof, blocks):
+        self.ndof = ndof
+        self.blocks = blocks        # list of (dof index array (nc, m), hess (nc, m, m))
+
+    def ldot(self, v):
+        out = np.zeros((self.ndof, self.ndof))
+        off = 0
+        for dofs, H in self.blocks:
+            nc = len(dofs)
+            if nc:
+                w = np.asarray(v[off:off + nc])
+                rows = np.repeat(dofs[:, :, None], dofs.shape[1], axis=2)
+                cols = np.repeat(dofs[:, None, :], dofs.shape[1], axis=1)
+                np.add.at(out, (rows.ravel(), cols.ravel()), (w[:, None, None] * H).ravel())
+            off += nc
+        return out
+
+
+class Constraints:
+    _names = ('translations', 'bonds', 'angles', 'dihedrals', 'other', 'rotations')
+
+    def __init__(self, atoms, dummies=None, dinds=None, ignore_rotation=True):
+        self.atoms = atoms
+        self.internals = {k: [] for k in self._names}
+        self._targets = {k: [] for k in self._names}
+        self._active = {k: [] for k in self._names}
+        self._kind = {k: [] for k in self._names}
+        self.ignore_rotation = ignore_rotation
+        for cons in getattr(atoms, 'constraints', None) or []:
+            self.merge_ase_constraint(cons)
+
+    # ---- bookkeeping ---------------------------------------------------------------------
+    @property
+    def all_atoms(self):
+        return self.atoms
+
+    @property
+    def natoms(self):
+        return len(self.atoms)
+
+    @property
+    def ndof(self):
+        return 3 * self.natoms
+
+    def _count(self, name):
+        return int(sum(self._active[name]))
+
+    ntrans = property(lambda self: self._count('translations'))
+    nbonds = property(lambda self: self._count('bonds'))
+    nangles = property(lambda self: self._count('angles'))
+    ndihedrals = property(lambda self: self._count('dihedrals'))
+    nother = property(lambda self: 0)
+    nrotations = property(lambda self: 0)
+
+    @property
+    def nint(self):
+        return self.ntrans + self.nbonds + self.nangles + self.ndihedrals
+
+    def copy(self):
+        new = self.__class__(self.atoms, ignore_rotation=self.ignore_rotation)
+        for name in self._names:
+            new.internals[name] = list(self.internals[name])
+            new._targets[name] = list(self._targets[name])
+            new._active[name] = list(self._active[name])
+            new._kind[name] = list(self._kind[name])
+        return new
+
+    def _active_list(self, name):
+        return [c for c, a in zip(self.internals[name], self._active[name]) if a]
+
+    @property
+    def targets(self):
+        vec = []
+        for name in self._names:
+            vec += [t for t, a in zip(self._targets[name], self._active[name]) if a]
+        return np.array(vec, dtype=np.float64)
+
+    # ---- numerics (batched per kind) --------------------------------------------------------
+    def _gather(self, name):
+        coords = self._active_list(name)
+        na = _KINDS[name][0]
+        idx = np.array([c.indices for c in coords], dtype=np.int64).reshape((len(coords), na))
+        ncv = np.array([c.ncvecs for c in coords], dtype=np.float64).reshape((len(coords), na - 1, 3))
+        pos = self.atoms.positions[idx] if len(coords) else np.zeros((0, na, 3))
+        tvec = ncv @ np.asarray(self.atoms.cell, dtype=float)
+        return idx, pos, tvec
+
+    def calc(self):
+        vals = [np.array([c.calc(self.atoms) for c in self._active_list('translations')])]
+        for name in ('bonds', 'angles', 'dihedrals'):
+            idx, pos, tvec = self._gather(name)
+            vals.append(evaluate_kind(name, pos, tvec)[0])
+        return np.concatenate(vals) if vals else np.zeros(0)
+
+    def wrap(self, vec):
+        """Dihedral differences live on the circle (internal.py:2577-2587)."""
+        nd = self.ndihedrals
+        if nd:
+            lo = self.ntrans + self.nbonds + self.nangles
+            vec[lo:lo + nd] = (vec[lo:lo + nd] + np.pi) % (2 * np.pi) - np.pi
+        return vec
+
+    def residual(self):
+        return self.wrap(self.calc() - self.targets)
+
+    def jacobian(self):
+        """Dense (nactive, 3N) constraint Jacobian."""
+        rows = []
+        n3 = self.ndof
+        for c in self._active_list('translations'):
+            r = np.zeros(n3)
+            r[3 * c.indices + c.kwargs['dim']] = 1.0 / len(c.indices)
+            rows.append(r)
+        J = np.array(rows).reshape((len(rows), n3))
+        for name in ('bonds', 'angles', 'dihedrals'):
+            idx, pos, tvec = self._gather(name)
+            if len(idx) == 0:
+                continue
+            grad = evaluate_kind(name, pos, tvec)[1]            # (nc, na, 3)
+            block = np.zeros((len(idx), n3))
+            dofs = (3 * idx[:, :, None] + np.arange(3)[None, None, :]).reshape(len(idx), -1)
+            np.add.at(block, (np.arange(len(idx))[:, None], dofs), grad.reshape(len(idx), -1))
+            J = np.vstack([J, block])
+        return J
+
+    def hessian(self):
+        blocks = [(np.zeros((self.ntrans, 0), dtype=np.int64), np.zeros((self.ntrans, 0, 0)))]
+        for name in ('bonds', 'angles', 'dihedrals'):
+            idx, pos, tvec = self._gather(name)
+            nc = len(idx)
+            na = idx.shape[1] if nc else 0
+            H = evaluate_kind(name, pos, tvec)[2].reshape(nc, 3 * na, 3 * na) if nc else np.zeros((0, 0, 0))
+            dofs = (3 * idx[:, :, None] + np.arange(3)[None, None, :]).reshape(nc, -1) if nc else np.zeros((0, 0), dtype=np.int64)
+            blocks.append((dofs, H))
+        return _HessianStack(self.ndof, blocks)
+
+    # ---- inequality bookkeeping (internal.py:2788-2823) ----------------------------------------
+    def has_inequalities(self):
+        return any(k in ('lt', 'gt') for name in self._names for k in self._kind[name])
+
+    def disable_satisfied_inequalities(self):
+        for name in self._names:
+            for i, (coord, kind, target) in enumerate(zip(self.internals[name], self._kind[name], self._targets[name])):
+                if kind == 'lt' and coord.calc(self.atoms) <= target:
+                    self._active[name][i] = False
+                elif kind == 'gt' and coord.calc(self.atoms) >= target:
+                    self._active[name][i] = False
+                else:
+                    self._active[name][i] = True
+
+    def validate_inequalities(self):
+        all_valid = True
+        for name in self._names:
+            for i, (coord, kind, target) in enumerate(zip(self.internals[name], self._kind[name], self._targets[name])):
+                if self._active[name][i]:
+                    continue
+                val = coord.calc(self.atoms)
+                if (kind == 'lt' and val > target) or (kind == 'gt' and val < target):
+                    self._active[name][i] = True
+                    all_valid = False
+        return all_valid
+
+    # ---- adding constraints (internal.py:2861-2955) ----------------------------------------------
+    def _add(self, name, new, target, kind, replace_ok):
+        try:
+            idx = self.internals[name].index(new)
+        except ValueError:
+            self.internals[name].append(new)
+            self._targets[name].append(target)
+            self._active[name].append(True)
+            self._kind[name].append(kind)
+            return
+        if replace_ok:
+            self._targets[name][idx] = target
+            self._kind[name][idx] = kind
+            return
+        raise DuplicateConstraintError(f'Coordinate {new} is already fixed to target {self._targets[name][idx]}')
+
+    def fix_translation(self, index=None, dim=None, target=None, replace_ok=True):
+        if isinstance(index, Translation):
+            if dim is not None:
+                raise ValueError('"dim" keyword cannot be used with explicit Translation')
+            new = index
+        else:
+            if index is None:
+                index = np.arange(self.natoms)
+            if np.isscalar(index):
+                index = np.array((index,))
+            if dim is None:
+                if target is not None:
+                    raise ValueError('"target" keyword requires explicit "dim"!')
+                for d in range(3):
+                    self.fix_translation(index, dim=d, replace_ok=replace_ok)
+                return
+            new = Translation(index, dim)
+        if target is None:
+            target = new.calc(self.atoms)
+        self._add('translations', new, target, 'eq', replace_ok)
+
+    def fix_rotation(self, indices=None, axis=None):
+        raise NotImplementedError('rotation constraints (TRIC) are outside the saddle-search scope '
+                                  '(periodic slabs never add them: peswrapper.py:244-253)')
+
+    def _fix_internal(self, cls, name, conv, indices, ncvecs=None, mic=None, target=None,
+                      comparator='eq', replace_ok=True):
+        new = indices if isinstance(indices, cls) else cls(indices, ncvecs=ncvecs)
+        target = new.calc(self.atoms) if target is None else target * conv
+        self._add(name, new, target, comparator, replace_ok)
+
+    fix_bond = partialmethod(_fix_internal, Bond, 'bonds', 1.)
+    fix_angle = partialmethod(_fix_internal, Angle, 'angles', np.pi / 180.)
+    fix_dihedral = partialmethod(_fix_internal, Dihedral, 'dihedrals', np.pi / 180.)
+
+    def merge_ase_constraint(self, cons):
+        """FixAtoms / FixCom equivalents by duck typing (internal.py:2981-3030)."""
+        name = cons.__class__.__name__
+        if name == 'FixAtoms':
+            for index in np.atleast_1d(cons.index):
+                self.fix_translation(int(index))
+        elif name == 'FixCom':
+            self.fix_translation()
+        else:
+            raise NotImplementedError(f'ASE constraint {name} is not supported by this path')

@@ -1,0 +1,346 @@
+"""`PES` — the potential-energy-surface wrapper of the saddle-point loop, drop-in for the Cartesian
+class of sella/peswrapper.py:214-607 (same constructor, getters, `diag()`, `kick()`,
+`converged()`), built on the device-resident `ApproximateHessian`.
+
+The calculator boundary is untouched: `eval()` calls `atoms.get_potential_energy()` /
+`atoms.get_forces()` exactly like peswrapper.py:413-418.  Everything n x n happens on the
+MI355X: B·s products, U^T B U projections, the eigendecomposition shared by the Davidson
+preconditioner / TS-BFGS / P-RFO, the Davidson loop and the quasi-Newton updates.
+Host-side (as in the reference, outside its accelerator seam): the rank-revealing pivoted QR
+of the (ncons x n) constraint Jacobian and O(n) vector algebra.
+
+Not restated here (out of the saddle-point scope): InternalPES / Cell*PES.
+"""
+import numpy as np
+from scipy.linalg import eigh, qr
+
+from .atoms import Atoms  # noqa: F401  (re-export for users without ASE)
+from .eigensolvers import rayleigh_ritz
+from .hessian_update import symmetrize_Y
+from .internal import Constraints, DuplicateInternalError
+from .linalg import ApproximateHessian, NumericalHessian
+
+
+class _LRU2:
+    """Two-entry cache keyed by the geometry hash (peswrapper.py:24-48)."""
+
+    def __init__(self):
+        self._entries = [None, None]
+        self._next = 0
+
+    def get(self, key):
+        for e in self._entries:
+            if e is not None and e[0] == key:
+                return e[1]
+        return None
+
+    def put(self, key, value):
+        if self.get(key) is not None:
+            return
+        self._entries[self._next] = (key, value)
+        self._next = 1 - self._next
+
+
+def _split_cons_subspace(drdx, tol_factor=1e-6):
+    """(Ucons, Ufree): row space of the constraint Jacobian and its orthogonal complement by
+    rank-revealing pivoted QR of drdx^T (peswrapper.py:51-69)."""
+    n = drdx.shape[1]
+    if drdx.shape[0] == 0:
+        return np.zeros((n, 0)), np.eye(n)
+    Q, R, _ = qr(drdx.T, mode='full', pivoting=True, check_finite=False)
+    diag = np.abs(np.diag(R))
+    ncons = int(np.sum(diag > tol_factor * diag[0])) if diag.size and diag[0] > 0 else 0
+    return Q[:, :ncons], Q[:, ncons:]
+
+
+class PES:
+    n_cell_dof = 0
+
+    def __init__(self, atoms, H0=None, constraints=None, eigensolver='jd0', trajectory=None,
+                 eta=1e-4, v0=None, proj_trans=None, proj_rot=None, hessian_function=None):
+        self.atoms = atoms
+        if constraints is None:
+            constraints = Constraints(self.atoms)
+        if proj_trans is None:
+            proj_trans = not constraints.internals['translations']
+        if proj_trans:
+            try:
+                constraints.fix_translation(replace_ok=False)
+            except DuplicateInternalError:
+                pass
+        if proj_rot is None:
+            proj_rot = not np.any(atoms.pbc)
+        if proj_rot:
+            # global rotations are a TRIC feature (out of scope); a non-periodic system is handled
+            # by the eigensolver seeing 3 extra soft modes, like Sella with proj_rot=False
+            pass
+        self.cons = constraints
+        self.eigensolver = eigensolver
+        self.traj = trajectory if not isinstance(trajectory, str) else None
+        self.eta = eta
+        self.v0 = v0
+        self.neval = 0
+        self.curr = dict(x=None, f=None, g=None)
+        self.last = self.curr.copy()
+        self.int = None
+        self.dummies = None
+        self.dim = 3 * len(atoms)
+        self.ncart = self.dim
+        if H0 is None:
+            self.set_H(None, initialized=False)
+        else:
+            self.set_H(H0, initialized=True)
+        self.savepoint = dict(apos=None, dpos=None)
+        self.first_diag = True
+        self.hessian_function = hessian_function
+        self._basis_cache = _LRU2()
+
+    apos = property(lambda self: self.atoms.positions.copy())
+    dpos = property(lambda self: None)
+
+    def _state_hash(self):
+        h = np.ascontiguousarray(self.atoms.positions).tobytes()
+        cell = np.asarray(self.atoms.cell, dtype=float)
+        if cell.any():
+            h += cell.tobytes()
+        return h
+
+    def save(self):
+        self.savepoint = dict(apos=self.apos, dpos=self.dpos)
+
+    def restore(self):
+        assert self.savepoint['apos'] is not None
+        self.atoms.positions = self.savepoint['apos']
+
+    def close(self):
+        if self.traj is not None:
+            self.traj.close()
+            self.traj = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    # ---- positions -------------------------------------------------------------------------
+    def set_x(self, target):
+        diff = target - self.get_x()
+        self.atoms.positions = target.reshape((-1, 3))
+        g = self.curr.get('g')
+        return diff, diff, (np.zeros_like(diff) if g is None else g)
+
+    def get_x(self):
+        return self.apos.ravel().copy()
+
+    # ---- Hessians ----------------------------------------------------------------------------
+    def get_H(self):
+        return self.H
+
+    def set_H(self, target, *args, **kwargs):
+        self.H = ApproximateHessian(self.dim, self.ncart, target, *args, **kwargs)
+
+    def get_Hc(self):
+        if self.curr.get('L') is None:
+            raise RuntimeError("PES.get_Hc() called with L=None.")
+        return self.cons.hessian().ldot(self.curr['L'])
+
+    def get_HL(self):
+        return self.get_H() + (-self.get_Hc())
+
+    def _has_curved_constraints(self):
+        c = self.cons
+        return (c.nbonds + c.nangles + c.ndihedrals) > 0
+
+    def get_HL_projected(self, U):
+        """ApproximateHessian(U^T (B - Hc) U) without forming HL (peswrapper.py:363-386)."""
+        H = self.get_H()
+        n = U.shape[1]
+        if H.B is None:
+            return ApproximateHessian(n, 0, None, H.update_method, H.symm)
+        identity = U.shape[0] == n and U[0, 0] == 1.0 and np.count_nonzero(U) == n and np.all(np.diag(U) == 1.0)
+        Bproj = H.B.copy() if identity else H.project(U).B
+        L = self.curr.get('L')
+        if L is not None and L.size > 0 and self._has_curved_constraints():
+            Hc = self.get_Hc()          # zero for translation-only constraints: skipped above
+            Bproj = Bproj - U.T @ Hc @ U
+        return ApproximateHessian(n, 0, Bproj, H.update_method, H.symm)
+
+    # ---- constraints ------------------------------------------------------------------------
+    def get_res(self):
+        return self.cons.residual()
+
+    def get_drdx(self):
+        return self.cons.jacobian()
+
+    def _calc_basis(self):
+        key = self._state_hash()
+        cached = self._basis_cache.get(key)
+        if cached is not None:
+            return cached
+        drdx = self.get_drdx()
+        Ucons, Ufree = _split_cons_subspace(drdx)
+        result = (drdx, Ucons, np.eye(self.dim), Ufree)
+        self._basis_cache.put(key, result)
+        return result
+
+    def write_traj(self):
+        if self.traj is not None:
+            self.traj.write()
+
+    # ---- the calculator boundary (peswrapper.py:413-418) ----------------------------------------
+    def eval(self):
+        self.neval += 1
+        f = self.atoms.get_potential_energy()
+        g = -np.asarray(self.atoms.get_forces()).ravel()
+        self.write_traj()
+        return f, g
+
+    def _calc_eg(self, x):
+        self.save()
+        self.set_x(x)
+        f, g = self.eval()
+        self.restore()
+        return f, g
+
+    def get_scons(self):
+        """Minimum-norm linear correction towards the constraint manifold (peswrapper.py:429-438)."""
+        Ucons = self.get_Ucons()
+        if Ucons.shape[1] == 0:
+            return np.zeros(self.dim)
+        return -Ucons @ np.linalg.lstsq(self.get_drdx() @ Ucons, self.get_res(), rcond=None)[0]
+
+    def _update(self, feval=True):
+        state = self._state_hash()
+        new_point = True
+        if self.curr['x'] is not None and state == self.curr.get('state_hash'):
+            if feval and self.curr['f'] is None:
+                new_point = False
+            else:
+                return False
+        x = self.get_x()
+        basis = self._calc_basis()
+        f, g = self.eval() if feval else (None, None)
+        if new_point:
+            self.last = self.curr.copy()
+        self.curr['x'] = x
+        self.curr['state_hash'] = state
+        self.curr['f'] = f
+        self.curr['g'] = g
+        self._update_basis(basis)
+        return True
+
+    def _update_basis(self, basis=None):
+        if basis is None:
+            basis = self._calc_basis()
+        drdx, Ucons, Unred, Ufree = basis
+        self.curr.update(drdx=drdx, Ucons=Ucons, Unred=Unred, Ufree=Ufree)
+        if self.curr['g'] is None:
+            L = None
+        elif drdx.shape[0] == 0:
+            L = np.zeros(0)
+        else:
+            L = np.linalg.lstsq(drdx.T, self.curr['g'], rcond=None)[0]
+        self.curr['L'] = L
+
+    def _update_H(self, dx, dg):
+        if self.last['x'] is None or self.last['g'] is None:
+            return
+        self.H.update(dx, dg)
+
+    def get_f(self):
+        self._update()
+        return self.curr['f']
+
+    def get_g(self):
+        self._update()
+        return self.curr['g'].copy()
+
+    def get_Unred(self):
+        self._update(False)
+        return self.curr['Unred']
+
+    def get_Ufree(self):
+        self._update(False)
+        return self.curr['Ufree']
+
+    def get_Ucons(self):
+        self._update(False)
+        return self.curr['Ucons']
+
+    # ---- iterative diagonalisation (peswrapper.py:508-556) ----------------------------------------
+    def diag(self, gamma=0.1, threepoint=False, maxiter=None):
+        if self.curr['f'] is None:
+            self._update(feval=True)
+        Ufree = self.get_Ufree()
+        nfree = Ufree.shape[1]
+        if nfree == 0:
+            return
+        P = self.get_HL_projected(Ufree)
+        P_is_none = P.B is None
+        if P_is_none or self.first_diag:
+            v0 = self.v0 if self.v0 is not None else self.get_g() @ Ufree
+            if v0 is not None and np.linalg.norm(v0) < 1e-12:
+                v0 = None
+        else:
+            v0 = None
+        Hproj = NumericalHessian(self._calc_eg, self.get_x(), self.get_g(), self.eta, threepoint, Ufree)
+        A = Hproj
+        Hc = None
+        if self._has_curved_constraints():
+            Hc = self.get_Hc()
+            A = Hproj + (-(Ufree.T @ Hc @ Ufree))
+        # P is handed over as the ApproximateHessian itself: its device eigendecomposition is the
+        # preconditioner of the JD correction (sella_amd/csrc/davidson.hip)
+        rayleigh_ritz(A, gamma, None if P_is_none else P, v0=v0, method=self.eigensolver, maxiter=maxiter)
+
+        Vs, AVs = Hproj.Vs, Hproj.AVs
+        # Ritz vectors of the collected full-space iterates (peswrapper.py:545-551)
+        Atilde = Vs.T @ symmetrize_Y(Vs, AVs, symm=2)
+        if Hc is not None:
+            Atilde = Atilde - Vs.T @ Hc @ Vs
+        _, X = eigh(Atilde)
+        self.H.update(Vs @ X, AVs @ X)
+        self.first_diag = False
+
+    def get_projected_forces(self):
+        g = self.get_g()
+        Ufree = self.get_Ufree()
+        return -(Ufree @ (Ufree.T @ g)).reshape((-1, 3))
+
+    def converged(self, fmax, cmax=1e-5):
+        fmax1 = np.linalg.norm(self.get_projected_forces(), axis=1).max()
+        cmax1 = np.linalg.norm(self.get_res())
+        return (fmax1 < fmax) and (cmax1 < cmax), fmax1, cmax1
+
+    def wrap_dx(self, dx):
+        return dx
+
+    def get_df_pred(self, dx, g, H):
+        if H is None:
+            return None
+        return g.T @ dx + (dx.T @ (H @ dx)) / 2.
+
+    # ---- step + update (peswrapper.py:578-602) -------------------------------------------------------
+    def kick(self, dx, diag=False, **diag_kwargs):
+        x0 = self.get_x()
+        f0 = self.get_f()
+        g0 = self.get_g()
+        dx_initial, dx_final, g_par = self.set_x(x0 + dx)
+        # B0 @ dx on the device (B0 = H.asarray(); the identity while uninitialised)
+        df_pred = self.get_df_pred(dx_initial, g0, self.H)
+        dg_actual = self.get_g() - g_par
+        df_actual = self.get_f() - f0
+        ratio = None if (df_pred is None or abs(df_pred) < 1e-14) else df_actual / df_pred
+        self._update_H(dx_final, dg_actual)
+        if diag:
+            if self.hessian_function is not None:
+                self.calculate_hessian()
+            else:
+                self.diag(**diag_kwargs)
+        return ratio
+
+    def calculate_hessian(self):
+        assert self.hessian_function is not None
+        self.H.set_B(self.hessian_function(self.atoms))

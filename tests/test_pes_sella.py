@@ -1,0 +1,120 @@
+"""PES wrapper and the `Sella` optimizer API over the device path.
+
+The reference classes need ASE + JAX and cannot be imported in the build image, so these are
+property tests re-stated from the reference's own suite: tests/test_peswrapper.py:15-38
+(kick / diag / basis orthogonality) and tests/integration/test_morse_cluster.py:20-46
+(run to convergence, projected gradient ~ 0, exactly `order` negative Hessian eigenvalues)."""
+import io
+
+import numpy as np
+import pytest
+
+
+def morse_atoms(nat=4, seed=4):
+    from sella_amd.atoms import Atoms, MorseCluster
+    rng = np.random.RandomState(seed)
+    atoms = Atoms(['Xe'] * nat, rng.normal(size=(nat, 3), scale=1.2))
+    atoms.calc = MorseCluster(D=1.0, a=1.3, r0=2.0)
+    return atoms
+
+
+def test_constraints_api():
+    from sella_amd.internal import Constraints, DuplicateConstraintError
+    atoms = morse_atoms(5)
+    c = Constraints(atoms)
+    c.fix_translation()
+    assert c.ntrans == 3 and c.nint == 3
+    c.fix_bond((0, 1))
+    c.fix_angle((1, 2, 3), target=100.0)
+    c.fix_dihedral((0, 1, 2, 3), comparator='lt', target=170.0)
+    assert c.has_inequalities()
+    assert c.jacobian().shape == (c.nint, 15)
+    res = c.residual()
+    assert res[:4] == pytest.approx(0, abs=1e-14) and abs(res[4]) > 1e-3
+    with pytest.raises(DuplicateConstraintError):
+        c.fix_bond((1, 0), replace_ok=False)
+    c.disable_satisfied_inequalities()
+    assert c.ndihedrals in (0, 1)
+    c2 = c.copy()
+    assert c2.nint == c.nint
+
+
+def test_PES(ctx):
+    from sella_amd.peswrapper import PES
+    atoms = morse_atoms(5, seed=1)
+    pes = PES(atoms)
+    pes.kick(0., diag=True, gamma=0.1)
+    for _ in range(2):
+        pes.kick(-pes.get_g() * 0.01)
+    assert pes.H.B is not None
+    assert not pes.converged(0.)[0]
+    assert pes.converged(1e100)[0]
+    A = pes.get_Ufree().T @ pes.get_Ucons()
+    np.testing.assert_allclose(A, 0, atol=1e-10)
+    assert pes.get_Ucons().shape[1] == 3          # global translation fixed automatically
+    pes.kick(-pes.get_g() * 0.001, diag=True, gamma=0.1)
+    # the approximate Hessian reproduces the finite-difference curvature along the Davidson vectors
+    B = pes.H.B
+    np.testing.assert_allclose(B, B.T, atol=0)
+    assert pes.neval > 5
+
+
+@pytest.mark.parametrize('order', [0, 1])
+def test_morse_cluster(ctx, order):
+    from sella_amd import Constraints, Sella
+    atoms = morse_atoms(4, seed=4)
+    cons = Constraints(atoms)
+    # remove the six rigid-body motions with translation constraints only (the reference test uses
+    # fix_rotation(), a TRIC feature outside this build): atom 0 pinned, atom 1 on a line, atom 2
+    # in a plane
+    cons.fix_translation(0)
+    cons.fix_translation(1, dim=1)
+    cons.fix_translation(1, dim=2)
+    cons.fix_translation(2, dim=2)
+    log = io.StringIO()
+    opt = Sella(atoms, order=order, gamma=1e-3, constraints=cons, logfile=log)
+    conv = opt.run(fmax=1e-3, steps=400)
+    assert conv, log.getvalue()[-800:]
+    Ufree = opt.pes.get_Ufree()
+    np.testing.assert_allclose(opt.pes.get_g() @ Ufree, 0, atol=5e-3)
+    opt.pes.diag(gamma=1e-16)
+    H = opt.pes.get_HL().project(Ufree)
+    assert np.sum(H.evals < 0) == order, H.evals
+    assert 'Sella' in log.getvalue() and 'rtrust' in log.getvalue()
+
+
+def test_model_pes_saddle(ctx):
+    """Order-1 search on the SURVEY §8(d) model PES: converges to a point with one negative mode."""
+    from conftest import hessian_like
+    from sella_amd import Sella
+    from sella_amd.atoms import Atoms, QuadraticCubicModel
+    n = 30
+    A, P, g = hessian_like(n, seed=3)
+    rng = np.random.RandomState(5)
+    U = rng.normal(size=(8, n))
+    U /= np.linalg.norm(U, axis=1)[:, None]
+    atoms = Atoms(['X'] * (n // 3), 0.05 * rng.normal(size=(n // 3, 3)), pbc=True)
+    atoms.calc = QuadraticCubicModel(A, U, c=0.05)
+    from sella_amd.internal import Constraints
+
+    class NoCons(Constraints):
+        pass
+    opt = Sella(atoms, order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', logfile=None,
+                constraints=NoCons(atoms), proj_trans=False)
+    conv = opt.run(fmax=1e-5, steps=200)
+    assert conv
+    x = atoms.positions.ravel()
+    p = U @ x
+    Hx = A + U.T @ ((2 * 0.05 * p)[:, None] * U)
+    w = np.linalg.eigvalsh(Hx)
+    assert np.sum(w < 0) == 1
+    assert np.linalg.norm(A @ x + U.T @ (0.05 * p ** 2)) < 1e-4
+
+
+def test_unsupported_options_fail_loudly(ctx):
+    from sella_amd import Sella
+    atoms = morse_atoms(4)
+    with pytest.raises(NotImplementedError):
+        Sella(atoms, internal=True)
+    with pytest.raises(NotImplementedError):
+        Sella(atoms, optimize_cell=True, order=0)

@@ -3,13 +3,19 @@
 // linalg.py:174-231, the TS-BFGS |B| term hessian_update.py:121, the P-RFO split stepper.py:163).
 //
 // Three stages, all device-resident:
-//   1. Householder tridiagonalisation  Q^T A Q = T.  The full symmetric trailing matrix is
-//      kept up to date, so the matrix-vector product of each step is the same row-panel matvec
-//      that drives the Davidson loop (coalesced 16-byte streams, wave64 reductions).
+//   1. Blocked Householder tridiagonalisation  Q^T A Q = T  (panels of nb columns, LAPACK
+//      dlatrd's algebra).  The full symmetric trailing matrix is kept, so the matrix-vector
+//      product of each column is the row-panel matvec of the Davidson loop (coalesced 16-byte
+//      streams, wave64 reductions).  Per column exactly TWO launches: `trd_row_kernel`
+//      (finish the previous w, form the updated row, partial norms / panel dots) and
+//      `trd_gemv_kernel` (reflector scalars from the partials, v staged on the fly, A22 v);
+//      the rank-2nb trailing update is two GEMMs per panel.
 //   2. Divide and conquer on T (Cuppen, with Gu/Eisenstat's stable eigenvectors): leaves by
 //      implicit QL (one wavefront per leaf), merges = deflation (host, O(N log N)) + secular
-//      equation (one thread per root) + one GEMM per merge (MFMA f64).
-//   3. Back-transformation with compact-WY blocks: X <- X (I - Y T Y^T)^T, three GEMMs per block.
+//      equation (one wavefront per root) + one GEMM per merge; two host synchronisations per
+//      tree level.
+//   3. Back-transformation X <- X (I - Y T Y^T)^T block by block inside ONE kernel: every
+//      workgroup owns 16 eigenvector rows and sweeps all reflector blocks (rows are independent).
 // Eigenvectors are handled as ROWS of a row-major matrix throughout (vector-major, like the
 // Krylov panels), so rotations, gathers and the final Q^T x products are all coalesced.
 #include "internal.h"
@@ -21,6 +27,11 @@
 
 namespace sella {
 namespace {
+
+constexpr int TRD_NBMAX = 64;              // max panel width
+constexpr int TRD_PA = 1 + 2 * TRD_NBMAX;  // doubles per block in the K1 partial buffer
+constexpr int WY_NB = 32;                  // reflectors per compact-WY block
+constexpr int TRD_TC = 2048;               // column tile of the fused matvec
 
 __device__ __forceinline__ double wave_sum_e(double v) {
 #pragma unroll
@@ -40,70 +51,189 @@ __device__ __forceinline__ double block_sum_256(double v, double* red /* >= 4 do
 // ---------------------------------------------------------------------------------------
 // stage 1 kernels
 // ---------------------------------------------------------------------------------------
-// Reflector for step j from row j of the (symmetric, fully updated) matrix.
-// vpad[0] = 0, vpad[1 + i] = v_i (v_0 = 1); the tail v_1.. is also stored in A[j][j+2..]
-__global__ __launch_bounds__(256) void house_gen_kernel(double* __restrict__ A, int ld, int n, int j,
-                                                        double* __restrict__ vpad,
-                                                        double* __restrict__ taus,
-                                                        double* __restrict__ dvec,
-                                                        double* __restrict__ evec) {
-    __shared__ double red[4];
-    const int m = n - j - 1;
-    double* x = A + (size_t)j * ld + j + 1;
-    double ss = 0.0;
-    for (int i = 1 + threadIdx.x; i < m; i += 256) ss += x[i] * x[i];
+struct TrdRowArgs {
+    double* A; int ld, n;
+    int j;              // global column (row) index handled now
+    int i;              // its local index in the panel; i == kb: only finish the last w
+    int do_row;
+    double* Vp; double* Wp; int ldp;
+    const double* u_prev; double* u_cur;        // row buffers, absolute column index
+    const double* wraw;                         // A22 v of column j-1, absolute row index
+    const double* partA_prev; int nblkA_prev;   // K1 partials of column j-1
+    double* partA_cur;
+    const double* partB; int nblkB;             // v.wraw partials of column j-1
+    const double* colscal;                      // {tau, scale} of column j-1
+    double* dvec;
+};
+
+// K1.  Thread owns absolute column c = j + blockIdx.x*256 + tid.
+//   (1) i > 0: finish w_{i-1} = tau (wraw - V c1 - W c2) + alpha2 v   (dlatrd), store in Wp
+//   (2) u[c] = A[j][c] - sum_{p<i} (V_p[c] W_p[j] + W_p[c] V_p[j])    (pending rank-2i update)
+//   (3) per-block partials: sum u^2 (c >= j+2), W_p.u and V_p.u (c >= j+1) for p < i
+__global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
+    __shared__ double c1s[TRD_NBMAX], c2s[TRD_NBMAX], red[4];
+    __shared__ double s1w[TRD_NBMAX][4], s2w[TRD_NBMAX][4];
+    const int tid = threadIdx.x;
+    const int j = a.j, i = a.i, ldp = a.ldp;
+    const int c = j + blockIdx.x * 256 + tid;
+    const bool valid = c < a.n;
+    double tau_p = 0.0, alpha2 = 0.0, wj = 0.0;
+    if (i > 0) {
+        const int ip = i - 1;
+        const double tau = a.colscal[0], scale = a.colscal[1];
+        const double alpha = a.u_prev[j];
+        if (tid < ip) {
+            double d1 = 0.0, d2 = 0.0;
+            for (int b = 0; b < a.nblkA_prev; ++b) {
+                d1 += a.partA_prev[(size_t)b * TRD_PA + 1 + tid];
+                d2 += a.partA_prev[(size_t)b * TRD_PA + 1 + TRD_NBMAX + tid];
+            }
+            const double wpj = a.Wp[(size_t)tid * ldp + j], vpj = a.Vp[(size_t)tid * ldp + j];
+            c1s[tid] = scale * (d1 - wpj * alpha) + wpj;      // W_p . v   (v_j = 1, rest scale*u)
+            c2s[tid] = scale * (d2 - vpj * alpha) + vpj;      // V_p . v
+        }
+        double vw = 0.0;
+        for (int b = tid; b < a.nblkB; b += 256) vw += a.partB[b];
+        vw = block_sum_256(vw, red);                           // (also publishes c1s / c2s)
+        double cc = (tid < ip) ? c1s[tid] * c2s[tid] : 0.0;
+        cc = block_sum_256(cc, red);
+        alpha2 = -0.5 * tau * tau * (vw - 2.0 * cc);
+        tau_p = tau;
+        double t = (tid < ip) ? (a.Vp[(size_t)tid * ldp + j] * c1s[tid] + a.Wp[(size_t)tid * ldp + j] * c2s[tid]) : 0.0;
+        t = block_sum_256(t, red);
+        wj = tau * (a.wraw[j] - t) + alpha2;                   // w_{i-1}[j], v_{i-1}[j] = 1
+    }
+    double wc = 0.0, vprev = 0.0, u = 0.0;
+    if (valid) {
+        if (i > 0) {
+            const int ip = i - 1;
+            double s = 0.0;
+            for (int p = 0; p < ip; ++p)
+                s += a.Vp[(size_t)p * ldp + c] * c1s[p] + a.Wp[(size_t)p * ldp + c] * c2s[p];
+            vprev = a.Vp[(size_t)ip * ldp + c];
+            wc = tau_p * (a.wraw[c] - s) + alpha2 * vprev;
+            a.Wp[(size_t)ip * ldp + c] = wc;
+        }
+        if (a.do_row) {
+            u = a.A[(size_t)j * a.ld + c];
+            for (int p = 0; p + 1 < i; ++p)
+                u -= a.Vp[(size_t)p * ldp + c] * a.Wp[(size_t)p * ldp + j] + a.Wp[(size_t)p * ldp + c] * a.Vp[(size_t)p * ldp + j];
+            if (i > 0) u -= vprev * wj + wc;                    // p = i-1: W[j] = wj, V[j] = 1
+            a.u_cur[c] = u;
+            if (c == j) a.dvec[j] = u;
+        }
+    }
+    if (!a.do_row) return;
+    double* out = a.partA_cur + (size_t)blockIdx.x * TRD_PA;
+    double ss = (valid && c >= j + 2) ? u * u : 0.0;
     ss = block_sum_256(ss, red);
-    const double alpha = x[0];
+    if (tid == 0) out[0] = ss;
+    const double um = (valid && c >= j + 1) ? u : 0.0;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int p = 0; p < i; ++p) {
+        const double wpc = (p == i - 1) ? wc : (valid ? a.Wp[(size_t)p * ldp + c] : 0.0);
+        const double vpc = valid ? a.Vp[(size_t)p * ldp + c] : 0.0;
+        const double r1 = wave_sum_e(wpc * um), r2 = wave_sum_e(vpc * um);
+        if (lane == 0) { s1w[p][wv] = r1; s2w[p][wv] = r2; }
+    }
+    __syncthreads();
+    if (tid < i) {
+        out[1 + tid] = s1w[tid][0] + s1w[tid][1] + s1w[tid][2] + s1w[tid][3];
+        out[1 + TRD_NBMAX + tid] = s2w[tid][0] + s2w[tid][1] + s2w[tid][2] + s2w[tid][3];
+    }
+}
+
+struct TrdGemvArgs {
+    const double* A22;          // A + o*ld + oc   (oc = o rounded down to even: aligned 16-byte rows)
+    int ld, m, shift, o, n, j;
+    const double* ubuf;         // updated row j (absolute column index)
+    const double* partA; int nblkA;
+    double* wraw;               // absolute row index
+    double* partB;
+    double* Vrow;               // Vp + i*ldp
+    double* Arow;               // A + j*ld (reflector tail stored for the back-transformation)
+    double* taus; double* evec; double* colscal;
+};
+
+// K2.  Reflector scalars from the K1 partials, then wraw = A22 v with v = [1, scale*u] staged
+// into LDS on the fly (same streaming structure as gemv_rows_kernel<1, 2>).
+__global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
+    HIP_DYNAMIC_SHARED(double, xs)
+    __shared__ double pv[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double ss = 0.0;
+    for (int b = 0; b < a.nblkA; ++b) ss += a.partA[(size_t)b * TRD_PA];
+    const double alpha = a.ubuf[a.o];
     double beta, tau, scale;
-    if (ss == 0.0) {
-        beta = alpha; tau = 0.0; scale = 0.0;
-    } else {
+    if (ss == 0.0) { beta = alpha; tau = 0.0; scale = 0.0; }
+    else {
         const double nrm = sqrt(alpha * alpha + ss);
         beta = (alpha >= 0.0) ? -nrm : nrm;
         tau = (beta - alpha) / beta;
         scale = 1.0 / (alpha - beta);
     }
-    __syncthreads();
-    for (int i = 1 + threadIdx.x; i < m; i += 256) {
-        const double v = x[i] * scale;
-        x[i] = v;
-        vpad[1 + i] = v;
-    }
-    if (threadIdx.x == 0) {
-        vpad[0] = 0.0;
-        vpad[1] = 1.0;
-        taus[j] = tau;
-        evec[j] = beta;
-        dvec[j] = A[(size_t)j * ld + j];
-    }
-}
-
-// w = tau*q - (tau^2/2)(q.v) v
-__global__ __launch_bounds__(256) void house_w_kernel(const double* __restrict__ q,
-                                                      const double* __restrict__ v,
-                                                      const double* __restrict__ taup, int m,
-                                                      double* __restrict__ w) {
-    __shared__ double red[4];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < m; i += 256) s += q[i] * v[i];
-    s = block_sum_256(s, red);
-    const double tau = taup[0];
-    const double c2 = 0.5 * tau * tau * s;
-    for (int i = threadIdx.x; i < m; i += 256) w[i] = tau * q[i] - c2 * v[i];
-}
-
-// A22[i][k] -= v[i] w[k] + w[i] v[k]; tile = 8 rows x 256 columns per workgroup
-__global__ __launch_bounds__(256) void rank2_kernel(double* __restrict__ A, int ld, int m,
-                                                    const double* __restrict__ v,
-                                                    const double* __restrict__ w) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    const int i0 = blockIdx.y * 8;
-    if (k >= m) return;
-    const double vk = v[k], wk = w[k];
+    const int row0 = (blockIdx.x * 4 + wave) * 2;
+    const double* arow[2];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int i = i0 + r;
-        if (i < m) A[(size_t)i * ld + k] -= v[i] * wk + w[i] * vk;
+    for (int r = 0; r < 2; ++r) {
+        int rr = row0 + r;
+        if (rr > a.m - 1) rr = a.m - 1;
+        arow[r] = a.A22 + (size_t)rr * a.ld;
+    }
+    double acc[2] = {0.0, 0.0};
+    const int cols = a.m + a.shift;
+    const int cols2 = (cols + 1) & ~1;
+    const int cbase = a.o - a.shift;                  // absolute column of local column 0
+    for (int c0 = 0; c0 < cols2; c0 += TRD_TC) {
+        const int tc = (cols2 - c0 < TRD_TC) ? (cols2 - c0) : TRD_TC;
+        for (int jj = threadIdx.x; jj < tc; jj += 256) {
+            const int cabs = cbase + c0 + jj;
+            double xv = 0.0;
+            if (cabs == a.o) xv = 1.0;
+            else if (cabs > a.o && cabs < a.n) xv = scale * a.ubuf[cabs];
+            xs[jj] = xv;
+        }
+        __syncthreads();
+        const int tc2 = tc >> 1;
+        const double2* xs2 = reinterpret_cast<const double2*>(xs);
+#pragma unroll 4
+        for (int jj = lane; jj < tc2; jj += 64) {
+            const double2 xv = xs2[jj];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const double2 av = *reinterpret_cast<const double2*>(arow[r] + c0 + 2 * jj);
+                acc[r] += av.x * xv.x + av.y * xv.y;
+            }
+        }
+        __syncthreads();
+    }
+    acc[0] = wave_sum_e(acc[0]);
+    acc[1] = wave_sum_e(acc[1]);
+    if (lane == 0) {
+        double p = 0.0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int rr = row0 + r;
+            if (rr < a.m) {
+                const int rabs = a.o + rr;
+                const double vr = (rr == 0) ? 1.0 : scale * a.ubuf[rabs];
+                a.wraw[rabs] = acc[r];
+                a.Vrow[rabs] = vr;
+                if (rr > 0) a.Arow[rabs] = vr;
+                p += vr * acc[r];
+            }
+        }
+        pv[wave] = p;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.partB[blockIdx.x] = pv[0] + pv[1] + pv[2] + pv[3];
+        if (blockIdx.x == 0) {
+            a.taus[a.j] = tau;
+            a.evec[a.j] = beta;
+            a.colscal[0] = tau;
+            a.colscal[1] = scale;
+        }
     }
 }
 
@@ -152,17 +282,16 @@ __global__ __launch_bounds__(64) void leaf_ql_kernel(const double* __restrict__ 
     }
 }
 
-// z_i = Zt[rows[i]][col_i] * sign_i with col = mid-1 for the left child, mid for the right one
+// z_i = last component of left-child eigenvector i / sign * first component of right-child ones
 __global__ __launch_bounds__(256) void gather_z_kernel(const double* __restrict__ Zt, int ld, int lo,
                                                        int n1, int N, int mid, double sgn,
                                                        double* __restrict__ z) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    z[i] = (i < n1) ? Zt[(size_t)(lo + i) * ld + mid - 1] : sgn * Zt[(size_t)(lo + i) * ld + mid];
+    z[lo + i] = (i < n1) ? Zt[(size_t)(lo + i) * ld + mid - 1] : sgn * Zt[(size_t)(lo + i) * ld + mid];
 }
 
-// apply a chain of Givens rotations to pairs of rows of the block Zb (N columns); rotation r:
-// x = row i1, y = row i2:  x' = c x + s y ; y' = c y - s x     (BLAS drot convention)
+// chain of Givens rotations on pairs of rows:  x' = c x + s y ; y' = c y - s x   (BLAS drot)
 __global__ __launch_bounds__(256) void rot_rows_kernel(double* __restrict__ Zb, int ld, int N, int nrot,
                                                        const int* __restrict__ i1,
                                                        const int* __restrict__ i2,
@@ -190,8 +319,7 @@ struct WaveProd {
     }
 };
 
-// one WAVEFRONT per root: the 64 lanes split every O(K) sum of the iteration (K wavefronts in
-// flight instead of K/64), all lanes follow the same control flow on wave-reduced values
+// one WAVEFRONT per root: the 64 lanes split every O(K) sum of the iteration
 __global__ __launch_bounds__(256) void secular_kernel(int K, const double* __restrict__ D,
                                                       const double* __restrict__ w, double rho,
                                                       double* __restrict__ tau, int* __restrict__ org,
@@ -244,20 +372,113 @@ __global__ __launch_bounds__(256) void build_u_kernel(int K, const double* __res
 // ---------------------------------------------------------------------------------------
 // stage 3 kernels
 // ---------------------------------------------------------------------------------------
-// Yt[r][c] = r-th reflector of the block (zero-padded, unit at c = j+1); zero row if tau == 0
-__global__ __launch_bounds__(256) void build_y_kernel(const double* __restrict__ A, int ld, int n, int j0,
-                                                      int nb, const double* __restrict__ taus,
-                                                      double* __restrict__ Yt, int ldy) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    const int r = blockIdx.y;
-    if (c >= n || r >= nb) return;
-    const int j = j0 + r;
-    double v = 0.0;
-    if (taus[j] != 0.0) {
-        if (c == j + 1) v = 1.0;
-        else if (c > j + 1) v = A[(size_t)j * ld + c];
+// component c of reflector j as stored by stage 1 (unit head at j+1, tail in A[j][j+2..])
+__device__ __forceinline__ double yval(const double* __restrict__ A, int ld, const double* __restrict__ taus,
+                                       int j, int c) {
+    if (c <= j || taus[j] == 0.0) return 0.0;
+    return (c == j + 1) ? 1.0 : A[(size_t)j * ld + c];
+}
+
+// G[b][p][q] = y_p . y_q for the reflectors of block b  (one workgroup per block)
+__global__ __launch_bounds__(256) void wy_gram_kernel(const double* __restrict__ A, int ld, int n, int nrefl,
+                                                      const double* __restrict__ taus,
+                                                      double* __restrict__ G) {
+    __shared__ double Ys[WY_NB][65];
+    const int b = blockIdx.x;
+    const int j0 = b * WY_NB;
+    const int kb = (nrefl - j0 < WY_NB) ? (nrefl - j0) : WY_NB;
+    const int p = threadIdx.x >> 3, q0 = (threadIdx.x & 7) * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int ct = j0 + 1; ct < n; ct += 64) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < WY_NB * 64; e += 256) {
+            const int r = e >> 6, cc = e & 63;
+            Ys[r][cc] = (r < kb && ct + cc < n) ? yval(A, ld, taus, j0 + r, ct + cc) : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int cc = 0; cc < 64; ++cc) {
+            const double yp = Ys[p][cc];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += yp * Ys[q0 + k][cc];
+        }
     }
-    Yt[(size_t)r * ldy + c] = v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) G[((size_t)b * WY_NB + p) * WY_NB + q0 + k] = acc[k];
+}
+
+// X <- X (H_{nrefl-1} ... H_0): every workgroup owns 16 rows of X and sweeps the compact-WY blocks
+// from the last to the first:  M = X Y_b^T ; M2 = M C_b ; X -= M2 Y_b   with C_b = T_b^T.
+__global__ __launch_bounds__(256) void wy_apply_kernel(double* __restrict__ X, int ldx, int n,
+                                                       const double* __restrict__ A, int ld, int nrefl,
+                                                       const double* __restrict__ taus,
+                                                       const double* __restrict__ Call, int nblk) {
+    __shared__ double Xs[16][65];
+    __shared__ double Ys[WY_NB][65];
+    __shared__ double Ms[16][WY_NB + 1];
+    __shared__ double M2s[16][WY_NB + 1];
+    __shared__ double Cs[WY_NB][WY_NB + 1];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * 16;
+    const int r = tid >> 4, h = tid & 15;
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int j0 = b * WY_NB;
+        const int kb = (nrefl - j0 < WY_NB) ? (nrefl - j0) : WY_NB;
+        const int c0 = j0 + 1;
+        double a0 = 0.0, a1 = 0.0;
+        for (int ct = c0; ct < n; ct += 64) {
+            __syncthreads();
+            for (int e = tid; e < 16 * 64; e += 256) {
+                const int rr = e >> 6, cc = e & 63;
+                Xs[rr][cc] = (r0 + rr < n && ct + cc < n) ? X[(size_t)(r0 + rr) * ldx + ct + cc] : 0.0;
+            }
+            for (int e = tid; e < WY_NB * 64; e += 256) {
+                const int pr = e >> 6, cc = e & 63;
+                Ys[pr][cc] = (pr < kb && ct + cc < n) ? yval(A, ld, taus, j0 + pr, ct + cc) : 0.0;
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int cc = 0; cc < 64; ++cc) {
+                const double x = Xs[r][cc];
+                a0 += x * Ys[2 * h][cc];
+                a1 += x * Ys[2 * h + 1][cc];
+            }
+        }
+        __syncthreads();
+        Ms[r][2 * h] = a0;
+        Ms[r][2 * h + 1] = a1;
+        for (int e = tid; e < WY_NB * WY_NB; e += 256) Cs[e >> 5][e & 31] = Call[(size_t)b * WY_NB * WY_NB + e];
+        __syncthreads();
+        double m0 = 0.0, m1 = 0.0;
+#pragma unroll 8
+        for (int p = 0; p < WY_NB; ++p) {
+            const double mv = Ms[r][p];
+            m0 += mv * Cs[p][2 * h];
+            m1 += mv * Cs[p][2 * h + 1];
+        }
+        M2s[r][2 * h] = m0;
+        M2s[r][2 * h + 1] = m1;
+        for (int ct = c0; ct < n; ct += 64) {
+            __syncthreads();
+            for (int e = tid; e < WY_NB * 64; e += 256) {
+                const int pr = e >> 6, cc = e & 63;
+                Ys[pr][cc] = (pr < kb && ct + cc < n) ? yval(A, ld, taus, j0 + pr, ct + cc) : 0.0;
+            }
+            __syncthreads();
+            if (r0 + r < n) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cc = 4 * h + k, cabs = ct + cc;
+                    if (cabs < n) {
+                        double s = 0.0;
+#pragma unroll 8
+                        for (int q = 0; q < WY_NB; ++q) s += M2s[r][q] * Ys[q][cc];
+                        X[(size_t)(r0 + r) * ldx + cabs] -= s;
+                    }
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -293,13 +514,24 @@ struct EighWork {
     double *A;                 // working copy (n x n), destroyed
     double *Za, *Zb;           // eigenvector rows, ping-pong
     double *Zc, *Ut;           // compacted rows / inner eigenvectors
-    double *vec;               // d, e, tau, vpad, q, w, z, D, w, tau, zhat, lam ... (device)
+    double *vec;               // vectors of length ld (slots)
     int* ibuf;                 // device ints
+};
+
+// vec slots (each ld doubles)
+enum { V_D = 0, V_E, V_W, V_Z, V_CS0, V_CS1, V_DD, V_WD, V_TAU, V_ZH, V_LAM, V_TAUS, V_U0, V_U1, V_WRAW, V_COL,
+       V_NSLOTS };
+
+struct MergePlan {
+    int lo, N, K, nrot;
+    double rho;
+    std::vector<int> nondef, defl, r1, r2;
+    std::vector<double> cs;
 };
 
 }  // namespace
 
-// Divide and conquer on the tridiagonal (d, e) (host copies, modified).  On exit w holds the
+// Divide and conquer on the tridiagonal (d, e) (host copies, modified).  On exit wout holds the
 // ascending eigenvalues and W.Za the eigenvectors as rows in matching order.
 static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e, double* wout) {
     sella_ctx* c = W.c;
@@ -319,17 +551,22 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
             d[nd.mid - 1] -= em;
             d[nd.mid] -= em;
         }
-    double* ddev = W.vec;               // n
-    double* edev = W.vec + W.ld;        // n
-    double* wdev = W.vec + 2 * (size_t)W.ld;   // leaf eigenvalues (n)
+    double* ddev = W.vec + (size_t)V_D * ld;
+    double* edev = W.vec + (size_t)V_E * ld;
+    double* wdev = W.vec + (size_t)V_W * ld;
     HIPCHK(hipMemcpyAsync(ddev, d.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(edev, e.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    // leaves
     const std::vector<int>& leaves = by_height[0];
     std::vector<int> ranges;
     for (int li : leaves) { ranges.push_back(nodes[li].lo); ranges.push_back(nodes[li].hi); }
-    int* info = W.ibuf;                 // 2 ints
+    // device int layout: [0,8) info | [8, 8+2*nleaves) leaf ranges | then 4 arrays of n ints
+    int* info = W.ibuf;
     int* rdev = W.ibuf + 8;
+    int* ibase = W.ibuf + 8 + 2 * (int)leaves.size() + 8;
+    int* i1d = ibase;
+    int* i2d = ibase + n;
+    int* idxd = ibase + 2 * n;
+    int* orgd = ibase + 3 * n;
     HIPCHK(hipMemsetAsync(info, 0, 8 * sizeof(int), c->stream));
     HIPCHK(hipMemcpyAsync(rdev, ranges.data(), ranges.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(set_identity_kernel, dim3((n + 255) / 256, n), dim3(256), 0, c->stream, W.Za, ld, n);
@@ -349,124 +586,127 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
     const double eps = 2.220446049250313e-16;
     double* cur = W.Za;
     double* nxt = W.Zb;
-    std::vector<double> z, Dn, wn, cs, lam;
-    std::vector<int> order, nondef, defl, r1, r2, idx;
+    double* zdev = W.vec + (size_t)V_Z * ld;
+    double* csd = W.vec + (size_t)V_CS0 * ld;          // 2 slots: (c, s) pairs
+    double* Dd = W.vec + (size_t)V_DD * ld;
+    double* wd = W.vec + (size_t)V_WD * ld;
+    double* taud = W.vec + (size_t)V_TAU * ld;
+    double* zhd = W.vec + (size_t)V_ZH * ld;
+    double* lamd = W.vec + (size_t)V_LAM * ld;
+    std::vector<double> z(n), lam(n), hD(n), hw(n), hcs(2 * (size_t)n);
+    std::vector<int> order, hidx(n), hr1(n), hr2(n);
     for (int h = 1; h <= maxdepth; ++h) {
-        // eigenvector rows of a node are supported on its own column range only: the blocks of
+        const std::vector<int>& lvl = by_height[h];
+        // eigenvector rows of a node are supported on its own column range only: everything of
         // `nxt` outside the diagonal blocks written below must read as zero at the next level
         HIPCHK(hipMemsetAsync(nxt, 0, (size_t)n * ld * sizeof(double), c->stream));
-        for (int ni : by_height[h]) {
+        // ---- (1) rank-one vectors of all merges of this level, one synchronisation ------------
+        for (int ni : lvl) {
             const Node& nd = nodes[ni];
-            const int lo = nd.lo, hi = nd.hi, mid = nd.mid, N = hi - lo, n1 = mid - lo;
-            const double em = e[mid - 1];
-            double* zdev = W.vec + 2 * (size_t)W.ld;
-            hipLaunchKernelGGL(gather_z_kernel, dim3((N + 255) / 256), dim3(256), 0, c->stream, cur, ld, lo, n1, N,
-                               mid, em < 0 ? -1.0 : 1.0, zdev);
-            HIPCHK(hipGetLastError());
-            z.resize(N);
-            HIPCHK(hipMemcpyAsync(z.data(), zdev, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            double* D = vals.data() + lo;       // eigenvalues of the two children, row order
-            // ---- deflation (host) ------------------------------------------------------------
-            const double rho = fabs(2.0 * em);
+            const int N = nd.hi - nd.lo;
+            hipLaunchKernelGGL(gather_z_kernel, dim3((N + 255) / 256), dim3(256), 0, c->stream, cur, ld, nd.lo,
+                               nd.mid - nd.lo, N, nd.mid, e[nd.mid - 1] < 0 ? -1.0 : 1.0, zdev);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(z.data(), zdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        // ---- (2) deflation of every merge on the host (dlaed2 logic) ------------------------------
+        std::vector<MergePlan> plans(lvl.size());
+        for (size_t mi = 0; mi < lvl.size(); ++mi) {
+            const Node& nd = nodes[lvl[mi]];
+            MergePlan& pl = plans[mi];
+            const int lo = nd.lo, N = nd.hi - nd.lo;
+            double* D = vals.data() + lo;
+            double* zz = z.data() + lo;
+            pl.lo = lo;
+            pl.N = N;
+            pl.rho = fabs(2.0 * e[nd.mid - 1]);
             double zmax = 0.0, dmax = 0.0;
             for (int i = 0; i < N; ++i) {
-                z[i] *= 0.7071067811865476;
-                zmax = std::max(zmax, fabs(z[i]));
+                zz[i] *= 0.7071067811865476;
+                zmax = std::max(zmax, fabs(zz[i]));
                 dmax = std::max(dmax, fabs(D[i]));
             }
             const double tol = 8.0 * eps * std::max(dmax, zmax);
             order.resize(N);
             std::iota(order.begin(), order.end(), 0);
             std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return D[a] < D[b]; });
-            nondef.clear(); defl.clear(); r1.clear(); r2.clear(); cs.clear();
-            if (rho * zmax <= tol) {
-                defl = order;
+            if (pl.rho * zmax <= tol) {
+                pl.defl = order;
             } else {
                 int pj = -1;
                 for (int jj = 0; jj < N; ++jj) {
                     const int nj = order[jj];
-                    if (rho * fabs(z[nj]) <= tol) { defl.push_back(nj); continue; }
+                    if (pl.rho * fabs(zz[nj]) <= tol) { pl.defl.push_back(nj); continue; }
                     if (pj < 0) { pj = nj; continue; }
-                    double s = z[pj], cc = z[nj];
+                    double s = zz[pj], cc = zz[nj];
                     const double tau = hypot(cc, s);
                     const double t = D[nj] - D[pj];
                     cc /= tau;
                     s = -s / tau;
                     if (fabs(t * cc * s) <= tol) {
-                        z[nj] = tau;
-                        z[pj] = 0.0;
-                        r1.push_back(pj); r2.push_back(nj); cs.push_back(cc); cs.push_back(s);
+                        zz[nj] = tau;
+                        zz[pj] = 0.0;
+                        pl.r1.push_back(pj); pl.r2.push_back(nj); pl.cs.push_back(cc); pl.cs.push_back(s);
                         const double tt = D[pj] * cc * cc + D[nj] * s * s;
                         D[nj] = D[pj] * s * s + D[nj] * cc * cc;
                         D[pj] = tt;
-                        defl.push_back(pj);
+                        pl.defl.push_back(pj);
                         pj = nj;
                     } else {
-                        nondef.push_back(pj);
+                        pl.nondef.push_back(pj);
                         pj = nj;
                     }
                 }
-                if (pj >= 0) nondef.push_back(pj);
+                if (pj >= 0) pl.nondef.push_back(pj);
             }
-            const int K = (int)nondef.size();
-            const int nrot = (int)r1.size();
-            if (getenv("SELLA_DEBUG")) {
-                fprintf(stderr, "merge [%d,%d) mid %d em %g rho %g K %d nrot %d\n  D:", lo, hi, mid, em, rho, K, nrot);
-                for (int i = 0; i < N; ++i) fprintf(stderr, " %.6f", D[i]);
-                fprintf(stderr, "\n  z:");
-                for (int i = 0; i < N; ++i) fprintf(stderr, " %.6f", z[i]);
-                fprintf(stderr, "\n");
+            pl.K = (int)pl.nondef.size();
+            pl.nrot = (int)pl.r1.size();
+            // staging (offset lo inside n-length host arrays; blocks of different merges are disjoint)
+            for (int p = 0; p < pl.K; ++p) {
+                hD[lo + p] = D[pl.nondef[p]];
+                hw[lo + p] = zz[pl.nondef[p]];
+                hidx[lo + p] = lo + pl.nondef[p];
             }
-            if (nrot > 0) {
-                int* i1d = W.ibuf + 16 + 2 * (int)leaves.size() + 16;
-                int* i2d = i1d + N;
-                double* csd = W.vec + 3 * (size_t)W.ld;    // 2*N doubles (two ld slots)
-                HIPCHK(hipMemcpyAsync(i1d, r1.data(), (size_t)nrot * sizeof(int), hipMemcpyHostToDevice, c->stream));
-                HIPCHK(hipMemcpyAsync(i2d, r2.data(), (size_t)nrot * sizeof(int), hipMemcpyHostToDevice, c->stream));
-                HIPCHK(hipMemcpyAsync(csd, cs.data(), (size_t)2 * nrot * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            for (int p = 0; p < N - pl.K; ++p) hidx[lo + pl.K + p] = lo + pl.defl[p];
+            for (int r = 0; r < pl.nrot; ++r) {
+                hr1[lo + r] = pl.r1[r];
+                hr2[lo + r] = pl.r2[r];
+                hcs[2 * (size_t)(lo + r)] = pl.cs[2 * r];
+                hcs[2 * (size_t)(lo + r) + 1] = pl.cs[2 * r + 1];
+            }
+        }
+        HIPCHK(hipMemcpyAsync(Dd, hD.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(wd, hw.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(idxd, hidx.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(i1d, hr1.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(i2d, hr2.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(csd, hcs.data(), (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        // ---- (3) device work of every merge, no synchronisation in between ----------------------------
+        for (size_t mi = 0; mi < lvl.size(); ++mi) {
+            const MergePlan& pl = plans[mi];
+            const int lo = pl.lo, N = pl.N, K = pl.K;
+            if (pl.nrot > 0)
                 hipLaunchKernelGGL(rot_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, c->stream,
-                                   cur + (size_t)lo * ld + lo, ld, N, nrot, i1d, i2d, csd);
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipStreamSynchronize(c->stream));   // host vectors are re-used below
-            }
-            // the nondeflated D may have lost strict ordering by a rounding; keep as produced
-            // ---- secular equation + inner eigenvectors (device) ----------------------------------
-            idx.clear();
-            for (int i : nondef) idx.push_back(lo + i);
-            for (int i : defl) idx.push_back(lo + i);
-            int* idxd = W.ibuf + 16 + 2 * (int)leaves.size() + 16 + 2 * n;
-            HIPCHK(hipMemcpyAsync(idxd, idx.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, c->stream));
-            lam.assign(N, 0.0);
+                                   cur + (size_t)lo * ld + lo, ld, N, pl.nrot, i1d + lo, i2d + lo, csd + 2 * (size_t)lo);
             if (K > 0) {
-                Dn.resize(K); wn.resize(K);
-                for (int p = 0; p < K; ++p) { Dn[p] = D[nondef[p]]; wn[p] = z[nondef[p]]; }
-                double* Dd = W.vec + 5 * (size_t)W.ld;
-                double* wd = W.vec + 6 * (size_t)W.ld;
-                double* taud = W.vec + 7 * (size_t)W.ld;
-                double* zhd = W.vec + 8 * (size_t)W.ld;
-                double* lamd = W.vec + 9 * (size_t)W.ld;
-                int* orgd = W.ibuf + 16 + 2 * (int)leaves.size() + 16 + 3 * n;
-                HIPCHK(hipMemcpyAsync(Dd, Dn.data(), (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-                HIPCHK(hipMemcpyAsync(wd, wn.data(), (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-                hipLaunchKernelGGL(secular_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd, wd, rho, taud,
-                                   orgd, lamd, info);
-                hipLaunchKernelGGL(zhat_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd, wd, taud, orgd, zhd);
-                const int ldu = round_up(K, 8);
-                hipLaunchKernelGGL(build_u_kernel, dim3(K), dim3(256), 0, c->stream, K, Dd, zhd, taud, orgd, W.Ut, ldu);
+                hipLaunchKernelGGL(secular_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd + lo, wd + lo,
+                                   pl.rho, taud + lo, orgd + lo, lamd + lo, info);
+                hipLaunchKernelGGL(zhat_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd + lo, wd + lo,
+                                   taud + lo, orgd + lo, zhd + lo);
+                double* Ub = W.Ut + (size_t)lo * ld + lo;
+                hipLaunchKernelGGL(build_u_kernel, dim3(K), dim3(256), 0, c->stream, K, Dd + lo, zhd + lo, taud + lo,
+                                   orgd + lo, Ub, ld);
                 HIPCHK(hipGetLastError());
-                // compact the non-deflated rows (sorted) and multiply
-                SCHK(launch_gather_rows(c, cur + lo, ld, idxd, K, N, W.Zc, ld));
-                SCHK(launch_gemm(c, 0, 0, K, N, K, 1.0, W.Ut, ldu, W.Zc, ld, 0.0, nxt + (size_t)lo * ld + lo, ld));
-                HIPCHK(hipMemcpyAsync(lam.data(), lamd, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                double* Zcb = W.Zc + (size_t)lo * ld + lo;
+                SCHK(launch_gather_rows(c, cur + lo, ld, idxd + lo, K, N, Zcb, ld));
+                SCHK(launch_gemm(c, 0, 0, K, N, K, 1.0, Ub, ld, Zcb, ld, 0.0, nxt + (size_t)lo * ld + lo, ld));
             }
             if (N - K > 0)
-                SCHK(launch_gather_rows(c, cur + lo, ld, idxd + K, N - K, N, nxt + (size_t)(lo + K) * ld + lo, ld));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            for (int p = 0; p < N - K; ++p) lam[K + p] = D[defl[p]];
-            for (int p = 0; p < N; ++p) D[p] = lam[p];
+                SCHK(launch_gather_rows(c, cur + lo, ld, idxd + lo + K, N - K, N, nxt + (size_t)(lo + K) * ld + lo, ld));
         }
-        std::swap(cur, nxt);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(lam.data(), lamd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         int hi2[2];
         HIPCHK(hipMemcpyAsync(hi2, info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -474,17 +714,93 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
             set_error("eigh: secular equation solver hit its iteration cap (root %d)", hi2[1] - 1);
             return SELLA_E_NOCONV;
         }
+        for (size_t mi = 0; mi < lvl.size(); ++mi) {
+            const MergePlan& pl = plans[mi];
+            double* D = vals.data() + pl.lo;
+            std::vector<double> nv(pl.N);
+            for (int p = 0; p < pl.K; ++p) nv[p] = lam[pl.lo + p];
+            for (int p = 0; p < pl.N - pl.K; ++p) nv[pl.K + p] = D[pl.defl[p]];
+            for (int p = 0; p < pl.N; ++p) D[p] = nv[p];
+        }
+        std::swap(cur, nxt);
     }
     // final ascending order
     order.resize(n);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return vals[a] < vals[b]; });
     for (int i = 0; i < n; ++i) wout[i] = vals[order[i]];
-    int* idxd = W.ibuf + 16 + 2 * (int)leaves.size() + 16 + 2 * n;
     HIPCHK(hipMemcpyAsync(idxd, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
     SCHK(launch_gather_rows(c, cur, ld, idxd, n, n, nxt, ld));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (nxt != W.Za) std::swap(W.Za, W.Zb);
+    return SELLA_OK;
+}
+
+// Blocked tridiagonalisation of W.A (destroyed; reflector tails are left in its rows).
+static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec) {
+    sella_ctx* c = W.c;
+    const int n = W.n, ld = W.ld;
+    int nb = (int)c->opt.eigh_nb;
+    if (nb > TRD_NBMAX) nb = TRD_NBMAX;
+    const int nrefl = n - 2;
+    double *Vp, *Wp, *part;
+    SCHK(scratch_get(c, SCR_MISC0, (size_t)2 * TRD_NBMAX * ld * sizeof(double), &Vp));
+    Wp = Vp + (size_t)TRD_NBMAX * ld;
+    const int maxblkA = (n + 255) / 256 + 1, maxblkB = (n + 7) / 8 + 1;
+    SCHK(scratch_get(c, SCR_MISC1, ((size_t)2 * maxblkA * TRD_PA + maxblkB + 64) * sizeof(double), &part));
+    double* partA[2] = {part, part + (size_t)maxblkA * TRD_PA};
+    double* partB = part + 2 * (size_t)maxblkA * TRD_PA;
+    double* ub[2] = {W.vec + (size_t)V_U0 * ld, W.vec + (size_t)V_U1 * ld};
+    double* wraw = W.vec + (size_t)V_WRAW * ld;
+    double* colscal = W.vec + (size_t)V_COL * ld;
+    int cur = 0, nblkA_prev = 0, nblkB_prev = 0;
+    for (int j0 = 0; j0 < nrefl; j0 += nb) {
+        const int kb = std::min(nb, nrefl - j0);
+        HIPCHK(hipMemsetAsync(Vp, 0, (size_t)2 * TRD_NBMAX * ld * sizeof(double), c->stream));
+        for (int i = 0; i <= kb; ++i) {
+            const int j = j0 + i;
+            const bool do_row = i < kb;
+            TrdRowArgs ra;
+            ra.A = W.A; ra.ld = ld; ra.n = n; ra.j = j; ra.i = i; ra.do_row = do_row ? 1 : 0;
+            ra.Vp = Vp; ra.Wp = Wp; ra.ldp = ld;
+            ra.u_prev = ub[1 - cur]; ra.u_cur = ub[cur];
+            ra.wraw = wraw;
+            ra.partA_prev = partA[1 - cur]; ra.nblkA_prev = nblkA_prev;
+            ra.partA_cur = partA[cur];
+            ra.partB = partB; ra.nblkB = nblkB_prev;
+            ra.colscal = colscal;
+            ra.dvec = dvec;
+            const int nblkA = (n - j + 255) / 256;
+            hipLaunchKernelGGL(trd_row_kernel, dim3(nblkA), dim3(256), 0, c->stream, ra);
+            if (!do_row) break;
+            const int o = j + 1, m = n - o, oc = o & ~1;
+            TrdGemvArgs ga;
+            ga.A22 = W.A + (size_t)o * ld + oc; ga.ld = ld; ga.m = m; ga.shift = o - oc; ga.o = o; ga.n = n; ga.j = j;
+            ga.ubuf = ub[cur];
+            ga.partA = partA[cur]; ga.nblkA = nblkA;
+            ga.wraw = wraw; ga.partB = partB;
+            ga.Vrow = Vp + (size_t)i * ld;
+            ga.Arow = W.A + (size_t)j * ld;
+            ga.taus = taus; ga.evec = evec; ga.colscal = colscal;
+            const int nblkB = (m + 7) / 8;
+            prof_begin(c, PROF_GEMV, 8.0 * m * (double)m, 2.0 * m * (double)m);
+            hipLaunchKernelGGL(trd_gemv_kernel, dim3(nblkB), dim3(256), TRD_TC * sizeof(double), c->stream, ga);
+            prof_end(c);
+            nblkA_prev = nblkA;
+            nblkB_prev = nblkB;
+            cur = 1 - cur;
+        }
+        HIPCHK(hipGetLastError());
+        // trailing update A22 -= V^T W + W^T V over rows/columns >= j0 + kb
+        const int r0 = j0 + kb, mt = n - r0;
+        if (mt > 0) {
+            double* At = W.A + (size_t)r0 * ld + r0;
+            SCHK(launch_gemm(c, 1, 0, mt, mt, kb, -1.0, Vp + r0, ld, Wp + r0, ld, 1.0, At, ld));
+            SCHK(launch_gemm(c, 1, 0, mt, mt, kb, -1.0, Wp + r0, ld, Vp + r0, ld, 1.0, At, ld));
+        }
+    }
+    hipLaunchKernelGGL(tridiag_tail_kernel, dim3(1), dim3(64), 0, c->stream, W.A, ld, n, dvec, evec, taus);
+    HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
 
@@ -500,105 +816,76 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     const int ld = round_up(n, 8);
     EighWork W;
     W.c = c; W.n = n; W.ld = ld;
-    // (the compact-WY work arrays of stage 3 need at least 64 rows / columns)
     const size_t mbytes = ((size_t)std::max(n, 64) + 2) * std::max(ld, 64) * sizeof(double);
     SCHK(scratch_get(c, SCR_EIG0, mbytes, &W.A));
     SCHK(scratch_get(c, SCR_EIG1, mbytes, &W.Za));
     SCHK(scratch_get(c, SCR_EIG2, mbytes, &W.Zb));
     SCHK(scratch_get(c, SCR_EIG3, mbytes, &W.Zc));
     SCHK(scratch_get(c, SCR_EIG4, mbytes, &W.Ut));
-    SCHK(scratch_get(c, SCR_EIG5, (size_t)16 * ld * sizeof(double) + (size_t)(6 * n + 256) * sizeof(int), &W.vec));
-    W.ibuf = reinterpret_cast<int*>(W.vec + 16 * (size_t)ld);
+    SCHK(scratch_get(c, SCR_EIG5, (size_t)V_NSLOTS * ld * sizeof(double) + (size_t)(6 * n + 256) * sizeof(int), &W.vec));
+    W.ibuf = reinterpret_cast<int*>(W.vec + (size_t)V_NSLOTS * ld);
     a = mat_get(c, hA);
     SCHK(launch_axpby2d(c, n, n, 1.0, a->d, a->ld, 0.0, nullptr, 0, W.A, ld));
 
-    // ---- stage 1: tridiagonalisation --------------------------------------------------------
-    double* dvec = W.vec;
-    double* evec = W.vec + ld;
-    double* taus = W.vec + 10 * (size_t)ld;
-    double* vpad = W.vec + 11 * (size_t)ld;     // 1 + m values (+ slack)
-    double* qv = W.vec + 13 * (size_t)ld;
-    double* wv = W.vec + 14 * (size_t)ld;
-    HIPCHK(hipMemsetAsync(vpad, 0, 2 * (size_t)ld * sizeof(double), c->stream));
-    for (int j = 0; j + 2 < n; ++j) {
-        const int m = n - j - 1, o = j + 1;
-        hipLaunchKernelGGL(house_gen_kernel, dim3(1), dim3(256), 0, c->stream, W.A, ld, n, j, vpad, taus, dvec, evec);
-        HIPCHK(hipGetLastError());
-        // q = A22 v ; start the row stream at an even column so 16-byte loads stay aligned
-        const int oc = o & ~1;
-        const double* x = vpad + 1 - (o - oc);
-        SCHK(launch_gemv_rows(c, W.A + (size_t)o * ld + oc, m, m + (o - oc), ld, x, ld, 1, qv, ld, GemvEpi()));
-        hipLaunchKernelGGL(house_w_kernel, dim3(1), dim3(256), 0, c->stream, qv, vpad + 1, taus + j, m, wv);
-        hipLaunchKernelGGL(rank2_kernel, dim3((m + 255) / 256, (m + 7) / 8), dim3(256), 0, c->stream,
-                           W.A + (size_t)o * ld + o, ld, m, vpad + 1, wv);
-        HIPCHK(hipGetLastError());
-    }
-    hipLaunchKernelGGL(tridiag_tail_kernel, dim3(1), dim3(64), 0, c->stream, W.A, ld, n, dvec, evec, taus);
-    HIPCHK(hipGetLastError());
+    // ---- stage 1 ----------------------------------------------------------------------------
+    double* dvec = W.vec + (size_t)V_D * ld;
+    double* evec = W.vec + (size_t)V_E * ld;
+    double* taus = W.vec + (size_t)V_TAUS * ld;
+    HIPCHK(hipMemsetAsync(W.vec, 0, (size_t)V_NSLOTS * ld * sizeof(double), c->stream));
+    SCHK(tridiagonalise(W, taus, dvec, evec));
     std::vector<double> d(n), e(n), tauh(n);
     HIPCHK(hipMemcpyAsync(d.data(), dvec, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(e.data(), evec, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(tauh.data(), taus, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
 
-    // ---- stage 2: divide and conquer on T ------------------------------------------------------
+    // ---- stage 2 ----------------------------------------------------------------------------
     SCHK(dc_solve(W, d, e, w));
     if (!hV && !hVt) return SELLA_OK;
 
-    // ---- stage 3: X = Z H_{n-3} ... H_0 (rows), compact-WY blocks from the last to the first ----
+    // ---- stage 3: X = Z H_{n-3} ... H_0 (rows) -------------------------------------------------
     double* X = W.Za;
     const int nrefl = n - 2;
     if (nrefl > 0) {
-        const int nb = 32;
-        double* Yt = W.Zb;                       // nb x n
-        double* Wt = W.Zb + (size_t)nb * ld;     // nb x n
-        double* Mx = W.Zc;                       // n x nb (ld = nbp)
-        double* Gd = W.Ut;                       // nb x nb
-        const int nbp = round_up(nb, 8);
-        std::vector<double> G((size_t)nb * nb), S((size_t)nb * nb), Tm((size_t)nb * nb);
-        const int nblk = (nrefl + nb - 1) / nb;
-        for (int b = nblk - 1; b >= 0; --b) {
-            const int j0 = b * nb;
-            const int kb = std::min(nb, nrefl - j0);
-            const int c0 = j0 + 1;               // first column touched by this block
-            const int nc = n - c0;
-            hipLaunchKernelGGL(build_y_kernel, dim3((n + 255) / 256, kb), dim3(256), 0, c->stream, W.A, ld, n, j0, kb,
-                               taus, Yt, ld);
-            HIPCHK(hipGetLastError());
-            SCHK(launch_gemm(c, 0, 1, kb, kb, nc, 1.0, Yt + c0, ld, Yt + c0, ld, 0.0, Gd, nbp));
-            HIPCHK(hipMemcpy2DAsync(G.data(), (size_t)kb * sizeof(double), Gd, (size_t)nbp * sizeof(double),
-                                    (size_t)kb * sizeof(double), kb, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            // S = striu(G) + diag(1/tau) ; T = S^-1 (upper) ; we need C = T^T
+        const int nblk = (nrefl + WY_NB - 1) / WY_NB;
+        double* Gd = W.Zb;                               // nblk x 32 x 32 Gram matrices, then C = T^T
+        const size_t gcount = (size_t)nblk * WY_NB * WY_NB;
+        hipLaunchKernelGGL(wy_gram_kernel, dim3(nblk), dim3(256), 0, c->stream, W.A, ld, n, nrefl, taus, Gd);
+        HIPCHK(hipGetLastError());
+        std::vector<double> G(gcount), Call(gcount, 0.0);
+        HIPCHK(hipMemcpyAsync(G.data(), Gd, gcount * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::vector<double> S((size_t)WY_NB * WY_NB), Tm((size_t)WY_NB * WY_NB);
+        for (int b = 0; b < nblk; ++b) {
+            const int j0 = b * WY_NB, kb = std::min(WY_NB, nrefl - j0);
+            const double* Gb = G.data() + (size_t)b * WY_NB * WY_NB;
+            // T^-1 = striu(Y^T Y) + diag(1/tau)  (forward, columnwise compact WY)
             for (int i = 0; i < kb; ++i)
                 for (int k2 = 0; k2 < kb; ++k2) {
                     double v = 0.0;
-                    if (k2 > i) v = G[(size_t)i * kb + k2];
+                    if (k2 > i) v = Gb[(size_t)i * WY_NB + k2];
                     else if (k2 == i) v = (tauh[j0 + i] != 0.0) ? 1.0 / tauh[j0 + i] : 1.0;
                     S[(size_t)i * kb + k2] = v;
                 }
-            // invert upper-triangular S by back substitution, column by column
-            for (int col = 0; col < kb; ++col) {
+            for (int col = 0; col < kb; ++col)
                 for (int i = kb - 1; i >= 0; --i) {
                     double s = (i == col) ? 1.0 : 0.0;
                     for (int k2 = i + 1; k2 < kb; ++k2) s -= S[(size_t)i * kb + k2] * Tm[(size_t)k2 * kb + col];
                     Tm[(size_t)i * kb + col] = (i <= col) ? s / S[(size_t)i * kb + i] : 0.0;
                 }
-            }
-            // upload C = T^T (kb x kb) into Gd
-            std::vector<double> Cm((size_t)kb * kb);
-            for (int i = 0; i < kb; ++i)
-                for (int k2 = 0; k2 < kb; ++k2) Cm[(size_t)i * kb + k2] = Tm[(size_t)k2 * kb + i];
-            HIPCHK(hipMemcpy2DAsync(Gd, (size_t)nbp * sizeof(double), Cm.data(), (size_t)kb * sizeof(double),
-                                    (size_t)kb * sizeof(double), kb, hipMemcpyHostToDevice, c->stream));
-            // Wt = C Yt ; Mx = X Yt^T ; X -= Mx Wt      (columns c0..n only)
-            SCHK(launch_gemm(c, 0, 0, kb, nc, kb, 1.0, Gd, nbp, Yt + c0, ld, 0.0, Wt + c0, ld));
-            SCHK(launch_gemm(c, 0, 1, n, kb, nc, 1.0, X + c0, ld, Yt + c0, ld, 0.0, Mx, nbp));
-            SCHK(launch_gemm(c, 0, 0, n, nc, kb, -1.0, Mx, nbp, Wt + c0, ld, 1.0, X + c0, ld));
-            HIPCHK(hipStreamSynchronize(c->stream));   // Cm goes out of scope
+            double* Cb = Call.data() + (size_t)b * WY_NB * WY_NB;      // C[p][q] = T[q][p]
+            for (int p = 0; p < kb; ++p)
+                for (int q = 0; q < kb; ++q) Cb[(size_t)p * WY_NB + q] = Tm[(size_t)q * kb + p];
         }
+        HIPCHK(hipMemcpyAsync(Gd, Call.data(), gcount * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        prof_begin(c, PROF_OTHER, 0.0, 2.0 * n * (double)n * n);
+        hipLaunchKernelGGL(wy_apply_kernel, dim3((n + 15) / 16), dim3(256), 0, c->stream, X, ld, n, W.A, ld, nrefl,
+                           taus, Gd, nblk);
+        prof_end(c);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));        // Call goes out of scope
     }
-    // ---- outputs ---------------------------------------------------------------------------------
+    // ---- outputs -------------------------------------------------------------------------------
     sella_mat vt = SELLA_NO_MAT, v = SELLA_NO_MAT;
     SCHK(mat_new(c, n, n, &vt));
     Mat* mvt = mat_get(c, vt);

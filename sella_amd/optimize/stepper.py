@@ -55,7 +55,11 @@ class BaseStepper:
     def _stepper_init(self) -> None:
         ctx = get_context()
         evals, V, Vt = self._device_eig()
-        if self.U is not None:
+        U = self.U
+        if U is not None and U.shape[0] == U.shape[1] and U[0, 0] == 1.0 \
+                and np.count_nonzero(U) == U.shape[0] and np.all(np.diag(U) == 1.0):
+            U = None                                  # unconstrained: the basis is the identity
+        if U is not None:
             # compose the projection with the eigenbasis once: (U V) is n x m
             dU = ctx.upload(self.U)
             VU = ctx.zeros(self.U.shape[0], V.shape[1])

@@ -29,7 +29,7 @@ namespace sella {
 namespace {
 
 constexpr int TRD_NBMAX = 64;              // max panel width
-constexpr int TRD_PA = 1 + 2 * TRD_NBMAX;  // doubles per block in the K1 partial buffer
+constexpr int TRD_PA = 1;                  // doubles per block in the K1 partial buffer (sum u^2)
 constexpr int WY_NB = 32;                  // reflectors per compact-WY block
 constexpr int TRD_TC = 2048;               // column tile of the fused matvec
 
@@ -63,16 +63,16 @@ struct TrdRowArgs {
     double* partA_cur;
     const double* partB; int nblkB;             // v.wraw partials of column j-1
     const double* colscal;                      // {tau, scale} of column j-1
+    const double* cdots;                        // W_p.v (p < i-1) at [p], V_p.v at [TRD_NBMAX + p] (from K2)
     double* dvec;
 };
 
 // K1.  Thread owns absolute column c = j + blockIdx.x*256 + tid.
 //   (1) i > 0: finish w_{i-1} = tau (wraw - V c1 - W c2) + alpha2 v   (dlatrd), store in Wp
 //   (2) u[c] = A[j][c] - sum_{p<i} (V_p[c] W_p[j] + W_p[c] V_p[j])    (pending rank-2i update)
-//   (3) per-block partials: sum u^2 (c >= j+2), W_p.u and V_p.u (c >= j+1) for p < i
+//   (3) per-block partial of sum u^2 (c >= j+2)
 __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
     __shared__ double c1s[TRD_NBMAX], c2s[TRD_NBMAX], red[4];
-    __shared__ double s1w[TRD_NBMAX][4], s2w[TRD_NBMAX][4];
     const int tid = threadIdx.x;
     const int j = a.j, i = a.i, ldp = a.ldp;
     const int c = j + blockIdx.x * 256 + tid;
@@ -80,17 +80,10 @@ __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
     double tau_p = 0.0, alpha2 = 0.0, wj = 0.0;
     if (i > 0) {
         const int ip = i - 1;
-        const double tau = a.colscal[0], scale = a.colscal[1];
-        const double alpha = a.u_prev[j];
+        const double tau = a.colscal[0];
         if (tid < ip) {
-            double d1 = 0.0, d2 = 0.0;
-            for (int b = 0; b < a.nblkA_prev; ++b) {
-                d1 += a.partA_prev[(size_t)b * TRD_PA + 1 + tid];
-                d2 += a.partA_prev[(size_t)b * TRD_PA + 1 + TRD_NBMAX + tid];
-            }
-            const double wpj = a.Wp[(size_t)tid * ldp + j], vpj = a.Vp[(size_t)tid * ldp + j];
-            c1s[tid] = scale * (d1 - wpj * alpha) + wpj;      // W_p . v   (v_j = 1, rest scale*u)
-            c2s[tid] = scale * (d2 - vpj * alpha) + vpj;      // V_p . v
+            c1s[tid] = a.cdots[tid];                            // W_p . v
+            c2s[tid] = a.cdots[TRD_NBMAX + tid];                // V_p . v
         }
         double vw = 0.0;
         for (int b = tid; b < a.nblkB; b += 256) vw += a.partB[b];
@@ -128,19 +121,6 @@ __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
     double ss = (valid && c >= j + 2) ? u * u : 0.0;
     ss = block_sum_256(ss, red);
     if (tid == 0) out[0] = ss;
-    const double um = (valid && c >= j + 1) ? u : 0.0;
-    const int lane = tid & 63, wv = tid >> 6;
-    for (int p = 0; p < i; ++p) {
-        const double wpc = (p == i - 1) ? wc : (valid ? a.Wp[(size_t)p * ldp + c] : 0.0);
-        const double vpc = valid ? a.Vp[(size_t)p * ldp + c] : 0.0;
-        const double r1 = wave_sum_e(wpc * um), r2 = wave_sum_e(vpc * um);
-        if (lane == 0) { s1w[p][wv] = r1; s2w[p][wv] = r2; }
-    }
-    __syncthreads();
-    if (tid < i) {
-        out[1 + tid] = s1w[tid][0] + s1w[tid][1] + s1w[tid][2] + s1w[tid][3];
-        out[1 + TRD_NBMAX + tid] = s2w[tid][0] + s2w[tid][1] + s2w[tid][2] + s2w[tid][3];
-    }
 }
 
 struct TrdGemvArgs {
@@ -153,10 +133,14 @@ struct TrdGemvArgs {
     double* Vrow;               // Vp + i*ldp
     double* Arow;               // A + j*ld (reflector tail stored for the back-transformation)
     double* taus; double* evec; double* colscal;
+    const double* Wp; const double* Vp; int ldp, i;   // panel rows appended to the matvec: exact W_p.v, V_p.v
+    double* cdots;
 };
 
 // K2.  Reflector scalars from the K1 partials, then wraw = A22 v with v = [1, scale*u] staged
-// into LDS on the fly (same streaming structure as gemv_rows_kernel<1, 2>).
+// into LDS on the fly (same streaming structure as gemv_rows_kernel<1, 2>).  The 2i panel rows
+// W_p, V_p (p < i) are appended as extra rows of the same launch: a wavefront streams a whole row, so
+// the dots the next column needs (dlatrd's W^T v, V^T v) come out exact, without partial buffers.
 __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
     HIP_DYNAMIC_SHARED(double, xs)
     __shared__ double pv[8];
@@ -173,12 +157,16 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
         scale = 1.0 / (alpha - beta);
     }
     const int row0 = (blockIdx.x * 4 + wave) * 2;
+    const int mtot = a.m + 2 * a.i;
+    const int oc = a.o - a.shift;
     const double* arow[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         int rr = row0 + r;
-        if (rr > a.m - 1) rr = a.m - 1;
-        arow[r] = a.A22 + (size_t)rr * a.ld;
+        if (rr > mtot - 1) rr = mtot - 1;
+        if (rr < a.m) arow[r] = a.A22 + (size_t)rr * a.ld;
+        else if (rr < a.m + a.i) arow[r] = a.Wp + (size_t)(rr - a.m) * a.ldp + oc;
+        else arow[r] = a.Vp + (size_t)(rr - a.m - a.i) * a.ldp + oc;
     }
     double acc[2] = {0.0, 0.0};
     const int cols = a.m + a.shift;
@@ -221,6 +209,10 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
                 a.Vrow[rabs] = vr;
                 if (rr > 0) a.Arow[rabs] = vr;
                 p += vr * acc[r];
+            } else if (rr < a.m + a.i) {
+                a.cdots[rr - a.m] = acc[r];
+            } else if (rr < mtot) {
+                a.cdots[TRD_NBMAX + rr - a.m - a.i] = acc[r];
             }
         }
         pv[wave] = p;
@@ -409,6 +401,8 @@ __global__ __launch_bounds__(256) void wy_gram_kernel(const double* __restrict__
 
 // X <- X (H_{nrefl-1} ... H_0): every workgroup owns 16 rows of X and sweeps the compact-WY blocks
 // from the last to the first:  M = X Y_b^T ; M2 = M C_b ; X -= M2 Y_b   with C_b = T_b^T.
+// 64-column tiles go through LDS; the global loads of tile t+1 are issued into registers before
+// the arithmetic on tile t starts (software pipelining), so HBM/L2 latency overlaps the FMAs.
 __global__ __launch_bounds__(256) void wy_apply_kernel(double* __restrict__ X, int ldx, int n,
                                                        const double* __restrict__ A, int ld, int nrefl,
                                                        const double* __restrict__ taus,
@@ -421,22 +415,47 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(double* __restrict__ X, i
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * 16;
     const int r = tid >> 4, h = tid & 15;
+    const bool rowok = r0 + r < n;
+    double* xrow = X + (size_t)(rowok ? r0 + r : 0) * ldx;
     for (int b = nblk - 1; b >= 0; --b) {
         const int j0 = b * WY_NB;
         const int kb = (nrefl - j0 < WY_NB) ? (nrefl - j0) : WY_NB;
         const int c0 = j0 + 1;
+        double xr[4], yr[8];
+        // the prefetch below reads X entries other threads updated in the previous block's phase 3
+        __syncthreads();
+        // ---- phase 1: M = X Y^T --------------------------------------------------------------
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + k * 256, rr = e >> 6, cc = e & 63;
+            xr[k] = (r0 + rr < n && c0 + cc < n) ? X[(size_t)(r0 + rr) * ldx + c0 + cc] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = tid + k * 256, pr = e >> 6, cc = e & 63;
+            yr[k] = (pr < kb && c0 + cc < n) ? yval(A, ld, taus, j0 + pr, c0 + cc) : 0.0;
+        }
         double a0 = 0.0, a1 = 0.0;
         for (int ct = c0; ct < n; ct += 64) {
             __syncthreads();
-            for (int e = tid; e < 16 * 64; e += 256) {
-                const int rr = e >> 6, cc = e & 63;
-                Xs[rr][cc] = (r0 + rr < n && ct + cc < n) ? X[(size_t)(r0 + rr) * ldx + ct + cc] : 0.0;
-            }
-            for (int e = tid; e < WY_NB * 64; e += 256) {
-                const int pr = e >> 6, cc = e & 63;
-                Ys[pr][cc] = (pr < kb && ct + cc < n) ? yval(A, ld, taus, j0 + pr, ct + cc) : 0.0;
-            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int e = tid + k * 256; Xs[e >> 6][e & 63] = xr[k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int e = tid + k * 256; Ys[e >> 6][e & 63] = yr[k]; }
             __syncthreads();
+            const int cn = ct + 64;
+            if (cn < n) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = tid + k * 256, rr = e >> 6, cc = e & 63;
+                    xr[k] = (r0 + rr < n && cn + cc < n) ? X[(size_t)(r0 + rr) * ldx + cn + cc] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = tid + k * 256, pr = e >> 6, cc = e & 63;
+                    yr[k] = (pr < kb && cn + cc < n) ? yval(A, ld, taus, j0 + pr, cn + cc) : 0.0;
+                }
+            }
 #pragma unroll 8
             for (int cc = 0; cc < 64; ++cc) {
                 const double x = Xs[r][cc];
@@ -449,6 +468,7 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(double* __restrict__ X, i
         Ms[r][2 * h + 1] = a1;
         for (int e = tid; e < WY_NB * WY_NB; e += 256) Cs[e >> 5][e & 31] = Call[(size_t)b * WY_NB * WY_NB + e];
         __syncthreads();
+        // ---- phase 2: M2 = M C ----------------------------------------------------------------
         double m0 = 0.0, m1 = 0.0;
 #pragma unroll 8
         for (int p = 0; p < WY_NB; ++p) {
@@ -458,25 +478,52 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(double* __restrict__ X, i
         }
         M2s[r][2 * h] = m0;
         M2s[r][2 * h + 1] = m1;
+        // ---- phase 3: X -= M2 Y  (thread: row r, columns 4h..4h+3 of every tile) -----------------
+        double xv[4], xn[4];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = tid + k * 256, pr = e >> 6, cc = e & 63;
+            yr[k] = (pr < kb && c0 + cc < n) ? yval(A, ld, taus, j0 + pr, c0 + cc) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cabs = c0 + 4 * h + k;
+            xv[k] = (rowok && cabs < n) ? xrow[cabs] : 0.0;
+        }
         for (int ct = c0; ct < n; ct += 64) {
             __syncthreads();
-            for (int e = tid; e < WY_NB * 64; e += 256) {
-                const int pr = e >> 6, cc = e & 63;
-                Ys[pr][cc] = (pr < kb && ct + cc < n) ? yval(A, ld, taus, j0 + pr, ct + cc) : 0.0;
-            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int e = tid + k * 256; Ys[e >> 6][e & 63] = yr[k]; }
             __syncthreads();
-            if (r0 + r < n) {
+            const int cn = ct + 64;
+            if (cn < n) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = tid + k * 256, pr = e >> 6, cc = e & 63;
+                    yr[k] = (pr < kb && cn + cc < n) ? yval(A, ld, taus, j0 + pr, cn + cc) : 0.0;
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int cc = 4 * h + k, cabs = ct + cc;
-                    if (cabs < n) {
-                        double s = 0.0;
-#pragma unroll 8
-                        for (int q = 0; q < WY_NB; ++q) s += M2s[r][q] * Ys[q][cc];
-                        X[(size_t)(r0 + r) * ldx + cabs] -= s;
-                    }
+                    const int cabs = cn + 4 * h + k;
+                    xn[k] = (rowok && cabs < n) ? xrow[cabs] : 0.0;
                 }
             }
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+            for (int q = 0; q < WY_NB; ++q) {
+                const double mq = M2s[r][q];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += mq * Ys[q][4 * h + k];
+            }
+            if (rowok) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cabs = ct + 4 * h + k;
+                    if (cabs < n) xrow[cabs] = xv[k] - s[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xv[k] = xn[k];
         }
     }
 }
@@ -746,13 +793,14 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     double *Vp, *Wp, *part;
     SCHK(scratch_get(c, SCR_MISC0, (size_t)2 * TRD_NBMAX * ld * sizeof(double), &Vp));
     Wp = Vp + (size_t)TRD_NBMAX * ld;
-    const int maxblkA = (n + 255) / 256 + 1, maxblkB = (n + 7) / 8 + 1;
-    SCHK(scratch_get(c, SCR_MISC1, ((size_t)2 * maxblkA * TRD_PA + maxblkB + 64) * sizeof(double), &part));
+    const int maxblkA = (n + 255) / 256 + 1, maxblkB = (n + 2 * TRD_NBMAX + 7) / 8 + 1;
+    SCHK(scratch_get(c, SCR_MISC1, ((size_t)2 * maxblkA * TRD_PA + maxblkB + 2 * TRD_NBMAX + 64) * sizeof(double), &part));
     double* partA[2] = {part, part + (size_t)maxblkA * TRD_PA};
     double* partB = part + 2 * (size_t)maxblkA * TRD_PA;
     double* ub[2] = {W.vec + (size_t)V_U0 * ld, W.vec + (size_t)V_U1 * ld};
     double* wraw = W.vec + (size_t)V_WRAW * ld;
     double* colscal = W.vec + (size_t)V_COL * ld;
+    double* cdots = partB + maxblkB + 8;               // 2 * TRD_NBMAX doubles
     int cur = 0, nblkA_prev = 0, nblkB_prev = 0;
     for (int j0 = 0; j0 < nrefl; j0 += nb) {
         const int kb = std::min(nb, nrefl - j0);
@@ -769,6 +817,7 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
             ra.partA_cur = partA[cur];
             ra.partB = partB; ra.nblkB = nblkB_prev;
             ra.colscal = colscal;
+            ra.cdots = cdots;
             ra.dvec = dvec;
             const int nblkA = (n - j + 255) / 256;
             hipLaunchKernelGGL(trd_row_kernel, dim3(nblkA), dim3(256), 0, c->stream, ra);
@@ -782,7 +831,8 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
             ga.Vrow = Vp + (size_t)i * ld;
             ga.Arow = W.A + (size_t)j * ld;
             ga.taus = taus; ga.evec = evec; ga.colscal = colscal;
-            const int nblkB = (m + 7) / 8;
+            ga.Wp = Wp; ga.Vp = Vp; ga.ldp = ld; ga.i = i; ga.cdots = cdots;
+            const int nblkB = (m + 2 * i + 7) / 8;
             prof_begin(c, PROF_GEMV, 8.0 * m * (double)m, 2.0 * m * (double)m);
             hipLaunchKernelGGL(trd_gemv_kernel, dim3(nblkB), dim3(256), TRD_TC * sizeof(double), c->stream, ga);
             prof_end(c);

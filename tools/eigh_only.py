@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Profiling target: a few device eigh calls at n = 3072 (run under rocprofv3 --kernel-trace)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sella_amd.device import Context  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+ctx = Context(0)
+rng = np.random.RandomState(0)
+A = rng.normal(size=(n, n))
+A = A + A.T
+dA = ctx.upload(A)
+for r in range(reps):
+    t0 = time.perf_counter()
+    w, V, Vt = ctx.eigh(dA)
+    ctx.sync()
+    print(f'eigh n={n}: {1e3 * (time.perf_counter() - t0):.2f} ms', flush=True)
+    V.free()
+    Vt.free()

@@ -137,13 +137,12 @@ struct TrdGemvArgs {
     double* cdots;
 };
 
-// K2.  Reflector scalars from the K1 partials, then wraw = A22 v with v = [1, scale*u] staged
-// into LDS on the fly (same streaming structure as gemv_rows_kernel<1, 2>).  The 2i panel rows
+// K2.  Reflector scalars from the K1 partials, then wraw = A22 v with v = [1, scale*u] formed on
+// the fly (same block-cooperative streaming structure as gemv_rows_kernel<1, 2>).  The 2i panel rows
 // W_p, V_p (p < i) are appended as extra rows of the same launch: a wavefront streams a whole row, so
 // the dots the next column needs (dlatrd's W^T v, V^T v) come out exact, without partial buffers.
 __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
-    HIP_DYNAMIC_SHARED(double, xs)
-    __shared__ double pv[8];
+    __shared__ double red[4][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double ss = 0.0;
     for (int b = 0; b < a.nblkA; ++b) ss += a.partA[(size_t)b * TRD_PA];
@@ -156,70 +155,66 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
         tau = (beta - alpha) / beta;
         scale = 1.0 / (alpha - beta);
     }
-    const int row0 = (blockIdx.x * 4 + wave) * 2;
+    const int row0 = blockIdx.x * 2;
     const int mtot = a.m + 2 * a.i;
-    const int oc = a.o - a.shift;
-    const double* arow[2];
+    const int oc = a.o - a.shift;                     // even absolute column of local column 0
+    const double2* arow[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         int rr = row0 + r;
         if (rr > mtot - 1) rr = mtot - 1;
-        if (rr < a.m) arow[r] = a.A22 + (size_t)rr * a.ld;
-        else if (rr < a.m + a.i) arow[r] = a.Wp + (size_t)(rr - a.m) * a.ldp + oc;
-        else arow[r] = a.Vp + (size_t)(rr - a.m - a.i) * a.ldp + oc;
+        const double* base;
+        if (rr < a.m) base = a.A22 + (size_t)rr * a.ld;
+        else if (rr < a.m + a.i) base = a.Wp + (size_t)(rr - a.m) * a.ldp + oc;
+        else base = a.Vp + (size_t)(rr - a.m - a.i) * a.ldp + oc;
+        arow[r] = reinterpret_cast<const double2*>(base);
     }
     double acc[2] = {0.0, 0.0};
-    const int cols = a.m + a.shift;
-    const int cols2 = (cols + 1) & ~1;
-    const int cbase = a.o - a.shift;                  // absolute column of local column 0
-    for (int c0 = 0; c0 < cols2; c0 += TRD_TC) {
-        const int tc = (cols2 - c0 < TRD_TC) ? (cols2 - c0) : TRD_TC;
-        for (int jj = threadIdx.x; jj < tc; jj += 256) {
-            const int cabs = cbase + c0 + jj;
-            double xv = 0.0;
-            if (cabs == a.o) xv = 1.0;
-            else if (cabs > a.o && cabs < a.n) xv = scale * a.ubuf[cabs];
-            xs[jj] = xv;
-        }
-        __syncthreads();
-        const int tc2 = tc >> 1;
-        const double2* xs2 = reinterpret_cast<const double2*>(xs);
-#pragma unroll 4
-        for (int jj = lane; jj < tc2; jj += 64) {
-            const double2 xv = xs2[jj];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const double2 av = *reinterpret_cast<const double2*>(arow[r] + c0 + 2 * jj);
-                acc[r] += av.x * xv.x + av.y * xv.y;
-            }
-        }
-        __syncthreads();
-    }
-    acc[0] = wave_sum_e(acc[0]);
-    acc[1] = wave_sum_e(acc[1]);
-    if (lane == 0) {
-        double p = 0.0;
+    const int n2 = (a.m + a.shift + 1) >> 1;
+    // v on the fly: 1 at column o, scale*u behind it, 0 in the alignment pad / beyond n
+    auto vval = [&](int cabs) -> double {
+        if (cabs == a.o) return 1.0;
+        return (cabs > a.o && cabs < a.n) ? scale * a.ubuf[cabs] : 0.0;
+    };
+    for (int j0 = threadIdx.x; j0 < n2; j0 += 512) {
+        const int j1 = j0 + 256;
+        const bool has1 = j1 < n2;
+        double2 a0[2], a1[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int rr = row0 + r;
-            if (rr < a.m) {
-                const int rabs = a.o + rr;
-                const double vr = (rr == 0) ? 1.0 : scale * a.ubuf[rabs];
-                a.wraw[rabs] = acc[r];
-                a.Vrow[rabs] = vr;
-                if (rr > 0) a.Arow[rabs] = vr;
-                p += vr * acc[r];
-            } else if (rr < a.m + a.i) {
-                a.cdots[rr - a.m] = acc[r];
-            } else if (rr < mtot) {
-                a.cdots[TRD_NBMAX + rr - a.m - a.i] = acc[r];
-            }
+            a0[r] = arow[r][j0];
+            a1[r] = has1 ? arow[r][j1] : make_double2(0.0, 0.0);
         }
-        pv[wave] = p;
+        const double x00 = vval(oc + 2 * j0), x01 = vval(oc + 2 * j0 + 1);
+        const double x10 = has1 ? vval(oc + 2 * j1) : 0.0, x11 = has1 ? vval(oc + 2 * j1 + 1) : 0.0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) acc[r] += a0[r].x * x00 + a0[r].y * x01 + a1[r].x * x10 + a1[r].y * x11;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const double v = wave_sum_e(acc[r]);
+        if (lane == 0) red[wave][r] = v;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        a.partB[blockIdx.x] = pv[0] + pv[1] + pv[2] + pv[3];
+        double p = 0.0;
+        for (int r = 0; r < 2; ++r) {
+            const int rr = row0 + r;
+            const double res = red[0][r] + red[1][r] + red[2][r] + red[3][r];
+            if (rr < a.m) {
+                const int rabs = a.o + rr;
+                const double vr = (rr == 0) ? 1.0 : scale * a.ubuf[rabs];
+                a.wraw[rabs] = res;
+                a.Vrow[rabs] = vr;
+                if (rr > 0) a.Arow[rabs] = vr;
+                p += vr * res;
+            } else if (rr < a.m + a.i) {
+                a.cdots[rr - a.m] = res;
+            } else if (rr < mtot) {
+                a.cdots[TRD_NBMAX + rr - a.m - a.i] = res;
+            }
+        }
+        a.partB[blockIdx.x] = p;
         if (blockIdx.x == 0) {
             a.taus[a.j] = tau;
             a.evec[a.j] = beta;
@@ -793,7 +788,7 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     double *Vp, *Wp, *part;
     SCHK(scratch_get(c, SCR_MISC0, (size_t)2 * TRD_NBMAX * ld * sizeof(double), &Vp));
     Wp = Vp + (size_t)TRD_NBMAX * ld;
-    const int maxblkA = (n + 255) / 256 + 1, maxblkB = (n + 2 * TRD_NBMAX + 7) / 8 + 1;
+    const int maxblkA = (n + 255) / 256 + 1, maxblkB = (n + 2 * TRD_NBMAX + 1) / 2 + 1;
     SCHK(scratch_get(c, SCR_MISC1, ((size_t)2 * maxblkA * TRD_PA + maxblkB + 2 * TRD_NBMAX + 64) * sizeof(double), &part));
     double* partA[2] = {part, part + (size_t)maxblkA * TRD_PA};
     double* partB = part + 2 * (size_t)maxblkA * TRD_PA;
@@ -832,9 +827,9 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
             ga.Arow = W.A + (size_t)j * ld;
             ga.taus = taus; ga.evec = evec; ga.colscal = colscal;
             ga.Wp = Wp; ga.Vp = Vp; ga.ldp = ld; ga.i = i; ga.cdots = cdots;
-            const int nblkB = (m + 2 * i + 7) / 8;
+            const int nblkB = (m + 2 * i + 1) / 2;
             prof_begin(c, PROF_GEMV, 8.0 * m * (double)m, 2.0 * m * (double)m);
-            hipLaunchKernelGGL(trd_gemv_kernel, dim3(nblkB), dim3(256), TRD_TC * sizeof(double), c->stream, ga);
+            hipLaunchKernelGGL(trd_gemv_kernel, dim3(nblkB), dim3(256), 0, c->stream, ga);
             prof_end(c);
             nblkA_prev = nblkA;
             nblkB_prev = nblkB;

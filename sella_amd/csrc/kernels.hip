@@ -19,103 +19,95 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ------------------------------------------------------------------------------------
-// K1: row-panel matvec.  One wavefront owns RW consecutive rows; lanes stride the row in
-// 16-byte pieces (1 KiB per wave-instruction, fully coalesced); the NRHS right-hand sides
-// are staged through LDS in column tiles of GEMV_TC doubles so arbitrarily long rows work
-// with <= NRHS*16 KiB of LDS.  Algorithmic traffic: 8*rows*cols bytes (matrix read once).
+// K1: row-panel matvec.  A 256-thread workgroup owns RB consecutive rows; its four wavefronts
+// stride each row together in 16-byte pieces (4 KiB per workgroup-instruction, fully coalesced,
+// two such loads in flight per lane per row), the right-hand sides are read straight from
+// global memory (24 KiB per vector at n = 3072: L1/L2 resident), each wavefront reduces with
+// the wave64 butterfly and the four partials meet in LDS.  Measured on MI355X at n = 3072
+// (tools/lab/gemv_lab.hip): 6.07 TB/s for 1 RHS, 5.7 TB/s for 2 — against 4.9 / 4.0 TB/s for the
+// wavefront-per-row + LDS-staged-x variant this replaced.  Algorithmic traffic: 8*rows*cols bytes.
 // ------------------------------------------------------------------------------------
-// column tile per right-hand side: the LDS footprint stays at 32 KiB for any NRHS (>= 5 blocks per CU)
-constexpr int gemv_tc(int nrhs) { return nrhs <= 2 ? 2048 : (nrhs <= 4 ? 1024 : 512); }
-
-template <int NRHS, int RW>
+template <int NRHS, int RB>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ A, int rows,
                                                         int cols, int lda,
                                                         const double* __restrict__ X, int ldx,
                                                         double* __restrict__ Y, int ldy,
                                                         GemvEpi epi) {
-    HIP_DYNAMIC_SHARED(double, xs)
-    constexpr int GEMV_TC = gemv_tc(NRHS);
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int row0 = (blockIdx.x * 4 + wave) * RW;
-
-    const double* arow[RW];
+    __shared__ double red[4][RB][NRHS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * RB;
+    const double2* arow[RB];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
+    for (int r = 0; r < RB; ++r) {
         int rr = row0 + r;
         if (rr > rows - 1) rr = rows - 1;
-        arow[r] = A + (size_t)rr * lda;
+        arow[r] = reinterpret_cast<const double2*>(A + (size_t)rr * lda);
     }
-    double acc[RW][NRHS];
+    double acc[RB][NRHS];
 #pragma unroll
-    for (int r = 0; r < RW; ++r)
+    for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int h = 0; h < NRHS; ++h) acc[r][h] = 0.0;
-
-    const int cols2 = (cols + 1) & ~1;
-    for (int c0 = 0; c0 < cols2; c0 += GEMV_TC) {
-        const int tc = (cols2 - c0 < GEMV_TC) ? (cols2 - c0) : GEMV_TC;
+    const int n2 = (cols + 1) >> 1;
+    const bool odd = cols & 1;
+    for (int j0 = threadIdx.x; j0 < n2; j0 += 512) {
+        const int j1 = j0 + 256;
+        const bool has1 = j1 < n2;
+        double2 a0[RB], a1[RB];
 #pragma unroll
-        for (int h = 0; h < NRHS; ++h)
-            for (int j = threadIdx.x; j < tc; j += 256) {
-                const int col = c0 + j;
-                xs[h * GEMV_TC + j] = (col < cols) ? X[(size_t)h * ldx + col] : 0.0;
-            }
-        __syncthreads();
-        const int tc2 = tc >> 1;
-        const double2* xs2 = reinterpret_cast<const double2*>(xs);
-#pragma unroll 4
-        for (int j = lane; j < tc2; j += 64) {
-            double2 av[RW];
-#pragma unroll
-            for (int r = 0; r < RW; ++r)
-                av[r] = *reinterpret_cast<const double2*>(arow[r] + c0 + 2 * j);
-#pragma unroll
-            for (int h = 0; h < NRHS; ++h) {
-                const double2 xv = xs2[h * (GEMV_TC / 2) + j];
-#pragma unroll
-                for (int r = 0; r < RW; ++r) acc[r][h] += av[r].x * xv.x + av[r].y * xv.y;
-            }
+        for (int r = 0; r < RB; ++r) {
+            a0[r] = arow[r][j0];
+            a1[r] = has1 ? arow[r][j1] : make_double2(0.0, 0.0);
         }
-        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < NRHS; ++h) {
+            const double* xh = X + (size_t)h * ldx;
+            double2 x0, x1;
+            x0.x = xh[2 * j0];
+            x0.y = (odd && j0 == n2 - 1) ? 0.0 : xh[2 * j0 + 1];
+            if (has1) {
+                x1.x = xh[2 * j1];
+                x1.y = (odd && j1 == n2 - 1) ? 0.0 : xh[2 * j1 + 1];
+            } else {
+                x1 = make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                acc[r][h] += a0[r].x * x0.x + a0[r].y * x0.y + a1[r].x * x1.x + a1[r].y * x1.y;
+        }
     }
 #pragma unroll
-    for (int r = 0; r < RW; ++r)
+    for (int r = 0; r < RB; ++r)
 #pragma unroll
-        for (int h = 0; h < NRHS; ++h) acc[r][h] = wave_sum(acc[r][h]);
-    if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            const int rr = row0 + r;
-            if (rr < rows) {
-#pragma unroll
-                for (int h = 0; h < NRHS; ++h) {
-                    double v = epi.alpha * acc[r][h];
-                    if (epi.mode == 1) v = v / (epi.dvec[rr] - epi.theta);
-                    else if (epi.mode == 2) v += epi.beta * Y[(size_t)h * ldy + rr];
-                    else if (epi.mode == 3) v *= fabs(epi.dvec[rr]);
-                    Y[(size_t)h * ldy + rr] = v;
-                }
-            }
+        for (int h = 0; h < NRHS; ++h) {
+            const double v = wave_sum(acc[r][h]);
+            if (lane == 0) red[wave][r][h] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < RB * NRHS) {
+        const int r = threadIdx.x / NRHS, h = threadIdx.x % NRHS;
+        const int rr = row0 + r;
+        if (rr < rows) {
+            double v = epi.alpha * (red[0][r][h] + red[1][r][h] + red[2][r][h] + red[3][r][h]);
+            if (epi.mode == 1) v = v / (epi.dvec[rr] - epi.theta);
+            else if (epi.mode == 2) v += epi.beta * Y[(size_t)h * ldy + rr];
+            else if (epi.mode == 3) v *= fabs(epi.dvec[rr]);
+            Y[(size_t)h * ldy + rr] = v;
         }
     }
 }
 
 template <int NRHS>
-static int gemv_rows_dispatch_rw(sella_ctx* c, int rw, const double* A, int rows, int cols, int lda,
+static int gemv_rows_dispatch_rw(sella_ctx* c, int rb, const double* A, int rows, int cols, int lda,
                                  const double* X, int ldx, double* Y, int ldy, const GemvEpi& epi) {
-    const size_t shmem = (size_t)NRHS * gemv_tc(NRHS) * sizeof(double);
-    if (rw == 4) {
-        int grid = (rows + 15) / 16;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 4>), dim3(grid), dim3(256), shmem,
+    if (rb == 4) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 4>), dim3((rows + 3) / 4), dim3(256), 0,
                            c->stream, A, rows, cols, lda, X, ldx, Y, ldy, epi);
-    } else if (rw == 2) {
-        int grid = (rows + 7) / 8;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 2>), dim3(grid), dim3(256), shmem,
+    } else if (rb == 2) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 2>), dim3((rows + 1) / 2), dim3(256), 0,
                            c->stream, A, rows, cols, lda, X, ldx, Y, ldy, epi);
     } else {
-        int grid = (rows + 3) / 4;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 1>), dim3(grid), dim3(256), shmem,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 1>), dim3(rows), dim3(256), 0,
                            c->stream, A, rows, cols, lda, X, ldx, Y, ldy, epi);
     }
     HIPCHK(hipGetLastError());
@@ -130,8 +122,10 @@ int launch_gemv_rows(sella_ctx* c, const double* A, int rows, int cols, int lda,
         return SELLA_E_INVALID;
     }
     int rw = (int)c->opt.gemv_rw;
-    // few rows (panel dots): one row per wavefront keeps more wavefronts in flight
+    // few rows (panel dots, small matrices): one row per workgroup keeps more of the chip busy
     if (rows < 1024) rw = 1;
+    // 8 right-hand sides x 4 rows would need 64 accumulators per lane
+    if (nrhs > 4 && rw == 4) rw = 2;
     for (int h0 = 0; h0 < nrhs; h0 += 8) {
         const int nh = (nrhs - h0 < 8) ? (nrhs - h0) : 8;
         const double* Xh = X + (size_t)h0 * ldx;

@@ -137,16 +137,19 @@ def main():
     for _ in range(max(1, min(args.steps, 5))):
         ctx.davidson(dA, n, g, args.gamma, method='jd0', maxiter=args.maxiter, Pvecs=V, PvecsT=Vt, pevals=w)
     ctx.prof_enable(False)
-    pg = ctx.prof_get(0)
+    pg = ctx.prof_get(0)          # n x n streams: gemv_rows_kernel<1,2> (A t) and <2,2> (Q^T[r v], Q[a b])
+    ps = ctx.prof_get(4)          # panel dots: same template, <*,1> instantiations, k x n, latency bound
     roof = None
     if pg['launches'] > 0 and pg['ms'] > 0:
-        # only the n x n streams matter for the roofline; panel dots are tiny launches of the
-        # same kernel, so report bytes/time over all launches (dominated by the n x n ones)
         achieved = pg['bytes'] / (pg['ms'] * 1e-3) / 1e9
-        roof = dict(bound='hbm', kernel='gemv_rows_kernel', achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+        roof = dict(bound='hbm', kernel='gemv_rows_kernel<NRHS,2> (n x n row-panel matvec)',
+                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                     unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                     launches=pg['launches'], mean_us=round(1e3 * pg['ms'] / pg['launches'], 2),
-                    bytes_per_launch=round(pg['bytes'] / pg['launches']))
+                    bytes_per_launch=round(pg['bytes'] / pg['launches']),
+                    small_panel_launches=dict(launches=ps['launches'],
+                                              mean_us=round(1e3 * ps['ms'] / max(1, ps['launches']), 2),
+                                              bytes_per_launch=round(ps['bytes'] / max(1, ps['launches']))))
 
     times = [elapsed]
     total_iters = iters

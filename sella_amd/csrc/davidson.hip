@@ -17,6 +17,8 @@
 #include "internal.h"
 #include "host_math.h"
 
+#include <chrono>
+
 namespace sella {
 namespace {
 
@@ -142,6 +144,22 @@ int apply_pinv(Dav& s, double theta, const double* in, int m, double* mid, doubl
     return launch_gemv_rows(c, s.Q->d, s.n, s.n, s.Q->ld, mid, s.ld, m, out, s.ld, GemvEpi());
 }
 
+// same with the inputs given as separate vectors
+int apply_pinv_xp(Dav& s, double theta, const double* const* in, int m, double* mid, double* out) {
+    sella_ctx* c = s.c;
+    if (s.Q == nullptr) {
+        for (int h = 0; h < m; ++h)
+            SCHK(launch_axpby(c, s.n, 1.0 / (s.pscale - theta), in[h], 0.0, nullptr, out + (size_t)h * s.ld));
+        return SELLA_OK;
+    }
+    GemvEpi e;
+    e.mode = 1;
+    e.dvec = s.pevals_dev;
+    e.theta = theta;
+    SCHK(launch_gemv_rows_xp(c, s.Qt->d, s.n, s.n, s.Qt->ld, in, m, mid, s.ld, e));
+    return launch_gemv_rows(c, s.Q->d, s.n, s.n, s.Q->ld, mid, s.ld, m, out, s.ld, GemvEpi());
+}
+
 // Orthonormalise t against V[0:k) with the reference's accept / drop rules (gs.hip).
 int orthonormalise(Dav& s, double* t, int k, int* kept, double* first_norm) {
     return gs_orthonormalise(s.c, s.Vp, s.ld, k, t, s.n, 1e-15, 1e-6, 100, kept, first_norm);
@@ -156,30 +174,19 @@ int append_vector(Dav& s) {
     double* At = s.AVp + (size_t)k * s.ld;
     SCHK(apply_A(s, t, At));
     double* ds = c->dscal + DS_GRAM;
-    // rows [0,k): V_a.t ; [cap, cap+k): V_a.At ; [2cap, 2cap+k): AV_a.t ; [3cap]: t.t ; [3cap+1]: t.At
-    if (k > 0) {
-        // X = [t, At] as a 2-row panel: rows are ld apart only if contiguous; copy into wk
-        double* x2 = s.wk;   // 2 rows
-        HIPCHK(hipMemcpyAsync(x2, t, (size_t)s.ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(x2 + s.ld, At, (size_t)s.ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        SCHK(launch_gemv_rows(c, s.Vp, k, s.n, s.ld, x2, s.ld, 2, ds, cap, GemvEpi()));
-        SCHK(launch_gemv_rows(c, s.AVp, k, s.n, s.ld, x2, s.ld, 1, ds + 2 * (size_t)cap, cap, GemvEpi()));
-        SCHK(launch_gemv_rows(c, t, 1, s.n, s.ld, x2, s.ld, 2, ds + 3 * (size_t)cap, 1, GemvEpi()));
-    } else {
-        double* x2 = s.wk;
-        HIPCHK(hipMemcpyAsync(x2, t, (size_t)s.ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(x2 + s.ld, At, (size_t)s.ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        SCHK(launch_gemv_rows(c, t, 1, s.n, s.ld, x2, s.ld, 2, ds + 3 * (size_t)cap, 1, GemvEpi()));
-    }
-    SCHK(read_scalars(c, DS_GRAM, 3 * cap + 2));
+    // rows [0,k]: V_a.t (a = k gives t.t) ; [cap, cap+k]: V_a.At (a = k gives t.At) ; [2cap, 2cap+k): AV_a.t
+    const double* xs[2] = {t, At};
+    SCHK(launch_gemv_rows_xp(c, s.Vp, k + 1, s.n, s.ld, xs, 2, ds, cap, GemvEpi()));
+    if (k > 0) SCHK(launch_gemv_rows_xp(c, s.AVp, k, s.n, s.ld, xs, 1, ds + 2 * (size_t)cap, cap, GemvEpi()));
+    SCHK(read_scalars(c, DS_GRAM, 3 * cap));
     const double* h = c->hscal + DS_GRAM;
     for (int a = 0; a < k; ++a) {
         s.Gvv[(size_t)a * cap + k] = s.Gvv[(size_t)k * cap + a] = h[a];
         s.Gva[(size_t)a * cap + k] = h[cap + a];
         s.Gva[(size_t)k * cap + a] = h[2 * cap + a];
     }
-    s.Gvv[(size_t)k * cap + k] = h[3 * cap];
-    s.Gva[(size_t)k * cap + k] = h[3 * cap + 1];
+    s.Gvv[(size_t)k * cap + k] = h[k];
+    s.Gva[(size_t)k * cap + k] = h[cap + k];
     s.k = k + 1;
     return SELLA_OK;
 }
@@ -287,8 +294,13 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
     int seeking = 0;
     unsigned long long lcg = 0x9E3779B97F4A7C15ull;   // deterministic stand-in for np.random.normal (:107)
 
+    double t_host = 0.0;
+    const bool dbg_time = getenv("SELLA_DEBUG_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     while (true) {
         const int k = s.k, cap = s.cap;
+        double th0 = now();
         // ---- Rayleigh-Ritz (eigensolvers.py:57-64) ---------------------------------------
         pack(s.Gvv, cap, k, gvv);
         pack(s.Gva, cap, k, gva);
@@ -308,6 +320,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
             set_error("davidson: Rayleigh-Ritz eigenproblem failed (V^T V not positive definite?)");
             return fail(SELLA_E_NOCONV);
         }
+        t_host += now() - th0;
         int nneg = 0;
         for (int i = 0; i < k; ++i) nneg += (lams[i] < 0.0);
         if (nneg < 1) nneg = 1;
@@ -319,6 +332,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
             DCHK(launch_lincomb(c, n, k, s.AVp, s.ld, k, dWp, k, nullptr, 0, 0, nullptr, 0, 0.0, s.AVq, s.ld));
             std::swap(s.Vp, s.Vq);
             std::swap(s.AVp, s.AVq);
+            th0 = now();
             tmpm.resize((size_t)k * k);
             hostm::congruence(k, W.data(), gvv.data(), tmpm.data());
             unpack(tmpm, k, s.Gvv, cap);
@@ -326,22 +340,25 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
             hostm::congruence(k, W.data(), gva.data(), tmpm.data());
             unpack(tmpm, k, s.Gva, cap);
             gva = tmpm;
+            t_host += now() - th0;
         }
         if (k >= kstop) break;                                            // :65-66
 
         // ---- residuals of the leading nneg Ritz pairs (:68-71) ---------------------------
         hostm::symm_coeffs(k, gvv.data(), gva.data(), 2, X.data());
         // R_j = AV_j + sum_{l<j} X[l][j] V_l - lams[j] V_j
-        coef.assign((size_t)nneg * nneg, 0.0);
+        // coefficient block 0 multiplies the V rows, block 1 (identity) selects the AV rows
+        coef.assign((size_t)2 * nneg * nneg, 0.0);
         for (int j = 0; j < nneg; ++j) {
             for (int l = 0; l < j; ++l) coef[(size_t)l * nneg + j] = X[(size_t)l * k + j];
             coef[(size_t)j * nneg + j] = -lams[j];
+            coef[(size_t)nneg * nneg + (size_t)j * nneg + j] = 1.0;
         }
         {
             double* dC;
-            DCHK(put_small(s, coef.data(), nneg * nneg, 1, (size_t)s.cap * s.cap + 8, &dC));
-            DCHK(launch_axpby2d(c, nneg, n, 1.0, s.AVp, s.ld, 0.0, nullptr, 0, s.Rp, s.ld));
-            DCHK(launch_lincomb(c, n, nneg, s.Vp, s.ld, nneg, dC, nneg, nullptr, 0, 0, nullptr, 0, 1.0, s.Rp, s.ld));
+            DCHK(put_small(s, coef.data(), 2 * nneg * nneg, 1, (size_t)s.cap * s.cap + 8, &dC));
+            DCHK(launch_lincomb(c, n, nneg, s.Vp, s.ld, nneg, dC, nneg, s.AVp, s.ld, nneg, dC + (size_t)nneg * nneg, nneg,
+                                0.0, s.Rp, s.ld));
             DCHK(launch_rows_sumsq(c, s.Rp, s.ld, nneg, n, c->dscal));
             int nread = nneg;
             if (vref) {
@@ -372,9 +389,9 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
             r = s.Rp + (size_t)seeking * s.ld;    // Rp was re-allocated: recompute the residual rows
             v = s.Vp + (size_t)seeking * s.ld;
             double* dC;
-            DCHK(put_small(s, coef.data(), nneg * nneg, 1, (size_t)s.cap * s.cap + 8, &dC));
-            DCHK(launch_axpby2d(c, nneg, n, 1.0, s.AVp, s.ld, 0.0, nullptr, 0, s.Rp, s.ld));
-            DCHK(launch_lincomb(c, n, nneg, s.Vp, s.ld, nneg, dC, nneg, nullptr, 0, 0, nullptr, 0, 1.0, s.Rp, s.ld));
+            DCHK(put_small(s, coef.data(), 2 * nneg * nneg, 1, (size_t)s.cap * s.cap + 8, &dC));
+            DCHK(launch_lincomb(c, n, nneg, s.Vp, s.ld, nneg, dC, nneg, s.AVp, s.ld, nneg, dC + (size_t)nneg * nneg, nneg,
+                                0.0, s.Rp, s.ld));
         }
 
         // ---- correction vector (expand, :115-153) into panel slot k -----------------------
@@ -389,12 +406,11 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         if (method == SELLA_DAV_LANCZOS) {
             DCHK(copy_row(t, r));
         } else if (method == SELLA_DAV_GD) {
-            DCHK(copy_row(in, r));
-            DCHK(apply_pinv(s, theta, in, 1, mid, t));
+            const double* rr[1] = {r};
+            DCHK(apply_pinv_xp(s, theta, rr, 1, mid, t));
         } else if (method == SELLA_DAV_JD0 || method == SELLA_DAV_JD0_ALT) {
-            DCHK(copy_row(in, r));
-            DCHK(copy_row(in + s.ld, v));
-            DCHK(apply_pinv(s, theta, in, 2, mid, out));
+            const double* rv[2] = {r, v};
+            DCHK(apply_pinv_xp(s, theta, rv, 2, mid, out));
             // dots[0] = v.x, dots[1] = v.y
             DCHK(launch_gemv_rows(c, v, 1, n, s.ld, out, s.ld, 2, c->dscal + 16, 1, GemvEpi()));
             DCHK(launch_jd_combine(c, out, out + s.ld, c->dscal + 16, t, n));
@@ -467,6 +483,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         DCHK(append_vector(s));
     }
 
+    if (dbg_time) fprintf(stderr, "davidson: k=%d total %.3f ms, host k x k algebra %.3f ms\n", s.k, 1e3 * (now() - t_begin), 1e3 * t_host);
     // ---- results: Ritz values, V and AV as (n x k) row-major host arrays ------------------
     const int k = s.k;
     for (int i = 0; i < k; ++i) lams_out[i] = lams[i];

@@ -21,8 +21,7 @@ static int gs_sweep(sella_ctx* c, const double* basis, int ldb, int k, double* t
         SCHK(launch_gemv_rows(c, basis, k, n, ldb, t, ldb, 1, cvec, k, neg));
         SCHK(launch_lincomb(c, n, 1, basis, ldb, k, cvec, 1, nullptr, 0, 0, nullptr, 0, 1.0, t, ldb));
     }
-    SCHK(launch_rows_sumsq(c, t, ldb, 1, n, c->dscal + slot));
-    return launch_scale_by(c, t, n, c->dscal + slot, 0);
+    return launch_normalize(c, t, n, c->dscal + slot);
 }
 
 // Orthonormalise the n-vector t against the k orthonormal rows of `basis`.
@@ -36,8 +35,7 @@ int gs_orthonormalise(sella_ctx* c, const double* basis, int ldb, int k, double*
         set_error("gram-schmidt: basis of %d vectors exceeds the coefficient buffer", k);
         return SELLA_E_UNSUPPORTED;
     }
-    SCHK(launch_rows_sumsq(c, t, ldb, 1, n, c->dscal + 8));
-    SCHK(launch_scale_by(c, t, n, c->dscal + 8, 0));
+    SCHK(launch_normalize(c, t, n, c->dscal + 8));
     SCHK(gs_sweep(c, basis, ldb, k, t, n, 9));
     SCHK(gs_sweep(c, basis, ldb, k, t, n, 10));
     SCHK(read_scalars(c, 8, 3));

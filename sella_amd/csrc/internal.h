@@ -45,7 +45,7 @@ struct Mat {
     bool live = false;
 };
 
-enum ProfKind { PROF_GEMV = 0, PROF_GEMM = 1, PROF_UPDATE = 2, PROF_OTHER = 3, PROF_NKIND = 4 };
+enum ProfKind { PROF_GEMV = 0, PROF_GEMM = 1, PROF_UPDATE = 2, PROF_OTHER = 3, PROF_GEMV_SMALL = 4, PROF_NKIND = 5 };
 
 struct ProfPending {
     hipEvent_t a, b;
@@ -114,10 +114,19 @@ struct GemvEpi {
     const double* dvec = nullptr;
     double theta = 0, alpha = 1, beta = 0;
 };
+// right-hand sides of the row-panel matvec as up to 8 independent vectors
+struct GemvX {
+    const double* p[8];
+};
 // Y[h*ldy + i] = epi(sum_j A[i*lda + j] * X[h*ldx + j]),  i < rows, j < cols, h < nrhs (<= 8).
 // A must be 16-byte aligned with even lda; X rows must be readable up to round_up(cols, 2).
 int launch_gemv_rows(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* X,
                      int ldx, int nrhs, double* Y, int ldy, const GemvEpi& epi);
+// same with the right-hand sides given as separate pointers (no contiguity requirement)
+int launch_gemv_rows_xp(sella_ctx* c, const double* A, int rows, int cols, int lda,
+                        const double* const* xs, int nrhs, double* Y, int ldy, const GemvEpi& epi);
+// |x|^2 -> out[0]; x <- x/|x|   (one single-workgroup launch)
+int launch_normalize(sella_ctx* c, double* x, int n, double* out);
 // Y[h*ldy + j] = sum_i A[i*lda + j] * X[h*ldx + i]   (transposed product, deterministic 2-pass)
 int launch_gemv_cols(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* X,
                      int ldx, int nrhs, double* Y, int ldy);

@@ -30,7 +30,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <int NRHS, int RB>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ A, int rows,
                                                         int cols, int lda,
-                                                        const double* __restrict__ X, int ldx,
+                                                        GemvX xp,
                                                         double* __restrict__ Y, int ldy,
                                                         GemvEpi epi) {
     __shared__ double red[4][RB][NRHS];
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
         }
 #pragma unroll
         for (int h = 0; h < NRHS; ++h) {
-            const double* xh = X + (size_t)h * ldx;
+            const double* xh = xp.p[h];
             double2 x0, x1;
             x0.x = xh[2 * j0];
             x0.y = (odd && j0 == n2 - 1) ? 0.0 : xh[2 * j0 + 1];
@@ -99,23 +99,23 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
 
 template <int NRHS>
 static int gemv_rows_dispatch_rw(sella_ctx* c, int rb, const double* A, int rows, int cols, int lda,
-                                 const double* X, int ldx, double* Y, int ldy, const GemvEpi& epi) {
+                                 const GemvX& xp, double* Y, int ldy, const GemvEpi& epi) {
     if (rb == 4) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 4>), dim3((rows + 3) / 4), dim3(256), 0,
-                           c->stream, A, rows, cols, lda, X, ldx, Y, ldy, epi);
+                           c->stream, A, rows, cols, lda, xp, Y, ldy, epi);
     } else if (rb == 2) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 2>), dim3((rows + 1) / 2), dim3(256), 0,
-                           c->stream, A, rows, cols, lda, X, ldx, Y, ldy, epi);
+                           c->stream, A, rows, cols, lda, xp, Y, ldy, epi);
     } else {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 1>), dim3(rows), dim3(256), 0,
-                           c->stream, A, rows, cols, lda, X, ldx, Y, ldy, epi);
+                           c->stream, A, rows, cols, lda, xp, Y, ldy, epi);
     }
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
 
-int launch_gemv_rows(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* X,
-                     int ldx, int nrhs, double* Y, int ldy, const GemvEpi& epi) {
+int launch_gemv_rows_xp(sella_ctx* c, const double* A, int rows, int cols, int lda,
+                        const double* const* xs, int nrhs, double* Y, int ldy, const GemvEpi& epi) {
     if (rows <= 0 || cols <= 0 || nrhs <= 0) return SELLA_OK;
     if ((lda & 1) || (((uintptr_t)A) & 15)) {
         set_error("gemv_rows: matrix must be 16-byte aligned with even leading dimension");
@@ -126,25 +126,57 @@ int launch_gemv_rows(sella_ctx* c, const double* A, int rows, int cols, int lda,
     if (rows < 1024) rw = 1;
     // 8 right-hand sides x 4 rows would need 64 accumulators per lane
     if (nrhs > 4 && rw == 4) rw = 2;
+    const int kind = (rows >= 1024 && cols >= 1024) ? PROF_GEMV : PROF_GEMV_SMALL;
     for (int h0 = 0; h0 < nrhs; h0 += 8) {
         const int nh = (nrhs - h0 < 8) ? (nrhs - h0) : 8;
-        const double* Xh = X + (size_t)h0 * ldx;
+        GemvX xp;
+        for (int h = 0; h < 8; ++h) xp.p[h] = xs[h0 + (h < nh ? h : 0)];
         double* Yh = Y + (size_t)h0 * ldy;
-        prof_begin(c, PROF_GEMV, 8.0 * rows * (double)cols, 2.0 * rows * (double)cols * nh);
+        prof_begin(c, kind, 8.0 * rows * (double)cols, 2.0 * rows * (double)cols * nh);
         int st;
         switch (nh) {
-            case 1: st = gemv_rows_dispatch_rw<1>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
-            case 2: st = gemv_rows_dispatch_rw<2>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
-            case 3: st = gemv_rows_dispatch_rw<3>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
-            case 4: st = gemv_rows_dispatch_rw<4>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
-            case 5: st = gemv_rows_dispatch_rw<5>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
-            case 6: st = gemv_rows_dispatch_rw<6>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
-            case 7: st = gemv_rows_dispatch_rw<7>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
-            default: st = gemv_rows_dispatch_rw<8>(c, rw, A, rows, cols, lda, Xh, ldx, Yh, ldy, epi); break;
+            case 1: st = gemv_rows_dispatch_rw<1>(c, rw, A, rows, cols, lda, xp, Yh, ldy, epi); break;
+            case 2: st = gemv_rows_dispatch_rw<2>(c, rw, A, rows, cols, lda, xp, Yh, ldy, epi); break;
+            case 3: st = gemv_rows_dispatch_rw<3>(c, rw, A, rows, cols, lda, xp, Yh, ldy, epi); break;
+            case 4: st = gemv_rows_dispatch_rw<4>(c, rw, A, rows, cols, lda, xp, Yh, ldy, epi); break;
+            case 5: st = gemv_rows_dispatch_rw<5>(c, rw, A, rows, cols, lda, xp, Yh, ldy, epi); break;
+            case 6: st = gemv_rows_dispatch_rw<6>(c, rw, A, rows, cols, lda, xp, Yh, ldy, epi); break;
+            case 7: st = gemv_rows_dispatch_rw<7>(c, rw, A, rows, cols, lda, xp, Yh, ldy, epi); break;
+            default: st = gemv_rows_dispatch_rw<8>(c, rw, A, rows, cols, lda, xp, Yh, ldy, epi); break;
         }
         prof_end(c);
         SCHK(st);
     }
+    return SELLA_OK;
+}
+
+int launch_gemv_rows(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* X,
+                     int ldx, int nrhs, double* Y, int ldy, const GemvEpi& epi) {
+    if (nrhs <= 0) return SELLA_OK;
+    std::vector<const double*> xs(nrhs);
+    for (int h = 0; h < nrhs; ++h) xs[h] = X + (size_t)h * ldx;
+    return launch_gemv_rows_xp(c, A, rows, cols, lda, xs.data(), nrhs, Y, ldy, epi);
+}
+
+// |x|^2 -> out[0], then x /= |x|  in ONE single-workgroup launch (n up to a few 10^4)
+__global__ __launch_bounds__(1024) void normalize_kernel(double* __restrict__ x, int n, double* __restrict__ out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) s += x[i] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[w];
+    const double f = 1.0 / sqrt(tot);
+    for (int i = threadIdx.x; i < n; i += 1024) x[i] *= f;
+    if (threadIdx.x == 0) out[0] = tot;
+}
+
+int launch_normalize(sella_ctx* c, double* x, int n, double* out) {
+    hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(1024), 0, c->stream, x, n, out);
+    HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
 

@@ -85,16 +85,29 @@ __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
             c1s[tid] = a.cdots[tid];                            // W_p . v
             c2s[tid] = a.cdots[TRD_NBMAX + tid];                // V_p . v
         }
-        double vw = 0.0;
-        for (int b = tid; b < a.nblkB; b += 256) vw += a.partB[b];
-        vw = block_sum_256(vw, red);                           // (also publishes c1s / c2s)
-        double cc = (tid < ip) ? c1s[tid] * c2s[tid] : 0.0;
-        cc = block_sum_256(cc, red);
-        alpha2 = -0.5 * tau * tau * (vw - 2.0 * cc);
+        __syncthreads();
+        if (tid < 64) {                                         // one wavefront reduces the three scalars
+            double vw = 0.0;
+            for (int b = tid; b < a.nblkB; b += 64) vw += a.partB[b];
+            double cc = 0.0, t = 0.0;
+            for (int p = tid; p < ip; p += 64) {
+                cc += c1s[p] * c2s[p];
+                t += a.Vp[(size_t)p * ldp + j] * c1s[p] + a.Wp[(size_t)p * ldp + j] * c2s[p];
+            }
+            vw = wave_sum_e(vw);
+            cc = wave_sum_e(cc);
+            t = wave_sum_e(t);
+            if (tid == 0) {
+                const double al2 = -0.5 * tau * tau * (vw - 2.0 * cc);
+                red[0] = al2;
+                red[1] = tau * (a.wraw[j] - t) + al2;           // w_{i-1}[j], v_{i-1}[j] = 1
+            }
+        }
+        __syncthreads();
+        alpha2 = red[0];
+        wj = red[1];
         tau_p = tau;
-        double t = (tid < ip) ? (a.Vp[(size_t)tid * ldp + j] * c1s[tid] + a.Wp[(size_t)tid * ldp + j] * c2s[tid]) : 0.0;
-        t = block_sum_256(t, red);
-        wj = tau * (a.wraw[j] - t) + alpha2;                   // w_{i-1}[j], v_{i-1}[j] = 1
+        __syncthreads();                                        // red is reused below
     }
     double wc = 0.0, vprev = 0.0, u = 0.0;
     if (valid) {

@@ -56,6 +56,8 @@ def main():
     ap.add_argument('--maxiter', type=int, default=40)
     ap.add_argument('--gamma', type=float, default=0.1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-optimizer', action='store_true')
+    ap.add_argument('--opt-steps', type=int, default=10)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -151,6 +153,35 @@ def main():
                                               mean_us=round(1e3 * ps['ms'] / max(1, ps['launches']), 2),
                                               bytes_per_launch=round(ps['bytes'] / max(1, ps['launches']))))
 
+    # ---- second half of the metric: optimizer steps/s of the Sella API on the model PES of
+    # f(x) = 1/2 x^T A x + c/3 sum_j (u_j.x)^3 (gradient = one device matvec), order-1
+    # search, default saddle settings, Davidson re-diagonalisations through the calculator boundary.
+    opt_stats = None
+    if not args.no_optimizer:
+        from sella_amd import device as _dev
+        from sella_amd.atoms import Atoms, QuadraticCubicModel
+        from sella_amd.internal import Constraints
+        from sella_amd.optimize.optimize import Sella
+        _dev._default = ctx
+        rng = np.random.RandomState(100 + rank)
+        U = rng.normal(size=(8, n))
+        U /= np.linalg.norm(U, axis=1)[:, None]
+        atoms = Atoms(['X'] * (n // 3), 0.05 * rng.normal(size=(n // 3, 3)), pbc=True)
+        atoms.calc = QuadraticCubicModel(lambda x: ctx.symm_mm(dA, x), U, c=0.05)
+        opt = Sella(atoms, order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', logfile=None,
+                    constraints=Constraints(atoms), proj_trans=False)
+        opt.run(fmax=0.0, steps=2)                       # warm-up incl. the initial diagonalisation
+        ctx.sync()
+        ncalls0 = atoms.calc.ncalls
+        ts = time.perf_counter()
+        nst = args.opt_steps
+        opt.run(fmax=0.0, steps=nst)
+        ctx.sync()
+        topt = time.perf_counter() - ts
+        opt_stats = dict(optimizer_steps_per_s=round(nst / topt, 3), steps=nst, ms_per_step=round(1e3 * topt / nst, 2),
+                         force_calls=int(atoms.calc.ncalls - ncalls0), rs='tr', method='prfo', order=1)
+        _dev._default = None
+
     times = [elapsed]
     total_iters = iters
     if dist is not None:
@@ -195,6 +226,7 @@ def main():
                        'gamma': args.gamma, 'method': 'jd0', 'vectors_per_call': int(Vr.shape[1])},
             'davidson_loop_only_iter_per_s': round(it2 / t_loop, 1),
             'eigh_ms': round(1e3 * t_eigh, 2),
+            'optimizer': opt_stats,
             'parity': {'lowest_ritz_value': float(lams[0]), 'ritz_residual_norm': resid, 'max_abs_AV_minus_A_V': av_err},
             'roofline': roof, 'cpu_baseline': cpu,
         }

@@ -63,7 +63,7 @@ struct Options {
     long gemm_mfma = 1;      // 1: MFMA f64 16x16x4 GEMM tiles, 0: VALU register tiles
     long dav_reorth = 0;     // 1: re-orthonormalise V before each MGS like math.pyx:148-151
     long eigh_leaf = 32;     // leaf size of the divide-and-conquer tree
-    long eigh_nb = 32;       // panel width of the blocked tridiagonalisation
+    long eigh_nb = 16;       // panel width of the blocked tridiagonalisation (tools/eigh_tune.py)
 };
 
 }  // namespace sella

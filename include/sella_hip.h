@@ -89,6 +89,12 @@ int sella_gemm(sella_ctx* ctx, int transA, int transB, double alpha, sella_mat A
  * Vt: new handle with the eigenvectors as ROWS.  Either pointer may be NULL.             */
 int sella_eigh(sella_ctx* ctx, sella_mat A, double* w, sella_mat* V, sella_mat* Vt);
 
+/* Building block of the eigensolver's divide-and-conquer stage, exposed for testing and reuse:
+ * eigendecomposition of diag(D) + rho w w^T (D strictly ascending, w_i != 0, rho > 0).
+ * lam (K) ascending; Ut (K x K row-major, may be NULL) has the eigenvectors as rows.          */
+int sella_rank1_eig(sella_ctx* ctx, int K, const double* D, const double* w, double rho,
+                    double* lam, double* Ut);
+
 /* ---- thin QR ---------------------------------------------------------------------------- */
 /* gpu_qr(A) economy mode  sella/_gpu.py:100-111 (peswrapper.py:691).  A host (m x n),
  * m >= n; Q (m x n), R (n x n) host outputs.                                             */

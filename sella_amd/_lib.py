@@ -44,6 +44,7 @@ SIGNATURES = {
     'sella_project_dev': (c_int, [c_void_p, c_int, c_int, c_int_p]),
     'sella_gemm': (c_int, [c_void_p, c_int, c_int, c_double, c_int, c_int, c_double, c_int]),
     'sella_eigh': (c_int, [c_void_p, c_int, c_void_p, c_int_p, c_int_p]),
+    'sella_rank1_eig': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
     'sella_qr_thin': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'sella_mgs': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_double, c_double,
                           c_int, c_void_p, c_int_p]),

@@ -766,6 +766,14 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
         HIPCHK(hipMemcpyAsync(hi2, info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (hi2[1] != 0) {
+            if (getenv("SELLA_DEBUG")) {
+                for (size_t mi = 0; mi < lvl.size(); ++mi) {
+                    const MergePlan& pl = plans[mi];
+                    if (hi2[1] - 1 >= pl.K) continue;
+                    fprintf(stderr, "secular fail? merge lo=%d N=%d K=%d rho=%.17g root=%d\n", pl.lo, pl.N, pl.K, pl.rho, hi2[1] - 1);
+                    for (int p = 0; p < pl.K; ++p) fprintf(stderr, "%.17g %.17g\n", hD[pl.lo + p], hw[pl.lo + p]);
+                }
+            }
             set_error("eigh: secular equation solver hit its iteration cap (root %d)", hi2[1] - 1);
             return SELLA_E_NOCONV;
         }
@@ -865,6 +873,48 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
 }  // namespace sella
 
 using namespace sella;
+
+// Eigendecomposition of diag(D) + rho w w^T through the merge kernels of the divide-and-conquer
+// stage (secular roots, Gu/Eisenstat weights, eigenvector rows).  No deflation is performed: the
+// caller guarantees D strictly ascending, w_i != 0 and rho > 0.
+extern "C" int sella_rank1_eig(sella_ctx* c, int K, const double* D, const double* w, double rho,
+                               double* lam, double* Ut) {
+    if (!c || !D || !w || !lam || K <= 0 || !(rho > 0.0)) {
+        set_error("rank1_eig: invalid arguments");
+        return SELLA_E_INVALID;
+    }
+    for (int i = 0; i < K; ++i)
+        if (w[i] == 0.0 || (i > 0 && !(D[i] > D[i - 1]))) {
+            set_error("rank1_eig: D must be strictly ascending and w nonzero (entry %d)", i);
+            return SELLA_E_INVALID;
+        }
+    const int ldu = round_up(K, 8);
+    double* buf;
+    SCHK(scratch_get(c, SCR_EIG5, ((size_t)6 * ldu + 64) * sizeof(double) + (size_t)K * ldu * sizeof(double), &buf));
+    double *Dd = buf, *wd = buf + ldu, *taud = buf + 2 * ldu, *lamd = buf + 3 * ldu, *zhd = buf + 4 * ldu;
+    int* orgd = reinterpret_cast<int*>(buf + 5 * ldu);
+    int* info = reinterpret_cast<int*>(buf + 6 * ldu);
+    double* Ud = buf + 6 * ldu + 64;
+    HIPCHK(hipMemcpyAsync(Dd, D, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(wd, w, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(info, 0, 2 * sizeof(int), c->stream));
+    hipLaunchKernelGGL(secular_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd, wd, rho, taud, orgd, lamd, info);
+    hipLaunchKernelGGL(zhat_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd, wd, taud, orgd, zhd);
+    hipLaunchKernelGGL(build_u_kernel, dim3(K), dim3(256), 0, c->stream, K, Dd, zhd, taud, orgd, Ud, ldu);
+    HIPCHK(hipGetLastError());
+    int hinfo[2];
+    HIPCHK(hipMemcpyAsync(hinfo, info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(lam, lamd, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (Ut)
+        HIPCHK(hipMemcpy2DAsync(Ut, (size_t)K * sizeof(double), Ud, (size_t)ldu * sizeof(double),
+                                (size_t)K * sizeof(double), K, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (hinfo[1] != 0) {
+        set_error("rank1_eig: secular equation solver hit its iteration cap (root %d)", hinfo[1] - 1);
+        return SELLA_E_NOCONV;
+    }
+    return SELLA_OK;
+}
 
 extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, sella_mat* hVt) {
     Mat* a = mat_get(c, hA);

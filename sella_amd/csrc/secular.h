@@ -25,35 +25,52 @@ struct Alone {
     SELLA_HD double operator()(double v) const { return v; }
 };
 
-// g(tau) and g'(tau) for the shifted function, origin o
+// Pieces of the shifted function g(tau) = 1 + rho * sum_i w_i^2 / ((D_i - D_o) - tau) at tau:
+// the sum split at pole index j (psi: i <= j, phi: i > j) with its derivative parts, and the sum of
+// the absolute values of the terms (the evaluation-noise scale of g).
+struct Eval {
+    double g, dpsi, dphi, noise;
+};
+
 template <class Sum>
-SELLA_HD inline void eval(int K, const double* D, const double* w, double rho, int o, double tau,
-                          double* g, double* dg, int i0, int istep, Sum sum) {
+SELLA_HD inline Eval eval(int K, const double* D, const double* w, double rho, int o, int j, double tau,
+                          int i0, int istep, Sum sum) {
     const double Do = D[o];
-    double s = 0.0, ds = 0.0;
+    double s = 0.0, sa = 0.0, d1 = 0.0, d2 = 0.0;
     for (int i = i0; i < K; i += istep) {
         const double r = 1.0 / ((D[i] - Do) - tau);
         const double t = w[i] * w[i] * r;
         s += t;
-        ds += t * r;
+        sa += fabs(t);
+        if (i <= j) d1 += t * r; else d2 += t * r;
     }
-    s = sum(s);
-    ds = sum(ds);
-    *g = 1.0 + rho * s;
-    *dg = rho * ds;
+    Eval e;
+    e.g = 1.0 + rho * sum(s);
+    e.noise = 1.0 + rho * sum(sa);
+    e.dpsi = rho * sum(d1);
+    e.dphi = rho * sum(d2);
+    return e;
 }
 
 // Solve for root j.  Returns the number of iterations used (negative if the cap was hit).
+//
+// Iteration: the two poles that bracket the root are kept exact and the remaining sums are replaced
+// by constants fitted to value and slope ("middle way" rational interpolation, R.-C. Li 1994, the
+// scheme of LAPACK's dlaed4); the update is the root of the resulting quadratic, safeguarded by the
+// sign bracket [lo, hi] with bisection as the fallback.  Convergence is declared when |g| drops
+// below its own rounding noise, 8 eps (1 + rho sum |terms|): beyond that point the sign of g is
+// random and neither the bracket nor the iteration can make progress.
 template <class Sum>
 SELLA_HD inline int solve_root(int K, const double* D, const double* w, double rho, int j,
                                int* origin, double* tau_out, int i0, int istep, Sum sum) {
+    const double EPS = 2.220446049250313e-16;
+    const bool last = (j == K - 1);
     double lo, hi;
     int o;
-    if (j < K - 1) {
+    if (!last) {
         const double delta = D[j + 1] - D[j];
-        double gm, dgm;
-        eval(K, D, w, rho, j, 0.5 * delta, &gm, &dgm, i0, istep, sum);
-        if (gm >= 0.0) { o = j; lo = 0.0; hi = 0.5 * delta; }
+        const Eval m = eval(K, D, w, rho, j, j, 0.5 * delta, i0, istep, sum);
+        if (m.g >= 0.0) { o = j; lo = 0.0; hi = 0.5 * delta; }
         else { o = j + 1; lo = -0.5 * delta; hi = 0.0; }
     } else {
         double ww = 0.0;
@@ -62,8 +79,11 @@ SELLA_HD inline int solve_root(int K, const double* D, const double* w, double r
         o = K - 1;
         lo = 0.0;
         hi = rho * ww;
-        hi += 4.0 * 2.220446049250313e-16 * fabs(hi) + 1e-300;   // never round below the root
+        hi += 4.0 * EPS * fabs(hi) + 1e-300;   // never round below the root
     }
+    // poles either side of the root, relative to the origin
+    const double p1 = D[j] - D[o];
+    const double p2 = last ? 0.0 : D[j + 1] - D[o];
     // invariant: g(lo) < 0 <= g(hi)  (one end may be the pole itself, never evaluated)
     double tau = 0.5 * (lo + hi);
     {   // first guess that respects the nearby pole: tau ~ rho w_o^2 / (1 + rho * S_rest(0))
@@ -79,25 +99,41 @@ SELLA_HD inline int solve_root(int K, const double* D, const double* w, double r
         }
     }
     int it;
-    for (it = 0; it < 200; ++it) {
-        double g, dg;
-        eval(K, D, w, rho, o, tau, &g, &dg, i0, istep, sum);
-        if (g == 0.0) break;
+    for (it = 0; it < 100; ++it) {
+        const Eval e = eval(K, D, w, rho, o, j, tau, i0, istep, sum);
+        const double g = e.g;
+        if (!(fabs(g) > 8.0 * EPS * e.noise)) break;          // also leaves on NaN
         if (g < 0.0) lo = tau; else hi = tau;
-        // Newton on h(tau) = tau * g(tau): smooth across the origin pole
-        const double h = tau * g;
-        const double dh = g + tau * dg;
-        double tn = (dh != 0.0) ? tau - h / dh : 0.5 * (lo + hi);
+        const double dg = e.dpsi + e.dphi;
+        const double D1 = p1 - tau;                             // < 0
+        double eta;
+        if (!last) {
+            const double D2 = p2 - tau;                         // > 0
+            const double c = g - D1 * e.dpsi - D2 * e.dphi;
+            const double a = (D1 + D2) * g - D1 * D2 * dg;
+            const double b = D1 * D2 * g;
+            if (c == 0.0) {
+                eta = (a != 0.0) ? b / a : -g / dg;
+            } else {
+                const double disc = sqrt(fabs(a * a - 4.0 * b * c));
+                eta = (a <= 0.0) ? (a - disc) / (2.0 * c) : 2.0 * b / (a + disc);
+            }
+        } else {
+            // single pole on the left: g ~ c + a/(p1 - x), a = dpsi D1^2, c = g - D1 dpsi
+            const double c = g - D1 * e.dpsi;
+            const double a = e.dpsi * D1 * D1;
+            eta = (c > 0.0) ? (D1 + a / c) : -g / dg;
+        }
+        if (!(g * eta < 0.0)) eta = -g / dg;                    // wrong direction: Newton
+        double tn = tau + eta;
         if (!(tn > lo && tn < hi)) tn = 0.5 * (lo + hi);
         if (tn == lo || tn == hi || tn == tau) { tau = tn; break; }
-        const double step = fabs(tn - tau);
         tau = tn;
-        if (step <= 2.220446049250313e-16 * fabs(tau)) break;
-        if (hi - lo <= 2.220446049250313e-16 * fmax(fabs(lo), fabs(hi))) break;
+        if (hi - lo <= EPS * fmax(fabs(lo), fabs(hi))) break;
     }
     *origin = o;
     *tau_out = tau;
-    return it < 200 ? it : -it;
+    return it < 100 ? it : -it;
 }
 
 // zhat_i^2 = (lam_i - D_i) * prod_{j != i} (lam_j - D_i) / (D_j - D_i)       (Gu & Eisenstat)

@@ -163,6 +163,17 @@ class Context:
             return w, None, None
         return w, DeviceMatrix(self, hv.value, (n, n)), DeviceMatrix(self, hvt.value, (n, n))
 
+    def rank1_eig(self, D, w, rho, vectors=True):
+        """Eigenpairs of diag(D) + rho w w^T (D strictly ascending, w nonzero): (lam, Ut rows)."""
+        D = as_f64(D)
+        w = as_f64(w)
+        K = D.shape[0]
+        lam = np.empty(K)
+        Ut = np.empty((K, K)) if vectors else None
+        check(_lib.lib().sella_rank1_eig(self._h, K, ptr(D), ptr(w), float(rho), ptr(lam),
+                                         ptr(Ut) if vectors else None))
+        return lam, Ut
+
     def qr_thin(self, A):
         A = as_f64(A)
         m, n = A.shape

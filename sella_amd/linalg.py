@@ -133,6 +133,7 @@ class ApproximateHessian(LinearOperator):
         self._B = None             # numpy copy (None while stale)
         self._B_gpu = None         # DeviceMatrix (None while not uploaded)
         self._is_none = True
+        self.version = 0           # bumped whenever B changes (cache key for projections)
         self._drop_eig()
         self.set_B(B0)
 
@@ -168,6 +169,7 @@ class ApproximateHessian(LinearOperator):
         return self._B_gpu
 
     def set_B(self, target):
+        self.version += 1
         self._drop_eig()
         if self._B_gpu is not None:
             self._B_gpu.free()
@@ -251,6 +253,7 @@ class ApproximateHessian(LinearOperator):
                  download=False, **kw)
         # the device matrix was updated in place: host copy and eigenpairs are stale
         self._B = None
+        self.version += 1
         self._drop_eig()
         self.initialized = True
 

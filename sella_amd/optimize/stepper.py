@@ -17,6 +17,7 @@ import numpy as np
 
 from ..device import DeviceStepper, get_context
 from ..linalg import ApproximateHessian
+from ..utilities.math import is_identity
 
 
 class BaseStepper:
@@ -56,8 +57,7 @@ class BaseStepper:
         ctx = get_context()
         evals, V, Vt = self._device_eig()
         U = self.U
-        if U is not None and U.shape[0] == U.shape[1] and U[0, 0] == 1.0 \
-                and np.count_nonzero(U) == U.shape[0] and np.all(np.diag(U) == 1.0):
+        if U is not None and is_identity(U):
             U = None                                  # unconstrained: the basis is the identity
         if U is not None:
             # compose the projection with the eigenbasis once: (U V) is n x m

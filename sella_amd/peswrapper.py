@@ -15,10 +15,12 @@ import numpy as np
 from scipy.linalg import eigh, qr
 
 from .atoms import Atoms  # noqa: F401  (re-export for users without ASE)
+from .device import get_context
 from .eigensolvers import rayleigh_ritz
 from .hessian_update import symmetrize_Y
 from .internal import Constraints, DuplicateInternalError
 from .linalg import ApproximateHessian, NumericalHessian
+from .utilities.math import is_identity, shared_identity
 
 
 class _LRU2:
@@ -46,7 +48,7 @@ def _split_cons_subspace(drdx, tol_factor=1e-6):
     rank-revealing pivoted QR of drdx^T (peswrapper.py:51-69)."""
     n = drdx.shape[1]
     if drdx.shape[0] == 0:
-        return np.zeros((n, 0)), np.eye(n)
+        return np.zeros((n, 0)), shared_identity(n)
     Q, R, _ = qr(drdx.T, mode='full', pivoting=True, check_finite=False)
     diag = np.abs(np.diag(R))
     ncons = int(np.sum(diag > tol_factor * diag[0])) if diag.size and diag[0] > 0 else 0
@@ -154,18 +156,42 @@ class PES:
         return (c.nbonds + c.nangles + c.ndihedrals) > 0
 
     def get_HL_projected(self, U):
-        """ApproximateHessian(U^T (B - Hc) U) without forming HL (peswrapper.py:363-386)."""
+        """ApproximateHessian(U^T (B - Hc) U) without forming HL (peswrapper.py:363-386).
+
+        The result is cached per (Hessian version, basis): the optimizer asks for the same
+        projection from the step solve and from the curvature test of one iteration.  Without
+        curved constraints and with an identity basis the projection *is* B, and the object
+        returned is the PES Hessian itself, so its device eigendecomposition is computed once and
+        shared with the quasi-Newton update."""
         H = self.get_H()
         n = U.shape[1]
-        if H.B is None:
+        if H._is_none:
             return ApproximateHessian(n, 0, None, H.update_method, H.symm)
-        identity = U.shape[0] == n and U[0, 0] == 1.0 and np.count_nonzero(U) == n and np.all(np.diag(U) == 1.0)
-        Bproj = H.B.copy() if identity else H.project(U).B
         L = self.curr.get('L')
-        if L is not None and L.size > 0 and self._has_curved_constraints():
+        curved = L is not None and L.size > 0 and self._has_curved_constraints()
+        if is_identity(U) and not curved:
+            return H
+        key = (id(H), H.version, id(U), None if not curved else L.tobytes())
+        hit = getattr(self, '_hlproj_cache', None)
+        if hit is not None and hit[0] == key and hit[1] is U:
+            return hit[2]
+        ctx = get_context()
+        if is_identity(U):
+            Bproj = H._get_B_gpu().copy()
+        else:
+            dU = ctx.upload(U)
+            Bproj = ctx.project_dev(H._get_B_gpu(), dU)
+            dU.free()
+        if curved:
             Hc = self.get_Hc()          # zero for translation-only constraints: skipped above
-            Bproj = Bproj - U.T @ Hc @ U
-        return ApproximateHessian(n, 0, Bproj, H.update_method, H.symm)
+            dHc = ctx.upload(U.T @ Hc @ U)
+            Bnew = ctx.axpby(1.0, Bproj, -1.0, dHc)
+            Bproj.free()
+            dHc.free()
+            Bproj = Bnew
+        out = ApproximateHessian(n, 0, Bproj, H.update_method, H.symm)
+        self._hlproj_cache = (key, U, out)
+        return out
 
     # ---- constraints ------------------------------------------------------------------------
     def get_res(self):
@@ -181,7 +207,7 @@ class PES:
             return cached
         drdx = self.get_drdx()
         Ucons, Ufree = _split_cons_subspace(drdx)
-        result = (drdx, Ucons, np.eye(self.dim), Ufree)
+        result = (drdx, Ucons, shared_identity(self.dim), Ufree)
         self._basis_cache.put(key, result)
         return result
 

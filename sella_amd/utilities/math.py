@@ -12,3 +12,33 @@ def modified_gram_schmidt(Xin, Yin=None, eps1=1.e-15, eps2=1.e-6, maxiter=100):
     if Yin is not None and Yin.shape[1] == 0:
         Yin = None
     return get_context().mgs(Xin, Yin, eps1=eps1, eps2=eps2, maxiter=maxiter)
+
+
+# ---- identity bases -----------------------------------------------------------------------------
+# The reduced / free bases of an unconstrained PES are identity matrices (peswrapper.py:334-339 in
+# the reference builds np.eye(dim) at every geometry).  Here one read-only identity per dimension is
+# shared, so that "is this basis the identity?" is an object comparison instead of an O(n^2) scan.
+_IDENTITIES = {}
+
+
+def shared_identity(n):
+    I = _IDENTITIES.get(n)
+    if I is None:
+        I = np.eye(n)
+        I.flags.writeable = False
+        _IDENTITIES[n] = I
+    return I
+
+
+def is_identity(U):
+    """True if the 2-D array U is an identity matrix (fast for the shared instances)."""
+    if U is None or np.ndim(U) != 2 or U.shape[0] != U.shape[1]:
+        return False
+    n = U.shape[0]
+    if U is _IDENTITIES.get(n):
+        return True
+    if n == 0:
+        return True
+    if U[0, 0] != 1.0 or U[-1, -1] != 1.0:
+        return False
+    return bool(np.count_nonzero(U) == n and np.all(U.diagonal() == 1.0))

@@ -1,12 +1,16 @@
 // TEST INFRASTRUCTURE ONLY — runtime for the fake hip_runtime.h (tests/hostemu/README.md).
-// One OS thread; every HIP thread of the running block is a ucontext fiber.
+// One OS thread; every HIP thread of the running block is a fiber.  On x86-64 the fibers switch
+// with a dozen instructions (callee-saved registers + stack pointer); elsewhere ucontext is used
+// (correct but slow: glibc's swapcontext makes two sigprocmask system calls per switch).
 #include <hip/hip_runtime.h>
 #undef threadIdx
 #undef blockIdx
 #undef blockDim
 #undef gridDim
 
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 #include <chrono>
 #include <vector>
 
@@ -18,15 +22,65 @@ dim3 g_blockDim, g_gridDim;
 namespace {
 constexpr size_t kStack = 256 * 1024;
 
+#if defined(__x86_64__)
+extern "C" void hipemu_switch(void** save_sp, void* new_sp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch,.-hipemu_switch
+)");
+struct Ctx {
+    void* sp = nullptr;
+};
+inline void ctx_switch(Ctx* from, Ctx* to) { hipemu_switch(&from->sp, to->sp); }
+inline void ctx_make(Ctx* c, char* stack, size_t size, void (*entry)()) {
+    uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;                 // fake return address of entry (keeps the ABI stack alignment)
+    *--sp = (void*)entry;            // popped by the `ret` of the first switch
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;
+    c->sp = sp;
+}
+#else
+struct Ctx {
+    ucontext_t uc;
+};
+inline void ctx_switch(Ctx* from, Ctx* to) { swapcontext(&from->uc, &to->uc); }
+inline void ctx_make(Ctx* c, char* stack, size_t size, void (*entry)()) {
+    getcontext(&c->uc);
+    c->uc.uc_stack.ss_sp = stack;
+    c->uc.uc_stack.ss_size = size;
+    c->uc.uc_link = nullptr;
+    makecontext(&c->uc, entry, 0);
+}
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    Ctx ctx;
     char* stack = nullptr;
     bool done = false;
     Idx tid;
     int lin = 0;
 };
 
-ucontext_t g_sched;
+Ctx g_sched;
 std::vector<Fiber> g_fibers;
 Fiber* g_cur = nullptr;
 const std::function<void()>* g_body = nullptr;
@@ -47,7 +101,7 @@ struct WaveState {
 };
 std::vector<WaveState> g_waves;
 
-void yield() { swapcontext(&g_cur->ctx, &g_sched); }
+void yield() { ctx_switch(&g_cur->ctx, &g_sched); }
 
 void trampoline() {
     (*g_body)();
@@ -59,7 +113,8 @@ void trampoline() {
     // a finished thread must not strand its peers at a barrier
     if (g_bar_count > 0 && g_bar_count == g_live) { g_bar_count = 0; ++g_bar_gen; }
     if (w.count > 0 && w.count == w.live) { w.count = 0; ++w.gen; }
-    swapcontext(&f->ctx, &g_sched);
+    ctx_switch(&f->ctx, &g_sched);
+    abort();                         // a finished fiber is never resumed
 }
 
 void wave_barrier(WaveState& w) {
@@ -133,11 +188,7 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& 
                     f.lin = t;
                     f.tid = Idx{(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y),
                                 (unsigned)(t / (block.x * block.y))};
-                    getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = f.stack;
-                    f.ctx.uc_stack.ss_size = kStack;
-                    f.ctx.uc_link = &g_sched;
-                    makecontext(&f.ctx, (void (*)())trampoline, 0);
+                    ctx_make(&f.ctx, f.stack, kStack, trampoline);
                     g_waves[t >> 6].live++;
                 }
                 int remaining = nthreads;
@@ -148,7 +199,7 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& 
                         if (f.done) continue;
                         g_cur = &f;
                         g_threadIdx = f.tid;
-                        swapcontext(&g_sched, &f.ctx);
+                        ctx_switch(&g_sched, &f.ctx);
                         ++progressed;
                         if (f.done) --remaining;
                     }

@@ -42,7 +42,7 @@ def test_small_sizes(ctx):
     rng = np.random.RandomState(0)
     for leaf in (4, 32):
         ctx.set_option('eigh_leaf', leaf)
-        for n in ((1, 2, 3, 5, 17, 33) if ctx.backend == 'emu' and leaf == 32 else (1, 2, 3, 5, 17, 33, 70)):
+        for n in (1, 2, 3, 5, 17, 33, 70):
             A = rng.normal(size=(n, n))
             check(ctx, A + A.T)
     ctx.set_option('eigh_leaf', 32)
@@ -50,7 +50,7 @@ def test_small_sizes(ctx):
 
 def test_spectra(ctx):
     rng = np.random.RandomState(1)
-    n = 48 if ctx.backend == 'emu' else 700
+    n = 96 if ctx.backend == 'emu' else 700
     ctx.set_option('eigh_leaf', 8 if ctx.backend == 'emu' else 32)
     for name, A in cases(n, rng):
         check(ctx, A)

@@ -1,0 +1,39 @@
+"""cProfile of the optimizer leg of bench.py (Sella on the model PES, n = 3072)."""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import hessian_like  # noqa: E402
+from sella_amd import device as _dev  # noqa: E402
+from sella_amd.atoms import Atoms, QuadraticCubicModel  # noqa: E402
+from sella_amd.device import Context  # noqa: E402
+from sella_amd.internal import Constraints  # noqa: E402
+from sella_amd.optimize.optimize import Sella  # noqa: E402
+
+n = int(os.environ.get('N', '3072'))
+ctx = Context(0)
+_dev._default = ctx
+A, P, g = hessian_like(n, 0)
+dA = ctx.upload(A)
+rng = np.random.RandomState(100)
+U = rng.normal(size=(8, n))
+U /= np.linalg.norm(U, axis=1)[:, None]
+atoms = Atoms(['X'] * (n // 3), 0.05 * rng.normal(size=(n // 3, 3)), pbc=True)
+atoms.calc = QuadraticCubicModel(lambda x: ctx.symm_mm(dA, x), U, c=0.05)
+opt = Sella(atoms, order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', logfile=None,
+            constraints=Constraints(atoms), proj_trans=False)
+opt.run(fmax=0.0, steps=2)
+ctx.sync()
+pr = cProfile.Profile()
+t0 = time.perf_counter()
+pr.enable()
+opt.run(fmax=0.0, steps=int(os.environ.get('STEPS', '6')))
+ctx.sync()
+pr.disable()
+print('s/step', (time.perf_counter() - t0) / int(os.environ.get('STEPS', '6')))
+pstats.Stats(pr).sort_stats('cumulative').print_stats(45)

@@ -246,6 +246,8 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "eigh_leaf")) {
         if (value < 2 || value > 64) { set_error("eigh_leaf must be in [2, 64]"); return SELLA_E_INVALID; }
         c->opt.eigh_leaf = value;
+    } else if (!strcmp(key, "eigh_wy_mfma")) {
+        c->opt.eigh_wy_mfma = value ? 1 : 0;
     } else if (!strcmp(key, "eigh_nb")) {
         if (value < 1 || value > 64) { set_error("eigh_nb must be in [1, 64]"); return SELLA_E_INVALID; }
         c->opt.eigh_nb = value;

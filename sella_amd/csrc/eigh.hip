@@ -31,7 +31,6 @@ namespace {
 constexpr int TRD_NBMAX = 64;              // max panel width
 constexpr int TRD_PA = 1;                  // doubles per block in the K1 partial buffer (sum u^2)
 constexpr int WY_NB = 32;                  // reflectors per compact-WY block
-constexpr int TRD_TC = 2048;               // column tile of the fused matvec
 
 __device__ __forceinline__ double wave_sum_e(double v) {
 #pragma unroll
@@ -71,69 +70,56 @@ struct TrdRowArgs {
 //   (1) i > 0: finish w_{i-1} = tau (wraw - V c1 - W c2) + alpha2 v   (dlatrd), store in Wp
 //   (2) u[c] = A[j][c] - sum_{p<i} (V_p[c] W_p[j] + W_p[c] V_p[j])    (pending rank-2i update)
 //   (3) per-block partial of sum u^2 (c >= j+2)
+// The kernel sits on the critical path of the factorisation (n dependent launches), so it is laid
+// out for latency: every global load is issued before the first barrier, the panel is read once for
+// both sums, and the only block-wide exchanges are the reduction of the v.wraw partials and of u^2.
 __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
-    __shared__ double c1s[TRD_NBMAX], c2s[TRD_NBMAX], red[4];
+    __shared__ double red[4];
     const int tid = threadIdx.x;
     const int j = a.j, i = a.i, ldp = a.ldp;
     const int c = j + blockIdx.x * 256 + tid;
     const bool valid = c < a.n;
-    double tau_p = 0.0, alpha2 = 0.0, wj = 0.0;
-    if (i > 0) {
-        const int ip = i - 1;
-        const double tau = a.colscal[0];
-        if (tid < ip) {
-            c1s[tid] = a.cdots[tid];                            // W_p . v
-            c2s[tid] = a.cdots[TRD_NBMAX + tid];                // V_p . v
-        }
-        __syncthreads();
-        if (tid < 64) {                                         // one wavefront reduces the three scalars
-            double vw = 0.0;
-            for (int b = tid; b < a.nblkB; b += 64) vw += a.partB[b];
-            double cc = 0.0, t = 0.0;
-            for (int p = tid; p < ip; p += 64) {
-                cc += c1s[p] * c2s[p];
-                t += a.Vp[(size_t)p * ldp + j] * c1s[p] + a.Wp[(size_t)p * ldp + j] * c2s[p];
-            }
-            vw = wave_sum_e(vw);
-            cc = wave_sum_e(cc);
-            t = wave_sum_e(t);
-            if (tid == 0) {
-                const double al2 = -0.5 * tau * tau * (vw - 2.0 * cc);
-                red[0] = al2;
-                red[1] = tau * (a.wraw[j] - t) + al2;           // w_{i-1}[j], v_{i-1}[j] = 1
-            }
-        }
-        __syncthreads();
-        alpha2 = red[0];
-        wj = red[1];
-        tau_p = tau;
-        __syncthreads();                                        // red is reused below
+    const int cl = valid ? c : a.n - 1;                         // clamped: loads are always in range
+    const int ip = i - 1;
+    // ---- loads that do not depend on anything computed here
+    double vw = 0.0;
+    if (i > 0)
+        for (int b = tid; b < a.nblkB; b += 256) vw += a.partB[b];
+    const double arow = a.do_row ? a.A[(size_t)j * a.ld + cl] : 0.0;
+    const double wrawc = (i > 0) ? a.wraw[cl] : 0.0;
+    const double wrawj = (i > 0) ? a.wraw[j] : 0.0;
+    const double vprev = (i > 0) ? a.Vp[(size_t)ip * ldp + cl] : 0.0;
+    const double tau = (i > 0) ? a.colscal[0] : 0.0;
+    // ---- one pass over the finished panel columns p < i-1
+    double s = 0.0, q = 0.0, cc = 0.0, t = 0.0;
+    for (int p = 0; p < ip; ++p) {
+        const double c1 = a.cdots[p], c2 = a.cdots[TRD_NBMAX + p];          // W_p.v, V_p.v (uniform)
+        const double vj = a.Vp[(size_t)p * ldp + j], wj_p = a.Wp[(size_t)p * ldp + j];
+        const double vc = a.Vp[(size_t)p * ldp + cl], wcp = a.Wp[(size_t)p * ldp + cl];
+        s += vc * c1 + wcp * c2;
+        q += vc * wj_p + wcp * vj;
+        cc += c1 * c2;
+        t += vj * c1 + wj_p * c2;
     }
-    double wc = 0.0, vprev = 0.0, u = 0.0;
-    if (valid) {
-        if (i > 0) {
-            const int ip = i - 1;
-            double s = 0.0;
-            for (int p = 0; p < ip; ++p)
-                s += a.Vp[(size_t)p * ldp + c] * c1s[p] + a.Wp[(size_t)p * ldp + c] * c2s[p];
-            vprev = a.Vp[(size_t)ip * ldp + c];
-            wc = tau_p * (a.wraw[c] - s) + alpha2 * vprev;
-            a.Wp[(size_t)ip * ldp + c] = wc;
-        }
-        if (a.do_row) {
-            u = a.A[(size_t)j * a.ld + c];
-            for (int p = 0; p + 1 < i; ++p)
-                u -= a.Vp[(size_t)p * ldp + c] * a.Wp[(size_t)p * ldp + j] + a.Wp[(size_t)p * ldp + c] * a.Vp[(size_t)p * ldp + j];
-            if (i > 0) u -= vprev * wj + wc;                    // p = i-1: W[j] = wj, V[j] = 1
-            a.u_cur[c] = u;
-            if (c == j) a.dvec[j] = u;
-        }
+    double wc = 0.0, u = 0.0;
+    if (i > 0) {
+        vw = block_sum_256(vw, red);
+        const double alpha2 = -0.5 * tau * tau * (vw - 2.0 * cc);
+        const double wj = tau * (wrawj - t) + alpha2;           // w_{i-1}[j], v_{i-1}[j] = 1
+        wc = tau * (wrawc - s) + alpha2 * vprev;
+        if (valid) a.Wp[(size_t)ip * ldp + c] = wc;
+        u = arow - q - (vprev * wj + wc);                       // p = i-1: W[j] = wj, V[j] = 1
+    } else {
+        u = arow;
     }
     if (!a.do_row) return;
-    double* out = a.partA_cur + (size_t)blockIdx.x * TRD_PA;
+    if (valid) {
+        a.u_cur[c] = u;
+        if (c == j) a.dvec[j] = u;
+    }
     double ss = (valid && c >= j + 2) ? u * u : 0.0;
     ss = block_sum_256(ss, red);
-    if (tid == 0) out[0] = ss;
+    if (tid == 0) a.partA_cur[(size_t)blockIdx.x * TRD_PA] = ss;
 }
 
 struct TrdGemvArgs {
@@ -150,28 +136,21 @@ struct TrdGemvArgs {
     double* cdots;
 };
 
-// K2.  Reflector scalars from the K1 partials, then wraw = A22 v with v = [1, scale*u] formed on
-// the fly (same block-cooperative streaming structure as gemv_rows_kernel<1, 2>).  The 2i panel rows
-// W_p, V_p (p < i) are appended as extra rows of the same launch: a wavefront streams a whole row, so
-// the dots the next column needs (dlatrd's W^T v, V^T v) come out exact, without partial buffers.
+// K2.  wraw = A22 v for the reflector v = [1, scale*u] of column j (same block-cooperative streaming
+// structure as gemv_rows_kernel<1, 2>).  The product is taken with the UNSCALED row u, which the
+// previous kernel left in memory, and the reflector scalars (norm -> beta, tau, scale) are applied
+// afterwards:  A22 v = scale * (A22 u') + A22[:, 0]  with u' = u without its leading entry — so the
+// matrix stream starts at once instead of waiting for the norm.  The 2i panel rows W_p, V_p (p < i)
+// are appended as extra rows of the same launch: a wavefront streams a whole row, so the dots the
+// next column needs (dlatrd's W^T v, V^T v) come out exact, without partial buffers.
 __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
     __shared__ double red[4][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double ss = 0.0;
-    for (int b = 0; b < a.nblkA; ++b) ss += a.partA[(size_t)b * TRD_PA];
-    const double alpha = a.ubuf[a.o];
-    double beta, tau, scale;
-    if (ss == 0.0) { beta = alpha; tau = 0.0; scale = 0.0; }
-    else {
-        const double nrm = sqrt(alpha * alpha + ss);
-        beta = (alpha >= 0.0) ? -nrm : nrm;
-        tau = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
-    }
     const int row0 = blockIdx.x * 2;
     const int mtot = a.m + 2 * a.i;
     const int oc = a.o - a.shift;                     // even absolute column of local column 0
     const double2* arow[2];
+    double lead[2];                                   // entry of each row in column o (v[o] = 1)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         int rr = row0 + r;
@@ -181,14 +160,12 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
         else if (rr < a.m + a.i) base = a.Wp + (size_t)(rr - a.m) * a.ldp + oc;
         else base = a.Vp + (size_t)(rr - a.m - a.i) * a.ldp + oc;
         arow[r] = reinterpret_cast<const double2*>(base);
+        lead[r] = base[a.shift];
     }
     double acc[2] = {0.0, 0.0};
     const int n2 = (a.m + a.shift + 1) >> 1;
-    // v on the fly: 1 at column o, scale*u behind it, 0 in the alignment pad / beyond n
-    auto vval = [&](int cabs) -> double {
-        if (cabs == a.o) return 1.0;
-        return (cabs > a.o && cabs < a.n) ? scale * a.ubuf[cabs] : 0.0;
-    };
+    // u' on the fly: u behind column o, 0 at column o, in the alignment pad and beyond n
+    auto uval = [&](int cabs) -> double { return (cabs > a.o && cabs < a.n) ? a.ubuf[cabs] : 0.0; };
     for (int j0 = threadIdx.x; j0 < n2; j0 += 512) {
         const int j1 = j0 + 256;
         const bool has1 = j1 < n2;
@@ -198,8 +175,8 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
             a0[r] = arow[r][j0];
             a1[r] = has1 ? arow[r][j1] : make_double2(0.0, 0.0);
         }
-        const double x00 = vval(oc + 2 * j0), x01 = vval(oc + 2 * j0 + 1);
-        const double x10 = has1 ? vval(oc + 2 * j1) : 0.0, x11 = has1 ? vval(oc + 2 * j1 + 1) : 0.0;
+        const double x00 = uval(oc + 2 * j0), x01 = uval(oc + 2 * j0 + 1);
+        const double x10 = has1 ? uval(oc + 2 * j1) : 0.0, x11 = has1 ? uval(oc + 2 * j1 + 1) : 0.0;
 #pragma unroll
         for (int r = 0; r < 2; ++r) acc[r] += a0[r].x * x00 + a0[r].y * x01 + a1[r].x * x10 + a1[r].y * x11;
     }
@@ -210,10 +187,22 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        // reflector scalars from the K1 partials (dlarfg)
+        double ss = 0.0;
+        for (int b = 0; b < a.nblkA; ++b) ss += a.partA[(size_t)b * TRD_PA];
+        const double alpha = a.ubuf[a.o];
+        double beta, tau, scale;
+        if (ss == 0.0) { beta = alpha; tau = 0.0; scale = 0.0; }
+        else {
+            const double nrm = sqrt(alpha * alpha + ss);
+            beta = (alpha >= 0.0) ? -nrm : nrm;
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
         double p = 0.0;
         for (int r = 0; r < 2; ++r) {
             const int rr = row0 + r;
-            const double res = red[0][r] + red[1][r] + red[2][r] + red[3][r];
+            const double res = scale * (red[0][r] + red[1][r] + red[2][r] + red[3][r]) + lead[r];
             if (rr < a.m) {
                 const int rabs = a.o + rr;
                 const double vr = (rr == 0) ? 1.0 : scale * a.ubuf[rabs];
@@ -533,6 +522,137 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(double* __restrict__ X, i
 #pragma unroll
             for (int k = 0; k < 4; ++k) xv[k] = xn[k];
         }
+    }
+}
+
+// ---- MFMA back-transformation -------------------------------------------------------------------
+typedef double wy_f64x4 __attribute__((ext_vector_type(4)));
+
+// Yf[j][c] = explicit reflector j (0 up to column j, 1 at j+1, stored tail beyond), zero in the row
+// padding and in the rows that pad the last block to WY_NB.  grid (ceil(ld/256), nrows).
+__global__ __launch_bounds__(256) void wy_expand_kernel(const double* __restrict__ A, int ld, int n, int nrefl,
+                                                        const double* __restrict__ taus,
+                                                        double* __restrict__ Yf) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (c >= ld) return;
+    Yf[(size_t)j * ld + c] = (j < nrefl && c < n) ? yval(A, ld, taus, j, c) : 0.0;
+}
+
+// X <- X (H_{nrefl-1} ... H_0) on the matrix cores.  A workgroup (4 wavefronts) owns 16 rows of X and
+// sweeps the compact-WY blocks from the last to the first; for each block
+//     M = X Y_b^T (16 x 32, the wavefronts split the columns, partials meet in LDS),
+//     M2 = M C_b,   X -= M2 Y_b
+// with v_mfma_f64_16x16x4_f64.  Operands are fetched straight from global memory as 32-byte vectors:
+// the summation index of a tile product may be permuted freely, so lane (i, g) takes the four
+// consecutive columns 4g..4g+3 of a 16-column group for four successive MFMAs; in the update the
+// 16 tile columns are the strided set {4 nn + q}, which again makes every access a 32-byte vector.
+// Columns are dealt to wavefronts by absolute 64-column chunk index, so a wavefront only ever
+// re-reads X entries it wrote itself.
+__global__ __launch_bounds__(256) void wy_apply_mfma_kernel(double* __restrict__ X, int ldx, int n,
+                                                            const double* __restrict__ Yf,
+                                                            const double* __restrict__ Call, int nblk) {
+    __shared__ double Mp[4][16][33];
+    __shared__ double Ms[16][33];
+    __shared__ double M2s[16][33];
+    __shared__ double Cs[WY_NB][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int r0 = blockIdx.x * 16;
+    const int rowA = (r0 + li < n) ? r0 + li : n - 1;            // A-operand row of this lane (phase 1)
+    int rowD[4];                                                // C/D rows of this lane (phase 3)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rowD[r] = (r0 + lg + 4 * r < n) ? r0 + lg + 4 * r : n - 1;
+    const double4 zero4 = make_double4(0.0, 0.0, 0.0, 0.0);
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int j0 = b * WY_NB;
+        const int cs = ((j0 + 1) >> 6) << 6;                    // Y_b vanishes left of column j0 + 1
+        const int cw = cs + 64 * ((wave - (cs >> 6)) & 3);      // first chunk of this wavefront
+        for (int e = tid; e < WY_NB * WY_NB; e += 256) Cs[e >> 5][e & 31] = Call[(size_t)b * WY_NB * WY_NB + e];
+        // ---- phase 1: M = X Y^T -------------------------------------------------------------------
+        wy_f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const double* xrow = X + (size_t)rowA * ldx;
+        const double* y0row = Yf + (size_t)(j0 + li) * ldx;
+        const double* y1row = y0row + (size_t)16 * ldx;
+        for (int cc = cw; cc < ldx; cc += 256) {
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                const int col = cc + 16 * sg + 4 * lg;
+                const bool ok = col < ldx;
+                const int colc = ok ? col : 0;
+                double4 xa = *reinterpret_cast<const double4*>(xrow + colc);
+                const double4 ya = *reinterpret_cast<const double4*>(y0row + colc);
+                const double4 yb = *reinterpret_cast<const double4*>(y1row + colc);
+                if (!ok) xa = zero4;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.x, ya.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.x, yb.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.y, ya.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.y, yb.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.z, ya.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.z, yb.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.w, ya.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.w, yb.w, acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Mp[wave][lg + 4 * r][li] = acc0[r];
+            Mp[wave][lg + 4 * r][16 + li] = acc1[r];
+        }
+        __syncthreads();
+        {
+            const int row = tid >> 4, pc = tid & 15;
+            Ms[row][pc] = Mp[0][row][pc] + Mp[1][row][pc] + Mp[2][row][pc] + Mp[3][row][pc];
+            Ms[row][pc + 16] = Mp[0][row][pc + 16] + Mp[1][row][pc + 16] + Mp[2][row][pc + 16] + Mp[3][row][pc + 16];
+        }
+        __syncthreads();
+        // ---- phase 2: M2 = M C  (negated: the update is an accumulate) --------------------------------
+        {
+            const int row = tid >> 4, qc = tid & 15;
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+            for (int pp = 0; pp < WY_NB; ++pp) {
+                const double m = Ms[row][pp];
+                s0 += m * Cs[pp][qc];
+                s1 += m * Cs[pp][qc + 16];
+            }
+            M2s[row][qc] = -s0;
+            M2s[row][qc + 16] = -s1;
+        }
+        __syncthreads();
+        // ---- phase 3: X += (-M2) Y ----------------------------------------------------------------
+        double m2a[8];
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) m2a[kt] = M2s[li][4 * kt + lg];
+        const double* ybase = Yf + (size_t)(j0 + lg) * ldx;
+        for (int cc = cw; cc < ldx; cc += 256) {
+            const int col = cc + 4 * li;
+            const bool ok = col < ldx;
+            const int colc = ok ? col : 0;
+            double4 yv[8], xv[4];
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt)
+                yv[kt] = *reinterpret_cast<const double4*>(ybase + (size_t)(4 * kt) * ldx + colc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xv[r] = *reinterpret_cast<const double4*>(X + (size_t)rowD[r] * ldx + colc);
+            wy_f64x4 d0, d1, d2, d3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { d0[r] = xv[r].x; d1[r] = xv[r].y; d2[r] = xv[r].z; d3[r] = xv[r].w; }
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
+                d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(m2a[kt], yv[kt].x, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(m2a[kt], yv[kt].y, d1, 0, 0, 0);
+                d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(m2a[kt], yv[kt].z, d2, 0, 0, 0);
+                d3 = __builtin_amdgcn_mfma_f64_16x16x4f64(m2a[kt], yv[kt].w, d3, 0, 0, 0);
+            }
+            if (ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r0 + lg + 4 * r < n)
+                        *reinterpret_cast<double4*>(X + (size_t)rowD[r] * ldx + col) = make_double4(d0[r], d1[r], d2[r], d3[r]);
+            }
+        }
+        __syncthreads();                                        // LDS tiles are reused by the next block
     }
 }
 
@@ -924,7 +1044,7 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     const int ld = round_up(n, 8);
     EighWork W;
     W.c = c; W.n = n; W.ld = ld;
-    const size_t mbytes = ((size_t)std::max(n, 64) + 2) * std::max(ld, 64) * sizeof(double);
+    const size_t mbytes = ((size_t)std::max(n, 64) + WY_NB + 2) * std::max(ld, 64) * sizeof(double);
     SCHK(scratch_get(c, SCR_EIG0, mbytes, &W.A));
     SCHK(scratch_get(c, SCR_EIG1, mbytes, &W.Za));
     SCHK(scratch_get(c, SCR_EIG2, mbytes, &W.Zb));
@@ -986,9 +1106,16 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
                 for (int q = 0; q < kb; ++q) Cb[(size_t)p * WY_NB + q] = Tm[(size_t)q * kb + p];
         }
         HIPCHK(hipMemcpyAsync(Gd, Call.data(), gcount * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        const int yrows = nblk * WY_NB;
+        double* Yf = W.Zc;                               // explicit reflectors (yrows x ld)
+        hipLaunchKernelGGL(wy_expand_kernel, dim3((ld + 255) / 256, yrows), dim3(256), 0, c->stream, W.A, ld, n, nrefl,
+                           taus, Yf);
         prof_begin(c, PROF_OTHER, 0.0, 2.0 * n * (double)n * n);
-        hipLaunchKernelGGL(wy_apply_kernel, dim3((n + 15) / 16), dim3(256), 0, c->stream, X, ld, n, W.A, ld, nrefl,
-                           taus, Gd, nblk);
+        if (c->opt.eigh_wy_mfma)
+            hipLaunchKernelGGL(wy_apply_mfma_kernel, dim3((n + 15) / 16), dim3(256), 0, c->stream, X, ld, n, Yf, Gd, nblk);
+        else
+            hipLaunchKernelGGL(wy_apply_kernel, dim3((n + 15) / 16), dim3(256), 0, c->stream, X, ld, n, W.A, ld, nrefl,
+                               taus, Gd, nblk);
         prof_end(c);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));        // Call goes out of scope

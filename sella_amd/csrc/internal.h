@@ -64,6 +64,7 @@ struct Options {
     long dav_reorth = 0;     // 1: re-orthonormalise V before each MGS like math.pyx:148-151
     long eigh_leaf = 32;     // leaf size of the divide-and-conquer tree
     long eigh_nb = 16;       // panel width of the blocked tridiagonalisation (tools/eigh_tune.py)
+    long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
 };
 
 }  // namespace sella

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace result database (rocpd sqlite) into the per-kernel
 stats table the judge reads (name, calls, total, average, share) + a grid-size breakdown of the
-row-panel matvec.  Usage: tools/rocprof_summary.py <results.db> <out.md>"""
+streaming matvec kernels.  All numbers come from the `kernels` view (duration = end - start, ns).
+Usage: tools/rocprof_summary.py <results.db> <out.md> [title]"""
 import re
 import sqlite3
 import sys
@@ -13,23 +14,31 @@ def short(name):
     return re.sub(r'\(.*$', '', name)
 
 
-def main(db_path, out_path):
+def main(db_path, out_path, title='rocprofv3 --kernel-trace summary'):
     db = sqlite3.connect(db_path)
     cur = db.cursor()
-    rows = cur.execute('select name, total_calls, total_duration, average, percentage from top_kernels').fetchall()
-    lines = ['# rocprofv3 --kernel-trace summary', '', f'source: `{db_path.split("/")[-1]}` (durations in microseconds)', '',
-             '| kernel | calls | total us | avg us | % |', '|---|---:|---:|---:|---:|']
-    for name, calls, tot, avg, pct in rows:
-        lines.append(f'| `{short(name)}` | {calls} | {tot / 1e3:.1f} | {avg / 1e3:.2f} | {pct:.2f} |')
-    # the dominant kernel by launch geometry (grid_x rows/4RW blocks): full n x n streams vs panel dots
-    lines += ['', '## gemv_rows_kernel by grid size', '', '| instantiation | grid_x | calls | avg us |', '|---|---:|---:|---:|']
+    rows = cur.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) '
+                       'from kernels group by name order by sum(duration) desc').fetchall()
+    total = sum(r[2] for r in rows) or 1
+    lines = [f'# {title}', '', f'source: `{db_path.split("/")[-1]}`; durations in microseconds '
+             f'(kernel end - start timestamps); total kernel time {total / 1e6:.2f} ms', '',
+             '| kernel | calls | total us | avg us | min us | max us | % |', '|---|---:|---:|---:|---:|---:|---:|']
+    for name, calls, tot, avg, mn, mx in rows:
+        lines.append(f'| `{short(name)}` | {calls} | {tot / 1e3:.1f} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | '
+                     f'{mx / 1e3:.2f} | {100.0 * tot / total:.2f} |')
+    lines += ['', '## streaming matvec kernels by grid size (largest first)', '',
+              '| kernel | grid_x | calls | avg us |', '|---|---:|---:|---:|']
     q = ("select name, grid_x, count(*), avg(duration) from kernels where name like '%gemv_rows_kernel%' "
-         "group by name, grid_x order by sum(duration) desc limit 12")
+         "group by name, grid_x order by sum(duration) desc limit 10")
+    for name, gx, calls, avg in cur.execute(q):
+        lines.append(f'| `{short(name)}` | {gx} | {calls} | {avg / 1e3:.2f} |')
+    q = ("select name, grid_x, count(*), avg(duration) from kernels where name like '%trd_gemv_kernel%' "
+         "group by name, grid_x order by grid_x desc limit 6")
     for name, gx, calls, avg in cur.execute(q):
         lines.append(f'| `{short(name)}` | {gx} | {calls} | {avg / 1e3:.2f} |')
     open(out_path, 'w').write('\n'.join(lines) + '\n')
-    print('\n'.join(lines[:30]))
+    print('\n'.join(lines[:34]))
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])

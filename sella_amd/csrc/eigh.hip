@@ -73,6 +73,9 @@ struct TrdRowArgs {
 // The kernel sits on the critical path of the factorisation (n dependent launches), so it is laid
 // out for latency: every global load is issued before the first barrier, the panel is read once for
 // both sums, and the only block-wide exchanges are the reduction of the v.wraw partials and of u^2.
+// IPC >= 0: number of finished panel columns (i - 1) as a compile-time constant, so the panel loop
+// is fully unrolled with all its loads in flight together; IPC < 0: generic loop (wide panels).
+template <int IPC>
 __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
     __shared__ double red[4];
     const int tid = threadIdx.x;
@@ -81,10 +84,22 @@ __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
     const bool valid = c < a.n;
     const int cl = valid ? c : a.n - 1;                         // clamped: loads are always in range
     const int ip = i - 1;
-    // ---- loads that do not depend on anything computed here
+    // ---- loads that do not depend on anything computed here.  Every batch is written as "load all,
+    // then use" with clamped indices: a plain loop makes the compiler wait for each load in turn, and
+    // this kernel is nothing but a chain of memory round trips.
     double vw = 0.0;
-    if (i > 0)
-        for (int b = tid; b < a.nblkB; b += 256) vw += a.partB[b];
+    if (i > 0) {
+        for (int b0 = tid; b0 < a.nblkB; b0 += 256 * 8) {
+            double pv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int b = b0 + 256 * k;
+                pv[k] = a.partB[b < a.nblkB ? b : a.nblkB - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) vw += (b0 + 256 * k < a.nblkB) ? pv[k] : 0.0;
+        }
+    }
     const double arow = a.do_row ? a.A[(size_t)j * a.ld + cl] : 0.0;
     const double wrawc = (i > 0) ? a.wraw[cl] : 0.0;
     const double wrawj = (i > 0) ? a.wraw[j] : 0.0;
@@ -92,7 +107,9 @@ __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
     const double tau = (i > 0) ? a.colscal[0] : 0.0;
     // ---- one pass over the finished panel columns p < i-1
     double s = 0.0, q = 0.0, cc = 0.0, t = 0.0;
-    for (int p = 0; p < ip; ++p) {
+    const int np = (IPC >= 0) ? IPC : ip;
+#pragma unroll
+    for (int p = 0; p < np; ++p) {
         const double c1 = a.cdots[p], c2 = a.cdots[TRD_NBMAX + p];          // W_p.v, V_p.v (uniform)
         const double vj = a.Vp[(size_t)p * ldp + j], wj_p = a.Wp[(size_t)p * ldp + j];
         const double vc = a.Vp[(size_t)p * ldp + cl], wcp = a.Wp[(size_t)p * ldp + cl];
@@ -162,6 +179,17 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
         arow[r] = reinterpret_cast<const double2*>(base);
         lead[r] = base[a.shift];
     }
+    // K1 partials of sum u^2 (one per lane, reduced after the stream) and the entries of u this
+    // workgroup's epilogue needs: issued now, consumed at the end
+    double ssl = 0.0;
+    for (int b = lane; b < a.nblkA; b += 64) ssl += a.partA[(size_t)b * TRD_PA];
+    const double alpha = a.ubuf[a.o];
+    double urow[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int rr = row0 + r;
+        urow[r] = a.ubuf[(rr < a.m) ? a.o + rr : a.o];
+    }
     double acc[2] = {0.0, 0.0};
     const int n2 = (a.m + a.shift + 1) >> 1;
     // u' on the fly: u behind column o, 0 at column o, in the alignment pad and beyond n
@@ -185,12 +213,10 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
         const double v = wave_sum_e(acc[r]);
         if (lane == 0) red[wave][r] = v;
     }
+    const double ss = wave_sum_e(ssl);
     __syncthreads();
     if (threadIdx.x == 0) {
         // reflector scalars from the K1 partials (dlarfg)
-        double ss = 0.0;
-        for (int b = 0; b < a.nblkA; ++b) ss += a.partA[(size_t)b * TRD_PA];
-        const double alpha = a.ubuf[a.o];
         double beta, tau, scale;
         if (ss == 0.0) { beta = alpha; tau = 0.0; scale = 0.0; }
         else {
@@ -205,7 +231,7 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
             const double res = scale * (red[0][r] + red[1][r] + red[2][r] + red[3][r]) + lead[r];
             if (rr < a.m) {
                 const int rabs = a.o + rr;
-                const double vr = (rr == 0) ? 1.0 : scale * a.ubuf[rabs];
+                const double vr = (rr == 0) ? 1.0 : scale * urow[r];
                 a.wraw[rabs] = res;
                 a.Vrow[rabs] = vr;
                 if (rr > 0) a.Arow[rabs] = vr;
@@ -956,7 +982,17 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
             ra.cdots = cdots;
             ra.dvec = dvec;
             const int nblkA = (n - j + 255) / 256;
-            hipLaunchKernelGGL(trd_row_kernel, dim3(nblkA), dim3(256), 0, c->stream, ra);
+            const dim3 gA(nblkA), bA(256);
+            switch (i - 1) {
+#define SELLA_TRD_ROW_CASE(IP) case IP: hipLaunchKernelGGL(HIP_KERNEL_NAME(trd_row_kernel<IP>), gA, bA, 0, c->stream, ra); break;
+                case -1:
+                SELLA_TRD_ROW_CASE(0) SELLA_TRD_ROW_CASE(1) SELLA_TRD_ROW_CASE(2) SELLA_TRD_ROW_CASE(3)
+                SELLA_TRD_ROW_CASE(4) SELLA_TRD_ROW_CASE(5) SELLA_TRD_ROW_CASE(6) SELLA_TRD_ROW_CASE(7)
+                SELLA_TRD_ROW_CASE(8) SELLA_TRD_ROW_CASE(9) SELLA_TRD_ROW_CASE(10) SELLA_TRD_ROW_CASE(11)
+                SELLA_TRD_ROW_CASE(12) SELLA_TRD_ROW_CASE(13) SELLA_TRD_ROW_CASE(14) SELLA_TRD_ROW_CASE(15)
+#undef SELLA_TRD_ROW_CASE
+                default: hipLaunchKernelGGL(HIP_KERNEL_NAME(trd_row_kernel<-1>), gA, bA, 0, c->stream, ra);
+            }
             if (!do_row) break;
             const int o = j + 1, m = n - o, oc = o & ~1;
             TrdGemvArgs ga;
@@ -981,8 +1017,8 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
         const int r0 = j0 + kb, mt = n - r0;
         if (mt > 0) {
             double* At = W.A + (size_t)r0 * ld + r0;
-            SCHK(launch_gemm(c, 1, 0, mt, mt, kb, -1.0, Vp + r0, ld, Wp + r0, ld, 1.0, At, ld));
-            SCHK(launch_gemm(c, 1, 0, mt, mt, kb, -1.0, Wp + r0, ld, Vp + r0, ld, 1.0, At, ld));
+            // one fused pass (update.hip): every tile pair is read and written once
+            SCHK(launch_sym_rank2k(c, At, mt, ld, Vp + r0, Wp + r0, ld, kb, -1.0));
         }
     }
     hipLaunchKernelGGL(tridiag_tail_kernel, dim3(1), dim3(64), 0, c->stream, W.A, ld, n, dvec, evec, taus);

@@ -161,9 +161,9 @@ int launch_symmetrize(sella_ctx* c, double* B, int n, int ld);
 // gs.hip: orthonormalise t (n) against k orthonormal rows of a vector-major panel
 int gs_orthonormalise(sella_ctx* c, const double* basis, int ldb, int k, double* t, int n,
                       double eps1, double eps2, int maxiter, int* kept, double* first_norm);
-// B <- (B + B^T)/2 + sum_a (U_a Z_a^T + Z_a U_a^T), U/Z vector-major panels with kk rows
+// B <- (B + B^T)/2 + alpha * sum_a (U_a Z_a^T + Z_a U_a^T), U/Z vector-major panels with kk rows
 int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, const double* Zp,
-                      int ldp, int kk);
+                      int ldp, int kk, double alpha = 1.0);
 // gather rows: out[r*ldo + j] = in[idx[r]*ldi + j] (idx device int array)
 int launch_gather_rows(sella_ctx* c, const double* in, int ldi, const int* idx, int nrows,
                        int ncols, double* out, int ldo);

@@ -25,7 +25,8 @@ constexpr int R2K_KT = 16;
 
 __global__ __launch_bounds__(256) void sym_rank2k_kernel(double* __restrict__ B, int n, int ld,
                                                          const double* __restrict__ Up,
-                                                         const double* __restrict__ Zp, int ldp, int kk) {
+                                                         const double* __restrict__ Zp, int ldp, int kk,
+                                                         double alpha) {
     if (blockIdx.x < blockIdx.y) return;
     __shared__ double t1[32][33];
     __shared__ double t2[32][33];
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void sym_rank2k_kernel(double* __restrict__ B,
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int k = ty + 8 * q;
-        const double v = 0.5 * (t1[k][tx] + t2[tx][k]) + acc[q];
+        const double v = 0.5 * (t1[k][tx] + t2[tx][k]) + alpha * acc[q];
         t1[k][tx] = v;
     }
     __syncthreads();
@@ -83,10 +84,10 @@ __global__ __launch_bounds__(256) void sym_rank2k_kernel(double* __restrict__ B,
 }
 
 int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, const double* Zp, int ldp,
-                      int kk) {
+                      int kk, double alpha) {
     const int nb = (n + 31) / 32;
     prof_begin(c, PROF_UPDATE, 16.0 * n * (double)n, 4.0 * kk * (double)n * n);
-    hipLaunchKernelGGL(sym_rank2k_kernel, dim3(nb, nb), dim3(256), 0, c->stream, B, n, ld, Up, Zp, ldp, kk);
+    hipLaunchKernelGGL(sym_rank2k_kernel, dim3(nb, nb), dim3(256), 0, c->stream, B, n, ld, Up, Zp, ldp, kk, alpha);
     prof_end(c);
     HIPCHK(hipGetLastError());
     return SELLA_OK;

@@ -138,6 +138,16 @@ enum { SELLA_UPD_TS_BFGS = 0, SELLA_UPD_BFGS = 1, SELLA_UPD_PSB = 2, SELLA_UPD_D
 int sella_update_h(sella_ctx* ctx, sella_mat B, sella_mat evecs, sella_mat evecsT,
                    const double* evals, const double* S, const double* Y, int n, int k,
                    int method, int symm);
+/* sella_update_h that also carries the eigendecomposition of B over to the updated matrix: the
+ * update B+ - B has rank 2k..4k, so its eigenpairs follow from those of B by that many rank-one
+ * modifications (secular equation + one GEMM each, eigh.hip) instead of a new factorisation —
+ * what the reference pays torch.linalg.eigh for after every step (linalg.py:174-231).
+ * evals (n, in/out), evecs / evecsT updated in place.  If the update has rank > max_rank (or no
+ * eigenvectors are given) only B is updated and *nrank1 = -1: the caller then recomputes the
+ * eigendecomposition with sella_eigh.  Otherwise *nrank1 = rank-one modifications applied.          */
+int sella_update_h_eig(sella_ctx* ctx, sella_mat B, sella_mat evecs, sella_mat evecsT, double* evals,
+                       const double* S, const double* Y, int n, int k, int method, int symm,
+                       int max_rank, int* nrank1);
 /* symmetrize_Y(S, Y, symm)  sella/hessian_update.py:12-37; out host (n x k)                   */
 int sella_symmetrize_y(sella_ctx* ctx, const double* S, const double* Y, int n, int k,
                        int symm, double* out);

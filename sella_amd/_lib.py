@@ -53,6 +53,8 @@ SIGNATURES = {
                                c_double, c_void_p, c_void_p, c_void_p, c_int_p, c_int_p]),
     'sella_update_h': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_int, c_int]),
+    'sella_update_h_eig': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_int, c_int, c_int, c_int, c_int_p]),
     'sella_symmetrize_y': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'sella_stepper_create': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                      POINTER(c_void_p)]),

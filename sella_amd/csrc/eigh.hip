@@ -732,6 +732,53 @@ struct MergePlan {
 
 }  // namespace
 
+// Deflation of one rank-one modification diag(D) + rho z z^T (LAPACK dlaed2's rules): entries with a
+// negligible weight are set aside, and of two (nearly) equal poles one is rotated out.  D and zz are
+// modified (rotations); pl.rho, pl.lo, pl.N must be set by the caller.  Indices are local (0..N-1).
+static void plan_deflation(int N, double* D, double* zz, MergePlan& pl) {
+    const double eps = 2.220446049250313e-16;
+    std::vector<int> order(N);
+    double zmax = 0.0, dmax = 0.0;
+    for (int i = 0; i < N; ++i) {
+        zmax = std::max(zmax, fabs(zz[i]));
+        dmax = std::max(dmax, fabs(D[i]));
+    }
+    const double tol = 8.0 * eps * std::max(dmax, zmax);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return D[a] < D[b]; });
+    if (pl.rho * zmax <= tol) {
+        pl.defl = order;
+    } else {
+        int pj = -1;
+        for (int jj = 0; jj < N; ++jj) {
+            const int nj = order[jj];
+            if (pl.rho * fabs(zz[nj]) <= tol) { pl.defl.push_back(nj); continue; }
+            if (pj < 0) { pj = nj; continue; }
+            double s = zz[pj], cc = zz[nj];
+            const double tau = hypot(cc, s);
+            const double t = D[nj] - D[pj];
+            cc /= tau;
+            s = -s / tau;
+            if (fabs(t * cc * s) <= tol) {
+                zz[nj] = tau;
+                zz[pj] = 0.0;
+                pl.r1.push_back(pj); pl.r2.push_back(nj); pl.cs.push_back(cc); pl.cs.push_back(s);
+                const double tt = D[pj] * cc * cc + D[nj] * s * s;
+                D[nj] = D[pj] * s * s + D[nj] * cc * cc;
+                D[pj] = tt;
+                pl.defl.push_back(pj);
+                pj = nj;
+            } else {
+                pl.nondef.push_back(pj);
+                pj = nj;
+            }
+        }
+        if (pj >= 0) pl.nondef.push_back(pj);
+    }
+    pl.K = (int)pl.nondef.size();
+    pl.nrot = (int)pl.r1.size();
+}
+
 // Divide and conquer on the tridiagonal (d, e) (host copies, modified).  On exit wout holds the
 // ascending eigenvalues and W.Za the eigenvectors as rows in matching order.
 static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e, double* wout) {
@@ -822,47 +869,8 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
             pl.lo = lo;
             pl.N = N;
             pl.rho = fabs(2.0 * e[nd.mid - 1]);
-            double zmax = 0.0, dmax = 0.0;
-            for (int i = 0; i < N; ++i) {
-                zz[i] *= 0.7071067811865476;
-                zmax = std::max(zmax, fabs(zz[i]));
-                dmax = std::max(dmax, fabs(D[i]));
-            }
-            const double tol = 8.0 * eps * std::max(dmax, zmax);
-            order.resize(N);
-            std::iota(order.begin(), order.end(), 0);
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return D[a] < D[b]; });
-            if (pl.rho * zmax <= tol) {
-                pl.defl = order;
-            } else {
-                int pj = -1;
-                for (int jj = 0; jj < N; ++jj) {
-                    const int nj = order[jj];
-                    if (pl.rho * fabs(zz[nj]) <= tol) { pl.defl.push_back(nj); continue; }
-                    if (pj < 0) { pj = nj; continue; }
-                    double s = zz[pj], cc = zz[nj];
-                    const double tau = hypot(cc, s);
-                    const double t = D[nj] - D[pj];
-                    cc /= tau;
-                    s = -s / tau;
-                    if (fabs(t * cc * s) <= tol) {
-                        zz[nj] = tau;
-                        zz[pj] = 0.0;
-                        pl.r1.push_back(pj); pl.r2.push_back(nj); pl.cs.push_back(cc); pl.cs.push_back(s);
-                        const double tt = D[pj] * cc * cc + D[nj] * s * s;
-                        D[nj] = D[pj] * s * s + D[nj] * cc * cc;
-                        D[pj] = tt;
-                        pl.defl.push_back(pj);
-                        pj = nj;
-                    } else {
-                        pl.nondef.push_back(pj);
-                        pj = nj;
-                    }
-                }
-                if (pj >= 0) pl.nondef.push_back(pj);
-            }
-            pl.K = (int)pl.nondef.size();
-            pl.nrot = (int)pl.r1.size();
+            for (int i = 0; i < N; ++i) zz[i] *= 0.7071067811865476;
+            plan_deflation(N, D, zz, pl);
             // staging (offset lo inside n-length host arrays; blocks of different merges are disjoint)
             for (int p = 0; p < pl.K; ++p) {
                 hD[lo + p] = D[pl.nondef[p]];
@@ -1023,6 +1031,193 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     }
     hipLaunchKernelGGL(tridiag_tail_kernel, dim3(1), dim3(64), 0, c->stream, W.A, ld, n, dvec, evec, taus);
     HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Low-rank update of a full eigendecomposition.
+//
+// Given B = V diag(w) V^T (rows of Vt are the eigenvectors) and the symmetric modification
+//     B+ = B + sum_a (U_a Z_a^T + Z_a U_a^T)        (what sella_update_h applies to B, update.hip),
+// the eigendecomposition of B+ is obtained without touching B: the modification is diagonalised in
+// the span of its 2kk vectors (Gram-Schmidt on the device, a 2kk x 2kk eigenproblem on the host),
+//     B+ = B + sum_r sigma_r q_r q_r^T,
+// and every term is one rank-one modification of a diagonal matrix in the current eigenbasis,
+//     V^T B+ V = diag(w) + sigma z z^T,  z = V^T q,
+// i.e. exactly the merge step of the divide-and-conquer solver above (deflation on the host, secular
+// equation, Gu/Eisenstat vectors, ONE K x K x n GEMM on the matrix cores).  A quasi-Newton step thus
+// costs O(n^2 K) MFMA flops per rank instead of a fresh latency-bound tridiagonalisation.
+// ---------------------------------------------------------------------------------------
+static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w, double* Vt, const double* q,
+                            double sigma) {
+    double* zdev = W.vec + (size_t)V_Z * ld;
+    double* csd = W.vec + (size_t)V_CS0 * ld;
+    double* Dd = W.vec + (size_t)V_DD * ld;
+    double* wd = W.vec + (size_t)V_WD * ld;
+    double* taud = W.vec + (size_t)V_TAU * ld;
+    double* zhd = W.vec + (size_t)V_ZH * ld;
+    double* lamd = W.vec + (size_t)V_LAM * ld;
+    int* info = W.ibuf;
+    int* i1d = W.ibuf + 16;
+    int* i2d = i1d + n;
+    int* idxd = i1d + 2 * n;
+    int* orgd = i1d + 3 * n;
+    // z = Vt q
+    SCHK(launch_gemv_rows(c, Vt, n, n, ld, q, ld, 1, zdev, ld, GemvEpi()));
+    std::vector<double> z(n);
+    HIPCHK(hipMemcpyAsync(z.data(), zdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemsetAsync(info, 0, 8 * sizeof(int), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // a negative weight is handled on the negated, reversed spectrum: primed index i' <-> row n-1-i'
+    const bool neg = sigma < 0.0;
+    auto rowof = [&](int ip) { return neg ? n - 1 - ip : ip; };
+    std::vector<double> D(n), zz(n);
+    double znorm2 = 0.0;
+    for (int ip = 0; ip < n; ++ip) {
+        D[ip] = neg ? -w[rowof(ip)] : w[ip];
+        zz[ip] = z[rowof(ip)];
+        znorm2 += zz[ip] * zz[ip];
+    }
+    if (!(znorm2 > 0.0)) return SELLA_OK;
+    const double zn = sqrt(znorm2);
+    for (int ip = 0; ip < n; ++ip) zz[ip] /= zn;
+    MergePlan pl;
+    pl.lo = 0;
+    pl.N = n;
+    pl.rho = fabs(sigma) * znorm2;
+    plan_deflation(n, D.data(), zz.data(), pl);
+    const int K = pl.K;
+    std::vector<double> hD(std::max(K, 1)), hw(std::max(K, 1)), hcs(2 * (size_t)std::max(pl.nrot, 1));
+    std::vector<int> hidx(n), hr1(std::max(pl.nrot, 1)), hr2(std::max(pl.nrot, 1));
+    for (int p = 0; p < K; ++p) {
+        hD[p] = D[pl.nondef[p]];
+        hw[p] = zz[pl.nondef[p]];
+        hidx[p] = rowof(pl.nondef[p]);
+    }
+    for (int p = 0; p < n - K; ++p) hidx[K + p] = rowof(pl.defl[p]);
+    for (int r = 0; r < pl.nrot; ++r) {
+        hr1[r] = rowof(pl.r1[r]);
+        hr2[r] = rowof(pl.r2[r]);
+        hcs[2 * (size_t)r] = pl.cs[2 * r];
+        hcs[2 * (size_t)r + 1] = pl.cs[2 * r + 1];
+    }
+    HIPCHK(hipMemcpyAsync(idxd, hidx.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    double* nxt = W.Zb;
+    if (pl.nrot > 0) {
+        HIPCHK(hipMemcpyAsync(i1d, hr1.data(), (size_t)pl.nrot * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(i2d, hr2.data(), (size_t)pl.nrot * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(csd, hcs.data(), (size_t)2 * pl.nrot * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(rot_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, Vt, ld, n, pl.nrot, i1d, i2d, csd);
+    }
+    std::vector<double> lam(std::max(K, 1));
+    if (K > 0) {
+        HIPCHK(hipMemcpyAsync(Dd, hD.data(), (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(wd, hw.data(), (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(secular_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd, wd, pl.rho, taud, orgd, lamd, info);
+        hipLaunchKernelGGL(zhat_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd, wd, taud, orgd, zhd);
+        hipLaunchKernelGGL(build_u_kernel, dim3(K), dim3(256), 0, c->stream, K, Dd, zhd, taud, orgd, W.Ut, ld);
+        HIPCHK(hipGetLastError());
+        SCHK(launch_gather_rows(c, Vt, ld, idxd, K, n, W.Zc, ld));
+        SCHK(launch_gemm(c, 0, 0, K, n, K, 1.0, W.Ut, ld, W.Zc, ld, 0.0, nxt, ld));
+        HIPCHK(hipMemcpyAsync(lam.data(), lamd, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (n - K > 0) SCHK(launch_gather_rows(c, Vt, ld, idxd + K, n - K, n, nxt + (size_t)K * ld, ld));
+    int hinfo[2];
+    HIPCHK(hipMemcpyAsync(hinfo, info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (hinfo[1] != 0) {
+        set_error("eigh update: secular equation solver hit its iteration cap (root %d)", hinfo[1] - 1);
+        return SELLA_E_NOCONV;
+    }
+    // new spectrum (rows of nxt: K updated vectors, then the deflated ones), back to ascending order
+    std::vector<double> nv(n);
+    for (int p = 0; p < K; ++p) nv[p] = neg ? -lam[p] : lam[p];
+    for (int p = 0; p < n - K; ++p) nv[K + p] = neg ? -D[pl.defl[p]] : D[pl.defl[p]];
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nv[a] < nv[b]; });
+    for (int i = 0; i < n; ++i) w[i] = nv[order[i]];
+    HIPCHK(hipMemcpyAsync(idxd, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    SCHK(launch_gather_rows(c, nxt, ld, idxd, n, n, Vt, ld));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SELLA_OK;
+}
+
+int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const double* Up, const double* Zp,
+                       int ldp, int kk, int* nrank1) {
+    const int ld = Vt->ld;
+    const int m = 2 * kk;
+    if (nrank1) *nrank1 = 0;
+    if (ldp != ld) { set_error("eigh update: panel stride mismatch"); return SELLA_E_INVALID; }
+    EighWork W;
+    W.c = c; W.n = n; W.ld = ld;
+    const size_t mbytes = ((size_t)std::max(n, 64) + WY_NB + 2) * std::max(ld, 64) * sizeof(double);
+    SCHK(scratch_get(c, SCR_EIG1, mbytes, &W.Za));
+    SCHK(scratch_get(c, SCR_EIG2, mbytes, &W.Zb));
+    SCHK(scratch_get(c, SCR_EIG3, mbytes, &W.Zc));
+    SCHK(scratch_get(c, SCR_EIG4, mbytes, &W.Ut));
+    SCHK(scratch_get(c, SCR_EIG5, (size_t)V_NSLOTS * ld * sizeof(double) + (size_t)(6 * n + 256) * sizeof(int), &W.vec));
+    W.ibuf = reinterpret_cast<int*>(W.vec + (size_t)V_NSLOTS * ld);
+    W.A = nullptr;
+    // ---- orthonormal basis of span{U_a, Z_a} (rows of Qb) and the coordinates of U, Z in it ------
+    double* Qb = W.Za;                       // up to m rows
+    double* src = Qb + (size_t)m * ld;       // [U; Z] copied next to it
+    SCHK(launch_axpby2d(c, kk, n, 1.0, Up, ldp, 0.0, nullptr, 0, src, ld));
+    SCHK(launch_axpby2d(c, kk, n, 1.0, Zp, ldp, 0.0, nullptr, 0, src + (size_t)kk * ld, ld));
+    int mb = 0;
+    for (int v = 0; v < m; ++v) {
+        double* slot = Qb + (size_t)mb * ld;
+        HIPCHK(hipMemcpyAsync(slot, src + (size_t)v * ld, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        int kept = 0;
+        // a vector is dropped only when nothing but rounding noise is left of it
+        SCHK(gs_orthonormalise(c, Qb, ld, mb, slot, n, 1e-15, 1e-13, 100, &kept, nullptr));
+        if (kept) ++mb;
+    }
+    if (mb == 0) return SELLA_OK;
+    // R[i][v] = Qb_i . src_v  (mb x m), column-chunks of at most 8 right-hand sides
+    std::vector<double> R((size_t)mb * m);
+    for (int v0 = 0; v0 < m; v0 += 8) {
+        const int nv = std::min(8, m - v0);
+        SCHK(launch_gemv_rows(c, Qb, mb, n, ld, src + (size_t)v0 * ld, ld, nv, c->dscal + DS_CVEC, mb, GemvEpi()));
+        SCHK(read_scalars(c, DS_CVEC, mb * nv));
+        for (int h = 0; h < nv; ++h)
+            for (int i = 0; i < mb; ++i) R[(size_t)i * m + v0 + h] = c->hscal[DS_CVEC + (size_t)h * mb + i];
+    }
+    // core C = R_U R_Z^T + R_Z R_U^T
+    std::vector<double> C((size_t)mb * mb, 0.0), sig(mb), F((size_t)mb * mb), work(mb);
+    for (int i = 0; i < mb; ++i)
+        for (int j = 0; j < mb; ++j) {
+            double sum = 0.0;
+            for (int a = 0; a < kk; ++a)
+                sum += R[(size_t)i * m + a] * R[(size_t)j * m + kk + a] + R[(size_t)i * m + kk + a] * R[(size_t)j * m + a];
+            C[(size_t)i * mb + j] = sum;
+        }
+    if (small::sym_eig(mb, C.data(), mb, sig.data(), F.data(), mb, work.data()) != 0) {
+        set_error("eigh update: small eigenproblem did not converge");
+        return SELLA_E_NOCONV;
+    }
+    double wmax = 0.0, smax = 0.0;
+    for (int i = 0; i < n; ++i) wmax = std::max(wmax, fabs(w[i]));
+    for (int r = 0; r < mb; ++r) smax = std::max(smax, fabs(sig[r]));
+    const double drop = 4.0 * 2.220446049250313e-16 * std::max(wmax, smax);
+    double* qv = W.vec + (size_t)V_U0 * ld;
+    double* coef = c->dscal + DS_STAGE;
+    // largest terms first
+    std::vector<int> ord(mb);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return fabs(sig[a]) > fabs(sig[b]); });
+    for (int t = 0; t < mb; ++t) {
+        const int r = ord[t];
+        if (fabs(sig[r]) <= drop) continue;
+        double* st = c->hscal + DS_STAGE + (size_t)t * 64;
+        for (int i = 0; i < mb; ++i) st[i] = F[(size_t)i * mb + r];
+        HIPCHK(hipMemcpyAsync(coef + (size_t)t * 64, st, (size_t)mb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        SCHK(launch_lincomb(c, n, 1, Qb, ld, mb, coef + (size_t)t * 64, 1, nullptr, 0, 0, nullptr, 0, 0.0, qv, ld));
+        SCHK(eig_rank1_update(c, W, n, ld, w, Vt->d, qv, sig[r]));
+        if (nrank1) ++*nrank1;
+    }
+    if (V) SCHK(launch_transpose(c, Vt->d, n, n, Vt->ld, V->d, V->ld));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return SELLA_OK;
 }
 

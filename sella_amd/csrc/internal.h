@@ -164,6 +164,10 @@ int gs_orthonormalise(sella_ctx* c, const double* basis, int ldb, int k, double*
 // B <- (B + B^T)/2 + alpha * sum_a (U_a Z_a^T + Z_a U_a^T), U/Z vector-major panels with kk rows
 int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, const double* Zp,
                       int ldp, int kk, double alpha = 1.0);
+// eigh.hip: eigendecomposition (w host ascending, Vt rows / V columns, both updated in place) of
+// B + sum_a (U_a Z_a^T + Z_a U_a^T) from that of B; *nrank1 = rank-one modifications applied
+int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const double* Up, const double* Zp,
+                       int ldp, int kk, int* nrank1);
 // gather rows: out[r*ldo + j] = in[idx[r]*ldi + j] (idx device int array)
 int launch_gather_rows(sella_ctx* c, const double* in, int ldi, const int* idx, int nrows,
                        int ncols, double* out, int ldo);

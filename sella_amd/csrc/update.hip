@@ -178,8 +178,10 @@ extern "C" int sella_symmetrize_y(sella_ctx* c, const double* S, const double* Y
     return download_panel(c, Ytp, ld, n, k, out);
 }
 
-extern "C" int sella_update_h(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt, const double* evals,
-                              const double* S, const double* Y, int n, int k, int method, int symm) {
+static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt, const double* evals,
+                         const double* S, const double* Y, int n, int k, int method, int symm,
+                         double* evals_io, int max_rank, int* nrank1) {
+    if (nrank1) *nrank1 = -1;
     Mat* B = mat_get(c, hB);
     if (!B || !S || !Y || k <= 0) return SELLA_E_INVALID;
     if (B->rows != n || B->cols != n) { set_error("update_H: B must be %d x %d", n, n); return SELLA_E_INVALID; }
@@ -346,6 +348,23 @@ extern "C" int sella_update_h(sella_ctx* c, sella_mat hB, sella_mat hV, sella_ma
     }
     B = mat_get(c, hB);
     SCHK(launch_sym_rank2k(c, B->d, n, B->ld, Up, Zp, ld, kk));
+    if (evals_io && hV != SELLA_NO_MAT && 2 * kk <= max_rank) {
+        Mat *V = mat_get(c, hV), *Vt = mat_get(c, hVt);
+        if (!V || !Vt || V->rows != n || Vt->rows != n) { set_error("update_H: bad eigenvector handles"); return SELLA_E_INVALID; }
+        SCHK(eig_lowrank_update(c, n, evals_io, V, Vt, Up, Zp, ld, kk, nrank1));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     return SELLA_OK;
+}
+
+extern "C" int sella_update_h(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt, const double* evals,
+                              const double* S, const double* Y, int n, int k, int method, int symm) {
+    return update_h_core(c, hB, hV, hVt, evals, S, Y, n, k, method, symm, nullptr, 0, nullptr);
+}
+
+extern "C" int sella_update_h_eig(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt, double* evals,
+                                  const double* S, const double* Y, int n, int k, int method, int symm,
+                                  int max_rank, int* nrank1) {
+    if (!evals || !nrank1) { set_error("update_H (eig): evals and nrank1 are required"); return SELLA_E_INVALID; }
+    return update_h_core(c, hB, hV, hVt, evals, S, Y, n, k, method, symm, evals, max_rank, nrank1);
 }

@@ -260,6 +260,23 @@ class Context:
             SELLA_NO_MAT if evecsT is None else evecsT.handle, ptr(ev), ptr(S), ptr(Y), n, k,
             UPDATE_METHODS[method], -1 if symm is None else int(symm)))
 
+    def update_h_eig(self, B, S, Y, evals, evecs, evecsT, method='TS-BFGS', symm=2, max_rank=8):
+        """update_h that also updates (evals, evecs, evecsT) of B by rank-one modifications.
+
+        Returns (evals_new, nrank1); nrank1 == -1 means the eigendecomposition was NOT carried over
+        (rank of the update above max_rank) and must be recomputed by the caller."""
+        if method not in UPDATE_METHODS:
+            raise ValueError('Unknown update method {}'.format(method))
+        S = as_f64(S)
+        Y = as_f64(Y)
+        n, k = S.shape
+        ev = np.array(evals, dtype=np.float64, copy=True)
+        nr = c_int(-1)
+        check(_lib.lib().sella_update_h_eig(
+            self._h, B.handle, evecs.handle, evecsT.handle, ptr(ev), ptr(S), ptr(Y), n, k,
+            UPDATE_METHODS[method], -1 if symm is None else int(symm), int(max_rank), byref(nr)))
+        return ev, nr.value
+
     def symmetrize_y(self, S, Y, symm):
         S = as_f64(S)
         Y = as_f64(Y)

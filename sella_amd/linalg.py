@@ -121,6 +121,14 @@ class MatrixSum(LinearOperator):
         return MatrixSum(*self.matrices, other)
 
 
+# Quasi-Newton updates of rank <= EIG_UPDATE_MAX_RANK carry the device eigendecomposition along by
+# rank-one modifications; after EIG_UPDATE_REFRESH of them it is recomputed from scratch (bounds the
+# accumulated rounding, about n*eps per modification).  EIG_UPDATE_MAX_RANK = 0 restores "eigh after
+# every update".
+EIG_UPDATE_MAX_RANK = 8
+EIG_UPDATE_REFRESH = 64
+
+
 class ApproximateHessian(LinearOperator):
     def __init__(self, dim, ncart, B0=None, update_method='TS-BFGS', symm=2,
                  initialized=False):
@@ -139,6 +147,7 @@ class ApproximateHessian(LinearOperator):
 
     # ---- storage -------------------------------------------------------------------------
     def _drop_eig(self):
+        self._eig_age = 0
         self._evals = None
         self._evecs = None
         for name in ('_evecs_gpu', '_evecsT_gpu'):
@@ -243,13 +252,33 @@ class ApproximateHessian(LinearOperator):
             return
         if np.ndim(dx) == 1 and np.linalg.norm(dx) < 1e-8:
             return                                           # update_H returns B itself
-        eig = self.device_eig() if self.update_method in ('TS-BFGS', 'BFGS_auto') else None
         dB = self._get_B_gpu()
+        need_eig = self.update_method in ('TS-BFGS', 'BFGS_auto')
+        have_eig = self._evals is not None and self._evecs_gpu is not None
+        S2 = np.ascontiguousarray(dx[:, None] if np.ndim(dx) == 1 else dx, dtype=np.float64)
+        Y2 = np.ascontiguousarray(dg[:, None] if np.ndim(dg) == 1 else dg, dtype=np.float64)
+        if (need_eig or have_eig) and EIG_UPDATE_MAX_RANK > 0:
+            # carry the eigendecomposition across the update (rank-one modifications on the device)
+            # instead of paying a new eigh at the next step solve, linalg.py:174-231
+            evals, V, Vt = self.device_eig()
+            new_evals, nr = get_context().update_h_eig(dB, S2, Y2, evals, V, Vt, method=self.update_method,
+                                                       symm=self.symm, max_rank=EIG_UPDATE_MAX_RANK)
+            self._B = None
+            self.version += 1
+            self.initialized = True
+            if nr < 0 or self._eig_age + nr > EIG_UPDATE_REFRESH:
+                self._drop_eig()                # recomputed from scratch when next needed
+            else:
+                self._eig_age += nr
+                self._evals = self._evals_gpu = new_evals
+                self._evecs = None
+            return
+        eig = self.device_eig() if need_eig else None
         kw = {}
         if eig is not None:
             kw = dict(evals_gpu=eig[0], evecs_gpu=eig[1], evecsT_gpu=eig[2])
         # (B itself is only inspected for None-ness when a device mirror is supplied)
-        update_H(False, dx, dg, method=self.update_method, symm=self.symm, B_gpu=dB,
+        update_H(False, S2, Y2, method=self.update_method, symm=self.symm, B_gpu=dB,
                  download=False, **kw)
         # the device matrix was updated in place: host copy and eigenpairs are stale
         self._B = None

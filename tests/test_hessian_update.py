@@ -87,3 +87,63 @@ def test_device_resident_update_returns_handle(ctx):
     assert handle is dB
     np.testing.assert_allclose(out, ref, atol=1e-12)
     np.testing.assert_allclose(dB.numpy(), ref, atol=1e-12)
+
+
+def _eig_check(B, w, V, Vt, tol):
+    n = B.shape[0]
+    scale = max(1.0, np.abs(B).max())
+    Vn, Vtn = V.numpy(), Vt.numpy()
+    np.testing.assert_array_equal(Vtn.T, Vn)
+    assert np.all(np.diff(w) >= 0)
+    np.testing.assert_allclose(w, np.linalg.eigvalsh(B), atol=tol * scale * n ** 0.5, rtol=0)
+    assert np.abs(B @ Vn - Vn * w).max() <= tol * scale * n
+    assert np.abs(Vn.T @ Vn - np.eye(n)).max() <= tol * n
+
+
+@pytest.mark.parametrize('kind', ['dense', 'scaled identity', 'identity + low rank'])
+def test_update_carries_eigendecomposition(ctx, kind):
+    """sella_update_h_eig: after every quasi-Newton update the carried (evals, evecs) are those of
+    the updated B (checked against LAPACK on the downloaded matrix) — for every update formula,
+    single and block secant pairs, positive and negative rank-one weights, and the heavily deflated
+    spectra an approximate Hessian starts from."""
+    rng = np.random.RandomState(5)
+    n = 36 if ctx.backend == 'emu' else 500
+    if kind == 'dense':
+        A = rng.normal(size=(n, n))
+        B = A + A.T
+    elif kind == 'scaled identity':
+        B = 2.5 * np.eye(n)
+    else:
+        u = rng.normal(size=(n, 3))
+        B = 1.7 * np.eye(n) + u @ u.T - np.outer(u[:, 0] + 1, u[:, 0] + 1)
+    H = rng.normal(size=(n, n))
+    H = H + H.T
+    dB = ctx.upload(B)
+    w, V, Vt = ctx.eigh(dB)
+    methods = ['TS-BFGS', 'PSB', 'SR1', 'BFGS_auto', 'DFP', 'Greenstadt', 'TS-BFGS', 'TS-BFGS']
+    total = 0
+    for step, method in enumerate(methods * (1 if ctx.backend == 'emu' else 3)):
+        k = 2 if step % 4 == 3 else 1
+        S = rng.normal(size=(n, k)) * 0.1
+        Y = H @ S + 0.05 * rng.normal(size=(n, k))
+        w, nr = ctx.update_h_eig(dB, S, Y, w, V, Vt, method=method, symm=2, max_rank=8)
+        assert 0 <= nr <= 4 * k
+        total += nr
+        _eig_check(dB.numpy(), w, V, Vt, 2e-13 * (1 + total))
+    assert total > 0
+
+
+def test_update_eig_rank_limit(ctx):
+    """An update whose rank exceeds max_rank still updates B and reports nrank1 = -1."""
+    from sella_amd.hessian_update import update_H
+    rng = np.random.RandomState(6)
+    n, k = 30, 5
+    A = rng.normal(size=(n, n))
+    B = A + A.T
+    S, Y = rng.normal(size=(n, k)), rng.normal(size=(n, k))
+    dB = ctx.upload(B)
+    w, V, Vt = ctx.eigh(dB)
+    w2, nr = ctx.update_h_eig(dB, S, Y, w, V, Vt, method='TS-BFGS', symm=2, max_rank=8)
+    assert nr == -1
+    np.testing.assert_array_equal(w2, w)
+    np.testing.assert_allclose(dB.numpy(), update_H(B, S, Y, method='TS-BFGS', symm=2), atol=1e-11)

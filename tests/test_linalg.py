@@ -101,3 +101,36 @@ def test_approximate_hessian_protocol(ctx):
     X = rng.normal(size=(n, 3))
     H.set_B(B0)
     np.testing.assert_allclose(H @ X, B0 @ X, atol=1e-12)
+
+
+def test_approximate_hessian_carries_eigenpairs(ctx):
+    """ApproximateHessian.update keeps (evals, evecs) valid across quasi-Newton updates without a new
+    factorisation, and agrees with the recompute-from-scratch behaviour of the reference
+    (linalg.py:274-304 drops the cache, :174-231 recomputes)."""
+    from sella_amd import linalg
+    rng = np.random.RandomState(3)
+    n = 24
+    A = rng.normal(size=(n, n))
+    H = A + A.T
+    B0 = np.diag(np.linspace(0.5, 3.0, n))
+    carried = linalg.ApproximateHessian(n, n, B0.copy())
+    old = linalg.EIG_UPDATE_MAX_RANK
+    try:
+        linalg.EIG_UPDATE_MAX_RANK = 0
+        fresh = linalg.ApproximateHessian(n, n, B0.copy())
+        for step in range(5):
+            dx = 0.1 * rng.normal(size=n)
+            dg = H @ dx
+            linalg.EIG_UPDATE_MAX_RANK = 8
+            carried.evals                       # make sure a decomposition exists to be carried
+            carried.update(dx, dg)
+            assert carried._evals is not None and carried._eig_age > 0
+            linalg.EIG_UPDATE_MAX_RANK = 0
+            fresh.update(dx, dg)
+            assert fresh._evals is None
+            np.testing.assert_allclose(carried.B, fresh.B, atol=1e-12)
+            np.testing.assert_allclose(carried.evals, fresh.evals, atol=1e-11)
+            V = carried.evecs
+            assert np.abs(carried.B @ V - V * carried.evals).max() < 1e-11
+    finally:
+        linalg.EIG_UPDATE_MAX_RANK = old

@@ -133,25 +133,36 @@ def main():
     resid = float(np.linalg.norm(A @ Vr[:, 0] - lams[0] * Vr[:, 0]))
     av_err = float(np.abs(AVr - A @ Vr).max())
 
-    # ---- roofline of the dominant kernel: instrumented pass (hipEvents on the library stream) ----
+    # ---- roofline: instrumented pass over whole steps (hipEvents on the library stream) ------------
+    # By time the dominant kernel of a step is the trailing-matrix matvec of the tridiagonalisation
+    # (`trd_gemv_kernel`, one launch per column of P, HBM bound: 8*m^2 algorithmic bytes for the
+    # m x m trailing block); the Davidson loop's own n x n streams are reported beside it.
     ctx.prof_reset()
     ctx.prof_enable(True)
-    for _ in range(max(1, min(args.steps, 5))):
-        ctx.davidson(dA, n, g, args.gamma, method='jd0', maxiter=args.maxiter, Pvecs=V, PvecsT=Vt, pevals=w)
+    nprof = max(1, min(args.steps, 3))
+    for _ in range(nprof):
+        one_step()
     ctx.prof_enable(False)
+    pt = ctx.prof_get(5)          # trd_gemv_kernel
     pg = ctx.prof_get(0)          # n x n streams: gemv_rows_kernel<1,2> (A t) and <2,2> (Q^T[r v], Q[a b])
     ps = ctx.prof_get(4)          # panel dots: same template, <*,1> instantiations, k x n, latency bound
-    roof = None
-    if pg['launches'] > 0 and pg['ms'] > 0:
-        achieved = pg['bytes'] / (pg['ms'] * 1e-3) / 1e9
-        roof = dict(bound='hbm', kernel='gemv_rows_kernel<NRHS,2> (n x n row-panel matvec)',
-                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
-                    unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
-                    launches=pg['launches'], mean_us=round(1e3 * pg['ms'] / pg['launches'], 2),
-                    bytes_per_launch=round(pg['bytes'] / pg['launches']),
-                    small_panel_launches=dict(launches=ps['launches'],
-                                              mean_us=round(1e3 * ps['ms'] / max(1, ps['launches']), 2),
-                                              bytes_per_launch=round(ps['bytes'] / max(1, ps['launches']))))
+
+    def hbm(p, kernel):
+        if p['launches'] <= 0 or p['ms'] <= 0:
+            return None
+        achieved = p['bytes'] / (p['ms'] * 1e-3) / 1e9
+        return dict(bound='hbm', kernel=kernel, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, launches=p['launches'],
+                    mean_us=round(1e3 * p['ms'] / p['launches'], 2),
+                    bytes_per_launch=round(p['bytes'] / p['launches']))
+
+    roof = hbm(pt, 'trd_gemv_kernel (m x m trailing-matrix matvec, one per column of the eigh of P)')
+    if roof is not None:
+        roof['share_of_step_ms'] = round(pt['ms'] / nprof, 2)
+        roof['davidson_matvec'] = hbm(pg, 'gemv_rows_kernel<NRHS,2> (n x n row-panel matvec of the Davidson loop)')
+        roof['davidson_panel_dots'] = dict(launches=ps['launches'],
+                                           mean_us=round(1e3 * ps['ms'] / max(1, ps['launches']), 2),
+                                           bytes_per_launch=round(ps['bytes'] / max(1, ps['launches'])))
 
     # ---- second half of the metric: optimizer steps/s of the Sella API on the model PES of
     # f(x) = 1/2 x^T A x + c/3 sum_j (u_j.x)^3 (gradient = one device matvec), order-1
@@ -207,10 +218,17 @@ def main():
         tc = time.perf_counter()
         lc, Vc, AVc = orc.rayleigh_ritz(A, args.gamma, P, v0=g, method='jd0', maxiter=args.maxiter)
         tcpu = time.perf_counter() - tc
+        # Step-for-step parity where it is defined: the Krylov trajectory amplifies a 1-ulp change about
+        # 10x per iteration (tools/krylov_sensitivity.py), so the comparison that means
+        # something is the Ritz value after the first few expansions, not after 25-30 of them.
+        l4c, _, _ = orc.rayleigh_ritz(A, args.gamma, P, v0=g, method='jd0', maxiter=4)
+        l4h, _, _, _ = ctx.davidson(dA, n, g, args.gamma, method='jd0', maxiter=4, Pvecs=V, PvecsT=Vt, pevals=w)
         cpu = dict(value=round(Vc.shape[1] / tcpu, 4), unit='davidson_iter/s', cores=int(threads), kind='port',
                    sample=f'1 call of oracle rayleigh_ritz (reference algorithm: dense LU per iteration), '
                           f'n={n}, k={Vc.shape[1]} vectors, {tcpu:.1f} s',
-                   lam0_abs_diff_vs_hip=float(abs(lc[0] - lams[0])), k=int(Vc.shape[1]))
+                   k=int(Vc.shape[1]),
+                   lam0_rel_diff_after_4_iterations=float(abs(l4c[0] - l4h[0]) / abs(l4c[0])),
+                   lam0_abs_diff_at_exit=float(abs(lc[0] - lams[0])))
 
     if rank == 0:
         value = total_iters / tmax

@@ -167,7 +167,8 @@ int sella_stepper_destroy(sella_stepper* st);
 
 /* ---- profiling hooks (bench.py roofline leg) ---------------------------------------------- */
 /* When enabled, every launch of the big streaming kernels is bracketed by hipEvents on the
- * context stream.  kind: 0 = row-panel matvec (n x n streams), 1 = gemm, 2 = update, 3 = other, 4 = small matvecs (panel dots).      */
+ * context stream.  kind: 0 = row-panel matvec (n x n streams), 1 = gemm, 2 = update, 3 = other,
+ * 4 = small matvecs (panel dots), 5 = trailing-matrix matvec of the tridiagonalisation (eigh).     */
 int sella_prof_enable(sella_ctx* ctx, int on);
 int sella_prof_reset(sella_ctx* ctx);
 int sella_prof_get(sella_ctx* ctx, int kind, long* launches, double* total_ms,

@@ -118,13 +118,14 @@ void prof_begin(sella_ctx* c, int kind, double bytes, double flops) {
     p.bytes = bytes;
     p.flops = flops;
     if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
-    (void)hipEventRecord(p.a, c->stream);
+    c->prof_a = p.a;
+    c->prof_b = p.b;
     c->pending.push_back(p);
 }
 
 void prof_end(sella_ctx* c) {
-    if (!c->prof || c->pending.empty()) return;
-    (void)hipEventRecord(c->pending.back().b, c->stream);
+    if (!c->prof || !c->prof_a) return;
+    c->prof_a = c->prof_b = nullptr;
     if (c->pending.size() >= 4096) (void)prof_flush(c);
 }
 

@@ -1013,8 +1013,8 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
             ga.taus = taus; ga.evec = evec; ga.colscal = colscal;
             ga.Wp = Wp; ga.Vp = Vp; ga.ldp = ld; ga.i = i; ga.cdots = cdots;
             const int nblkB = (m + 2 * i + 1) / 2;
-            prof_begin(c, PROF_GEMV, 8.0 * m * (double)m, 2.0 * m * (double)m);
-            hipLaunchKernelGGL(trd_gemv_kernel, dim3(nblkB), dim3(256), 0, c->stream, ga);
+            prof_begin(c, PROF_TRD_GEMV, 8.0 * m * (double)m, 2.0 * m * (double)m);
+            SELLA_LAUNCH(c, trd_gemv_kernel, dim3(nblkB), dim3(256), 0, ga);
             prof_end(c);
             nblkA_prev = nblkA;
             nblkB_prev = nblkB;
@@ -1343,10 +1343,9 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
                            taus, Yf);
         prof_begin(c, PROF_OTHER, 0.0, 2.0 * n * (double)n * n);
         if (c->opt.eigh_wy_mfma)
-            hipLaunchKernelGGL(wy_apply_mfma_kernel, dim3((n + 15) / 16), dim3(256), 0, c->stream, X, ld, n, Yf, Gd, nblk);
+            SELLA_LAUNCH(c, wy_apply_mfma_kernel, dim3((n + 15) / 16), dim3(256), 0, X, ld, n, Yf, Gd, nblk);
         else
-            hipLaunchKernelGGL(wy_apply_kernel, dim3((n + 15) / 16), dim3(256), 0, c->stream, X, ld, n, W.A, ld, nrefl,
-                               taus, Gd, nblk);
+            SELLA_LAUNCH(c, wy_apply_kernel, dim3((n + 15) / 16), dim3(256), 0, X, ld, n, W.A, ld, nrefl, taus, Gd, nblk);
         prof_end(c);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));        // Call goes out of scope

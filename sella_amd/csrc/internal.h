@@ -1,6 +1,7 @@
 // internal.h — shared declarations of libsella_hip (context, device matrices, kernel launchers).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -45,7 +46,8 @@ struct Mat {
     bool live = false;
 };
 
-enum ProfKind { PROF_GEMV = 0, PROF_GEMM = 1, PROF_UPDATE = 2, PROF_OTHER = 3, PROF_GEMV_SMALL = 4, PROF_NKIND = 5 };
+enum ProfKind { PROF_GEMV = 0, PROF_GEMM = 1, PROF_UPDATE = 2, PROF_OTHER = 3, PROF_GEMV_SMALL = 4, PROF_TRD_GEMV = 5,
+                PROF_NKIND = 6 };
 
 struct ProfPending {
     hipEvent_t a, b;
@@ -81,6 +83,7 @@ struct sella_ctx {
     std::vector<std::pair<double*, size_t>> scratch;   // slot -> (ptr, bytes)
     sella::Options opt;
     bool prof = false;
+    hipEvent_t prof_a = nullptr, prof_b = nullptr;   // events of the launch being profiled
     std::vector<sella::ProfPending> pending;
     sella::ProfSlot slots[sella::PROF_NKIND];
     char name[256] = {0};
@@ -98,9 +101,21 @@ int download_panel(sella_ctx* c, const double* dpanel, int ldp, int n, int k, do
 int read_scalars(sella_ctx* c, int offset, int count);             // dscal -> hscal (sync)
 // layout of the scalar exchange buffer (doubles)
 enum { DS_MISC = 0, DS_CVEC = 16384, DS_STAGE = 32768, DS_GRAM = 65536, DS_TOTAL = 131072 };
+// Profiling (bench.py roofline leg): prof_begin creates an event pair, the launch between begin and
+// end must go through SELLA_LAUNCH, which attaches the pair to the kernel's own dispatch packet
+// (hipExtLaunchKernelGGL) so that the elapsed time is the kernel's execution time — the same
+// start/end timestamps rocprofv3 reports — and not the distance between two stream markers.
 void prof_begin(sella_ctx* c, int kind, double bytes, double flops);
 void prof_end(sella_ctx* c);
 int prof_flush(sella_ctx* c);
+#define SELLA_LAUNCH(c, kernel, grid, block, shmem, ...)                                             \
+    do {                                                                                             \
+        if ((c)->prof_a)                                                                             \
+            hipExtLaunchKernelGGL((kernel), grid, block, shmem, (c)->stream, (c)->prof_a,            \
+                                  (c)->prof_b, 0, __VA_ARGS__);                                                   \
+        else                                                                                         \
+            hipLaunchKernelGGL((kernel), grid, block, shmem, (c)->stream, __VA_ARGS__);              \
+    } while (0)
 
 enum ScratchSlot {
     SCR_X = 0, SCR_Y, SCR_PART, SCR_V, SCR_AV, SCR_V2, SCR_AV2, SCR_R, SCR_T, SCR_W, SCR_C,

@@ -101,14 +101,14 @@ template <int NRHS>
 static int gemv_rows_dispatch_rw(sella_ctx* c, int rb, const double* A, int rows, int cols, int lda,
                                  const GemvX& xp, double* Y, int ldy, const GemvEpi& epi) {
     if (rb == 4) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 4>), dim3((rows + 3) / 4), dim3(256), 0,
-                           c->stream, A, rows, cols, lda, xp, Y, ldy, epi);
+        SELLA_LAUNCH(c, HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 4>), dim3((rows + 3) / 4), dim3(256), 0,
+                     A, rows, cols, lda, xp, Y, ldy, epi);
     } else if (rb == 2) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 2>), dim3((rows + 1) / 2), dim3(256), 0,
-                           c->stream, A, rows, cols, lda, xp, Y, ldy, epi);
+        SELLA_LAUNCH(c, HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 2>), dim3((rows + 1) / 2), dim3(256), 0,
+                     A, rows, cols, lda, xp, Y, ldy, epi);
     } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 1>), dim3(rows), dim3(256), 0,
-                           c->stream, A, rows, cols, lda, xp, Y, ldy, epi);
+        SELLA_LAUNCH(c, HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 1>), dim3(rows), dim3(256), 0,
+                     A, rows, cols, lda, xp, Y, ldy, epi);
     }
     HIPCHK(hipGetLastError());
     return SELLA_OK;
@@ -246,8 +246,8 @@ static int gemv_cols_run(sella_ctx* c, const double* A, int rows, int cols, int 
     SCHK(scratch_get(c, SCR_PART, (size_t)nsplit * NRHS * ldpart * sizeof(double), &part));
     dim3 grid((cols2 / 2 + 255) / 256, nsplit);
     prof_begin(c, PROF_GEMV, 8.0 * rows * (double)cols, 2.0 * rows * (double)cols * NRHS);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gemv_cols_partial_kernel<NRHS>), grid, dim3(256), 0, c->stream,
-                       A, rows, cols, lda, X, ldx, part, ldpart);
+    SELLA_LAUNCH(c, HIP_KERNEL_NAME(gemv_cols_partial_kernel<NRHS>), grid, dim3(256), 0,
+                 A, rows, cols, lda, X, ldx, part, ldpart);
     prof_end(c);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(gemv_cols_reduce_kernel, dim3((cols + 255) / 256, NRHS), dim3(256), 0, c->stream,
@@ -655,11 +655,11 @@ int launch_gemm(sella_ctx* c, int transA, int transB, int M, int N, int K, doubl
     dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM);
     prof_begin(c, PROF_GEMM, 8.0 * ((double)M * K + (double)K * N + 2.0 * M * N), 2.0 * M * (double)N * K);
     if (c->opt.gemm_mfma)
-        hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), 0, c->stream, transA, transB, M, N, K, alpha,
-                           A, lda, B, ldb, beta, C, ldc);
+        SELLA_LAUNCH(c, gemm_mfma_kernel, grid, dim3(256), 0, transA, transB, M, N, K, alpha,
+                     A, lda, B, ldb, beta, C, ldc);
     else
-        hipLaunchKernelGGL(gemm_valu_kernel, grid, dim3(256), 0, c->stream, transA, transB, M, N, K, alpha,
-                           A, lda, B, ldb, beta, C, ldc);
+        SELLA_LAUNCH(c, gemm_valu_kernel, grid, dim3(256), 0, transA, transB, M, N, K, alpha,
+                     A, lda, B, ldb, beta, C, ldc);
     prof_end(c);
     HIPCHK(hipGetLastError());
     return SELLA_OK;

@@ -87,7 +87,7 @@ int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, 
                       int kk, double alpha) {
     const int nb = (n + 31) / 32;
     prof_begin(c, PROF_UPDATE, 16.0 * n * (double)n, 4.0 * kk * (double)n * n);
-    hipLaunchKernelGGL(sym_rank2k_kernel, dim3(nb, nb), dim3(256), 0, c->stream, B, n, ld, Up, Zp, ldp, kk, alpha);
+    SELLA_LAUNCH(c, sym_rank2k_kernel, dim3(nb, nb), dim3(256), 0, B, n, ld, Up, Zp, ldp, kk, alpha);
     prof_end(c);
     HIPCHK(hipGetLastError());
     return SELLA_OK;

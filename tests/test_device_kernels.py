@@ -87,3 +87,23 @@ def test_error_reporting(ctx):
         dA.numpy()
     with pytest.raises(SellaHipError):
         ctx.set_option('no_such_option', 1)
+
+
+def test_profiling_hooks(ctx):
+    """sella_prof_*: launches between enable/disable are counted per kind with their algorithmic
+    bytes; the timed launch is the kernel's own dispatch (events attached to the packet)."""
+    rng = np.random.RandomState(9)
+    n = 64
+    A = rng.normal(size=(n, n))
+    dA = ctx.upload(A + A.T)
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    ctx.symm_mm(dA, rng.normal(size=n))
+    ctx.eigh(dA)
+    ctx.prof_enable(False)
+    small, trd = ctx.prof_get(4), ctx.prof_get(5)
+    assert small['launches'] >= 1 and small['bytes'] >= 8.0 * n * n and small['ms'] >= 0.0
+    assert trd['launches'] == n - 2
+    assert abs(trd['bytes'] - 8.0 * sum((n - 1 - j) ** 2 for j in range(n - 2))) < 1e-6
+    ctx.symm_mm(dA, rng.normal(size=n))          # not counted once disabled
+    assert ctx.prof_get(4)['launches'] == small['launches']

@@ -1,22 +1,33 @@
 #!/bin/bash
-# One GPU visit: smoke, gpu tests, micro-benchmarks, bench line, rocprof kernel trace.
-# Usage (from the repo root, via gpurun):  bash tools/gpu_session.sh [tag]
+# One GPU visit: smoke, gpu tests, bench line, rocprof kernel trace of the bench command, PMC passes.
+# Usage (from the repo root, via gpurun):  bash tools/gpu_session.sh [tag] [fast]
 TAG=${1:-r01}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
 echo "== smoke" | tee $OUT/session.log
 timeout 600 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/session.log
 tail -3 $OUT/smoke.log | tee -a $OUT/session.log
+if [ "$2" != "fast" ]; then
 echo "== pytest -m gpu" | tee -a $OUT/session.log
-timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" | tee -a $OUT/session.log
-tail -15 $OUT/pytest_gpu.log | tee -a $OUT/session.log
-echo "== microbench" | tee -a $OUT/session.log
-MB_SIZES=${MB_SIZES:-768,3072} timeout 900 python tools/microbench.py > $OUT/microbench.log 2>&1; echo "microbench exit $?" | tee -a $OUT/session.log
-tail -5 $OUT/microbench.log | tee -a $OUT/session.log
+timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" | tee -a $OUT/session.log
+tail -6 $OUT/pytest_gpu.log | tee -a $OUT/session.log
+fi
 echo "== bench" | tee -a $OUT/session.log
-timeout 900 python bench.py --steps 10 --warmup 2 > $OUT/bench.log 2>&1; echo "bench exit $?" | tee -a $OUT/session.log
-tail -2 $OUT/bench.log | tee -a $OUT/session.log
-echo "== rocprof" | tee -a $OUT/session.log
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1); echo "rocprof exit $?" | tee -a $OUT/session.log
-find $OUT/prof -name "*stats*" | head | tee -a $OUT/session.log
+timeout 900 python bench.py > $OUT/bench.log 2>&1; echo "bench exit $?" | tee -a $OUT/session.log
+tail -1 $OUT/bench.log | tee -a $OUT/session.log
+echo "== rocprof kernel trace of the bench command" | tee -a $OUT/session.log
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/$OUT/rocprof.log 2>&1); echo "rocprof exit $?" | tee -a $OUT/session.log
+DB=$(find $OUT/prof -name "*.db" | head -1)
+python tools/rocprof_summary.py $DB $OUT/bench_kernel_stats.md "bench.py --steps 5 --warmup 1 --no-cpu-baseline (rocprofv3 --kernel-trace --stats)" > /dev/null
+head -20 $OUT/bench_kernel_stats.md | tee -a $OUT/session.log
+echo "== PMC passes (own runs, no tracing domains besides kernel dispatch)" | tee -a $OUT/session.log
+for CNT in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d $R/$OUT/pmc_$CNT -o pmc -- python $R/tools/eigh_only.py 3072 1 > $R/$OUT/pmc_$CNT.log 2>&1); echo "pmc $CNT exit $?" | tee -a $OUT/session.log
+  DBP=$(find $OUT/pmc_$CNT -name "*.db" | head -1)
+  python tools/pmc_dump.py $DBP trd_gemv > $OUT/pmc_$CNT.txt 2>&1
+  head -12 $OUT/pmc_$CNT.txt | tee -a $OUT/session.log
+  rm -rf $OUT/pmc_$CNT
+done
+rm -f $OUT/prof/*/*.db.tmp

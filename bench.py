@@ -57,7 +57,7 @@ def main():
     ap.add_argument('--gamma', type=float, default=0.1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true')
-    ap.add_argument('--opt-steps', type=int, default=10)
+    ap.add_argument('--opt-steps', type=int, default=20)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -158,6 +158,17 @@ def main():
 
     roof = hbm(pt, 'trd_gemv_kernel (m x m trailing-matrix matvec, one per column of the eigh of P)')
     if roof is not None:
+        # HBM traffic per launch cannot be counted from inside this process: it comes from the PMC
+        # passes of tools/gpu_session.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own runs), whose
+        # per-launch means are committed in profiles/pmc_traffic.json with the guide's gfx950 correction
+        try:
+            with open(os.path.join(REPO, 'profiles', 'pmc_traffic.json')) as f:
+                pmc = json.load(f)['trd_gemv_kernel']
+            if pmc['n'] == n:
+                roof['traffic'] = round(pmc['bytes_per_launch'])
+                roof['traffic_source'] = pmc['source']
+        except (OSError, KeyError, ValueError):
+            pass
         roof['share_of_step_ms'] = round(pt['ms'] / nprof, 2)
         roof['davidson_matvec'] = hbm(pg, 'gemv_rows_kernel<NRHS,2> (n x n row-panel matvec of the Davidson loop)')
         roof['davidson_panel_dots'] = dict(launches=ps['launches'],

@@ -991,16 +991,19 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
             ra.dvec = dvec;
             const int nblkA = (n - j + 255) / 256;
             const dim3 gA(nblkA), bA(256);
+            // (profiled too, so that the matvec launches below are timed under the same queue conditions)
+            prof_begin(c, PROF_OTHER, 8.0 * (2.0 * i + 3.0) * (n - j), 0.0);
             switch (i - 1) {
-#define SELLA_TRD_ROW_CASE(IP) case IP: hipLaunchKernelGGL(HIP_KERNEL_NAME(trd_row_kernel<IP>), gA, bA, 0, c->stream, ra); break;
+#define SELLA_TRD_ROW_CASE(IP) case IP: SELLA_LAUNCH(c, HIP_KERNEL_NAME(trd_row_kernel<IP>), gA, bA, 0, ra); break;
                 case -1:
                 SELLA_TRD_ROW_CASE(0) SELLA_TRD_ROW_CASE(1) SELLA_TRD_ROW_CASE(2) SELLA_TRD_ROW_CASE(3)
                 SELLA_TRD_ROW_CASE(4) SELLA_TRD_ROW_CASE(5) SELLA_TRD_ROW_CASE(6) SELLA_TRD_ROW_CASE(7)
                 SELLA_TRD_ROW_CASE(8) SELLA_TRD_ROW_CASE(9) SELLA_TRD_ROW_CASE(10) SELLA_TRD_ROW_CASE(11)
                 SELLA_TRD_ROW_CASE(12) SELLA_TRD_ROW_CASE(13) SELLA_TRD_ROW_CASE(14) SELLA_TRD_ROW_CASE(15)
 #undef SELLA_TRD_ROW_CASE
-                default: hipLaunchKernelGGL(HIP_KERNEL_NAME(trd_row_kernel<-1>), gA, bA, 0, c->stream, ra);
+                default: SELLA_LAUNCH(c, HIP_KERNEL_NAME(trd_row_kernel<-1>), gA, bA, 0, ra);
             }
+            prof_end(c);
             if (!do_row) break;
             const int o = j + 1, m = n - o, oc = o & ~1;
             TrdGemvArgs ga;

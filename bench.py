@@ -58,6 +58,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--opt-steps', type=int, default=20)
+    ap.add_argument('--ensemble-per-gpu', type=int, default=8)
+    ap.add_argument('--ensemble-steps', type=int, default=20)
+    ap.add_argument('--ensemble-n', type=int, default=768)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -75,7 +78,7 @@ def main():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from sella_amd.device import Context
-    ctx = Context(local_rank)
+    ctx = Context()             # LOCAL_RANK selects the device (one process per GPU)
     n = args.n
     A, P, g = hessian_like(n, seed=rank)            # one independent replica per rank
     dA = ctx.upload(A)
@@ -202,6 +205,38 @@ def main():
         topt = time.perf_counter() - ts
         opt_stats = dict(optimizer_steps_per_s=round(nst / topt, 3), steps=nst, ms_per_step=round(1e3 * topt / nst, 2),
                          force_calls=int(atoms.calc.ncalls - ncalls0), rs='tr', method='prfo', order=1)
+        # ---- ensemble (BASELINE configs[3]): independent 256-atom-equivalent searches (3N = 768),
+        # 8 per GPU, sharded round-robin over the ranks, one all-gather of the summaries at the end
+        if args.ensemble_per_gpu > 0:
+            from sella_amd.ensemble import local_members, run_ensemble
+            ne, total = args.ensemble_n, args.ensemble_per_gpu * world
+            members = {}
+            for i in local_members(total, rank, world):
+                Ai = hessian_like(ne, seed=5000 + i)[0]
+                dAi = ctx.upload(Ai)
+                rngi = np.random.RandomState(6000 + i)
+                Ui = rngi.normal(size=(8, ne))
+                Ui /= np.linalg.norm(Ui, axis=1)[:, None]
+                at = Atoms(['X'] * (ne // 3), 0.05 * rngi.normal(size=(ne // 3, 3)), pbc=True)
+                at.calc = QuadraticCubicModel(lambda x, dAi=dAi: ctx.symm_mm(dAi, x), Ui, c=0.05)
+                members[i] = at
+            barrier()
+            te = time.perf_counter()
+            res = run_ensemble(members.__getitem__, total, fmax=0.0, steps=args.ensemble_steps,
+                               sella_kwargs=dict(order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', proj_trans=False))
+            ctx.sync()
+            tens = time.perf_counter() - te
+            if dist is not None:
+                dev_e = 'cuda' if torch.cuda.is_available() else 'cpu'
+                tt = torch.tensor([tens], dtype=torch.float64, device=dev_e)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tens = float(tt.item())
+            nst_tot = float(res['summary'][:, 1].sum())
+            opt_stats['ensemble'] = dict(replicas=total, per_gpu=args.ensemble_per_gpu, n=ne,
+                                         steps_per_replica=args.ensemble_steps,
+                                         optimizer_steps_per_s=round(nst_tot / tens, 2),
+                                         searches_per_s=round(total / tens, 3), seconds=round(tens, 3),
+                                         lambda_min_negative=int((res['summary'][:, 4] < 0).sum()))
         _dev._default = None
 
     times = [elapsed]

@@ -333,6 +333,8 @@ class PES:
     def get_projected_forces(self):
         g = self.get_g()
         Ufree = self.get_Ufree()
+        if is_identity(Ufree):
+            return -g.reshape((-1, 3))
         return -(Ufree @ (Ufree.T @ g)).reshape((-1, 3))
 
     def converged(self, fmax, cmax=1e-5):

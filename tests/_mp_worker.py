@@ -1,0 +1,79 @@
+"""Worker of tests/test_multi.py: one rank of a torch.distributed (gloo) job on the CPU.
+The kernel sources run through the host emulation (tests/hostemu) — same code path as on a GPU box
+with RCCL, only the backend and the device library differ."""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests', 'hostemu'))
+
+
+def use_emulator():
+    import build_emu
+    from sella_amd import _lib
+    _lib._set_library_for_tests(ctypes.CDLL(build_emu.build()))
+
+
+def make_replica(i):
+    """Replica i: 4-atom model PES with one negative mode, deterministic in i."""
+    from sella_amd.atoms import Atoms, QuadraticCubicModel
+    rng = np.random.RandomState(1000 + i)
+    n = 12
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    lam = np.linspace(0.5, 3.0, n)
+    lam[0] = -0.8
+    A = (Q * lam) @ Q.T
+    U = rng.normal(size=(2, n))
+    U /= np.linalg.norm(U, axis=1)[:, None]
+    atoms = Atoms(['X'] * (n // 3), 0.05 * rng.normal(size=(n // 3, 3)), pbc=True)
+    atoms.calc = QuadraticCubicModel(lambda x: A @ x, U, c=0.02)
+    return atoms
+
+
+def ensemble(out_path, n_replicas):
+    import torch.distributed as dist
+    from sella_amd.ensemble import run_ensemble
+    from sella_amd.internal import Constraints
+    dist.init_process_group(backend='gloo')
+    res = run_ensemble(make_replica, n_replicas, fmax=1e-6, steps=60,
+                       sella_kwargs=dict(order=1, eta=1e-5, gamma=0.0, rs='tr', proj_trans=False))
+    if dist.get_rank() == 0:
+        np.savez(out_path, summary=res['summary'], owner=res['owner'],
+                 **{f'pos{i}': p for i, p in enumerate(res['positions'])})
+    dist.destroy_process_group()
+
+
+def bench(out_path):
+    import io
+    from contextlib import redirect_stdout
+    import bench as bench_mod
+    sys.argv = ['bench.py', '--gpus', os.environ['WORLD_SIZE'], '--steps', '2', '--warmup', '1', '--n', '36',
+                '--maxiter', '8', '--no-cpu-baseline', '--opt-steps', '2', '--ensemble-per-gpu', '2', '--ensemble-n', '12', '--ensemble-steps', '2']
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench_mod.main()
+    if os.environ.get('RANK', '0') == '0':
+        with open(out_path, 'w') as f:
+            f.write(buf.getvalue())
+
+
+if __name__ == '__main__':
+    use_emulator()
+    if sys.argv[1] == 'ensemble':
+        ensemble(sys.argv[2], int(sys.argv[3]))
+    elif sys.argv[1] == 'bench':
+        bench(sys.argv[2])
+    elif sys.argv[1] == 'ensemble-serial':
+        from sella_amd.ensemble import run_ensemble
+        res = run_ensemble(make_replica, int(sys.argv[3]), fmax=1e-6, steps=60,
+                           sella_kwargs=dict(order=1, eta=1e-5, gamma=0.0, rs='tr', proj_trans=False))
+        np.savez(sys.argv[2], summary=res['summary'], owner=res['owner'],
+                 **{f'pos{i}': p for i, p in enumerate(res['positions'])})
+    else:
+        raise SystemExit('unknown mode')
+    json.dump({'ok': True}, sys.stderr)

@@ -1,0 +1,64 @@
+"""N > 1 paths on the CPU: two gloo ranks (torch.distributed.run, 127.0.0.1) drive the same code that
+runs one-process-per-GPU over RCCL on the GPU box — the ensemble driver with its single all-gather
+and bench.py's replica mode with its barrier / max-over-ranks timing."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, '_mp_worker.py')
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch(nproc, *args, timeout=600):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if nproc == 1:
+        cmd = [sys.executable, WORKER, *args]
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
+               '--master-addr', '127.0.0.1', '--master-port', str(free_port()), WORKER, *args]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r
+
+
+def test_ensemble_two_ranks_matches_single_process(tmp_path):
+    n_rep = 5                                   # odd: the ranks hold 3 and 2 members
+    two = str(tmp_path / 'two.npz')
+    one = str(tmp_path / 'one.npz')
+    launch(2, 'ensemble', two, str(n_rep))
+    launch(1, 'ensemble-serial', one, str(n_rep))
+    a, b = np.load(two), np.load(one)
+    np.testing.assert_array_equal(a['owner'], np.arange(n_rep) % 2)
+    # identical per-replica results whether or not the ensemble was sharded
+    np.testing.assert_array_equal(a['summary'], b['summary'])
+    for i in range(n_rep):
+        np.testing.assert_array_equal(a[f'pos{i}'], b[f'pos{i}'])
+    s = a['summary']
+    assert np.all(s[:, 0] == 1.0), s            # every search converged ...
+    assert np.all(s[:, 3] < 1e-6)               # ... to a stationary point ...
+    assert np.all(s[:, 4] < 0.0)                # ... with a negative lowest Hessian eigenvalue
+
+
+def test_bench_two_ranks(tmp_path):
+    out = str(tmp_path / 'bench.json')
+    launch(2, 'bench', out)
+    lines = [ln for ln in open(out).read().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                      # rank 0 prints exactly one JSON line
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1
+    assert d['scaling'] == 'weak' and d['unit'] == 'davidson_iter/s' and d['higher_is_better'] is True
+    assert d['value'] > 0 and d['ms_per_step'] > 0
+    assert d['cpu_baseline'] is None            # rank 0 at N = 1 only
+    assert d['roofline']['launches'] > 0
+    ens = d['optimizer']['ensemble']
+    assert ens['replicas'] == 4 and ens['per_gpu'] == 2 and ens['optimizer_steps_per_s'] > 0

@@ -165,6 +165,17 @@ int sella_stepper_create(sella_ctx* ctx, int kind, sella_mat evecs, sella_mat ev
 int sella_stepper_get_s(sella_stepper* st, double alpha, double* s, double* dsda);
 int sella_stepper_destroy(sella_stepper* st);
 
+/* ---- internal-coordinate primitives ----------------------------------------------------------- */
+/* Batched value / gradient / Hessian-vector product / Hessian of bonds (natoms = 2), angles (3) and
+ * dihedrals (4): the vmapped JAX functions of sella/internal.py:58-135
+ *   _bond_value/_angle_value/_dihedral_value (:58-80), *_grad_batched (:85-87),
+ *   *_hess_batched (:95-97), *_hvp_batched (:106-135).
+ * pos (nc, natoms, 3) gathered atom positions; tvec (nc, natoms-1, 3) periodic shift vectors or NULL;
+ * tangent (nc, natoms, 3) or NULL.  Outputs (host): q (nc), grad (nc, natoms, 3),
+ * hvp (nc, natoms, 3) when tangent is given, hess (nc, 3 natoms, 3 natoms) when not NULL.            */
+int sella_internals_eval(sella_ctx* ctx, int natoms, int nc, const double* pos, const double* tvec,
+                         const double* tangent, double* q, double* grad, double* hvp, double* hess);
+
 /* ---- profiling hooks (bench.py roofline leg) ---------------------------------------------- */
 /* When enabled, every launch of the big streaming kernels is bracketed by hipEvents on the
  * context stream.  kind: 0 = row-panel matvec (n x n streams), 1 = gemm, 2 = update, 3 = other,

@@ -286,6 +286,21 @@ class Context:
                                             -1 if symm is None else int(symm), ptr(out)))
         return out
 
+    # ---- internal-coordinate primitives -----------------------------------------------------------
+    def internals_eval(self, pos, tvec=None, tangent=None, hessian=False):
+        """Batched q, dq/dx[, H t][, H] of bonds / angles / dihedrals (pos: (nc, 2|3|4, 3))."""
+        pos = as_f64(pos)
+        nc, na = pos.shape[0], pos.shape[1]
+        tv = as_f64(tvec) if tvec is not None else None
+        tan = as_f64(tangent) if tangent is not None else None
+        q = np.empty(nc)
+        grad = np.empty((nc, na, 3))
+        hvp = np.empty((nc, na, 3)) if tan is not None else None
+        hess = np.empty((nc, na, 3, na, 3)) if hessian else None
+        check(_lib.lib().sella_internals_eval(self._h, na, nc, ptr(pos), ptr(tv), ptr(tan), ptr(q), ptr(grad),
+                                              ptr(hvp), ptr(hess)))
+        return q, grad, hvp, hess
+
     # ---- profiling ---------------------------------------------------------------------------
     def prof_enable(self, on=True):
         check(_lib.lib().sella_prof_enable(self._h, int(bool(on))))

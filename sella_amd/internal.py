@@ -9,13 +9,15 @@ sella/internal.py the saddle-point path needs:
     (internal.py:2189-2305, linalg.py:601-618), inequality bookkeeping (internal.py:2788-2823).
 
 The reference differentiates these functions with JAX (CPU).  Here the derivatives are exact
-too, but come from a small hyper-dual-number (second-order forward-mode) arithmetic vectorised
-over all coordinates of one kind — no JAX.  Out of scope here: TRIC rotations,
+too: second-order forward-mode (hyper-dual) arithmetic inside one HIP kernel per coordinate kind
+(csrc/internals.hip), one thread per (coordinate, component) — no JAX.  Out of scope here: TRIC rotations,
 cell derivatives, dummy atoms, automatic topology search.
 """
 from functools import partialmethod
 
 import numpy as np
+
+from .device import get_context
 
 
 class DuplicateInternalError(ValueError):
@@ -27,140 +29,23 @@ class DuplicateConstraintError(DuplicateInternalError):
 
 
 # ------------------------------------------------------------------------------------------
-# hyper-dual numbers: value v (nc,), gradient g (nc, m), Hessian H (nc, m, m)
+# batched primitives: one device launch per kind (csrc/internals.hip, sella_internals_eval)
 # ------------------------------------------------------------------------------------------
-class HD:
-    __slots__ = ('v', 'g', 'H')
-
-    def __init__(self, v, g, H):
-        self.v, self.g, self.H = v, g, H
-
-    @staticmethod
-    def variables(x):
-        """x (nc, m) -> list of m independent variables."""
-        nc, m = x.shape
-        out = []
-        for i in range(m):
-            g = np.zeros((nc, m))
-            g[:, i] = 1.0
-            out.append(HD(x[:, i].copy(), g, np.zeros((nc, m, m))))
-        return out
-
-    @staticmethod
-    def _lift(o, like):
-        if isinstance(o, HD):
-            return o
-        v = np.broadcast_to(np.asarray(o, dtype=float), like.v.shape)
-        return HD(v, np.zeros_like(like.g), np.zeros_like(like.H))
-
-    def __add__(self, o):
-        o = HD._lift(o, self)
-        return HD(self.v + o.v, self.g + o.g, self.H + o.H)
-
-    __radd__ = __add__
-
-    def __neg__(self):
-        return HD(-self.v, -self.g, -self.H)
-
-    def __sub__(self, o):
-        return self + (-HD._lift(o, self))
-
-    def __rsub__(self, o):
-        return HD._lift(o, self) - self
-
-    def __mul__(self, o):
-        o = HD._lift(o, self)
-        gg = self.g[:, :, None] * o.g[:, None, :]
-        return HD(self.v * o.v, self.v[:, None] * o.g + o.v[:, None] * self.g,
-                  self.v[:, None, None] * o.H + o.v[:, None, None] * self.H + gg + gg.transpose(0, 2, 1))
-
-    __rmul__ = __mul__
-
-    def apply(self, f, df, d2f):
-        """Elementwise function with first and second derivative values."""
-        return HD(f, df[:, None] * self.g,
-                  df[:, None, None] * self.H + d2f[:, None, None] * (self.g[:, :, None] * self.g[:, None, :]))
-
-    def recip(self):
-        return self.apply(1.0 / self.v, -1.0 / self.v ** 2, 2.0 / self.v ** 3)
-
-    def __truediv__(self, o):
-        return self * HD._lift(o, self).recip()
-
-    def sqrt(self):
-        s = np.sqrt(self.v)
-        return self.apply(s, 0.5 / s, -0.25 / s ** 3)
-
-    def arccos(self):
-        c = np.clip(self.v, -1.0, 1.0)
-        om = np.maximum(1.0 - c * c, 1e-300)
-        return self.apply(np.arccos(c), -1.0 / np.sqrt(om), -c / om ** 1.5)
+_NATOMS = {'bonds': 2, 'angles': 3, 'dihedrals': 4}
 
 
-def hd_arctan2(y, x):
-    r2 = x * x + y * y
-    U = x / r2
-    W = -(y / r2)
-    g = U.v[:, None] * y.g + W.v[:, None] * x.g
-    H = (U.v[:, None, None] * y.H + W.v[:, None, None] * x.H
-         + U.g[:, :, None] * y.g[:, None, :] + W.g[:, :, None] * x.g[:, None, :])
-    return HD(np.arctan2(y.v, x.v), g, 0.5 * (H + H.transpose(0, 2, 1)))
-
-
-def _dot(a, b):
-    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
-
-
-def _cross(a, b):
-    return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
-
-
-def _sub(a, b, t=None):
-    out = [a[i] - b[i] for i in range(3)]
-    if t is not None:
-        out = [out[i] + t[:, i] for i in range(3)]
-    return out
-
-
-def _norm(a):
-    return _dot(a, a).sqrt()
-
-
-# value functions on hyper-dual inputs; p = list of atoms, each a list of 3 HD; t (nc, nvec, 3)
-def _bond_hd(p, t):                                           # internal.py:58-60
-    return _norm(_sub(p[1], p[0], t[:, 0]))
-
-
-def _angle_hd(p, t):                                          # internal.py:63-70
-    dx1 = [-c for c in _sub(p[1], p[0], t[:, 0])]
-    dx2 = _sub(p[2], p[1], t[:, 1])
-    return (_dot(dx1, dx2) / (_norm(dx1) * _norm(dx2))).arccos()
-
-
-def _dihedral_hd(p, t):                                       # internal.py:73-80
-    dx1 = _sub(p[1], p[0], t[:, 0])
-    dx2 = _sub(p[2], p[1], t[:, 1])
-    dx3 = _sub(p[3], p[2], t[:, 2])
-    c12, c23 = _cross(dx1, dx2), _cross(dx2, dx3)
-    numer = _dot(dx2, _cross(c12, c23))
-    denom = _norm(dx2) * _dot(c12, c23)
-    return hd_arctan2(numer, denom)
-
-
-_KINDS = {'bonds': (2, _bond_hd), 'angles': (3, _angle_hd), 'dihedrals': (4, _dihedral_hd)}
-
-
-def evaluate_kind(kind, pos, tvec):
+def evaluate_kind(kind, pos, tvec, tangent=None, hessian=True):
     """pos (nc, natoms, 3), tvec (nc, natoms-1, 3) -> value (nc,), grad (nc, natoms, 3),
-    hess (nc, natoms, 3, natoms, 3)."""
-    na, fn = _KINDS[kind]
+    hess (nc, natoms, 3, natoms, 3) [, hvp (nc, natoms, 3) when `tangent` is given]
+    — internal.py:85-97 / :106-135 batched over the coordinates of one kind."""
+    na = _NATOMS[kind]
+    pos = np.asarray(pos, dtype=np.float64).reshape(-1, na, 3)
     nc = pos.shape[0]
     if nc == 0:
-        return np.zeros(0), np.zeros((0, na, 3)), np.zeros((0, na, 3, na, 3))
-    vars_ = HD.variables(pos.reshape(nc, 3 * na))
-    p = [[vars_[3 * a + d] for d in range(3)] for a in range(na)]
-    out = fn(p, tvec)
-    return out.v, out.g.reshape(nc, na, 3), out.H.reshape(nc, na, 3, na, 3)
+        out = (np.zeros(0), np.zeros((0, na, 3)), np.zeros((0, na, 3, na, 3)))
+        return out + (np.zeros((0, na, 3)),) if tangent is not None else out
+    q, g, hv, H = get_context().internals_eval(pos, tvec, tangent, hessian=hessian)
+    return (q, g, H, hv) if tangent is not None else (q, g, H)
 
 
 # ------------------------------------------------------------------------------------------
@@ -315,7 +200,7 @@ class Constraints:
     # ---- numerics (batched per kind) --------------------------------------------------------
     def _gather(self, name):
         coords = self._active_list(name)
-        na = _KINDS[name][0]
+        na = _NATOMS[name]
         idx = np.array([c.indices for c in coords], dtype=np.int64).reshape((len(coords), na))
         ncv = np.array([c.ncvecs for c in coords], dtype=np.float64).reshape((len(coords), na - 1, 3))
         pos = self.atoms.positions[idx] if len(coords) else np.zeros((0, na, 3))

@@ -18,7 +18,7 @@ def morse_atoms(nat=4, seed=4):
     return atoms
 
 
-def test_constraints_api():
+def test_constraints_api(ctx):
     from sella_amd.internal import Constraints, DuplicateConstraintError
     atoms = morse_atoms(5)
     c = Constraints(atoms)

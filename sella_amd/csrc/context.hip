@@ -247,6 +247,8 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "eigh_leaf")) {
         if (value < 2 || value > 64) { set_error("eigh_leaf must be in [2, 64]"); return SELLA_E_INVALID; }
         c->opt.eigh_leaf = value;
+    } else if (!strcmp(key, "panel_mfma")) {
+        c->opt.panel_mfma = value ? 1 : 0;
     } else if (!strcmp(key, "eigh_wy_mfma")) {
         c->opt.eigh_wy_mfma = value ? 1 : 0;
     } else if (!strcmp(key, "eigh_nb")) {
@@ -356,6 +358,19 @@ int sella_symm_mm(sella_ctx* c, sella_mat A, const double* X, int k, double* Y) 
     double *dx, *dy;
     SCHK(scratch_get(c, SCR_X, (size_t)k * ldx * sizeof(double), &dx));
     SCHK(scratch_get(c, SCR_Y, (size_t)k * ldy * sizeof(double), &dy));
+    a = mat_get(c, A);
+    if (k > 8 && c->opt.panel_mfma && a->ld == ldx) {
+        // block product: 16 right-hand sides per pass over the matrix (kernels.hip, panel16_mfma_kernel)
+        const int kpad = round_up(k, 16);
+        SCHK(scratch_get(c, SCR_X, (size_t)kpad * ldx * sizeof(double), &dx));
+        HIPCHK(hipMemsetAsync(dx, 0, (size_t)kpad * ldx * sizeof(double), c->stream));
+        SCHK(upload_panel(c, X, cols, k, dx, ldx));
+        a = mat_get(c, A);
+        for (int h0 = 0; h0 < k; h0 += 16)
+            SCHK(launch_panel16(c, a->d, rows, cols, a->ld, dx + (size_t)h0 * ldx, std::min(16, k - h0),
+                                dy + (size_t)h0 * ldy, ldy));
+        return download_panel(c, dy, ldy, rows, k, Y);
+    }
     SCHK(upload_panel(c, X, cols, k, dx, ldx));
     a = mat_get(c, A);
     SCHK(launch_gemv_rows(c, a->d, rows, cols, a->ld, dx, ldx, k, dy, ldy, GemvEpi()));

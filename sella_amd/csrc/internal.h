@@ -66,6 +66,7 @@ struct Options {
     long dav_reorth = 0;     // 1: re-orthonormalise V before each MGS like math.pyx:148-151
     long eigh_leaf = 32;     // leaf size of the divide-and-conquer tree
     long eigh_nb = 16;       // panel width of the blocked tridiagonalisation (tools/eigh_tune.py)
+    long panel_mfma = 1;     // 1: products with more than 8 right-hand sides stream the matrix once (MFMA panel kernel)
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
 };
 
@@ -141,6 +142,10 @@ int launch_gemv_rows(sella_ctx* c, const double* A, int rows, int cols, int lda,
 // same with the right-hand sides given as separate pointers (no contiguity requirement)
 int launch_gemv_rows_xp(sella_ctx* c, const double* A, int rows, int cols, int lda,
                         const double* const* xs, int nrhs, double* Y, int ldy, const GemvEpi& epi);
+// Y (nrhs <= 16 rows, vector-major) = A X^T on the matrix cores; Xp: 16-row panel with leading dimension lda,
+// rows beyond nrhs and the row padding zero
+int launch_panel16(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* Xp, int nrhs,
+                   double* Y, int ldy);
 // |x|^2 -> out[0]; x <- x/|x|   (one single-workgroup launch)
 int launch_normalize(sella_ctx* c, double* x, int n, double* out);
 // Y[h*ldy + j] = sum_i A[i*lda + j] * X[h*ldx + i]   (transposed product, deterministic 2-pass)

@@ -62,12 +62,30 @@ def bench(out_path):
             f.write(buf.getvalue())
 
 
+def panel(out_path):
+    import torch.distributed as dist
+    from sella_amd.parallel import RowShardedOperator
+    dist.init_process_group(backend='gloo')
+    rng = np.random.RandomState(77)
+    n, k = 37, 16                                # ragged: 19 + 18 rows over two ranks
+    H = rng.normal(size=(n, n))
+    H = H + H.T
+    X = rng.normal(size=(n, k))
+    op = RowShardedOperator.from_full(H)
+    Y = op.matmat(X)
+    y1 = op.matmat(X[:, 0])
+    np.savez(out_path + f'.rank{dist.get_rank()}.npz', Y=Y, ref=H @ X, y1=y1, m_local=op.m_local, row0=op.row0)
+    dist.destroy_process_group()
+
+
 if __name__ == '__main__':
     use_emulator()
     if sys.argv[1] == 'ensemble':
         ensemble(sys.argv[2], int(sys.argv[3]))
     elif sys.argv[1] == 'bench':
         bench(sys.argv[2])
+    elif sys.argv[1] == 'panel':
+        panel(sys.argv[2])
     elif sys.argv[1] == 'ensemble-serial':
         from sella_amd.ensemble import run_ensemble
         res = run_ensemble(make_replica, int(sys.argv[3]), fmax=1e-6, steps=60,

@@ -107,3 +107,26 @@ def test_profiling_hooks(ctx):
     assert abs(trd['bytes'] - 8.0 * sum((n - 1 - j) ** 2 for j in range(n - 2))) < 1e-6
     ctx.symm_mm(dA, rng.normal(size=n))          # not counted once disabled
     assert ctx.prof_get(4)['launches'] == small['launches']
+
+
+def test_block_panel_product(ctx):
+    """More than 8 right-hand sides go through the MFMA panel kernel (matrix streamed once per 16
+    vectors); same results as the row-panel matvec path and as NumPy, for ragged shapes."""
+    rng = np.random.RandomState(21)
+    shapes = [(40, 40, 9), (70, 53, 16), (33, 90, 17), (5, 12, 33), (130, 64, 12)]
+    if ctx.backend == 'hip':
+        shapes += [(3072, 3072, 16), (1537, 2049, 24)]
+    for rows, cols, k in shapes:
+        A = rng.normal(size=(rows, cols))
+        X = rng.normal(size=(cols, k))
+        dA = ctx.upload(A)
+        ref = A @ X
+        tol = 1e-13 * cols * max(1.0, np.abs(ref).max())
+        ctx.set_option('panel_mfma', 1)
+        Y1 = ctx.symm_mm(dA, X)
+        ctx.set_option('panel_mfma', 0)
+        Y0 = ctx.symm_mm(dA, X)
+        ctx.set_option('panel_mfma', 1)
+        np.testing.assert_allclose(Y1, ref, atol=tol, rtol=0)
+        np.testing.assert_allclose(Y0, ref, atol=tol, rtol=0)
+        dA.free()

@@ -62,3 +62,15 @@ def test_bench_two_ranks(tmp_path):
     assert d['roofline']['launches'] > 0
     ens = d['optimizer']['ensemble']
     assert ens['replicas'] == 4 and ens['per_gpu'] == 2 and ens['optimizer_steps_per_s'] > 0
+
+
+def test_row_sharded_block_product(tmp_path):
+    """configs[4] exchange step: each rank multiplies its row panel, one all-gather assembles H V."""
+    out = str(tmp_path / 'panel')
+    launch(2, 'panel', out)
+    r0, r1 = np.load(out + '.rank0.npz'), np.load(out + '.rank1.npz')
+    assert int(r0['m_local']) == 19 and int(r1['m_local']) == 18 and int(r1['row0']) == 19
+    for r in (r0, r1):
+        np.testing.assert_allclose(r['Y'], r['ref'], atol=1e-11)
+        np.testing.assert_allclose(r['y1'], r['ref'][:, 0], atol=1e-11)
+    np.testing.assert_array_equal(r0['Y'], r1['Y'])      # every rank holds the same assembled block

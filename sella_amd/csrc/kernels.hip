@@ -673,48 +673,55 @@ int launch_gemm(sella_ctx* c, int transA, int transB, int M, int N, int K, doubl
 // straight from global memory as 32-byte vectors: lane (i, g) takes columns 4g..4g+3 of a 16-column
 // group for four successive v_mfma_f64_16x16x4_f64 (the summation index may be permuted freely).
 // ------------------------------------------------------------------------------------
+template <int RT>   // RT = 1: 16 rows per workgroup, RT = 2: 32 rows (halves the re-reads of X from L2)
 __global__ __launch_bounds__(256) void panel16_mfma_kernel(const double* __restrict__ A, int rows, int ld,
                                                            const double* __restrict__ Xp, int nrhs,
                                                            double* __restrict__ Y, int ldy) {
-    __shared__ double part[4][32][17];
+    constexpr int WR = 16 * RT;
+    __shared__ double part[4][WR][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    const int r0 = blockIdx.x * 32;
-    const int ra = (r0 + li < rows) ? r0 + li : rows - 1;
-    const int rb = (r0 + 16 + li < rows) ? r0 + 16 + li : rows - 1;
-    const double* a0 = A + (size_t)ra * ld;
-    const double* a1 = A + (size_t)rb * ld;
+    const int r0 = blockIdx.x * WR;
+    const double* arow[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int r = r0 + 16 * t + li;
+        arow[t] = A + (size_t)(r < rows ? r : rows - 1) * ld;
+    }
     const double* xr = Xp + (size_t)li * ld;
-    f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    f64x4 acc[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
     for (int cc = 64 * wave; cc < ld; cc += 256) {
+        double4 va[RT][4], vx[4];
 #pragma unroll
         for (int sg = 0; sg < 4; ++sg) {
             const int col = cc + 16 * sg + 4 * lg;
             const bool ok = col < ld;
             const int colc = ok ? col : 0;
-            const double4 va = *reinterpret_cast<const double4*>(a0 + colc);
-            const double4 vb = *reinterpret_cast<const double4*>(a1 + colc);
-            double4 vx = *reinterpret_cast<const double4*>(xr + colc);
-            if (!ok) vx = make_double4(0.0, 0.0, 0.0, 0.0);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va.x, vx.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vb.x, vx.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va.y, vx.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vb.y, vx.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va.z, vx.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vb.z, vx.z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va.w, vx.w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vb.w, vx.w, acc1, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) va[t][sg] = *reinterpret_cast<const double4*>(arow[t] + colc);
+            vx[sg] = *reinterpret_cast<const double4*>(xr + colc);
+            if (!ok) vx[sg] = make_double4(0.0, 0.0, 0.0, 0.0);
+        }
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[t][sg].x, vx[sg].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[t][sg].y, vx[sg].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[t][sg].z, vx[sg].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[t][sg].w, vx[sg].w, acc[t], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        part[wave][lg + 4 * r][li] = acc0[r];
-        part[wave][16 + lg + 4 * r][li] = acc1[r];
-    }
-    __syncthreads();
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
-    for (int e = tid; e < 32 * 16; e += 256) {
-        const int h = e >> 5, row = e & 31;               // consecutive threads -> consecutive rows of Y[h]
+        for (int r = 0; r < 4; ++r) part[wave][16 * t + lg + 4 * r][li] = acc[t][r];
+    __syncthreads();
+    for (int e = tid; e < WR * 16; e += 256) {
+        const int h = e / WR, row = e % WR;               // consecutive threads -> consecutive rows of Y[h]
         if (h < nrhs && r0 + row < rows)
             Y[(size_t)h * ldy + r0 + row] = part[0][row][h] + part[1][row][h] + part[2][row][h] + part[3][row][h];
     }
@@ -729,7 +736,13 @@ int launch_panel16(sella_ctx* c, const double* A, int rows, int cols, int lda, c
         return SELLA_E_INVALID;
     }
     prof_begin(c, PROF_GEMV, 8.0 * rows * (double)cols, 2.0 * rows * (double)cols * nrhs);
-    SELLA_LAUNCH(c, panel16_mfma_kernel, dim3((rows + 31) / 32), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
+    // 16-row workgroups measured equal (n = 12288) or faster (n = 3072) than 32-row ones: tools/panel_bench.py
+    long rt = c->opt.panel_rows;
+    if (rt == 0) rt = 16;
+    if (rt == 32)
+        SELLA_LAUNCH(c, HIP_KERNEL_NAME(panel16_mfma_kernel<2>), dim3((rows + 31) / 32), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
+    else
+        SELLA_LAUNCH(c, HIP_KERNEL_NAME(panel16_mfma_kernel<1>), dim3((rows + 15) / 16), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
     prof_end(c);
     HIPCHK(hipGetLastError());
     return SELLA_OK;

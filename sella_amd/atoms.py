@@ -33,6 +33,7 @@ class Atoms:
         self.pbc = np.array([pbc] * 3 if np.isscalar(pbc) else pbc, dtype=bool)
         self.calc = calculator
         self.constraints = []
+        self.info = {}
 
     def __len__(self):
         return len(self.positions)
@@ -40,6 +41,7 @@ class Atoms:
     def copy(self):
         new = Atoms(self.symbols, self.positions.copy(), self.cell.copy(), self.pbc.copy(), self.calc,
                     self.numbers.copy())
+        new.info = dict(self.info)
         return new
 
     def get_positions(self):
@@ -53,6 +55,59 @@ class Atoms:
 
     def get_forces(self):
         return np.asarray(self.calc.get_forces(self), dtype=np.float64).reshape((-1, 3))
+
+    # `for atom in slab: atom.position, atom.index` (README.md:23-25 of the reference)
+    def __getitem__(self, i):
+        return _Atom(self, int(i) % len(self))
+
+    def __iter__(self):
+        return (_Atom(self, i) for i in range(len(self)))
+
+    def extend(self, symbol, position):
+        self.symbols.append(symbol)
+        self.positions = np.vstack([self.positions, np.asarray(position, dtype=np.float64).reshape(1, 3)])
+        self.numbers = np.append(self.numbers, 0)
+
+
+class _Atom:
+    def __init__(self, atoms, index):
+        self._atoms, self.index = atoms, index
+
+    position = property(lambda self: self._atoms.positions[self.index])
+    symbol = property(lambda self: self._atoms.symbols[self.index])
+
+
+# ---- structure builders: the two ase.build functions the reference's README example uses -----------
+def fcc111(symbol, size, a=3.61, vacuum=None):
+    """Orthogonal-free hexagonal fcc(111) slab, size = (nx, ny, nlayers), ABC stacking, periodic in x, y."""
+    nx, ny, nz = size
+    d = a / np.sqrt(2.0)                       # nearest-neighbour distance
+    a1 = np.array([d, 0.0, 0.0])
+    a2 = np.array([0.5 * d, 0.5 * np.sqrt(3.0) * d, 0.0])
+    dz = a / np.sqrt(3.0)                      # interlayer spacing
+    shift = (a1 + a2) / 3.0                    # lateral offset between consecutive layers
+    pos = []
+    for k in range(nz):
+        off = ((nz - 1 - k) % 3) * shift       # top layer unshifted, like ase.build.fcc111
+        for j in range(ny):
+            for i in range(nx):
+                pos.append(i * a1 + j * a2 + off + np.array([0.0, 0.0, k * dz]))
+    pos = np.array(pos)
+    cell = np.array([nx * a1, ny * a2, [0.0, 0.0, (nz - 1) * dz]])
+    if vacuum is not None:
+        pos[:, 2] += vacuum
+        cell[2, 2] += 2.0 * vacuum
+    atoms = Atoms([symbol] * len(pos), pos, cell=cell, pbc=[True, True, False])
+    atoms.info = dict(adsorbate_sites=dict(ontop=np.zeros(2), bridge=0.5 * a1[:2], fcc=(a1 + a2)[:2] / 3.0,
+                                           hcp=2.0 * (a1 + a2)[:2] / 3.0))
+    return atoms
+
+
+def add_adsorbate(slab, symbol, height, position='ontop'):
+    """Put one atom `height` above the top layer at a named site (or an (x, y) pair)."""
+    xy = slab.info['adsorbate_sites'][position] if isinstance(position, str) else np.asarray(position, float)
+    ztop = slab.positions[:, 2].max()
+    slab.extend(symbol, [xy[0], xy[1], ztop + height])
 
 
 class Calculator:
@@ -121,6 +176,49 @@ class MorseCluster(Calculator):
         u = d[iu] / rr[:, None]
         np.add.at(g, iu[0], de[:, None] * u)
         np.add.at(g, iu[1], -de[:, None] * u)
+        return e, g
+
+
+class PeriodicMorse(Calculator):
+    """Morse pair potential under the minimum-image convention of a (partially) periodic cell, in
+    shifted-force form (energy and force continuous at `rcut`) — a stand-in for EMT on the far side of the calculator boundary (ASE's EMT is not
+    available in this image).  Defaults: Girifalco-Weizer parameters for Cu (eV, Angstrom)."""
+
+    def __init__(self, D=0.3429, a=1.3588, r0=2.866, rcut=6.0):
+        super().__init__()
+        self.D, self.a, self.r0, self.rcut = D, a, r0, rcut
+        self.cell, self.pbc = None, None
+
+    def _get(self, atoms):
+        self.cell, self.pbc = np.asarray(atoms.cell, dtype=float), np.asarray(atoms.pbc, dtype=bool)
+        return super()._get(atoms)
+
+    def energy_and_gradient(self, pos):
+        n = len(pos)
+        iu = np.triu_indices(n, 1)
+        d = pos[iu[0]] - pos[iu[1]]
+        rcut = self.rcut
+        if self.pbc is not None and self.pbc.any():
+            per = np.where(self.pbc)[0]
+            C = self.cell[per]                                   # periodic lattice vectors (rows)
+            Cinv = np.linalg.pinv(C)
+            d = d - np.round(d @ Cinv) @ C
+            # the minimum image is unique (and the energy smooth) only inside half the cell width
+            rcut = min(rcut, 0.5 / np.linalg.norm(Cinv, axis=0).max())
+        rr = np.linalg.norm(d, axis=1)
+        m = rr < rcut
+        d, rr, i0, i1 = d[m], rr[m], iu[0][m], iu[1][m]
+        # shifted-force form: energy AND force go to zero continuously at the cutoff
+        ex = np.exp(-self.a * (rr - self.r0))
+        exc = np.exp(-self.a * (rcut - self.r0))
+        vc = self.D * (1 - exc) ** 2
+        dvc = 2 * self.D * self.a * (1 - exc) * exc
+        e = np.sum(self.D * (1 - ex) ** 2 - vc - dvc * (rr - rcut))
+        de = 2 * self.D * self.a * (1 - ex) * ex - dvc
+        g = np.zeros_like(pos)
+        u = d / rr[:, None]
+        np.add.at(g, i0, de[:, None] * u)
+        np.add.at(g, i1, -de[:, None] * u)
         return e, g
 
 

@@ -118,3 +118,54 @@ def test_unsupported_options_fail_loudly(ctx):
         Sella(atoms, internal=True)
     with pytest.raises(NotImplementedError):
         Sella(atoms, optimize_cell=True, order=0)
+
+
+def test_readme_example_slab_adatom(ctx):
+    """README.md:10-40 of the reference (Cu fcc(111) + adatom at the bridge site, lower half of the slab
+    held by translation constraints, default Sella settings) with the Morse stand-in calculator:
+    the search must end on a first-order saddle of the constrained problem."""
+    from sella_amd import Constraints, Sella
+    from sella_amd.atoms import PeriodicMorse, add_adsorbate, fcc111
+    emu = ctx.backend == 'emu'
+    size = (3, 3, 2) if emu else (5, 5, 6)
+    slab = fcc111('Cu', size, vacuum=7.5)
+    add_adsorbate(slab, 'Cu', 2.0, 'bridge')
+    slab.positions[-1, :2] += [0.08, -0.05]                  # off the symmetric site
+    cons = Constraints(slab)
+    nfixed = 0
+    for atom in slab:
+        if atom.position[2] < slab.cell[2, 2] / 2. - 1e-6:
+            cons.fix_translation(atom.index)
+            nfixed += 1
+    assert 0 < nfixed < len(slab)
+    slab.calc = PeriodicMorse()
+    x_fixed = slab.positions[:nfixed].copy()
+    dyn = Sella(slab, constraints=cons, logfile=None)
+    f0 = np.linalg.norm(slab.get_forces()[nfixed:], axis=1).max()
+    if emu:
+        # the host emulation is ~1 s per optimizer step here: a few steps only (constraints held,
+        # projected force decreasing); the full convergence + inertia check runs under -m gpu
+        dyn.run(1e-3, 8)
+        np.testing.assert_allclose(slab.positions[:nfixed], x_fixed, atol=1e-10)
+        assert dyn.nsteps == 8 and 0.3 < dyn.rho < 3.0 and f0 > 0
+        return
+    assert dyn.run(1e-3, 300)
+    pes = dyn.pes
+    np.testing.assert_allclose(slab.positions[:nfixed], x_fixed, atol=1e-10)     # constraints held
+    assert np.linalg.norm(pes.get_projected_forces(), axis=1).max() < 1e-3
+    # inertia of the true Hessian in the free subspace (central differences of the forces)
+    Ufree = pes.get_Ufree()
+    m = Ufree.shape[1]
+    assert m == 3 * (len(slab) - nfixed)
+    x0 = slab.positions.ravel().copy()
+    h = 1e-4
+    Hf = np.zeros((m, m))
+    for j in range(m):
+        g = []
+        for sgn in (1, -1):
+            slab.set_positions((x0 + sgn * h * Ufree[:, j]).reshape(-1, 3))
+            g.append(-slab.get_forces().ravel())
+        Hf[:, j] = Ufree.T @ (g[0] - g[1]) / (2 * h)
+    slab.set_positions(x0.reshape(-1, 3))
+    w = np.linalg.eigvalsh(0.5 * (Hf + Hf.T))
+    assert w[0] < -1e-3 and w[1] > -1e-6, w[:4]

@@ -24,11 +24,7 @@ int mat_new(sella_ctx* c, int rows, int cols, sella_mat* h) {
     m.ld = round_up(cols > 0 ? cols : 1, 8);
     // two spare rows so 16-byte reads that start inside the last row never leave the buffer
     const size_t bytes = ((size_t)(rows > 0 ? rows : 1) + 2) * m.ld * sizeof(double);
-    hipError_t e = hipMalloc((void**)&m.d, bytes);
-    if (e != hipSuccess) {
-        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-        return SELLA_E_NOMEM;
-    }
+    SCHK(dev_alloc(c, bytes, &m.d));
     HIPCHK(hipMemsetAsync(m.d, 0, bytes, c->stream));
     m.live = true;
     for (size_t i = 0; i < c->mats.size(); ++i)
@@ -40,6 +36,47 @@ int mat_new(sella_ctx* c, int rows, int cols, sella_mat* h) {
     c->mats.push_back(m);
     *h = (int)c->mats.size() - 1;
     return SELLA_OK;
+}
+
+static size_t pool_class(size_t bytes) { return (size_t)round_up_l((long)bytes, 4096); }
+
+int dev_alloc(sella_ctx* c, size_t bytes, double** p) {
+    const size_t cls = pool_class(bytes);
+    auto it = c->pool.find(cls);
+    if (it != c->pool.end() && !it->second.empty()) {
+        *p = (double*)it->second.back();
+        it->second.pop_back();
+        c->pool_bytes -= cls;
+        return SELLA_OK;
+    }
+    hipError_t e = hipMalloc((void**)p, cls);
+    if (e != hipSuccess && c->pool_bytes > 0) {
+        // out of memory with blocks parked in the cache: release them and retry once
+        (void)hipStreamSynchronize(c->stream);
+        for (auto& kv : c->pool)
+            for (void* q : kv.second) (void)hipFree(q);
+        c->pool.clear();
+        c->pool_bytes = 0;
+        e = hipMalloc((void**)p, cls);
+    }
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", cls, hipGetErrorString(e));
+        return SELLA_E_NOMEM;
+    }
+    return SELLA_OK;
+}
+
+void dev_free(sella_ctx* c, double* p, size_t bytes) {
+    if (!p) return;
+    const size_t cls = pool_class(bytes);
+    const size_t cap = (size_t)64 << 30;                 // keep at most 64 GiB parked (of 288 GB)
+    if (c->pool_bytes + cls > cap) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(p);
+        return;
+    }
+    c->pool[cls].push_back(p);
+    c->pool_bytes += cls;
 }
 
 Mat* mat_get(sella_ctx* c, sella_mat h) {
@@ -216,6 +253,8 @@ int sella_ctx_destroy(sella_ctx* c) {
     (void)prof_flush(c);
     for (auto& m : c->mats)
         if (m.live && m.d) (void)hipFree(m.d);
+    for (auto& kv : c->pool)
+        for (void* q : kv.second) (void)hipFree(q);
     for (auto& s : c->scratch)
         if (s.first) (void)hipFree(s.first);
     if (c->dscal) (void)hipFree(c->dscal);
@@ -309,8 +348,7 @@ int sella_mat_shape(sella_ctx* c, sella_mat h, int* rows, int* cols) {
 int sella_mat_free(sella_ctx* c, sella_mat h) {
     Mat* m = mat_get(c, h);
     if (!m) return SELLA_E_INVALID;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipFree(m->d));
+    dev_free(c, m->d, ((size_t)(m->rows > 0 ? m->rows : 1) + 2) * m->ld * sizeof(double));
     *m = Mat();
     return SELLA_OK;
 }

@@ -41,6 +41,7 @@ struct Dav {
     const double* pevals_dev = nullptr;
     double pscale = 1.0;
     int nmatvec = 0;
+    size_t pbytes = 0;           // size of each panel allocation
     vec hv, hav;                 // host staging for the callback operator
 };
 
@@ -50,9 +51,9 @@ int dav_alloc(Dav& s, int cap) {
     // panels are re-allocated on growth; old contents are copied
     double *nV, *nAV, *nVq, *nAVq, *nR;
     // use dedicated allocations (not the scratch pool) so growth can copy old -> new
-    if (hipMalloc((void**)&nV, pbytes) != hipSuccess || hipMalloc((void**)&nAV, pbytes) != hipSuccess ||
-        hipMalloc((void**)&nVq, pbytes) != hipSuccess || hipMalloc((void**)&nAVq, pbytes) != hipSuccess ||
-        hipMalloc((void**)&nR, pbytes) != hipSuccess) {
+    if (dev_alloc(c, pbytes, &nV) != SELLA_OK || dev_alloc(c, pbytes, &nAV) != SELLA_OK ||
+        dev_alloc(c, pbytes, &nVq) != SELLA_OK || dev_alloc(c, pbytes, &nAVq) != SELLA_OK ||
+        dev_alloc(c, pbytes, &nR) != SELLA_OK) {
         set_error("davidson: cannot allocate panels for %d vectors of length %d", cap, s.n);
         return SELLA_E_NOMEM;
     }
@@ -67,10 +68,11 @@ int dav_alloc(Dav& s, int cap) {
             HIPCHK(hipMemcpyAsync(nV, s.Vp, old, hipMemcpyDeviceToDevice, c->stream));
             HIPCHK(hipMemcpyAsync(nAV, s.AVp, old, hipMemcpyDeviceToDevice, c->stream));
         }
-        HIPCHK(hipStreamSynchronize(c->stream));
-        (void)hipFree(s.Vp); (void)hipFree(s.AVp); (void)hipFree(s.Vq); (void)hipFree(s.AVq); (void)hipFree(s.Rp);
+        dev_free(c, s.Vp, s.pbytes); dev_free(c, s.AVp, s.pbytes); dev_free(c, s.Vq, s.pbytes);
+        dev_free(c, s.AVq, s.pbytes); dev_free(c, s.Rp, s.pbytes);
     }
     s.Vp = nV; s.AVp = nAV; s.Vq = nVq; s.AVq = nAVq; s.Rp = nR;
+    s.pbytes = pbytes;
     // Gram matrices: re-layout with the new leading dimension
     vec gvv((size_t)cap * cap, 0.0), gva((size_t)cap * cap, 0.0);
     for (int i = 0; i < s.k; ++i)
@@ -86,7 +88,10 @@ int dav_alloc(Dav& s, int cap) {
 
 void dav_free(Dav& s) {
     if (s.c) (void)hipStreamSynchronize(s.c->stream);
-    if (s.Vp) { (void)hipFree(s.Vp); (void)hipFree(s.AVp); (void)hipFree(s.Vq); (void)hipFree(s.AVq); (void)hipFree(s.Rp); }
+    if (s.Vp) {
+        dev_free(s.c, s.Vp, s.pbytes); dev_free(s.c, s.AVp, s.pbytes); dev_free(s.c, s.Vq, s.pbytes);
+        dev_free(s.c, s.AVq, s.pbytes); dev_free(s.c, s.Rp, s.pbytes);
+    }
     s.Vp = nullptr;
 }
 

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -81,6 +82,11 @@ struct sella_ctx {
     double* dscal = nullptr;
     double* hscal = nullptr;
     int nscal = 0;
+    // caching device allocator: freed blocks are kept by size and handed out again.  hipMalloc/hipFree
+    // cost milliseconds and synchronise the device; an optimizer loop allocates the same few sizes
+    // over and over.  One stream per context, so a recycled block is always used after its last reader.
+    std::map<size_t, std::vector<void*>> pool;
+    size_t pool_bytes = 0;
     // pooled scratch (grown on demand, never shrunk)
     std::vector<std::pair<double*, size_t>> scratch;   // slot -> (ptr, bytes)
     sella::Options opt;
@@ -98,6 +104,8 @@ namespace sella {
 int mat_new(sella_ctx* c, int rows, int cols, sella_mat* h);       // zero-initialised
 Mat* mat_get(sella_ctx* c, sella_mat h);
 int scratch_get(sella_ctx* c, int slot, size_t bytes, double** p); // persistent scratch slot
+int dev_alloc(sella_ctx* c, size_t bytes, double** p);             // caching allocator (contents undefined)
+void dev_free(sella_ctx* c, double* p, size_t bytes);
 int upload_panel(sella_ctx* c, const double* X, int n, int k, double* dpanel, int ldp);   // (n x k) host -> k rows
 int download_panel(sella_ctx* c, const double* dpanel, int ldp, int n, int k, double* X); // k rows -> (n x k) host
 int read_scalars(sella_ctx* c, int offset, int count);             // dscal -> hscal (sync)

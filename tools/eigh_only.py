@@ -13,8 +13,13 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 ctx = Context(0)
 rng = np.random.RandomState(0)
-A = rng.normal(size=(n, n))
-A = A + A.T
+kind = sys.argv[3] if len(sys.argv) > 3 else 'dense'
+if kind == 'dense':
+    A = rng.normal(size=(n, n))
+    A = A + A.T
+else:                                   # what an approximate Hessian looks like early on: lam0*I + low rank
+    u = rng.normal(size=(n, 6))
+    A = 1.7 * np.eye(n) + u[:, :4] @ u[:, :4].T - u[:, 4:] @ u[:, 4:].T
 dA = ctx.upload(A)
 for r in range(reps):
     t0 = time.perf_counter()

@@ -61,6 +61,7 @@ def main():
     ap.add_argument('--ensemble-per-gpu', type=int, default=8)
     ap.add_argument('--ensemble-steps', type=int, default=20)
     ap.add_argument('--ensemble-n', type=int, default=768)
+    ap.add_argument('--ensemble-threads', type=int, default=1)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -210,20 +211,28 @@ def main():
         if args.ensemble_per_gpu > 0:
             from sella_amd.ensemble import local_members, run_ensemble
             ne, total = args.ensemble_n, args.ensemble_per_gpu * world
-            members = {}
+            # host-side data of this rank's members is prepared outside the timed region; the device
+            # upload happens in the worker thread that runs the member (one context per thread)
+            host = {}
             for i in local_members(total, rank, world):
-                Ai = hessian_like(ne, seed=5000 + i)[0]
-                dAi = ctx.upload(Ai)
                 rngi = np.random.RandomState(6000 + i)
                 Ui = rngi.normal(size=(8, ne))
                 Ui /= np.linalg.norm(Ui, axis=1)[:, None]
-                at = Atoms(['X'] * (ne // 3), 0.05 * rngi.normal(size=(ne // 3, 3)), pbc=True)
-                at.calc = QuadraticCubicModel(lambda x, dAi=dAi: ctx.symm_mm(dAi, x), Ui, c=0.05)
-                members[i] = at
+                host[i] = (hessian_like(ne, seed=5000 + i)[0], Ui, 0.05 * rngi.normal(size=(ne // 3, 3)))
+
+            def make_member(i):
+                Ai, Ui, x0 = host[i]
+                c_i = _dev.get_context()
+                dAi = c_i.upload(Ai)
+                at = Atoms(['X'] * (ne // 3), x0.copy(), pbc=True)
+                at.calc = QuadraticCubicModel(lambda x, c_i=c_i, dAi=dAi: c_i.symm_mm(dAi, x), Ui, c=0.05)
+                return at
+
             barrier()
             te = time.perf_counter()
-            res = run_ensemble(members.__getitem__, total, fmax=0.0, steps=args.ensemble_steps,
-                               sella_kwargs=dict(order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', proj_trans=False))
+            res = run_ensemble(make_member, total, fmax=0.0, steps=args.ensemble_steps,
+                               sella_kwargs=dict(order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', proj_trans=False),
+                               threads=args.ensemble_threads)
             ctx.sync()
             tens = time.perf_counter() - te
             if dist is not None:
@@ -233,6 +242,7 @@ def main():
                 tens = float(tt.item())
             nst_tot = float(res['summary'][:, 1].sum())
             opt_stats['ensemble'] = dict(replicas=total, per_gpu=args.ensemble_per_gpu, n=ne,
+                                         host_threads_per_gpu=args.ensemble_threads,
                                          steps_per_replica=args.ensemble_steps,
                                          optimizer_steps_per_s=round(nst_tot / tens, 2),
                                          searches_per_s=round(total / tens, 3), seconds=round(tens, 3),

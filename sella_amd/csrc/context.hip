@@ -38,7 +38,7 @@ int mat_new(sella_ctx* c, int rows, int cols, sella_mat* h) {
     return SELLA_OK;
 }
 
-static size_t pool_class(size_t bytes) { return (size_t)round_up_l((long)bytes, 4096); }
+static size_t pool_class(size_t bytes) { return (size_t)round_up_l((long)(bytes ? bytes : 1), 4096); }
 
 int dev_alloc(sella_ctx* c, size_t bytes, double** p) {
     const size_t cls = pool_class(bytes);
@@ -46,37 +46,36 @@ int dev_alloc(sella_ctx* c, size_t bytes, double** p) {
     if (it != c->pool.end() && !it->second.empty()) {
         *p = (double*)it->second.back();
         it->second.pop_back();
-        c->pool_bytes -= cls;
         return SELLA_OK;
     }
-    hipError_t e = hipMalloc((void**)p, cls);
-    if (e != hipSuccess && c->pool_bytes > 0) {
-        // out of memory with blocks parked in the cache: release them and retry once
-        (void)hipStreamSynchronize(c->stream);
-        for (auto& kv : c->pool)
-            for (void* q : kv.second) (void)hipFree(q);
-        c->pool.clear();
-        c->pool_bytes = 0;
-        e = hipMalloc((void**)p, cls);
+    for (auto& a : c->arenas)
+        if (a.size - a.used >= cls) {
+            *p = (double*)(a.base + a.used);
+            a.used += cls;
+            return SELLA_OK;
+        }
+    // new arena: 512 MiB, doubling with every arena up to 8 GiB, or the request itself if larger
+    size_t want = (size_t)512 << 20;
+    for (size_t i = 0; i < c->arenas.size() && want < ((size_t)8 << 30); ++i) want *= 2;
+    if (want < cls) want = cls;
+    char* base = nullptr;
+    hipError_t e = hipMalloc((void**)&base, want);
+    if (e != hipSuccess && want > cls) {
+        want = cls;
+        e = hipMalloc((void**)&base, want);
     }
     if (e != hipSuccess) {
-        set_error("hipMalloc(%zu bytes) failed: %s", cls, hipGetErrorString(e));
+        set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
         return SELLA_E_NOMEM;
     }
+    c->arenas.push_back(sella_ctx::Arena{base, want, cls});
+    *p = (double*)base;
     return SELLA_OK;
 }
 
 void dev_free(sella_ctx* c, double* p, size_t bytes) {
     if (!p) return;
-    const size_t cls = pool_class(bytes);
-    const size_t cap = (size_t)64 << 30;                 // keep at most 64 GiB parked (of 288 GB)
-    if (c->pool_bytes + cls > cap) {
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(p);
-        return;
-    }
-    c->pool[cls].push_back(p);
-    c->pool_bytes += cls;
+    c->pool[pool_class(bytes)].push_back(p);
 }
 
 Mat* mat_get(sella_ctx* c, sella_mat h) {
@@ -97,17 +96,12 @@ int scratch_get(sella_ctx* c, int slot, size_t bytes, double** p) {
     bytes = round_up_l((long)bytes + 64, 256);
     if (s.second < bytes) {
         if (s.first) {
-            HIPCHK(hipStreamSynchronize(c->stream));
-            HIPCHK(hipFree(s.first));
+            dev_free(c, s.first, s.second);
             s.first = nullptr;
             s.second = 0;
         }
         size_t want = bytes + bytes / 4;
-        hipError_t e = hipMalloc((void**)&s.first, want);
-        if (e != hipSuccess) {
-            set_error("hipMalloc(%zu bytes) for scratch failed: %s", want, hipGetErrorString(e));
-            return SELLA_E_NOMEM;
-        }
+        SCHK(dev_alloc(c, want, &s.first));
         s.second = want;
         HIPCHK(hipMemsetAsync(s.first, 0, want, c->stream));
     }
@@ -251,12 +245,7 @@ int sella_ctx_destroy(sella_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)prof_flush(c);
-    for (auto& m : c->mats)
-        if (m.live && m.d) (void)hipFree(m.d);
-    for (auto& kv : c->pool)
-        for (void* q : kv.second) (void)hipFree(q);
-    for (auto& s : c->scratch)
-        if (s.first) (void)hipFree(s.first);
+    for (auto& a : c->arenas) (void)hipFree(a.base);       // matrices, panels and scratch all live in the arenas
     if (c->dscal) (void)hipFree(c->dscal);
     if (c->hscal) (void)hipHostFree(c->hscal);
     (void)hipStreamDestroy(c->stream);

@@ -82,11 +82,17 @@ struct sella_ctx {
     double* dscal = nullptr;
     double* hscal = nullptr;
     int nscal = 0;
-    // caching device allocator: freed blocks are kept by size and handed out again.  hipMalloc/hipFree
-    // cost milliseconds and synchronise the device; an optimizer loop allocates the same few sizes
-    // over and over.  One stream per context, so a recycled block is always used after its last reader.
+    // Device allocator: blocks are carved out of a few large arenas and recycled through per-size free
+    // lists.  A single hipMalloc was measured at 40-80 ms on this stack whenever the driver has to map new
+    // memory, and hipFree synchronises the device; an optimizer loop (or every new member of an ensemble)
+    // allocates the same few sizes over and over.  One stream per context, so a recycled block is always
+    // used after its last reader.  Arenas are only returned when the context is destroyed.
+    struct Arena {
+        char* base;
+        size_t size, used;
+    };
+    std::vector<Arena> arenas;
     std::map<size_t, std::vector<void*>> pool;
-    size_t pool_bytes = 0;
     // pooled scratch (grown on demand, never shrunk)
     std::vector<std::pair<double*, size_t>> scratch;   // slot -> (ptr, bytes)
     sella::Options opt;

@@ -3,6 +3,7 @@ handles.  numpy in / numpy out, fp64, like the reference's accelerator seam
 (sella/_gpu.py:55-132) — but the device side is libsella_hip, not torch.
 """
 import os
+import threading
 import weakref
 from ctypes import byref, c_char_p, c_double, c_int, c_long, c_void_p, create_string_buffer
 
@@ -27,8 +28,14 @@ class DeviceMatrix:
 
     @staticmethod
     def _release(ctx, handle):
-        if ctx._h is not None:
+        if ctx._h is None:
+            return
+        if threading.get_ident() == ctx._owner:
             _lib.lib().sella_mat_free(ctx._h, handle)
+        else:
+            # the garbage collector may run this in another thread: a context is single-threaded, so
+            # the handle is parked and freed by the owning thread at its next allocation
+            ctx._parked.append(handle)
 
     def free(self):
         self._fin()
@@ -66,7 +73,13 @@ class Context:
         check(L.sella_ctx_create(int(device), byref(h)))
         self._h = h
         self.device = int(device)
+        self._owner = threading.get_ident()
+        self._parked = []
         self._fin = weakref.finalize(self, Context._destroy, self, L)
+
+    def _drain(self):
+        while self._parked:
+            _lib.lib().sella_mat_free(self._h, self._parked.pop())
 
     @staticmethod
     def _destroy(self, L):
@@ -92,6 +105,7 @@ class Context:
 
     # ---- matrices ---------------------------------------------------------------------
     def upload(self, A):
+        self._drain()
         A = as_f64(A)
         if A.ndim == 1:
             A = A[:, None]
@@ -100,6 +114,7 @@ class Context:
         return DeviceMatrix(self, h.value, A.shape)
 
     def zeros(self, rows, cols):
+        self._drain()
         h = c_int(-1)
         check(_lib.lib().sella_mat_alloc(self._h, rows, cols, byref(h)))
         return DeviceMatrix(self, h.value, (rows, cols))
@@ -154,6 +169,7 @@ class Context:
     # ---- factorizations -------------------------------------------------------------------
     def eigh(self, A, vectors=True):
         """(w, V, Vt): eigenvalues ascending (numpy), eigenvectors as columns / rows (device)."""
+        self._drain()
         n = A.shape[0]
         w = np.empty(n)
         hv, hvt = c_int(-1), c_int(-1)
@@ -344,12 +360,25 @@ class DeviceStepper:
 _default = None
 
 
+_tls = threading.local()
+
+
 def get_context():
-    """Process-wide default context (one process per GPU)."""
+    """The context of the calling thread if one was installed with `use_context`, otherwise the
+    process-wide default (one process per GPU).  A context is single-threaded (include/sella_hip.h);
+    several host threads may drive the same GPU through one context each."""
     global _default
+    ctx = getattr(_tls, 'ctx', None)
+    if ctx is not None:
+        return ctx
     if _default is None:
         _default = Context()
     return _default
+
+
+def use_context(ctx):
+    """Install `ctx` as the calling thread's context (None removes it)."""
+    _tls.ctx = ctx
 
 
 def _reset_default_context():

@@ -57,15 +57,50 @@ def run_one(atoms, fmax, steps, sella_kwargs):
     return summary, np.asarray(atoms.positions, dtype=np.float64).copy()
 
 
-def run_ensemble(make_replica, n_replicas, fmax=0.05, steps=1000, sella_kwargs=None):
+def _run_members(members, make_replica, fmax, steps, sella_kwargs, own_context):
+    """Worker: runs its members one after the other on a context of its own."""
+    from . import device
+    out = {}
+    ctx = None
+    if own_context:
+        ctx = device.Context()
+        device.use_context(ctx)
+    try:
+        for i in members:
+            out[i] = run_one(make_replica(i), fmax, steps, sella_kwargs)
+    finally:
+        if own_context:
+            device.use_context(None)
+            import gc
+            gc.collect()
+            ctx.close()
+    return out
+
+
+def run_ensemble(make_replica, n_replicas, fmax=0.05, steps=1000, sella_kwargs=None, threads=1):
     """Run `n_replicas` independent searches, sharded over the initialised process group (or all in
     this process when there is none).  Every rank returns the same
-    `dict(summary=(n_replicas, 5) array, positions=list of (N_i, 3) arrays, owner=(n_replicas,))`."""
+    `dict(summary=(n_replicas, 5) array, positions=list of (N_i, 3) arrays, owner=(n_replicas,))`.
+
+    threads > 1: the rank's members are dealt to that many host threads, each with its own device
+    context (own HIP stream): a small search is host-latency bound (Python between sub-millisecond
+    kernels), so several of them keep one GPU busy.  `make_replica(i)` is then called inside the
+    worker thread and must build its calculator on `sella_amd.device.get_context()`."""
     rank, world = rank_and_world()
     mine = local_members(n_replicas, rank, world)
     summaries, positions = {}, {}
-    for i in mine:
-        summaries[i], positions[i] = run_one(make_replica(i), fmax, steps, sella_kwargs)
+    if threads > 1 and len(mine) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        nt = min(threads, len(mine))
+        with ThreadPoolExecutor(max_workers=nt) as pool:
+            futs = [pool.submit(_run_members, mine[t::nt], make_replica, fmax, steps, sella_kwargs, True)
+                    for t in range(nt)]
+            for f in futs:
+                for i, (sm, ps) in f.result().items():
+                    summaries[i], positions[i] = sm, ps
+    else:
+        for i, (sm, ps) in _run_members(mine, make_replica, fmax, steps, sella_kwargs, False).items():
+            summaries[i], positions[i] = sm, ps
     owner = np.arange(n_replicas) % world
     if world == 1:
         return dict(summary=np.array([summaries[i] for i in range(n_replicas)]),

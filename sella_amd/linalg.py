@@ -14,6 +14,7 @@ from scipy.sparse.linalg import LinearOperator
 
 from .device import DeviceMatrix, get_context
 from .hessian_update import update_H
+from .utilities.math import is_identity
 
 _DEVICE_MIN = 64        # below this a projection basis is not worth a device round trip
 
@@ -39,15 +40,21 @@ class NumericalHessian(LinearOperator):
         self.Vs = np.empty((self.ntrue, 0), dtype=self.dtype)
         self.AVs = np.empty((self.ntrue, 0), dtype=self.dtype)
         self._U_gpu = None
-        if Uproj is not None and min(Uproj.shape) >= _DEVICE_MIN:
+        # an identity basis (unconstrained Cartesian search, peswrapper.py:403) needs no products at all
+        self._U_identity = Uproj is not None and is_identity(Uproj)
+        if Uproj is not None and not self._U_identity and min(Uproj.shape) >= _DEVICE_MIN:
             self._U_gpu = get_context().upload(Uproj)
 
     def _lift(self, v):
+        if self._U_identity:
+            return v
         if self._U_gpu is not None:
             return get_context().symm_mm(self._U_gpu, v)
         return self.Uproj @ v
 
     def _restrict(self, w):
+        if self._U_identity:
+            return w
         if self._U_gpu is not None:
             return get_context().tmatmul(self._U_gpu, w)
         return self.Uproj.T @ w

@@ -306,7 +306,7 @@ class PES:
         P = self.get_HL_projected(Ufree)
         P_is_none = P.B is None
         if P_is_none or self.first_diag:
-            v0 = self.v0 if self.v0 is not None else self.get_g() @ Ufree
+            v0 = self.v0 if self.v0 is not None else (self.get_g() if is_identity(Ufree) else self.get_g() @ Ufree)
             if v0 is not None and np.linalg.norm(v0) < 1e-12:
                 v0 = None
         else:

@@ -86,10 +86,11 @@ if __name__ == '__main__':
         bench(sys.argv[2])
     elif sys.argv[1] == 'panel':
         panel(sys.argv[2])
-    elif sys.argv[1] == 'ensemble-serial':
+    elif sys.argv[1] in ('ensemble-serial', 'ensemble-threads'):
         from sella_amd.ensemble import run_ensemble
         res = run_ensemble(make_replica, int(sys.argv[3]), fmax=1e-6, steps=60,
-                           sella_kwargs=dict(order=1, eta=1e-5, gamma=0.0, rs='tr', proj_trans=False))
+                           sella_kwargs=dict(order=1, eta=1e-5, gamma=0.0, rs='tr', proj_trans=False),
+                           threads=3 if sys.argv[1] == 'ensemble-threads' else 1)
         np.savez(sys.argv[2], summary=res['summary'], owner=res['owner'],
                  **{f'pos{i}': p for i, p in enumerate(res['positions'])})
     else:

@@ -12,6 +12,7 @@
 #include <ucontext.h>
 #endif
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 namespace hipemu {
@@ -159,6 +160,9 @@ void wave_gather64(const void* in, size_t bytes, void* all64) {
 }
 
 void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+    // the emulated device is one global machine: launches from several host threads take turns
+    static std::mutex mu;
+    std::lock_guard<std::mutex> hold(mu);
     ++g_launches;
     const int nthreads = (int)(block.x * block.y * block.z);
     if (nthreads <= 0 || nthreads > 1024) { fprintf(stderr, "hipemu: bad block size %d\n", nthreads); abort(); }

@@ -49,6 +49,17 @@ def test_ensemble_two_ranks_matches_single_process(tmp_path):
     assert np.all(s[:, 4] < 0.0)                # ... with a negative lowest Hessian eigenvalue
 
 
+def test_ensemble_host_threads_match_serial(tmp_path):
+    """Several host threads, one device context each, drive one device: same per-replica results."""
+    thr, one = str(tmp_path / 'thr.npz'), str(tmp_path / 'one.npz')
+    launch(1, 'ensemble-threads', thr, '5')
+    launch(1, 'ensemble-serial', one, '5')
+    a, b = np.load(thr), np.load(one)
+    np.testing.assert_array_equal(a['summary'], b['summary'])
+    for i in range(5):
+        np.testing.assert_array_equal(a[f'pos{i}'], b[f'pos{i}'])
+
+
 def test_bench_two_ranks(tmp_path):
     out = str(tmp_path / 'bench.json')
     launch(2, 'bench', out)

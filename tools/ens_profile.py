@@ -31,12 +31,13 @@ def member(i):
 
 
 kw = dict(order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', proj_trans=False)
-run_one(member(0), 0.0, 20, kw)                      # warm-up (scratch allocation)
-at = member(1)
+for w in range(3):
+    run_one(member(w), 0.0, 20, kw)                  # warm-up (scratch allocation)
+at = member(3)
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()
 run_one(at, 0.0, 20, kw)
 pr.disable()
 print('seconds per member', time.perf_counter() - t0)
-pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
+pstats.Stats(pr).sort_stats('tottime').print_stats(14)

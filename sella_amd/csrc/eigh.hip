@@ -306,21 +306,61 @@ __global__ __launch_bounds__(256) void gather_z_kernel(const double* __restrict_
     z[lo + i] = (i < n1) ? Zt[(size_t)(lo + i) * ld + mid - 1] : sgn * Zt[(size_t)(lo + i) * ld + mid];
 }
 
-// chain of Givens rotations on pairs of rows:  x' = c x + s y ; y' = c y - s x   (BLAS drot)
-__global__ __launch_bounds__(256) void rot_rows_kernel(double* __restrict__ Zb, int ld, int N, int nrot,
-                                                       const int* __restrict__ i1,
-                                                       const int* __restrict__ i2,
-                                                       const double* __restrict__ cs) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
+// Givens rotations on pairs of rows, in order:  x' = c x + s y ; y' = c y - s x   (BLAS drot), one
+// column per lane.  The deflation of a merge produces CHAINS: the row left as y by one rotation is
+// the x of the next, and no row is touched again once it has been an x (plan_deflation visits the poles
+// in ascending order).  The chained value therefore stays in a register, every row is read once and
+// written once, and — since the indices do not depend on the data — the loads of a whole batch of
+// rotations are issued before the (sequential) arithmetic on it, which turns a chain of nrot memory
+// round trips into nrot/16 of them.
+constexpr int ROT_BATCH = 16;
+__global__ __launch_bounds__(64) void rot_rows_kernel(double* __restrict__ Zb, int ld, int N, int nrot,
+                                                      const int* __restrict__ i1,
+                                                      const int* __restrict__ i2,
+                                                      const double* __restrict__ cs) {
+    const int col = blockIdx.x * 64 + threadIdx.x;
     if (col >= N) return;
-    for (int r = 0; r < nrot; ++r) {
-        double* xp = Zb + (size_t)i1[r] * ld + col;
-        double* yp = Zb + (size_t)i2[r] * ld + col;
-        const double c = cs[2 * r], s = cs[2 * r + 1];
-        const double x = *xp, y = *yp;
-        *xp = c * x + s * y;
-        *yp = c * y - s * x;
+    double carry = 0.0;
+    int crow = -1;                                              // row whose new value sits in `carry`
+    for (int r0 = 0; r0 < nrot; r0 += ROT_BATCH) {
+        double y[ROT_BATCH], xf[ROT_BATCH], c[ROT_BATCH], sn[ROT_BATCH];
+        int ra[ROT_BATCH], rb[ROT_BATCH];
+        bool fresh[ROT_BATCH];
+#pragma unroll
+        for (int k = 0; k < ROT_BATCH; ++k) {
+            const int r = (r0 + k < nrot) ? r0 + k : nrot - 1;
+            ra[k] = i1[r];
+            rb[k] = i2[r];
+            c[k] = cs[2 * r];
+            sn[k] = cs[2 * r + 1];
+            fresh[k] = (k == 0) ? (ra[0] != crow) : (ra[k] != rb[k - 1]);
+            y[k] = Zb[(size_t)rb[k] * ld + col];
+            xf[k] = fresh[k] ? Zb[(size_t)ra[k] * ld + col] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < ROT_BATCH; ++k) {
+            if (r0 + k < nrot) {
+                double x = carry;
+                if (fresh[k]) {
+                    if (crow >= 0) Zb[(size_t)crow * ld + col] = carry;
+                    x = xf[k];
+                }
+                Zb[(size_t)ra[k] * ld + col] = c[k] * x + sn[k] * y[k];
+                carry = c[k] * y[k] - sn[k] * x;
+                crow = rb[k];
+            }
+        }
     }
+    if (crow >= 0) Zb[(size_t)crow * ld + col] = carry;
+}
+
+// R[i][c] -= tau v[i] w[c] on a block of rows (Householder reflection applied to eigenvector rows)
+__global__ __launch_bounds__(256) void rows_ger_kernel(double* __restrict__ R, int ld, int nrows, int ncols,
+                                                       const double* __restrict__ v,
+                                                       const double* __restrict__ wv, double tau) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (col < ncols && i < nrows) R[(size_t)i * ld + col] -= tau * v[i] * wv[col];
 }
 
 struct WaveSum {
@@ -896,7 +936,7 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
             const MergePlan& pl = plans[mi];
             const int lo = pl.lo, N = pl.N, K = pl.K;
             if (pl.nrot > 0)
-                hipLaunchKernelGGL(rot_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, c->stream,
+                hipLaunchKernelGGL(rot_rows_kernel, dim3((N + 63) / 64), dim3(64), 0, c->stream,
                                    cur + (size_t)lo * ld + lo, ld, N, pl.nrot, i1d + lo, i2d + lo, csd + 2 * (size_t)lo);
             if (K > 0) {
                 hipLaunchKernelGGL(secular_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd + lo, wd + lo,
@@ -1088,6 +1128,52 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     pl.lo = 0;
     pl.N = n;
     pl.rho = fabs(sigma) * znorm2;
+    // ---- clusters of (numerically) equal eigenvalues: one Householder reflection per cluster --------
+    // An approximate Hessian starts as lam0*I + low rank, so most of its spectrum is one value repeated
+    // ~n times.  The pairwise Givens deflation below would walk through such a cluster with a chain of
+    // ~n dependent row rotations; a single reflection H = I - tau v v^T with H z_cluster = beta e_last
+    // does the same job (all weight moved onto one row, the others deflate with z = 0) as one
+    // transposed matvec and one rank-one update over the cluster's rows, which are contiguous because
+    // the rows are kept in eigenvalue order.
+    {
+        const double eps = 2.220446049250313e-16;
+        double dmax = 0.0;
+        for (int ip = 0; ip < n; ++ip) dmax = std::max(dmax, fabs(D[ip]));
+        const double spread = 4.0 * eps * dmax;
+        double* vdev = W.vec + (size_t)V_U1 * ld;
+        double* wvd = W.vec + (size_t)V_WRAW * ld;
+        std::vector<double> vh;
+        int ip = 0;
+        while (ip < n) {
+            int j = ip;
+            while (j + 1 < n && D[j + 1] - D[ip] <= spread) ++j;
+            const int len = j - ip + 1;
+            if (len >= 8) {
+                double nrm2 = 0.0;
+                for (int t = ip; t <= j; ++t) nrm2 += zz[t] * zz[t];
+                const double xl = zz[j];
+                const double beta = (xl >= 0.0) ? -sqrt(nrm2) : sqrt(nrm2);
+                // v = x - beta e_last ; v^T v = 2 (nrm2 - beta x_last)
+                const double vtv = 2.0 * (nrm2 - beta * xl);
+                if (nrm2 > 0.0 && vtv > 0.0 && nrm2 > zz[j] * zz[j]) {
+                    vh.assign(len, 0.0);
+                    const int rlo = std::min(rowof(ip), rowof(j));
+                    for (int t = ip; t <= j; ++t) vh[rowof(t) - rlo] = zz[t] - ((t == j) ? beta : 0.0);
+                    const double tau = 2.0 / vtv;
+                    HIPCHK(hipMemcpyAsync(vdev, vh.data(), (size_t)len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                    double* R = Vt + (size_t)rlo * ld;
+                    SCHK(launch_gemv_cols(c, R, len, n, ld, vdev, ld, 1, wvd, ld));
+                    hipLaunchKernelGGL(rows_ger_kernel, dim3((n + 255) / 256, len), dim3(256), 0, c->stream, R, ld, len, n,
+                                       vdev, wvd, tau);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipStreamSynchronize(c->stream));     // vh is reused by the next cluster
+                    for (int t = ip; t < j; ++t) zz[t] = 0.0;
+                    zz[j] = beta;
+                }
+            }
+            ip = j + 1;
+        }
+    }
     plan_deflation(n, D.data(), zz.data(), pl);
     const int K = pl.K;
     std::vector<double> hD(std::max(K, 1)), hw(std::max(K, 1)), hcs(2 * (size_t)std::max(pl.nrot, 1));
@@ -1110,7 +1196,7 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
         HIPCHK(hipMemcpyAsync(i1d, hr1.data(), (size_t)pl.nrot * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(i2d, hr2.data(), (size_t)pl.nrot * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(csd, hcs.data(), (size_t)2 * pl.nrot * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(rot_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, Vt, ld, n, pl.nrot, i1d, i2d, csd);
+        hipLaunchKernelGGL(rot_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, Vt, ld, n, pl.nrot, i1d, i2d, csd);
     }
     std::vector<double> lam(std::max(K, 1));
     if (K > 0) {

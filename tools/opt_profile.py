@@ -32,8 +32,8 @@ ctx.sync()
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()
-opt.run(fmax=0.0, steps=int(os.environ.get('STEPS', '6')))
+opt.run(fmax=0.0, steps=int(os.environ.get('STEPS', '20')))
 ctx.sync()
 pr.disable()
-print('s/step', (time.perf_counter() - t0) / int(os.environ.get('STEPS', '6')))
-pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
+print('s/step', (time.perf_counter() - t0) / int(os.environ.get('STEPS', '20')))
+pstats.Stats(pr).sort_stats('tottime').print_stats(16)

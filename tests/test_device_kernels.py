@@ -103,8 +103,9 @@ def test_profiling_hooks(ctx):
     ctx.prof_enable(False)
     small, trd = ctx.prof_get(4), ctx.prof_get(5)
     assert small['launches'] >= 1 and small['bytes'] >= 8.0 * n * n and small['ms'] >= 0.0
-    assert trd['launches'] == n - 2
-    assert abs(trd['bytes'] - 8.0 * sum((n - 1 - j) ** 2 for j in range(n - 2))) < 1e-6
+    cols = [j for j in range(n - 2) if j % 4 == 0]              # every 4th column is sampled
+    assert trd['launches'] == len(cols)
+    assert abs(trd['bytes'] - 8.0 * sum((n - 1 - j) ** 2 for j in cols)) < 1e-6
     ctx.symm_mm(dA, rng.normal(size=n))          # not counted once disabled
     assert ctx.prof_get(4)['launches'] == small['launches']
 

@@ -1031,11 +1031,14 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
             ra.dvec = dvec;
             const int nblkA = (n - j + 255) / 256;
             const dim3 gA(nblkA), bA(256);
-            // Profiling samples every 4th column (both kernels of the column, so the matvec is timed under the
-            // queue conditions of a fully traced run): attaching events to all 6000 launches slows the host
-            // enqueue below the GPU's pace and the kernels are then measured starting from an idle device.
+            // Profiling samples every 4th column.  The event pair is attached to the dispatch packet, whose
+            // start stamp is taken when the packet is picked up — behind a backlog of earlier launches that
+            // would include queueing time.  So the queue is drained first and then BOTH kernels of the column
+            // are launched with events: the matvec starts right behind its row kernel exactly as in the
+            // untraced run, and nothing else is ahead of it.
             const bool prof_all = c->prof;
             if (prof_all && (j & 3)) c->prof = false;
+            if (c->prof) HIPCHK(hipStreamSynchronize(c->stream));
             prof_begin(c, PROF_OTHER, 8.0 * (2.0 * i + 3.0) * (n - j), 0.0);
             switch (i - 1) {
 #define SELLA_TRD_ROW_CASE(IP) case IP: SELLA_LAUNCH(c, HIP_KERNEL_NAME(trd_row_kernel<IP>), gA, bA, 0, ra); break;

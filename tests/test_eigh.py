@@ -48,6 +48,27 @@ def test_small_sizes(ctx):
     ctx.set_option('eigh_leaf', 32)
 
 
+def test_panel_widths_and_variants(ctx):
+    """Every panel width runs the same algebra (specialised row kernels up to 16 columns, the generic
+    loop beyond), and the VALU back-transformation agrees with the matrix-core one."""
+    rng = np.random.RandomState(4)
+    n = 70
+    A = rng.normal(size=(n, n))
+    A = A + A.T
+    ref = None
+    try:
+        for nb, wy in ((16, 1), (4, 1), (24, 1), (64, 1), (16, 0)):
+            ctx.set_option('eigh_nb', nb)
+            ctx.set_option('eigh_wy_mfma', wy)
+            w = check(ctx, A)
+            if ref is None:
+                ref = w
+            np.testing.assert_allclose(w, ref, atol=1e-12 * np.abs(ref).max())
+    finally:
+        ctx.set_option('eigh_nb', 16)
+        ctx.set_option('eigh_wy_mfma', 1)
+
+
 def test_spectra(ctx):
     rng = np.random.RandomState(1)
     n = 96 if ctx.backend == 'emu' else 700

@@ -162,8 +162,12 @@ int run_kind(sella_ctx* c, int nc, const double* dpos, const double* dtv, const 
              double* dgrad, double* dhvp, double* dhess) {
     constexpr int NV = 3 * NA;
     const long n0 = (long)nc * NV;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(internals_kernel<NA>), dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0,
-                       c->stream, nc, 0, dpos, dtv, dtan, dq, dgrad, dhvp, dhess);
+    // algorithmic bytes: positions + shift vectors (+ tangent) in, value + gradient (+ H t) out
+    const double bytes = 8.0 * nc * (NV + 3.0 * (NA - 1) + (dtan ? NV : 0) + 1.0 + NV + (dtan ? NV : 0));
+    prof_begin(c, PROF_OTHER, bytes, 0.0);
+    SELLA_LAUNCH(c, HIP_KERNEL_NAME(internals_kernel<NA>), dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0,
+                 nc, 0, dpos, dtv, dtan, dq, dgrad, dhvp, dhess);
+    prof_end(c);
     if (dhess) {
         const long n1 = (long)nc * NV * NV;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(internals_kernel<NA>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0,

@@ -343,3 +343,135 @@ class Constraints:
             self.fix_translation()
         else:
             raise NotImplementedError(f'ASE constraint {name} is not supported by this path')
+
+
+# ------------------------------------------------------------------------------------------
+# array-based redundant internal coordinates (the numerical core of BaseInternals,
+# sella/internal.py:1362-1902, 2189-2587: calc / jacobian / hessian ldot / hessian_rdot / wrap)
+# ------------------------------------------------------------------------------------------
+class InternalCoordinates:
+    """Bonds, angles and dihedrals of one structure as index arrays, evaluated in batches on the device.
+
+    The reference keeps a Python object per coordinate and builds padded batch arrays from them
+    (`_build_batched_arrays`, internal.py:1362-1529); here the index arrays ARE the representation:
+    `bonds (nb, 2)`, `angles (na, 3)`, `dihedrals (nd, 4)` atom indices plus integer cell offsets
+    `*_ncvecs (n, natoms-1, 3)` for periodic images.  Order of the coordinates: bonds, angles, dihedrals.
+    Automatic topology search, dummy atoms and TRIC rotations are not part of this class.
+    """
+    _order = ('bonds', 'angles', 'dihedrals')
+
+    def __init__(self, atoms, bonds=None, angles=None, dihedrals=None, bond_ncvecs=None, angle_ncvecs=None,
+                 dihedral_ncvecs=None):
+        self.atoms = atoms
+        self.idx, self.ncv = {}, {}
+        for name, arr, ncv in (('bonds', bonds, bond_ncvecs), ('angles', angles, angle_ncvecs),
+                               ('dihedrals', dihedrals, dihedral_ncvecs)):
+            na = _NATOMS[name]
+            a = np.zeros((0, na), dtype=np.int64) if arr is None else np.asarray(arr, dtype=np.int64).reshape(-1, na)
+            v = np.zeros((len(a), na - 1, 3)) if ncv is None else np.asarray(ncv, dtype=np.float64).reshape(len(a), na - 1, 3)
+            self.idx[name], self.ncv[name] = a, v
+
+    ndof = property(lambda self: 3 * len(self.atoms))
+    nint = property(lambda self: sum(len(self.idx[k]) for k in self._order))
+
+    def _batch(self, name):
+        idx = self.idx[name]
+        pos = self.atoms.positions[idx]
+        tvec = self.ncv[name] @ np.asarray(self.atoms.cell, dtype=np.float64)
+        dofs = (3 * idx[:, :, None] + np.arange(3)[None, None, :]).reshape(len(idx), 3 * _NATOMS[name])
+        return pos, tvec, dofs
+
+    def calc(self):
+        """q(x) (internal.py:1735-1778)."""
+        return np.concatenate([evaluate_kind(k, *self._batch(k)[:2], hessian=False)[0] for k in self._order])
+
+    def wrap(self, vec):
+        """Map dihedral differences into (-pi, pi] (internal.py:2577-2587)."""
+        nd = len(self.idx['dihedrals'])
+        if nd:
+            vec = np.array(vec, dtype=np.float64)
+            vec[-nd:] = (vec[-nd:] + np.pi) % (2 * np.pi) - np.pi
+        return vec
+
+    def jacobian(self):
+        """Dense Wilson B-matrix dq/dx, (nint, 3N) (internal.py:1780-1902)."""
+        B = np.zeros((self.nint, self.ndof))
+        row = 0
+        for k in self._order:
+            pos, tvec, dofs = self._batch(k)
+            nc = len(pos)
+            if nc:
+                g = evaluate_kind(k, pos, tvec, hessian=False)[1].reshape(nc, -1)
+                np.add.at(B, (np.arange(row, row + nc)[:, None], dofs), g)
+            row += nc
+        return B
+
+    def hessian_rdot(self, v):
+        """D(v)_i = H_i v as a dense (nint, 3N) matrix (internal.py:2307-2575: one HVP per coordinate)."""
+        v = np.asarray(v, dtype=np.float64).ravel()
+        D = np.zeros((self.nint, self.ndof))
+        row = 0
+        for k in self._order:
+            pos, tvec, dofs = self._batch(k)
+            nc = len(pos)
+            if nc:
+                tan = v[dofs].reshape(pos.shape)
+                hv = evaluate_kind(k, pos, tvec, tangent=tan, hessian=False)[3].reshape(nc, -1)
+                np.add.at(D, (np.arange(row, row + nc)[:, None], dofs), hv)
+            row += nc
+        return D
+
+    def hessian(self):
+        """Per-coordinate Hessian blocks with the `ldot` contraction (internal.py:2189-2305)."""
+        blocks = []
+        for k in self._order:
+            pos, tvec, dofs = self._batch(k)
+            nc, m = len(pos), 3 * _NATOMS[k]
+            H = evaluate_kind(k, pos, tvec)[2].reshape(nc, m, m) if nc else np.zeros((0, m, m))
+            blocks.append((dofs, H))
+        return _HessianStack(self.ndof, blocks)
+
+
+def neighbour_bonds(atoms, rcut):
+    """All pairs closer than rcut under the minimum-image convention of the periodic directions:
+    (bonds (nb, 2), ncvecs (nb, 1, 3)) with i < j.  A vectorised stand-in for `find_all_bonds`
+    (internal.py:3260-3400) on regular lattices; O(N^2) memory."""
+    pos = atoms.positions
+    n = len(pos)
+    iu = np.triu_indices(n, 1)
+    d = pos[iu[1]] - pos[iu[0]]
+    cell = np.asarray(atoms.cell, dtype=np.float64)
+    shift = np.zeros((len(d), 3))
+    per = np.where(atoms.pbc)[0]
+    if len(per):
+        C = cell[per]
+        s = -np.round(d @ np.linalg.pinv(C))
+        shift[:, per] = s
+        d = d + s @ C
+    m = np.linalg.norm(d, axis=1) < rcut
+    return np.stack([iu[0][m], iu[1][m]], axis=1), shift[m][:, None, :]
+
+
+def angles_from_bonds(bonds, ncvecs):
+    """Every pair of bonds sharing an atom gives an angle with that atom at the vertex
+    (internal.py:3402-3470): (angles (na, 3), ncvecs (na, 2, 3))."""
+    nb = len(bonds)
+    # directed half-bonds centre -> neighbour with the image offset seen from the centre
+    cen = np.concatenate([bonds[:, 0], bonds[:, 1]])
+    nei = np.concatenate([bonds[:, 1], bonds[:, 0]])
+    off = np.concatenate([ncvecs[:, 0], -ncvecs[:, 0]])
+    order = np.argsort(cen, kind='stable')
+    cen, nei, off = cen[order], nei[order], off[order]
+    starts = np.flatnonzero(np.r_[True, cen[1:] != cen[:-1], True])
+    ang, ncv = [], []
+    for a, b in zip(starts[:-1], starts[1:]):
+        k = b - a
+        if k < 2:
+            continue
+        i, j = np.triu_indices(k, 1)
+        # angle (n_i, centre, n_j): first vector centre - n_i image = -off_i, second n_j - centre = off_j
+        ang.append(np.stack([nei[a + i], np.full(len(i), cen[a]), nei[a + j]], axis=1))
+        ncv.append(np.stack([-off[a + i], off[a + j]], axis=1))
+    if not ang:
+        return np.zeros((0, 3), dtype=np.int64), np.zeros((0, 2, 3))
+    return np.concatenate(ang), np.concatenate(ncv)

@@ -83,3 +83,45 @@ def test_edge_cases(ctx):
     assert q.shape == (0,) and g.shape == (0, 2, 3)
     with pytest.raises(Exception):
         ctx.internals_eval(np.zeros((1, 5, 3)))
+
+
+def _slab(size):
+    from sella_amd.atoms import fcc111
+    slab = fcc111('Cu', size, vacuum=6.0)
+    rng = np.random.RandomState(3)
+    slab.positions += 0.05 * rng.normal(size=slab.positions.shape)
+    return slab
+
+
+def test_internal_coordinates_container(ctx):
+    """B-matrix, D(v) and ldot of a periodic slab's bonds + angles: finite-difference consistency of
+    q(x) -> B and B -> D(v) through the periodic images (config 3 of BASELINE.json in small)."""
+    from sella_amd.internal import InternalCoordinates, angles_from_bonds, neighbour_bonds
+    slab = _slab((3, 3, 2))
+    bonds, bncv = neighbour_bonds(slab, 1.25 * 3.61 / np.sqrt(2))
+    assert len(bonds) == 9 * 2 * 3 + 9 * 3                     # 6 in-plane / 2 per atom + 3 interlayer per atom
+    angles, ancv = angles_from_bonds(bonds, bncv)
+    ic = InternalCoordinates(slab, bonds=bonds, angles=angles, bond_ncvecs=bncv, angle_ncvecs=ancv)
+    q0 = ic.calc()
+    nb = len(bonds)
+    np.testing.assert_allclose(q0[:nb], 3.61 / np.sqrt(2), atol=0.25)          # nearest-neighbour lengths
+    assert np.all((q0[nb:] > 0.8) & (q0[nb:] < np.pi + 1e-9))                  # 60 / 90 / 120 / 180 degree families
+    B = ic.jacobian()
+    x0 = slab.positions.copy()
+    rng = np.random.RandomState(8)
+    v = rng.normal(size=x0.size)
+    h = 1e-6
+    slab.positions = x0 + h * v.reshape(-1, 3)
+    qp, Bp = ic.calc(), ic.jacobian()
+    slab.positions = x0 - h * v.reshape(-1, 3)
+    qm, Bm = ic.calc(), ic.jacobian()
+    slab.positions = x0
+    np.testing.assert_allclose(B @ v, ic.wrap(qp - qm) / (2 * h), rtol=1e-6, atol=1e-7)
+    D = ic.hessian_rdot(v)
+    np.testing.assert_allclose(D, (Bp - Bm) / (2 * h), rtol=1e-5, atol=1e-6)
+    # ldot(w) v == D(v)^T w for any w (linalg.py:601-640)
+    w = rng.normal(size=ic.nint)
+    np.testing.assert_allclose(ic.hessian().ldot(w) @ v, D.T @ w, rtol=1e-10, atol=1e-10)
+    # translation of the whole slab leaves every internal coordinate unchanged: B t = 0
+    t = np.tile([0.3, -0.2, 0.5], len(slab))
+    np.testing.assert_allclose(B @ t, 0.0, atol=1e-12)

@@ -23,6 +23,7 @@
 #include "secular.h"
 
 #include <algorithm>
+#include <chrono>
 #include <numeric>
 
 namespace sella {
@@ -314,10 +315,9 @@ __global__ __launch_bounds__(256) void gather_z_kernel(const double* __restrict_
 // rotations are issued before the (sequential) arithmetic on it, which turns a chain of nrot memory
 // round trips into nrot/16 of them.
 constexpr int ROT_BATCH = 16;
-__global__ __launch_bounds__(64) void rot_rows_kernel(double* __restrict__ Zb, int ld, int N, int nrot,
-                                                      const int* __restrict__ i1,
-                                                      const int* __restrict__ i2,
-                                                      const double* __restrict__ cs) {
+__device__ __forceinline__ void rot_rows_body(double* __restrict__ Zb, int ld, int N, int nrot,
+                                              const int* __restrict__ i1, const int* __restrict__ i2,
+                                              const double* __restrict__ cs) {
     const int col = blockIdx.x * 64 + threadIdx.x;
     if (col >= N) return;
     double carry = 0.0;
@@ -354,6 +354,13 @@ __global__ __launch_bounds__(64) void rot_rows_kernel(double* __restrict__ Zb, i
     if (crow >= 0) Zb[(size_t)crow * ld + col] = carry;
 }
 
+__global__ __launch_bounds__(64) void rot_rows_kernel(double* __restrict__ Zb, int ld, int N, int nrot,
+                                                      const int* __restrict__ i1,
+                                                      const int* __restrict__ i2,
+                                                      const double* __restrict__ cs) {
+    rot_rows_body(Zb, ld, N, nrot, i1, i2, cs);
+}
+
 // R[i][c] -= tau v[i] w[c] on a block of rows (Householder reflection applied to eigenvector rows)
 __global__ __launch_bounds__(256) void rows_ger_kernel(double* __restrict__ R, int ld, int nrows, int ncols,
                                                        const double* __restrict__ v,
@@ -375,10 +382,9 @@ struct WaveProd {
 };
 
 // one WAVEFRONT per root: the 64 lanes split every O(K) sum of the iteration
-__global__ __launch_bounds__(256) void secular_kernel(int K, const double* __restrict__ D,
-                                                      const double* __restrict__ w, double rho,
-                                                      double* __restrict__ tau, int* __restrict__ org,
-                                                      double* __restrict__ lam, int* __restrict__ info) {
+__device__ __forceinline__ void secular_body(int K, const double* __restrict__ D, const double* __restrict__ w,
+                                             double rho, double* __restrict__ tau, int* __restrict__ org,
+                                             double* __restrict__ lam, int* __restrict__ info) {
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (j >= K) return;            // whole wavefront leaves together
@@ -393,10 +399,16 @@ __global__ __launch_bounds__(256) void secular_kernel(int K, const double* __res
     }
 }
 
-__global__ __launch_bounds__(256) void zhat_kernel(int K, const double* __restrict__ D,
-                                                   const double* __restrict__ w,
-                                                   const double* __restrict__ tau,
-                                                   const int* __restrict__ org, double* __restrict__ zh) {
+__global__ __launch_bounds__(256) void secular_kernel(int K, const double* __restrict__ D,
+                                                      const double* __restrict__ w, double rho,
+                                                      double* __restrict__ tau, int* __restrict__ org,
+                                                      double* __restrict__ lam, int* __restrict__ info) {
+    secular_body(K, D, w, rho, tau, org, lam, info);
+}
+
+__device__ __forceinline__ void zhat_body(int K, const double* __restrict__ D, const double* __restrict__ w,
+                                          const double* __restrict__ tau, const int* __restrict__ org,
+                                          double* __restrict__ zh) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= K) return;
@@ -404,12 +416,17 @@ __global__ __launch_bounds__(256) void zhat_kernel(int K, const double* __restri
     if (lane == 0) zh[i] = z;
 }
 
+__global__ __launch_bounds__(256) void zhat_kernel(int K, const double* __restrict__ D,
+                                                   const double* __restrict__ w,
+                                                   const double* __restrict__ tau,
+                                                   const int* __restrict__ org, double* __restrict__ zh) {
+    zhat_body(K, D, w, tau, org, zh);
+}
+
 // Ut[j][i] = zhat_i / ((D_i - D_org_j) - tau_j), row j normalised
-__global__ __launch_bounds__(256) void build_u_kernel(int K, const double* __restrict__ D,
-                                                      const double* __restrict__ zh,
-                                                      const double* __restrict__ tau,
-                                                      const int* __restrict__ org,
-                                                      double* __restrict__ Ut, int ldu) {
+__device__ __forceinline__ void build_u_body(int K, const double* __restrict__ D, const double* __restrict__ zh,
+                                             const double* __restrict__ tau, const int* __restrict__ org,
+                                             double* __restrict__ Ut, int ldu) {
     __shared__ double red[4];
     const int j = blockIdx.x;
     const double Do = D[org[j]], tj = tau[j];
@@ -422,6 +439,87 @@ __global__ __launch_bounds__(256) void build_u_kernel(int K, const double* __res
     ss = block_sum_256(ss, red);
     const double inv = 1.0 / sqrt(ss);
     for (int i = threadIdx.x; i < K; i += 256) Ut[(size_t)j * ldu + i] *= inv;
+}
+
+__global__ __launch_bounds__(256) void build_u_kernel(int K, const double* __restrict__ D,
+                                                      const double* __restrict__ zh,
+                                                      const double* __restrict__ tau,
+                                                      const int* __restrict__ org,
+                                                      double* __restrict__ Ut, int ldu) {
+    build_u_body(K, D, zh, tau, org, Ut, ldu);
+}
+
+// ---- one launch per tree level: blockIdx.y (or .z) selects the merge ----------------------------------
+// Per-merge parameters on the device.  The per-row arrays (D, w, tau, origin, lambda, zhat, rotation
+// lists, gather indices) of all merges of a level share n-length buffers at offset lo.
+struct MergeDev {
+    int lo, N, K, nrot;     // first row/column, size, non-deflated count, rotations
+    int n1, mid;            // rows of the left child, first column of the right child
+    double rho, sgn;
+};
+
+__global__ __launch_bounds__(256) void gather_z_batched_kernel(const MergeDev* __restrict__ md,
+                                                               const double* __restrict__ Zt, int ld,
+                                                               double* __restrict__ z) {
+    const MergeDev m = md[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m.N) return;
+    z[m.lo + i] = (i < m.n1) ? Zt[(size_t)(m.lo + i) * ld + m.mid - 1] : m.sgn * Zt[(size_t)(m.lo + i) * ld + m.mid];
+}
+
+__global__ __launch_bounds__(64) void rot_rows_batched_kernel(const MergeDev* __restrict__ md, double* __restrict__ Zb,
+                                                              int ld, const int* __restrict__ i1,
+                                                              const int* __restrict__ i2,
+                                                              const double* __restrict__ cs) {
+    const MergeDev m = md[blockIdx.y];
+    if (m.nrot == 0 || (int)(blockIdx.x * 64) >= m.N) return;
+    rot_rows_body(Zb + (size_t)m.lo * ld + m.lo, ld, m.N, m.nrot, i1 + m.lo, i2 + m.lo, cs + 2 * (size_t)m.lo);
+}
+
+__global__ __launch_bounds__(256) void secular_batched_kernel(const MergeDev* __restrict__ md,
+                                                              const double* __restrict__ D,
+                                                              const double* __restrict__ w,
+                                                              double* __restrict__ tau, int* __restrict__ org,
+                                                              double* __restrict__ lam, int* __restrict__ info) {
+    const MergeDev m = md[blockIdx.y];
+    secular_body(m.K, D + m.lo, w + m.lo, m.rho, tau + m.lo, org + m.lo, lam + m.lo, info);
+}
+
+__global__ __launch_bounds__(256) void zhat_batched_kernel(const MergeDev* __restrict__ md,
+                                                           const double* __restrict__ D,
+                                                           const double* __restrict__ w,
+                                                           const double* __restrict__ tau,
+                                                           const int* __restrict__ org, double* __restrict__ zh) {
+    const MergeDev m = md[blockIdx.y];
+    zhat_body(m.K, D + m.lo, w + m.lo, tau + m.lo, org + m.lo, zh + m.lo);
+}
+
+__global__ __launch_bounds__(256) void build_u_batched_kernel(const MergeDev* __restrict__ md,
+                                                              const double* __restrict__ D,
+                                                              const double* __restrict__ zh,
+                                                              const double* __restrict__ tau,
+                                                              const int* __restrict__ org,
+                                                              double* __restrict__ Ut, int ldu) {
+    const MergeDev m = md[blockIdx.y];
+    if ((int)blockIdx.x >= m.K) return;
+    build_u_body(m.K, D + m.lo, zh + m.lo, tau + m.lo, org + m.lo, Ut + (size_t)m.lo * ldu + m.lo, ldu);
+}
+
+// Row p of the level's output layout takes row idx[p] of `cur` restricted to its merge's columns: the
+// first K rows of a merge (non-deflated, secular order) go to Zc for the GEMM, the others straight to nxt.
+__global__ __launch_bounds__(256) void gather_level_kernel(const MergeDev* __restrict__ md,
+                                                           const int* __restrict__ merge_of_row,
+                                                           const int* __restrict__ idx,
+                                                           const double* __restrict__ cur,
+                                                           double* __restrict__ Zc, double* __restrict__ nxt,
+                                                           int ld) {
+    const int p = blockIdx.y;
+    const MergeDev m = md[merge_of_row[p]];
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= m.N) return;
+    const double v = cur[(size_t)idx[p] * ld + m.lo + col];
+    double* dst = (p - m.lo < m.K) ? Zc : nxt;
+    dst[(size_t)p * ld + m.lo + col] = v;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -855,6 +953,11 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
     int* i2d = ibase + n;
     int* idxd = ibase + 2 * n;
     int* orgd = ibase + 3 * n;
+    int* mrowd = ibase + 4 * n;                       // merge index of every row (per level)
+    int* gdescd = ibase + 5 * n;                      // GEMM descriptors, 4 ints per merge
+    double* mdraw;                                    // per-merge parameters (the stage-1 partial buffer is free now)
+    SCHK(scratch_get(c, SCR_MISC1, ((size_t)n / 2 + 8) * sizeof(MergeDev), &mdraw));
+    MergeDev* mdd = reinterpret_cast<MergeDev*>(mdraw);
     HIPCHK(hipMemsetAsync(info, 0, 8 * sizeof(int), c->stream));
     HIPCHK(hipMemcpyAsync(rdev, ranges.data(), ranges.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(set_identity_kernel, dim3((n + 255) / 256, n), dim3(256), 0, c->stream, W.Za, ld, n);
@@ -883,18 +986,29 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
     double* lamd = W.vec + (size_t)V_LAM * ld;
     std::vector<double> z(n), lam(n), hD(n), hw(n), hcs(2 * (size_t)n);
     std::vector<int> order, hidx(n), hr1(n), hr2(n);
+    // Eigenvector rows of a node are supported on its own column range only, so everything outside the
+    // diagonal blocks must read as zero.  One clearing of the second buffer suffices: level h overwrites
+    // its diagonal blocks completely (K updated + N-K deflated rows of N columns each), and the blocks
+    // this buffer held two levels earlier lie inside them.
+    HIPCHK(hipMemsetAsync(nxt, 0, (size_t)n * ld * sizeof(double), c->stream));
     for (int h = 1; h <= maxdepth; ++h) {
         const std::vector<int>& lvl = by_height[h];
-        // eigenvector rows of a node are supported on its own column range only: everything of
-        // `nxt` outside the diagonal blocks written below must read as zero at the next level
-        HIPCHK(hipMemsetAsync(nxt, 0, (size_t)n * ld * sizeof(double), c->stream));
-        // ---- (1) rank-one vectors of all merges of this level, one synchronisation ------------
-        for (int ni : lvl) {
-            const Node& nd = nodes[ni];
-            const int N = nd.hi - nd.lo;
-            hipLaunchKernelGGL(gather_z_kernel, dim3((N + 255) / 256), dim3(256), 0, c->stream, cur, ld, nd.lo,
-                               nd.mid - nd.lo, N, nd.mid, e[nd.mid - 1] < 0 ? -1.0 : 1.0, zdev);
+        // ---- (1) rank-one vectors of all merges of this level: one launch, one synchronisation -------
+        const int nm = (int)lvl.size();
+        std::vector<MergeDev> hmd(nm);
+        std::vector<int> hmrow(n);
+        int maxN = 0;
+        for (int mi = 0; mi < nm; ++mi) {
+            const Node& nd = nodes[lvl[mi]];
+            MergeDev& m = hmd[mi];
+            m.lo = nd.lo; m.N = nd.hi - nd.lo; m.K = 0; m.nrot = 0;
+            m.n1 = nd.mid - nd.lo; m.mid = nd.mid;
+            m.rho = 0.0; m.sgn = e[nd.mid - 1] < 0 ? -1.0 : 1.0;
+            maxN = std::max(maxN, m.N);
+            for (int p = nd.lo; p < nd.hi; ++p) hmrow[p] = mi;
         }
+        HIPCHK(hipMemcpyAsync(mdd, hmd.data(), (size_t)nm * sizeof(MergeDev), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(gather_z_batched_kernel, dim3((maxN + 255) / 256, nm), dim3(256), 0, c->stream, mdd, cur, ld, zdev);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(z.data(), zdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -931,28 +1045,37 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
         HIPCHK(hipMemcpyAsync(i1d, hr1.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(i2d, hr2.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(csd, hcs.data(), (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        // ---- (3) device work of every merge, no synchronisation in between ----------------------------
-        for (size_t mi = 0; mi < lvl.size(); ++mi) {
-            const MergePlan& pl = plans[mi];
-            const int lo = pl.lo, N = pl.N, K = pl.K;
-            if (pl.nrot > 0)
-                hipLaunchKernelGGL(rot_rows_kernel, dim3((N + 63) / 64), dim3(64), 0, c->stream,
-                                   cur + (size_t)lo * ld + lo, ld, N, pl.nrot, i1d + lo, i2d + lo, csd + 2 * (size_t)lo);
-            if (K > 0) {
-                hipLaunchKernelGGL(secular_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd + lo, wd + lo,
-                                   pl.rho, taud + lo, orgd + lo, lamd + lo, info);
-                hipLaunchKernelGGL(zhat_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd + lo, wd + lo,
-                                   taud + lo, orgd + lo, zhd + lo);
-                double* Ub = W.Ut + (size_t)lo * ld + lo;
-                hipLaunchKernelGGL(build_u_kernel, dim3(K), dim3(256), 0, c->stream, K, Dd + lo, zhd + lo, taud + lo,
-                                   orgd + lo, Ub, ld);
-                HIPCHK(hipGetLastError());
-                double* Zcb = W.Zc + (size_t)lo * ld + lo;
-                SCHK(launch_gather_rows(c, cur + lo, ld, idxd + lo, K, N, Zcb, ld));
-                SCHK(launch_gemm(c, 0, 0, K, N, K, 1.0, Ub, ld, Zcb, ld, 0.0, nxt + (size_t)lo * ld + lo, ld));
+        // ---- (3) device work of the whole level: one launch per kernel, blockIdx.y = merge -------------
+        {
+            int maxK = 0, maxrot = 0;
+            std::vector<int> hgd(4 * (size_t)nm);
+            for (int mi = 0; mi < nm; ++mi) {
+                const MergePlan& pl = plans[mi];
+                hmd[mi].K = pl.K;
+                hmd[mi].nrot = pl.nrot;
+                hmd[mi].rho = pl.rho;
+                maxK = std::max(maxK, pl.K);
+                maxrot = std::max(maxrot, pl.nrot);
+                hgd[4 * mi] = pl.lo; hgd[4 * mi + 1] = pl.N; hgd[4 * mi + 2] = pl.K; hgd[4 * mi + 3] = 0;
             }
-            if (N - K > 0)
-                SCHK(launch_gather_rows(c, cur + lo, ld, idxd + lo + K, N - K, N, nxt + (size_t)(lo + K) * ld + lo, ld));
+            HIPCHK(hipMemcpyAsync(mdd, hmd.data(), (size_t)nm * sizeof(MergeDev), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(mrowd, hmrow.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(gdescd, hgd.data(), hgd.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            if (maxrot > 0)
+                hipLaunchKernelGGL(rot_rows_batched_kernel, dim3((maxN + 63) / 64, nm), dim3(64), 0, c->stream, mdd, cur, ld,
+                                   i1d, i2d, csd);
+            if (maxK > 0) {
+                hipLaunchKernelGGL(secular_batched_kernel, dim3((maxK + 3) / 4, nm), dim3(256), 0, c->stream, mdd, Dd, wd,
+                                   taud, orgd, lamd, info);
+                hipLaunchKernelGGL(zhat_batched_kernel, dim3((maxK + 3) / 4, nm), dim3(256), 0, c->stream, mdd, Dd, wd, taud,
+                                   orgd, zhd);
+                hipLaunchKernelGGL(build_u_batched_kernel, dim3(maxK, nm), dim3(256), 0, c->stream, mdd, Dd, zhd, taud, orgd,
+                                   W.Ut, ld);
+            }
+            hipLaunchKernelGGL(gather_level_kernel, dim3((maxN + 255) / 256, n), dim3(256), 0, c->stream, mdd, mrowd, idxd, cur,
+                               W.Zc, nxt, ld);
+            HIPCHK(hipGetLastError());
+            SCHK(launch_gemm_merge_batched(c, nm, gdescd, maxN, maxK, W.Ut, W.Zc, nxt, ld));
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(lam.data(), lamd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1253,7 +1376,7 @@ int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const do
     SCHK(scratch_get(c, SCR_EIG2, mbytes, &W.Zb));
     SCHK(scratch_get(c, SCR_EIG3, mbytes, &W.Zc));
     SCHK(scratch_get(c, SCR_EIG4, mbytes, &W.Ut));
-    SCHK(scratch_get(c, SCR_EIG5, (size_t)V_NSLOTS * ld * sizeof(double) + (size_t)(6 * n + 256) * sizeof(int), &W.vec));
+    SCHK(scratch_get(c, SCR_EIG5, (size_t)V_NSLOTS * ld * sizeof(double) + (size_t)(8 * n + 512) * sizeof(int), &W.vec));
     W.ibuf = reinterpret_cast<int*>(W.vec + (size_t)V_NSLOTS * ld);
     W.A = nullptr;
     // ---- orthonormal basis of span{U_a, Z_a} (rows of Qb) and the coordinates of U, Z in it ------
@@ -1378,11 +1501,14 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     SCHK(scratch_get(c, SCR_EIG2, mbytes, &W.Zb));
     SCHK(scratch_get(c, SCR_EIG3, mbytes, &W.Zc));
     SCHK(scratch_get(c, SCR_EIG4, mbytes, &W.Ut));
-    SCHK(scratch_get(c, SCR_EIG5, (size_t)V_NSLOTS * ld * sizeof(double) + (size_t)(6 * n + 256) * sizeof(int), &W.vec));
+    SCHK(scratch_get(c, SCR_EIG5, (size_t)V_NSLOTS * ld * sizeof(double) + (size_t)(8 * n + 512) * sizeof(int), &W.vec));
     W.ibuf = reinterpret_cast<int*>(W.vec + (size_t)V_NSLOTS * ld);
     a = mat_get(c, hA);
     SCHK(launch_axpby2d(c, n, n, 1.0, a->d, a->ld, 0.0, nullptr, 0, W.A, ld));
 
+    const bool dbg_time = getenv("SELLA_DEBUG_TIMING") != nullptr;
+    auto now = [&] { if (dbg_time) (void)hipStreamSynchronize(c->stream); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_s0 = now();
     // ---- stage 1 ----------------------------------------------------------------------------
     double* dvec = W.vec + (size_t)V_D * ld;
     double* evec = W.vec + (size_t)V_E * ld;
@@ -1395,10 +1521,12 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     HIPCHK(hipMemcpyAsync(tauh.data(), taus, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
 
+    const double t_s1 = now();
     // ---- stage 2 ----------------------------------------------------------------------------
     SCHK(dc_solve(W, d, e, w));
     if (!hV && !hVt) return SELLA_OK;
 
+    const double t_s2 = now();
     // ---- stage 3: X = Z H_{n-3} ... H_0 (rows) -------------------------------------------------
     double* X = W.Za;
     const int nrefl = n - 2;
@@ -1447,6 +1575,7 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));        // Call goes out of scope
     }
+    const double t_s3 = now();
     // ---- outputs -------------------------------------------------------------------------------
     sella_mat vt = SELLA_NO_MAT, v = SELLA_NO_MAT;
     SCHK(mat_new(c, n, n, &vt));
@@ -1462,5 +1591,8 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     HIPCHK(hipStreamSynchronize(c->stream));
     if (hVt) *hVt = vt;
     else sella_mat_free(c, vt);
+    if (dbg_time)
+        fprintf(stderr, "eigh n=%d: tridiagonalise %.2f ms, divide&conquer %.2f ms, back-transform %.2f ms, outputs %.2f ms\n", n,
+                1e3 * (t_s1 - t_s0), 1e3 * (t_s2 - t_s1), 1e3 * (t_s3 - t_s2), 1e3 * (now() - t_s3));
     return SELLA_OK;
 }

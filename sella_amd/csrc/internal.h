@@ -203,6 +203,11 @@ int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, 
 // B + sum_a (U_a Z_a^T + Z_a U_a^T) from that of B; *nrank1 = rank-one modifications applied
 int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const double* Up, const double* Zp,
                        int ldp, int kk, int* nrank1);
+// batched NN GEMM for the merges of one divide-and-conquer level: batch b multiplies the diagonal blocks
+// at offset lo_b:  C[lo.., lo..] (K_b x N_b) = A[lo.., lo..] (K_b x K_b) * B[lo.., lo..] (K_b x N_b), all with
+// leading dimension ld.  desc (device): 4 ints per batch {lo, N, K, unused}.
+int launch_gemm_merge_batched(sella_ctx* c, int nbatch, const int* desc, int maxN, int maxK, const double* A,
+                              const double* B, double* C, int ld);
 // gather rows: out[r*ldo + j] = in[idx[r]*ldi + j] (idx device int array)
 int launch_gather_rows(sella_ctx* c, const double* in, int ldi, const int* idx, int nrows,
                        int ncols, double* out, int ldo);

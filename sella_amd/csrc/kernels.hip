@@ -555,15 +555,12 @@ __device__ __forceinline__ void gemm_load_tiles(const double* __restrict__ A, in
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(int transA, int transB, int M, int N, int K,
-                                                        double alpha, const double* __restrict__ A,
-                                                        int lda, const double* __restrict__ B,
-                                                        int ldb, double beta, double* __restrict__ C,
-                                                        int ldc) {
-    __shared__ double As[GM_BK][GM_LD];
-    __shared__ double Bs[GM_BK][GM_LD];
+__device__ __forceinline__ void gemm_mfma_tile(int transA, int transB, int M, int N, int K, double alpha,
+                                               const double* __restrict__ A, int lda,
+                                               const double* __restrict__ B, int ldb, double beta,
+                                               double* __restrict__ C, int ldc, int m0, int n0,
+                                               double (*As)[GM_LD], double (*Bs)[GM_LD]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int li = lane & 15, lk = lane >> 4;
     f64x4 acc[2][2];
@@ -603,6 +600,31 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(int transA, int transB, 
                     *cp = (beta == 0.0) ? v : (v + beta * (*cp));
                 }
             }
+}
+
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(int transA, int transB, int M, int N, int K,
+                                                        double alpha, const double* __restrict__ A,
+                                                        int lda, const double* __restrict__ B,
+                                                        int ldb, double beta, double* __restrict__ C,
+                                                        int ldc) {
+    __shared__ double As[GM_BK][GM_LD];
+    __shared__ double Bs[GM_BK][GM_LD];
+    gemm_mfma_tile(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, blockIdx.y * GM_BM,
+                   blockIdx.x * GM_BN, As, Bs);
+}
+
+// one launch for all merges of a divide-and-conquer level (blockIdx.z = merge)
+__global__ __launch_bounds__(256) void gemm_merge_batched_kernel(const int* __restrict__ desc,
+                                                                 const double* __restrict__ A,
+                                                                 const double* __restrict__ B,
+                                                                 double* __restrict__ C, int ld) {
+    __shared__ double As[GM_BK][GM_LD];
+    __shared__ double Bs[GM_BK][GM_LD];
+    const int lo = desc[4 * blockIdx.z], N = desc[4 * blockIdx.z + 1], K = desc[4 * blockIdx.z + 2];
+    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
+    if (m0 >= K || n0 >= N) return;                          // whole workgroup leaves together
+    const size_t off = (size_t)lo * ld + lo;
+    gemm_mfma_tile(0, 0, K, N, K, 1.0, A + off, ld, B + off, ld, 0.0, C + off, ld, m0, n0, As, Bs);
 }
 
 __global__ __launch_bounds__(256) void gemm_valu_kernel(int transA, int transB, int M, int N, int K,
@@ -661,6 +683,15 @@ int launch_gemm(sella_ctx* c, int transA, int transB, int M, int N, int K, doubl
         SELLA_LAUNCH(c, gemm_valu_kernel, grid, dim3(256), 0, transA, transB, M, N, K, alpha,
                      A, lda, B, ldb, beta, C, ldc);
     prof_end(c);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+int launch_gemm_merge_batched(sella_ctx* c, int nbatch, const int* desc, int maxN, int maxK, const double* A,
+                              const double* B, double* C, int ld) {
+    if (nbatch <= 0 || maxN <= 0 || maxK <= 0) return SELLA_OK;
+    dim3 grid((maxN + GM_BN - 1) / GM_BN, (maxK + GM_BM - 1) / GM_BM, nbatch);
+    hipLaunchKernelGGL(gemm_merge_batched_kernel, grid, dim3(256), 0, c->stream, desc, A, B, C, ld);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }

@@ -33,11 +33,7 @@ constexpr int TRD_NBMAX = 64;              // max panel width
 constexpr int TRD_PA = 1;                  // doubles per block in the K1 partial buffer (sum u^2)
 constexpr int WY_NB = 32;                  // reflectors per compact-WY block
 
-__device__ __forceinline__ double wave_sum_e(double v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum_e(double v) { return wave_sum64(v); }
 
 // block-wide sum for 256 threads; every thread gets the result
 __device__ __forceinline__ double block_sum_256(double v, double* red /* >= 4 doubles LDS */) {
@@ -143,6 +139,7 @@ __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
 struct TrdGemvArgs {
     const double* A22;          // A + o*ld + oc   (oc = o rounded down to even: aligned 16-byte rows)
     int ld, m, shift, o, n, j;
+    int pad;                    // dummy rows in front (see the launch: keeps row -> XCD fixed across columns)
     const double* ubuf;         // updated row j (absolute column index)
     const double* partA; int nblkA;
     double* wraw;               // absolute row index
@@ -164,7 +161,7 @@ struct TrdGemvArgs {
 __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
     __shared__ double red[4][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = blockIdx.x * 2;
+    const int row0 = blockIdx.x * 2 - a.pad;              // local row of this workgroup's first row (may be < 0)
     const int mtot = a.m + 2 * a.i;
     const int oc = a.o - a.shift;                     // even absolute column of local column 0
     const double2* arow[2];
@@ -172,6 +169,7 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         int rr = row0 + r;
+        if (rr < 0) rr = 0;
         if (rr > mtot - 1) rr = mtot - 1;
         const double* base;
         if (rr < a.m) base = a.A22 + (size_t)rr * a.ld;
@@ -189,7 +187,7 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int rr = row0 + r;
-        urow[r] = a.ubuf[(rr < a.m) ? a.o + rr : a.o];
+        urow[r] = a.ubuf[(rr >= 0 && rr < a.m) ? a.o + rr : a.o];
     }
     double acc[2] = {0.0, 0.0};
     const int n2 = (a.m + a.shift + 1) >> 1;
@@ -230,7 +228,9 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
         for (int r = 0; r < 2; ++r) {
             const int rr = row0 + r;
             const double res = scale * (red[0][r] + red[1][r] + red[2][r] + red[3][r]) + lead[r];
-            if (rr < a.m) {
+            if (rr < 0) {
+                // dummy row of the alignment pad
+            } else if (rr < a.m) {
                 const int rabs = a.o + rr;
                 const double vr = (rr == 0) ? 1.0 : scale * urow[r];
                 a.wraw[rabs] = res;
@@ -1126,7 +1126,7 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     double *Vp, *Wp, *part;
     SCHK(scratch_get(c, SCR_MISC0, (size_t)2 * TRD_NBMAX * ld * sizeof(double), &Vp));
     Wp = Vp + (size_t)TRD_NBMAX * ld;
-    const int maxblkA = (n + 255) / 256 + 1, maxblkB = (n + 2 * TRD_NBMAX + 1) / 2 + 1;
+    const int maxblkA = (n + 255) / 256 + 1, maxblkB = (n + 16 + 2 * TRD_NBMAX + 1) / 2 + 1;
     SCHK(scratch_get(c, SCR_MISC1, ((size_t)2 * maxblkA * TRD_PA + maxblkB + 2 * TRD_NBMAX + 64) * sizeof(double), &part));
     double* partA[2] = {part, part + (size_t)maxblkA * TRD_PA};
     double* partB = part + 2 * (size_t)maxblkA * TRD_PA;
@@ -1185,7 +1185,12 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
             ga.Arow = W.A + (size_t)j * ld;
             ga.taus = taus; ga.evec = evec; ga.colscal = colscal;
             ga.Wp = Wp; ga.Vp = Vp; ga.ldp = ld; ga.i = i; ga.cdots = cdots;
-            const int nblkB = (m + 2 * i + 1) / 2;
+            // Row pair P = (absolute row)/2 is always handled by workgroup P - P0 with P0 a multiple of 8, so a
+            // given row stays on the same XCD (workgroup id mod 8) from one column to the next and is served
+            // from that XCD's L2 once the trailing block fits (m <~ 1800); the <= 15 rows between 2 P0 and o
+            // are dummies.
+            ga.pad = o - (o / 16) * 16;
+            const int nblkB = (ga.pad + m + 2 * i + 1) / 2;
             prof_begin(c, PROF_TRD_GEMV, 8.0 * m * (double)m, 2.0 * m * (double)m);
             SELLA_LAUNCH(c, trd_gemv_kernel, dim3(nblkB), dim3(256), 0, ga);
             prof_end(c);

@@ -18,6 +18,29 @@
 
 namespace sella {
 
+// ---- wave64 sum, every lane gets the result -------------------------------------------------------
+// Four DPP steps (two quad permutes, half-row mirror, row mirror: VALU-rate cross-lane moves inside
+// rows of 16 lanes) and four v_readlane for the rows.  `__shfl_xor` on a double lowers to a pair of
+// ds_bpermute_b32 per step, six dependent LDS round trips — the reductions were a visible part of the
+// 4.5 us floor of the latency-bound kernels.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ double wave_dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_readlane(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum64(double v) {
+    v = wave_dpp_add<0xB1>(v);          // quad_perm [1,0,3,2]
+    v = wave_dpp_add<0x4E>(v);          // quad_perm [2,3,0,1]
+    v = wave_dpp_add<0x141>(v);         // row_half_mirror
+    v = wave_dpp_add<0x140>(v);         // row_mirror
+    return (wave_readlane(v, 0) + wave_readlane(v, 16)) + (wave_readlane(v, 32) + wave_readlane(v, 48));
+}
+
 void set_error(const char* fmt, ...);
 
 #define HIPCHK(expr)                                                                       \

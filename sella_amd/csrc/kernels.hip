@@ -12,11 +12,7 @@ namespace sella {
 // ------------------------------------------------------------------------------------
 // wave64 butterfly sum
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum64(v); }
 
 // ------------------------------------------------------------------------------------
 // K1: row-panel matvec.  A 256-thread workgroup owns RB consecutive rows; its four wavefronts

@@ -10,11 +10,7 @@
 namespace sella {
 namespace {
 
-__device__ __forceinline__ double wave_sum_q(double v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum_q(double v) { return wave_sum64(v); }
 
 // Householder vector of x (len): x <- [beta, v_1, ...]; vpad[0] = 0, vpad[1..len] = [1, v_1, ...]
 __global__ __launch_bounds__(256) void house_vec_kernel(double* __restrict__ x, int len,

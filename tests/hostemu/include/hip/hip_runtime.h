@@ -129,6 +129,33 @@ static inline T __shfl_up(T v, unsigned delta, int width = 64) {
     return out;
 }
 
+// DPP / readlane subset used by the wave reductions (quad_perm, row_mirror 0x140, row_half_mirror 0x141)
+static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool) {
+    (void)old;
+    const int l = hipemu::lane_id(), base = l & ~15, idx = l & 15;
+    int from;
+    if (ctrl < 0x100) from = base + (idx & ~3) + ((ctrl >> (2 * (idx & 3))) & 3);
+    else if (ctrl == 0x140) from = base + (15 - idx);
+    else if (ctrl == 0x141) from = base + (idx & 8) + (7 - (idx & 7));
+    else { fprintf(stderr, "hipemu: unsupported DPP control 0x%x\n", ctrl); abort(); }
+    int out;
+    hipemu::wave_exchange(&src, &out, sizeof(int), from);
+    return out;
+}
+#define __builtin_amdgcn_update_dpp hipemu_update_dpp
+static inline int hipemu_readlane(int v, int lane) {
+    int out;
+    hipemu::wave_exchange(&v, &out, sizeof(int), lane);
+    return out;
+}
+#define __builtin_amdgcn_readlane hipemu_readlane
+static inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
+static inline int __double2hiint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b >> 32); }
+static inline double __hiloint2double(int hi, int lo) {
+    long long b = ((long long)hi << 32) | (unsigned)lo;
+    double d; memcpy(&d, &b, 8); return d;
+}
+
 static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }

@@ -275,6 +275,8 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "eigh_leaf")) {
         if (value < 2 || value > 64) { set_error("eigh_leaf must be in [2, 64]"); return SELLA_E_INVALID; }
         c->opt.eigh_leaf = value;
+    } else if (!strcmp(key, "gemm_tile128")) {
+        c->opt.gemm_tile128 = value ? 1 : 0;
     } else if (!strcmp(key, "panel_mfma")) {
         c->opt.panel_mfma = value ? 1 : 0;
     } else if (!strcmp(key, "panel_rows")) {

@@ -87,6 +87,7 @@ struct ProfSlot {
 struct Options {
     long gemv_rw = 2;        // rows per wavefront in the row-panel matvec (1, 2 or 4)
     long gemm_mfma = 1;      // 1: MFMA f64 16x16x4 GEMM tiles, 0: VALU register tiles
+    long gemm_tile128 = 1;   // 1: 128x128 double-buffered tiles for large NN/TN products
     long dav_reorth = 0;     // 1: re-orthonormalise V before each MGS like math.pyx:148-151
     long eigh_leaf = 32;     // leaf size of the divide-and-conquer tree
     long eigh_nb = 16;       // panel width of the blocked tridiagonalisation (tools/eigh_tune.py)

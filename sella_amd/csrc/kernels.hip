@@ -623,6 +623,112 @@ __global__ __launch_bounds__(256) void gemm_merge_batched_kernel(const int* __re
     gemm_mfma_tile(0, 0, K, N, K, 1.0, A + off, ld, B + off, ld, 0.0, C + off, ld, m0, n0, As, Bs);
 }
 
+// ---- 128 x 128 x 16 tiles, double-buffered -----------------------------------------------------------
+// For the large NN / TN products (divide-and-conquer merges, eigen-update merges, U^T H U): a workgroup
+// owns a 128 x 128 tile of C, each wavefront a 64 x 64 quadrant = 4 x 4 MFMA tiles (64 MFMAs between two
+// barriers instead of 16), and the global loads of k-step t+1 are issued into registers before the MFMAs
+// of step t and stored to the other LDS buffer afterwards, so one workgroup hides its own load latency.
+constexpr int G2_BM = 128, G2_BN = 128, G2_BK = 16, G2_LD = 129;
+
+__device__ __forceinline__ void gemm128_tile(int transA, int M, int N, int K, double alpha,
+                                             const double* __restrict__ A, int lda,
+                                             const double* __restrict__ B, int ldb, double beta,
+                                             double* __restrict__ C, int ldc, int m0, int n0,
+                                             double (*As)[G2_BK][G2_LD], double (*Bs)[G2_BK][G2_LD]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int li = lane & 15, lk = lane >> 4;
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    double ra[8], rb[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int e = tid + 256 * p;
+            int m, k;
+            if (transA) { m = e & 127; k = e >> 7; }          // A is K x M: contiguous along m
+            else { k = e & 15; m = e >> 4; }                  // A is M x K: contiguous along k
+            const int gm = m0 + m, gk = k0 + k;
+            ra[p] = (gm < M && gk < K) ? (transA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk]) : 0.0;
+            const int nn = e & 127, kb = e >> 7;              // B is K x N: contiguous along n
+            const int gn = n0 + nn, gkb = k0 + kb;
+            rb[p] = (gn < N && gkb < K) ? B[(size_t)gkb * ldb + gn] : 0.0;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int e = tid + 256 * p;
+            if (transA) As[buf][e >> 7][e & 127] = ra[p];
+            else As[buf][e & 15][e >> 4] = ra[p];
+            Bs[buf][e >> 7][e & 127] = rb[p];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += G2_BK) {
+        const bool more = k0 + G2_BK < K;
+        if (more) fetch(k0 + G2_BK);
+#pragma unroll
+        for (int kk = 0; kk < G2_BK; kk += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) af[a] = As[buf][kk + lk][wm + a * 16 + li];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bf[b] = Bs[buf][kk + lk][wn + b * 16 + li];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm + a * 16 + lk + 4 * r;
+                const int gn = n0 + wn + b * 16 + li;
+                if (gm < M && gn < N) {
+                    double* cp = C + (size_t)gm * ldc + gn;
+                    const double v = alpha * acc[a][b][r];
+                    *cp = (beta == 0.0) ? v : (v + beta * (*cp));
+                }
+            }
+}
+
+__global__ __launch_bounds__(256) void gemm128_kernel(int transA, int M, int N, int K, double alpha,
+                                                      const double* __restrict__ A, int lda,
+                                                      const double* __restrict__ B, int ldb, double beta,
+                                                      double* __restrict__ C, int ldc) {
+    __shared__ double As[2][G2_BK][G2_LD];
+    __shared__ double Bs[2][G2_BK][G2_LD];
+    gemm128_tile(transA, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, blockIdx.y * G2_BM, blockIdx.x * G2_BN, As, Bs);
+}
+
+__global__ __launch_bounds__(256) void gemm128_merge_batched_kernel(const int* __restrict__ desc,
+                                                                    const double* __restrict__ A,
+                                                                    const double* __restrict__ B,
+                                                                    double* __restrict__ C, int ld) {
+    __shared__ double As[2][G2_BK][G2_LD];
+    __shared__ double Bs[2][G2_BK][G2_LD];
+    const int lo = desc[4 * blockIdx.z], N = desc[4 * blockIdx.z + 1], K = desc[4 * blockIdx.z + 2];
+    const int m0 = blockIdx.y * G2_BM, n0 = blockIdx.x * G2_BN;
+    if (m0 >= K || n0 >= N) return;
+    const size_t off = (size_t)lo * ld + lo;
+    gemm128_tile(0, K, N, K, 1.0, A + off, ld, B + off, ld, 0.0, C + off, ld, m0, n0, As, Bs);
+}
+
 __global__ __launch_bounds__(256) void gemm_valu_kernel(int transA, int transB, int M, int N, int K,
                                                         double alpha, const double* __restrict__ A,
                                                         int lda, const double* __restrict__ B,
@@ -672,7 +778,10 @@ int launch_gemm(sella_ctx* c, int transA, int transB, int M, int N, int K, doubl
     if (M <= 0 || N <= 0) return SELLA_OK;
     dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM);
     prof_begin(c, PROF_GEMM, 8.0 * ((double)M * K + (double)K * N + 2.0 * M * N), 2.0 * M * (double)N * K);
-    if (c->opt.gemm_mfma)
+    if (c->opt.gemm_mfma && !transB && M >= 192 && N >= 192 && c->opt.gemm_tile128) {
+        dim3 g2((N + G2_BN - 1) / G2_BN, (M + G2_BM - 1) / G2_BM);
+        SELLA_LAUNCH(c, gemm128_kernel, g2, dim3(256), 0, transA, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
+    } else if (c->opt.gemm_mfma)
         SELLA_LAUNCH(c, gemm_mfma_kernel, grid, dim3(256), 0, transA, transB, M, N, K, alpha,
                      A, lda, B, ldb, beta, C, ldc);
     else
@@ -686,8 +795,13 @@ int launch_gemm(sella_ctx* c, int transA, int transB, int M, int N, int K, doubl
 int launch_gemm_merge_batched(sella_ctx* c, int nbatch, const int* desc, int maxN, int maxK, const double* A,
                               const double* B, double* C, int ld) {
     if (nbatch <= 0 || maxN <= 0 || maxK <= 0) return SELLA_OK;
-    dim3 grid((maxN + GM_BN - 1) / GM_BN, (maxK + GM_BM - 1) / GM_BM, nbatch);
-    hipLaunchKernelGGL(gemm_merge_batched_kernel, grid, dim3(256), 0, c->stream, desc, A, B, C, ld);
+    if (maxK >= 192 && c->opt.gemm_tile128) {
+        dim3 g2((maxN + G2_BN - 1) / G2_BN, (maxK + G2_BM - 1) / G2_BM, nbatch);
+        hipLaunchKernelGGL(gemm128_merge_batched_kernel, g2, dim3(256), 0, c->stream, desc, A, B, C, ld);
+    } else {
+        dim3 grid((maxN + GM_BN - 1) / GM_BN, (maxK + GM_BM - 1) / GM_BM, nbatch);
+        hipLaunchKernelGGL(gemm_merge_batched_kernel, grid, dim3(256), 0, c->stream, desc, A, B, C, ld);
+    }
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }

@@ -42,7 +42,7 @@ def test_rectangular_and_transposed_products(ctx):
 def test_gemm(ctx, mfma):
     rng = np.random.RandomState(2)
     ctx.set_option('gemm_mfma', mfma)
-    shapes = [(64, 64, 16), (70, 45, 33), (130, 64, 100), (5, 3, 2)]
+    shapes = [(64, 64, 16), (70, 45, 33), (130, 64, 100), (5, 3, 2), (200, 193, 37)]   # last: 128x128 tiles
     if ctx.backend == 'hip':
         shapes += [(512, 384, 256), (1000, 1000, 64), (33, 2000, 1500)]
     for M, N, K in shapes:

@@ -58,6 +58,7 @@ def main():
     ap.add_argument('--maxiter', type=int, default=40)
     ap.add_argument('--gamma', type=float, default=0.1)
     ap.add_argument('--seeds', type=int, default=4)
+    ap.add_argument('--converged-n', type=int, default=768)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--opt-steps', type=int, default=20)
@@ -152,9 +153,27 @@ def main():
     ctx.sync()
     t_eigh = (time.perf_counter() - t2) / 3
 
-    # parity evidence carried on the line: lowest Ritz pair vs LAPACK on the host
+    # parity evidence carried on the line: lowest Ritz pair of the benchmark call against the host, and
+    # the north_star criterion proper — the CONVERGED lowest eigenvalue (gamma = 1e-7, run to convergence)
+    # against the exact one, which is -1 by construction of the synthetic Hessian
     resid = float(np.linalg.norm(A @ Vr[:, 0] - lams[0] * Vr[:, 0]))
     av_err = float(np.abs(AVr - A @ Vr).max())
+    conv = None
+    if rank == 0 and world == 1 and args.converged_n > 0:
+        # (done at 3N = 768, the ensemble-member size: the Rayleigh-Ritz algebra on the host is O(k^3) per
+        # iteration in scalar C++, so the ~500-vector run at 3N = 3072 takes 90 s; it is a -m gpu test,
+        # tests/test_big_gpu.py::test_davidson_converged_eigenpair, 3e-15 there)
+        nc = args.converged_n
+        Ac, Pc, gc = hessian_like(nc, seed=0)
+        dAc, dPc = ctx.upload(Ac), ctx.upload(Pc)
+        wc_, Vc0, Vtc0 = ctx.eigh(dPc)
+        tcv = time.perf_counter()
+        lc_, Vc_, _, _ = ctx.davidson(dAc, nc, gc, 1e-7, method='jd0', maxiter=900, Pvecs=Vc0, PvecsT=Vtc0, pevals=wc_)
+        conv = dict(n=nc, gamma=1e-7, vectors=int(Vc_.shape[1]), seconds=round(time.perf_counter() - tcv, 3),
+                    lowest_eigenvalue_abs_err=float(abs(lc_[0] + 1.0)),
+                    residual_norm=float(np.linalg.norm(Ac @ Vc_[:, 0] - lc_[0] * Vc_[:, 0])))
+        for m_ in (dAc, dPc, Vc0, Vtc0):
+            m_.free()
 
     # ---- roofline: instrumented pass over whole steps (hipEvents on the library stream) ------------
     # By time the dominant kernel of a step is the trailing-matrix matvec of the tridiagonalisation
@@ -303,7 +322,9 @@ def main():
                           f'n={n}, k={Vc.shape[1]} vectors, {tcpu:.1f} s',
                    k=int(Vc.shape[1]),
                    lam0_rel_diff_after_4_iterations=float(abs(l4c[0] - l4h[0]) / abs(l4c[0])),
-                   lam0_abs_diff_at_exit=float(abs(lc[0] - lams[0])))
+                   lam0_abs_diff_at_exit=float(abs(lc[0] - lams[0])),
+                   note='the exit point of the gamma = 0.1 run is chaotic in the reference itself (DESIGN.md section 4): '
+                        'compare after 4 iterations, and the converged run in parity.converged_run')
 
     if rank == 0:
         value = total_iters / tmax
@@ -321,7 +342,8 @@ def main():
             'davidson_loop_only_iter_per_s': round(it2 / t_loop, 1),
             'eigh_ms': round(1e3 * t_eigh, 2),
             'optimizer': opt_stats,
-            'parity': {'lowest_ritz_value': float(lams[0]), 'ritz_residual_norm': resid, 'max_abs_AV_minus_A_V': av_err},
+            'parity': {'lowest_ritz_value': float(lams[0]), 'ritz_residual_norm': resid, 'max_abs_AV_minus_A_V': av_err,
+                       'converged_run': conv},
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)

@@ -142,6 +142,14 @@ int read_scalars(sella_ctx* c, int offset, int count) {
     return SELLA_OK;
 }
 
+double* scal_out(sella_ctx* c, int offset) { return (c->opt.host_scalars ? c->hscal : c->dscal) + offset; }
+
+int sync_scalars(sella_ctx* c, int offset, int count) {
+    if (!c->opt.host_scalars) return read_scalars(c, offset, count);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SELLA_OK;
+}
+
 void prof_begin(sella_ctx* c, int kind, double bytes, double flops) {
     if (!c->prof) return;
     ProfPending p;
@@ -275,6 +283,8 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "eigh_leaf")) {
         if (value < 2 || value > 64) { set_error("eigh_leaf must be in [2, 64]"); return SELLA_E_INVALID; }
         c->opt.eigh_leaf = value;
+    } else if (!strcmp(key, "host_scalars")) {
+        c->opt.host_scalars = value ? 1 : 0;
     } else if (!strcmp(key, "gemm_tile128")) {
         c->opt.gemm_tile128 = value ? 1 : 0;
     } else if (!strcmp(key, "panel_mfma")) {

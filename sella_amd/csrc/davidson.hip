@@ -178,12 +178,12 @@ int append_vector(Dav& s) {
     double* t = s.Vp + (size_t)k * s.ld;
     double* At = s.AVp + (size_t)k * s.ld;
     SCHK(apply_A(s, t, At));
-    double* ds = c->dscal + DS_GRAM;
+    double* ds = scal_out(c, DS_GRAM);
     // rows [0,k]: V_a.t (a = k gives t.t) ; [cap, cap+k]: V_a.At (a = k gives t.At) ; [2cap, 2cap+k): AV_a.t
     const double* xs[2] = {t, At};
     SCHK(launch_gemv_rows_xp(c, s.Vp, k + 1, s.n, s.ld, xs, 2, ds, cap, GemvEpi()));
     if (k > 0) SCHK(launch_gemv_rows_xp(c, s.AVp, k, s.n, s.ld, xs, 1, ds + 2 * (size_t)cap, cap, GemvEpi()));
-    SCHK(read_scalars(c, DS_GRAM, 3 * cap));
+    SCHK(sync_scalars(c, DS_GRAM, 3 * cap));
     const double* h = c->hscal + DS_GRAM;
     for (int a = 0; a < k; ++a) {
         s.Gvv[(size_t)a * cap + k] = s.Gvv[(size_t)k * cap + a] = h[a];
@@ -364,17 +364,17 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
             DCHK(put_small(s, coef.data(), 2 * nneg * nneg, 1, (size_t)s.cap * s.cap + 8, &dC));
             DCHK(launch_lincomb(c, n, nneg, s.Vp, s.ld, nneg, dC, nneg, s.AVp, s.ld, nneg, dC + (size_t)nneg * nneg, nneg,
                                 0.0, s.Rp, s.ld));
-            DCHK(launch_rows_sumsq(c, s.Rp, s.ld, nneg, n, c->dscal));
+            DCHK(launch_rows_sumsq(c, s.Rp, s.ld, nneg, n, scal_out(c, 0)));
             int nread = nneg;
             if (vref) {
                 double* dv = s.wk + 39 * (size_t)s.ld;
                 if (hipMemcpyAsync(dv, vref, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess)
                     return fail(SELLA_E_HIP);
-                DCHK(launch_gemv_rows(c, s.Vp, 1, n, s.ld, dv, s.ld, 1, c->dscal + nneg, 1, GemvEpi()));
+                DCHK(launch_gemv_rows(c, s.Vp, 1, n, s.ld, dv, s.ld, 1, scal_out(c, nneg), 1, GemvEpi()));
                 nread += 1;
             }
             if (nread > 4000) { set_error("davidson: too many negative Ritz values (%d)", nneg); return fail(SELLA_E_UNSUPPORTED); }
-            DCHK(read_scalars(c, 0, nread));
+            DCHK(sync_scalars(c, 0, nread));
         }
         if (vref && fabs(c->hscal[nneg]) > vreftol) break;                // :74-77
         seeking = -1;

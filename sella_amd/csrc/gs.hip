@@ -21,7 +21,7 @@ static int gs_sweep(sella_ctx* c, const double* basis, int ldb, int k, double* t
         SCHK(launch_gemv_rows(c, basis, k, n, ldb, t, ldb, 1, cvec, k, neg));
         SCHK(launch_lincomb(c, n, 1, basis, ldb, k, cvec, 1, nullptr, 0, 0, nullptr, 0, 1.0, t, ldb));
     }
-    return launch_normalize(c, t, n, c->dscal + slot);
+    return launch_normalize(c, t, n, scal_out(c, slot));
 }
 
 // Orthonormalise the n-vector t against the k orthonormal rows of `basis`.
@@ -35,10 +35,10 @@ int gs_orthonormalise(sella_ctx* c, const double* basis, int ldb, int k, double*
         set_error("gram-schmidt: basis of %d vectors exceeds the coefficient buffer", k);
         return SELLA_E_UNSUPPORTED;
     }
-    SCHK(launch_normalize(c, t, n, c->dscal + 8));
+    SCHK(launch_normalize(c, t, n, scal_out(c, 8)));
     SCHK(gs_sweep(c, basis, ldb, k, t, n, 9));
     SCHK(gs_sweep(c, basis, ldb, k, t, n, 10));
-    SCHK(read_scalars(c, 8, 3));
+    SCHK(sync_scalars(c, 8, 3));
     const double n0sq = c->hscal[8];
     double n1 = sqrt(c->hscal[9]), n2 = sqrt(c->hscal[10]);
     if (first_norm) *first_norm = n1;
@@ -48,7 +48,7 @@ int gs_orthonormalise(sella_ctx* c, const double* basis, int ldb, int k, double*
         if (n2 != n2 || n2 < eps2) return SELLA_OK;
         if (fabs(1.0 - n2) <= eps1) { *kept = 1; return SELLA_OK; }
         SCHK(gs_sweep(c, basis, ldb, k, t, n, 10));
-        SCHK(read_scalars(c, 10, 1));
+        SCHK(sync_scalars(c, 10, 1));
         n2 = sqrt(c->hscal[10]);
     }
     set_error("MGS failed.");

@@ -87,6 +87,7 @@ struct ProfSlot {
 struct Options {
     long gemv_rw = 2;        // rows per wavefront in the row-panel matvec (1, 2 or 4)
     long gemm_mfma = 1;      // 1: MFMA f64 16x16x4 GEMM tiles, 0: VALU register tiles
+    long host_scalars = 0;   // 1: host-consumed scalars are written straight into pinned host memory (measured: no gain)
     long gemm_tile128 = 1;   // 1: 128x128 double-buffered tiles for large NN/TN products
     long dav_reorth = 0;     // 1: re-orthonormalise V before each MGS like math.pyx:148-151
     long eigh_leaf = 32;     // leaf size of the divide-and-conquer tree
@@ -139,6 +140,11 @@ void dev_free(sella_ctx* c, double* p, size_t bytes);
 int upload_panel(sella_ctx* c, const double* X, int n, int k, double* dpanel, int ldp);   // (n x k) host -> k rows
 int download_panel(sella_ctx* c, const double* dpanel, int ldp, int n, int k, double* X); // k rows -> (n x k) host
 int read_scalars(sella_ctx* c, int offset, int count);             // dscal -> hscal (sync)
+// Where a kernel should put scalars that only the HOST consumes next: with `host_scalars` on, the pinned,
+// device-visible host mirror itself (zero-copy: the readback is then just the stream synchronisation and the
+// 4 us copy launch disappears from the critical path); otherwise the device buffer.
+double* scal_out(sella_ctx* c, int offset);
+int sync_scalars(sella_ctx* c, int offset, int count);             // makes hscal[offset, offset+count) valid
 // layout of the scalar exchange buffer (doubles)
 enum { DS_MISC = 0, DS_CVEC = 16384, DS_STAGE = 32768, DS_GRAM = 65536, DS_TOTAL = 131072 };
 // Profiling (bench.py roofline leg): prof_begin creates an event pair, the launch between begin and

@@ -343,22 +343,22 @@ int launch_lincomb(sella_ctx* c, int n, int nout, const double* P1, int ldp1, in
 // ------------------------------------------------------------------------------------
 // small vector kernels
 // ------------------------------------------------------------------------------------
+// one workgroup per row: 256 lanes take 16-byte pieces, four loads in flight each
 __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restrict__ P, int ldp,
                                                          int nrows, int n, double* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= nrows) return;   // whole wavefront leaves together
-    const double* p = P + (size_t)r * ldp;
+    __shared__ double red[4];
+    const double* p = P + (size_t)blockIdx.x * ldp;
     double s = 0.0;
-    for (int i = lane; i < n; i += 64) s += p[i] * p[i];
+    for (int i = threadIdx.x; i < n; i += 256) s += p[i] * p[i];
     s = wave_sum(s);
-    if (lane == 0) out[r] = s;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 int launch_rows_sumsq(sella_ctx* c, const double* P, int ldp, int nrows, int n, double* out) {
     if (nrows <= 0) return SELLA_OK;
-    hipLaunchKernelGGL(rows_sumsq_kernel, dim3((nrows + 3) / 4), dim3(256), 0, c->stream, P, ldp, nrows,
-                       n, out);
+    hipLaunchKernelGGL(rows_sumsq_kernel, dim3(nrows), dim3(256), 0, c->stream, P, ldp, nrows, n, out);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }

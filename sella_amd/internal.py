@@ -475,3 +475,132 @@ def angles_from_bonds(bonds, ncvecs):
     if not ang:
         return np.zeros((0, 3), dtype=np.int64), np.zeros((0, 2, 3))
     return np.concatenate(ang), np.concatenate(ncv)
+
+
+# ------------------------------------------------------------------------------------------
+# what InternalPES needs on top of the numerical core: counts, constraints, guess Hessian, topology
+# ------------------------------------------------------------------------------------------
+_HARTREE, _BOHR = 27.211386245988, 0.529177210903        # eV, Angstrom
+# covalent radii (Cordero et al. 2008, the table ase.data.covalent_radii carries), Angstrom
+_RCOV = dict(H=0.31, He=0.28, Li=1.28, Be=0.96, B=0.84, C=0.76, N=0.71, O=0.66, F=0.57, Ne=0.58, Na=1.66, Mg=1.41,
+             Al=1.21, Si=1.11, P=1.07, S=1.05, Cl=1.02, Ar=1.06, K=2.03, Ca=1.76, Ti=1.60, Fe=1.32, Co=1.26, Ni=1.24,
+             Cu=1.32, Zn=1.22, Br=1.20, Pd=1.39, Ag=1.45, Pt=1.36, Au=1.36)
+
+
+def covalent_radius(symbol, default=1.0):
+    return _RCOV.get(symbol, default)
+
+
+def _ic_counts(self):
+    return dict(ntrans=0, nbonds=len(self.idx['bonds']), nangles=len(self.idx['angles']),
+                ndihedrals=len(self.idx['dihedrals']), nother=0, nrotations=0)
+
+
+for _name in ('ntrans', 'nbonds', 'nangles', 'ndihedrals', 'nother', 'nrotations'):
+    setattr(InternalCoordinates, _name, property(lambda self, _n=_name: _ic_counts(self)[_n]))
+
+
+def _ic_copy(self):
+    new = InternalCoordinates(self.atoms, self.idx['bonds'], self.idx['angles'], self.idx['dihedrals'],
+                              self.ncv['bonds'], self.ncv['angles'], self.ncv['dihedrals'])
+    new.cons = self.cons.copy() if getattr(self, 'cons', None) is not None else None
+    return new
+
+
+def _ic_radii(self):
+    return np.array([covalent_radius(s) for s in self.atoms.symbols])
+
+
+def _ic_guess_hessian(self):
+    """Diagonal model Hessian in the internal coordinates (internal.py:3738-3820: the Schlegel-type
+    exponential formulas of `_h0_bond`, `_h0_angle`, `_h0_dihedral`)."""
+    rc = _ic_radii(self)
+    q = self.calc()
+    nb, na, nd = self.nbonds, self.nangles, self.ndihedrals
+    h0 = np.zeros(self.nint)
+    b = self.idx['bonds']
+    rcov = rc[b].sum(axis=1) if nb else np.zeros(0)
+    h0[:nb] = 0.3601 * np.exp(-1.944 * (q[:nb] - rcov) / _BOHR) * _HARTREE / _BOHR ** 2
+    nbonds_of = np.bincount(b.ravel(), minlength=len(self.atoms)) if nb else np.zeros(len(self.atoms), dtype=int)
+    if na:
+        a = self.idx['angles']
+        pa, ta, _ = self._batch('angles')
+        rab = np.linalg.norm(pa[:, 1] - pa[:, 0] + ta[:, 0], axis=1)
+        rbc = np.linalg.norm(pa[:, 2] - pa[:, 1] + ta[:, 1], axis=1)
+        cab, cbc = rc[a[:, 0]] + rc[a[:, 1]], rc[a[:, 1]] + rc[a[:, 2]]
+        h0[nb:nb + na] = (0.089 + 0.11 * np.exp(-0.44 * (rab + rbc - cab - cbc) / _BOHR)
+                          / (cab * cbc / _BOHR ** 2) ** (-0.42)) * _HARTREE
+    if nd:
+        d = self.idx['dihedrals']
+        pd, td, _ = self._batch('dihedrals')
+        rbc = np.linalg.norm(pd[:, 2] - pd[:, 1] + td[:, 1], axis=1)
+        cbc = rc[d[:, 1]] + rc[d[:, 2]]
+        L = nbonds_of[d[:, 1]] + nbonds_of[d[:, 2]] - 2
+        h0[nb + na:] = (0.0015 + 14.0 * np.maximum(L, 0) ** 0.57 * np.exp(-2.85 * (rbc - cbc) / _BOHR)
+                        / (rbc * cbc / _BOHR ** 2) ** 4.00) * _HARTREE
+    return np.diag(np.abs(h0))
+
+
+def _ic_check_bad(self, tol=np.pi / 36):
+    """Angles that have become (nearly) linear make dihedrals ill defined (internal.py:3700-3736); the
+    reference then inserts dummy atoms — not part of this build, so the caller raises."""
+    if not self.nangles:
+        return None
+    pos, tvec, _ = self._batch('angles')
+    ang = evaluate_kind('angles', pos, tvec, hessian=False)[0]
+    bad = np.flatnonzero(ang > np.pi - tol)
+    return bad if len(bad) else None
+
+
+def _ic_from_atoms(cls, atoms, cons=None, scale=1.25, dihedrals=True):
+    """Bonds closer than scale * (r_cov,i + r_cov,j) (internal.py:3260-3400), every angle between two bonds
+    at an atom, every proper dihedral a-b-c-d along three consecutive bonds whose two angles are not
+    (nearly) linear."""
+    rc = np.array([covalent_radius(s) for s in atoms.symbols])
+    bonds, bncv = neighbour_bonds(atoms, scale * 2.0 * rc.max())
+    if len(bonds):
+        pos = atoms.positions
+        cell = np.asarray(atoms.cell, dtype=np.float64)
+        d = np.linalg.norm(pos[bonds[:, 1]] - pos[bonds[:, 0]] + bncv[:, 0] @ cell, axis=1)
+        keep = d < scale * (rc[bonds[:, 0]] + rc[bonds[:, 1]])
+        bonds, bncv = bonds[keep], bncv[keep]
+    angles, ancv = angles_from_bonds(bonds, bncv)
+    dih, dncv = np.zeros((0, 4), dtype=np.int64), np.zeros((0, 3, 3))
+    if dihedrals and len(angles):
+        ic0 = cls(atoms, angles=angles, angle_ncvecs=ancv)
+        aval = ic0.calc()
+        ok = aval < np.pi - np.pi / 18
+        A, Av = angles[ok], ancv[ok]
+        dl, dv, seen = [], [], set()
+        # join angles (a, b, c) and (b, c, d): shared bond b-c with consistent image offsets
+        by_bond = {}
+        for k, (a, b, c) in enumerate(A):
+            by_bond.setdefault((b, c, tuple(Av[k, 1])), []).append((a, Av[k, 0]))            # ... a-b-c, bond b->c
+            by_bond.setdefault((b, a, tuple(-Av[k, 0])), []).append((c, -Av[k, 1]))          # reversed: c-b-a, bond b->a
+        for (b, c, off), lefts in by_bond.items():
+            rights = by_bond.get((c, b, tuple(-np.array(off))), [])
+            for a, oa in lefts:
+                for dd, od in rights:
+                    if a == dd or a == c or dd == b:
+                        continue
+                    key = (a, b, c, dd) if (a, b) < (dd, c) else (dd, c, b, a)
+                    if key in seen:
+                        continue
+                    seen.add(key)
+                    # offsets along the chain a -> b -> c -> d: a->b is the reverse of "b sees a at oa"... stored as
+                    # tvec_k = image shift of atom k+1 relative to atom k
+                    dl.append([a, b, c, dd])
+                    dv.append([oa, np.array(off), -od])
+        if dl:
+            dih, dncv = np.array(dl, dtype=np.int64), np.array(dv, dtype=np.float64)
+    ic = cls(atoms, bonds=bonds, angles=angles, dihedrals=dih, bond_ncvecs=bncv, angle_ncvecs=ancv,
+             dihedral_ncvecs=dncv)
+    ic.cons = cons if cons is not None else Constraints(atoms)
+    return ic
+
+
+InternalCoordinates.copy = _ic_copy
+InternalCoordinates.guess_hessian = _ic_guess_hessian
+InternalCoordinates.check_for_bad_internals = _ic_check_bad
+InternalCoordinates.from_atoms = classmethod(_ic_from_atoms)
+InternalCoordinates.cons = None

@@ -3,8 +3,9 @@ path: same constructor keywords and defaults table (:20-39), `run(fmax, steps)` 
 ASE `Optimizer` (or the built-in equivalent when ASE is absent), the diagonalisation schedule and
 trust-radius rules of `step()` (:359-434).
 
-Options that select code outside the saddle-point scope raise NotImplementedError:
-`internal=True` (InternalPES), `optimize_cell=True` (Cell*PES).
+`internal=True` (or an `InternalCoordinates` object) selects `InternalPES` (geodesic steps in redundant
+internal coordinates).  Options outside the saddle-point scope raise NotImplementedError:
+`optimize_cell=True` (Cell*PES).
 """
 import warnings
 from time import localtime, strftime
@@ -31,8 +32,6 @@ class Sella(Optimizer):
                  constraints=None, constraints_tol=1e-5, v0=None, internal=False,
                  append_trajectory=False, rs=None, nsteps_per_diag=3, diag_every_n=None,
                  hessian_function=None, optimize_cell=False, **kwargs):
-        if internal:
-            raise NotImplementedError('internal=True (InternalPES) is not part of this build yet')
         if optimize_cell:
             raise NotImplementedError('optimize_cell requires order=0 and is outside the saddle-point scope')
         default = _default_kwargs['minimum' if order == 0 else 'saddle']
@@ -42,7 +41,7 @@ class Sella(Optimizer):
         self.initialize_pes(atoms, trajectory, order, eta, constraints, v0, internal,
                             hessian_function, **kwargs)
         if rs is None:
-            rs = 'ras'
+            rs = 'mis' if internal else 'ras'                                    # :178-179
         self.rs = get_restricted_step(rs)
         Optimizer.__init__(self, atoms, restart=restart, logfile=logfile, trajectory=None,
                            master=master)
@@ -78,6 +77,24 @@ class Sella(Optimizer):
 
     def initialize_pes(self, atoms, trajectory=None, order=1, eta=1e-4, constraints=None, v0=None,
                        internal=False, hessian_function=None, **kwargs):
+        if internal:                                                              # :237-285
+            from ..internal import InternalCoordinates
+            from ..peswrapper import InternalPES
+            if isinstance(internal, InternalCoordinates):
+                if constraints is not None:
+                    raise ValueError("Internals object and Constraint object cannot both be provided to Sella. "
+                                     "Instead, you must pass the Constraints object to the constructor of the "
+                                     "Internals object.")
+                auto = False
+            else:
+                internal = InternalCoordinates.from_atoms(atoms, cons=constraints)
+                auto = True
+            self.internal = internal.copy()
+            self.constraints = None
+            self.pes = InternalPES(atoms, internals=internal, trajectory=trajectory, eta=eta, v0=v0,
+                                   auto_find_internals=auto, hessian_function=hessian_function, **kwargs)
+            self.trajectory = self.pes.traj
+            return
         self.internal = None
         if constraints is None:
             constraints = Constraints(atoms)

@@ -372,3 +372,267 @@ class PES:
     def calculate_hessian(self):
         assert self.hessian_function is not None
         self.H.set_B(self.hessian_function(self.atoms))
+
+
+# ------------------------------------------------------------------------------------------------
+# InternalPES — optimisation in redundant internal coordinates with geodesic steps
+# (sella/peswrapper.py:609-1288; Hermes et al., J. Chem. Phys. 155, 094105 (2021)).
+#
+# Scope of this build: bonds / angles / dihedrals given as an `InternalCoordinates` object (or found
+# automatically from covalent radii), Cartesian constraints expressed through the usual `Constraints`
+# object.  Not built: dummy atoms and the re-generation of internals when an angle becomes linear
+# (`update_internals`, :1126-1172 — a RuntimeError is raised instead), the Newton "iterative stepper"
+# shortcut (:742-838; the ODE path it falls back to is the one implemented), cell degrees of freedom.
+# The heavy pieces run on the device: B-matrix rows and D(v) = H_i v (csrc/internals.hip), the economy
+# QR of B (`sella_qr_thin`, the reference's `_gpu_qr`, :691), the Hessian algebra as for `PES`.
+# Parity: the reference class needs ASE + JAX and cannot be imported in the build container, so this
+# restatement is property-tested only (tests/test_internal_pes.py) — unpinned.
+# ------------------------------------------------------------------------------------------------
+from scipy.integrate import LSODA  # noqa: E402
+from scipy.linalg import solve_triangular  # noqa: E402
+
+from .internal import InternalCoordinates  # noqa: E402
+
+
+def _range_space_projector(B):
+    """Orthogonal projector onto range(B) with rank truncation via pivoted QR (peswrapper.py:72-82)."""
+    Q, R, _ = qr(B, mode='full', pivoting=True, check_finite=False)
+    rdiag = np.abs(np.diag(R))
+    rcond = max(B.shape) * np.finfo(B.dtype).eps
+    nkeep = int(np.sum(rdiag > rcond * rdiag[0])) if rdiag.size and rdiag[0] > 0 else 0
+    Qr = Q[:, :nkeep]
+    return Qr @ Qr.T
+
+
+class InternalPES(PES):
+    def __init__(self, atoms, internals, *args, H0=None, iterative_stepper=0, auto_find_internals=True,
+                 exact_geodesic=False, **kwargs):
+        if internals is None or internals is True:
+            internals = InternalCoordinates.from_atoms(atoms, cons=kwargs.pop('constraints', None))
+        self.int_orig = internals
+        new_int = internals.copy()
+        if new_int.cons is None:
+            new_int.cons = Constraints(atoms)
+        kwargs.pop('constraints', None)
+        PES.__init__(self, atoms, *args, constraints=new_int.cons, H0=None, proj_trans=False, proj_rot=False,
+                     **kwargs)
+        self.int = new_int
+        self.dim = len(self.get_x())
+        self.ncart = self.int.ndof
+        if H0 is None:
+            # guess Hessian with the components in the infeasible (redundant) subspace zeroed, :644-650
+            B = self.int.jacobian()
+            P = _range_space_projector(B)
+            self.set_H(P @ self.int.guess_hessian() @ P, initialized=False)
+        else:
+            self.set_H(H0, initialized=True)
+        self.bad_int = None
+        self.exact_geodesic = exact_geodesic
+        self._pinv_cache = _LRU2()
+        self._qr_cache = _LRU2()
+        self._Hc_cache = _LRU2()
+
+    # ---- B = dq/dx: economy QR shared by the basis and the pseudo-inverse (:674-736) ------------------
+    def _get_jacobian_qr(self):
+        key = self._state_hash()
+        cached = self._qr_cache.get(key)
+        if cached is not None:
+            return cached
+        B = self.int.jacobian()
+        if B.shape[0] >= B.shape[1]:
+            Q, R = get_context().qr_thin(B)                   # _gpu_qr(B), peswrapper.py:691
+        else:
+            Q, R = qr(B, mode='economic', check_finite=False)
+        rdiag = np.abs(np.diag(R))
+        if len(rdiag) > 0 and rdiag.min() < 1e-6 * rdiag.max():
+            # rank deficient (always the case for a free molecule: 6 rigid-body modes): SVD truncation
+            Ui, Si, VTi = np.linalg.svd(B, full_matrices=False)
+            nnred = int(np.sum(Si > 1e-6))
+            Q = Ui[:, :nnred]
+            R = np.diag(Si[:nnred]) @ VTi[:nnred]
+            self._pinv_cache.put(key, VTi[:nnred].T @ np.diag(1.0 / Si[:nnred]) @ Ui[:, :nnred].T)
+        self._qr_cache.put(key, (Q, R))
+        return Q, R
+
+    def _get_Binv(self):
+        key = self._state_hash()
+        cached = self._pinv_cache.get(key)
+        if cached is not None:
+            return cached
+        Q, R = self._get_jacobian_qr()
+        cached = self._pinv_cache.get(key)                  # the SVD branch above fills it
+        if cached is not None:
+            return cached
+        if R.size == 0:
+            Binv = np.empty((3 * len(self.atoms), 0))
+        elif R.shape[0] == R.shape[1]:
+            Binv = solve_triangular(R, Q.T, check_finite=False)
+        else:
+            Binv = np.linalg.pinv(self.int.jacobian())
+        self._pinv_cache.put(key, Binv)
+        return Binv
+
+    # ---- geodesic position update (:840-880, :1200-1221) ----------------------------------------------
+    def _q_ode(self, t, y):
+        nx = 3 * len(self.atoms)
+        x, dxdt, g = y.reshape((3, nx))
+        dydt = np.zeros((3, nx))
+        dydt[0] = dxdt
+        self.atoms.positions = x.reshape((-1, 3)).copy()
+        D_rdot = self.int.hessian_rdot(dxdt)                   # (nint, nx): rows H_i dxdt, one device launch per kind
+        Binv = self._get_Binv() if self.exact_geodesic else self._ode_Binv
+        out = -Binv @ (D_rdot @ np.column_stack((dxdt, g)))    # (nx, 2)
+        dydt[1] = out[:, 0]
+        dydt[2] = out[:, 1]
+        return dydt.ravel()
+
+    def _set_x_ode(self, target):
+        dx = self.wrap_dx(target - self.get_x())
+        Binv = self._get_Binv()
+        self._ode_Binv = Binv
+        g_int = self.curr.get('g')
+        if g_int is None:
+            g_int = np.zeros_like(dx)
+        y0 = np.hstack((self.apos.ravel(), Binv @ dx, Binv @ g_int))
+        ode = LSODA(self._q_ode, 0.0, y0, t_bound=1.0, atol=1e-6)
+        t0, y = 0.0, y0
+        while ode.status == 'running':
+            ode.step()
+            y, t0 = ode.y, ode.t
+            self.bad_int = self.int.check_for_bad_internals()
+            if self.bad_int is not None:
+                break
+            if ode.nfev > 1000:
+                raise RuntimeError("Geometry update ODE is taking too long to converge!")
+        if ode.status == 'failed':
+            raise RuntimeError("Geometry update ODE failed to converge!")
+        nx = 3 * len(self.atoms)
+        y = y.reshape((3, nx))
+        self.atoms.positions = y[0].reshape((-1, 3))
+        B = self.int.jacobian()
+        return t0 * dx, t0 * B @ y[1], B @ y[2]
+
+    def set_x(self, target):
+        dx_initial, dx_final_ode, g_final = self._set_x_ode(target)
+        q_after = self.int.calc().copy()
+        moved = self._project_to_constraints()
+        return dx_initial, self._add_proj_delta(dx_final_ode, q_after, moved), g_final
+
+    def _add_proj_delta(self, dx_int_final, q_after_ode, proj_moved):                 # :903-926
+        if not proj_moved:
+            return dx_int_final
+        return dx_int_final + self.int.wrap(self.int.calc() - q_after_ode)
+
+    def _project_to_constraints(self, target_tol=1e-7, max_iter=8, safety_limit=0.05):  # :928-994
+        if self.cons.residual().size == 0:
+            return False
+        moved = False
+        for _ in range(max_iter):
+            r = self.cons.residual()
+            if np.linalg.norm(r, ord=np.inf) < target_tol:
+                return moved
+            drdx, Ucons, _, _ = self._compute_basis_int()
+            if Ucons.shape[1] == 0:
+                return moved
+            s = np.linalg.lstsq(drdx @ Ucons, -r, rcond=None)[0]
+            dx = self._get_Binv() @ (Ucons @ s)
+            if np.linalg.norm(dx, ord=np.inf) > safety_limit:
+                return moved
+            self.atoms.positions = self.atoms.positions + dx.reshape(-1, 3)
+            moved = True
+        return moved
+
+    def get_x(self):
+        x = self.int.calc()
+        nd = self.int.ndihedrals
+        if self.curr['x'] is not None and nd:
+            # keep dihedrals continuous with the previous point instead of jumping by 2 pi (:996-1008)
+            dx = x[-nd:] - self.curr['x'][-nd:]
+            x[-nd:] = self.curr['x'][-nd:] + (dx + np.pi) % (2 * np.pi) - np.pi
+        return x
+
+    def wrap_dx(self, dx):
+        return self.int.wrap(dx)
+
+    # ---- constraints in internal space (:1011-1122) ------------------------------------------------------
+    def _compute_Hc_int(self):
+        if self.curr['L'] is None:
+            raise RuntimeError("InternalPES.get_Hc() called with L=None.")
+        Binv = self._get_Binv()
+        n_dof = Binv.shape[1]
+        if self.curr['L'].size == 0:
+            return np.zeros((n_dof, n_dof))
+        D_cons = self.cons.hessian().ldot(self.curr['L'])
+        L_int = self.curr['L'] @ self.cons.jacobian() @ Binv
+        D_int = self.int.hessian().ldot(L_int)
+        return Binv.T @ (D_cons - D_int) @ Binv
+
+    def get_Hc(self):
+        key = self._state_hash()
+        cached = self._Hc_cache.get(key)
+        if cached is None:
+            cached = self._compute_Hc_int()
+            self._Hc_cache.put(key, cached)
+        return cached
+
+    def _has_curved_constraints(self):
+        return True                      # in internal space even a fixed translation has a curvature term
+
+    def get_drdx(self):
+        return PES.get_drdx(self) @ self._get_Binv()          # dr/dq = dr/dx dx/dq
+
+    def _compute_basis_int(self):
+        Q, R = self._get_jacobian_qr()
+        Unred = Q
+        n_int = Q.shape[0]
+        cons_jac = self.cons.jacobian()
+        if cons_jac.shape[0] == 0:
+            return np.zeros((0, n_int)), np.zeros((n_int, 0)), Unred, Unred
+        if R.shape[0] == R.shape[1]:
+            drdxnred = solve_triangular(R.T, cons_jac.T, lower=True, check_finite=False).T
+        else:
+            drdxnred = cons_jac @ (self._get_Binv() @ Q)
+        Vcons, Vfree = _split_cons_subspace(drdxnred)
+        return drdxnred @ Q.T, Unred @ Vcons, Unred, Unred @ Vfree
+
+    def _calc_basis(self):
+        key = self._state_hash()
+        cached = self._basis_cache.get(key)
+        if cached is None:
+            cached = self._compute_basis_int()
+            self._basis_cache.put(key, cached)
+        return cached
+
+    # ---- calculator boundary: Cartesian gradient -> internal (:1124-1127) ---------------------------------
+    def eval(self):
+        f, g_cart = PES.eval(self)
+        return f, g_cart @ self._get_Binv()
+
+    def get_df_pred(self, dx, g, H):                                                    # :1174-1181
+        if H is None:
+            return None
+        Unred = self.get_Unred()
+        dx_r, g_r = dx @ Unred, g @ Unred
+        H_r = Unred.T @ (H @ Unred)
+        return g_r @ dx_r + (dx_r @ H_r @ dx_r) / 2.
+
+    def get_projected_forces(self):                                                     # :1183-1192
+        g = self.get_g()
+        Ufree = self.get_Ufree()
+        B = self.curr.get('B')
+        if B is None:
+            B = self.int.jacobian()
+        return -((Ufree @ (Ufree.T @ g)) @ B).reshape((-1, 3))
+
+    def _update(self, feval=True):
+        if not PES._update(self, feval=feval):
+            return
+        self.curr.update(B=self.int.jacobian(), Binv=self._get_Binv())
+        return True
+
+    def kick(self, dx, diag=False, **diag_kwargs):
+        ratio = PES.kick(self, dx, diag=diag, **diag_kwargs)
+        if self.bad_int is not None:
+            raise RuntimeError('an angle became (nearly) linear: regenerating the internal coordinates with dummy '
+                               'atoms (peswrapper.py:1126-1172) is not part of this build')
+        return ratio

@@ -1,0 +1,123 @@
+"""InternalPES (sella/peswrapper.py:609-1288): geodesic steps in redundant internal coordinates.
+The reference class cannot be imported here (ASE + JAX), so these are property tests: the geodesic update
+reaches its target, energy/gradient transform consistently, and a search in internal coordinates ends on
+the same stationary point as the Cartesian one."""
+import numpy as np
+import pytest
+
+
+def chain(n=5, seed=0):
+    from sella_amd.atoms import Atoms, MorseCluster
+    rng = np.random.RandomState(seed)
+    pos = np.array([[1.25 * i, 0.55 * (i % 2), 0.15 * i * (i % 3)] for i in range(n)], dtype=float)
+    pos += 0.03 * rng.normal(size=pos.shape)
+    at = Atoms(['C'] * n, pos)
+    at.calc = MorseCluster(D=1.0, a=1.2, r0=1.45)
+    return at
+
+
+def test_geodesic_step_reaches_target(ctx):
+    from sella_amd.internal import InternalCoordinates
+    from sella_amd.peswrapper import InternalPES
+    at = chain()
+    pes = InternalPES(at, InternalCoordinates.from_atoms(at))
+    assert pes.dim == pes.int.nint == 9 and pes.ncart == 15
+    q0 = pes.get_x()
+    g0 = pes.get_g()
+    # a feasible target: the internals of a displaced geometry
+    rng = np.random.RandomState(1)
+    x0 = at.positions.copy()
+    at.positions = x0 + 0.05 * rng.normal(size=x0.shape)
+    q1 = pes.int.calc()
+    at.positions = x0
+    dx_initial, dx_final, g_par = pes.set_x(q1)
+    np.testing.assert_allclose(dx_initial, pes.wrap_dx(q1 - q0), atol=1e-12)
+    # default: the pseudo-inverse of the starting point is used along the whole path (peswrapper.py:1213),
+    # so the target is met to second order in the step
+    np.testing.assert_allclose(pes.int.calc(), q1, atol=2e-3)
+    np.testing.assert_allclose(dx_final, dx_initial, atol=2e-3)        # integrated tangent = requested change
+    # exact geodesic: pseudo-inverse re-evaluated at every point of the path -> integrator accuracy
+    at.positions = x0
+    pes2 = InternalPES(at, InternalCoordinates.from_atoms(at), exact_geodesic=True)
+    pes2.get_g()
+    pes2.set_x(q1)
+    np.testing.assert_allclose(pes2.int.calc(), q1, atol=2e-5)
+    # the gradient was parallel-transported, not re-evaluated: same length to first order
+    assert abs(np.linalg.norm(g_par) - np.linalg.norm(g0)) < 0.2 * np.linalg.norm(g0) + 1e-8
+
+
+def test_energy_gradient_consistency(ctx):
+    """f(q + dq) - f(q) = g_int . dq to first order along a geodesic step."""
+    from sella_amd.internal import InternalCoordinates
+    from sella_amd.peswrapper import InternalPES
+    at = chain(seed=2)
+    pes = InternalPES(at, InternalCoordinates.from_atoms(at))
+    f0, g = pes.get_f(), pes.get_g()
+    Unred = pes.get_Unred()
+    assert Unred.shape == (9, 9)
+    rng = np.random.RandomState(3)
+    dq = Unred @ (Unred.T @ rng.normal(size=pes.dim))
+    dq *= 1e-3 / np.linalg.norm(dq)
+    x0, q0 = at.positions.copy(), pes.get_x()
+    pes.set_x(q0 + dq)
+    f1 = pes.get_f()
+    at.positions = x0
+    pes.get_f()
+    pes.set_x(q0 - dq)
+    f2 = pes.get_f()
+    assert abs(0.5 * (f1 - f2) - g @ dq) < 1e-4 * abs(g @ dq) + 1e-9      # central difference: third order
+    assert abs(f1 - f0 - g @ dq) < 0.05 * abs(g @ dq)
+    # projected forces come back in Cartesian shape
+    assert pes.get_projected_forces().shape == (5, 3)
+
+
+@pytest.mark.parametrize('order', [0, 1])
+def test_internal_search_matches_cartesian(ctx, order):
+    from sella_amd import Sella
+    from sella_amd.internal import Constraints
+
+    def start():
+        if order == 0:
+            return chain(n=4, seed=5)
+        # near the planar rhombus of the 4-atom Morse cluster: the first-order saddle between two tetrahedra
+        from sella_amd.atoms import Atoms, MorseCluster
+        r0 = 1.45
+        pos = np.array([[0, 0, 0], [r0, 0, 0], [0.5 * r0, 0.866 * r0, 0.12], [0.5 * r0, -0.866 * r0, 0.12]])
+        pos += 0.02 * np.random.RandomState(6).normal(size=pos.shape)
+        at = Atoms(['C'] * 4, pos)
+        at.calc = MorseCluster(D=1.0, a=1.2, r0=r0)
+        return at
+
+    def run(internal):
+        at = start()
+        kw = dict(order=order, logfile=None, eta=1e-5, gamma=1e-3)
+        if internal:
+            dyn = Sella(at, internal=True, **kw)
+        else:
+            dyn = Sella(at, constraints=Constraints(at), proj_trans=False, **kw)
+        assert dyn.run(fmax=2e-4, steps=250), dyn.nsteps
+        return at.get_potential_energy(), np.linalg.norm(at.get_forces(), axis=1).max(), dyn
+
+    e_int, f_int, dyn = run(True)
+    assert dyn.pes.int is not None and dyn.rs.__name__ == 'MaxInternalStep'
+    assert f_int < 5e-4
+    if order == 0:
+        e_car, f_car, _ = run(False)
+        assert abs(e_int - e_car) < 1e-5                        # same minimum
+    else:
+        # a first-order saddle: one negative eigenvalue of the (finite-difference) Hessian off the rigid modes
+        at = dyn.atoms
+        x0 = at.positions.ravel().copy()
+        h = 1e-4
+        H = np.zeros((x0.size, x0.size))
+        for j in range(x0.size):
+            g = []
+            for s in (1, -1):
+                x = x0.copy()
+                x[j] += s * h
+                at.positions = x.reshape(-1, 3)
+                g.append(-at.get_forces().ravel())
+            H[:, j] = (g[0] - g[1]) / (2 * h)
+        at.positions = x0.reshape(-1, 3)
+        w = np.linalg.eigvalsh(0.5 * (H + H.T))
+        assert w[0] < -1e-2 and np.sum(w < -1e-3) == 1, w     # rigid rotations sit at O(fmax / r) ~ 1e-4

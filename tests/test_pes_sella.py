@@ -115,9 +115,10 @@ def test_unsupported_options_fail_loudly(ctx):
     from sella_amd import Sella
     atoms = morse_atoms(4)
     with pytest.raises(NotImplementedError):
-        Sella(atoms, internal=True)
-    with pytest.raises(NotImplementedError):
         Sella(atoms, optimize_cell=True, order=0)
+    with pytest.raises(ValueError):                       # optimize.py:239-246
+        from sella_amd.internal import Constraints, InternalCoordinates
+        Sella(atoms, internal=InternalCoordinates.from_atoms(atoms), constraints=Constraints(atoms))
 
 
 def test_readme_example_slab_adatom(ctx):

@@ -12,6 +12,8 @@ from sella_amd.device import Context  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3072
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 ctx = Context(0)
+if os.environ.get('EIGH_NB'):
+    ctx.set_option('eigh_nb', int(os.environ['EIGH_NB']))
 if os.environ.get('EIGH_LEAF'):
     ctx.set_option('eigh_leaf', int(os.environ['EIGH_LEAF']))
 rng = np.random.RandomState(0)

@@ -121,3 +121,29 @@ def test_internal_search_matches_cartesian(ctx, order):
         at.positions = x0.reshape(-1, 3)
         w = np.linalg.eigvalsh(0.5 * (H + H.T))
         assert w[0] < -1e-2 and np.sum(w < -1e-3) == 1, w     # rigid rotations sit at O(fmax / r) ~ 1e-4
+
+
+def test_internal_search_with_fixed_bond(ctx):
+    """A bond-length constraint handled in internal space (constraint Hessian `_compute_Hc_int`, projection
+    back onto the constraint manifold): same constrained minimum as the Cartesian path."""
+    from sella_amd import Sella
+    from sella_amd.internal import Constraints, InternalCoordinates
+
+    def run(internal):
+        at = chain(n=4, seed=7)
+        cons = Constraints(at)
+        cons.fix_bond((0, 1), target=1.60)
+        kw = dict(order=0, logfile=None, eta=1e-5)
+        if internal:
+            dyn = Sella(at, internal=InternalCoordinates.from_atoms(at, cons=cons), **kw)
+        else:
+            dyn = Sella(at, constraints=cons, proj_trans=False, **kw)
+        assert dyn.run(fmax=3e-4, steps=300), dyn.nsteps
+        return at, dyn
+
+    at_i, dyn_i = run(True)
+    at_c, _ = run(False)
+    d_i = np.linalg.norm(at_i.positions[1] - at_i.positions[0])
+    assert abs(d_i - 1.60) < 1e-5
+    assert abs(at_i.get_potential_energy() - at_c.get_potential_energy()) < 1e-5
+    assert dyn_i.pes.get_res().size == 1 and abs(dyn_i.pes.get_res()[0]) < 1e-5

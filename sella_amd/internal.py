@@ -402,7 +402,7 @@ class InternalCoordinates:
             nc = len(pos)
             if nc:
                 g = evaluate_kind(k, pos, tvec, hessian=False)[1].reshape(nc, -1)
-                np.add.at(B, (np.arange(row, row + nc)[:, None], dofs), g)
+                B[np.arange(row, row + nc)[:, None], dofs] = g        # the atoms of one coordinate are distinct
             row += nc
         return B
 
@@ -417,7 +417,7 @@ class InternalCoordinates:
             if nc:
                 tan = v[dofs].reshape(pos.shape)
                 hv = evaluate_kind(k, pos, tvec, tangent=tan, hessian=False)[3].reshape(nc, -1)
-                np.add.at(D, (np.arange(row, row + nc)[:, None], dofs), hv)
+                D[np.arange(row, row + nc)[:, None], dofs] = hv
             row += nc
         return D
 

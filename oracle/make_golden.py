@@ -425,6 +425,54 @@ def gen_restricted(ref, orc):
     return cases
 
 
+def gen_irc(ref, orc):
+    """IRC step family (stepper.py:99-111) and its mass-weighted trust sphere (restricted_step.py:145-158),
+    driven exactly as sella/optimize/irc.py:128-137 does: method=QuasiNewtonIRC, d1, W = diag(1/sqrt(m))."""
+    out, cases = {}, []
+    n = 36
+    i = 0
+    for delta, ncons in ((0.1, 0), (0.05, 0), (0.2, 0), (0.1, 6)):
+        A, P, g = hessian_like(n, seed=700 + i, nneg=1)
+        rng = np.random.RandomState(800 + i)
+        masses = np.repeat(rng.uniform(1.0, 40.0, n // 3), 3)
+        sqrtm = np.sqrt(masses)
+        W = np.diag(1.0 / sqrtm)
+        d1 = rng.normal(size=n)
+        pr = FakePES(ref.linalg.ApproximateHessian, P, g, ncons, seed=i)
+        po = FakePES(orc.QuasiNewtonHessian, P, g, ncons, seed=i)
+        if ncons:
+            d1 = pr.Ufree @ (pr.Ufree.T @ d1)
+            pr.scons[:] = 0.0                       # irc.py builds its PES without constraints
+            po.scons[:] = 0.0
+        # like irc.py:93 the accumulated displacement has mass-weighted length <= dx
+        d1 *= (0.9 if i % 2 else 1.0) * delta / np.linalg.norm(d1 * sqrtm)
+        s, smag = ref.rs.IRCTrustRegion(pr, 0, delta, method=ref.stepper.QuasiNewtonIRC, sqrtm=sqrtm,
+                                        d1=d1.copy(), W=W).get_s()
+        ro = orc.IRCTrustRegionStep(po, 0, delta, method=orc.QuasiNewtonIRCStep, sqrtm=sqrtm, d1=d1.copy(), W=W)
+        s2, smag2 = ro.get_s()
+        close(s2, s, 1e-9, f'irc[{delta},{ncons}] s')
+        close(smag2, smag, 1e-12, 'irc smag')
+        # raw stepper values at fixed alphas
+        Hr = ref.linalg.ApproximateHessian(n, 0, P)
+        Ho = orc.QuasiNewtonHessian(n, 0, P)
+        str_ = ref.stepper.QuasiNewtonIRC(g, Hr, 0, d1=d1)
+        sto = orc.QuasiNewtonIRCStep(g, Ho, 0, d1=d1)
+        for k, alpha in enumerate((0.0, 0.1, 1.0, 25.0)):
+            a, b = str_.get_s(alpha)
+            a2, b2 = sto.get_s(alpha)
+            close(a2, a, 1e-10, 'irc stepper s')
+            close(b2, b, 1e-10, 'irc stepper dsda')
+            out[f'c{i}_a{k}_s'], out[f'c{i}_a{k}_dsda'] = a, b
+        out[f'c{i}_H'], out[f'c{i}_g'], out[f'c{i}_d1'] = P, g, d1
+        out[f'c{i}_sqrtm'] = sqrtm
+        out[f'c{i}_Ufree'], out[f'c{i}_scons'] = pr.Ufree, pr.scons
+        out[f'c{i}_s'], out[f'c{i}_smag'] = s, smag
+        cases.append(dict(id=i, delta=delta, ncons=ncons, alphas=[0.0, 0.1, 1.0, 25.0]))
+        i += 1
+    np.savez_compressed(os.path.join(GOLD, 'g10_irc.npz'), **out)
+    return cases
+
+
 def quartic_factory(n, seed):
     """Small analytic PES (value, gradient, Hessian) with random symmetric
     cubic and quartic couplings through a few directions."""
@@ -537,7 +585,8 @@ def main():
                      ('g6_approx_hessian', gen_approx_hessian),
                      ('g7_steppers', gen_steppers),
                      ('g8_restricted_step', gen_restricted),
-                     ('g9_numhess', gen_numhess)):
+                     ('g9_numhess', gen_numhess),
+                     ('g10_irc', gen_irc)):
         t0 = time.time()
         manifest[name] = fn(ref, orc)
         print(f'{name}: {len(manifest[name])} cases, oracle == reference '

@@ -6,4 +6,5 @@ from .hessian_ops import (FiniteDifferenceHessian, OperatorSum,  # noqa: F401
                           QuasiNewtonHessian)
 from .stepsolve import (get_stepper, get_restricted_step,        # noqa: F401
                         QuasiNewtonStep, RFOStep, PRFOStep,
-                        TrustRegionStep, PerAtomStep, NaiveStep)
+                        TrustRegionStep, PerAtomStep, NaiveStep,
+                        QuasiNewtonIRCStep, IRCTrustRegionStep)

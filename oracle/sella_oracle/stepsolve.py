@@ -41,6 +41,19 @@ class QuasiNewtonStep:                                   # stepper.py:58-96
         return -self.V @ sp, self.V @ (sp / den)
 
 
+class QuasiNewtonIRCStep(QuasiNewtonStep):               # stepper.py:99-111
+    """Quasi-Newton step towards the IRC constraint sphere centred at -d1."""
+
+    def __init__(self, g, H, order=0, d1=None):
+        QuasiNewtonStep.__init__(self, g, H, order, d1)
+        self.Vd1 = self.V.T @ d1
+
+    def get_s(self, alpha):
+        den = np.abs(self.L) + alpha
+        sp = -(self.Vg + alpha * self.Vd1) / den
+        return self.V @ sp, -self.V @ ((sp + self.Vd1) / den)
+
+
 class RFOStep:                                           # stepper.py:114-157
     alpha0, alphamin, alphamax, slope, newton_safe = 1.0, 0.0, 1.0, 1.0, False
 
@@ -107,21 +120,25 @@ def get_stepper(name):                                   # stepper.py:195-199
 class RestrictedStep:                                    # restricted_step.py:11-124
     names = []
 
-    def __init__(self, pes, order, delta, method='qn', tol=None, maxiter=1000):
+    def __init__(self, pes, order, delta, method='qn', tol=None, maxiter=1000,
+                 d1=None, W=None):
         self.pes = pes
         self.delta = delta
+        self.d1 = d1
         g0 = pes.get_g()
         self.scons = pes.get_scons()
         g = g0 + pes.get_H() @ self.scons
-        stepper = get_stepper(method.lower())
+        stepper = method if isinstance(method, type) else get_stepper(method.lower())
         if self.cons(self.scons) - self.delta > 1e-8:    # :44-48
             self.P = pes.get_Unred().T
             self.stepper = NaiveStep(self.P @ self.scons)
             self.scons[:] *= 0
         else:
-            self.P = pes.get_Ufree().T
+            self.P = pes.get_Ufree().T if W is None else pes.get_Ufree().T @ W   # :50-53
+            if d1 is not None:                                                # :54-56
+                d1 = np.linalg.lstsq(self.P.T, d1, rcond=None)[0]
             self.stepper = stepper(self.P @ g,
-                                   pes.get_HL_projected(self.P.T), order)
+                                   pes.get_HL_projected(self.P.T), order, d1=d1)
         if tol is None:
             tol = 1e-10 if self.stepper.newton_safe else 1e-15
         self.tol = tol
@@ -183,6 +200,23 @@ class TrustRegionStep(RestrictedStep):                   # :127-142
         if dsda is None:
             return val
         return val, dsda @ s / max(val, 1e-12)
+
+
+class IRCTrustRegionStep(TrustRegionStep):               # :145-158
+    names = []
+
+    def __init__(self, *args, sqrtm=None, **kwargs):
+        assert sqrtm is not None
+        self.sqrtm = sqrtm
+        self.d1 = kwargs.get('d1')
+        TrustRegionStep.__init__(self, *args, **kwargs)
+        assert self.d1 is not None
+
+    def cons(self, s, dsda=None):
+        s = (s + self.d1) * self.sqrtm
+        if dsda is not None:
+            dsda = dsda * self.sqrtm
+        return TrustRegionStep.cons(self, s, dsda)
 
 
 class PerAtomStep(RestrictedStep):                       # :161-183

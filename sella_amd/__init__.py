@@ -9,7 +9,10 @@ __version__ = '0.1.0'
 
 _LAZY = {
     'Sella': ('sella_amd.optimize.optimize', 'Sella'),
+    'IRC': ('sella_amd.optimize.irc', 'IRC'),
     'PES': ('sella_amd.peswrapper', 'PES'),
+    'InternalPES': ('sella_amd.peswrapper', 'InternalPES'),
+    'InternalCoordinates': ('sella_amd.internal', 'InternalCoordinates'),
     'Constraints': ('sella_amd.internal', 'Constraints'),
     'Atoms': ('sella_amd.atoms', 'Atoms'),
 }

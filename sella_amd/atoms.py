@@ -22,6 +22,11 @@ except Exception:                                           # noqa: BLE001
     HAVE_ASE = False
 
 
+# standard atomic weights of the elements the examples use (u); unknown symbols weigh 1
+_MASSES = dict(H=1.008, C=12.011, N=14.007, O=15.999, F=18.998, Al=26.982, Si=28.085, P=30.974, S=32.06, Cl=35.45,
+               Ar=39.948, Ni=58.693, Cu=63.546, Pd=106.42, Ag=107.868, Pt=195.084, Au=196.967, Xe=131.293)
+
+
 class Atoms:
     def __init__(self, symbols=None, positions=None, cell=None, pbc=False, calculator=None,
                  numbers=None):
@@ -34,6 +39,7 @@ class Atoms:
         self.calc = calculator
         self.constraints = []
         self.info = {}
+        self.masses = np.array([_MASSES.get(sym, 1.0) for sym in self.symbols], dtype=np.float64)
 
     def __len__(self):
         return len(self.positions)
@@ -42,6 +48,7 @@ class Atoms:
         new = Atoms(self.symbols, self.positions.copy(), self.cell.copy(), self.pbc.copy(), self.calc,
                     self.numbers.copy())
         new.info = dict(self.info)
+        new.masses = self.masses.copy()
         return new
 
     def get_positions(self):
@@ -49,6 +56,12 @@ class Atoms:
 
     def set_positions(self, pos):
         self.positions = np.array(pos, dtype=np.float64).reshape((-1, 3))
+
+    def get_masses(self):
+        return self.masses.copy()
+
+    def set_masses(self, masses):
+        self.masses = np.asarray(masses, dtype=np.float64).copy()
 
     def get_potential_energy(self):
         return float(self.calc.get_potential_energy(self))
@@ -67,6 +80,7 @@ class Atoms:
         self.symbols.append(symbol)
         self.positions = np.vstack([self.positions, np.asarray(position, dtype=np.float64).reshape(1, 3)])
         self.numbers = np.append(self.numbers, 0)
+        self.masses = np.append(self.masses, _MASSES.get(symbol, 1.0))
 
 
 class _Atom:

@@ -24,8 +24,6 @@ class BaseRestrictedStep:
         self.pes = pes
         self.delta = delta
         self.d1 = d1
-        if d1 is not None or W is not None:
-            raise NotImplementedError('d1 / W (IRC path) are outside the saddle-search hot path')
         g0 = self.pes.get_g()
         self.scons = self.pes.get_scons()
         g = g0 + self.pes.get_H() @ self.scons                      # :35-37
@@ -42,10 +40,23 @@ class BaseRestrictedStep:
             self.scons[:] *= 0
         else:
             Ufree = self.pes.get_Ufree()
-            # the stepper composes Ufree with the eigenbasis on the device and returns
+            if W is not None:
+                # P = Ufree^T W (restricted_step.py:50-53); P^T = W^T Ufree is the basis handed on.  A diagonal W
+                # (the IRC's mass weighting, irc.py:174-175) is a row scaling, not an n^2 product.
+                W = np.asarray(W, dtype=np.float64)
+                if W.ndim == 1:
+                    Ufree = W[:, None] * Ufree
+                elif np.count_nonzero(W - np.diag(np.diagonal(W))) == 0:
+                    Ufree = np.diagonal(W)[:, None] * Ufree
+                else:
+                    Ufree = W.T @ Ufree
+            kw = {}
+            if d1 is not None:
+                kw['d1'] = np.linalg.lstsq(Ufree, d1, rcond=None)[0]          # :54-56
+            # the stepper composes the basis with the eigenbasis on the device and returns
             # unprojected vectors, so eval() needs no further products
             self._lift = None
-            self.stepper = stepper(g, self.pes.get_HL_projected(Ufree), order, U=Ufree)
+            self.stepper = stepper(g, self.pes.get_HL_projected(Ufree), order, U=Ufree, **kw)
 
         if tol is None:
             tol = 1e-10 if self.stepper.newton_safe else 1e-15
@@ -116,6 +127,24 @@ class TrustRegion(BaseRestrictedStep):
         if dsda is None:
             return val
         return val, dsda @ s / max(val, 1e-12)
+
+
+class IRCTrustRegion(TrustRegion):
+    """Trust sphere of the IRC inner loop: |(s + d1) * sqrt(m)| = dx (restricted_step.py:145-158)."""
+    synonyms = []
+
+    def __init__(self, *args, sqrtm=None, **kwargs):
+        assert sqrtm is not None
+        self.sqrtm = sqrtm
+        self.d1 = kwargs.get('d1')
+        TrustRegion.__init__(self, *args, **kwargs)
+        assert self.d1 is not None
+
+    def cons(self, s, dsda=None):
+        s = (s + self.d1) * self.sqrtm
+        if dsda is not None:
+            dsda = dsda * self.sqrtm
+        return TrustRegion.cons(self, s, dsda)
 
 
 class RestrictedAtomicStep(BaseRestrictedStep):

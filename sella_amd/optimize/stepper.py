@@ -98,6 +98,40 @@ class QuasiNewton(BaseStepper):
     ]
 
 
+class QuasiNewtonIRC(QuasiNewton):
+    """Quasi-Newton step family of the IRC inner loop (stepper.py:99-111):
+    s(alpha) = -V (V^T g + alpha V^T d1) / (|lam| + alpha), d1 given in the projected space.
+    The O(m) arithmetic in the eigenbasis stays on the host; the two products with the (projection-composed)
+    eigenvector matrix are one 2-column panel product on the device."""
+    synonyms = []
+
+    def _stepper_init(self) -> None:
+        ctx = get_context()
+        evals, V, Vt = self._device_eig()
+        self.L = np.abs(evals)
+        self._Veig = V
+        self.Vg_full = None
+        U = self.U
+        if U is not None and is_identity(U):
+            U = None
+        if U is not None:
+            dU = ctx.upload(U)
+            VU = ctx.zeros(U.shape[0], V.shape[1])
+            ctx.gemm(dU, V, VU)
+            dU.free()
+            self._Vout = VU
+        else:
+            self._Vout = V
+        self.Vg = ctx.tmatmul(self._Vout, self.g)            # V^T (U^T g)
+        self.Vd1 = ctx.tmatmul(V, self.d1)                   # d1 lives in the projected space already
+
+    def get_s(self, alpha: float) -> Tuple[np.ndarray, np.ndarray]:
+        denom = self.L + alpha
+        sproj = -(self.Vg + alpha * self.Vd1) / denom
+        out = get_context().symm_mm(self._Vout, np.column_stack((sproj, -(sproj + self.Vd1) / denom)))
+        return out[:, 0].copy(), out[:, 1].copy()
+
+
 class RationalFunctionOptimization(BaseStepper):
     alpha0 = 1.
     alphamin = 0.

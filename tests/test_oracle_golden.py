@@ -113,3 +113,60 @@ def test_numerical_hessian(manifest):
         np.testing.assert_allclose(H.dot(g[f'c{i}_M']), g[f'c{i}_out'], atol=1e-12)
         np.testing.assert_allclose(H.Vs, g[f'c{i}_Vs'], atol=1e-12)
         np.testing.assert_allclose(H.AVs, g[f'c{i}_AVs'], atol=1e-12)
+
+
+class _OraclePES:
+    int = None
+    n_cell_dof = 0
+
+    def __init__(self, H, g, Ufree, scons):
+        n = len(g)
+        self.H = orc.QuasiNewtonHessian(n, n, H)
+        self.g, self.Ufree, self.scons = g, Ufree, scons
+
+    def get_g(self):
+        return self.g.copy()
+
+    def get_scons(self):
+        return self.scons.copy()
+
+    def get_H(self):
+        return self.H
+
+    def get_Unred(self):
+        return np.eye(len(self.g))
+
+    def get_Ufree(self):
+        return self.Ufree
+
+    def get_HL_projected(self, U):
+        return orc.QuasiNewtonHessian(U.shape[1], 0, U.T @ self.H.B @ U)
+
+
+def test_restricted_step(manifest):
+    g = load_golden('g8_restricted_step')
+    for case in manifest['g8_restricted_step']:
+        i = case['id']
+        pes = _OraclePES(g[f'c{i}_H'], g[f'c{i}_g'], g[f'c{i}_Ufree'], g[f'c{i}_scons'])
+        rs = orc.get_restricted_step(case['rs'])(pes, case['order'], case['delta'], case['method'])
+        s, smag = rs.get_s()
+        assert smag == pytest.approx(float(g[f'c{i}_smag']), abs=1e-12)
+        np.testing.assert_allclose(s, g[f'c{i}_s'], atol=1e-9 * max(1, np.abs(s).max()))
+        assert len(rs.alpha_trace) == int(g[f'c{i}_nalpha'])
+
+
+def test_irc_steps(manifest):
+    g = load_golden('g10_irc')
+    for case in manifest['g10_irc']:
+        i = case['id']
+        H, gr, d1, sqrtm = g[f'c{i}_H'], g[f'c{i}_g'], g[f'c{i}_d1'], g[f'c{i}_sqrtm']
+        st = orc.QuasiNewtonIRCStep(gr, orc.QuasiNewtonHessian(len(gr), 0, H), 0, d1=d1)
+        for k, alpha in enumerate(case['alphas']):
+            s, ds = st.get_s(alpha)
+            np.testing.assert_allclose(s, g[f'c{i}_a{k}_s'], atol=1e-10 * max(1, np.abs(s).max()))
+            np.testing.assert_allclose(ds, g[f'c{i}_a{k}_dsda'], atol=1e-10 * max(1, np.abs(ds).max()))
+        pes = _OraclePES(H, gr, g[f'c{i}_Ufree'], g[f'c{i}_scons'])
+        s, smag = orc.IRCTrustRegionStep(pes, 0, case['delta'], method=orc.QuasiNewtonIRCStep, sqrtm=sqrtm,
+                                         d1=d1.copy(), W=np.diag(1.0 / sqrtm)).get_s()
+        assert smag == pytest.approx(float(g[f'c{i}_smag']), abs=1e-12)
+        np.testing.assert_allclose(s, g[f'c{i}_s'], atol=1e-9 * max(1, np.abs(s).max()))

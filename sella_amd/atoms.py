@@ -124,6 +124,42 @@ def add_adsorbate(slab, symbol, height, position='ontop'):
     slab.extend(symbol, [xy[0], xy[1], ztop + height])
 
 
+class XYZTrajectory:
+    """Extended-XYZ trajectory writer (one frame per call of write()), readable by ase.io.read(..., ':').
+    Stands in for ase.io.Trajectory when a file NAME is passed as `trajectory=` (peswrapper.py:409-418 writes
+    a frame at every energy/force evaluation); with ASE installed pass a real Trajectory object instead."""
+
+    def __init__(self, filename, atoms, mode='w'):
+        self.atoms = atoms
+        self.f = open(filename, mode)
+        self.nframes = 0
+
+    def write(self, atoms=None):
+        at = self.atoms if atoms is None else atoms
+        cell = np.asarray(at.cell, dtype=float).ravel()
+        calc = at.calc
+        res = getattr(calc, '_res', None)
+        have = res is not None and getattr(calc, '_key', None) == at.positions.tobytes()
+        head = 'Lattice="%s" Properties=species:S:1:pos:R:3%s pbc="%s"' % (
+            ' '.join('%.10f' % v for v in cell), ':forces:R:3' if have else '',
+            ' '.join('T' if b else 'F' for b in at.pbc))
+        if have:
+            head += ' energy=%.12f' % res[0]
+        self.f.write('%d\n%s\n' % (len(at), head))
+        for i, (sym, p) in enumerate(zip(at.symbols, at.positions)):
+            line = '%-3s %18.10f %18.10f %18.10f' % (sym, p[0], p[1], p[2])
+            if have:
+                fr = -res[1][i]
+                line += ' %18.10f %18.10f %18.10f' % (fr[0], fr[1], fr[2])
+            self.f.write(line + '\n')
+        self.f.flush()
+        self.nframes += 1
+
+    def close(self):
+        if not self.f.closed:
+            self.f.close()
+
+
 class Calculator:
     """energy_and_gradient(positions (N,3)) -> (E, dE/dx (N,3)); results cached per geometry."""
 

@@ -103,6 +103,24 @@ class Sella(Optimizer):
                        hessian_function=hessian_function, **kwargs)
         self.trajectory = self.pes.traj
 
+    # ---- restartable state (the reference has no resume) --------------------------------
+    def save_state(self, filename):
+        """Everything the next step depends on besides the atoms: approximate Hessian, trust radius, schedule."""
+        H = self.pes.H
+        np.savez(filename, positions=self.pes.atoms.positions, B=(np.zeros((0, 0)) if H.B is None else H.B),
+                 has_B=H.B is not None, H_initialized=H.initialized, delta=self.delta, rho=self.rho,
+                 nsteps=self.nsteps, nsteps_since_diag=self.nsteps_since_diag, initialized=self.initialized,
+                 first_diag=self.pes.first_diag)
+
+    def load_state(self, filename):
+        z = np.load(filename if str(filename).endswith('.npz') else str(filename) + '.npz')
+        self.pes.atoms.positions = z['positions'].copy()
+        self.pes.set_H(z['B'].copy() if bool(z['has_B']) else None, initialized=bool(z['H_initialized']))
+        self.delta, self.rho = float(z['delta']), float(z['rho'])
+        self.nsteps, self.nsteps_since_diag = int(z['nsteps']), int(z['nsteps_since_diag'])
+        self.initialized = bool(z['initialized'])
+        self.pes.first_diag = bool(z['first_diag'])
+
     def _predict_step(self):                                                     # :317-357
         if not self.initialized:
             self.pes.get_g()

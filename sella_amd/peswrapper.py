@@ -78,7 +78,10 @@ class PES:
             pass
         self.cons = constraints
         self.eigensolver = eigensolver
-        self.traj = trajectory if not isinstance(trajectory, str) else None
+        if isinstance(trajectory, str):
+            from .atoms import XYZTrajectory
+            trajectory = XYZTrajectory(trajectory, atoms)
+        self.traj = trajectory
         self.eta = eta
         self.v0 = v0
         self.neval = 0

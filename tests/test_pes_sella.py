@@ -170,3 +170,33 @@ def test_readme_example_slab_adatom(ctx):
     slab.set_positions(x0.reshape(-1, 3))
     w = np.linalg.eigvalsh(0.5 * (Hf + Hf.T))
     assert w[0] < -1e-3 and w[1] > -1e-6, w[:4]
+
+
+def test_trajectory_file_and_restart(ctx, tmp_path):
+    """`trajectory='name.xyz'` writes one extended-XYZ frame per force call; an optimizer restarted from
+    save_state() continues exactly where the uninterrupted run goes."""
+    from sella_amd import Sella
+    from sella_amd.internal import Constraints
+
+    def make(traj=None):
+        atoms = morse_atoms(4, seed=4)
+        return atoms, Sella(atoms, order=0, logfile=None, constraints=Constraints(atoms), proj_trans=False,
+                            trajectory=traj)
+
+    traj = str(tmp_path / 'run.xyz')
+    atoms, opt = make(traj)
+    opt.run(fmax=0.0, steps=4)
+    ncalls = atoms.calc.ncalls
+    opt.pes.close()
+    lines = open(traj).read().splitlines()
+    assert lines.count('4') == ncalls                       # one frame per evaluation
+    assert 'energy=' in lines[1] and 'forces:R:3' in lines[1] and len(lines[2].split()) == 7
+    state = str(tmp_path / 'state.npz')
+    opt.save_state(state)
+    opt.run(fmax=0.0, steps=3)                              # uninterrupted: 4 + 3 steps
+    ref = atoms.positions.copy()
+    atoms2, opt2 = make()
+    opt2.load_state(state)
+    opt2.run(fmax=0.0, steps=3)
+    np.testing.assert_allclose(atoms2.positions, ref, atol=1e-9)
+    assert opt2.nsteps == opt.nsteps == 7

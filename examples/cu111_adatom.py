@@ -2,16 +2,16 @@
 """The example script of the reference's README (README.md:10-40) on the MI355X path: adatom hop on
 Cu fcc(111), bottom half of the slab frozen with translation constraints.
 
-Differences from the reference script: the two `ase` imports (ASE is not in this image; the builders
-and a Morse stand-in for EMT come from sella_amd.atoms — with ASE installed the original imports work
-unchanged, the calculator boundary is untouched) and no trajectory file."""
+Differences from the reference script: the two `ase` imports (ASE is not in this image; the builders and
+an EMT restatement come from sella_amd.atoms — with ASE installed the original imports work unchanged, the
+calculator boundary is untouched); the trajectory is written as extended XYZ."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from a source checkout
 
 from sella_amd import Constraints, Sella  # noqa: E402
-from sella_amd.atoms import PeriodicMorse, add_adsorbate, fcc111  # noqa: E402
+from sella_amd.atoms import EMT, add_adsorbate, fcc111  # noqa: E402
 
 size = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (5, 5, 6)
 
@@ -26,12 +26,13 @@ for atom in slab:
         cons.fix_translation(atom.index)
 
 # Set up your calculator
-slab.calc = PeriodicMorse()
+slab.calc = EMT()
 
 # Set up a Sella Dynamics object
 dyn = Sella(
     slab,
     constraints=cons,
+    trajectory='test_emt.xyz',
 )
 
 dyn.run(1e-3, 1000)

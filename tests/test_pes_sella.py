@@ -200,3 +200,33 @@ def test_trajectory_file_and_restart(ctx, tmp_path):
     opt2.run(fmax=0.0, steps=3)
     np.testing.assert_allclose(atoms2.positions, ref, atol=1e-9)
     assert opt2.nsteps == opt.nsteps == 7
+
+
+def test_emt_restatement():
+    """EMT (sella_amd.atoms.EMT, unpinned): forces = -dE/dx by central differences on a rattled slab with an
+    adatom, zero forces and an energy minimum near the experimental lattice constant for bulk Cu."""
+    from sella_amd.atoms import EMT, Atoms, add_adsorbate, fcc111
+    slab = fcc111('Cu', (3, 3, 3), vacuum=6.0)
+    add_adsorbate(slab, 'Cu', 1.9, 'fcc')
+    rng = np.random.RandomState(0)
+    slab.positions += 0.05 * rng.normal(size=slab.positions.shape)
+    slab.calc = EMT()
+    f = slab.get_forces()
+    x0 = slab.positions.copy()
+    dv = rng.normal(size=x0.shape)
+    h = 1e-5
+    slab.set_positions(x0 + h * dv)
+    ep = slab.get_potential_energy()
+    slab.set_positions(x0 - h * dv)
+    em = slab.get_potential_energy()
+    assert (ep - em) / (2 * h) == pytest.approx(-(f * dv).sum(), rel=1e-7)
+    a = 3.61
+    base = [(np.array([i, j, k]) + b) * a for i in range(3) for j in range(3) for k in range(3)
+            for b in ([0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5])]
+    e = {}
+    for s_ in (0.98, 1.0, 1.02):
+        bulk = Atoms(['Cu'] * len(base), np.array(base) * s_, cell=np.eye(3) * 3 * a * s_, pbc=True)
+        bulk.calc = EMT()
+        e[s_] = bulk.get_potential_energy() / len(bulk)
+        assert np.abs(bulk.get_forces()).max() < 1e-10
+    assert e[1.0] < e[0.98] and e[1.0] < e[1.02] and abs(e[1.0]) < 0.02

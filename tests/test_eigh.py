@@ -71,7 +71,7 @@ def test_panel_widths_and_variants(ctx):
 
 def test_spectra(ctx):
     rng = np.random.RandomState(1)
-    n = 96 if ctx.backend == 'emu' else 700
+    n = 72 if ctx.backend == 'emu' else 700
     ctx.set_option('eigh_leaf', 8 if ctx.backend == 'emu' else 32)
     for name, A in cases(n, rng):
         check(ctx, A)

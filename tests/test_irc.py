@@ -82,7 +82,7 @@ def test_irc_from_rhombus_saddle(ctx):
         irc = IRC(at, logfile=None, dx=0.1, eta=1e-5, gamma=1e-3, keep_going=True)
         energies = []
         irc.attach(lambda: energies.append(at.get_potential_energy()))
-        irc.run(fmax=5e-3, steps=60, direction=direction)
+        irc.run(fmax=5e-3, steps=25 if ctx.backend == 'emu' else 60, direction=direction)
         assert len(energies) > 3
         assert energies[-1] < e_ts - 0.05                       # went downhill a finite amount
         assert np.all(np.diff(energies[1:]) < 1e-6)             # monotonically

@@ -176,6 +176,15 @@ int sella_stepper_destroy(sella_stepper* st);
 int sella_internals_eval(sella_ctx* ctx, int natoms, int nc, const double* pos, const double* tvec,
                          const double* tangent, double* q, double* grad, double* hvp, double* hess);
 
+/* ---- EMT calculator (far side of the calculator boundary, sella/peswrapper.py:413-418) -------------- */
+/* Energy and gradient of the effective-medium potential (functional form of ase/calculators/emt.py).
+ * pos (n x 3); par (9 x n): per-atom E0, s0, V0, eta2, kappa, lambda, n0, gamma1, gamma2 in eV / Angstrom;
+ * shifts (nshift x 3): lattice translations of the periodic images to include (with the zero vector);
+ * rc, acut, cutoff, beta: cutoff function parameters.  Outputs: *energy, grad (n x 3) = dE/dx.         */
+int sella_emt_eval(sella_ctx* ctx, int n, const double* pos, const double* par, int nshift,
+                   const double* shifts, double rc, double acut, double cutoff, double beta,
+                   double* energy, double* grad);
+
 /* ---- profiling hooks (bench.py roofline leg) ---------------------------------------------- */
 /* When enabled, every launch of the big streaming kernels is bracketed by hipEvents on the
  * context stream.  kind: 0 = row-panel matvec (n x n streams), 1 = gemm, 2 = update, 3 = other,

@@ -62,6 +62,8 @@ SIGNATURES = {
     'sella_stepper_destroy': (c_int, [c_void_p]),
     'sella_internals_eval': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
+    'sella_emt_eval': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_double, c_double, c_double,
+                               c_double, c_double_p, c_void_p]),
     'sella_prof_enable': (c_int, [c_void_p, c_int]),
     'sella_prof_reset': (c_int, [c_void_p]),
     'sella_prof_get': (c_int, [c_void_p, c_int, POINTER(c_long), c_double_p, c_double_p, c_double_p]),

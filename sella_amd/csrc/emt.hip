@@ -1,0 +1,167 @@
+// emt.hip — effective-medium-theory energy and forces (the calculator on the far side of PES.eval,
+// sella/peswrapper.py:413-418).  Functional form and parameter handling of
+// ASE's ase/calculators/emt.py (Jacobsen, Stoltze, Norskov, Surf. Sci. 366, 394 (1996)); ASE is not part of
+// /root/reference, so this is a restatement of the published algorithm, checked against the NumPy
+// restatement in oracle/ and against finite differences of its own energy.
+//
+// All-pairs formulation: one workgroup per atom sweeps every (neighbour, periodic image) pair inside the
+// cutoff — 1024 atoms x 9 images are 9.4 M pair terms per pass, far below anything a neighbour list would
+// pay for itself on this device — and reduces in-block, so energies and forces are deterministic (no atomics).
+//   pass 1: sigma1_i = sum_j dsigma(i <- j), pair energy of atom i
+//   pass 2: cohesive function, dE/dsigma1_i                           (one thread per atom)
+//   pass 3: F_i by gathering both ordered pairs (i <- j) and (j <- i) of every neighbour
+#include "internal.h"
+
+namespace sella {
+namespace {
+
+struct EmtPar {             // per-atom parameters, already converted to eV / Angstrom
+    const double *E0, *s0, *V0, *eta2, *kappa, *lam, *n0, *gamma1, *gamma2;
+};
+
+struct EmtArgs {
+    int n, nshift;
+    const double* pos;      // n x 3
+    const double* shifts;   // nshift x 3 lattice translations (including 0)
+    EmtPar p;
+    double rc, acut, cutoff, beta;
+    double* sigma1; double* epair; double* dEdsig; double* eatom; double* grad;
+};
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void emt_density_kernel(EmtArgs a) {
+    __shared__ double red[4];
+    const int i = blockIdx.x;
+    const double xi = a.pos[3 * i], yi = a.pos[3 * i + 1], zi = a.pos[3 * i + 2];
+    const double n0i = a.p.n0[i], g1i = a.p.gamma1[i], g2i = a.p.gamma2[i], V0i = a.p.V0[i];
+    double sig = 0.0, ep = 0.0;
+    const long total = (long)a.n * a.nshift;
+    for (long t = threadIdx.x; t < total; t += 256) {
+        const int j = (int)(t % a.n), s = (int)(t / a.n);
+        const double dx = a.pos[3 * j] + a.shifts[3 * s] - xi;
+        const double dy = a.pos[3 * j + 1] + a.shifts[3 * s + 1] - yi;
+        const double dz = a.pos[3 * j + 2] + a.shifts[3 * s + 2] - zi;
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        if (r < a.cutoff && r > 1e-8) {
+            const double theta = 1.0 / (1.0 + exp(a.acut * (r - a.rc)));
+            const double chi = a.p.n0[j] / n0i;
+            sig += exp(-a.p.eta2[j] * (r - a.beta * a.p.s0[j])) * chi * theta / g1i;
+            ep += 0.5 * V0i * exp(-a.p.kappa[j] * (r / a.beta - a.p.s0[j])) * chi / g2i * theta;
+        }
+    }
+    sig = block_sum(sig, red);
+    ep = block_sum(ep, red);
+    if (threadIdx.x == 0) {
+        a.sigma1[i] = sig;
+        a.epair[i] = -ep;
+    }
+}
+
+__global__ __launch_bounds__(256) void emt_cohesive_kernel(EmtArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const double sig = a.sigma1[i];
+    const double ds = -log(sig / 12.0) / (a.beta * a.p.eta2[i]);
+    const double xl = a.p.lam[i] * ds, yl = exp(-xl);
+    const double z = 6.0 * a.p.V0[i] * exp(-a.p.kappa[i] * ds);
+    a.eatom[i] = a.p.E0[i] * ((1.0 + xl) * yl - 1.0) + z + a.epair[i];
+    a.dEdsig[i] = (a.p.E0[i] * xl * yl * a.p.lam[i] + z * a.p.kappa[i]) / (sig * a.beta * a.p.eta2[i]);
+}
+
+__global__ __launch_bounds__(256) void emt_force_kernel(EmtArgs a) {
+    __shared__ double red[4];
+    const int i = blockIdx.x;
+    const double xi = a.pos[3 * i], yi = a.pos[3 * i + 1], zi = a.pos[3 * i + 2];
+    const double n0i = a.p.n0[i], g1i = a.p.gamma1[i], g2i = a.p.gamma2[i], V0i = a.p.V0[i];
+    const double eta2i = a.p.eta2[i], kapi = a.p.kappa[i], s0i = a.p.s0[i], dEi = a.dEdsig[i];
+    double gx = 0.0, gy = 0.0, gz = 0.0;
+    const long total = (long)a.n * a.nshift;
+    for (long t = threadIdx.x; t < total; t += 256) {
+        const int j = (int)(t % a.n), s = (int)(t / a.n);
+        const double dx = a.pos[3 * j] + a.shifts[3 * s] - xi;
+        const double dy = a.pos[3 * j + 1] + a.shifts[3 * s + 1] - yi;
+        const double dz = a.pos[3 * j + 2] + a.shifts[3 * s + 2] - zi;
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        if (r < a.cutoff && r > 1e-8) {
+            const double x = exp(a.acut * (r - a.rc));
+            const double theta = 1.0 / (1.0 + x);
+            const double dth = -a.acut * x * theta;             // d(theta)/dr / theta
+            const double chi = a.p.n0[j] / n0i;
+            // ordered pair (i <- j): neighbour j seen from i
+            const double dsig_ij = exp(-a.p.eta2[j] * (r - a.beta * a.p.s0[j])) * chi * theta / g1i;
+            const double y_ij = 0.5 * V0i * exp(-a.p.kappa[j] * (r / a.beta - a.p.s0[j])) * chi / g2i * theta;
+            // ordered pair (j <- i): this atom seen from j (same distance, opposite direction)
+            const double dsig_ji = exp(-eta2i * (r - a.beta * s0i)) / chi * theta / a.p.gamma1[j];
+            const double y_ji = 0.5 * a.p.V0[j] * exp(-kapi * (r / a.beta - s0i)) / chi / a.p.gamma2[j] * theta;
+            // dE/dr of this pair distance, both ordered pairs:  dE/dsigma1 * dsigma/dr - d(pair energy)/dr
+            const double dEdr = dEi * dsig_ij * (-a.p.eta2[j] + dth) - y_ij * (-a.p.kappa[j] / a.beta + dth)
+                                + a.dEdsig[j] * dsig_ji * (-eta2i + dth) - y_ji * (-kapi / a.beta + dth);
+            const double f = dEdr / r;                          // dr/dx_i = -(d / r)
+            gx -= f * dx;
+            gy -= f * dy;
+            gz -= f * dz;
+        }
+    }
+    gx = block_sum(gx, red);
+    gy = block_sum(gy, red);
+    gz = block_sum(gz, red);
+    if (threadIdx.x == 0) {
+        a.grad[3 * i] = gx;
+        a.grad[3 * i + 1] = gy;
+        a.grad[3 * i + 2] = gz;
+    }
+}
+
+}  // namespace
+}  // namespace sella
+
+using namespace sella;
+
+extern "C" int sella_emt_eval(sella_ctx* c, int n, const double* pos, const double* par /* 9 x n */, int nshift,
+                              const double* shifts, double rc, double acut, double cutoff, double beta,
+                              double* energy, double* grad) {
+    if (!c || n <= 0 || !pos || !par || nshift <= 0 || !shifts || !energy || !grad) {
+        set_error("emt_eval: invalid arguments");
+        return SELLA_E_INVALID;
+    }
+    const size_t words = (size_t)3 * n + (size_t)9 * n + (size_t)3 * nshift + (size_t)4 * n + (size_t)3 * n + 64;
+    double* buf;
+    SCHK(scratch_get(c, SCR_MISC0, words * sizeof(double), &buf));
+    double* dpos = buf;
+    double* dpar = dpos + 3 * (size_t)n;
+    double* dsh = dpar + 9 * (size_t)n;
+    double* dsig = dsh + 3 * (size_t)nshift;
+    double* dep = dsig + n;
+    double* dde = dep + n;
+    double* dea = dde + n;
+    double* dgr = dea + n;
+    HIPCHK(hipMemcpyAsync(dpos, pos, (size_t)3 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dpar, par, (size_t)9 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dsh, shifts, (size_t)3 * nshift * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    EmtArgs a;
+    a.n = n; a.nshift = nshift; a.pos = dpos; a.shifts = dsh;
+    a.p.E0 = dpar; a.p.s0 = dpar + n; a.p.V0 = dpar + 2 * (size_t)n; a.p.eta2 = dpar + 3 * (size_t)n;
+    a.p.kappa = dpar + 4 * (size_t)n; a.p.lam = dpar + 5 * (size_t)n; a.p.n0 = dpar + 6 * (size_t)n;
+    a.p.gamma1 = dpar + 7 * (size_t)n; a.p.gamma2 = dpar + 8 * (size_t)n;
+    a.rc = rc; a.acut = acut; a.cutoff = cutoff; a.beta = beta;
+    a.sigma1 = dsig; a.epair = dep; a.dEdsig = dde; a.eatom = dea; a.grad = dgr;
+    hipLaunchKernelGGL(emt_density_kernel, dim3(n), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(emt_cohesive_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(emt_force_kernel, dim3(n), dim3(256), 0, c->stream, a);
+    HIPCHK(hipGetLastError());
+    std::vector<double> ea(n);
+    HIPCHK(hipMemcpyAsync(ea.data(), dea, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(grad, dgr, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double e = 0.0;
+    for (int i = 0; i < n; ++i) e += ea[i];
+    *energy = e;
+    return SELLA_OK;
+}

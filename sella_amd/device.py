@@ -317,6 +317,19 @@ class Context:
                                               ptr(hvp), ptr(hess)))
         return q, grad, hvp, hess
 
+    # ---- EMT calculator -------------------------------------------------------------------------
+    def emt_eval(self, pos, par, shifts, rc, acut, cutoff, beta):
+        """(energy, gradient (n, 3)) of the EMT potential; par (9, n), shifts (nshift, 3)."""
+        pos = as_f64(pos)
+        par = as_f64(par)
+        shifts = as_f64(shifts)
+        n = pos.shape[0]
+        e = c_double(0.0)
+        grad = np.empty((n, 3))
+        check(_lib.lib().sella_emt_eval(self._h, n, ptr(pos), ptr(par), shifts.shape[0], ptr(shifts), float(rc),
+                                        float(acut), float(cutoff), float(beta), byref(e), ptr(grad)))
+        return e.value, grad
+
     # ---- profiling ---------------------------------------------------------------------------
     def prof_enable(self, on=True):
         check(_lib.lib().sella_prof_enable(self._h, int(bool(on))))

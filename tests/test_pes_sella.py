@@ -202,16 +202,21 @@ def test_trajectory_file_and_restart(ctx, tmp_path):
     assert opt2.nsteps == opt.nsteps == 7
 
 
-def test_emt_restatement():
-    """EMT (sella_amd.atoms.EMT, unpinned): forces = -dE/dx by central differences on a rattled slab with an
-    adatom, zero forces and an energy minimum near the experimental lattice constant for bulk Cu."""
+def test_emt_device_against_oracle_and_finite_differences(ctx):
+    """EMT on the device (csrc/emt.hip) against the NumPy restatement (oracle/sella_oracle/emt.py; both unpinned
+    against ASE) and against central differences of its own energy; bulk Cu has zero forces and an energy
+    minimum near the experimental lattice constant."""
+    from oracle.sella_oracle.emt import EMTOracle
     from sella_amd.atoms import EMT, Atoms, add_adsorbate, fcc111
     slab = fcc111('Cu', (3, 3, 3), vacuum=6.0)
     add_adsorbate(slab, 'Cu', 1.9, 'fcc')
     rng = np.random.RandomState(0)
     slab.positions += 0.05 * rng.normal(size=slab.positions.shape)
     slab.calc = EMT()
-    f = slab.get_forces()
+    e, f = slab.get_potential_energy(), slab.get_forces()
+    orc = EMTOracle()
+    assert e == pytest.approx(orc.get_potential_energy(slab), abs=1e-10)
+    np.testing.assert_allclose(f, orc.get_forces(slab), atol=1e-11)
     x0 = slab.positions.copy()
     dv = rng.normal(size=x0.shape)
     h = 1e-5
@@ -230,3 +235,7 @@ def test_emt_restatement():
         e[s_] = bulk.get_potential_energy() / len(bulk)
         assert np.abs(bulk.get_forces()).max() < 1e-10
     assert e[1.0] < e[0.98] and e[1.0] < e[1.02] and abs(e[1.0]) < 0.02
+    # a two-element alloy exercises the chi = n0_j / n0_i asymmetry of the ordered pairs
+    alloy = Atoms(['Cu', 'Ag', 'Au', 'Cu', 'Pt'], rng.normal(size=(5, 3)) * 1.6 + np.arange(5)[:, None] * 1.4)
+    alloy.calc = EMT()
+    np.testing.assert_allclose(alloy.get_forces(), EMTOracle().get_forces(alloy), atol=1e-11)

@@ -1,0 +1,30 @@
+"""EMT force call on the 1024-atom Cu(111) slab of BASELINE configs[1] (device kernels vs the NumPy restatement)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.sella_oracle.emt import EMTOracle  # noqa: E402  (checker)
+from sella_amd.atoms import EMT, fcc111  # noqa: E402
+
+size = tuple(int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (8, 8, 16)
+slab = fcc111('Cu', size, vacuum=7.5)
+rng = np.random.RandomState(0)
+slab.positions += 0.03 * rng.normal(size=slab.positions.shape)
+slab.calc = EMT()
+e = slab.get_potential_energy()
+f = slab.get_forces()
+t0 = time.perf_counter()
+reps = 20
+for r in range(reps):
+    slab.positions[0, 0] += 1e-9
+    slab.get_forces()
+dt = (time.perf_counter() - t0) / reps
+t0 = time.perf_counter()
+orc = EMTOracle()
+eo, fo = orc.get_potential_energy(slab), orc.get_forces(slab)
+dto = time.perf_counter() - t0
+print(f'{len(slab)} atoms: device force call {1e3 * dt:.3f} ms, numpy restatement {1e3 * dto:.1f} ms; '
+      f'|dE| = {abs(e - eo):.2e}, max |dF| = {np.abs(f - fo).max():.2e}')

@@ -17,14 +17,14 @@ slab.calc = EMT()
 e = slab.get_potential_energy()
 f = slab.get_forces()
 t0 = time.perf_counter()
-reps = 20
-for r in range(reps):
-    slab.positions[0, 0] += 1e-9
-    slab.get_forces()
-dt = (time.perf_counter() - t0) / reps
-t0 = time.perf_counter()
 orc = EMTOracle()
 eo, fo = orc.get_potential_energy(slab), orc.get_forces(slab)
 dto = time.perf_counter() - t0
+t0 = time.perf_counter()
+reps = 20
+for r in range(reps):
+    slab.positions[0, 0] += 1e-9                  # defeat the calculator's cache
+    slab.get_forces()
+dt = (time.perf_counter() - t0) / reps
 print(f'{len(slab)} atoms: device force call {1e3 * dt:.3f} ms, numpy restatement {1e3 * dto:.1f} ms; '
       f'|dE| = {abs(e - eo):.2e}, max |dF| = {np.abs(f - fo).max():.2e}')

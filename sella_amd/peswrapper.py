@@ -49,6 +49,16 @@ def _split_cons_subspace(drdx, tol_factor=1e-6):
     n = drdx.shape[1]
     if drdx.shape[0] == 0:
         return np.zeros((n, 0)), shared_identity(n)
+    # Constraints that each pin one Cartesian coordinate (fix_translation on single atoms, the README slab) span a
+    # coordinate subspace: the bases are columns of the identity and no O(n^3) full QR is needed.  Any
+    # orthonormal basis of the same subspaces gives the same projected problem.
+    nz = drdx != 0.0
+    if np.all(nz.sum(axis=1) == 1):
+        cols = np.flatnonzero(nz.any(axis=0))
+        if len(cols) == drdx.shape[0]:
+            free = np.setdiff1d(np.arange(n), cols)
+            eye = shared_identity(n)
+            return eye[:, cols], eye[:, free]
     Q, R, _ = qr(drdx.T, mode='full', pivoting=True, check_finite=False)
     diag = np.abs(np.diag(R))
     ncons = int(np.sum(diag > tol_factor * diag[0])) if diag.size and diag[0] > 0 else 0

@@ -34,18 +34,23 @@ void bordered_root(int mm, const double* D, const double* b, int j, int* origin,
     double bb = 0.0, dmax = 0.0;
     for (int i = 0; i < mm; ++i) { bb += b[i] * b[i]; dmax = std::max(dmax, fabs(D[i])); }
     const double bound = dmax + sqrt(bb) + 1.0;
-    auto f = [&](double shift, double t, double* df) {
-        // mu = shift + t
-        double s = shift + t, ds = 1.0;
+    // value, noise scale and the derivative split at pole index j (left part: poles i < j, right part: i >= j)
+    struct Ev { double f, noise, dl, dr; };
+    auto eval = [&](double shift, double t) {
+        Ev e;
+        double s = 0.0, sa = 0.0, dl = 0.0, dr = 0.0;
         for (int i = 0; i < mm; ++i) {
-            const double den = (D[i] - shift) - t;
-            const double r = 1.0 / den;
+            const double r = 1.0 / ((D[i] - shift) - t);
             const double q = b[i] * b[i] * r;
             s += q;
-            ds += q * r;
+            sa += fabs(q);
+            if (i < j) dl += q * r; else dr += q * r;
         }
-        if (df) *df = ds;
-        return s;
+        e.f = (shift + t) + s;
+        e.noise = fabs(shift + t) + sa;
+        e.dl = dl;
+        e.dr = dr;
+        return e;
     };
     double shift, lo, hi;
     int org;
@@ -55,26 +60,48 @@ void bordered_root(int mm, const double* D, const double* b, int j, int* origin,
     else {
         const double delta = D[j] - D[j - 1];
         if (delta <= 0.0) { *origin = j; *tau = 0.0; return; }      // coincident poles: mu = D_j
-        double fm = f(D[j - 1], 0.5 * delta, nullptr);
+        const double fm = eval(D[j - 1], 0.5 * delta).f;
         if (fm >= 0.0) { org = j - 1; shift = D[j - 1]; lo = 0.0; hi = 0.5 * delta; }
         else { org = j; shift = D[j]; lo = -0.5 * delta; hi = 0.0; }
     }
-    // f is increasing between poles: f(lo) < 0 <= f(hi) (pole ends are never evaluated)
+    // f is increasing between poles: f(lo) < 0 <= f(hi) (pole ends are never evaluated).  Iteration as in the
+    // eigensolver's secular equation (secular.h): the one or two poles next to the root are kept exact, the rest of
+    // the sum is frozen at value and slope ("middle way" rational model), bracket + bisection as the safeguard,
+    // and the stop is |f| below its own rounding noise.  The linear term is carried in the constant of the model.
+    const double EPS = 2.220446049250313e-16;
     double t = 0.5 * (lo + hi);
-    for (int it = 0; it < 300; ++it) {
-        double df;
-        const double fv = f(shift, t, &df);
-        if (fv == 0.0) break;
+    for (int it = 0; it < 200; ++it) {
+        const Ev e = eval(shift, t);
+        const double fv = e.f;
+        if (!(fabs(fv) > 8.0 * EPS * e.noise)) break;
         if (fv < 0.0) lo = t; else hi = t;
-        // Newton on t * f(t): smooth through the origin pole
-        const double h = t * fv, dh = fv + t * df;
-        double tn = (dh != 0.0) ? t - h / dh : 0.5 * (lo + hi);
+        const double df = 1.0 + e.dl + e.dr;
+        double eta;
+        if (j > 0 && j < mm) {
+            const double D1 = (D[j - 1] - shift) - t, D2 = (D[j] - shift) - t;     // < 0 < 
+            const double c_ = fv - D1 * e.dl - D2 * e.dr;
+            const double a_ = (D1 + D2) * fv - D1 * D2 * (e.dl + e.dr);
+            const double b_ = D1 * D2 * fv;
+            if (c_ == 0.0) eta = (a_ != 0.0) ? b_ / a_ : -fv / df;
+            else {
+                const double disc = sqrt(fabs(a_ * a_ - 4.0 * b_ * c_));
+                eta = (a_ <= 0.0) ? (a_ - disc) / (2.0 * c_) : 2.0 * b_ / (a_ + disc);
+            }
+        } else if (j == 0) {
+            const double D2 = (D[0] - shift) - t;                                   // only a pole on the right
+            const double c_ = fv - D2 * e.dr;
+            eta = (c_ < 0.0) ? D2 + e.dr * D2 * D2 / c_ : -fv / df;
+        } else {
+            const double D1 = (D[mm - 1] - shift) - t;                              // only a pole on the left
+            const double c_ = fv - D1 * e.dl;
+            eta = (c_ > 0.0) ? D1 + e.dl * D1 * D1 / c_ : -fv / df;
+        }
+        if (!(fv * eta < 0.0)) eta = -fv / df;
+        double tn = t + eta;
         if (!(tn > lo && tn < hi)) tn = 0.5 * (lo + hi);
         if (tn == lo || tn == hi || tn == t) { t = tn; break; }
-        const double step = fabs(tn - t);
         t = tn;
-        if (step <= 2.220446049250313e-16 * fabs(t)) break;
-        if (hi - lo <= 2.220446049250313e-16 * std::max(fabs(lo), fabs(hi))) break;
+        if (hi - lo <= EPS * std::max(fabs(lo), fabs(hi))) break;
     }
     *origin = org;
     *tau = t;
@@ -218,12 +245,32 @@ extern "C" int sella_stepper_get_s(sella_stepper* st, double alpha, double* s_ou
     double *dx, *dy;
     SCHK(scratch_get(c, SCR_STEP0, (size_t)2 * std::max(ldx, ldy) * sizeof(double), &dx));
     SCHK(scratch_get(c, SCR_STEP1, (size_t)2 * std::max(ldx, ldy) * sizeof(double), &dy));
-    HIPCHK(hipMemcpyAsync(dx, shat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dx + ldx, dshat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // The trust-radius search calls this ~50 times per optimizer step: the four small transfers go through the
+    // pinned exchange buffer (a pageable hipMemcpyAsync is a synchronous staged copy, ~0.1 ms each)
+    const bool pinned = m <= 8192 && nout <= 8192;
+    double* hin = c->hscal + DS_STAGE;
+    double* hout = c->hscal + DS_STAGE + 16384;
+    if (pinned) {
+        memcpy(hin, shat, (size_t)m * sizeof(double));
+        memcpy(hin + m, dshat, (size_t)m * sizeof(double));
+        HIPCHK(hipMemcpyAsync(dx, hin, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(dx + ldx, hin + m, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(dx, shat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(dx + ldx, dshat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
     SCHK(launch_gemv_rows(c, V->d, nout, m, V->ld, dx, ldx, 2, dy, ldy, GemvEpi()));
-    HIPCHK(hipMemcpyAsync(s_out, dy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(dsda_out, dy + ldy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (pinned) {
+        HIPCHK(hipMemcpyAsync(hout, dy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(hout + nout, dy + ldy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(s_out, hout, (size_t)nout * sizeof(double));
+        memcpy(dsda_out, hout + nout, (size_t)nout * sizeof(double));
+    } else {
+        HIPCHK(hipMemcpyAsync(s_out, dy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(dsda_out, dy + ldy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     return SELLA_OK;
 }
 

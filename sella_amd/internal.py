@@ -207,8 +207,27 @@ class Constraints:
         tvec = ncv @ np.asarray(self.atoms.cell, dtype=float)
         return idx, pos, tvec
 
+    def _translation_arrays(self):
+        """Translations as a sparse averaging operator: (row, dof, weight) triplets, rebuilt only when the set of
+        active translation constraints changes (thousands of single-atom pins on a slab: no Python loop per call)."""
+        trans = self._active_list('translations')
+        key = (len(trans), tuple(id(c) for c in trans))
+        hit = getattr(self, '_trans_cache', None)
+        if hit is None or hit[0] != key:
+            rows, dofs, wts = [], [], []
+            for r, c in enumerate(trans):
+                k = len(c.indices)
+                rows += [r] * k
+                dofs += (3 * c.indices + c.kwargs['dim']).tolist()
+                wts += [1.0 / k] * k
+            hit = (key, np.array(rows, dtype=np.int64), np.array(dofs, dtype=np.int64), np.array(wts), len(trans))
+            self._trans_cache = hit
+        return hit[1:]
+
     def calc(self):
-        vals = [np.array([c.calc(self.atoms) for c in self._active_list('translations')])]
+        rows, dofs, wts, nt = self._translation_arrays()
+        x = self.atoms.positions.ravel()
+        vals = [np.bincount(rows, weights=wts * x[dofs], minlength=nt) if nt else np.zeros(0)]
         for name in ('bonds', 'angles', 'dihedrals'):
             idx, pos, tvec = self._gather(name)
             vals.append(evaluate_kind(name, pos, tvec)[0])
@@ -227,13 +246,10 @@ class Constraints:
 
     def jacobian(self):
         """Dense (nactive, 3N) constraint Jacobian."""
-        rows = []
         n3 = self.ndof
-        for c in self._active_list('translations'):
-            r = np.zeros(n3)
-            r[3 * c.indices + c.kwargs['dim']] = 1.0 / len(c.indices)
-            rows.append(r)
-        J = np.array(rows).reshape((len(rows), n3))
+        rows, dofs, wts, nt = self._translation_arrays()
+        J = np.zeros((nt, n3))
+        J[rows, dofs] = wts
         for name in ('bonds', 'angles', 'dihedrals'):
             idx, pos, tvec = self._gather(name)
             if len(idx) == 0:

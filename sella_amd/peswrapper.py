@@ -43,6 +43,21 @@ class _LRU2:
         self._next = 1 - self._next
 
 
+def _pinned_coordinates(drdx):
+    """(column index, value) per row when every constraint pins exactly one distinct Cartesian coordinate
+    (fix_translation on single atoms), else None.  For such constraints the least-squares solves of the glue
+    code (multipliers, linear constraint correction, peswrapper.py:429-438, 475-479) are componentwise divisions."""
+    if drdx.shape[0] == 0:
+        return None
+    nz = drdx != 0.0
+    if not np.all(nz.sum(axis=1) == 1):
+        return None
+    cidx = nz.argmax(axis=1)
+    if len(np.unique(cidx)) != len(cidx):
+        return None
+    return cidx, drdx[np.arange(len(cidx)), cidx]
+
+
 def _split_cons_subspace(drdx, tol_factor=1e-6):
     """(Ucons, Ufree): row space of the constraint Jacobian and its orthogonal complement by
     rank-revealing pivoted QR of drdx^T (peswrapper.py:51-69)."""
@@ -58,7 +73,8 @@ def _split_cons_subspace(drdx, tol_factor=1e-6):
         if len(cols) == drdx.shape[0]:
             free = np.setdiff1d(np.arange(n), cols)
             eye = shared_identity(n)
-            return eye[:, cols], eye[:, free]
+            # (fancy indexing along axis 1 returns a Fortran-ordered array: make the C copy once, not at every upload)
+            return np.ascontiguousarray(eye[:, cols]), np.ascontiguousarray(eye[:, free])
     Q, R, _ = qr(drdx.T, mode='full', pivoting=True, check_finite=False)
     diag = np.abs(np.diag(R))
     ncons = int(np.sum(diag > tol_factor * diag[0])) if diag.size and diag[0] > 0 else 0
@@ -219,7 +235,20 @@ class PES:
         if cached is not None:
             return cached
         drdx = self.get_drdx()
-        Ucons, Ufree = _split_cons_subspace(drdx)
+        pinned = _pinned_coordinates(drdx)
+        self._pinned_cache = (key, pinned)
+        if pinned is not None:
+            # coordinate-pinning constraints: the bases depend on the constraint set only, so the SAME arrays are
+            # handed out at every geometry (downstream caches and device uploads key on the object)
+            sig = pinned[0].tobytes()
+            hit = getattr(self, '_pinned_basis', None)
+            if hit is None or hit[0] != sig:
+                Ucons, Ufree = _split_cons_subspace(drdx)
+                hit = (sig, Ucons, Ufree)
+                self._pinned_basis = hit
+            Ucons, Ufree = hit[1], hit[2]
+        else:
+            Ucons, Ufree = _split_cons_subspace(drdx)
         result = (drdx, Ucons, shared_identity(self.dim), Ufree)
         self._basis_cache.put(key, result)
         return result
@@ -248,7 +277,22 @@ class PES:
         Ucons = self.get_Ucons()
         if Ucons.shape[1] == 0:
             return np.zeros(self.dim)
+        pinned = self._pinned()
+        if pinned is not None and self.int is None:
+            s = np.zeros(self.dim)
+            s[pinned[0]] = -self.get_res() / pinned[1]
+            return s
         return -Ucons @ np.linalg.lstsq(self.get_drdx() @ Ucons, self.get_res(), rcond=None)[0]
+
+    def _pinned(self):
+        """Cached `_pinned_coordinates` of the current constraint Jacobian (it only depends on the constraint
+        set for translation constraints, but is keyed on the geometry like the basis)."""
+        key = self._state_hash()
+        hit = getattr(self, '_pinned_cache', None)
+        if hit is None or hit[0] != key:
+            hit = (key, _pinned_coordinates(PES.get_drdx(self)) if self.int is None else None)
+            self._pinned_cache = hit
+        return hit[1]
 
     def _update(self, feval=True):
         state = self._state_hash()
@@ -280,7 +324,11 @@ class PES:
         elif drdx.shape[0] == 0:
             L = np.zeros(0)
         else:
-            L = np.linalg.lstsq(drdx.T, self.curr['g'], rcond=None)[0]
+            pinned = self._pinned()
+            if pinned is not None:
+                L = self.curr['g'][pinned[0]] / pinned[1]
+            else:
+                L = np.linalg.lstsq(drdx.T, self.curr['g'], rcond=None)[0]
         self.curr['L'] = L
 
     def _update_H(self, dx, dg):

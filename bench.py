@@ -62,6 +62,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--opt-steps', type=int, default=20)
+    ap.add_argument('--emt-steps', type=int, default=10)
     ap.add_argument('--ensemble-per-gpu', type=int, default=8)
     ap.add_argument('--ensemble-steps', type=int, default=20)
     ap.add_argument('--ensemble-n', type=int, default=768)
@@ -285,6 +286,30 @@ def main():
                                          optimizer_steps_per_s=round(nst_tot / tens, 2),
                                          searches_per_s=round(total / tens, 3), seconds=round(tens, 3),
                                          lambda_min_negative=int((res['summary'][:, 4] < 0).sum()))
+        # ---- BASELINE configs[1] as named: 1024-atom Cu(111) EMT slab (3N = 3072), one surface atom lifted onto a
+        # bridge site, lower half frozen by translation constraints (the README pattern), default Sella settings,
+        # device EMT calculator.  Host-glue bound (Python between sub-millisecond kernels), reported for the record.
+        if args.emt_steps > 0 and world == 1:
+            from sella_amd.atoms import EMT
+            from tools.emt_slab_opt import make_slab
+            slab = make_slab()
+            cons_s = Constraints(slab)
+            for atom in slab:
+                if atom.position[2] < slab.cell[2, 2] / 2.:
+                    cons_s.fix_translation(atom.index)
+            slab.calc = EMT()
+            dyn = Sella(slab, constraints=cons_s, logfile=None)
+            dyn.run(0.0, 2)
+            ctx.sync()
+            nc0 = slab.calc.ncalls
+            tse = time.perf_counter()
+            dyn.run(0.0, args.emt_steps)
+            ctx.sync()
+            tsl = time.perf_counter() - tse
+            opt_stats['emt_slab'] = dict(atoms=len(slab), n=3 * len(slab), nfree=int(dyn.pes.get_Ufree().shape[1]),
+                                         steps=args.emt_steps, optimizer_steps_per_s=round(args.emt_steps / tsl, 2),
+                                         ms_per_step=round(1e3 * tsl / args.emt_steps, 1),
+                                         force_calls=int(slab.calc.ncalls - nc0), rs='ras', calculator='EMT (device)')
         _dev._default = None
 
     times = [elapsed]

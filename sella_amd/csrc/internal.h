@@ -95,6 +95,7 @@ struct Options {
     long panel_mfma = 1;     // 1: products with more than 8 right-hand sides stream the matrix once (MFMA panel kernel)
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
+    long eigh_graph = 1;     // 1: replay the tridiagonalisation launch chain from a cached hipGraph (n >= 512)
 };
 
 }  // namespace sella
@@ -127,6 +128,15 @@ struct sella_ctx {
     sella::ProfSlot slots[sella::PROF_NKIND];
     char name[256] = {0};
     int num_cu = 256;
+    // Captured launch chains of the tridiagonalisation (eigh.hip), keyed by size and buffer addresses.
+    struct TrdGraph {
+        int n, ld, nb;
+        const void* ptr[4];
+        hipGraphExec_t exec;
+        unsigned long stamp;
+    };
+    std::vector<TrdGraph> trd_graphs;
+    unsigned long trd_stamp = 0;
 };
 
 namespace sella {

@@ -422,6 +422,40 @@ class InternalCoordinates:
             row += nc
         return B
 
+    def jacobian_csr(self):
+        """The same B-matrix in CSR form, 6 / 9 / 12 stored entries per row (the sparsity the reference keeps
+        for D(v) only, internal.py:1481-1527) — what `InternalPES` works with, so that nothing of size
+        nint x 3N is ever dense on the way to the pseudo-inverse."""
+        from scipy.sparse import csr_matrix
+        data, cols, counts = [], [], []
+        for k in self._order:
+            pos, tvec, dofs = self._batch(k)
+            nc = len(pos)
+            if nc:
+                data.append(evaluate_kind(k, pos, tvec, hessian=False)[1].reshape(-1))
+                cols.append(dofs.reshape(-1))
+                counts.append(np.full(nc, dofs.shape[1], dtype=np.int64))
+        if not data:
+            return csr_matrix((0, self.ndof))
+        indptr = np.concatenate([[0], np.cumsum(np.concatenate(counts))])
+        return csr_matrix((np.concatenate(data), np.concatenate(cols), indptr), shape=(self.nint, self.ndof))
+
+    def hessian_rdot_mult(self, v, W):
+        """D(v) @ W for W (3N, k) without forming D(v): (nint, k)."""
+        v = np.asarray(v, dtype=np.float64).ravel()
+        W = np.asarray(W, dtype=np.float64).reshape(self.ndof, -1)
+        out = np.zeros((self.nint, W.shape[1]))
+        row = 0
+        for k in self._order:
+            pos, tvec, dofs = self._batch(k)
+            nc = len(pos)
+            if nc:
+                tan = v[dofs].reshape(pos.shape)
+                hv = evaluate_kind(k, pos, tvec, tangent=tan, hessian=False)[3].reshape(nc, -1)
+                out[row:row + nc] = np.einsum('ia,iak->ik', hv, W[dofs])
+            row += nc
+        return out
+
     def hessian_rdot(self, v):
         """D(v)_i = H_i v as a dense (nint, 3N) matrix (internal.py:2307-2575: one HVP per coordinate)."""
         v = np.asarray(v, dtype=np.float64).ravel()
@@ -527,7 +561,7 @@ def _ic_radii(self):
     return np.array([covalent_radius(s) for s in self.atoms.symbols])
 
 
-def _ic_guess_hessian(self):
+def _ic_guess_hessian(self, diagonal_only=False):
     """Diagonal model Hessian in the internal coordinates (internal.py:3738-3820: the Schlegel-type
     exponential formulas of `_h0_bond`, `_h0_angle`, `_h0_dihedral`)."""
     rc = _ic_radii(self)
@@ -554,7 +588,7 @@ def _ic_guess_hessian(self):
         L = nbonds_of[d[:, 1]] + nbonds_of[d[:, 2]] - 2
         h0[nb + na:] = (0.0015 + 14.0 * np.maximum(L, 0) ** 0.57 * np.exp(-2.85 * (rbc - cbc) / _BOHR)
                         / (rbc * cbc / _BOHR ** 2) ** 4.00) * _HARTREE
-    return np.diag(np.abs(h0))
+    return np.abs(h0) if diagonal_only else np.diag(np.abs(h0))
 
 
 def _ic_check_bad(self, tol=np.pi / 36):

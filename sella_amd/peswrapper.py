@@ -444,25 +444,131 @@ class PES:
 # object.  Not built: dummy atoms and the re-generation of internals when an angle becomes linear
 # (`update_internals`, :1126-1172 — a RuntimeError is raised instead), the Newton "iterative stepper"
 # shortcut (:742-838; the ODE path it falls back to is the one implemented), cell degrees of freedom.
-# The heavy pieces run on the device: B-matrix rows and D(v) = H_i v (csrc/internals.hip), the economy
-# QR of B (`sella_qr_thin`, the reference's `_gpu_qr`, :691), the Hessian algebra as for `PES`.
+# The heavy pieces run on the device: B-matrix rows and D(v) = H_i v (csrc/internals.hip), the range basis
+# and pseudo-inverse of B through the device eigensolver (`_BFactor`, in place of the reference's
+# `_gpu_qr` + SVD, :691-709), the Hessian algebra as for `PES`.
 # Parity: the reference class needs ASE + JAX and cannot be imported in the build container, so this
 # restatement is property-tested only (tests/test_internal_pes.py) — unpinned.
 # ------------------------------------------------------------------------------------------------
 from scipy.integrate import LSODA  # noqa: E402
-from scipy.linalg import solve_triangular  # noqa: E402
 
 from .internal import InternalCoordinates  # noqa: E402
 
 
-def _range_space_projector(B):
-    """Orthogonal projector onto range(B) with rank truncation via pivoted QR (peswrapper.py:72-82)."""
-    Q, R, _ = qr(B, mode='full', pivoting=True, check_finite=False)
-    rdiag = np.abs(np.diag(R))
-    rcond = max(B.shape) * np.finfo(B.dtype).eps
-    nkeep = int(np.sum(rdiag > rcond * rdiag[0])) if rdiag.size and rdiag[0] > 0 else 0
-    Qr = Q[:, :nkeep]
-    return Qr @ Qr.T
+class _BFactor:
+    """B = dq/dx (nint x 3N) held sparse together with the spectral factor of its Gram matrix.
+
+    The reference takes an economy QR of the dense B and, because B never has full column rank without
+    TRIC coordinates (the rigid-body motions are in its null space), falls through to a dense SVD
+    (peswrapper.py:674-709) to get the range basis Q and the pseudo-inverse.  Both follow from the
+    eigendecomposition of the small Gram matrix — G = B^T B = V L V^T (3N x 3N) when nint >= 3N, else
+    G = B B^T — which is assembled from the sparse rows and diagonalised by the device eigensolver:
+
+        Q = B V_r L_r^-1/2   R = L_r^1/2 V_r^T   B^+ = M B^T,  M = V_r L_r^-1 V_r^T   (device resident)
+
+    (singular values s_i = sqrt(l_i) > 1e-6 kept, like `Si > 1e-6` in the reference).  B^+ y is then one
+    sparse product and one symmetric matrix-panel product on the device; nothing of size nint x 3N is
+    formed unless a caller asks for the dense pseudo-inverse.  The pseudo-inverse is unique, Q is one of
+    the (equally arbitrary) orthonormal bases of range(B)."""
+
+    def __init__(self, Bs, tol=1e-6):
+        ctx = get_context()
+        self.Bs = Bs.tocsr()
+        self.BsT = Bs.T.tocsr()
+        nint, nx = Bs.shape
+        self.shape = (nint, nx)
+        self.left = nint < nx                       # Gram matrix on the short side
+        G = ((self.Bs @ self.BsT) if self.left else (self.BsT @ self.Bs)).toarray()
+        n = G.shape[0]
+        if n == 0:
+            self.rank, self.s, self.M = 0, np.zeros(0), None
+            self._Q, self._R, self.BinvQ, self._dense = np.zeros((nint, 0)), np.zeros((0, nx)), np.zeros((nx, 0)), None
+            return
+        hG = ctx.upload(G)
+        w, V, Vt = ctx.eigh(hG)
+        hG.free()
+        V.free()
+        floor = max(tol * tol, 64 * n * np.finfo(float).eps * max(w[-1], 0.0))
+        keep = np.flatnonzero(w > floor)[::-1]                    # descending singular values
+        Vr = Vt.numpy()[keep]                                     # (r, n): eigenvectors as rows
+        Vt.free()
+        self.s = np.sqrt(w[keep])
+        self.rank = len(keep)
+        X = np.ascontiguousarray(Vr / self.s[:, None])            # rows v_i / s_i
+        hX = ctx.upload(X)
+        self.M = ctx.zeros(n, n)
+        ctx.gemm(hX, hX, self.M, transA=True)                     # M = V_r L_r^-1 V_r^T
+        hX.free()
+        self._Vr = Vr
+        self.BinvQ = None if self.left else np.ascontiguousarray(X.T)        # B^+ Q = V_r L_r^-1/2
+        self._Q = self._R = self._dense = None
+        if self.left:
+            self._Q = np.ascontiguousarray(Vr.T)                  # left singular vectors
+            self._R = np.ascontiguousarray((self.BsT @ self._Q).T)          # Q^T B
+            self.BinvQ = np.ascontiguousarray(self._R.T / (self.s ** 2)[None, :])
+
+    @property
+    def Q(self):
+        """Orthonormal basis of range(B), (nint, rank) — dense, formed on first use."""
+        if self._Q is None:
+            self._Q = np.ascontiguousarray(self.Bs @ self.BinvQ)
+        return self._Q
+
+    @property
+    def R(self):
+        if self._R is None:
+            self._R = self.s[:, None] * self._Vr
+        return self._R
+
+    def pinv_dot(self, Y):
+        """B^+ Y for Y (nint,) or (nint, k)."""
+        if self.M is None or np.size(Y) == 0:
+            return np.zeros((self.shape[1],) + np.shape(Y)[1:])
+        ctx = get_context()
+        if self.left:
+            return self.BsT @ ctx.symm_mm(self.M, Y)
+        return ctx.symm_mm(self.M, self.BsT @ Y)
+
+    def pinvT_dot(self, Y):
+        """(B^+)^T Y for Y (3N,) or (3N, k) — e.g. the Cartesian gradient -> internal gradient."""
+        if self.M is None or np.size(Y) == 0:
+            return np.zeros((self.shape[0],) + np.shape(Y)[1:])
+        ctx = get_context()
+        if self.left:
+            return ctx.symm_mm(self.M, self.Bs @ Y)
+        return self.Bs @ ctx.symm_mm(self.M, Y)
+
+    def pinv(self):
+        """Dense B^+ (3N x nint)."""
+        if self._dense is None:
+            if self.M is None:
+                self._dense = np.zeros(self.shape[::-1])
+            else:
+                M = self.M.numpy()
+                self._dense = np.asarray(self.BsT @ M) if self.left else np.ascontiguousarray(np.asarray(self.Bs @ M).T)
+        return self._dense
+
+    def project_diag(self, h):
+        """P diag(h) P with P = Q Q^T the projector onto range(B) (`_range_space_projector`,
+        peswrapper.py:72-82, applied as in :644-650): three device GEMMs."""
+        nint = self.shape[0]
+        if self.rank == 0:
+            return np.zeros((nint, nint))
+        ctx = get_context()
+        hQ = ctx.upload(self.Q)
+        hQh = ctx.upload(self.Q * np.asarray(h)[:, None])
+        hT = ctx.zeros(self.rank, self.rank)
+        ctx.gemm(hQ, hQh, hT, transA=True)
+        hQh.free()
+        hZ = ctx.zeros(nint, self.rank)
+        ctx.gemm(hQ, hT, hZ)
+        hT.free()
+        hH = ctx.zeros(nint, nint)
+        ctx.gemm(hZ, hQ, hH, transB=True)
+        H = hH.numpy()
+        for hnd in (hQ, hZ, hH):
+            hnd.free()
+        return 0.5 * (H + H.T)
 
 
 class InternalPES(PES):
@@ -475,6 +581,8 @@ class InternalPES(PES):
         if new_int.cons is None:
             new_int.cons = Constraints(atoms)
         kwargs.pop('constraints', None)
+        self._factor_cache = _LRU2()
+        self._Hc_cache = _LRU2()
         PES.__init__(self, atoms, *args, constraints=new_int.cons, H0=None, proj_trans=False, proj_rot=False,
                      **kwargs)
         self.int = new_int
@@ -482,56 +590,27 @@ class InternalPES(PES):
         self.ncart = self.int.ndof
         if H0 is None:
             # guess Hessian with the components in the infeasible (redundant) subspace zeroed, :644-650
-            B = self.int.jacobian()
-            P = _range_space_projector(B)
-            self.set_H(P @ self.int.guess_hessian() @ P, initialized=False)
+            self.set_H(self._get_factor().project_diag(self.int.guess_hessian(diagonal_only=True)), initialized=False)
         else:
             self.set_H(H0, initialized=True)
         self.bad_int = None
         self.exact_geodesic = exact_geodesic
-        self._pinv_cache = _LRU2()
-        self._qr_cache = _LRU2()
-        self._Hc_cache = _LRU2()
 
-    # ---- B = dq/dx: economy QR shared by the basis and the pseudo-inverse (:674-736) ------------------
-    def _get_jacobian_qr(self):
+    # ---- B = dq/dx: range basis and pseudo-inverse from one factorisation (:674-736) -------------------
+    def _get_factor(self):
         key = self._state_hash()
-        cached = self._qr_cache.get(key)
-        if cached is not None:
-            return cached
-        B = self.int.jacobian()
-        if B.shape[0] >= B.shape[1]:
-            Q, R = get_context().qr_thin(B)                   # _gpu_qr(B), peswrapper.py:691
-        else:
-            Q, R = qr(B, mode='economic', check_finite=False)
-        rdiag = np.abs(np.diag(R))
-        if len(rdiag) > 0 and rdiag.min() < 1e-6 * rdiag.max():
-            # rank deficient (always the case for a free molecule: 6 rigid-body modes): SVD truncation
-            Ui, Si, VTi = np.linalg.svd(B, full_matrices=False)
-            nnred = int(np.sum(Si > 1e-6))
-            Q = Ui[:, :nnred]
-            R = np.diag(Si[:nnred]) @ VTi[:nnred]
-            self._pinv_cache.put(key, VTi[:nnred].T @ np.diag(1.0 / Si[:nnred]) @ Ui[:, :nnred].T)
-        self._qr_cache.put(key, (Q, R))
-        return Q, R
+        cached = self._factor_cache.get(key)
+        if cached is None:
+            cached = _BFactor(self.int.jacobian_csr())
+            self._factor_cache.put(key, cached)
+        return cached
+
+    def _get_jacobian_qr(self):
+        fac = self._get_factor()
+        return fac.Q, fac.R
 
     def _get_Binv(self):
-        key = self._state_hash()
-        cached = self._pinv_cache.get(key)
-        if cached is not None:
-            return cached
-        Q, R = self._get_jacobian_qr()
-        cached = self._pinv_cache.get(key)                  # the SVD branch above fills it
-        if cached is not None:
-            return cached
-        if R.size == 0:
-            Binv = np.empty((3 * len(self.atoms), 0))
-        elif R.shape[0] == R.shape[1]:
-            Binv = solve_triangular(R, Q.T, check_finite=False)
-        else:
-            Binv = np.linalg.pinv(self.int.jacobian())
-        self._pinv_cache.put(key, Binv)
-        return Binv
+        return self._get_factor().pinv()
 
     # ---- geodesic position update (:840-880, :1200-1221) ----------------------------------------------
     def _q_ode(self, t, y):
@@ -540,21 +619,21 @@ class InternalPES(PES):
         dydt = np.zeros((3, nx))
         dydt[0] = dxdt
         self.atoms.positions = x.reshape((-1, 3)).copy()
-        D_rdot = self.int.hessian_rdot(dxdt)                   # (nint, nx): rows H_i dxdt, one device launch per kind
-        Binv = self._get_Binv() if self.exact_geodesic else self._ode_Binv
-        out = -Binv @ (D_rdot @ np.column_stack((dxdt, g)))    # (nx, 2)
+        # rows of D(dxdt) are H_i dxdt (one device launch per kind); only D @ [dxdt, g] is needed
+        fac = self._get_factor() if self.exact_geodesic else self._ode_factor
+        out = -fac.pinv_dot(self.int.hessian_rdot_mult(dxdt, np.column_stack((dxdt, g))))    # (nx, 2)
         dydt[1] = out[:, 0]
         dydt[2] = out[:, 1]
         return dydt.ravel()
 
     def _set_x_ode(self, target):
         dx = self.wrap_dx(target - self.get_x())
-        Binv = self._get_Binv()
-        self._ode_Binv = Binv
+        fac = self._get_factor()
+        self._ode_factor = fac
         g_int = self.curr.get('g')
         if g_int is None:
             g_int = np.zeros_like(dx)
-        y0 = np.hstack((self.apos.ravel(), Binv @ dx, Binv @ g_int))
+        y0 = np.hstack((self.apos.ravel(), fac.pinv_dot(np.column_stack((dx, g_int))).T.ravel()))
         ode = LSODA(self._q_ode, 0.0, y0, t_bound=1.0, atol=1e-6)
         t0, y = 0.0, y0
         while ode.status == 'running':
@@ -570,8 +649,8 @@ class InternalPES(PES):
         nx = 3 * len(self.atoms)
         y = y.reshape((3, nx))
         self.atoms.positions = y[0].reshape((-1, 3))
-        B = self.int.jacobian()
-        return t0 * dx, t0 * B @ y[1], B @ y[2]
+        B = self.int.jacobian_csr()
+        return t0 * dx, t0 * (B @ y[1]), B @ y[2]
 
     def set_x(self, target):
         dx_initial, dx_final_ode, g_final = self._set_x_ode(target)
@@ -596,7 +675,7 @@ class InternalPES(PES):
             if Ucons.shape[1] == 0:
                 return moved
             s = np.linalg.lstsq(drdx @ Ucons, -r, rcond=None)[0]
-            dx = self._get_Binv() @ (Ucons @ s)
+            dx = self._get_factor().pinv_dot(Ucons @ s)
             if np.linalg.norm(dx, ord=np.inf) > safety_limit:
                 return moved
             self.atoms.positions = self.atoms.positions + dx.reshape(-1, 3)
@@ -619,14 +698,15 @@ class InternalPES(PES):
     def _compute_Hc_int(self):
         if self.curr['L'] is None:
             raise RuntimeError("InternalPES.get_Hc() called with L=None.")
-        Binv = self._get_Binv()
-        n_dof = Binv.shape[1]
+        fac = self._get_factor()
+        n_dof = fac.shape[0]
         if self.curr['L'].size == 0:
             return np.zeros((n_dof, n_dof))
         D_cons = self.cons.hessian().ldot(self.curr['L'])
-        L_int = self.curr['L'] @ self.cons.jacobian() @ Binv
+        L_int = fac.pinvT_dot(self.curr['L'] @ self.cons.jacobian())
         D_int = self.int.hessian().ldot(L_int)
-        return Binv.T @ (D_cons - D_int) @ Binv
+        # Binv^T D Binv with D symmetric (3N x 3N)
+        return fac.pinvT_dot(fac.pinvT_dot(D_cons - D_int).T)
 
     def get_Hc(self):
         key = self._state_hash()
@@ -640,19 +720,16 @@ class InternalPES(PES):
         return True                      # in internal space even a fixed translation has a curvature term
 
     def get_drdx(self):
-        return PES.get_drdx(self) @ self._get_Binv()          # dr/dq = dr/dx dx/dq
+        return self._get_factor().pinvT_dot(PES.get_drdx(self).T).T     # dr/dq = dr/dx dx/dq
 
     def _compute_basis_int(self):
-        Q, R = self._get_jacobian_qr()
-        Unred = Q
+        fac = self._get_factor()
+        Unred = Q = fac.Q
         n_int = Q.shape[0]
         cons_jac = self.cons.jacobian()
         if cons_jac.shape[0] == 0:
             return np.zeros((0, n_int)), np.zeros((n_int, 0)), Unred, Unred
-        if R.shape[0] == R.shape[1]:
-            drdxnred = solve_triangular(R.T, cons_jac.T, lower=True, check_finite=False).T
-        else:
-            drdxnred = cons_jac @ (self._get_Binv() @ Q)
+        drdxnred = cons_jac @ fac.BinvQ                    # dr/dx B^+ Q
         Vcons, Vfree = _split_cons_subspace(drdxnred)
         return drdxnred @ Q.T, Unred @ Vcons, Unred, Unred @ Vfree
 
@@ -667,7 +744,7 @@ class InternalPES(PES):
     # ---- calculator boundary: Cartesian gradient -> internal (:1124-1127) ---------------------------------
     def eval(self):
         f, g_cart = PES.eval(self)
-        return f, g_cart @ self._get_Binv()
+        return f, self._get_factor().pinvT_dot(g_cart)
 
     def get_df_pred(self, dx, g, H):                                                    # :1174-1181
         if H is None:
@@ -682,13 +759,13 @@ class InternalPES(PES):
         Ufree = self.get_Ufree()
         B = self.curr.get('B')
         if B is None:
-            B = self.int.jacobian()
-        return -((Ufree @ (Ufree.T @ g)) @ B).reshape((-1, 3))
+            B = self.int.jacobian_csr()
+        return -np.asarray((Ufree @ (Ufree.T @ g)) @ B).reshape((-1, 3))
 
     def _update(self, feval=True):
         if not PES._update(self, feval=feval):
             return
-        self.curr.update(B=self.int.jacobian(), Binv=self._get_Binv())
+        self.curr.update(B=self._get_factor().Bs)
         return True
 
     def kick(self, dx, diag=False, **diag_kwargs):

@@ -212,3 +212,14 @@ hipError_t hipGetLastError();
 hipError_t hipPeekAtLastError();
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b);
+// Graph capture is not emulated: hipStreamBeginCapture reports failure and the library issues the
+// launches directly (the branch it also takes on a device whose stream cannot capture).
+typedef struct hipemu_graph_t* hipGraph_t;
+typedef struct hipemu_graphexec_t* hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorInvalidValue; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorInvalidValue; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, void*, void*, size_t) { *e = nullptr; return hipErrorInvalidValue; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorInvalidValue; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }

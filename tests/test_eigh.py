@@ -87,6 +87,25 @@ def test_benchmark_size(ctx):
     check(ctx, P, tol=2e-12)
 
 
+@pytest.mark.gpu
+def test_graph_replay(ctx):
+    """The tridiagonalisation chain is captured once per size and replayed (eigh.hip): the replays must act on
+    the matrix of the current call, also across other sizes in between and with the feature switched off."""
+    if ctx.backend != 'hip':
+        pytest.skip('hardware only (capture is not emulated)')
+    rng = np.random.RandomState(5)
+    mats = {n: [m for _, m in zip(range(2), (a for _, a in cases(n, rng)))] for n in (640, 777)}
+    ref = {}
+    ctx.set_option('eigh_graph', 0)
+    for n in mats:
+        ref[n] = [check(ctx, A) for A in mats[n]]
+    ctx.set_option('eigh_graph', 1)
+    for rep in range(3):
+        for n in mats:
+            for k, A in enumerate(mats[n]):
+                np.testing.assert_array_equal(check(ctx, A), ref[n][k])
+
+
 def _rank1_check(ctx, D, w, rho, tol=2e-14):
     K = len(D)
     lam, Ut = ctx.rank1_eig(D, w, rho)

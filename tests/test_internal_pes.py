@@ -147,3 +147,50 @@ def test_internal_search_with_fixed_bond(ctx):
     assert abs(d_i - 1.60) < 1e-5
     assert abs(at_i.get_potential_energy() - at_c.get_potential_energy()) < 1e-5
     assert dyn_i.pes.get_res().size == 1 and abs(dyn_i.pes.get_res()[0]) < 1e-5
+
+
+@pytest.mark.parametrize('case', ['tall', 'wide', 'slab'])
+def test_spectral_factor_matches_svd(ctx, case):
+    """`_BFactor` (Gram matrix + device eigensolver) against the dense SVD the reference falls through to
+    (peswrapper.py:696-709): same pseudo-inverse, an orthonormal basis of the same range, and the
+    projected guess Hessian P H0 P of :644-650."""
+    from sella_amd.atoms import fcc111
+    from sella_amd.internal import InternalCoordinates, neighbour_bonds
+    from sella_amd.peswrapper import _BFactor
+    if case == 'slab':
+        at = fcc111('Cu', (3, 3, 3), vacuum=6.0)
+        at.positions += 0.05 * np.random.RandomState(3).normal(size=at.positions.shape)
+        b, nc = neighbour_bonds(at, 1.25 * 3.61 / np.sqrt(2))
+        ic = InternalCoordinates(at, bonds=b, bond_ncvecs=nc)
+    else:
+        at = chain(7 if case == 'tall' else 4)
+        ic = InternalCoordinates.from_atoms(at, dihedrals=(case == 'tall'))
+        if case == 'wide':
+            ic = InternalCoordinates(at, bonds=ic.idx['bonds'])         # 3 internals, 12 Cartesians
+    B = ic.jacobian()
+    Bs = ic.jacobian_csr()
+    np.testing.assert_array_equal(Bs.toarray(), B)
+    fac = _BFactor(Bs)
+    U, S, VT = np.linalg.svd(B, full_matrices=False)
+    r = int(np.sum(S > 1e-6))
+    assert fac.rank == r and fac.left == (B.shape[0] < B.shape[1])
+    np.testing.assert_allclose(fac.s, S[:r], rtol=1e-9)
+    pinv = VT[:r].T @ np.diag(1.0 / S[:r]) @ U[:, :r].T
+    scale = np.abs(pinv).max()
+    np.testing.assert_allclose(fac.pinv(), pinv, atol=1e-9 * scale)
+    np.testing.assert_allclose(fac.Q.T @ fac.Q, np.eye(r), atol=1e-9)
+    np.testing.assert_allclose(fac.Q @ fac.R, B, atol=1e-9)
+    np.testing.assert_allclose(fac.Q @ fac.Q.T, U[:, :r] @ U[:, :r].T, atol=1e-9)
+    np.testing.assert_allclose(fac.BinvQ, pinv @ fac.Q, atol=1e-9 * scale)
+    rng = np.random.RandomState(0)
+    Y = rng.normal(size=(B.shape[0], 3))
+    G = rng.normal(size=(B.shape[1], 2))
+    np.testing.assert_allclose(fac.pinv_dot(Y), pinv @ Y, atol=1e-9 * scale)
+    np.testing.assert_allclose(fac.pinv_dot(Y[:, 0]), pinv @ Y[:, 0], atol=1e-9 * scale)
+    np.testing.assert_allclose(fac.pinvT_dot(G), pinv.T @ G, atol=1e-9 * scale)
+    h = np.exp(rng.normal(size=B.shape[0]))
+    P = U[:, :r] @ U[:, :r].T
+    np.testing.assert_allclose(fac.project_diag(h), P @ np.diag(h) @ P, atol=1e-9 * h.max())
+    # D(v) W without the dense D(v)
+    v = rng.normal(size=B.shape[1])
+    np.testing.assert_allclose(ic.hessian_rdot_mult(v, G), ic.hessian_rdot(v) @ G, atol=1e-12)

@@ -1135,10 +1135,12 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     double* colscal = W.vec + (size_t)V_COL * ld;
     double* cdots = partB + maxblkB + 8;               // 2 * TRD_NBMAX doubles
     // The chain below is ~2n dependent launches whose arguments depend only on n and on the buffer
-    // addresses: it is captured once per (size, buffers) into a hipGraph and replayed afterwards — measured
-    // on this stack (tools/lab/graph_lab.hip), a replayed chain costs 2.0 us per launch against 3.4 us
-    // for the same launches issued one by one on the stream.  Profiling runs (event pairs attached to single
-    // dispatches) and small problems use the stream path.
+    // addresses, so it can be captured once per (size, buffers) into a hipGraph and replayed (option
+    // `eigh_graph`).  Measured on this stack: a replayed chain of EMPTY kernels costs 2.0 us per launch
+    // against 3.4 us issued one by one (tools/lab/graph_lab.hip), but the real chain does not get faster
+    // (38.4 ms replayed, 37.5 ms streamed at n = 3072): each kernel's duration is its own dependent
+    // memory round trips on data the previous kernel wrote from other XCDs, and the dispatch of the next
+    // launch already overlaps with them.  Hence off by default.
     auto enqueue = [&]() -> int {
     int cur = 0, nblkA_prev = 0, nblkB_prev = 0;
     for (int j0 = 0; j0 < nrefl; j0 += nb) {

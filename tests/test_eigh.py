@@ -89,8 +89,8 @@ def test_benchmark_size(ctx):
 
 @pytest.mark.gpu
 def test_graph_replay(ctx):
-    """The tridiagonalisation chain is captured once per size and replayed (eigh.hip): the replays must act on
-    the matrix of the current call, also across other sizes in between and with the feature switched off."""
+    """Option `eigh_graph`: the tridiagonalisation chain is captured once per size and replayed (eigh.hip); the
+    replays must act on the matrix of the current call, also with other sizes in between."""
     if ctx.backend != 'hip':
         pytest.skip('hardware only (capture is not emulated)')
     rng = np.random.RandomState(5)
@@ -100,10 +100,13 @@ def test_graph_replay(ctx):
     for n in mats:
         ref[n] = [check(ctx, A) for A in mats[n]]
     ctx.set_option('eigh_graph', 1)
-    for rep in range(3):
-        for n in mats:
-            for k, A in enumerate(mats[n]):
-                np.testing.assert_array_equal(check(ctx, A), ref[n][k])
+    try:
+        for rep in range(3):
+            for n in mats:
+                for k, A in enumerate(mats[n]):
+                    np.testing.assert_array_equal(check(ctx, A), ref[n][k])
+    finally:
+        ctx.set_option('eigh_graph', 0)
 
 
 def _rank1_check(ctx, D, w, rho, tol=2e-14):

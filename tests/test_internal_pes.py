@@ -194,3 +194,40 @@ def test_spectral_factor_matches_svd(ctx, case):
     # D(v) W without the dense D(v)
     v = rng.normal(size=B.shape[1])
     np.testing.assert_allclose(ic.hessian_rdot_mult(v, G), ic.hessian_rdot(v) @ G, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_config2_geodesic_step(ctx):
+    """BASELINE configs[2] at full size (1024-atom Cu(111) slab, nearest-neighbour bonds, device EMT) through
+    size-independent properties: B B^+ B = B, the geodesic step meets a feasible target to second order in the
+    step, the transported gradient keeps its length, and the energy change of a small step matches g_int . dq."""
+    if ctx.backend != 'hip':
+        pytest.skip('hardware only (3N = 3072)')
+    from sella_amd.atoms import EMT, fcc111
+    from sella_amd.internal import InternalCoordinates, neighbour_bonds
+    from sella_amd.peswrapper import InternalPES
+    slab = fcc111('Cu', (8, 8, 16), vacuum=7.5)
+    rng = np.random.RandomState(0)
+    slab.positions += 0.03 * rng.normal(size=slab.positions.shape)
+    slab.calc = EMT()
+    bonds, ncv = neighbour_bonds(slab, 1.25 * 3.61 / np.sqrt(2))
+    pes = InternalPES(slab, InternalCoordinates(slab, bonds=bonds, bond_ncvecs=ncv))
+    fac = pes._get_factor()
+    assert fac.shape == (len(bonds), 3072) and fac.rank == 3069          # three translations in the null space
+    probe = fac.Bs @ rng.normal(size=(3072, 2))
+    np.testing.assert_allclose(fac.Bs @ fac.pinv_dot(probe), probe, atol=1e-11 * np.abs(probe).max())
+    x0, q0, f0 = slab.positions.copy(), pes.get_x(), pes.get_f()
+    g0 = pes.get_g()
+    for step, tol in ((0.02, 3e-4), (0.002, 3e-6)):
+        slab.positions = x0 + step * rng.normal(size=x0.shape)
+        q1 = pes.int.calc()
+        slab.positions = x0.copy()
+        pes.get_g()
+        dx_i, dx_f, g_par = pes.set_x(q1)
+        dq = np.abs(q1 - q0).max()
+        assert np.abs(pes.int.calc() - q1).max() < tol * dq / step * 0.02 + 1e-9
+        np.testing.assert_allclose(dx_f, dx_i, atol=0.02 * dq)
+        assert abs(np.linalg.norm(g_par) - np.linalg.norm(g0)) < 0.05 * np.linalg.norm(g0)
+    # first-order energy change of the small step
+    df = pes.get_f() - f0
+    assert abs(df - g0 @ (q1 - q0)) < 0.05 * abs(g0 @ (q1 - q0)) + 1e-6

@@ -84,6 +84,10 @@ def main():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from sella_amd.device import Context
+    from sella_amd.utilities.hostcpu import effective_cpu_count, limit_blas_threads
+    # host threads: the CPUs this container may use (cgroup quota, not the visible count), shared by the ranks
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+    host_threads = limit_blas_threads(max(1, effective_cpu_count() // max(1, local_world)))
     ctx = Context()             # LOCAL_RANK selects the device (one process per GPU)
     n = args.n
     # The exit iteration of the gamma = 0.1 run is chaotic (20 ... 31 vectors for the

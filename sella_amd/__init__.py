@@ -7,6 +7,10 @@ runs in hand-written HIP kernels for gfx950 (libsella_hip.so).  There is no CPU 
 """
 __version__ = '0.1.0'
 
+from .utilities.hostcpu import limit_blas_threads as _limit_blas_threads  # noqa: E402
+
+_limit_blas_threads()          # see utilities/hostcpu.py: BLAS pools capped at the CPUs this process may use
+
 _LAZY = {
     'Sella': ('sella_amd.optimize.optimize', 'Sella'),
     'IRC': ('sella_amd.optimize.irc', 'IRC'),

@@ -11,6 +11,8 @@
 // pseudo-inverse solve with the same bordered-diagonal matrix.  The only O(m^2) work per alpha
 // is mapping (s, ds/dalpha) back with one 2-right-hand-side row-panel matvec on the device.
 #include "internal.h"
+#include <chrono>
+#include <cstdlib>
 
 #include <algorithm>
 
@@ -20,6 +22,8 @@ struct sella_stepper {
     sella_mat V = SELLA_NO_MAT;      // m x m eigenvectors (columns)   [not owned]
     sella_mat VU = SELLA_NO_MAT;     // nout x m : U V when a projection U (nout x m) was given [owned]
     std::vector<double> lam, ghat;
+    double t_host = 0.0, t_dev = 0.0;     // SELLA_DEBUG_TIMING: seconds in the secular solves / in the device round trip
+    long calls = 0, sweeps = 0;
 };
 
 namespace sella {
@@ -30,6 +34,8 @@ typedef std::vector<double> vec;
 // Root number j (ascending, 0..mm) of f(mu) = mu + sum b_i^2 / (D_i - mu), D ascending.
 // Returned as (origin, tau): mu = D_origin + tau with the origin the closer pole
 // (origin = -1: mu = tau, used for the two exterior roots far from every pole).
+long g_sweeps = 0;      // SELLA_DEBUG_TIMING statistics only
+
 void bordered_root(int mm, const double* D, const double* b, int j, int* origin, double* tau) {
     double bb = 0.0, dmax = 0.0;
     for (int i = 0; i < mm; ++i) { bb += b[i] * b[i]; dmax = std::max(dmax, fabs(D[i])); }
@@ -72,6 +78,7 @@ void bordered_root(int mm, const double* D, const double* b, int j, int* origin,
     double t = 0.5 * (lo + hi);
     for (int it = 0; it < 200; ++it) {
         const Ev e = eval(shift, t);
+        ++g_sweeps;
         const double fv = e.f;
         if (!(fabs(fv) > 8.0 * EPS * e.noise)) break;
         if (fv < 0.0) lo = t; else hi = t;
@@ -219,6 +226,8 @@ extern "C" int sella_stepper_get_s(sella_stepper* st, double alpha, double* s_ou
     if (!st || !s_out || !dsda_out) return SELLA_E_INVALID;
     sella_ctx* c = st->c;
     const int m = st->m, o = st->order;
+    const auto t0 = std::chrono::steady_clock::now();
+    const long sw0 = g_sweeps;
     std::vector<double> sh(2 * (size_t)m, 0.0);     // [shat | dshat]
     double* shat = sh.data();
     double* dshat = sh.data() + m;
@@ -238,6 +247,16 @@ extern "C" int sella_stepper_get_s(sella_stepper* st, double alpha, double* s_ou
         rfo_block(o, lam, gh, o, alpha, shat, dshat);                       // max block: top root
         rfo_block(m - o, lam + o, gh + o, 0, alpha, shat + o, dshat + o);   // min block: lowest root
     }
+    const auto t1 = std::chrono::steady_clock::now();
+    struct Acc {
+        sella_stepper* st; std::chrono::steady_clock::time_point a, b; long sw;
+        ~Acc() {
+            st->t_host += std::chrono::duration<double>(b - a).count();
+            st->t_dev += std::chrono::duration<double>(std::chrono::steady_clock::now() - b).count();
+            st->calls += 1;
+            st->sweeps += sw;
+        }
+    } acc{st, t0, t1, g_sweeps - sw0};
     Mat* V = mat_get(c, st->V);
     if (!V) return SELLA_E_INVALID;
     const int nout = st->nout;
@@ -276,6 +295,10 @@ extern "C" int sella_stepper_get_s(sella_stepper* st, double alpha, double* s_ou
 
 extern "C" int sella_stepper_destroy(sella_stepper* st) {
     if (!st) return SELLA_OK;
+    if (st->calls && getenv("SELLA_DEBUG_TIMING"))
+        fprintf(stderr, "stepper m=%d nout=%d: %ld get_s calls, %.1f us host solve (%.1f sweeps) + %.1f us device round trip per call\n",
+                st->m, st->nout, st->calls, 1e6 * st->t_host / st->calls, (double)st->sweeps / st->calls,
+                1e6 * st->t_dev / st->calls);
     delete st;
     return SELLA_OK;
 }

@@ -749,10 +749,12 @@ class InternalPES(PES):
     def get_df_pred(self, dx, g, H):                                                    # :1174-1181
         if H is None:
             return None
+        # dx_r . (Unred^T H Unred) . dx_r = p . H p with p = Unred Unred^T dx: two thin products and ONE
+        # Hessian-vector product instead of the reference's projected matrix
         Unred = self.get_Unred()
         dx_r, g_r = dx @ Unred, g @ Unred
-        H_r = Unred.T @ (H @ Unred)
-        return g_r @ dx_r + (dx_r @ H_r @ dx_r) / 2.
+        p = Unred @ dx_r
+        return g_r @ dx_r + (p @ (H @ p)) / 2.
 
     def get_projected_forces(self):                                                     # :1183-1192
         g = self.get_g()

@@ -134,3 +134,29 @@ def test_approximate_hessian_carries_eigenpairs(ctx):
             assert np.abs(carried.B @ V - V * carried.evals).max() < 1e-11
     finally:
         linalg.EIG_UPDATE_MAX_RANK = old
+
+
+def test_host_thread_cap():
+    """utilities/hostcpu.py: the BLAS pools are capped at the CPUs the process may use (cgroup quota).
+    In a subprocess: the cap is process-wide."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import os\n"
+        "from threadpoolctl import threadpool_info\n"
+        "import sella_amd\n"
+        "from sella_amd.utilities.hostcpu import effective_cpu_count, limit_blas_threads\n"
+        "import numpy, scipy.linalg\n"
+        "n = effective_cpu_count()\n"
+        "assert 1 <= n <= (os.cpu_count() or 1)\n"
+        "assert all(p['num_threads'] <= n for p in threadpool_info()), threadpool_info()\n"
+        "assert limit_blas_threads(1) == 1\n"
+        "assert all(p['num_threads'] == 1 for p in threadpool_info())\n"
+        "limit_blas_threads(n)\n"
+        "assert all(p['num_threads'] == 1 for p in threadpool_info())\n"
+        "print('ok')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ('SELLA_HOST_THREADS', 'OPENBLAS_NUM_THREADS')}
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=repo, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr

@@ -35,6 +35,7 @@ ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--sella-steps', type=int, default=0)
 ap.add_argument('--angles', action='store_true', help='also time the factor with all bond angles added')
 ap.add_argument('--dx', type=float, default=0.02)
+ap.add_argument('--profile', action='store_true', help='cProfile the Sella steps')
 args = ap.parse_args()
 
 ctx = Context()
@@ -123,6 +124,15 @@ if args.sella_steps:
     dyn = Sella(slab, internal=ic, logfile='-', order=0)
     _, t_s1 = clock(dyn.run, 1e-3, 1)
     n0 = slab.calc.ncalls
+    if args.profile:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
     _, t_s = clock(dyn.run, 1e-3, args.sella_steps)
+    if args.profile:
+        pr.disable()
+        pstats.Stats(pr).sort_stats('tottime').print_stats(18)
+        pstats.Stats(pr).sort_stats('cumulative').print_stats(30)
     out(stage='Sella(internal)', first_step_s=round(t_s1, 2), steps=args.sella_steps,
         s_per_step=round(t_s / args.sella_steps, 3), force_calls=slab.calc.ncalls - n0)

@@ -148,6 +148,16 @@ int sella_update_h(sella_ctx* ctx, sella_mat B, sella_mat evecs, sella_mat evecs
 int sella_update_h_eig(sella_ctx* ctx, sella_mat B, sella_mat evecs, sella_mat evecsT, double* evals,
                        const double* S, const double* Y, int n, int k, int method, int symm,
                        int max_rank, int* nrank1);
+/* The same, keeping a principal submatrix of B in step with it: Bsub = B[idx][idx] (idx ascending, m
+ * entries) is what `get_HL_projected` (sella/peswrapper.py:363-386) yields when the constraints pin single
+ * Cartesian coordinates — U^T B U with U columns of the identity — and the reference re-diagonalises it at
+ * every step.  Bsub receives the update restricted to idx; if evecs_sub / evecsT_sub / evals_sub are given
+ * (handles != SELLA_NO_MAT) its eigendecomposition is carried the same way, *nrank1_sub as above.          */
+int sella_update_h_eig_view(sella_ctx* ctx, sella_mat B, sella_mat evecs, sella_mat evecsT, double* evals,
+                            const double* S, const double* Y, int n, int k, int method, int symm,
+                            int max_rank, int* nrank1, sella_mat Bsub, sella_mat evecs_sub,
+                            sella_mat evecsT_sub, double* evals_sub, const int* idx, int m,
+                            int* nrank1_sub);
 /* symmetrize_Y(S, Y, symm)  sella/hessian_update.py:12-37; out host (n x k)                   */
 int sella_symmetrize_y(sella_ctx* ctx, const double* S, const double* Y, int n, int k,
                        int symm, double* out);

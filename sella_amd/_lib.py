@@ -55,6 +55,9 @@ SIGNATURES = {
                                c_int, c_int, c_int]),
     'sella_update_h_eig': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                    c_int, c_int, c_int, c_int, c_int_p]),
+    'sella_update_h_eig_view': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                        c_int, c_int, c_int, c_int, c_int_p, c_int, c_int, c_int, c_void_p,
+                                        c_void_p, c_int, c_int_p]),
     'sella_symmetrize_y': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'sella_stepper_create': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                      POINTER(c_void_p)]),

@@ -178,10 +178,30 @@ extern "C" int sella_symmetrize_y(sella_ctx* c, const double* S, const double* Y
     return download_panel(c, Ytp, ld, n, k, out);
 }
 
+// Principal submatrix B[idx][idx] kept in step with B (the Hessian projected on the free coordinates of a
+// constraint set that pins single coordinates, peswrapper.py:363-386): its matrix and, when given, its
+// eigendecomposition receive the same update restricted to idx.
+struct SubView {
+    sella_mat B, V, Vt;
+    double* evals;
+    const int* idx;
+    int m;
+    int* nrank1;
+};
+
+__global__ __launch_bounds__(256) void gather_cols_kernel(const double* __restrict__ P, int ldp, int rows,
+                                                          const int* __restrict__ idx, int m,
+                                                          double* __restrict__ out, int ldo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (i < m && r < rows) out[(size_t)r * ldo + i] = P[(size_t)r * ldp + idx[i]];
+}
+
 static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt, const double* evals,
                          const double* S, const double* Y, int n, int k, int method, int symm,
-                         double* evals_io, int max_rank, int* nrank1) {
+                         double* evals_io, int max_rank, int* nrank1, const SubView* sv = nullptr) {
     if (nrank1) *nrank1 = -1;
+    if (sv && sv->nrank1) *sv->nrank1 = -1;
     Mat* B = mat_get(c, hB);
     if (!B || !S || !Y || k <= 0) return SELLA_E_INVALID;
     if (B->rows != n || B->cols != n) { set_error("update_H: B must be %d x %d", n, n); return SELLA_E_INVALID; }
@@ -348,13 +368,53 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
     }
     B = mat_get(c, hB);
     SCHK(launch_sym_rank2k(c, B->d, n, B->ld, Up, Zp, ld, kk));
+    double *Us = nullptr, *Zs = nullptr;
+    int lds = 0;
+    if (sv) {
+        // the update vectors restricted to the view's coordinates (before the panels are consumed below)
+        Mat* Bs = mat_get(c, sv->B);
+        const int m = sv->m;
+        if (!Bs || Bs->rows != m || Bs->cols != m || m <= 0 || m > n || !sv->idx) {
+            set_error("update_H: bad principal-submatrix view");
+            return SELLA_E_INVALID;
+        }
+        lds = round_up(m, 8);
+        double* wks;
+        SCHK(scratch_get(c, SCR_UPD4, ((size_t)2 * kk * lds + (size_t)m / 2 + 8) * sizeof(double), &wks));
+        Us = wks;
+        Zs = wks + (size_t)kk * lds;
+        int* didx = reinterpret_cast<int*>(wks + 2 * (size_t)kk * lds);
+        HIPCHK(hipMemcpyAsync(didx, sv->idx, (size_t)m * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemsetAsync(wks, 0, (size_t)2 * kk * lds * sizeof(double), c->stream));
+        const dim3 gg((m + 255) / 256, kk);
+        hipLaunchKernelGGL(gather_cols_kernel, gg, dim3(256), 0, c->stream, Up, ld, kk, didx, m, Us, lds);
+        hipLaunchKernelGGL(gather_cols_kernel, gg, dim3(256), 0, c->stream, Zp, ld, kk, didx, m, Zs, lds);
+        HIPCHK(hipGetLastError());
+        SCHK(launch_sym_rank2k(c, Bs->d, m, Bs->ld, Us, Zs, lds, kk));
+    }
     if (evals_io && hV != SELLA_NO_MAT && 2 * kk <= max_rank) {
         Mat *V = mat_get(c, hV), *Vt = mat_get(c, hVt);
         if (!V || !Vt || V->rows != n || Vt->rows != n) { set_error("update_H: bad eigenvector handles"); return SELLA_E_INVALID; }
         SCHK(eig_lowrank_update(c, n, evals_io, V, Vt, Up, Zp, ld, kk, nrank1));
     }
+    if (sv && sv->evals && sv->V != SELLA_NO_MAT && 2 * kk <= max_rank) {
+        Mat *V = mat_get(c, sv->V), *Vt = mat_get(c, sv->Vt);
+        if (!V || !Vt || V->rows != sv->m || Vt->rows != sv->m) { set_error("update_H: bad eigenvector handles of the view"); return SELLA_E_INVALID; }
+        SCHK(eig_lowrank_update(c, sv->m, sv->evals, V, Vt, Us, Zs, lds, kk, sv->nrank1));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     return SELLA_OK;
+}
+
+extern "C" int sella_update_h_eig_view(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt, double* evals,
+                                       const double* S, const double* Y, int n, int k, int method, int symm,
+                                       int max_rank, int* nrank1, sella_mat hBsub, sella_mat hVsub, sella_mat hVtsub,
+                                       double* evals_sub, const int* idx, int m, int* nrank1_sub) {
+    if (!evals || !nrank1 || !idx || !nrank1_sub) { set_error("update_H (view): evals, nrank1, idx and nrank1_sub are required"); return SELLA_E_INVALID; }
+    for (int i = 0; i < m; ++i)
+        if (idx[i] < 0 || idx[i] >= n || (i && idx[i] <= idx[i - 1])) { set_error("update_H (view): idx must be ascending in [0, n)"); return SELLA_E_INVALID; }
+    SubView sv{hBsub, hVsub, hVtsub, evals_sub, idx, m, nrank1_sub};
+    return update_h_core(c, hB, hV, hVt, evals, S, Y, n, k, method, symm, evals, max_rank, nrank1, &sv);
 }
 
 extern "C" int sella_update_h(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt, const double* evals,

@@ -113,6 +113,21 @@ class Context:
         check(_lib.lib().sella_mat_upload(self._h, ptr(A), A.shape[0], A.shape[1], byref(h)))
         return DeviceMatrix(self, h.value, A.shape)
 
+    def resident(self, A):
+        """Device copy of a host array that is handed out as the SAME object over and over (projection bases
+        shared across geometries, peswrapper.py): uploaded once and kept, keyed on the object.  The array must not
+        be modified afterwards; at most four copies are kept, least recently used dropped."""
+        cache = self.__dict__.setdefault('_resident', [])
+        for k, (host, dev) in enumerate(cache):
+            if host is A:
+                cache.append(cache.pop(k))
+                return dev
+        dev = self.upload(A)
+        cache.append((A, dev))
+        if len(cache) > 4:
+            cache.pop(0)[1].free()
+        return dev
+
     def zeros(self, rows, cols):
         self._drain()
         h = c_int(-1)
@@ -292,6 +307,27 @@ class Context:
             self._h, B.handle, evecs.handle, evecsT.handle, ptr(ev), ptr(S), ptr(Y), n, k,
             UPDATE_METHODS[method], -1 if symm is None else int(symm), int(max_rank), byref(nr)))
         return ev, nr.value
+
+    def update_h_eig_view(self, B, S, Y, evals, evecs, evecsT, Bsub, idx, evals_sub=None, evecs_sub=None,
+                          evecsT_sub=None, method='TS-BFGS', symm=2, max_rank=8):
+        """`update_h_eig` that keeps the principal submatrix Bsub = B[idx][idx] (and, when given, its
+        eigendecomposition) in step.  Returns (evals_new, nrank1, evals_sub_new or None, nrank1_sub)."""
+        if method not in UPDATE_METHODS:
+            raise ValueError('Unknown update method {}'.format(method))
+        S = as_f64(S)
+        Y = as_f64(Y)
+        n, k = S.shape
+        ev = np.array(evals, dtype=np.float64, copy=True)
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        have = evals_sub is not None and evecs_sub is not None and evecsT_sub is not None
+        evs = np.array(evals_sub, dtype=np.float64, copy=True) if have else None
+        nr, nrs = c_int(-1), c_int(-1)
+        check(_lib.lib().sella_update_h_eig_view(
+            self._h, B.handle, evecs.handle, evecsT.handle, ptr(ev), ptr(S), ptr(Y), n, k,
+            UPDATE_METHODS[method], -1 if symm is None else int(symm), int(max_rank), byref(nr),
+            Bsub.handle, evecs_sub.handle if have else SELLA_NO_MAT, evecsT_sub.handle if have else SELLA_NO_MAT,
+            ptr(evs) if have else None, idx.ctypes.data_as(c_void_p), len(idx), byref(nrs)))
+        return ev, nr.value, evs, nrs.value
 
     def symmetrize_y(self, S, Y, symm):
         S = as_f64(S)

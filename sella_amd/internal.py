@@ -248,8 +248,20 @@ class Constraints:
         """Dense (nactive, 3N) constraint Jacobian."""
         n3 = self.ndof
         rows, dofs, wts, nt = self._translation_arrays()
+        only_trans = not any(len(self._gather(name)[0]) for name in ('bonds', 'angles', 'dihedrals'))
+        if only_trans:
+            # translation constraints do not depend on the geometry: the SAME (read-only) array is handed out as
+            # long as the constraint set is unchanged, so everything downstream that keys on the object
+            # (pinned-coordinate analysis, bases, device copies) is computed once per search, not once per step
+            hit = getattr(self, '_jac_cache', None)
+            if hit is not None and hit[0] is rows and hit[1].shape == (nt, n3):      # `rows` is itself cached
+                return hit[1]
         J = np.zeros((nt, n3))
         J[rows, dofs] = wts
+        if only_trans:
+            J.setflags(write=False)
+            self._jac_cache = (rows, J)
+            return J
         for name in ('bonds', 'angles', 'dihedrals'):
             idx, pos, tvec = self._gather(name)
             if len(idx) == 0:

@@ -149,6 +149,7 @@ class ApproximateHessian(LinearOperator):
         self._B_gpu = None         # DeviceMatrix (None while not uploaded)
         self._is_none = True
         self.version = 0           # bumped whenever B changes (cache key for projections)
+        self._view = None          # (idx, basis, ApproximateHessian of B[idx][idx], version it is in step with)
         self._drop_eig()
         self.set_B(B0)
 
@@ -186,6 +187,7 @@ class ApproximateHessian(LinearOperator):
 
     def set_B(self, target):
         self.version += 1
+        self._view = None
         self._drop_eig()
         if self._B_gpu is not None:
             self._B_gpu.free()
@@ -268,8 +270,29 @@ class ApproximateHessian(LinearOperator):
             # carry the eigendecomposition across the update (rank-one modifications on the device)
             # instead of paying a new eigh at the next step solve, linalg.py:174-231
             evals, V, Vt = self.device_eig()
-            new_evals, nr = get_context().update_h_eig(dB, S2, Y2, evals, V, Vt, method=self.update_method,
-                                                       symm=self.symm, max_rank=EIG_UPDATE_MAX_RANK)
+            view = self._view if (self._view is not None and self._view[3] == self.version) else None
+            if view is not None:
+                # the projected Hessian of a pinned-coordinate constraint set (PES.get_HL_projected) receives
+                # the same update restricted to its coordinates, and keeps its eigendecomposition the same way
+                idx, _, sub, _ = view
+                seig = sub.device_eig() if sub._evals is not None else None
+                new_evals, nr, sub_evals, nrs = get_context().update_h_eig_view(
+                    dB, S2, Y2, evals, V, Vt, sub._get_B_gpu(), idx,
+                    *(seig if seig is not None else (None, None, None)),
+                    method=self.update_method, symm=self.symm, max_rank=EIG_UPDATE_MAX_RANK)
+                sub._B = None
+                sub.version += 1
+                if seig is None or nrs < 0 or sub._eig_age + nrs > EIG_UPDATE_REFRESH:
+                    sub._drop_eig()
+                else:
+                    sub._eig_age += nrs
+                    sub._evals = sub._evals_gpu = sub_evals
+                    sub._evecs = None
+                self._view = (view[0], view[1], sub, self.version + 1)
+            else:
+                self._view = None
+                new_evals, nr = get_context().update_h_eig(dB, S2, Y2, evals, V, Vt, method=self.update_method,
+                                                           symm=self.symm, max_rank=EIG_UPDATE_MAX_RANK)
             self._B = None
             self.version += 1
             self.initialized = True
@@ -290,8 +313,24 @@ class ApproximateHessian(LinearOperator):
         # the device matrix was updated in place: host copy and eigenpairs are stale
         self._B = None
         self.version += 1
+        self._view = None
         self._drop_eig()
         self.initialized = True
+
+    def principal_view(self, U):
+        """U^T B U for a basis U made of columns of the identity, as an ApproximateHessian that `update` keeps
+        in step with B (matrix and eigendecomposition): the projection of peswrapper.py:363-386 for constraints
+        that pin single coordinates, without a fresh eigh at every step.  None if no view of U is in step."""
+        v = self._view
+        if v is not None and v[1] is U and v[3] == self.version:
+            return v[2]
+        return None
+
+    def register_view(self, U, sub):
+        idx = np.ascontiguousarray(U.argmax(axis=0), dtype=np.int32)
+        if len(idx) > 1 and not np.all(np.diff(idx) > 0):
+            return                                   # not an ordered selection of coordinates
+        self._view = (idx, U, sub, self.version)
 
     def project(self, U):
         """Project B into the subspace spanned by the columns of U (linalg.py:306-317)."""

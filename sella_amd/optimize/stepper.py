@@ -61,10 +61,8 @@ class BaseStepper:
             U = None                                  # unconstrained: the basis is the identity
         if U is not None:
             # compose the projection with the eigenbasis once: (U V) is n x m
-            dU = ctx.upload(self.U)
             VU = ctx.zeros(self.U.shape[0], V.shape[1])
-            ctx.gemm(dU, V, VU)
-            dU.free()
+            ctx.gemm(ctx.resident(self.U), V, VU)
             V, Vt = VU, VU.transpose()
         self._dev = DeviceStepper(ctx, self._kind, V, Vt, evals, self.g, self.order)
 
@@ -115,10 +113,8 @@ class QuasiNewtonIRC(QuasiNewton):
         if U is not None and is_identity(U):
             U = None
         if U is not None:
-            dU = ctx.upload(U)
             VU = ctx.zeros(U.shape[0], V.shape[1])
-            ctx.gemm(dU, V, VU)
-            dU.free()
+            ctx.gemm(ctx.resident(U), V, VU)
             self._Vout = VU
         else:
             self._Vout = V

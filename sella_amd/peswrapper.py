@@ -49,13 +49,20 @@ def _pinned_coordinates(drdx):
     code (multipliers, linear constraint correction, peswrapper.py:429-438, 475-479) are componentwise divisions."""
     if drdx.shape[0] == 0:
         return None
+    if _pinned_memo[0] is drdx:                      # read-only Jacobian of a translation-only constraint set
+        return _pinned_memo[1]
     nz = drdx != 0.0
     if not np.all(nz.sum(axis=1) == 1):
-        return None
-    cidx = nz.argmax(axis=1)
-    if len(np.unique(cidx)) != len(cidx):
-        return None
-    return cidx, drdx[np.arange(len(cidx)), cidx]
+        out = None
+    else:
+        cidx = nz.argmax(axis=1)
+        out = None if len(np.unique(cidx)) != len(cidx) else (cidx, drdx[np.arange(len(cidx)), cidx])
+    if not drdx.flags.writeable:
+        _pinned_memo[0], _pinned_memo[1] = drdx, out
+    return out
+
+
+_pinned_memo = [None, None]
 
 
 def _split_cons_subspace(drdx, tol_factor=1e-6):
@@ -200,6 +207,11 @@ class PES:
         curved = L is not None and L.size > 0 and self._has_curved_constraints()
         if is_identity(U) and not curved:
             return H
+        selection = (not curved) and getattr(self, '_pinned_basis', None) is not None and U is self._pinned_basis[2]
+        if selection:
+            view = H.principal_view(U)
+            if view is not None:
+                return view
         key = (id(H), H.version, id(U), None if not curved else L.tobytes())
         hit = getattr(self, '_hlproj_cache', None)
         if hit is not None and hit[0] == key and hit[1] is U:
@@ -208,9 +220,7 @@ class PES:
         if is_identity(U):
             Bproj = H._get_B_gpu().copy()
         else:
-            dU = ctx.upload(U)
-            Bproj = ctx.project_dev(H._get_B_gpu(), dU)
-            dU.free()
+            Bproj = ctx.project_dev(H._get_B_gpu(), ctx.resident(U))
         if curved:
             Hc = self.get_Hc()          # zero for translation-only constraints: skipped above
             dHc = ctx.upload(U.T @ Hc @ U)
@@ -220,6 +230,8 @@ class PES:
             Bproj = Bnew
         out = ApproximateHessian(n, 0, Bproj, H.update_method, H.symm)
         self._hlproj_cache = (key, U, out)
+        if selection:
+            H.register_view(U, out)          # from now on updated together with H (linalg.ApproximateHessian.update)
         return out
 
     # ---- constraints ------------------------------------------------------------------------

@@ -136,6 +136,43 @@ def test_approximate_hessian_carries_eigenpairs(ctx):
         linalg.EIG_UPDATE_MAX_RANK = old
 
 
+def test_principal_view_stays_in_step(ctx):
+    """The projected Hessian of a pinned-coordinate constraint set (U = columns of the identity) is registered
+    as a view of B: every quasi-Newton update reaches its matrix and its eigendecomposition too, so the step
+    solve never re-diagonalises (the reference: get_HL_projected + eigh at every step, peswrapper.py:363-386)."""
+    from sella_amd import linalg
+    rng = np.random.RandomState(7)
+    n = 30
+    A = rng.normal(size=(n, n))
+    Htrue = A + A.T + 4 * np.eye(n)
+    free = np.sort(rng.choice(n, 17, replace=False))
+    U = np.ascontiguousarray(np.eye(n)[:, free])
+    H = linalg.ApproximateHessian(n, n, np.diag(np.linspace(0.5, 3.0, n)))
+    sub = H.project(U)
+    sub.evals                                   # the step solve diagonalised it once
+    H.evals
+    H.register_view(U, sub)
+    assert H.principal_view(U) is sub and H.principal_view(U.copy()) is None
+    for step in range(6):
+        dx = 0.1 * rng.normal(size=n)
+        H.update(dx, Htrue @ dx)
+        view = H.principal_view(U)
+        assert view is sub and sub._evals is not None and sub._eig_age > 0      # carried, not recomputed
+        Bs = H.B[np.ix_(free, free)]
+        np.testing.assert_allclose(sub.B, Bs, atol=1e-12)
+        np.testing.assert_allclose(sub.evals, np.linalg.eigvalsh(Bs), atol=1e-11)
+        V = sub.evecs
+        assert np.abs(Bs @ V - V * sub.evals).max() < 1e-11
+        assert np.abs(V.T @ V - np.eye(len(free))).max() < 1e-12
+    # a view without eigenpairs still gets the matrix update; set_B drops the view
+    sub._drop_eig()
+    dx = 0.1 * rng.normal(size=n)
+    H.update(dx, Htrue @ dx)
+    np.testing.assert_allclose(H.principal_view(U).B, H.B[np.ix_(free, free)], atol=1e-12)
+    H.set_B(np.eye(n))
+    assert H.principal_view(U) is None
+
+
 def test_host_thread_cap():
     """utilities/hostcpu.py: the BLAS pools are capped at the CPUs the process may use (cgroup quota).
     In a subprocess: the cap is process-wide."""

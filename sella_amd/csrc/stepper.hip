@@ -37,20 +37,27 @@ typedef std::vector<double> vec;
 long g_sweeps = 0;      // SELLA_DEBUG_TIMING statistics only
 
 void bordered_root(int mm, const double* D, const double* b, int j, int* origin, double* tau) {
-    double bb = 0.0, dmax = 0.0;
-    for (int i = 0; i < mm; ++i) { bb += b[i] * b[i]; dmax = std::max(dmax, fabs(D[i])); }
-    const double bound = dmax + sqrt(bb) + 1.0;
+    double bb = 0.0;
+    for (int i = 0; i < mm; ++i) bb += b[i] * b[i];
     // value, noise scale and the derivative split at pole index j (left part: poles i < j, right part: i >= j)
     struct Ev { double f, noise, dl, dr; };
+    const int ext = (j == 0) ? 0 : (j == mm ? mm - 1 : -1);      // nearest pole of an exterior root
     auto eval = [&](double shift, double t) {
         Ev e;
         double s = 0.0, sa = 0.0, dl = 0.0, dr = 0.0;
-        for (int i = 0; i < mm; ++i) {
+        for (int i = 0; i < j; ++i) {                 // poles left of the root (two plain loops: both vectorise)
             const double r = 1.0 / ((D[i] - shift) - t);
             const double q = b[i] * b[i] * r;
             s += q;
             sa += fabs(q);
-            if (i < j) dl += q * r; else dr += q * r;
+            dl += q * r;
+        }
+        for (int i = j; i < mm; ++i) {                // poles right of the root
+            const double r = 1.0 / ((D[i] - shift) - t);
+            const double q = b[i] * b[i] * r;
+            s += q;
+            sa += fabs(q);
+            dr += q * r;
         }
         e.f = (shift + t) + s;
         e.noise = fabs(shift + t) + sa;
@@ -58,24 +65,39 @@ void bordered_root(int mm, const double* D, const double* b, int j, int* origin,
         e.dr = dr;
         return e;
     };
-    double shift, lo, hi;
+    double shift, lo, hi, t;
     int org;
     if (mm == 0) { *origin = -1; *tau = 0.0; return; }
-    if (j == 0) { org = 0; shift = D[0]; lo = -bound - fabs(D[0]) - bound; hi = 0.0; }
-    else if (j == mm) { org = mm - 1; shift = D[mm - 1]; lo = 0.0; hi = 2.0 * bound + fabs(D[mm - 1]); }
-    else {
+    if (j == 0 || j == mm) {
+        // Exterior root.  Brackets from two one-pole problems mu + c / (d - mu) = 0 with d the nearest pole D_e:
+        // all weight on that pole (c = |b|^2) overshoots the root, only that pole's own weight (c = b_e^2) falls
+        // short of it — every term of the sum has the same sign on this side of the spectrum.
+        const int e = (j == 0) ? 0 : mm - 1;
+        const double sg = (j == 0) ? -1.0 : 1.0;
+        org = e;
+        shift = D[e];
+        const double far = 0.5 * (-shift + sg * sqrt(shift * shift + 4.0 * bb));          // t of the overshooting model
+        const double near = 0.5 * (-shift + sg * sqrt(shift * shift + 4.0 * b[e] * b[e]));
+        if (j == 0) { lo = far; hi = std::min(near, 0.0); }
+        else { lo = std::max(near, 0.0); hi = far; }
+        if (!(hi > lo)) { *origin = org; *tau = 0.5 * (lo + hi); return; }                 // b = 0: mu = min/max(D_e, 0)
+        t = far;
+        if (t == 0.0) t = 0.5 * (lo + hi);
+    } else {
         const double delta = D[j] - D[j - 1];
         if (delta <= 0.0) { *origin = j; *tau = 0.0; return; }      // coincident poles: mu = D_j
         const double fm = eval(D[j - 1], 0.5 * delta).f;
         if (fm >= 0.0) { org = j - 1; shift = D[j - 1]; lo = 0.0; hi = 0.5 * delta; }
         else { org = j; shift = D[j]; lo = -0.5 * delta; hi = 0.0; }
+        t = 0.5 * (lo + hi);
     }
-    // f is increasing between poles: f(lo) < 0 <= f(hi) (pole ends are never evaluated).  Iteration as in the
-    // eigensolver's secular equation (secular.h): the one or two poles next to the root are kept exact, the rest of
-    // the sum is frozen at value and slope ("middle way" rational model), bracket + bisection as the safeguard,
-    // and the stop is |f| below its own rounding noise.  The linear term is carried in the constant of the model.
+    // f is increasing between poles: f(lo) <= 0 <= f(hi) (pole ends are never evaluated).  Interior roots: as in
+    // the eigensolver's secular equation (secular.h), the two poles next to the root are kept exact and the rest of
+    // the sum is frozen at value and slope ("middle way" rational model).  Exterior roots: the nearest pole is
+    // kept exact and the rest of the sum is replaced by the one-pole function that matches its value and slope (all terms have
+    // the same sign there) next to the exact nearest pole — with the nearest pole alone these roots took 30-60
+    // sweeps at the sizes of a slab search, now 3-6.  Bracket + bisection as the safeguard, stop at |f| below its rounding noise.
     const double EPS = 2.220446049250313e-16;
-    double t = 0.5 * (lo + hi);
     for (int it = 0; it < 200; ++it) {
         const Ev e = eval(shift, t);
         ++g_sweeps;
@@ -94,14 +116,31 @@ void bordered_root(int mm, const double* D, const double* b, int j, int* origin,
                 const double disc = sqrt(fabs(a_ * a_ - 4.0 * b_ * c_));
                 eta = (a_ <= 0.0) ? (a_ - disc) / (2.0 * c_) : 2.0 * b_ / (a_ + disc);
             }
-        } else if (j == 0) {
-            const double D2 = (D[0] - shift) - t;                                   // only a pole on the right
-            const double c_ = fv - D2 * e.dr;
-            eta = (c_ < 0.0) ? D2 + e.dr * D2 * D2 / c_ : -fv / df;
         } else {
-            const double D1 = (D[mm - 1] - shift) - t;                              // only a pole on the left
-            const double c_ = fv - D1 * e.dl;
-            eta = (c_ > 0.0) ? D1 + e.dl * D1 * D1 / c_ : -fv / df;
+            // model: (mu + eta) + a1 / (p1 - eta) + a2 / (p2 - eta) = 0 with the nearest pole exact
+            // (a1 = b_e^2, p1 = D_e - mu) and the REST of the sum R replaced by the one-pole function that
+            // matches R and R' at the current point (p2 = R / R', a2 = R p2).  Solved for eta by a safeguarded
+            // scalar Newton iteration inside the bracket — O(1) work per sweep.
+            const double mu = shift + t;
+            const double p1 = (D[ext] - shift) - t, a1 = b[ext] * b[ext];
+            const double q1 = a1 / p1;
+            const double R = (fv - mu) - q1, Rp = (e.dl + e.dr) - q1 / p1;
+            double a2 = 0.0, p2 = 1.0;
+            if (Rp > 0.0 && R != 0.0) { p2 = R / Rp; a2 = R * p2; }
+            double elo = lo - t, ehi = hi - t, x = 0.0, Fx = fv;
+            eta = -fv / df;
+            for (int in = 0; in < 40; ++in) {
+                if (Fx < 0.0) elo = x; else ehi = x;
+                const double r1 = 1.0 / (p1 - x), r2 = 1.0 / (p2 - x);
+                const double dF = 1.0 + a1 * r1 * r1 + a2 * r2 * r2;
+                double xn = x - Fx / dF;
+                if (!(xn > elo && xn < ehi)) xn = 0.5 * (elo + ehi);
+                if (xn == x) break;
+                x = xn;
+                Fx = (mu + x) + a1 / (p1 - x) + a2 / (p2 - x);
+                if (fabs(Fx) <= 4.0 * EPS * (fabs(mu + x) + fabs(a1 / (p1 - x)) + fabs(a2 / (p2 - x)))) break;
+            }
+            if (x != 0.0) eta = x;
         }
         if (!(fv * eta < 0.0)) eta = -fv / df;
         double tn = t + eta;
@@ -264,28 +303,26 @@ extern "C" int sella_stepper_get_s(sella_stepper* st, double alpha, double* s_ou
     double *dx, *dy;
     SCHK(scratch_get(c, SCR_STEP0, (size_t)2 * std::max(ldx, ldy) * sizeof(double), &dx));
     SCHK(scratch_get(c, SCR_STEP1, (size_t)2 * std::max(ldx, ldy) * sizeof(double), &dy));
-    // The trust-radius search calls this ~50 times per optimizer step: the four small transfers go through the
-    // pinned exchange buffer (a pageable hipMemcpyAsync is a synchronous staged copy, ~0.1 ms each)
-    const bool pinned = m <= 8192 && nout <= 8192;
+    // The trust-radius search calls this ~50 times per optimizer step, so the round trip is kept short: the two
+    // coefficient vectors go down as ONE copy from the pinned exchange buffer (a pageable hipMemcpyAsync is a
+    // synchronous staged copy, ~0.1 ms), and the matvec writes its 2 x nout results straight into that pinned,
+    // device-visible buffer (each output is written once: posted PCIe writes, no copy-back launches); the
+    // stream synchronisation is then the only wait.
+    const bool pinned = 2 * ldx <= 16384 && 2 * ldy <= 16384;
     double* hin = c->hscal + DS_STAGE;
     double* hout = c->hscal + DS_STAGE + 16384;
     if (pinned) {
         memcpy(hin, shat, (size_t)m * sizeof(double));
-        memcpy(hin + m, dshat, (size_t)m * sizeof(double));
-        HIPCHK(hipMemcpyAsync(dx, hin, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(dx + ldx, hin + m, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        memcpy(hin + ldx, dshat, (size_t)m * sizeof(double));
+        HIPCHK(hipMemcpyAsync(dx, hin, (size_t)(ldx + m) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        SCHK(launch_gemv_rows(c, V->d, nout, m, V->ld, dx, ldx, 2, hout, ldy, GemvEpi()));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(s_out, hout, (size_t)nout * sizeof(double));
+        memcpy(dsda_out, hout + ldy, (size_t)nout * sizeof(double));
     } else {
         HIPCHK(hipMemcpyAsync(dx, shat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(dx + ldx, dshat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    }
-    SCHK(launch_gemv_rows(c, V->d, nout, m, V->ld, dx, ldx, 2, dy, ldy, GemvEpi()));
-    if (pinned) {
-        HIPCHK(hipMemcpyAsync(hout, dy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(hout + nout, dy + ldy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        memcpy(s_out, hout, (size_t)nout * sizeof(double));
-        memcpy(dsda_out, hout + nout, (size_t)nout * sizeof(double));
-    } else {
+        SCHK(launch_gemv_rows(c, V->d, nout, m, V->ld, dx, ldx, 2, dy, ldy, GemvEpi()));
         HIPCHK(hipMemcpyAsync(s_out, dy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(dsda_out, dy + ldy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));

@@ -148,8 +148,19 @@ class Constraints:
         self._active = {k: [] for k in self._names}
         self._kind = {k: [] for k in self._names}
         self.ignore_rotation = ignore_rotation
+        self._ver = 0                 # bumped whenever the set of (active) constraints or a target changes
+        self._memo_store = {}
         for cons in getattr(atoms, 'constraints', None) or []:
             self.merge_ase_constraint(cons)
+
+    def _memo(self, key, fn):
+        """Per-structure cache: a slab search carries thousands of single-atom pins, and the optimizer asks for
+        counts, active lists and targets several times per step."""
+        hit = self._memo_store.get(key)
+        if hit is None or hit[0] != self._ver:
+            hit = (self._ver, fn())
+            self._memo_store[key] = hit
+        return hit[1]
 
     # ---- bookkeeping ---------------------------------------------------------------------
     @property
@@ -165,7 +176,7 @@ class Constraints:
         return 3 * self.natoms
 
     def _count(self, name):
-        return int(sum(self._active[name]))
+        return self._memo(('count', name), lambda: int(sum(self._active[name])))
 
     ntrans = property(lambda self: self._count('translations'))
     nbonds = property(lambda self: self._count('bonds'))
@@ -188,14 +199,17 @@ class Constraints:
         return new
 
     def _active_list(self, name):
-        return [c for c, a in zip(self.internals[name], self._active[name]) if a]
+        return self._memo(('active', name),
+                          lambda: [c for c, a in zip(self.internals[name], self._active[name]) if a])
 
     @property
     def targets(self):
-        vec = []
-        for name in self._names:
-            vec += [t for t, a in zip(self._targets[name], self._active[name]) if a]
-        return np.array(vec, dtype=np.float64)
+        def build():
+            vec = []
+            for name in self._names:
+                vec += [t for t, a in zip(self._targets[name], self._active[name]) if a]
+            return np.array(vec, dtype=np.float64)
+        return self._memo('targets', build).copy()
 
     # ---- numerics (batched per kind) --------------------------------------------------------
     def _gather(self, name):
@@ -210,8 +224,8 @@ class Constraints:
     def _translation_arrays(self):
         """Translations as a sparse averaging operator: (row, dof, weight) triplets, rebuilt only when the set of
         active translation constraints changes (thousands of single-atom pins on a slab: no Python loop per call)."""
-        trans = self._active_list('translations')
-        key = (len(trans), tuple(id(c) for c in trans))
+        trans = self._active_list('translations')          # memoised: the same list object while the set is unchanged
+        key = (self._ver, id(trans))
         hit = getattr(self, '_trans_cache', None)
         if hit is None or hit[0] != key:
             rows, dofs, wts = [], [], []
@@ -286,19 +300,28 @@ class Constraints:
 
     # ---- inequality bookkeeping (internal.py:2788-2823) ----------------------------------------
     def has_inequalities(self):
-        return any(k in ('lt', 'gt') for name in self._names for k in self._kind[name])
+        return self._memo('has_ineq', lambda: any(k in ('lt', 'gt') for name in self._names for k in self._kind[name]))
+
+    def _set_active(self, name, i, value):
+        if self._active[name][i] != value:
+            self._active[name][i] = value
+            self._ver += 1
 
     def disable_satisfied_inequalities(self):
+        if not self.has_inequalities():
+            return
         for name in self._names:
             for i, (coord, kind, target) in enumerate(zip(self.internals[name], self._kind[name], self._targets[name])):
                 if kind == 'lt' and coord.calc(self.atoms) <= target:
-                    self._active[name][i] = False
+                    self._set_active(name, i, False)
                 elif kind == 'gt' and coord.calc(self.atoms) >= target:
-                    self._active[name][i] = False
+                    self._set_active(name, i, False)
                 else:
-                    self._active[name][i] = True
+                    self._set_active(name, i, True)
 
     def validate_inequalities(self):
+        if not self.has_inequalities():
+            return True
         all_valid = True
         for name in self._names:
             for i, (coord, kind, target) in enumerate(zip(self.internals[name], self._kind[name], self._targets[name])):
@@ -306,7 +329,7 @@ class Constraints:
                     continue
                 val = coord.calc(self.atoms)
                 if (kind == 'lt' and val > target) or (kind == 'gt' and val < target):
-                    self._active[name][i] = True
+                    self._set_active(name, i, True)
                     all_valid = False
         return all_valid
 
@@ -319,10 +342,12 @@ class Constraints:
             self._targets[name].append(target)
             self._active[name].append(True)
             self._kind[name].append(kind)
+            self._ver += 1
             return
         if replace_ok:
             self._targets[name][idx] = target
             self._kind[name][idx] = kind
+            self._ver += 1
             return
         raise DuplicateConstraintError(f'Coordinate {new} is already fixed to target {self._targets[name][idx]}')
 

@@ -41,3 +41,15 @@ run_one(at, 0.0, 20, kw)
 pr.disable()
 print('seconds per member', time.perf_counter() - t0)
 pstats.Stats(pr).sort_stats('tottime').print_stats(14)
+
+# the bench leg itself: 8 members through run_ensemble on this context
+from sella_amd.ensemble import run_ensemble  # noqa: E402
+
+ats = {i: member(10 + i) for i in range(8)}
+pr = cProfile.Profile()
+t0 = time.perf_counter()
+pr.enable()
+res = run_ensemble(lambda i: ats[i], 8, fmax=0.0, steps=20, sella_kwargs=kw, threads=1)
+pr.disable()
+print('run_ensemble: seconds per member', (time.perf_counter() - t0) / 8)
+pstats.Stats(pr).sort_stats('tottime').print_stats(10)

@@ -22,6 +22,12 @@ echo "== rocprof kernel trace of the bench command" | tee -a $OUT/session.log
 DB=$(find $OUT/prof -name "*.db" | head -1)
 python tools/rocprof_summary.py $DB $OUT/bench_kernel_stats.md "bench.py --steps 5 --warmup 1 --no-cpu-baseline (rocprofv3 --kernel-trace --stats)" > /dev/null
 head -20 $OUT/bench_kernel_stats.md | tee -a $OUT/session.log
+echo "== rocprof kernel trace of the eigensolver alone (4 calls at n = 3072)" | tee -a $OUT/session.log
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_eigh -o eigh -- python $R/tools/eigh_only.py 3072 4 > $R/$OUT/rocprof_eigh.log 2>&1); echo "rocprof eigh exit $?" | tee -a $OUT/session.log
+DBE=$(find $OUT/prof_eigh -name "*.db" | head -1)
+python tools/rocprof_summary.py $DBE $OUT/eigh_kernel_stats.md "tools/eigh_only.py 3072 4 (rocprofv3 --kernel-trace --stats)" > /dev/null
+head -16 $OUT/eigh_kernel_stats.md | tee -a $OUT/session.log
+rm -rf $OUT/prof_eigh
 echo "== PMC passes (own runs, no tracing domains besides kernel dispatch)" | tee -a $OUT/session.log
 for CNT in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d $R/$OUT/pmc_$CNT -o pmc -- python $R/tools/eigh_only.py 3072 1 > $R/$OUT/pmc_$CNT.log 2>&1); echo "pmc $CNT exit $?" | tee -a $OUT/session.log

@@ -253,6 +253,188 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
     }
 }
 
+// ---- one launch per column for small trailing blocks -------------------------------------
+// Below m ~ 1000 both kernels above are nothing but latency (row kernel 3.5-5 us, matvec >= 4.1 us for a block
+// that streams in well under a microsecond), so for those panels the two are fused: EVERY workgroup repeats
+// the row kernel's work for all columns (reads of the panel, (2i+3) m doubles from L2, instead of a kernel
+// boundary), keeps u and w_{i-1} in LDS, and then does its 8 rows of the matvec.  Its matrix rows are loaded
+// into registers before anything else, so that stream overlaps the prologue.  What one launch writes and the
+// same launch reads elsewhere is double-buffered by column parity (wraw, v.wraw partials, panel dots,
+// reflector scalars); the reflector tails go to the panel only and are copied into A once per panel
+// (`trd_store_reflectors_kernel`), because row j of A is still being read by the other workgroups.
+constexpr int TRD_FUSE_MAX = 1000;         // largest trailing size handled by the fused kernel
+constexpr int TRD_FUSE_IT = 8;             // double2 loads per lane and row: 64 * 8 * 2 >= TRD_FUSE_MAX + 2
+constexpr int TRD_FUSE_LDS = TRD_FUSE_MAX + 8;
+
+struct TrdFusedArgs {
+    double* A; int ld, n;
+    int j, i;                                   // global column, index in the panel
+    double* Vp; double* Wp; int ldp;
+    const double* wraw_prev; double* wraw_cur;
+    const double* partB_prev; int nblk_prev; double* partB_cur;
+    const double* colscal_prev; double* colscal_cur;
+    const double* cdots_prev; double* cdots_cur;
+    double* dvec; double* taus; double* evec;
+    int w0;                                     // first workgroup's row block: absolute row = 8 (blockIdx.x + w0) + ...
+};
+
+__global__ __launch_bounds__(256) void trd_fused_kernel(TrdFusedArgs a) {
+    __shared__ double ul[TRD_FUSE_LDS], wl[TRD_FUSE_LDS];
+    __shared__ double red[4];
+    __shared__ double pred[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = a.j, i = a.i, ip = i - 1, n = a.n, ldp = a.ldp;
+    const int o = j + 1, m = n - o, L = n - j;
+    const int oc = o & ~1, shift = o - oc;
+    const int n2 = (m + shift + 1) >> 1;
+    // ---- this wave's two rows of the product: addresses and data first ------------------------------------
+    // virtual row index v: [o, n) matrix rows, [n, n+i) rows W_p, [n+i, n+2i) rows V_p
+    const int vtot = n + 2 * i;
+    double2 rowd[2][TRD_FUSE_IT];
+    double lead[2];
+    int vrow[2];
+    bool from_lds[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int v = 8 * (blockIdx.x + a.w0) + 2 * wave + r;
+        vrow[r] = v;
+        from_lds[r] = (v == n + ip) && i > 0;                 // W_{i-1}: only exists in this launch's LDS
+        const double* base = nullptr;
+        if (v >= o && v < n) base = a.A + (size_t)v * a.ld;
+        else if (v >= n && v < n + i && !from_lds[r]) base = a.Wp + (size_t)(v - n) * ldp;
+        else if (v >= n + i && v < vtot) base = a.Vp + (size_t)(v - n - i) * ldp;
+        lead[r] = base ? base[o] : 0.0;
+        const double2* b2 = reinterpret_cast<const double2*>(base ? base + oc : a.A);
+#pragma unroll
+        for (int k = 0; k < TRD_FUSE_IT; ++k) {
+            const int q = lane + 64 * k;
+            rowd[r][k] = (base && q < n2) ? b2[q] : make_double2(0.0, 0.0);
+        }
+    }
+    // ---- prologue = the row kernel for ALL columns c = j + l ------------------------------------------------
+    double vw = 0.0;
+    if (i > 0)
+        for (int b = tid; b < a.nblk_prev; b += 256) vw += a.partB_prev[b];
+    const double tau_p = (i > 0) ? a.colscal_prev[0] : 0.0;
+    const double wrawj = (i > 0) ? a.wraw_prev[j] : 0.0;
+    double tsum = 0.0, cc = 0.0;                               // uniform: t = sum_p V_p[j] c1_p + W_p[j] c2_p, cc = sum c1 c2
+    for (int p = 0; p < ip; ++p) {
+        const double c1 = a.cdots_prev[p], c2 = a.cdots_prev[TRD_NBMAX + p];
+        tsum += a.Vp[(size_t)p * ldp + j] * c1 + a.Wp[(size_t)p * ldp + j] * c2;
+        cc += c1 * c2;
+    }
+    constexpr int PL = (TRD_FUSE_MAX + 1 + 255) / 256;         // columns per thread
+    double base_l[PL], s_l[PL], wr_l[PL], vp_l[PL];
+#pragma unroll
+    for (int t = 0; t < PL; ++t) {
+        const int l = tid + 256 * t;
+        const int c = (l < L) ? j + l : n - 1;
+        double q = 0.0, sx = 0.0;
+        for (int p = 0; p < ip; ++p) {
+            const double vc = a.Vp[(size_t)p * ldp + c], wc_p = a.Wp[(size_t)p * ldp + c];
+            sx += vc * a.cdots_prev[p] + wc_p * a.cdots_prev[TRD_NBMAX + p];
+            q += vc * a.Wp[(size_t)p * ldp + j] + wc_p * a.Vp[(size_t)p * ldp + j];
+        }
+        base_l[t] = a.A[(size_t)j * a.ld + c] - q;
+        s_l[t] = sx;
+        wr_l[t] = (i > 0) ? a.wraw_prev[c] : 0.0;
+        vp_l[t] = (i > 0) ? a.Vp[(size_t)ip * ldp + c] : 0.0;
+    }
+    double ss = 0.0;
+    if (i > 0) {
+        vw = block_sum_256(vw, red);
+        const double alpha2 = -0.5 * tau_p * tau_p * (vw - 2.0 * cc);
+        const double wj = tau_p * (wrawj - tsum) + alpha2;
+#pragma unroll
+        for (int t = 0; t < PL; ++t) {
+            const int l = tid + 256 * t;
+            if (l < L) {
+                const double wc = tau_p * (wr_l[t] - s_l[t]) + alpha2 * vp_l[t];
+                const double u = base_l[t] - (vp_l[t] * wj + wc);
+                ul[l] = u;
+                wl[l] = wc;
+                if (blockIdx.x == 0) a.Wp[(size_t)ip * ldp + j + l] = wc;
+                if (l >= 2) ss += u * u;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < PL; ++t) {
+            const int l = tid + 256 * t;
+            if (l < L) {
+                ul[l] = base_l[t];
+                if (l >= 2) ss += base_l[t] * base_l[t];
+            }
+        }
+    }
+    ss = block_sum_256(ss, red);                               // (its barriers also publish ul / wl)
+    const double alpha = ul[1];
+    if (blockIdx.x == 0 && tid == 0) a.dvec[j] = ul[0];
+    double beta, tau, scale;
+    if (ss == 0.0) { beta = alpha; tau = 0.0; scale = 0.0; }
+    else {
+        const double nrm = sqrt(alpha * alpha + ss);
+        beta = (alpha >= 0.0) ? -nrm : nrm;
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+    }
+    // ---- the wave's two rows against u' (u behind column o; 0 at column o, in the alignment pad, beyond n) ------
+    double pw = 0.0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int v = vrow[r];
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < TRD_FUSE_IT; ++k) {
+            const int q = lane + 64 * k;
+            if (q < n2) {
+                const int c0 = oc + 2 * q, c1 = c0 + 1;
+                const double x0 = (c0 > o && c0 < n) ? ul[c0 - j] : 0.0;
+                const double x1 = (c1 > o && c1 < n) ? ul[c1 - j] : 0.0;
+                double a0 = rowd[r][k].x, a1 = rowd[r][k].y;
+                if (from_lds[r]) {
+                    a0 = (c0 >= j && c0 < n) ? wl[c0 - j] : 0.0;
+                    a1 = (c1 >= j && c1 < n) ? wl[c1 - j] : 0.0;
+                }
+                acc += a0 * x0 + a1 * x1;
+            }
+        }
+        acc = wave_sum_e(acc);
+        if (lane == 0 && v >= o && v < vtot) {
+            const double ld0 = from_lds[r] ? wl[o - j] : lead[r];
+            const double res = scale * acc + ld0;
+            if (v < n) {
+                const double vr = (v == o) ? 1.0 : scale * ul[v - j];
+                a.wraw_cur[v] = res;
+                a.Vp[(size_t)i * ldp + v] = vr;
+                pw += vr * res;
+            } else if (v < n + i) {
+                a.cdots_cur[v - n] = res;
+            } else {
+                a.cdots_cur[TRD_NBMAX + v - n - i] = res;
+            }
+        }
+    }
+    if (lane == 0) pred[wave] = pw;
+    __syncthreads();
+    if (tid == 0) {
+        a.partB_cur[blockIdx.x] = pred[0] + pred[1] + pred[2] + pred[3];
+        if (blockIdx.x == 0) {
+            a.taus[j] = tau;
+            a.evec[j] = beta;
+            a.colscal_cur[0] = tau;
+            a.colscal_cur[1] = scale;
+        }
+    }
+}
+
+// reflector tails of a finished panel: A[j0 + i][c] = V_i[c] for c >= j0 + i + 2 (read by the back-transformation)
+__global__ __launch_bounds__(256) void trd_store_reflectors_kernel(double* __restrict__ A, int ld, int n, int j0,
+                                                                   const double* __restrict__ Vp, int ldp) {
+    const int i = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c < n && c >= j0 + i + 2) A[(size_t)(j0 + i) * ld + c] = Vp[(size_t)i * ldp + c];
+}
+
 __global__ void tridiag_tail_kernel(const double* __restrict__ A, int ld, int n, double* dvec,
                                     double* evec, double* taus) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -858,7 +1040,7 @@ struct EighWork {
 };
 
 // vec slots (each ld doubles)
-enum { V_D = 0, V_E, V_W, V_Z, V_CS0, V_CS1, V_DD, V_WD, V_TAU, V_ZH, V_LAM, V_TAUS, V_U0, V_U1, V_WRAW, V_COL,
+enum { V_D = 0, V_E, V_W, V_Z, V_CS0, V_CS1, V_DD, V_WD, V_TAU, V_ZH, V_LAM, V_TAUS, V_U0, V_U1, V_WRAW, V_COL, V_WRAW2,
        V_NSLOTS };
 
 struct MergePlan {
@@ -1127,13 +1309,19 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     SCHK(scratch_get(c, SCR_MISC0, (size_t)2 * TRD_NBMAX * ld * sizeof(double), &Vp));
     Wp = Vp + (size_t)TRD_NBMAX * ld;
     const int maxblkA = (n + 255) / 256 + 1, maxblkB = (n + 16 + 2 * TRD_NBMAX + 1) / 2 + 1;
-    SCHK(scratch_get(c, SCR_MISC1, ((size_t)2 * maxblkA * TRD_PA + maxblkB + 2 * TRD_NBMAX + 64) * sizeof(double), &part));
+    SCHK(scratch_get(c, SCR_MISC1, ((size_t)2 * maxblkA * TRD_PA + 2 * (size_t)maxblkB + 4 * TRD_NBMAX + 64) * sizeof(double), &part));
     double* partA[2] = {part, part + (size_t)maxblkA * TRD_PA};
     double* partB = part + 2 * (size_t)maxblkA * TRD_PA;
     double* ub[2] = {W.vec + (size_t)V_U0 * ld, W.vec + (size_t)V_U1 * ld};
     double* wraw = W.vec + (size_t)V_WRAW * ld;
     double* colscal = W.vec + (size_t)V_COL * ld;
     double* cdots = partB + maxblkB + 8;               // 2 * TRD_NBMAX doubles
+    // second copies for the fused one-launch-per-column kernel (double-buffered by column parity)
+    double* wraw2[2] = {wraw, W.vec + (size_t)V_WRAW2 * ld};
+    double* colscal2[2] = {colscal, colscal + 8};
+    double* cdots2[2] = {cdots, cdots + 2 * TRD_NBMAX + 8};
+    double* partB2[2] = {partB, cdots + 4 * TRD_NBMAX + 16};
+    const int fuse_max = (c->opt.eigh_fuse && !c->prof) ? TRD_FUSE_MAX : 0;
     // The chain below is ~2n dependent launches whose arguments depend only on n and on the buffer
     // addresses, so it can be captured once per (size, buffers) into a hipGraph and replayed (option
     // `eigh_graph`).  Measured on this stack: a replayed chain of EMPTY kernels costs 2.0 us per launch
@@ -1146,19 +1334,37 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     for (int j0 = 0; j0 < nrefl; j0 += nb) {
         const int kb = std::min(nb, nrefl - j0);
         HIPCHK(hipMemsetAsync(Vp, 0, (size_t)2 * TRD_NBMAX * ld * sizeof(double), c->stream));
-        for (int i = 0; i <= kb; ++i) {
+        const bool fused = (n - j0 - 1) <= fuse_max;
+        int nblkF_prev = 0;
+        for (int i = 0; fused && i < kb; ++i) {
+            const int j = j0 + i, o = j + 1, par = j & 1;
+            TrdFusedArgs fa;
+            fa.A = W.A; fa.ld = ld; fa.n = n; fa.j = j; fa.i = i;
+            fa.Vp = Vp; fa.Wp = Wp; fa.ldp = ld;
+            fa.wraw_prev = wraw2[1 - par]; fa.wraw_cur = wraw2[par];
+            fa.partB_prev = partB2[1 - par]; fa.nblk_prev = nblkF_prev; fa.partB_cur = partB2[par];
+            fa.colscal_prev = colscal2[1 - par]; fa.colscal_cur = colscal2[par];
+            fa.cdots_prev = cdots2[1 - par]; fa.cdots_cur = cdots2[par];
+            fa.dvec = dvec; fa.taus = taus; fa.evec = evec;
+            fa.w0 = (o / 64) * 8;
+            const int nblkF = (n + 2 * i - 8 * fa.w0 + 7) / 8;
+            hipLaunchKernelGGL(trd_fused_kernel, dim3(nblkF), dim3(256), 0, c->stream, fa);
+            nblkF_prev = nblkF;
+        }
+        for (int i = fused ? kb : 0; i <= kb; ++i) {
             const int j = j0 + i;
             const bool do_row = i < kb;
+            const int parp = fused ? ((j - 1) & 1) : 0;          // buffers the last fused column wrote
             TrdRowArgs ra;
             ra.A = W.A; ra.ld = ld; ra.n = n; ra.j = j; ra.i = i; ra.do_row = do_row ? 1 : 0;
             ra.Vp = Vp; ra.Wp = Wp; ra.ldp = ld;
             ra.u_prev = ub[1 - cur]; ra.u_cur = ub[cur];
-            ra.wraw = wraw;
+            ra.wraw = wraw2[parp];
             ra.partA_prev = partA[1 - cur]; ra.nblkA_prev = nblkA_prev;
             ra.partA_cur = partA[cur];
-            ra.partB = partB; ra.nblkB = nblkB_prev;
-            ra.colscal = colscal;
-            ra.cdots = cdots;
+            ra.partB = partB2[parp]; ra.nblkB = fused ? nblkF_prev : nblkB_prev;
+            ra.colscal = colscal2[parp];
+            ra.cdots = cdots2[parp];
             ra.dvec = dvec;
             const int nblkA = (n - j + 255) / 256;
             const dim3 gA(nblkA), bA(256);
@@ -1210,6 +1416,11 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
         HIPCHK(hipGetLastError());
         // trailing update A22 -= V^T W + W^T V over rows/columns >= j0 + kb
         const int r0 = j0 + kb, mt = n - r0;
+        if (fused) {
+            hipLaunchKernelGGL(trd_store_reflectors_kernel, dim3((n + 255) / 256, kb), dim3(256), 0, c->stream, W.A, ld, n,
+                               j0, Vp, ld);
+            HIPCHK(hipGetLastError());
+        }
         if (mt > 0) {
             double* At = W.A + (size_t)r0 * ld + r0;
             // one fused pass (update.hip): every tile pair is read and written once

@@ -253,15 +253,19 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
     }
 }
 
-// ---- one launch per column for small trailing blocks -------------------------------------
+// ---- one launch per column for small trailing blocks (option `eigh_fuse`, off by default) ----------
 // Below m ~ 1000 both kernels above are nothing but latency (row kernel 3.5-5 us, matvec >= 4.1 us for a block
-// that streams in well under a microsecond), so for those panels the two are fused: EVERY workgroup repeats
-// the row kernel's work for all columns (reads of the panel, (2i+3) m doubles from L2, instead of a kernel
-// boundary), keeps u and w_{i-1} in LDS, and then does its 8 rows of the matvec.  Its matrix rows are loaded
-// into registers before anything else, so that stream overlaps the prologue.  What one launch writes and the
-// same launch reads elsewhere is double-buffered by column parity (wraw, v.wraw partials, panel dots,
-// reflector scalars); the reflector tails go to the panel only and are copied into A once per panel
+// that streams in well under a microsecond).  This kernel fuses the two: EVERY workgroup repeats the row
+// kernel's work for all columns (reads of the panel, (2i+3) m doubles from L2, instead of a kernel boundary),
+// keeps u and w_{i-1} in LDS, and then does its 8 rows of the matvec; its matrix rows are loaded into
+// registers before anything else, so that stream overlaps the prologue.  What one launch writes and the same
+// launch reads elsewhere is double-buffered by column parity (wraw, v.wraw partials, panel dots, reflector
+// scalars); the reflector tails go to the panel only and are copied into A once per panel
 // (`trd_store_reflectors_kernel`), because row j of A is still being read by the other workgroups.
+// MEASURED (gpurun_out/r27): correct, but 11.5 us per column against ~8 us for the two kernels it replaces
+// (n = 768: 10.9 vs 8.5 ms, n = 3072: 50.6 vs 47.0 ms): pulling the panel through every CU (up to 240 KB per
+// workgroup at panel column 15) with an un-unrolled panel loop costs more than the launch it saves.  Kept as
+// the starting point for a version with a compile-time panel depth and a narrower panel.
 constexpr int TRD_FUSE_MAX = 1000;         // largest trailing size handled by the fused kernel
 constexpr int TRD_FUSE_IT = 8;             // double2 loads per lane and row: 64 * 8 * 2 >= TRD_FUSE_MAX + 2
 constexpr int TRD_FUSE_LDS = TRD_FUSE_MAX + 8;

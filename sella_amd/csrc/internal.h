@@ -95,7 +95,8 @@ struct Options {
     long panel_mfma = 1;     // 1: products with more than 8 right-hand sides stream the matrix once (MFMA panel kernel)
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
-    long eigh_fuse = 1;      // 1: one fused launch per column once the trailing block is <= 1000 (eigh.hip)
+    long eigh_fuse = 0;      // 1: one fused launch per column once the trailing block is <= 1000 (eigh.hip);
+                             // measured SLOWER (11.5 us per column against 8 us for the two-kernel scheme)
     long eigh_graph = 0;     // 1: replay the tridiagonalisation launch chain from a cached hipGraph (n >= 512);
                              // measured neutral (38.4 vs 37.5 ms at n = 3072): the chain is bound by the
                              // kernels' own dependent memory round trips, not by the dispatch gap

@@ -87,6 +87,19 @@ def test_benchmark_size(ctx):
     check(ctx, P, tol=2e-12)
 
 
+def test_fused_column_kernel(ctx):
+    """Option `eigh_fuse`: one launch per column of the tridiagonalisation (eigh.hip, `trd_fused_kernel`)."""
+    rng = np.random.RandomState(11)
+    ctx.set_option('eigh_fuse', 1)
+    try:
+        for n in (5, 37, 150):
+            for name, A in cases(n, rng):
+                if name in ('random', 'identity + low rank', 'tridiagonal'):
+                    check(ctx, A)
+    finally:
+        ctx.set_option('eigh_fuse', 0)
+
+
 @pytest.mark.gpu
 def test_graph_replay(ctx):
     """Option `eigh_graph`: the tridiagonalisation chain is captured once per size and replayed (eigh.hip); the

@@ -262,10 +262,11 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
 // launch reads elsewhere is double-buffered by column parity (wraw, v.wraw partials, panel dots, reflector
 // scalars); the reflector tails go to the panel only and are copied into A once per panel
 // (`trd_store_reflectors_kernel`), because row j of A is still being read by the other workgroups.
-// MEASURED (gpurun_out/r27): correct, but 11.5 us per column against ~8 us for the two kernels it replaces
-// (n = 768: 10.9 vs 8.5 ms, n = 3072: 50.6 vs 47.0 ms): pulling the panel through every CU (up to 240 KB per
-// workgroup at panel column 15) with an un-unrolled panel loop costs more than the launch it saves.  Kept as
-// the starting point for a version with a compile-time panel depth and a narrower panel.
+// MEASURED (gpurun_out/r27, r28): correct and no faster.  With a plain panel loop 11.5 us per column; with the
+// panel depth as a compile-time constant (loads batched, 253-256 VGPRs) 8 us per column — exactly what the two
+// kernels it replaces take (n = 768: 9.2 vs 8.6 ms, 8.5 ms with 8-wide panels; n = 3072: 47.6 vs 47.3 ms).  One
+// launch or two, a column is the same chain of dependent memory round trips (panel + previous results in,
+// two block reductions, rows, partials out); the launch boundary itself is not what costs.  Off by default.
 constexpr int TRD_FUSE_MAX = 1000;         // largest trailing size handled by the fused kernel
 constexpr int TRD_FUSE_IT = 8;             // double2 loads per lane and row: 64 * 8 * 2 >= TRD_FUSE_MAX + 2
 constexpr int TRD_FUSE_LDS = TRD_FUSE_MAX + 8;
@@ -282,6 +283,9 @@ struct TrdFusedArgs {
     int w0;                                     // first workgroup's row block: absolute row = 8 (blockIdx.x + w0) + ...
 };
 
+// IPC: finished panel columns (i - 1) as a compile-time constant (all panel loads of a column in flight
+// together, as in trd_row_kernel); IPC < 0: generic loop.
+template <int IPC>
 __global__ __launch_bounds__(256) void trd_fused_kernel(TrdFusedArgs a) {
     __shared__ double ul[TRD_FUSE_LDS], wl[TRD_FUSE_LDS];
     __shared__ double red[4];
@@ -321,11 +325,29 @@ __global__ __launch_bounds__(256) void trd_fused_kernel(TrdFusedArgs a) {
         for (int b = tid; b < a.nblk_prev; b += 256) vw += a.partB_prev[b];
     const double tau_p = (i > 0) ? a.colscal_prev[0] : 0.0;
     const double wrawj = (i > 0) ? a.wraw_prev[j] : 0.0;
+    const int np = (IPC >= 0) ? IPC : ip;
+    constexpr int NPC = (IPC >= 0) ? (IPC > 0 ? IPC : 1) : 1;
     double tsum = 0.0, cc = 0.0;                               // uniform: t = sum_p V_p[j] c1_p + W_p[j] c2_p, cc = sum c1 c2
-    for (int p = 0; p < ip; ++p) {
-        const double c1 = a.cdots_prev[p], c2 = a.cdots_prev[TRD_NBMAX + p];
-        tsum += a.Vp[(size_t)p * ldp + j] * c1 + a.Wp[(size_t)p * ldp + j] * c2;
-        cc += c1 * c2;
+    double c1u[NPC], c2u[NPC], vju[NPC], wju[NPC];             // uniform panel scalars (IPC >= 0: kept in registers)
+    if (IPC >= 0) {
+#pragma unroll
+        for (int p = 0; p < np; ++p) {
+            c1u[p] = a.cdots_prev[p];
+            c2u[p] = a.cdots_prev[TRD_NBMAX + p];
+            vju[p] = a.Vp[(size_t)p * ldp + j];
+            wju[p] = a.Wp[(size_t)p * ldp + j];
+        }
+#pragma unroll
+        for (int p = 0; p < np; ++p) {
+            tsum += vju[p] * c1u[p] + wju[p] * c2u[p];
+            cc += c1u[p] * c2u[p];
+        }
+    } else {
+        for (int p = 0; p < np; ++p) {
+            const double c1 = a.cdots_prev[p], c2 = a.cdots_prev[TRD_NBMAX + p];
+            tsum += a.Vp[(size_t)p * ldp + j] * c1 + a.Wp[(size_t)p * ldp + j] * c2;
+            cc += c1 * c2;
+        }
     }
     constexpr int PL = (TRD_FUSE_MAX + 1 + 255) / 256;         // columns per thread
     double base_l[PL], s_l[PL], wr_l[PL], vp_l[PL];
@@ -334,10 +356,24 @@ __global__ __launch_bounds__(256) void trd_fused_kernel(TrdFusedArgs a) {
         const int l = tid + 256 * t;
         const int c = (l < L) ? j + l : n - 1;
         double q = 0.0, sx = 0.0;
-        for (int p = 0; p < ip; ++p) {
-            const double vc = a.Vp[(size_t)p * ldp + c], wc_p = a.Wp[(size_t)p * ldp + c];
-            sx += vc * a.cdots_prev[p] + wc_p * a.cdots_prev[TRD_NBMAX + p];
-            q += vc * a.Wp[(size_t)p * ldp + j] + wc_p * a.Vp[(size_t)p * ldp + j];
+        if (IPC >= 0) {
+            double vcs[NPC], wcs[NPC];
+#pragma unroll
+            for (int p = 0; p < np; ++p) {                     // load all, then use
+                vcs[p] = a.Vp[(size_t)p * ldp + c];
+                wcs[p] = a.Wp[(size_t)p * ldp + c];
+            }
+#pragma unroll
+            for (int p = 0; p < np; ++p) {
+                sx += vcs[p] * c1u[p] + wcs[p] * c2u[p];
+                q += vcs[p] * wju[p] + wcs[p] * vju[p];
+            }
+        } else {
+            for (int p = 0; p < np; ++p) {
+                const double vc = a.Vp[(size_t)p * ldp + c], wc_p = a.Wp[(size_t)p * ldp + c];
+                sx += vc * a.cdots_prev[p] + wc_p * a.cdots_prev[TRD_NBMAX + p];
+                q += vc * a.Wp[(size_t)p * ldp + j] + wc_p * a.Vp[(size_t)p * ldp + j];
+            }
         }
         base_l[t] = a.A[(size_t)j * a.ld + c] - q;
         s_l[t] = sx;
@@ -1352,7 +1388,16 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
             fa.dvec = dvec; fa.taus = taus; fa.evec = evec;
             fa.w0 = (o / 64) * 8;
             const int nblkF = (n + 2 * i - 8 * fa.w0 + 7) / 8;
-            hipLaunchKernelGGL(trd_fused_kernel, dim3(nblkF), dim3(256), 0, c->stream, fa);
+            switch (i - 1) {
+#define SELLA_TRD_FUSED_CASE(IP) case IP: hipLaunchKernelGGL(HIP_KERNEL_NAME(trd_fused_kernel<IP>), dim3(nblkF), dim3(256), 0, c->stream, fa); break;
+                case -1:
+                SELLA_TRD_FUSED_CASE(0) SELLA_TRD_FUSED_CASE(1) SELLA_TRD_FUSED_CASE(2) SELLA_TRD_FUSED_CASE(3)
+                SELLA_TRD_FUSED_CASE(4) SELLA_TRD_FUSED_CASE(5) SELLA_TRD_FUSED_CASE(6) SELLA_TRD_FUSED_CASE(7)
+                SELLA_TRD_FUSED_CASE(8) SELLA_TRD_FUSED_CASE(9) SELLA_TRD_FUSED_CASE(10) SELLA_TRD_FUSED_CASE(11)
+                SELLA_TRD_FUSED_CASE(12) SELLA_TRD_FUSED_CASE(13) SELLA_TRD_FUSED_CASE(14) SELLA_TRD_FUSED_CASE(15)
+#undef SELLA_TRD_FUSED_CASE
+                default: hipLaunchKernelGGL(HIP_KERNEL_NAME(trd_fused_kernel<-1>), dim3(nblkF), dim3(256), 0, c->stream, fa);
+            }
             nblkF_prev = nblkF;
         }
         for (int i = fused ? kb : 0; i <= kb; ++i) {

@@ -96,7 +96,7 @@ struct Options {
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
     long eigh_fuse = 0;      // 1: one fused launch per column once the trailing block is <= 1000 (eigh.hip);
-                             // measured SLOWER (11.5 us per column against 8 us for the two-kernel scheme)
+                             // measured no faster (8 us per column either way, see the kernel's comment)
     long eigh_graph = 0;     // 1: replay the tridiagonalisation launch chain from a cached hipGraph (n >= 512);
                              // measured neutral (38.4 vs 37.5 ms at n = 3072): the chain is bound by the
                              // kernels' own dependent memory round trips, not by the dispatch gap

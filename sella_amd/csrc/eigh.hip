@@ -105,19 +105,50 @@ __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
     // ---- one pass over the finished panel columns p < i-1
     double s = 0.0, q = 0.0, cc = 0.0, t = 0.0;
     const int np = (IPC >= 0) ? IPC : ip;
+    bool vw_done = false;
+    if (IPC > 8) {
+        // Deep panels: the 4 uniform scalars per panel column (W_p.v, V_p.v, V_p[j], W_p[j]) no longer fit the
+        // scalar register file (58 SGPRs spilled at depth 15, and the row kernel went from 4.4 to 7.9 us): they
+        // are fetched once by 4 IPC lanes into LDS and read back as broadcasts, behind the barrier the v.wraw
+        // reduction needs anyway; the per-column panel loads are issued before it.
+        __shared__ double uni[4 * 16];
+        constexpr int NPC = IPC > 0 ? IPC : 1;
+        double vcs[NPC], wcs[NPC];
 #pragma unroll
-    for (int p = 0; p < np; ++p) {
-        const double c1 = a.cdots[p], c2 = a.cdots[TRD_NBMAX + p];          // W_p.v, V_p.v (uniform)
-        const double vj = a.Vp[(size_t)p * ldp + j], wj_p = a.Wp[(size_t)p * ldp + j];
-        const double vc = a.Vp[(size_t)p * ldp + cl], wcp = a.Wp[(size_t)p * ldp + cl];
-        s += vc * c1 + wcp * c2;
-        q += vc * wj_p + wcp * vj;
-        cc += c1 * c2;
-        t += vj * c1 + wj_p * c2;
+        for (int p = 0; p < NPC; ++p) {
+            vcs[p] = a.Vp[(size_t)p * ldp + cl];
+            wcs[p] = a.Wp[(size_t)p * ldp + cl];
+        }
+        if (tid < 4 * NPC) {
+            const int p = tid >> 2, k = tid & 3;
+            uni[tid] = (k == 0) ? a.cdots[p] : (k == 1) ? a.cdots[TRD_NBMAX + p]
+                     : (k == 2) ? a.Vp[(size_t)p * ldp + j] : a.Wp[(size_t)p * ldp + j];
+        }
+        vw = block_sum_256(vw, red);                                        // (i > 0 always holds here)
+        vw_done = true;
+#pragma unroll
+        for (int p = 0; p < NPC; ++p) {
+            const double c1 = uni[4 * p], c2 = uni[4 * p + 1], vj = uni[4 * p + 2], wj_p = uni[4 * p + 3];
+            s += vcs[p] * c1 + wcs[p] * c2;
+            q += vcs[p] * wj_p + wcs[p] * vj;
+            cc += c1 * c2;
+            t += vj * c1 + wj_p * c2;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < np; ++p) {
+            const double c1 = a.cdots[p], c2 = a.cdots[TRD_NBMAX + p];          // W_p.v, V_p.v (uniform)
+            const double vj = a.Vp[(size_t)p * ldp + j], wj_p = a.Wp[(size_t)p * ldp + j];
+            const double vc = a.Vp[(size_t)p * ldp + cl], wcp = a.Wp[(size_t)p * ldp + cl];
+            s += vc * c1 + wcp * c2;
+            q += vc * wj_p + wcp * vj;
+            cc += c1 * c2;
+            t += vj * c1 + wj_p * c2;
+        }
     }
     double wc = 0.0, u = 0.0;
     if (i > 0) {
-        vw = block_sum_256(vw, red);
+        if (!vw_done) vw = block_sum_256(vw, red);
         const double alpha2 = -0.5 * tau * tau * (vw - 2.0 * cc);
         const double wj = tau * (wrawj - t) + alpha2;           // w_{i-1}[j], v_{i-1}[j] = 1
         wc = tau * (wrawc - s) + alpha2 * vprev;

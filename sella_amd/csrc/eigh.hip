@@ -106,12 +106,12 @@ __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
     double s = 0.0, q = 0.0, cc = 0.0, t = 0.0;
     const int np = (IPC >= 0) ? IPC : ip;
     bool vw_done = false;
-    if (IPC > 8) {
+    if (IPC > 3) {
         // Deep panels: the 4 uniform scalars per panel column (W_p.v, V_p.v, V_p[j], W_p[j]) no longer fit the
         // scalar register file (58 SGPRs spilled at depth 15, and the row kernel went from 4.4 to 7.9 us): they
         // are fetched once by 4 IPC lanes into LDS and read back as broadcasts, behind the barrier the v.wraw
         // reduction needs anyway; the per-column panel loads are issued before it.
-        __shared__ double uni[4 * 16];
+        __shared__ double uni[4 * 32];
         constexpr int NPC = IPC > 0 ? IPC : 1;
         double vcs[NPC], wcs[NPC];
 #pragma unroll
@@ -1464,6 +1464,10 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
                 SELLA_TRD_ROW_CASE(4) SELLA_TRD_ROW_CASE(5) SELLA_TRD_ROW_CASE(6) SELLA_TRD_ROW_CASE(7)
                 SELLA_TRD_ROW_CASE(8) SELLA_TRD_ROW_CASE(9) SELLA_TRD_ROW_CASE(10) SELLA_TRD_ROW_CASE(11)
                 SELLA_TRD_ROW_CASE(12) SELLA_TRD_ROW_CASE(13) SELLA_TRD_ROW_CASE(14) SELLA_TRD_ROW_CASE(15)
+                SELLA_TRD_ROW_CASE(16) SELLA_TRD_ROW_CASE(17) SELLA_TRD_ROW_CASE(18) SELLA_TRD_ROW_CASE(19)
+                SELLA_TRD_ROW_CASE(20) SELLA_TRD_ROW_CASE(21) SELLA_TRD_ROW_CASE(22) SELLA_TRD_ROW_CASE(23)
+                SELLA_TRD_ROW_CASE(24) SELLA_TRD_ROW_CASE(25) SELLA_TRD_ROW_CASE(26) SELLA_TRD_ROW_CASE(27)
+                SELLA_TRD_ROW_CASE(28) SELLA_TRD_ROW_CASE(29) SELLA_TRD_ROW_CASE(30) SELLA_TRD_ROW_CASE(31)
 #undef SELLA_TRD_ROW_CASE
                 default: SELLA_LAUNCH(c, HIP_KERNEL_NAME(trd_row_kernel<-1>), gA, bA, 0, ra);
             }

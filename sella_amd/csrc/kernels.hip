@@ -349,7 +349,18 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restric
     __shared__ double red[4];
     const double* p = P + (size_t)blockIdx.x * ldp;
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += p[i] * p[i];
+    // usually ONE row (the residual of the lowest Ritz pair): a single workgroup walks it, so the loads are
+    // issued four at a time instead of one per trip (12 dependent trips at n = 3072 cost 12 us)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 1024) {
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 256 * k;
+            v[k] = p[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += (i0 + 256 * k < n) ? v[k] * v[k] : 0.0;
+    }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();

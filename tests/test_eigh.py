@@ -92,9 +92,10 @@ def test_fused_column_kernel(ctx):
     rng = np.random.RandomState(11)
     ctx.set_option('eigh_fuse', 1)
     try:
-        for n in (5, 37, 150):
+        for n, names in ((5, ('random', 'tridiagonal')), (37, ('random', 'identity + low rank', 'tridiagonal')),
+                         (90, ('hessian-like',))):
             for name, A in cases(n, rng):
-                if name in ('random', 'identity + low rank', 'tridiagonal'):
+                if name in names:
                     check(ctx, A)
     finally:
         ctx.set_option('eigh_fuse', 0)

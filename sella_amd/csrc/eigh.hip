@@ -942,6 +942,41 @@ __global__ __launch_bounds__(256) void wy_apply_kernel(double* __restrict__ X, i
     }
 }
 
+// C_b = T_b^T from the block's Gram matrix, in place: T^-1 = striu(Y Y^T) + diag(1/tau) (forward, columnwise
+// compact WY), inverted by back-substitution — one workgroup per block, thread `col` owns column col of T.
+// (This was host code between two synchronisations, ~1 ms with the queue empty at n = 3072.)
+__global__ __launch_bounds__(64) void wy_tinv_kernel(double* __restrict__ G, int nrefl,
+                                                     const double* __restrict__ taus) {
+    __shared__ double S[WY_NB][WY_NB + 1], Tm[WY_NB][WY_NB + 1];
+    const int b = blockIdx.x, j0 = b * WY_NB;
+    const int kb = (nrefl - j0 < WY_NB) ? (nrefl - j0) : WY_NB;
+    double* Gb = G + (size_t)b * WY_NB * WY_NB;
+    for (int e = threadIdx.x; e < WY_NB * WY_NB; e += 64) {
+        const int i = e / WY_NB, k2 = e % WY_NB;
+        double v = 0.0;
+        if (i < kb && k2 < kb) {
+            if (k2 > i) v = Gb[e];
+            else if (k2 == i) { const double t = taus[j0 + i]; v = (t != 0.0) ? 1.0 / t : 1.0; }
+        }
+        S[i][k2] = v;
+        Tm[i][k2] = 0.0;
+    }
+    __syncthreads();
+    const int col = threadIdx.x;
+    if (col < kb) {
+        for (int i = col; i >= 0; --i) {                       // entries below the diagonal of T stay zero
+            double s = (i == col) ? 1.0 : 0.0;
+            for (int k2 = i + 1; k2 <= col; ++k2) s -= S[i][k2] * Tm[k2][col];
+            Tm[i][col] = s / S[i][i];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < WY_NB * WY_NB; e += 64) {
+        const int p = e / WY_NB, q = e % WY_NB;                  // C[p][q] = T[q][p]
+        Gb[e] = (p < kb && q < kb) ? Tm[q][p] : 0.0;
+    }
+}
+
 // ---- MFMA back-transformation -------------------------------------------------------------------
 typedef double wy_f64x4 __attribute__((ext_vector_type(4)));
 
@@ -1864,11 +1899,21 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     double* taus = W.vec + (size_t)V_TAUS * ld;
     HIPCHK(hipMemsetAsync(W.vec, 0, (size_t)V_NSLOTS * ld * sizeof(double), c->stream));
     SCHK(tridiagonalise(W, taus, dvec, evec));
-    std::vector<double> d(n), e(n), tauh(n);
+    std::vector<double> d(n), e(n);
     HIPCHK(hipMemcpyAsync(d.data(), dvec, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(e.data(), evec, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(tauh.data(), taus, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    // The compact-WY factors of the back-transformation depend on the reflectors only: their Gram matrices
+    // and triangular factors are enqueued now and run while the host plans the divide & conquer stage.
+    const int nrefl = n - 2;
+    const int nblk = nrefl > 0 ? (nrefl + WY_NB - 1) / WY_NB : 0;
+    double* Gd = nullptr;                                // nblk x 32 x 32: Gram matrices, then C = T^T
+    if ((hV || hVt) && nblk > 0) {
+        SCHK(scratch_get(c, SCR_EIG6, (size_t)nblk * WY_NB * WY_NB * sizeof(double), &Gd));
+        hipLaunchKernelGGL(wy_gram_kernel, dim3(nblk), dim3(256), 0, c->stream, W.A, ld, n, nrefl, taus, Gd);
+        hipLaunchKernelGGL(wy_tinv_kernel, dim3(nblk), dim3(64), 0, c->stream, Gd, nrefl, taus);
+        HIPCHK(hipGetLastError());
+    }
 
     const double t_s1 = now();
     // ---- stage 2 ----------------------------------------------------------------------------
@@ -1878,39 +1923,7 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     const double t_s2 = now();
     // ---- stage 3: X = Z H_{n-3} ... H_0 (rows) -------------------------------------------------
     double* X = W.Za;
-    const int nrefl = n - 2;
     if (nrefl > 0) {
-        const int nblk = (nrefl + WY_NB - 1) / WY_NB;
-        double* Gd = W.Zb;                               // nblk x 32 x 32 Gram matrices, then C = T^T
-        const size_t gcount = (size_t)nblk * WY_NB * WY_NB;
-        hipLaunchKernelGGL(wy_gram_kernel, dim3(nblk), dim3(256), 0, c->stream, W.A, ld, n, nrefl, taus, Gd);
-        HIPCHK(hipGetLastError());
-        std::vector<double> G(gcount), Call(gcount, 0.0);
-        HIPCHK(hipMemcpyAsync(G.data(), Gd, gcount * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        std::vector<double> S((size_t)WY_NB * WY_NB), Tm((size_t)WY_NB * WY_NB);
-        for (int b = 0; b < nblk; ++b) {
-            const int j0 = b * WY_NB, kb = std::min(WY_NB, nrefl - j0);
-            const double* Gb = G.data() + (size_t)b * WY_NB * WY_NB;
-            // T^-1 = striu(Y^T Y) + diag(1/tau)  (forward, columnwise compact WY)
-            for (int i = 0; i < kb; ++i)
-                for (int k2 = 0; k2 < kb; ++k2) {
-                    double v = 0.0;
-                    if (k2 > i) v = Gb[(size_t)i * WY_NB + k2];
-                    else if (k2 == i) v = (tauh[j0 + i] != 0.0) ? 1.0 / tauh[j0 + i] : 1.0;
-                    S[(size_t)i * kb + k2] = v;
-                }
-            for (int col = 0; col < kb; ++col)
-                for (int i = kb - 1; i >= 0; --i) {
-                    double s = (i == col) ? 1.0 : 0.0;
-                    for (int k2 = i + 1; k2 < kb; ++k2) s -= S[(size_t)i * kb + k2] * Tm[(size_t)k2 * kb + col];
-                    Tm[(size_t)i * kb + col] = (i <= col) ? s / S[(size_t)i * kb + i] : 0.0;
-                }
-            double* Cb = Call.data() + (size_t)b * WY_NB * WY_NB;      // C[p][q] = T[q][p]
-            for (int p = 0; p < kb; ++p)
-                for (int q = 0; q < kb; ++q) Cb[(size_t)p * WY_NB + q] = Tm[(size_t)q * kb + p];
-        }
-        HIPCHK(hipMemcpyAsync(Gd, Call.data(), gcount * sizeof(double), hipMemcpyHostToDevice, c->stream));
         const int yrows = nblk * WY_NB;
         double* Yf = W.Zc;                               // explicit reflectors (yrows x ld)
         hipLaunchKernelGGL(wy_expand_kernel, dim3((ld + 255) / 256, yrows), dim3(256), 0, c->stream, W.A, ld, n, nrefl,
@@ -1922,7 +1935,6 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
             SELLA_LAUNCH(c, wy_apply_kernel, dim3((n + 15) / 16), dim3(256), 0, X, ld, n, W.A, ld, nrefl, taus, Gd, nblk);
         prof_end(c);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));        // Call goes out of scope
     }
     const double t_s3 = now();
     // ---- outputs -------------------------------------------------------------------------------

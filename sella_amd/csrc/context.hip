@@ -142,6 +142,20 @@ int read_scalars(sella_ctx* c, int offset, int count) {
     return SELLA_OK;
 }
 
+int host_stage(sella_ctx* c, size_t bytes, void** p) {
+    if (bytes > c->hstage_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->hstage) (void)hipHostFree(c->hstage);
+        c->hstage = nullptr;
+        c->hstage_bytes = 0;
+        const size_t want = std::max(bytes + bytes / 2, (size_t)1 << 20);
+        HIPCHK(hipHostMalloc(&c->hstage, want, hipHostMallocDefault));
+        c->hstage_bytes = want;
+    }
+    *p = c->hstage;
+    return SELLA_OK;
+}
+
 double* scal_out(sella_ctx* c, int offset) { return (c->opt.host_scalars ? c->hscal : c->dscal) + offset; }
 
 int sync_scalars(sella_ctx* c, int offset, int count) {
@@ -257,6 +271,7 @@ int sella_ctx_destroy(sella_ctx* c) {
     for (auto& a : c->arenas) (void)hipFree(a.base);       // matrices, panels and scratch all live in the arenas
     if (c->dscal) (void)hipFree(c->dscal);
     if (c->hscal) (void)hipHostFree(c->hscal);
+    if (c->hstage) (void)hipHostFree(c->hstage);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return SELLA_OK;

@@ -1272,8 +1272,28 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
     double* taud = W.vec + (size_t)V_TAU * ld;
     double* zhd = W.vec + (size_t)V_ZH * ld;
     double* lamd = W.vec + (size_t)V_LAM * ld;
-    std::vector<double> z(n), lam(n), hD(n), hw(n), hcs(2 * (size_t)n);
-    std::vector<int> order, hidx(n), hr1(n), hr2(n);
+    // Per-level host <-> device traffic goes through one pinned staging buffer laid out like the device side
+    // (the (c,s) | D | w slots and the int arrays are contiguous there), so a level is 4 asynchronous uploads
+    // and 2 downloads instead of 13 pageable — i.e. synchronous, ~20 us each — copies.
+    void* stage;
+    const size_t nmmax = (size_t)n / 2 + 8;
+    const size_t stage_doubles = 4 * (size_t)ld + 2 * (size_t)n + 8;
+    const size_t stage_ints = 5 * (size_t)n + 4 * nmmax + 16;
+    SCHK(host_stage(c, stage_doubles * sizeof(double) + stage_ints * sizeof(int) + nmmax * sizeof(MergeDev), &stage));
+    double* hcs = static_cast<double*>(stage);                 // mirrors csd (2 slots), Dd, wd
+    double* hD = hcs + 2 * (size_t)ld;
+    double* hw = hcs + 3 * (size_t)ld;
+    double* z = hcs + 4 * (size_t)ld;
+    double* lam = z + n;
+    int* hint = reinterpret_cast<int*>(lam + n + 8);           // [hi2 (8)] then mirrors i1d | i2d | idxd
+    int* hi2 = hint;
+    int* hr1 = hint + 8;
+    int* hr2 = hr1 + n;
+    int* hidx = hr1 + 2 * (size_t)n;
+    int* hmrow = hr1 + 3 * (size_t)n;                          // mirrors mrowd | gdescd (device: + n for orgd in between)
+    int* hgd = hmrow + n;
+    MergeDev* hmd = reinterpret_cast<MergeDev*>(hgd + 4 * nmmax + 8 - ((4 * nmmax + 8) & 1));
+    std::vector<int> order;
     // Eigenvector rows of a node are supported on its own column range only, so everything outside the
     // diagonal blocks must read as zero.  One clearing of the second buffer suffices: level h overwrites
     // its diagonal blocks completely (K updated + N-K deflated rows of N columns each), and the blocks
@@ -1283,8 +1303,6 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
         const std::vector<int>& lvl = by_height[h];
         // ---- (1) rank-one vectors of all merges of this level: one launch, one synchronisation -------
         const int nm = (int)lvl.size();
-        std::vector<MergeDev> hmd(nm);
-        std::vector<int> hmrow(n);
         int maxN = 0;
         for (int mi = 0; mi < nm; ++mi) {
             const Node& nd = nodes[lvl[mi]];
@@ -1295,10 +1313,10 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
             maxN = std::max(maxN, m.N);
             for (int p = nd.lo; p < nd.hi; ++p) hmrow[p] = mi;
         }
-        HIPCHK(hipMemcpyAsync(mdd, hmd.data(), (size_t)nm * sizeof(MergeDev), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(mdd, hmd, (size_t)nm * sizeof(MergeDev), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(gather_z_batched_kernel, dim3((maxN + 255) / 256, nm), dim3(256), 0, c->stream, mdd, cur, ld, zdev);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(z.data(), zdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(z, zdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         // ---- (2) deflation of every merge on the host (dlaed2 logic) ------------------------------
         std::vector<MergePlan> plans(lvl.size());
@@ -1307,7 +1325,7 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
             MergePlan& pl = plans[mi];
             const int lo = nd.lo, N = nd.hi - nd.lo;
             double* D = vals.data() + lo;
-            double* zz = z.data() + lo;
+            double* zz = z + lo;
             pl.lo = lo;
             pl.N = N;
             pl.rho = fabs(2.0 * e[nd.mid - 1]);
@@ -1327,16 +1345,14 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
                 hcs[2 * (size_t)(lo + r) + 1] = pl.cs[2 * r + 1];
             }
         }
-        HIPCHK(hipMemcpyAsync(Dd, hD.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(wd, hw.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(idxd, hidx.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(i1d, hr1.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(i2d, hr2.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(csd, hcs.data(), (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        // (c,s) pairs | D | w in one piece (device slots V_CS0, V_CS1, V_DD, V_WD are consecutive), rotation and
+        // gather indices in another
+        static_assert(V_CS1 == V_CS0 + 1 && V_DD == V_CS0 + 2 && V_WD == V_CS0 + 3, "slot order");
+        HIPCHK(hipMemcpyAsync(csd, hcs, (3 * (size_t)ld + n) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(i1d, hr1, 3 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
         // ---- (3) device work of the whole level: one launch per kernel, blockIdx.y = merge -------------
         {
             int maxK = 0, maxrot = 0;
-            std::vector<int> hgd(4 * (size_t)nm);
             for (int mi = 0; mi < nm; ++mi) {
                 const MergePlan& pl = plans[mi];
                 hmd[mi].K = pl.K;
@@ -1346,9 +1362,8 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
                 maxrot = std::max(maxrot, pl.nrot);
                 hgd[4 * mi] = pl.lo; hgd[4 * mi + 1] = pl.N; hgd[4 * mi + 2] = pl.K; hgd[4 * mi + 3] = 0;
             }
-            HIPCHK(hipMemcpyAsync(mdd, hmd.data(), (size_t)nm * sizeof(MergeDev), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(mrowd, hmrow.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(gdescd, hgd.data(), hgd.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(mdd, hmd, (size_t)nm * sizeof(MergeDev), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(mrowd, hmrow, ((size_t)n + 4 * (size_t)nm) * sizeof(int), hipMemcpyHostToDevice, c->stream));
             if (maxrot > 0)
                 hipLaunchKernelGGL(rot_rows_batched_kernel, dim3((maxN + 63) / 64, nm), dim3(64), 0, c->stream, mdd, cur, ld,
                                    i1d, i2d, csd);
@@ -1366,8 +1381,7 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
             SCHK(launch_gemm_merge_batched(c, nm, gdescd, maxN, maxK, W.Ut, W.Zc, nxt, ld));
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(lam.data(), lamd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        int hi2[2];
+        HIPCHK(hipMemcpyAsync(lam, lamd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(hi2, info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (hi2[1] != 0) {

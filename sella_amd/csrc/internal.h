@@ -139,6 +139,10 @@ struct sella_ctx {
         hipGraphExec_t exec;
         unsigned long stamp;
     };
+    // pinned host staging for bursts of small transfers (divide & conquer levels): pageable copies are
+    // synchronous staged copies, ~20 us each with the queue empty
+    void* hstage = nullptr;
+    size_t hstage_bytes = 0;
     std::vector<TrdGraph> trd_graphs;
     unsigned long trd_stamp = 0;
 };
@@ -149,6 +153,7 @@ namespace sella {
 int mat_new(sella_ctx* c, int rows, int cols, sella_mat* h);       // zero-initialised
 Mat* mat_get(sella_ctx* c, sella_mat h);
 int scratch_get(sella_ctx* c, int slot, size_t bytes, double** p); // persistent scratch slot
+int host_stage(sella_ctx* c, size_t bytes, void** p);               // pinned host staging buffer (grown on demand)
 int dev_alloc(sella_ctx* c, size_t bytes, double** p);             // caching allocator (contents undefined)
 void dev_free(sella_ctx* c, double* p, size_t bytes);
 int upload_panel(sella_ctx* c, const double* X, int n, int k, double* dpanel, int ldp);   // (n x k) host -> k rows

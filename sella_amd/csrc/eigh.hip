@@ -1228,11 +1228,22 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
     double* ddev = W.vec + (size_t)V_D * ld;
     double* edev = W.vec + (size_t)V_E * ld;
     double* wdev = W.vec + (size_t)V_W * ld;
-    HIPCHK(hipMemcpyAsync(ddev, d.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(edev, e.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     const std::vector<int>& leaves = by_height[0];
-    std::vector<int> ranges;
-    for (int li : leaves) { ranges.push_back(nodes[li].lo); ranges.push_back(nodes[li].hi); }
+    // pinned staging (see the level loop below): torn d | e in the layout of the device slots, leaf ranges behind
+    void* stage;
+    const size_t nmmax = (size_t)n / 2 + 8;
+    const size_t stage_doubles = 4 * (size_t)ld + 2 * (size_t)n + 8;
+    const size_t stage_ints = 5 * (size_t)n + 4 * nmmax + 16;
+    SCHK(host_stage(c, stage_doubles * sizeof(double) + stage_ints * sizeof(int) + nmmax * sizeof(MergeDev), &stage));
+    {
+        double* hde = static_cast<double*>(stage);
+        std::copy(d.begin(), d.end(), hde);
+        std::copy(e.begin(), e.end(), hde + ld);
+        HIPCHK(hipMemcpyAsync(ddev, hde, ((size_t)ld + n) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    int* ranges = reinterpret_cast<int*>(static_cast<double*>(stage) + 2 * (size_t)ld);
+    const size_t nranges = 2 * leaves.size();
+    for (size_t q = 0; q < leaves.size(); ++q) { ranges[2 * q] = nodes[leaves[q]].lo; ranges[2 * q + 1] = nodes[leaves[q]].hi; }
     // device int layout: [0,8) info | [8, 8+2*nleaves) leaf ranges | then 4 arrays of n ints
     int* info = W.ibuf;
     int* rdev = W.ibuf + 8;
@@ -1247,16 +1258,23 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
     SCHK(scratch_get(c, SCR_MISC1, ((size_t)n / 2 + 8) * sizeof(MergeDev), &mdraw));
     MergeDev* mdd = reinterpret_cast<MergeDev*>(mdraw);
     HIPCHK(hipMemsetAsync(info, 0, 8 * sizeof(int), c->stream));
-    HIPCHK(hipMemcpyAsync(rdev, ranges.data(), ranges.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(rdev, ranges, nranges * sizeof(int), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(set_identity_kernel, dim3((n + 255) / 256, n), dim3(256), 0, c->stream, W.Za, ld, n);
     hipLaunchKernelGGL(leaf_ql_kernel, dim3((unsigned)leaves.size()), dim3(64), 0, c->stream, ddev, edev, wdev,
                        rdev, W.Za, ld, info);
     HIPCHK(hipGetLastError());
     std::vector<double> vals(n);
     int hinfo[2];
-    HIPCHK(hipMemcpyAsync(vals.data(), wdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(hinfo, info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    {
+        double* hv = static_cast<double*>(stage) + 3 * (size_t)ld;
+        int* hinfo_p = reinterpret_cast<int*>(hv + n);
+        HIPCHK(hipMemcpyAsync(hv, wdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(hinfo_p, info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::copy(hv, hv + n, vals.begin());
+        hinfo[0] = hinfo_p[0];
+        hinfo[1] = hinfo_p[1];
+    }
     if (hinfo[0] != 0) {
         set_error("eigh: QL iteration did not converge in a leaf (eigenvalue %d)", hinfo[0]);
         return SELLA_E_NOCONV;
@@ -1275,11 +1293,6 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
     // Per-level host <-> device traffic goes through one pinned staging buffer laid out like the device side
     // (the (c,s) | D | w slots and the int arrays are contiguous there), so a level is 4 asynchronous uploads
     // and 2 downloads instead of 13 pageable — i.e. synchronous, ~20 us each — copies.
-    void* stage;
-    const size_t nmmax = (size_t)n / 2 + 8;
-    const size_t stage_doubles = 4 * (size_t)ld + 2 * (size_t)n + 8;
-    const size_t stage_ints = 5 * (size_t)n + 4 * nmmax + 16;
-    SCHK(host_stage(c, stage_doubles * sizeof(double) + stage_ints * sizeof(int) + nmmax * sizeof(MergeDev), &stage));
     double* hcs = static_cast<double*>(stage);                 // mirrors csd (2 slots), Dd, wd
     double* hD = hcs + 2 * (size_t)ld;
     double* hw = hcs + 3 * (size_t)ld;
@@ -1411,7 +1424,8 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return vals[a] < vals[b]; });
     for (int i = 0; i < n; ++i) wout[i] = vals[order[i]];
-    HIPCHK(hipMemcpyAsync(idxd, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    std::copy(order.begin(), order.end(), hidx);
+    HIPCHK(hipMemcpyAsync(idxd, hidx, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
     SCHK(launch_gather_rows(c, cur, ld, idxd, n, n, nxt, ld));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (nxt != W.Za) std::swap(W.Za, W.Zb);
@@ -1914,9 +1928,16 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     HIPCHK(hipMemsetAsync(W.vec, 0, (size_t)V_NSLOTS * ld * sizeof(double), c->stream));
     SCHK(tridiagonalise(W, taus, dvec, evec));
     std::vector<double> d(n), e(n);
-    HIPCHK(hipMemcpyAsync(d.data(), dvec, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(e.data(), evec, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    {
+        static_assert(V_E == V_D + 1, "slot order");
+        void* st;
+        SCHK(host_stage(c, ((size_t)ld + n) * sizeof(double), &st));       // pinned: one asynchronous download
+        const double* hd = static_cast<const double*>(st);
+        HIPCHK(hipMemcpyAsync(st, dvec, ((size_t)ld + n) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::copy(hd, hd + n, d.begin());
+        std::copy(hd + ld, hd + ld + n, e.begin());
+    }
     // The compact-WY factors of the back-transformation depend on the reflectors only: their Gram matrices
     // and triangular factors are enqueued now and run while the host plans the divide & conquer stage.
     const int nrefl = n - 2;

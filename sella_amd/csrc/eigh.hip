@@ -1650,8 +1650,19 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     int* orgd = i1d + 3 * n;
     // z = Vt q
     SCHK(launch_gemv_rows(c, Vt, n, n, ld, q, ld, 1, zdev, ld, GemvEpi()));
-    std::vector<double> z(n);
-    HIPCHK(hipMemcpyAsync(z.data(), zdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    // small transfers through the pinned staging buffer, laid out like the device side (see dc_solve)
+    void* stage;
+    SCHK(host_stage(c, (4 * (size_t)ld + 2 * (size_t)n + 8) * sizeof(double) + (3 * (size_t)n + 16) * sizeof(int), &stage));
+    double* hcs = static_cast<double*>(stage);                 // mirrors csd (2 slots) | Dd | wd
+    double* hD = hcs + 2 * (size_t)ld;
+    double* hw = hcs + 3 * (size_t)ld;
+    double* z = hcs + 4 * (size_t)ld;
+    double* lam = z + n;
+    int* hinfo = reinterpret_cast<int*>(lam + n + 8);
+    int* hr1 = hinfo + 8;                                      // mirrors i1d | i2d | idxd
+    int* hr2 = hr1 + n;
+    int* hidx = hr1 + 2 * (size_t)n;
+    HIPCHK(hipMemcpyAsync(z, zdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemsetAsync(info, 0, 8 * sizeof(int), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     // a negative weight is handled on the negated, reversed spectrum: primed index i' <-> row n-1-i'
@@ -1719,8 +1730,6 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     }
     plan_deflation(n, D.data(), zz.data(), pl);
     const int K = pl.K;
-    std::vector<double> hD(std::max(K, 1)), hw(std::max(K, 1)), hcs(2 * (size_t)std::max(pl.nrot, 1));
-    std::vector<int> hidx(n), hr1(std::max(pl.nrot, 1)), hr2(std::max(pl.nrot, 1));
     for (int p = 0; p < K; ++p) {
         hD[p] = D[pl.nondef[p]];
         hw[p] = zz[pl.nondef[p]];
@@ -1733,28 +1742,23 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
         hcs[2 * (size_t)r] = pl.cs[2 * r];
         hcs[2 * (size_t)r + 1] = pl.cs[2 * r + 1];
     }
-    HIPCHK(hipMemcpyAsync(idxd, hidx.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    static_assert(V_CS1 == V_CS0 + 1 && V_DD == V_CS0 + 2 && V_WD == V_CS0 + 3, "slot order");
+    HIPCHK(hipMemcpyAsync(i1d, hr1, 3 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(csd, hcs, (3 * (size_t)ld + n) * sizeof(double), hipMemcpyHostToDevice, c->stream));
     double* nxt = W.Zb;
     if (pl.nrot > 0) {
-        HIPCHK(hipMemcpyAsync(i1d, hr1.data(), (size_t)pl.nrot * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(i2d, hr2.data(), (size_t)pl.nrot * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(csd, hcs.data(), (size_t)2 * pl.nrot * sizeof(double), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(rot_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, Vt, ld, n, pl.nrot, i1d, i2d, csd);
     }
-    std::vector<double> lam(std::max(K, 1));
     if (K > 0) {
-        HIPCHK(hipMemcpyAsync(Dd, hD.data(), (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(wd, hw.data(), (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(secular_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd, wd, pl.rho, taud, orgd, lamd, info);
         hipLaunchKernelGGL(zhat_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd, wd, taud, orgd, zhd);
         hipLaunchKernelGGL(build_u_kernel, dim3(K), dim3(256), 0, c->stream, K, Dd, zhd, taud, orgd, W.Ut, ld);
         HIPCHK(hipGetLastError());
         SCHK(launch_gather_rows(c, Vt, ld, idxd, K, n, W.Zc, ld));
         SCHK(launch_gemm(c, 0, 0, K, n, K, 1.0, W.Ut, ld, W.Zc, ld, 0.0, nxt, ld));
-        HIPCHK(hipMemcpyAsync(lam.data(), lamd, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(lam, lamd, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     if (n - K > 0) SCHK(launch_gather_rows(c, Vt, ld, idxd + K, n - K, n, nxt + (size_t)K * ld, ld));
-    int hinfo[2];
     HIPCHK(hipMemcpyAsync(hinfo, info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (hinfo[1] != 0) {
@@ -1769,7 +1773,8 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nv[a] < nv[b]; });
     for (int i = 0; i < n; ++i) w[i] = nv[order[i]];
-    HIPCHK(hipMemcpyAsync(idxd, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    std::copy(order.begin(), order.end(), hidx);
+    HIPCHK(hipMemcpyAsync(idxd, hidx, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
     SCHK(launch_gather_rows(c, nxt, ld, idxd, n, n, Vt, ld));
     HIPCHK(hipStreamSynchronize(c->stream));
     return SELLA_OK;

@@ -9,7 +9,7 @@ maxiter=40)` call of the HIP path with A and P already resident in HBM — inclu
 eigendecomposition of the preconditioner P that the eigenbasis form of the JD correction needs
 once per call (the reference pays a dense LU per iteration instead).  `value` = Davidson
 iterations (vectors added to the subspace, the unit BASELINE.md quotes) summed over all ranks,
-divided by the slowest rank's time for the K steps.  The steps cycle through `--seeds` (4) independent
+divided by the slowest rank's time for the K steps.  The steps run through `--seeds` (4) x `--starts` (5) independent
 problems of the same recipe, because the exit iteration of one gamma = 0.1 run is chaotic (20 ... 31
 vectors for the same matrices) and the per-call eigh is amortised over it.  Ranks are independent replicas (the path has
 no exchange step), so scaling is weak.
@@ -58,6 +58,7 @@ def main():
     ap.add_argument('--maxiter', type=int, default=40)
     ap.add_argument('--gamma', type=float, default=0.1)
     ap.add_argument('--seeds', type=int, default=4)
+    ap.add_argument('--starts', type=int, default=5)
     ap.add_argument('--converged-n', type=int, default=768)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true')
@@ -92,14 +93,23 @@ def main():
     n = args.n
     # The exit iteration of the gamma = 0.1 run is chaotic (20 ... 31 vectors for the
     # same matrix depending on the last bit of the arithmetic), and the fixed eigh cost is amortised over
-    # it, so the steps cycle through `args.seeds` independent problems of the same recipe and the
-    # reported rate is the average over them.  Seed 0 of rank 0 is the problem the CPU baseline runs.
-    problems = []
+    # it, so the steps run through `args.seeds` independent matrices of the same recipe, each with
+    # `args.starts` start vectors (the recipe's own gradient first, then further draws of the same
+    # distribution) — 20 distinct problems by default, one per step — and the reported rate is the average
+    # over them: a one-ulp change anywhere in the arithmetic moves single exits by +-5 iterations, the mean
+    # over 20 by about one.  Seed 0 / start 0 of rank 0 is the problem the CPU baseline runs.
+    mats = []
     for sd in range(args.seeds):
         A_s, P_s, g_s = hessian_like(n, seed=rank * args.seeds + sd)
-        problems.append((ctx.upload(A_s), ctx.upload(P_s), g_s))
+        mats.append((ctx.upload(A_s), ctx.upload(P_s), g_s))
         if sd == 0:
             A, P, g = A_s, P_s, g_s
+    problems = []
+    for st in range(args.starts):
+        for sd in range(args.seeds):
+            g_v = mats[sd][2] if st == 0 else np.random.RandomState(
+                777000 + 1000 * (rank * args.seeds + sd) + st).normal(size=n)
+            problems.append((mats[sd][0], mats[sd][1], g_v))
     dA, dP = problems[0][0], problems[0][1]
     step_no = [0]
 
@@ -366,7 +376,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'1024-atom-equivalent 3N={n} fp64 Davidson (BASELINE configs[1]), '
                                    f'one independent replica per GPU', 'n': n, 'maxiter': args.maxiter,
-                       'gamma': args.gamma, 'method': 'jd0', 'problems': args.seeds,
+                       'gamma': args.gamma, 'method': 'jd0', 'problems': args.seeds * args.starts, 'matrices': args.seeds,
                        'vectors_per_call': round(total_iters / (args.steps * world), 2)},
             'davidson_loop_only_iter_per_s': round(it2 / t_loop, 1),
             'eigh_ms': round(1e3 * t_eigh, 2),

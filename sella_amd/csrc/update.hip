@@ -13,6 +13,8 @@
 // matvecs) and ONE fused pass over B that symmetrises and applies the rank-2kk update
 // (reads and writes B once: 16 n^2 bytes).  All k x k algebra is host code (host_math.h).
 #include "internal.h"
+#include <chrono>
+#include <cstdlib>
 #include "host_math.h"
 
 namespace sella {
@@ -202,6 +204,9 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
                          double* evals_io, int max_rank, int* nrank1, const SubView* sv = nullptr) {
     if (nrank1) *nrank1 = -1;
     if (sv && sv->nrank1) *sv->nrank1 = -1;
+    const bool dbg_time = getenv("SELLA_DEBUG_TIMING") != nullptr;
+    auto now = [&] { if (dbg_time) (void)hipStreamSynchronize(c->stream); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_u0 = now();
     Mat* B = mat_get(c, hB);
     if (!B || !S || !Y || k <= 0) return SELLA_E_INVALID;
     if (B->rows != n || B->cols != n) { set_error("update_H: B must be %d x %d", n, n); return SELLA_E_INVALID; }
@@ -366,6 +371,7 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
         SCHK(put_k(c, CsT, 2 * (size_t)k * k, &dC));
         SCHK(launch_lincomb(c, n, k, Up, ld, k, dC, k, nullptr, 0, 0, nullptr, 0, 1.0, Zp, ld));
     }
+    const double t_u1 = now();
     B = mat_get(c, hB);
     SCHK(launch_sym_rank2k(c, B->d, n, B->ld, Up, Zp, ld, kk));
     double *Us = nullptr, *Zs = nullptr;
@@ -392,17 +398,23 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
         HIPCHK(hipGetLastError());
         SCHK(launch_sym_rank2k(c, Bs->d, m, Bs->ld, Us, Zs, lds, kk));
     }
+    const double t_u2 = now();
     if (evals_io && hV != SELLA_NO_MAT && 2 * kk <= max_rank) {
         Mat *V = mat_get(c, hV), *Vt = mat_get(c, hVt);
         if (!V || !Vt || V->rows != n || Vt->rows != n) { set_error("update_H: bad eigenvector handles"); return SELLA_E_INVALID; }
         SCHK(eig_lowrank_update(c, n, evals_io, V, Vt, Up, Zp, ld, kk, nrank1));
     }
+    const double t_u3 = now();
     if (sv && sv->evals && sv->V != SELLA_NO_MAT && 2 * kk <= max_rank) {
         Mat *V = mat_get(c, sv->V), *Vt = mat_get(c, sv->Vt);
         if (!V || !Vt || V->rows != sv->m || Vt->rows != sv->m) { set_error("update_H: bad eigenvector handles of the view"); return SELLA_E_INVALID; }
         SCHK(eig_lowrank_update(c, sv->m, sv->evals, V, Vt, Us, Zs, lds, kk, sv->nrank1));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (dbg_time)
+        fprintf(stderr, "update_H n=%d k=%d: vectors %.3f ms, rank-2k (+view gather) %.3f ms, eigen-update %.3f ms (%d rank-one), view %.3f ms (%d)\n",
+                n, k, 1e3 * (t_u1 - t_u0), 1e3 * (t_u2 - t_u1), 1e3 * (t_u3 - t_u2), nrank1 ? *nrank1 : -1,
+                1e3 * (now() - t_u3), (sv && sv->nrank1) ? *sv->nrank1 : -1);
     return SELLA_OK;
 }
 

@@ -96,7 +96,8 @@ struct Options {
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
     long rank2k_rows = 1;    // 1: row-streaming rank-2k update for the (symmetric) trailing block of the tridiagonalisation
-    long rank2k_tile64 = 1;  // 1: 64x64 tile pairs in the fused symmetric rank-2k pass for n >= 256
+    long rank2k_tile64 = 0;  // 1: 64x64 tile pairs in the fused symmetric rank-2k pass for n >= 256 (measured equal to
+                             // the 32x32 tiles: the pass is bound by mixed read/write streaming at ~2.1 TB/s either way)
     long eigh_fuse = 0;      // 1: one fused launch per column once the trailing block is <= 1000 (eigh.hip);
                              // measured no faster (8 us per column either way, see the kernel's comment)
     long eigh_graph = 0;     // 1: replay the tridiagonalisation launch chain from a cached hipGraph (n >= 512);

@@ -86,12 +86,14 @@ __global__ __launch_bounds__(256) void sym_rank2k_kernel(double* __restrict__ B,
     }
 }
 
-// The same pass with 64x64 tile pairs for matrices beyond a few tiles: the 32x32 version re-reads the two
-// panels (4 x kk x 32 doubles) for every 2 x 8 KB of matrix it touches and moves 256-byte row pieces; here a
-// workgroup owns T1 = B[r0.., c0..] (64 x 64) and its mirror, every thread a 4 x 4 micro-tile (rows ty + 16 q,
-// columns 2 tx, 2 tx + 1, 32 + 2 tx, 33 + 2 tx: 16-byte accesses, 256 bytes per row and wavefront quarter), the
-// mirror tile goes through LDS for the transposition both ways, and the grid holds the upper-triangular tile
-// pairs only.  Requires 16-byte aligned rows (B and ld even).
+// The same pass with 64x64 tile pairs (option `rank2k_tile64`): a workgroup owns T1 = B[r0.., c0..] (64 x 64) and
+// its mirror, every thread a 4 x 4 micro-tile (rows ty + 16 q, columns 2 tx, 2 tx + 1, 32 + 2 tx, 33 + 2 tx:
+// 16-byte accesses), the mirror tile goes through LDS for the transposition both ways, and the grid holds the
+// upper-triangular tile pairs only.  Requires 16-byte aligned rows (B and ld even).
+// MEASURED (gpurun_out/r38, r39): no faster than the 32x32 tiles — the 192 trailing updates of a 3072
+// tridiagonalisation take 4.6 ms with either (9.7 GB read + written: 2.1 TB/s), and a variant that streams whole
+// row strips without the mirror tile (possible there because the block is symmetric already) was slower still.
+// The pass is bound by mixed read/write streaming, not by tile shape or panel re-reads.  Off by default.
 constexpr int R2K_T = 64;
 
 __global__ __launch_bounds__(256) void sym_rank2k64_kernel(double* __restrict__ B, int n, int ld,

@@ -310,8 +310,6 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
         c->opt.panel_rows = value;
     } else if (!strcmp(key, "eigh_wy_mfma")) {
         c->opt.eigh_wy_mfma = value ? 1 : 0;
-    } else if (!strcmp(key, "rank2k_rows")) {
-        c->opt.rank2k_rows = value ? 1 : 0;
     } else if (!strcmp(key, "rank2k_tile64")) {
         c->opt.rank2k_tile64 = value ? 1 : 0;
     } else if (!strcmp(key, "eigh_fuse")) {

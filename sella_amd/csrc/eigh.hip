@@ -1571,10 +1571,7 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
         if (mt > 0) {
             double* At = W.A + (size_t)r0 * ld + r0;
             // one fused pass (update.hip): every tile pair is read and written once
-            // the first pass also symmetrises (the caller's matrix need not be symmetric to the last bit); from then
-            // on the block is exactly symmetric and the update streams row strips (update.hip)
-            if (j0 == 0) SCHK(launch_sym_rank2k(c, At, mt, ld, Vp + r0, Wp + r0, ld, kb, -1.0));
-            else SCHK(launch_rank2k_symmetric(c, At, mt, ld, Vp + r0, Wp + r0, ld, kb, -1.0));
+            SCHK(launch_sym_rank2k(c, At, mt, ld, Vp + r0, Wp + r0, ld, kb, -1.0));
         }
     }
     hipLaunchKernelGGL(tridiag_tail_kernel, dim3(1), dim3(64), 0, c->stream, W.A, ld, n, dvec, evec, taus);

@@ -95,7 +95,6 @@ struct Options {
     long panel_mfma = 1;     // 1: products with more than 8 right-hand sides stream the matrix once (MFMA panel kernel)
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
-    long rank2k_rows = 1;    // 1: row-streaming rank-2k update for the (symmetric) trailing block of the tridiagonalisation
     long rank2k_tile64 = 0;  // 1: 64x64 tile pairs in the fused symmetric rank-2k pass for n >= 256 (measured equal to
                              // the 32x32 tiles: the pass is bound by mixed read/write streaming at ~2.1 TB/s either way)
     long eigh_fuse = 0;      // 1: one fused launch per column once the trailing block is <= 1000 (eigh.hip);
@@ -251,8 +250,6 @@ int gs_orthonormalise(sella_ctx* c, const double* basis, int ldb, int k, double*
 // B <- (B + B^T)/2 + alpha * sum_a (U_a Z_a^T + Z_a U_a^T), U/Z vector-major panels with kk rows
 int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, const double* Zp,
                       int ldp, int kk, double alpha = 1.0);
-int launch_rank2k_symmetric(sella_ctx* c, double* B, int n, int ld, const double* Up, const double* Zp, int ldp,
-                            int kk, double alpha);   // B symmetric on entry: no mirror pass
 // eigh.hip: eigendecomposition (w host ascending, Vt rows / V columns, both updated in place) of
 // B + sum_a (U_a Z_a^T + Z_a U_a^T) from that of B; *nrank1 = rank-one modifications applied
 int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const double* Up, const double* Zp,

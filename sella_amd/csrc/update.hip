@@ -258,108 +258,6 @@ int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, 
     return SELLA_OK;
 }
 
-// Rank-2kk update of a matrix that IS symmetric already (the trailing block of the tridiagonalisation):
-// B[r][c] += alpha sum_a (U_a[r] Z_a[c] + Z_a[r] U_a[c]) needs no mirror element, so the pass can stream whole
-// row strips like a matvec instead of visiting 64-row tiles and their mirrors (128 different pages for every
-// 64 KB moved: the tiled kernels reach 2.1 TB/s on the 75 MB block, a row stream 5).  A workgroup takes 64 rows
-// and a range of columns in chunks of 128; the two products of a term are rounded separately and added before
-// they join the accumulator, which makes the term — and with it the result — bitwise symmetric in (r, c).
-constexpr int RS_ROWS = 64, RS_CCH = 128;
-
-__global__ __launch_bounds__(256) void rank2k_rows_kernel(double* __restrict__ B, int n, int ld,
-                                                          const double* __restrict__ Up,
-                                                          const double* __restrict__ Zp, int ldp, int kk,
-                                                          double alpha, int cols_per_split) {
-#pragma clang fp contract(off)
-    __shared__ double ur[R2K_KT][RS_ROWS], zr[R2K_KT][RS_ROWS];
-    __shared__ double ucs[R2K_KT][RS_CCH], zcs[R2K_KT][RS_CCH];
-    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;         // columns 4 cx .. 4 cx + 3, rows ry + 8 q
-    const int r0 = blockIdx.x * RS_ROWS;
-    const int cbeg = blockIdx.y * cols_per_split;
-    const int cend = (cbeg + cols_per_split < n) ? cbeg + cols_per_split : n;
-    for (int c0 = cbeg; c0 < cend; c0 += RS_CCH) {
-        const int col = c0 + 4 * cx;
-        double4 bv[8];
-        double acc[8][4];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int r = r0 + ry + 8 * q;
-            bv[q] = make_double4(0.0, 0.0, 0.0, 0.0);
-            if (r < n && col + 3 < n) bv[q] = *reinterpret_cast<const double4*>(B + (size_t)r * ld + col);
-            else if (r < n) {
-                if (col < n) bv[q].x = B[(size_t)r * ld + col];
-                if (col + 1 < n) bv[q].y = B[(size_t)r * ld + col + 1];
-                if (col + 2 < n) bv[q].z = B[(size_t)r * ld + col + 2];
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) acc[q][p] = 0.0;
-        }
-        for (int a0 = 0; a0 < kk; a0 += R2K_KT) {
-            const int at = (kk - a0 < R2K_KT) ? (kk - a0) : R2K_KT;
-            __syncthreads();
-            for (int t = threadIdx.x; t < R2K_KT * RS_ROWS; t += 256) {
-                const int a = t >> 6, i = t & 63;
-                const bool ok = a < at && r0 + i < n;
-                ur[a][i] = ok ? Up[(size_t)(a0 + a) * ldp + r0 + i] : 0.0;
-                zr[a][i] = ok ? Zp[(size_t)(a0 + a) * ldp + r0 + i] : 0.0;
-            }
-            for (int t = threadIdx.x; t < R2K_KT * RS_CCH; t += 256) {
-                const int a = t >> 7, i = t & 127;
-                const bool ok = a < at && c0 + i < n;
-                ucs[a][i] = ok ? Up[(size_t)(a0 + a) * ldp + c0 + i] : 0.0;
-                zcs[a][i] = ok ? Zp[(size_t)(a0 + a) * ldp + c0 + i] : 0.0;
-            }
-            __syncthreads();
-#pragma unroll 2
-            for (int a = 0; a < R2K_KT; ++a) {
-                double ucx[4], zcx[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) { ucx[p] = ucs[a][4 * cx + p]; zcx[p] = zcs[a][4 * cx + p]; }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const double urx = ur[a][ry + 8 * q], zrx = zr[a][ry + 8 * q];
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const double t1 = urx * zcx[p], t2 = zrx * ucx[p];
-                        acc[q][p] += t1 + t2;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int r = r0 + ry + 8 * q;
-            if (r >= n) continue;
-            const double v0 = bv[q].x + alpha * acc[q][0], v1 = bv[q].y + alpha * acc[q][1];
-            const double v2 = bv[q].z + alpha * acc[q][2], v3 = bv[q].w + alpha * acc[q][3];
-            if (col + 3 < n) *reinterpret_cast<double4*>(B + (size_t)r * ld + col) = make_double4(v0, v1, v2, v3);
-            else {
-                if (col < n) B[(size_t)r * ld + col] = v0;
-                if (col + 1 < n) B[(size_t)r * ld + col + 1] = v1;
-                if (col + 2 < n) B[(size_t)r * ld + col + 2] = v2;
-            }
-        }
-    }
-}
-
-// B += alpha sum_a (U_a Z_a^T + Z_a U_a^T) for a symmetric B (no symmetrisation pass)
-int launch_rank2k_symmetric(sella_ctx* c, double* B, int n, int ld, const double* Up, const double* Zp, int ldp,
-                            int kk, double alpha) {
-    if (n < 256 || (ld & 3) != 0 || (reinterpret_cast<uintptr_t>(B) & 31) != 0 || !c->opt.rank2k_rows)
-        return launch_sym_rank2k(c, B, n, ld, Up, Zp, ldp, kk, alpha);
-    const int nstrip = (n + RS_ROWS - 1) / RS_ROWS;
-    int nsplit = (768 + nstrip - 1) / nstrip;                                   // ~3 workgroups per CU
-    int cps = ((n + nsplit - 1) / nsplit + RS_CCH - 1) / RS_CCH * RS_CCH;
-    if (cps < RS_CCH) cps = RS_CCH;
-    nsplit = (n + cps - 1) / cps;
-    prof_begin(c, PROF_UPDATE, 16.0 * n * (double)n, 4.0 * kk * (double)n * n);
-    SELLA_LAUNCH(c, rank2k_rows_kernel, dim3(nstrip, nsplit), dim3(256), 0, B, n, ld, Up, Zp, ldp, kk, alpha, cps);
-    prof_end(c);
-    HIPCHK(hipGetLastError());
-    return SELLA_OK;
-}
-
-
 namespace {
 
 using hostm::vec;

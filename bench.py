@@ -354,12 +354,26 @@ def main():
         # Step-for-step parity where it is defined: the Krylov trajectory amplifies a 1-ulp change about
         # 10x per iteration (tools/krylov_sensitivity.py), so the comparison that means
         # something is the Ritz value after the first few expansions, not after 25-30 of them.
+        t4 = time.perf_counter()
         l4c, _, _ = orc.rayleigh_ritz(A, args.gamma, P, v0=g, method='jd0', maxiter=4)
+        t4 = time.perf_counter() - t4
         l4h, _, _, _ = ctx.davidson(dA, n, g, args.gamma, method='jd0', maxiter=4, Pvecs=V, PvecsT=Vt, pevals=w)
+        # the same 4-iteration sample on ONE core (SURVEY.md section 8d asks for both ends)
+        one_core = None
+        try:
+            from threadpoolctl import threadpool_limits
+            with threadpool_limits(limits=1):
+                t1c = time.perf_counter()
+                orc.rayleigh_ritz(A, args.gamma, P, v0=g, method='jd0', maxiter=4)
+                t1c = time.perf_counter() - t1c
+            one_core = dict(value=round(4 / t1c, 4), cores=1, sample=f'4 iterations, {t1c:.1f} s '
+                            f'(the same 4 iterations on {int(threads)} threads: {t4:.1f} s)')
+        except ImportError:
+            pass
         cpu = dict(value=round(Vc.shape[1] / tcpu, 4), unit='davidson_iter/s', cores=int(threads), kind='port',
                    sample=f'1 call of oracle rayleigh_ritz (reference algorithm: dense LU per iteration), '
                           f'n={n}, k={Vc.shape[1]} vectors, {tcpu:.1f} s',
-                   k=int(Vc.shape[1]),
+                   k=int(Vc.shape[1]), one_core=one_core,
                    lam0_rel_diff_after_4_iterations=float(abs(l4c[0] - l4h[0]) / abs(l4c[0])),
                    lam0_abs_diff_at_exit=float(abs(lc[0] - lams[0])),
                    note='the exit point of the gamma = 0.1 run is chaotic in the reference itself (DESIGN.md section 4): '

@@ -50,7 +50,14 @@ int sella_ctx_create(int device, sella_ctx** ctx);
 int sella_ctx_destroy(sella_ctx* ctx);
 int sella_ctx_sync(sella_ctx* ctx);
 int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
-/* integer tuning knobs (kernel variant selection for benchmarking); unknown key -> -1  */
+/* integer tuning knobs (kernel variant selection for benchmarking); unknown key -> error.  Keys (defaults):
+ *   gemv_rw (2) rows per wavefront of the streaming matvec | gemm_mfma (1) GEMMs on the matrix cores |
+ *   gemm_tile128 (1) 128x128 GEMM tiles for large products | panel_mfma (1), panel_rows (0 = by size) the
+ *   H.V block product | dav_reorth (0) re-orthonormalise V before each MGS | host_scalars (0) zero-copy scalars |
+ *   eigh_nb (16) panel width, eigh_leaf (32) leaf size, eigh_wy_mfma (1) MFMA back-transformation,
+ *   eigh_graph (0) hipGraph replay of the tridiagonalisation chain, eigh_fuse (0) one launch per column for
+ *   small trailing blocks, rank2k_tile64 (0) 64x64 tiles in the symmetric rank-2k pass — the last three are
+ *   measured-neutral variants kept for reference.                                     */
 int sella_ctx_set_option(sella_ctx* ctx, const char* key, long value);
 
 /* ---- device matrices --------------------------------------------------------------- */

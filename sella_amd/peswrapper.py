@@ -408,6 +408,14 @@ class PES:
         Ufree = self.get_Ufree()
         if is_identity(Ufree):
             return -g.reshape((-1, 3))
+        hit = getattr(self, '_pinned_basis', None)
+        if hit is not None and Ufree is hit[2]:
+            # columns of the identity: the projection keeps the free components and zeroes the pinned ones
+            if len(hit) < 4:
+                hit = self._pinned_basis = hit + (Ufree.argmax(axis=0),)
+            out = np.zeros_like(g)
+            out[hit[3]] = g[hit[3]]
+            return -out.reshape((-1, 3))
         return -(Ufree @ (Ufree.T @ g)).reshape((-1, 3))
 
     def converged(self, fmax, cmax=1e-5):

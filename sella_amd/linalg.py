@@ -327,7 +327,9 @@ class ApproximateHessian(LinearOperator):
         return None
 
     def register_view(self, U, sub):
-        idx = np.ascontiguousarray(U.argmax(axis=0), dtype=np.int32)
+        from .utilities.math import selection_of
+        sel = selection_of(U)
+        idx = np.ascontiguousarray(U.argmax(axis=0) if sel is None else sel, dtype=np.int32)
         if len(idx) > 1 and not np.all(np.diff(idx) > 0):
             return                                   # not an ordered selection of coordinates
         self._view = (idx, U, sub, self.version)

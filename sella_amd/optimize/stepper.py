@@ -17,7 +17,7 @@ import numpy as np
 
 from ..device import DeviceStepper, get_context
 from ..linalg import ApproximateHessian
-from ..utilities.math import is_identity
+from ..utilities.math import is_identity, selection_of
 
 
 class BaseStepper:
@@ -59,15 +59,30 @@ class BaseStepper:
         U = self.U
         if U is not None and is_identity(U):
             U = None                                  # unconstrained: the basis is the identity
+        self._sel = None
+        g = self.g
         if U is not None:
-            # compose the projection with the eigenbasis once: (U V) is n x m
-            VU = ctx.zeros(self.U.shape[0], V.shape[1])
-            ctx.gemm(ctx.resident(self.U), V, VU)
-            V, Vt = VU, VU.transpose()
-        self._dev = DeviceStepper(ctx, self._kind, V, Vt, evals, self.g, self.order)
+            sel = selection_of(U)
+            if sel is not None:
+                # columns of the identity (constraints that pin single coordinates): U^T g and U s are index
+                # operations on the host, the device works in the projected space only
+                self._sel, self._nfull = sel, U.shape[0]
+                g = np.ascontiguousarray(np.asarray(g, dtype=np.float64)[sel])
+            else:
+                # compose the projection with the eigenbasis once: (U V) is n x m
+                VU = ctx.zeros(self.U.shape[0], V.shape[1])
+                ctx.gemm(ctx.resident(self.U), V, VU)
+                V, Vt = VU, VU.transpose()
+        self._dev = DeviceStepper(ctx, self._kind, V, Vt, evals, g, self.order)
 
     def get_s(self, alpha: float) -> Tuple[np.ndarray, np.ndarray]:
-        return self._dev.get_s(alpha)
+        s, dsda = self._dev.get_s(alpha)
+        if self._sel is None:
+            return s, dsda
+        s_full, ds_full = np.zeros(self._nfull), np.zeros(self._nfull)
+        s_full[self._sel] = s
+        ds_full[self._sel] = dsda
+        return s_full, ds_full
 
 
 class NaiveStepper(BaseStepper):

@@ -20,7 +20,7 @@ from .eigensolvers import rayleigh_ritz
 from .hessian_update import symmetrize_Y
 from .internal import Constraints, DuplicateInternalError
 from .linalg import ApproximateHessian, NumericalHessian
-from .utilities.math import is_identity, shared_identity
+from .utilities.math import register_selection, selection_of, is_identity, shared_identity
 
 
 class _LRU2:
@@ -81,7 +81,8 @@ def _split_cons_subspace(drdx, tol_factor=1e-6):
             free = np.setdiff1d(np.arange(n), cols)
             eye = shared_identity(n)
             # (fancy indexing along axis 1 returns a Fortran-ordered array: make the C copy once, not at every upload)
-            return np.ascontiguousarray(eye[:, cols]), np.ascontiguousarray(eye[:, free])
+            return (register_selection(np.ascontiguousarray(eye[:, cols]), cols),
+                    register_selection(np.ascontiguousarray(eye[:, free]), free))
     Q, R, _ = qr(drdx.T, mode='full', pivoting=True, check_finite=False)
     diag = np.abs(np.diag(R))
     ncons = int(np.sum(diag > tol_factor * diag[0])) if diag.size and diag[0] > 0 else 0
@@ -412,7 +413,8 @@ class PES:
         if hit is not None and Ufree is hit[2]:
             # columns of the identity: the projection keeps the free components and zeroes the pinned ones
             if len(hit) < 4:
-                hit = self._pinned_basis = hit + (Ufree.argmax(axis=0),)
+                sel = selection_of(Ufree)
+                hit = self._pinned_basis = hit + (Ufree.argmax(axis=0) if sel is None else sel,)
             out = np.zeros_like(g)
             out[hit[3]] = g[hit[3]]
             return -out.reshape((-1, 3))

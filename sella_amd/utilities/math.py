@@ -30,6 +30,27 @@ def shared_identity(n):
     return I
 
 
+_SELECTIONS = []          # (basis array, row index of every column): bases made of columns of the identity
+
+
+def register_selection(U, idx):
+    """Remember that U[:, k] = e_idx[k] (built by peswrapper._split_cons_subspace for constraints that pin single
+    coordinates).  Products with such a basis are index operations; consumers ask `selection_of`."""
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    _SELECTIONS.append((U, idx))
+    if len(_SELECTIONS) > 8:
+        _SELECTIONS.pop(0)
+    return U
+
+
+def selection_of(U):
+    """Row indices if U is a registered selection basis (same object), else None."""
+    for B, idx in _SELECTIONS:
+        if B is U:
+            return idx
+    return None
+
+
 def is_identity(U):
     """True if the 2-D array U is an identity matrix (fast for the shared instances)."""
     if U is None or np.ndim(U) != 2 or U.shape[0] != U.shape[1]:

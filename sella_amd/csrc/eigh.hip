@@ -1161,17 +1161,39 @@ struct MergePlan {
 // Deflation of one rank-one modification diag(D) + rho z z^T (LAPACK dlaed2's rules): entries with a
 // negligible weight are set aside, and of two (nearly) equal poles one is rotated out.  D and zz are
 // modified (rotations); pl.rho, pl.lo, pl.N must be set by the caller.  Indices are local (0..N-1).
+// Stable ascending order of v[0..N): the inputs here are sorted already (eigenvalues carried by a rank-one
+// update) or two sorted runs back to back (the halves of a merge; new roots followed by deflated values), so the
+// order is the identity or ONE linear merge; anything else falls back to a sort.  Same result as
+// std::stable_sort on the indices, at a fraction of its ~100 us for N = 3072.
+static void ascending_order(const double* v, int N, std::vector<int>& order) {
+    order.resize(N);
+    std::iota(order.begin(), order.end(), 0);
+    int split = -1;
+    for (int i = 1; i < N; ++i)
+        if (v[i] < v[i - 1]) {
+            if (split >= 0) { split = -2; break; }
+            split = i;
+        }
+    if (split == -1) return;
+    auto less = [&](int a, int b) { return v[a] < v[b]; };
+    if (split == -2) { std::stable_sort(order.begin(), order.end(), less); return; }
+    std::vector<int> tmp(N);
+    std::merge(order.begin(), order.begin() + split, order.begin() + split, order.end(), tmp.begin(), less);
+    order.swap(tmp);
+}
+
 static void plan_deflation(int N, double* D, double* zz, MergePlan& pl) {
     const double eps = 2.220446049250313e-16;
-    std::vector<int> order(N);
+    std::vector<int> order;
     double zmax = 0.0, dmax = 0.0;
     for (int i = 0; i < N; ++i) {
         zmax = std::max(zmax, fabs(zz[i]));
         dmax = std::max(dmax, fabs(D[i]));
     }
     const double tol = 8.0 * eps * std::max(dmax, zmax);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return D[a] < D[b]; });
+    ascending_order(D, N, order);
+    pl.defl.reserve(N);
+    pl.nondef.reserve(N);
     if (pl.rho * zmax <= tol) {
         pl.defl = order;
     } else {
@@ -1648,6 +1670,9 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     int* i2d = i1d + n;
     int* idxd = i1d + 2 * n;
     int* orgd = i1d + 3 * n;
+    static const bool dbg_time = getenv("SELLA_DEBUG_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tt0 = now();
     // z = Vt q
     SCHK(launch_gemv_rows(c, Vt, n, n, ld, q, ld, 1, zdev, ld, GemvEpi()));
     // small transfers through the pinned staging buffer, laid out like the device side (see dc_solve)
@@ -1665,6 +1690,7 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     HIPCHK(hipMemcpyAsync(z, zdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemsetAsync(info, 0, 8 * sizeof(int), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    const double tt1 = now();
     // a negative weight is handled on the negated, reversed spectrum: primed index i' <-> row n-1-i'
     const bool neg = sigma < 0.0;
     auto rowof = [&](int ip) { return neg ? n - 1 - ip : ip; };
@@ -1742,6 +1768,7 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
         hcs[2 * (size_t)r] = pl.cs[2 * r];
         hcs[2 * (size_t)r + 1] = pl.cs[2 * r + 1];
     }
+    const double tt2 = now();
     static_assert(V_CS1 == V_CS0 + 1 && V_DD == V_CS0 + 2 && V_WD == V_CS0 + 3, "slot order");
     HIPCHK(hipMemcpyAsync(i1d, hr1, 3 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(csd, hcs, (3 * (size_t)ld + n) * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1765,18 +1792,22 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
         set_error("eigh update: secular equation solver hit its iteration cap (root %d)", hinfo[1] - 1);
         return SELLA_E_NOCONV;
     }
+    const double tt3 = now();
     // new spectrum (rows of nxt: K updated vectors, then the deflated ones), back to ascending order
     std::vector<double> nv(n);
     for (int p = 0; p < K; ++p) nv[p] = neg ? -lam[p] : lam[p];
     for (int p = 0; p < n - K; ++p) nv[K + p] = neg ? -D[pl.defl[p]] : D[pl.defl[p]];
-    std::vector<int> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nv[a] < nv[b]; });
+    std::vector<int> order;
+    ascending_order(nv.data(), n, order);
     for (int i = 0; i < n; ++i) w[i] = nv[order[i]];
     std::copy(order.begin(), order.end(), hidx);
     HIPCHK(hipMemcpyAsync(idxd, hidx, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    const double tt4 = now();
     SCHK(launch_gather_rows(c, nxt, ld, idxd, n, n, Vt, ld));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (dbg_time)
+        fprintf(stderr, "rank-one eigen-update n=%d K=%d rot=%d: z %.0f us, plan %.0f us, device %.0f us, order %.0f us, final gather %.0f us\n",
+                n, K, pl.nrot, 1e6 * (tt1 - tt0), 1e6 * (tt2 - tt1), 1e6 * (tt3 - tt2), 1e6 * (tt4 - tt3), 1e6 * (now() - tt4));
     return SELLA_OK;
 }
 

@@ -1794,12 +1794,14 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     }
     const double tt3 = now();
     // new spectrum (rows of nxt: K updated vectors, then the deflated ones), back to ascending order
+    // (ordered in the primed spectrum, where both pieces ascend; a negative weight reverses the result)
     std::vector<double> nv(n);
-    for (int p = 0; p < K; ++p) nv[p] = neg ? -lam[p] : lam[p];
-    for (int p = 0; p < n - K; ++p) nv[K + p] = neg ? -D[pl.defl[p]] : D[pl.defl[p]];
+    for (int p = 0; p < K; ++p) nv[p] = lam[p];
+    for (int p = 0; p < n - K; ++p) nv[K + p] = D[pl.defl[p]];
     std::vector<int> order;
     ascending_order(nv.data(), n, order);
-    for (int i = 0; i < n; ++i) w[i] = nv[order[i]];
+    if (neg) std::reverse(order.begin(), order.end());
+    for (int i = 0; i < n; ++i) w[i] = neg ? -nv[order[i]] : nv[order[i]];
     std::copy(order.begin(), order.end(), hidx);
     HIPCHK(hipMemcpyAsync(idxd, hidx, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
     const double tt4 = now();

@@ -31,9 +31,20 @@ class Sella(Optimizer):
                  order=1, eig=None, eta=1e-4, method=None, gamma=0.1, threepoint=False,
                  constraints=None, constraints_tol=1e-5, v0=None, internal=False,
                  append_trajectory=False, rs=None, nsteps_per_diag=3, diag_every_n=None,
-                 hessian_function=None, optimize_cell=False, **kwargs):
+                 hessian_function=None, optimize_cell=False, cell_mask=None, exp_cell_factor=None,
+                 scalar_pressure=0.0, smax=None, allow_fragments=False, niggli=False,
+                 refine_initial_hessian=False, save_hessian=None, exact_geodesic=None, **kwargs):
+        # keyword set of the reference constructor (optimize.py:42-80).  The cell keywords (cell_mask,
+        # exp_cell_factor, scalar_pressure, smax, niggli, refine_initial_hessian, save_hessian) only act with
+        # optimize_cell=True there and are accepted and ignored here as there; the two that would change the
+        # saddle-point path are refused.
         if optimize_cell:
             raise NotImplementedError('optimize_cell requires order=0 and is outside the saddle-point scope')
+        if allow_fragments:
+            raise NotImplementedError('allow_fragments needs the TRIC translation / rotation coordinates, which '
+                                      'are outside the saddle-point scope (DESIGN.md section 7)')
+        # the reference integrates the exact geodesic unless told otherwise (optimize.py:125)
+        self.exact_geodesic = True if exact_geodesic is None else bool(exact_geodesic)
         default = _default_kwargs['minimum' if order == 0 else 'saddle']
         self.optimize_cell = False
         self.peskwargs = kwargs.copy()
@@ -92,7 +103,8 @@ class Sella(Optimizer):
             self.internal = internal.copy()
             self.constraints = None
             self.pes = InternalPES(atoms, internals=internal, trajectory=trajectory, eta=eta, v0=v0,
-                                   auto_find_internals=auto, hessian_function=hessian_function, **kwargs)
+                                   auto_find_internals=auto, hessian_function=hessian_function,
+                                   exact_geodesic=getattr(self, 'exact_geodesic', True), **kwargs)
             self.trajectory = self.pes.traj
             return
         self.internal = None

@@ -386,6 +386,11 @@ class Constraints:
     fix_angle = partialmethod(_fix_internal, Angle, 'angles', np.pi / 180.)
     fix_dihedral = partialmethod(_fix_internal, Dihedral, 'dihedrals', np.pi / 180.)
 
+    def fix_other(self, *args, **kwargs):
+        raise NotImplementedError('user-defined constraint functions are differentiated with JAX in the reference '
+                                  '(internal.py:2932-2955); this build has closed-form kernels for translations, '
+                                  'bonds, angles and dihedrals only')
+
     def merge_ase_constraint(self, cons):
         """FixAtoms / FixCom equivalents by duck typing (internal.py:2981-3030)."""
         name = cons.__class__.__name__

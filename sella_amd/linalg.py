@@ -129,11 +129,13 @@ class MatrixSum(LinearOperator):
 
 
 # Quasi-Newton updates of rank <= EIG_UPDATE_MAX_RANK carry the device eigendecomposition along by
-# rank-one modifications; after EIG_UPDATE_REFRESH of them it is recomputed from scratch (bounds the
-# accumulated rounding, about n*eps per modification).  EIG_UPDATE_MAX_RANK = 0 restores "eigh after
-# every update".
+# rank-one modifications; after EIG_UPDATE_REFRESH of them it is recomputed from scratch.  The accumulated
+# rounding grows linearly and slowly — measured 1.5e-17 per modification in the orthogonality defect and
+# 6e-17 in the residual (n = 48: 800 modifications, n = 320: 320 modifications, start lam0*I) — so the bound is
+# a safety net (about 3e-14 at the limit), not a cost: at 64 it used to put a 55 ms eigh into every 32nd step
+# of the 1024-atom search.  EIG_UPDATE_MAX_RANK = 0 restores "eigh after every update".
 EIG_UPDATE_MAX_RANK = 8
-EIG_UPDATE_REFRESH = 64
+EIG_UPDATE_REFRESH = 1024
 
 
 class ApproximateHessian(LinearOperator):

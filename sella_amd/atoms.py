@@ -296,6 +296,7 @@ class EMT(Calculator):
         key = (tuple(atoms.symbols), np.asarray(atoms.cell, dtype=float).tobytes(), tuple(atoms.pbc))
         if self._setup is None or self._setup[0] != key:
             self._setup = (key, self._initialize(atoms))
+            self._key = None                       # results cached for the old cell / species are stale
         return super()._get(atoms)
 
     def _initialize(self, atoms):
@@ -393,17 +394,21 @@ class _MiniOptimizer:
     def irun(self, fmax=0.05, steps=100000000):
         self.fmax = fmax
         self.max_steps = self.nsteps + steps
+        # ASE's order (ase/optimize/optimize.py irun): convergence is evaluated first, so that log() reports
+        # the fmax / cmax of the geometry whose energy it prints
+        conv = self.converged()
         self.log()
         self.call_observers()
-        if self.converged():
+        if conv:
             yield True
             return
         while self.nsteps < self.max_steps:
             self.step()
             self.nsteps += 1
+            conv = self.converged()
             self.log()
             self.call_observers()
-            if self.converged():
+            if conv:
                 yield True
                 return
             yield False

@@ -267,7 +267,6 @@ int sella_ctx_destroy(sella_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)prof_flush(c);
-    for (auto& g : c->trd_graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto& a : c->arenas) (void)hipFree(a.base);       // matrices, panels and scratch all live in the arenas
     if (c->dscal) (void)hipFree(c->dscal);
     if (c->hscal) (void)hipHostFree(c->hscal);
@@ -310,12 +309,6 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
         c->opt.panel_rows = value;
     } else if (!strcmp(key, "eigh_wy_mfma")) {
         c->opt.eigh_wy_mfma = value ? 1 : 0;
-    } else if (!strcmp(key, "rank2k_tile64")) {
-        c->opt.rank2k_tile64 = value ? 1 : 0;
-    } else if (!strcmp(key, "eigh_fuse")) {
-        c->opt.eigh_fuse = value ? 1 : 0;
-    } else if (!strcmp(key, "eigh_graph")) {
-        c->opt.eigh_graph = value ? 1 : 0;
     } else if (!strcmp(key, "eigh_nb")) {
         if (value < 1 || value > 64) { set_error("eigh_nb must be in [1, 64]"); return SELLA_E_INVALID; }
         c->opt.eigh_nb = value;

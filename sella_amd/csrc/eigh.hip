@@ -284,228 +284,6 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
     }
 }
 
-// ---- one launch per column for small trailing blocks (option `eigh_fuse`, off by default) ----------
-// Below m ~ 1000 both kernels above are nothing but latency (row kernel 3.5-5 us, matvec >= 4.1 us for a block
-// that streams in well under a microsecond).  This kernel fuses the two: EVERY workgroup repeats the row
-// kernel's work for all columns (reads of the panel, (2i+3) m doubles from L2, instead of a kernel boundary),
-// keeps u and w_{i-1} in LDS, and then does its 8 rows of the matvec; its matrix rows are loaded into
-// registers before anything else, so that stream overlaps the prologue.  What one launch writes and the same
-// launch reads elsewhere is double-buffered by column parity (wraw, v.wraw partials, panel dots, reflector
-// scalars); the reflector tails go to the panel only and are copied into A once per panel
-// (`trd_store_reflectors_kernel`), because row j of A is still being read by the other workgroups.
-// MEASURED (gpurun_out/r27, r28): correct and no faster.  With a plain panel loop 11.5 us per column; with the
-// panel depth as a compile-time constant (loads batched, 253-256 VGPRs) 8 us per column — exactly what the two
-// kernels it replaces take (n = 768: 9.2 vs 8.6 ms, 8.5 ms with 8-wide panels; n = 3072: 47.6 vs 47.3 ms).  One
-// launch or two, a column is the same chain of dependent memory round trips (panel + previous results in,
-// two block reductions, rows, partials out); the launch boundary itself is not what costs.  Off by default.
-constexpr int TRD_FUSE_MAX = 1000;         // largest trailing size handled by the fused kernel
-constexpr int TRD_FUSE_IT = 8;             // double2 loads per lane and row: 64 * 8 * 2 >= TRD_FUSE_MAX + 2
-constexpr int TRD_FUSE_LDS = TRD_FUSE_MAX + 8;
-
-struct TrdFusedArgs {
-    double* A; int ld, n;
-    int j, i;                                   // global column, index in the panel
-    double* Vp; double* Wp; int ldp;
-    const double* wraw_prev; double* wraw_cur;
-    const double* partB_prev; int nblk_prev; double* partB_cur;
-    const double* colscal_prev; double* colscal_cur;
-    const double* cdots_prev; double* cdots_cur;
-    double* dvec; double* taus; double* evec;
-    int w0;                                     // first workgroup's row block: absolute row = 8 (blockIdx.x + w0) + ...
-};
-
-// IPC: finished panel columns (i - 1) as a compile-time constant (all panel loads of a column in flight
-// together, as in trd_row_kernel); IPC < 0: generic loop.
-template <int IPC>
-__global__ __launch_bounds__(256) void trd_fused_kernel(TrdFusedArgs a) {
-    __shared__ double ul[TRD_FUSE_LDS], wl[TRD_FUSE_LDS];
-    __shared__ double red[4];
-    __shared__ double pred[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = a.j, i = a.i, ip = i - 1, n = a.n, ldp = a.ldp;
-    const int o = j + 1, m = n - o, L = n - j;
-    const int oc = o & ~1, shift = o - oc;
-    const int n2 = (m + shift + 1) >> 1;
-    // ---- this wave's two rows of the product: addresses and data first ------------------------------------
-    // virtual row index v: [o, n) matrix rows, [n, n+i) rows W_p, [n+i, n+2i) rows V_p
-    const int vtot = n + 2 * i;
-    double2 rowd[2][TRD_FUSE_IT];
-    double lead[2];
-    int vrow[2];
-    bool from_lds[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int v = 8 * (blockIdx.x + a.w0) + 2 * wave + r;
-        vrow[r] = v;
-        from_lds[r] = (v == n + ip) && i > 0;                 // W_{i-1}: only exists in this launch's LDS
-        const double* base = nullptr;
-        if (v >= o && v < n) base = a.A + (size_t)v * a.ld;
-        else if (v >= n && v < n + i && !from_lds[r]) base = a.Wp + (size_t)(v - n) * ldp;
-        else if (v >= n + i && v < vtot) base = a.Vp + (size_t)(v - n - i) * ldp;
-        lead[r] = base ? base[o] : 0.0;
-        const double2* b2 = reinterpret_cast<const double2*>(base ? base + oc : a.A);
-#pragma unroll
-        for (int k = 0; k < TRD_FUSE_IT; ++k) {
-            const int q = lane + 64 * k;
-            rowd[r][k] = (base && q < n2) ? b2[q] : make_double2(0.0, 0.0);
-        }
-    }
-    // ---- prologue = the row kernel for ALL columns c = j + l ------------------------------------------------
-    double vw = 0.0;
-    if (i > 0)
-        for (int b = tid; b < a.nblk_prev; b += 256) vw += a.partB_prev[b];
-    const double tau_p = (i > 0) ? a.colscal_prev[0] : 0.0;
-    const double wrawj = (i > 0) ? a.wraw_prev[j] : 0.0;
-    const int np = (IPC >= 0) ? IPC : ip;
-    constexpr int NPC = (IPC >= 0) ? (IPC > 0 ? IPC : 1) : 1;
-    double tsum = 0.0, cc = 0.0;                               // uniform: t = sum_p V_p[j] c1_p + W_p[j] c2_p, cc = sum c1 c2
-    double c1u[NPC], c2u[NPC], vju[NPC], wju[NPC];             // uniform panel scalars (IPC >= 0: kept in registers)
-    if (IPC >= 0) {
-#pragma unroll
-        for (int p = 0; p < np; ++p) {
-            c1u[p] = a.cdots_prev[p];
-            c2u[p] = a.cdots_prev[TRD_NBMAX + p];
-            vju[p] = a.Vp[(size_t)p * ldp + j];
-            wju[p] = a.Wp[(size_t)p * ldp + j];
-        }
-#pragma unroll
-        for (int p = 0; p < np; ++p) {
-            tsum += vju[p] * c1u[p] + wju[p] * c2u[p];
-            cc += c1u[p] * c2u[p];
-        }
-    } else {
-        for (int p = 0; p < np; ++p) {
-            const double c1 = a.cdots_prev[p], c2 = a.cdots_prev[TRD_NBMAX + p];
-            tsum += a.Vp[(size_t)p * ldp + j] * c1 + a.Wp[(size_t)p * ldp + j] * c2;
-            cc += c1 * c2;
-        }
-    }
-    constexpr int PL = (TRD_FUSE_MAX + 1 + 255) / 256;         // columns per thread
-    double base_l[PL], s_l[PL], wr_l[PL], vp_l[PL];
-#pragma unroll
-    for (int t = 0; t < PL; ++t) {
-        const int l = tid + 256 * t;
-        const int c = (l < L) ? j + l : n - 1;
-        double q = 0.0, sx = 0.0;
-        if (IPC >= 0) {
-            double vcs[NPC], wcs[NPC];
-#pragma unroll
-            for (int p = 0; p < np; ++p) {                     // load all, then use
-                vcs[p] = a.Vp[(size_t)p * ldp + c];
-                wcs[p] = a.Wp[(size_t)p * ldp + c];
-            }
-#pragma unroll
-            for (int p = 0; p < np; ++p) {
-                sx += vcs[p] * c1u[p] + wcs[p] * c2u[p];
-                q += vcs[p] * wju[p] + wcs[p] * vju[p];
-            }
-        } else {
-            for (int p = 0; p < np; ++p) {
-                const double vc = a.Vp[(size_t)p * ldp + c], wc_p = a.Wp[(size_t)p * ldp + c];
-                sx += vc * a.cdots_prev[p] + wc_p * a.cdots_prev[TRD_NBMAX + p];
-                q += vc * a.Wp[(size_t)p * ldp + j] + wc_p * a.Vp[(size_t)p * ldp + j];
-            }
-        }
-        base_l[t] = a.A[(size_t)j * a.ld + c] - q;
-        s_l[t] = sx;
-        wr_l[t] = (i > 0) ? a.wraw_prev[c] : 0.0;
-        vp_l[t] = (i > 0) ? a.Vp[(size_t)ip * ldp + c] : 0.0;
-    }
-    double ss = 0.0;
-    if (i > 0) {
-        vw = block_sum_256(vw, red);
-        const double alpha2 = -0.5 * tau_p * tau_p * (vw - 2.0 * cc);
-        const double wj = tau_p * (wrawj - tsum) + alpha2;
-#pragma unroll
-        for (int t = 0; t < PL; ++t) {
-            const int l = tid + 256 * t;
-            if (l < L) {
-                const double wc = tau_p * (wr_l[t] - s_l[t]) + alpha2 * vp_l[t];
-                const double u = base_l[t] - (vp_l[t] * wj + wc);
-                ul[l] = u;
-                wl[l] = wc;
-                if (blockIdx.x == 0) a.Wp[(size_t)ip * ldp + j + l] = wc;
-                if (l >= 2) ss += u * u;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < PL; ++t) {
-            const int l = tid + 256 * t;
-            if (l < L) {
-                ul[l] = base_l[t];
-                if (l >= 2) ss += base_l[t] * base_l[t];
-            }
-        }
-    }
-    ss = block_sum_256(ss, red);                               // (its barriers also publish ul / wl)
-    const double alpha = ul[1];
-    if (blockIdx.x == 0 && tid == 0) a.dvec[j] = ul[0];
-    double beta, tau, scale;
-    if (ss == 0.0) { beta = alpha; tau = 0.0; scale = 0.0; }
-    else {
-        const double nrm = sqrt(alpha * alpha + ss);
-        beta = (alpha >= 0.0) ? -nrm : nrm;
-        tau = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
-    }
-    // ---- the wave's two rows against u' (u behind column o; 0 at column o, in the alignment pad, beyond n) ------
-    double pw = 0.0;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int v = vrow[r];
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < TRD_FUSE_IT; ++k) {
-            const int q = lane + 64 * k;
-            if (q < n2) {
-                const int c0 = oc + 2 * q, c1 = c0 + 1;
-                const double x0 = (c0 > o && c0 < n) ? ul[c0 - j] : 0.0;
-                const double x1 = (c1 > o && c1 < n) ? ul[c1 - j] : 0.0;
-                double a0 = rowd[r][k].x, a1 = rowd[r][k].y;
-                if (from_lds[r]) {
-                    a0 = (c0 >= j && c0 < n) ? wl[c0 - j] : 0.0;
-                    a1 = (c1 >= j && c1 < n) ? wl[c1 - j] : 0.0;
-                }
-                acc += a0 * x0 + a1 * x1;
-            }
-        }
-        acc = wave_sum_e(acc);
-        if (lane == 0 && v >= o && v < vtot) {
-            const double ld0 = from_lds[r] ? wl[o - j] : lead[r];
-            const double res = scale * acc + ld0;
-            if (v < n) {
-                const double vr = (v == o) ? 1.0 : scale * ul[v - j];
-                a.wraw_cur[v] = res;
-                a.Vp[(size_t)i * ldp + v] = vr;
-                pw += vr * res;
-            } else if (v < n + i) {
-                a.cdots_cur[v - n] = res;
-            } else {
-                a.cdots_cur[TRD_NBMAX + v - n - i] = res;
-            }
-        }
-    }
-    if (lane == 0) pred[wave] = pw;
-    __syncthreads();
-    if (tid == 0) {
-        a.partB_cur[blockIdx.x] = pred[0] + pred[1] + pred[2] + pred[3];
-        if (blockIdx.x == 0) {
-            a.taus[j] = tau;
-            a.evec[j] = beta;
-            a.colscal_cur[0] = tau;
-            a.colscal_cur[1] = scale;
-        }
-    }
-}
-
-// reflector tails of a finished panel: A[j0 + i][c] = V_i[c] for c >= j0 + i + 2 (read by the back-transformation)
-__global__ __launch_bounds__(256) void trd_store_reflectors_kernel(double* __restrict__ A, int ld, int n, int j0,
-                                                                   const double* __restrict__ Vp, int ldp) {
-    const int i = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    if (c < n && c >= j0 + i + 2) A[(size_t)(j0 + i) * ld + c] = Vp[(size_t)i * ldp + c];
-}
-
 __global__ void tridiag_tail_kernel(const double* __restrict__ A, int ld, int n, double* dvec,
                                     double* evec, double* taus) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1483,64 +1261,23 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     double* wraw = W.vec + (size_t)V_WRAW * ld;
     double* colscal = W.vec + (size_t)V_COL * ld;
     double* cdots = partB + maxblkB + 8;               // 2 * TRD_NBMAX doubles
-    // second copies for the fused one-launch-per-column kernel (double-buffered by column parity)
-    double* wraw2[2] = {wraw, W.vec + (size_t)V_WRAW2 * ld};
-    double* colscal2[2] = {colscal, colscal + 8};
-    double* cdots2[2] = {cdots, cdots + 2 * TRD_NBMAX + 8};
-    double* partB2[2] = {partB, cdots + 4 * TRD_NBMAX + 16};
-    const int fuse_max = (c->opt.eigh_fuse && !c->prof) ? TRD_FUSE_MAX : 0;
-    // The chain below is ~2n dependent launches whose arguments depend only on n and on the buffer
-    // addresses, so it can be captured once per (size, buffers) into a hipGraph and replayed (option
-    // `eigh_graph`).  Measured on this stack: a replayed chain of EMPTY kernels costs 2.0 us per launch
-    // against 3.4 us issued one by one (tools/lab/graph_lab.hip), but the real chain does not get faster
-    // (38.4 ms replayed, 37.5 ms streamed at n = 3072): each kernel's duration is its own dependent
-    // memory round trips on data the previous kernel wrote from other XCDs, and the dispatch of the next
-    // launch already overlaps with them.  Hence off by default.
-    auto enqueue = [&]() -> int {
     int cur = 0, nblkA_prev = 0, nblkB_prev = 0;
     for (int j0 = 0; j0 < nrefl; j0 += nb) {
         const int kb = std::min(nb, nrefl - j0);
         HIPCHK(hipMemsetAsync(Vp, 0, (size_t)2 * TRD_NBMAX * ld * sizeof(double), c->stream));
-        const bool fused = (n - j0 - 1) <= fuse_max;
-        int nblkF_prev = 0;
-        for (int i = 0; fused && i < kb; ++i) {
-            const int j = j0 + i, o = j + 1, par = j & 1;
-            TrdFusedArgs fa;
-            fa.A = W.A; fa.ld = ld; fa.n = n; fa.j = j; fa.i = i;
-            fa.Vp = Vp; fa.Wp = Wp; fa.ldp = ld;
-            fa.wraw_prev = wraw2[1 - par]; fa.wraw_cur = wraw2[par];
-            fa.partB_prev = partB2[1 - par]; fa.nblk_prev = nblkF_prev; fa.partB_cur = partB2[par];
-            fa.colscal_prev = colscal2[1 - par]; fa.colscal_cur = colscal2[par];
-            fa.cdots_prev = cdots2[1 - par]; fa.cdots_cur = cdots2[par];
-            fa.dvec = dvec; fa.taus = taus; fa.evec = evec;
-            fa.w0 = (o / 64) * 8;
-            const int nblkF = (n + 2 * i - 8 * fa.w0 + 7) / 8;
-            switch (i - 1) {
-#define SELLA_TRD_FUSED_CASE(IP) case IP: hipLaunchKernelGGL(HIP_KERNEL_NAME(trd_fused_kernel<IP>), dim3(nblkF), dim3(256), 0, c->stream, fa); break;
-                case -1:
-                SELLA_TRD_FUSED_CASE(0) SELLA_TRD_FUSED_CASE(1) SELLA_TRD_FUSED_CASE(2) SELLA_TRD_FUSED_CASE(3)
-                SELLA_TRD_FUSED_CASE(4) SELLA_TRD_FUSED_CASE(5) SELLA_TRD_FUSED_CASE(6) SELLA_TRD_FUSED_CASE(7)
-                SELLA_TRD_FUSED_CASE(8) SELLA_TRD_FUSED_CASE(9) SELLA_TRD_FUSED_CASE(10) SELLA_TRD_FUSED_CASE(11)
-                SELLA_TRD_FUSED_CASE(12) SELLA_TRD_FUSED_CASE(13) SELLA_TRD_FUSED_CASE(14) SELLA_TRD_FUSED_CASE(15)
-#undef SELLA_TRD_FUSED_CASE
-                default: hipLaunchKernelGGL(HIP_KERNEL_NAME(trd_fused_kernel<-1>), dim3(nblkF), dim3(256), 0, c->stream, fa);
-            }
-            nblkF_prev = nblkF;
-        }
-        for (int i = fused ? kb : 0; i <= kb; ++i) {
+        for (int i = 0; i <= kb; ++i) {
             const int j = j0 + i;
             const bool do_row = i < kb;
-            const int parp = fused ? ((j - 1) & 1) : 0;          // buffers the last fused column wrote
             TrdRowArgs ra;
             ra.A = W.A; ra.ld = ld; ra.n = n; ra.j = j; ra.i = i; ra.do_row = do_row ? 1 : 0;
             ra.Vp = Vp; ra.Wp = Wp; ra.ldp = ld;
             ra.u_prev = ub[1 - cur]; ra.u_cur = ub[cur];
-            ra.wraw = wraw2[parp];
+            ra.wraw = wraw;
             ra.partA_prev = partA[1 - cur]; ra.nblkA_prev = nblkA_prev;
             ra.partA_cur = partA[cur];
-            ra.partB = partB2[parp]; ra.nblkB = fused ? nblkF_prev : nblkB_prev;
-            ra.colscal = colscal2[parp];
-            ra.cdots = cdots2[parp];
+            ra.partB = partB; ra.nblkB = nblkB_prev;
+            ra.colscal = colscal;
+            ra.cdots = cdots;
             ra.dvec = dvec;
             const int nblkA = (n - j + 255) / 256;
             const dim3 gA(nblkA), bA(256);
@@ -1596,11 +1333,6 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
         HIPCHK(hipGetLastError());
         // trailing update A22 -= V^T W + W^T V over rows/columns >= j0 + kb
         const int r0 = j0 + kb, mt = n - r0;
-        if (fused) {
-            hipLaunchKernelGGL(trd_store_reflectors_kernel, dim3((n + 255) / 256, kb), dim3(256), 0, c->stream, W.A, ld, n,
-                               j0, Vp, ld);
-            HIPCHK(hipGetLastError());
-        }
         if (mt > 0) {
             double* At = W.A + (size_t)r0 * ld + r0;
             // one fused pass (update.hip): every tile pair is read and written once
@@ -1609,47 +1341,6 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     }
     hipLaunchKernelGGL(tridiag_tail_kernel, dim3(1), dim3(64), 0, c->stream, W.A, ld, n, dvec, evec, taus);
     HIPCHK(hipGetLastError());
-    return SELLA_OK;
-    };
-    if (!c->opt.eigh_graph || c->prof || n < 512) return enqueue();
-    const void* key[4] = {W.A, W.vec, Vp, part};
-    for (auto& g : c->trd_graphs)
-        if (g.n == n && g.ld == ld && g.nb == nb && !memcmp(g.ptr, key, sizeof(key))) {
-            g.stamp = ++c->trd_stamp;
-            HIPCHK(hipGraphLaunch(g.exec, c->stream));
-            return SELLA_OK;
-        }
-    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-        (void)hipGetLastError();                      // capture not available on this stream: plain launches
-        return enqueue();
-    }
-    const int rc = enqueue();
-    hipGraph_t graph = nullptr;
-    const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
-    if (rc != SELLA_OK || ce != hipSuccess || !graph) {
-        if (graph) (void)hipGraphDestroy(graph);
-        (void)hipGetLastError();
-        if (rc != SELLA_OK) return rc;
-        return enqueue();
-    }
-    hipGraphExec_t exec = nullptr;
-    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ie != hipSuccess || !exec) {
-        (void)hipGetLastError();
-        return enqueue();
-    }
-    if (c->trd_graphs.size() >= 6) {                  // evict the least recently used chain
-        size_t lru = 0;
-        for (size_t k = 1; k < c->trd_graphs.size(); ++k)
-            if (c->trd_graphs[k].stamp < c->trd_graphs[lru].stamp) lru = k;
-        (void)hipGraphExecDestroy(c->trd_graphs[lru].exec);
-        c->trd_graphs.erase(c->trd_graphs.begin() + lru);
-    }
-    sella_ctx::TrdGraph g;
-    g.n = n; g.ld = ld; g.nb = nb; memcpy(g.ptr, key, sizeof(key)); g.exec = exec; g.stamp = ++c->trd_stamp;
-    c->trd_graphs.push_back(g);
-    HIPCHK(hipGraphLaunch(exec, c->stream));
     return SELLA_OK;
 }
 

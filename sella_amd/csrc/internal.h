@@ -95,13 +95,6 @@ struct Options {
     long panel_mfma = 1;     // 1: products with more than 8 right-hand sides stream the matrix once (MFMA panel kernel)
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
-    long rank2k_tile64 = 0;  // 1: 64x64 tile pairs in the fused symmetric rank-2k pass for n >= 256 (measured equal to
-                             // the 32x32 tiles: the pass is bound by mixed read/write streaming at ~2.1 TB/s either way)
-    long eigh_fuse = 0;      // 1: one fused launch per column once the trailing block is <= 1000 (eigh.hip);
-                             // measured no faster (8 us per column either way, see the kernel's comment)
-    long eigh_graph = 0;     // 1: replay the tridiagonalisation launch chain from a cached hipGraph (n >= 512);
-                             // measured neutral (38.4 vs 37.5 ms at n = 3072): the chain is bound by the
-                             // kernels' own dependent memory round trips, not by the dispatch gap
 };
 
 }  // namespace sella
@@ -134,19 +127,10 @@ struct sella_ctx {
     sella::ProfSlot slots[sella::PROF_NKIND];
     char name[256] = {0};
     int num_cu = 256;
-    // Captured launch chains of the tridiagonalisation (eigh.hip), keyed by size and buffer addresses.
-    struct TrdGraph {
-        int n, ld, nb;
-        const void* ptr[4];
-        hipGraphExec_t exec;
-        unsigned long stamp;
-    };
     // pinned host staging for bursts of small transfers (divide & conquer levels): pageable copies are
     // synchronous staged copies, ~20 us each with the queue empty
     void* hstage = nullptr;
     size_t hstage_bytes = 0;
-    std::vector<TrdGraph> trd_graphs;
-    unsigned long trd_stamp = 0;
 };
 
 namespace sella {

@@ -86,173 +86,11 @@ __global__ __launch_bounds__(256) void sym_rank2k_kernel(double* __restrict__ B,
     }
 }
 
-// The same pass with 64x64 tile pairs (option `rank2k_tile64`): a workgroup owns T1 = B[r0.., c0..] (64 x 64) and
-// its mirror, every thread a 4 x 4 micro-tile (rows ty + 16 q, columns 2 tx, 2 tx + 1, 32 + 2 tx, 33 + 2 tx:
-// 16-byte accesses), the mirror tile goes through LDS for the transposition both ways, and the grid holds the
-// upper-triangular tile pairs only.  Requires 16-byte aligned rows (B and ld even).
-// MEASURED (gpurun_out/r38, r39): no faster than the 32x32 tiles — the 192 trailing updates of a 3072
-// tridiagonalisation take 4.6 ms with either (9.7 GB read + written: 2.1 TB/s), and a variant that streams whole
-// row strips without the mirror tile (possible there because the block is symmetric already) was slower still.
-// The pass is bound by mixed read/write streaming, not by tile shape or panel re-reads.  Off by default.
-constexpr int R2K_T = 64;
-
-__global__ __launch_bounds__(256) void sym_rank2k64_kernel(double* __restrict__ B, int n, int ld,
-                                                           const double* __restrict__ Up,
-                                                           const double* __restrict__ Zp, int ldp, int kk,
-                                                           double alpha, int ntile) {
-    __shared__ double t2s[R2K_T][R2K_T + 1];
-    __shared__ double ur[R2K_KT][R2K_T], zr[R2K_KT][R2K_T], uc[R2K_KT][R2K_T], zc[R2K_KT][R2K_T];
-    // linear index -> (by <= bx) in the upper triangle, row by row
-    int by = 0, rem = blockIdx.x;
-    while (rem >= ntile - by) { rem -= ntile - by; ++by; }
-    const int bx = by + rem;
-    const bool diag = (bx == by);
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int r0 = by * R2K_T, c0 = bx * R2K_T;
-    const int cl[2] = {2 * tx, 32 + 2 * tx};                   // local column pairs of this thread
-    // ---- T1 in registers, mirror tile into LDS (coalesced, its rows are T1's columns) ----------------------
-    double t1[4][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = r0 + ty + 16 * q;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int cc = c0 + cl[h];
-            double2 v = make_double2(0.0, 0.0);
-            if (r < n && cc + 1 < n) v = *reinterpret_cast<const double2*>(B + (size_t)r * ld + cc);
-            else if (r < n && cc < n) v.x = B[(size_t)r * ld + cc];
-            t1[q][2 * h] = v.x;
-            t1[q][2 * h + 1] = v.y;
-        }
-    }
-    if (!diag) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = ty + 16 * q, r = c0 + k;              // row of the mirror tile
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int cc = r0 + cl[h];
-                double2 v = make_double2(0.0, 0.0);
-                if (r < n && cc + 1 < n) v = *reinterpret_cast<const double2*>(B + (size_t)r * ld + cc);
-                else if (r < n && cc < n) v.x = B[(size_t)r * ld + cc];
-                t2s[k][cl[h]] = v.x;
-                t2s[k][cl[h] + 1] = v.y;
-            }
-        }
-    }
-    double acc[4][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[q][p] = 0.0;
-    for (int a0 = 0; a0 < kk; a0 += R2K_KT) {
-        const int at = (kk - a0 < R2K_KT) ? (kk - a0) : R2K_KT;
-        __syncthreads();
-        for (int t = threadIdx.x; t < R2K_KT * R2K_T; t += 256) {
-            const int a = t >> 6, i = t & 63;
-            const bool ok = a < at;
-            const int gr = r0 + i, gc = c0 + i;
-            ur[a][i] = (ok && gr < n) ? Up[(size_t)(a0 + a) * ldp + gr] : 0.0;
-            zr[a][i] = (ok && gr < n) ? Zp[(size_t)(a0 + a) * ldp + gr] : 0.0;
-            uc[a][i] = (ok && gc < n) ? Up[(size_t)(a0 + a) * ldp + gc] : 0.0;
-            zc[a][i] = (ok && gc < n) ? Zp[(size_t)(a0 + a) * ldp + gc] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int a = 0; a < R2K_KT; ++a) {
-            double ucx[4], zcx[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int c = cl[p >> 1] + (p & 1);
-                ucx[p] = uc[a][c];
-                zcx[p] = zc[a][c];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double urx = ur[a][ty + 16 * q], zrx = zr[a][ty + 16 * q];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) acc[q][p] += urx * zcx[p] + zrx * ucx[p];
-            }
-        }
-    }
-    __syncthreads();
-    // ---- new values; the mirror tile gets them through LDS --------------------------------------------------
-    if (diag) {
-        // own tile is its own mirror: symmetrise with the transposed element, publish the upper-triangle value
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) t2s[ty + 16 * q][cl[p >> 1] + (p & 1)] = t1[q][p];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int k = ty + 16 * q, c = cl[p >> 1] + (p & 1);
-                t1[q][p] = 0.5 * (t1[q][p] + t2s[c][k]) + alpha * acc[q][p];
-            }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) t2s[ty + 16 * q][cl[p >> 1] + (p & 1)] = t1[q][p];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int k = ty + 16 * q, c = cl[p >> 1] + (p & 1);
-                if (k > c) t1[q][p] = t2s[c][k];               // (k, c) below the diagonal: value computed for (c, k)
-            }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int k = ty + 16 * q, c = cl[p >> 1] + (p & 1);
-                t1[q][p] = 0.5 * (t1[q][p] + t2s[c][k]) + alpha * acc[q][p];
-            }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) t2s[cl[p >> 1] + (p & 1)][ty + 16 * q] = t1[q][p];
-        __syncthreads();
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = r0 + ty + 16 * q;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int cc = c0 + cl[h];
-            if (r < n && cc + 1 < n) *reinterpret_cast<double2*>(B + (size_t)r * ld + cc) = make_double2(t1[q][2 * h], t1[q][2 * h + 1]);
-            else if (r < n && cc < n) B[(size_t)r * ld + cc] = t1[q][2 * h];
-        }
-    }
-    if (!diag) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = ty + 16 * q, r = c0 + k;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int cc = r0 + cl[h];
-                if (r < n && cc + 1 < n) *reinterpret_cast<double2*>(B + (size_t)r * ld + cc) = make_double2(t2s[k][cl[h]], t2s[k][cl[h] + 1]);
-                else if (r < n && cc < n) B[(size_t)r * ld + cc] = t2s[k][cl[h]];
-            }
-        }
-    }
-}
-
 int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, const double* Zp, int ldp,
                       int kk, double alpha) {
     prof_begin(c, PROF_UPDATE, 16.0 * n * (double)n, 4.0 * kk * (double)n * n);
-    if (n >= 256 && (ld & 1) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && c->opt.rank2k_tile64) {
-        const int nt = (n + R2K_T - 1) / R2K_T;
-        SELLA_LAUNCH(c, sym_rank2k64_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, B, n, ld, Up, Zp, ldp, kk, alpha, nt);
-    } else {
-        const int nb = (n + 31) / 32;
-        SELLA_LAUNCH(c, sym_rank2k_kernel, dim3(nb, nb), dim3(256), 0, B, n, ld, Up, Zp, ldp, kk, alpha);
-    }
+    const int nb = (n + 31) / 32;
+    SELLA_LAUNCH(c, sym_rank2k_kernel, dim3(nb, nb), dim3(256), 0, B, n, ld, Up, Zp, ldp, kk, alpha);
     prof_end(c);
     HIPCHK(hipGetLastError());
     return SELLA_OK;

@@ -75,20 +75,17 @@ class Context:
         self.device = int(device)
         self._owner = threading.get_ident()
         self._parked = []
-        self._fin = weakref.finalize(self, Context._destroy, self, L)
+        # the finalizer holds only the raw handle: passing `self` would keep the context alive for ever
+        self._fin = weakref.finalize(self, L.sella_ctx_destroy, h)
 
     def _drain(self):
         while self._parked:
             _lib.lib().sella_mat_free(self._h, self._parked.pop())
 
-    @staticmethod
-    def _destroy(self, L):
-        if self._h is not None:
-            L.sella_ctx_destroy(self._h)
-            self._h = None
-
     def close(self):
-        self._fin()
+        if self._h is not None:
+            self._fin()
+            self._h = None
 
     # ---- misc -------------------------------------------------------------------------
     @property

@@ -116,6 +116,41 @@ class Translation(Coordinate):
         return float(atoms.positions[self.indices, self.kwargs['dim']].mean())
 
 
+class RotationGenerator(Coordinate):
+    """Infinitesimal rigid rotation of a group of atoms about one Cartesian axis through their centroid."""
+    natoms = 0
+
+    def __init__(self, indices, axis):
+        self.indices = np.array(indices, dtype=np.int64).ravel()
+        self.ncvecs = np.zeros((0, 3), dtype=np.int64)
+        self.kwargs = dict(axis=int(axis))
+
+    def reverse(self):
+        return self
+
+    def __eq__(self, other):
+        return (isinstance(other, RotationGenerator) and self.kwargs['axis'] == other.kwargs['axis']
+                and np.array_equal(np.sort(self.indices), np.sort(other.indices)))
+
+    def __repr__(self):
+        return f'RotationGenerator(axis={self.kwargs["axis"]}, natoms={len(self.indices)})'
+
+    def calc(self, atoms):
+        return 0.0
+
+    def generator(self, atoms):
+        """(1, 3N) row: d(theta_axis)/dx for a rigid rotation, unit norm (zero row for a degenerate group)."""
+        pos = np.asarray(atoms.positions, dtype=np.float64)[self.indices]
+        rel = pos - pos.mean(axis=0)
+        e = np.zeros(3)
+        e[self.kwargs['axis']] = 1.0
+        g = np.cross(e, rel)
+        row = np.zeros((1, 3 * len(atoms)))
+        row[0, (3 * self.indices[:, None] + np.arange(3)[None, :]).ravel()] = g.ravel()
+        nrm = np.linalg.norm(row)
+        return row / nrm if nrm > 1e-12 else row
+
+
 class _HessianStack:
     """Per-coordinate Hessians with the `ldot` contraction of SparseInternalHessians
     (sella/linalg.py:601-618): ldot(v) = sum_i v_i H_i as a dense (ndof, ndof) matrix."""
@@ -183,11 +218,11 @@ class Constraints:
     nangles = property(lambda self: self._count('angles'))
     ndihedrals = property(lambda self: self._count('dihedrals'))
     nother = property(lambda self: 0)
-    nrotations = property(lambda self: 0)
+    nrotations = property(lambda self: self._count('rotations'))
 
     @property
     def nint(self):
-        return self.ntrans + self.nbonds + self.nangles + self.ndihedrals
+        return self.ntrans + self.nbonds + self.nangles + self.ndihedrals + self.nrotations
 
     def copy(self):
         new = self.__class__(self.atoms, ignore_rotation=self.ignore_rotation)
@@ -245,6 +280,7 @@ class Constraints:
         for name in ('bonds', 'angles', 'dihedrals'):
             idx, pos, tvec = self._gather(name)
             vals.append(evaluate_kind(name, pos, tvec)[0])
+        vals.append(np.zeros(self.nrotations))              # linearised rotations: value 0 at every geometry
         return np.concatenate(vals) if vals else np.zeros(0)
 
     def wrap(self, vec):
@@ -262,7 +298,8 @@ class Constraints:
         """Dense (nactive, 3N) constraint Jacobian."""
         n3 = self.ndof
         rows, dofs, wts, nt = self._translation_arrays()
-        only_trans = not any(len(self._gather(name)[0]) for name in ('bonds', 'angles', 'dihedrals'))
+        only_trans = (not any(len(self._gather(name)[0]) for name in ('bonds', 'angles', 'dihedrals'))
+                      and self.nrotations == 0)
         if only_trans:
             # translation constraints do not depend on the geometry: the SAME (read-only) array is handed out as
             # long as the constraint set is unchanged, so everything downstream that keys on the object
@@ -285,6 +322,9 @@ class Constraints:
             dofs = (3 * idx[:, :, None] + np.arange(3)[None, None, :]).reshape(len(idx), -1)
             np.add.at(block, (np.arange(len(idx))[:, None], dofs), grad.reshape(len(idx), -1))
             J = np.vstack([J, block])
+        rot = self._active_list('rotations')
+        if rot:
+            J = np.vstack([J] + [r.generator(self.atoms) for r in rot])
         return J
 
     def hessian(self):
@@ -296,6 +336,8 @@ class Constraints:
             H = evaluate_kind(name, pos, tvec)[2].reshape(nc, 3 * na, 3 * na) if nc else np.zeros((0, 0, 0))
             dofs = (3 * idx[:, :, None] + np.arange(3)[None, None, :]).reshape(nc, -1) if nc else np.zeros((0, 0), dtype=np.int64)
             blocks.append((dofs, H))
+        nrot = self.nrotations                              # linear in x at fixed generators: no curvature term
+        blocks.append((np.zeros((nrot, 0), dtype=np.int64), np.zeros((nrot, 0, 0))))
         return _HessianStack(self.ndof, blocks)
 
     # ---- inequality bookkeeping (internal.py:2788-2823) ----------------------------------------
@@ -373,8 +415,17 @@ class Constraints:
         self._add('translations', new, target, 'eq', replace_ok)
 
     def fix_rotation(self, indices=None, axis=None):
-        raise NotImplementedError('rotation constraints (TRIC) are outside the saddle-search scope '
-                                  '(periodic slabs never add them: peswrapper.py:244-253)')
+        """Remove the rigid rotation of `indices` (default: all atoms) about `axis` (0, 1, 2; default: all three)
+        from the free subspace (internal.py:2871-2893 adds a TRIC `Rotation` coordinate there; peswrapper.py:244-253
+        does so for every non-periodic system).  Here the constraint is the LINEARISED rotation: its Jacobian row is
+        the infinitesimal generator e_axis x (r_i - centroid), normalised, re-evaluated at every geometry, with
+        residual and curvature identically zero — which is what the saddle search needs from it (the rotational
+        soft modes leave the Davidson / P-RFO subspace); finite rotation targets (TRIC proper) are out of scope."""
+        if indices is None:
+            indices = np.arange(self.natoms)
+        axes = range(3) if axis is None else (int(axis),)
+        for ax in axes:
+            self._add('rotations', RotationGenerator(indices, ax), 0.0, 'eq', True)
 
     def _fix_internal(self, cls, name, conv, indices, ncvecs=None, mic=None, target=None,
                       comparator='eq', replace_ok=True):
@@ -521,6 +572,8 @@ class InternalCoordinates:
             nc, m = len(pos), 3 * _NATOMS[k]
             H = evaluate_kind(k, pos, tvec)[2].reshape(nc, m, m) if nc else np.zeros((0, m, m))
             blocks.append((dofs, H))
+        nrot = self.nrotations                              # linear in x at fixed generators: no curvature term
+        blocks.append((np.zeros((nrot, 0), dtype=np.int64), np.zeros((nrot, 0, 0))))
         return _HessianStack(self.ndof, blocks)
 
 

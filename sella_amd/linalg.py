@@ -160,11 +160,10 @@ class ApproximateHessian(LinearOperator):
         self._eig_age = 0
         self._evals = None
         self._evecs = None
-        for name in ('_evecs_gpu', '_evecsT_gpu'):
-            old = getattr(self, name, None)
-            if old is not None:
-                old.free()
-            setattr(self, name, None)
+        # (references only: a live DeviceStepper or a caller of device_eig() may still hold the matrices, and
+        # handles are table indices — the DeviceMatrix finalizer frees them when the last holder lets go)
+        self._evecs_gpu = None
+        self._evecsT_gpu = None
         self._evals_gpu = None
 
     @property

@@ -49,20 +49,21 @@ def _pinned_coordinates(drdx):
     code (multipliers, linear constraint correction, peswrapper.py:429-438, 475-479) are componentwise divisions."""
     if drdx.shape[0] == 0:
         return None
-    if _pinned_memo[0] is drdx:                      # read-only Jacobian of a translation-only constraint set
-        return _pinned_memo[1]
+    memo = _pinned_memo[0]                           # ONE read of ONE slot: (drdx, out) is published atomically, so
+    if memo is not None and memo[0] is drdx:         # threads driving different replicas never mix key and value
+        return memo[1]
     nz = drdx != 0.0
     if not np.all(nz.sum(axis=1) == 1):
         out = None
     else:
         cidx = nz.argmax(axis=1)
         out = None if len(np.unique(cidx)) != len(cidx) else (cidx, drdx[np.arange(len(cidx)), cidx])
-    if not drdx.flags.writeable:
-        _pinned_memo[0], _pinned_memo[1] = drdx, out
+    if not drdx.flags.writeable:                     # read-only Jacobian of a translation-only constraint set
+        _pinned_memo[0] = (drdx, out)
     return out
 
 
-_pinned_memo = [None, None]
+_pinned_memo = [None]
 
 
 def _split_cons_subspace(drdx, tol_factor=1e-6):
@@ -106,10 +107,11 @@ class PES:
                 pass
         if proj_rot is None:
             proj_rot = not np.any(atoms.pbc)
-        if proj_rot:
-            # global rotations are a TRIC feature (out of scope); a non-periodic system is handled
-            # by the eigensolver seeing 3 extra soft modes, like Sella with proj_rot=False
-            pass
+        if proj_rot and not constraints.internals['rotations']:
+            # peswrapper.py:244-253: non-periodic systems get a global rotation constraint.  Here it is the
+            # linearised form (infinitesimal rotation generators about the centroid, internal.py Constraints.fix_rotation):
+            # the three rotational soft modes leave the Davidson / P-RFO subspace exactly as in the reference.
+            constraints.fix_rotation()
         self.cons = constraints
         self.eigensolver = eigensolver
         if isinstance(trajectory, str):

@@ -1,5 +1,7 @@
 """`modified_gram_schmidt` — drop-in for the reference's Cython routine
 (sella/utilities/math.pyx:143-159) running on the device (sella_amd/csrc/gs.hip)."""
+import weakref
+
 import numpy as np
 
 from ..device import get_context
@@ -30,24 +32,25 @@ def shared_identity(n):
     return I
 
 
-_SELECTIONS = []          # (basis array, row index of every column): bases made of columns of the identity
+_SELECTIONS = {}          # id(basis array) -> (weak reference, row index of every column)
 
 
 def register_selection(U, idx):
     """Remember that U[:, k] = e_idx[k] (built by peswrapper._split_cons_subspace for constraints that pin single
-    coordinates).  Products with such a basis are index operations; consumers ask `selection_of`."""
+    coordinates).  Products with such a basis are index operations; consumers ask `selection_of`.  The record lives
+    exactly as long as the array (weak reference keyed on its identity): any number of replicas, driven from any
+    number of host threads, keep their own bases without evicting each other."""
     idx = np.ascontiguousarray(idx, dtype=np.int64)
-    _SELECTIONS.append((U, idx))
-    if len(_SELECTIONS) > 8:
-        _SELECTIONS.pop(0)
+    key = id(U)
+    _SELECTIONS[key] = (weakref.ref(U, lambda _r, key=key: _SELECTIONS.pop(key, None)), idx)
     return U
 
 
 def selection_of(U):
     """Row indices if U is a registered selection basis (same object), else None."""
-    for B, idx in _SELECTIONS:
-        if B is U:
-            return idx
+    hit = _SELECTIONS.get(id(U))
+    if hit is not None and hit[0]() is U:
+        return hit[1]
     return None
 
 

@@ -27,23 +27,29 @@ def emu_library():
     return ctypes.CDLL(build_emu.build())
 
 
-@pytest.fixture(scope='module', params=BACKENDS)
-def ctx(request):
-    """A sella_amd Context on the real HIP library ('hip', gpu-marked) or on the host
-    emulation of the same sources ('emu', CPU CI)."""
+def make_context(request, backend):
+    """Generator behind the `ctx` fixtures: a sella_amd Context on the real HIP library ('hip') or on
+    the host emulation of the same sources ('emu'; built on first use)."""
     from sella_amd import _lib, device
     device._reset_default_context()
-    if request.param == 'emu':
+    if backend == 'emu':
         _lib._set_library_for_tests(request.getfixturevalue('emu_library'))
     else:
         _lib._set_library_for_tests(None)
     c = device.Context(0)
-    c.backend = request.param
+    c.backend = backend
     device._default = c
     yield c
     device._default = None
     c.close()
     _lib._set_library_for_tests(None)
+
+
+@pytest.fixture(scope='module', params=BACKENDS)
+def ctx(request):
+    """A sella_amd Context on the real HIP library ('hip', gpu-marked) or on the host
+    emulation of the same sources ('emu', CPU CI)."""
+    yield from make_context(request, request.param)
 
 
 @pytest.fixture(scope='session')

@@ -7,9 +7,16 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, hessian_like
+from conftest import GOLD, hessian_like, make_context
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx(request):
+    """Hardware only: this module never instantiates the emulator (the module-level gpu mark would otherwise
+    select the 'emu' parameter of the shared fixture and build the host emulation on the GPU box)."""
+    yield from make_context(request, 'hip')
 
 
 @pytest.fixture(scope='module')
@@ -30,8 +37,6 @@ def test_davidson_trajectory_digest(ctx, digests, n):
     amplifies roundoff ~3x per iteration: the same NumPy code stops at k = 16 in the build container
     and at k = 31 on this box's CPU for n = 3072), so the trajectory is pinned where it is well
     defined: the lowest Ritz value after j = 2..8 vectors must equal the reference's to 1e-10."""
-    if ctx.backend != 'hip':
-        pytest.skip('hardware only')
     from sella_amd.eigensolvers import rayleigh_ritz
     d = digests[str(n)]
     A, P, g = hessian_like(n, 0, eps=5e-3)
@@ -60,8 +65,6 @@ def test_davidson_trajectory_digest(ctx, digests, n):
 @pytest.mark.parametrize('n', [768, 3072])
 def test_davidson_converged_eigenpair(ctx, n):
     """north_star: the converged lowest eigenpair within 1e-10 of the exact (LAPACK) one."""
-    if ctx.backend != 'hip':
-        pytest.skip('hardware only')
     from sella_amd.eigensolvers import rayleigh_ritz
     A, P, g = hessian_like(n, 0, eps=5e-3)
     lams, V, AV = rayleigh_ritz(A, 1e-7, P, v0=g, method='jd0', maxiter=900)
@@ -72,8 +75,6 @@ def test_davidson_converged_eigenpair(ctx, n):
 
 @pytest.mark.parametrize('n', [300, 768, 3072])
 def test_update_digest(ctx, digests, n):
-    if ctx.backend != 'hip':
-        pytest.skip('hardware only')
     from sella_amd.linalg import ApproximateHessian
     d = digests[str(n)]
     A, P, g = hessian_like(n, 0, eps=5e-3)
@@ -91,8 +92,6 @@ def test_update_digest(ctx, digests, n):
 
 @pytest.mark.parametrize('n', [300, 768])
 def test_prfo_digest(ctx, digests, n):
-    if ctx.backend != 'hip':
-        pytest.skip('hardware only')
     from helpers import FakePES
     from sella_amd.linalg import ApproximateHessian
     from sella_amd.optimize.restricted_step import get_restricted_step
@@ -105,8 +104,6 @@ def test_prfo_digest(ctx, digests, n):
 
 
 def test_eigh_properties_3072(ctx):
-    if ctx.backend != 'hip':
-        pytest.skip('hardware only')
     n = 3072
     A, P, g = hessian_like(n, 1)
     dP = ctx.upload(P)
@@ -122,8 +119,6 @@ def test_eigh_properties_3072(ctx):
 
 
 def test_matvec_linearity_3072(ctx):
-    if ctx.backend != 'hip':
-        pytest.skip('hardware only')
     n = 3072
     rng = np.random.RandomState(5)
     A = rng.normal(size=(n, n))
@@ -133,3 +128,107 @@ def test_matvec_linearity_3072(ctx):
     rhs = 2.0 * ctx.symm_mm(dA, x) - 3.0 * ctx.symm_mm(dA, y)
     np.testing.assert_allclose(lhs, rhs, atol=1e-9)
     np.testing.assert_allclose(ctx.symm_mm(dA, x), A @ x, atol=1e-9)
+
+
+# ---- BASELINE configs[3]: ensemble of independent searches on one device -------------------------------------
+def _ensemble_member_factory(ctx, ne, host):
+    from sella_amd.atoms import Atoms, QuadraticCubicModel
+
+    def make_member(i):
+        Ai, Ui, x0 = host[i]
+        dAi = ctx.upload(Ai)
+        at = Atoms(['X'] * (ne // 3), x0.copy(), pbc=True)
+        at.calc = QuadraticCubicModel(lambda x, dAi=dAi: ctx.symm_mm(dAi, x), Ui, c=0.05)
+        return at
+    return make_member
+
+
+def test_ensemble_single_gpu(ctx):
+    """8 x (3N = 768) saddle searches through `run_ensemble` on the real device (configs[3], one GPU's share):
+    per-replica summaries and final positions bit-identical to running each member alone, every lambda_min < 0."""
+    from sella_amd.ensemble import run_ensemble, run_one
+    ne, nrep, steps = 768, 8, 12
+    host = {}
+    for i in range(nrep):
+        rng = np.random.RandomState(6000 + i)
+        U = rng.normal(size=(8, ne))
+        U /= np.linalg.norm(U, axis=1)[:, None]
+        host[i] = (hessian_like(ne, seed=5000 + i)[0], U, 0.05 * rng.normal(size=(ne // 3, 3)))
+    kw = dict(order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', proj_trans=False)
+    make_member = _ensemble_member_factory(ctx, ne, host)
+    res = run_ensemble(make_member, nrep, fmax=0.0, steps=steps, sella_kwargs=kw)
+    assert res['summary'].shape == (nrep, 5)
+    assert np.all(res['summary'][:, 1] == steps)
+    assert np.all(res['summary'][:, 4] < 0.0), res['summary'][:, 4]
+    assert np.all(np.isfinite(res['summary']))
+    for i in (0, 3, 7):
+        sm, pos = run_one(make_member(i), 0.0, steps, kw)
+        np.testing.assert_array_equal(sm, res['summary'][i])
+        np.testing.assert_array_equal(pos, res['positions'][i])
+    # host threads, one context per thread on the same device: same per-replica results
+    from sella_amd import device
+
+    def make_member_t(i):
+        return _ensemble_member_factory(device.get_context(), ne, host)(i)
+    res_t = run_ensemble(make_member_t, nrep, fmax=0.0, steps=steps, sella_kwargs=kw, threads=4)
+    np.testing.assert_array_equal(res_t['summary'], res['summary'])
+
+
+# ---- BASELINE configs[4]: n = 12288 --------------------------------------------------------------------------
+N4 = 12288
+
+
+@pytest.fixture(scope='module')
+def big_matrix():
+    """Dense symmetric 12288 x 12288 (1.2 GB): Wigner-type, no O(n^3) host work to build."""
+    rng = np.random.RandomState(12288)
+    G = rng.standard_normal((N4, N4))
+    G += G.T
+    return G
+
+
+def test_panel16_12288(ctx, big_matrix):
+    """Block product H V with k = 16 right-hand sides on the matrix cores (`panel16_mfma_kernel`) vs NumPy."""
+    rng = np.random.RandomState(3)
+    X = rng.standard_normal((N4, 16))
+    dH = ctx.upload(big_matrix)
+    Y = ctx.symm_mm(dH, X)
+    ref = big_matrix @ X
+    np.testing.assert_allclose(Y, ref, atol=1e-9 * np.abs(ref).max())
+    # linearity through the same kernel (size-independent property)
+    Y2 = ctx.symm_mm(dH, 2.0 * X[:, ::-1] - X)
+    np.testing.assert_allclose(Y2, 2.0 * Y[:, ::-1] - Y, atol=1e-9 * np.abs(ref).max())
+    dH.free()
+
+
+def test_eigh_12288(ctx, big_matrix):
+    """`sella_eigh` at configs[4] size: ordering, trace / Frobenius invariants, and residual / orthogonality of a
+    sample of eigenpairs against the host (a full LAPACK eigh at this size takes minutes on the box's cores)."""
+    A = big_matrix
+    dA = ctx.upload(A)
+    w, V, Vt = ctx.eigh(dA)
+    assert np.all(np.diff(w) >= 0)
+    scale = np.abs(w).max()
+    assert abs(w.sum() - np.trace(A)) < 1e-9 * scale * N4
+    assert abs(np.sqrt((w ** 2).sum()) - np.linalg.norm(A)) < 1e-10 * np.linalg.norm(A)
+    Vt_n = Vt.numpy()
+    idx = np.r_[0:8, N4 // 2 - 4:N4 // 2 + 4, N4 - 8:N4, np.random.RandomState(1).randint(0, N4, 40)]
+    Vs = Vt_n[idx].T
+    assert np.abs(A @ Vs - Vs * w[idx]).max() < 5e-13 * N4 * scale / 100
+    G = Vt_n[idx] @ Vt_n.T
+    G[np.arange(len(idx)), idx] -= 1.0
+    assert np.abs(G).max() < 1e-10
+    # known spectrum: three Householder reflections of a diagonal matrix (O(n^2) to build, eigenvalues exact)
+    rng = np.random.RandomState(9)
+    d = np.sort(rng.uniform(-3.0, 7.0, N4))
+    M = np.diag(d)
+    for _ in range(3):
+        u = rng.standard_normal(N4)
+        u /= np.linalg.norm(u)
+        Mu = M @ u
+        M = M - 2.0 * np.outer(u, Mu) - 2.0 * np.outer(Mu, u) + 4.0 * (u @ Mu) * np.outer(u, u)
+    dA.set(M)
+    w2, V2, Vt2 = ctx.eigh(dA)
+    np.testing.assert_allclose(w2, d, atol=1e-10)
+    for m in (dA, V, Vt, V2, Vt2):
+        m.free()

@@ -87,42 +87,6 @@ def test_benchmark_size(ctx):
     check(ctx, P, tol=2e-12)
 
 
-def test_fused_column_kernel(ctx):
-    """Option `eigh_fuse`: one launch per column of the tridiagonalisation (eigh.hip, `trd_fused_kernel`)."""
-    rng = np.random.RandomState(11)
-    ctx.set_option('eigh_fuse', 1)
-    try:
-        for n, names in ((5, ('random', 'tridiagonal')), (37, ('random', 'identity + low rank', 'tridiagonal')),
-                         (90, ('hessian-like',))):
-            for name, A in cases(n, rng):
-                if name in names:
-                    check(ctx, A)
-    finally:
-        ctx.set_option('eigh_fuse', 0)
-
-
-@pytest.mark.gpu
-def test_graph_replay(ctx):
-    """Option `eigh_graph`: the tridiagonalisation chain is captured once per size and replayed (eigh.hip); the
-    replays must act on the matrix of the current call, also with other sizes in between."""
-    if ctx.backend != 'hip':
-        pytest.skip('hardware only (capture is not emulated)')
-    rng = np.random.RandomState(5)
-    mats = {n: [m for _, m in zip(range(2), (a for _, a in cases(n, rng)))] for n in (640, 777)}
-    ref = {}
-    ctx.set_option('eigh_graph', 0)
-    for n in mats:
-        ref[n] = [check(ctx, A) for A in mats[n]]
-    ctx.set_option('eigh_graph', 1)
-    try:
-        for rep in range(3):
-            for n in mats:
-                for k, A in enumerate(mats[n]):
-                    np.testing.assert_array_equal(check(ctx, A), ref[n][k])
-    finally:
-        ctx.set_option('eigh_graph', 0)
-
-
 def _rank1_check(ctx, D, w, rho, tol=2e-14):
     K = len(D)
     lam, Ut = ctx.rank1_eig(D, w, rho)

@@ -51,7 +51,11 @@ def test_PES(ctx):
     assert pes.converged(1e100)[0]
     A = pes.get_Ufree().T @ pes.get_Ucons()
     np.testing.assert_allclose(A, 0, atol=1e-10)
-    assert pes.get_Ucons().shape[1] == 3          # global translation fixed automatically
+    assert pes.get_Ucons().shape[1] == 6          # global translation and rotation fixed automatically
+    # (peswrapper.py:233-253: a non-periodic system gets fix_translation() and fix_rotation())
+    from sella_amd.internal import Constraints
+    pes_t = PES(morse_atoms(5, seed=1), constraints=Constraints(morse_atoms(5, seed=1)), proj_rot=False)
+    assert pes_t.cons.nrotations == 0 and pes_t.cons.ntrans == 3
     pes.kick(-pes.get_g() * 0.001, diag=True, gamma=0.1)
     # the approximate Hessian reproduces the finite-difference curvature along the Davidson vectors
     B = pes.H.B
@@ -59,20 +63,27 @@ def test_PES(ctx):
     assert pes.neval > 5
 
 
+@pytest.mark.parametrize('rigid', ['pins', 'rotation'])
 @pytest.mark.parametrize('order', [0, 1])
-def test_morse_cluster(ctx, order):
+def test_morse_cluster(ctx, order, rigid):
     from sella_amd import Constraints, Sella
     atoms = morse_atoms(4, seed=4)
     cons = Constraints(atoms)
-    # remove the six rigid-body motions with translation constraints only (the reference test uses
-    # fix_rotation(), a TRIC feature outside this build): atom 0 pinned, atom 1 on a line, atom 2
-    # in a plane
-    cons.fix_translation(0)
-    cons.fix_translation(1, dim=1)
-    cons.fix_translation(1, dim=2)
-    cons.fix_translation(2, dim=2)
+    kw = {}
+    if rigid == 'pins':
+        # the six rigid-body motions removed with translation constraints only: atom 0 pinned, atom 1 on a
+        # line, atom 2 in a plane (no rotation constraint on top: proj_rot=False)
+        cons.fix_translation(0)
+        cons.fix_translation(1, dim=1)
+        cons.fix_translation(1, dim=2)
+        cons.fix_translation(2, dim=2)
+        kw['proj_rot'] = False
+    else:
+        # the reference's own set-up (tests/integration/test_morse_cluster.py:29-31)
+        cons.fix_translation()
+        cons.fix_rotation()
     log = io.StringIO()
-    opt = Sella(atoms, order=order, gamma=1e-3, constraints=cons, logfile=log)
+    opt = Sella(atoms, order=order, gamma=1e-3, constraints=cons, logfile=log, **kw)
     conv = opt.run(fmax=1e-3, steps=400)
     assert conv, log.getvalue()[-800:]
     Ufree = opt.pes.get_Ufree()

@@ -14,10 +14,6 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 ctx = Context(0)
 if os.environ.get('EIGH_NB'):
     ctx.set_option('eigh_nb', int(os.environ['EIGH_NB']))
-if os.environ.get('EIGH_FUSE'):
-    ctx.set_option('eigh_fuse', int(os.environ['EIGH_FUSE']))
-if os.environ.get('EIGH_GRAPH'):
-    ctx.set_option('eigh_graph', int(os.environ['EIGH_GRAPH']))
 if os.environ.get('EIGH_LEAF'):
     ctx.set_option('eigh_leaf', int(os.environ['EIGH_LEAF']))
 rng = np.random.RandomState(0)

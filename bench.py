@@ -68,28 +68,43 @@ def main():
     ap.add_argument('--ensemble-steps', type=int, default=20)
     ap.add_argument('--ensemble-n', type=int, default=768)
     ap.add_argument('--ensemble-threads', type=int, default=1)
+    ap.add_argument('--block-n', type=int, default=12288, help='configs[4] leg: operator size (0 disables)')
+    ap.add_argument('--block-iters', type=int, default=12)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
 
+    from sella_amd import comm as comm_mod
     from sella_amd.device import Context
     from sella_amd.utilities.hostcpu import effective_cpu_count, limit_blas_threads
     # host threads: the CPUs this container may use (cgroup quota, not the visible count), shared by the ranks
     local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
     host_threads = limit_blas_threads(max(1, effective_cpu_count() // max(1, local_world)))
     ctx = Context()             # LOCAL_RANK selects the device (one process per GPU)
+    # Collectives: librccl bound with ctypes on this context's stream and buffers (sella_amd/comm.py) — no PyTorch.
+    # The CPU tests (gloo, host emulation) set SELLA_BENCH_COMM=gloo; if the direct binding cannot come up on a GPU
+    # box, torch.distributed's nccl backend (the same RCCL) is the fallback, and the line says which was used.
+    comm = comm_mod.SingleProcess()
+    if world > 1:
+        def torch_group(backend):
+            import torch
+            import torch.distributed as tdist
+            if backend == 'nccl':
+                torch.cuda.set_device(local_rank)
+            tdist.init_process_group(backend=backend, rank=rank, world_size=world)
+            return comm_mod.GlooCommunicator()
+        if os.environ.get('SELLA_BENCH_COMM') == 'gloo':
+            comm = torch_group('gloo')
+        else:
+            try:
+                comm = comm_mod.RcclCommunicator(ctx, rank, world)
+            except Exception as e:                       # noqa: BLE001 — any failure of the direct binding
+                sys.stderr.write(f'[bench rank {rank}] direct RCCL binding failed ({e}); using torch.distributed\n')
+                comm = torch_group('nccl')
+        comm_mod._comm = comm                            # the ensemble / sharded-operator code uses the same one
     n = args.n
     # The exit iteration of the gamma = 0.1 run is chaotic (20 ... 31 vectors for the
     # same matrix depending on the last bit of the arithmetic), and the fixed eigh cost is amortised over
@@ -125,10 +140,7 @@ def main():
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-            dist.barrier()
+        comm.barrier()
 
     for _ in range(args.warmup):
         one_step()
@@ -144,8 +156,6 @@ def main():
             first = out                             # problem 0: the one the parity block refers to
     lams, Vr, AVr, nmv = first
     ctx.sync()
-    if dist is not None and torch.cuda.is_available():
-        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
 
@@ -288,11 +298,7 @@ def main():
                                threads=args.ensemble_threads)
             ctx.sync()
             tens = time.perf_counter() - te
-            if dist is not None:
-                dev_e = 'cuda' if torch.cuda.is_available() else 'cpu'
-                tt = torch.tensor([tens], dtype=torch.float64, device=dev_e)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                tens = float(tt.item())
+            tens = comm.max_host(tens)
             nst_tot = float(res['summary'][:, 1].sum())
             opt_stats['ensemble'] = dict(replicas=total, per_gpu=args.ensemble_per_gpu, n=ne,
                                          host_threads_per_gpu=args.ensemble_threads,
@@ -326,13 +332,59 @@ def main():
                                          force_calls=int(slab.calc.ncalls - nc0), rs='ras', calculator='EMT (device)')
         _dev._default = None
 
+    # ---- BASELINE configs[4]: block Davidson, 16 new vectors per iteration, H.V panel on the matrix cores, rows of
+    # H sharded over the ranks (strong scaling: the operator is fixed, every rank streams n / N rows of it and ONE
+    # all-gather per block iteration assembles H V).  The operator is a dense symmetric pseudo-random matrix built
+    # panel by panel from an integer hash (no rank ever holds more than its rows); the iteration count is fixed,
+    # so the figure is time per block iteration, not convergence (that is tests/test_big_gpu.py).
+    block_stats = None
+    if args.block_n > 0 and args.block_iters > 0:
+        from sella_amd import device as _dev2
+        from sella_amd.parallel import RowShardedOperator
+        _dev2._default = ctx
+        nb_ = args.block_n
+        m_ = -(-nb_ // world)
+        lo_, hi_ = min(rank * m_, nb_), min((rank + 1) * m_, nb_)
+        ii = np.arange(lo_, hi_, dtype=np.int64)[:, None]
+        jj = np.arange(nb_, dtype=np.int64)[None, :]
+        a_, b_ = np.minimum(ii, jj), np.maximum(ii, jj)
+        hsh = ((a_ * 73856093) ^ (b_ * 19349663) ^ 0x5bd1e995) & 0xFFFFF
+        Hloc = (hsh.astype(np.float64) / 0xFFFFF - 0.5) * 0.02
+        Hloc[np.arange(hi_ - lo_), np.arange(lo_, hi_)] += 0.5 + 50.0 * (np.arange(lo_, hi_) / nb_) ** 2
+        dgl = np.zeros(nb_)
+        dgl[lo_:hi_] = Hloc[np.arange(hi_ - lo_), np.arange(lo_, hi_)]
+        dg_all = comm.allgather_host(dgl).sum(axis=0) if world > 1 else dgl
+        op = RowShardedOperator(Hloc, lo_, nb_)
+        del Hloc, hsh, a_, b_
+        op.block_davidson(16, block=16, tol=1e-14, maxiter=2, maxvec=96, diag=dg_all)          # warm-up
+        # one panel pass alone (the roofline-relevant part of the iteration): 8 * rows * n bytes
+        Xp = np.random.RandomState(1).standard_normal((nb_, 16))
+        op.local_matmat(Xp)
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        for _ in range(3):
+            op.local_matmat(Xp)
+        ctx.prof_enable(False)
+        pp = ctx.prof_get(0)
+        barrier()
+        tb = time.perf_counter()
+        outb = op.block_davidson(16, block=16, tol=1e-14, maxiter=args.block_iters, maxvec=96, diag=dg_all)
+        ctx.sync()
+        tblk = comm.max_host(time.perf_counter() - tb)
+        nit = max(1, outb['niter'])
+        block_stats = dict(n=nb_, block=16, rows_per_rank=int(hi_ - lo_), iterations=int(outb['niter']),
+                           ms_per_block_iter=round(1e3 * tblk / nit, 3), block_iter_per_s=round(nit / tblk, 2),
+                           vectors_per_s=round(outb['nmatvec'] / tblk, 1),
+                           panel_pass_us=round(1e3 * pp['ms'] / max(1, pp['launches']), 1),
+                           panel_pass_gbs=round(pp['bytes'] / max(1e-12, pp['ms'] * 1e-3) / 1e9, 1) if pp['launches'] else None,
+                           lowest_ritz=float(outb['lams'][0]), scaling='strong (rows of H sharded over the ranks)',
+                           preconditioner='diagonal')
+        _dev2._default = None
+
     times = [elapsed]
     total_iters = iters
-    if dist is not None:
-        dev = 'cuda' if torch.cuda.is_available() else 'cpu'
-        t = torch.tensor([elapsed, float(iters)], dtype=torch.float64, device=dev)
-        gathered = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t)                 # RCCL all-gather of the per-replica results
+    if world > 1:
+        gathered = comm.allgather_host(np.array([elapsed, float(iters)]))     # RCCL all-gather of the per-replica results
         times = [float(x[0]) for x in gathered]
         total_iters = int(sum(float(x[1]) for x in gathered))
     tmax = max(times)
@@ -395,13 +447,17 @@ def main():
             'davidson_loop_only_iter_per_s': round(it2 / t_loop, 1),
             'eigh_ms': round(1e3 * t_eigh, 2),
             'optimizer': opt_stats,
+            'block_davidson': block_stats,
             'parity': {'lowest_ritz_value': float(lams[0]), 'ritz_residual_norm': resid, 'max_abs_AV_minus_A_V': av_err,
                        'converged_run': conv},
+            'collective': {'kind': comm.kind, 'nranks': getattr(comm, 'nranks', comm.world)},
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
+    if comm.kind == 'torch.distributed':
+        comm.dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -21,6 +21,8 @@
 #ifndef SELLA_HIP_H
 #define SELLA_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -54,10 +56,7 @@ int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
  *   gemv_rw (2) rows per wavefront of the streaming matvec | gemm_mfma (1) GEMMs on the matrix cores |
  *   gemm_tile128 (1) 128x128 GEMM tiles for large products | panel_mfma (1), panel_rows (0 = by size) the
  *   H.V block product | dav_reorth (0) re-orthonormalise V before each MGS | host_scalars (0) zero-copy scalars |
- *   eigh_nb (16) panel width, eigh_leaf (32) leaf size, eigh_wy_mfma (1) MFMA back-transformation,
- *   eigh_graph (0) hipGraph replay of the tridiagonalisation chain, eigh_fuse (0) one launch per column for
- *   small trailing blocks, rank2k_tile64 (0) 64x64 tiles in the symmetric rank-2k pass — the last three are
- *   measured-neutral variants kept for reference.                                     */
+ *   eigh_nb (16) panel width, eigh_leaf (32) leaf size, eigh_wy_mfma (1) MFMA back-transformation.            */
 int sella_ctx_set_option(sella_ctx* ctx, const char* key, long value);
 
 /* ---- device matrices --------------------------------------------------------------- */
@@ -133,6 +132,38 @@ int sella_davidson(sella_ctx* ctx, sella_mat A, sella_matvec_fn matvec, void* us
                    int n, const double* v0, int nv0, double gamma, int method, int maxiter,
                    const double* vref, double vreftol,
                    double* lams, double* V, double* AV, int* k, int* nmatvec);
+
+/* Block Davidson for the lowest `nev` eigenpairs of a large dense symmetric operator, `block` (<= 16) new
+ * vectors per iteration with the operator streamed once per block on the matrix cores (BASELINE.json
+ * configs[4]; the reference adds one vector per iteration, sella/eigensolvers.py:111-112, so there is no
+ * trajectory to match: the converged pairs equal those of exact(), sella/eigensolvers.py:9-28).
+ * A: resident (n x n), or — with `gather` — this rank's row panel A[row0 : row0 + rows, :] of a matrix whose rows
+ *    are split evenly (ceil(n / world) per rank) over `world` ranks; `gather` must all-gather `bytes` bytes from
+ *    every rank's device buffer `send` into `recv` (rank-major) on the given HIP stream (ncclAllGather).
+ * Preconditioner: the eigendecomposition of an approximate operator P (Pvecs / PvecsT / pevals as for
+ *    sella_davidson: t = Q (d - theta)^-1 Q^T r, the 'gd' correction of sella/eigensolvers.py:119-121), else
+ *    diag (n, host: t_i = r_i / (diag_i - theta)), else none.
+ * V0 (n x nv0, host, nv0 <= 16) start block or NULL.  tol: a pair counts as converged when
+ *    |r| <= tol |theta| (the reference's gamma test, sella/eigensolvers.py:80-89).
+ * Outputs (host): lams (nev), V (n x nev row-major), res (nev residual norms, may be NULL), *niter,
+ *    *nmatvec (operator columns applied), *nconv (pairs converged; nev on success).                           */
+typedef int (*sella_allgather_fn)(void* user, const void* send, void* recv, size_t bytes, void* hip_stream);
+int sella_davidson_block(sella_ctx* ctx, sella_mat A, int n, int row0, int world,
+                         sella_allgather_fn gather, void* user, sella_mat Pvecs, sella_mat PvecsT,
+                         const double* pevals, const double* diag, const double* V0, int nv0, int nev,
+                         int block, int maxvec, double tol, int maxiter, double* lams, double* V,
+                         double* res, int* niter, int* nmatvec, int* nconv);
+
+/* Raw copy between buffers handed to a callback (kind 0: device -> device, 1: device -> host, 2: host -> device),
+ * ordered on the context's stream and complete on return.  Lets a host-side all-gather (the gloo shim of the CPU
+ * tests) stage the device buffers of sella_davidson_block; RCCL takes the device pointers directly.              */
+int sella_dev_copy(sella_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);
+/* The context's HIP stream (hipStream_t) and the device address / leading dimension of a resident matrix: the
+ * handles a collective library bound from the host language (librccl through ctypes: ncclAllGather(send, recv,
+ * count, ncclDouble, comm, stream)) needs to run on the library's own buffers in stream order, without PyTorch.
+ * The reference has no collective anywhere; this is new surface for configs[3] / [4].     */
+int sella_ctx_stream(sella_ctx* ctx, void** hip_stream);
+int sella_mat_ptr(sella_ctx* ctx, sella_mat h, void** device_ptr, int* ld);
 
 /* ---- quasi-Newton update ------------------------------------------------------------------ */
 /* update_H(B, S, Y, method, symm, lams, vecs, B_gpu, evals_gpu, evecs_gpu)

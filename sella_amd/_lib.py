@@ -18,6 +18,7 @@ _lib = None
 c_double_p = POINTER(c_double)
 c_int_p = POINTER(c_int)
 MATVEC_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_double_p, c_double_p, c_int)
+ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p)
 
 # name -> (restype, argtypes); mirrors include/sella_hip.h one to one
 SIGNATURES = {
@@ -51,6 +52,12 @@ SIGNATURES = {
     'sella_davidson': (c_int, [c_void_p, c_int, MATVEC_FN, c_void_p, c_int, c_int, c_void_p,
                                c_double, c_int, c_void_p, c_int, c_double, c_int, c_int, c_void_p,
                                c_double, c_void_p, c_void_p, c_void_p, c_int_p, c_int_p]),
+    'sella_davidson_block': (c_int, [c_void_p, c_int, c_int, c_int, c_int, ALLGATHER_FN, c_void_p, c_int, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_int_p, c_int_p, c_int_p]),
+    'sella_ctx_stream': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'sella_mat_ptr': (c_int, [c_void_p, c_int, POINTER(c_void_p), c_int_p]),
+    'sella_dev_copy': (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_int]),
     'sella_update_h': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_int, c_int]),
     'sella_update_h_eig': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,

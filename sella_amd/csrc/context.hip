@@ -492,6 +492,33 @@ int sella_project(sella_ctx* c, sella_mat H, const double* U, int m, double* out
 }
 
 // ---- profiling ----------------------------------------------------------------------------
+// the context's HIP stream and the raw address of a resident matrix: what a collective library (RCCL, bound from the
+// host language without PyTorch) needs to work on the library's own buffers in stream order
+int sella_ctx_stream(sella_ctx* c, void** stream) {
+    if (!c || !stream) return SELLA_E_INVALID;
+    *stream = (void*)c->stream;
+    return SELLA_OK;
+}
+
+int sella_mat_ptr(sella_ctx* c, sella_mat h, void** dptr, int* ld) {
+    if (!c || !dptr) return SELLA_E_INVALID;
+    Mat* m = mat_get(c, h);
+    if (!m) return SELLA_E_INVALID;
+    *dptr = (void*)m->d;
+    if (ld) *ld = m->ld;
+    return SELLA_OK;
+}
+
+// raw copies for buffers handed to callbacks (the all-gather of sella_davidson_block): kind 0 = device -> device,
+// 1 = device -> host, 2 = host -> device; synchronous at the boundary
+int sella_dev_copy(sella_ctx* c, void* dst, const void* src, size_t bytes, int kind) {
+    if (!c || !dst || !src || kind < 0 || kind > 2) return SELLA_E_INVALID;
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyDeviceToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, k, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SELLA_OK;
+}
+
 int sella_prof_enable(sella_ctx* c, int on) {
     if (!c) return SELLA_E_INVALID;
     if (!on) SCHK(prof_flush(c));

@@ -274,6 +274,73 @@ class Context:
         return (lams[:kk].copy(), V[:n * kk].reshape(n, kk).copy(),
                 AV[:n * kk].reshape(n, kk).copy(), nmv.value)
 
+    def davidson_block(self, A, n, nev, block=16, tol=1e-8, maxiter=500, maxvec=0, V0=None, Pvecs=None,
+                       PvecsT=None, pevals=None, diag=None, row0=0, world=1, allgather=None):
+        """Lowest `nev` eigenpairs by block Davidson (csrc/davidson_block.hip).  A: DeviceMatrix (n x n), or this
+        rank's row panel with `allgather(send_ptr, recv_ptr, nbytes, stream_ptr) -> None` assembling the block
+        product over the ranks.  Returns dict(lams, V (n x nev), res, niter, nmatvec, nconv)."""
+        lams = np.zeros(nev)
+        V = np.zeros((n, nev))
+        res = np.zeros(nev)
+        niter, nmv, nconv = c_int(0), c_int(0), c_int(0)
+        err = []
+        if allgather is None:
+            cb = _lib.ALLGATHER_FN()
+        else:
+            def _cb(user, send, recv, nbytes, stream):
+                try:
+                    allgather(send, recv, nbytes, stream)
+                    return 0
+                except BaseException as e:      # noqa: B902 — must not unwind through C
+                    err.append(e)
+                    return 1
+            cb = _lib.ALLGATHER_FN(_cb)
+        v0 = None
+        nv0 = 0
+        if V0 is not None:
+            v0 = as_f64(V0)
+            if v0.ndim == 1:
+                v0 = v0[:, None]
+            v0 = np.ascontiguousarray(v0)
+            nv0 = v0.shape[1]
+        pe = as_f64(pevals) if pevals is not None else None
+        dg = as_f64(diag) if diag is not None else None
+        st = _lib.lib().sella_davidson_block(
+            self._h, A.handle, int(n), int(row0), int(world), cb, None,
+            SELLA_NO_MAT if Pvecs is None else Pvecs.handle, SELLA_NO_MAT if PvecsT is None else PvecsT.handle,
+            ptr(pe), ptr(dg), ptr(v0), nv0, int(nev), int(block), int(maxvec), float(tol), int(maxiter),
+            ptr(lams), ptr(V), ptr(res), byref(niter), byref(nmv), byref(nconv))
+        if err:
+            raise err[0]
+        check(st)
+        return dict(lams=lams, V=V, res=res, niter=niter.value, nmatvec=nmv.value, nconv=nconv.value)
+
+    @property
+    def stream(self):
+        """Address of the context's hipStream_t (for collectives issued on the library's own stream)."""
+        st = c_void_p()
+        check(_lib.lib().sella_ctx_stream(self._h, byref(st)))
+        return st.value or 0
+
+    def device_pointer(self, M):
+        """(device address, leading dimension) of a resident matrix."""
+        p, ld = c_void_p(), c_int(0)
+        check(_lib.lib().sella_mat_ptr(self._h, M.handle, byref(p), byref(ld)))
+        return p.value, ld.value
+
+    def copy_device(self, dst, src, nbytes):
+        """Device-to-device copy between raw device addresses (buffers handed to an all-gather callback)."""
+        check(_lib.lib().sella_dev_copy(self._h, c_void_p(dst), c_void_p(src), int(nbytes), 0))
+
+    def device_to_host(self, src, nbytes):
+        out = np.empty(int(nbytes) // 8, dtype=np.float64)
+        check(_lib.lib().sella_dev_copy(self._h, ptr(out), c_void_p(src), int(nbytes), 1))
+        return out
+
+    def host_to_device(self, dst, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        check(_lib.lib().sella_dev_copy(self._h, c_void_p(dst), ptr(arr), arr.nbytes, 2))
+
     # ---- quasi-Newton -----------------------------------------------------------------------
     def update_h(self, B, S, Y, method='TS-BFGS', symm=2, evals=None, evecs=None, evecsT=None):
         """In-place update of the resident B (n x n)."""

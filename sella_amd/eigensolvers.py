@@ -108,3 +108,34 @@ def rayleigh_ritz(A, gamma, P, B=None, v0=None, vref=None, vreftol=0.99,
         for h in owned:
             h.free()
     return lams, V, AV
+
+
+def block_davidson(A, nev, P=None, tol=1e-8, block=16, maxiter=500, maxvec=0, v0=None):
+    """Lowest `nev` eigenpairs of a dense symmetric A by block Davidson (`sella_davidson_block`: `block` <= 16 new
+    vectors per iteration, A streamed once per block on the matrix cores — BASELINE configs[4]).  The reference has
+    no block method (one vector per iteration, eigensolvers.py:111-112); the result matches `exact(A)` truncated.
+    P: approximate operator whose eigenbasis preconditions the corrections ('gd', eigensolvers.py:119-121),
+    an ApproximateHessian, or None (diagonal of A).  Returns (lams (nev,), V (n, nev), residual norms (nev,))."""
+    ctx = get_context()
+    own = []
+    if isinstance(A, DeviceMatrix):
+        dA, diag = A, None
+    else:
+        A = np.asarray(A, dtype=np.float64)
+        dA, diag = ctx.upload(A), np.ascontiguousarray(A.diagonal())
+        own.append(dA)
+    n = dA.shape[0]
+    kw = {}
+    if P is not None:
+        pk, owned = _preconditioner(P)
+        own += owned
+        if 'Pvecs' in pk:
+            kw = dict(Pvecs=pk['Pvecs'], PvecsT=pk['PvecsT'], pevals=pk['pevals'])
+    if not kw and diag is not None:
+        kw = dict(diag=diag)
+    out = ctx.davidson_block(dA, n, nev, block=block, tol=tol, maxiter=maxiter, maxvec=maxvec, V0=v0, **kw)
+    for m in own:
+        m.free()
+    if out['nconv'] < nev:
+        raise RuntimeError(f'block_davidson: {out["nconv"]} of {nev} pairs converged in {out["niter"]} iterations')
+    return out['lams'], out['V'], out['res']

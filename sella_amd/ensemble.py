@@ -3,11 +3,11 @@ BASELINE.json configs[3]).
 
 The reference has no multi-GPU code: every `Sella` object is independent, so an ensemble shards
 with zero coupling.  Replica r runs on rank r mod world (one process and one device context per
-GPU, launched with `python -m torch.distributed.run`); the only exchange is ONE all-gather of the
-per-replica summaries `[converged, nsteps, energy, fmax, lambda_min]` and final positions at the
-end — a few hundred KB in total, latency bound, so any xGMI link suffices and there is nothing to
-overlap.  `torch.distributed` is used for exactly that (backend "nccl" = RCCL on a GPU box, "gloo"
-in the CPU tests); the data path itself has no collective.
+GPU); the only exchange is ONE all-gather of the per-replica summaries `[converged, nsteps, energy, fmax,
+lambda_min]` and final positions at the end — a few hundred KB in total, latency bound, so any xGMI link
+suffices and there is nothing to overlap.  The collective is `ncclAllGather` on a device buffer of this
+library's context, bound with ctypes (`sella_amd/comm.py`); PyTorch is not imported on that path.  (In the CPU
+tests an initialised `torch.distributed` gloo group takes its place.)  The data path itself has no collective.
 
     results = run_ensemble(make_replica, 64, fmax=1e-3, steps=200, sella_kwargs=dict(order=1))
 
@@ -22,20 +22,12 @@ import numpy as np
 SUMMARY_FIELDS = ('converged', 'nsteps', 'energy', 'fmax', 'lambda_min')
 
 
-def _dist():
-    # A process group can only have been initialised by code that imported torch already: single-process use
-    # neither needs torch nor pays its import (0.9 s, which used to land inside the first ensemble call).
-    if 'torch' not in sys.modules:
-        return None
-    import torch.distributed as dist
-    return dist if dist.is_available() and dist.is_initialized() else None
-
-
 def rank_and_world():
-    dist = _dist()
-    if dist is None:
-        return 0, 1
-    return dist.get_rank(), dist.get_world_size()
+    from .comm import get_communicator
+    if int(os.environ.get('WORLD_SIZE', '1')) == 1 and 'torch' not in sys.modules:
+        return 0, 1                      # plain single-process use: no communicator, no device context needed yet
+    comm = get_communicator()
+    return comm.rank, comm.world
 
 
 def local_members(n_replicas, rank, world):
@@ -108,29 +100,23 @@ def run_ensemble(make_replica, n_replicas, fmax=0.05, steps=1000, sella_kwargs=N
         return dict(summary=np.array([summaries[i] for i in range(n_replicas)]),
                     positions=[positions[i] for i in range(n_replicas)], owner=owner)
 
-    import torch
-    dist = _dist()
-    on_gpu = dist.get_backend() == 'nccl'
-    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0'))) if on_gpu else torch.device('cpu')
+    from .comm import get_communicator
+    comm = get_communicator()
     # fixed-size payload per rank: max members per rank x (5 + 1 + 3 * max atoms)
     per_rank = (n_replicas + world - 1) // world
     natoms_local = max([positions[i].shape[0] for i in mine], default=0)
-    t = torch.tensor([natoms_local], dtype=torch.int64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    natoms_max = int(t.item())
+    natoms_max = int(comm.max_host(natoms_local))
     width = len(SUMMARY_FIELDS) + 1 + 3 * natoms_max
-    payload = torch.zeros((per_rank, width), dtype=torch.float64)
+    payload = np.zeros((per_rank, width))
     for slot, i in enumerate(mine):
-        payload[slot, :5] = torch.from_numpy(summaries[i])
+        payload[slot, :5] = summaries[i]
         payload[slot, 5] = positions[i].shape[0]
-        payload[slot, 6:6 + positions[i].size] = torch.from_numpy(positions[i].ravel())
-    payload = payload.to(dev)
-    gathered = [torch.empty_like(payload) for _ in range(world)]
-    dist.all_gather(gathered, payload)             # the one collective of the ensemble (RCCL over xGMI)
+        payload[slot, 6:6 + positions[i].size] = positions[i].ravel()
+    gathered = comm.allgather_host(payload.ravel())      # the one collective of the ensemble (RCCL over xGMI)
     out_s = np.zeros((n_replicas, len(SUMMARY_FIELDS)))
     out_p = [None] * n_replicas
     for r in range(world):
-        block = gathered[r].cpu().numpy()
+        block = gathered[r].reshape(per_rank, width)
         for slot, i in enumerate(local_members(n_replicas, r, world)):
             out_s[i] = block[slot, :5]
             na = int(block[slot, 5])

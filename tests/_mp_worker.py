@@ -11,6 +11,7 @@ import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, 'tests', 'hostemu'))
+sys.path.insert(0, os.path.join(REPO, 'tests'))
 
 
 def use_emulator():
@@ -52,8 +53,9 @@ def bench(out_path):
     import io
     from contextlib import redirect_stdout
     import bench as bench_mod
+    os.environ['SELLA_BENCH_COMM'] = 'gloo'
     sys.argv = ['bench.py', '--gpus', os.environ['WORLD_SIZE'], '--steps', '2', '--warmup', '1', '--n', '36',
-                '--maxiter', '8', '--seeds', '2', '--converged-n', '0', '--emt-steps', '0', '--no-cpu-baseline', '--opt-steps', '2', '--ensemble-per-gpu', '2', '--ensemble-n', '12', '--ensemble-steps', '2']
+                '--maxiter', '8', '--seeds', '2', '--converged-n', '0', '--emt-steps', '0', '--no-cpu-baseline', '--opt-steps', '2', '--ensemble-per-gpu', '2', '--ensemble-n', '12', '--ensemble-steps', '2', '--block-n', '70', '--block-iters', '3']
     buf = io.StringIO()
     with redirect_stdout(buf):
         bench_mod.main()
@@ -74,7 +76,13 @@ def panel(out_path):
     op = RowShardedOperator.from_full(H)
     Y = op.matmat(X)
     y1 = op.matmat(X[:, 0])
-    np.savez(out_path + f'.rank{dist.get_rank()}.npz', Y=Y, ref=H @ X, y1=y1, m_local=op.m_local, row0=op.row0)
+    # block Davidson on the sharded operator (configs[4] at toy size): one all-gather per block iteration
+    from conftest_shim import hessian_like
+    A, P, g = hessian_like(n, 5, nneg=2)
+    opA = RowShardedOperator.from_full(A)
+    out = opA.block_davidson(4, block=4, tol=1e-9, maxiter=300, diag=np.diag(A).copy())
+    np.savez(out_path + f'.rank{dist.get_rank()}.npz', Y=Y, ref=H @ X, y1=y1, m_local=op.m_local, row0=op.row0,
+             lams=out['lams'], V=out['V'], nconv=out['nconv'], exact=np.linalg.eigvalsh(A)[:4])
     dist.destroy_process_group()
 
 

@@ -71,6 +71,9 @@ def test_bench_two_ranks(tmp_path):
     assert d['value'] > 0 and d['ms_per_step'] > 0
     assert d['cpu_baseline'] is None            # rank 0 at N = 1 only
     assert d['roofline']['launches'] > 0
+    blk = d['block_davidson']
+    assert blk['n'] == 70 and blk['rows_per_rank'] == 35 and blk['iterations'] >= 1 and blk['block_iter_per_s'] > 0
+    assert d['collective']['kind'] == 'torch.distributed' and d['collective']['nranks'] == 2
     ens = d['optimizer']['ensemble']
     assert ens['replicas'] == 4 and ens['per_gpu'] == 2 and ens['optimizer_steps_per_s'] > 0
 
@@ -85,3 +88,9 @@ def test_row_sharded_block_product(tmp_path):
         np.testing.assert_allclose(r['Y'], r['ref'], atol=1e-11)
         np.testing.assert_allclose(r['y1'], r['ref'][:, 0], atol=1e-11)
     np.testing.assert_array_equal(r0['Y'], r1['Y'])      # every rank holds the same assembled block
+    # block Davidson over the sharded rows: converged, equal to LAPACK, identical on both ranks
+    for r in (r0, r1):
+        assert int(r['nconv']) == 4
+        np.testing.assert_allclose(r['lams'], r['exact'], atol=1e-10)
+    np.testing.assert_array_equal(r0['lams'], r1['lams'])
+    np.testing.assert_array_equal(r0['V'], r1['V'])

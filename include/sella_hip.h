@@ -205,13 +205,44 @@ int sella_symmetrize_y(sella_ctx* ctx, const double* S, const double* Y, int n, 
  * (RFO), :179-185 (P-RFO) in the eigenbasis of the (projected) Hessian:
  *   evecs (m x m resident, columns) / evecsT (rows), evals (m), g (m) host.
  * kind: 0 = qn, 1 = rfo, 2 = prfo.  Outputs s, dsda (m) host.                               */
-enum { SELLA_STEP_QN = 0, SELLA_STEP_RFO = 1, SELLA_STEP_PRFO = 2 };
+enum { SELLA_STEP_QN = 0, SELLA_STEP_RFO = 1, SELLA_STEP_PRFO = 2, SELLA_STEP_QN_IRC = 3 };
 typedef struct sella_stepper sella_stepper;
 int sella_stepper_create(sella_ctx* ctx, int kind, sella_mat evecs, sella_mat evecsT,
                          const double* evals, const double* g, int m, int order,
                          sella_stepper** st);
 int sella_stepper_get_s(sella_stepper* st, double alpha, double* s, double* dsda);
 int sella_stepper_destroy(sella_stepper* st);
+/* QuasiNewtonIRC (sella/optimize/stepper.py:99-111): kind SELLA_STEP_QN_IRC evaluates
+ * s(alpha) = -V (V^T g + alpha V^T d1) / (|lam| + alpha); d1hat = V^T d1 (m entries: the accumulated IRC
+ * displacement in the eigenbasis of the projected Hessian).  Must be set before the first evaluation.            */
+int sella_stepper_set_d1hat(sella_stepper* st, const double* d1hat, int m);
+
+/* The whole restricted-step root find, BaseRestrictedStep.get_s of sella/optimize/restricted_step.py:64-120, in ONE
+ * call: the 1-D search over the step-length parameter alpha of the family `st` until the constraint measure of the
+ * total step s(alpha) + scons equals the radius delta — same start value, bracket updates, Newton / bisection
+ * schedule (bisection only once niter > 4 unless newton_safe), nextafter bracket test and tolerances as the
+ * reference, so the sequence of trial alphas is the reference's.
+ *   cons: 0 trust region |s| (TrustRegion.cons :136-142); 1 largest per-atom displacement (RestrictedAtomicStep.cons
+ *         :172-183, nout = 3 natoms); 2 largest weighted component |w_i s_i| (MaxInternalStep.cons :206-216);
+ *         3 weighted sphere |(s + d1) * w| (IRCTrustRegion.cons :152-158).
+ *   scons (nout) or NULL: the constraint-correction step added to every trial step (:35-37, :73-76);
+ *   w (nout) for cons 2 / 3, d1 (nout) for cons 3;
+ *   alpha0, alphamin, alphamax, slope, newton_safe: the family's class attributes (stepper.py:20-41);
+ *   orthonormal != 0: the columns of the stepper's eigenvector matrix are orthonormal in the OUTPUT space, so for
+ *         cons 0 the norm is evaluated in the eigenbasis (|s|^2 = |shat|^2 + 2 shat.V^T scons + |scons|^2) and no
+ *         device work at all happens per trial alpha.
+ *   sel (m ints) / nfull: the family lives in the subspace of the free coordinates sel[0..m) of an nfull-dimensional
+ *         space (projection basis = columns of the identity, constraints that pin single coordinates); scons, w, d1,
+ *         the measure and the returned step are then nfull-dimensional.  NULL / 0 otherwise.
+ * Per trial alpha otherwise: O(m) host arithmetic, one 2-right-hand-side device matvec and one single-workgroup
+ * reduction; only two scalars come back.  Outputs: s (nout) = total step at the final alpha, *val = the measure
+ * reported by the reference (the value itself inside the radius, delta on the boundary), alphas[0 .. *nalpha) the
+ * trial sequence (capacity maxiter + 1; may be NULL).  Returns SELLA_E_NOCONV where the reference raises
+ * RuntimeError("Restricted step failed to converge!").                                                          */
+int sella_restricted_step(sella_stepper* st, int cons, double delta, const double* scons, const double* w,
+                          const double* d1, double alpha0, double alphamin, double alphamax, double slope,
+                          int newton_safe, int orthonormal, double tol, int maxiter, const int* sel, int nfull,
+                          double* s, double* val, double* alphas, int* nalpha);
 
 /* ---- internal-coordinate primitives ----------------------------------------------------------- */
 /* Batched value / gradient / Hessian-vector product / Hessian of bonds (natoms = 2), angles (3) and

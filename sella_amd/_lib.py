@@ -70,6 +70,10 @@ SIGNATURES = {
                                      POINTER(c_void_p)]),
     'sella_stepper_get_s': (c_int, [c_void_p, c_double, c_void_p, c_void_p]),
     'sella_stepper_destroy': (c_int, [c_void_p]),
+    'sella_stepper_set_d1hat': (c_int, [c_void_p, c_void_p, c_int]),
+    'sella_restricted_step': (c_int, [c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_double, c_double,
+                                      c_double, c_double, c_int, c_int, c_double, c_int, c_void_p, c_int, c_void_p,
+                                      c_double_p, c_void_p, c_int_p]),
     'sella_internals_eval': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
     'sella_emt_eval': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_double, c_double, c_double,

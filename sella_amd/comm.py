@@ -123,7 +123,7 @@ def broadcast_from_root(payload, rank, world, timeout=120.0):
 
 # ---- RCCL through ctypes ---------------------------------------------------------------------------------------------
 class _UniqueId(ctypes.Structure):
-    _fields_ = [('internal', ctypes.c_char * 128)]
+    _fields_ = [('internal', ctypes.c_ubyte * 128)]      # (c_char arrays read back truncated at the first NUL)
 
 
 NCCL_DOUBLE, NCCL_SUM, NCCL_MAX = 8, 0, 2
@@ -169,8 +169,11 @@ class RcclCommunicator:
         uid = _UniqueId()
         if self.rank == 0:
             self._chk(self.lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
-        raw = broadcast_from_root(bytes(uid.internal) if self.rank == 0 else b'', self.rank, self.world)
-        ctypes.memmove(ctypes.byref(uid), raw, 128)
+        raw = broadcast_from_root(ctypes.string_at(ctypes.addressof(uid), 128) if self.rank == 0 else b'',
+                                  self.rank, self.world)
+        if len(raw) != 128:
+            raise RuntimeError(f'sella_amd.comm: unique id of {len(raw)} bytes from the rendezvous')
+        ctypes.memmove(ctypes.addressof(uid), raw, 128)
         self.comm = ctypes.c_void_p()
         self._chk(self.lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), 'ncclCommInitRank')
         n = ctypes.c_int(0)

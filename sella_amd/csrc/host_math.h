@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "bordered.h"
 #include "small_linalg.h"
 
 namespace sella {
@@ -124,6 +125,120 @@ inline int gen_sym_eig(int k, const double* A, const double* M, double* lams, do
             for (int l = i + 1; l < k; ++l) s -= L[(size_t)l * k + i] * W[(size_t)l * k + c];
             W[(size_t)i * k + c] = s / L[(size_t)i * k + i];
         }
+    return 0;
+}
+
+
+// Eigendecomposition of the (m + 1) x (m + 1) arrowhead matrix  [[diag(D), z], [z^T, alpha]]  in O(m^2):
+// what the Rayleigh-Ritz step of the Davidson loop becomes once the basis has been rotated into the previous
+// Ritz vectors (the old block is diag(theta), the new vector contributes the border).  D need not be sorted.
+// lam (m + 1) ascending; W ((m + 1) x (m + 1) row-major) has the eigenvectors as COLUMNS, orthonormal to
+// working precision: deflation as in LAPACK's dlaed2 (negligible border entries, coincident poles rotated
+// apart), roots of the secular equation by `bordered_root` as (pole, offset) pairs, and the border recomputed
+// from the roots (Gu & Eisenstat) so that close roots still give orthogonal vectors.  Returns 0 on success.
+inline int arrow_eig(int m, const double* Din, const double* zin, double alpha, double* lam, double* W) {
+    const int M = m + 1;
+    if (m == 0) { lam[0] = alpha; W[0] = 1.0; return 0; }
+    const double EPS = 2.220446049250313e-16;
+    std::vector<int> ord(m);
+    for (int i = 0; i < m; ++i) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return Din[a] < Din[b]; });
+    vec d(m), b(m);
+    double scale = fabs(alpha);
+    for (int i = 0; i < m; ++i) {
+        d[i] = Din[ord[i]];
+        b[i] = zin[ord[i]];
+        scale = std::max(scale, std::max(fabs(d[i]), fabs(b[i])));
+    }
+    const double tol = 8.0 * EPS * scale;
+    // deflation; rotations recorded as (p, q, c, s): coordinates x_p = c y_p + s y_q, x_q = -s y_p + c y_q
+    struct Rot { int p, q; double c, s; };
+    std::vector<Rot> rots;
+    std::vector<char> active(m, 1);
+    for (int i = 0; i < m; ++i)
+        if (fabs(b[i]) <= tol) { active[i] = 0; b[i] = 0.0; }
+    int prev = -1;
+    for (int i = 0; i < m; ++i) {
+        if (!active[i]) continue;
+        if (prev >= 0 && d[i] - d[prev] <= tol) {
+            const double r = hypot(b[prev], b[i]);
+            const double c = b[i] / r, sn = b[prev] / r;
+            const double dp = c * c * d[prev] + sn * sn * d[i], dq = sn * sn * d[prev] + c * c * d[i];
+            d[prev] = dp;
+            d[i] = dq;
+            b[prev] = 0.0;
+            b[i] = r;
+            active[prev] = 0;
+            rots.push_back({prev, i, c, sn});
+        }
+        prev = i;
+    }
+    std::vector<int> act;
+    for (int i = 0; i < m; ++i)
+        if (active[i]) act.push_back(i);
+    const int ma = (int)act.size();
+    // eigenvector matrix in the sorted / rotated coordinates: Y (M x M), columns = eigenvectors
+    vec Y((size_t)M * M, 0.0), ev(M);
+    int col = 0;
+    for (int i = 0; i < m; ++i)
+        if (!active[i]) {
+            ev[col] = d[i];
+            Y[(size_t)i * M + col] = 1.0;
+            ++col;
+        }
+    if (ma == 0) {
+        ev[col] = alpha;
+        Y[(size_t)m * M + col] = 1.0;
+        ++col;
+    } else {
+        vec Dp(ma), bp(ma), tau(ma + 1), bh(ma);
+        std::vector<int> org(ma + 1);
+        for (int a = 0; a < ma; ++a) { Dp[a] = d[act[a]] - alpha; bp[a] = b[act[a]]; }
+        for (int j = 0; j <= ma; ++j) bordered::bordered_root(ma, Dp.data(), bp.data(), j, &org[j], &tau[j]);
+        // mu_j - D_a with full relative accuracy
+        auto diff = [&](int j, int a) { return (org[j] >= 0 ? (Dp[org[j]] - Dp[a]) : -Dp[a]) + tau[j]; };
+        for (int a = 0; a < ma; ++a) {
+            // bhat_a^2 = -(mu_a - D_a)(mu_{a+1} - D_a) prod_{l<a} (mu_l - D_a)/(D_l - D_a) prod_{l>a} (mu_{l+1} - D_a)/(D_l - D_a)
+            double p = -diff(a, a) * diff(a + 1, a);
+            for (int l = 0; l < a; ++l) p *= diff(l, a) / (Dp[l] - Dp[a]);
+            for (int l = a + 1; l < ma; ++l) p *= diff(l + 1, a) / (Dp[l] - Dp[a]);
+            const double v = sqrt(fabs(p));
+            bh[a] = (bp[a] >= 0.0) ? v : -v;
+        }
+        for (int j = 0; j <= ma; ++j) {
+            double nrm2 = 1.0;
+            for (int a = 0; a < ma; ++a) {
+                const double x = bh[a] / diff(j, a);
+                Y[(size_t)act[a] * M + col] = x;
+                nrm2 += x * x;
+            }
+            const double inv = 1.0 / sqrt(nrm2);
+            for (int a = 0; a < ma; ++a) Y[(size_t)act[a] * M + col] *= inv;
+            Y[(size_t)m * M + col] = inv;
+            ev[col] = alpha + (org[j] >= 0 ? Dp[org[j]] : 0.0) + tau[j];
+            ++col;
+        }
+    }
+    // undo the deflating rotations (reverse order) on the coordinate rows
+    for (int r = (int)rots.size() - 1; r >= 0; --r) {
+        const Rot& g = rots[r];
+        double* yp = Y.data() + (size_t)g.p * M;
+        double* yq = Y.data() + (size_t)g.q * M;
+        for (int cidx = 0; cidx < M; ++cidx) {
+            const double a = yp[cidx], bq = yq[cidx];
+            yp[cidx] = g.c * a + g.s * bq;
+            yq[cidx] = -g.s * a + g.c * bq;
+        }
+    }
+    // ascending order of the eigenvalues, rows back to the caller's order of D
+    std::vector<int> eo(M);
+    for (int j = 0; j < M; ++j) eo[j] = j;
+    std::stable_sort(eo.begin(), eo.end(), [&](int a, int b2) { return ev[a] < ev[b2]; });
+    for (int j = 0; j < M; ++j) {
+        lam[j] = ev[eo[j]];
+        for (int i = 0; i < m; ++i) W[(size_t)ord[i] * M + j] = Y[(size_t)i * M + eo[j]];
+        W[(size_t)m * M + j] = Y[(size_t)m * M + eo[j]];
+    }
     return 0;
 }
 

@@ -192,6 +192,10 @@ int launch_gemv_rows(sella_ctx* c, const double* A, int rows, int cols, int lda,
 // same with the right-hand sides given as separate pointers (no contiguity requirement)
 int launch_gemv_rows_xp(sella_ctx* c, const double* A, int rows, int cols, int lda,
                         const double* const* xs, int nrhs, double* Y, int ldy, const GemvEpi& epi);
+// y = A x and y2 = A2 x in ONE launch (two row sources, one right-hand side): the speculative A t and the panel dots
+// V t of the Davidson chain share a launch boundary
+int launch_gemv_rows2(sella_ctx* c, const double* A, int rows, int lda, const double* A2, int rows2, int lda2, int cols,
+                      const double* x, double* y, double* y2);
 // Y (nrhs <= 16 rows, vector-major) = A X^T on the matrix cores; Xp: 16-row panel with leading dimension lda,
 // rows beyond nrhs and the row padding zero
 int launch_panel16(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* Xp, int nrhs,

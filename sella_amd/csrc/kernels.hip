@@ -154,6 +154,76 @@ int launch_gemv_rows(sella_ctx* c, const double* A, int rows, int cols, int lda,
     return launch_gemv_rows_xp(c, A, rows, cols, lda, xs.data(), nrhs, Y, ldy, epi);
 }
 
+// Two row sources, one right-hand side: rows [0, rows) come from A, rows [rows, rows + rows2) from A2 (same column
+// count); same streaming structure as gemv_rows_kernel<1, 2>.
+__global__ __launch_bounds__(256) void gemv_rows2_kernel(const double* __restrict__ A, int rows, int lda,
+                                                         const double* __restrict__ A2, int rows2, int lda2, int cols,
+                                                         const double* __restrict__ x, double* __restrict__ y,
+                                                         double* __restrict__ y2) {
+    constexpr int RB = 2;
+    __shared__ double red[4][RB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * RB, rtot = rows + rows2;
+    const double2* arow[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        int rr = row0 + r;
+        if (rr > rtot - 1) rr = rtot - 1;
+        arow[r] = reinterpret_cast<const double2*>(rr < rows ? A + (size_t)rr * lda : A2 + (size_t)(rr - rows) * lda2);
+    }
+    double acc[RB] = {0.0, 0.0};
+    const int n2 = (cols + 1) >> 1;
+    const bool odd = cols & 1;
+    for (int j0 = threadIdx.x; j0 < n2; j0 += 512) {
+        const int j1 = j0 + 256;
+        const bool has1 = j1 < n2;
+        double2 a0[RB], a1[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            a0[r] = arow[r][j0];
+            a1[r] = has1 ? arow[r][j1] : make_double2(0.0, 0.0);
+        }
+        double2 x0, x1;
+        x0.x = x[2 * j0];
+        x0.y = (odd && j0 == n2 - 1) ? 0.0 : x[2 * j0 + 1];
+        if (has1) {
+            x1.x = x[2 * j1];
+            x1.y = (odd && j1 == n2 - 1) ? 0.0 : x[2 * j1 + 1];
+        } else {
+            x1 = make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] += a0[r].x * x0.x + a0[r].y * x0.y + a1[r].x * x1.x + a1[r].y * x1.y;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const double v = wave_sum(acc[r]);
+        if (lane == 0) red[wave][r] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < RB) {
+        const int rr = row0 + threadIdx.x;
+        if (rr < rtot) {
+            const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            if (rr < rows) y[rr] = v; else y2[rr - rows] = v;
+        }
+    }
+}
+
+int launch_gemv_rows2(sella_ctx* c, const double* A, int rows, int lda, const double* A2, int rows2, int lda2, int cols,
+                      const double* x, double* y, double* y2) {
+    if (rows + rows2 <= 0 || cols <= 0) return SELLA_OK;
+    if ((lda & 1) || (lda2 & 1) || (((uintptr_t)A) & 15) || (((uintptr_t)A2) & 15)) {
+        set_error("gemv_rows2: matrices must be 16-byte aligned with even leading dimensions");
+        return SELLA_E_INVALID;
+    }
+    prof_begin(c, PROF_GEMV, 8.0 * (rows + rows2) * (double)cols, 2.0 * (rows + rows2) * (double)cols);
+    SELLA_LAUNCH(c, gemv_rows2_kernel, dim3((rows + rows2 + 1) / 2), dim3(256), 0, A, rows, lda, A2, rows2, lda2, cols, x, y, y2);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
 // |x|^2 -> out[0], then x /= |x|  in ONE single-workgroup launch (n up to a few 10^4)
 __global__ __launch_bounds__(1024) void normalize_kernel(double* __restrict__ x, int n, double* __restrict__ out) {
     __shared__ double red[16];

@@ -11,6 +11,7 @@
 // pseudo-inverse solve with the same bordered-diagonal matrix.  The only O(m^2) work per alpha
 // is mapping (s, ds/dalpha) back with one 2-right-hand-side row-panel matvec on the device.
 #include "internal.h"
+#include "bordered.h"
 #include <chrono>
 #include <cstdlib>
 
@@ -22,6 +23,8 @@ struct sella_stepper {
     sella_mat V = SELLA_NO_MAT;      // m x m eigenvectors (columns)   [not owned]
     sella_mat VU = SELLA_NO_MAT;     // nout x m : U V when a projection U (nout x m) was given [owned]
     std::vector<double> lam, ghat;
+    std::vector<double> d1hat;       // V^T d1 of the IRC quasi-Newton family (kind SELLA_STEP_QN_IRC)
+    sella_mat Vt = SELLA_NO_MAT;     // rows = eigenvectors [not owned]; needed for V^T scons in the root finder
     double t_host = 0.0, t_dev = 0.0;     // SELLA_DEBUG_TIMING: seconds in the secular solves / in the device round trip
     long calls = 0, sweeps = 0;
 };
@@ -30,128 +33,6 @@ namespace sella {
 namespace {
 
 typedef std::vector<double> vec;
-
-// Root number j (ascending, 0..mm) of f(mu) = mu + sum b_i^2 / (D_i - mu), D ascending.
-// Returned as (origin, tau): mu = D_origin + tau with the origin the closer pole
-// (origin = -1: mu = tau, used for the two exterior roots far from every pole).
-long g_sweeps = 0;      // SELLA_DEBUG_TIMING statistics only
-
-void bordered_root(int mm, const double* D, const double* b, int j, int* origin, double* tau) {
-    double bb = 0.0;
-    for (int i = 0; i < mm; ++i) bb += b[i] * b[i];
-    // value, noise scale and the derivative split at pole index j (left part: poles i < j, right part: i >= j)
-    struct Ev { double f, noise, dl, dr; };
-    const int ext = (j == 0) ? 0 : (j == mm ? mm - 1 : -1);      // nearest pole of an exterior root
-    auto eval = [&](double shift, double t) {
-        Ev e;
-        double s = 0.0, sa = 0.0, dl = 0.0, dr = 0.0;
-        for (int i = 0; i < j; ++i) {                 // poles left of the root (two plain loops: both vectorise)
-            const double r = 1.0 / ((D[i] - shift) - t);
-            const double q = b[i] * b[i] * r;
-            s += q;
-            sa += fabs(q);
-            dl += q * r;
-        }
-        for (int i = j; i < mm; ++i) {                // poles right of the root
-            const double r = 1.0 / ((D[i] - shift) - t);
-            const double q = b[i] * b[i] * r;
-            s += q;
-            sa += fabs(q);
-            dr += q * r;
-        }
-        e.f = (shift + t) + s;
-        e.noise = fabs(shift + t) + sa;
-        e.dl = dl;
-        e.dr = dr;
-        return e;
-    };
-    double shift, lo, hi, t;
-    int org;
-    if (mm == 0) { *origin = -1; *tau = 0.0; return; }
-    if (j == 0 || j == mm) {
-        // Exterior root.  Brackets from two one-pole problems mu + c / (d - mu) = 0 with d the nearest pole D_e:
-        // all weight on that pole (c = |b|^2) overshoots the root, only that pole's own weight (c = b_e^2) falls
-        // short of it — every term of the sum has the same sign on this side of the spectrum.
-        const int e = (j == 0) ? 0 : mm - 1;
-        const double sg = (j == 0) ? -1.0 : 1.0;
-        org = e;
-        shift = D[e];
-        const double far = 0.5 * (-shift + sg * sqrt(shift * shift + 4.0 * bb));          // t of the overshooting model
-        const double near = 0.5 * (-shift + sg * sqrt(shift * shift + 4.0 * b[e] * b[e]));
-        if (j == 0) { lo = far; hi = std::min(near, 0.0); }
-        else { lo = std::max(near, 0.0); hi = far; }
-        if (!(hi > lo)) { *origin = org; *tau = 0.5 * (lo + hi); return; }                 // b = 0: mu = min/max(D_e, 0)
-        t = far;
-        if (t == 0.0) t = 0.5 * (lo + hi);
-    } else {
-        const double delta = D[j] - D[j - 1];
-        if (delta <= 0.0) { *origin = j; *tau = 0.0; return; }      // coincident poles: mu = D_j
-        const double fm = eval(D[j - 1], 0.5 * delta).f;
-        if (fm >= 0.0) { org = j - 1; shift = D[j - 1]; lo = 0.0; hi = 0.5 * delta; }
-        else { org = j; shift = D[j]; lo = -0.5 * delta; hi = 0.0; }
-        t = 0.5 * (lo + hi);
-    }
-    // f is increasing between poles: f(lo) <= 0 <= f(hi) (pole ends are never evaluated).  Interior roots: as in
-    // the eigensolver's secular equation (secular.h), the two poles next to the root are kept exact and the rest of
-    // the sum is frozen at value and slope ("middle way" rational model).  Exterior roots: the nearest pole is
-    // kept exact and the rest of the sum is replaced by the one-pole function that matches its value and slope (all terms have
-    // the same sign there) next to the exact nearest pole — with the nearest pole alone these roots took 30-60
-    // sweeps at the sizes of a slab search, now 3-6.  Bracket + bisection as the safeguard, stop at |f| below its rounding noise.
-    const double EPS = 2.220446049250313e-16;
-    for (int it = 0; it < 200; ++it) {
-        const Ev e = eval(shift, t);
-        ++g_sweeps;
-        const double fv = e.f;
-        if (!(fabs(fv) > 8.0 * EPS * e.noise)) break;
-        if (fv < 0.0) lo = t; else hi = t;
-        const double df = 1.0 + e.dl + e.dr;
-        double eta;
-        if (j > 0 && j < mm) {
-            const double D1 = (D[j - 1] - shift) - t, D2 = (D[j] - shift) - t;     // < 0 < 
-            const double c_ = fv - D1 * e.dl - D2 * e.dr;
-            const double a_ = (D1 + D2) * fv - D1 * D2 * (e.dl + e.dr);
-            const double b_ = D1 * D2 * fv;
-            if (c_ == 0.0) eta = (a_ != 0.0) ? b_ / a_ : -fv / df;
-            else {
-                const double disc = sqrt(fabs(a_ * a_ - 4.0 * b_ * c_));
-                eta = (a_ <= 0.0) ? (a_ - disc) / (2.0 * c_) : 2.0 * b_ / (a_ + disc);
-            }
-        } else {
-            // model: (mu + eta) + a1 / (p1 - eta) + a2 / (p2 - eta) = 0 with the nearest pole exact
-            // (a1 = b_e^2, p1 = D_e - mu) and the REST of the sum R replaced by the one-pole function that
-            // matches R and R' at the current point (p2 = R / R', a2 = R p2).  Solved for eta by a safeguarded
-            // scalar Newton iteration inside the bracket — O(1) work per sweep.
-            const double mu = shift + t;
-            const double p1 = (D[ext] - shift) - t, a1 = b[ext] * b[ext];
-            const double q1 = a1 / p1;
-            const double R = (fv - mu) - q1, Rp = (e.dl + e.dr) - q1 / p1;
-            double a2 = 0.0, p2 = 1.0;
-            if (Rp > 0.0 && R != 0.0) { p2 = R / Rp; a2 = R * p2; }
-            double elo = lo - t, ehi = hi - t, x = 0.0, Fx = fv;
-            eta = -fv / df;
-            for (int in = 0; in < 40; ++in) {
-                if (Fx < 0.0) elo = x; else ehi = x;
-                const double r1 = 1.0 / (p1 - x), r2 = 1.0 / (p2 - x);
-                const double dF = 1.0 + a1 * r1 * r1 + a2 * r2 * r2;
-                double xn = x - Fx / dF;
-                if (!(xn > elo && xn < ehi)) xn = 0.5 * (elo + ehi);
-                if (xn == x) break;
-                x = xn;
-                Fx = (mu + x) + a1 / (p1 - x) + a2 / (p2 - x);
-                if (fabs(Fx) <= 4.0 * EPS * (fabs(mu + x) + fabs(a1 / (p1 - x)) + fabs(a2 / (p2 - x)))) break;
-            }
-            if (x != 0.0) eta = x;
-        }
-        if (!(fv * eta < 0.0)) eta = -fv / df;
-        double tn = t + eta;
-        if (!(tn > lo && tn < hi)) tn = 0.5 * (lo + hi);
-        if (tn == lo || tn == hi || tn == t) { t = tn; break; }
-        t = tn;
-        if (hi - lo <= EPS * std::max(fabs(lo), fabs(hi))) break;
-    }
-    *origin = org;
-    *tau = t;
-}
 
 // RFO step in the eigenbasis for a block (lam, ghat) of size mm, eigenpair index `o` of the
 // augmented matrix (stepper.py:128-157).  Outputs shat, dshat (mm).
@@ -162,7 +43,7 @@ void rfo_block(int mm, const double* lam, const double* ghat, int o, double alph
     for (int i = 0; i < mm; ++i) { D[i] = alpha * alpha * lam[i]; b[i] = alpha * ghat[i]; }
     int org;
     double tau;
-    bordered_root(mm, D.data(), b.data(), o, &org, &tau);
+    bordered::bordered_root(mm, D.data(), b.data(), o, &org, &tau);
     const double shift = org >= 0 ? D[org] : 0.0;
     // eigenvector (unnormalised): y_i = b_i / (mu - D_i), eta = 1
     double nrm2 = 1.0;
@@ -225,7 +106,7 @@ extern "C" int sella_stepper_create(sella_ctx* c, int kind, sella_mat hV, sella_
         set_error("stepper: invalid arguments");
         return SELLA_E_INVALID;
     }
-    if (kind < SELLA_STEP_QN || kind > SELLA_STEP_PRFO) {
+    if (kind < SELLA_STEP_QN || kind > SELLA_STEP_QN_IRC) {
         set_error("Unknown stepper kind %d", kind);
         return SELLA_E_INVALID;
     }
@@ -242,6 +123,7 @@ extern "C" int sella_stepper_create(sella_ctx* c, int kind, sella_mat hV, sella_
     st->order = order;
     st->nout = V->rows;
     st->V = hV;
+    st->Vt = hVt;
     st->lam.assign(evals, evals + m);
     st->ghat.resize(m);
     // ghat = V^T g through the row form: rows of Vt are the eigenvectors
@@ -261,15 +143,9 @@ extern "C" int sella_stepper_create(sella_ctx* c, int kind, sella_mat hV, sella_
     return SELLA_OK;
 }
 
-extern "C" int sella_stepper_get_s(sella_stepper* st, double alpha, double* s_out, double* dsda_out) {
-    if (!st || !s_out || !dsda_out) return SELLA_E_INVALID;
-    sella_ctx* c = st->c;
+// (shat, dshat) of one trial alpha in the eigenbasis — O(m) host arithmetic
+static void eval_hat(const sella_stepper* st, double alpha, double* shat, double* dshat) {
     const int m = st->m, o = st->order;
-    const auto t0 = std::chrono::steady_clock::now();
-    const long sw0 = g_sweeps;
-    std::vector<double> sh(2 * (size_t)m, 0.0);     // [shat | dshat]
-    double* shat = sh.data();
-    double* dshat = sh.data() + m;
     const double* lam = st->lam.data();
     const double* gh = st->ghat.data();
     if (st->kind == SELLA_STEP_QN) {                                        // stepper.py:82-96
@@ -280,12 +156,32 @@ extern "C" int sella_stepper_get_s(sella_stepper* st, double alpha, double* s_ou
             shat[i] = -sp;
             dshat[i] = sp / den;
         }
+    } else if (st->kind == SELLA_STEP_QN_IRC) {                             // stepper.py:99-111
+        const double* dh = st->d1hat.data();
+        for (int i = 0; i < m; ++i) {
+            const double den = fabs(lam[i]) + alpha;
+            const double sp = -(gh[i] + alpha * dh[i]) / den;
+            shat[i] = sp;
+            dshat[i] = -(sp + dh[i]) / den;
+        }
     } else if (st->kind == SELLA_STEP_RFO) {
-        rfo_block(m, lam, gh, o, alpha, shat, dshat);
+        sella::rfo_block(m, lam, gh, o, alpha, shat, dshat);
     } else {                                                                // P-RFO, stepper.py:163-185
-        rfo_block(o, lam, gh, o, alpha, shat, dshat);                       // max block: top root
-        rfo_block(m - o, lam + o, gh + o, 0, alpha, shat + o, dshat + o);   // min block: lowest root
+        sella::rfo_block(o, lam, gh, o, alpha, shat, dshat);                       // max block: top root
+        sella::rfo_block(m - o, lam + o, gh + o, 0, alpha, shat + o, dshat + o);   // min block: lowest root
     }
+}
+
+extern "C" int sella_stepper_get_s(sella_stepper* st, double alpha, double* s_out, double* dsda_out) {
+    if (!st || !s_out || !dsda_out) return SELLA_E_INVALID;
+    sella_ctx* c = st->c;
+    const int m = st->m;
+    const auto t0 = std::chrono::steady_clock::now();
+    const long sw0 = bordered::g_sweeps;
+    std::vector<double> sh(2 * (size_t)m, 0.0);     // [shat | dshat]
+    double* shat = sh.data();
+    double* dshat = sh.data() + m;
+    eval_hat(st, alpha, shat, dshat);
     const auto t1 = std::chrono::steady_clock::now();
     struct Acc {
         sella_stepper* st; std::chrono::steady_clock::time_point a, b; long sw;
@@ -295,7 +191,7 @@ extern "C" int sella_stepper_get_s(sella_stepper* st, double alpha, double* s_ou
             st->calls += 1;
             st->sweeps += sw;
         }
-    } acc{st, t0, t1, g_sweeps - sw0};
+    } acc{st, t0, t1, bordered::g_sweeps - sw0};
     Mat* V = mat_get(c, st->V);
     if (!V) return SELLA_E_INVALID;
     const int nout = st->nout;
@@ -327,6 +223,272 @@ extern "C" int sella_stepper_get_s(sella_stepper* st, double alpha, double* s_ou
         HIPCHK(hipMemcpyAsync(dsda_out, dy + ldy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
+    return SELLA_OK;
+}
+
+extern "C" int sella_stepper_set_d1hat(sella_stepper* st, const double* d1hat, int m) {
+    if (!st || !d1hat || m != st->m) {
+        set_error("stepper: d1hat must have %d entries", st ? st->m : -1);
+        return SELLA_E_INVALID;
+    }
+    st->d1hat.assign(d1hat, d1hat + m);
+    return SELLA_OK;
+}
+
+namespace sella {
+namespace {
+
+// Constraint measure of the total step and its derivative along the family, in ONE workgroup:
+//   stot = s + scons (written back to `stot`),  out[0] = val, out[1] = dval.
+//   cons 0: |stot|, dsda.stot / |stot|;   cons 3: the same for (stot + d1) * w and dsda * w;
+//   cons 1: atom with the largest |stot_a|: (|stot_a|, dsda_a.stot_a / |stot_a|);
+//   cons 2: component with the largest |stot_i w_i|: (that value, sign(stot_i) dsda_i w_i).
+// Ties resolve to the lowest index (np.argmax).  val is clamped at 1e-12 in the denominators like the reference.
+__global__ __launch_bounds__(1024) void rs_cons_kernel(int cons, int nout, const double* s_in, const double* dsda_in,
+                                                       const double* __restrict__ scons, const double* __restrict__ w,
+                                                       const double* __restrict__ d1, double* stot, double* out,
+                                                       const int* __restrict__ sel, int m, double* sfull, double* dfull) {
+    __shared__ double r1[16], r2[16];
+    __shared__ int ri[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* s = s_in;
+    const double* dsda = dsda_in;
+    if (sel != nullptr) {
+        // the family works in the subspace of the free coordinates (basis = columns of the identity): scatter
+        // (s, ds/dalpha) into the full space first, zeros elsewhere
+        for (int i = tid; i < nout; i += 1024) { sfull[i] = 0.0; dfull[i] = 0.0; }
+        __syncthreads();
+        for (int i = tid; i < m; i += 1024) { sfull[sel[i]] = s_in[i]; dfull[sel[i]] = dsda_in[i]; }
+        __syncthreads();
+        s = sfull;
+        dsda = dfull;
+    }
+    if (cons == 0 || cons == 3) {
+        double a = 0.0, b = 0.0;
+        for (int i = tid; i < nout; i += 1024) {
+            const double st = s[i] + (scons ? scons[i] : 0.0);
+            stot[i] = st;
+            double x = st, d = dsda[i];
+            if (cons == 3) { x = (st + d1[i]) * w[i]; d *= w[i]; }
+            a += x * x;
+            b += d * x;
+        }
+        a = wave_sum64(a);
+        b = wave_sum64(b);
+        if (lane == 0) { r1[wave] = a; r2[wave] = b; }
+        __syncthreads();
+        if (tid == 0) {
+            double A = 0.0, B = 0.0;
+            for (int q = 0; q < 16; ++q) { A += r1[q]; B += r2[q]; }
+            const double val = sqrt(A);
+            out[0] = val;
+            out[1] = B / (val > 1e-12 ? val : 1e-12);
+        }
+        return;
+    }
+    // argmax kinds: every thread scans its groups, keeps (value, index, derivative numerator)
+    double best = -1.0, bd = 0.0;
+    int bi = 0x7fffffff;
+    if (cons == 1) {
+        const int natoms = nout / 3;
+        for (int a = tid; a < natoms; a += 1024) {
+            double n2 = 0.0, dd = 0.0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int i = 3 * a + q;
+                const double st = s[i] + (scons ? scons[i] : 0.0);
+                stot[i] = st;
+                n2 += st * st;
+                dd += dsda[i] * st;
+            }
+            const double v = sqrt(n2);
+            if (v > best) { best = v; bi = a; bd = dd; }
+        }
+    } else {
+        for (int i = tid; i < nout; i += 1024) {
+            const double st = s[i] + (scons ? scons[i] : 0.0);
+            stot[i] = st;
+            const double v = fabs(st * w[i]);
+            if (v > best) { best = v; bi = i; bd = (st >= 0.0 ? 1.0 : -1.0) * dsda[i] * w[i]; }
+        }
+    }
+    // wave reduction by shuffles (64 lanes), then across the 16 waves; lower index wins ties
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const double od = __shfl_xor(bd, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bd = od; bi = oi; }
+    }
+    if (lane == 0) { r1[wave] = best; r2[wave] = bd; ri[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int q = 1; q < 16; ++q)
+            if (r1[q] > best || (r1[q] == best && ri[q] < bi)) { best = r1[q]; bd = r2[q]; bi = ri[q]; }
+        out[0] = best;
+        out[1] = (cons == 1) ? bd / (best > 1e-12 ? best : 1e-12) : bd;
+    }
+}
+
+}  // namespace
+}  // namespace sella
+
+extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, const double* scons, const double* w,
+                                     const double* d1, double alpha0, double alphamin, double alphamax, double slope,
+                                     int newton_safe, int orthonormal, double tol, int maxiter, const int* sel,
+                                     int nfull, double* s_out, double* val_out, double* alphas, int* nalpha) {
+    if (!st || !s_out || !val_out || cons < 0 || cons > 3 || maxiter < 0) {
+        set_error("restricted_step: invalid arguments");
+        return SELLA_E_INVALID;
+    }
+    if ((cons >= 2 && !w) || (cons == 3 && !d1)) {
+        set_error("restricted_step: constraint kind %d needs weights%s", cons, cons == 3 ? " and d1" : "");
+        return SELLA_E_INVALID;
+    }
+    if (st->kind == SELLA_STEP_QN_IRC && (int)st->d1hat.size() != st->m) {
+        set_error("restricted_step: the IRC family needs sella_stepper_set_d1hat first");
+        return SELLA_E_INVALID;
+    }
+    sella_ctx* c = st->c;
+    Mat* V = mat_get(c, st->V);
+    if (!V) return SELLA_E_INVALID;
+    const int m = st->m;
+    if (sel && (st->nout != m || nfull < m)) { set_error("restricted_step: a selection needs a square family and nfull >= m"); return SELLA_E_INVALID; }
+    const int nfam = st->nout;                         // rows of the family's eigenvector matrix
+    const int nout = sel ? nfull : nfam;               // dimension of the step handed back
+    if (cons == 1 && nout % 3 != 0) { set_error("restricted_step: per-atom measure needs 3 N components"); return SELLA_E_INVALID; }
+    const int ldx = round_up(m, 8), ldy = round_up(std::max(nout, nfam), 8);
+    double *dx, *dy, *dv;
+    SCHK(scratch_get(c, SCR_STEP0, (size_t)2 * std::max(ldx, ldy) * sizeof(double), &dx));
+    SCHK(scratch_get(c, SCR_STEP1, (size_t)2 * std::max(ldx, ldy) * sizeof(double), &dy));
+    SCHK(scratch_get(c, SCR_QR0, (size_t)7 * ldy * sizeof(double), &dv));     // scons | w | d1 | stot | sfull | dfull | sel
+    double* dscons = scons ? dv : nullptr;
+    double* dw = w ? dv + ldy : nullptr;
+    double* dd1 = d1 ? dv + 2 * (size_t)ldy : nullptr;
+    double* dstot = dv + 3 * (size_t)ldy;
+    double* dsfull = dv + 4 * (size_t)ldy;
+    double* ddfull = dv + 5 * (size_t)ldy;
+    int* dsel = sel ? reinterpret_cast<int*>(dv + 6 * (size_t)ldy) : nullptr;
+    if (sel) HIPCHK(hipMemcpyAsync(dsel, sel, (size_t)m * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    const bool eig_only = orthonormal && cons == 0;
+    std::vector<double> chat;                 // V^T scons (eigenbasis measure)
+    double scons2 = 0.0;
+    if (scons) {
+        for (int i = 0; i < nout; ++i) scons2 += scons[i] * scons[i];
+        HIPCHK(hipMemcpyAsync(dscons, scons, (size_t)nout * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    if (w) HIPCHK(hipMemcpyAsync(dw, w, (size_t)nout * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (d1) HIPCHK(hipMemcpyAsync(dd1, d1, (size_t)nout * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (eig_only && scons && scons2 > 0.0) {
+        Mat* Vt = mat_get(c, st->Vt);
+        if (!Vt) return SELLA_E_INVALID;
+        chat.resize(m);
+        const double* dsrc = dscons;
+        if (sel) {                                      // the family sees the free components of the correction only
+            std::vector<double> sc(m);
+            for (int i = 0; i < m; ++i) sc[i] = scons[sel[i]];
+            SCHK(upload_panel(c, sc.data(), m, 1, dsfull, ldy));
+            dsrc = dsfull;
+        }
+        SCHK(launch_gemv_rows(c, Vt->d, m, nfam, Vt->ld, dsrc, ldy, 1, dx, ldx, GemvEpi()));
+        SCHK(download_panel(c, dx, ldx, m, 1, chat.data()));
+    }
+    const bool pinned = 2 * ldx <= 16384;
+    double* hin = c->hscal + DS_STAGE;
+    double* hres = c->hscal + DS_MISC + 64;            // val, dval land here (written by the kernel, pinned host memory)
+    std::vector<double> sh(2 * (size_t)m, 0.0);
+    double* shat = sh.data();
+    double* dshat = sh.data() + m;
+    int ntrial = 0;
+    // one trial alpha -> (val, dval); leaves [shat | dshat] on the host and (unless eig_only) stot on the device
+    auto evaluate = [&](double alpha, double* val, double* dval) -> int {
+        eval_hat(st, alpha, shat, dshat);
+        if (alphas && ntrial <= maxiter) alphas[ntrial] = alpha;
+        ++ntrial;
+        if (eig_only) {
+            double ss = scons2, sd = 0.0;
+            for (int i = 0; i < m; ++i) {
+                const double ci = chat.empty() ? 0.0 : chat[i];
+                ss += shat[i] * (shat[i] + 2.0 * ci);
+                sd += dshat[i] * (shat[i] + ci);
+            }
+            *val = sqrt(ss > 0.0 ? ss : 0.0);
+            *dval = sd / (*val > 1e-12 ? *val : 1e-12);
+            return SELLA_OK;
+        }
+        if (pinned) {
+            memcpy(hin, shat, (size_t)m * sizeof(double));
+            memcpy(hin + ldx, dshat, (size_t)m * sizeof(double));
+            HIPCHK(hipMemcpyAsync(dx, hin, (size_t)(ldx + m) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIPCHK(hipMemcpyAsync(dx, shat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(dx + ldx, dshat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        SCHK(launch_gemv_rows(c, V->d, nfam, m, V->ld, dx, ldx, 2, dy, ldy, GemvEpi()));
+        hipLaunchKernelGGL(rs_cons_kernel, dim3(1), dim3(1024), 0, c->stream, cons, nout, dy, dy + ldy, dscons, dw, dd1, dstot,
+                           hres, dsel, m, dsfull, ddfull);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *val = hres[0];
+        *dval = hres[1];
+        return SELLA_OK;
+    };
+    // ---- restricted_step.py:78-120 --------------------------------------------------------------------------------
+    double alpha = alpha0, val = 0.0, dval = 0.0;
+    SCHK(evaluate(alpha, &val, &dval));
+    bool inside = val < delta;
+    if (!inside) {
+        double err = val - delta, lower = alphamin, upper = alphamax;
+        bool converged = false;
+        for (int niter = 0; niter < maxiter; ++niter) {
+            if (fabs(err) <= tol) { converged = true; break; }
+            if (nextafter(lower, upper) >= upper) { converged = true; break; }
+            if (err * slope > 0.0) upper = alpha; else lower = alpha;
+            const double newton = alpha - err / dval;
+            const bool bisect = (newton != newton) || newton <= lower || newton >= upper || (niter > 4 && !newton_safe);
+            if (bisect) {
+                const double mid = 0.5 * (lower + upper);
+                if (std::isinf(mid)) alpha = alpha + std::max(1.0, 0.5 * alpha) * (mid > 0.0 ? 1.0 : -1.0);
+                else alpha = mid;
+            } else {
+                alpha = newton;
+            }
+            SCHK(evaluate(alpha, &val, &dval));
+            err = val - delta;
+        }
+        if (!converged) {
+            set_error("Restricted step failed to converge!");
+            return SELLA_E_NOCONV;
+        }
+    }
+    // ---- the step at the final alpha ------------------------------------------------------------------------------
+    if (eig_only) {
+        if (pinned) {
+            memcpy(hin, shat, (size_t)m * sizeof(double));
+            HIPCHK(hipMemcpyAsync(dx, hin, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIPCHK(hipMemcpyAsync(dx, shat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        SCHK(launch_gemv_rows(c, V->d, nfam, m, V->ld, dx, ldx, 1, dy, ldy, GemvEpi()));
+        if (sel) {
+            std::vector<double> sp(nfam);
+            HIPCHK(hipMemcpyAsync(sp.data(), dy, (size_t)nfam * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            for (int i = 0; i < nout; ++i) s_out[i] = 0.0;
+            for (int i = 0; i < m; ++i) s_out[sel[i]] = sp[i];
+        } else {
+            HIPCHK(hipMemcpyAsync(s_out, dy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        if (scons)
+            for (int i = 0; i < nout; ++i) s_out[i] += scons[i];
+    } else {
+        HIPCHK(hipMemcpyAsync(s_out, dstot, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    *val_out = inside ? val : delta;
+    if (nalpha) *nalpha = ntrial;
+    st->calls += ntrial;
     return SELLA_OK;
 }
 

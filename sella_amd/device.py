@@ -443,7 +443,8 @@ class Context:
         return dict(launches=n.value, ms=ms.value, bytes=b.value, flops=f.value)
 
 
-STEPPER_KINDS = {'qn': 0, 'rfo': 1, 'prfo': 2}
+STEPPER_KINDS = {'qn': 0, 'rfo': 1, 'prfo': 2, 'qn_irc': 3}
+CONSTRAINT_KINDS = {'tr': 0, 'ras': 1, 'mis': 2, 'sphere': 3}
 
 
 class DeviceStepper:
@@ -468,6 +469,31 @@ class DeviceStepper:
         dsda = np.empty(self.nout)
         check(_lib.lib().sella_stepper_get_s(self._h, float(alpha), ptr(s), ptr(dsda)))
         return s, dsda
+
+    def set_d1hat(self, d1hat):
+        """V^T d1 of the IRC quasi-Newton family (m entries, eigenbasis of the projected Hessian)."""
+        d1hat = as_f64(d1hat)
+        check(_lib.lib().sella_stepper_set_d1hat(self._h, ptr(d1hat), len(d1hat)))
+
+    def restricted_step(self, cons, delta, alpha0, alphamin, alphamax, slope, newton_safe, tol, maxiter=1000,
+                        scons=None, w=None, d1=None, orthonormal=False, sel=None, nfull=0):
+        """The whole trust-radius root find in one call (`sella_restricted_step`):
+        returns (s_total (nout,), val, alphas tried)."""
+        sc = as_f64(scons) if scons is not None else None
+        ww = as_f64(w) if w is not None else None
+        dd = as_f64(d1) if d1 is not None else None
+        isel = np.ascontiguousarray(sel, dtype=np.int32) if sel is not None else None
+        s = np.empty(int(nfull) if sel is not None else self.nout)
+        val = c_double(0.0)
+        alphas = np.empty(int(maxiter) + 1)
+        na = c_int(0)
+        big = 1.7976931348623157e308
+        check(_lib.lib().sella_restricted_step(
+            self._h, CONSTRAINT_KINDS[cons], float(delta), ptr(sc), ptr(ww), ptr(dd), float(alpha0),
+            float(max(alphamin, -big)), float(alphamax), float(slope), int(bool(newton_safe)), int(bool(orthonormal)),
+            float(tol), int(maxiter), isel.ctypes.data_as(c_void_p) if isel is not None else None, int(nfull),
+            ptr(s), byref(val), ptr(alphas), byref(na)))
+        return s, val.value, alphas[:min(na.value, len(alphas))].copy()
 
 
 _default = None

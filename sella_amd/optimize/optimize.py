@@ -44,47 +44,41 @@ class Sella(Optimizer):
             raise NotImplementedError('allow_fragments needs the TRIC translation / rotation coordinates, which '
                                       'are outside the saddle-point scope (DESIGN.md section 7)')
         # the reference integrates the exact geodesic unless told otherwise (optimize.py:125)
-        self.exact_geodesic = True if exact_geodesic is None else bool(exact_geodesic)
-        default = _default_kwargs['minimum' if order == 0 else 'saddle']
+        self.exact_geodesic = exact_geodesic is None or bool(exact_geodesic)
         self.optimize_cell = False
-        self.peskwargs = kwargs.copy()
-        self.user_internal = internal
-        self.initialize_pes(atoms, trajectory, order, eta, constraints, v0, internal,
-                            hessian_function, **kwargs)
-        if rs is None:
-            rs = 'mis' if internal else 'ras'                                    # :178-179
-        self.rs = get_restricted_step(rs)
-        Optimizer.__init__(self, atoms, restart=restart, logfile=logfile, trajectory=None,
-                           master=master)
-        if delta0 is None:
-            delta0 = default['delta0']
-        if rs in ['mis', 'ras']:
-            self.delta = delta0
-        else:
-            self.delta = delta0 * self.pes.get_Ufree().shape[1]                 # :183-186
-        pick = lambda v, k: v if v is not None else default[k]                  # noqa: E731
-        self.sigma_inc = pick(sigma_inc, 'sigma_inc')
-        self.sigma_dec = pick(sigma_dec, 'sigma_dec')
-        self.rho_inc = pick(rho_inc, 'rho_inc')
-        self.rho_dec = pick(rho_dec, 'rho_dec')
-        self.method = pick(method, 'method')
-        self.eig = pick(eig, 'eig')
-        self.ord = order
-        self.eta = eta
-        self.delta_min = self.eta
-        self.constraints_tol = constraints_tol
-        self.diagkwargs = dict(gamma=gamma, threepoint=threepoint)
-        self.rho = 1.
-        if self.ord != 0 and not self.eig:
+        self.user_internal, self.peskwargs = internal, dict(kwargs)
+        self.initialize_pes(atoms, trajectory, order, eta, constraints, v0, internal, hessian_function, **kwargs)
+        Optimizer.__init__(self, atoms, restart=restart, logfile=logfile, trajectory=None, master=master)
+
+        # tunables: explicit keyword > table for the kind of stationary point sought (optimize.py:20-39, 120-123)
+        given = dict(delta0=delta0, sigma_inc=sigma_inc, sigma_dec=sigma_dec, rho_inc=rho_inc, rho_dec=rho_dec,
+                     method=method, eig=eig)
+        table = _default_kwargs['minimum' if order == 0 else 'saddle']
+        chosen = {key: (table[key] if val is None else val) for key, val in given.items()}
+        for key in ('sigma_inc', 'sigma_dec', 'rho_inc', 'rho_dec', 'method', 'eig'):
+            setattr(self, key, chosen[key])
+        self.ord, self.eta, self.constraints_tol = order, eta, constraints_tol
+        if order != 0 and not self.eig:
             warnings.warn("Saddle point optimizations with eig=False will most likely fail!\n"
                           " Proceeding anyway, but you shouldn't be optimistic.")
-        self.initialized = False
-        self.xi = 1.
+
+        # trust region: measure (:174-179) and initial radius — per degree of freedom for the Euclidean measure,
+        # per atom / per coordinate for the max-norm ones (:183-186); never below eta (:198)
+        rs_name = rs if rs is not None else ('mis' if internal else 'ras')
+        self.rs = get_restricted_step(rs_name)
+        per_dof = rs_name not in ('mis', 'ras')
+        self.delta = chosen['delta0'] * (self.pes.get_Ufree().shape[1] if per_dof else 1)
+        self.delta_min = eta
+        self.rho, self.xi = 1., 1.
+
+        # curvature schedule (:187-197)
+        self.diagkwargs = {'gamma': gamma, 'threepoint': threepoint}
         self.nsteps_per_diag = nsteps_per_diag
+        self.diag_every_n = diag_every_n if diag_every_n is not None else np.inf
+        self.nsteps_since_diag = 0
+        self.initialized = False
         self.fmax = None
         self._last_converged = None
-        self.nsteps_since_diag = 0
-        self.diag_every_n = np.inf if diag_every_n is None else diag_every_n
 
     def initialize_pes(self, atoms, trajectory=None, order=1, eta=1e-4, constraints=None, v0=None,
                        internal=False, hessian_function=None, **kwargs):
@@ -133,84 +127,122 @@ class Sella(Optimizer):
         self.initialized = bool(z['initialized'])
         self.pes.first_diag = bool(z['first_diag'])
 
-    def _predict_step(self):                                                     # :317-357
+    # ---- one optimizer step ---------------------------------------------------------------------------------------
+    # optimize.py:317-440 as three separable decisions — which step, whether to re-diagonalise, how the trust
+    # radius reacts — around the single device call that solves the restricted step.
+    def _first_use(self):
+        """Initial gradient and curvature information (optimize.py:318-326)."""
+        self.pes.get_g()
+        if self.eig:
+            if self.pes.hessian_function is not None:
+                self.pes.calculate_hessian()
+            else:
+                self.pes.diag(**self.diagkwargs)
+            self.nsteps_since_diag = -1
+        self.initialized = True
+
+    def _solve_step(self):
+        """(s, smag) of the restricted step at the current geometry — `sella_restricted_step` behind the rs class."""
+        return self.rs(self.pes, self.ord, self.delta, method=self.method).get_s()
+
+    def _predict_step(self):
         if not self.initialized:
-            self.pes.get_g()
-            if self.eig:
-                if self.pes.hessian_function is not None:
-                    self.pes.calculate_hessian()
-                else:
-                    self.pes.diag(**self.diagkwargs)
-                self.nsteps_since_diag = -1
-            self.initialized = True
-        self.pes.cons.disable_satisfied_inequalities()
-        self.pes._update_basis()
-        self.pes.save()
-        x0 = self.pes.get_x()
-        if self.pes.cons.has_inequalities():
-            all_valid = False
-            while not all_valid:
-                s, smag = self.rs(self.pes, self.ord, self.delta, method=self.method).get_s()
-                self.pes.set_x(x0 + s)
-                all_valid = self.pes.cons.validate_inequalities()
-                self.pes._update_basis()
-                self.pes.restore()
-            self.pes._update_basis()
-        else:
-            s, smag = self.rs(self.pes, self.ord, self.delta, method=self.method).get_s()
+            self._first_use()
+        pes = self.pes
+        pes.cons.disable_satisfied_inequalities()
+        pes._update_basis()
+        pes.save()
+        if not pes.cons.has_inequalities():
+            return self._solve_step()
+        # inequality constraints: re-solve until the trial geometry violates none that was switched off (:339-350)
+        origin = pes.get_x()
+        while True:
+            s, smag = self._solve_step()
+            pes.set_x(origin + s)
+            feasible = pes.cons.validate_inequalities()
+            pes._update_basis()
+            pes.restore()
+            if feasible:
+                break
+        pes._update_basis()
         return s, smag
 
-    def step(self):                                                              # :359-434
-        s, smag = self._predict_step()
+    def _wants_diagonalisation(self):
+        """The re-diagonalisation schedule (optimize.py:363-378): always after `diag_every_n` steps; after
+        `nsteps_per_diag` steps only if the approximate Hessian has lost the `order` negative modes."""
         if self.nsteps_since_diag >= self.diag_every_n:
-            ev = True
-        elif self.eig and self.nsteps_since_diag >= self.nsteps_per_diag:
-            if self.pes.H.evals is None:
-                ev = True
-            else:
-                Unred = self.pes.get_Unred()
-                ev = bool((self.pes.get_HL_projected(Unred).evals[:self.ord] > 0).any())
-        else:
-            ev = False
-        if ev:
-            self.nsteps_since_diag = 0
-        else:
-            self.nsteps_since_diag += 1
-        rho = self.pes.kick(s, ev, **self.diagkwargs)
-        if rho is not None:
-            if rho < 1. / self.rho_dec or rho > self.rho_dec:
-                self.delta = max(smag * self.sigma_dec, self.delta_min)
-            elif 1. / self.rho_inc < rho < self.rho_inc:
-                self.delta = max(self.sigma_inc * smag, self.delta)
-            self.rho = rho
-        else:
-            self.rho = 1.
+            return True
+        if not (self.eig and self.nsteps_since_diag >= self.nsteps_per_diag):
+            return False
+        if self.pes.H.evals is None:
+            return True
+        lowest = self.pes.get_HL_projected(self.pes.get_Unred()).evals[:self.ord]
+        return bool(np.any(lowest > 0))
 
-    def gradient_converged(self, gradient=None):
-        return self.converged()
+    def _adapt_radius(self, rho, smag):
+        """Trust radius from the ratio of actual to predicted change (optimize.py:413-434)."""
+        if rho is None:
+            self.rho = 1.
+            return
+        if not (1. / self.rho_dec <= rho <= self.rho_dec):
+            self.delta = max(smag * self.sigma_dec, self.delta_min)
+        elif 1. / self.rho_inc < rho < self.rho_inc:
+            self.delta = max(self.sigma_inc * smag, self.delta)
+        self.rho = rho
+
+    def _rebuild_if_internals_degraded(self):
+        """optimize.py:384-410: a step that drives an internal coordinate into a singular region (an angle near
+        0 / pi, `check_for_bad_internals`) invalidates the coordinate system: build a fresh PES — new internals
+        from the current geometry unless the user supplied them, new approximate Hessian, new initial
+        diagonalisation — and skip this step's trust-radius update."""
+        if not self.internal:
+            return False
+        pes = self.pes
+        stale = bool(getattr(pes, 'bad_int', None)) or bool(pes.int.check_for_bad_internals())
+        if not stale:
+            return False
+        self.initialize_pes(pes.atoms, trajectory=pes.traj, order=self.ord, eta=pes.eta, constraints=self.constraints,
+                            v0=None, internal=self.user_internal, hessian_function=pes.hessian_function,
+                            **self.peskwargs)
+        self.initialized = False
+        self.rho = 1
+        return True
+
+    def step(self):
+        s, smag = self._predict_step()
+        rediag = self._wants_diagonalisation()
+        self.nsteps_since_diag = 0 if rediag else self.nsteps_since_diag + 1
+        rho = self.pes.kick(s, rediag, **self.diagkwargs)
+        if self._rebuild_if_internals_degraded():
+            return
+        self._adapt_radius(rho, smag)
+
+    # ---- ASE Optimizer protocol -------------------------------------------------------------------------------------
+    def _verdict(self):
+        """(converged, fmax, cmax) at the threshold of the current run (0.05 before `run` set one)."""
+        self._last_converged = self.pes.converged(0.05 if self.fmax is None else self.fmax)
+        return self._last_converged
 
     def converged(self, forces=None):
-        fmax = self.fmax if self.fmax is not None else 0.05
-        result = self.pes.converged(fmax)
-        self._last_converged = result
-        return result[0]
+        return self._verdict()[0]
+
+    gradient_converged = converged            # newer ASE releases ask under this name
 
     def log(self, forces=None):
-        if self.logfile is None:
+        """One line per step: Step Time Energy fmax cmax rtrust rho (optimize.py:457-502)."""
+        out = self.logfile
+        if out is None:
             return
-        result = self._last_converged
-        if result is None or len(result) != 3:
-            result = self.pes.converged(self.fmax if self.fmax is not None else 0.05)
-        _, fmax, cmax = result
-        e = self.pes.get_f()
-        T = strftime("%H:%M:%S", localtime())
-        name = self.__class__.__name__
+        verdict = self._last_converged
+        if verdict is None or len(verdict) != 3:
+            verdict = self._verdict()
+        label = type(self).__name__
         if self.nsteps == 0:
-            self.logfile.write(" " * len(name) + "{:>4s} {:>8s} {:>15s} {:>12s} {:>12s} {:>12s} {:>12s}\n"
-                               .format("Step", "Time", "Energy", "fmax", "cmax", "rtrust", "rho"))
-        self.logfile.write("{} {:>3d} {:>8s} {:>15.6f} {:>12.4f} {:>12.4f} {:>12.4f} {:>12.4f}\n"
-                           .format(name, self.nsteps, T, e, fmax, cmax, self.delta, self.rho))
-        try:
-            self.logfile.flush()
-        except (AttributeError, TypeError):
-            pass
+            heads = ("Step", "Time", "Energy", "fmax", "cmax", "rtrust", "rho")
+            out.write(" " * len(label) + "{:>4s} {:>8s} {:>15s} {:>12s} {:>12s} {:>12s} {:>12s}\n".format(*heads))
+        out.write("{} {:>3d} {:>8s} {:>15.6f} {:>12.4f} {:>12.4f} {:>12.4f} {:>12.4f}\n".format(
+            label, self.nsteps, strftime("%H:%M:%S", localtime()), self.pes.get_f(), verdict[1], verdict[2],
+            self.delta, self.rho))
+        flush = getattr(out, 'flush', None)
+        if callable(flush):
+            flush()

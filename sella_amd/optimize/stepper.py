@@ -84,6 +84,14 @@ class BaseStepper:
         ds_full[self._sel] = dsda
         return s_full, ds_full
 
+    def solve_radius(self, measure, delta, tol, maxiter, scons=None, orthonormal=True, w=None, d1=None):
+        """The restricted-step root find over this family in one device call (`sella_restricted_step`):
+        -> (total step, reported measure, trial alphas).  Same alpha schedule as restricted_step.py:78-120."""
+        sel = self._sel
+        return self._dev.restricted_step(measure, delta, self.alpha0, self.alphamin, self.alphamax, self.slope,
+                                         self.newton_safe, tol, maxiter, scons=scons, w=w, d1=d1,
+                                         orthonormal=orthonormal, sel=sel, nfull=self._nfull if sel is not None else 0)
+
 
 class NaiveStepper(BaseStepper):
     synonyms = []
@@ -114,33 +122,16 @@ class QuasiNewton(BaseStepper):
 class QuasiNewtonIRC(QuasiNewton):
     """Quasi-Newton step family of the IRC inner loop (stepper.py:99-111):
     s(alpha) = -V (V^T g + alpha V^T d1) / (|lam| + alpha), d1 given in the projected space.
-    The O(m) arithmetic in the eigenbasis stays on the host; the two products with the (projection-composed)
-    eigenvector matrix are one 2-column panel product on the device."""
+    Evaluated by the same device family object as the others (kind `qn_irc`); only V^T d1 is formed here."""
     synonyms = []
+    _kind = 'qn_irc'
 
     def _stepper_init(self) -> None:
-        ctx = get_context()
-        evals, V, Vt = self._device_eig()
-        self.L = np.abs(evals)
-        self._Veig = V
-        self.Vg_full = None
-        U = self.U
-        if U is not None and is_identity(U):
-            U = None
-        if U is not None:
-            VU = ctx.zeros(U.shape[0], V.shape[1])
-            ctx.gemm(ctx.resident(U), V, VU)
-            self._Vout = VU
-        else:
-            self._Vout = V
-        self.Vg = ctx.tmatmul(self._Vout, self.g)            # V^T (U^T g)
-        self.Vd1 = ctx.tmatmul(V, self.d1)                   # d1 lives in the projected space already
-
-    def get_s(self, alpha: float) -> Tuple[np.ndarray, np.ndarray]:
-        denom = self.L + alpha
-        sproj = -(self.Vg + alpha * self.Vd1) / denom
-        out = get_context().symm_mm(self._Vout, np.column_stack((sproj, -(sproj + self.Vd1) / denom)))
-        return out[:, 0].copy(), out[:, 1].copy()
+        if self.d1 is None:
+            raise ValueError('QuasiNewtonIRC needs the accumulated displacement d1 (projected space)')
+        Veig = self._device_eig()[1]                                    # eigenvectors of the projected Hessian
+        BaseStepper._stepper_init(self)
+        self._dev.set_d1hat(get_context().tmatmul(Veig, np.asarray(self.d1, dtype=np.float64)))
 
 
 class RationalFunctionOptimization(BaseStepper):

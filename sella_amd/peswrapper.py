@@ -795,8 +795,7 @@ class InternalPES(PES):
         return True
 
     def kick(self, dx, diag=False, **diag_kwargs):
-        ratio = PES.kick(self, dx, diag=diag, **diag_kwargs)
-        if self.bad_int is not None:
-            raise RuntimeError('an angle became (nearly) linear: regenerating the internal coordinates with dummy '
-                               'atoms (peswrapper.py:1126-1172) is not part of this build')
-        return ratio
+        # A geodesic that runs into a degenerate internal coordinate (an angle close to 0 or pi) stops there:
+        # `bad_int` stays set and the caller — `Sella.step`, optimize.py:384-410 — rebuilds the coordinate system
+        # from the geometry reached.
+        return PES.kick(self, dx, diag=diag, **diag_kwargs)

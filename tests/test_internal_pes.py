@@ -325,3 +325,27 @@ def test_internal_space_quantities_match_dense_formulas(ctx):
     np.testing.assert_allclose(Ufree.T @ Ucons, 0, atol=1e-9)
     np.testing.assert_allclose(Unred @ Unred.T, P, atol=1e-8)
     assert Ucons.shape[1] == 1 and Ufree.shape[1] == Unred.shape[1] - 1
+
+
+def test_bad_internals_rebuild_the_pes(ctx, monkeypatch):
+    """optimize.py:384-410: when a step leaves an internal coordinate degenerate, `Sella.step` builds a fresh PES
+    (new internals from the geometry reached, new Hessian, initial diagonalisation pending), resets rho and skips
+    the trust-radius update; the search then continues to the same stationary point."""
+    from sella_amd import Sella
+    from sella_amd.internal import InternalCoordinates
+    atoms = chain(5, seed=3)
+    opt = Sella(atoms, order=0, internal=True, logfile=None, exact_geodesic=False)
+    opt.run(fmax=1e-9, steps=2)
+    first_pes, delta = opt.pes, opt.delta
+    calls = {'n': 0}
+    real = InternalCoordinates.check_for_bad_internals
+
+    def once_bad(self):
+        calls['n'] += 1
+        return {'bonds': [], 'angles': ['forced']} if calls['n'] == 1 else real(self)
+    monkeypatch.setattr(InternalCoordinates, 'check_for_bad_internals', once_bad)
+    opt.step()
+    assert opt.pes is not first_pes and not opt.initialized and opt.rho == 1 and opt.delta == delta
+    monkeypatch.setattr(InternalCoordinates, 'check_for_bad_internals', real)
+    assert opt.run(fmax=1e-3, steps=200)
+    assert np.abs(atoms.get_forces()).max() < 2e-3

@@ -94,3 +94,20 @@ def test_row_sharded_block_product(tmp_path):
         np.testing.assert_allclose(r['lams'], r['exact'], atol=1e-10)
     np.testing.assert_array_equal(r0['lams'], r1['lams'])
     np.testing.assert_array_equal(r0['V'], r1['V'])
+
+
+def test_tcp_rendezvous_broadcast(tmp_path):
+    """The unique-id hand-over of sella_amd.comm (what ncclCommInitRank needs before any collective exists):
+    rank 0 -> ranks 1, 2 over TCP on MASTER_ADDR, no torch involved."""
+    port = free_port()
+    code = ("import os, sys; sys.path.insert(0, %r); from sella_amd.comm import broadcast_from_root; "
+            "r = int(os.environ['RANK']); p = broadcast_from_root(bytes(range(128)) if r == 0 else b'', r, 3); "
+            "assert p == bytes(range(128)), p; assert 'torch' not in sys.modules; print('ok', r)" % os.path.dirname(HERE))
+    procs = []
+    for r in (1, 2, 0):                       # the root comes up last: the others must retry
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE='3')
+        procs.append(subprocess.Popen([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    for p in procs:
+        out = p.communicate(timeout=120)[0]
+        assert p.returncode == 0, out

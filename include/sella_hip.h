@@ -55,7 +55,7 @@ int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
 /* integer tuning knobs (kernel variant selection for benchmarking); unknown key -> error.  Keys (defaults):
  *   gemv_rw (2) rows per wavefront of the streaming matvec | gemm_mfma (1) GEMMs on the matrix cores |
  *   gemm_tile128 (1) 128x128 GEMM tiles for large products | panel_mfma (1), panel_rows (0 = by size) the
- *   H.V block product | dav_reorth (0) re-orthonormalise V before each MGS | host_scalars (0) zero-copy scalars |
+ *   H.V block product | host_scalars (0) zero-copy scalars | rank2k_stream (1) mirror-free trailing update |
  *   eigh_nb (16) panel width, eigh_leaf (32) leaf size, eigh_wy_mfma (1) MFMA back-transformation.            */
 int sella_ctx_set_option(sella_ctx* ctx, const char* key, long value);
 

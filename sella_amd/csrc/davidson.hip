@@ -733,6 +733,19 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         }
         t_host += now() - th0;
         if (k >= kstop) break;                                            // :65-66
+        if (k >= 64) {
+            // large subspaces (converged runs: hundreds of vectors): carrying the cumulative rotation on the host is
+            // O(k^3) per iteration; apply it to the device panels instead (two k x k x n products) and restart from
+            // the identity — the panels then ARE the Ritz vectors, as in the reference (eigensolvers.py:62-64)
+            double* dWp;
+            DCHK(put_small(s, Wc.data(), k * k, 0, 0, &dWp));
+            DCHK(launch_lincomb(c, n, k, s.Vp, s.ld, k, dWp, k, nullptr, 0, 0, nullptr, 0, 0.0, s.Vq, s.ld));
+            DCHK(launch_lincomb(c, n, k, s.AVp, s.ld, k, dWp, k, nullptr, 0, 0, nullptr, 0, 0.0, s.AVq, s.ld));
+            std::swap(s.Vp, s.Vq);
+            std::swap(s.AVp, s.AVq);
+            Wc.assign((size_t)k * k, 0.0);
+            for (int a = 0; a < k; ++a) Wc[(size_t)a * k + a] = 1.0;
+        }
         if (nneg > 4000) { set_error("davidson: too many negative Ritz values (%d)", nneg); return fail(SELLA_E_UNSUPPORTED); }
 
         // ---- residual coefficients in the raw basis (:68-71) -------------------------------

@@ -1336,7 +1336,8 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
         if (mt > 0) {
             double* At = W.A + (size_t)r0 * ld + r0;
             // one fused pass (update.hip): every tile pair is read and written once
-            SCHK(launch_sym_rank2k(c, At, mt, ld, Vp + r0, Wp + r0, ld, kb, -1.0));
+            if (c->opt.rank2k_stream) SCHK(launch_rank2k_stream(c, At, mt, ld, Vp + r0, Wp + r0, ld, kb, -1.0));
+            else SCHK(launch_sym_rank2k(c, At, mt, ld, Vp + r0, Wp + r0, ld, kb, -1.0));
         }
     }
     hipLaunchKernelGGL(tridiag_tail_kernel, dim3(1), dim3(64), 0, c->stream, W.A, ld, n, dvec, evec, taus);

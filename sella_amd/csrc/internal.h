@@ -89,12 +89,12 @@ struct Options {
     long gemm_mfma = 1;      // 1: MFMA f64 16x16x4 GEMM tiles, 0: VALU register tiles
     long host_scalars = 0;   // 1: host-consumed scalars are written straight into pinned host memory (measured: no gain)
     long gemm_tile128 = 1;   // 1: 128x128 double-buffered tiles for large NN/TN products
-    long dav_reorth = 0;     // 1: re-orthonormalise V before each MGS like math.pyx:148-151
     long eigh_leaf = 32;     // leaf size of the divide-and-conquer tree
     long eigh_nb = 16;       // panel width of the blocked tridiagonalisation (tools/eigh_tune.py)
     long panel_mfma = 1;     // 1: products with more than 8 right-hand sides stream the matrix once (MFMA panel kernel)
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
+    long rank2k_stream = 1;  // 1: trailing update of the tridiagonalisation as a mirror-free MFMA stream (update.hip)
 };
 
 }  // namespace sella
@@ -238,6 +238,10 @@ int gs_orthonormalise(sella_ctx* c, const double* basis, int ldb, int k, double*
 // B <- (B + B^T)/2 + alpha * sum_a (U_a Z_a^T + Z_a U_a^T), U/Z vector-major panels with kk rows
 int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, const double* Zp,
                       int ldp, int kk, double alpha = 1.0);
+// C <- C + alpha sum_a (U_a Z_a^T + Z_a U_a^T) for an ALREADY symmetric block, as a pure stream (no mirror tile; the two
+// triangles agree to roundoff, not bitwise): the trailing update of the tridiagonalisation
+int launch_rank2k_stream(sella_ctx* c, double* C, int m, int ld, const double* Up, const double* Zp, int ldp, int kk,
+                         double alpha);
 // eigh.hip: eigendecomposition (w host ascending, Vt rows / V columns, both updated in place) of
 // B + sum_a (U_a Z_a^T + Z_a U_a^T) from that of B; *nrank1 = rank-one modifications applied
 int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const double* Up, const double* Zp,

@@ -86,6 +86,88 @@ __global__ __launch_bounds__(256) void sym_rank2k_kernel(double* __restrict__ B,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Streaming rank-2kk update of an ALREADY SYMMETRIC block (the trailing update of the tridiagonalisation,
+// eigh.hip):  C <- C + alpha (U^T Z + Z^T U)  with U, Z vector-major (kk rows).  No mirror tile is read: every
+// element is updated in place from its own row and column of the panels, so the pass is a pure stream — 16-byte
+// loads and stores along rows (a workgroup owns a 32 x 128 tile: 1 KiB contiguous per row), the 2 kk-deep products
+// on the matrix cores (v_mfma_f64_16x16x4: X = [U; Z]^T, Y = [Z; U]^T, K = 2 kk), the MFMA fragments passed
+// through LDS once to reach the row-major order of the global accesses.  The two triangles receive the same
+// products in a different summation order, i.e. equal to roundoff, not bitwise: fine for a block whose rows are
+// the only thing read afterwards; the quasi-Newton path keeps the exactly symmetric kernel above.
+// Traffic: 16 m^2 bytes (read + write once), 4 kk m^2 flop.
+// ------------------------------------------------------------------------------------------
+typedef double upd_f64x4 __attribute__((ext_vector_type(4)));
+constexpr int RS_TR = 32, RS_TC = 128;
+
+__global__ __launch_bounds__(256) void rank2k_stream_kernel(double* __restrict__ C, int m, int ld,
+                                                            const double* __restrict__ Up,
+                                                            const double* __restrict__ Zp, int ldp, int kk,
+                                                            double alpha) {
+    __shared__ double dl[RS_TR][RS_TC + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int r0 = blockIdx.y * RS_TR, c0 = blockIdx.x * RS_TC;
+    const int wr = r0 + 16 * (wave & 1);                 // this wave's 16 rows
+    const int wc = c0 + 64 * (wave >> 1);                // ... and 64 columns (4 MFMA tiles)
+    upd_f64x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = upd_f64x4{0.0, 0.0, 0.0, 0.0};
+    const int rr = (wr + li < m) ? wr + li : m - 1;
+    const int K = 2 * kk;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + lq;                           // summation index of this lane
+        const bool ok = k < K;
+        const int kc = ok ? k : 0;
+        // X[r][k] = (k < kk ? U[k][r] : Z[k - kk][r]);  Y[c][k] = (k < kk ? Z[k][c] : U[k - kk][c])
+        const double* xrow = (kc < kk) ? Up + (size_t)kc * ldp : Zp + (size_t)(kc - kk) * ldp;
+        const double* yrow = (kc < kk) ? Zp + (size_t)kc * ldp : Up + (size_t)(kc - kk) * ldp;
+        const double a = ok ? xrow[rr] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int cc = wc + 16 * t + li;
+            const double b = (ok && cc < m) ? yrow[cc] : 0.0;
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    // fragments -> LDS (C/D layout of the f64 MFMA: row = (lane >> 4) + 4 reg, col = lane & 15)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dl[16 * (wave & 1) + lq + 4 * q][64 * (wave >> 1) + 16 * t + li] = acc[t][q];
+    __syncthreads();
+    // row-major pass: thread -> (row, 16-byte piece): 64 pieces per row, 4 rows per sweep
+    const int pc = tid & 63, pr = tid >> 6;
+#pragma unroll
+    for (int s8 = 0; s8 < RS_TR; s8 += 4) {
+        const int r = r0 + s8 + pr, cidx = c0 + 2 * pc;
+        if (r < m && cidx < m) {
+            double* p = C + (size_t)r * ld + cidx;
+            const double d0 = dl[s8 + pr][2 * pc], d1 = dl[s8 + pr][2 * pc + 1];
+            if (cidx + 1 < m) {
+                double2 v = *reinterpret_cast<double2*>(p);
+                v.x += alpha * d0;
+                v.y += alpha * d1;
+                *reinterpret_cast<double2*>(p) = v;
+            } else {
+                p[0] += alpha * d0;
+            }
+        }
+    }
+}
+
+int launch_rank2k_stream(sella_ctx* c, double* C, int m, int ld, const double* Up, const double* Zp, int ldp, int kk,
+                         double alpha) {
+    if (m <= 0 || kk <= 0) return SELLA_OK;
+    if ((ld & 1) || (reinterpret_cast<uintptr_t>(C) & 15)) return launch_sym_rank2k(c, C, m, ld, Up, Zp, ldp, kk, alpha);
+    prof_begin(c, PROF_UPDATE, 16.0 * m * (double)m, 4.0 * kk * (double)m * m);
+    SELLA_LAUNCH(c, rank2k_stream_kernel, dim3((m + RS_TC - 1) / RS_TC, (m + RS_TR - 1) / RS_TR), dim3(256), 0, C, m, ld, Up,
+                 Zp, ldp, kk, alpha);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
 int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, const double* Zp, int ldp,
                       int kk, double alpha) {
     prof_begin(c, PROF_UPDATE, 16.0 * n * (double)n, 4.0 * kk * (double)n * n);

@@ -619,6 +619,7 @@ class InternalPES(PES):
             self.set_H(H0, initialized=True)
         self.bad_int = None
         self.exact_geodesic = exact_geodesic
+        self.iterative_stepper = iterative_stepper
 
     # ---- B = dq/dx: range basis and pseudo-inverse from one factorisation (:674-736) -------------------
     def _get_factor(self):
@@ -676,8 +677,53 @@ class InternalPES(PES):
         B = self.int.jacobian_csr()
         return t0 * dx, t0 * (B @ y[1]), B @ y[2]
 
+    def _set_x_iterative(self, target, max_iter=20):
+        """Newton back-transformation q(x) = target (peswrapper.py:749-839): faster than the geodesic for small
+        feasible steps; returns None — positions restored — when it does not settle, and `set_x` integrates the
+        geodesic instead.  Acceptance rules as in the reference: root-mean-square residual below 1e-8, or a
+        stagnated iteration that at least halved it and ends below 1e-6; a residual that doubles, a stagnation
+        above half the initial residual or an internal coordinate turning degenerate abort.  The Newton correction
+        is B^+ (target - q) with the pseudo-inverse of the CURRENT geometry (spectral factor, cached per geometry)."""
+        start = self.atoms.positions.copy()
+        q0 = self.get_x()
+        dq_wanted = target - q0
+        g_int = self.curr.get('g')
+        g_cart = self._get_factor().pinv_dot(g_int if g_int is not None else np.zeros_like(dq_wanted))
+
+        def give_up():
+            self.atoms.positions = start
+            return None
+
+        first = previous = None
+        stalled = 0
+        for sweep in range(max_iter):
+            miss = self.wrap_dx(target - self.get_x())
+            rms = float(np.sqrt(miss @ miss / len(miss)))
+            first = rms if first is None else first
+            if rms < 1e-8:
+                break
+            if rms > 2.0 * first:
+                return give_up()
+            if sweep > 3 and rms > 0.95 * previous:
+                stalled += 1
+                if stalled >= 3:
+                    if rms > 0.5 * first:
+                        return give_up()
+                    break
+            elif sweep > 3:
+                stalled = 0
+            previous = rms
+            self.atoms.positions = self.atoms.positions + self._get_factor().pinv_dot(miss).reshape((-1, 3))
+            if self.int.check_for_bad_internals() is not None:
+                return give_up()
+        miss = self.wrap_dx(target - self.get_x())
+        if np.sqrt(miss @ miss / len(dq_wanted)) > 1e-6:
+            return give_up()
+        return dq_wanted, self.get_x() - q0, self.int.jacobian_csr() @ g_cart
+
     def set_x(self, target):
-        dx_initial, dx_final_ode, g_final = self._set_x_ode(target)
+        res = self._set_x_iterative(target) if self.iterative_stepper else None
+        dx_initial, dx_final_ode, g_final = res if res is not None else self._set_x_ode(target)
         q_after = self.int.calc().copy()
         moved = self._project_to_constraints()
         return dx_initial, self._add_proj_delta(dx_final_ode, q_after, moved), g_final

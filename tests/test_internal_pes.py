@@ -349,3 +349,44 @@ def test_bad_internals_rebuild_the_pes(ctx, monkeypatch):
     monkeypatch.setattr(InternalCoordinates, 'check_for_bad_internals', real)
     assert opt.run(fmax=1e-3, steps=200)
     assert np.abs(atoms.get_forces()).max() < 2e-3
+
+
+def test_iterative_stepper_and_fallback(ctx):
+    """`iterative_stepper` (peswrapper.py:749-903): the Newton back-transformation reaches a feasible target to
+    1e-8 and agrees with the geodesic end point; an infeasible / too large target makes it give up (positions
+    restored) and `set_x` falls back to the geodesic integrator."""
+    from sella_amd.internal import InternalCoordinates
+    from sella_amd.peswrapper import InternalPES
+    at = chain(seed=5)
+    x0 = at.positions.copy()
+    pes = InternalPES(at, InternalCoordinates.from_atoms(at), iterative_stepper=1)
+    pes.get_g()
+    q0 = pes.get_x()
+    rng = np.random.RandomState(2)
+    at.positions = x0 + 0.02 * rng.normal(size=x0.shape)
+    q1 = pes.int.calc()                                   # internals of a real geometry: feasible
+    at.positions = x0
+    out = pes._set_x_iterative(q1)
+    assert out is not None
+    np.testing.assert_allclose(pes.int.calc(), q1, atol=1e-7)
+    np.testing.assert_allclose(out[1], pes.wrap_dx(q1 - q0), atol=1e-7)
+    # same end point as the exact geodesic, up to a rigid motion: compare internals
+    at.positions = x0
+    ref = InternalPES(at, InternalCoordinates.from_atoms(at), exact_geodesic=True)
+    ref.get_g()
+    ref.set_x(q1)
+    np.testing.assert_allclose(ref.int.calc(), q1, atol=5e-5)
+    # redundant internals (a compact 4-atom cluster: 6 bonds + 12 angles for 6 internal degrees of freedom) and a
+    # random target: infeasible, Newton stagnates -> None, positions untouched; set_x then takes the geodesic
+    from sella_amd.atoms import Atoms, MorseCluster
+    tet = np.array([[0., 0., 0.], [1.5, 0.1, 0.], [0.7, 1.3, 0.1], [0.8, 0.5, 1.2]])
+    at2 = Atoms(['C'] * 4, tet.copy())
+    at2.calc = MorseCluster(D=1.0, a=1.2, r0=1.45)
+    pes2 = InternalPES(at2, InternalCoordinates.from_atoms(at2), iterative_stepper=1)
+    assert pes2.dim > 6
+    pes2.get_g()
+    bad = pes2.get_x().copy() + 0.2 * rng.normal(size=pes2.dim)
+    assert pes2._set_x_iterative(bad) is None
+    np.testing.assert_array_equal(at2.positions, tet)
+    dxi, dxf, gpar = pes2.set_x(bad)
+    assert np.isfinite(dxf).all() and np.abs(at2.positions - tet).max() > 1e-3

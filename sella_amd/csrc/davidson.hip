@@ -608,6 +608,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
     // vector whatever pair is pursued: synchronous path only)
     const bool fast_ok = s.A != nullptr && method <= SELLA_DAV_JD0_ALT && vref == nullptr && !getenv("SELLA_DAV_SYNC");
     int last_seek = 0;
+    bool wc_identity = false;   // Wc is exactly the identity (set by the device rotation of large subspaces)
     bool old_diag = false;      // rotated Gram matrices are (I, diag(lams)) apart from the newest row / column
     long n_fast = 0, n_slow = 0;
 
@@ -685,17 +686,22 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         // panels stay raw (eigensolvers.py:62-64 rotates V and AV themselves every iteration: O(n k^2) traffic
         // and two launches that nothing downstream needs before the final result)
         {
-            Wn.assign((size_t)k * k, 0.0);
-            for (int a = 0; a < k; ++a) {
-                double* wn = Wn.data() + (size_t)a * k;
-                for (int l = 0; l < k; ++l) {
-                    const double w = Wc[(size_t)a * k + l];
-                    if (w == 0.0) continue;
-                    const double* wl = W.data() + (size_t)l * k;
-                    for (int b = 0; b < k; ++b) wn[b] += w * wl[b];
+            if (wc_identity) {
+                Wc = W;                                   // panels were just rotated on the device: Wc = I
+            } else {
+                Wn.assign((size_t)k * k, 0.0);
+                for (int a = 0; a < k; ++a) {
+                    double* wn = Wn.data() + (size_t)a * k;
+                    for (int l = 0; l < k; ++l) {
+                        const double w = Wc[(size_t)a * k + l];
+                        if (w == 0.0) continue;
+                        const double* wl = W.data() + (size_t)l * k;
+                        for (int b = 0; b < k; ++b) wn[b] += w * wl[b];
+                    }
                 }
+                Wc.swap(Wn);
             }
-            Wc.swap(Wn);
+            wc_identity = false;
             if (arrow) {
                 // exact by construction: the rotated basis diagonalises the (mirrored) projected operator
                 for (int a = 0; a < k; ++a)
@@ -745,6 +751,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
             std::swap(s.AVp, s.AVq);
             Wc.assign((size_t)k * k, 0.0);
             for (int a = 0; a < k; ++a) Wc[(size_t)a * k + a] = 1.0;
+            wc_identity = true;                           // (gram_append keeps it the identity, one size larger)
         }
         if (nneg > 4000) { set_error("davidson: too many negative Ritz values (%d)", nneg); return fail(SELLA_E_UNSUPPORTED); }
 

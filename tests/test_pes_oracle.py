@@ -1,0 +1,87 @@
+"""a13 / a14 against an oracle: the product's `PES` + `Sella.step` (device mirrors, carried eigendecompositions,
+selection bases, fused restricted-step root finder) compared STEP BY STEP with the dense NumPy restatement of
+sella/peswrapper.py:214-607 and sella/optimize/optimize.py:317-440 in oracle/sella_oracle/pes.py.  That restatement
+is unpinned (the reference classes need ASE + JAX) but independent: it shares no code with the product."""
+import numpy as np
+import pytest
+
+from oracle.sella_oracle.pes import OracleSella, TranslationConstraints
+
+
+def morse(nat, seed):
+    from sella_amd.atoms import Atoms, MorseCluster
+    rng = np.random.RandomState(seed)
+    at = Atoms(['Xe'] * nat, rng.normal(size=(nat, 3), scale=1.2))
+    at.calc = MorseCluster(D=1.0, a=1.3, r0=2.0)
+    return at
+
+
+def pin_rigid(cons):
+    cons.fix_translation(0)
+    cons.fix_translation(1, dim=1)
+    cons.fix_translation(1, dim=2)
+    cons.fix_translation(2, dim=2)
+
+
+
+
+@pytest.mark.parametrize('order,rs', [(1, 'tr'), (1, 'ras'), (0, 'ras')])
+def test_morse_cluster_step_by_step(ctx, order, rs):
+    from sella_amd import Constraints, Sella
+    a1, a2 = morse(4, 4), morse(4, 4)
+    c1 = Constraints(a1)
+    pin_rigid(c1)
+    c2 = TranslationConstraints(a2)
+    pin_rigid(c2)
+    dev = Sella(a1, order=order, rs=rs, constraints=c1, logfile=None, proj_rot=False, gamma=1e-3)
+    ora = OracleSella(a2, c2, order=order, rs=rs, gamma=1e-3)
+    assert dev.delta == pytest.approx(ora.delta)
+    nsteps = 12
+    for i in range(nsteps):
+        x_before = dev.pes.get_x().copy()
+        dev.step()
+        ora.step()
+        t = ora.trace[-1]
+        tol = 1e-7 * 4 ** min(i, 8)              # roundoff of the finite-difference Hessians compounds along the path
+        np.testing.assert_allclose(dev.pes.get_x() - x_before, t['s'], atol=tol, err_msg=f'step {i}')
+        assert abs(dev.pes.get_f() - t['f']) < tol, i
+        np.testing.assert_allclose(dev.pes.get_g(), t['g'], atol=10 * tol)
+        assert dev.delta == pytest.approx(t['delta'], rel=1e-5, abs=tol), i
+        if t['rho'] is not None:
+            assert dev.rho == pytest.approx(t['rho'], rel=1e-4, abs=1e-4), i
+        np.testing.assert_allclose(dev.pes.H.B, t['B'], atol=100 * tol * max(1.0, np.abs(t['B']).max()))
+    assert dev.pes.neval == ora.pes.neval       # same number of force calls: same diagonalisation schedule
+
+
+def test_pinned_slab_step_by_step(ctx):
+    """The README pattern (lower layers frozen by per-atom translation constraints -> selection bases, principal
+    submatrix view on the device) against the dense oracle, which knows none of those shortcuts."""
+    from sella_amd import Constraints, Sella
+    from sella_amd.atoms import Atoms, MorseCluster
+    rng = np.random.RandomState(3)
+    pos = np.array([[i * 2.1, j * 2.1, k * 2.0] for k in range(2) for j in range(2) for i in range(3)], dtype=float)
+    pos += 0.05 * rng.normal(size=pos.shape)
+    pos[-1] += [0.4, 0.3, 0.6]
+
+    def build():
+        at = Atoms(['Cu'] * len(pos), pos.copy())
+        at.calc = MorseCluster(D=0.8, a=1.4, r0=2.2)
+        return at
+    a1, a2 = build(), build()
+    c1, c2 = Constraints(a1), TranslationConstraints(a2)
+    for i in range(6):                           # bottom layer pinned atom by atom
+        c1.fix_translation(i)
+        c2.fix_translation(i)
+    dev = Sella(a1, order=1, constraints=c1, logfile=None, proj_rot=False)
+    ora = OracleSella(a2, c2, order=1, rs='ras')
+    for i in range(8):
+        x_before = dev.pes.get_x().copy()
+        dev.step()
+        ora.step()
+        t = ora.trace[-1]
+        tol = 1e-7 * 4 ** min(i, 8)
+        np.testing.assert_allclose(dev.pes.get_x() - x_before, t['s'], atol=tol, err_msg=f'step {i}')
+        assert abs(dev.pes.get_f() - t['f']) < tol
+        assert dev.delta == pytest.approx(t['delta'], rel=1e-5, abs=tol)
+        # pinned coordinates never move
+        np.testing.assert_array_equal(a1.positions[:6], pos[:6])

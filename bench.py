@@ -356,7 +356,7 @@ def main():
         dg_all = comm.allgather_host(dgl).sum(axis=0) if world > 1 else dgl
         op = RowShardedOperator(Hloc, lo_, nb_)
         del Hloc, hsh, a_, b_
-        op.block_davidson(16, block=16, tol=1e-14, maxiter=2, maxvec=96, diag=dg_all)          # warm-up
+        op.block_davidson(16, block=16, tol=1e-14, maxiter=2, diag=dg_all)          # warm-up
         # one panel pass alone (the roofline-relevant part of the iteration): 8 * rows * n bytes
         Xp = np.random.RandomState(1).standard_normal((nb_, 16))
         op.local_matmat(Xp)
@@ -368,7 +368,7 @@ def main():
         pp = ctx.prof_get(0)
         barrier()
         tb = time.perf_counter()
-        outb = op.block_davidson(16, block=16, tol=1e-14, maxiter=args.block_iters, maxvec=96, diag=dg_all)
+        outb = op.block_davidson(16, block=16, tol=1e-14, maxiter=args.block_iters, diag=dg_all)
         ctx.sync()
         tblk = comm.max_host(time.perf_counter() - tb)
         nit = max(1, outb['niter'])

@@ -286,7 +286,10 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
     if (block <= 0 || block > BD_NB) block = BD_NB;
     if (nev > n) nev = n;
     if (block > n) block = n;
-    if (maxvec <= 0) maxvec = std::max(8 * block, nev + 4 * block);
+    // default basis limit: the nev + block lowest Ritz vectors kept at a restart plus one new block — the k x k
+    // Rayleigh-Ritz problem on the host is O(k^3) in scalar code (0.5 ms at k = 48, 3 ms at k = 96: more than the
+    // whole device side of an iteration at 3N = 12288), so a larger history has to be asked for explicitly
+    if (maxvec <= 0) maxvec = nev + 2 * block;
     if (maxvec < nev + 2 * block) maxvec = nev + 2 * block;
     if (maxvec > n) maxvec = n;
     if (maxvec + BD_NB > 2048) {

@@ -553,6 +553,41 @@ class _BFactor:
             return self.BsT @ ctx.symm_mm(self.M, Y)
         return ctx.symm_mm(self.M, self.BsT @ Y)
 
+    def pinv_dot_moved(self, Bs_new, Y, tol=1e-11, maxit=30):
+        """B_new^+ Y for the Jacobian of a NEARBY geometry, without a new factorisation: preconditioned conjugate
+        gradients on the normal equations (B_new^T B_new) x = B_new^T Y with this factor's M = (B^T B)^+ as the
+        preconditioner — M B_new^T B_new is the projector onto range(B^T) plus a perturbation of the size of the
+        geometry change, so a handful of iterations (two sparse products and one device panel product each) reach
+        1e-11.  The result is a least-squares solution; where the null space of B_new has rotated away from this
+        factor's (rigid rotations of a molecule) it differs from the minimum-norm one by a null vector of B_new, i.e.
+        by a motion that changes no internal coordinate.  Returns None if it does not converge (the caller then
+        factorises anew)."""
+        if self.M is None or self.left or np.size(Y) == 0:
+            return None
+        ctx = get_context()
+        Y2 = Y[:, None] if np.ndim(Y) == 1 else Y
+        BT_new = Bs_new.T.tocsr()
+        R = np.asarray(BT_new @ Y2)
+        X = np.zeros_like(R)
+        Z = ctx.symm_mm(self.M, R)
+        P = Z.copy()
+        rz = np.einsum('ij,ij->j', R, Z)
+        rz0 = np.where(rz > 0, rz, 1.0)
+        for _ in range(maxit):
+            AP = np.asarray(BT_new @ (Bs_new @ P))
+            pap = np.einsum('ij,ij->j', P, AP)
+            live = (rz > tol * tol * rz0) & (pap > 0)
+            if not live.any():
+                return X[:, 0] if np.ndim(Y) == 1 else X
+            alpha = np.where(live, rz / np.where(pap > 0, pap, 1.0), 0.0)
+            X += alpha * P
+            R -= alpha * AP
+            Z = ctx.symm_mm(self.M, R)
+            rz_new = np.einsum('ij,ij->j', R, Z)
+            P = Z + np.where(live, rz_new / np.where(rz != 0, rz, 1.0), 0.0) * P
+            rz = rz_new
+        return None
+
     def pinvT_dot(self, Y):
         """(B^+)^T Y for Y (3N,) or (3N, k) — e.g. the Cartesian gradient -> internal gradient."""
         if self.M is None or np.size(Y) == 0:
@@ -645,8 +680,20 @@ class InternalPES(PES):
         dydt[0] = dxdt
         self.atoms.positions = x.reshape((-1, 3)).copy()
         # rows of D(dxdt) are H_i dxdt (one device launch per kind); only D @ [dxdt, g] is needed
-        fac = self._get_factor() if self.exact_geodesic else self._ode_factor
-        out = -fac.pinv_dot(self.int.hessian_rdot_mult(dxdt, np.column_stack((dxdt, g))))    # (nx, 2)
+        rhs = self.int.hessian_rdot_mult(dxdt, np.column_stack((dxdt, g)))
+        fac = self._ode_factor
+        if self.exact_geodesic:
+            # pseudo-inverse AT THE CURRENT POINT of the path (peswrapper.py:1200-1221 re-evaluates it at every
+            # right-hand side): carried from the factor of the starting point by a few preconditioned CG
+            # iterations on the sparse Jacobian instead of a new spectral factorisation per right-hand side
+            # (130 ms each at 1024 atoms); a new factor is taken — and becomes the carrier — only if that stalls
+            sol = fac.pinv_dot_moved(self.int.jacobian_csr(), rhs)
+            if sol is None:
+                fac = self._ode_factor = self._get_factor()
+                sol = fac.pinv_dot(rhs)
+            out = -sol
+        else:
+            out = -fac.pinv_dot(rhs)                                                          # (nx, 2)
         dydt[1] = out[:, 0]
         dydt[2] = out[:, 1]
         return dydt.ravel()

@@ -686,58 +686,116 @@ def _ic_guess_hessian(self, diagonal_only=False):
     return np.abs(h0) if diagonal_only else np.diag(np.abs(h0))
 
 
-def _ic_check_bad(self, tol=np.pi / 36):
-    """Angles that have become (nearly) linear make dihedrals ill defined (internal.py:3700-3736); the
-    reference then inserts dummy atoms — not part of this build, so the caller raises."""
+def _ic_check_bad(self, tol=np.pi / 12):
+    """Angles within `tol` (15 degrees, `Internals.atol`) of 0 or pi make the coordinate system degenerate
+    (internal.py:3704-3736); the caller stops the step there and `Sella.step` rebuilds the internals."""
     if not self.nangles:
         return None
     pos, tvec, _ = self._batch('angles')
     ang = evaluate_kind('angles', pos, tvec, hessian=False)[0]
-    bad = np.flatnonzero(ang > np.pi - tol)
+    bad = np.flatnonzero((ang > np.pi - tol) | (ang < tol))
     return bad if len(bad) else None
 
 
-def _ic_from_atoms(cls, atoms, cons=None, scale=1.25, dihedrals=True):
-    """Bonds closer than scale * (r_cov,i + r_cov,j) (internal.py:3260-3400), every angle between two bonds
-    at an atom, every proper dihedral a-b-c-d along three consecutive bonds whose two angles are not
-    (nearly) linear."""
+def _fragments(natoms, bonds):
+    """Connected components of the bond graph: label per atom (union-find, path halving)."""
+    parent = np.arange(natoms)
+
+    def find(i):
+        while parent[i] != i:
+            parent[i] = parent[parent[i]]
+            i = parent[i]
+        return i
+    for i, j in bonds:
+        ri, rj = find(int(i)), find(int(j))
+        if ri != rj:
+            parent[max(ri, rj)] = min(ri, rj)
+    return np.array([find(i) for i in range(natoms)])
+
+
+def _ic_from_atoms(cls, atoms, cons=None, scale=1.25, dihedrals=True, atol=15.):
+    """Automatic redundant internals, the topology search of sella/internal.py:3366-3671 as array code:
+
+    * bonds: pairs closer than scale * (r_cov,i + r_cov,j); while the bond graph is disconnected the scale grows by
+      5 % and bonds BETWEEN fragments are added (`find_all_bonds`, :3366-3423; minimum-image convention);
+    * angles: every pair of bonds at an atom whose angle lies in (atol, pi - atol), atol = 15 degrees; a (nearly)
+      linear one at an atom with a third neighbour is replaced by the improper dihedral through that neighbour
+      (`find_all_angles`, :3458-3573; the two-neighbour case needs a dummy atom there — out of scope, the angle
+      is simply left out);
+    * dihedrals: every chain a-b-c-d of two kept angles sharing the bond b-c (`find_all_dihedrals`, :3575-3600), plus
+      one improper n0-c-n1-n2 for centres with 3 or 4 neighbours that no proper dihedral passes through
+      (:3602-3660: keeps the Jacobian well conditioned at planar geometries)."""
+    atol = atol * np.pi / 180.
+    natoms = len(atoms)
     rc = np.array([covalent_radius(s) for s in atoms.symbols])
-    bonds, bncv = neighbour_bonds(atoms, scale * 2.0 * rc.max())
-    if len(bonds):
-        pos = atoms.positions
-        cell = np.asarray(atoms.cell, dtype=np.float64)
-        d = np.linalg.norm(pos[bonds[:, 1]] - pos[bonds[:, 0]] + bncv[:, 0] @ cell, axis=1)
-        keep = d < scale * (rc[bonds[:, 0]] + rc[bonds[:, 1]])
-        bonds, bncv = bonds[keep], bncv[keep]
+    cell = np.asarray(atoms.cell, dtype=np.float64)
+    pos = atoms.positions
+    allp, allv = neighbour_bonds(atoms, np.inf)                          # every pair once, minimum image
+    if len(allp):
+        dist = np.linalg.norm(pos[allp[:, 1]] - pos[allp[:, 0]] + allv[:, 0] @ cell, axis=1)
+        reach = rc[allp[:, 0]] + rc[allp[:, 1]]
+        have = dist <= scale * reach
+        for _ in range(200):
+            labels = _fragments(natoms, allp[have])
+            if len(np.unique(labels)) == 1:
+                break
+            scale *= 1.05
+            have |= (labels[allp[:, 0]] != labels[allp[:, 1]]) & (dist <= scale * reach)
+        bonds, bncv = allp[have], allv[have]
+    else:
+        bonds, bncv = np.zeros((0, 2), dtype=np.int64), np.zeros((0, 1, 3))
     angles, ancv = angles_from_bonds(bonds, bncv)
-    dih, dncv = np.zeros((0, 4), dtype=np.int64), np.zeros((0, 3, 3))
+    dl, dv, seen = [], [], set()
+
+    def add_dihedral(idx4, ncv3):
+        a, b2, c, d = (int(v) for v in idx4)
+        key = (a, b2, c, d) if (a, b2) < (d, c) else (d, c, b2, a)
+        if key not in seen:
+            seen.add(key)
+            dl.append([a, b2, c, d])
+            dv.append([np.asarray(v, dtype=np.float64) for v in ncv3])
+
+    if len(angles):
+        aval = cls(atoms, angles=angles, angle_ncvecs=ancv).calc()
+        ok = (aval > atol) & (aval < np.pi - atol)
+        # neighbour lists (neighbour, image offset seen from the centre) in bond order, both directions
+        nbrs = [[] for _ in range(natoms)]
+        for (i, j), v in zip(bonds, bncv[:, 0]):
+            nbrs[int(i)].append((int(j), v))
+            nbrs[int(j)].append((int(i), -v))
+        if dihedrals:
+            for (n1, c, n2), (v1, v2) in zip(angles[~ok], ancv[~ok]):
+                # linear n1-c-n2 with a third neighbour n3: improper (n1, c, n3, n2), :3556-3573
+                for n3, v3 in nbrs[int(c)]:
+                    if (n3 == n1 and np.array_equal(v3, -v1)) or (n3 == n2 and np.array_equal(v3, v2)):
+                        continue
+                    add_dihedral((n1, c, n3, n2), (v1, v3, v2 - v3))
+                    break
+        angles, ancv = angles[ok], ancv[ok]
     if dihedrals and len(angles):
-        ic0 = cls(atoms, angles=angles, angle_ncvecs=ancv)
-        aval = ic0.calc()
-        ok = aval < np.pi - np.pi / 18
-        A, Av = angles[ok], ancv[ok]
-        dl, dv, seen = [], [], set()
-        # join angles (a, b, c) and (b, c, d): shared bond b-c with consistent image offsets
+        # proper dihedrals: join angles (a, b, c) and (b, c, d) over the shared bond b-c with consistent images
         by_bond = {}
-        for k, (a, b, c) in enumerate(A):
-            by_bond.setdefault((b, c, tuple(Av[k, 1])), []).append((a, Av[k, 0]))            # ... a-b-c, bond b->c
-            by_bond.setdefault((b, a, tuple(-Av[k, 0])), []).append((c, -Av[k, 1]))          # reversed: c-b-a, bond b->a
-        for (b, c, off), lefts in by_bond.items():
-            rights = by_bond.get((c, b, tuple(-np.array(off))), [])
+        for k, (a, b2, c) in enumerate(angles):
+            by_bond.setdefault((b2, c, tuple(ancv[k, 1])), []).append((a, ancv[k, 0]))           # ... a-b-c, bond b->c
+            by_bond.setdefault((b2, a, tuple(-ancv[k, 0])), []).append((c, -ancv[k, 1]))         # reversed: c-b-a, bond b->a
+        for (b2, c, off), lefts in by_bond.items():
+            rights = by_bond.get((c, b2, tuple(-np.array(off))), [])
             for a, oa in lefts:
                 for dd, od in rights:
-                    if a == dd or a == c or dd == b:
+                    if a == c or dd == b2:
                         continue
-                    key = (a, b, c, dd) if (a, b) < (dd, c) else (dd, c, b, a)
-                    if key in seen:
-                        continue
-                    seen.add(key)
-                    # offsets along the chain a -> b -> c -> d: a->b is the reverse of "b sees a at oa"... stored as
-                    # tvec_k = image shift of atom k+1 relative to atom k
-                    dl.append([a, b, c, dd])
-                    dv.append([oa, np.array(off), -od])
-        if dl:
-            dih, dncv = np.array(dl, dtype=np.int64), np.array(dv, dtype=np.float64)
+                    if a == dd and not np.any(np.asarray(oa) + np.array(off) - np.asarray(od)):
+                        continue                                   # the same atom (same image) at both ends, :3593-3599
+                    add_dihedral((a, b2, c, dd), (oa, np.array(off), -od))
+        centres = set()
+        for a, b2, c, d in dl:
+            centres.update((b2, c))
+        for centre in range(natoms):
+            if len(nbrs[centre]) in (3, 4) and centre not in centres:
+                (n0, v0), (n1, v1), (n2, v2) = nbrs[centre][:3]
+                add_dihedral((n0, centre, n1, n2), (-v0, v1, v2 - v1))
+    dih = np.array(dl, dtype=np.int64) if dl else np.zeros((0, 4), dtype=np.int64)
+    dncv = np.array(dv, dtype=np.float64) if dl else np.zeros((0, 3, 3))
     ic = cls(atoms, bonds=bonds, angles=angles, dihedrals=dih, bond_ncvecs=bncv, angle_ncvecs=ancv,
              dihedral_ncvecs=dncv)
     ic.cons = cons if cons is not None else Constraints(atoms)

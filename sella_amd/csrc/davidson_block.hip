@@ -289,7 +289,7 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
     // default basis limit: the nev + block lowest Ritz vectors kept at a restart plus one new block — the k x k
     // Rayleigh-Ritz problem on the host is O(k^3) in scalar code (0.5 ms at k = 48, 3 ms at k = 96: more than the
     // whole device side of an iteration at 3N = 12288), so a larger history has to be asked for explicitly
-    if (maxvec <= 0) maxvec = nev + 2 * block;
+    if (maxvec <= 0) maxvec = std::max(nev + 2 * block, 24);
     if (maxvec < nev + 2 * block) maxvec = nev + 2 * block;
     if (maxvec > n) maxvec = n;
     if (maxvec + BD_NB > 2048) {

@@ -25,7 +25,7 @@ def check_pairs(A, out, nev, tol=1e-10):
             assert abs(abs(V[:, j] @ Z[:, j]) - 1.0) < 1e-8, j
 
 
-@pytest.mark.parametrize('n,nev,block', [(96, 4, 4), (200, 16, 16), (130, 20, 16)])
+@pytest.mark.parametrize('n,nev,block', [(96, 4, 4), (128, 16, 16), (100, 20, 16)])
 def test_block_davidson_eigenbasis_preconditioner(ctx, n, nev, block):
     A, P, g = hessian_like(n, seed=n, nneg=2)
     dA, dP = ctx.upload(A), ctx.upload(P)
@@ -54,7 +54,7 @@ def test_block_davidson_row_sharded_callback(ctx):
     """The row-sharded product path with a single rank: the all-gather callback sees device buffers and a stream
     (what ncclAllGather takes); here it is a device-to-device copy through the library."""
     import ctypes
-    n, nev = 160, 5
+    n, nev = 96, 5
     A, P, g = hessian_like(n, seed=11)
     dA, dP = ctx.upload(A), ctx.upload(P)
     w, Q, Qt = ctx.eigh(dP)

@@ -37,3 +37,11 @@ for CNT in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/pmc_$CNT
 done
 rm -f $OUT/prof/*/*.db.tmp
+echo "== configs[2]: internal coordinates / geodesic at 1024 atoms" | tee -a $OUT/session.log
+timeout 600 python tools/geodesic_bench.py --steps 3 --sella-steps 2 > $OUT/geodesic.log 2>&1; echo "geodesic exit $?" | tee -a $OUT/session.log
+grep "^{" $OUT/geodesic.log | cut -c1-400 | tee -a $OUT/session.log
+EXACT_GEODESIC=1 timeout 600 python tools/geodesic_bench.py --steps 1 --sella-steps 2 > $OUT/geodesic_exact.log 2>&1; grep "Sella(internal)" $OUT/geodesic_exact.log | cut -c1-300 | tee -a $OUT/session.log
+echo "== Davidson loop alone" | tee -a $OUT/session.log
+SELLA_DEBUG_TIMING=1 timeout 300 python tools/dav_time.py > $OUT/dav_time.log 2>&1; grep -v "^davidson\|^eigh" $OUT/dav_time.log | tail -4 | tee -a $OUT/session.log; grep "^davidson" $OUT/dav_time.log | tail -1 | tee -a $OUT/session.log
+echo "== rccl (1 rank)" | tee -a $OUT/session.log
+timeout 120 python tools/rccl_smoke.py > $OUT/rccl.log 2>&1; tail -1 $OUT/rccl.log | tee -a $OUT/session.log

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the Sella inner saddle-point linear-algebra loop on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run; the ranks
+                                                             talk through librccl bound with ctypes, sella_amd/comm.py)
 
 Metric (BASELINE.json): Davidson iterations per second on the synthetic 3N = 3072 Hessian of
 SURVEY.md §8(d).  One *step* = one complete `rayleigh_ritz(A, gamma=0.1, P, v0=g, 'jd0',
@@ -15,9 +16,13 @@ vectors for the same matrices) and the per-call eigh is amortised over it.  Rank
 no exchange step), so scaling is weak.
 
 Extra objects on the JSON line:
-  roofline      row-panel matvec (`gemv_rows_kernel`, the dominant kernel): algorithmic bytes per
-                launch (8*rows*cols) / mean launch time from hipEvents on the library's own stream,
-                collected in a separate instrumented pass over the same K steps.
+  roofline      the dominant kernel of the step (`trd_gemv_kernel`, the trailing-matrix matvec of the eigh of P):
+                algorithmic bytes per launch (8 m^2) / mean launch time from hipEvents attached to the dispatch
+                packets on the library's own stream, collected in a separate instrumented pass; the Davidson
+                loop's own n x n streams are reported beside it.
+  block_davidson  BASELINE configs[4]: block Davidson (16 vectors per iteration, H.V panel on the matrix cores) at
+                3N = 12288, rows of H sharded over the ranks (strong scaling), time per block iteration.
+  collective    which binding carried the multi-rank exchanges (direct RCCL or the torch.distributed fallback).
   cpu_baseline  the NumPy/SciPy oracle port of the reference algorithm (dense LU per iteration)
                 timed on this box's host cores on the same inputs (one call), rank 0 at N = 1 only.
 """

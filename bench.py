@@ -54,6 +54,43 @@ def hessian_like(n, seed, eps=5e-3):
     return A, P, g
 
 
+class EnsembleMember:
+    """Picklable factory of the ensemble leg's members (BASELINE configs[3]): `prepare(i)` builds the host-side data
+    (outside the timed region), `factory(i)` uploads the model Hessian to the calling process's device context and
+    returns the Atoms object."""
+
+    def __init__(self, ne):
+        self.ne = ne
+        self.host = {}
+
+    def prepare(self, i):
+        rngi = np.random.RandomState(6000 + i)
+        Ui = rngi.normal(size=(8, self.ne))
+        Ui /= np.linalg.norm(Ui, axis=1)[:, None]
+        self.host[i] = (hessian_like(self.ne, seed=5000 + i)[0], Ui, 0.05 * rngi.normal(size=(self.ne // 3, 3)))
+
+    SELLA_KW = dict(order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', proj_trans=False)
+
+    def warmup(self):
+        """Called once per worker process before the clock: a short search on a member outside the ensemble's index
+        range, so that code objects, scratch and pinned buffers exist — what the earlier legs do for the parent."""
+        from sella_amd.ensemble import run_one
+        run_one(self(-1), 0.0, 3, self.SELLA_KW)
+        del self.host[-1]
+
+    def __call__(self, i):
+        from sella_amd import device as _dev
+        from sella_amd.atoms import Atoms, QuadraticCubicModel
+        if i not in self.host:
+            self.prepare(i)
+        Ai, Ui, x0 = self.host[i]
+        c_i = _dev.get_context()
+        dAi = c_i.upload(Ai)
+        at = Atoms(['X'] * (self.ne // 3), x0.copy(), pbc=True)
+        at.calc = QuadraticCubicModel(lambda x, c_i=c_i, dAi=dAi: c_i.symm_mm(dAi, x), Ui, c=0.05)
+        return at
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -73,6 +110,8 @@ def main():
     ap.add_argument('--ensemble-steps', type=int, default=20)
     ap.add_argument('--ensemble-n', type=int, default=768)
     ap.add_argument('--ensemble-threads', type=int, default=1)
+    ap.add_argument('--ensemble-procs', type=int, default=-1,
+                    help='worker processes per GPU for the ensemble leg (-1: min(members, CPUs of this rank); 0/1: none)')
     ap.add_argument('--block-n', type=int, default=12288, help='configs[4] leg: operator size (0 disables)')
     ap.add_argument('--block-iters', type=int, default=12)
     args = ap.parse_args()
@@ -279,38 +318,41 @@ def main():
         if args.ensemble_per_gpu > 0:
             from sella_amd.ensemble import local_members, run_ensemble
             ne, total = args.ensemble_n, args.ensemble_per_gpu * world
-            # host-side data of this rank's members is prepared outside the timed region; the device
-            # upload happens in the worker thread that runs the member (one context per thread)
-            host = {}
-            for i in local_members(total, rank, world):
-                rngi = np.random.RandomState(6000 + i)
-                Ui = rngi.normal(size=(8, ne))
-                Ui /= np.linalg.norm(Ui, axis=1)[:, None]
-                host[i] = (hessian_like(ne, seed=5000 + i)[0], Ui, 0.05 * rngi.normal(size=(ne // 3, 3)))
-
-            def make_member(i):
-                Ai, Ui, x0 = host[i]
-                c_i = _dev.get_context()
-                dAi = c_i.upload(Ai)
-                at = Atoms(['X'] * (ne // 3), x0.copy(), pbc=True)
-                at.calc = QuadraticCubicModel(lambda x, c_i=c_i, dAi=dAi: c_i.symm_mm(dAi, x), Ui, c=0.05)
-                return at
-
+            # host-side data of this rank's members is prepared outside the timed region; the device upload
+            # happens inside it, in the process (or thread) that runs the member.  --ensemble-procs P > 1: the
+            # members run in P worker processes on this GPU (sella_amd.ensemble.EnsemblePool), started before the clock
+            # like the library and the context of this process.
+            from sella_amd.ensemble import EnsemblePool
+            make_member = EnsembleMember(ne)
+            mine_e = local_members(total, rank, world)
+            nproc_e = args.ensemble_procs
+            if nproc_e < 0:
+                nproc_e = min(args.ensemble_per_gpu, max(1, effective_cpu_count() // max(1, local_world)))
+            pool = None
+            if nproc_e > 1 and os.environ.get('SELLA_BENCH_COMM') != 'gloo':
+                pool = EnsemblePool(nproc_e)
+                pool.prepare(make_member, mine_e)
+            else:
+                for i in mine_e:
+                    make_member.prepare(i)
             barrier()
             te = time.perf_counter()
             res = run_ensemble(make_member, total, fmax=0.0, steps=args.ensemble_steps,
-                               sella_kwargs=dict(order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', proj_trans=False),
-                               threads=args.ensemble_threads)
+                               sella_kwargs=EnsembleMember.SELLA_KW,
+                               threads=args.ensemble_threads, pool=pool, prepared=pool is not None)
             ctx.sync()
             tens = time.perf_counter() - te
             tens = comm.max_host(tens)
             nst_tot = float(res['summary'][:, 1].sum())
             opt_stats['ensemble'] = dict(replicas=total, per_gpu=args.ensemble_per_gpu, n=ne,
                                          host_threads_per_gpu=args.ensemble_threads,
+                                         worker_processes_per_gpu=(pool.processes if pool is not None else 0),
                                          steps_per_replica=args.ensemble_steps,
                                          optimizer_steps_per_s=round(nst_tot / tens, 2),
                                          searches_per_s=round(total / tens, 3), seconds=round(tens, 3),
                                          lambda_min_negative=int((res['summary'][:, 4] < 0).sum()))
+            if pool is not None:
+                pool.close()
         # ---- BASELINE configs[1] as named: 1024-atom Cu(111) EMT slab (3N = 3072), one surface atom lifted onto a
         # bridge site, lower half frozen by translation constraints (the README pattern), default Sella settings,
         # device EMT calculator.  Host-glue bound (Python between sub-millisecond kernels), reported for the record.

@@ -27,13 +27,26 @@ _MASSES = dict(H=1.008, C=12.011, N=14.007, O=15.999, F=18.998, Al=26.982, Si=28
                Ar=39.948, Ni=58.693, Cu=63.546, Pd=106.42, Ag=107.868, Pt=195.084, Au=196.967, Xe=131.293)
 
 
+# chemical symbols by atomic number ('X' = 0: a placeholder species, as in ase.data.chemical_symbols)
+CHEMICAL_SYMBOLS = ('X H He Li Be B C N O F Ne Na Mg Al Si P S Cl Ar K Ca Sc Ti V Cr Mn Fe Co Ni Cu Zn Ga Ge As Se Br Kr '
+                    'Rb Sr Y Zr Nb Mo Tc Ru Rh Pd Ag Cd In Sn Sb Te I Xe Cs Ba La Ce Pr Nd Pm Sm Eu Gd Tb Dy Ho Er Tm Yb '
+                    'Lu Hf Ta W Re Os Ir Pt Au Hg Tl Pb Bi Po At Rn Fr Ra Ac Th Pa U Np Pu Am Cm Bk Cf Es Fm Md No Lr Rf '
+                    'Db Sg Bh Hs Mt Ds Rg Cn Nh Fl Mc Lv Ts Og').split()
+_ATOMIC_NUMBER = {sym: z for z, sym in enumerate(CHEMICAL_SYMBOLS)}
+
+
 class Atoms:
     def __init__(self, symbols=None, positions=None, cell=None, pbc=False, calculator=None,
                  numbers=None):
         self.positions = np.array(positions, dtype=np.float64).reshape((-1, 3))
         n = len(self.positions)
+        if symbols is not None and len(symbols) and not isinstance(symbols[0], str):
+            symbols, numbers = None, symbols                    # Atoms(numbers, positions), as read from a trajectory
+        if symbols is None and numbers is not None:
+            symbols = [CHEMICAL_SYMBOLS[int(z)] for z in numbers]
         self.symbols = list(symbols) if symbols is not None else ['X'] * n
-        self.numbers = np.array(numbers if numbers is not None else np.zeros(n, dtype=int))
+        self.numbers = np.array(numbers if numbers is not None else [_ATOMIC_NUMBER.get(sym, 0) for sym in self.symbols],
+                                dtype=int)
         self.cell = np.zeros((3, 3)) if cell is None else np.array(cell, dtype=np.float64).reshape(3, 3)
         self.pbc = np.array([pbc] * 3 if np.isscalar(pbc) else pbc, dtype=bool)
         self.calc = calculator
@@ -57,6 +70,12 @@ class Atoms:
     def set_positions(self, pos):
         self.positions = np.array(pos, dtype=np.float64).reshape((-1, 3))
 
+    def get_atomic_numbers(self):
+        return self.numbers.copy()
+
+    def get_chemical_symbols(self):
+        return list(self.symbols)
+
     def get_masses(self):
         return self.masses.copy()
 
@@ -79,7 +98,7 @@ class Atoms:
     def extend(self, symbol, position):
         self.symbols.append(symbol)
         self.positions = np.vstack([self.positions, np.asarray(position, dtype=np.float64).reshape(1, 3)])
-        self.numbers = np.append(self.numbers, 0)
+        self.numbers = np.append(self.numbers, _ATOMIC_NUMBER.get(symbol, 0))
         self.masses = np.append(self.masses, _MASSES.get(symbol, 1.0))
 
 
@@ -378,6 +397,14 @@ class _MiniOptimizer:
         self.fmax = None
         self.observers = []
         self._closers = []
+        if trajectory is not None:
+            # ase/optimize/optimize.py: a name opens a Trajectory writer owned by the optimizer; either way its
+            # write() becomes an observer (one image per step)
+            if isinstance(trajectory, str):
+                from .trajectory import Trajectory
+                trajectory = self.closelater(Trajectory(trajectory, 'w', atoms, master=master))
+            self.attach(trajectory.write)
+            self.trajectory = trajectory
 
     def closelater(self, obj):
         self._closers.append(obj)

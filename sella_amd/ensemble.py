@@ -13,6 +13,15 @@ tests an initialised `torch.distributed` gloo group takes its place.)  The data 
 
 `make_replica(i) -> atoms` must build replica i (with its calculator) deterministically from i, so
 every rank can construct exactly its own members.
+
+Within one GPU a small search (3N = 768) is bound by the host: Python between sub-millisecond kernels leaves the
+device idle two thirds of the time, and host threads do not help (the interpreter lock).  `EnsemblePool(P)` therefore
+runs the rank's members in P worker PROCESSES, each with its own interpreter, device context and HIP stream on the same
+GPU; kernels of different workers overlap on the device.  The members stay independent — the sharding rule of the
+ranks, one level further down — and the results are bit-identical to the serial run.
+
+    with EnsemblePool(8) as pool:
+        results = run_ensemble(make_replica, 64, ..., pool=pool)       # make_replica must be picklable
 """
 import os
 import sys
@@ -71,7 +80,134 @@ def _run_members(members, make_replica, fmax, steps, sella_kwargs, own_context):
     return out
 
 
-def run_ensemble(make_replica, n_replicas, fmax=0.05, steps=1000, sella_kwargs=None, threads=1):
+def _pool_worker(conn, initializer, initargs):
+    """Main of one worker process: own interpreter, own default device context."""
+    try:
+        if initializer is not None:
+            initializer(*initargs)
+        from . import device
+        ctx = device.get_context()
+        conn.send(('ready', os.getpid()))
+    except BaseException as e:                                  # noqa: BLE001 - reported to the parent, which raises
+        conn.send(('error', repr(e)))
+        return
+    factory = None
+    while True:
+        try:
+            msg = conn.recv()
+        except EOFError:
+            break
+        try:
+            if msg[0] == 'stop':
+                break
+            if msg[0] == 'prepare':
+                factory = msg[1]
+                prep = getattr(factory, 'prepare', None)
+                if prep is not None:
+                    for i in msg[2]:
+                        prep(i)
+                warm = getattr(factory, 'warmup', None)
+                if warm is not None:
+                    warm()
+                conn.send(('ok', None))
+            elif msg[0] == 'run':
+                _, fac, members, fmax, steps, kw = msg
+                if fac is not None:
+                    factory = fac
+                out = {i: run_one(factory(i), fmax, steps, kw) for i in members}
+                ctx.sync()
+                conn.send(('ok', out))
+        except BaseException as e:                              # noqa: BLE001
+            import traceback
+            conn.send(('error', traceback.format_exc() + repr(e)))
+
+
+class EnsemblePool:
+    """P worker processes on this rank's GPU, started once and reused.
+
+    `initializer(*initargs)` runs first in every worker (the CPU tests use it to select the host emulation).  The
+    workers are started with the `spawn` method — the HIP runtime of the parent must not be forked — and inherit the
+    environment, so they open the same device as the parent (`LOCAL_RANK` / `SELLA_HIP_DEVICE`); their BLAS pools are
+    capped at (CPUs of this process) / P through `SELLA_HOST_THREADS`."""
+
+    def __init__(self, processes, initializer=None, initargs=()):
+        import multiprocessing as mp
+        from .utilities.hostcpu import effective_cpu_count
+        self.processes = int(processes)
+        if self.processes < 1:
+            raise ValueError('EnsemblePool needs at least one process')
+        mpc = mp.get_context('spawn')
+        keep = os.environ.get('SELLA_HOST_THREADS')
+        os.environ['SELLA_HOST_THREADS'] = str(max(1, effective_cpu_count() // self.processes))
+        self._workers = []
+        try:
+            for _ in range(self.processes):
+                parent, child = mpc.Pipe()
+                p = mpc.Process(target=_pool_worker, args=(child, initializer, initargs), daemon=True)
+                p.start()
+                child.close()
+                self._workers.append((p, parent))
+        finally:
+            if keep is None:
+                del os.environ['SELLA_HOST_THREADS']
+            else:
+                os.environ['SELLA_HOST_THREADS'] = keep
+        self.pids = [self._expect(conn) for _, conn in self._workers]
+
+    @staticmethod
+    def _expect(conn):
+        try:
+            tag, val = conn.recv()
+        except EOFError:
+            raise RuntimeError('ensemble worker died') from None
+        if tag == 'error':
+            raise RuntimeError('ensemble worker failed: ' + str(val))
+        return val
+
+    def deal(self, members):
+        return [list(members[p::self.processes]) for p in range(self.processes)]
+
+    def prepare(self, factory, members):
+        """Ship the factory to the workers and let each call `factory.prepare(i)` for its members (host-side data
+        built ahead of the searches, e.g. outside a timed region) and then `factory.warmup()`, if it has them."""
+        for (_, conn), mine in zip(self._workers, self.deal(members)):
+            conn.send(('prepare', factory, mine))
+        for _, conn in self._workers:
+            self._expect(conn)
+        self._prepared = True
+
+    def run(self, factory, members, fmax, steps, sella_kwargs):
+        """All members, dealt round-robin to the workers; returns {member: (summary, positions)}.  factory=None
+        re-uses the one shipped by `prepare`."""
+        for (_, conn), mine in zip(self._workers, self.deal(members)):
+            conn.send(('run', factory, mine, fmax, steps, sella_kwargs))
+        out = {}
+        for _, conn in self._workers:
+            out.update(self._expect(conn))
+        return out
+
+    def close(self):
+        for p, conn in self._workers:
+            try:
+                conn.send(('stop',))
+            except (OSError, BrokenPipeError):
+                pass
+        for p, conn in self._workers:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+            conn.close()
+        self._workers = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def run_ensemble(make_replica, n_replicas, fmax=0.05, steps=1000, sella_kwargs=None, threads=1, pool=None,
+                 prepared=False):
     """Run `n_replicas` independent searches, sharded over the initialised process group (or all in
     this process when there is none).  Every rank returns the same
     `dict(summary=(n_replicas, 5) array, positions=list of (N_i, 3) arrays, owner=(n_replicas,))`.
@@ -79,11 +215,18 @@ def run_ensemble(make_replica, n_replicas, fmax=0.05, steps=1000, sella_kwargs=N
     threads > 1: the rank's members are dealt to that many host threads, each with its own device
     context (own HIP stream): a small search is host-latency bound (Python between sub-millisecond
     kernels), so several of them keep one GPU busy.  `make_replica(i)` is then called inside the
-    worker thread and must build its calculator on `sella_amd.device.get_context()`."""
+    worker thread and must build its calculator on `sella_amd.device.get_context()`.
+
+    pool: an `EnsemblePool`; the rank's members run in its worker processes (`make_replica` is pickled to them,
+    or — prepared=True — the factory already shipped by `pool.prepare` is used)."""
     rank, world = rank_and_world()
     mine = local_members(n_replicas, rank, world)
     summaries, positions = {}, {}
-    if threads > 1 and len(mine) > 1:
+    if pool is not None:
+        done = pool.run(None if prepared else make_replica, mine, fmax, steps, sella_kwargs)
+        for i, (sm, ps) in done.items():
+            summaries[i], positions[i] = sm, ps
+    elif threads > 1 and len(mine) > 1:
         from concurrent.futures import ThreadPoolExecutor
         nt = min(threads, len(mine))
         with ThreadPoolExecutor(max_workers=nt) as pool:

@@ -45,7 +45,7 @@ class _Saddle:
 class IRC(Optimizer):
     def __init__(self, atoms, logfile='-', trajectory=None, master=None, ninner_iter=10, irctol=1e-2, dx=0.1,
                  eta=1e-4, gamma=0.1, peskwargs=None, keep_going=False, **kwargs):
-        Optimizer.__init__(self, atoms, restart=None, logfile=logfile, trajectory=None, master=master)
+        Optimizer.__init__(self, atoms, restart=None, logfile=logfile, trajectory=trajectory, master=master)
         self.ninner_iter, self.irctol, self.dx, self.keep_going = ninner_iter, irctol, dx, keep_going
         self.peskwargs = {'gamma': gamma} if peskwargs is None else peskwargs
         self.sqrtm = np.sqrt(np.repeat(self.atoms.get_masses(), 3))

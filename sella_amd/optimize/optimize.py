@@ -47,8 +47,14 @@ class Sella(Optimizer):
         self.exact_geodesic = exact_geodesic is None or bool(exact_geodesic)
         self.optimize_cell = False
         self.user_internal, self.peskwargs = internal, dict(kwargs)
+        own_traj = isinstance(trajectory, str)
+        if own_traj:                                                              # :144-150
+            from ..peswrapper import open_trajectory
+            trajectory = open_trajectory(trajectory, atoms, append=append_trajectory)
         self.initialize_pes(atoms, trajectory, order, eta, constraints, v0, internal, hessian_function, **kwargs)
         Optimizer.__init__(self, atoms, restart=restart, logfile=logfile, trajectory=None, master=master)
+        if own_traj:
+            self.closelater(trajectory)
 
         # tunables: explicit keyword > table for the kind of stationary point sought (optimize.py:20-39, 120-123)
         given = dict(delta0=delta0, sigma_inc=sigma_inc, sigma_dec=sigma_dec, rho_inc=rho_inc, rho_dec=rho_dec,

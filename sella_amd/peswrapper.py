@@ -90,6 +90,17 @@ def _split_cons_subspace(drdx, tol_factor=1e-6):
     return Q[:, :ncons], Q[:, ncons:]
 
 
+def open_trajectory(name, atoms, append=False):
+    """A file NAME passed as `trajectory=` (peswrapper.py:257-261, optimize.py:144-150 of the reference): an ASE
+    `.traj` file (sella_amd/trajectory.py) like the reference writes — or, for names ending in .xyz / .extxyz, the
+    extended-XYZ text writer."""
+    if name.lower().endswith(('.xyz', '.extxyz')):
+        from .atoms import XYZTrajectory
+        return XYZTrajectory(name, atoms, mode='a' if append else 'w')
+    from .trajectory import Trajectory
+    return Trajectory(name, 'a' if append else 'w', atoms)
+
+
 class PES:
     n_cell_dof = 0
 
@@ -115,8 +126,7 @@ class PES:
         self.cons = constraints
         self.eigensolver = eigensolver
         if isinstance(trajectory, str):
-            from .atoms import XYZTrajectory
-            trajectory = XYZTrajectory(trajectory, atoms)
+            trajectory = open_trajectory(trajectory, atoms)
         self.traj = trajectory
         self.eta = eta
         self.v0 = v0

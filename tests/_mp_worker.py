@@ -101,6 +101,14 @@ if __name__ == '__main__':
                            threads=3 if sys.argv[1] == 'ensemble-threads' else 1)
         np.savez(sys.argv[2], summary=res['summary'], owner=res['owner'],
                  **{f'pos{i}': p for i, p in enumerate(res['positions'])})
+    elif sys.argv[1] == 'ensemble-pool':
+        from sella_amd.ensemble import EnsemblePool, run_ensemble
+        with EnsemblePool(2, initializer=use_emulator) as pool:
+            assert len(set(pool.pids)) == 2 and os.getpid() not in pool.pids
+            res = run_ensemble(make_replica, int(sys.argv[3]), fmax=1e-6, steps=60, pool=pool,
+                               sella_kwargs=dict(order=1, eta=1e-5, gamma=0.0, rs='tr', proj_trans=False))
+        np.savez(sys.argv[2], summary=res['summary'], owner=res['owner'],
+                 **{f'pos{i}': p for i, p in enumerate(res['positions'])})
     else:
         raise SystemExit('unknown mode')
     json.dump({'ok': True}, sys.stderr)

@@ -60,6 +60,17 @@ def test_ensemble_host_threads_match_serial(tmp_path):
         np.testing.assert_array_equal(a[f'pos{i}'], b[f'pos{i}'])
 
 
+def test_ensemble_process_pool_matches_serial(tmp_path):
+    """Worker processes (own interpreter, own device context each) on one device: same per-replica results."""
+    pool, one = str(tmp_path / 'pool.npz'), str(tmp_path / 'one.npz')
+    launch(1, 'ensemble-pool', pool, '5')
+    launch(1, 'ensemble-serial', one, '5')
+    a, b = np.load(pool), np.load(one)
+    np.testing.assert_array_equal(a['summary'], b['summary'])
+    for i in range(5):
+        np.testing.assert_array_equal(a[f'pos{i}'], b[f'pos{i}'])
+
+
 def test_bench_two_ranks(tmp_path):
     out = str(tmp_path / 'bench.json')
     launch(2, 'bench', out)

@@ -111,7 +111,7 @@ def main():
     ap.add_argument('--ensemble-n', type=int, default=768)
     ap.add_argument('--ensemble-threads', type=int, default=1)
     ap.add_argument('--ensemble-procs', type=int, default=-1,
-                    help='worker processes per GPU for the ensemble leg (-1: min(members, CPUs of this rank); 0/1: none)')
+                    help='worker processes per GPU for the ensemble leg (-1: min(members, 4, CPUs of this rank); 0/1: none)')
     ap.add_argument('--block-n', type=int, default=12288, help='configs[4] leg: operator size (0 disables)')
     ap.add_argument('--block-iters', type=int, default=12)
     args = ap.parse_args()
@@ -327,7 +327,8 @@ def main():
             mine_e = local_members(total, rank, world)
             nproc_e = args.ensemble_procs
             if nproc_e < 0:
-                nproc_e = min(args.ensemble_per_gpu, max(1, effective_cpu_count() // max(1, local_world)))
+                nproc_e = min(args.ensemble_per_gpu, EnsemblePool.BEST_PER_GPU,
+                              max(1, effective_cpu_count() // max(1, local_world)))
             pool = None
             if nproc_e > 1 and os.environ.get('SELLA_BENCH_COMM') != 'gloo':
                 pool = EnsemblePool(nproc_e)

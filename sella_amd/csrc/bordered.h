@@ -1,8 +1,9 @@
 // bordered.h — roots of the secular equation of a bordered diagonal (arrowhead) matrix
 //     [[diag(D), b], [b^T, 0]]  :  f(mu) = mu + sum_i b_i^2 / (D_i - mu) = 0.
-// Host code shared by the RFO / P-RFO step solve (stepper.hip) and the O(k^2) Rayleigh-Ritz update of the Davidson
-// loop (host_math.h `arrow_eig`).
+// Shared by the RFO / P-RFO step solve (stepper.hip: on the host per trial alpha, on the device for batches of
+// trial alphas) and the O(k^2) Rayleigh-Ritz update of the Davidson loop (host_math.h `arrow_eig`).
 #pragma once
+#include <hip/hip_runtime.h>
 #include <math.h>
 
 #include <algorithm>
@@ -15,36 +16,17 @@ inline long g_sweeps = 0;      // SELLA_DEBUG_TIMING statistics only (not thread
 // Root number j (ascending, 0..mm) of f(mu) = mu + sum b_i^2 / (D_i - mu), D ascending.
 // Returned as (origin, tau): mu = D_origin + tau with the origin the closer pole
 // (origin = -1: mu = tau, used for the two exterior roots far from every pole).
+//
+// The O(1) logic is shared by the host (plain loops over arrays) and the device (one workgroup per problem, the
+// sums as block reductions — stepper.hip `rs_batch_kernel`): `Dat(i)`, `bat(i)` return single entries, `bb` is
+// sum b_i^2, and `eval(shift, t)` returns the value, its noise scale and the derivative split at pole index j
+// (dl: poles i < j, dr: poles i >= j) of f at mu = shift + t.
+struct Ev { double f, noise, dl, dr; };
 
-inline void bordered_root(int mm, const double* D, const double* b, int j, int* origin, double* tau) {
-    double bb = 0.0;
-    for (int i = 0; i < mm; ++i) bb += b[i] * b[i];
-    // value, noise scale and the derivative split at pole index j (left part: poles i < j, right part: i >= j)
-    struct Ev { double f, noise, dl, dr; };
+template <class DAt, class BAt, class Eval>
+__host__ __device__ inline void bordered_root_core(int mm, DAt Dat, BAt bat, double bb, int j, Eval eval, int* origin,
+                                                   double* tau) {
     const int ext = (j == 0) ? 0 : (j == mm ? mm - 1 : -1);      // nearest pole of an exterior root
-    auto eval = [&](double shift, double t) {
-        Ev e;
-        double s = 0.0, sa = 0.0, dl = 0.0, dr = 0.0;
-        for (int i = 0; i < j; ++i) {                 // poles left of the root (two plain loops: both vectorise)
-            const double r = 1.0 / ((D[i] - shift) - t);
-            const double q = b[i] * b[i] * r;
-            s += q;
-            sa += fabs(q);
-            dl += q * r;
-        }
-        for (int i = j; i < mm; ++i) {                // poles right of the root
-            const double r = 1.0 / ((D[i] - shift) - t);
-            const double q = b[i] * b[i] * r;
-            s += q;
-            sa += fabs(q);
-            dr += q * r;
-        }
-        e.f = (shift + t) + s;
-        e.noise = fabs(shift + t) + sa;
-        e.dl = dl;
-        e.dr = dr;
-        return e;
-    };
     double shift, lo, hi, t;
     int org;
     if (mm == 0) { *origin = -1; *tau = 0.0; return; }
@@ -55,7 +37,7 @@ inline void bordered_root(int mm, const double* D, const double* b, int j, int* 
         const int e = (j == 0) ? 0 : mm - 1;
         const double sg = (j == 0) ? -1.0 : 1.0;
         org = e;
-        shift = D[e];
+        shift = Dat(e);
         // t = (-shift + sg sqrt(shift^2 + 4 c)) / 2, written without cancellation when -shift and sg have opposite
         // signs (a border that is tiny next to |shift| — every nearly converged Ritz pair — would otherwise give 0)
         auto qroot = [&](double cw) {
@@ -63,18 +45,18 @@ inline void bordered_root(int mm, const double* D, const double* b, int j, int* 
             return (-shift * sg >= 0.0) ? 0.5 * (-shift + sg * R) : 2.0 * cw / (shift + sg * R);
         };
         const double far = qroot(bb);                         // t of the overshooting model
-        const double near = qroot(b[e] * b[e]);
-        if (j == 0) { lo = far; hi = std::min(near, 0.0); }
-        else { lo = std::max(near, 0.0); hi = far; }
+        const double near = qroot(bat(e) * bat(e));
+        if (j == 0) { lo = far; hi = fmin(near, 0.0); }
+        else { lo = fmax(near, 0.0); hi = far; }
         if (!(hi > lo)) { *origin = org; *tau = 0.5 * (lo + hi); return; }                 // b = 0: mu = min/max(D_e, 0)
         t = far;
         if (t == 0.0) t = 0.5 * (lo + hi);
     } else {
-        const double delta = D[j] - D[j - 1];
+        const double delta = Dat(j) - Dat(j - 1);
         if (delta <= 0.0) { *origin = j; *tau = 0.0; return; }      // coincident poles: mu = D_j
-        const double fm = eval(D[j - 1], 0.5 * delta).f;
-        if (fm >= 0.0) { org = j - 1; shift = D[j - 1]; lo = 0.0; hi = 0.5 * delta; }
-        else { org = j; shift = D[j]; lo = -0.5 * delta; hi = 0.0; }
+        const double fm = eval(Dat(j - 1), 0.5 * delta).f;
+        if (fm >= 0.0) { org = j - 1; shift = Dat(j - 1); lo = 0.0; hi = 0.5 * delta; }
+        else { org = j; shift = Dat(j); lo = -0.5 * delta; hi = 0.0; }
         t = 0.5 * (lo + hi);
     }
     // f is increasing between poles: f(lo) <= 0 <= f(hi) (pole ends are never evaluated).  Interior roots: as in
@@ -86,7 +68,6 @@ inline void bordered_root(int mm, const double* D, const double* b, int j, int* 
     const double EPS = 2.220446049250313e-16;
     for (int it = 0; it < 200; ++it) {
         const Ev e = eval(shift, t);
-        ++g_sweeps;
         const double fv = e.f;
         if (!(fabs(fv) > 8.0 * EPS * e.noise)) break;
         if (fv < 0.0) lo = t; else hi = t;
@@ -99,10 +80,10 @@ inline void bordered_root(int mm, const double* D, const double* b, int j, int* 
             // per cent per sweep.  Model:  F(x) = (mu + x) + c0 + a1 / (p1 - x) + a2 / (p2 - x),  p1 < 0 < p2,
             // increasing between the poles; its root by safeguarded scalar Newton (O(1) per sweep).
             const double mu = shift + t;
-            const double p1 = (D[j - 1] - shift) - t, p2 = (D[j] - shift) - t;
+            const double p1 = (Dat(j - 1) - shift) - t, p2 = (Dat(j) - shift) - t;
             const double a1 = e.dl * p1 * p1, a2 = e.dr * p2 * p2;
             const double c0 = (fv - mu) - e.dl * p1 - e.dr * p2;
-            double elo = std::max(lo - t, p1), ehi = std::min(hi - t, p2), x = 0.0, Fx = fv;
+            double elo = fmax(lo - t, p1), ehi = fmin(hi - t, p2), x = 0.0, Fx = fv;
             eta = -fv / df;
             for (int in = 0; in < 60; ++in) {
                 if (Fx < 0.0) elo = x; else ehi = x;
@@ -123,7 +104,7 @@ inline void bordered_root(int mm, const double* D, const double* b, int j, int* 
             // matches R and R' at the current point (p2 = R / R', a2 = R p2).  Solved for eta by a safeguarded
             // scalar Newton iteration inside the bracket — O(1) work per sweep.
             const double mu = shift + t;
-            const double p1 = (D[ext] - shift) - t, a1 = b[ext] * b[ext];
+            const double p1 = (Dat(ext) - shift) - t, a1 = bat(ext) * bat(ext);
             const double q1 = a1 / p1;
             const double R = (fv - mu) - q1, Rp = (e.dl + e.dr) - q1 / p1;
             double a2 = 0.0, p2 = 1.0;
@@ -148,10 +129,41 @@ inline void bordered_root(int mm, const double* D, const double* b, int j, int* 
         if (!(tn > lo && tn < hi)) tn = 0.5 * (lo + hi);
         if (tn == lo || tn == hi || tn == t) { t = tn; break; }
         t = tn;
-        if (hi - lo <= EPS * std::max(fabs(lo), fabs(hi))) break;
+        if (hi - lo <= EPS * fmax(fabs(lo), fabs(hi))) break;
     }
     *origin = org;
     *tau = t;
+}
+
+// host form: arrays D (ascending), b
+inline void bordered_root(int mm, const double* D, const double* b, int j, int* origin, double* tau) {
+    double bb = 0.0;
+    for (int i = 0; i < mm; ++i) bb += b[i] * b[i];
+    auto eval = [&](double shift, double t) {
+        Ev e;
+        double s = 0.0, sa = 0.0, dl = 0.0, dr = 0.0;
+        for (int i = 0; i < j; ++i) {                 // poles left of the root (two plain loops: both vectorise)
+            const double r = 1.0 / ((D[i] - shift) - t);
+            const double q = b[i] * b[i] * r;
+            s += q;
+            sa += fabs(q);
+            dl += q * r;
+        }
+        for (int i = j; i < mm; ++i) {                // poles right of the root
+            const double r = 1.0 / ((D[i] - shift) - t);
+            const double q = b[i] * b[i] * r;
+            s += q;
+            sa += fabs(q);
+            dr += q * r;
+        }
+        e.f = (shift + t) + s;
+        e.noise = fabs(shift + t) + sa;
+        e.dl = dl;
+        e.dr = dr;
+        ++g_sweeps;
+        return e;
+    };
+    bordered_root_core(mm, [&](int i) { return D[i]; }, [&](int i) { return b[i]; }, bb, j, eval, origin, tau);
 }
 
 }  // namespace bordered

@@ -238,6 +238,167 @@ extern "C" int sella_stepper_set_d1hat(sella_stepper* st, const double* d1hat, i
 namespace sella {
 namespace {
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched trial alphas.  Once the reference's schedule has degenerated into pure bisection (restricted_step.py:100-110:
+// niter > 4 and a family that is not newton_safe) the next L levels of trial alphas form a binary tree of 2^L - 1
+// midpoints that is known before any of them is evaluated.  The whole tree is evaluated in ONE round trip:
+//   rs_batch_kernel    one workgroup per candidate: shat(alpha) in the eigenbasis (the bordered-diagonal root find with
+//                      its O(m) sums as block reductions, bordered.h) -> a 16-row panel
+//   panel16            V . panel on the matrix cores: the eigenvector matrix is streamed once for all candidates
+//   rs_measure_kernel  one workgroup per candidate: the constraint value
+// and the host then walks the tree with the reference's control flow.  The alphas visited are exactly the reference's.
+// ---------------------------------------------------------------------------------------------------------------------
+struct RsBatchArgs {
+    int kind, m, order, ncand, ldx;
+    double alpha[16];
+    const double* lam; const double* ghat; const double* d1hat;
+    double* X;                                  // 16 x ldx panel, rows >= ncand and columns >= m stay zero
+};
+
+// block-wide sums of 4 values (256 threads); every thread gets the result
+__device__ __forceinline__ void block_sum4_256(double v[4], double (*red)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = wave_sum64(v[q]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[threadIdx.x >> 6][q] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+}
+
+// shat of one RFO block (rfo_block above, without ds/dalpha) by the whole workgroup
+__device__ void rfo_block_dev(int mm, const double* __restrict__ lam, const double* __restrict__ gh, int o, double alpha,
+                              double* __restrict__ shat, double (*red)[4]) {
+    if (mm == 0) return;
+    const int tid = threadIdx.x;
+    const double a2 = alpha * alpha;
+    auto Dat = [&](int i) { return a2 * lam[i]; };
+    auto bat = [&](int i) { return alpha * gh[i]; };
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = tid; i < mm; i += 256) { const double b = bat(i); acc[0] += b * b; }
+    block_sum4_256(acc, red);
+    const double bb = acc[0];
+    auto eval = [&](double shift, double t) {
+        double v[4] = {0.0, 0.0, 0.0, 0.0};                  // s, sum |q|, dl, dr
+        for (int i = tid; i < mm; i += 256) {
+            const double b = bat(i);
+            const double r = 1.0 / ((Dat(i) - shift) - t);
+            const double q = b * b * r;
+            v[0] += q;
+            v[1] += fabs(q);
+            if (i < o) v[2] += q * r; else v[3] += q * r;
+        }
+        block_sum4_256(v, red);
+        bordered::Ev e;
+        e.f = (shift + t) + v[0];
+        e.noise = fabs(shift + t) + v[1];
+        e.dl = v[2];
+        e.dr = v[3];
+        return e;
+    };
+    int org;
+    double tau;
+    bordered::bordered_root_core(mm, Dat, bat, bb, o, eval, &org, &tau);
+    const double shift = org >= 0 ? Dat(org) : 0.0;
+    // eigenvector (unnormalised): y_i = b_i / (mu - D_i), eta = 1
+    double w[4] = {0.0, 0.0, 0.0, 0.0};                      // sum y^2, degenerate flag, first degenerate index (as -i)
+    w[2] = -1e300;
+    for (int i = tid; i < mm; i += 256) {
+        const double den = tau - (Dat(i) - shift);
+        if (den == 0.0) { w[1] += 1.0; }
+        else { const double y = bat(i) / den; w[0] += y * y; }
+    }
+    block_sum4_256(w, red);
+    if (w[1] > 0.0) {
+        // mu coincides with a pole: the eigenvector is e_i of the FIRST such pole, last component zero, denominator
+        // clamped at 1e-12 (stepper.py:134-136)
+        __shared__ int first;
+        if (tid == 0) first = 0x7fffffff;
+        __syncthreads();
+        for (int i = tid; i < mm; i += 256)
+            if (tau - (Dat(i) - shift) == 0.0) atomicMin(&first, i);
+        __syncthreads();
+        for (int i = tid; i < mm; i += 256) shat[i] = (i == first) ? alpha / 1e-12 : 0.0;
+        __syncthreads();
+        return;
+    }
+    const double inv = 1.0 / sqrt(1.0 + w[0]);
+    double den = inv;
+    if (fabs(den) < 1e-12) den = 1e-12;
+    for (int i = tid; i < mm; i += 256) {
+        const double y = bat(i) / (tau - (Dat(i) - shift));
+        shat[i] = (y * inv) * alpha / den;
+    }
+}
+
+__global__ __launch_bounds__(256) void rs_batch_kernel(RsBatchArgs a) {
+    __shared__ double red[4][4];
+    const int cand = blockIdx.x, tid = threadIdx.x;
+    if (cand >= a.ncand) return;
+    const double alpha = a.alpha[cand];
+    double* shat = a.X + (size_t)cand * a.ldx;
+    const int m = a.m, o = a.order;
+    if (a.kind == SELLA_STEP_QN) {
+        for (int i = tid; i < m; i += 256) {
+            const double sgn = (i < o) ? -1.0 : 1.0;
+            shat[i] = -(a.ghat[i] / (sgn * fabs(a.lam[i]) + alpha * sgn));
+        }
+    } else if (a.kind == SELLA_STEP_QN_IRC) {
+        for (int i = tid; i < m; i += 256) shat[i] = -(a.ghat[i] + alpha * a.d1hat[i]) / (fabs(a.lam[i]) + alpha);
+    } else if (a.kind == SELLA_STEP_RFO) {
+        rfo_block_dev(m, a.lam, a.ghat, o, alpha, shat, red);
+    } else {
+        rfo_block_dev(o, a.lam, a.ghat, o, alpha, shat, red);
+        rfo_block_dev(m - o, a.lam + o, a.ghat + o, 0, alpha, shat + o, red);
+    }
+}
+
+// value of the constraint for candidate blockIdx.x: y = V shat (row blockIdx.x of Y), optionally scattered through the
+// inverse selection map (inv[i] = position of full coordinate i in the family's space, -1: not a free coordinate)
+__global__ __launch_bounds__(256) void rs_measure_kernel(int cons, int nout, const double* __restrict__ Y, int ldy,
+                                                         const double* __restrict__ scons, const double* __restrict__ w,
+                                                         const double* __restrict__ d1, const int* __restrict__ inv,
+                                                         double* out) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* y = Y + (size_t)blockIdx.x * ldy;
+    auto stot = [&](int i) {
+        double s;
+        if (inv) { const int p = inv[i]; s = (p >= 0) ? y[p] : 0.0; }
+        else s = y[i];
+        return s + (scons ? scons[i] : 0.0);
+    };
+    double acc = 0.0;
+    if (cons == 0 || cons == 3) {
+        for (int i = tid; i < nout; i += 256) {
+            double x = stot(i);
+            if (cons == 3) x = (x + d1[i]) * w[i];
+            acc += x * x;
+        }
+        acc = wave_sum64(acc);
+    } else {
+        if (cons == 1) {
+            for (int at = tid; at < nout / 3; at += 256) {
+                double n2 = 0.0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { const double st = stot(3 * at + q); n2 += st * st; }
+                acc = fmax(acc, sqrt(n2));
+            }
+        } else {
+            for (int i = tid; i < nout; i += 256) acc = fmax(acc, fabs(stot(i) * w[i]));
+        }
+        for (int off = 32; off > 0; off >>= 1) acc = fmax(acc, __shfl_xor(acc, off));
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        if (cons == 0 || cons == 3) out[blockIdx.x] = sqrt(red[0] + red[1] + red[2] + red[3]);
+        else out[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    }
+}
+
 // Constraint measure of the total step and its derivative along the family, in ONE workgroup:
 //   stot = s + scons (written back to `stot`),  out[0] = val, out[1] = dval.
 //   cons 0: |stot|, dsda.stot / |stot|;   cons 3: the same for (stot + d1) * w and dsda * w;
@@ -433,17 +594,95 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         *dval = hres[1];
         return SELLA_OK;
     };
+    // ---- a tree of bisection midpoints in one round trip (kernels above) ------------------------------------------
+    // Candidates in heap order: node 1 = mid(lower, upper), node 2q = midpoint of the lower half of node q's bracket,
+    // node 2q + 1 of its upper half; computed with the reference's own expression 0.5 * (lower + upper).
+    constexpr int BATCH_LEVELS = 4, BATCH_NODES = (1 << BATCH_LEVELS) - 1;
+    const bool can_batch = !eig_only && !newton_safe && c->opt.rs_batch && (V->ld % 4 == 0) && m <= V->ld;
+    double* dbatch = nullptr;                  // lam | ghat | d1hat | X (16 x ld) | Y (16 x ldy) | inv
+    int ldb = 0;
+    bool batch_ready = false;
+    double cand[BATCH_NODES + 1], cval[BATCH_NODES + 1];
+    int nbatch = 0;
+    auto batch_setup = [&]() -> int {
+        ldb = V->ld;
+        const size_t need = (size_t)3 * ldx + (size_t)16 * ldb + (size_t)16 * ldy + (size_t)ldy + 64;
+        SCHK(scratch_get(c, SCR_STEP2, need * sizeof(double), &dbatch));
+        std::vector<double> pack((size_t)3 * ldx, 0.0);
+        std::copy(st->lam.begin(), st->lam.end(), pack.begin());
+        std::copy(st->ghat.begin(), st->ghat.end(), pack.begin() + ldx);
+        if ((int)st->d1hat.size() == m) std::copy(st->d1hat.begin(), st->d1hat.end(), pack.begin() + 2 * (size_t)ldx);
+        HIPCHK(hipMemcpyAsync(dbatch, pack.data(), pack.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemsetAsync(dbatch + 3 * (size_t)ldx, 0, (size_t)16 * ldb * sizeof(double), c->stream));
+        if (sel) {
+            std::vector<int> inv(nout, -1);
+            for (int i = 0; i < m; ++i) inv[sel[i]] = i;
+            HIPCHK(hipMemcpyAsync(dbatch + 3 * (size_t)ldx + (size_t)16 * ldb + (size_t)16 * ldy, inv.data(),
+                                  (size_t)nout * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));                       // `pack` and `inv` leave scope
+        batch_ready = true;
+        return SELLA_OK;
+    };
+    auto batch_evaluate = [&](double lower, double upper) -> int {
+        if (!batch_ready) SCHK(batch_setup());
+        double lo[BATCH_NODES + 1], hi[BATCH_NODES + 1];
+        lo[1] = lower; hi[1] = upper;
+        for (int q = 1; q <= BATCH_NODES; ++q) {
+            cand[q] = 0.5 * (lo[q] + hi[q]);
+            if (2 * q + 1 <= BATCH_NODES) {
+                lo[2 * q] = lo[q]; hi[2 * q] = cand[q];
+                lo[2 * q + 1] = cand[q]; hi[2 * q + 1] = hi[q];
+            }
+        }
+        RsBatchArgs ba;
+        ba.kind = st->kind; ba.m = m; ba.order = st->order; ba.ncand = BATCH_NODES; ba.ldx = ldb;
+        for (int q = 0; q < BATCH_NODES; ++q) ba.alpha[q] = cand[q + 1];
+        ba.alpha[15] = 0.0;
+        ba.lam = dbatch; ba.ghat = dbatch + ldx; ba.d1hat = dbatch + 2 * (size_t)ldx;
+        ba.X = dbatch + 3 * (size_t)ldx;
+        double* dY = ba.X + (size_t)16 * ldb;
+        const int* dinv = sel ? reinterpret_cast<const int*>(dY + (size_t)16 * ldy) : nullptr;
+        hipLaunchKernelGGL(rs_batch_kernel, dim3(BATCH_NODES), dim3(256), 0, c->stream, ba);
+        HIPCHK(hipGetLastError());
+        SCHK(launch_panel16(c, V->d, nfam, m, V->ld, ba.X, BATCH_NODES, dY, ldy));
+        hipLaunchKernelGGL(rs_measure_kernel, dim3(BATCH_NODES), dim3(256), 0, c->stream, cons, nout, dY, ldy, dscons, dw, dd1,
+                           dinv, hres + 2);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int q = 1; q <= BATCH_NODES; ++q) cval[q] = hres[1 + q];
+        ++nbatch;
+        return SELLA_OK;
+    };
     // ---- restricted_step.py:78-120 --------------------------------------------------------------------------------
     double alpha = alpha0, val = 0.0, dval = 0.0;
     SCHK(evaluate(alpha, &val, &dval));
     bool inside = val < delta;
+    bool stale = false;                        // the device no longer holds stot of the final alpha (batched evaluations)
     if (!inside) {
         double err = val - delta, lower = alphamin, upper = alphamax;
         bool converged = false;
+        int node = 0;                          // position in the current candidate tree (0: none)
         for (int niter = 0; niter < maxiter; ++niter) {
             if (fabs(err) <= tol) { converged = true; break; }
             if (nextafter(lower, upper) >= upper) { converged = true; break; }
             if (err * slope > 0.0) upper = alpha; else lower = alpha;
+            if (can_batch && niter > 4 && std::isfinite(lower) && std::isfinite(upper)) {
+                // pure bisection from here on: take this trial alpha from the tree, refilling it when exhausted
+                if (node == 0 || node > BATCH_NODES) {
+                    SCHK(batch_evaluate(lower, upper));
+                    node = 1;
+                }
+                alpha = cand[node];                                  // == 0.5 * (lower + upper)
+                val = cval[node];
+                err = val - delta;
+                if (alphas && ntrial <= maxiter) alphas[ntrial] = alpha;
+                ++ntrial;
+                stale = true;
+                // the next bracket update decides which child follows: upper = alpha -> lower half
+                node = 2 * node + ((err * slope > 0.0) ? 0 : 1);
+                continue;
+            }
             const double newton = alpha - err / dval;
             const bool bisect = (newton != newton) || newton <= lower || newton >= upper || (niter > 4 && !newton_safe);
             if (bisect) {
@@ -459,6 +698,12 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         if (!converged) {
             set_error("Restricted step failed to converge!");
             return SELLA_E_NOCONV;
+        }
+        if (stale) {
+            // s (and stot on the device) of the final alpha; not a trial of the schedule
+            const int keep = ntrial;
+            SCHK(evaluate(alpha, &val, &dval));
+            ntrial = keep;
         }
     }
     // ---- the step at the final alpha ------------------------------------------------------------------------------

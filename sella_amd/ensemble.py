@@ -128,17 +128,26 @@ class EnsemblePool:
     `initializer(*initargs)` runs first in every worker (the CPU tests use it to select the host emulation).  The
     workers are started with the `spawn` method — the HIP runtime of the parent must not be forked — and inherit the
     environment, so they open the same device as the parent (`LOCAL_RANK` / `SELLA_HIP_DEVICE`); their BLAS pools are
-    capped at (CPUs of this process) / P through `SELLA_HOST_THREADS`."""
+    capped at one thread each (`SELLA_POOL_HOST_THREADS` overrides).
+
+    Measured on one MI355X with 3N = 768 members (tools/ensemble_probe.py, profiles/r02_ensemble_pool.md): 24 searches/s
+    in one process, 45 with P = 2, 79 with P = 4, then DOWN again — 59 (P = 6), 41 (P = 8), 26 (P = 12): beyond four
+    client processes the device time-slices their queues instead of overlapping them (fewer hardware queues per
+    process, `GPU_MAX_HW_QUEUES`, does not help: 41 / 33 / 28 searches/s at P = 4 / 6 / 8 with one queue each).  Use
+    P <= 4 per GPU."""
+
+    BEST_PER_GPU = 4
 
     def __init__(self, processes, initializer=None, initargs=()):
         import multiprocessing as mp
-        from .utilities.hostcpu import effective_cpu_count
         self.processes = int(processes)
         if self.processes < 1:
             raise ValueError('EnsemblePool needs at least one process')
         mpc = mp.get_context('spawn')
         keep = os.environ.get('SELLA_HOST_THREADS')
-        os.environ['SELLA_HOST_THREADS'] = str(max(1, effective_cpu_count() // self.processes))
+        # one BLAS thread per worker unless told otherwise: the members are small, and idle pool threads spinning in
+        # P processes at once exhaust a container's CPU quota (utilities/hostcpu.py)
+        os.environ['SELLA_HOST_THREADS'] = os.environ.get('SELLA_POOL_HOST_THREADS', '1')
         self._workers = []
         try:
             for _ in range(self.processes):
@@ -149,7 +158,7 @@ class EnsemblePool:
                 self._workers.append((p, parent))
         finally:
             if keep is None:
-                del os.environ['SELLA_HOST_THREADS']
+                os.environ.pop('SELLA_HOST_THREADS', None)
             else:
                 os.environ['SELLA_HOST_THREADS'] = keep
         self.pids = [self._expect(conn) for _, conn in self._workers]

@@ -160,6 +160,7 @@ static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v;
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 
 // f64 MFMA 16x16x4, gfx950 layout (cdna_hip_programming.md §3):
 //   A: lane l holds A[i = l & 15][k = l >> 4];  B: lane l holds B[k = l >> 4][j = l & 15]

@@ -81,6 +81,30 @@ def test_alpha_trace_matches_oracle(ctx):
         np.testing.assert_allclose(dev.alphas[:m], ref.alpha_trace[:m], rtol=1e-6, atol=1e-12)
 
 
+def test_batched_bisection_matches_sequential(ctx):
+    """The bisection phase evaluated 15 trial alphas per round trip (`rs_batch`, csrc/stepper.hip) visits the same
+    alphas and returns the same step as one evaluation per round trip."""
+    from conftest import hessian_like
+    from sella_amd.linalg import ApproximateHessian
+    from sella_amd.optimize.restricted_step import get_restricted_step
+    for n, ncons, order, method in ((30, 0, 1, 'prfo'), (45, 3, 1, 'prfo'), (33, 0, 0, 'rfo'), (36, 2, 2, 'prfo')):
+        A, P, gvec = hessian_like(n, seed=7 + n, nneg=max(order, 1))
+        out = {}
+        for flag in (0, 1):
+            ctx.set_option('rs_batch', flag)
+            rs = get_restricted_step('ras')(FakePES(ApproximateHessian, P, gvec, ncons, 1), order, 0.03, method)
+            s, smag = rs.get_s()
+            out[flag] = (s, smag, np.array(rs.alphas))
+        ctx.set_option('rs_batch', 1)
+        (s0, m0, a0), (s1, m1, a1) = out[0], out[1]
+        assert len(a0) > 20                                      # the schedule did reach its bisection phase
+        assert abs(len(a0) - len(a1)) <= 1
+        k = min(len(a0), len(a1)) - 2                            # the last levels sit in the rounding noise of val
+        np.testing.assert_allclose(a1[:k], a0[:k], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(s1, s0, atol=1e-12 * max(1.0, np.abs(s0).max()))
+        assert m0 == m1
+
+
 def test_registry_and_errors(ctx):
     from sella_amd.optimize.restricted_step import (MaxInternalStep, RestrictedAtomicStep, TrustRegion,
                                                     get_restricted_step)

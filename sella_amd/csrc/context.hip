@@ -111,13 +111,47 @@ int scratch_get(sella_ctx* c, int slot, size_t bytes, double** p) {
 
 // Host (n x k) row-major  <->  device panel of k rows (vector-major).  The transposition is
 // done on the host side of the copy (n*k doubles, negligible next to the n^2 streams).
+// Host-to-device copy of CALLER memory that does not wait: a hipMemcpyAsync from pageable memory is staged
+// synchronously by the runtime (20-100 us each on the optimizer's per-step paths), so the payload is copied into a
+// pinned ring first and the DMA reads from there.  The source may be reused at once.  The ring is only rewound behind a
+// stream synchronisation, so a slot is never overwritten while a copy that reads it is still queued.
+static constexpr size_t H2D_RING_BYTES = (size_t)8 << 20;
+
+int h2d_async(sella_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return SELLA_OK;
+    if (!c->hring) {
+        void* p = nullptr;
+        HIPCHK(hipHostMalloc(&p, H2D_RING_BYTES, hipHostMallocDefault));
+        c->hring = static_cast<char*>(p);
+        c->hring_bytes = H2D_RING_BYTES;
+        c->hring_pos = 0;
+    }
+    if (bytes > c->hring_bytes / 2) {                       // large payloads: the runtime's own staging
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));            // the source may be a temporary of the caller
+        return SELLA_OK;
+    }
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (c->hring_pos + need > c->hring_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->hring_pos = 0;
+    }
+    char* slot = c->hring + c->hring_pos;
+    memcpy(slot, src, bytes);
+    HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+    c->hring_pos += need;
+    return SELLA_OK;
+}
+
+// X is n x k row-major (k vectors as columns); the device panel holds them as k rows of stride ldp.  Stream-ordered:
+// returns without waiting.
 int upload_panel(sella_ctx* c, const double* X, int n, int k, double* dpanel, int ldp) {
+    if (k == 1) return h2d_async(c, dpanel, X, (size_t)n * sizeof(double));
     std::vector<double> tmp((size_t)k * n);
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < k; ++j) tmp[(size_t)j * n + i] = X[(size_t)i * k + j];
-    HIPCHK(hipMemcpy2DAsync(dpanel, (size_t)ldp * sizeof(double), tmp.data(), (size_t)n * sizeof(double),
-                            (size_t)n * sizeof(double), k, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (ldp == n) return h2d_async(c, dpanel, tmp.data(), tmp.size() * sizeof(double));
+    for (int j = 0; j < k; ++j) SCHK(h2d_async(c, dpanel + (size_t)j * ldp, tmp.data() + (size_t)j * n, (size_t)n * sizeof(double)));
     return SELLA_OK;
 }
 
@@ -271,6 +305,7 @@ int sella_ctx_destroy(sella_ctx* c) {
     if (c->dscal) (void)hipFree(c->dscal);
     if (c->hscal) (void)hipHostFree(c->hscal);
     if (c->hstage) (void)hipHostFree(c->hstage);
+    if (c->hring) (void)hipHostFree(c->hring);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return SELLA_OK;

@@ -562,8 +562,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         }
         double* dev;
         SCHK(scratch_get(c, SCR_C, (size_t)s.ld * sizeof(double), &dev));
-        HIPCHK(hipMemcpyAsync(dev, pevals, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(h2d_async(c, dev, pevals, (size_t)n * sizeof(double)));
         s.pevals_dev = dev;
     }
     if (maxiter <= 0) maxiter = 2 * n + 1;

@@ -1443,13 +1443,12 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
                     const int rlo = std::min(rowof(ip), rowof(j));
                     for (int t = ip; t <= j; ++t) vh[rowof(t) - rlo] = zz[t] - ((t == j) ? beta : 0.0);
                     const double tau = 2.0 / vtv;
-                    HIPCHK(hipMemcpyAsync(vdev, vh.data(), (size_t)len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+                    SCHK(h2d_async(c, vdev, vh.data(), (size_t)len * sizeof(double)));
                     double* R = Vt + (size_t)rlo * ld;
                     SCHK(launch_gemv_cols(c, R, len, n, ld, vdev, ld, 1, wvd, ld));
                     hipLaunchKernelGGL(rows_ger_kernel, dim3((n + 255) / 256, len), dim3(256), 0, c->stream, R, ld, len, n,
                                        vdev, wvd, tau);
                     HIPCHK(hipGetLastError());
-                    HIPCHK(hipStreamSynchronize(c->stream));     // vh is reused by the next cluster
                     for (int t = ip; t < j; ++t) zz[t] = 0.0;
                     zz[j] = beta;
                 }

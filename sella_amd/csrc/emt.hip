@@ -142,9 +142,9 @@ extern "C" int sella_emt_eval(sella_ctx* c, int n, const double* pos, const doub
     double* dde = dep + n;
     double* dea = dde + n;
     double* dgr = dea + n;
-    HIPCHK(hipMemcpyAsync(dpos, pos, (size_t)3 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dpar, par, (size_t)9 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dsh, shifts, (size_t)3 * nshift * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    SCHK(h2d_async(c, dpos, pos, (size_t)3 * n * sizeof(double)));
+    SCHK(h2d_async(c, dpar, par, (size_t)9 * n * sizeof(double)));
+    SCHK(h2d_async(c, dsh, shifts, (size_t)3 * nshift * sizeof(double)));
     EmtArgs a;
     a.n = n; a.nshift = nshift; a.pos = dpos; a.shifts = dsh;
     a.p.E0 = dpar; a.p.s0 = dpar + n; a.p.V0 = dpar + 2 * (size_t)n; a.p.eta2 = dpar + 3 * (size_t)n;

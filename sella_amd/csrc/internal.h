@@ -132,6 +132,8 @@ struct sella_ctx {
     // synchronous staged copies, ~20 us each with the queue empty
     void* hstage = nullptr;
     size_t hstage_bytes = 0;
+    char* hring = nullptr;          // pinned ring behind h2d_async
+    size_t hring_bytes = 0, hring_pos = 0;
 };
 
 namespace sella {
@@ -145,6 +147,7 @@ int dev_alloc(sella_ctx* c, size_t bytes, double** p);             // caching al
 void dev_free(sella_ctx* c, double* p, size_t bytes);
 int upload_panel(sella_ctx* c, const double* X, int n, int k, double* dpanel, int ldp);   // (n x k) host -> k rows
 int download_panel(sella_ctx* c, const double* dpanel, int ldp, int n, int k, double* X); // k rows -> (n x k) host
+int h2d_async(sella_ctx* c, void* dst, const void* src, size_t bytes);   // caller memory -> device, no wait (pinned ring)
 int read_scalars(sella_ctx* c, int offset, int count);             // dscal -> hscal (sync)
 // Where a kernel should put scalars that only the HOST consumes next: with `host_scalars` on, the pinned,
 // device-visible host mirror itself (zero-copy: the readback is then just the stream synchronisation and the

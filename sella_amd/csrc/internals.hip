@@ -201,9 +201,9 @@ extern "C" int sella_internals_eval(sella_ctx* c, int natoms, int nc, const doub
     double* dgrad = dq + nc;
     double* dhvp = dgrad + (size_t)nc * nv;
     double* dhess = dhvp + (size_t)nc * nv;
-    HIPCHK(hipMemcpyAsync(dpos, pos, (size_t)nc * nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (tvec) HIPCHK(hipMemcpyAsync(dtv, tvec, (size_t)nc * ntv * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (tangent) HIPCHK(hipMemcpyAsync(dtan, tangent, (size_t)nc * nv * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    SCHK(h2d_async(c, dpos, pos, (size_t)nc * nv * sizeof(double)));
+    if (tvec) SCHK(h2d_async(c, dtv, tvec, (size_t)nc * ntv * sizeof(double)));
+    if (tangent) SCHK(h2d_async(c, dtan, tangent, (size_t)nc * nv * sizeof(double)));
     const double* atv = tvec ? dtv : nullptr;
     const double* atan_ = tangent ? dtan : nullptr;
     int st;

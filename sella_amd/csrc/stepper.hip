@@ -35,11 +35,15 @@ namespace {
 typedef std::vector<double> vec;
 
 // RFO step in the eigenbasis for a block (lam, ghat) of size mm, eigenpair index `o` of the
-// augmented matrix (stepper.py:128-157).  Outputs shat, dshat (mm).
-void rfo_block(int mm, const double* lam, const double* ghat, int o, double alpha, double* shat,
-               double* dshat) {
-    if (mm == 0) return;
-    vec D(mm), b(mm), vh(mm + 1), c1(mm + 1), xp(mm + 1);
+// augmented matrix (stepper.py:128-157).  Outputs shat, dshat (mm).  dshat == nullptr: the step only (the bisection
+// phase of the trust-radius search never looks at ds/dalpha).  shat == nullptr as well: nothing is written and
+// |shat|^2 is returned — for a unit-norm eigenvector (y, 1) / sqrt(1 + |y|^2) the step is alpha y, so its norm is
+// alpha |y| and costs one pass behind the root find.
+double rfo_block(int mm, const double* lam, const double* ghat, int o, double alpha, double* shat,
+                 double* dshat) {
+    if (mm == 0) return 0.0;
+    static thread_local vec D, b, vh, c1, xp;            // ~50 calls per optimizer step: no allocation per call
+    D.resize(mm); b.resize(mm); vh.resize(mm + 1); c1.resize(mm + 1); xp.resize(mm + 1);
     for (int i = 0; i < mm; ++i) { D[i] = alpha * alpha * lam[i]; b[i] = alpha * ghat[i]; }
     int org;
     double tau;
@@ -57,19 +61,32 @@ void rfo_block(int mm, const double* lam, const double* ghat, int o, double alph
     if (degenerate) {
         // mu coincides with a pole (b_i = 0 there): the eigenvector is e_i, its last component is
         // zero and the reference clamps the denominator at 1e-12 (stepper.py:134-136)
+        if (!shat) return (alpha / 1e-12) * (alpha / 1e-12);
         int ip = 0;
         for (int i = 0; i < mm; ++i) if (tau - (D[i] - shift) == 0.0) { ip = i; break; }
-        for (int i = 0; i < mm; ++i) { shat[i] = 0.0; dshat[i] = 0.0; }
+        for (int i = 0; i < mm; ++i) shat[i] = 0.0;
         shat[ip] = alpha / 1e-12;
-        dshat[ip] = 1.0 / 1e-12;
-        return;
+        if (dshat) {
+            for (int i = 0; i < mm; ++i) dshat[i] = 0.0;
+            dshat[ip] = 1.0 / 1e-12;
+        }
+        return shat[ip] * shat[ip];
+    }
+    if (!shat) {
+        const double invn = 1.0 / sqrt(nrm2);
+        double dn = invn;
+        if (fabs(dn) < 1e-12) dn = 1e-12;
+        const double f = invn * alpha / dn;              // shat_i = y_i * f
+        return f * f * (nrm2 - 1.0);
     }
     const double inv = 1.0 / sqrt(nrm2);
     for (int i = 0; i < mm; ++i) vh[i] *= inv;
     vh[mm] = inv;
     double den = vh[mm];
     if (fabs(den) < 1e-12) den = 1e-12;
-    for (int i = 0; i < mm; ++i) shat[i] = vh[i] * alpha / den;
+    double ss = 0.0;
+    for (int i = 0; i < mm; ++i) { shat[i] = vh[i] * alpha / den; ss += shat[i] * shat[i]; }
+    if (!dshat) return ss;
     // c = dA/dalpha v : dA = [[2 alpha lam, ghat], [ghat^T, 0]]
     double last = 0.0;
     for (int i = 0; i < mm; ++i) {
@@ -93,6 +110,7 @@ void rfo_block(int mm, const double* lam, const double* ghat, int o, double alph
     for (int i = 0; i <= mm; ++i) xp[i] -= vx * vh[i];
     for (int i = 0; i < mm; ++i)
         dshat[i] = vh[i] / den + (alpha / den) * xp[i] - (vh[i] * alpha / (den * den)) * xp[mm];
+    return ss;
 }
 
 }  // namespace
@@ -143,33 +161,39 @@ extern "C" int sella_stepper_create(sella_ctx* c, int kind, sella_mat hV, sella_
     return SELLA_OK;
 }
 
-// (shat, dshat) of one trial alpha in the eigenbasis — O(m) host arithmetic
-static void eval_hat(const sella_stepper* st, double alpha, double* shat, double* dshat) {
+// (shat, dshat) of one trial alpha in the eigenbasis — O(m) host arithmetic.  Returns |shat|^2; dshat (and, for the
+// RFO families, shat as well) may be null when only that is wanted.
+static double eval_hat(const sella_stepper* st, double alpha, double* shat, double* dshat) {
     const int m = st->m, o = st->order;
     const double* lam = st->lam.data();
     const double* gh = st->ghat.data();
+    double ss = 0.0;
     if (st->kind == SELLA_STEP_QN) {                                        // stepper.py:82-96
         for (int i = 0; i < m; ++i) {
             const double sgn = (i < o) ? -1.0 : 1.0;
             const double den = sgn * fabs(lam[i]) + alpha * sgn;
             const double sp = gh[i] / den;
-            shat[i] = -sp;
-            dshat[i] = sp / den;
+            ss += sp * sp;
+            if (shat) shat[i] = -sp;
+            if (dshat) dshat[i] = sp / den;
         }
     } else if (st->kind == SELLA_STEP_QN_IRC) {                             // stepper.py:99-111
         const double* dh = st->d1hat.data();
         for (int i = 0; i < m; ++i) {
             const double den = fabs(lam[i]) + alpha;
             const double sp = -(gh[i] + alpha * dh[i]) / den;
-            shat[i] = sp;
-            dshat[i] = -(sp + dh[i]) / den;
+            ss += sp * sp;
+            if (shat) shat[i] = sp;
+            if (dshat) dshat[i] = -(sp + dh[i]) / den;
         }
     } else if (st->kind == SELLA_STEP_RFO) {
-        sella::rfo_block(m, lam, gh, o, alpha, shat, dshat);
+        ss = sella::rfo_block(m, lam, gh, o, alpha, shat, dshat);
     } else {                                                                // P-RFO, stepper.py:163-185
-        sella::rfo_block(o, lam, gh, o, alpha, shat, dshat);                       // max block: top root
-        sella::rfo_block(m - o, lam + o, gh + o, 0, alpha, shat + o, dshat + o);   // min block: lowest root
+        ss = sella::rfo_block(o, lam, gh, o, alpha, shat, dshat);                               // max block: top root
+        ss += sella::rfo_block(m - o, lam + o, gh + o, 0, alpha, shat ? shat + o : nullptr,    // min block: lowest root
+                               dshat ? dshat + o : nullptr);
     }
+    return ss;
 }
 
 extern "C" int sella_stepper_get_s(sella_stepper* st, double alpha, double* s_out, double* dsda_out) {
@@ -529,17 +553,16 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     double* dsfull = dv + 4 * (size_t)ldy;
     double* ddfull = dv + 5 * (size_t)ldy;
     int* dsel = sel ? reinterpret_cast<int*>(dv + 6 * (size_t)ldy) : nullptr;
-    if (sel) HIPCHK(hipMemcpyAsync(dsel, sel, (size_t)m * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (sel) SCHK(h2d_async(c, dsel, sel, (size_t)m * sizeof(int)));
     const bool eig_only = orthonormal && cons == 0;
     std::vector<double> chat;                 // V^T scons (eigenbasis measure)
     double scons2 = 0.0;
     if (scons) {
         for (int i = 0; i < nout; ++i) scons2 += scons[i] * scons[i];
-        HIPCHK(hipMemcpyAsync(dscons, scons, (size_t)nout * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        SCHK(h2d_async(c, dscons, scons, (size_t)nout * sizeof(double)));
     }
-    if (w) HIPCHK(hipMemcpyAsync(dw, w, (size_t)nout * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (d1) HIPCHK(hipMemcpyAsync(dd1, d1, (size_t)nout * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (w) SCHK(h2d_async(c, dw, w, (size_t)nout * sizeof(double)));
+    if (d1) SCHK(h2d_async(c, dd1, d1, (size_t)nout * sizeof(double)));
     if (eig_only && scons && scons2 > 0.0) {
         Mat* Vt = mat_get(c, st->Vt);
         if (!Vt) return SELLA_E_INVALID;
@@ -561,11 +584,42 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     double* shat = sh.data();
     double* dshat = sh.data() + m;
     int ntrial = 0;
+    bool hat_stale = false;                   // shat on the host does not belong to the last trial alpha
     // one trial alpha -> (val, dval); leaves [shat | dshat] on the host and (unless eig_only) stot on the device
-    auto evaluate = [&](double alpha, double* val, double* dval) -> int {
-        eval_hat(st, alpha, shat, dshat);
+    // value_only: the caller is in the pure-bisection phase and ignores dval (restricted_step.py:100-110)
+    auto evaluate = [&](double alpha, double* val, double* dval, bool value_only = false) -> int {
         if (alphas && ntrial <= maxiter) alphas[ntrial] = alpha;
         ++ntrial;
+        const auto th0 = std::chrono::steady_clock::now();
+        struct HostTime {                      // SELLA_DEBUG_TIMING: host arithmetic up to `mark`, the rest is the device round trip
+            sella_stepper* st; std::chrono::steady_clock::time_point a, mark;
+            ~HostTime() {
+                st->t_host += std::chrono::duration<double>(mark - a).count();
+                st->t_dev += std::chrono::duration<double>(std::chrono::steady_clock::now() - mark).count();
+            }
+        } ht{st, th0, th0};
+        const long sw0 = bordered::g_sweeps;
+        if (eig_only && value_only) {
+            // |s + scons|^2 = |shat|^2 + 2 shat.chat + |scons|^2 in the orthonormal eigenbasis; without a constraint
+            // correction the step vector itself is not needed
+            double ss;
+            if (chat.empty()) {
+                ss = scons2 + eval_hat(st, alpha, nullptr, nullptr);
+            } else {
+                ss = scons2 + eval_hat(st, alpha, shat, nullptr);
+                for (int i = 0; i < m; ++i) ss += 2.0 * shat[i] * chat[i];
+            }
+            *val = sqrt(ss > 0.0 ? ss : 0.0);
+            *dval = 0.0;
+            hat_stale = true;
+            ht.mark = std::chrono::steady_clock::now();
+            st->sweeps += bordered::g_sweeps - sw0;
+            return SELLA_OK;
+        }
+        eval_hat(st, alpha, shat, dshat);
+        hat_stale = false;
+        ht.mark = std::chrono::steady_clock::now();
+        st->sweeps += bordered::g_sweeps - sw0;
         if (eig_only) {
             double ss = scons2, sd = 0.0;
             for (int i = 0; i < m; ++i) {
@@ -612,15 +666,14 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         std::copy(st->lam.begin(), st->lam.end(), pack.begin());
         std::copy(st->ghat.begin(), st->ghat.end(), pack.begin() + ldx);
         if ((int)st->d1hat.size() == m) std::copy(st->d1hat.begin(), st->d1hat.end(), pack.begin() + 2 * (size_t)ldx);
-        HIPCHK(hipMemcpyAsync(dbatch, pack.data(), pack.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        SCHK(h2d_async(c, dbatch, pack.data(), pack.size() * sizeof(double)));
         HIPCHK(hipMemsetAsync(dbatch + 3 * (size_t)ldx, 0, (size_t)16 * ldb * sizeof(double), c->stream));
         if (sel) {
             std::vector<int> inv(nout, -1);
             for (int i = 0; i < m; ++i) inv[sel[i]] = i;
-            HIPCHK(hipMemcpyAsync(dbatch + 3 * (size_t)ldx + (size_t)16 * ldb + (size_t)16 * ldy, inv.data(),
-                                  (size_t)nout * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            SCHK(h2d_async(c, dbatch + 3 * (size_t)ldx + (size_t)16 * ldb + (size_t)16 * ldy, inv.data(),
+                           (size_t)nout * sizeof(int)));
         }
-        HIPCHK(hipStreamSynchronize(c->stream));                       // `pack` and `inv` leave scope
         batch_ready = true;
         return SELLA_OK;
     };
@@ -692,18 +745,20 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
             } else {
                 alpha = newton;
             }
-            SCHK(evaluate(alpha, &val, &dval));
+            SCHK(evaluate(alpha, &val, &dval, niter >= 4 && !newton_safe));
             err = val - delta;
         }
         if (!converged) {
             set_error("Restricted step failed to converge!");
             return SELLA_E_NOCONV;
         }
-        if (stale) {
+        if (stale || hat_stale) {
             // s (and stot on the device) of the final alpha; not a trial of the schedule
             const int keep = ntrial;
+            const double vkeep = val;
             SCHK(evaluate(alpha, &val, &dval));
             ntrial = keep;
+            val = vkeep;
         }
     }
     // ---- the step at the final alpha ------------------------------------------------------------------------------

@@ -195,13 +195,12 @@ int gram(sella_ctx* c, const double* P, int ka, const double* Q, int kb, int n, 
     return SELLA_OK;
 }
 
-// device copy of a small host matrix in the SCR_W scratch (synchronous; k x k only)
+// device copy of a small host matrix in the SCR_W scratch (stream-ordered, no wait; k x k only)
 int put_k(sella_ctx* c, const vec& h, size_t offset, double** d) {
     double* base;
     SCHK(scratch_get(c, SCR_W, (size_t)(1 << 16) * sizeof(double), &base));
     if (offset + h.size() > (size_t)(1 << 16)) { set_error("update: coefficient buffer overflow"); return SELLA_E_UNSUPPORTED; }
-    HIPCHK(hipMemcpyAsync(base + offset, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(h2d_async(c, base + offset, h.data(), h.size() * sizeof(double)));
     *d = base + offset;
     return SELLA_OK;
 }
@@ -282,6 +281,22 @@ __global__ __launch_bounds__(256) void gather_cols_kernel(const double* __restri
     if (i < m && r < rows) out[(size_t)r * ldo + i] = P[(size_t)r * ldp + idx[i]];
 }
 
+// k = 1 TS-BFGS (the per-step quasi-Newton update): the three scalars of hessian_update.py:120-126 stay on the
+// device.  in: d[0] = s.ytilde, d[1] = s.|B|s, d[2] = j.s;  out: coef[0], coef[1] = pinv(G) [M1, M2] with
+// G = M1^2 + M2^2, coef[2] = -1/2 sym(J^T S).  Same operations in the same order as the host k x k code.
+__global__ void tsbfgs_k1_coef_kernel(const double* __restrict__ d, double* __restrict__ coef) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double m1 = d[0], m2 = d[1];
+    const double g = m1 * m1 + m2 * m2;
+    const double gp = (fabs(g) <= 2.220446049250313e-16 * fabs(g)) ? 0.0 : 1.0 / g;      // sym_pinv_solve's cut, m = 1
+    coef[0] = gp * m1;
+    coef[1] = gp * m2;
+    coef[2] = -0.25 * (d[2] + d[2]);
+}
+
 static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt, const double* evals,
                          const double* S, const double* Y, int n, int k, int method, int symm,
                          double* evals_io, int max_rank, int* nrank1, const SubView* sv = nullptr) {
@@ -336,6 +351,7 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
     }
 
     int kk = k;
+    bool uz_done = false;                    // U and Z already formed on the device (k = 1 TS-BFGS)
     auto panel_times = [&](const hostm::vec& M, const double* P, double* out, size_t off) -> int {
         // out_a = sum_b M[a][b] P_b   (k x k times a k-row panel)
         hostm::vec Mt((size_t)k * k);
@@ -389,8 +405,7 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
                 if (!V || !Vt || !evals) { set_error("TS-BFGS needs evecs, evecsT and evals"); return SELLA_E_INVALID; }
                 double* dev;
                 SCHK(scratch_get(c, SCR_C, (size_t)ld * sizeof(double), &dev));
-                HIPCHK(hipMemcpyAsync(dev, evals, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-                HIPCHK(hipStreamSynchronize(c->stream));
+                SCHK(h2d_async(c, dev, evals, (size_t)n * sizeof(double)));
                 GemvEpi e;
                 e.mode = 3;
                 e.dvec = dev;
@@ -399,7 +414,23 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
             }
             // X = X1 + X2 = M1 Ytilde^T + M2 absBS^T with M1 = S^T Ytilde, M2 = S^T absBS  (k x n)
             // G = X S = M1 M1^T + M2 M2^T ;  U^T = pinv(G) X                  hessian_update.py:120-123
+            if (k == 1) {
+                // one secant pair: no host round trip (three dots, one single-thread kernel, two combinations)
+                double* dd = c->dscal + DS_CVEC;
+                double* dcoef;
+                SCHK(scratch_get(c, SCR_W, (size_t)(1 << 16) * sizeof(double), &dcoef));
+                SCHK(launch_gemv_rows(c, Ytp, 1, n, ld, Sp, ld, 1, dd, 1, GemvEpi()));
+                SCHK(launch_gemv_rows(c, absBS, 1, n, ld, Sp, ld, 1, dd + 1, 1, GemvEpi()));
+                SCHK(launch_gemv_rows(c, Jp, 1, n, ld, Sp, ld, 1, dd + 2, 1, GemvEpi()));
+                hipLaunchKernelGGL(tsbfgs_k1_coef_kernel, dim3(1), dim3(64), 0, c->stream, dd, dcoef);
+                HIPCHK(hipGetLastError());
+                SCHK(launch_lincomb(c, n, 1, Ytp, ld, 1, dcoef, 1, absBS, ld, 1, dcoef + 1, 1, 0.0, Up, ld));
+                SCHK(launch_axpby2d(c, 1, n, 1.0, Jp, ld, 0.0, nullptr, 0, Zp, ld));
+                SCHK(launch_lincomb(c, n, 1, Up, ld, 1, dcoef + 2, 1, nullptr, 0, 0, nullptr, 0, 1.0, Zp, ld));
+                uz_done = true;
+            }
             hostm::vec M1, M2, G((size_t)k * k, 0.0), Gp, C1((size_t)k * k), C2((size_t)k * k);
+            if (!uz_done) {
             SCHK(gram(c, Sp, k, Ytp, k, n, ld, M1));
             SCHK(gram(c, Sp, k, absBS, k, n, ld, M2));
             for (int a = 0; a < k; ++a)
@@ -426,6 +457,7 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
             SCHK(put_k(c, C2, (size_t)k * k, &d2));
             // Up cannot alias its inputs: absBS lives in Zp, Ytp is separate; write U into Up
             SCHK(launch_lincomb(c, n, k, Ytp, ld, k, d1, k, absBS, ld, k, d2, k, 0.0, Up, ld));
+            }
         } else if (method == SELLA_UPD_PSB) {                                   // U = S (S^T S)^-1
             SCHK(gram(c, Sp, k, Sp, k, n, ld, STS));
             if (!invert(k, STS, Minv)) { set_error("PSB update: singular S^T S"); return SELLA_E_NOCONV; }
@@ -441,6 +473,7 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
             SCHK(panel_times(Minv, BSp, Up, 0));
         }
         // Z = J - 1/2 sym(J^T S) U
+        if (!uz_done) {
         SCHK(gram(c, Jp, k, Sp, k, n, ld, C));
         hostm::vec Cs((size_t)k * k);
         for (int a = 0; a < k; ++a)
@@ -453,6 +486,7 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
         double* dC;
         SCHK(put_k(c, CsT, 2 * (size_t)k * k, &dC));
         SCHK(launch_lincomb(c, n, k, Up, ld, k, dC, k, nullptr, 0, 0, nullptr, 0, 1.0, Zp, ld));
+        }
     }
     const double t_u1 = now();
     B = mat_get(c, hB);
@@ -473,7 +507,7 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
         Us = wks;
         Zs = wks + (size_t)kk * lds;
         int* didx = reinterpret_cast<int*>(wks + 2 * (size_t)kk * lds);
-        HIPCHK(hipMemcpyAsync(didx, sv->idx, (size_t)m * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        SCHK(h2d_async(c, didx, sv->idx, (size_t)m * sizeof(int)));
         HIPCHK(hipMemsetAsync(wks, 0, (size_t)2 * kk * lds * sizeof(double), c->stream));
         const dim3 gg((m + 255) / 256, kk);
         hipLaunchKernelGGL(gather_cols_kernel, gg, dim3(256), 0, c->stream, Up, ld, kk, didx, m, Us, lds);

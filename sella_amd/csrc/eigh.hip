@@ -1264,7 +1264,10 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     int cur = 0, nblkA_prev = 0, nblkB_prev = 0;
     for (int j0 = 0; j0 < nrefl; j0 += nb) {
         const int kb = std::min(nb, nrefl - j0);
-        HIPCHK(hipMemsetAsync(Vp, 0, (size_t)2 * TRD_NBMAX * ld * sizeof(double), c->stream));
+        // only the kb rows of each half that this panel uses (the scratch is shared: stale pad columns must not
+        // reach the products as 0 * inf)
+        HIPCHK(hipMemsetAsync(Vp, 0, (size_t)kb * ld * sizeof(double), c->stream));
+        HIPCHK(hipMemsetAsync(Wp, 0, (size_t)kb * ld * sizeof(double), c->stream));
         for (int i = 0; i <= kb; ++i) {
             const int j = j0 + i;
             const bool do_row = i < kb;

@@ -38,6 +38,11 @@ def make_context(request, backend):
         _lib._set_library_for_tests(None)
     c = device.Context(0)
     c.backend = backend
+    if backend == 'emu':
+        # the batched trial-alpha kernels are one workgroup per candidate with a barrier per secular sweep — minutes of
+        # fibre switching per optimizer run in the emulation; they have their own tests (test_step_solve.py) and are the
+        # default on the device
+        c.set_option('rs_batch', 0)
     device._default = c
     yield c
     device._default = None

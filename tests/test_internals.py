@@ -125,3 +125,17 @@ def test_internal_coordinates_container(ctx):
     # translation of the whole slab leaves every internal coordinate unchanged: B t = 0
     t = np.tile([0.3, -0.2, 0.5], len(slab))
     np.testing.assert_allclose(B @ t, 0.0, atol=1e-12)
+
+
+def test_uploads_survive_the_pinned_ring_wrapping(ctx):
+    """Host-to-device copies go through an 8 MB pinned ring that is rewound behind a synchronisation
+    (csrc/context.hip `h2d_async`): far more than 8 MB of distinct payloads, every result still right."""
+    rng = np.random.RandomState(5)
+    nc = 30000                                              # 30000 bonds x 6 doubles = 1.4 MB per call
+    for it in range(14):
+        pos = rng.normal(size=(nc, 2, 3))
+        q, grad, _, _ = ctx.internals_eval(pos)
+        d = pos[:, 1] - pos[:, 0]
+        r = np.linalg.norm(d, axis=1)
+        np.testing.assert_allclose(q, r, rtol=1e-14)
+        np.testing.assert_allclose(grad[:, 1], d / r[:, None], rtol=1e-13, atol=1e-15)

@@ -11,7 +11,7 @@
 namespace sella {
 namespace bordered {
 
-inline long g_sweeps = 0;      // SELLA_DEBUG_TIMING statistics only (not thread-exact)
+inline thread_local long g_sweeps = 0;      // SELLA_DEBUG_TIMING statistics (one context per host thread)
 
 // Root number j (ascending, 0..mm) of f(mu) = mu + sum b_i^2 / (D_i - mu), D ascending.
 // Returned as (origin, tau): mu = D_origin + tau with the origin the closer pole

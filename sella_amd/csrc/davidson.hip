@@ -98,6 +98,12 @@ void dav_free(Dav& s) {
 
 // Device copy of a small host array through one of three pinned staging slots (a slot is not
 // re-used before the next host synchronisation, of which there is at least one per iteration).
+// pscale - theta with the exact-hit guard of the eigenbasis epilogue (kernels.hip, GemvEpi mode 1)
+inline double guarded_shift(double d, double theta) {
+    const double den = d - theta;
+    return den != 0.0 ? den : 2.220446049250313e-16 * fmax(fabs(theta), 2.2250738585072014e-308);
+}
+
 int put_small(Dav& s, const double* h, int count, int stage, size_t dev_offset, double** dptr) {
     sella_ctx* c = s.c;
     double* base;
@@ -138,7 +144,7 @@ int apply_pinv(Dav& s, double theta, const double* in, int m, double* mid, doubl
     sella_ctx* c = s.c;
     if (s.Q == nullptr) {
         for (int h = 0; h < m; ++h)
-            SCHK(launch_axpby(c, s.n, 1.0 / (s.pscale - theta), in + (size_t)h * s.ld, 0.0, nullptr,
+            SCHK(launch_axpby(c, s.n, 1.0 / guarded_shift(s.pscale, theta), in + (size_t)h * s.ld, 0.0, nullptr,
                               out + (size_t)h * s.ld));
         return SELLA_OK;
     }
@@ -155,7 +161,7 @@ int apply_pinv_xp(Dav& s, double theta, const double* const* in, int m, double* 
     sella_ctx* c = s.c;
     if (s.Q == nullptr) {
         for (int h = 0; h < m; ++h)
-            SCHK(launch_axpby(c, s.n, 1.0 / (s.pscale - theta), in[h], 0.0, nullptr, out + (size_t)h * s.ld));
+            SCHK(launch_axpby(c, s.n, 1.0 / guarded_shift(s.pscale, theta), in[h], 0.0, nullptr, out + (size_t)h * s.ld));
         return SELLA_OK;
     }
     GemvEpi e;

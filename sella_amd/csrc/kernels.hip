@@ -85,7 +85,13 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
         const int rr = row0 + r;
         if (rr < rows) {
             double v = epi.alpha * (red[0][r][h] + red[1][r][h] + red[2][r][h] + red[3][r][h]);
-            if (epi.mode == 1) v = v / (epi.dvec[rr] - epi.theta);
+            if (epi.mode == 1) {
+                // (P - theta I)^-1 in P's eigenbasis; a shift that hits an eigenvalue exactly (the reference's LU solve
+                // raises LinAlgError there) gets the denominator a nearly singular solve would see instead of 1 / 0
+                double den = epi.dvec[rr] - epi.theta;
+                if (den == 0.0) den = 2.220446049250313e-16 * fmax(fabs(epi.theta), 2.2250738585072014e-308);
+                v = v / den;
+            }
             else if (epi.mode == 2) v += epi.beta * Y[(size_t)h * ldy + rr];
             else if (epi.mode == 3) v *= fabs(epi.dvec[rr]);
             Y[(size_t)h * ldy + rr] = v;

@@ -56,7 +56,8 @@ int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
  *   gemv_rw (2) rows per wavefront of the streaming matvec | gemm_mfma (1) GEMMs on the matrix cores |
  *   gemm_tile128 (1) 128x128 GEMM tiles for large products | panel_mfma (1), panel_rows (0 = by size) the
  *   H.V block product | host_scalars (0) zero-copy scalars | rank2k_stream (1) mirror-free trailing update |
- *   eigh_nb (16) panel width, eigh_leaf (32) leaf size, eigh_wy_mfma (1) MFMA back-transformation.            */
+ *   eigh_nb (16) panel width, eigh_leaf (32) leaf size, eigh_wy_mfma (1) MFMA back-transformation |
+ *   rs_batch (1) bisection phase of sella_restricted_step: 15 trial alphas per device round trip.               */
 int sella_ctx_set_option(sella_ctx* ctx, const char* key, long value);
 
 /* ---- device matrices --------------------------------------------------------------- */
@@ -235,7 +236,10 @@ int sella_stepper_set_d1hat(sella_stepper* st, const double* d1hat, int m);
  *         space (projection basis = columns of the identity, constraints that pin single coordinates); scons, w, d1,
  *         the measure and the returned step are then nfull-dimensional.  NULL / 0 otherwise.
  * Per trial alpha otherwise: O(m) host arithmetic, one 2-right-hand-side device matvec and one single-workgroup
- * reduction; only two scalars come back.  Outputs: s (nout) = total step at the final alpha, *val = the measure
+ * reduction; only two scalars come back.  Once the schedule is pure bisection (sixth trial on for the families that are
+ * not newton_safe, restricted_step.py:100-110) the next four levels of midpoints — 15 trial alphas, the reference's own —
+ * are evaluated per round trip (option rs_batch): secular roots per candidate on the device, ONE pass over the
+ * eigenvector matrix for all of them on the matrix cores, one measure per workgroup.  Outputs: s (nout) = total step at the final alpha, *val = the measure
  * reported by the reference (the value itself inside the radius, delta on the boundary), alphas[0 .. *nalpha) the
  * trial sequence (capacity maxiter + 1; may be NULL).  Returns SELLA_E_NOCONV where the reference raises
  * RuntimeError("Restricted step failed to converge!").                                                          */

@@ -20,78 +20,79 @@ _DEVICE_MIN = 64        # below this a projection basis is not worth a device ro
 
 
 class NumericalHessian(LinearOperator):
+    """H v by finite differences of the gradient, `func(x) -> (f, g)`, around (x0, g0) with displacement eta;
+    optionally seen through a basis Uproj (ntrue x n): v -> Uproj^T H Uproj v.  Every product is remembered — the
+    displaced directions as columns of `Vs`, the differences as columns of `AVs` (both in the full space) — because
+    `PES.diag` turns them into secant pairs for the Hessian update afterwards (peswrapper.py:545-553)."""
     dtype = np.dtype('float64')
+    _SIGNIFICANT = 1e-4        # linalg.py:45-73: components / projections below this do not fix the orientation
 
     def __init__(self, func, x0, g0, eta, threepoint=False, Uproj=None):
-        self.func = func
-        self.x0 = x0.copy()
-        self.g0 = g0.copy()
-        self.eta = eta
-        self.threepoint = threepoint
+        self.func, self.eta, self.threepoint, self.Uproj = func, eta, threepoint, Uproj
+        self.x0, self.g0 = np.array(x0, dtype=np.float64), np.array(g0, dtype=np.float64)
+        self.ntrue = self.x0.size
         self.calls = 0
-        self.Uproj = Uproj
-        self.ntrue = len(self.x0)
-        if Uproj is not None:
-            ntrue, n = Uproj.shape
-            assert ntrue == self.ntrue
-        else:
-            n = self.ntrue
+        if Uproj is not None and Uproj.shape[0] != self.ntrue:
+            raise ValueError('Uproj must have %d rows' % self.ntrue)
+        n = self.ntrue if Uproj is None else Uproj.shape[1]
         super().__init__(self.dtype, (n, n))
-        self.Vs = np.empty((self.ntrue, 0), dtype=self.dtype)
-        self.AVs = np.empty((self.ntrue, 0), dtype=self.dtype)
+        self._pairs = []                     # (direction, difference quotient), full space, in call order
         self._U_gpu = None
         # an identity basis (unconstrained Cartesian search, peswrapper.py:403) needs no products at all
         self._U_identity = Uproj is not None and is_identity(Uproj)
         if Uproj is not None and not self._U_identity and min(Uproj.shape) >= _DEVICE_MIN:
             self._U_gpu = get_context().upload(Uproj)
 
+    # the reference keeps two growing (ntrue x k) arrays; callers only read them after the Davidson run
+    def _stacked(self, which):
+        if not self._pairs:
+            return np.empty((self.ntrue, 0), dtype=self.dtype)
+        return np.column_stack([p[which] for p in self._pairs])
+
+    Vs = property(lambda self: self._stacked(0))
+    AVs = property(lambda self: self._stacked(1))
+
     def _lift(self, v):
-        if self._U_identity:
+        if self.Uproj is None or self._U_identity:
             return v
         if self._U_gpu is not None:
             return get_context().symm_mm(self._U_gpu, v)
         return self.Uproj @ v
 
     def _restrict(self, w):
-        if self._U_identity:
+        if self.Uproj is None or self._U_identity:
             return w
         if self._U_gpu is not None:
             return get_context().tmatmul(self._U_gpu, w)
         return self.Uproj.T @ w
 
+    def _orientation(self, v):
+        """+1 / -1: which of +-v is displaced along.  Downhill if v has a gradient component, else towards the origin,
+        else so that the first significant component is positive (a deterministic choice keeps H v reproducible when
+        the same direction comes back with the other sign)."""
+        for ref in (self.g0, self.x0):
+            proj = v @ ref
+            if abs(proj) > self._SIGNIFICANT:
+                return -1.0 if proj > 0 else 1.0
+        lead = np.flatnonzero(np.abs(v) > self._SIGNIFICANT)
+        return -1.0 if lead.size and v[lead[0]] < 0 else 1.0
+
     def _matvec(self, v):
         self.calls += 1
-        v = np.asarray(v, dtype=np.float64).ravel()
-        if self.Uproj is not None:
-            v = self._lift(v)
-        # canonical displacement direction (linalg.py:45-73): downhill, else towards the
-        # origin, else first significant component positive
-        vdotg = v @ self.g0
-        vdotx = v @ self.x0
-        sign = 1.
-        if abs(vdotg) > 1e-4:
-            sign = 2. * (vdotg < 0) - 1.
-        elif abs(vdotx) > 1e-4:
-            sign = 2. * (vdotx < 0) - 1.
-        else:
-            big = np.flatnonzero(np.abs(v) > 1e-4)
-            if big.size:
-                sign = 1. if v[big[0]] > 0 else -1.
-        vnorm = np.linalg.norm(v)
-        if vnorm < 1e-12:
+        v = self._lift(np.asarray(v, dtype=np.float64).ravel())
+        length = np.linalg.norm(v)
+        if length < 1e-12:
             return np.zeros(self.shape[0])
-        vnorm *= sign
-        _, gplus = self.func(self.x0 + self.eta * v / vnorm)
+        scale = self._orientation(v) * length            # v / scale is the unit displacement direction
+        # operation order as in linalg.py:75-84: a last-bit change of the displaced point is amplified by 1 / eta
+        ahead = self.func(self.x0 + self.eta * v / scale)[1]
         if self.threepoint:
-            _, gminus = self.func(self.x0 - self.eta * v / vnorm)
-            Av = vnorm * (gplus - gminus) / (2 * self.eta)
+            behind = self.func(self.x0 - self.eta * v / scale)[1]
+            Av = scale * (ahead - behind) / (2 * self.eta)
         else:
-            Av = vnorm * (gplus - self.g0) / self.eta
-        self.Vs = np.hstack((self.Vs, v.reshape((self.ntrue, -1))))
-        self.AVs = np.hstack((self.AVs, Av.reshape((self.ntrue, -1))))
-        if self.Uproj is not None:
-            Av = self._restrict(Av)
-        return Av
+            Av = scale * (ahead - self.g0) / self.eta
+        self._pairs.append((v.copy(), Av))
+        return self._restrict(Av)
 
     def __add__(self, other):
         return MatrixSum(self, other)
@@ -101,28 +102,24 @@ class NumericalHessian(LinearOperator):
 
 
 class MatrixSum(LinearOperator):
+    """Sum of operators of one shape (linalg.py:104-140); dense terms are folded into a single array."""
+
     def __init__(self, *matrices):
-        dtype = sorted([mat.dtype for mat in matrices], reverse=True)[0]
-        super().__init__(dtype, matrices[0].shape)
-        dense = None
-        self.matrices = []
-        for matrix in matrices:
-            assert matrix.shape == self.shape, (matrix.shape, self.shape)
-            if isinstance(matrix, np.ndarray):
-                dense = matrix.astype(self.dtype) if dense is None else dense + matrix
-            else:
-                self.matrices.append(matrix)
-        if dense is not None:
-            self.matrices.append(dense)
+        shape = matrices[0].shape
+        for mat in matrices:
+            if mat.shape != shape:
+                raise ValueError('MatrixSum: shapes differ: %s vs %s' % (mat.shape, shape))
+        super().__init__(np.result_type(*[mat.dtype for mat in matrices]), shape)
+        arrays = [mat for mat in matrices if isinstance(mat, np.ndarray)]
+        self.matrices = [mat for mat in matrices if not isinstance(mat, np.ndarray)]
+        if arrays:
+            self.matrices.append(np.sum(arrays, axis=0, dtype=self.dtype))
 
     def _matvec(self, v):
-        w = np.zeros(self.shape[0], dtype=self.dtype)
-        for matrix in self.matrices:
-            w += np.asarray(matrix.dot(v)).ravel()
-        return w
+        return sum(np.asarray(mat.dot(v), dtype=self.dtype).ravel() for mat in self.matrices)
 
     def _transpose(self):
-        return MatrixSum(*[mat.T for mat in self.matrices])
+        return MatrixSum(*(mat.T for mat in self.matrices))
 
     def __add__(self, other):
         return MatrixSum(*self.matrices, other)

@@ -329,11 +329,18 @@ def main():
             if nproc_e < 0:
                 nproc_e = min(args.ensemble_per_gpu, EnsemblePool.BEST_PER_GPU,
                               max(1, effective_cpu_count() // max(1, local_world)))
-            pool = None
+            pool, pool_note = None, None
             if nproc_e > 1 and os.environ.get('SELLA_BENCH_COMM') != 'gloo':
-                pool = EnsemblePool(nproc_e)
-                pool.prepare(make_member, mine_e)
-            else:
+                try:
+                    pool = EnsemblePool(nproc_e)
+                    pool.prepare(make_member, mine_e)
+                except Exception as e:                   # noqa: BLE001 — the leg then runs in this process, and says so
+                    pool_note = 'worker pool unavailable (%s): members run in the rank process' % (str(e)[:200],)
+                    sys.stderr.write('[bench rank %d] %s\n' % (rank, pool_note))
+                    if pool is not None:
+                        pool.close()
+                    pool = None
+            if pool is None:
                 for i in mine_e:
                     make_member.prepare(i)
             barrier()
@@ -352,6 +359,8 @@ def main():
                                          optimizer_steps_per_s=round(nst_tot / tens, 2),
                                          searches_per_s=round(total / tens, 3), seconds=round(tens, 3),
                                          lambda_min_negative=int((res['summary'][:, 4] < 0).sum()))
+            if pool_note:
+                opt_stats['ensemble']['note'] = pool_note
             if pool is not None:
                 pool.close()
         # ---- BASELINE configs[1] as named: 1024-atom Cu(111) EMT slab (3N = 3072), one surface atom lifted onto a

@@ -161,7 +161,11 @@ class EnsemblePool:
                 os.environ.pop('SELLA_HOST_THREADS', None)
             else:
                 os.environ['SELLA_HOST_THREADS'] = keep
-        self.pids = [self._expect(conn) for _, conn in self._workers]
+        try:
+            self.pids = [self._expect(conn) for _, conn in self._workers]
+        except Exception:
+            self.close()
+            raise
 
     @staticmethod
     def _expect(conn):

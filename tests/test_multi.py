@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, '_mp_worker.py')
@@ -69,6 +70,16 @@ def test_ensemble_process_pool_matches_serial(tmp_path):
     np.testing.assert_array_equal(a['summary'], b['summary'])
     for i in range(5):
         np.testing.assert_array_equal(a[f'pos{i}'], b[f'pos{i}'])
+
+
+def test_ensemble_pool_reports_worker_failures():
+    """A worker that cannot start (here: its initializer raises) surfaces as an exception in the parent, with the
+    worker's message, and leaves no process behind."""
+    import operator
+
+    from sella_amd.ensemble import EnsemblePool
+    with pytest.raises(RuntimeError, match='ZeroDivisionError'):
+        EnsemblePool(2, initializer=operator.truediv, initargs=(1, 0))
 
 
 def test_bench_two_ranks(tmp_path):

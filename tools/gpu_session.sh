@@ -18,9 +18,9 @@ echo "== bench" | tee -a $OUT/session.log
 timeout 900 python bench.py > $OUT/bench.log 2>&1; echo "bench exit $?" | tee -a $OUT/session.log
 tail -1 $OUT/bench.log | tee -a $OUT/session.log
 echo "== rocprof kernel trace of the bench command" | tee -a $OUT/session.log
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/$OUT/rocprof.log 2>&1); echo "rocprof exit $?" | tee -a $OUT/session.log
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --ensemble-procs 0 > $R/$OUT/rocprof.log 2>&1); echo "rocprof exit $?" | tee -a $OUT/session.log
 DB=$(find $OUT/prof -name "*.db" | head -1)
-python tools/rocprof_summary.py $DB $OUT/bench_kernel_stats.md "bench.py --steps 5 --warmup 1 --no-cpu-baseline (rocprofv3 --kernel-trace --stats)" > /dev/null
+python tools/rocprof_summary.py $DB $OUT/bench_kernel_stats.md "bench.py --steps 5 --warmup 1 --no-cpu-baseline --ensemble-procs 0 (rocprofv3 --kernel-trace --stats)" > /dev/null
 head -20 $OUT/bench_kernel_stats.md | tee -a $OUT/session.log
 echo "== rocprof kernel trace of the eigensolver alone (4 calls at n = 3072)" | tee -a $OUT/session.log
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_eigh -o eigh -- python $R/tools/eigh_only.py 3072 4 > $R/$OUT/rocprof_eigh.log 2>&1); echo "rocprof eigh exit $?" | tee -a $OUT/session.log
@@ -43,5 +43,16 @@ grep "^{" $OUT/geodesic.log | cut -c1-400 | tee -a $OUT/session.log
 EXACT_GEODESIC=1 timeout 600 python tools/geodesic_bench.py --steps 1 --sella-steps 2 > $OUT/geodesic_exact.log 2>&1; grep "Sella(internal)" $OUT/geodesic_exact.log | cut -c1-300 | tee -a $OUT/session.log
 echo "== Davidson loop alone" | tee -a $OUT/session.log
 SELLA_DEBUG_TIMING=1 timeout 300 python tools/dav_time.py > $OUT/dav_time.log 2>&1; grep -v "^davidson\|^eigh" $OUT/dav_time.log | tail -4 | tee -a $OUT/session.log; grep "^davidson" $OUT/dav_time.log | tail -1 | tee -a $OUT/session.log
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_dav -o dav -- python $R/tools/dav_time.py > $R/$OUT/rocprof_dav.log 2>&1); echo "rocprof dav exit $?" | tee -a $OUT/session.log
+DBD=$(find $OUT/prof_dav -name "*.db" | head -1)
+python tools/rocprof_summary.py $DBD $OUT/dav_kernel_stats.md "tools/dav_time.py (rocprofv3 --kernel-trace --stats)" > /dev/null
+rm -rf $OUT/prof_dav
+echo "== EMT slab, optimizer profile" | tee -a $OUT/session.log
+SELLA_DEBUG_TIMING=1 timeout 300 python tools/emt_slab_opt.py > $OUT/emt.log 2> $OUT/emt_timing.log; grep "per optimizer step" -A8 $OUT/emt.log | tee -a $OUT/session.log
+grep "update_H\|rank-one" $OUT/emt_timing.log | tail -5 | tee -a $OUT/session.log
+SELLA_DEBUG_TIMING=1 timeout 300 python tools/opt_profile.py 3072 20 > $OUT/opt_3072.log 2> $OUT/opt_3072_timing.log; head -10 $OUT/opt_3072.log | tee -a $OUT/session.log
+grep "update_H" $OUT/opt_3072_timing.log | tail -1 | tee -a $OUT/session.log
+echo "== ensemble worker processes" | tee -a $OUT/session.log
+timeout 300 python tools/ensemble_probe.py 16 2 4 > $OUT/probe.log 2>&1; grep pool $OUT/probe.log | tee -a $OUT/session.log
 echo "== rccl (1 rank)" | tee -a $OUT/session.log
 timeout 120 python tools/rccl_smoke.py > $OUT/rccl.log 2>&1; tail -1 $OUT/rccl.log | tee -a $OUT/session.log

@@ -1252,7 +1252,12 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     const int nrefl = n - 2;
     double *Vp, *Wp, *part;
     SCHK(scratch_get(c, SCR_MISC0, (size_t)2 * TRD_NBMAX * ld * sizeof(double), &Vp));
-    Wp = Vp + (size_t)TRD_NBMAX * ld;
+    Wp = Vp + (size_t)nb * ld;
+    // Cleared ONCE per factorisation (a memset is ~5 us whatever its size: per panel it was 1 ms of every eigh).  Within
+    // a panel every entry of V_p, W_p that meets a non-zero factor has been written by this panel (indices >= j0 + p + 1);
+    // the entries in front of it — left over from the previous panel — only ever meet the zeros of the masked row u',
+    // so they must be finite, nothing more: the shared scratch may hold anything before the first panel.
+    HIPCHK(hipMemsetAsync(Vp, 0, (size_t)2 * nb * ld * sizeof(double), c->stream));
     const int maxblkA = (n + 255) / 256 + 1, maxblkB = (n + 16 + 2 * TRD_NBMAX + 1) / 2 + 1;
     SCHK(scratch_get(c, SCR_MISC1, ((size_t)2 * maxblkA * TRD_PA + 2 * (size_t)maxblkB + 4 * TRD_NBMAX + 64) * sizeof(double), &part));
     double* partA[2] = {part, part + (size_t)maxblkA * TRD_PA};
@@ -1264,10 +1269,6 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     int cur = 0, nblkA_prev = 0, nblkB_prev = 0;
     for (int j0 = 0; j0 < nrefl; j0 += nb) {
         const int kb = std::min(nb, nrefl - j0);
-        // only the kb rows of each half that this panel uses (the scratch is shared: stale pad columns must not
-        // reach the products as 0 * inf)
-        HIPCHK(hipMemsetAsync(Vp, 0, (size_t)kb * ld * sizeof(double), c->stream));
-        HIPCHK(hipMemsetAsync(Wp, 0, (size_t)kb * ld * sizeof(double), c->stream));
         for (int i = 0; i <= kb; ++i) {
             const int j = j0 + i;
             const bool do_row = i < kb;

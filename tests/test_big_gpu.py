@@ -172,6 +172,15 @@ def test_ensemble_single_gpu(ctx):
         return _ensemble_member_factory(device.get_context(), ne, host)(i)
     res_t = run_ensemble(make_member_t, nrep, fmax=0.0, steps=steps, sella_kwargs=kw, threads=4)
     np.testing.assert_array_equal(res_t['summary'], res['summary'])
+    # worker processes, own interpreter and device context each (`EnsemblePool`, what bench.py uses): the same again
+    from conftest_shim import EnsembleFactory
+    from sella_amd.ensemble import EnsemblePool
+    with EnsemblePool(3) as pool:
+        assert len(set(pool.pids)) == 3
+        res_p = run_ensemble(EnsembleFactory(ne, host), nrep, fmax=0.0, steps=steps, sella_kwargs=kw, pool=pool)
+    np.testing.assert_array_equal(res_p['summary'], res['summary'])
+    for i in range(nrep):
+        np.testing.assert_array_equal(res_p['positions'][i], res['positions'][i])
 
 
 # ---- BASELINE configs[4]: n = 12288 --------------------------------------------------------------------------

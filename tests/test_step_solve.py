@@ -105,6 +105,39 @@ def test_batched_bisection_matches_sequential(ctx):
         assert m0 == m1
 
 
+def test_batched_bisection_all_measures(ctx):
+    """The same for every measure of `sella_restricted_step` (component-wise 'mis', Euclidean 'tr' in the output space,
+    mass-weighted 'sphere') and a selection basis, straight through the stepper binding."""
+    from sella_amd.device import DeviceStepper
+    rng = np.random.RandomState(11)
+    m = 40
+    Q, _ = np.linalg.qr(rng.normal(size=(m, m)))
+    lam = np.sort(np.exp(rng.uniform(np.log(0.05), np.log(20.0), m)))
+    lam[0] = -0.6
+    g = 0.3 * rng.normal(size=m)
+    V, Vt = ctx.upload(Q), ctx.upload(Q.T.copy())
+    w = rng.uniform(0.5, 2.0, size=m)
+    d1 = 1e-3 * rng.normal(size=m)           # |d1 w| below the radius: the sphere is reachable as alpha -> 0
+    sel = np.sort(rng.choice(60, size=m, replace=False)).astype(np.int32)
+    wf, sc = rng.uniform(0.5, 2.0, size=60), np.zeros(60)
+    cases = [dict(cons='mis', w=w), dict(cons='tr'), dict(cons='sphere', w=w, d1=d1),
+             dict(cons='ras', sel=sel, nfull=60), dict(cons='mis', w=wf, sel=sel, nfull=60, scons=sc)]
+    for kw in cases:
+        out = {}
+        for flag in (0, 1):
+            ctx.set_option('rs_batch', flag)
+            st = DeviceStepper(ctx, 'prfo', V, Vt, lam, g, 1)
+            out[flag] = st.restricted_step(delta=0.02, alpha0=1.0, alphamin=0.0, alphamax=1.0, slope=1.0,
+                                           newton_safe=False, tol=1e-15, **kw)
+        ctx.set_option('rs_batch', 0 if ctx.backend == 'emu' else 1)
+        (s0, v0, a0), (s1, v1, a1) = out[0], out[1]
+        assert len(a0) > 20 and abs(len(a0) - len(a1)) <= 1, kw['cons']
+        k = min(len(a0), len(a1)) - 2
+        np.testing.assert_allclose(a1[:k], a0[:k], rtol=1e-12, atol=0, err_msg=kw['cons'])
+        np.testing.assert_allclose(s1, s0, atol=1e-12 * max(1.0, np.abs(s0).max()), err_msg=kw['cons'])
+        assert v0 == v1 == 0.02
+
+
 def test_registry_and_errors(ctx):
     from sella_amd.optimize.restricted_step import (MaxInternalStep, RestrictedAtomicStep, TrustRegion,
                                                     get_restricted_step)

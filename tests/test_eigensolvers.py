@@ -147,3 +147,13 @@ def test_callback_failure_propagates(ctx):
             raise RuntimeError('calculator failed')
     with pytest.raises(RuntimeError, match='calculator failed'):
         rayleigh_ritz(Boom(), 0.1, np.eye(8), v0=np.ones(8))
+
+
+def test_size_limit_of_the_one_vector_solver_is_reported(ctx):
+    """`sella_davidson` keeps its per-iteration partial sums in a fixed exchange layout (3N <= 16000: all BASELINE
+    configurations, 12288 included); beyond it the call fails with a message naming the block solver instead of
+    overrunning the layout."""
+    from sella_amd._lib import SellaHipError
+    n = 16001
+    with pytest.raises(SellaHipError, match='sella_davidson_block'):
+        ctx.davidson(lambda v: v, n, np.ones(n), 0.1, method='lanczos', maxiter=2)

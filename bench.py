@@ -436,6 +436,12 @@ def main():
                            panel_pass_gbs=round(pp['bytes'] / max(1e-12, pp['ms'] * 1e-3) / 1e9, 1) if pp['launches'] else None,
                            lowest_ritz=float(outb['lams'][0]), scaling='strong (rows of H sharded over the ranks)',
                            preconditioner='diagonal')
+        if pp['launches']:
+            # the one MFMA kernel of the path: 2 * rows * n * 16 flop per pass against the dense fp64 MFMA peak
+            # (78.6 TFLOP/s, MI355X_MICROARCH.md); it is an HBM-bound product — 16 flop per 8 streamed bytes
+            tfl = 2.0 * (hi_ - lo_) * nb_ * 16 / max(1e-12, pp['ms'] * 1e-3 / pp['launches']) / 1e12
+            block_stats.update(panel_pass_tflops=round(tfl, 2), panel_pass_mfma_frac=round(tfl / 78.6, 3),
+                               panel_pass_hbm_frac=round(block_stats['panel_pass_gbs'] / HBM_PEAK_GBS, 3))
         _dev2._default = None
 
     times = [elapsed]

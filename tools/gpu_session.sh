@@ -36,6 +36,18 @@ for CNT in FETCH_SIZE WRITE_SIZE; do
   head -12 $OUT/pmc_$CNT.txt | tee -a $OUT/session.log
   rm -rf $OUT/pmc_$CNT
 done
+echo "== MFMA utilisation (PMC, own runs): block product H.V at 3N = 12288, eigensolver GEMMs / back-transformation" | tee -a $OUT/session.log
+(cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc_mfma_panel -o pmc -- python $R/tools/panel_bench.py 12288 16 > $R/$OUT/pmc_mfma_panel.log 2>&1); echo "pmc mfma panel exit $?" | tee -a $OUT/session.log
+DBM=$(find $OUT/pmc_mfma_panel -name "*.db" | head -1)
+python tools/mfma_util.py $DBM panel16_mfma_kernel 4831838208 > $OUT/pmc_mfma.txt 2>&1
+rm -rf $OUT/pmc_mfma_panel
+(cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc_mfma_eigh -o pmc -- python $R/tools/eigh_only.py 3072 1 > $R/$OUT/pmc_mfma_eigh.log 2>&1); echo "pmc mfma eigh exit $?" | tee -a $OUT/session.log
+DBM=$(find $OUT/pmc_mfma_eigh -name "*.db" | head -1)
+python tools/mfma_util.py $DBM wy_apply_mfma_kernel 57982058496 >> $OUT/pmc_mfma.txt 2>&1
+python tools/mfma_util.py $DBM gemm128_merge_batched_kernel >> $OUT/pmc_mfma.txt 2>&1
+python tools/mfma_util.py $DBM rank2k_stream_kernel >> $OUT/pmc_mfma.txt 2>&1
+rm -rf $OUT/pmc_mfma_eigh
+cat $OUT/pmc_mfma.txt | tee -a $OUT/session.log
 rm -f $OUT/prof/*/*.db.tmp
 echo "== configs[2]: internal coordinates / geodesic at 1024 atoms" | tee -a $OUT/session.log
 timeout 600 python tools/geodesic_bench.py --steps 3 --sella-steps 2 > $OUT/geodesic.log 2>&1; echo "geodesic exit $?" | tee -a $OUT/session.log

@@ -17,7 +17,13 @@ OBJ = os.path.join(HERE, '_obj')
 LIB = os.path.join(HERE, 'libsella_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
+# Host code (the k x k algebra of the Davidson loop, the secular solves of the step families, deflation planning) is
+# compiled for AVX2 + FMA hosts: every MI355X platform ships with a CPU that has them.  SELLA_HOST_MARCH='' builds for
+# the baseline x86-64 instead.
+HOST_MARCH = os.environ.get('SELLA_HOST_MARCH', 'x86-64-v3')
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-result']
+if HOST_MARCH:
+    FLAGS += ['-Xarch_host', f'-march={HOST_MARCH}']
 
 
 def sources():

@@ -23,7 +23,8 @@ ARCH = 'gfx950'
 HOST_MARCH = os.environ.get('SELLA_HOST_MARCH', 'x86-64-v3')
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-result']
 if HOST_MARCH:
-    FLAGS += ['-Xarch_host', f'-march={HOST_MARCH}']
+    # no fused multiply-add contraction on the host: the host arithmetic stays what the baseline build computes
+    FLAGS += ['-Xarch_host', f'-march={HOST_MARCH}', '-Xarch_host', '-ffp-contract=off']
 
 
 def sources():

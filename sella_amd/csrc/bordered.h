@@ -137,7 +137,9 @@ __host__ __device__ inline void bordered_root_core(int mm, DAt Dat, BAt bat, dou
 }
 
 // host form: arrays D (ascending), b
-inline void bordered_root(int mm, const double* D, const double* b, int j, int* origin, double* tau) {
+// wide: sum four terms at a time (the step families' O(m) problems); the Davidson loop's k x k Rayleigh-Ritz keeps the
+// sequential order — its trajectory is sensitive to the last bit and nothing is gained at k <= 40.
+inline void bordered_root(int mm, const double* D, const double* b, int j, int* origin, double* tau, bool wide = false) {
     double bb = 0.0;
     for (int i = 0; i < mm; ++i) bb += b[i] * b[i];
     // The sums are the whole cost (one division per term, 3-6 sweeps per root, one root per Ritz value and iteration in
@@ -149,7 +151,7 @@ inline void bordered_root(int mm, const double* D, const double* b, int j, int* 
         v4d s4 = {0.0, 0.0, 0.0, 0.0}, a4 = s4, d4 = s4;
         const v4i mask = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0x7fffffffffffffffLL, 0x7fffffffffffffffLL};
         int i = lo;
-        for (; i + 4 <= hi; i += 4) {
+        for (; wide && i + 4 <= hi; i += 4) {
             v4d Dv, bv;
             memcpy(&Dv, D + i, sizeof(v4d));
             memcpy(&bv, b + i, sizeof(v4d));
@@ -164,8 +166,13 @@ inline void bordered_root(int mm, const double* D, const double* b, int j, int* 
             a4 += aq;
             d4 += q * r;
         }
-        double ss = (s4[0] + s4[1]) + (s4[2] + s4[3]), sas = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-        double ds = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+        // the scalar path continues the running sums term by term (the order of the plain loops this replaces)
+        double ss = *s, sas = *sa, ds = *dd;
+        if (i > lo) {
+            ss += (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            sas += (a4[0] + a4[1]) + (a4[2] + a4[3]);
+            ds += (d4[0] + d4[1]) + (d4[2] + d4[3]);
+        }
         for (; i < hi; ++i) {
             const double r = 1.0 / ((D[i] - shift) - t);
             const double q = b[i] * b[i] * r;
@@ -173,9 +180,9 @@ inline void bordered_root(int mm, const double* D, const double* b, int j, int* 
             sas += fabs(q);
             ds += q * r;
         }
-        *s += ss;
-        *sa += sas;
-        *dd += ds;
+        *s = ss;
+        *sa = sas;
+        *dd = ds;
     };
     auto eval = [&](double shift, double t) {
         Ev e;

@@ -47,7 +47,7 @@ double rfo_block(int mm, const double* lam, const double* ghat, int o, double al
     for (int i = 0; i < mm; ++i) { D[i] = alpha * alpha * lam[i]; b[i] = alpha * ghat[i]; }
     int org;
     double tau;
-    bordered::bordered_root(mm, D.data(), b.data(), o, &org, &tau);
+    bordered::bordered_root(mm, D.data(), b.data(), o, &org, &tau, /*wide=*/true);
     const double shift = org >= 0 ? D[org] : 0.0;
     // eigenvector (unnormalised): y_i = b_i / (mu - D_i), eta = 1
     double nrm2 = 1.0;

@@ -4,7 +4,8 @@ Cu fcc(111), bottom half of the slab frozen with translation constraints.
 
 Differences from the reference script: the two `ase` imports (ASE is not in this image; the builders and
 an EMT restatement come from sella_amd.atoms — with ASE installed the original imports work unchanged, the
-calculator boundary is untouched); the trajectory is written as extended XYZ."""
+calculator boundary is untouched).  The trajectory file is ASE's own `.traj` format (sella_amd/trajectory.py),
+like the README's `trajectory='test_emt.traj'`."""
 import os
 import sys
 
@@ -32,7 +33,12 @@ slab.calc = EMT()
 dyn = Sella(
     slab,
     constraints=cons,
-    trajectory='test_emt.xyz',
+    trajectory='test_emt.traj',
 )
 
 dyn.run(1e-3, 1000)
+
+from sella_amd.trajectory import Trajectory  # noqa: E402
+
+with Trajectory('test_emt.traj') as traj:
+    print('%d images in test_emt.traj, final energy %.6f eV' % (len(traj), traj[-1].get_potential_energy()))

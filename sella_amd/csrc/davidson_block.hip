@@ -168,10 +168,14 @@ int combine(Blk& s, int nh, int k, const double* dC, int ldc, const double* P, d
 
 // host coefficients (nh x k, row h = output h) -> device buffer dC (ld kcap)
 int put_coeffs(Blk& s, const vec& Ch, int nh, int k) {
-    HIPCHK(hipMemcpy2DAsync(s.dC, (size_t)s.kcap * sizeof(double), Ch.data(), (size_t)k * sizeof(double),
-                            (size_t)k * sizeof(double), nh, hipMemcpyHostToDevice, s.c->stream));
-    HIPCHK(hipStreamSynchronize(s.c->stream));     // Ch is a pageable temporary of the caller
-    return SELLA_OK;
+    // rows of stride kcap on the device; through the pinned ring (context.hip h2d_async): no wait, and the caller's
+    // temporary may go at once
+    // (ONE transfer: the rows are re-strided on the host first; the columns behind k are never read)
+    if (k == s.kcap) return h2d_async(s.c, s.dC, Ch.data(), (size_t)nh * k * sizeof(double));
+    static thread_local vec packed;
+    packed.resize((size_t)nh * s.kcap);
+    for (int h = 0; h < nh; ++h) memcpy(packed.data() + (size_t)h * s.kcap, Ch.data() + (size_t)h * k, (size_t)k * sizeof(double));
+    return h2d_async(s.c, s.dC, packed.data(), ((size_t)(nh - 1) * s.kcap + k) * sizeof(double));
 }
 
 // Y (nh rows) = A X^T for the 16-row panel X (rows >= nh zero): local panel product (+ all-gather)
@@ -337,8 +341,7 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
     const double* pdiag = s.Q ? pevals : diag;
     if (pdiag) {
         BCHK(scratch_get(c, SCR_C, (size_t)s.ld * sizeof(double), &s.dP));
-        BHIP(hipMemcpyAsync(s.dP, pdiag, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        BHIP(hipStreamSynchronize(c->stream));
+        BCHK(h2d_async(c, s.dP, pdiag, (size_t)n * sizeof(double)));
         double amax = 0.0;
         for (int i = 0; i < n; ++i) amax = std::max(amax, fabs(pdiag[i]));
         s.guard = std::max(1e-300, 1e-10 * amax);

@@ -454,17 +454,30 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
             BCHK(launch_rows_sumsq(c, s.R, s.ld, nh, n, c->dscal + DS_MISC));
             BCHK(read_scalars(c, DS_MISC, nh));
             const bool feed = (na == 0);
+            int run_src = -1, run_dst = 0, run_len = 0;              // consecutive residual rows travel as one copy
+            auto flush_run = [&]() -> int {
+                if (run_len > 0)
+                    HIPCHK(hipMemcpyAsync(s.T + (size_t)run_dst * s.ld, s.R + (size_t)run_src * s.ld,
+                                          (size_t)run_len * s.ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                run_len = 0;
+                return SELLA_OK;
+            };
             for (int h = 0; h < nh; ++h) {
                 rn[j0 + h] = sqrt(c->hscal[DS_MISC + h]);
                 const bool ok = rn[j0 + h] <= tol * std::max(fabs(theta[j0 + h]), 1e-300);
                 conv[j0 + h] = ok ? 1 : 0;
                 nconv += ok ? 1 : 0;
                 if (!ok && feed && na < block) {
-                    BHIP(hipMemcpyAsync(s.T + (size_t)na * s.ld, s.R + (size_t)h * s.ld, (size_t)s.ld * sizeof(double),
-                                        hipMemcpyDeviceToDevice, c->stream));
+                    if (run_len > 0 && h == run_src + run_len) {
+                        ++run_len;
+                    } else {
+                        BCHK(flush_run());
+                        run_src = h; run_dst = na; run_len = 1;
+                    }
                     th.v[na++] = theta[j0 + h];
                 }
             }
+            BCHK(flush_run());
         }
         if (nconv == nwant && nwant == nev) { done = true; break; }
         if (iter >= maxiter) break;

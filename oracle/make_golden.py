@@ -425,6 +425,111 @@ def gen_restricted(ref, orc):
     return cases
 
 
+class _Counts:
+    """The six block counts MaxInternalStep._get_weights reads from `pes.int` (restricted_step.py:217-243)."""
+
+    def __init__(self, ntrans, nbonds, nangles, ndihedrals, nother, nrotations):
+        self.ntrans, self.nbonds, self.nangles, self.ndihedrals = ntrans, nbonds, nangles, ndihedrals
+        self.nother, self.nrotations = nother, nrotations
+
+
+MIS_BLOCKS = (0, 12, 14, 8, 2, 0)              # 36 internal coordinates: bonds, angles, dihedrals, other
+
+
+def _trace_alphas(rs_obj):
+    """Record the trial alphas of a reference restricted-step object (its `eval` is the only place one is used)."""
+    trace = []
+    inner = rs_obj.eval
+
+    def eval_and_record(alpha):
+        trace.append(float(alpha))
+        return inner(alpha)
+    rs_obj.eval = eval_and_record
+    return trace
+
+
+def gen_restricted_mis(ref, orc):
+    """MaxInternalStep (`mis`, restricted_step.py:186-243) — the trust measure of every internal-coordinate search —
+    through a fake PES whose `int` carries the block counts; with the alpha trace of the reference's search."""
+    out, cases = {}, []
+    i = 0
+    n = sum(MIS_BLOCKS)
+    weights = (dict(), dict(wb=1.0, wa=0.5, wd=0.25, wo=2.0))
+    for method in ('qn', 'rfo', 'prfo'):
+        for order, delta, ncons in ((1, 0.05, 0), (1, 10.0, 0), (0, 0.05, 0), (1, 0.05, 6)):
+            for wkw in weights:
+                if wkw and (delta > 1 or order == 0):
+                    continue
+                A, P, g = hessian_like(n, seed=900 + i, nneg=max(order, 1))
+                pr = FakePES(ref.linalg.ApproximateHessian, P, g, ncons, seed=50 + i)
+                po = FakePES(orc.QuasiNewtonHessian, P, g, ncons, seed=50 + i)
+                pr.int = po.int = _Counts(*MIS_BLOCKS)
+                robj = ref.rs.get_restricted_step('mis')(pr, order, delta, method, **wkw)
+                alphas = _trace_alphas(robj)
+                s, smag = robj.get_s()
+                ro = orc.get_restricted_step('mis')(po, order, delta, method, **wkw)
+                s2, smag2 = ro.get_s()
+                close(s2, s, 1e-9, f'mis[{method},{order},{delta},{ncons},{wkw}] s')
+                close(smag2, smag, 1e-12, 'mis smag')
+                m = min(len(alphas), len(ro.alpha_trace))
+                assert abs(len(alphas) - len(ro.alpha_trace)) <= 1
+                close(ro.alpha_trace[:m - 2], alphas[:m - 2], 1e-6, 'mis alpha trace')
+                close(ro.weights(), robj._get_weights(), 0.0, 'mis weights')
+                out[f'c{i}_H'], out[f'c{i}_g'] = P, g
+                out[f'c{i}_Ufree'], out[f'c{i}_scons'] = pr.Ufree, pr.scons
+                out[f'c{i}_s'], out[f'c{i}_smag'] = s, smag
+                out[f'c{i}_alphas'] = np.array(alphas)
+                out[f'c{i}_w'] = robj._get_weights()
+                cases.append(dict(id=i, rs='mis', method=method, order=order, delta=delta, ncons=ncons,
+                                  weights=wkw, blocks=list(MIS_BLOCKS), seed=50 + i))
+                i += 1
+    np.savez_compressed(os.path.join(GOLD, 'g8_mis.npz'), **out)
+    return cases
+
+
+def gen_sparse_internal(ref, orc):
+    """SparseInternalJacobian / SparseInternalHessian / SparseInternalHessians (linalg.py:362-646): random 2- / 3- /
+    4-atom blocks in a mixed order, one coordinate with a repeated atom (the scatter must accumulate)."""
+    from oracle.sella_oracle import sparse_internal as spo
+    out, cases = {}, []
+    for i, (natoms, sizes) in enumerate(((7, (2, 3, 4, 2, 4, 3, 3, 2)), (12, (4, 4, 2, 3, 2, 2, 3, 4, 4, 3, 2, 4)),
+                                         (5, (2, 2, 2)), (9, (3, 4, 3, 4)))):
+        rng = np.random.RandomState(1100 + i)
+        indices = [rng.choice(natoms, size=m, replace=False) for m in sizes]
+        if i == 1:
+            indices[3] = np.array([5, 2, 5])                     # periodic image of the same atom: repeated index
+        gvals = [rng.normal(size=(m, 3)) for m in sizes]
+        hvals = []
+        for m in sizes:
+            h = rng.normal(size=(3 * m, 3 * m))
+            hvals.append((0.5 * (h + h.T)).reshape(m, 3, m, 3))
+        nint = len(sizes)
+        x, u = rng.normal(size=3 * natoms), rng.normal(size=3 * natoms)
+        y = rng.normal(size=nint)
+        J = ref.linalg.SparseInternalJacobian(natoms, [list(ix) for ix in indices], [list(v) for v in gvals])
+        hs = [ref.linalg.SparseInternalHessian(natoms, list(ix), hv) for ix, hv in zip(indices, hvals)]
+        Hs = ref.linalg.SparseInternalHessians(hs, 3 * natoms)
+        res = dict(J=J.asarray(), Jx=J.matvec(x), JTy=J.rmatvec(y),
+                   H0=hs[0].asarray(), H0x=hs[0].matvec(x), Hall=Hs.asarray(),
+                   ldot=Hs.ldot(y), rdot=Hs.rdot(x), ddot=Hs.ddot(u, x))
+        ours = dict(J=spo.jacobian_dense(natoms, indices, gvals), Jx=spo.jacobian_matvec(natoms, indices, gvals, x),
+                    JTy=spo.jacobian_rmatvec(natoms, indices, gvals, y),
+                    H0=spo.hessian_dense(natoms, indices[0], hvals[0]),
+                    H0x=spo.hessian_matvec(natoms, indices[0], hvals[0], x),
+                    Hall=np.array([spo.hessian_dense(natoms, ix, hv) for ix, hv in zip(indices, hvals)]),
+                    ldot=spo.hessians_ldot(natoms, indices, hvals, y), rdot=spo.hessians_rdot(natoms, indices, hvals, x),
+                    ddot=spo.hessians_ddot(natoms, indices, hvals, u, x))
+        for key in res:
+            close(ours[key], res[key], 1e-13, f'sparse_internal[{i}].{key}')
+            out[f'c{i}_{key}'] = res[key]
+        out[f'c{i}_x'], out[f'c{i}_u'], out[f'c{i}_y'] = x, u, y
+        for k, (ix, gv, hv) in enumerate(zip(indices, gvals, hvals)):
+            out[f'c{i}_idx{k}'], out[f'c{i}_g{k}'], out[f'c{i}_h{k}'] = np.asarray(ix), gv, hv
+        cases.append(dict(id=i, natoms=natoms, sizes=list(sizes)))
+    np.savez_compressed(os.path.join(GOLD, 'g11_sparse_internal.npz'), **out)
+    return cases
+
+
 def gen_irc(ref, orc):
     """IRC step family (stepper.py:99-111) and its mass-weighted trust sphere (restricted_step.py:145-158),
     driven exactly as sella/optimize/irc.py:128-137 does: method=QuasiNewtonIRC, d1, W = diag(1/sqrt(m))."""
@@ -568,9 +673,39 @@ def gen_big_digests(ref, orc, sizes):
         json.dump(dig, f, indent=1)
 
 
+def gen_converged_digests(ref, orc, sizes):
+    """The reference's CONVERGED lowest eigenpair at benchmark sizes, merged into big_digests.json: the run the
+    optimizer flow makes (start block = P's negative-curvature eigenvectors, eigensolvers.py:46-50, v0=None), to
+    gamma = 1e-7.  Trajectories at gamma = 0.1 are chaotic; this is the quantity north_star's
+    1e-10 is about."""
+    path = os.path.join(GOLD, 'big_digests.json')
+    with open(path) as f:
+        dig = json.load(f)
+    for n in sizes:
+        A, P, g = hessian_like(n, seed=0, eps=5e-3)
+        t0 = time.time()
+        lams, V, AV = ref.eig.rayleigh_ritz(A, 1e-7, P, v0=None, method='jd0', maxiter=n)
+        dt = time.time() - t0
+        ol, oV, _ = orc.rayleigh_ritz(A, 1e-7, P, v0=None, method='jd0', maxiter=n)
+        assert oV.shape == V.shape
+        close(ol[:1], lams[:1], 1e-12, f'converged lam0 n={n}')
+        probe = np.cos(np.arange(n) * 0.37)
+        v = V[:, 0] * (1.0 if V[np.argmax(np.abs(V[:, 0])), 0] > 0 else -1.0)        # sign: largest component positive
+        dig[str(n)]['converged'] = dict(
+            recipe='hessian_like(n, seed=0, eps=5e-3); rayleigh_ritz(A,1e-7,P,v0=None,jd0,maxiter=n)',
+            k=int(V.shape[1]), lam0=float(lams[0]), residual=float(np.linalg.norm(AV[:, 0] - lams[0] * V[:, 0])),
+            v0_probe=float(probe @ v), v0_absmax=float(np.abs(v).max()), v0_argmax=int(np.argmax(np.abs(v))),
+            ref_seconds=dt)
+        print(f'  converged n={n}: k={V.shape[1]} lam0={lams[0]:.15f} ({dt:.1f}s reference)')
+    with open(path, 'w') as f:
+        json.dump(dig, f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--big', action='store_true')
+    ap.add_argument('--converged', action='store_true', help='add the converged-eigenpair digests only')
+    ap.add_argument('--only', default='', help='comma-separated fixture names: regenerate these, keep the rest')
     ap.add_argument('--sizes', default='300,768,3072')
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
@@ -579,14 +714,22 @@ def main():
     sys.path.insert(0, REPO)
     import oracle.sella_oracle as orc
     manifest = {}
+    only = [x for x in args.only.split(',') if x]
+    if only or args.converged:
+        with open(os.path.join(GOLD, 'manifest.json')) as f:
+            manifest = json.load(f)
     for name, fn in (('g1_davidson', gen_davidson), ('g2_expand', gen_expand),
                      ('g3_mgs', gen_mgs), ('g4_symmetrize', gen_symmetrize),
                      ('g5_update_h', gen_update),
                      ('g6_approx_hessian', gen_approx_hessian),
                      ('g7_steppers', gen_steppers),
                      ('g8_restricted_step', gen_restricted),
+                     ('g8_mis', gen_restricted_mis),
                      ('g9_numhess', gen_numhess),
-                     ('g10_irc', gen_irc)):
+                     ('g10_irc', gen_irc),
+                     ('g11_sparse_internal', gen_sparse_internal)):
+        if (only and name not in only) or (args.converged and not only):
+            continue
         t0 = time.time()
         manifest[name] = fn(ref, orc)
         print(f'{name}: {len(manifest[name])} cases, oracle == reference '
@@ -595,6 +738,8 @@ def main():
         json.dump(manifest, f, indent=1)
     if args.big:
         gen_big_digests(ref, orc, [int(s) for s in args.sizes.split(',')])
+    if args.big or args.converged:
+        gen_converged_digests(ref, orc, [int(s) for s in args.sizes.split(',') if int(s) >= 768])
 
 
 if __name__ == '__main__':

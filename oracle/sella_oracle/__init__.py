@@ -7,4 +7,5 @@ from .hessian_ops import (FiniteDifferenceHessian, OperatorSum,  # noqa: F401
 from .stepsolve import (get_stepper, get_restricted_step,        # noqa: F401
                         QuasiNewtonStep, RFOStep, PRFOStep,
                         TrustRegionStep, PerAtomStep, NaiveStep,
-                        QuasiNewtonIRCStep, IRCTrustRegionStep)
+                        QuasiNewtonIRCStep, IRCTrustRegionStep, MaxInternalStepOracle)
+from . import sparse_internal                                    # noqa: F401

@@ -232,8 +232,35 @@ class PerAtomStep(RestrictedStep):                       # :161-183
         return val, dsda.reshape((-1, 3))[i] @ sm[i] / max(val, 1e-12)
 
 
+class MaxInternalStepOracle(RestrictedStep):             # :186-243
+    """Largest weighted internal-coordinate displacement: one weight per block of coordinates, in the storage
+    order translations, bonds, angles, dihedrals, other, rotations (+ cell degrees of freedom)."""
+    names = ['mis', 'max internal step']
+
+    def __init__(self, pes, *args, wx=1., wb=1., wa=1., wd=1., wo=1., wc=1., **kwargs):
+        if pes.int is None:
+            raise ValueError("Internal coordinates are required for the MaxInternalStep trust region method")
+        self.wx, self.wb, self.wa, self.wd, self.wo, self.wc = wx, wb, wa, wd, wo, wc
+        RestrictedStep.__init__(self, pes, *args, **kwargs)
+
+    def weights(self):                                   # _get_weights :217-243
+        i = self.pes.int
+        w = ([self.wx] * i.ntrans + [self.wb] * i.nbonds + [self.wa] * i.nangles + [self.wd] * i.ndihedrals
+             + [self.wo] * i.nother + [self.wx] * i.nrotations + [self.wc] * getattr(self.pes, 'n_cell_dof', 0))
+        return np.array(w, dtype=float)
+
+    def cons(self, s, dsda=None):                        # :206-216
+        w = self.weights()
+        assert len(w) == len(s)
+        sw = np.abs(s * w)
+        i = np.argmax(sw)
+        if dsda is None:
+            return sw[i]
+        return sw[i], np.sign(s[i]) * dsda[i] * w[i]
+
+
 def get_restricted_step(name):                           # :249-253
-    for cls in (TrustRegionStep, PerAtomStep):
+    for cls in (TrustRegionStep, PerAtomStep, MaxInternalStepOracle):
         if name in cls.names:
             return cls
     raise ValueError("Unknown restricted step name: {}".format(name))

@@ -152,24 +152,98 @@ class RotationGenerator(Coordinate):
 
 
 class _HessianStack:
-    """Per-coordinate Hessians with the `ldot` contraction of SparseInternalHessians
-    (sella/linalg.py:601-618): ldot(v) = sum_i v_i H_i as a dense (ndof, ndof) matrix."""
+    """Per-coordinate Hessians held as blocks — (dof index array (nc, m), hess (nc, m, m)) per group of
+    coordinates that touch the same number of atoms, rows numbered through the groups in order — with the
+    contractions of SparseInternalHessians (sella/linalg.py:520-646): `ldot(v) = sum_i v_i H_i` as a dense
+    (ndof, ndof) matrix (:601-618), `rdot(x)_i = H_i x` (:620-640), `ddot(u, x)_i = u . H_i x` (:642-646),
+    `asarray()` the dense stack (:595-596).  An atom that occurs twice in one coordinate (a periodic image of
+    itself) accumulates, as the reference's np.add.at / bincount scatter does."""
 
     def __init__(self, ndof, blocks):
         self.ndof = ndof
-        self.blocks = blocks        # list of (dof index array (nc, m), hess (nc, m, m))
+        self.blocks = blocks
+        self.shape = (sum(len(d) for d, _ in blocks), ndof, ndof)
 
-    def ldot(self, v):
-        out = np.zeros((self.ndof, self.ndof))
+    def _groups(self):
         off = 0
         for dofs, H in self.blocks:
             nc = len(dofs)
-            if nc:
-                w = np.asarray(v[off:off + nc])
-                rows = np.repeat(dofs[:, :, None], dofs.shape[1], axis=2)
-                cols = np.repeat(dofs[:, None, :], dofs.shape[1], axis=1)
-                np.add.at(out, (rows.ravel(), cols.ravel()), (w[:, None, None] * H).ravel())
+            if nc and dofs.shape[1]:
+                yield off, dofs, H
             off += nc
+
+    def ldot(self, v):
+        out = np.zeros((self.ndof, self.ndof))
+        for off, dofs, H in self._groups():
+            nc, m = dofs.shape
+            w = np.asarray(v[off:off + nc])
+            rows = np.repeat(dofs[:, :, None], m, axis=2)
+            cols = np.repeat(dofs[:, None, :], m, axis=1)
+            np.add.at(out, (rows.ravel(), cols.ravel()), (w[:, None, None] * H).ravel())
+        return out
+
+    def rdot(self, x):
+        x = np.asarray(x, dtype=np.float64).ravel()
+        out = np.zeros((self.shape[0], self.ndof))
+        for off, dofs, H in self._groups():
+            nc = len(dofs)
+            hv = np.einsum('iab,ib->ia', H, x[dofs])
+            np.add.at(out, (np.arange(off, off + nc)[:, None], dofs), hv)
+        return out
+
+    def ddot(self, u, x):
+        u, x = np.asarray(u, dtype=np.float64).ravel(), np.asarray(x, dtype=np.float64).ravel()
+        out = np.zeros(self.shape[0])
+        for off, dofs, H in self._groups():
+            out[off:off + len(dofs)] = np.einsum('ia,iab,ib->i', u[dofs], H, x[dofs])
+        return out
+
+    def asarray(self):
+        out = np.zeros(self.shape)
+        for off, dofs, H in self._groups():
+            nc, m = dofs.shape
+            i = np.repeat(np.arange(off, off + nc), m * m)
+            rows = np.repeat(dofs[:, :, None], m, axis=2).ravel()
+            cols = np.repeat(dofs[:, None, :], m, axis=1).ravel()
+            np.add.at(out, (i, rows, cols), H.ravel())
+        return out
+
+
+class _JacobianStack:
+    """Per-coordinate gradients as blocks (dof index array (nc, m), grad (nc, m)): the scatter and the two
+    products of SparseInternalJacobian (sella/linalg.py:362-401)."""
+
+    def __init__(self, ndof, blocks):
+        self.ndof = ndof
+        self.blocks = blocks
+        self.shape = (sum(len(d) for d, _ in blocks), ndof)
+
+    def _groups(self):
+        off = 0
+        for dofs, G in self.blocks:
+            nc = len(dofs)
+            if nc and dofs.shape[1]:
+                yield off, dofs, G
+            off += nc
+
+    def asarray(self):
+        B = np.zeros(self.shape)
+        for off, dofs, G in self._groups():
+            np.add.at(B, (np.arange(off, off + len(dofs))[:, None], dofs), G)
+        return B
+
+    def matvec(self, x):
+        x = np.asarray(x, dtype=np.float64).ravel()
+        out = np.zeros(self.shape[0])
+        for off, dofs, G in self._groups():
+            out[off:off + len(dofs)] = np.einsum('ia,ia->i', G, x[dofs])
+        return out
+
+    def rmatvec(self, y):
+        y = np.asarray(y, dtype=np.float64).ravel()
+        out = np.zeros(self.ndof)
+        for off, dofs, G in self._groups():
+            np.add.at(out, dofs, y[off:off + len(dofs), None] * G)
         return out
 
 
@@ -502,18 +576,19 @@ class InternalCoordinates:
             vec[-nd:] = (vec[-nd:] + np.pi) % (2 * np.pi) - np.pi
         return vec
 
-    def jacobian(self):
-        """Dense Wilson B-matrix dq/dx, (nint, 3N) (internal.py:1780-1902)."""
-        B = np.zeros((self.nint, self.ndof))
-        row = 0
+    def jacobian_blocks(self):
+        """The B-matrix as per-kind gradient blocks (`_JacobianStack`)."""
+        blocks = []
         for k in self._order:
             pos, tvec, dofs = self._batch(k)
             nc = len(pos)
-            if nc:
-                g = evaluate_kind(k, pos, tvec, hessian=False)[1].reshape(nc, -1)
-                B[np.arange(row, row + nc)[:, None], dofs] = g        # the atoms of one coordinate are distinct
-            row += nc
-        return B
+            g = evaluate_kind(k, pos, tvec, hessian=False)[1].reshape(nc, -1) if nc else np.zeros((0, dofs.shape[1]))
+            blocks.append((dofs, g))
+        return _JacobianStack(self.ndof, blocks)
+
+    def jacobian(self):
+        """Dense Wilson B-matrix dq/dx, (nint, 3N) (internal.py:1780-1902)."""
+        return self.jacobian_blocks().asarray()
 
     def jacobian_csr(self):
         """The same B-matrix in CSR form, 6 / 9 / 12 stored entries per row (the sparsity the reference keeps
@@ -550,19 +625,20 @@ class InternalCoordinates:
         return out
 
     def hessian_rdot(self, v):
-        """D(v)_i = H_i v as a dense (nint, 3N) matrix (internal.py:2307-2575: one HVP per coordinate)."""
+        """D(v)_i = H_i v as a dense (nint, 3N) matrix (internal.py:2307-2575: one HVP per coordinate, from the
+        device's Hessian-vector kernel; the scatter is `_JacobianStack`'s)."""
         v = np.asarray(v, dtype=np.float64).ravel()
-        D = np.zeros((self.nint, self.ndof))
-        row = 0
+        blocks = []
         for k in self._order:
             pos, tvec, dofs = self._batch(k)
             nc = len(pos)
             if nc:
                 tan = v[dofs].reshape(pos.shape)
                 hv = evaluate_kind(k, pos, tvec, tangent=tan, hessian=False)[3].reshape(nc, -1)
-                D[np.arange(row, row + nc)[:, None], dofs] = hv
-            row += nc
-        return D
+            else:
+                hv = np.zeros((0, dofs.shape[1]))
+            blocks.append((dofs, hv))
+        return _JacobianStack(self.ndof, blocks).asarray()
 
     def hessian(self):
         """Per-coordinate Hessian blocks with the `ldot` contraction (internal.py:2189-2305)."""

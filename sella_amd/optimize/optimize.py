@@ -47,6 +47,7 @@ class Sella(Optimizer):
         self.exact_geodesic = exact_geodesic is None or bool(exact_geodesic)
         self.optimize_cell = False
         self.user_internal, self.peskwargs = internal, dict(kwargs)
+        self._user_constraints = constraints
         own_traj = isinstance(trajectory, str)
         if own_traj:                                                              # :144-150
             from ..peswrapper import open_trajectory
@@ -204,10 +205,15 @@ class Sella(Optimizer):
         if not self.internal:
             return False
         pes = self.pes
-        stale = bool(getattr(pes, 'bad_int', None)) or bool(pes.int.check_for_bad_internals())
+        # both are index arrays (np.flatnonzero) or None: an array has no truth value, and [0] would read as False
+        stale = getattr(pes, 'bad_int', None) is not None or pes.int.check_for_bad_internals() is not None
         if not stale:
             return False
-        self.initialize_pes(pes.atoms, trajectory=pes.traj, order=self.ord, eta=pes.eta, constraints=self.constraints,
+        # the user's Constraints object goes along when the internals are regenerated from the geometry (with a
+        # user-supplied InternalCoordinates object the constraints live inside it)
+        from ..internal import InternalCoordinates
+        cons = None if isinstance(self.user_internal, InternalCoordinates) else self._user_constraints
+        self.initialize_pes(pes.atoms, trajectory=pes.traj, order=self.ord, eta=pes.eta, constraints=cons,
                             v0=None, internal=self.user_internal, hessian_function=pes.hessian_function,
                             **self.peskwargs)
         self.initialized = False

@@ -107,11 +107,22 @@ class BaseRestrictedStep:
         self.alphas.append(alpha)
         return total, size, dsize
 
+    def _device_search_applies(self):
+        """The one-call device search evaluates the BUILT-IN families and measures.  A user-supplied stepper that
+        overrides `get_s` (or never ran `BaseStepper._stepper_init`), a restricted-step subclass with its own `cons`,
+        or one without a named measure is searched on the host with the same schedule."""
+        st = self.stepper
+        if self._lift is not None or self.measure is None or getattr(st, '_dev', None) is None:
+            return False
+        if getattr(type(st), 'get_s', None) is not BaseStepper.get_s:
+            return False
+        return any(type(self).cons is base.cons for base in _builtin_measures())
+
     def get_s(self):
-        solve = getattr(self.stepper, 'solve_radius', None)
-        if solve is not None and self._lift is None:
-            s, size, trials = solve(self.measure, self.delta, self.tol, self.maxiter, scons=self.scons,
-                                    orthonormal=self._orthonormal, **self._measure_args())
+        if self._device_search_applies():
+            s, size, trials = self.stepper.solve_radius(self.measure, self.delta, self.tol, self.maxiter,
+                                                        scons=self.scons, orthonormal=self._orthonormal,
+                                                        **self._measure_args())
             self.alphas = list(trials)
             return s, size
         del self.alphas[:]
@@ -206,6 +217,10 @@ class MaxInternalStep(BaseRestrictedStep):
 
 
 _all_restricted_step = [TrustRegion, RestrictedAtomicStep, MaxInternalStep]
+
+
+def _builtin_measures():
+    return (TrustRegion, IRCTrustRegion, RestrictedAtomicStep, MaxInternalStep)
 
 
 def get_restricted_step(name):

@@ -515,7 +515,7 @@ class _BFactor:
         G = ((self.Bs @ self.BsT) if self.left else (self.BsT @ self.Bs)).toarray()
         n = G.shape[0]
         if n == 0:
-            self.rank, self.s, self.M = 0, np.zeros(0), None
+            self.rank, self.s, self.M, self._N0 = 0, np.zeros(0), None, None
             self._Q, self._R, self.BinvQ, self._dense = np.zeros((nint, 0)), np.zeros((0, nx)), np.zeros((nx, 0)), None
             return
         hG = ctx.upload(G)
@@ -524,7 +524,11 @@ class _BFactor:
         V.free()
         floor = max(tol * tol, 64 * n * np.finfo(float).eps * max(w[-1], 0.0))
         keep = np.flatnonzero(w > floor)[::-1]                    # descending singular values
-        Vr = Vt.numpy()[keep]                                     # (r, n): eigenvectors as rows
+        Vall = Vt.numpy()
+        Vr = Vall[keep]                                           # (r, n): eigenvectors as rows
+        # null space of the Gram matrix = null(B) on the Cartesian side (rigid-body motions): its basis lets
+        # `pinv_dot_moved` return the MINIMUM-NORM solution at a nearby geometry
+        self._N0 = None if self.left else np.ascontiguousarray(Vall[np.setdiff1d(np.arange(n), keep)].T)
         Vt.free()
         self.s = np.sqrt(w[keep])
         self.rank = len(keep)
@@ -563,19 +567,31 @@ class _BFactor:
             return self.BsT @ ctx.symm_mm(self.M, Y)
         return ctx.symm_mm(self.M, self.BsT @ Y)
 
+    _NULL_MAX = 16          # more null directions than this: not a rigid-body null space, factorise anew
+
     def pinv_dot_moved(self, Bs_new, Y, tol=1e-11, maxit=30):
         """B_new^+ Y for the Jacobian of a NEARBY geometry, without a new factorisation: preconditioned conjugate
         gradients on the normal equations (B_new^T B_new) x = B_new^T Y with this factor's M = (B^T B)^+ as the
         preconditioner — M B_new^T B_new is the projector onto range(B^T) plus a perturbation of the size of the
         geometry change, so a handful of iterations (two sparse products and one device panel product each) reach
-        1e-11.  The result is a least-squares solution; where the null space of B_new has rotated away from this
-        factor's (rigid rotations of a molecule) it differs from the minimum-norm one by a null vector of B_new, i.e.
-        by a motion that changes no internal coordinate.  Returns None if it does not converge (the caller then
-        factorises anew)."""
+        1e-11.  The CG iterates stay in range(B^T) of the OLD geometry, so what converges is a least-squares solution
+        that differs from the minimum-norm one by a null vector of B_new (the null space — rigid rotations of a
+        molecule — has turned with the geometry).  The same solve therefore carries d extra columns B_new N0 (N0 = this
+        factor's null basis, d = 3 ... 6): N0 - C spans null(B_new), and the solution is projected onto its
+        orthogonal complement, which makes it B_new^+ Y exactly (the reference applies the pseudo-inverse of the
+        current point, peswrapper.py:1200-1221).  Returns None if CG does not converge or the null space is not
+        a small rigid-body one (the caller then factorises anew)."""
         if self.M is None or self.left or np.size(Y) == 0:
             return None
         ctx = get_context()
         Y2 = Y[:, None] if np.ndim(Y) == 1 else Y
+        ny = Y2.shape[1]
+        N0 = self._N0
+        d = 0 if N0 is None else N0.shape[1]
+        if d > self._NULL_MAX:
+            return None
+        if d:
+            Y2 = np.column_stack((Y2, np.asarray(Bs_new @ N0)))
         BT_new = Bs_new.T.tocsr()
         R = np.asarray(BT_new @ Y2)
         X = np.zeros_like(R)
@@ -583,12 +599,15 @@ class _BFactor:
         P = Z.copy()
         rz = np.einsum('ij,ij->j', R, Z)
         rz0 = np.where(rz > 0, rz, 1.0)
+        # (null directions that B_new barely sees start with a residual at rounding level: relative to the scale
+        # of the data columns they are converged from the start)
+        floor = tol * tol * max(float(rz0[:ny].max()), 1e-300) * 1e-6
         for _ in range(maxit):
             AP = np.asarray(BT_new @ (Bs_new @ P))
             pap = np.einsum('ij,ij->j', P, AP)
-            live = (rz > tol * tol * rz0) & (pap > 0)
+            live = (rz > np.maximum(tol * tol * rz0, floor)) & (pap > 0)
             if not live.any():
-                return X[:, 0] if np.ndim(Y) == 1 else X
+                break
             alpha = np.where(live, rz / np.where(pap > 0, pap, 1.0), 0.0)
             X += alpha * P
             R -= alpha * AP
@@ -596,7 +615,13 @@ class _BFactor:
             rz_new = np.einsum('ij,ij->j', R, Z)
             P = Z + np.where(live, rz_new / np.where(rz != 0, rz, 1.0), 0.0) * P
             rz = rz_new
-        return None
+        else:
+            return None
+        sol = X[:, :ny]
+        if d:
+            Nn, _ = np.linalg.qr(N0 - X[:, ny:])                 # orthonormal basis of null(B_new)
+            sol = sol - Nn @ (Nn.T @ sol)
+        return sol[:, 0] if np.ndim(Y) == 1 else sol
 
     def pinvT_dot(self, Y):
         """(B^+)^T Y for Y (3N,) or (3N, k) — e.g. the Cartesian gradient -> internal gradient."""
@@ -650,6 +675,10 @@ class InternalPES(PES):
         if new_int.cons is None:
             new_int.cons = Constraints(atoms)
         kwargs.pop('constraints', None)
+        # global translations / rotations are never projected out in internal space (peswrapper.py:633-641): a
+        # caller's `Sella(internal=True, proj_rot=...)` must not collide with the explicit keywords below
+        kwargs.pop('proj_trans', None)
+        kwargs.pop('proj_rot', None)
         self._factor_cache = _LRU2()
         self._Hc_cache = _LRU2()
         PES.__init__(self, atoms, *args, constraints=new_int.cons, H0=None, proj_trans=False, proj_rot=False,

@@ -89,3 +89,11 @@ class FakePES:
 
     def get_HL_projected(self, U):
         return self.Hcls(U.shape[1], 0, U.T @ self.H.B @ U)
+
+
+class InternalCounts:
+    """The block counts `MaxInternalStep._get_weights` reads from `pes.int` (restricted_step.py:217-243)."""
+
+    def __init__(self, ntrans, nbonds, nangles, ndihedrals, nother, nrotations):
+        self.ntrans, self.nbonds, self.nangles, self.ndihedrals = ntrans, nbonds, nangles, ndihedrals
+        self.nother, self.nrotations = nother, nrotations

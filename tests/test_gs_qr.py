@@ -45,3 +45,39 @@ def test_qr_thin(ctx):
         assert np.abs(np.tril(R, -1)).max() == 0
         Qr, Rr = np.linalg.qr(A)          # same Householder sign convention as LAPACK
         np.testing.assert_allclose(np.abs(R), np.abs(Rr), atol=1e-11 * m)
+
+
+def test_accelerator_seam_by_name(ctx):
+    """The five functions of the reference's accelerator seam (sella/_gpu.py:38-132), called BY THESE NAMES with the
+    reference's numpy-in / numpy-out contract: `to_gpu`, `gpu_eigh(A, A_gpu=None)`, `gpu_eigh_t(A_gpu)`,
+    `gpu_qr(A)`, `gpu_project(H, U, H_gpu=None)` — and `_gpu_ok`."""
+    from sella_amd import _gpu
+    from sella_amd._gpu import _gpu_ok, gpu_eigh, gpu_eigh_t, gpu_project, gpu_qr, to_gpu
+    assert set(_gpu.__all__) >= {'to_gpu', 'gpu_eigh', 'gpu_eigh_t', 'gpu_qr', 'gpu_project'}
+    rng = np.random.RandomState(9)
+    n, m = 48, 11
+    A = rng.normal(size=(n, n))
+    A = 0.5 * (A + A.T)
+    A0 = A.copy()
+    assert _gpu_ok(n)
+    h = to_gpu(A)
+    np.testing.assert_array_equal(h.numpy(), A)                     # upload / download round trip
+    w, V = gpu_eigh(A)
+    wl = np.linalg.eigvalsh(A)
+    np.testing.assert_allclose(w, wl, atol=1e-12 * n)
+    np.testing.assert_allclose(A @ V, V * w, atol=1e-11 * n)
+    np.testing.assert_allclose(V.T @ V, np.eye(n), atol=1e-12 * n)
+    w2, V2 = gpu_eigh(None, A_gpu=h)                                # cached device copy (linalg.py:183-207)
+    np.testing.assert_allclose(w2, w, atol=1e-13)
+    w3, Vd, Vtd = gpu_eigh_t(h)
+    np.testing.assert_allclose(w3, w, atol=1e-13)
+    np.testing.assert_allclose(Vd.numpy(), Vtd.numpy().T, atol=0)
+    B = rng.normal(size=(n, m))
+    Q, R = gpu_qr(B)
+    assert Q.shape == (n, m) and R.shape == (m, m)
+    np.testing.assert_allclose(Q @ R, B, atol=1e-12 * n)
+    np.testing.assert_allclose(Q.T @ Q, np.eye(m), atol=1e-13 * n)
+    U = np.linalg.qr(rng.normal(size=(n, m)))[0]
+    np.testing.assert_allclose(gpu_project(A, U), U.T @ A @ U, atol=1e-12 * n)
+    np.testing.assert_allclose(gpu_project(None, U, H_gpu=h), U.T @ A @ U, atol=1e-12 * n)
+    np.testing.assert_array_equal(A, A0)                            # inputs are never mutated (_gpu.py:64)

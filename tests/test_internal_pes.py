@@ -327,6 +327,75 @@ def test_internal_space_quantities_match_dense_formulas(ctx):
     assert Ucons.shape[1] == 1 and Ufree.shape[1] == Unred.shape[1] - 1
 
 
+def test_moved_pseudo_inverse_is_minimum_norm(ctx):
+    """`_BFactor.pinv_dot_moved` (the exact geodesic's pseudo-inverse at the current point, peswrapper.py:1200-1221,
+    carried from the starting point's factor by preconditioned CG) must equal B_new^+ Y — the MINIMUM-NORM solution —
+    also when the molecule has turned, i.e. when null(B_new) (rigid rotations) is no longer the starting null space."""
+    from sella_amd.internal import InternalCoordinates
+    from sella_amd.peswrapper import _BFactor
+    from sella_amd.atoms import Atoms, MorseCluster
+    # compact cluster: redundant internals (nint >= 3N), so the Gram matrix is the Cartesian-side one
+    pos = np.array([[0., 0., 0.], [1.5, 0.1, 0.], [0.7, 1.3, 0.1], [0.8, 0.5, 1.2], [2.0, 1.4, 1.0]])
+    at = Atoms(['C'] * 5, pos)
+    at.calc = MorseCluster(D=1.0, a=1.2, r0=1.45)
+    ic = InternalCoordinates.from_atoms(at)
+    assert ic.nint >= 15
+    fac0 = _BFactor(ic.jacobian_csr())
+    assert fac0._N0 is not None and fac0._N0.shape[1] == 6                 # translations + rotations
+    # rotate by 0.25 rad about a skew axis and distort a little
+    ax = np.array([0.3, -0.5, 0.8])
+    ax /= np.linalg.norm(ax)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    Rm = np.eye(3) + np.sin(0.25) * K + (1 - np.cos(0.25)) * K @ K
+    cen = at.positions.mean(axis=0)
+    rng = np.random.RandomState(11)
+    at.positions = (at.positions - cen) @ Rm.T + cen + 0.01 * rng.normal(size=at.positions.shape)
+    Bnew = ic.jacobian_csr()
+    Y = rng.normal(size=(Bnew.shape[0], 2))
+    got = fac0.pinv_dot_moved(Bnew, Y)
+    assert got is not None
+    want = np.linalg.pinv(Bnew.toarray(), rcond=1e-9) @ Y
+    fresh = _BFactor(Bnew).pinv_dot(Y)
+    np.testing.assert_allclose(fresh, want, atol=1e-8 * np.abs(want).max())
+    np.testing.assert_allclose(got, want, atol=1e-8 * np.abs(want).max())
+    np.testing.assert_allclose(fac0.pinv_dot_moved(Bnew, Y[:, 0]), want[:, 0], atol=1e-8 * np.abs(want).max())
+
+
+def test_real_bad_angles_trigger_the_rebuild(ctx):
+    """The real return type of `check_for_bad_internals` (index array or None, internal.py:3704-3736) through
+    `Sella._rebuild_if_internals_degraded`: one bad angle at index 0 and two bad angles at once both rebuild."""
+    from sella_amd import Sella
+    from sella_amd.atoms import Atoms, MorseCluster
+    from sella_amd.internal import InternalCoordinates
+    for bend in ([0], [0, 1]):
+        pos = np.array([[0., 0., 0.], [1.45, 0.3, 0.], [2.9, 0.0, 0.1], [4.3, 0.5, 0.0], [5.6, 0.2, 0.4]])
+        at = Atoms(['C'] * 5, pos.copy())
+        at.calc = MorseCluster(D=1.0, a=1.2, r0=1.45)
+        ic = InternalCoordinates(at, bonds=np.array([[0, 1], [1, 2], [2, 3], [3, 4]]),
+                                 angles=np.array([[0, 1, 2], [1, 2, 3], [2, 3, 4]]))
+        opt = Sella(at, order=0, internal=ic, logfile=None, exact_geodesic=False)
+        assert opt.pes.int.check_for_bad_internals() is None
+        first = opt.pes
+        # straighten the chosen angles past 165 degrees, the others stay well bent
+        d = 1.45
+        c60, s60 = 0.5, np.sqrt(0.75)
+        new = np.zeros((5, 3))
+        new[1] = [d, 0.01, 0]
+        new[2] = [2 * d, 0, 0]
+        if bend == [0]:
+            new[3] = new[2] + d * np.array([c60, s60, 0])
+            new[4] = new[3] + d * np.array([s60, -c60, 0])
+        else:
+            new[3] = [3 * d, 0.01, 0]
+            new[4] = new[3] + d * np.array([c60, s60, 0])
+        at.positions = new
+        bad = opt.pes.int.check_for_bad_internals()
+        assert bad is not None and list(bad) == bend
+        opt.user_internal = True                                            # regenerate the internals from the geometry
+        assert opt._rebuild_if_internals_degraded()
+        assert opt.pes is not first and not opt.initialized and opt.rho == 1
+
+
 def test_bad_internals_rebuild_the_pes(ctx, monkeypatch):
     """optimize.py:384-410: when a step leaves an internal coordinate degenerate, `Sella.step` builds a fresh PES
     (new internals from the geometry reached, new Hessian, initial diagonalisation pending), resets rho and skips
@@ -342,7 +411,7 @@ def test_bad_internals_rebuild_the_pes(ctx, monkeypatch):
 
     def once_bad(self):
         calls['n'] += 1
-        return {'bonds': [], 'angles': ['forced']} if calls['n'] == 1 else real(self)
+        return np.array([0]) if calls['n'] == 1 else real(self)            # one bad angle, at index 0
     monkeypatch.setattr(InternalCoordinates, 'check_for_bad_internals', once_bad)
     opt.step()
     assert opt.pes is not first_pes and not opt.initialized and opt.rho == 1 and opt.delta == delta

@@ -127,6 +127,81 @@ def test_internal_coordinates_container(ctx):
     np.testing.assert_allclose(B @ t, 0.0, atol=1e-12)
 
 
+def _g11_blocks(g, i, sizes, order=None):
+    """Golden blocks as the product's stacks take them: one group per run of equal-sized coordinates in `order`."""
+    order = list(range(len(sizes))) if order is None else list(order)
+    jb, hb = [], []
+    for k in order:
+        idx = g[f'c{i}_idx{k}']
+        dofs = (3 * idx[:, None] + np.arange(3)[None, :]).reshape(1, -1)
+        m = dofs.shape[1]
+        jb.append((dofs, g[f'c{i}_g{k}'].reshape(1, m)))
+        hb.append((dofs, g[f'c{i}_h{k}'].reshape(1, m, m)))
+    # merge neighbours of equal size into one batched group (the way the classes are fed in production)
+    def merge(blocks):
+        out = []
+        for dofs, val in blocks:
+            if out and out[-1][0].shape[1] == dofs.shape[1]:
+                out[-1] = (np.vstack((out[-1][0], dofs)), np.concatenate((out[-1][1], val)))
+            else:
+                out.append((dofs, val))
+        return out
+    return merge(jb), merge(hb)
+
+
+def test_golden_sparse_internal(manifest):
+    """a17: the scatter / contraction layer of the internal-coordinate Jacobian and Hessians against the reference's
+    SparseInternalJacobian / SparseInternalHessian(s) (sella/linalg.py:362-646; fixture g11 generated by
+    oracle/make_golden.py from the real classes): asarray, matvec, rmatvec; ldot, rdot, ddot, asarray — fed in the
+    reference's mixed order and grouped by size as in production (bonds, angles, dihedrals)."""
+    from conftest import load_golden
+    from sella_amd.internal import _HessianStack, _JacobianStack
+    g = load_golden('g11_sparse_internal')
+    for case in manifest['g11_sparse_internal']:
+        i, natoms, sizes = case['id'], case['natoms'], case['sizes']
+        x, u, y = g[f'c{i}_x'], g[f'c{i}_u'], g[f'c{i}_y']
+        for order in (None, np.argsort(sizes, kind='stable')):
+            perm = np.arange(len(sizes)) if order is None else np.asarray(order)
+            jb, hb = _g11_blocks(g, i, sizes, order)
+            J = _JacobianStack(3 * natoms, jb)
+            H = _HessianStack(3 * natoms, hb)
+            np.testing.assert_allclose(J.asarray(), g[f'c{i}_J'][perm], atol=1e-14)
+            np.testing.assert_allclose(J.matvec(x), g[f'c{i}_Jx'][perm], atol=1e-13)
+            np.testing.assert_allclose(J.rmatvec(y[perm]), g[f'c{i}_JTy'], atol=1e-13)
+            np.testing.assert_allclose(H.asarray(), g[f'c{i}_Hall'][perm], atol=1e-14)
+            np.testing.assert_allclose(H.ldot(y[perm]), g[f'c{i}_ldot'], atol=1e-13)
+            np.testing.assert_allclose(H.rdot(x), g[f'c{i}_rdot'][perm], atol=1e-13)
+            np.testing.assert_allclose(H.ddot(u, x), g[f'c{i}_ddot'][perm], atol=1e-13)
+        single = _HessianStack(3 * natoms, _g11_blocks(g, i, sizes[:1])[1])
+        np.testing.assert_allclose(single.asarray()[0], g[f'c{i}_H0'], atol=1e-14)
+        np.testing.assert_allclose(single.rdot(x)[0], g[f'c{i}_H0x'], atol=1e-13)
+
+
+def test_container_contractions_agree_with_the_stacks(ctx):
+    """The device-evaluated coordinate data through the same pinned scatter layer: `hessian().rdot(v)` (dense
+    per-coordinate Hessians) equals `hessian_rdot(v)` (Hessian-vector kernel), `ddot` and `asarray` agree with
+    `ldot`, and the CSR B-matrix equals the dense one — incl. a bond between an atom and its own periodic image."""
+    from sella_amd.atoms import Atoms
+    from sella_amd.internal import InternalCoordinates, angles_from_bonds, neighbour_bonds
+    slab = _slab((2, 2, 2))
+    bonds, bncv = neighbour_bonds(slab, 1.25 * 3.61 / np.sqrt(2))
+    angles, ancv = angles_from_bonds(bonds, bncv)
+    ic = InternalCoordinates(slab, bonds=bonds, angles=angles[:40], bond_ncvecs=bncv, angle_ncvecs=ancv[:40])
+    rng = np.random.RandomState(4)
+    v, u, w = rng.normal(size=ic.ndof), rng.normal(size=ic.ndof), rng.normal(size=ic.nint)
+    H = ic.hessian()
+    np.testing.assert_allclose(H.rdot(v), ic.hessian_rdot(v), atol=1e-11)
+    np.testing.assert_allclose(H.ddot(u, v), ic.hessian_rdot(v) @ u, atol=1e-11)
+    np.testing.assert_allclose(np.einsum('i,ijk->jk', w, H.asarray()), H.ldot(w), atol=1e-12)
+    np.testing.assert_allclose(ic.jacobian_csr().toarray(), ic.jacobian(), atol=1e-15)
+    # one atom in a small periodic cell bonded to its own image: both ends scatter onto the same columns
+    at = Atoms(['Cu'], np.array([[0.1, 0.2, 0.3]]), cell=np.diag([2.5, 9.0, 9.0]), pbc=True)
+    one = InternalCoordinates(at, bonds=np.array([[0, 0]]), bond_ncvecs=np.array([[[1.0, 0.0, 0.0]]]))
+    np.testing.assert_allclose(one.calc(), [2.5], atol=1e-14)
+    np.testing.assert_allclose(one.jacobian(), np.zeros((1, 3)), atol=1e-14)          # -e_x + e_x
+    np.testing.assert_allclose(one.jacobian_csr().toarray(), np.zeros((1, 3)), atol=1e-14)
+
+
 def test_uploads_survive_the_pinned_ring_wrapping(ctx):
     """Host-to-device copies go through an 8 MB pinned ring that is rewound behind a synchronisation
     (csrc/context.hip `h2d_async`): far more than 8 MB of distinct payloads, every result still right."""

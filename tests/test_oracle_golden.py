@@ -170,3 +170,22 @@ def test_irc_steps(manifest):
                                          d1=d1.copy(), W=np.diag(1.0 / sqrtm)).get_s()
         assert smag == pytest.approx(float(g[f'c{i}_smag']), abs=1e-12)
         np.testing.assert_allclose(s, g[f'c{i}_s'], atol=1e-9 * max(1, np.abs(s).max()))
+
+
+def test_sparse_internal(manifest):
+    """oracle/sella_oracle/sparse_internal.py against the fixtures from the reference's sparse containers
+    (sella/linalg.py:362-646)."""
+    from oracle.sella_oracle import sparse_internal as spo
+    g = load_golden('g11_sparse_internal')
+    for case in manifest['g11_sparse_internal']:
+        i, natoms, sizes = case['id'], case['natoms'], case['sizes']
+        idx = [g[f'c{i}_idx{k}'] for k in range(len(sizes))]
+        gv = [g[f'c{i}_g{k}'] for k in range(len(sizes))]
+        hv = [g[f'c{i}_h{k}'] for k in range(len(sizes))]
+        x, u, y = g[f'c{i}_x'], g[f'c{i}_u'], g[f'c{i}_y']
+        np.testing.assert_allclose(spo.jacobian_dense(natoms, idx, gv), g[f'c{i}_J'], atol=1e-14)
+        np.testing.assert_allclose(spo.jacobian_matvec(natoms, idx, gv, x), g[f'c{i}_Jx'], atol=1e-13)
+        np.testing.assert_allclose(spo.jacobian_rmatvec(natoms, idx, gv, y), g[f'c{i}_JTy'], atol=1e-13)
+        np.testing.assert_allclose(spo.hessians_ldot(natoms, idx, hv, y), g[f'c{i}_ldot'], atol=1e-13)
+        np.testing.assert_allclose(spo.hessians_rdot(natoms, idx, hv, x), g[f'c{i}_rdot'], atol=1e-13)
+        np.testing.assert_allclose(spo.hessians_ddot(natoms, idx, hv, u, x), g[f'c{i}_ddot'], atol=1e-13)

@@ -6,7 +6,7 @@ import pytest
 
 import oracle.sella_oracle as orc
 from conftest import load_golden
-from helpers import FakePES
+from helpers import FakePES, InternalCounts
 
 
 def test_golden_steppers(ctx, manifest):
@@ -62,6 +62,91 @@ def test_golden_restricted_step(ctx, manifest):
         np.testing.assert_allclose(s, ref, atol=1e-10 * max(1, np.abs(ref).max()), err_msg=str(case))
         # same number of trial alphas as the reference algorithm (per-iteration parity)
         assert abs(len(rs.alphas) - int(g[f'c{i}_nalpha'])) <= 1, case
+
+
+def _mis_pes(Hcls, g, case, i):
+    pes = FakePES(Hcls, g[f'c{i}_H'], g[f'c{i}_g'], case['ncons'], seed=case['seed'])
+    pes.int = InternalCounts(*case['blocks'])
+    return pes
+
+
+def test_golden_restricted_mis(ctx, manifest):
+    """`mis` — MaxInternalStep (restricted_step.py:186-243), the trust measure of every internal-coordinate search —
+    against fixtures from the real reference class (oracle/make_golden.py::gen_restricted_mis): weights per block of
+    coordinates, step, reported size and the trial-alpha sequence of the search."""
+    from sella_amd.linalg import ApproximateHessian
+    from sella_amd.optimize.restricted_step import get_restricted_step
+    g = load_golden('g8_mis')
+    for case in manifest['g8_mis']:
+        i = case['id']
+        pes = _mis_pes(ApproximateHessian, g, case, i)
+        np.testing.assert_array_equal(pes.Ufree, g[f'c{i}_Ufree'])
+        rs = get_restricted_step('mis')(pes, case['order'], case['delta'], case['method'], **case['weights'])
+        np.testing.assert_array_equal(rs._get_weights(), g[f'c{i}_w'])
+        s, smag = rs.get_s()
+        ref, ref_alphas = g[f'c{i}_s'], g[f'c{i}_alphas']
+        np.testing.assert_allclose(smag, float(g[f'c{i}_smag']), rtol=1e-12)
+        m = min(len(rs.alphas), len(ref_alphas))
+        # the first trials are pinned tightly; deep in the bisection the bracket decisions sit in the rounding noise of
+        # the measure, so later alphas are compared through the step they lead to
+        head = min(m, 12)
+        np.testing.assert_allclose(rs.alphas[:head], ref_alphas[:head], rtol=1e-7, atol=1e-13, err_msg=str(case))
+        if case['method'] == 'rfo' and case['order'] >= 1 and len(ref_alphas) > 60:
+            cos = s @ ref / np.linalg.norm(s) / np.linalg.norm(ref)          # see test_golden_restricted_step
+            assert cos > 0.9, case
+            continue
+        assert abs(len(rs.alphas) - len(ref_alphas)) <= 1, case
+        np.testing.assert_allclose(s, ref, atol=1e-10 * max(1, np.abs(ref).max()), err_msg=str(case))
+
+
+def test_oracle_restricted_mis_golden(manifest):
+    g = load_golden('g8_mis')
+    for case in manifest['g8_mis']:
+        i = case['id']
+        ro = orc.get_restricted_step('mis')(_mis_pes(orc.QuasiNewtonHessian, g, case, i), case['order'], case['delta'],
+                                            case['method'], **case['weights'])
+        s, smag = ro.get_s()
+        np.testing.assert_allclose(s, g[f'c{i}_s'], atol=1e-9)
+        np.testing.assert_allclose(smag, float(g[f'c{i}_smag']), rtol=1e-12)
+        np.testing.assert_array_equal(ro.weights(), g[f'c{i}_w'])
+
+
+def test_user_supplied_families_are_searched_on_the_host(ctx):
+    """The one-call device search evaluates the built-in families and measures only: a stepper subclass with its own
+    `get_s`, or a restricted-step subclass with its own `cons`, goes through the host search with the same schedule."""
+    from conftest import hessian_like
+    from sella_amd.linalg import ApproximateHessian
+    from sella_amd.optimize.restricted_step import TrustRegion
+    from sella_amd.optimize.stepper import QuasiNewton
+    n = 24
+    A, P, gvec = hessian_like(n, seed=3)
+    calls = {'get_s': 0, 'cons': 0}
+
+    class HalfQuasiNewton(QuasiNewton):
+        def get_s(self, alpha):
+            calls['get_s'] += 1
+            s, ds = QuasiNewton.get_s(self, alpha)
+            return 0.5 * s, 0.5 * ds
+
+    class InfinityNorm(TrustRegion):
+        measure = None
+
+        def cons(self, s, dsda=None):
+            calls['cons'] += 1
+            i = int(np.abs(s).argmax())
+            return abs(s[i]) if dsda is None else (abs(s[i]), np.sign(s[i]) * dsda[i])
+
+    ref_s, ref_mag = TrustRegion(FakePES(ApproximateHessian, P, gvec, 0, 1), 1, 0.05, 'qn').get_s()
+    rs = TrustRegion(FakePES(ApproximateHessian, P, gvec, 0, 1), 1, 0.05, HalfQuasiNewton)
+    assert not rs._device_search_applies()
+    s, mag = rs.get_s()
+    assert calls['get_s'] > 1 and abs(np.linalg.norm(s) - 0.05) < 1e-9
+    rs2 = InfinityNorm(FakePES(ApproximateHessian, P, gvec, 0, 1), 1, 0.01, 'qn')
+    assert not rs2._device_search_applies()
+    s2, mag2 = rs2.get_s()
+    assert calls['cons'] > 1 and abs(np.abs(s2).max() - 0.01) < 1e-9
+    assert TrustRegion(FakePES(ApproximateHessian, P, gvec, 0, 1), 1, 0.05, 'qn')._device_search_applies()
+    assert abs(ref_mag - 0.05) < 1e-12 and abs(np.linalg.norm(ref_s) - 0.05) < 1e-9
 
 
 def test_alpha_trace_matches_oracle(ctx):

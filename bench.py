@@ -280,7 +280,12 @@ def main():
                 roof['traffic_source'] = pmc['source']
         except (OSError, KeyError, ValueError):
             pass
-        roof['share_of_step_ms'] = round(pt['ms'] / nprof, 2)
+        # every 4th column of the tridiagonalisation is instrumented (csrc/eigh.hip: the queue is drained before an
+        # instrumented column so that the packet time stamps are the kernel's own): the sampled time is a quarter of
+        # the kernel's share of a step
+        roof['sampled_every'] = 4
+        roof['sampled_ms_per_step'] = round(pt['ms'] / nprof, 2)
+        roof['share_of_step_ms'] = round(4.0 * pt['ms'] / nprof, 2)
         roof['davidson_matvec'] = hbm(pg, 'gemv_rows_kernel<NRHS,2> (n x n row-panel matvec of the Davidson loop)')
         roof['davidson_panel_dots'] = dict(launches=ps['launches'],
                                            mean_us=round(1e3 * ps['ms'] / max(1, ps['launches']), 2),
@@ -437,6 +442,13 @@ def main():
                            lowest_ritz=float(outb['lams'][0]), scaling='strong (rows of H sharded over the ranks)',
                            preconditioner='diagonal')
         if pp['launches']:
+            # Amdahl: only the panel pass shards over the ranks (rows of H); the rest of a block iteration is replicated
+            t_it, t_pp = 1e3 * tblk / nit, 1e-3 * block_stats['panel_pass_us'] * world
+            ser = max(0.0, 1.0 - t_pp / t_it) if world == 1 else None
+            if ser is not None:
+                block_stats['serial_fraction'] = round(ser, 3)
+                block_stats['amdahl_speedup_at_8_ranks'] = round(1.0 / (ser + (1.0 - ser) / 8.0), 2)
+        if pp['launches']:
             # the one MFMA kernel of the path: 2 * rows * n * 16 flop per pass against the dense fp64 MFMA peak
             # (78.6 TFLOP/s, MI355X_MICROARCH.md); it is an HBM-bound product — 16 flop per 8 streamed bytes
             tfl = 2.0 * (hi_ - lo_) * nb_ * 16 / max(1e-12, pp['ms'] * 1e-3 / pp['launches']) / 1e12
@@ -494,6 +506,17 @@ def main():
                    note='the exit point of the gamma = 0.1 run is chaotic in the reference itself (DESIGN.md section 4): '
                         'compare after 4 iterations, and the converged run in parity.converged_run')
 
+    if rank == 0 and roof is not None:
+        # the whole timed step in SURVEY section 8(d)'s own unit: 24 n^2 bytes per Davidson vector (A t, Q^T [r v],
+        # Q [a b]) + 8 n^3 / 3 bytes of trailing-matrix reads of the one-stage tridiagonalisation of P, per call
+        vec_per_call = total_iters / (args.steps * world)
+        alg = 24.0 * n * n * vec_per_call + 8.0 * n ** 3 / 3.0
+        gbs = alg / (tmax / args.steps) / 1e9
+        roof['whole_step'] = dict(algorithmic_bytes=round(alg), davidson_bytes=round(24.0 * n * n * vec_per_call),
+                                  eigh_bytes=round(8.0 * n ** 3 / 3.0), achieved_gbs=round(gbs, 1),
+                                  frac=round(gbs / HBM_PEAK_GBS, 4),
+                                  loop_only_gbs=round(24.0 * n * n * (it2 / t_loop) / 1e9, 1),
+                                  loop_only_frac=round(24.0 * n * n * (it2 / t_loop) / 1e9 / HBM_PEAK_GBS, 4))
     if rank == 0:
         value = total_iters / tmax
         line = {

@@ -274,7 +274,8 @@ int sella_ctx_create(int device, sella_ctx** out) {
     c->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
-        snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+        // (the marketing name is empty on some driver stacks: the architecture string always identifies the part)
+        snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName);
         c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     hipError_t e = hipStreamCreate(&c->stream);

@@ -11,8 +11,8 @@ tests an initialised `torch.distributed` gloo group takes its place.)  The data 
 
     results = run_ensemble(make_replica, 64, fmax=1e-3, steps=200, sella_kwargs=dict(order=1))
 
-`make_replica(i) -> atoms` must build replica i (with its calculator) deterministically from i, so
-every rank can construct exactly its own members.
+`make_replica(i) -> atoms` (or `(atoms, sella_keywords_of_this_member)`) must build replica i (with its
+calculator) deterministically from i, so every rank can construct exactly its own members.
 
 Within one GPU a small search (3N = 768) is bound by the host: Python between sub-millisecond kernels leaves the
 device idle two thirds of the time, and host threads do not help (the interpreter lock).  `EnsemblePool(P)` therefore
@@ -45,10 +45,14 @@ def local_members(n_replicas, rank, world):
 
 
 def run_one(atoms, fmax, steps, sella_kwargs):
-    """One saddle search; returns (summary[5], positions (N, 3))."""
+    """One saddle search; returns (summary[5], positions (N, 3)).  `atoms` may be a pair (atoms, keywords): what a
+    replica factory returns when a member needs `Sella` keywords of its own (its Constraints object, say)."""
     from .optimize.optimize import Sella
     kw = dict(logfile=None)
     kw.update(sella_kwargs or {})
+    if isinstance(atoms, tuple):
+        atoms, own = atoms
+        kw.update(own)
     opt = Sella(atoms, **kw)
     conv = opt.run(fmax=fmax, steps=steps)
     pes = opt.pes

@@ -33,3 +33,35 @@ class EnsembleFactory:
         at = Atoms(['X'] * (self.ne // 3), x0.copy(), pbc=True)
         at.calc = QuadraticCubicModel(lambda x, ctx=ctx, dA=dA: ctx.symm_mm(dA, x), U, c=0.05)
         return at
+
+
+def emt_slab(size, lift=1.9, seed=None, jitter=0.0, calculator=None):
+    """Cu(111) slab with one top-layer atom lifted onto the neighbouring bridge site (adatom + vacancy), lower half
+    frozen atom by atom — the README pattern (README.md:18-25).  Returns (atoms, Constraints, pinned atom indices)."""
+    from sella_amd import Constraints
+    from sella_amd.atoms import EMT, fcc111
+    slab = fcc111('Cu', size, vacuum=7.5)
+    if seed is not None:
+        slab.positions += jitter * np.random.RandomState(seed).normal(size=slab.positions.shape)
+    top = int(np.argmax(slab.positions[:, 2]))
+    site = slab.info['adsorbate_sites']['bridge']
+    slab.positions[top] += np.array([site[0], site[1], lift])
+    cons = Constraints(slab)
+    pinned = [a.index for a in slab if a.position[2] < slab.cell[2, 2] / 2.]
+    for i in pinned:
+        cons.fix_translation(i)
+    slab.calc = EMT() if calculator is None else calculator
+    return slab, cons, np.array(pinned)
+
+
+class EmtMember:
+    """Picklable factory of configs[3] members as BASELINE names them: member i = 256-atom Cu(111) EMT slab
+    (8 x 8 x 4) with a lifted surface atom, lower half pinned, thermal jitter from seed i; returns
+    (atoms, the member's own `Sella` keywords)."""
+
+    def __init__(self, size=(8, 8, 4)):
+        self.size = size
+
+    def __call__(self, i):
+        slab, cons, _ = emt_slab(self.size, seed=100 + i, jitter=0.02)
+        return slab, dict(constraints=cons)

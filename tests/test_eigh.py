@@ -78,15 +78,6 @@ def test_spectra(ctx):
     ctx.set_option('eigh_leaf', 32)
 
 
-@pytest.mark.gpu
-def test_benchmark_size(ctx):
-    if ctx.backend != 'hip':
-        pytest.skip('hardware only')
-    from conftest import hessian_like
-    A, P, g = hessian_like(3072, 0)
-    check(ctx, P, tol=2e-12)
-
-
 def _rank1_check(ctx, D, w, rho, tol=2e-14):
     K = len(D)
     lam, Ut = ctx.rank1_eig(D, w, rho)

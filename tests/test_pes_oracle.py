@@ -85,3 +85,35 @@ def test_pinned_slab_step_by_step(ctx):
         assert dev.delta == pytest.approx(t['delta'], rel=1e-5, abs=tol)
         # pinned coordinates never move
         np.testing.assert_array_equal(a1.positions[:6], pos[:6])
+
+
+def test_emt_slab_twin_step_by_step(ctx):
+    """BASELINE configs[1] on a down-sized twin — Cu(111) 3 x 3 x 4 EMT slab with a lifted surface atom, lower half
+    pinned atom by atom, default `Sella` — product (device EMT, selection bases, principal-submatrix view, carried
+    eigendecompositions, fused root finder) against the dense oracle driving the NumPy restatement of the EMT
+    (oracle/sella_oracle/emt.py), step by step.  The 1024-atom original runs in tests/test_configs_gpu.py."""
+    from conftest_shim import emt_slab
+    from oracle.sella_oracle.emt import EMTOracle
+    from sella_amd import Sella
+    a1, c1, pinned = emt_slab((3, 3, 4))
+    a2, _, _ = emt_slab((3, 3, 4), calculator=EMTOracle())
+    start = a1.positions.copy()
+    c2 = TranslationConstraints(a2)
+    for i in pinned:
+        c2.fix_translation(int(i))
+    np.testing.assert_allclose(a1.get_potential_energy(), a2.get_potential_energy(), atol=1e-10)
+    np.testing.assert_allclose(a1.get_forces(), a2.get_forces(), atol=1e-10)
+    dev = Sella(a1, constraints=c1, logfile=None)
+    ora = OracleSella(a2, c2, order=1, rs='ras')
+    for i in range(6):
+        x_before = dev.pes.get_x().copy()
+        dev.step()
+        ora.step()
+        t = ora.trace[-1]
+        tol = 2e-7 * 4 ** min(i, 8)
+        np.testing.assert_allclose(dev.pes.get_x() - x_before, t['s'], atol=tol, err_msg=f'step {i}')
+        assert abs(dev.pes.get_f() - t['f']) < tol, i
+        np.testing.assert_allclose(dev.pes.get_g(), t['g'], atol=10 * tol)
+        assert dev.delta == pytest.approx(t['delta'], rel=1e-5, abs=tol), i
+        np.testing.assert_array_equal(a1.positions[pinned], start[pinned])
+    assert dev.pes.neval == ora.pes.neval

@@ -128,18 +128,60 @@ int h2d_async(sella_ctx* c, void* dst, const void* src, size_t bytes) {
     }
     if (bytes > c->hring_bytes / 2) {                       // large payloads: the runtime's own staging
         HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));            // the source may be a temporary of the caller
-        return SELLA_OK;
+        return stream_wait(c);                              // the source may be a temporary of the caller
     }
     const size_t need = (bytes + 63) & ~(size_t)63;
-    if (c->hring_pos + need > c->hring_bytes) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        c->hring_pos = 0;
-    }
+    if (c->hring_pos + need > c->hring_bytes) SCHK(stream_wait(c));           // rewinds the ring
     char* slot = c->hring + c->hring_pos;
     memcpy(slot, src, bytes);
     HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
     c->hring_pos += need;
+    return SELLA_OK;
+}
+
+static constexpr size_t D2H_RING_BYTES = (size_t)8 << 20;
+
+int d2h_async_2d(sella_ctx* c, void* dst, const void* src_dev, size_t spitch, size_t width, size_t rows) {
+    const size_t bytes = width * rows;
+    if (bytes == 0) return SELLA_OK;
+    if (!c->dring) {
+        void* p = nullptr;
+        HIPCHK(hipHostMalloc(&p, D2H_RING_BYTES, hipHostMallocDefault));
+        c->dring = static_cast<char*>(p);
+        c->dring_bytes = D2H_RING_BYTES;
+        c->dring_pos = 0;
+    }
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (need > c->dring_bytes - c->dring_pos) {
+        if (need > c->dring_bytes) {                        // a whole matrix: the runtime's own staging, in place
+            if (rows == 1 || spitch == width)
+                HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+            else
+                HIPCHK(hipMemcpy2DAsync(dst, width, src_dev, spitch, width, rows, hipMemcpyDeviceToHost, c->stream));
+            return SELLA_OK;
+        }
+        SCHK(stream_wait(c));                                // delivers what is queued and rewinds the ring
+    }
+    char* slot = c->dring + c->dring_pos;
+    if (rows == 1 || spitch == width)
+        HIPCHK(hipMemcpyAsync(slot, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    else
+        HIPCHK(hipMemcpy2DAsync(slot, width, src_dev, spitch, width, rows, hipMemcpyDeviceToHost, c->stream));
+    c->d2h_pending.push_back({dst, slot, bytes, width, width, rows});
+    c->dring_pos += need;
+    return SELLA_OK;
+}
+
+int d2h_async(sella_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+    return d2h_async_2d(c, dst, src_dev, bytes, bytes, 1);
+}
+
+int stream_wait(sella_ctx* c) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (const auto& p : c->d2h_pending) memcpy(p.dst, p.slot, p.bytes);
+    c->d2h_pending.clear();
+    c->dring_pos = 0;
+    c->hring_pos = 0;                                        // nothing that reads the upload ring is still queued
     return SELLA_OK;
 }
 
@@ -156,10 +198,13 @@ int upload_panel(sella_ctx* c, const double* X, int n, int k, double* dpanel, in
 }
 
 int download_panel(sella_ctx* c, const double* dpanel, int ldp, int n, int k, double* X) {
+    if (k == 1) {
+        SCHK(d2h_async(c, X, dpanel, (size_t)n * sizeof(double)));
+        return stream_wait(c);
+    }
     std::vector<double> tmp((size_t)k * n);
-    HIPCHK(hipMemcpy2DAsync(tmp.data(), (size_t)n * sizeof(double), dpanel, (size_t)ldp * sizeof(double),
-                            (size_t)n * sizeof(double), k, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(d2h_async_2d(c, tmp.data(), dpanel, (size_t)ldp * sizeof(double), (size_t)n * sizeof(double), k));
+    SCHK(stream_wait(c));
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < k; ++j) X[(size_t)i * k + j] = tmp[(size_t)j * n + i];
     return SELLA_OK;
@@ -172,13 +217,13 @@ int read_scalars(sella_ctx* c, int offset, int count) {
     }
     HIPCHK(hipMemcpyAsync(c->hscal + offset, c->dscal + offset, (size_t)count * sizeof(double),
                           hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     return SELLA_OK;
 }
 
 int host_stage(sella_ctx* c, size_t bytes, void** p) {
     if (bytes > c->hstage_bytes) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(stream_wait(c));
         if (c->hstage) (void)hipHostFree(c->hstage);
         c->hstage = nullptr;
         c->hstage_bytes = 0;
@@ -194,7 +239,7 @@ double* scal_out(sella_ctx* c, int offset) { return (c->opt.host_scalars ? c->hs
 
 int sync_scalars(sella_ctx* c, int offset, int count) {
     if (!c->opt.host_scalars) return read_scalars(c, offset, count);
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     return SELLA_OK;
 }
 
@@ -218,7 +263,7 @@ void prof_end(sella_ctx* c) {
 
 int prof_flush(sella_ctx* c) {
     if (c->pending.empty()) return SELLA_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     for (auto& p : c->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -278,7 +323,12 @@ int sella_ctx_create(int device, sella_ctx** out) {
         snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName);
         c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    hipError_t e = hipStreamCreate(&c->stream);
+    // A stream of its own per context, NOT synchronising with the legacy default stream: with several contexts per
+    // process (ensemble members on host threads) a blocking stream would serialise behind every other context's
+    // implicit default-stream work.  SELLA_STREAM_BLOCKING=1 restores hipStreamCreate's default for comparison.
+    const char* sb = getenv("SELLA_STREAM_BLOCKING");
+    hipError_t e = (sb && sb[0] == '1') ? hipStreamCreate(&c->stream)
+                                        : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
         delete c;
@@ -307,6 +357,7 @@ int sella_ctx_destroy(sella_ctx* c) {
     if (c->hscal) (void)hipHostFree(c->hscal);
     if (c->hstage) (void)hipHostFree(c->hstage);
     if (c->hring) (void)hipHostFree(c->hring);
+    if (c->dring) (void)hipHostFree(c->dring);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return SELLA_OK;
@@ -314,7 +365,7 @@ int sella_ctx_destroy(sella_ctx* c) {
 
 int sella_ctx_sync(sella_ctx* c) {
     if (!c) return SELLA_E_INVALID;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     return SELLA_OK;
 }
 
@@ -368,7 +419,7 @@ int sella_mat_set(sella_ctx* c, sella_mat h, const double* A) {
     if (m->rows == 0 || m->cols == 0) return SELLA_OK;
     HIPCHK(hipMemcpy2DAsync(m->d, (size_t)m->ld * sizeof(double), A, (size_t)m->cols * sizeof(double),
                             (size_t)m->cols * sizeof(double), m->rows, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     return SELLA_OK;
 }
 
@@ -384,10 +435,8 @@ int sella_mat_download(sella_ctx* c, sella_mat h, double* out) {
     Mat* m = mat_get(c, h);
     if (!m || !out) return SELLA_E_INVALID;
     if (m->rows == 0 || m->cols == 0) return SELLA_OK;
-    HIPCHK(hipMemcpy2DAsync(out, (size_t)m->cols * sizeof(double), m->d, (size_t)m->ld * sizeof(double),
-                            (size_t)m->cols * sizeof(double), m->rows, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return SELLA_OK;
+    SCHK(d2h_async_2d(c, out, m->d, (size_t)m->ld * sizeof(double), (size_t)m->cols * sizeof(double), m->rows));
+    return stream_wait(c);
 }
 
 int sella_mat_shape(sella_ctx* c, sella_mat h, int* rows, int* cols) {
@@ -552,7 +601,7 @@ int sella_dev_copy(sella_ctx* c, void* dst, const void* src, size_t bytes, int k
     if (!c || !dst || !src || kind < 0 || kind > 2) return SELLA_E_INVALID;
     const hipMemcpyKind k = kind == 0 ? hipMemcpyDeviceToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
     HIPCHK(hipMemcpyAsync(dst, src, bytes, k, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     return SELLA_OK;
 }
 

@@ -114,8 +114,8 @@ int put_small(Dav& s, const double* h, int count, int stage, size_t dev_offset, 
         memcpy(st, h, (size_t)count * sizeof(double));
         HIPCHK(hipMemcpyAsync(d, st, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream));
     } else {
-        HIPCHK(hipMemcpyAsync(d, h, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(h2d_async(c, d, h, (size_t)count * sizeof(double)));
+        SCHK(stream_wait(c));
     }
     *dptr = d;
     return SELLA_OK;
@@ -128,14 +128,14 @@ int apply_A(Dav& s, const double* x, double* y) {
     if (s.A) return launch_gemv_rows(c, s.A->d, s.n, s.n, s.A->ld, x, s.ld, 1, y, s.ld, GemvEpi());
     s.hv.resize(s.n);
     s.hav.resize(s.n);
-    HIPCHK(hipMemcpyAsync(s.hv.data(), x, (size_t)s.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(d2h_async(c, s.hv.data(), x, (size_t)s.n * sizeof(double)));
+    SCHK(stream_wait(c));
     if (s.matvec(s.user, s.hv.data(), s.hav.data(), s.n) != 0) {
         set_error("davidson: host matvec callback failed");
         return SELLA_E_CALLBACK;
     }
-    HIPCHK(hipMemcpyAsync(y, s.hav.data(), (size_t)s.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(h2d_async(c, y, s.hav.data(), (size_t)s.n * sizeof(double)));
+    SCHK(stream_wait(c));
     return SELLA_OK;
 }
 
@@ -810,7 +810,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         double* dvref = s.wk + 39 * (size_t)s.ld;
         double* dsc = scal_out(c, DS_GRAM);              // scalars of this iteration (device, or pinned host: zero-copy)
         const size_t S0 = 3 * (size_t)capn;
-        if (vref) DHIP(hipMemcpyAsync(dvref, vref, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (vref) DCHK(h2d_async(c, dvref, vref, (size_t)n * sizeof(double)));
 
         // coefficients to the device (pinned staging, asynchronous)
         auto launch_resid = [&]() -> int {
@@ -1003,8 +1003,8 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
                         }
                         rnd[i] = acc - 6.0;
                     }
-                    DHIP(hipMemcpyAsync(t, rnd.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-                    DHIP(hipStreamSynchronize(c->stream));
+                    DCHK(h2d_async(c, t, rnd.data(), (size_t)n * sizeof(double)));
+                    DCHK(stream_wait(c));
                     DCHK(orthonormalise(s, t, s.k, &kept, nullptr));
                     if (!kept) { stop = true; }
                 }

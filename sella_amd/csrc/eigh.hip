@@ -1081,7 +1081,7 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
         int* hinfo_p = reinterpret_cast<int*>(hv + n);
         HIPCHK(hipMemcpyAsync(hv, wdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(hinfo_p, info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(stream_wait(c));
         std::copy(hv, hv + n, vals.begin());
         hinfo[0] = hinfo_p[0];
         hinfo[1] = hinfo_p[1];
@@ -1141,7 +1141,7 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
         hipLaunchKernelGGL(gather_z_batched_kernel, dim3((maxN + 255) / 256, nm), dim3(256), 0, c->stream, mdd, cur, ld, zdev);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(z, zdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(stream_wait(c));
         // ---- (2) deflation of every merge on the host (dlaed2 logic) ------------------------------
         std::vector<MergePlan> plans(lvl.size());
         for (size_t mi = 0; mi < lvl.size(); ++mi) {
@@ -1207,7 +1207,7 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(lam, lamd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(hi2, info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(stream_wait(c));
         if (hi2[1] != 0) {
             if (getenv("SELLA_DEBUG")) {
                 for (size_t mi = 0; mi < lvl.size(); ++mi) {
@@ -1238,7 +1238,7 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
     std::copy(order.begin(), order.end(), hidx);
     HIPCHK(hipMemcpyAsync(idxd, hidx, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
     SCHK(launch_gather_rows(c, cur, ld, idxd, n, n, nxt, ld));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     if (nxt != W.Za) std::swap(W.Za, W.Zb);
     return SELLA_OK;
 }
@@ -1292,7 +1292,7 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
             // untraced run, and nothing else is ahead of it.
             const bool prof_all = c->prof;
             if (prof_all && (j & 3)) c->prof = false;
-            if (c->prof) HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->prof) SCHK(stream_wait(c));
             prof_begin(c, PROF_OTHER, 8.0 * (2.0 * i + 3.0) * (n - j), 0.0);
             switch (i - 1) {
 #define SELLA_TRD_ROW_CASE(IP) case IP: SELLA_LAUNCH(c, HIP_KERNEL_NAME(trd_row_kernel<IP>), gA, bA, 0, ra); break;
@@ -1396,7 +1396,7 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     int* hidx = hr1 + 2 * (size_t)n;
     HIPCHK(hipMemcpyAsync(z, zdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemsetAsync(info, 0, 8 * sizeof(int), c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     const double tt1 = now();
     // a negative weight is handled on the negated, reversed spectrum: primed index i' <-> row n-1-i'
     const bool neg = sigma < 0.0;
@@ -1493,7 +1493,7 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     }
     if (n - K > 0) SCHK(launch_gather_rows(c, Vt, ld, idxd + K, n - K, n, nxt + (size_t)K * ld, ld));
     HIPCHK(hipMemcpyAsync(hinfo, info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     if (hinfo[1] != 0) {
         set_error("eigh update: secular equation solver hit its iteration cap (root %d)", hinfo[1] - 1);
         return SELLA_E_NOCONV;
@@ -1512,7 +1512,7 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     HIPCHK(hipMemcpyAsync(idxd, hidx, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
     const double tt4 = now();
     SCHK(launch_gather_rows(c, nxt, ld, idxd, n, n, Vt, ld));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     if (dbg_time)
         fprintf(stderr, "rank-one eigen-update n=%d K=%d rot=%d: z %.0f us, plan %.0f us, device %.0f us, order %.0f us, final gather %.0f us\n",
                 n, K, pl.nrot, 1e6 * (tt1 - tt0), 1e6 * (tt2 - tt1), 1e6 * (tt3 - tt2), 1e6 * (tt4 - tt3), 1e6 * (now() - tt4));
@@ -1593,7 +1593,7 @@ int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const do
         if (nrank1) ++*nrank1;
     }
     if (V) SCHK(launch_transpose(c, Vt->d, n, n, Vt->ld, V->d, V->ld));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     return SELLA_OK;
 }
 
@@ -1635,7 +1635,7 @@ extern "C" int sella_rank1_eig(sella_ctx* c, int K, const double* D, const doubl
     if (Ut)
         HIPCHK(hipMemcpy2DAsync(Ut, (size_t)K * sizeof(double), Ud, (size_t)ldu * sizeof(double),
                                 (size_t)K * sizeof(double), K, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     if (hinfo[1] != 0) {
         set_error("rank1_eig: secular equation solver hit its iteration cap (root %d)", hinfo[1] - 1);
         return SELLA_E_NOCONV;
@@ -1678,7 +1678,7 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
         SCHK(host_stage(c, ((size_t)ld + n) * sizeof(double), &st));       // pinned: one asynchronous download
         const double* hd = static_cast<const double*>(st);
         HIPCHK(hipMemcpyAsync(st, dvec, ((size_t)ld + n) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(stream_wait(c));
         std::copy(hd, hd + n, d.begin());
         std::copy(hd + ld, hd + ld + n, e.begin());
     }
@@ -1728,7 +1728,7 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
         SCHK(launch_transpose(c, mvt->d, n, n, mvt->ld, mv->d, mv->ld));
         *hV = v;
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     if (hVt) *hVt = vt;
     else sella_mat_free(c, vt);
     if (dbg_time)

@@ -157,9 +157,9 @@ extern "C" int sella_emt_eval(sella_ctx* c, int n, const double* pos, const doub
     hipLaunchKernelGGL(emt_force_kernel, dim3(n), dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     std::vector<double> ea(n);
-    HIPCHK(hipMemcpyAsync(ea.data(), dea, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(grad, dgr, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(d2h_async(c, ea.data(), dea, (size_t)n * sizeof(double)));
+    SCHK(d2h_async(c, grad, dgr, (size_t)3 * n * sizeof(double)));
+    SCHK(stream_wait(c));
     double e = 0.0;
     for (int i = 0; i < n; ++i) e += ea[i];
     *energy = e;

@@ -134,6 +134,12 @@ struct sella_ctx {
     size_t hstage_bytes = 0;
     char* hring = nullptr;          // pinned ring behind h2d_async
     size_t hring_bytes = 0, hring_pos = 0;
+    // pinned ring behind d2h_async: device -> CALLER memory without a pageable (runtime-staged, process-serialising)
+    // copy; the payload lands in the ring and is handed to its destination by stream_wait()
+    char* dring = nullptr;
+    size_t dring_bytes = 0, dring_pos = 0;
+    struct PendingD2H { void* dst; const char* slot; size_t bytes; size_t dpitch, width, rows; };
+    std::vector<PendingD2H> d2h_pending;
 };
 
 namespace sella {
@@ -148,6 +154,13 @@ void dev_free(sella_ctx* c, double* p, size_t bytes);
 int upload_panel(sella_ctx* c, const double* X, int n, int k, double* dpanel, int ldp);   // (n x k) host -> k rows
 int download_panel(sella_ctx* c, const double* dpanel, int ldp, int n, int k, double* X); // k rows -> (n x k) host
 int h2d_async(sella_ctx* c, void* dst, const void* src, size_t bytes);   // caller memory -> device, no wait (pinned ring)
+// device -> caller memory through the pinned ring: `dst` is valid after the next stream_wait(c).  The 2-D form copies
+// `rows` rows of `width` bytes from a device pitch `spitch` into a dense destination.
+int d2h_async(sella_ctx* c, void* dst, const void* src_dev, size_t bytes);
+int d2h_async_2d(sella_ctx* c, void* dst, const void* src_dev, size_t spitch, size_t width, size_t rows);
+// THE wait of the library: stream synchronisation, then the queued device-to-host payloads are delivered and both
+// pinned rings rewound.  Every host-side wait goes through here (never hipStreamSynchronize directly).
+int stream_wait(sella_ctx* c);
 int read_scalars(sella_ctx* c, int offset, int count);             // dscal -> hscal (sync)
 // Where a kernel should put scalars that only the HOST consumes next: with `host_scalars` on, the pinned,
 // device-visible host mirror itself (zero-copy: the readback is then just the stream synchronisation and the

@@ -211,10 +211,10 @@ extern "C" int sella_internals_eval(sella_ctx* c, int natoms, int nc, const doub
     else if (natoms == 3) st = run_kind<3>(c, nc, dpos, atv, atan_, dq, dgrad, dhvp, hess ? dhess : nullptr);
     else st = run_kind<4>(c, nc, dpos, atv, atan_, dq, dgrad, dhvp, hess ? dhess : nullptr);
     SCHK(st);
-    HIPCHK(hipMemcpyAsync(q, dq, (size_t)nc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(grad, dgrad, (size_t)nc * nv * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (tangent) HIPCHK(hipMemcpyAsync(hvp, dhvp, (size_t)nc * nv * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (hess) HIPCHK(hipMemcpyAsync(hess, dhess, (size_t)nc * nv * nv * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(d2h_async(c, q, dq, (size_t)nc * sizeof(double)));
+    SCHK(d2h_async(c, grad, dgrad, (size_t)nc * nv * sizeof(double)));
+    if (tangent) SCHK(d2h_async(c, hvp, dhvp, (size_t)nc * nv * sizeof(double)));
+    if (hess) SCHK(d2h_async(c, hess, dhess, (size_t)nc * nv * nv * sizeof(double)));
+    SCHK(stream_wait(c));
     return SELLA_OK;
 }

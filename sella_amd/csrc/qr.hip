@@ -107,9 +107,8 @@ extern "C" int sella_qr_thin(sella_ctx* c, const double* A, int m, int n, double
     // R: upper triangle lives in At[l][j] for j <= l
     {
         std::vector<double> at((size_t)n * n);
-        HIPCHK(hipMemcpy2DAsync(at.data(), (size_t)n * sizeof(double), At, (size_t)ld * sizeof(double),
-                                (size_t)n * sizeof(double), n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(d2h_async_2d(c, at.data(), At, (size_t)ld * sizeof(double), (size_t)n * sizeof(double), n));
+        SCHK(stream_wait(c));
         for (int j = 0; j < n; ++j)
             for (int l = 0; l < n; ++l) R[(size_t)j * n + l] = (l >= j) ? at[(size_t)l * n + j] : 0.0;
     }
@@ -121,7 +120,7 @@ extern "C" int sella_qr_thin(sella_ctx* c, const double* A, int m, int n, double
                                 hipMemcpyHostToDevice, c->stream));
         // a device-resident 1.0 in the spare row (source of the unit head of every reflector)
         HIPCHK(hipMemcpyAsync(Qt + (size_t)(n + 1) * ld, ones.data(), sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(stream_wait(c));
     }
     for (int j = n - 1; j >= 0; --j) {
         // rebuild vpad from the stored reflector: vpad[1] = 1, vpad[2..] = At[j][j+1..]

@@ -236,16 +236,16 @@ extern "C" int sella_stepper_get_s(sella_stepper* st, double alpha, double* s_ou
         memcpy(hin + ldx, dshat, (size_t)m * sizeof(double));
         HIPCHK(hipMemcpyAsync(dx, hin, (size_t)(ldx + m) * sizeof(double), hipMemcpyHostToDevice, c->stream));
         SCHK(launch_gemv_rows(c, V->d, nout, m, V->ld, dx, ldx, 2, hout, ldy, GemvEpi()));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(stream_wait(c));
         memcpy(s_out, hout, (size_t)nout * sizeof(double));
         memcpy(dsda_out, hout + ldy, (size_t)nout * sizeof(double));
     } else {
-        HIPCHK(hipMemcpyAsync(dx, shat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(dx + ldx, dshat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        SCHK(h2d_async(c, dx, shat, (size_t)m * sizeof(double)));
+        SCHK(h2d_async(c, dx + ldx, dshat, (size_t)m * sizeof(double)));
         SCHK(launch_gemv_rows(c, V->d, nout, m, V->ld, dx, ldx, 2, dy, ldy, GemvEpi()));
-        HIPCHK(hipMemcpyAsync(s_out, dy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(dsda_out, dy + ldy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(d2h_async(c, s_out, dy, (size_t)nout * sizeof(double)));
+        SCHK(d2h_async(c, dsda_out, dy + ldy, (size_t)nout * sizeof(double)));
+        SCHK(stream_wait(c));
     }
     return SELLA_OK;
 }
@@ -636,14 +636,14 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
             memcpy(hin + ldx, dshat, (size_t)m * sizeof(double));
             HIPCHK(hipMemcpyAsync(dx, hin, (size_t)(ldx + m) * sizeof(double), hipMemcpyHostToDevice, c->stream));
         } else {
-            HIPCHK(hipMemcpyAsync(dx, shat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(dx + ldx, dshat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            SCHK(h2d_async(c, dx, shat, (size_t)m * sizeof(double)));
+            SCHK(h2d_async(c, dx + ldx, dshat, (size_t)m * sizeof(double)));
         }
         SCHK(launch_gemv_rows(c, V->d, nfam, m, V->ld, dx, ldx, 2, dy, ldy, GemvEpi()));
         hipLaunchKernelGGL(rs_cons_kernel, dim3(1), dim3(1024), 0, c->stream, cons, nout, dy, dy + ldy, dscons, dw, dd1, dstot,
                            hres, dsel, m, dsfull, ddfull);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(stream_wait(c));
         *val = hres[0];
         *dval = hres[1];
         return SELLA_OK;
@@ -702,7 +702,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         hipLaunchKernelGGL(rs_measure_kernel, dim3(BATCH_NODES), dim3(256), 0, c->stream, cons, nout, dY, ldy, dscons, dw, dd1,
                            dinv, hres + 2);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(stream_wait(c));
         for (int q = 1; q <= BATCH_NODES; ++q) cval[q] = hres[1 + q];
         ++nbatch;
         return SELLA_OK;
@@ -767,24 +767,24 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
             memcpy(hin, shat, (size_t)m * sizeof(double));
             HIPCHK(hipMemcpyAsync(dx, hin, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
         } else {
-            HIPCHK(hipMemcpyAsync(dx, shat, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            SCHK(h2d_async(c, dx, shat, (size_t)m * sizeof(double)));
         }
         SCHK(launch_gemv_rows(c, V->d, nfam, m, V->ld, dx, ldx, 1, dy, ldy, GemvEpi()));
         if (sel) {
             std::vector<double> sp(nfam);
-            HIPCHK(hipMemcpyAsync(sp.data(), dy, (size_t)nfam * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
+            SCHK(d2h_async(c, sp.data(), dy, (size_t)nfam * sizeof(double)));
+            SCHK(stream_wait(c));
             for (int i = 0; i < nout; ++i) s_out[i] = 0.0;
             for (int i = 0; i < m; ++i) s_out[sel[i]] = sp[i];
         } else {
-            HIPCHK(hipMemcpyAsync(s_out, dy, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
+            SCHK(d2h_async(c, s_out, dy, (size_t)nout * sizeof(double)));
+            SCHK(stream_wait(c));
         }
         if (scons)
             for (int i = 0; i < nout; ++i) s_out[i] += scons[i];
     } else {
-        HIPCHK(hipMemcpyAsync(s_out, dstot, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        SCHK(d2h_async(c, s_out, dstot, (size_t)nout * sizeof(double)));
+        SCHK(stream_wait(c));
     }
     *val_out = inside ? val : delta;
     if (nalpha) *nalpha = ntrial;

@@ -527,7 +527,7 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
         if (!V || !Vt || V->rows != sv->m || Vt->rows != sv->m) { set_error("update_H: bad eigenvector handles of the view"); return SELLA_E_INVALID; }
         SCHK(eig_lowrank_update(c, sv->m, sv->evals, V, Vt, Us, Zs, lds, kk, sv->nrank1));
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SCHK(stream_wait(c));
     if (dbg_time)
         fprintf(stderr, "update_H n=%d k=%d: vectors %.3f ms, rank-2k (+view gather) %.3f ms, eigen-update %.3f ms (%d rank-one), view %.3f ms (%d)\n",
                 n, k, 1e3 * (t_u1 - t_u0), 1e3 * (t_u2 - t_u1), 1e3 * (t_u3 - t_u2), nrank1 ? *nrank1 : -1,

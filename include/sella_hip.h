@@ -69,6 +69,13 @@ int sella_mat_download(sella_ctx* ctx, sella_mat h, double* out);       /* .cpu(
 int sella_mat_shape(sella_ctx* ctx, sella_mat h, int* rows, int* cols);
 int sella_mat_copy(sella_ctx* ctx, sella_mat src, sella_mat* dst);
 int sella_mat_transpose(sella_ctx* ctx, sella_mat src, sella_mat* dst);
+/* new matrix holding rows [row0, row0 + nrows) of src (the explicit eigenvectors of a structured eigendecomposition
+ * are the leading rows of a larger buffer)                                                                        */
+int sella_mat_rows(sella_ctx* ctx, sella_mat src, int row0, int nrows, sella_mat* dst);
+/* dst rows [0, nrows) <- src rows [0, nrows) (equal column counts): growing such a buffer                          */
+int sella_mat_copy_into(sella_ctx* ctx, sella_mat src, sella_mat dst, int nrows);
+/* A[i][i] += alpha: B = lam0 * I of the first-update rule (sella/linalg.py:274-289) is a zero matrix plus this      */
+int sella_mat_add_diag(sella_ctx* ctx, sella_mat h, double alpha);
 int sella_mat_free(sella_ctx* ctx, sella_mat h);
 /* C = alpha * A + beta * B (same shapes; B may be SELLA_NO_MAT with beta ignored)       */
 int sella_mat_axpby(sella_ctx* ctx, double alpha, sella_mat A, double beta, sella_mat B,
@@ -124,7 +131,11 @@ int sella_mgs(sella_ctx* ctx, const double* X, int n, int nx, const double* Y, i
  *    (Pvecs) and as rows (PvecsT) — exactly what sella_eigh returns — or Pvecs = SELLA_NO_MAT
  *    for P = pscale * I.
  * v0: host (n x nv0) start block (nv0 >= 1).  vref may be NULL.
- * Outputs (host): lams (kmax), V and AV (n x k row-major, Ritz vectors as columns), *k.     */
+ * Outputs (host): lams (kmax), V and AV (n x k row-major, Ritz vectors as columns), *k.
+ * STRUCTURED P: Pvecs (n x r) and PvecsT (r x n) with r < n hold r explicit eigenpairs (pevals, r entries) and the
+ *    remaining n - r eigenvalues all equal pscale, their eigenspace being the orthogonal complement of the r vectors:
+ *    P = pscale (I - W^T W) + W^T diag(pevals) W — what an approximate Hessian that started as a scaled identity
+ *    (sella/linalg.py:274-289) is after any number of quasi-Newton updates.  (P - theta)^-1 then costs O(n r).     */
 typedef int (*sella_matvec_fn)(void* user, const double* v, double* Av, int n);
 enum { SELLA_DAV_LANCZOS = 0, SELLA_DAV_GD = 1, SELLA_DAV_JD0 = 2, SELLA_DAV_JD0_ALT = 3,
        SELLA_DAV_MJD0 = 4, SELLA_DAV_MJD0_ALT = 5 };
@@ -197,6 +208,25 @@ int sella_update_h_eig_view(sella_ctx* ctx, sella_mat B, sella_mat evecs, sella_
                             int max_rank, int* nrank1, sella_mat Bsub, sella_mat evecs_sub,
                             sella_mat evecsT_sub, double* evals_sub, const int* idx, int m,
                             int* nrank1_sub);
+/* STRUCTURED eigendecomposition.  An approximate Hessian initialised by the first-update rule (sella/linalg.py:274-289:
+ * B = lam0 I + update) stays lam0 I + (rank r) for ever: r explicit eigenpairs — mu (host, ascending) and the leading r
+ * rows of Wt (capacity rows x n, resident) — plus the eigenvalue lam0 on the orthogonal complement of their span.  The
+ * reference re-diagonalises the dense matrix after every update (linalg.py:174-231, torch.linalg.eigh); sella_update_h_eig
+ * carries n explicit eigenvectors by rank-one merges with O(n^2) passes; here a rank-one term costs O(n r): the component
+ * of its vector outside span(W) joins W as a row with eigenvalue lam0 and the merge runs on r + 1 rows.
+ *   B (n x n resident) receives the update as in sella_update_h; *r and mu are updated (r grows by at most 4k per call:
+ *   the caller provides capacity); *nrank1 = rank-one merges applied.
+ *   Optional principal-submatrix view Bsub = B[idx][idx] with a structured eigendecomposition of its own
+ *   (Wt_sub capacity x m, *r_sub, mu_sub; lam0 the same) kept in step; pass Bsub = SELLA_NO_MAT for none, or
+ *   Wt_sub = SELLA_NO_MAT to update the view's matrix only.                                                          */
+int sella_update_h_lr(sella_ctx* ctx, sella_mat B, sella_mat Wt, int* r, double* mu, double lam0, const double* S,
+                      const double* Y, int n, int k, int method, int symm, int* nrank1, sella_mat Bsub,
+                      sella_mat Wt_sub, int* r_sub, double* mu_sub, const int* idx, int m, int* nrank1_sub);
+/* Structured eigendecomposition of the principal submatrix B[idx][idx] (idx ascending, m entries) from that of B:
+ * U^T B U for U = columns of the identity, sella/peswrapper.py:363-386, without an m x m eigh.
+ * Wt_sub: capacity (>= min(r, m)) x m; outputs *r_sub, mu_sub (capacity entries).                                    */
+int sella_lr_restrict(sella_ctx* ctx, sella_mat Wt, int r, const double* mu, double lam0, const int* idx, int m,
+                      sella_mat Wt_sub, int* r_sub, double* mu_sub);
 /* symmetrize_Y(S, Y, symm)  sella/hessian_update.py:12-37; out host (n x k)                   */
 int sella_symmetrize_y(sella_ctx* ctx, const double* S, const double* Y, int n, int k,
                        int symm, double* out);
@@ -211,6 +241,13 @@ typedef struct sella_stepper sella_stepper;
 int sella_stepper_create(sella_ctx* ctx, int kind, sella_mat evecs, sella_mat evecsT,
                          const double* evals, const double* g, int m, int order,
                          sella_stepper** st);
+/* The same families on a STRUCTURED eigendecomposition (see sella_update_h_lr): r explicit eigenpairs (mu ascending,
+ * leading rows of Wt) + eigenvalue lam0 on the complement.  A mode without a gradient component gets a zero step in
+ * every family, so the n - r cluster modes are represented by ONE — the normalised component of g outside span(W) —
+ * plus min(order, n - r - 1) weightless copies that keep "the `order` lowest modes" and the RFO root index counting the
+ * cluster's multiplicity.  The stepper then behaves exactly like one created from the dense eigendecomposition.      */
+int sella_stepper_create_lr(sella_ctx* ctx, int kind, sella_mat Wt, int r, const double* mu, double lam0,
+                            const double* g, int n, int order, sella_stepper** st);
 int sella_stepper_get_s(sella_stepper* st, double alpha, double* s, double* dsda);
 int sella_stepper_destroy(sella_stepper* st);
 /* QuasiNewtonIRC (sella/optimize/stepper.py:99-111): kind SELLA_STEP_QN_IRC evaluates

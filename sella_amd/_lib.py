@@ -37,6 +37,9 @@ SIGNATURES = {
     'sella_mat_shape': (c_int, [c_void_p, c_int, c_int_p, c_int_p]),
     'sella_mat_copy': (c_int, [c_void_p, c_int, c_int_p]),
     'sella_mat_transpose': (c_int, [c_void_p, c_int, c_int_p]),
+    'sella_mat_rows': (c_int, [c_void_p, c_int, c_int, c_int, c_int_p]),
+    'sella_mat_copy_into': (c_int, [c_void_p, c_int, c_int, c_int]),
+    'sella_mat_add_diag': (c_int, [c_void_p, c_int, c_double]),
     'sella_mat_free': (c_int, [c_void_p, c_int]),
     'sella_mat_axpby': (c_int, [c_void_p, c_double, c_int, c_double, c_int, c_int_p]),
     'sella_symm_mm': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
@@ -65,9 +68,15 @@ SIGNATURES = {
     'sella_update_h_eig_view': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                         c_int, c_int, c_int, c_int, c_int_p, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_int, c_int_p]),
+    'sella_update_h_lr': (c_int, [c_void_p, c_int, c_int, c_int_p, c_void_p, c_double, c_void_p, c_void_p, c_int, c_int,
+                                  c_int, c_int, c_int_p, c_int, c_int, c_int_p, c_void_p, c_void_p, c_int, c_int_p]),
+    'sella_lr_restrict': (c_int, [c_void_p, c_int, c_int, c_void_p, c_double, c_void_p, c_int, c_int, c_int_p,
+                                  c_void_p]),
     'sella_symmetrize_y': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'sella_stepper_create': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                      POINTER(c_void_p)]),
+    'sella_stepper_create_lr': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_double, c_void_p, c_int, c_int,
+                                        POINTER(c_void_p)]),
     'sella_stepper_get_s': (c_int, [c_void_p, c_double, c_void_p, c_void_p]),
     'sella_stepper_destroy': (c_int, [c_void_p]),
     'sella_stepper_set_d1hat': (c_int, [c_void_p, c_void_p, c_int]),

@@ -465,6 +465,48 @@ int sella_mat_copy(sella_ctx* c, sella_mat src, sella_mat* dst) {
     return launch_axpby2d(c, rows, cols, 1.0, s->d, s->ld, 0.0, nullptr, 0, d->d, d->ld);
 }
 
+// A[i][i] += alpha (square or not: the leading min(rows, cols) diagonal entries)
+__global__ void add_diag_kernel(double* __restrict__ A, int ld, int n, double alpha) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) A[(size_t)i * ld + i] += alpha;
+}
+
+int sella_mat_add_diag(sella_ctx* c, sella_mat h, double alpha) {
+    Mat* m = mat_get(c, h);
+    if (!m) return SELLA_E_INVALID;
+    const int n = std::min(m->rows, m->cols);
+    if (n == 0) return SELLA_OK;
+    hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, m->d, m->ld, n, alpha);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+// dst rows [0, nrows) <- src rows [0, nrows)   (same number of columns; growing a row buffer)
+int sella_mat_copy_into(sella_ctx* c, sella_mat src, sella_mat dst, int nrows) {
+    Mat *s = mat_get(c, src), *d = mat_get(c, dst);
+    if (!s || !d || s->cols != d->cols || nrows < 0 || nrows > s->rows || nrows > d->rows) {
+        set_error("mat_copy_into: shapes do not match");
+        return SELLA_E_INVALID;
+    }
+    if (nrows == 0) return SELLA_OK;
+    return launch_axpby2d(c, nrows, s->cols, 1.0, s->d, s->ld, 0.0, nullptr, 0, d->d, d->ld);
+}
+
+// new matrix holding rows [row0, row0 + nrows) of src
+int sella_mat_rows(sella_ctx* c, sella_mat src, int row0, int nrows, sella_mat* dst) {
+    Mat* s = mat_get(c, src);
+    if (!s || !dst || row0 < 0 || nrows < 0 || row0 + nrows > s->rows) {
+        set_error("mat_rows: row range outside the matrix");
+        return SELLA_E_INVALID;
+    }
+    const int cols = s->cols;
+    SCHK(mat_new(c, nrows, cols, dst));
+    if (nrows == 0) return SELLA_OK;
+    s = mat_get(c, src);
+    Mat* d = mat_get(c, *dst);
+    return launch_axpby2d(c, nrows, cols, 1.0, s->d + (size_t)row0 * s->ld, s->ld, 0.0, nullptr, 0, d->d, d->ld);
+}
+
 int sella_mat_transpose(sella_ctx* c, sella_mat src, sella_mat* dst) {
     Mat* s = mat_get(c, src);
     if (!s || !dst) return SELLA_E_INVALID;

@@ -40,6 +40,8 @@ struct Dav {
     const Mat *Q = nullptr, *Qt = nullptr;
     const double* pevals_dev = nullptr;
     double pscale = 1.0;
+    int prank = 0;               // explicit eigenpairs of P (== n: full eigendecomposition; < n: the complement of
+                                 // their span is the eigenspace of pscale, see apply_pinv)
     int nmatvec = 0;
     size_t pbytes = 0;           // size of each panel allocation
     double* dcoef = nullptr;     // device copy of the residual coefficients of the current iteration
@@ -152,6 +154,20 @@ int apply_pinv(Dav& s, double theta, const double* in, int m, double* mid, doubl
     e.mode = 1;
     e.dvec = s.pevals_dev;
     e.theta = theta;
+    if (s.prank < s.n) {
+        // P = lam0 (I - W^T W) + W^T diag(mu) W:  (P - theta)^-1 x = x / (lam0 - theta) + W^T [(1/(mu - theta) - 1/(lam0 - theta)) W x]
+        const double inv0 = 1.0 / guarded_shift(s.pscale, theta);
+        for (int h = 0; h < m; ++h)
+            SCHK(launch_axpby(c, s.n, inv0, in + (size_t)h * s.ld, 0.0, nullptr, out + (size_t)h * s.ld));
+        if (s.prank == 0) return SELLA_OK;
+        e.mode = 5;
+        e.beta = inv0;
+        SCHK(launch_gemv_rows(c, s.Qt->d, s.prank, s.n, s.Qt->ld, in, s.ld, m, mid, s.ld, e));
+        GemvEpi acc;
+        acc.mode = 2;
+        acc.beta = 1.0;
+        return launch_gemv_rows(c, s.Q->d, s.n, s.prank, s.Q->ld, mid, s.ld, m, out, s.ld, acc);
+    }
     SCHK(launch_gemv_rows(c, s.Qt->d, s.n, s.n, s.Qt->ld, in, s.ld, m, mid, s.ld, e));
     return launch_gemv_rows(c, s.Q->d, s.n, s.n, s.Q->ld, mid, s.ld, m, out, s.ld, GemvEpi());
 }
@@ -168,6 +184,18 @@ int apply_pinv_xp(Dav& s, double theta, const double* const* in, int m, double* 
     e.mode = 1;
     e.dvec = s.pevals_dev;
     e.theta = theta;
+    if (s.prank < s.n) {
+        const double inv0 = 1.0 / guarded_shift(s.pscale, theta);
+        for (int h = 0; h < m; ++h) SCHK(launch_axpby(c, s.n, inv0, in[h], 0.0, nullptr, out + (size_t)h * s.ld));
+        if (s.prank == 0) return SELLA_OK;
+        e.mode = 5;
+        e.beta = inv0;
+        SCHK(launch_gemv_rows_xp(c, s.Qt->d, s.prank, s.n, s.Qt->ld, in, m, mid, s.ld, e));
+        GemvEpi acc;
+        acc.mode = 2;
+        acc.beta = 1.0;
+        return launch_gemv_rows(c, s.Q->d, s.n, s.prank, s.Q->ld, mid, s.ld, m, out, s.ld, acc);
+    }
     SCHK(launch_gemv_rows_xp(c, s.Qt->d, s.n, s.n, s.Qt->ld, in, m, mid, s.ld, e));
     return launch_gemv_rows(c, s.Q->d, s.n, s.n, s.Q->ld, mid, s.ld, m, out, s.ld, GemvEpi());
 }
@@ -562,14 +590,20 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         s.Q = mat_get(c, hPvecs);
         s.Qt = mat_get(c, hPvecsT);
         if (!s.Q || !s.Qt || !pevals) { set_error("davidson: P needs Pvecs, PvecsT and pevals"); return SELLA_E_INVALID; }
-        if (s.Q->rows != n || s.Q->cols != n || s.Qt->rows != n || s.Qt->cols != n) {
-            set_error("davidson: eigenvector matrices of P must be %d x %d", n, n);
+        // Pvecs (n x r) / PvecsT (r x n): r == n is a full eigendecomposition; r < n a structured one whose remaining
+        // n - r eigenvalues all equal pscale, with the orthogonal complement of the r vectors as their eigenspace
+        const int pr = s.Q->cols;
+        if (s.Q->rows != n || pr < 1 || pr > n || s.Qt->rows != pr || s.Qt->cols != n) {
+            set_error("davidson: eigenvector matrices of P must be %d x r and r x %d", n, n);
             return SELLA_E_INVALID;
         }
+        s.prank = pr;
         double* dev;
         SCHK(scratch_get(c, SCR_C, (size_t)s.ld * sizeof(double), &dev));
-        SCHK(h2d_async(c, dev, pevals, (size_t)n * sizeof(double)));
+        SCHK(h2d_async(c, dev, pevals, (size_t)pr * sizeof(double)));
         s.pevals_dev = dev;
+    } else {
+        s.prank = n;
     }
     if (maxiter <= 0) maxiter = 2 * n + 1;
     const int kstop = (n < maxiter) ? n : maxiter;

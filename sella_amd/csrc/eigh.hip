@@ -1363,7 +1363,9 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
 // equation, Gu/Eisenstat vectors, ONE K x K x n GEMM on the matrix cores).  A quasi-Newton step thus
 // costs O(n^2 K) MFMA flops per rank instead of a fresh latency-bound tridiagonalisation.
 // ---------------------------------------------------------------------------------------
-static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w, double* Vt, const double* q,
+// Vt holds nr eigenvectors of length n as rows (nr == n: a full eigendecomposition; nr < n: the explicit part of a
+// structured one, see lr_lowrank_update below); w (host, nr) ascending on entry and on exit.
+static int eig_rank1_update(sella_ctx* c, EighWork& W, int nr, int n, int ld, double* w, double* Vt, const double* q,
                             double sigma) {
     double* zdev = W.vec + (size_t)V_Z * ld;
     double* csd = W.vec + (size_t)V_CS0 * ld;
@@ -1376,12 +1378,12 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     int* i1d = W.ibuf + 16;
     int* i2d = i1d + n;
     int* idxd = i1d + 2 * n;
-    int* orgd = i1d + 3 * n;
+    int* orgd = i1d + 3 * n;                 // (strides of n >= nr entries)
     static const bool dbg_time = getenv("SELLA_DEBUG_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tt0 = now();
     // z = Vt q
-    SCHK(launch_gemv_rows(c, Vt, n, n, ld, q, ld, 1, zdev, ld, GemvEpi()));
+    SCHK(launch_gemv_rows(c, Vt, nr, n, ld, q, ld, 1, zdev, ld, GemvEpi()));
     // small transfers through the pinned staging buffer, laid out like the device side (see dc_solve)
     void* stage;
     SCHK(host_stage(c, (4 * (size_t)ld + 2 * (size_t)n + 8) * sizeof(double) + (3 * (size_t)n + 16) * sizeof(int), &stage));
@@ -1394,26 +1396,26 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     int* hr1 = hinfo + 8;                                      // mirrors i1d | i2d | idxd
     int* hr2 = hr1 + n;
     int* hidx = hr1 + 2 * (size_t)n;
-    HIPCHK(hipMemcpyAsync(z, zdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(z, zdev, (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemsetAsync(info, 0, 8 * sizeof(int), c->stream));
     SCHK(stream_wait(c));
     const double tt1 = now();
     // a negative weight is handled on the negated, reversed spectrum: primed index i' <-> row n-1-i'
     const bool neg = sigma < 0.0;
-    auto rowof = [&](int ip) { return neg ? n - 1 - ip : ip; };
-    std::vector<double> D(n), zz(n);
+    auto rowof = [&](int ip) { return neg ? nr - 1 - ip : ip; };
+    std::vector<double> D(nr), zz(nr);
     double znorm2 = 0.0;
-    for (int ip = 0; ip < n; ++ip) {
+    for (int ip = 0; ip < nr; ++ip) {
         D[ip] = neg ? -w[rowof(ip)] : w[ip];
         zz[ip] = z[rowof(ip)];
         znorm2 += zz[ip] * zz[ip];
     }
     if (!(znorm2 > 0.0)) return SELLA_OK;
     const double zn = sqrt(znorm2);
-    for (int ip = 0; ip < n; ++ip) zz[ip] /= zn;
+    for (int ip = 0; ip < nr; ++ip) zz[ip] /= zn;
     MergePlan pl;
     pl.lo = 0;
-    pl.N = n;
+    pl.N = nr;
     pl.rho = fabs(sigma) * znorm2;
     // ---- clusters of (numerically) equal eigenvalues: one Householder reflection per cluster --------
     // An approximate Hessian starts as lam0*I + low rank, so most of its spectrum is one value repeated
@@ -1425,15 +1427,16 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     {
         const double eps = 2.220446049250313e-16;
         double dmax = 0.0;
-        for (int ip = 0; ip < n; ++ip) dmax = std::max(dmax, fabs(D[ip]));
+        for (int ip = 0; ip < nr; ++ip) dmax = std::max(dmax, fabs(D[ip]));
         const double spread = 4.0 * eps * dmax;
         double* vdev = W.vec + (size_t)V_U1 * ld;
         double* wvd = W.vec + (size_t)V_WRAW * ld;
         std::vector<double> vh;
         int ip = 0;
-        while (ip < n) {
+        while (ip < nr) {
             int j = ip;
-            while (j + 1 < n && D[j + 1] - D[ip] <= spread) ++j;
+            while (j + 1 < nr && fabs(D[j + 1] - D[ip]) <= spread) ++j;       // (fabs: a freshly appended row of a
+                                                                              // structured update sits out of order)
             const int len = j - ip + 1;
             if (len >= 8) {
                 double nrm2 = 0.0;
@@ -1460,14 +1463,14 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
             ip = j + 1;
         }
     }
-    plan_deflation(n, D.data(), zz.data(), pl);
+    plan_deflation(nr, D.data(), zz.data(), pl);
     const int K = pl.K;
     for (int p = 0; p < K; ++p) {
         hD[p] = D[pl.nondef[p]];
         hw[p] = zz[pl.nondef[p]];
         hidx[p] = rowof(pl.nondef[p]);
     }
-    for (int p = 0; p < n - K; ++p) hidx[K + p] = rowof(pl.defl[p]);
+    for (int p = 0; p < nr - K; ++p) hidx[K + p] = rowof(pl.defl[p]);
     for (int r = 0; r < pl.nrot; ++r) {
         hr1[r] = rowof(pl.r1[r]);
         hr2[r] = rowof(pl.r2[r]);
@@ -1491,7 +1494,7 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
         SCHK(launch_gemm(c, 0, 0, K, n, K, 1.0, W.Ut, ld, W.Zc, ld, 0.0, nxt, ld));
         HIPCHK(hipMemcpyAsync(lam, lamd, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    if (n - K > 0) SCHK(launch_gather_rows(c, Vt, ld, idxd + K, n - K, n, nxt + (size_t)K * ld, ld));
+    if (nr - K > 0) SCHK(launch_gather_rows(c, Vt, ld, idxd + K, nr - K, n, nxt + (size_t)K * ld, ld));
     HIPCHK(hipMemcpyAsync(hinfo, info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     SCHK(stream_wait(c));
     if (hinfo[1] != 0) {
@@ -1501,21 +1504,21 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int n, int ld, double* w,
     const double tt3 = now();
     // new spectrum (rows of nxt: K updated vectors, then the deflated ones), back to ascending order
     // (ordered in the primed spectrum, where both pieces ascend; a negative weight reverses the result)
-    std::vector<double> nv(n);
+    std::vector<double> nv(nr);
     for (int p = 0; p < K; ++p) nv[p] = lam[p];
-    for (int p = 0; p < n - K; ++p) nv[K + p] = D[pl.defl[p]];
+    for (int p = 0; p < nr - K; ++p) nv[K + p] = D[pl.defl[p]];
     std::vector<int> order;
-    ascending_order(nv.data(), n, order);
+    ascending_order(nv.data(), nr, order);
     if (neg) std::reverse(order.begin(), order.end());
-    for (int i = 0; i < n; ++i) w[i] = neg ? -nv[order[i]] : nv[order[i]];
+    for (int i = 0; i < nr; ++i) w[i] = neg ? -nv[order[i]] : nv[order[i]];
     std::copy(order.begin(), order.end(), hidx);
     HIPCHK(hipMemcpyAsync(idxd, hidx, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
     const double tt4 = now();
-    SCHK(launch_gather_rows(c, nxt, ld, idxd, n, n, Vt, ld));
+    SCHK(launch_gather_rows(c, nxt, ld, idxd, nr, n, Vt, ld));
     SCHK(stream_wait(c));
     if (dbg_time)
-        fprintf(stderr, "rank-one eigen-update n=%d K=%d rot=%d: z %.0f us, plan %.0f us, device %.0f us, order %.0f us, final gather %.0f us\n",
-                n, K, pl.nrot, 1e6 * (tt1 - tt0), 1e6 * (tt2 - tt1), 1e6 * (tt3 - tt2), 1e6 * (tt4 - tt3), 1e6 * (now() - tt4));
+        fprintf(stderr, "rank-one eigen-update n=%d rows=%d K=%d rot=%d: z %.0f us, plan %.0f us, device %.0f us, order %.0f us, final gather %.0f us\n",
+                n, nr, K, pl.nrot, 1e6 * (tt1 - tt0), 1e6 * (tt2 - tt1), 1e6 * (tt3 - tt2), 1e6 * (tt4 - tt3), 1e6 * (now() - tt4));
     return SELLA_OK;
 }
 
@@ -1589,10 +1592,129 @@ int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const do
         for (int i = 0; i < mb; ++i) st[i] = F[(size_t)i * mb + r];
         HIPCHK(hipMemcpyAsync(coef + (size_t)t * 64, st, (size_t)mb * sizeof(double), hipMemcpyHostToDevice, c->stream));
         SCHK(launch_lincomb(c, n, 1, Qb, ld, mb, coef + (size_t)t * 64, 1, nullptr, 0, 0, nullptr, 0, 0.0, qv, ld));
-        SCHK(eig_rank1_update(c, W, n, ld, w, Vt->d, qv, sig[r]));
+        SCHK(eig_rank1_update(c, W, n, n, ld, w, Vt->d, qv, sig[r]));
         if (nrank1) ++*nrank1;
     }
     if (V) SCHK(launch_transpose(c, Vt->d, n, n, Vt->ld, V->d, V->ld));
+    SCHK(stream_wait(c));
+    return SELLA_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Low-rank update of a STRUCTURED eigendecomposition.
+//
+// An approximate Hessian that started as lam0 * I (linalg.py:274-289: the first update of an uninitialised
+// Hessian) is, after any number of quasi-Newton updates, lam0 * I plus a matrix of rank r << n:
+//     B = lam0 (I - W^T W) + W^T diag(mu) W,      W (r x n) orthonormal rows,
+// i.e. r explicit eigenpairs (mu_i, W_i) and the eigenvalue lam0 on the orthogonal complement of span(W),
+// multiplicity n - r, with no basis stored for it.  The dense form above carries that cluster as ~n explicit rows
+// and pays an n x n pass to reflect / reorder them at every rank-one modification.  Here a modification
+// B+ = B + sigma q q^T touches span{W, q} only: the component of q outside span(W), normalised, joins W as a new row
+// with eigenvalue lam0 (it IS an eigenvector of B for lam0), and the modification becomes the SAME rank-one merge
+// as above on r + 1 rows of length n — O(n r) memory traffic instead of O(n^2).  Identical eigenpairs, to roundoff,
+// as the dense update (tests/test_lr_eig.py).
+//   Wt: rows [0, *r) valid, capacity Wt->rows; mu (host, capacity >= Wt->rows) ascending; both updated.
+// ---------------------------------------------------------------------------------------
+int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, Mat* Wt, const double* Up, const double* Zp,
+                      int ldp, int kk, int* nrank1) {
+    const int ld = Wt->ld;
+    const int m = 2 * kk;
+    if (nrank1) *nrank1 = 0;
+    if (ldp != ld || Wt->cols != n) { set_error("structured eigen-update: panel stride mismatch"); return SELLA_E_INVALID; }
+    if (m > 64) { set_error("structured eigen-update: at most 32 pairs per call (%d given)", kk); return SELLA_E_INVALID; }
+    EighWork W;
+    W.c = c; W.n = n; W.ld = ld;
+    const int cap = Wt->rows;
+    const size_t rows_max = (size_t)std::max(cap + m + 2, 64) + 2;
+    const size_t mbytes = rows_max * std::max(ld, 64) * sizeof(double);
+    SCHK(scratch_get(c, SCR_EIG1, mbytes, &W.Za));
+    SCHK(scratch_get(c, SCR_EIG2, mbytes, &W.Zb));
+    SCHK(scratch_get(c, SCR_EIG3, mbytes, &W.Zc));
+    SCHK(scratch_get(c, SCR_EIG4, mbytes, &W.Ut));
+    SCHK(scratch_get(c, SCR_EIG5, (size_t)V_NSLOTS * ld * sizeof(double) + (size_t)(8 * n + 512) * sizeof(int), &W.vec));
+    W.ibuf = reinterpret_cast<int*>(W.vec + (size_t)V_NSLOTS * ld);
+    W.A = nullptr;
+    // ---- orthonormal basis of span{U_a, Z_a} and the 2kk x 2kk core, as in eig_lowrank_update ------------------
+    double* Qb = W.Za;
+    double* src = Qb + (size_t)m * ld;
+    SCHK(launch_axpby2d(c, kk, n, 1.0, Up, ldp, 0.0, nullptr, 0, src, ld));
+    SCHK(launch_axpby2d(c, kk, n, 1.0, Zp, ldp, 0.0, nullptr, 0, src + (size_t)kk * ld, ld));
+    int mb = 0;
+    for (int v = 0; v < m; ++v) {
+        double* slot = Qb + (size_t)mb * ld;
+        HIPCHK(hipMemcpyAsync(slot, src + (size_t)v * ld, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        int kept = 0;
+        SCHK(gs_orthonormalise(c, Qb, ld, mb, slot, n, 1e-15, 1e-13, 100, &kept, nullptr));
+        if (kept) ++mb;
+    }
+    if (mb == 0) return SELLA_OK;
+    std::vector<double> R((size_t)mb * m);
+    for (int v0 = 0; v0 < m; v0 += 8) {
+        const int nv = std::min(8, m - v0);
+        SCHK(launch_gemv_rows(c, Qb, mb, n, ld, src + (size_t)v0 * ld, ld, nv, c->dscal + DS_CVEC, mb, GemvEpi()));
+        SCHK(read_scalars(c, DS_CVEC, mb * nv));
+        for (int h = 0; h < nv; ++h)
+            for (int i = 0; i < mb; ++i) R[(size_t)i * m + v0 + h] = c->hscal[DS_CVEC + (size_t)h * mb + i];
+    }
+    std::vector<double> C((size_t)mb * mb, 0.0), sig(mb), F((size_t)mb * mb), work(mb);
+    for (int i = 0; i < mb; ++i)
+        for (int j = 0; j < mb; ++j) {
+            double sum = 0.0;
+            for (int a = 0; a < kk; ++a)
+                sum += R[(size_t)i * m + a] * R[(size_t)j * m + kk + a] + R[(size_t)i * m + kk + a] * R[(size_t)j * m + a];
+            C[(size_t)i * mb + j] = sum;
+        }
+    if (small::sym_eig(mb, C.data(), mb, sig.data(), F.data(), mb, work.data()) != 0) {
+        set_error("structured eigen-update: small eigenproblem did not converge");
+        return SELLA_E_NOCONV;
+    }
+    int r = *r_io;
+    double wmax = fabs(lam0), smax = 0.0;
+    for (int i = 0; i < r; ++i) wmax = std::max(wmax, fabs(mu[i]));
+    for (int t = 0; t < mb; ++t) smax = std::max(smax, fabs(sig[t]));
+    const double drop = 4.0 * 2.220446049250313e-16 * std::max(wmax, smax);
+    double* qv = W.vec + (size_t)V_U0 * ld;
+    double* coef = c->dscal + DS_STAGE;
+    std::vector<int> ord(mb);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return fabs(sig[a]) > fabs(sig[b]); });
+    for (int t = 0; t < mb; ++t) {
+        const int rr = ord[t];
+        if (fabs(sig[rr]) <= drop) continue;
+        double* st = c->hscal + DS_STAGE + (size_t)t * 64;
+        for (int i = 0; i < mb; ++i) st[i] = F[(size_t)i * mb + rr];
+        HIPCHK(hipMemcpyAsync(coef + (size_t)t * 64, st, (size_t)mb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        SCHK(launch_lincomb(c, n, 1, Qb, ld, mb, coef + (size_t)t * 64, 1, nullptr, 0, 0, nullptr, 0, 0.0, qv, ld));
+        // the part of q outside span(W) is an eigenvector of B for lam0: it becomes an explicit row
+        if (r >= cap) { set_error("structured eigen-update: capacity of %d rows exhausted", cap); return SELLA_E_INVALID; }
+        double* slot = Wt->d + (size_t)r * ld;
+        HIPCHK(hipMemcpyAsync(slot, qv, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        int kept = 0;
+        SCHK(gs_orthonormalise(c, Wt->d, ld, r, slot, n, 1e-15, 1e-13, 100, &kept, nullptr));
+        if (kept) { mu[r] = lam0; ++r; }
+        if (getenv("SELLA_DEBUG")) fprintf(stderr, "lr term %d/%d: sigma %.6e kept %d rows %d\n", t, mb, sig[rr], kept, r);
+        if (r == 0) continue;
+        SCHK(eig_rank1_update(c, W, r, n, ld, mu, Wt->d, qv, sig[rr]));
+        if (nrank1) ++*nrank1;
+    }
+    // explicit rows whose eigenvalue is (still) exactly lam0 belong to the cluster again: drop them
+    {
+        int keep = 0;
+        std::vector<int> idx;
+        for (int i = 0; i < r; ++i)
+            if (mu[i] != lam0) idx.push_back(i);
+        keep = (int)idx.size();
+        if (keep != r) {
+            int* idxd = W.ibuf + 16;
+            SCHK(h2d_async(c, idxd, idx.data(), (size_t)keep * sizeof(int)));
+            SCHK(launch_gather_rows(c, Wt->d, ld, idxd, keep, n, W.Zb, ld));
+            if (keep) SCHK(launch_axpby2d(c, keep, n, 1.0, W.Zb, ld, 0.0, nullptr, 0, Wt->d, ld));
+            for (int i = 0; i < keep; ++i) mu[i] = mu[idx[i]];
+            r = keep;
+        }
+    }
+    *r_io = r;
     SCHK(stream_wait(c));
     return SELLA_OK;
 }

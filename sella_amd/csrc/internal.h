@@ -194,7 +194,8 @@ enum ScratchSlot {
 // ---- kernel launchers (kernels.hip) -------------------------------------------------------
 // Epilogue of the row-panel matvec.
 struct GemvEpi {
-    int mode = 0;            // 0: y = alpha*acc; 1: y = alpha*acc/(dvec[i]-theta); 2: y = alpha*acc + beta*y
+    int mode = 0;            // 0: y = alpha*acc; 1: y = alpha*acc/(dvec[i]-theta); 2: y = alpha*acc + beta*y;
+                             // 3: * |dvec[i]|; 4: * dvec[i]; 5: * (1/(dvec[i]-theta) - beta)
     const double* dvec = nullptr;
     double theta = 0, alpha = 1, beta = 0;
 };
@@ -263,6 +264,10 @@ int launch_rank2k_stream(sella_ctx* c, double* C, int m, int ld, const double* U
 // B + sum_a (U_a Z_a^T + Z_a U_a^T) from that of B; *nrank1 = rank-one modifications applied
 int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const double* Up, const double* Zp,
                        int ldp, int kk, int* nrank1);
+// the same for a STRUCTURED eigendecomposition: r explicit eigenpairs (mu ascending, rows of Wt) + the eigenvalue lam0
+// on the orthogonal complement of their span; *r_io and mu are updated (r grows by at most one per rank-one term)
+int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, Mat* Wt, const double* Up, const double* Zp,
+                      int ldp, int kk, int* nrank1);
 // batched NN GEMM for the merges of one divide-and-conquer level: batch b multiplies the diagonal blocks
 // at offset lo_b:  C[lo.., lo..] (K_b x N_b) = A[lo.., lo..] (K_b x K_b) * B[lo.., lo..] (K_b x N_b), all with
 // leading dimension ld.  desc (device): 4 ints per batch {lo, N, K, unused}.

@@ -94,6 +94,14 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
             }
             else if (epi.mode == 2) v += epi.beta * Y[(size_t)h * ldy + rr];
             else if (epi.mode == 3) v *= fabs(epi.dvec[rr]);
+            else if (epi.mode == 4) v *= epi.dvec[rr];
+            else if (epi.mode == 5) {
+                // structured (P - theta I)^-1: explicit eigenpair i contributes 1 / (d_i - theta) - 1 / (lam0 - theta) on
+                // top of the scaled identity of the complement; beta carries 1 / (lam0 - theta)
+                double den = epi.dvec[rr] - epi.theta;
+                if (den == 0.0) den = 2.220446049250313e-16 * fmax(fabs(epi.theta), 2.2250738585072014e-308);
+                v *= 1.0 / den - epi.beta;
+            }
             Y[(size_t)h * ldy + rr] = v;
         }
     }

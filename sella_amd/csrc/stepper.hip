@@ -22,6 +22,7 @@ struct sella_stepper {
     int kind = 0, m = 0, order = 0, nout = 0;
     sella_mat V = SELLA_NO_MAT;      // m x m eigenvectors (columns)   [not owned]
     sella_mat VU = SELLA_NO_MAT;     // nout x m : U V when a projection U (nout x m) was given [owned]
+    sella_mat ownV = SELLA_NO_MAT, ownVt = SELLA_NO_MAT;   // mode matrices built by sella_stepper_create_lr [owned]
     std::vector<double> lam, ghat;
     std::vector<double> d1hat;       // V^T d1 of the IRC quasi-Newton family (kind SELLA_STEP_QN_IRC)
     sella_mat Vt = SELLA_NO_MAT;     // rows = eigenvectors [not owned]; needed for V^T scons in the root finder
@@ -537,8 +538,9 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     Mat* V = mat_get(c, st->V);
     if (!V) return SELLA_E_INVALID;
     const int m = st->m;
-    if (sel && (st->nout != m || nfull < m)) { set_error("restricted_step: a selection needs a square family and nfull >= m"); return SELLA_E_INVALID; }
-    const int nfam = st->nout;                         // rows of the family's eigenvector matrix
+    const int nfam = st->nout;                         // rows of the family's eigenvector matrix (m modes of length nfam;
+                                                       // m < nfam for a structured eigendecomposition, sella_stepper_create_lr)
+    if (sel && nfull < nfam) { set_error("restricted_step: a selection needs nfull >= the family's dimension"); return SELLA_E_INVALID; }
     const int nout = sel ? nfull : nfam;               // dimension of the step handed back
     if (cons == 1 && nout % 3 != 0) { set_error("restricted_step: per-atom measure needs 3 N components"); return SELLA_E_INVALID; }
     const int ldx = round_up(m, 8), ldy = round_up(std::max(nout, nfam), 8);
@@ -553,7 +555,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     double* dsfull = dv + 4 * (size_t)ldy;
     double* ddfull = dv + 5 * (size_t)ldy;
     int* dsel = sel ? reinterpret_cast<int*>(dv + 6 * (size_t)ldy) : nullptr;
-    if (sel) SCHK(h2d_async(c, dsel, sel, (size_t)m * sizeof(int)));
+    if (sel) SCHK(h2d_async(c, dsel, sel, (size_t)nfam * sizeof(int)));
     const bool eig_only = orthonormal && cons == 0;
     std::vector<double> chat;                 // V^T scons (eigenbasis measure)
     double scons2 = 0.0;
@@ -569,9 +571,9 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         chat.resize(m);
         const double* dsrc = dscons;
         if (sel) {                                      // the family sees the free components of the correction only
-            std::vector<double> sc(m);
-            for (int i = 0; i < m; ++i) sc[i] = scons[sel[i]];
-            SCHK(upload_panel(c, sc.data(), m, 1, dsfull, ldy));
+            std::vector<double> sc(nfam);
+            for (int i = 0; i < nfam; ++i) sc[i] = scons[sel[i]];
+            SCHK(upload_panel(c, sc.data(), nfam, 1, dsfull, ldy));
             dsrc = dsfull;
         }
         SCHK(launch_gemv_rows(c, Vt->d, m, nfam, Vt->ld, dsrc, ldy, 1, dx, ldx, GemvEpi()));
@@ -641,7 +643,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         }
         SCHK(launch_gemv_rows(c, V->d, nfam, m, V->ld, dx, ldx, 2, dy, ldy, GemvEpi()));
         hipLaunchKernelGGL(rs_cons_kernel, dim3(1), dim3(1024), 0, c->stream, cons, nout, dy, dy + ldy, dscons, dw, dd1, dstot,
-                           hres, dsel, m, dsfull, ddfull);
+                           hres, dsel, nfam, dsfull, ddfull);
         HIPCHK(hipGetLastError());
         SCHK(stream_wait(c));
         *val = hres[0];
@@ -670,7 +672,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         HIPCHK(hipMemsetAsync(dbatch + 3 * (size_t)ldx, 0, (size_t)16 * ldb * sizeof(double), c->stream));
         if (sel) {
             std::vector<int> inv(nout, -1);
-            for (int i = 0; i < m; ++i) inv[sel[i]] = i;
+            for (int i = 0; i < nfam; ++i) inv[sel[i]] = i;
             SCHK(h2d_async(c, dbatch + 3 * (size_t)ldx + (size_t)16 * ldb + (size_t)16 * ldy, inv.data(),
                            (size_t)nout * sizeof(int)));
         }
@@ -775,7 +777,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
             SCHK(d2h_async(c, sp.data(), dy, (size_t)nfam * sizeof(double)));
             SCHK(stream_wait(c));
             for (int i = 0; i < nout; ++i) s_out[i] = 0.0;
-            for (int i = 0; i < m; ++i) s_out[sel[i]] = sp[i];
+            for (int i = 0; i < nfam; ++i) s_out[sel[i]] = sp[i];
         } else {
             SCHK(d2h_async(c, s_out, dy, (size_t)nout * sizeof(double)));
             SCHK(stream_wait(c));
@@ -798,6 +800,85 @@ extern "C" int sella_stepper_destroy(sella_stepper* st) {
         fprintf(stderr, "stepper m=%d nout=%d: %ld get_s calls, %.1f us host solve (%.1f sweeps) + %.1f us device round trip per call\n",
                 st->m, st->nout, st->calls, 1e6 * st->t_host / st->calls, (double)st->sweeps / st->calls,
                 1e6 * st->t_dev / st->calls);
+    if (st->ownV != SELLA_NO_MAT) sella_mat_free(st->c, st->ownV);
+    if (st->ownVt != SELLA_NO_MAT) sella_mat_free(st->c, st->ownVt);
     delete st;
+    return SELLA_OK;
+}
+
+// Step family on a STRUCTURED eigendecomposition (r explicit eigenpairs mu / rows of Wt, eigenvalue lam0 on the
+// complement of their span; eigh.hip lr_lowrank_update).  Every family of stepper.py gives a mode whose gradient
+// component vanishes a zero step, so the step lives in span{W, g_perp}, g_perp = g - W^T W g: the n - r eigenvectors of
+// the cluster are REPLACED by one, g_perp / |g_perp| (weight |g_perp|), plus min(order, n - r - 1) weightless copies
+// so that "the `order` lowest modes" (P-RFO's partition, RFO's root index) still counts the cluster's multiplicity.
+// The compressed problem — r + 1 + copies modes of length n — is handed to the dense machinery unchanged
+// (sella_stepper_create on rectangular mode matrices), so sella_stepper_get_s / sella_restricted_step work as is.
+extern "C" int sella_stepper_create_lr(sella_ctx* c, int kind, sella_mat hWt, int r, const double* mu, double lam0,
+                                       const double* g, int n, int order, sella_stepper** out) {
+    if (!c || !out || !g || n <= 0 || r < 0 || r > n || order < 0 || order > n || (r > 0 && !mu)) {
+        set_error("stepper (structured): invalid arguments");
+        return SELLA_E_INVALID;
+    }
+    Mat* Wm = mat_get(c, hWt);
+    if (r > 0 && (!Wm || Wm->cols != n || Wm->rows < r)) { set_error("stepper (structured): bad eigenvector handle"); return SELLA_E_INVALID; }
+    const int ld = round_up(n, 8);
+    const int ncl = n - r;                                   // multiplicity of lam0
+    const int ncopy = ncl > 0 ? std::min(order, ncl - 1) : 0;
+    const int m = r + (ncl > 0 ? 1 : 0) + ncopy;
+    // source panel: [W rows | g_perp normalised | zero row]
+    double* src;
+    SCHK(scratch_get(c, SCR_STEP2, (size_t)(r + 2) * ld * sizeof(double), &src));
+    if (r > 0) {
+        Wm = mat_get(c, hWt);
+        SCHK(launch_axpby2d(c, r, n, 1.0, Wm->d, Wm->ld, 0.0, nullptr, 0, src, ld));
+    }
+    double* gp = src + (size_t)r * ld;
+    HIPCHK(hipMemsetAsync(gp, 0, (size_t)2 * ld * sizeof(double), c->stream));
+    bool have_perp = false;
+    if (ncl > 0) {
+        SCHK(h2d_async(c, gp, g, (size_t)n * sizeof(double)));
+        int kept = 0;
+        // normalised component of g outside span(W); dropped (zero weight) when g lies in span(W) to rounding
+        SCHK(gs_orthonormalise(c, src, ld, r, gp, n, 1e-15, 1e-13, 100, &kept, nullptr));
+        have_perp = kept != 0;
+        if (!have_perp) HIPCHK(hipMemsetAsync(gp, 0, (size_t)ld * sizeof(double), c->stream));
+    }
+    // modes in ascending order of eigenvalue; within the cluster the weighted mode first
+    std::vector<double> ev(m);
+    std::vector<int> idx(m);
+    {
+        int i = 0, p = 0;
+        while (i < r && mu[i] < lam0) { ev[p] = mu[i]; idx[p++] = i++; }
+        if (ncl > 0) {
+            ev[p] = lam0; idx[p++] = r;
+            for (int q = 0; q < ncopy; ++q) { ev[p] = lam0; idx[p++] = r + 1; }
+        }
+        while (i < r) { ev[p] = mu[i]; idx[p++] = i++; }
+    }
+    sella_mat hVt = SELLA_NO_MAT, hV = SELLA_NO_MAT;
+    SCHK(mat_new(c, m, n, &hVt));
+    int st = mat_new(c, n, m, &hV);
+    if (st != SELLA_OK) { sella_mat_free(c, hVt); return st; }
+    auto bail = [&](int code) { sella_mat_free(c, hVt); sella_mat_free(c, hV); return code; };
+    int* didx;
+    {
+        double* ib;
+        st = scratch_get(c, SCR_STEP0, (size_t)(2 * std::max(ld, round_up(m, 8)) + m / 2 + 8) * sizeof(double), &ib);
+        if (st != SELLA_OK) return bail(st);
+        didx = reinterpret_cast<int*>(ib + 2 * (size_t)std::max(ld, round_up(m, 8)));
+    }
+    st = h2d_async(c, didx, idx.data(), (size_t)m * sizeof(int));
+    if (st != SELLA_OK) return bail(st);
+    Mat* Vt = mat_get(c, hVt);
+    st = launch_gather_rows(c, src, ld, didx, m, n, Vt->d, Vt->ld);
+    if (st != SELLA_OK) return bail(st);
+    Mat* V = mat_get(c, hV);
+    Vt = mat_get(c, hVt);
+    st = launch_transpose(c, Vt->d, m, n, Vt->ld, V->d, V->ld);
+    if (st != SELLA_OK) return bail(st);
+    st = sella_stepper_create(c, kind, hV, hVt, ev.data(), g, m, order, out);
+    if (st != SELLA_OK) return bail(st);
+    (*out)->ownV = hV;
+    (*out)->ownVt = hVt;
     return SELLA_OK;
 }

@@ -271,7 +271,42 @@ struct SubView {
     const int* idx;
     int m;
     int* nrank1;
+    // structured eigendecomposition of the view (Vt = explicit rows, V unused) when lr_r != nullptr
+    int* lr_r = nullptr;
+    double lr_lam0 = 0.0;
 };
+
+// Structured eigendecomposition of B (eigh.hip, lr_lowrank_update): r explicit eigenpairs (mu ascending, rows of Wt)
+// and the eigenvalue lam0 on the orthogonal complement of their span.
+struct LrRef {
+    sella_mat Wt;
+    int* r;
+    double* mu;
+    double lam0;
+    int* nrank1;
+};
+
+// |B| S for a structured B:  |lam0| S + W^T [(|mu| - |lam0|) (W S)]   (k rows, vector-major panels)
+static int lr_abs_times(sella_ctx* c, const LrRef& lr, const double* Sp, int n, int k, int ld, double* mid, double* out) {
+    SCHK(launch_axpby2d(c, k, n, fabs(lr.lam0), Sp, ld, 0.0, nullptr, 0, out, ld));
+    const int r = *lr.r;
+    if (r <= 0) return SELLA_OK;
+    Mat* Wm = mat_get(c, lr.Wt);
+    if (!Wm || Wm->cols != n || Wm->rows < r) { set_error("update_H: bad structured eigenvector handle"); return SELLA_E_INVALID; }
+    std::vector<double> dv(r);
+    for (int i = 0; i < r; ++i) dv[i] = fabs(lr.mu[i]) - fabs(lr.lam0);
+    double* dev;
+    SCHK(scratch_get(c, SCR_C, (size_t)std::max(ld, round_up(r, 8)) * sizeof(double), &dev));
+    SCHK(h2d_async(c, dev, dv.data(), (size_t)r * sizeof(double)));
+    GemvEpi e;
+    e.mode = 4;
+    e.dvec = dev;
+    SCHK(launch_gemv_rows(c, Wm->d, r, n, Wm->ld, Sp, ld, k, mid, ld, e));
+    for (int h = 0; h < k; ++h)
+        SCHK(launch_lincomb(c, n, 1, Wm->d, Wm->ld, r, mid + (size_t)h * ld, 1, nullptr, 0, 0, nullptr, 0, 1.0,
+                            out + (size_t)h * ld, ld));
+    return SELLA_OK;
+}
 
 __global__ __launch_bounds__(256) void gather_cols_kernel(const double* __restrict__ P, int ldp, int rows,
                                                           const int* __restrict__ idx, int m,
@@ -299,7 +334,8 @@ __global__ void tsbfgs_k1_coef_kernel(const double* __restrict__ d, double* __re
 
 static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt, const double* evals,
                          const double* S, const double* Y, int n, int k, int method, int symm,
-                         double* evals_io, int max_rank, int* nrank1, const SubView* sv = nullptr) {
+                         double* evals_io, int max_rank, int* nrank1, const SubView* sv = nullptr,
+                         const LrRef* lr = nullptr) {
     if (nrank1) *nrank1 = -1;
     if (sv && sv->nrank1) *sv->nrank1 = -1;
     const bool dbg_time = getenv("SELLA_DEBUG_TIMING") != nullptr;
@@ -333,8 +369,11 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
     hostm::vec STY, STS, C, tmp, Minv;
     if (method == SELLA_UPD_BFGS_AUTO) {                                   // hessian_update.py:80-87
         method = SELLA_UPD_TS_BFGS;
-        bool pd = evals != nullptr;
-        if (pd) {
+        bool pd = evals != nullptr || lr != nullptr;
+        if (pd && lr) {
+            pd = lr->lam0 > 0.0;
+            for (int i = 0; i < *lr->r && pd; ++i) pd = lr->mu[i] > 0.0;
+        } else if (pd) {
             if (hV == SELLA_NO_MAT) pd = evals[0] > 0.0;
             else for (int i = 0; i < n; ++i) if (!(evals[i] > 0.0)) { pd = false; break; }
         }
@@ -397,7 +436,9 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
             // |B| S = Q (|lam| * (Q^T S))                                      hessian_update.py:121
             double* absBS = Zp;                  // temporary use of the Z rows
             double* mid = Up;
-            if (hV == SELLA_NO_MAT) {
+            if (lr) {
+                SCHK(lr_abs_times(c, *lr, Sp, n, k, ld, mid, absBS));
+            } else if (hV == SELLA_NO_MAT) {
                 if (!evals) { set_error("TS-BFGS needs the eigendecomposition of B"); return SELLA_E_INVALID; }
                 SCHK(launch_axpby2d(c, k, n, fabs(evals[0]), Sp, ld, 0.0, nullptr, 0, absBS, ld));
             } else {
@@ -516,13 +557,37 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
         SCHK(launch_sym_rank2k(c, Bs->d, m, Bs->ld, Us, Zs, lds, kk));
     }
     const double t_u2 = now();
-    if (evals_io && hV != SELLA_NO_MAT && 2 * kk <= max_rank) {
+    if (lr) {
+        // structured eigendecomposition: every rank is carried (O(n r) per rank-one term), 32 pairs per call
+        Mat* Wm = mat_get(c, lr->Wt);
+        if (!Wm || Wm->cols != n) { set_error("update_H: bad structured eigenvector handle"); return SELLA_E_INVALID; }
+        int total = 0;
+        for (int a0 = 0; a0 < kk; a0 += 32) {
+            const int kc = std::min(32, kk - a0);
+            int nr1 = 0;
+            SCHK(lr_lowrank_update(c, n, lr->r, lr->mu, lr->lam0, Wm, Up + (size_t)a0 * ld, Zp + (size_t)a0 * ld, ld, kc, &nr1));
+            total += nr1;
+        }
+        if (lr->nrank1) *lr->nrank1 = total;
+    } else if (evals_io && hV != SELLA_NO_MAT && 2 * kk <= max_rank) {
         Mat *V = mat_get(c, hV), *Vt = mat_get(c, hVt);
         if (!V || !Vt || V->rows != n || Vt->rows != n) { set_error("update_H: bad eigenvector handles"); return SELLA_E_INVALID; }
         SCHK(eig_lowrank_update(c, n, evals_io, V, Vt, Up, Zp, ld, kk, nrank1));
     }
     const double t_u3 = now();
-    if (sv && sv->evals && sv->V != SELLA_NO_MAT && 2 * kk <= max_rank) {
+    if (sv && sv->lr_r) {
+        Mat* Wm = mat_get(c, sv->Vt);
+        if (!Wm || Wm->cols != sv->m) { set_error("update_H: bad structured eigenvector handle of the view"); return SELLA_E_INVALID; }
+        int total = 0;
+        for (int a0 = 0; a0 < kk; a0 += 32) {
+            const int kc = std::min(32, kk - a0);
+            int nr1 = 0;
+            SCHK(lr_lowrank_update(c, sv->m, sv->lr_r, sv->evals, sv->lr_lam0, Wm, Us + (size_t)a0 * lds, Zs + (size_t)a0 * lds,
+                                   lds, kc, &nr1));
+            total += nr1;
+        }
+        if (sv->nrank1) *sv->nrank1 = total;
+    } else if (sv && sv->evals && sv->V != SELLA_NO_MAT && 2 * kk <= max_rank) {
         Mat *V = mat_get(c, sv->V), *Vt = mat_get(c, sv->Vt);
         if (!V || !Vt || V->rows != sv->m || Vt->rows != sv->m) { set_error("update_H: bad eigenvector handles of the view"); return SELLA_E_INVALID; }
         SCHK(eig_lowrank_update(c, sv->m, sv->evals, V, Vt, Us, Zs, lds, kk, sv->nrank1));
@@ -556,4 +621,98 @@ extern "C" int sella_update_h_eig(sella_ctx* c, sella_mat hB, sella_mat hV, sell
                                   int max_rank, int* nrank1) {
     if (!evals || !nrank1) { set_error("update_H (eig): evals and nrank1 are required"); return SELLA_E_INVALID; }
     return update_h_core(c, hB, hV, hVt, evals, S, Y, n, k, method, symm, evals, max_rank, nrank1);
+}
+
+// Quasi-Newton update of a matrix held as dense B PLUS a structured eigendecomposition (lam0 * I + rank r): B updated in
+// place as in sella_update_h; the r explicit eigenpairs (mu, rows of Wt) are carried by rank-one merges on r + 1 rows —
+// O(n r) traffic instead of the O(n^2) passes of sella_update_h_eig.  Optionally a principal-submatrix view with a
+// structured eigendecomposition of its own (lam0 the same) is kept in step.
+extern "C" int sella_update_h_lr(sella_ctx* c, sella_mat hB, sella_mat hWt, int* r, double* mu, double lam0,
+                                 const double* S, const double* Y, int n, int k, int method, int symm, int* nrank1,
+                                 sella_mat hBsub, sella_mat hWtsub, int* rsub, double* musub, const int* idx, int m,
+                                 int* nrank1_sub) {
+    if (!c || !r || !mu || !nrank1) { set_error("update_H (structured): r, mu and nrank1 are required"); return SELLA_E_INVALID; }
+    Mat* Wm = mat_get(c, hWt);
+    if (!Wm || *r < 0 || *r > Wm->rows) { set_error("update_H (structured): bad eigenvector handle or rank"); return SELLA_E_INVALID; }
+    LrRef lr{hWt, r, mu, lam0, nrank1};
+    if (hBsub == SELLA_NO_MAT)
+        return update_h_core(c, hB, SELLA_NO_MAT, SELLA_NO_MAT, nullptr, S, Y, n, k, method, symm, nullptr, 0, nullptr, nullptr, &lr);
+    if (!idx || !nrank1_sub) { set_error("update_H (structured view): idx and nrank1_sub are required"); return SELLA_E_INVALID; }
+    for (int i = 0; i < m; ++i)
+        if (idx[i] < 0 || idx[i] >= n || (i && idx[i] <= idx[i - 1])) { set_error("update_H (view): idx must be ascending in [0, n)"); return SELLA_E_INVALID; }
+    SubView sv{hBsub, SELLA_NO_MAT, hWtsub, musub, idx, m, nrank1_sub};
+    if (hWtsub != SELLA_NO_MAT && rsub && musub) { sv.lr_r = rsub; sv.lr_lam0 = lam0; }
+    return update_h_core(c, hB, SELLA_NO_MAT, SELLA_NO_MAT, nullptr, S, Y, n, k, method, symm, nullptr, 0, nullptr, &sv, &lr);
+}
+
+// Structured eigendecomposition of a PRINCIPAL SUBMATRIX: B = lam0 I + W^T diag(mu - lam0) W restricted to the ascending
+// coordinates idx (m of them) is lam0 I_m + Wf^T diag(mu - lam0) Wf with Wf = W[:, idx] — rank <= r again, but the rows
+// of Wf are no longer orthonormal.  They are orthonormalised on the device (Gram-Schmidt with the reference's
+// accept / drop rules, gs.hip), Wf = R Qf, the r' x r' core R^T diag(mu - lam0) R is diagonalised on the host, and
+// the explicit eigenvectors of the submatrix are F^T Qf.  What `get_HL_projected` needs when the constraints pin single
+// coordinates (peswrapper.py:363-386) without an m x m eigh.   Wt_sub: capacity rows x m; r_sub, mu_sub outputs.
+extern "C" int sella_lr_restrict(sella_ctx* c, sella_mat hWt, int r, const double* mu, double lam0, const int* idx, int m,
+                                 sella_mat hWt_sub, int* r_sub, double* mu_sub) {
+    if (!c || !r_sub || !mu_sub || r < 0 || m <= 0 || !idx || (r > 0 && !mu)) {
+        set_error("lr_restrict: invalid arguments");
+        return SELLA_E_INVALID;
+    }
+    Mat *Wm = mat_get(c, hWt), *Ws = mat_get(c, hWt_sub);
+    if (!Wm || !Ws || Wm->rows < r || Ws->cols != m || Ws->rows < std::min(r, m)) {
+        set_error("lr_restrict: bad handles (need %d rows of capacity)", std::min(r, m));
+        return SELLA_E_INVALID;
+    }
+    *r_sub = 0;
+    if (r == 0) return SELLA_OK;
+    const int n = Wm->cols;
+    for (int i = 0; i < m; ++i)
+        if (idx[i] < 0 || idx[i] >= n || (i && idx[i] <= idx[i - 1])) { set_error("lr_restrict: idx must be ascending in [0, n)"); return SELLA_E_INVALID; }
+    if (r > 256) { set_error("lr_restrict: rank %d too large for the host-side core", r); return SELLA_E_UNSUPPORTED; }
+    const int lds = Ws->ld;
+    double* wk;
+    SCHK(scratch_get(c, SCR_UPD4, ((size_t)2 * r * lds + (size_t)m / 2 + 8 + (size_t)r * round_up(r, 8)) * sizeof(double), &wk));
+    double* Wf = wk;                               // r x m   (restricted rows)
+    double* Qf = wk + (size_t)r * lds;             // up to r x m (orthonormalised)
+    int* didx = reinterpret_cast<int*>(wk + 2 * (size_t)r * lds);
+    double* Rd = wk + 2 * (size_t)r * lds + (size_t)m / 2 + 8;      // r' x r coordinates (device)
+    SCHK(h2d_async(c, didx, idx, (size_t)m * sizeof(int)));
+    HIPCHK(hipMemsetAsync(wk, 0, (size_t)2 * r * lds * sizeof(double), c->stream));
+    Wm = mat_get(c, hWt);
+    hipLaunchKernelGGL(gather_cols_kernel, dim3((m + 255) / 256, r), dim3(256), 0, c->stream, Wm->d, Wm->ld, r, didx, m, Wf, lds);
+    HIPCHK(hipGetLastError());
+    int rq = 0;
+    for (int v = 0; v < r && rq < m; ++v) {
+        double* slot = Qf + (size_t)rq * lds;
+        HIPCHK(hipMemcpyAsync(slot, Wf + (size_t)v * lds, (size_t)lds * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        int kept = 0;
+        SCHK(gs_orthonormalise(c, Qf, lds, rq, slot, m, 1e-15, 1e-13, 100, &kept, nullptr));
+        if (kept) ++rq;
+    }
+    if (rq == 0) return SELLA_OK;
+    // R[j][v] = Qf_j . Wf_v   (rq x r): Wf_v = sum_j R[j][v] Qf_j
+    const int ldr = round_up(r, 8);
+    SCHK(launch_gemm(c, 0, 1, rq, r, m, 1.0, Qf, lds, Wf, lds, 0.0, Rd, ldr));
+    std::vector<double> R((size_t)rq * r);
+    SCHK(d2h_async_2d(c, R.data(), Rd, (size_t)ldr * sizeof(double), (size_t)r * sizeof(double), rq));
+    SCHK(stream_wait(c));
+    // core C = R diag(mu - lam0) R^T (rq x rq), eigenpairs C = F Sigma F^T
+    std::vector<double> C((size_t)rq * rq), sig(rq), F((size_t)rq * rq), work(rq);
+    for (int i = 0; i < rq; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = 0.0;
+            for (int v = 0; v < r; ++v) s += R[(size_t)i * r + v] * (mu[v] - lam0) * R[(size_t)j * r + v];
+            C[(size_t)i * rq + j] = C[(size_t)j * rq + i] = s;
+        }
+    if (small::sym_eig(rq, C.data(), rq, sig.data(), F.data(), rq, work.data()) != 0) {
+        set_error("lr_restrict: small eigenproblem did not converge");
+        return SELLA_E_NOCONV;
+    }
+    // W_sub row t = sum_j F[j][t] Qf_j  -> lincomb with coefficient matrix (rq x rq), W1[j*ldw + t] = F[j][t]
+    double* dF;
+    SCHK(put_k(c, F, 0, &dF));
+    Ws = mat_get(c, hWt_sub);
+    SCHK(launch_lincomb(c, m, rq, Qf, lds, rq, dF, rq, nullptr, 0, 0, nullptr, 0, 0.0, Ws->d, Ws->ld));
+    for (int t = 0; t < rq; ++t) mu_sub[t] = lam0 + sig[t];
+    *r_sub = rq;
+    return stream_wait(c);
 }

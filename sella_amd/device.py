@@ -393,6 +393,59 @@ class Context:
             ptr(evs) if have else None, idx.ctypes.data_as(c_void_p), len(idx), byref(nrs)))
         return ev, nr.value, evs, nrs.value
 
+    # ---- structured eigendecompositions (lam0 * I + rank r; csrc/eigh.hip lr_lowrank_update) -----------------------
+    def mat_rows(self, M, row0, nrows):
+        h = c_int(-1)
+        check(_lib.lib().sella_mat_rows(self._h, M.handle, int(row0), int(nrows), byref(h)))
+        return DeviceMatrix(self, h.value, (int(nrows), M.shape[1]))
+
+    def mat_copy_into(self, src, dst, nrows):
+        check(_lib.lib().sella_mat_copy_into(self._h, src.handle, dst.handle, int(nrows)))
+
+    def mat_add_diag(self, M, alpha):
+        check(_lib.lib().sella_mat_add_diag(self._h, M.handle, float(alpha)))
+
+    def update_h_lr(self, B, S, Y, lr, method='TS-BFGS', symm=2, view=None):
+        """`sella_update_h_lr`: quasi-Newton update of the dense B together with its STRUCTURED eigendecomposition
+        `lr` = dict(Wt=DeviceMatrix (capacity x n), r, mu (capacity,), lam0), updated in place; `view` =
+        (Bsub DeviceMatrix, idx, lr_sub or None) keeps a principal submatrix in step.  Returns (nrank1, nrank1_sub)."""
+        if method not in UPDATE_METHODS:
+            raise ValueError('Unknown update method {}'.format(method))
+        S = as_f64(S)
+        Y = as_f64(Y)
+        n, k = S.shape
+        r = c_int(int(lr['r']))
+        nr, nrs = c_int(-1), c_int(-1)
+        if view is None:
+            check(_lib.lib().sella_update_h_lr(
+                self._h, B.handle, lr['Wt'].handle, byref(r), ptr(lr['mu']), float(lr['lam0']), ptr(S), ptr(Y), n, k,
+                UPDATE_METHODS[method], -1 if symm is None else int(symm), byref(nr), SELLA_NO_MAT, SELLA_NO_MAT, None,
+                None, None, 0, None))
+        else:
+            Bsub, idx, lrs = view
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+            rs = c_int(int(lrs['r']) if lrs is not None else 0)
+            check(_lib.lib().sella_update_h_lr(
+                self._h, B.handle, lr['Wt'].handle, byref(r), ptr(lr['mu']), float(lr['lam0']), ptr(S), ptr(Y), n, k,
+                UPDATE_METHODS[method], -1 if symm is None else int(symm), byref(nr), Bsub.handle,
+                lrs['Wt'].handle if lrs is not None else SELLA_NO_MAT, byref(rs) if lrs is not None else None,
+                ptr(lrs['mu']) if lrs is not None else None, idx.ctypes.data_as(c_void_p), len(idx), byref(nrs)))
+            if lrs is not None:
+                lrs['r'] = rs.value
+        lr['r'] = r.value
+        return nr.value, nrs.value
+
+    def lr_restrict(self, lr, idx, capacity):
+        """Structured eigendecomposition of the principal submatrix [idx][idx] (`sella_lr_restrict`)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        m = len(idx)
+        Wts = self.zeros(int(capacity), m)
+        mus = np.zeros(int(capacity))
+        rs = c_int(0)
+        check(_lib.lib().sella_lr_restrict(self._h, lr['Wt'].handle, int(lr['r']), ptr(lr['mu']), float(lr['lam0']),
+                                           idx.ctypes.data_as(c_void_p), m, Wts.handle, byref(rs), ptr(mus)))
+        return dict(Wt=Wts, r=rs.value, mu=mus, lam0=float(lr['lam0']))
+
     def symmetrize_y(self, S, Y, symm):
         S = as_f64(S)
         Y = as_f64(Y)
@@ -452,15 +505,23 @@ class DeviceStepper:
     (sella_amd/csrc/stepper.hip).  V is (nout x m) with the eigenvectors (optionally already
     multiplied by a projection basis) as columns, Vt its transpose; g has Vt.shape[1] entries."""
 
-    def __init__(self, ctx, kind, V, Vt, evals, g, order):
+    def __init__(self, ctx, kind, V, Vt, evals, g, order, lr=None):
         self.ctx = ctx
-        self.nout = V.shape[0]
-        self._keep = (V, Vt)
-        evals = as_f64(evals)
         g = as_f64(g)
         h = c_void_p()
-        check(_lib.lib().sella_stepper_create(ctx._h, STEPPER_KINDS[kind], V.handle, Vt.handle,
-                                              ptr(evals), ptr(g), len(evals), int(order), byref(h)))
+        if lr is not None:
+            # structured eigendecomposition (`sella_stepper_create_lr`): r explicit pairs + lam0 on the complement
+            self.nout = lr['Wt'].shape[1]
+            self._keep = (lr['Wt'],)
+            check(_lib.lib().sella_stepper_create_lr(ctx._h, STEPPER_KINDS[kind], lr['Wt'].handle, int(lr['r']),
+                                                     ptr(lr['mu']), float(lr['lam0']), ptr(g), self.nout, int(order),
+                                                     byref(h)))
+        else:
+            self.nout = V.shape[0]
+            self._keep = (V, Vt)
+            evals = as_f64(evals)
+            check(_lib.lib().sella_stepper_create(ctx._h, STEPPER_KINDS[kind], V.handle, Vt.handle,
+                                                  ptr(evals), ptr(g), len(evals), int(order), byref(h)))
         self._h = h
         self._fin = weakref.finalize(self, _lib.lib().sella_stepper_destroy, h)
 

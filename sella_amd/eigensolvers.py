@@ -52,8 +52,16 @@ def _preconditioner(P):
     if P is None:
         return dict(pscale=1.0), []
     if isinstance(P, ApproximateHessian):
-        if P.B is None:
+        if P._is_none:
             return dict(pscale=1.0), []
+        lr = P.device_eig_lr()
+        if lr is not None:
+            # structured P = lam0 (I - W^T W) + W^T diag(mu) W: r explicit pairs, lam0 on the complement
+            if lr['r'] == 0:
+                return dict(pscale=float(lr['lam0'])), []
+            Wt = ctx.mat_rows(lr['Wt'], 0, lr['r'])
+            W = Wt.transpose()
+            return dict(Pvecs=W, PvecsT=Wt, pevals=lr['mu'][:lr['r']].copy(), pscale=float(lr['lam0'])), [W, Wt]
         w, V, Vt = P.device_eig()
         return dict(Pvecs=V, PvecsT=Vt, pevals=w), []
     P = np.asarray(P, dtype=np.float64)

@@ -134,6 +134,17 @@ class MatrixSum(LinearOperator):
 EIG_UPDATE_MAX_RANK = 8
 EIG_UPDATE_REFRESH = 1024
 
+# STRUCTURED eigendecomposition.  An approximate Hessian that starts uninitialised becomes lam0 * I + (its first
+# update) (linalg.py:274-289) and stays "lam0 * I + rank r" through every later quasi-Newton update: r explicit eigenpairs
+# and the eigenvalue lam0 on the complement of their span (csrc/eigh.hip, lr_lowrank_update).  Carrying THAT costs O(n r)
+# per update instead of the O(n^2) passes of the dense form, the step families work on r + 1 modes instead of n
+# (csrc/stepper.hip, sella_stepper_create_lr) and the Davidson preconditioner costs O(n r) per application.  Used from
+# LR_MIN_DIM on (below it the dense machinery is already cheap and r would reach dim at once) while
+# r <= LR_MAX_FRACTION * dim; then the decomposition goes dense (one device eigh) and stays so.  LR_MIN_DIM = None
+# switches the structured form off.
+LR_MIN_DIM = 96
+LR_MAX_FRACTION = 0.4
+
 
 class ApproximateHessian(LinearOperator):
     def __init__(self, dim, ncart, B0=None, update_method='TS-BFGS', symm=2,
@@ -162,6 +173,59 @@ class ApproximateHessian(LinearOperator):
         self._evecs_gpu = None
         self._evecsT_gpu = None
         self._evals_gpu = None
+        self._lr = None            # structured form: dict(Wt, r, mu, lam0)
+
+    def _drop_dense_eig(self):
+        lr = self._lr
+        self._drop_eig()
+        self._lr = lr
+
+    # ---- structured eigendecomposition ---------------------------------------------------------------------------
+    def device_eig_lr(self):
+        """dict(Wt DeviceMatrix (capacity x dim, leading r rows = explicit eigenvectors), r, mu (ascending), lam0) if
+        the eigendecomposition is held in structured form, else None."""
+        return None if self._is_none else self._lr
+
+    def _lr_evals(self):
+        lr = self._lr
+        r = lr['r']
+        return np.sort(np.concatenate((lr['mu'][:r], np.full(self.dim - r, lr['lam0']))))
+
+    def _lr_reserve(self, extra):
+        """Room for `extra` more explicit rows; False if the explicit rank would pass LR_MAX_FRACTION * dim (the caller
+        then goes dense)."""
+        lr = self._lr
+        need = lr['r'] + extra
+        if need > max(1, int(LR_MAX_FRACTION * self.dim)) and need > 8:
+            return False
+        cap = lr['Wt'].shape[0]
+        if need > cap:
+            ctx = get_context()
+            newcap = min(self.dim, max(2 * cap, need + 64))
+            Wt = ctx.zeros(newcap, self.dim)
+            ctx.mat_copy_into(lr['Wt'], Wt, lr['r'])
+            mu = np.zeros(newcap)
+            mu[:lr['r']] = lr['mu'][:lr['r']]
+            lr['Wt'].free()
+            lr['Wt'], lr['mu'] = Wt, mu
+        return True
+
+    def _init_structured(self, S, Y):
+        """First update of an uninitialised Hessian (linalg.py:274-289 with hessian_update.py:58-67): B = lam0 I + update,
+        lam0 the geometric mean of |eig(S^T Ytilde)| — formed on the device together with its structured eigenpairs."""
+        from .hessian_update import _small_eigh, symmetrize_Y
+        ctx = get_context()
+        n, k = self.dim, S.shape[1]
+        Yt = symmetrize_Y(S, Y, self.symm)
+        thetas = np.maximum(np.abs(_small_eigh(S.T @ Yt)[0]), 1e-12)
+        lam0 = float(np.exp(np.average(np.log(thetas))))
+        dB = ctx.zeros(n, n)
+        ctx.mat_add_diag(dB, lam0)
+        cap = min(n, 2 * k + 64)
+        lr = dict(Wt=ctx.zeros(cap, n), r=0, mu=np.zeros(cap), lam0=lam0)
+        ctx.update_h_lr(dB, S, Y, lr, method=self.update_method, symm=self.symm)
+        self.set_B(dB)
+        self._lr = lr
 
     @property
     def B(self):
@@ -221,6 +285,8 @@ class ApproximateHessian(LinearOperator):
 
     @property
     def evals(self):
+        if self._lr is not None and self._evals is None and not self._is_none:
+            return self._lr_evals()
         self._ensure_eigen_computed()
         return self._evals
 
@@ -252,6 +318,13 @@ class ApproximateHessian(LinearOperator):
         if not self.initialized:
             self.initialized = True
             nc = self.ncart
+            if (self._is_none and nc == self.dim and LR_MIN_DIM is not None and self.dim >= LR_MIN_DIM
+                    and not (np.ndim(dx) == 1 and np.linalg.norm(dx) < 1e-8)):
+                S0 = np.ascontiguousarray(dx[:, None] if np.ndim(dx) == 1 else dx, dtype=np.float64)
+                Y0 = np.ascontiguousarray(dg[:, None] if np.ndim(dg) == 1 else dg, dtype=np.float64)
+                if 2 * S0.shape[1] <= max(8, int(LR_MAX_FRACTION * self.dim)):
+                    self._init_structured(S0, Y0)
+                    return
             B = np.zeros(self.shape) if self._is_none else self.B.copy()
             B[:nc, :nc] = update_H(None, dx[:nc], dg[:nc], method=self.update_method,
                                    symm=self.symm)
@@ -264,6 +337,29 @@ class ApproximateHessian(LinearOperator):
         have_eig = self._evals is not None and self._evecs_gpu is not None
         S2 = np.ascontiguousarray(dx[:, None] if np.ndim(dx) == 1 else dx, dtype=np.float64)
         Y2 = np.ascontiguousarray(dg[:, None] if np.ndim(dg) == 1 else dg, dtype=np.float64)
+        if self._lr is not None:
+            if self._lr_reserve(2 * S2.shape[1]):
+                view = self._view if (self._view is not None and self._view[3] == self.version) else None
+                if view is not None:
+                    idx, _, sub, _ = view
+                    lrs = sub._lr
+                    if lrs is not None and not sub._lr_reserve(2 * S2.shape[1]):
+                        lrs = sub._lr = None                  # the view goes dense (eigh when next needed)
+                    get_context().update_h_lr(dB, S2, Y2, self._lr, method=self.update_method, symm=self.symm,
+                                              view=(sub._get_B_gpu(), idx, lrs))
+                    sub._B = None
+                    sub.version += 1
+                    sub._drop_dense_eig()
+                    self._view = (view[0], view[1], sub, self.version + 1)
+                else:
+                    self._view = None
+                    get_context().update_h_lr(dB, S2, Y2, self._lr, method=self.update_method, symm=self.symm)
+                self._B = None
+                self.version += 1
+                self.initialized = True
+                self._drop_dense_eig()
+                return
+            self._lr = None                                   # rank no longer low: dense from here on
         if (need_eig or have_eig) and EIG_UPDATE_MAX_RANK > 0:
             # carry the eigendecomposition across the update (rank-one modifications on the device)
             # instead of paying a new eigh at the next step solve, linalg.py:174-231
@@ -331,6 +427,10 @@ class ApproximateHessian(LinearOperator):
         if len(idx) > 1 and not np.all(np.diff(idx) > 0):
             return                                   # not an ordered selection of coordinates
         self._view = (idx, U, sub, self.version)
+        if self._lr is not None and sub._lr is None and sub._evals is None and self._lr['r'] <= 256:
+            # structured eigendecomposition of the principal submatrix from that of B (`sella_lr_restrict`)
+            m = len(idx)
+            sub._lr = get_context().lr_restrict(self._lr, idx, min(m, self._lr['r'] + 64))
 
     def project(self, U):
         """Project B into the subspace spanned by the columns of U (linalg.py:306-317)."""

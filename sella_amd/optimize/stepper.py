@@ -55,12 +55,23 @@ class BaseStepper:
 
     def _stepper_init(self) -> None:
         ctx = get_context()
-        evals, V, Vt = self._device_eig()
         U = self.U
         if U is not None and is_identity(U):
             U = None                                  # unconstrained: the basis is the identity
         self._sel = None
         g = self.g
+        # structured eigendecomposition (lam0 I + rank r, linalg.ApproximateHessian): the family is evaluated on r + 1
+        # modes instead of dim (`sella_stepper_create_lr`); not for a general projection basis, whose projected
+        # Hessian is a dense matrix of its own
+        lr = self.H.device_eig_lr() if (self._kind != 'qn_irc' and hasattr(self.H, 'device_eig_lr')) else None
+        sel = selection_of(U) if U is not None else None
+        if lr is not None and (U is None or sel is not None):
+            if sel is not None:
+                self._sel, self._nfull = sel, U.shape[0]
+                g = np.ascontiguousarray(np.asarray(g, dtype=np.float64)[sel])
+            self._dev = DeviceStepper(ctx, self._kind, None, None, None, g, self.order, lr=lr)
+            return
+        evals, V, Vt = self._device_eig()
         if U is not None:
             sel = selection_of(U)
             if sel is not None:

@@ -390,7 +390,7 @@ class PES:
         if nfree == 0:
             return
         P = self.get_HL_projected(Ufree)
-        P_is_none = P.B is None
+        P_is_none = P._is_none
         if P_is_none or self.first_diag:
             v0 = self.v0 if self.v0 is not None else (self.get_g() if is_identity(Ufree) else self.get_g() @ Ufree)
             if v0 is not None and np.linalg.norm(v0) < 1e-12:

@@ -1,0 +1,204 @@
+"""STRUCTURED eigendecomposition of the approximate Hessian (lam0 * I + rank r; csrc/eigh.hip lr_lowrank_update,
+csrc/stepper.hip sella_stepper_create_lr, structured preconditioner of csrc/davidson.hip): the same matrices, eigenpairs,
+steps and Davidson iterates as the dense machinery / the oracle, which re-diagonalises B after every update like the
+reference does (sella/linalg.py:174-231)."""
+import numpy as np
+import pytest
+
+import oracle.sella_oracle as orc
+from conftest import hessian_like
+from helpers import FakePES
+
+
+def _sequence(n, seed, blocks=(6, 1, 1, 1, 3, 1, 1)):
+    rng = np.random.RandomState(seed)
+    Htrue = hessian_like(n, seed)[0]
+    out = []
+    for k in blocks:
+        dx = 0.3 * (rng.normal(size=n) if k == 1 else rng.normal(size=(n, k)))
+        out.append((dx, Htrue @ dx + 0.01 * rng.normal(size=dx.shape)))
+    return out
+
+
+def _structured_pair(ctx, n=120, seed=3, method='TS-BFGS'):
+    from sella_amd import linalg
+    H = linalg.ApproximateHessian(n, n, None, update_method=method)
+    Ho = orc.QuasiNewtonHessian(n, n, None, update_method=method)
+    for dx, dg in _sequence(n, seed):
+        H.update(dx, dg)
+        Ho.update(dx, dg)
+    return H, Ho
+
+
+@pytest.mark.parametrize('method', ['TS-BFGS', 'SR1', 'BFGS_auto'])
+def test_structured_updates_match_the_oracle(ctx, method):
+    n = 120
+    H, Ho = _structured_pair(ctx, n, 3, method)
+    lr = H.device_eig_lr()
+    assert lr is not None and 0 < lr['r'] <= 2 * (6 + 1 + 1 + 1 + 3 + 1 + 1)
+    B = H.B
+    scale = np.abs(Ho.B).max()
+    np.testing.assert_allclose(B, Ho.B, atol=1e-10 * scale)
+    np.testing.assert_array_equal(B, B.T)
+    # eigenvalues: explicit ones + lam0 with multiplicity n - r
+    w = np.linalg.eigvalsh(B)
+    np.testing.assert_allclose(H.evals, w, atol=1e-10 * scale)
+    r, mu, lam0 = lr['r'], lr['mu'][:lr['r']], lr['lam0']
+    W = lr['Wt'].numpy()[:r]
+    np.testing.assert_allclose(W @ W.T, np.eye(r), atol=1e-12)
+    np.testing.assert_allclose(B @ W.T, W.T * mu, atol=1e-10 * scale)
+    # the complement of span(W) is the eigenspace of lam0
+    x = np.random.RandomState(0).normal(size=n)
+    x -= W.T @ (W @ x)
+    np.testing.assert_allclose(B @ x, lam0 * x, atol=1e-10 * scale * np.abs(x).max())
+    assert np.all(np.diff(mu) >= 0)
+
+
+def test_structured_form_is_switched_off_below_the_size_limit(ctx):
+    from sella_amd import linalg
+    H = linalg.ApproximateHessian(30, 30, None)
+    dx = np.random.RandomState(1).normal(size=30)
+    H.update(dx, 2.0 * dx + 0.1)
+    assert H.device_eig_lr() is None and H.B is not None
+
+
+@pytest.mark.parametrize('kind', ['qn', 'rfo', 'prfo'])
+@pytest.mark.parametrize('order', [0, 1, 2])
+def test_structured_steppers_match_dense(ctx, kind, order):
+    """`sella_stepper_create_lr` (r + 1 + copies modes) against the dense stepper on LAPACK's eigendecomposition of the
+    same matrix: s(alpha) and ds/dalpha."""
+    from sella_amd.linalg import ApproximateHessian
+    from sella_amd.optimize.stepper import get_stepper
+    n = 120
+    H, _ = _structured_pair(ctx, n, 5 + order)
+    g = np.random.RandomState(9).normal(size=n)
+    dense = ApproximateHessian(n, 0, H.B.copy())
+    assert dense.device_eig_lr() is None
+    st_lr = get_stepper(kind)(g, H, order)
+    st_de = get_stepper(kind)(g, dense, order)
+    for alpha in ((0.0 if kind == 'qn' else 1e-3), 0.1, 0.7, 1.0):
+        s1, d1 = st_lr.get_s(alpha)
+        s0, d0 = st_de.get_s(alpha)
+        np.testing.assert_allclose(s1, s0, atol=1e-9 * max(1.0, np.abs(s0).max()), err_msg=f'{kind} {order} {alpha}')
+        np.testing.assert_allclose(d1, d0, atol=1e-8 * max(1.0, np.abs(d0).max()), err_msg=f'{kind} {order} {alpha}')
+    # gradient inside span(W): no component on the cluster
+    lr = H.device_eig_lr()
+    W = lr['Wt'].numpy()[:lr['r']]
+    g_in = W.T @ np.random.RandomState(2).normal(size=lr['r'])
+    s1, _ = get_stepper(kind)(g_in, H, order).get_s(0.5)
+    s0, _ = get_stepper(kind)(g_in, dense, order).get_s(0.5)
+    np.testing.assert_allclose(s1, s0, atol=1e-9 * max(1.0, np.abs(s0).max()))
+
+
+@pytest.mark.parametrize('rs,method', [('tr', 'prfo'), ('ras', 'prfo'), ('tr', 'qn'), ('ras', 'rfo')])
+def test_structured_restricted_step_matches_dense(ctx, rs, method):
+    from sella_amd.linalg import ApproximateHessian
+    from sella_amd.optimize.restricted_step import get_restricted_step
+    n = 120
+    H, _ = _structured_pair(ctx, n, 11)
+    g = 0.5 * np.random.RandomState(4).normal(size=n)
+    B = H.B.copy()
+
+    class PES(FakePES):
+        def __init__(self, Hobj):
+            self.H, self.g = Hobj, g
+            self.Ucons, self.Ufree = np.zeros((n, 0)), np.eye(n)
+            self.scons = np.zeros(n)
+
+        def get_HL_projected(self, U):
+            return self.H
+    order = 0 if method == 'rfo' else 1
+    s1, m1 = get_restricted_step(rs)(PES(H), order, 0.05, method).get_s()
+    s0, m0 = get_restricted_step(rs)(PES(ApproximateHessian(n, 0, B)), order, 0.05, method).get_s()
+    assert m1 == pytest.approx(m0, rel=1e-12)
+    np.testing.assert_allclose(s1, s0, atol=1e-9)
+
+
+def test_structured_preconditioner_in_davidson(ctx):
+    """rayleigh_ritz with P = structured approximate Hessian against P = the same matrix held dense."""
+    from sella_amd.eigensolvers import rayleigh_ritz
+    from sella_amd.linalg import ApproximateHessian
+    n = 120
+    H, _ = _structured_pair(ctx, n, 21)
+    A = hessian_like(n, 21)[0]
+    g = np.random.RandomState(6).normal(size=n)
+    dense = ApproximateHessian(n, 0, H.B.copy())
+    for meth in ('jd0', 'gd'):
+        for maxiter in (2, 5, 9):
+            l1, V1, AV1 = rayleigh_ritz(A, 1e-12, H, v0=g, method=meth, maxiter=maxiter)
+            l0, V0, AV0 = rayleigh_ritz(A, 1e-12, dense, v0=g, method=meth, maxiter=maxiter)
+            assert V1.shape == V0.shape == (n, maxiter)
+            tol = 1e-9 * 10 ** maxiter if meth == 'gd' else 1e-10 * 4 ** maxiter
+            np.testing.assert_allclose(l1, l0, atol=tol * np.abs(l0).max(), err_msg=f'{meth} {maxiter}')
+            np.testing.assert_allclose(AV1, A @ V1, atol=1e-10)
+    # start block from P (v0=None): the negative-curvature eigenvectors of P
+    l1, V1, _ = rayleigh_ritz(A, 1e-3, H, v0=None, method='jd0', maxiter=30)
+    l0, V0, _ = rayleigh_ritz(A, 1e-3, dense, v0=None, method='jd0', maxiter=30)
+    assert abs(l1[0] - l0[0]) < 1e-6 * abs(l0[0])
+
+
+def test_structured_view_of_pinned_coordinates(ctx):
+    """Principal-submatrix view (constraints that pin single coordinates, peswrapper.py:363-386) with a structured
+    eigendecomposition of its own (`sella_lr_restrict`), kept in step by `sella_update_h_lr`."""
+    from sella_amd.linalg import ApproximateHessian
+    from sella_amd.utilities.math import register_selection
+    n = 132
+    rng = np.random.RandomState(8)
+    free = np.sort(rng.choice(n, size=100, replace=False))
+    U = register_selection(np.ascontiguousarray(np.eye(n)[:, free]), free)
+    H, _ = _structured_pair(ctx, n, 31)
+    sub = ApproximateHessian(len(free), 0, ctx.upload(H.B[np.ix_(free, free)]))
+    H.register_view(U, sub)
+    assert sub.device_eig_lr() is not None
+
+    def check():
+        B = H.B
+        Bf = B[np.ix_(free, free)]
+        scale = np.abs(B).max()
+        np.testing.assert_allclose(sub.B, Bf, atol=1e-11 * scale)
+        lrs = sub.device_eig_lr()
+        assert lrs is not None
+        np.testing.assert_allclose(sub.evals, np.linalg.eigvalsh(Bf), atol=1e-9 * scale)
+        r = lrs['r']
+        W = lrs['Wt'].numpy()[:r]
+        np.testing.assert_allclose(W @ W.T, np.eye(r), atol=1e-11)
+        np.testing.assert_allclose(Bf @ W.T, W.T * lrs['mu'][:r], atol=1e-9 * scale)
+    check()
+    Htrue = hessian_like(n, 77)[0]
+    for _ in range(4):
+        dx = 0.2 * rng.normal(size=n)
+        H.update(dx, Htrue @ dx)
+        assert H.principal_view(U) is sub
+        check()
+
+
+def test_structured_and_dense_searches_agree(ctx):
+    """A whole `Sella` search with the structured form on (default) and off: same trajectory."""
+    from sella_amd import Sella, linalg
+    from sella_amd.atoms import Atoms, QuadraticCubicModel
+    from sella_amd.internal import Constraints
+    n = 120
+    A = hessian_like(n, 41)[0]
+    rng = np.random.RandomState(42)
+    Uc = rng.normal(size=(8, n))
+    Uc /= np.linalg.norm(Uc, axis=1)[:, None]
+    x0 = 0.05 * rng.normal(size=(n // 3, 3))
+    traj = {}
+    for flag in (96, None):
+        linalg.LR_MIN_DIM = flag
+        try:
+            at = Atoms(['X'] * (n // 3), x0.copy(), pbc=True)
+            at.calc = QuadraticCubicModel(lambda x: A @ x, Uc, c=0.05)
+            opt = Sella(at, order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', logfile=None,
+                        constraints=Constraints(at), proj_trans=False)
+            xs = []
+            for _ in range(8):
+                opt.step()
+                xs.append(opt.pes.get_x().copy())
+            traj[flag] = (np.array(xs), opt.pes.H.device_eig_lr() is not None, opt.pes.neval)
+        finally:
+            linalg.LR_MIN_DIM = 96
+    assert traj[96][1] and not traj[None][1]
+    assert traj[96][2] == traj[None][2]
+    for i in range(8):
+        np.testing.assert_allclose(traj[96][0][i], traj[None][0][i], atol=1e-7 * 4 ** i, err_msg=f'step {i}')

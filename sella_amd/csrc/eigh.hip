@@ -1365,8 +1365,14 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
 // ---------------------------------------------------------------------------------------
 // Vt holds nr eigenvectors of length n as rows (nr == n: a full eigendecomposition; nr < n: the explicit part of a
 // structured one, see lr_lowrank_update below); w (host, nr) ascending on entry and on exit.
+//
+// append_lam0 != nullptr (structured decompositions): the component of q outside the span of the nr rows — an
+// eigenvector for *append_lam0 — is orthonormalised into row nr SPECULATIVELY (two Gram-Schmidt sweeps, no host round
+// trip of their own), z is taken over nr + 1 rows, and the accept / drop rules of gs_orthonormalise are applied to the
+// sweep norms that come back with z; *nr_out = rows held on exit (nr or nr + 1).  The row re-ordering at the end is left
+// queued (the host-side eigenvalues are final before it).
 static int eig_rank1_update(sella_ctx* c, EighWork& W, int nr, int n, int ld, double* w, double* Vt, const double* q,
-                            double sigma) {
+                            double sigma, const double* append_lam0 = nullptr, int* nr_out = nullptr) {
     double* zdev = W.vec + (size_t)V_Z * ld;
     double* csd = W.vec + (size_t)V_CS0 * ld;
     double* Dd = W.vec + (size_t)V_DD * ld;
@@ -1382,6 +1388,13 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int nr, int n, int ld, do
     static const bool dbg_time = getenv("SELLA_DEBUG_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tt0 = now();
+    const int nr_in = nr;
+    if (append_lam0) {
+        double* slot = Vt + (size_t)nr * ld;
+        HIPCHK(hipMemcpyAsync(slot, q, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        SCHK(gs_project_twice(c, Vt, ld, nr, slot, n));          // sweep norms -> scalar slots 8, 9, 10
+        ++nr;                                                     // z includes the speculative row
+    }
     // z = Vt q
     SCHK(launch_gemv_rows(c, Vt, nr, n, ld, q, ld, 1, zdev, ld, GemvEpi()));
     // small transfers through the pinned staging buffer, laid out like the device side (see dc_solve)
@@ -1398,7 +1411,30 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int nr, int n, int ld, do
     int* hidx = hr1 + 2 * (size_t)n;
     HIPCHK(hipMemcpyAsync(z, zdev, (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemsetAsync(info, 0, 8 * sizeof(int), c->stream));
-    SCHK(stream_wait(c));
+    if (append_lam0) SCHK(sync_scalars(c, 8, 3));
+    else SCHK(stream_wait(c));
+    if (append_lam0) {
+        // gs_orthonormalise's verdict on the speculative row (math.pyx:112-129 thresholds as used there: dropped when
+        // a sweep leaves less than 1e-13 of it, accepted when the second sweep's norm is one to 1e-15)
+        const double n0sq = c->hscal[8], n1 = sqrt(c->hscal[9]), n2 = sqrt(c->hscal[10]);
+        bool kept = (n0sq > 0.0) && (n1 == n1) && !(n1 < 1e-13) && (n2 == n2) && !(n2 < 1e-13);
+        if (kept && fabs(1.0 - n2) > 1e-15) {
+            // rare: a third sweep is needed — finish the row synchronously and take its z entry again
+            int k2 = 0;
+            double* slot = Vt + (size_t)nr_in * ld;
+            SCHK(gs_orthonormalise(c, Vt, ld, nr_in, slot, n, 1e-15, 1e-13, 100, &k2, nullptr));
+            kept = k2 != 0;
+            if (kept) {
+                SCHK(launch_gemv_rows(c, slot, 1, n, ld, q, ld, 1, zdev + nr_in, ld, GemvEpi()));
+                HIPCHK(hipMemcpyAsync(z + nr_in, zdev + nr_in, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                SCHK(stream_wait(c));
+            }
+        }
+        if (kept) w[nr_in] = *append_lam0;
+        else nr = nr_in;
+        if (nr_out) *nr_out = nr;
+        if (nr == 0) return SELLA_OK;
+    }
     const double tt1 = now();
     // a negative weight is handled on the negated, reversed spectrum: primed index i' <-> row n-1-i'
     const bool neg = sigma < 0.0;
@@ -1515,10 +1551,44 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int nr, int n, int ld, do
     HIPCHK(hipMemcpyAsync(idxd, hidx, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
     const double tt4 = now();
     SCHK(launch_gather_rows(c, nxt, ld, idxd, nr, n, Vt, ld));
-    SCHK(stream_wait(c));
+    if (!append_lam0) SCHK(stream_wait(c));
     if (dbg_time)
         fprintf(stderr, "rank-one eigen-update n=%d rows=%d K=%d rot=%d: z %.0f us, plan %.0f us, device %.0f us, order %.0f us, final gather %.0f us\n",
                 n, nr, K, pl.nrot, 1e6 * (tt1 - tt0), 1e6 * (tt2 - tt1), 1e6 * (tt3 - tt2), 1e6 * (tt4 - tt3), 1e6 * (now() - tt4));
+    return SELLA_OK;
+}
+
+// One secant pair (kk = 1, the per-step quasi-Newton update): Delta = u z^T + z u^T has rank two and its two terms
+// sigma_t q_t q_t^T follow in closed form from the three dots u.u, u.z, z.z — ONE round trip instead of two
+// Gram-Schmidt passes and a coordinate read-back.  With e1 = u / |u|, e2 the normalised part of z orthogonal to u,
+// Delta = [e1 e2] [[2b, s], [s, 0]] [e1 e2]^T, b = u.z, s = |u| |z_perp|: sigma = b +- sqrt(b^2 + s^2), eigenvectors
+// (sigma, s).  src: rows u, z; Q: two output rows.  *ok = false when z is too nearly parallel to u for the Gram form
+// to keep 1e-13 (|z_perp|^2 < 1e-3 |z|^2): the caller takes the Gram-Schmidt path.
+static int pair_terms(sella_ctx* c, const double* src, int n, int ld, double* Q, double sig[2], int* nterms, bool* ok) {
+    *nterms = 0;
+    *ok = true;
+    SCHK(launch_gemv_rows(c, src, 2, n, ld, src, ld, 2, c->dscal + DS_CVEC, 2, GemvEpi()));
+    SCHK(read_scalars(c, DS_CVEC, 4));
+    const double a = c->hscal[DS_CVEC], b = c->hscal[DS_CVEC + 1], cc = c->hscal[DS_CVEC + 3];
+    if (!(a > 0.0) || !(cc > 0.0)) return SELLA_OK;                 // one factor vanishes: Delta = 0
+    const double rr = cc - b * b / a;
+    if (!(rr >= 1e-3 * cc)) { *ok = false; return SELLA_OK; }
+    const double s = sqrt(a * rr), root = sqrt(b * b + s * s);
+    const double lam[2] = {b + root, b - root};
+    // q = (lam e1 + s e2) / norm = alpha u + beta z
+    double* st = c->hscal + DS_STAGE;
+    for (int t = 0; t < 2; ++t) {
+        const double nrm = sqrt(lam[t] * lam[t] + s * s);
+        const double beta = s / (nrm * sqrt(rr));
+        const double alpha = lam[t] / (nrm * sqrt(a)) - beta * b / a;
+        st[0 * 2 + t] = alpha;                                        // W1[j * nout + t]: coefficient of src row j
+        st[1 * 2 + t] = beta;
+        sig[t] = lam[t];
+    }
+    double* coef = c->dscal + DS_STAGE;
+    HIPCHK(hipMemcpyAsync(coef, st, 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    SCHK(launch_lincomb(c, n, 2, src, ld, 2, coef, 2, nullptr, 0, 0, nullptr, 0, 0.0, Q, ld));
+    *nterms = 2;
     return SELLA_OK;
 }
 
@@ -1543,6 +1613,27 @@ int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const do
     double* src = Qb + (size_t)m * ld;       // [U; Z] copied next to it
     SCHK(launch_axpby2d(c, kk, n, 1.0, Up, ldp, 0.0, nullptr, 0, src, ld));
     SCHK(launch_axpby2d(c, kk, n, 1.0, Zp, ldp, 0.0, nullptr, 0, src + (size_t)kk * ld, ld));
+    if (kk == 1) {
+        double sg[2];
+        int nt = 0;
+        bool ok = true;
+        SCHK(pair_terms(c, src, n, ld, Qb, sg, &nt, &ok));
+        if (ok) {
+            double wm = 0.0;
+            for (int i = 0; i < n; ++i) wm = std::max(wm, fabs(w[i]));
+            const double dropk = 4.0 * 2.220446049250313e-16 * std::max(wm, std::max(fabs(sg[0]), fabs(sg[1])));
+            const int first = fabs(sg[0]) >= fabs(sg[1]) ? 0 : 1;
+            for (int t = 0; t < nt; ++t) {
+                const int rr = t == 0 ? first : 1 - first;
+                if (fabs(sg[rr]) <= dropk) continue;
+                SCHK(eig_rank1_update(c, W, n, n, ld, w, Vt->d, Qb + (size_t)rr * ld, sg[rr]));
+                if (nrank1) ++*nrank1;
+            }
+            if (V) SCHK(launch_transpose(c, Vt->d, n, n, Vt->ld, V->d, V->ld));
+            SCHK(stream_wait(c));
+            return SELLA_OK;
+        }
+    }
     int mb = 0;
     for (int v = 0; v < m; ++v) {
         double* slot = Qb + (size_t)mb * ld;
@@ -1640,6 +1731,30 @@ int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, M
     double* src = Qb + (size_t)m * ld;
     SCHK(launch_axpby2d(c, kk, n, 1.0, Up, ldp, 0.0, nullptr, 0, src, ld));
     SCHK(launch_axpby2d(c, kk, n, 1.0, Zp, ldp, 0.0, nullptr, 0, src + (size_t)kk * ld, ld));
+    int r = *r_io;
+    double* qv = W.vec + (size_t)V_U0 * ld;
+    bool done = false;
+    if (kk == 1) {
+        double sg[2];
+        int nt = 0;
+        bool ok = true;
+        SCHK(pair_terms(c, src, n, ld, Qb, sg, &nt, &ok));
+        if (ok) {
+            double wmax = fabs(lam0);
+            for (int i = 0; i < r; ++i) wmax = std::max(wmax, fabs(mu[i]));
+            const double drop = 4.0 * 2.220446049250313e-16 * std::max(wmax, std::max(fabs(sg[0]), fabs(sg[1])));
+            const int first = fabs(sg[0]) >= fabs(sg[1]) ? 0 : 1;          // largest term first
+            for (int t = 0; t < nt; ++t) {
+                const int rr = t == 0 ? first : 1 - first;
+                if (fabs(sg[rr]) <= drop) continue;
+                if (r >= cap) { set_error("structured eigen-update: capacity of %d rows exhausted", cap); return SELLA_E_INVALID; }
+                SCHK(eig_rank1_update(c, W, r, n, ld, mu, Wt->d, Qb + (size_t)rr * ld, sg[rr], &lam0, &r));
+                if (nrank1) ++*nrank1;
+            }
+            done = true;
+        }
+    }
+    if (!done) {
     int mb = 0;
     for (int v = 0; v < m; ++v) {
         double* slot = Qb + (size_t)mb * ld;
@@ -1669,12 +1784,10 @@ int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, M
         set_error("structured eigen-update: small eigenproblem did not converge");
         return SELLA_E_NOCONV;
     }
-    int r = *r_io;
     double wmax = fabs(lam0), smax = 0.0;
     for (int i = 0; i < r; ++i) wmax = std::max(wmax, fabs(mu[i]));
     for (int t = 0; t < mb; ++t) smax = std::max(smax, fabs(sig[t]));
     const double drop = 4.0 * 2.220446049250313e-16 * std::max(wmax, smax);
-    double* qv = W.vec + (size_t)V_U0 * ld;
     double* coef = c->dscal + DS_STAGE;
     std::vector<int> ord(mb);
     std::iota(ord.begin(), ord.end(), 0);
@@ -1686,17 +1799,12 @@ int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, M
         for (int i = 0; i < mb; ++i) st[i] = F[(size_t)i * mb + rr];
         HIPCHK(hipMemcpyAsync(coef + (size_t)t * 64, st, (size_t)mb * sizeof(double), hipMemcpyHostToDevice, c->stream));
         SCHK(launch_lincomb(c, n, 1, Qb, ld, mb, coef + (size_t)t * 64, 1, nullptr, 0, 0, nullptr, 0, 0.0, qv, ld));
-        // the part of q outside span(W) is an eigenvector of B for lam0: it becomes an explicit row
+        // the part of q outside span(W) is an eigenvector of B for lam0: it becomes an explicit row (speculatively,
+        // decided with the same round trip that brings z back)
         if (r >= cap) { set_error("structured eigen-update: capacity of %d rows exhausted", cap); return SELLA_E_INVALID; }
-        double* slot = Wt->d + (size_t)r * ld;
-        HIPCHK(hipMemcpyAsync(slot, qv, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        int kept = 0;
-        SCHK(gs_orthonormalise(c, Wt->d, ld, r, slot, n, 1e-15, 1e-13, 100, &kept, nullptr));
-        if (kept) { mu[r] = lam0; ++r; }
-        if (getenv("SELLA_DEBUG")) fprintf(stderr, "lr term %d/%d: sigma %.6e kept %d rows %d\n", t, mb, sig[rr], kept, r);
-        if (r == 0) continue;
-        SCHK(eig_rank1_update(c, W, r, n, ld, mu, Wt->d, qv, sig[rr]));
+        SCHK(eig_rank1_update(c, W, r, n, ld, mu, Wt->d, qv, sig[rr], &lam0, &r));
         if (nrank1) ++*nrank1;
+    }
     }
     // explicit rows whose eigenvalue is (still) exactly lam0 belong to the cluster again: drop them
     {

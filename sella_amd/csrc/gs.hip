@@ -24,6 +24,19 @@ static int gs_sweep(sella_ctx* c, const double* basis, int ldb, int k, double* t
     return launch_normalize(c, t, n, scal_out(c, slot));
 }
 
+// Two sweeps of t against the k orthonormal rows of `basis`, normalised; NO host synchronisation: |t|^2 of the input,
+// after the first and after the second sweep are left in scalar slots 8, 9, 10 for the caller's next round trip
+// (gs_orthonormalise's accept / drop decision is taken from exactly these three numbers).
+int gs_project_twice(sella_ctx* c, const double* basis, int ldb, int k, double* t, int n) {
+    if (k > DS_STAGE - DS_CVEC) {
+        set_error("gram-schmidt: basis of %d vectors exceeds the coefficient buffer", k);
+        return SELLA_E_UNSUPPORTED;
+    }
+    SCHK(launch_normalize(c, t, n, scal_out(c, 8)));
+    SCHK(gs_sweep(c, basis, ldb, k, t, n, 9));
+    return gs_sweep(c, basis, ldb, k, t, n, 10);
+}
+
 // Orthonormalise the n-vector t against the k orthonormal rows of `basis`.
 // *kept = 1 if t was accepted (unit norm, orthogonal to the basis), 0 if it was dropped.
 // *first_norm (optional) = |t - V V^T t| of the normalised input, the quantity the Davidson

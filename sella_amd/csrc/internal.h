@@ -253,6 +253,8 @@ int launch_symmetrize(sella_ctx* c, double* B, int n, int ld);
 // gs.hip: orthonormalise t (n) against k orthonormal rows of a vector-major panel
 int gs_orthonormalise(sella_ctx* c, const double* basis, int ldb, int k, double* t, int n,
                       double eps1, double eps2, int maxiter, int* kept, double* first_norm);
+// two sweeps + normalisation without a host round trip: |t|^2 before / after sweep 1 / after sweep 2 -> scalar slots 8..10
+int gs_project_twice(sella_ctx* c, const double* basis, int ldb, int k, double* t, int n);
 // B <- (B + B^T)/2 + alpha * sum_a (U_a Z_a^T + Z_a U_a^T), U/Z vector-major panels with kk rows
 int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, const double* Zp,
                       int ldp, int kk, double alpha = 1.0);

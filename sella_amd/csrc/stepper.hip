@@ -119,9 +119,10 @@ double rfo_block(int mm, const double* lam, const double* ghat, int o, double al
 
 using namespace sella;
 
-extern "C" int sella_stepper_create(sella_ctx* c, int kind, sella_mat hV, sella_mat hVt, const double* evals,
-                                    const double* g, int m, int order, sella_stepper** out) {
-    if (!c || !out || !evals || !g || m <= 0 || order < 0 || order > m) {
+// ghat_in != nullptr: V^T g is known already (g is then not read)
+static int stepper_make(sella_ctx* c, int kind, sella_mat hV, sella_mat hVt, const double* evals,
+                        const double* g, const double* ghat_in, int m, int order, sella_stepper** out) {
+    if (!c || !out || !evals || (!g && !ghat_in) || m <= 0 || order < 0 || order > m) {
         set_error("stepper: invalid arguments");
         return SELLA_E_INVALID;
     }
@@ -145,6 +146,11 @@ extern "C" int sella_stepper_create(sella_ctx* c, int kind, sella_mat hV, sella_
     st->Vt = hVt;
     st->lam.assign(evals, evals + m);
     st->ghat.resize(m);
+    if (ghat_in) {
+        std::copy(ghat_in, ghat_in + m, st->ghat.begin());
+        *out = st;
+        return SELLA_OK;
+    }
     // ghat = V^T g through the row form: rows of Vt are the eigenvectors
     const int nin = Vt->cols;
     const int ldx = round_up(nin, 8), ldy = round_up(m, 8);
@@ -164,6 +170,12 @@ extern "C" int sella_stepper_create(sella_ctx* c, int kind, sella_mat hV, sella_
 
 // (shat, dshat) of one trial alpha in the eigenbasis — O(m) host arithmetic.  Returns |shat|^2; dshat (and, for the
 // RFO families, shat as well) may be null when only that is wanted.
+extern "C" int sella_stepper_create(sella_ctx* c, int kind, sella_mat hV, sella_mat hVt, const double* evals,
+                                    const double* g, int m, int order, sella_stepper** out) {
+    if (!g) { set_error("stepper: invalid arguments"); return SELLA_E_INVALID; }
+    return stepper_make(c, kind, hV, hVt, evals, g, nullptr, m, order, out);
+}
+
 static double eval_hat(const sella_stepper* st, double alpha, double* shat, double* dshat) {
     const int m = st->m, o = st->order;
     const double* lam = st->lam.data();
@@ -834,14 +846,43 @@ extern "C" int sella_stepper_create_lr(sella_ctx* c, int kind, sella_mat hWt, in
     }
     double* gp = src + (size_t)r * ld;
     HIPCHK(hipMemsetAsync(gp, 0, (size_t)2 * ld * sizeof(double), c->stream));
+    // ONE round trip: a = W g (weights of the explicit modes), then the normalised component of g outside span(W) by two
+    // Gram-Schmidt sweeps whose norms come back with a — |g_perp| = |g| n1 n2 is the weight of the cluster's mode
     bool have_perp = false;
-    if (ncl > 0) {
+    std::vector<double> aw(r + 1, 0.0);
+    double gperp = 0.0;
+    {
         SCHK(h2d_async(c, gp, g, (size_t)n * sizeof(double)));
-        int kept = 0;
-        // normalised component of g outside span(W); dropped (zero weight) when g lies in span(W) to rounding
-        SCHK(gs_orthonormalise(c, src, ld, r, gp, n, 1e-15, 1e-13, 100, &kept, nullptr));
-        have_perp = kept != 0;
-        if (!have_perp) HIPCHK(hipMemsetAsync(gp, 0, (size_t)ld * sizeof(double), c->stream));
+        double* da = c->dscal + DS_CVEC + 8192;                       // r <= 8192 explicit pairs
+        if (r > 8192) { set_error("stepper (structured): too many explicit eigenpairs"); return SELLA_E_UNSUPPORTED; }
+        if (r > 0) {
+            SCHK(launch_gemv_rows(c, src, r, n, ld, gp, ld, 1, da, std::max(r, 1), GemvEpi()));
+            HIPCHK(hipMemcpyAsync(c->hscal + DS_CVEC + 8192, da, (size_t)r * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
+        if (ncl > 0) SCHK(gs_project_twice(c, src, ld, r, gp, n));
+        SCHK(sync_scalars(c, 8, 3));
+        for (int i = 0; i < r; ++i) aw[i] = c->hscal[DS_CVEC + 8192 + i];
+        if (ncl > 0) {
+            const double n0sq = c->hscal[8], n1 = sqrt(c->hscal[9]), n2 = sqrt(c->hscal[10]);
+            have_perp = (n0sq > 0.0) && (n1 == n1) && !(n1 < 1e-13) && (n2 == n2) && !(n2 < 1e-13);
+            if (have_perp && fabs(1.0 - n2) > 1e-15) {
+                int kept = 0;                                           // rare: more sweeps, synchronously
+                SCHK(gs_orthonormalise(c, src, ld, r, gp, n, 1e-15, 1e-13, 100, &kept, nullptr));
+                have_perp = kept != 0;
+                if (have_perp) {
+                    // weight of the finished row: gp . g
+                    double* gd;
+                    SCHK(scratch_get(c, SCR_STEP1, (size_t)2 * ld * sizeof(double), &gd));
+                    SCHK(h2d_async(c, gd, g, (size_t)n * sizeof(double)));
+                    SCHK(launch_gemv_rows(c, gp, 1, n, ld, gd, ld, 1, c->dscal + DS_CVEC, 1, GemvEpi()));
+                    SCHK(read_scalars(c, DS_CVEC, 1));
+                    gperp = c->hscal[DS_CVEC];
+                }
+            } else if (have_perp) {
+                gperp = sqrt(n0sq) * n1 * n2;
+            }
+            if (!have_perp) HIPCHK(hipMemsetAsync(gp, 0, (size_t)ld * sizeof(double), c->stream));
+        }
     }
     // modes in ascending order of eigenvalue; within the cluster the weighted mode first
     std::vector<double> ev(m);
@@ -876,7 +917,9 @@ extern "C" int sella_stepper_create_lr(sella_ctx* c, int kind, sella_mat hWt, in
     Vt = mat_get(c, hVt);
     st = launch_transpose(c, Vt->d, m, n, Vt->ld, V->d, V->ld);
     if (st != SELLA_OK) return bail(st);
-    st = sella_stepper_create(c, kind, hV, hVt, ev.data(), g, m, order, out);
+    std::vector<double> gh(m);
+    for (int p = 0; p < m; ++p) gh[p] = idx[p] < r ? aw[idx[p]] : (idx[p] == r ? gperp : 0.0);
+    st = stepper_make(c, kind, hV, hVt, ev.data(), nullptr, gh.data(), m, order, out);
     if (st != SELLA_OK) return bail(st);
     (*out)->ownV = hV;
     (*out)->ownVt = hVt;

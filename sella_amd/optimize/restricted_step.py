@@ -63,7 +63,8 @@ class BaseRestrictedStep:
         family = method if isinstance(method, type) and issubclass(method, BaseStepper) else get_stepper(method.lower())
         # gradient as seen after the linear constraint correction (restricted_step.py:33-37)
         self.scons = pes.get_scons()
-        g = pes.get_g() + pes.get_H() @ self.scons
+        # (no matrix pass for the usual case of satisfied constraints: H @ 0)
+        g = pes.get_g() + (pes.get_H() @ self.scons if np.any(self.scons) else 0.0)
         self._lift = None
         self._orthonormal = W is None
         if self.cons(self.scons) - delta > 1e-8:

@@ -1788,6 +1788,28 @@ int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, M
     for (int i = 0; i < r; ++i) wmax = std::max(wmax, fabs(mu[i]));
     for (int t = 0; t < mb; ++t) smax = std::max(smax, fabs(sig[t]));
     const double drop = 4.0 * 2.220446049250313e-16 * std::max(wmax, smax);
+    if (r == 0) {
+        // no explicit pairs yet (the first update of lam0 * I, i.e. the block of secant pairs of the initial
+        // diagonalisation): the eigenpairs ARE those of the core — W = F^T Qb, mu = lam0 + sigma — no merges at all
+        std::vector<double> Fk;
+        int keep = 0;
+        std::vector<int> cols;
+        for (int t = 0; t < mb; ++t)
+            if (fabs(sig[t]) > drop) cols.push_back(t);
+        keep = (int)cols.size();
+        if (keep > cap) { set_error("structured eigen-update: capacity of %d rows exhausted", cap); return SELLA_E_INVALID; }
+        if (keep > 0) {
+            Fk.resize((size_t)mb * keep);
+            for (int j = 0; j < mb; ++j)
+                for (int t = 0; t < keep; ++t) Fk[(size_t)j * keep + t] = F[(size_t)j * mb + cols[t]];
+            SCHK(h2d_async(c, W.Ut, Fk.data(), Fk.size() * sizeof(double)));
+            SCHK(launch_lincomb(c, n, keep, Qb, ld, mb, W.Ut, keep, nullptr, 0, 0, nullptr, 0, 0.0, Wt->d, ld));
+            for (int t = 0; t < keep; ++t) mu[t] = lam0 + sig[cols[t]];          // sym_eig: ascending
+        }
+        *r_io = keep;
+        if (nrank1) *nrank1 = keep;
+        return stream_wait(c);
+    }
     double* coef = c->dscal + DS_STAGE;
     std::vector<int> ord(mb);
     std::iota(ord.begin(), ord.end(), 0);

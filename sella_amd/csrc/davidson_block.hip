@@ -29,9 +29,12 @@ constexpr int BD_HG = 4;       // outputs per thread of the combine kernel
 // out[h][i] = beta out[h][i] + alpha sum_a C[h ldc + a] P[a ldp + i],  h < nh (<= 16), a < k.
 // Thread i owns element i of BD_HG outputs (blockIdx.y picks the group): coalesced panel reads, coefficients
 // broadcast from LDS.
+// rowscale (device, nh entries, may be null): output h is additionally scaled by rowscale[h] — the -theta_h of the
+// residual when the Ritz values never leave the device.
 __global__ __launch_bounds__(256) void bd_combine_kernel(int n, int nh, int k, const double* __restrict__ C, int ldc,
                                                          const double* __restrict__ P, int ldp, double alpha, double beta,
-                                                         double* __restrict__ out, int ldo) {
+                                                         double* __restrict__ out, int ldo,
+                                                         const double* __restrict__ rowscale) {
     __shared__ double cs[128][BD_HG];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int h0 = blockIdx.y * BD_HG;
@@ -60,7 +63,8 @@ __global__ __launch_bounds__(256) void bd_combine_kernel(int n, int nh, int k, c
         for (int h = 0; h < BD_HG; ++h)
             if (h0 + h < nh) {
                 double* o = out + (size_t)(h0 + h) * ldo + i;
-                *o = (beta == 0.0) ? alpha * acc[h] : (beta * (*o) + alpha * acc[h]);
+                const double al = rowscale ? alpha * rowscale[h0 + h] : alpha;
+                *o = (beta == 0.0) ? al * acc[h] : (beta * (*o) + al * acc[h]);
             }
     }
 }
@@ -68,6 +72,159 @@ __global__ __launch_bounds__(256) void bd_combine_kernel(int n, int nh, int k, c
 struct Theta16 {
     double v[BD_NB];
 };
+
+// ---- Rayleigh-Ritz on the device ---------------------------------------------------------------------------------
+// The k x k projected eigenproblem (k <= 64: nev + 2 blocks) used to be solved on the host — 0.3-0.5 ms of scalar
+// tred2 / tql2 per block iteration at k = 48, more than the sharded panel product it sits behind.  One workgroup does it
+// by parallel cyclic Jacobi instead: the matrix in LDS, k / 2 disjoint rotations per step in round-robin order, k - 1
+// steps per sweep, ~6-8 sweeps to full accuracy (Jacobi is backward stable and at least as accurate as QL); the
+// eigenvectors accumulate as ROWS of Wt in global memory (L2 resident), sorted ascending with the host routine's sign
+// convention, ready to be read as the coefficient rows of bd_combine_kernel — so neither the Ritz vectors' coefficients
+// nor the Gram matrix ever travel to the host.
+constexpr int BD_JMAX = 64;
+
+__global__ __launch_bounds__(256) void bd_jacobi_eig_kernel(int k, const double* __restrict__ G, int ldg,
+                                                            double* __restrict__ theta, double* __restrict__ Wt, int ldw,
+                                                            double* __restrict__ Wtmp, int* __restrict__ info) {
+    __shared__ double A[BD_JMAX][BD_JMAX];
+    __shared__ double cc[BD_JMAX / 2], ss[BD_JMAX / 2], red[256];
+    __shared__ int pp[BD_JMAX / 2], qq[BD_JMAX / 2], rankof[BD_JMAX];
+    __shared__ double dsort[BD_JMAX];
+    __shared__ int again;
+    const int tid = threadIdx.x;
+    const int k2 = k + (k & 1);                       // even size; the pad index carries a decoupled zero
+    for (int e = tid; e < k2 * k2; e += 256) {
+        const int i = e / k2, j = e % k2;
+        double v = 0.0;
+        if (i < k && j < k) v = 0.5 * (G[(size_t)i * ldg + j] + G[(size_t)j * ldg + i]);
+        A[i][j] = v;
+    }
+    for (int e = tid; e < k2 * k2; e += 256) {
+        const int i = e / k2, j = e % k2;
+        Wtmp[(size_t)i * ldw + j] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const int half = k2 / 2, m1 = k2 - 1;
+    int sweep = 0;
+    for (; sweep < 40; ++sweep) {
+        // convergence: off-diagonal mass against the diagonal's
+        double off = 0.0, dia = 0.0;
+        for (int e = tid; e < k2 * k2; e += 256) {
+            const int i = e / k2, j = e % k2;
+            const double v = A[i][j];
+            if (i == j) dia += v * v; else off += v * v;
+        }
+        red[tid] = off;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+        const double offt = red[0];
+        __syncthreads();
+        red[tid] = dia;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+        const double diat = red[0];
+        __syncthreads();
+        // rounding floor of the rotations: (4 eps)^2 per entry against the diagonal's mass
+        if (tid == 0) again = (offt > 7.9e-31 * k2 * diat && offt > 0.0) ? 1 : 0;
+        __syncthreads();
+        if (!again) break;
+        for (int step = 0; step < m1; ++step) {
+            if (tid < half) {
+                int p, q;
+                if (tid == 0) { p = m1; q = step % m1; }
+                else { p = (step + tid) % m1; q = (step + m1 - tid) % m1; }
+                if (p > q) { const int t = p; p = q; q = t; }
+                const double apq = A[p][q];
+                double c = 1.0, sn = 0.0;
+                if (apq != 0.0) {
+                    const double app = A[p][p], aqq = A[q][q];
+                    if (fabs(apq) > 1e-300) {
+                        const double tau = (aqq - app) / (2.0 * apq);
+                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        sn = t * c;
+                    }
+                }
+                pp[tid] = p; qq[tid] = q; cc[tid] = c; ss[tid] = sn;
+            }
+            __syncthreads();
+            // A <- J^T A : rows p, q
+            for (int e = tid; e < half * k2; e += 256) {
+                const int t = e / k2, j = e % k2;
+                const int p = pp[t], q = qq[t];
+                const double c = cc[t], sn = ss[t];
+                const double ap = A[p][j], aq = A[q][j];
+                A[p][j] = c * ap - sn * aq;
+                A[q][j] = sn * ap + c * aq;
+            }
+            __syncthreads();
+            // A <- A J : columns p, q;  eigenvector rows of Wtmp likewise
+            for (int e = tid; e < half * k2; e += 256) {
+                const int t = e / k2, i = e % k2;
+                const int p = pp[t], q = qq[t];
+                const double c = cc[t], sn = ss[t];
+                const double ap = A[i][p], aq = A[i][q];
+                A[i][p] = c * ap - sn * aq;
+                A[i][q] = sn * ap + c * aq;
+                const double wp = Wtmp[(size_t)p * ldw + i], wq = Wtmp[(size_t)q * ldw + i];
+                Wtmp[(size_t)p * ldw + i] = c * wp - sn * wq;
+                Wtmp[(size_t)q * ldw + i] = sn * wp + c * wq;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0 && sweep >= 40) info[0] = 1;
+    // ascending order (ties: lower index first), sign: largest-magnitude component positive
+    if (tid < k) dsort[tid] = A[tid][tid];
+    __syncthreads();
+    if (tid < k) {
+        const double d = dsort[tid];
+        int r = 0;
+        for (int j = 0; j < k; ++j) r += (dsort[j] < d || (dsort[j] == d && j < tid)) ? 1 : 0;
+        rankof[tid] = r;
+        theta[r] = d;
+    }
+    __syncthreads();
+    for (int row = tid >> 6; row < k; row += 4) {                 // one wavefront per eigenvector row
+        const int lane = tid & 63;
+        double best = 0.0;
+        int bi = 0;
+        for (int j = lane; j < k; j += 64) {
+            const double v = fabs(Wtmp[(size_t)row * ldw + j]);
+            if (v > best) { best = v; bi = j; }
+        }
+        for (int mz = 32; mz > 0; mz >>= 1) {
+            const double ob = __shfl_xor(best, mz, 64);
+            const int oi = __shfl_xor(bi, mz, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        const double sgn = (Wtmp[(size_t)row * ldw + bi] < 0.0) ? -1.0 : 1.0;
+        const int r = rankof[row];
+        for (int j = lane; j < k; j += 64) Wt[(size_t)r * ldw + j] = sgn * Wtmp[(size_t)row * ldw + j];
+    }
+}
+
+// New rows / columns of the projected matrix from the panel product dY[h * ldy + a] = V_a . (A T)_h, h < nbk, a < k:
+// G[a][k0 + h] = G[k0 + h][a], the new diagonal block exactly symmetric.
+__global__ __launch_bounds__(256) void bd_gram_rows_kernel(const double* __restrict__ dY, int ldy, int k0, int nbk, int k,
+                                                           double* __restrict__ G, int ldg) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nbk * k) return;
+    const int h = e / k, a = e % k;
+    double v = dY[(size_t)h * ldy + a];
+    if (a >= k0) v = 0.5 * (v + dY[(size_t)(a - k0) * ldy + k0 + h]);
+    G[(size_t)a * ldg + k0 + h] = v;
+    G[(size_t)(k0 + h) * ldg + a] = v;
+}
+
+// G <- diag(theta[0 .. keep)) after a thick restart (the restarted basis is the Ritz basis)
+__global__ __launch_bounds__(256) void bd_gram_reset_kernel(double* __restrict__ G, int ldg, int kcap, int keep,
+                                                            const double* __restrict__ theta) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= kcap * kcap) return;
+    const int i = e / kcap, j = e % kcap;
+    G[(size_t)i * ldg + j] = (i == j && i < keep) ? theta[i] : 0.0;
+}
 
 // X[h][i] <- X[h][i] / (d[i] - theta_h), the denominator kept away from zero (|.| >= guard, sign preserved):
 // the eigenbasis form of (P - theta)^-1 would otherwise inject inf when a Ritz value hits an eigenvalue of P.
@@ -107,6 +264,10 @@ struct Blk {
     int nmatvec = 0;
     vec G;                         // (maxvec + 16)^2 host Gram matrix V^T A V, leading dimension kcap
     int kcap = 0;
+    // Rayleigh-Ritz on the device (kcap <= 64): projected matrix, Ritz values, Ritz coefficient rows
+    bool dev_rr = false;
+    double *dG = nullptr, *dWt = nullptr, *dWtmp = nullptr, *dtheta = nullptr;
+    int* dinfo = nullptr;
 };
 
 int blk_alloc(Blk& s) {
@@ -134,6 +295,16 @@ int blk_alloc(Blk& s) {
         HIPCHK(hipMemsetAsync(s.send, 0, s.bytesS, c->stream));
     }
     s.G.assign((size_t)s.kcap * s.kcap, 0.0);
+    s.dev_rr = s.kcap <= BD_JMAX && c->opt.bd_dev_rr;
+    if (s.dev_rr) {
+        const size_t kk2 = (size_t)s.kcap * s.kcap;
+        SCHK(dev_alloc(c, (3 * kk2 + 2 * (size_t)s.kcap + 16) * sizeof(double), &s.dG));
+        HIPCHK(hipMemsetAsync(s.dG, 0, (3 * kk2 + 2 * (size_t)s.kcap + 16) * sizeof(double), c->stream));
+        s.dWt = s.dG + kk2;
+        s.dWtmp = s.dWt + kk2;
+        s.dtheta = s.dWtmp + kk2;
+        s.dinfo = reinterpret_cast<int*>(s.dtheta + 2 * (size_t)s.kcap);
+    }
     return SELLA_OK;
 }
 
@@ -148,12 +319,14 @@ void blk_free(Blk& s) {
     for (double* p : small16)
         if (p) dev_free(c, p, s.bytes16);
     if (s.dC) dev_free(c, s.dC, s.bytesC);
+    if (s.dG) dev_free(c, s.dG, (3 * (size_t)s.kcap * s.kcap + 2 * (size_t)s.kcap + 16) * sizeof(double));
     if (s.send) dev_free(c, s.send, s.bytesS);
     if (s.recv) dev_free(c, s.recv, s.bytesR);
     s.V = nullptr;
 }
 
-int combine(Blk& s, int nh, int k, const double* dC, int ldc, const double* P, double alpha, double beta, double* out) {
+int combine(Blk& s, int nh, int k, const double* dC, int ldc, const double* P, double alpha, double beta, double* out,
+            const double* rowscale = nullptr) {
     if (nh <= 0) return SELLA_OK;
     if (k <= 0) {
         if (beta == 0.0) HIPCHK(hipMemsetAsync(out, 0, (size_t)nh * s.ld * sizeof(double), s.c->stream));
@@ -161,7 +334,7 @@ int combine(Blk& s, int nh, int k, const double* dC, int ldc, const double* P, d
     }
     dim3 grid((s.n + 255) / 256, (nh + BD_HG - 1) / BD_HG);
     hipLaunchKernelGGL(bd_combine_kernel, grid, dim3(256), 0, s.c->stream, s.n, nh, k, dC, ldc, P, s.ld, alpha, beta, out,
-                       s.ld);
+                       s.ld, rowscale);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
@@ -205,9 +378,13 @@ int project_out(Blk& s, double* T, int nt, int k) {
 // the Gram matrix, the squared norms of the rows BEFORE they were projected against V — a row that lost more than `drop` of its norm
 // there is discarded (math.pyx:112-117, eps2), as are directions whose singular value falls below `drop` of the
 // largest one.
-int svqb(Blk& s, double*& T, double*& T2, int nt, bool has_pre, double drop, int* kept) {
+// *clean (optional) = the pass lost little: every surviving row kept at least a quarter of its squared norm in the
+// projection against V and the block's Gram matrix has a condition number below 1e3 — one classical Gram-Schmidt
+// pass then already leaves orthogonality at the 1e-13 level and the second pass can be skipped.
+int svqb(Blk& s, double*& T, double*& T2, int nt, bool has_pre, double drop, int* kept, bool* clean = nullptr) {
     sella_ctx* c = s.c;
     *kept = 0;
+    if (clean) *clean = false;
     if (nt <= 0) return SELLA_OK;
     double* dS = c->dscal + DS_GRAM;
     SCHK(launch_panel16(c, T, nt, s.n, s.ld, T, nt, dS, BD_NB));                  // dS[h * 16 + r] = T_r . T_h
@@ -238,6 +415,11 @@ int svqb(Blk& s, double*& T, double*& T2, int nt, bool has_pre, double drop, int
         if (sig[j] > drop * drop * smax) good.push_back(j);
     const int mk = (int)good.size();
     if (mk == 0) return SELLA_OK;
+    if (clean && pre) {
+        bool ok = mk == m && (int)live.size() == nt && sig[0] > 1e-3 * smax;
+        for (int a = 0; a < m && ok; ++a) ok = S[live[a] * BD_NB + live[a]] >= 0.25 * pre[live[a]];
+        *clean = ok;
+    }
     // T_new[jj] = sum_a dinv_a U[a][j] / sqrt(sig_j) T[live_a]
     vec Ch((size_t)mk * nt, 0.0);
     for (int jj = 0; jj < mk; ++jj) {
@@ -262,8 +444,10 @@ int orthonormalise_block(Blk& s, int nt, int k, int* kept) {
     SCHK(launch_rows_sumsq(c, s.T, s.ld, nt, s.n, c->dscal + DS_GRAM + BD_NB * BD_NB));
     SCHK(project_out(s, s.T, nt, k));
     int m1 = 0;
-    SCHK(svqb(s, s.T, s.T2, nt, true, 1e-6, &m1));
+    bool clean = false;
+    SCHK(svqb(s, s.T, s.T2, nt, true, 1e-6, &m1, &clean));
     if (m1 == 0) return SELLA_OK;
+    if (clean && k > 0 && c->opt.bd_dev_rr) { *kept = m1; return SELLA_OK; }
     // second pass: re-project (classical Gram-Schmidt twice) and re-orthonormalise; nothing is dropped here
     // unless the block collapsed to roundoff
     SCHK(project_out(s, s.T, m1, k));
@@ -406,6 +590,11 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
             if (nbk < BD_NB)
                 BHIP(hipMemsetAsync(s.AT + (size_t)nbk * s.ld, 0, (size_t)(BD_NB - nbk) * s.ld * sizeof(double), c->stream));
             BCHK(launch_panel16(c, s.V, s.k, n, s.ld, s.AT, nbk, dY, s.kcap));
+            if (s.dev_rr) {
+                hipLaunchKernelGGL(bd_gram_rows_kernel, dim3((nbk * s.k + 255) / 256), dim3(256), 0, c->stream, dY, s.kcap, k0,
+                                   nbk, s.k, s.dG, s.kcap);
+                BHIP(hipGetLastError());
+            } else {
             BCHK(read_scalars(c, DS_GRAM, BD_NB * s.kcap));
             const double* Y = c->hscal + DS_GRAM;
             for (int h = 0; h < nbk; ++h)
@@ -419,18 +608,26 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
                     const double v = 0.5 * (s.G[(size_t)(k0 + h) * s.kcap + k0 + g] + s.G[(size_t)(k0 + g) * s.kcap + k0 + h]);
                     s.G[(size_t)(k0 + h) * s.kcap + k0 + g] = s.G[(size_t)(k0 + g) * s.kcap + k0 + h] = v;
                 }
+            }
         }
         // ---- Rayleigh-Ritz ------------------------------------------------------------------------------------
         const int k = s.k;
+        theta.assign(k, 0.0);
+        if (s.dev_rr) {
+            // one workgroup: Ritz values -> dtheta, Ritz coefficient rows -> dWt; theta comes back with the residual norms
+            hipLaunchKernelGGL(bd_jacobi_eig_kernel, dim3(1), dim3(256), 0, c->stream, k, s.dG, s.kcap, s.dtheta, s.dWt, s.kcap,
+                               s.dWtmp, s.dinfo);
+            BHIP(hipGetLastError());
+        } else {
         Gk.resize((size_t)k * k);
         for (int a = 0; a < k; ++a)
             for (int b = 0; b < k; ++b) Gk[(size_t)a * k + b] = s.G[(size_t)a * s.kcap + b];
-        theta.assign(k, 0.0);
         W.assign((size_t)k * k, 0.0);
         work.resize(k);
         if (small::sym_eig(k, Gk.data(), k, theta.data(), W.data(), k, work.data()) != 0) {
             set_error("davidson_block: Rayleigh-Ritz eigenproblem failed");
             return fail(SELLA_E_NOCONV);
+        }
         }
         // ---- residuals of the lowest nev Ritz pairs, 16 at a time; the first chunk with unconverged pairs feeds
         // the correction block s.T (its rows are copied out before s.R is reused) --------------------------------
@@ -442,6 +639,22 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
         nconv = 0;
         for (int j0 = 0; j0 < nwant; j0 += BD_NB) {
             const int nh = std::min(BD_NB, nwant - j0);
+            if (s.dev_rr) {
+                // R = (AV) W - theta (V W) with the coefficient rows and -theta read from the device
+                const double* Crow = s.dWt + (size_t)j0 * s.kcap;
+                BCHK(combine(s, nh, k, Crow, s.kcap, s.AV, 1.0, 0.0, s.R));
+                BCHK(combine(s, nh, k, Crow, s.kcap, s.V, -1.0, 1.0, s.R, s.dtheta + j0));
+                BCHK(launch_rows_sumsq(c, s.R, s.ld, nh, n, c->dscal + DS_MISC));
+                if (j0 == 0) {
+                    BCHK(d2h_async(c, theta.data(), s.dtheta, (size_t)k * sizeof(double)));
+                    BHIP(hipMemcpyAsync(c->hscal + DS_MISC + 32, s.dinfo, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                }
+                BCHK(read_scalars(c, DS_MISC, nh));
+                if (j0 == 0 && *reinterpret_cast<const int*>(c->hscal + DS_MISC + 32) != 0) {
+                    set_error("davidson_block: Rayleigh-Ritz eigenproblem failed (Jacobi sweeps exhausted)");
+                    return fail(SELLA_E_NOCONV);
+                }
+            } else {
             Ch.assign((size_t)nh * k, 0.0);
             for (int h = 0; h < nh; ++h)
                 for (int a = 0; a < k; ++a) Ch[(size_t)h * k + a] = W[(size_t)a * k + j0 + h];
@@ -453,6 +666,7 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
             BCHK(combine(s, nh, k, s.dC, s.kcap, s.V, 1.0, 1.0, s.R));
             BCHK(launch_rows_sumsq(c, s.R, s.ld, nh, n, c->dscal + DS_MISC));
             BCHK(read_scalars(c, DS_MISC, nh));
+            }
             const bool feed = (na == 0);
             int run_src = -1, run_dst = 0, run_len = 0;              // consecutive residual rows travel as one copy
             auto flush_run = [&]() -> int {
@@ -515,6 +729,10 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
                 double* src = pass ? s.AV : s.V;
                 for (int j0 = 0; j0 < keep; j0 += BD_NB) {
                     const int nh = std::min(BD_NB, keep - j0);
+                    if (s.dev_rr) {
+                        BCHK(combine(s, nh, s.k, s.dWt + (size_t)j0 * s.kcap, s.kcap, src, 1.0, 0.0, s.Vt + (size_t)j0 * s.ld));
+                        continue;
+                    }
                     Ch.assign((size_t)nh * s.k, 0.0);
                     for (int h = 0; h < nh; ++h)
                         for (int a = 0; a < s.k; ++a) Ch[(size_t)h * s.k + a] = W[(size_t)a * s.k + j0 + h];
@@ -524,12 +742,20 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
                 BHIP(hipMemcpyAsync(src, s.Vt, (size_t)keep * s.ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
                 BHIP(hipMemsetAsync(src + (size_t)keep * s.ld, 0, (size_t)(s.kcap - keep) * s.ld * sizeof(double), c->stream));
             }
-            std::fill(s.G.begin(), s.G.end(), 0.0);
-            for (int a = 0; a < keep; ++a) s.G[(size_t)a * s.kcap + a] = theta[a];
+            if (s.dev_rr) {
+                hipLaunchKernelGGL(bd_gram_reset_kernel, dim3((s.kcap * s.kcap + 255) / 256), dim3(256), 0, c->stream, s.dG,
+                                   s.kcap, s.kcap, keep, s.dtheta);
+                BHIP(hipGetLastError());
+            } else {
+                std::fill(s.G.begin(), s.G.end(), 0.0);
+                for (int a = 0; a < keep; ++a) s.G[(size_t)a * s.kcap + a] = theta[a];
+            }
             s.k = keep;
             theta.resize(keep);                       // the restarted basis IS the Ritz basis: W = I until the next RR
-            W.assign((size_t)keep * keep, 0.0);
-            for (int a = 0; a < keep; ++a) W[(size_t)a * keep + a] = 1.0;
+            if (!s.dev_rr) {
+                W.assign((size_t)keep * keep, 0.0);
+                for (int a = 0; a < keep; ++a) W[(size_t)a * keep + a] = 1.0;
+            }
         }
         BCHK(orthonormalise_block(s, na, s.k, &kept));
         ++iter;
@@ -545,11 +771,15 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
     for (size_t e = 0; e < (size_t)n * nev; ++e) V_out[e] = 0.0;
     for (int j0 = 0; j0 < nout; j0 += BD_NB) {
         const int nh = std::min(BD_NB, nout - j0);
+        if (s.dev_rr) {
+            BCHK(combine(s, nh, k, s.dWt + (size_t)j0 * s.kcap, s.kcap, s.V, 1.0, 0.0, s.R));
+        } else {
         Ch.assign((size_t)nh * k, 0.0);
         for (int h = 0; h < nh; ++h)
             for (int a = 0; a < k; ++a) Ch[(size_t)h * k + a] = W[(size_t)a * k + j0 + h];
         BCHK(put_coeffs(s, Ch, nh, k));
         BCHK(combine(s, nh, k, s.dC, s.kcap, s.V, 1.0, 0.0, s.R));
+        }
         BCHK(download_panel(c, s.R, s.ld, n, nh, Xh.data()));
         for (int i = 0; i < n; ++i)
             for (int h = 0; h < nh; ++h) V_out[(size_t)i * nev + j0 + h] = Xh[(size_t)i * nh + h];

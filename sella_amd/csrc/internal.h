@@ -95,6 +95,7 @@ struct Options {
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
     long rank2k_stream = 1;  // 1: trailing update of the tridiagonalisation as a mirror-free MFMA stream (update.hip)
+    long bd_dev_rr = 1;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 64) on the device (davidson_block.hip)
     long rs_batch = 1;       // 1: bisection phase of the restricted-step root find evaluates 15 trial alphas per round trip (stepper.hip)
 };
 

@@ -81,12 +81,12 @@ struct Theta16 {
 // eigenvectors accumulate as ROWS of Wt in global memory (L2 resident), sorted ascending with the host routine's sign
 // convention, ready to be read as the coefficient rows of bd_combine_kernel — so neither the Ritz vectors' coefficients
 // nor the Gram matrix ever travel to the host.
-constexpr int BD_JMAX = 64;
+constexpr int BD_JMAX = 56;      // both k x k matrices of the Jacobi kernel live in LDS: 2 x 56 x 56 doubles = 49 KB
 
 __global__ __launch_bounds__(256) void bd_jacobi_eig_kernel(int k, const double* __restrict__ G, int ldg,
                                                             double* __restrict__ theta, double* __restrict__ Wt, int ldw,
-                                                            double* __restrict__ Wtmp, int* __restrict__ info) {
-    __shared__ double A[BD_JMAX][BD_JMAX];
+                                                            double* __restrict__ /*unused*/, int* __restrict__ info) {
+    __shared__ double Af[BD_JMAX * BD_JMAX], Wf[BD_JMAX * BD_JMAX];
     __shared__ double cc[BD_JMAX / 2], ss[BD_JMAX / 2], red[256];
     __shared__ int pp[BD_JMAX / 2], qq[BD_JMAX / 2], rankof[BD_JMAX];
     __shared__ double dsort[BD_JMAX];
@@ -97,11 +97,11 @@ __global__ __launch_bounds__(256) void bd_jacobi_eig_kernel(int k, const double*
         const int i = e / k2, j = e % k2;
         double v = 0.0;
         if (i < k && j < k) v = 0.5 * (G[(size_t)i * ldg + j] + G[(size_t)j * ldg + i]);
-        A[i][j] = v;
+        Af[(i) * k2 + (j)] = v;
     }
     for (int e = tid; e < k2 * k2; e += 256) {
         const int i = e / k2, j = e % k2;
-        Wtmp[(size_t)i * ldw + j] = (i == j) ? 1.0 : 0.0;
+        Wf[(i) * k2 + (j)] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
     const int half = k2 / 2, m1 = k2 - 1;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void bd_jacobi_eig_kernel(int k, const double*
         double off = 0.0, dia = 0.0;
         for (int e = tid; e < k2 * k2; e += 256) {
             const int i = e / k2, j = e % k2;
-            const double v = A[i][j];
+            const double v = Af[(i) * k2 + (j)];
             if (i == j) dia += v * v; else off += v * v;
         }
         red[tid] = off;
@@ -134,10 +134,10 @@ __global__ __launch_bounds__(256) void bd_jacobi_eig_kernel(int k, const double*
                 if (tid == 0) { p = m1; q = step % m1; }
                 else { p = (step + tid) % m1; q = (step + m1 - tid) % m1; }
                 if (p > q) { const int t = p; p = q; q = t; }
-                const double apq = A[p][q];
+                const double apq = Af[(p) * k2 + (q)];
                 double c = 1.0, sn = 0.0;
                 if (apq != 0.0) {
-                    const double app = A[p][p], aqq = A[q][q];
+                    const double app = Af[(p) * k2 + (p)], aqq = Af[(q) * k2 + (q)];
                     if (fabs(apq) > 1e-300) {
                         const double tau = (aqq - app) / (2.0 * apq);
                         const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
@@ -153,9 +153,9 @@ __global__ __launch_bounds__(256) void bd_jacobi_eig_kernel(int k, const double*
                 const int t = e / k2, j = e % k2;
                 const int p = pp[t], q = qq[t];
                 const double c = cc[t], sn = ss[t];
-                const double ap = A[p][j], aq = A[q][j];
-                A[p][j] = c * ap - sn * aq;
-                A[q][j] = sn * ap + c * aq;
+                const double ap = Af[(p) * k2 + (j)], aq = Af[(q) * k2 + (j)];
+                Af[(p) * k2 + (j)] = c * ap - sn * aq;
+                Af[(q) * k2 + (j)] = sn * ap + c * aq;
             }
             __syncthreads();
             // A <- A J : columns p, q;  eigenvector rows of Wtmp likewise
@@ -163,19 +163,19 @@ __global__ __launch_bounds__(256) void bd_jacobi_eig_kernel(int k, const double*
                 const int t = e / k2, i = e % k2;
                 const int p = pp[t], q = qq[t];
                 const double c = cc[t], sn = ss[t];
-                const double ap = A[i][p], aq = A[i][q];
-                A[i][p] = c * ap - sn * aq;
-                A[i][q] = sn * ap + c * aq;
-                const double wp = Wtmp[(size_t)p * ldw + i], wq = Wtmp[(size_t)q * ldw + i];
-                Wtmp[(size_t)p * ldw + i] = c * wp - sn * wq;
-                Wtmp[(size_t)q * ldw + i] = sn * wp + c * wq;
+                const double ap = Af[(i) * k2 + (p)], aq = Af[(i) * k2 + (q)];
+                Af[(i) * k2 + (p)] = c * ap - sn * aq;
+                Af[(i) * k2 + (q)] = sn * ap + c * aq;
+                const double wp = Wf[(p) * k2 + (i)], wq = Wf[(q) * k2 + (i)];
+                Wf[(p) * k2 + (i)] = c * wp - sn * wq;
+                Wf[(q) * k2 + (i)] = sn * wp + c * wq;
             }
             __syncthreads();
         }
     }
     if (tid == 0 && sweep >= 40) info[0] = 1;
     // ascending order (ties: lower index first), sign: largest-magnitude component positive
-    if (tid < k) dsort[tid] = A[tid][tid];
+    if (tid < k) dsort[tid] = Af[(tid) * k2 + (tid)];
     __syncthreads();
     if (tid < k) {
         const double d = dsort[tid];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void bd_jacobi_eig_kernel(int k, const double*
         double best = 0.0;
         int bi = 0;
         for (int j = lane; j < k; j += 64) {
-            const double v = fabs(Wtmp[(size_t)row * ldw + j]);
+            const double v = fabs(Wf[(row) * k2 + (j)]);
             if (v > best) { best = v; bi = j; }
         }
         for (int mz = 32; mz > 0; mz >>= 1) {
@@ -198,9 +198,9 @@ __global__ __launch_bounds__(256) void bd_jacobi_eig_kernel(int k, const double*
             const int oi = __shfl_xor(bi, mz, 64);
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
-        const double sgn = (Wtmp[(size_t)row * ldw + bi] < 0.0) ? -1.0 : 1.0;
+        const double sgn = (Wf[(row) * k2 + (bi)] < 0.0) ? -1.0 : 1.0;
         const int r = rankof[row];
-        for (int j = lane; j < k; j += 64) Wt[(size_t)r * ldw + j] = sgn * Wtmp[(size_t)row * ldw + j];
+        for (int j = lane; j < k; j += 64) Wt[(size_t)r * ldw + j] = sgn * Wf[(row) * k2 + (j)];
     }
 }
 
@@ -295,7 +295,7 @@ int blk_alloc(Blk& s) {
         HIPCHK(hipMemsetAsync(s.send, 0, s.bytesS, c->stream));
     }
     s.G.assign((size_t)s.kcap * s.kcap, 0.0);
-    s.dev_rr = s.kcap <= BD_JMAX && c->opt.bd_dev_rr;
+    s.dev_rr = s.maxvec <= BD_JMAX && c->opt.bd_dev_rr;      // the basis never holds more than maxvec vectors
     if (s.dev_rr) {
         const size_t kk2 = (size_t)s.kcap * s.kcap;
         SCHK(dev_alloc(c, (3 * kk2 + 2 * (size_t)s.kcap + 16) * sizeof(double), &s.dG));

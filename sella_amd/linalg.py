@@ -139,10 +139,12 @@ EIG_UPDATE_REFRESH = 1024
 # and the eigenvalue lam0 on the complement of their span (csrc/eigh.hip, lr_lowrank_update).  Carrying THAT costs O(n r)
 # per update instead of the O(n^2) passes of the dense form, the step families work on r + 1 modes instead of n
 # (csrc/stepper.hip, sella_stepper_create_lr) and the Davidson preconditioner costs O(n r) per application.  Used from
-# LR_MIN_DIM on (below it the dense machinery is already cheap and r would reach dim at once) while
-# r <= LR_MAX_FRACTION * dim; then the decomposition goes dense (one device eigh) and stays so.  LR_MIN_DIM = None
-# switches the structured form off.
-LR_MIN_DIM = 96
+# LR_MIN_DIM on while r <= LR_MAX_FRACTION * dim; then the decomposition goes dense (one device eigh) and stays so.
+# Both forms are latency bound below a thousand degrees of freedom and measure the same there in one process (37 ms per
+# 3N = 768 search), but the structured one issues smaller kernels, which several worker processes sharing the device
+# interleave worse (56 against 86 searches/s with four workers, session r03f): hence 1024.  LR_MIN_DIM = None switches
+# the structured form off; the tests lower it to exercise the structured path at emulation sizes.
+LR_MIN_DIM = 1024
 LR_MAX_FRACTION = 0.4
 
 

@@ -68,8 +68,14 @@ def test_config1_emt_slab_1024_atoms(ctx):
     dx, dg = x1 - x0, g1 - g0
     np.testing.assert_allclose(B @ dx, dg, atol=1e-8 * max(1.0, np.abs(dg).max()))
     np.testing.assert_array_equal(B, B.T)
-    # the eigendecompositions carried across the updates (B itself and its free-free principal submatrix) still
-    # diagonalise what they belong to
+    # the eigendecompositions carried across the updates (B itself and its free-free principal submatrix; at this size in
+    # the structured form lam0 I + rank r) still diagonalise what they belong to
+    lr = pes.H.device_eig_lr()
+    assert lr is not None and 0 < lr['r'] < 400
+    W = lr['Wt'].numpy()[:lr['r']]
+    assert np.abs(W @ W.T - np.eye(lr['r'])).max() < 1e-11
+    assert np.abs(B @ W.T - W.T * lr['mu'][:lr['r']]).max() < 1e-9 * max(1.0, np.abs(lr['mu'][:lr['r']]).max())
+    np.testing.assert_allclose(pes.H.evals, np.linalg.eigvalsh(B), atol=1e-9 * max(1.0, np.abs(B).max()))
     w, V, Vt = pes.H.device_eig()
     Vn = V.numpy()
     scale = max(1.0, np.abs(w).max())

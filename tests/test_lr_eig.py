@@ -10,6 +10,16 @@ from conftest import hessian_like
 from helpers import FakePES
 
 
+@pytest.fixture(autouse=True)
+def structured_from_96():
+    """The product switches the structured form on from 1024 degrees of freedom; here from 96 (emulation sizes)."""
+    from sella_amd import linalg
+    old = linalg.LR_MIN_DIM
+    linalg.LR_MIN_DIM = 96
+    yield
+    linalg.LR_MIN_DIM = old
+
+
 def _sequence(n, seed, blocks=(6, 1, 1, 1, 3, 1, 1)):
     rng = np.random.RandomState(seed)
     Htrue = hessian_like(n, seed)[0]

@@ -87,14 +87,15 @@ def test_pinned_slab_step_by_step(ctx):
         np.testing.assert_array_equal(a1.positions[:6], pos[:6])
 
 
-def test_emt_slab_twin_step_by_step(ctx):
+def test_emt_slab_twin_step_by_step(ctx, monkeypatch):
     """BASELINE configs[1] on a down-sized twin — Cu(111) 3 x 3 x 4 EMT slab with a lifted surface atom, lower half
     pinned atom by atom, default `Sella` — product (device EMT, selection bases, principal-submatrix view, carried
     eigendecompositions, fused root finder) against the dense oracle driving the NumPy restatement of the EMT
     (oracle/sella_oracle/emt.py), step by step.  The 1024-atom original runs in tests/test_configs_gpu.py."""
     from conftest_shim import emt_slab
     from oracle.sella_oracle.emt import EMTOracle
-    from sella_amd import Sella
+    from sella_amd import Sella, linalg
+    monkeypatch.setattr(linalg, 'LR_MIN_DIM', 96)       # the structured eigendecomposition, as at the named size
     a1, c1, pinned = emt_slab((3, 3, 4))
     a2, _, _ = emt_slab((3, 3, 4), calculator=EMTOracle())
     start = a1.positions.copy()

@@ -131,44 +131,52 @@ __global__ __launch_bounds__(256) void bd_jacobi_eig_kernel(int k, const double*
         for (int step = 0; step < m1; ++step) {
             if (tid < half) {
                 int p, q;
-                if (tid == 0) { p = m1; q = step % m1; }
-                else { p = (step + tid) % m1; q = (step + m1 - tid) % m1; }
+                if (tid == 0) { p = m1; q = step; }
+                else {
+                    p = step + tid; if (p >= m1) p -= m1;
+                    q = step + m1 - tid; if (q >= m1) q -= m1;
+                }
                 if (p > q) { const int t = p; p = q; q = t; }
-                const double apq = Af[(p) * k2 + (q)];
+                const double apq = Af[p * k2 + q];
                 double c = 1.0, sn = 0.0;
-                if (apq != 0.0) {
-                    const double app = Af[(p) * k2 + (p)], aqq = Af[(q) * k2 + (q)];
-                    if (fabs(apq) > 1e-300) {
-                        const double tau = (aqq - app) / (2.0 * apq);
-                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                        c = 1.0 / sqrt(1.0 + t * t);
-                        sn = t * c;
-                    }
+                if (fabs(apq) > 1e-300) {
+                    const double tau = (Af[q * k2 + q] - Af[p * k2 + p]) / (2.0 * apq);
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    c = 1.0 / sqrt(1.0 + t * t);
+                    sn = t * c;
                 }
                 pp[tid] = p; qq[tid] = q; cc[tid] = c; ss[tid] = sn;
             }
             __syncthreads();
-            // A <- J^T A : rows p, q
-            for (int e = tid; e < half * k2; e += 256) {
-                const int t = e / k2, j = e % k2;
-                const int p = pp[t], q = qq[t];
-                const double c = cc[t], sn = ss[t];
-                const double ap = Af[(p) * k2 + (j)], aq = Af[(q) * k2 + (j)];
-                Af[(p) * k2 + (j)] = c * ap - sn * aq;
-                Af[(q) * k2 + (j)] = sn * ap + c * aq;
+            // A <- J^T A J in ONE phase: the index pairs partition the matrix into disjoint 2 x 2 blocks
+            // (row pair tr) x (column pair tc), each read and written by one thread; thread (tr, tc) = (tid / 32, tid % 32)
+            const int tc = tid & 31;
+            for (int tr = tid >> 5; tr < half; tr += 8) {
+                if (tc < half) {
+                    const int p = pp[tr], q = qq[tr], u = pp[tc], v = qq[tc];
+                    const double cr = cc[tr], sr = ss[tr], c2 = cc[tc], s2 = ss[tc];
+                    const double apu = Af[p * k2 + u], apv = Af[p * k2 + v], aqu = Af[q * k2 + u], aqv = Af[q * k2 + v];
+                    // rows: (p, q) <- (c p - s q, s p + c q)
+                    const double bpu = cr * apu - sr * aqu, bpv = cr * apv - sr * aqv;
+                    const double bqu = sr * apu + cr * aqu, bqv = sr * apv + cr * aqv;
+                    // columns: (u, v) <- (c u - s v, s u + c v)
+                    Af[p * k2 + u] = c2 * bpu - s2 * bpv;
+                    Af[p * k2 + v] = s2 * bpu + c2 * bpv;
+                    Af[q * k2 + u] = c2 * bqu - s2 * bqv;
+                    Af[q * k2 + v] = s2 * bqu + c2 * bqv;
+                }
             }
-            __syncthreads();
-            // A <- A J : columns p, q;  eigenvector rows of Wtmp likewise
-            for (int e = tid; e < half * k2; e += 256) {
-                const int t = e / k2, i = e % k2;
-                const int p = pp[t], q = qq[t];
-                const double c = cc[t], sn = ss[t];
-                const double ap = Af[(i) * k2 + (p)], aq = Af[(i) * k2 + (q)];
-                Af[(i) * k2 + (p)] = c * ap - sn * aq;
-                Af[(i) * k2 + (q)] = sn * ap + c * aq;
-                const double wp = Wf[(p) * k2 + (i)], wq = Wf[(q) * k2 + (i)];
-                Wf[(p) * k2 + (i)] = c * wp - sn * wq;
-                Wf[(q) * k2 + (i)] = sn * wp + c * wq;
+            // eigenvector rows p, q of W: thread (tr, column j), 64 columns per pass
+            {
+                const int j = tid & 63;
+                if (j < k2)
+                    for (int tr = tid >> 6; tr < half; tr += 4) {
+                        const int p = pp[tr], q = qq[tr];
+                        const double c = cc[tr], sn = ss[tr];
+                        const double wp = Wf[p * k2 + j], wq = Wf[q * k2 + j];
+                        Wf[p * k2 + j] = c * wp - sn * wq;
+                        Wf[q * k2 + j] = sn * wp + c * wq;
+                    }
             }
             __syncthreads();
         }

@@ -95,6 +95,8 @@ struct Options {
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
     long rank2k_stream = 1;  // 1: trailing update of the tridiagonalisation as a mirror-free MFMA stream (update.hip)
+    long panel_small = 2048; // panel products with <= 64 rows and at least this many columns split the long index over the
+                             // chip (kernels.hip); 0: never
     long bd_dev_rr = 1;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 64) on the device (davidson_block.hip)
     long rs_batch = 1;       // 1: bisection phase of the restricted-step root find evaluates 15 trial alphas per round trip (stepper.hip)
 };
@@ -189,7 +191,7 @@ int prof_flush(sella_ctx* c);
 enum ScratchSlot {
     SCR_X = 0, SCR_Y, SCR_PART, SCR_V, SCR_AV, SCR_V2, SCR_AV2, SCR_R, SCR_T, SCR_W, SCR_C,
     SCR_EIG0, SCR_EIG1, SCR_EIG2, SCR_EIG3, SCR_EIG4, SCR_EIG5, SCR_EIG6, SCR_UPD0, SCR_UPD1, SCR_UPD2,
-    SCR_UPD3, SCR_UPD4, SCR_QR0, SCR_QR1, SCR_STEP0, SCR_STEP1, SCR_STEP2, SCR_MISC0, SCR_MISC1, SCR_NSLOTS
+    SCR_UPD3, SCR_UPD4, SCR_QR0, SCR_QR1, SCR_STEP0, SCR_STEP1, SCR_STEP2, SCR_MISC0, SCR_MISC1, SCR_PSMALL, SCR_NSLOTS
 };
 
 // ---- kernel launchers (kernels.hip) -------------------------------------------------------

@@ -963,10 +963,80 @@ __global__ __launch_bounds__(256) void panel16_mfma_kernel(const double* __restr
     }
 }
 
+// ---- short-and-wide panel products -----------------------------------------------------------------------------
+// Gram blocks and projections of the block methods: rows <= 64 (the basis), nrhs <= 16 (the block), cols = n long.
+// The row-parallel kernels above give such a product 1 - 4 workgroups, each streaming whole rows: 82 us for a 48 x 12288
+// panel (57 GB/s) — five of them per block-Davidson iteration were its largest serial part.  Here the LONG index is
+// split: workgroup w takes columns [w cpw, (w + 1) cpw) in tiles of 64 staged through LDS, thread (r, hg) accumulates the
+// four outputs (r, 4 hg .. 4 hg + 3); the per-workgroup partial results are summed by a second, single-workgroup
+// kernel in workgroup order (deterministic, no atomics).
+constexpr int PS_ROWS = 64, PS_TILE = 64;
+
+__global__ __launch_bounds__(256) void panel_small_partial_kernel(const double* __restrict__ A, int rows, int cols, int lda,
+                                                                  const double* __restrict__ X, int ldx, int nrhs, int cpw,
+                                                                  double* __restrict__ part) {
+    __shared__ double As[PS_ROWS][PS_TILE + 1];
+    __shared__ double Xs[16][PS_TILE];
+    const int tid = threadIdx.x, r = tid & 63, hg = tid >> 6;
+    const int c0 = blockIdx.x * cpw, c1 = (c0 + cpw < cols) ? c0 + cpw : cols;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t0 = c0; t0 < c1; t0 += PS_TILE) {
+        __syncthreads();
+        // stage: 64 lanes along the columns (coalesced), 4 rows per pass
+        for (int rr = tid >> 6; rr < PS_ROWS; rr += 4) {
+            const int j = t0 + (tid & 63);
+            As[rr][tid & 63] = (rr < rows && j < c1) ? A[(size_t)rr * lda + j] : 0.0;
+        }
+        for (int hh = tid >> 6; hh < 16; hh += 4) {
+            const int j = t0 + (tid & 63);
+            Xs[hh][tid & 63] = (hh < nrhs && j < c1) ? X[(size_t)hh * ldx + j] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int j = 0; j < PS_TILE; ++j) {
+            const double a = As[r][j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += a * Xs[4 * hg + q][j];
+        }
+    }
+    double* out = part + (size_t)blockIdx.x * 16 * PS_ROWS;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[(4 * hg + q) * PS_ROWS + r] = acc[q];
+}
+
+__global__ __launch_bounds__(256) void panel_small_reduce_kernel(const double* __restrict__ part, int nsplit, int rows,
+                                                                 int nrhs, double* __restrict__ Y, int ldy) {
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 16 * PS_ROWS; e += 256) {
+        const int h = e >> 6, r = e & 63;
+        if (h >= nrhs || r >= rows) continue;
+        double s = 0.0;
+        for (int w = 0; w < nsplit; ++w) s += part[(size_t)w * 16 * PS_ROWS + e];
+        Y[(size_t)h * ldy + r] = s;
+    }
+}
+
+static int launch_panel_small(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* X, int ldx, int nrhs,
+                              double* Y, int ldy) {
+    int nsplit = (cols + PS_TILE - 1) / PS_TILE;
+    if (nsplit > 256) nsplit = 256;
+    int cpw = (cols + nsplit - 1) / nsplit;
+    cpw = (cpw + PS_TILE - 1) / PS_TILE * PS_TILE;
+    nsplit = (cols + cpw - 1) / cpw;
+    double* part;
+    SCHK(scratch_get(c, SCR_PSMALL, (size_t)256 * 16 * PS_ROWS * sizeof(double), &part));
+    hipLaunchKernelGGL(panel_small_partial_kernel, dim3(nsplit), dim3(256), 0, c->stream, A, rows, cols, lda, X, ldx, nrhs, cpw, part);
+    hipLaunchKernelGGL(panel_small_reduce_kernel, dim3(1), dim3(256), 0, c->stream, part, nsplit, rows, nrhs, Y, ldy);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
 // Y (nrhs rows, vector-major) = A X^T for a zero-padded 16-row panel Xp with the matrix's leading dimension
 int launch_panel16(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* Xp, int nrhs,
                    double* Y, int ldy) {
     if (rows <= 0 || nrhs <= 0) return SELLA_OK;
+    if (rows <= PS_ROWS && nrhs <= 16 && c->opt.panel_small > 0 && cols >= c->opt.panel_small)
+        return launch_panel_small(c, A, rows, cols, lda, Xp, lda, nrhs, Y, ldy);
     if (nrhs > 16 || (lda & 3) || (((uintptr_t)A) & 31) || (((uintptr_t)Xp) & 31)) {
         set_error("panel16: needs <= 16 right-hand sides and 32-byte aligned rows");
         return SELLA_E_INVALID;

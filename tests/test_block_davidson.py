@@ -68,3 +68,23 @@ def test_block_davidson_row_sharded_callback(ctx):
     out = ctx.davidson_block(dA, n, nev, tol=1e-8, Pvecs=Q, PvecsT=Qt, pevals=w, row0=0, world=1, allgather=gather)
     check_pairs(A, out, nev)
     assert calls and all(b == 16 * n * 8 for b in calls)
+
+
+def test_block_davidson_split_panel_products(ctx):
+    """The short-and-wide panel products of the iteration (basis <= 64 rows against the block: projections, Gram blocks)
+    through the split-index kernels (`panel_small_*`, on by default from 2048 columns; forced here at test size) and
+    through the row-parallel MFMA kernel: same converged pairs."""
+    n, nev = 160, 6
+    A, P, g = hessian_like(n, seed=5, nneg=2)
+    dA, dP = ctx.upload(A), ctx.upload(P)
+    w, Q, Qt = ctx.eigh(dP)
+    outs = {}
+    for flag in (64, 0):
+        ctx.set_option('panel_small', flag)
+        try:
+            outs[flag] = ctx.davidson_block(dA, n, nev, block=8, tol=1e-9, maxiter=200, maxvec=32, Pvecs=Q, PvecsT=Qt, pevals=w)
+        finally:
+            ctx.set_option('panel_small', 2048)
+        check_pairs(A, outs[flag], nev)
+    np.testing.assert_allclose(outs[64]['lams'], outs[0]['lams'], atol=1e-11)
+    assert outs[64]['niter'] == outs[0]['niter']

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Block Davidson iterations at BASELINE configs[4] size on one GPU (dense symmetric pseudo-random operator, diagonal
+preconditioner, fixed iteration count): ms per block iteration, with the Rayleigh-Ritz step on the device and on the
+host.   usage: block_iter.py [n] [iterations]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sella_amd import device as _dev  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 12288
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+ctx = _dev.get_context()
+rng = np.random.RandomState(0)
+H = rng.standard_normal((n, n)) * 0.01
+H = H + H.T
+H[np.arange(n), np.arange(n)] += 0.5 + 50.0 * (np.arange(n) / n) ** 2
+dH = ctx.upload(H)
+diag = np.ascontiguousarray(H.diagonal())
+del H
+for flag in (1, 0, 1):
+    ctx.set_option('bd_dev_rr', flag)
+    ctx.davidson_block(dH, n, 16, block=16, tol=1e-14, maxiter=2, diag=diag)
+    ctx.sync()
+    t = time.perf_counter()
+    out = ctx.davidson_block(dH, n, 16, block=16, tol=1e-14, maxiter=iters, diag=diag)
+    ctx.sync()
+    dt = time.perf_counter() - t
+    print('bd_dev_rr=%d: %d iterations, %.3f ms per block iteration, lowest Ritz %.12f'
+          % (flag, out['niter'], 1e3 * dt / max(1, out['niter']), out['lams'][0]), flush=True)

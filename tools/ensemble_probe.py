@@ -9,6 +9,7 @@ from sella_amd.ensemble import EnsemblePool, run_ensemble, run_one  # noqa: E402
 
 if __name__ == '__main__':
     nmem = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    print('host cpus: os.cpu_count() = %s, usable = %d' % (os.cpu_count(), len(os.sched_getaffinity(0))), flush=True)
     procs = [int(a) for a in sys.argv[2:]] or [4]
     fac = EnsembleMember(768)
     for i in range(nmem):

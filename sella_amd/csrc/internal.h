@@ -97,7 +97,9 @@ struct Options {
     long rank2k_stream = 1;  // 1: trailing update of the tridiagonalisation as a mirror-free MFMA stream (update.hip)
     long panel_small = 2048; // panel products with <= 64 rows and at least this many columns split the long index over the
                              // chip (kernels.hip); 0: never
-    long bd_dev_rr = 1;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 64) on the device (davidson_block.hip)
+    long bd_dev_rr = 0;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 56) on the device by parallel cyclic
+                             // Jacobi in one workgroup (davidson_block.hip).  Measured at k = 48: 456 us per solve against ~270 us
+                             // for the host's tred2 / tql2 (session r03l: 1.16 against 0.85 ms per block iteration), hence off
     long rs_batch = 1;       // 1: bisection phase of the restricted-step root find evaluates 15 trial alphas per round trip (stepper.hip)
 };
 

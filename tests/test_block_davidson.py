@@ -88,3 +88,21 @@ def test_block_davidson_split_panel_products(ctx):
         check_pairs(A, outs[flag], nev)
     np.testing.assert_allclose(outs[64]['lams'], outs[0]['lams'], atol=1e-11)
     assert outs[64]['niter'] == outs[0]['niter']
+
+
+def test_block_davidson_device_rayleigh_ritz(ctx):
+    """Option bd_dev_rr: the k x k Rayleigh-Ritz problem solved on the device (parallel cyclic Jacobi in one workgroup,
+    Ritz coefficients read by the combine kernels straight from HBM) against the default host solve: same pairs."""
+    n, nev = 128, 16
+    A, P, g = hessian_like(n, seed=n, nneg=2)
+    dA, dP = ctx.upload(A), ctx.upload(P)
+    w, Q, Qt = ctx.eigh(dP)
+    outs = {}
+    for flag in (1, 0):
+        ctx.set_option('bd_dev_rr', flag)
+        try:
+            outs[flag] = ctx.davidson_block(dA, n, nev, block=16, tol=1e-8, maxiter=200, Pvecs=Q, PvecsT=Qt, pevals=w)
+        finally:
+            ctx.set_option('bd_dev_rr', 0)
+        check_pairs(A, outs[flag], nev)
+    np.testing.assert_allclose(outs[1]['lams'], outs[0]['lams'], atol=1e-10)

@@ -144,6 +144,12 @@ static constexpr size_t D2H_RING_BYTES = (size_t)8 << 20;
 int d2h_async_2d(sella_ctx* c, void* dst, const void* src_dev, size_t spitch, size_t width, size_t rows) {
     const size_t bytes = width * rows;
     if (bytes == 0) return SELLA_OK;
+    static const bool direct = getenv("SELLA_D2H_DIRECT") != nullptr;      // measurement knob: the runtime's own staging
+    if (direct) {
+        if (rows == 1 || spitch == width) HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        else HIPCHK(hipMemcpy2DAsync(dst, width, src_dev, spitch, width, rows, hipMemcpyDeviceToHost, c->stream));
+        return SELLA_OK;
+    }
     if (!c->dring) {
         void* p = nullptr;
         HIPCHK(hipHostMalloc(&p, D2H_RING_BYTES, hipHostMallocDefault));

@@ -455,7 +455,7 @@ int orthonormalise_block(Blk& s, int nt, int k, int* kept) {
     bool clean = false;
     SCHK(svqb(s, s.T, s.T2, nt, true, 1e-6, &m1, &clean));
     if (m1 == 0) return SELLA_OK;
-    if (clean && k > 0 && c->opt.bd_dev_rr) { *kept = m1; return SELLA_OK; }
+    if (clean && k > 0) { *kept = m1; return SELLA_OK; }
     // second pass: re-project (classical Gram-Schmidt twice) and re-orthonormalise; nothing is dropped here
     // unless the block collapsed to roundoff
     SCHK(project_out(s, s.T, m1, k));

@@ -152,6 +152,14 @@ class EnsemblePool:
         # one BLAS thread per worker unless told otherwise: the members are small, and idle pool threads spinning in
         # P processes at once exhaust a container's CPU quota (utilities/hostcpu.py)
         os.environ['SELLA_HOST_THREADS'] = os.environ.get('SELLA_POOL_HOST_THREADS', '1')
+        # Small transfers of several client processes queue up behind each other on the device's few SDMA engines:
+        # with four workers the same members take 0.35 s through the copy engines and 0.19 s with the copies issued
+        # as shader blits (46 against 84 searches/s, session r03n) — while ONE process is faster with the engines
+        # (eigh 43.7 against 49.0 ms, optimizer step 1.01 against 1.35 ms).  So the workers, and only they, run with
+        # HSA_ENABLE_SDMA=0 (read by the runtime when it starts; an explicit setting of the caller wins).
+        keep_sdma = os.environ.get('HSA_ENABLE_SDMA')
+        if keep_sdma is None:
+            os.environ['HSA_ENABLE_SDMA'] = os.environ.get('SELLA_POOL_SDMA', '0')
         self._workers = []
         try:
             for _ in range(self.processes):
@@ -165,6 +173,8 @@ class EnsemblePool:
                 os.environ.pop('SELLA_HOST_THREADS', None)
             else:
                 os.environ['SELLA_HOST_THREADS'] = keep
+            if keep_sdma is None:
+                os.environ.pop('HSA_ENABLE_SDMA', None)
         try:
             self.pids = [self._expect(conn) for _, conn in self._workers]
         except Exception:

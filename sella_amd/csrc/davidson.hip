@@ -29,6 +29,11 @@ struct Dav {
     int n = 0, ld = 0, cap = 0, k = 0;
     double *Vp = nullptr, *AVp = nullptr, *Vq = nullptr, *AVq = nullptr;   // ping-pong panels
     double *Rp = nullptr;        // residual panel (cap rows)
+    // carried images of the panels in the eigenbasis of P (fused iteration with an eigenbasis preconditioner):
+    // QtV_a = Q^T V_a, QtAV_a = Q^T AV_a, rows [0, k); one allocation, QtAV = QtV + cap * ld
+    double *QtV = nullptr, *QtAV = nullptr;
+    bool qt_mode = false;
+    hipEvent_t ev = nullptr;
     double *wk = nullptr;        // work vectors: 4 x 8 rows of ld (pinv input / mid / output, t)
     double *dW = nullptr;        // device copy of small coefficient matrices
     int capW = 0;
@@ -52,7 +57,7 @@ int dav_alloc(Dav& s, int cap) {
     sella_ctx* c = s.c;
     const size_t pbytes = (size_t)cap * s.ld * sizeof(double);
     // panels are re-allocated on growth; old contents are copied
-    double *nV, *nAV, *nVq, *nAVq, *nR;
+    double *nV, *nAV, *nVq, *nAVq, *nR, *nQt = nullptr;
     // use dedicated allocations (not the scratch pool) so growth can copy old -> new
     if (dev_alloc(c, pbytes, &nV) != SELLA_OK || dev_alloc(c, pbytes, &nAV) != SELLA_OK ||
         dev_alloc(c, pbytes, &nVq) != SELLA_OK || dev_alloc(c, pbytes, &nAVq) != SELLA_OK ||
@@ -65,16 +70,27 @@ int dav_alloc(Dav& s, int cap) {
     HIPCHK(hipMemsetAsync(nVq, 0, pbytes, c->stream));
     HIPCHK(hipMemsetAsync(nAVq, 0, pbytes, c->stream));
     HIPCHK(hipMemsetAsync(nR, 0, pbytes, c->stream));
+    if (s.qt_mode) {
+        if (dev_alloc(c, 2 * pbytes, &nQt) != SELLA_OK) { set_error("davidson: cannot allocate the eigenbasis panels"); return SELLA_E_NOMEM; }
+        HIPCHK(hipMemsetAsync(nQt, 0, 2 * pbytes, c->stream));
+    }
     if (s.Vp) {
         const size_t old = (size_t)s.k * s.ld * sizeof(double);
         if (old) {
             HIPCHK(hipMemcpyAsync(nV, s.Vp, old, hipMemcpyDeviceToDevice, c->stream));
             HIPCHK(hipMemcpyAsync(nAV, s.AVp, old, hipMemcpyDeviceToDevice, c->stream));
+            if (s.qt_mode && s.QtV) {
+                HIPCHK(hipMemcpyAsync(nQt, s.QtV, old, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(hipMemcpyAsync(nQt + (size_t)cap * s.ld, s.QtAV, old, hipMemcpyDeviceToDevice, c->stream));
+            }
         }
+        if (s.QtV) dev_free(c, s.QtV, 2 * s.pbytes);
         dev_free(c, s.Vp, s.pbytes); dev_free(c, s.AVp, s.pbytes); dev_free(c, s.Vq, s.pbytes);
         dev_free(c, s.AVq, s.pbytes); dev_free(c, s.Rp, s.pbytes);
     }
     s.Vp = nV; s.AVp = nAV; s.Vq = nVq; s.AVq = nAVq; s.Rp = nR;
+    s.QtV = nQt;
+    s.QtAV = nQt ? nQt + (size_t)cap * s.ld : nullptr;
     s.pbytes = pbytes;
     // Gram matrices: re-layout with the new leading dimension
     vec gvv((size_t)cap * cap, 0.0), gva((size_t)cap * cap, 0.0);
@@ -94,7 +110,11 @@ void dav_free(Dav& s) {
     if (s.Vp) {
         dev_free(s.c, s.Vp, s.pbytes); dev_free(s.c, s.AVp, s.pbytes); dev_free(s.c, s.Vq, s.pbytes);
         dev_free(s.c, s.AVq, s.pbytes); dev_free(s.c, s.Rp, s.pbytes);
+        if (s.QtV) dev_free(s.c, s.QtV, 2 * s.pbytes);
     }
+    if (s.ev) (void)hipEventDestroy(s.ev);
+    s.ev = nullptr;
+    s.QtV = s.QtAV = nullptr;
     s.Vp = nullptr;
 }
 
@@ -198,6 +218,32 @@ int apply_pinv_xp(Dav& s, double theta, const double* const* in, int m, double* 
     }
     SCHK(launch_gemv_rows_xp(c, s.Qt->d, s.n, s.n, s.Qt->ld, in, m, mid, s.ld, e));
     return launch_gemv_rows(c, s.Q->d, s.n, s.n, s.Q->ld, mid, s.ld, m, out, s.ld, GemvEpi());
+}
+
+// mid_h[i] = in_h[i] / (d[i] - theta), h < nh (<= 2): the diagonal of (P - theta)^-1 in P's eigenbasis, with the exact-hit
+// guard of the matvec epilogue (kernels.hip, GemvEpi mode 1)
+__global__ __launch_bounds__(256) void dav_eigscale_kernel(int n, int nh, const double* __restrict__ in0,
+                                                           const double* __restrict__ in1, const double* __restrict__ d,
+                                                           double theta, double* __restrict__ mid, int ld) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double den = d[i] - theta;
+    if (den == 0.0) den = 2.220446049250313e-16 * fmax(fabs(theta), 2.2250738585072014e-308);
+    mid[i] = in0[i] / den;
+    if (nh > 1) mid[(size_t)ld + i] = in1[i] / den;
+}
+
+// rows [row0, row0 + nrows) of the eigenbasis panels from the raw panels: QtV_a = Q^T V_a, QtAV_a = Q^T AV_a
+int qt_update(Dav& s, int row0, int nrows) {
+    sella_ctx* c = s.c;
+    for (int r = row0; r < row0 + nrows; r += 8) {
+        const int nr = std::min(8, row0 + nrows - r);
+        SCHK(launch_gemv_rows(c, s.Qt->d, s.n, s.n, s.Qt->ld, s.Vp + (size_t)r * s.ld, s.ld, nr, s.QtV + (size_t)r * s.ld, s.ld,
+                              GemvEpi()));
+        SCHK(launch_gemv_rows(c, s.Qt->d, s.n, s.n, s.Qt->ld, s.AVp + (size_t)r * s.ld, s.ld, nr, s.QtAV + (size_t)r * s.ld,
+                              s.ld, GemvEpi()));
+    }
+    return SELLA_OK;
 }
 
 // Orthonormalise t against V[0:k) with the reference's accept / drop rules (gs.hip).
@@ -605,6 +651,12 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
     } else {
         s.prank = n;
     }
+    // Fused iteration with an eigenbasis preconditioner: the images Q^T V, Q^T AV of the panels are carried (one
+    // 2-right-hand-side pass per NEW vector, queued behind the iteration's last kernel so that it runs while the host
+    // does its k x k algebra), and Q^T r, Q^T v of the correction are linear combinations of their rows — the
+    // Rayleigh-Ritz-dependent chain then holds two n x n passes (Q, A) instead of three.
+    s.qt_mode = s.A != nullptr && s.Q != nullptr && s.prank == n && method >= SELLA_DAV_GD && method <= SELLA_DAV_JD0_ALT &&
+                vref == nullptr && !getenv("SELLA_DAV_SYNC") && !getenv("SELLA_DAV_NOQT");
     if (maxiter <= 0) maxiter = 2 * n + 1;
     const int kstop = (n < maxiter) ? n : maxiter;
 
@@ -655,6 +707,10 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
     const bool dbg_time = getenv("SELLA_DEBUG_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
+    if (s.qt_mode) {
+        DCHK(qt_update(s, 0, s.k));
+        DHIP(hipEventCreate(&s.ev));
+    }
     while (true) {
         const int k = s.k, cap = s.cap;
         double th0 = now();
@@ -778,6 +834,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         }
         t_host += now() - th0;
         if (k >= kstop) break;                                            // :65-66
+        if (k >= 64) s.qt_mode = false;       // (the flush below rotates the raw panels only; old chain from here on)
         if (k >= 64) {
             // large subspaces (converged runs: hundreds of vectors): carrying the cumulative rotation on the host is
             // O(k^3) per iteration; apply it to the device panels instead (two k x k x n products) and restart from
@@ -895,8 +952,33 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         if (fast_ok) {
             // ---- speculative chain for the predicted pair ---------------------------------------------------
             int mode = 0;
+            if (s.qt_mode) {
+                // Q^T r_j, Q^T v from the carried eigenbasis panels (same kernel, same coefficients; |Q^T r| = |r| for
+                // the convergence test), the diagonal of (P - theta)^-1, then the ONE n x n pass with Q
+                double* dC;
+                const int ncoef = (2 * nneg + 1) * k;
+                DCHK(put_small(s, coef.data(), ncoef, 1, (size_t)s.cap * s.cap + 8, &dC));
+                s.dcoef = dC;
+                double* Rq = s.Vq;                           // free between flushes: rows Q^T r_j
+                double* vq = s.AVq;                          // row 0: Q^T v
+                dim3 grid(nblk, (nneg + 3) / 4);
+                if (nneg == 1) {
+                    grid.y = 1;
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(dav_resid_kernel<1>), grid, dim3(256), 0, c->stream, n, k, nneg, s.QtV,
+                                       s.QtAV, s.ld, dC, Rq, vq, rpart);
+                } else {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(dav_resid_kernel<4>), grid, dim3(256), 0, c->stream, n, k, nneg, s.QtV,
+                                       s.QtAV, s.ld, dC, Rq, vq, rpart);
+                }
+                mode = (method == SELLA_DAV_GD) ? 0 : 1;
+                hipLaunchKernelGGL(dav_eigscale_kernel, dim3(nblke), dim3(256), 0, c->stream, n, mode == 1 ? 2 : 1,
+                                   Rq + (size_t)seek_pred * s.ld, vq, s.pevals_dev, lams[seek_pred], mid, s.ld);
+                DHIP(hipGetLastError());
+                DCHK(launch_gemv_rows(c, s.Q->d, n, n, s.Q->ld, mid, s.ld, mode == 1 ? 2 : 1, out, s.ld, GemvEpi()));
+            } else {
             DCHK(launch_resid());
             DCHK(launch_expand(seek_pred, lams[seek_pred], &mode));
+            }
             {
                 const double* xs[2] = {out, out + s.ld};           // V.[x y] in one launch: dyd = dxd + ld
                 DCHK(launch_gemv_rows_xp(c, s.Vp, k, n, s.ld, xs, mode == 1 ? 2 : 1, dxd, s.ld, GemvEpi()));
@@ -912,7 +994,20 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
                                t2, At2, part, part + 2 * DF_MAXBLK, nblk, nblke, s.Vp + (size_t)k * s.ld,
                                s.AVp + (size_t)k * s.ld, dsc);
             DHIP(hipGetLastError());
-            DCHK(sync_scalars(c, DS_GRAM, (int)(S0 + 8 + nneg)));
+            if (s.qt_mode && !c->opt.host_scalars) {
+                // read the scalars back, mark that point, queue the eigenbasis images of the new vector behind it (they
+                // run while the host decides and does the next Rayleigh-Ritz step), wait for the mark only
+                const int cnt = (int)(S0 + 8 + nneg);
+                DHIP(hipMemcpyAsync(c->hscal + DS_GRAM, c->dscal + DS_GRAM, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost,
+                                    c->stream));
+                DHIP(hipEventRecord(s.ev, c->stream));
+                const double* xs[2] = {s.Vp + (size_t)k * s.ld, s.AVp + (size_t)k * s.ld};
+                DCHK(launch_gemv_rows_xp(c, s.Qt->d, n, n, s.Qt->ld, xs, 2, s.QtV + (size_t)k * s.ld, capn * s.ld, GemvEpi()));
+                DHIP(hipEventSynchronize(s.ev));
+            } else {
+                DCHK(sync_scalars(c, DS_GRAM, (int)(S0 + 8 + nneg)));
+                if (s.qt_mode) DCHK(qt_update(s, k, 1));
+            }
             const double* h = c->hscal + DS_GRAM;
             // ---- verdict: the reference's control flow evaluated after the fact --------------------------------
             for (int i = 0; i < nneg; ++i) {                                   // :80-89
@@ -933,6 +1028,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         if (!appended) {
             // ---- synchronous path: the reference's steps one by one -------------------------------------------
             ++n_slow;
+            if (seeking >= 0 && s.qt_mode) DCHK(launch_resid());      // the fast attempt left Q^T r only: r and v themselves
             if (seeking < 0) {
                 DCHK(launch_resid());
                 DCHK(launch_rows_sumsq(c, s.Rp, s.ld, nneg, n, scal_out(c, 0)));
@@ -1045,6 +1141,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
             }
             if (stop) break;
             DCHK(append_vector(s, Wc));
+            if (s.qt_mode) DCHK(qt_update(s, s.k - 1, 1));
         }
         last_seek = seeking;
     }

@@ -9,6 +9,8 @@
                      rows, ready for the Davidson preconditioner, the TS-BFGS |B| term and the
                      P-RFO step; numpy copies are produced lazily.
 """
+import os
+
 import numpy as np
 from scipy.sparse.linalg import LinearOperator
 
@@ -140,11 +142,14 @@ EIG_UPDATE_REFRESH = 1024
 # per update instead of the O(n^2) passes of the dense form, the step families work on r + 1 modes instead of n
 # (csrc/stepper.hip, sella_stepper_create_lr) and the Davidson preconditioner costs O(n r) per application.  Used from
 # LR_MIN_DIM on while r <= LR_MAX_FRACTION * dim; then the decomposition goes dense (one device eigh) and stays so.
-# Both forms are latency bound below a thousand degrees of freedom and measure the same there in one process (37 ms per
-# 3N = 768 search), but the structured one issues smaller kernels, which several worker processes sharing the device
-# interleave worse (56 against 86 searches/s with four workers, session r03f): hence 1024.  LR_MIN_DIM = None switches
-# the structured form off; the tests lower it to exercise the structured path at emulation sizes.
-LR_MIN_DIM = 1024
+# Below a few hundred degrees of freedom the explicit rank reaches that limit within a handful of steps and the dense
+# machinery is cheap anyway.  Measured at 3N = 768 (16 searches of 20 steps): 33 against 29 searches/s in one process,
+# 103 against 85 with four worker processes (session r03p).  LR_MIN_DIM = None switches the structured form off; the
+# tests lower it to exercise the structured path at emulation sizes.
+LR_MIN_DIM = 256
+if os.environ.get('SELLA_LR_MIN_DIM'):                 # measurement knob ('0' or 'none': off)
+    _v = os.environ['SELLA_LR_MIN_DIM'].lower()
+    LR_MIN_DIM = None if _v in ('0', 'none', 'off') else int(_v)
 LR_MAX_FRACTION = 0.4
 
 

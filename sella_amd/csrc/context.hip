@@ -364,9 +364,6 @@ int sella_ctx_destroy(sella_ctx* c) {
     if (c->hstage) (void)hipHostFree(c->hstage);
     if (c->hring) (void)hipHostFree(c->hring);
     if (c->dring) (void)hipHostFree(c->dring);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     (void)hipStreamDestroy(c->stream);
     delete c;
     return SELLA_OK;
@@ -393,7 +390,6 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "rank2k_stream")) c->opt.rank2k_stream = value ? 1 : 0;
     else if (!strcmp(key, "rs_batch")) c->opt.rs_batch = value ? 1 : 0;
     else if (!strcmp(key, "bd_dev_rr")) c->opt.bd_dev_rr = value ? 1 : 0;
-    else if (!strcmp(key, "eigh_overlap")) c->opt.eigh_overlap = value > 0 ? value : 0;
     else if (!strcmp(key, "panel_small")) c->opt.panel_small = value > 0 ? value : 0;
     else if (!strcmp(key, "eigh_leaf")) {
         if (value < 2 || value > 64) { set_error("eigh_leaf must be in [2, 64]"); return SELLA_E_INVALID; }

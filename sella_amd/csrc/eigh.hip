@@ -1939,57 +1939,22 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     const int nrefl = n - 2;
     const int nblk = nrefl > 0 ? (nrefl + WY_NB - 1) / WY_NB : 0;
     double* Gd = nullptr;                                // nblk x 32 x 32: Gram matrices, then C = T^T
-    // With `eigh_overlap` the whole reflector product Q = H_{n-3} ... H_0 (the back-transformation applied to the
-    // identity: 2 n^3 flop on the matrix cores, 3.2 ms at n = 3072) is formed on the SIDE stream while divide & conquer
-    // (host-planned, two synchronisations per level, the device idle most of the time) runs on the main one; the
-    // back-transformation proper is then ONE GEMM, X = Z Q, at the GEMM kernel's rate instead of the reflector kernel's.
-    const bool overlap = c->opt.eigh_overlap > 0 && n >= c->opt.eigh_overlap && (hV || hVt) && nblk > 0;
-    double *Yside = nullptr, *Qm = nullptr;
     if ((hV || hVt) && nblk > 0) {
         SCHK(scratch_get(c, SCR_EIG6, (size_t)nblk * WY_NB * WY_NB * sizeof(double), &Gd));
-        hipStream_t st = c->stream;
-        if (overlap) {
-            if (!c->stream2) {
-                HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-                HIPCHK(hipEventCreate(&c->ev_fork));
-                HIPCHK(hipEventCreate(&c->ev_join));
-            }
-            const size_t yrows = (size_t)nblk * WY_NB;
-            SCHK(scratch_get(c, SCR_EIG7, (yrows + 2) * std::max(ld, 64) * sizeof(double), &Yside));
-            SCHK(scratch_get(c, SCR_EIG8, mbytes, &Qm));
-            HIPCHK(hipEventRecord(c->ev_fork, c->stream));            // reflectors (W.A, taus) are final here
-            HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-            st = c->stream2;
-        }
-        hipLaunchKernelGGL(wy_gram_kernel, dim3(nblk), dim3(256), 0, st, W.A, ld, n, nrefl, taus, Gd);
-        hipLaunchKernelGGL(wy_tinv_kernel, dim3(nblk), dim3(64), 0, st, Gd, nrefl, taus);
-        if (overlap) {
-            hipLaunchKernelGGL(wy_expand_kernel, dim3((ld + 255) / 256, nblk * WY_NB), dim3(256), 0, st, W.A, ld, n, nrefl, taus,
-                               Yside);
-            hipLaunchKernelGGL(set_identity_kernel, dim3((ld + 255) / 256, n), dim3(256), 0, st, Qm, ld, ld);
-            hipLaunchKernelGGL(wy_apply_mfma_kernel, dim3((n + 15) / 16), dim3(256), 0, st, Qm, ld, n, Yside, Gd, nblk);
-            HIPCHK(hipEventRecord(c->ev_join, st));
-        }
+        hipLaunchKernelGGL(wy_gram_kernel, dim3(nblk), dim3(256), 0, c->stream, W.A, ld, n, nrefl, taus, Gd);
+        hipLaunchKernelGGL(wy_tinv_kernel, dim3(nblk), dim3(64), 0, c->stream, Gd, nrefl, taus);
         HIPCHK(hipGetLastError());
     }
 
     const double t_s1 = now();
     // ---- stage 2 ----------------------------------------------------------------------------
-    int dcst = dc_solve(W, d, e, w);
-    if (dcst != SELLA_OK) {
-        if (overlap) (void)hipStreamSynchronize(c->stream2);
-        return dcst;
-    }
+    SCHK(dc_solve(W, d, e, w));
     if (!hV && !hVt) return SELLA_OK;
 
     const double t_s2 = now();
     // ---- stage 3: X = Z H_{n-3} ... H_0 (rows) -------------------------------------------------
     double* X = W.Za;
-    bool x_is_product = false;
-    if (nrefl > 0 && overlap) {
-        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        x_is_product = true;                                 // X = Z Q is formed straight into the output matrix below
-    } else if (nrefl > 0) {
+    if (nrefl > 0) {
         const int yrows = nblk * WY_NB;
         double* Yf = W.Zc;                               // explicit reflectors (yrows x ld)
         hipLaunchKernelGGL(wy_expand_kernel, dim3((ld + 255) / 256, yrows), dim3(256), 0, c->stream, W.A, ld, n, nrefl,
@@ -2007,13 +1972,7 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     sella_mat vt = SELLA_NO_MAT, v = SELLA_NO_MAT;
     SCHK(mat_new(c, n, n, &vt));
     Mat* mvt = mat_get(c, vt);
-    if (x_is_product) {
-        prof_begin(c, PROF_GEMM, 0.0, 2.0 * n * (double)n * n);
-        SCHK(launch_gemm(c, 0, 0, n, n, n, 1.0, W.Za, ld, Qm, ld, 0.0, mvt->d, mvt->ld));
-        prof_end(c);
-    } else {
-        SCHK(launch_axpby2d(c, n, n, 1.0, X, ld, 0.0, nullptr, 0, mvt->d, mvt->ld));
-    }
+    SCHK(launch_axpby2d(c, n, n, 1.0, X, ld, 0.0, nullptr, 0, mvt->d, mvt->ld));
     if (hV) {
         SCHK(mat_new(c, n, n, &v));
         mvt = mat_get(c, vt);

@@ -97,8 +97,6 @@ struct Options {
     long rank2k_stream = 1;  // 1: trailing update of the tridiagonalisation as a mirror-free MFMA stream (update.hip)
     long panel_small = 2048; // panel products with <= 64 rows and at least this many columns split the long index over the
                              // chip (kernels.hip); 0: never
-    long eigh_overlap = 512; // from this size on Q of the back-transformation is formed on the side stream during divide &
-                             // conquer and applied as one GEMM (eigh.hip); 0: never
     long bd_dev_rr = 0;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 56) on the device by parallel cyclic
                              // Jacobi in one workgroup (davidson_block.hip).  Measured at k = 48: 456 us per solve against ~270 us
                              // for the host's tred2 / tql2 (session r03l: 1.16 against 0.85 ms per block iteration), hence off
@@ -110,10 +108,6 @@ struct Options {
 struct sella_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    // side stream + event pair: work that only depends on an earlier point of the main stream and is needed later runs
-    // beside it (the reflector product of the eigensolver's back-transformation beside the divide & conquer stage)
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<sella::Mat> mats;
     // small exchange buffers: device scalars + pinned host mirror
     double* dscal = nullptr;
@@ -199,7 +193,7 @@ int prof_flush(sella_ctx* c);
 enum ScratchSlot {
     SCR_X = 0, SCR_Y, SCR_PART, SCR_V, SCR_AV, SCR_V2, SCR_AV2, SCR_R, SCR_T, SCR_W, SCR_C,
     SCR_EIG0, SCR_EIG1, SCR_EIG2, SCR_EIG3, SCR_EIG4, SCR_EIG5, SCR_EIG6, SCR_UPD0, SCR_UPD1, SCR_UPD2,
-    SCR_UPD3, SCR_UPD4, SCR_QR0, SCR_QR1, SCR_STEP0, SCR_STEP1, SCR_STEP2, SCR_MISC0, SCR_MISC1, SCR_PSMALL, SCR_EIG7, SCR_EIG8, SCR_NSLOTS
+    SCR_UPD3, SCR_UPD4, SCR_QR0, SCR_QR1, SCR_STEP0, SCR_STEP1, SCR_STEP2, SCR_MISC0, SCR_MISC1, SCR_PSMALL, SCR_NSLOTS
 };
 
 // ---- kernel launchers (kernels.hip) -------------------------------------------------------

@@ -203,7 +203,6 @@ hipError_t hipStreamCreate(hipStream_t* s);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
-hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipDeviceSynchronize();
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventDestroy(hipEvent_t e);

@@ -78,23 +78,6 @@ def test_spectra(ctx):
     ctx.set_option('eigh_leaf', 32)
 
 
-def test_reflector_product_on_the_side_stream(ctx):
-    """`eigh_overlap`: Q = H_{n-3} ... H_0 formed beside the divide & conquer stage and applied as one GEMM (default from
-    n = 512; forced here at test size) against the in-place back-transformation: same eigenpairs."""
-    rng = np.random.RandomState(17)
-    n = 70 if ctx.backend == 'emu' else 700
-    A = rng.normal(size=(n, n))
-    A = A + A.T
-    out = {}
-    for flag in (8, 0):
-        ctx.set_option('eigh_overlap', flag)
-        try:
-            out[flag] = check(ctx, A)
-        finally:
-            ctx.set_option('eigh_overlap', 512)
-    np.testing.assert_allclose(out[8], out[0], atol=1e-12 * n)
-
-
 def _rank1_check(ctx, D, w, rho, tol=2e-14):
     K = len(D)
     lam, Ut = ctx.rank1_eig(D, w, rho)

@@ -319,42 +319,45 @@ class PES:
             self._pinned_cache = hit
         return hit[1]
 
+    # ---- the cached point: geometry -> (basis, energy, gradient, multipliers) ---------------------------------------
+    # `curr` / `last` are plain dicts because callers swap them in and out (IRC, sella/optimize/irc.py:62-75); what
+    # fills them is organised around ONE question — does the cache describe the geometry the atoms have now?
+    def _cache_status(self, want_energy):
+        """'fresh': nothing to do; 'energy': same geometry, energy / gradient still missing; 'moved': new geometry."""
+        here = self._state_hash()
+        if self.curr['x'] is None or here != self.curr.get('state_hash'):
+            return 'moved', here
+        if want_energy and self.curr['f'] is None:
+            return 'energy', here
+        return 'fresh', here
+
     def _update(self, feval=True):
-        state = self._state_hash()
-        new_point = True
-        if self.curr['x'] is not None and state == self.curr.get('state_hash'):
-            if feval and self.curr['f'] is None:
-                new_point = False
-            else:
-                return False
-        x = self.get_x()
+        status, here = self._cache_status(feval)
+        if status == 'fresh':
+            return False
         basis = self._calc_basis()
-        f, g = self.eval() if feval else (None, None)
-        if new_point:
-            self.last = self.curr.copy()
-        self.curr['x'] = x
-        self.curr['state_hash'] = state
-        self.curr['f'] = f
-        self.curr['g'] = g
+        energy, gradient = self.eval() if feval else (None, None)
+        if status == 'moved':
+            self.last = self.curr.copy()          # the previous point becomes the reference of the next secant pair
+        self.curr.update(x=self.get_x(), state_hash=here, f=energy, g=gradient)
         self._update_basis(basis)
         return True
 
+    def _multipliers(self, drdx, g):
+        """Lagrange multipliers of the constraint forces: least-squares solution of drdx^T L = g (peswrapper.py:475-479);
+        a division per constraint when every constraint pins one coordinate."""
+        if g is None:
+            return None
+        if drdx.shape[0] == 0:
+            return np.zeros(0)
+        pinned = self._pinned()
+        if pinned is not None:
+            return g[pinned[0]] / pinned[1]
+        return np.linalg.lstsq(drdx.T, g, rcond=None)[0]
+
     def _update_basis(self, basis=None):
-        if basis is None:
-            basis = self._calc_basis()
-        drdx, Ucons, Unred, Ufree = basis
-        self.curr.update(drdx=drdx, Ucons=Ucons, Unred=Unred, Ufree=Ufree)
-        if self.curr['g'] is None:
-            L = None
-        elif drdx.shape[0] == 0:
-            L = np.zeros(0)
-        else:
-            pinned = self._pinned()
-            if pinned is not None:
-                L = self.curr['g'][pinned[0]] / pinned[1]
-            else:
-                L = np.linalg.lstsq(drdx.T, self.curr['g'], rcond=None)[0]
-        self.curr['L'] = L
+        drdx, Ucons, Unred, Ufree = self._calc_basis() if basis is None else basis
+        self.curr.update(drdx=drdx, Ucons=Ucons, Unred=Unred, Ufree=Ufree, L=self._multipliers(drdx, self.curr['g']))
 
     def _update_H(self, dx, dg):
         if self.last['x'] is None or self.last['g'] is None:
@@ -447,16 +450,17 @@ class PES:
 
     # ---- step + update (peswrapper.py:578-602) -------------------------------------------------------
     def kick(self, dx, diag=False, **diag_kwargs):
-        x0 = self.get_x()
-        f0 = self.get_f()
-        g0 = self.get_g()
-        dx_initial, dx_final, g_par = self.set_x(x0 + dx)
-        # B0 @ dx on the device (B0 = H.asarray(); the identity while uninitialised)
-        df_pred = self.get_df_pred(dx_initial, g0, self.H)
-        dg_actual = self.get_g() - g_par
-        df_actual = self.get_f() - f0
-        ratio = None if (df_pred is None or abs(df_pred) < 1e-14) else df_actual / df_pred
-        self._update_H(dx_final, dg_actual)
+        """Take the step dx: returns the ratio of the actual to the predicted energy change (None when no prediction
+        is possible), after teaching the approximate Hessian the new secant pair and — if asked — refreshing its
+        lowest modes by iterative diagonalisation."""
+        before = dict(x=self.get_x(), f=self.get_f(), g=self.get_g())
+        dx_asked, dx_taken, g_transported = self.set_x(before['x'] + dx)
+        # quadratic model of the energy change along the step that was asked for (B dx on the device)
+        predicted = self.get_df_pred(dx_asked, before['g'], self.H)
+        secant_dg = self.get_g() - g_transported
+        actual = self.get_f() - before['f']
+        ratio = actual / predicted if (predicted is not None and abs(predicted) >= 1e-14) else None
+        self._update_H(dx_taken, secant_dg)
         if diag:
             if self.hessian_function is not None:
                 self.calculate_hessian()

@@ -1,70 +1,86 @@
 #!/bin/bash
-# One GPU visit: smoke, gpu tests, bench line, rocprof kernel trace of the bench command, PMC passes.
-# Usage (from the repo root, via gpurun):  bash tools/gpu_session.sh [tag] [fast]
-TAG=${1:-r01}
+# One GPU visit for the evidence kept under profiles/: smoke, gpu tests, bench line, rocprofv3 kernel statistics of the
+# bench / the eigensolver / the Davidson loop / the block iteration / the optimizer step, PMC passes (own runs, kernel
+# dispatch tracing only).   Usage (repo root, via gpurun):  bash tools/gpu_session.sh [tag] [fast]
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-echo "== smoke" | tee $OUT/session.log
-timeout 600 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/session.log
-tail -3 $OUT/smoke.log | tee -a $OUT/session.log
+say() { echo "$@" | tee -a $OUT/session.log; }
+prof() {   # prof <name> <title> <cmd...>: kernel trace + stats of a command, summary -> $OUT/<name>_kernel_stats.md
+  local name=$1 title=$2; shift 2
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_$name -o $name -- "$@" > $R/$OUT/rocprof_$name.log 2>&1); say "rocprof $name exit $?"
+  local db=$(find $OUT/prof_$name -name "*.db" | head -1)
+  python tools/rocprof_summary.py $db $OUT/${name}_kernel_stats.md "$title" > /dev/null
+  head -18 $OUT/${name}_kernel_stats.md | tee -a $OUT/session.log
+  rm -rf $OUT/prof_$name
+}
+pmc() {    # pmc <name> <kernel substring> <counters...> -- <cmd...>
+  local name=$1 needle=$2; shift 2
+  local ctr=()
+  while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
+  (cd /tmp && timeout 600 rocprofv3 --pmc "${ctr[@]}" --kernel-trace -d $R/$OUT/pmc_$name -o pmc -- "$@" > $R/$OUT/pmc_$name.log 2>&1); say "pmc $name (${ctr[*]}) exit $?"
+  local db=$(find $OUT/pmc_$name -name "*.db" | head -1)
+  python tools/pmc_dump.py $db "$needle" 2>&1 | grep -v "^tables\|columns:" > $OUT/pmc_$name.txt
+  head -8 $OUT/pmc_$name.txt | cut -c1-220 | tee -a $OUT/session.log
+  rm -rf $OUT/pmc_$name
+}
+: > $OUT/session.log
+say "== smoke"
+timeout 600 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; say "smoke exit $?"
+tail -2 $OUT/smoke.log | tee -a $OUT/session.log
 if [ "$2" != "fast" ]; then
-echo "== pytest -m gpu" | tee -a $OUT/session.log
-timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" | tee -a $OUT/session.log
-tail -6 $OUT/pytest_gpu.log | tee -a $OUT/session.log
+say "== pytest -m gpu"
+timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; say "pytest exit $?"
+tail -5 $OUT/pytest_gpu.log | tee -a $OUT/session.log
 fi
-echo "== bench" | tee -a $OUT/session.log
-timeout 900 python bench.py > $OUT/bench.log 2>&1; echo "bench exit $?" | tee -a $OUT/session.log
-tail -1 $OUT/bench.log | tee -a $OUT/session.log
-echo "== rocprof kernel trace of the bench command" | tee -a $OUT/session.log
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --ensemble-procs 0 > $R/$OUT/rocprof.log 2>&1); echo "rocprof exit $?" | tee -a $OUT/session.log
-DB=$(find $OUT/prof -name "*.db" | head -1)
-python tools/rocprof_summary.py $DB $OUT/bench_kernel_stats.md "bench.py --steps 5 --warmup 1 --no-cpu-baseline --ensemble-procs 0 (rocprofv3 --kernel-trace --stats)" > /dev/null
-head -20 $OUT/bench_kernel_stats.md | tee -a $OUT/session.log
-echo "== rocprof kernel trace of the eigensolver alone (4 calls at n = 3072)" | tee -a $OUT/session.log
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_eigh -o eigh -- python $R/tools/eigh_only.py 3072 4 > $R/$OUT/rocprof_eigh.log 2>&1); echo "rocprof eigh exit $?" | tee -a $OUT/session.log
-DBE=$(find $OUT/prof_eigh -name "*.db" | head -1)
-python tools/rocprof_summary.py $DBE $OUT/eigh_kernel_stats.md "tools/eigh_only.py 3072 4 (rocprofv3 --kernel-trace --stats)" > /dev/null
-head -16 $OUT/eigh_kernel_stats.md | tee -a $OUT/session.log
-rm -rf $OUT/prof_eigh
-echo "== PMC passes (own runs, no tracing domains besides kernel dispatch)" | tee -a $OUT/session.log
+say "== bench"
+timeout 900 python bench.py > $OUT/bench.log 2>&1; say "bench exit $?"
+tail -1 $OUT/bench.log > $OUT/bench_line.json; cat $OUT/bench_line.json | tee -a $OUT/session.log
+say "== kernel statistics"
+prof bench "bench.py --steps 5 --warmup 1 --no-cpu-baseline --ensemble-procs 0 (rocprofv3 --kernel-trace --stats)" python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --ensemble-procs 0
+prof eigh "tools/eigh_only.py 3072 4 (rocprofv3 --kernel-trace --stats)" python $R/tools/eigh_only.py 3072 4
+prof davidson_loop "tools/dav_time.py (rocprofv3 --kernel-trace --stats)" python $R/tools/dav_time.py
+prof block_iter "tools/block_iter.py 12288 12 (rocprofv3 --kernel-trace --stats)" python $R/tools/block_iter.py 12288 12
+prof optimizer_step "tools/opt_profile.py 3072 20 (rocprofv3 --kernel-trace --stats)" python $R/tools/opt_profile.py 3072 20
+say "== PMC passes"
 for CNT in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace -d $R/$OUT/pmc_$CNT -o pmc -- python $R/tools/eigh_only.py 3072 1 > $R/$OUT/pmc_$CNT.log 2>&1); echo "pmc $CNT exit $?" | tee -a $OUT/session.log
-  DBP=$(find $OUT/pmc_$CNT -name "*.db" | head -1)
-  python tools/pmc_dump.py $DBP trd_gemv > $OUT/pmc_$CNT.txt 2>&1
-  head -12 $OUT/pmc_$CNT.txt | tee -a $OUT/session.log
-  rm -rf $OUT/pmc_$CNT
+  pmc eigh_$CNT trd_gemv $CNT -- python $R/tools/eigh_only.py 3072 1
 done
-echo "== MFMA utilisation (PMC, own runs): block product H.V at 3N = 12288, eigensolver GEMMs / back-transformation" | tee -a $OUT/session.log
-(cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc_mfma_panel -o pmc -- python $R/tools/panel_bench.py 12288 16 > $R/$OUT/pmc_mfma_panel.log 2>&1); echo "pmc mfma panel exit $?" | tee -a $OUT/session.log
+# the same two databases hold the write-bound question of the streaming rank-2k update
+pmc rank2k_FETCH rank2k_stream FETCH_SIZE -- python $R/tools/eigh_only.py 3072 1
+pmc rank2k_WRITE rank2k_stream WRITE_SIZE -- python $R/tools/eigh_only.py 3072 1
+# L2 re-read traffic of the back-transformation (requests from the CUs into L2, hits / misses there)
+pmc wy_l2req wy_apply_mfma TCP_TCC_READ_REQ_sum -- python $R/tools/eigh_only.py 3072 1
+pmc wy_l2hit wy_apply_mfma TCC_HIT_sum TCC_MISS_sum -- python $R/tools/eigh_only.py 3072 1
+pmc wy_fetch wy_apply_mfma FETCH_SIZE -- python $R/tools/eigh_only.py 3072 1
+say "== MFMA utilisation (PMC): block product, eigensolver kernels"
+(cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc_mfma_panel -o pmc -- python $R/tools/panel_bench.py 12288 16 > $R/$OUT/pmc_mfma_panel.log 2>&1); say "pmc mfma panel exit $?"
 DBM=$(find $OUT/pmc_mfma_panel -name "*.db" | head -1)
 python tools/mfma_util.py $DBM panel16_mfma_kernel 4831838208 > $OUT/pmc_mfma.txt 2>&1
 rm -rf $OUT/pmc_mfma_panel
-(cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc_mfma_eigh -o pmc -- python $R/tools/eigh_only.py 3072 1 > $R/$OUT/pmc_mfma_eigh.log 2>&1); echo "pmc mfma eigh exit $?" | tee -a $OUT/session.log
+(cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc_mfma_eigh -o pmc -- python $R/tools/eigh_only.py 3072 1 > $R/$OUT/pmc_mfma_eigh.log 2>&1); say "pmc mfma eigh exit $?"
 DBM=$(find $OUT/pmc_mfma_eigh -name "*.db" | head -1)
 python tools/mfma_util.py $DBM wy_apply_mfma_kernel 57982058496 >> $OUT/pmc_mfma.txt 2>&1
 python tools/mfma_util.py $DBM gemm128_merge_batched_kernel >> $OUT/pmc_mfma.txt 2>&1
 python tools/mfma_util.py $DBM rank2k_stream_kernel >> $OUT/pmc_mfma.txt 2>&1
 rm -rf $OUT/pmc_mfma_eigh
 cat $OUT/pmc_mfma.txt | tee -a $OUT/session.log
-rm -f $OUT/prof/*/*.db.tmp
-echo "== configs[2]: internal coordinates / geodesic at 1024 atoms" | tee -a $OUT/session.log
-timeout 600 python tools/geodesic_bench.py --steps 3 --sella-steps 2 > $OUT/geodesic.log 2>&1; echo "geodesic exit $?" | tee -a $OUT/session.log
-grep "^{" $OUT/geodesic.log | cut -c1-400 | tee -a $OUT/session.log
-EXACT_GEODESIC=1 timeout 600 python tools/geodesic_bench.py --steps 1 --sella-steps 2 > $OUT/geodesic_exact.log 2>&1; grep "Sella(internal)" $OUT/geodesic_exact.log | cut -c1-300 | tee -a $OUT/session.log
-echo "== Davidson loop alone" | tee -a $OUT/session.log
+say "== timings"
 SELLA_DEBUG_TIMING=1 timeout 300 python tools/dav_time.py > $OUT/dav_time.log 2>&1; grep -v "^davidson\|^eigh" $OUT/dav_time.log | tail -4 | tee -a $OUT/session.log; grep "^davidson" $OUT/dav_time.log | tail -1 | tee -a $OUT/session.log
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_dav -o dav -- python $R/tools/dav_time.py > $R/$OUT/rocprof_dav.log 2>&1); echo "rocprof dav exit $?" | tee -a $OUT/session.log
-DBD=$(find $OUT/prof_dav -name "*.db" | head -1)
-python tools/rocprof_summary.py $DBD $OUT/dav_kernel_stats.md "tools/dav_time.py (rocprofv3 --kernel-trace --stats)" > /dev/null
-rm -rf $OUT/prof_dav
-echo "== EMT slab, optimizer profile" | tee -a $OUT/session.log
+timeout 300 python tools/block_iter.py > $OUT/block_iter.log 2>&1; cat $OUT/block_iter.log | tee -a $OUT/session.log
+SELLA_DEBUG_TIMING=1 timeout 300 python tools/opt_profile.py 3072 20 > $OUT/opt_3072.log 2> $OUT/opt_3072_timing.log; head -12 $OUT/opt_3072.log | tee -a $OUT/session.log
+grep "update_H\|rank-one" $OUT/opt_3072_timing.log | tail -3 | tee -a $OUT/session.log
 SELLA_DEBUG_TIMING=1 timeout 300 python tools/emt_slab_opt.py > $OUT/emt.log 2> $OUT/emt_timing.log; grep "per optimizer step" -A8 $OUT/emt.log | tee -a $OUT/session.log
-grep "update_H\|rank-one" $OUT/emt_timing.log | tail -5 | tee -a $OUT/session.log
-SELLA_DEBUG_TIMING=1 timeout 300 python tools/opt_profile.py 3072 20 > $OUT/opt_3072.log 2> $OUT/opt_3072_timing.log; head -10 $OUT/opt_3072.log | tee -a $OUT/session.log
-grep "update_H" $OUT/opt_3072_timing.log | tail -1 | tee -a $OUT/session.log
-echo "== ensemble worker processes" | tee -a $OUT/session.log
-timeout 300 python tools/ensemble_probe.py 16 2 4 > $OUT/probe.log 2>&1; grep pool $OUT/probe.log | tee -a $OUT/session.log
-echo "== rccl (1 rank)" | tee -a $OUT/session.log
+grep "update_H" $OUT/emt_timing.log | tail -2 | tee -a $OUT/session.log
+say "== configs[2]: internal coordinates / geodesic at 1024 atoms"
+timeout 600 python tools/geodesic_bench.py --steps 3 --sella-steps 2 > $OUT/geodesic.log 2>&1; say "geodesic exit $?"
+grep "^{" $OUT/geodesic.log | cut -c1-400 | tee -a $OUT/session.log
+say "== ensemble: worker processes, host threads"
+timeout 300 python tools/ensemble_probe.py 16 1 2 4 > $OUT/probe.log 2>&1; grep "pool\|cpus" $OUT/probe.log | tee -a $OUT/session.log
+timeout 300 python tools/ensemble_threads.py 16 1 2 4 > $OUT/threads.log 2>&1; grep threads $OUT/threads.log | tee -a $OUT/session.log
+timeout 300 python tools/thread_scaling.py 768 40 > $OUT/thread_scaling.log 2>&1; cat $OUT/thread_scaling.log | tee -a $OUT/session.log
+say "== rccl: 1 rank, then 2 ranks on the one GPU"
 timeout 120 python tools/rccl_smoke.py > $OUT/rccl.log 2>&1; tail -1 $OUT/rccl.log | tee -a $OUT/session.log
+NCCL_DEBUG=WARN timeout 300 python tools/rccl_two_ranks_one_gpu.py > $OUT/rccl2.log 2>&1; grep -i "duplicate\|two RCCL" $OUT/rccl2.log | cut -c1-400 | tee -a $OUT/session.log

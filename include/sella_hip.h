@@ -60,7 +60,8 @@ int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
  *   rs_batch (1) bisection phase of sella_restricted_step: 15 trial alphas per device round trip |
  *   panel_small (2048) panel products with <= 64 rows and <= 16 right-hand sides take the split-K kernels from this
  *   many columns on | bd_dev_rr (0) Rayleigh-Ritz eigenproblem of sella_davidson_block on the device (one-workgroup
- *   Jacobi kernel) instead of the host.                                                                         */
+ *   Jacobi kernel) instead of the host | lr_dev (1) sella_opt_step updates structured eigendecompositions in
+ *   coordinates with every decision on the device (0: the host-planned rank-one merges of sella_update_h_lr).     */
 int sella_ctx_set_option(sella_ctx* ctx, const char* key, long value);
 
 /* ---- device matrices --------------------------------------------------------------- */
@@ -287,6 +288,58 @@ int sella_restricted_step(sella_stepper* st, int cons, double delta, const doubl
                           const double* d1, double alpha0, double alphamin, double alphamax, double slope,
                           int newton_safe, int orthonormal, double tol, int maxiter, const int* sel, int nfull,
                           double* s, double* val, double* alphas, int* nalpha);
+
+/* ---- one optimizer step per call ------------------------------------------------------------- */
+/* Sella.step (sella/optimize/optimize.py:359-440) between two force calls, in ONE call: PES.kick's model prediction,
+ * ratio and quasi-Newton update (peswrapper.py:578-602, linalg.py:274-304), the trust-radius rule (optimize.py:413-434)
+ * and the restricted step at the new point (restricted_step.py:28-120, stepper.py) — for the Cartesian PES whose
+ * approximate Hessian carries a STRUCTURED eigendecomposition (sella_update_h_lr), unconstrained or with constraints
+ * that pin single coordinates (idx / m: the free coordinates; the view Bsub = B[idx][idx] with its own structured
+ * decomposition as in sella_update_h_lr), constraints satisfied (no correction step).  The calculator boundary
+ * (peswrapper.py:413-418) stays with the caller: it moves the atoms by the step returned, evaluates f and g, calls again.
+ * Every phase runs the routines of the one-phase entry points, so results are theirs bit for bit.
+ *   flags: SELLA_OPT_LEARN  uses dx (step taken, n), g_old, g_new, f_old, f_new, smag (measure of the step taken as
+ *                           reported by the restricted step), delta / rho (in-out), the five radius parameters;
+ *                           outputs df_pred, ratio + ratio_valid (|df_pred| >= 1e-14), nrank1, nrank1_sub, *r, mu, ...
+ *          SELLA_OPT_PROPOSE uses g_new, delta, stepper_kind (SELLA_STEP_*), order, cons (0 tr, 1 ras), tol, maxiter;
+ *                           outputs s_out (n), smag_out, nalpha.
+ * The re-diagonalisation schedule (optimize.py:363-378) stays with the caller: it asks for LEARN only, runs the
+ * iterative diagonalisation, then asks for PROPOSE.                                                                  */
+enum { SELLA_OPT_LEARN = 1, SELLA_OPT_PROPOSE = 2 };
+typedef struct sella_opt_step_t {
+    int flags, n;
+    /* approximate Hessian and its structured eigendecomposition (sella_update_h_lr) */
+    sella_mat B, Wt;
+    int* r;
+    double* mu;
+    double lam0;
+    int update_method, symm;
+    int B_stale, Bsub_stale;   /* in-out: the dense mirrors lag behind (W, mu, lam0); rebuilt by sella_lr_materialize when needed */
+    /* principal-submatrix view of pinned-coordinate constraints (idx == NULL: none) */
+    sella_mat Bsub, Wt_sub;
+    int* r_sub;
+    double* mu_sub;
+    const int* idx;
+    int m;
+    /* learn */
+    const double *dx, *g_old, *g_new;
+    double f_old, f_new, smag;
+    double delta, rho;                                      /* in-out */
+    double delta_min, sigma_inc, sigma_dec, rho_inc, rho_dec;
+    double df_pred, ratio;                                  /* out */
+    int ratio_valid, updated, nrank1, nrank1_sub;           /* out; updated = 0: step shorter than 1e-8, B left alone */
+    /* propose */
+    int stepper_kind, order, cons, maxiter;
+    double tol;
+    double* s_out;                                          /* n */
+    double smag_out;                                        /* out */
+    int nalpha;                                             /* out */
+} sella_opt_step_t;
+int sella_opt_step(sella_ctx* ctx, sella_opt_step_t* io);
+/* Dense mirror of a structured decomposition: B <- lam0 I + W^T diag(mu - lam0) W (B n x n resident, overwritten).  The
+ * fast form of sella_opt_step updates (W, mu) only and marks B stale; whoever needs the matrix itself — `H.B`, a matvec, a
+ * projection, the general update route — rebuilds it first.                                                             */
+int sella_lr_materialize(sella_ctx* ctx, sella_mat B, sella_mat Wt, int r, const double* mu, double lam0);
 
 /* ---- internal-coordinate primitives ----------------------------------------------------------- */
 /* Batched value / gradient / Hessian-vector product / Hessian of bonds (natoms = 2), angles (3) and

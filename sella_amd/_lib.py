@@ -20,6 +20,28 @@ c_int_p = POINTER(c_int)
 MATVEC_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_double_p, c_double_p, c_int)
 ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p)
 
+class OptStepArgs(ctypes.Structure):
+    """`sella_opt_step_t` of include/sella_hip.h, field for field."""
+    _fields_ = [
+        ('flags', c_int), ('n', c_int),
+        ('B', c_int), ('Wt', c_int), ('r', c_int_p), ('mu', c_void_p), ('lam0', c_double),
+        ('update_method', c_int), ('symm', c_int), ('B_stale', c_int), ('Bsub_stale', c_int),
+        ('Bsub', c_int), ('Wt_sub', c_int), ('r_sub', c_int_p), ('mu_sub', c_void_p), ('idx', c_void_p), ('m', c_int),
+        ('dx', c_void_p), ('g_old', c_void_p), ('g_new', c_void_p),
+        ('f_old', c_double), ('f_new', c_double), ('smag', c_double),
+        ('delta', c_double), ('rho', c_double),
+        ('delta_min', c_double), ('sigma_inc', c_double), ('sigma_dec', c_double), ('rho_inc', c_double),
+        ('rho_dec', c_double),
+        ('df_pred', c_double), ('ratio', c_double),
+        ('ratio_valid', c_int), ('updated', c_int), ('nrank1', c_int), ('nrank1_sub', c_int),
+        ('stepper_kind', c_int), ('order', c_int), ('cons', c_int), ('maxiter', c_int),
+        ('tol', c_double),
+        ('s_out', c_void_p),
+        ('smag_out', c_double),
+        ('nalpha', c_int),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/sella_hip.h one to one
 SIGNATURES = {
     'sella_last_error': (c_char_p, []),
@@ -77,6 +99,8 @@ SIGNATURES = {
                                      POINTER(c_void_p)]),
     'sella_stepper_create_lr': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_double, c_void_p, c_int, c_int,
                                         POINTER(c_void_p)]),
+    'sella_opt_step': (c_int, [c_void_p, POINTER(OptStepArgs)]),
+    'sella_lr_materialize': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_double]),
     'sella_stepper_get_s': (c_int, [c_void_p, c_double, c_void_p, c_void_p]),
     'sella_stepper_destroy': (c_int, [c_void_p]),
     'sella_stepper_set_d1hat': (c_int, [c_void_p, c_void_p, c_int]),

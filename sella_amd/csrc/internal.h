@@ -94,6 +94,7 @@ struct Options {
     long panel_mfma = 1;     // 1: products with more than 8 right-hand sides stream the matrix once (MFMA panel kernel)
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
+    long lr_dev = 1;         // 1: sella_opt_step updates structured decompositions in coordinates, all decisions on the device (lrstep.hip)
     long rank2k_stream = 1;  // 1: trailing update of the tridiagonalisation as a mirror-free MFMA stream (update.hip)
     long panel_small = 2048; // panel products with <= 64 rows and at least this many columns split the long index over the
                              // chip (kernels.hip); 0: never
@@ -145,6 +146,7 @@ struct sella_ctx {
     size_t dring_bytes = 0, dring_pos = 0;
     struct PendingD2H { void* dst; const char* slot; size_t bytes; size_t dpitch, width, rows; };
     std::vector<PendingD2H> d2h_pending;
+    std::vector<double> hbuf_a, hbuf_b;             // host work vectors of sella_opt_step (optstep.hip)
 };
 
 namespace sella {
@@ -275,6 +277,11 @@ int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const do
 // on the orthogonal complement of their span; *r_io and mu are updated (r grows by at most one per rank-one term)
 int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, Mat* Wt, const double* Up, const double* Zp,
                       int ldp, int kk, int* nrank1);
+// stepper.hip: step family on m modes = rows idx[0..m) of a device panel (gathered into matrices the stepper owns)
+int stepper_from_panel(sella_ctx* c, int kind, const double* src, int ld, const int* idx, int m, int n, const double* ev,
+                       const double* gh, int order, sella_stepper** out);
+// lrstep.hip: the learn / adapt / propose step on structured decompositions with every decision on the device
+int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled);
 // batched NN GEMM for the merges of one divide-and-conquer level: batch b multiplies the diagonal blocks
 // at offset lo_b:  C[lo.., lo..] (K_b x N_b) = A[lo.., lo..] (K_b x K_b) * B[lo.., lo..] (K_b x N_b), all with
 // leading dimension ld.  desc (device): 4 ints per batch {lo, N, K, unused}.

@@ -1,0 +1,725 @@
+// Device-resident rank-two update of a STRUCTURED eigendecomposition  B = lam0 (I - W^T W) + W^T diag(mu) W
+// (r explicit pairs, see eigh.hip lr_lowrank_update for the host-planned form) — the per-step quasi-Newton update of
+// sella/hessian_update.py:114-126 (TS-BFGS, one secant pair) and sella/linalg.py:274-304 with NO host decision inside:
+// the two new directions, the TS-BFGS vectors in coordinates, their rank-one terms, deflation, secular roots,
+// Gu/Eisenstat vectors and the ordering of the new spectrum are all decided on the device; the host queues a fixed
+// sequence of launches and reads the result back once.
+//
+// The algebra.  With c_s = W s, c_y = W y and the parts of s, y outside span(W) orthonormalised into two new rows
+// e1, e2, every vector of the update lives in span(E), E = [W; e1; e2] (r + 2 rows), and B acts on span(E) as
+// D = diag(mu, lam0, lam0) in these coordinates:  s~ = (c_s, |s_perp|, 0), y~ = (c_y, y.e1, y.e2),
+//     B s -> D s~,  |B| s -> |D| s~,  j~ = y~ - D s~,  m1 = s.y, m2 = s~.|D| s~,  u~ = (m1 y~ + m2 |D| s~) / (m1^2 + m2^2),
+//     z~ = j~ - (j.s / 2) u~,     B+ = B + u z^T + z u^T      (hessian_update.py:120-126),
+// so the update is the (r + 2)-dimensional problem  T = D + u~ z~^T + z~ u~^T  = D + sigma_1 p_1 p_1^T + sigma_2 p_2 p_2^T
+// (closed form in the plane of u~, z~), solved as two rank-one modifications IN COORDINATES — the eigenvector panel is
+// touched once, by the final product  W+ = Q^T E  on the matrix cores.  No n x n object appears: the dense mirror of B
+// is rebuilt from (W, mu, lam0) when somebody asks for it (sella_lr_materialize).
+//
+// Kernels: lr_pre_kernel (one workgroup: coordinates, TS-BFGS scalars, the two rank-one terms), lr_plan_kernel (one
+// workgroup: z = Q^T p, ordering, LAPACK dlaed2's deflation rules, Givens rotations on the columns of Q),
+// lr_secular_kernel / lr_zhat_kernel (one wavefront per root, secular.h), lr_apply_kernel (one workgroup per new
+// eigenpair: its vector, its place in the ascending order, its column of the new Q).
+#include "internal.h"
+#include "secular.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <vector>
+
+namespace sella {
+namespace {
+
+constexpr int LR_DEV_MAX = 512;          // rows (r + 2) up to which the coordinate kernels are used
+
+__device__ __forceinline__ double blk_sum(double v, double* red) {
+    v = wave_sum64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double blk_max(double v, double* red) {
+    for (int m = 32; m > 0; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// scalar slots of the workspace (doubles)
+enum { SC_M1 = 0, SC_M2, SC_JS, SC_SBS, SC_SIG1, SC_SIG2, SC_CAREFUL, SC_KEEP1, SC_KEEP2, SC_GPERP2 = 16, SC_N = 32 };
+// gram slots: host / device Gram of the input rows and of the residual rows
+enum { G_SS = 0, G_SY, G_YY, G_A11 = 8, G_A12, G_A22 = 11 };
+
+struct PreArgs {
+    int r, nr, ldr, mode;                 // mode 0: rows are (s, y) -> TS-BFGS; 1: rows are (u, z) themselves
+    const double *C, *C2, *G, *mu;        // C[h * ldr + i], C2[h * ldr + i]
+    double lam0;
+    double *sc, *ec, *UZ, *P, *D;
+};
+
+__global__ __launch_bounds__(256) void lr_pre_kernel(PreArgs a) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    __shared__ double red[4];
+    const int tid = threadIdx.x, r = a.r, nr = a.nr;
+    const double ss = a.G[G_SS], sy = a.G[G_SY], yy = a.G[G_YY];
+    const double a11 = a.G[G_A11], a12 = a.G[G_A12], a22 = a.G[G_A22];
+    // the two new rows: e1 = s_perp / |s_perp|, e2 = (y_perp - (a12 / a11) s_perp) / |.|; a part below 1e-13 of the
+    // vector is dropped (the thresholds of math.pyx:112-117 as gs.hip uses them): its row stays zero
+    const bool keep1 = ss > 0.0 && a11 > 1e-26 * ss;
+    const double r11 = keep1 ? sqrt(a11) : 0.0;
+    const double y1 = keep1 ? a12 / r11 : 0.0;
+    const double rho2sq = a22 - y1 * y1;
+    const bool keep2 = yy > 0.0 && rho2sq > 1e-26 * yy;
+    const double r22 = keep2 ? sqrt(rho2sq) : 0.0;
+    // the second direction comes out of a cancellation: below 1e-8 of |y_perp|^2 its orthogonality to e1 is no longer
+    // at roundoff and the caller takes the Gram-Schmidt path of eigh.hip instead
+    const bool careful = keep2 && rho2sq < 1e-8 * a22;
+    if (tid == 0) {
+        a.ec[0] = keep1 ? 1.0 / r11 : 0.0;                                  // W1[j * 2 + c]: residual row j -> new row c
+        a.ec[1] = (keep1 && keep2) ? -(a12 / a11) / r22 : 0.0;
+        a.ec[2] = 0.0;
+        a.ec[3] = keep2 ? 1.0 / r22 : 0.0;
+        a.sc[SC_CAREFUL] = careful ? 1.0 : 0.0;
+        a.sc[SC_KEEP1] = keep1 ? 1.0 : 0.0;
+        a.sc[SC_KEEP2] = keep2 ? 1.0 : 0.0;
+    }
+    auto Dof = [&](int i) { return i < r ? a.mu[i] : a.lam0; };
+    auto s_of = [&](int i) { return i < r ? -(a.C[i] + a.C2[i]) : (i == r ? r11 : 0.0); };      // (C, C2: negated W x)
+    auto y_of = [&](int i) { return i < r ? -(a.C[a.ldr + i] + a.C2[a.ldr + i]) : (i == r ? y1 : r22); };
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    if (a.mode == 0) {
+        double p2 = 0.0, p3 = 0.0;
+        for (int i = tid; i < nr; i += 256) {
+            const double si = s_of(i), di = Dof(i);
+            p2 += fabs(di) * si * si;
+            p3 += di * si * si;
+        }
+        const double m2 = blk_sum(p2, red), sBs = blk_sum(p3, red);
+        const double m1 = sy, js = sy - sBs;
+        const double g = m1 * m1 + m2 * m2;
+        const double gp = (g > 0.0) ? 1.0 / g : 0.0;
+        c0 = gp * m1;
+        c1 = gp * m2;
+        c2 = -0.5 * js;
+        if (tid == 0) { a.sc[SC_M1] = m1; a.sc[SC_M2] = m2; a.sc[SC_JS] = js; a.sc[SC_SBS] = sBs; }
+    }
+    // u~, z~ (kept in UZ: the coefficient matrix of u, z over the rows of E, nr x 2)
+    double pa = 0.0, pb = 0.0;
+    for (int i = tid; i < nr; i += 256) {
+        const double si = s_of(i), yi = y_of(i);
+        double ui, zi;
+        if (a.mode == 0) {
+            const double di = Dof(i);
+            ui = c0 * yi + c1 * fabs(di) * si;
+            zi = (yi - di * si) + c2 * ui;
+        } else {
+            ui = si;
+            zi = yi;
+        }
+        a.UZ[2 * i] = ui;
+        a.UZ[2 * i + 1] = zi;
+        a.D[i] = Dof(i);
+        pa += ui * ui;
+        pb += ui * zi;
+    }
+    const double uu = blk_sum(pa, red), uz = blk_sum(pb, red);
+    // u z^T + z u^T in the plane (f1, f2), f1 = u / |u|, f2 = z_perp / |z_perp|:  [[2b, s], [s, 0]], b = u.z, s = |u| |z_perp|
+    double pn = 0.0;
+    const double proj = uu > 0.0 ? uz / uu : 0.0;
+    for (int i = tid; i < nr; i += 256) {
+        const double zp = a.UZ[2 * i + 1] - proj * a.UZ[2 * i];
+        pn += zp * zp;
+    }
+    const double n2 = blk_sum(pn, red);
+    const double un = sqrt(uu), zn = sqrt(n2), s = un * zn, b = uz;
+    double sig[2] = {0.0, 0.0}, w1[2] = {0.0, 0.0}, w2[2] = {0.0, 0.0};        // p_t = w1[t] f1 + w2[t] f2
+    if (uu > 0.0) {
+        if (s > 0.0) {
+            const double root = sqrt(b * b + s * s);           // (the smaller root from the product, -s^2: no cancellation)
+            if (b >= 0.0) { sig[0] = b + root; sig[1] = -(s * s) / sig[0]; }
+            else { sig[1] = b - root; sig[0] = -(s * s) / sig[1]; }
+            for (int t = 0; t < 2; ++t) {
+                const double nrm = sqrt(sig[t] * sig[t] + s * s);
+                w1[t] = sig[t] / nrm;
+                w2[t] = s / nrm;
+            }
+        } else {
+            sig[0] = 2.0 * b;
+            w1[0] = 1.0;
+        }
+    }
+    for (int i = tid; i < nr; i += 256) {
+        const double f1 = uu > 0.0 ? a.UZ[2 * i] / un : 0.0;
+        const double f2 = zn > 0.0 ? (a.UZ[2 * i + 1] - proj * a.UZ[2 * i]) / zn : 0.0;
+        a.P[i] = w1[0] * f1 + w2[0] * f2;
+        a.P[a.ldr + i] = w1[1] * f1 + w2[1] * f2;
+    }
+    if (tid == 0) { a.sc[SC_SIG1] = sig[0]; a.sc[SC_SIG2] = sig[1]; }
+}
+
+struct PlanArgs {
+    int nr, ldr, ldq, first;              // first: Q is the identity (z = p)
+    const double* p;
+    const double* sigma;                  // device scalar
+    const double* Dcur;
+    double* Q;                            // nr x nr, columns = current eigenvectors in coordinates (rotated in place)
+    double *z, *Dp, *zz, *Dd, *wd, *cs, *pl;
+    int *perm, *nd, *df, *i1, *i2, *cnt;
+};
+
+// One workgroup: weights of the term in the current eigenbasis, ascending order of the (signed) poles, deflation by
+// LAPACK dlaed2's rules (a negligible weight; of two nearly equal poles one rotated out), the rotations applied to the
+// columns of Q, the compact secular problem.  A negative sigma is solved as -(-D + |sigma| z z^T).
+__global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    __shared__ double red[4];
+    __shared__ int sK, sRot;
+    const int tid = threadIdx.x, nr = a.nr;
+    const double sigma = a.sigma[0];
+    double pz = 0.0;
+    for (int i = tid; i < nr; i += 256) {
+        double zi;
+        if (a.first) {
+            zi = a.p[i];
+        } else {
+            zi = 0.0;
+            for (int k = 0; k < nr; ++k) zi += a.Q[(size_t)k * a.ldq + i] * a.p[k];
+        }
+        a.z[i] = zi;
+        pz += zi * zi;
+    }
+    const double zn2 = blk_sum(pz, red);
+    const double sgn = sigma < 0.0 ? -1.0 : 1.0;
+    const bool idle = !(sigma != 0.0) || !(zn2 > 0.0);
+    const double zn = idle ? 1.0 : sqrt(zn2);
+    double dmax = 0.0, zmax = 0.0;
+    for (int i = tid; i < nr; i += 256) {
+        const double d = sgn * a.Dcur[i], w = a.z[i] / zn;
+        a.Dp[i] = d;
+        a.zz[i] = w;
+        dmax = fmax(dmax, fabs(d));
+        zmax = fmax(zmax, fabs(w));
+    }
+    dmax = blk_max(dmax, red);
+    zmax = blk_max(zmax, red);
+    __syncthreads();
+    // stable ascending order of the poles: perm[rank] = index
+    for (int i = tid; i < nr; i += 256) {
+        const double di = a.Dp[i];
+        int rank = 0;
+        for (int j = 0; j < nr; ++j) {
+            const double dj = a.Dp[j];
+            rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
+        }
+        a.perm[rank] = i;
+    }
+    __syncthreads();
+    const double rho = fabs(sigma) * zn2;
+    if (tid == 0) {
+        const double eps = 2.220446049250313e-16;
+        const double tol = 8.0 * eps * fmax(dmax, zmax);
+        int K = 0, nd = 0, nrot = 0;
+        if (idle || rho * zmax <= tol) {
+            for (int jj = 0; jj < nr; ++jj) a.df[nd++] = a.perm[jj];
+        } else {
+            int pj = -1;
+            for (int jj = 0; jj < nr; ++jj) {
+                const int nj = a.perm[jj];
+                if (rho * fabs(a.zz[nj]) <= tol) { a.df[nd++] = nj; continue; }
+                if (pj < 0) { pj = nj; continue; }
+                double s = a.zz[pj], cc = a.zz[nj];
+                const double tau = hypot(cc, s);
+                const double t = a.Dp[nj] - a.Dp[pj];
+                cc /= tau;
+                s = -s / tau;
+                if (fabs(t * cc * s) <= tol) {
+                    a.zz[nj] = tau;
+                    a.zz[pj] = 0.0;
+                    a.i1[nrot] = pj;
+                    a.i2[nrot] = nj;
+                    a.cs[2 * nrot] = cc;
+                    a.cs[2 * nrot + 1] = s;
+                    ++nrot;
+                    const double tt = a.Dp[pj] * cc * cc + a.Dp[nj] * s * s;
+                    a.Dp[nj] = a.Dp[pj] * s * s + a.Dp[nj] * cc * cc;
+                    a.Dp[pj] = tt;
+                    a.df[nd++] = pj;
+                    pj = nj;
+                } else {
+                    a.nd[K++] = pj;
+                    pj = nj;
+                }
+            }
+            if (pj >= 0) a.nd[K++] = pj;
+        }
+        sK = K;
+        sRot = nrot;
+        a.cnt[0] = K;
+        a.cnt[1] = nrot;
+        a.pl[0] = rho;
+        a.pl[1] = sgn;
+    }
+    __syncthreads();
+    const int K = sK, nrot = sRot;
+    // rotations on column pairs of Q (x' = c x + s y, y' = c y - s x: the row rotations of eigh.hip, transposed)
+    for (int q = 0; q < nrot; ++q) {
+        const int c1 = a.i1[q], c2 = a.i2[q];
+        const double cc = a.cs[2 * q], s = a.cs[2 * q + 1];
+        for (int k = tid; k < nr; k += 256) {
+            double* row = a.Q + (size_t)k * a.ldq;
+            const double x = row[c1], y = row[c2];
+            row[c1] = cc * x + s * y;
+            row[c2] = cc * y - s * x;
+        }
+        __syncthreads();
+    }
+    for (int p = tid; p < K; p += 256) {
+        a.Dd[p] = a.Dp[a.nd[p]];
+        a.wd[p] = a.zz[a.nd[p]];
+    }
+}
+
+struct WaveSum2 {
+    __device__ double operator()(double v) const { return wave_sum64(v); }
+};
+struct WaveProd2 {
+    __device__ double operator()(double v) const {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v *= __shfl_xor(v, m, 64);
+        return v;
+    }
+};
+
+// one wavefront per root; K and rho come from the plan kernel
+__global__ __launch_bounds__(256) void lr_secular_kernel(const int* __restrict__ cnt, const double* __restrict__ pl,
+                                                         const double* __restrict__ D, const double* __restrict__ w,
+                                                         double* __restrict__ tau, int* __restrict__ org,
+                                                         double* __restrict__ lam) {
+    const int K = cnt[0];
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= K) return;
+    int o;
+    double t;
+    const int it = secular::solve_root(K, D, w, pl[0], j, &o, &t, lane, 64, WaveSum2());
+    if (lane == 0) {
+        tau[j] = t;
+        org[j] = o;
+        lam[j] = D[o] + t;
+        if (it < 0) const_cast<int*>(cnt)[2] = j + 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void lr_zhat_kernel(const int* __restrict__ cnt, const double* __restrict__ D,
+                                                      const double* __restrict__ w, const double* __restrict__ tau,
+                                                      const int* __restrict__ org, double* __restrict__ zh) {
+    const int K = cnt[0];
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= K) return;
+    const double z = secular::zhat(K, D, w, tau, org, i, lane, 64, WaveProd2());
+    if (lane == 0) zh[i] = z;
+}
+
+struct ApplyArgs {
+    int nr, ldq;
+    const int *cnt, *nd, *df, *org;
+    const double *pl, *Dd, *Dp, *zh, *tau, *lam;
+    const double* Qin;
+    double *Qout, *Dnext;
+};
+
+// Workgroup j: new eigenpair j of the term — an updated one (j < K: Gu/Eisenstat vector over the non-deflated columns)
+// or a deflated one (copied) — goes to its place in the ascending order of the new spectrum.
+__global__ __launch_bounds__(256) void lr_apply_kernel(ApplyArgs a) {
+    __shared__ double red[4];
+    __shared__ double u[LR_DEV_MAX];
+    const int tid = threadIdx.x, nr = a.nr, j = blockIdx.x;
+    const int K = a.cnt[0];
+    const double sgn = a.pl[1];
+    auto value = [&](int t) { return sgn * (t < K ? a.lam[t] : a.Dp[a.df[t - K]]); };
+    const double vj = value(j);
+    double cntl = 0.0;
+    for (int t = tid; t < nr; t += 256) {
+        const double vt = value(t);
+        cntl += (vt < vj || (vt == vj && t < j)) ? 1.0 : 0.0;
+    }
+    const int pos = (int)(blk_sum(cntl, red) + 0.5);
+    if (tid == 0) a.Dnext[pos] = vj;
+    if (j >= K) {
+        const int src = a.df[j - K];
+        for (int k = tid; k < nr; k += 256) a.Qout[(size_t)k * a.ldq + pos] = a.Qin[(size_t)k * a.ldq + src];
+        return;
+    }
+    const double Do = a.Dd[a.org[j]], tj = a.tau[j];
+    double ssq = 0.0;
+    for (int i = tid; i < K; i += 256) {
+        const double ui = a.zh[i] / ((a.Dd[i] - Do) - tj);
+        u[i] = ui;
+        ssq += ui * ui;
+    }
+    const double inv = 1.0 / sqrt(blk_sum(ssq, red));
+    for (int k = tid; k < nr; k += 256) {
+        const double* row = a.Qin + (size_t)k * a.ldq;
+        double acc = 0.0;
+        for (int i = 0; i < K; ++i) acc += row[a.nd[i]] * u[i];
+        a.Qout[(size_t)k * a.ldq + pos] = acc * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void lr_identity_kernel(double* __restrict__ Q, int nr, int ldq) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nr * ldq) Q[i] = ((i / ldq) == (i % ldq)) ? 1.0 : 0.0;
+}
+
+// rows i < r of out scaled copies of W: out_i = (mu_i - lam0) W_i   (dense mirror: B = lam0 I + W^T out)
+__global__ __launch_bounds__(256) void lr_scale_rows_kernel(const double* __restrict__ W, int ldw, int r, int n,
+                                                            const double* __restrict__ mu, double lam0,
+                                                            double* __restrict__ out, int ldo) {
+    const int i = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    if (i < n && row < r) out[(size_t)row * ldo + i] = (mu[row] - lam0) * W[(size_t)row * ldw + i];
+}
+
+}  // namespace
+
+// Workspace of one job, carved out of one scratch slot.
+struct LrWork {
+    int nr, ldr, ldq;
+    double *C, *C2, *G, *sc, *ec, *UZ, *P, *D0, *D1, *z, *Dp, *zz, *Dd, *wd, *tau, *zh, *lam, *cs, *pl, *mu, *ghat, *Qa, *Qb;
+    int *perm, *nd, *df, *i1, *i2, *org, *cnt;
+};
+
+static int lr_work(sella_ctx* c, int slot, int nr, LrWork& w) {
+    w.nr = nr;
+    w.ldr = round_up(nr + 2, 8);
+    w.ldq = w.ldr;
+    const size_t ldr = w.ldr;
+    const size_t ndbl = 3 * ldr + 2 * ldr + 16 + SC_N + 8 + 2 * ldr + 2 * ldr + 14 * ldr + 8 + 2 * ldr * ldr;
+    const size_t nint = 7 * ldr + 8;
+    double* base;
+    SCHK(scratch_get(c, slot, (ndbl + nint / 2 + 8) * sizeof(double), &base));
+    double* p = base;
+    auto take = [&](size_t k) { double* q = p; p += k; return q; };
+    w.C = take(3 * ldr); w.C2 = take(2 * ldr); w.G = take(16); w.sc = take(SC_N); w.ec = take(8);
+    w.UZ = take(2 * ldr); w.P = take(2 * ldr);
+    w.D0 = take(ldr); w.D1 = take(ldr); w.z = take(ldr); w.Dp = take(ldr); w.zz = take(ldr); w.Dd = take(ldr);
+    w.wd = take(ldr); w.tau = take(ldr); w.zh = take(ldr); w.lam = take(ldr); w.cs = take(2 * ldr); w.mu = take(ldr);
+    w.ghat = take(ldr); w.pl = take(8);
+    w.Qa = take(ldr * ldr); w.Qb = take(ldr * ldr);
+    int* ip = reinterpret_cast<int*>(p);
+    w.perm = ip; w.nd = ip + ldr; w.df = ip + 2 * ldr; w.i1 = ip + 3 * ldr; w.i2 = ip + 4 * ldr; w.org = ip + 5 * ldr;
+    w.cnt = ip + 6 * ldr;
+    return SELLA_OK;
+}
+
+// One job: the structured decomposition (Wt rows 0..r-1, mu, lam0) receives the update defined by the two rows of Xd
+// (mode 0: s and y, TS-BFGS; mode 1: u and z themselves).  Xd row 2 (optional, want_modes): the gradient whose
+// components along the NEW eigenvectors (and whose part outside their span) the next step family needs.
+// Everything is queued on the stream; results are valid after stream_wait:
+//   Wnew: panel of nr + 2 rows: the r + 2 new eigenvector rows (ascending eigenvalues), then the unnormalised g_perp row, then
+//   a zero row;  hD (nr) new eigenvalues, hghat (nr) = -(Wnew g), hsc (SC_N) scalars, hcnt (4 ints).
+struct LrJob {
+    Mat* Wt;
+    int r, n, mode;
+    const double* mu;
+    double lam0;
+    const double* Xd;          // device rows: (s | u), (y | z), g
+    int ldx;
+    const double* gram;        // host: ss, sy, yy of the two rows (mode 0) or nullptr (computed on the device)
+    bool want_modes;
+    int slot_ws, slot_panel;
+    // results
+    LrWork w;
+    double* Wnew;
+    int ldw;
+    std::vector<double> hD, hghat, hsc;
+    int hcnt[4];
+};
+
+static int lr_job_queue(sella_ctx* c, LrJob& j) {
+    const int r = j.r, n = j.n, nr = r + 2;
+    Mat* Wm = j.Wt;
+    const int ld = Wm->ld;
+    if (Wm->rows < nr + 2) { set_error("structured update: eigenvector panel too small"); return SELLA_E_INVALID; }
+    SCHK(lr_work(c, j.slot_ws, nr, j.w));
+    LrWork& w = j.w;
+    double* panel;
+    SCHK(scratch_get(c, j.slot_panel, ((size_t)(nr + 2) + 2) * ld * sizeof(double), &panel));
+    double* R = panel;                               // residual rows (2)
+    j.Wnew = panel + 2 * (size_t)ld;
+    j.ldw = ld;
+    double* W = Wm->d;
+    // small uploads: mu and the Gram of the input rows
+    HIPCHK(hipMemsetAsync(w.C, 0, (size_t)(5 * w.ldr + 16 + SC_N) * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(w.cnt, 0, 8 * sizeof(int), c->stream));
+    if (r > 0) SCHK(h2d_async(c, w.mu, j.mu, (size_t)r * sizeof(double)));
+    if (j.gram) {
+        SCHK(h2d_async(c, w.G, j.gram, 3 * sizeof(double)));
+    } else {
+        // G[h * 2 + i] = X_i . X_h -> ss = G[0], sy = G[1] ... laid out to match (ss, sy, yy) needs a shuffle: use 3 dots
+        SCHK(launch_gemv_rows(c, j.Xd, 1, n, j.ldx, j.Xd, j.ldx, 2, w.G, 1, GemvEpi()));                  // ss, sy
+        SCHK(launch_gemv_rows(c, j.Xd + j.ldx, 1, n, j.ldx, j.Xd + j.ldx, j.ldx, 1, w.G + 2, 1, GemvEpi()));   // yy
+    }
+    // residual rows start as copies of the inputs
+    SCHK(launch_axpby2d(c, 2, n, 1.0, j.Xd, j.ldx, 0.0, nullptr, 0, R, ld));
+    if (r > 0) {
+        // two classical Gram-Schmidt sweeps of both rows against W
+        GemvEpi neg;                                  // C, C2 hold the NEGATED coefficients: lincomb adds them
+        neg.alpha = -1.0;
+        SCHK(launch_gemv_rows(c, W, r, n, ld, R, ld, 2, w.C, w.ldr, neg));
+        for (int h = 0; h < 2; ++h)
+            SCHK(launch_lincomb(c, n, 1, W, ld, r, w.C + (size_t)h * w.ldr, 1, nullptr, 0, 0, nullptr, 0, 1.0,
+                                R + (size_t)h * ld, ld));
+        SCHK(launch_gemv_rows(c, W, r, n, ld, R, ld, 2, w.C2, w.ldr, neg));
+        for (int h = 0; h < 2; ++h)
+            SCHK(launch_lincomb(c, n, 1, W, ld, r, w.C2 + (size_t)h * w.ldr, 1, nullptr, 0, 0, nullptr, 0, 1.0,
+                                R + (size_t)h * ld, ld));
+    }
+    // Gram of the residual rows: G[8 + h * 2 + i] = R_i . R_h -> a11 = G[8], a12 = G[9] (= G[10]), a22 = G[11]
+    SCHK(launch_gemv_rows(c, R, 2, n, ld, R, ld, 2, w.G + G_A11, 2, GemvEpi()));
+    PreArgs pa;
+    pa.r = r; pa.nr = nr; pa.ldr = w.ldr; pa.mode = j.mode;
+    pa.C = w.C; pa.C2 = w.C2; pa.G = w.G; pa.mu = w.mu; pa.lam0 = j.lam0;
+    pa.sc = w.sc; pa.ec = w.ec; pa.UZ = w.UZ; pa.P = w.P; pa.D = w.D0;
+    hipLaunchKernelGGL(lr_pre_kernel, dim3(1), dim3(256), 0, c->stream, pa);
+    HIPCHK(hipGetLastError());
+    // the two new rows of E, in place behind W
+    SCHK(launch_lincomb(c, n, 2, R, ld, 2, w.ec, 2, nullptr, 0, 0, nullptr, 0, 0.0, W + (size_t)r * ld, ld));
+    // two rank-one terms in coordinates
+    hipLaunchKernelGGL(lr_identity_kernel, dim3((nr * w.ldq + 255) / 256), dim3(256), 0, c->stream, w.Qa, nr, w.ldq);
+    double *Qin = w.Qa, *Qout = w.Qb, *Din = w.D0, *Dout = w.D1;
+    for (int t = 0; t < 2; ++t) {
+        PlanArgs pl;
+        pl.nr = nr; pl.ldr = w.ldr; pl.ldq = w.ldq; pl.first = (t == 0);
+        pl.p = w.P + (size_t)t * w.ldr; pl.sigma = w.sc + SC_SIG1 + t; pl.Dcur = Din; pl.Q = Qin;
+        pl.z = w.z; pl.Dp = w.Dp; pl.zz = w.zz; pl.Dd = w.Dd; pl.wd = w.wd; pl.cs = w.cs; pl.pl = w.pl;
+        pl.perm = w.perm; pl.nd = w.nd; pl.df = w.df; pl.i1 = w.i1; pl.i2 = w.i2; pl.cnt = w.cnt;
+        hipLaunchKernelGGL(lr_plan_kernel, dim3(1), dim3(256), 0, c->stream, pl);
+        hipLaunchKernelGGL(lr_secular_kernel, dim3((nr + 3) / 4), dim3(256), 0, c->stream, w.cnt, w.pl, w.Dd, w.wd, w.tau,
+                           w.org, w.lam);
+        hipLaunchKernelGGL(lr_zhat_kernel, dim3((nr + 3) / 4), dim3(256), 0, c->stream, w.cnt, w.Dd, w.wd, w.tau, w.org,
+                           w.zh);
+        ApplyArgs ap;
+        ap.nr = nr; ap.ldq = w.ldq; ap.cnt = w.cnt; ap.nd = w.nd; ap.df = w.df; ap.org = w.org; ap.pl = w.pl;
+        ap.Dd = w.Dd; ap.Dp = w.Dp; ap.zh = w.zh; ap.tau = w.tau; ap.lam = w.lam; ap.Qin = Qin; ap.Qout = Qout; ap.Dnext = Dout;
+        hipLaunchKernelGGL(lr_apply_kernel, dim3(nr), dim3(256), 0, c->stream, ap);
+        HIPCHK(hipGetLastError());
+        std::swap(Qin, Qout);
+        std::swap(Din, Dout);
+    }
+    // (after two terms: Qin == Qa, Din == D0 again)
+    // W+ = Q^T E on the matrix cores
+    SCHK(launch_gemm(c, 1, 0, nr, n, nr, 1.0, Qin, w.ldq, W, ld, 0.0, j.Wnew, ld));
+    HIPCHK(hipMemsetAsync(j.Wnew + (size_t)nr * ld, 0, (size_t)2 * ld * sizeof(double), c->stream));
+    j.hD.assign(nr, 0.0);
+    j.hsc.assign(SC_N, 0.0);
+    if (j.want_modes) {
+        const double* g = j.Xd + 2 * (size_t)j.ldx;
+        GemvEpi e;
+        e.alpha = -1.0;                               // -(W+ g): the coefficients lincomb adds to g
+        SCHK(launch_gemv_rows(c, j.Wnew, nr, n, ld, g, j.ldx, 1, w.ghat, w.ldr, e));
+        double* gp = j.Wnew + (size_t)nr * ld;
+        SCHK(launch_axpby2d(c, 1, n, 1.0, g, j.ldx, 0.0, nullptr, 0, gp, ld));
+        SCHK(launch_lincomb(c, n, 1, j.Wnew, ld, nr, w.ghat, 1, nullptr, 0, 0, nullptr, 0, 1.0, gp, ld));
+        SCHK(launch_rows_sumsq(c, gp, ld, 1, n, w.sc + SC_GPERP2));
+        j.hghat.assign(nr, 0.0);
+        SCHK(d2h_async(c, j.hghat.data(), w.ghat, (size_t)nr * sizeof(double)));
+    }
+    SCHK(d2h_async(c, j.hD.data(), Din, (size_t)nr * sizeof(double)));
+    SCHK(d2h_async(c, j.hsc.data(), w.sc, SC_N * sizeof(double)));
+    SCHK(d2h_async(c, j.hcnt, w.cnt, 4 * sizeof(int)));
+    return SELLA_OK;
+}
+
+__global__ __launch_bounds__(256) void lr_gather_cols_kernel(const double* __restrict__ P, int ldp, int rows,
+                                                             const int* __restrict__ idx, int m,
+                                                             double* __restrict__ out, int ldo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (i < m && r < rows) out[(size_t)r * ldo + i] = P[(size_t)r * ldp + idx[i]];
+}
+
+// After the wait: the new explicit pairs of one job (rows whose eigenvalue is exactly lam0 belong to the cluster again:
+// dropped, zero rows of a direction that was already in span(W) included) written back into the decomposition.
+static int lr_job_commit(sella_ctx* c, LrJob& j, int* r_io, double* mu, std::vector<int>& kept) {
+    const int nr = j.r + 2, n = j.n;
+    kept.clear();
+    for (int i = 0; i < nr; ++i)
+        if (j.hD[i] != j.lam0) kept.push_back(i);
+    const int rn = (int)kept.size();
+    Mat* Wm = j.Wt;
+    if (rn == nr) {
+        SCHK(launch_axpby2d(c, nr, n, 1.0, j.Wnew, j.ldw, 0.0, nullptr, 0, Wm->d, Wm->ld));
+    } else if (rn > 0) {
+        int* didx = j.w.perm;                                          // (free again after the wait)
+        SCHK(h2d_async(c, didx, kept.data(), (size_t)rn * sizeof(int)));
+        SCHK(launch_gather_rows(c, j.Wnew, j.ldw, didx, rn, n, Wm->d, Wm->ld));
+    }
+    for (int i = 0; i < rn; ++i) mu[i] = j.hD[kept[i]];
+    *r_io = rn;
+    return SELLA_OK;
+}
+
+// The fast form of sella_opt_step (optstep.hip): TS-BFGS, one secant pair, structured decompositions small enough for
+// the coordinate kernels.  *handled = false: nothing was changed and the caller takes the general route.
+int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled) {
+    *handled = false;
+    const int n = a->n;
+    const bool view = a->idx != nullptr && a->m > 0;
+    if (!(a->flags & SELLA_OPT_LEARN) || a->update_method != SELLA_UPD_TS_BFGS || !c->opt.lr_dev) return SELLA_OK;
+    if (*a->r + 2 > LR_DEV_MAX || (view && (!a->r_sub || *a->r_sub + 2 > LR_DEV_MAX))) return SELLA_OK;
+    Mat* Wm = mat_get(c, a->Wt);
+    Mat* Ws = view ? mat_get(c, a->Wt_sub) : nullptr;
+    if (!Wm || Wm->cols != n || Wm->rows < *a->r + 4 || (view && (!Ws || Ws->cols != a->m || Ws->rows < *a->r_sub + 4)))
+        return SELLA_OK;
+    const bool propose = (a->flags & SELLA_OPT_PROPOSE) != 0;
+    // host side of the secant pair
+    std::vector<double>& y = c->hbuf_a;
+    y.resize((size_t)n);
+    double gram[3] = {0.0, 0.0, 0.0}, gd = 0.0, gg = 0.0;
+    for (int i = 0; i < n; ++i) {
+        y[i] = a->g_new[i] - a->g_old[i];
+        gram[0] += a->dx[i] * a->dx[i];
+        gram[1] += a->dx[i] * y[i];
+        gram[2] += y[i] * y[i];
+        gd += a->g_old[i] * a->dx[i];
+        gg += a->g_new[i] * a->g_new[i];
+    }
+    if (!(std::sqrt(gram[0]) >= 1e-8)) return SELLA_OK;             // B is left alone: the general route knows how
+    const int ld = round_up(n, 8);
+    double* X;
+    SCHK(scratch_get(c, SCR_UPD0, (size_t)3 * ld * sizeof(double), &X));
+    SCHK(h2d_async(c, X, a->dx, (size_t)n * sizeof(double)));
+    SCHK(h2d_async(c, X + ld, y.data(), (size_t)n * sizeof(double)));
+    SCHK(h2d_async(c, X + 2 * (size_t)ld, a->g_new, (size_t)n * sizeof(double)));
+    LrJob F;
+    F.Wt = Wm; F.r = *a->r; F.n = n; F.mode = 0; F.mu = a->mu; F.lam0 = a->lam0; F.Xd = X; F.ldx = ld; F.gram = gram;
+    F.want_modes = propose && !view; F.slot_ws = SCR_EIG0; F.slot_panel = SCR_EIG1;
+    SCHK(lr_job_queue(c, F));
+    LrJob S;
+    std::vector<double> gsub;
+    if (view) {
+        const int m = a->m, lds = round_up(m, 8), nr = F.r + 2;
+        double *UZp, *Xs;
+        SCHK(scratch_get(c, SCR_UPD1, (size_t)2 * ld * sizeof(double), &UZp));
+        SCHK(scratch_get(c, SCR_UPD2, ((size_t)3 * lds + (size_t)m / 2 + 8) * sizeof(double), &Xs));
+        int* didx = reinterpret_cast<int*>(Xs + 3 * (size_t)lds);
+        // u, z as vectors (rows of E weighted by their coordinates), restricted to the view's coordinates
+        SCHK(launch_lincomb(c, n, 2, Wm->d, Wm->ld, nr, F.w.UZ, 2, nullptr, 0, 0, nullptr, 0, 0.0, UZp, ld));
+        SCHK(h2d_async(c, didx, a->idx, (size_t)m * sizeof(int)));
+        HIPCHK(hipMemsetAsync(Xs, 0, (size_t)3 * lds * sizeof(double), c->stream));
+        hipLaunchKernelGGL(lr_gather_cols_kernel, dim3((m + 255) / 256, 2), dim3(256), 0, c->stream, UZp, ld, 2, didx, m, Xs, lds);
+        HIPCHK(hipGetLastError());
+        gsub.resize((size_t)m);
+        for (int q = 0; q < m; ++q) gsub[q] = a->g_new[a->idx[q]];
+        SCHK(h2d_async(c, Xs + 2 * (size_t)lds, gsub.data(), (size_t)m * sizeof(double)));
+        S.Wt = Ws; S.r = *a->r_sub; S.n = m; S.mode = 1; S.mu = a->mu_sub; S.lam0 = a->lam0; S.Xd = Xs; S.ldx = lds;
+        S.gram = nullptr; S.want_modes = propose; S.slot_ws = SCR_EIG2; S.slot_panel = SCR_EIG3;
+        SCHK(lr_job_queue(c, S));
+    }
+    SCHK(stream_wait(c));
+    auto sound = [](const LrJob& j) {
+        if (j.hsc[SC_CAREFUL] != 0.0 || j.hcnt[2] != 0) return false;
+        for (double v : j.hD) if (!(v == v)) return false;
+        return true;
+    };
+    if (!sound(F) || (view && !sound(S))) return SELLA_OK;              // nothing committed
+    *handled = true;
+    std::vector<int> keptF, keptS;
+    SCHK(lr_job_commit(c, F, a->r, a->mu, keptF));
+    if (view) SCHK(lr_job_commit(c, S, a->r_sub, a->mu_sub, keptS));
+    a->updated = 1;
+    a->nrank1 = 2;
+    a->nrank1_sub = view ? 2 : 0;
+    a->B_stale = 1;
+    if (view) a->Bsub_stale = 1;
+    // model prediction with s.B s from the coordinates (peswrapper.py:446-449), ratio, radius (optimize.py:413-434)
+    const double predicted = gd + 0.5 * F.hsc[SC_SBS];
+    a->df_pred = predicted;
+    a->ratio_valid = 0;
+    if (std::fabs(predicted) >= 1e-14) {
+        a->ratio = (a->f_new - a->f_old) / predicted;
+        a->ratio_valid = 1;
+    }
+    if (!a->ratio_valid) {
+        a->rho = 1.0;
+    } else {
+        const double rho = a->ratio;
+        if (!(1.0 / a->rho_dec <= rho && rho <= a->rho_dec)) a->delta = std::fmax(a->smag * a->sigma_dec, a->delta_min);
+        else if (1.0 / a->rho_inc < rho && rho < a->rho_inc) a->delta = std::fmax(a->sigma_inc * a->smag, a->delta);
+        a->rho = rho;
+    }
+    if (!propose) return SELLA_OK;
+    // step family on the new modes: explicit pairs + the part of g outside their span (+ weightless copies), as
+    // sella_stepper_create_lr builds it, from what came back with the update
+    LrJob& J = view ? S : F;
+    const std::vector<int>& kept = view ? keptS : keptF;
+    const int nd = J.n, nrj = J.r + 2, rn = (int)kept.size();
+    double g2 = gg;
+    if (view) { g2 = 0.0; for (double v : gsub) g2 += v * v; }
+    const double gp2 = J.hsc[SC_GPERP2];
+    const int ncl = nd - rn;
+    const bool have_perp = ncl > 0 && gp2 > 0.0 && gp2 > 1e-26 * g2;
+    double* gprow = J.Wnew + (size_t)nrj * J.ldw;
+    if (have_perp) SCHK(launch_scale_by(c, gprow, nd, J.w.sc + SC_GPERP2, 0));
+    else HIPCHK(hipMemsetAsync(gprow, 0, (size_t)J.ldw * sizeof(double), c->stream));
+    const int ncopy = ncl > 0 ? std::min(a->order, ncl - 1) : 0;
+    const int mm = rn + (ncl > 0 ? 1 : 0) + ncopy;
+    std::vector<double> ev(mm), gh(mm);
+    std::vector<int> idx(mm);
+    {
+        int i = 0, p = 0;
+        auto mu_of = [&](int q) { return J.hD[kept[q]]; };
+        auto put = [&](int q) { ev[p] = mu_of(q); idx[p] = kept[q]; gh[p] = -J.hghat[kept[q]]; ++p; };
+        while (i < rn && mu_of(i) < J.lam0) put(i++);
+        if (ncl > 0) {
+            ev[p] = J.lam0; idx[p] = nrj; gh[p] = have_perp ? std::sqrt(gp2) : 0.0; ++p;
+            for (int q = 0; q < ncopy; ++q) { ev[p] = J.lam0; idx[p] = nrj + 1; gh[p] = 0.0; ++p; }
+        }
+        while (i < rn) put(i++);
+    }
+    sella_stepper* st = nullptr;
+    SCHK(stepper_from_panel(c, a->stepper_kind, J.Wnew, J.ldw, idx.data(), mm, nd, ev.data(), gh.data(), a->order, &st));
+    const bool qn = a->stepper_kind == SELLA_STEP_QN;
+    const double alpha0 = qn ? 0.0 : 1.0, alphamax = qn ? std::numeric_limits<double>::infinity() : 1.0;
+    const int rc = sella_restricted_step(st, a->cons, a->delta, nullptr, nullptr, nullptr, alpha0, 0.0, alphamax,
+                                         qn ? -1.0 : 1.0, qn ? 1 : 0, 1, a->tol, a->maxiter, view ? a->idx : nullptr,
+                                         view ? n : 0, a->s_out, &a->smag_out, nullptr, &a->nalpha);
+    sella_stepper_destroy(st);
+    return rc;
+}
+
+}  // namespace sella
+
+using namespace sella;
+
+// Dense mirror of a structured decomposition: B = lam0 I + W^T diag(mu - lam0) W.
+extern "C" int sella_lr_materialize(sella_ctx* c, sella_mat hB, sella_mat hWt, int r, const double* mu, double lam0) {
+    Mat *B = mat_get(c, hB), *Wm = mat_get(c, hWt);
+    if (!B || B->rows != B->cols || r < 0 || (r > 0 && (!Wm || !mu || Wm->cols != B->rows || Wm->rows < r))) {
+        set_error("lr_materialize: invalid arguments");
+        return SELLA_E_INVALID;
+    }
+    const int n = B->rows;
+    HIPCHK(hipMemsetAsync(B->d, 0, (size_t)n * B->ld * sizeof(double), c->stream));
+    if (r > 0) {
+        const int ld = Wm->ld;
+        double *scaled, *dmu;
+        SCHK(scratch_get(c, SCR_MISC0, (size_t)r * ld * sizeof(double), &scaled));
+        SCHK(scratch_get(c, SCR_MISC1, (size_t)round_up(r, 8) * sizeof(double), &dmu));
+        SCHK(h2d_async(c, dmu, mu, (size_t)r * sizeof(double)));
+        B = mat_get(c, hB);
+        Wm = mat_get(c, hWt);
+        hipLaunchKernelGGL(lr_scale_rows_kernel, dim3((n + 255) / 256, r), dim3(256), 0, c->stream, Wm->d, ld, r, n, dmu, lam0,
+                           scaled, ld);
+        HIPCHK(hipGetLastError());
+        SCHK(launch_gemm(c, 1, 0, n, n, r, 1.0, Wm->d, ld, scaled, ld, 0.0, B->d, B->ld));
+    }
+    return sella_mat_add_diag(c, hB, lam0);
+}

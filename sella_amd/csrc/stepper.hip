@@ -896,6 +896,15 @@ extern "C" int sella_stepper_create_lr(sella_ctx* c, int kind, sella_mat hWt, in
         }
         while (i < r) { ev[p] = mu[i]; idx[p++] = i++; }
     }
+    std::vector<double> gh(m);
+    for (int p = 0; p < m; ++p) gh[p] = idx[p] < r ? aw[idx[p]] : (idx[p] == r ? gperp : 0.0);
+    return stepper_from_panel(c, kind, src, ld, idx.data(), m, n, ev.data(), gh.data(), order, out);
+}
+
+// Step family whose m modes are rows idx[0..m) of a device panel (ascending eigenvalues ev, gradient components gh):
+// the rows are gathered into mode matrices the stepper owns.
+int sella::stepper_from_panel(sella_ctx* c, int kind, const double* src, int ld, const int* idx, int m, int n,
+                              const double* ev, const double* gh, int order, sella_stepper** out) {
     sella_mat hVt = SELLA_NO_MAT, hV = SELLA_NO_MAT;
     SCHK(mat_new(c, m, n, &hVt));
     int st = mat_new(c, n, m, &hV);
@@ -908,7 +917,7 @@ extern "C" int sella_stepper_create_lr(sella_ctx* c, int kind, sella_mat hWt, in
         if (st != SELLA_OK) return bail(st);
         didx = reinterpret_cast<int*>(ib + 2 * (size_t)std::max(ld, round_up(m, 8)));
     }
-    st = h2d_async(c, didx, idx.data(), (size_t)m * sizeof(int));
+    st = h2d_async(c, didx, idx, (size_t)m * sizeof(int));
     if (st != SELLA_OK) return bail(st);
     Mat* Vt = mat_get(c, hVt);
     st = launch_gather_rows(c, src, ld, didx, m, n, Vt->d, Vt->ld);
@@ -917,9 +926,7 @@ extern "C" int sella_stepper_create_lr(sella_ctx* c, int kind, sella_mat hWt, in
     Vt = mat_get(c, hVt);
     st = launch_transpose(c, Vt->d, m, n, Vt->ld, V->d, V->ld);
     if (st != SELLA_OK) return bail(st);
-    std::vector<double> gh(m);
-    for (int p = 0; p < m; ++p) gh[p] = idx[p] < r ? aw[idx[p]] : (idx[p] == r ? gperp : 0.0);
-    st = stepper_make(c, kind, hV, hVt, ev.data(), nullptr, gh.data(), m, order, out);
+    st = stepper_make(c, kind, hV, hVt, ev, nullptr, gh, m, order, out);
     if (st != SELLA_OK) return bail(st);
     (*out)->ownV = hV;
     (*out)->ownVt = hVt;

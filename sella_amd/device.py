@@ -5,7 +5,7 @@ handles.  numpy in / numpy out, fp64, like the reference's accelerator seam
 import os
 import threading
 import weakref
-from ctypes import byref, c_char_p, c_double, c_int, c_long, c_void_p, create_string_buffer
+from ctypes import byref, c_char_p, c_double, c_int, c_long, c_void_p, create_string_buffer, pointer
 
 import numpy as np
 
@@ -446,6 +446,14 @@ class Context:
                                            idx.ctypes.data_as(c_void_p), m, Wts.handle, byref(rs), ptr(mus)))
         return dict(Wt=Wts, r=rs.value, mu=mus, lam0=float(lr['lam0']))
 
+    def lr_materialize(self, B, Wt, r, mu, lam0):
+        """`sella_lr_materialize`: B <- lam0 I + W^T diag(mu - lam0) W (dense mirror of a structured decomposition)."""
+        check(_lib.lib().sella_lr_materialize(self._h, B.handle, Wt.handle, int(r), ptr(mu), float(lam0)))
+
+    def opt_step(self, args):
+        """`sella_opt_step`: one optimizer step (learn + adapt + propose) in one call; `args` is an `OptStep` holder."""
+        check(_lib.lib().sella_opt_step(self._h, byref(args.c)))
+
     def symmetrize_y(self, S, Y, symm):
         S = as_f64(S)
         Y = as_f64(Y)
@@ -494,6 +502,49 @@ class Context:
         n, ms, b, f = c_long(0), c_double(0), c_double(0), c_double(0)
         check(_lib.lib().sella_prof_get(self._h, int(kind), byref(n), byref(ms), byref(b), byref(f)))
         return dict(launches=n.value, ms=ms.value, bytes=b.value, flops=f.value)
+
+
+class OptStep:
+    """Argument block of `sella_opt_step` (include/sella_hip.h) together with the arrays it points into — the block
+    holds raw addresses, so the arrays live here for as long as the block does."""
+    LEARN, PROPOSE = 1, 2
+
+    def __init__(self, n):
+        self.c = _lib.OptStepArgs()
+        self.c.n = int(n)
+        self.s = np.zeros(int(n))
+        self.c.s_out = self.s.ctypes.data
+        self._r, self._r_sub = c_int(0), c_int(0)
+        self._keep = {}
+
+    def point(self, field, array):
+        """Store the address of a float64 / int32 array in `field` and keep the array alive."""
+        self._keep[field] = array
+        setattr(self.c, field, None if array is None else array.ctypes.data)
+
+    def set_hessian(self, B, lr, method, symm, view=None, stale=False, stale_sub=False):
+        c = self.c
+        c.B, c.Wt, c.lam0 = B.handle, lr['Wt'].handle, float(lr['lam0'])
+        c.B_stale, c.Bsub_stale = int(bool(stale)), int(bool(stale_sub))
+        self._r.value = int(lr['r'])
+        c.r = pointer(self._r)
+        self.point('mu', lr['mu'])
+        c.update_method, c.symm = UPDATE_METHODS[method], -1 if symm is None else int(symm)
+        if view is None:
+            c.Bsub, c.Wt_sub, c.m = SELLA_NO_MAT, SELLA_NO_MAT, 0
+            c.r_sub = None
+            self.point('mu_sub', None)
+            self.point('idx', None)
+        else:
+            Bsub, idx, lrs = view
+            c.Bsub, c.Wt_sub, c.m = Bsub.handle, lrs['Wt'].handle, len(idx)
+            self._r_sub.value = int(lrs['r'])
+            c.r_sub = pointer(self._r_sub)
+            self.point('mu_sub', lrs['mu'])
+            self.point('idx', idx)
+
+    r = property(lambda self: self._r.value)
+    r_sub = property(lambda self: self._r_sub.value)
 
 
 STEPPER_KINDS = {'qn': 0, 'rfo': 1, 'prfo': 2, 'qn_irc': 3}

@@ -164,6 +164,7 @@ class ApproximateHessian(LinearOperator):
         self.initialized = initialized
         self._B = None             # numpy copy (None while stale)
         self._B_gpu = None         # DeviceMatrix (None while not uploaded)
+        self._B_stale = False      # the device matrix lags behind the structured decomposition (sella_opt_step)
         self._is_none = True
         self.version = 0           # bumped whenever B changes (cache key for projections)
         self._view = None          # (idx, basis, ApproximateHessian of B[idx][idx], version it is in step with)
@@ -197,6 +198,18 @@ class ApproximateHessian(LinearOperator):
         lr = self._lr
         r = lr['r']
         return np.sort(np.concatenate((lr['mu'][:r], np.full(self.dim - r, lr['lam0']))))
+
+    def lowest_evals(self, k):
+        """The k lowest eigenvalues (what the re-diagonalisation schedule of `Sella.step` looks at, optimize.py:363-378)
+        — from the structured form without expanding the (n - r)-fold eigenvalue; None for an unset Hessian."""
+        if self._is_none:
+            return None
+        if self._lr is not None and self._evals is None:
+            lr = self._lr
+            r = lr['r']
+            pool = np.concatenate((lr['mu'][:r], np.full(min(int(k), self.dim - r), lr['lam0'])))
+            return np.sort(pool)[:k]
+        return self.evals[:k]
 
     def _lr_reserve(self, extra):
         """Room for `extra` more explicit rows; False if the explicit rank would pass LR_MAX_FRACTION * dim (the caller
@@ -239,7 +252,7 @@ class ApproximateHessian(LinearOperator):
         if self._is_none:
             return None
         if self._B is None:
-            self._B = self._B_gpu.numpy()
+            self._B = self._get_B_gpu().numpy()
         return self._B
 
     @B.setter
@@ -252,11 +265,17 @@ class ApproximateHessian(LinearOperator):
             return None
         if self._B_gpu is None:
             self._B_gpu = get_context().upload(self._B)
+        if self._B_stale:
+            # the one-call optimizer step keeps (W, mu, lam0) only; the matrix is rebuilt for whoever asks for it
+            lr = self._lr
+            get_context().lr_materialize(self._B_gpu, lr['Wt'], lr['r'], lr['mu'], lr['lam0'])
+            self._B_stale = False
         return self._B_gpu
 
     def set_B(self, target):
         self.version += 1
         self._view = None
+        self._B_stale = False
         self._drop_eig()
         if self._B_gpu is not None:
             self._B_gpu.free()

@@ -181,9 +181,9 @@ class Sella(Optimizer):
             return True
         if not (self.eig and self.nsteps_since_diag >= self.nsteps_per_diag):
             return False
-        if self.pes.H.evals is None:
+        if self.pes.H._is_none:
             return True
-        lowest = self.pes.get_HL_projected(self.pes.get_Unred()).evals[:self.ord]
+        lowest = self.pes.get_HL_projected(self.pes.get_Unred()).lowest_evals(self.ord)
         return bool(np.any(lowest > 0))
 
     def _adapt_radius(self, rho, smag):
@@ -220,7 +220,128 @@ class Sella(Optimizer):
         self.rho = 1
         return True
 
+    # ---- the step as ONE library call (`sella_opt_step`, csrc/optstep.hip) ----------------------------------------
+    # Between two force calls the reference runs kick's model prediction and quasi-Newton update, the trust-radius
+    # rule and the next restricted step as a few hundred interpreter-level operations; for the common configuration —
+    # Cartesian PES, no constraints or constraints that pin single coordinates (all satisfied), approximate Hessian in
+    # structured form, built-in step family and measure — they are one call that hands back the next step.  Anything
+    # else (and every step that re-diagonalises) takes the general path below; both produce the same numbers
+    # (tests/test_fused_step.py).
+    use_fused_step = True
+
+    def _fused_block(self):
+        """The argument block of `sella_opt_step` for the current state, or None if this step needs the general path."""
+        from ..device import CONSTRAINT_KINDS, STEPPER_KINDS, UPDATE_METHODS, OptStep
+        from .restricted_step import RestrictedAtomicStep, TrustRegion
+        from .stepper import _all_steppers, get_stepper
+        pes = self.pes
+        if not self.use_fused_step or type(pes) is not PES or not self.initialized:
+            return None
+        if self.rs not in (TrustRegion, RestrictedAtomicStep):
+            return None
+        family = self.method if isinstance(self.method, type) else get_stepper(self.method.lower())
+        if family not in _all_steppers:
+            return None
+        H = pes.H
+        if H._is_none or H._lr is None or H.update_method not in UPDATE_METHODS:
+            return None
+        cons = pes.cons
+        if cons.has_inequalities() or pes._has_curved_constraints():
+            return None
+        drdx = pes.curr.get('drdx')
+        if drdx is None:
+            return None
+        view = None
+        if drdx.shape[0] > 0:
+            hit = getattr(pes, '_pinned_basis', None)
+            if pes._pinned() is None or hit is None or pes.curr.get('Ufree') is not hit[2] or np.any(pes.get_res()):
+                return None
+            v = H._view
+            if v is None or v[1] is not hit[2] or v[3] != H.version or v[2]._lr is None:
+                return None
+            if not v[2]._lr_reserve(4):                        # two new rows + the work rows of the coordinate update
+                return None
+            view = (self._mirror(v[2]), v[0], v[2]._lr)
+        if not H._lr_reserve(4):
+            return None
+        blk = getattr(self, '_opt_block', None)
+        if blk is None or blk.c.n != pes.dim:
+            blk = self._opt_block = OptStep(pes.dim)
+        blk.set_hessian(self._mirror(H), H._lr, H.update_method, H.symm, view, stale=H._B_stale,
+                        stale_sub=view is not None and H._view[2]._B_stale)
+        c = blk.c
+        c.stepper_kind, c.order, c.cons = STEPPER_KINDS[family._kind], int(self.ord), CONSTRAINT_KINDS[self.rs.measure]
+        c.tol, c.maxiter = (1e-10 if family.newton_safe else 1e-15), 1000
+        c.delta_min, c.sigma_inc, c.sigma_dec = self.delta_min, self.sigma_inc, self.sigma_dec
+        c.rho_inc, c.rho_dec = self.rho_inc, self.rho_dec
+        return blk
+
+    @staticmethod
+    def _mirror(H):
+        """The device matrix of H as it is — possibly lagging behind the decomposition (`_B_stale`): the library call
+        rebuilds it itself if its general route needs it."""
+        if H._B_gpu is None:
+            return H._get_B_gpu()
+        return H._B_gpu
+
+    def _step_fused(self, blk):
+        from ..device import get_context
+        pes = self.pes
+        ahead = self.__dict__.pop('_proposed', None)
+        if (ahead is not None and ahead[0] == pes.curr.get('state_hash') and ahead[1] == self.delta
+                and ahead[2] == pes.H.version):
+            s, smag = ahead[3], ahead[4]
+            pes.save()
+        else:
+            s, smag = self._predict_step()
+        rediag = self._wants_diagonalisation()
+        self.nsteps_since_diag = 0 if rediag else self.nsteps_since_diag + 1
+        # PES.kick: the move and the force call stay here (calculator boundary) ...
+        origin, f_old, g_old = pes.get_x(), pes.get_f(), pes.get_g()
+        dx = pes.set_x(origin + s)[0]
+        g_new, f_new = pes.get_g(), pes.get_f()
+        # ... everything after it is the library's
+        c = blk.c
+        c.flags = blk.LEARN | (0 if rediag else blk.PROPOSE)
+        blk.point('dx', np.ascontiguousarray(dx, dtype=np.float64))
+        blk.point('g_old', g_old)
+        blk.point('g_new', g_new)
+        c.f_old, c.f_new, c.smag = float(f_old), float(f_new), float(smag)
+        c.delta, c.rho = float(self.delta), float(self.rho)
+        get_context().opt_step(blk)
+        H = pes.H
+        H._B_stale = bool(c.B_stale)
+        if c.m > 0:
+            H._view[2]._B_stale = bool(c.Bsub_stale)
+        if c.updated:
+            H._lr['r'] = blk.r
+            v = H._view
+            if c.m > 0:
+                sub = v[2]
+                sub._lr['r'] = blk.r_sub
+                sub._B = None
+                sub.version += 1
+                sub._drop_dense_eig()
+                H._view = (v[0], v[1], sub, H.version + 1)
+            else:
+                H._view = None
+            H._B = None
+            H.version += 1
+            H._drop_dense_eig()
+        self.delta, self.rho = c.delta, c.rho
+        if rediag:
+            if pes.hessian_function is not None:
+                pes.calculate_hessian()
+            else:
+                pes.diag(**self.diagkwargs)
+        else:
+            self._proposed = (pes.curr.get('state_hash'), self.delta, pes.H.version, blk.s.copy(), c.smag_out)
+
     def step(self):
+        blk = self._fused_block()
+        if blk is not None:
+            return self._step_fused(blk)
+        self.__dict__.pop('_proposed', None)
         s, smag = self._predict_step()
         rediag = self._wants_diagonalisation()
         self.nsteps_since_diag = 0 if rediag else self.nsteps_since_diag + 1

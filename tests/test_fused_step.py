@@ -1,0 +1,110 @@
+"""`Sella.step` as one library call (`sella_opt_step`, csrc/optstep.hip: model prediction + quasi-Newton update with the
+structured eigendecomposition + trust-radius rule + next restricted step) against the general path, which performs the
+same operations one library call at a time (sella/optimize/optimize.py:359-440, peswrapper.py:578-602): the same
+trajectories, radii, ratios, force-call counts and Hessians."""
+import numpy as np
+import pytest
+
+from conftest import hessian_like
+
+
+@pytest.fixture(autouse=True)
+def structured_from_96():
+    from sella_amd import linalg
+    old = linalg.LR_MIN_DIM
+    linalg.LR_MIN_DIM = 96
+    yield
+    linalg.LR_MIN_DIM = old
+
+
+def _model_search(fused, rs, method, order, nsteps=10, n=120):
+    from sella_amd import Sella
+    from sella_amd.atoms import Atoms, QuadraticCubicModel
+    from sella_amd.internal import Constraints
+    A = hessian_like(n, 41)[0]
+    rng = np.random.RandomState(42)
+    Uc = rng.normal(size=(8, n))
+    Uc /= np.linalg.norm(Uc, axis=1)[:, None]
+    at = Atoms(['X'] * (n // 3), 0.05 * rng.normal(size=(n // 3, 3)), pbc=True)
+    at.calc = QuadraticCubicModel(lambda x: A @ x, Uc, c=0.05)
+    opt = Sella(at, order=order, eta=1e-4, gamma=0.1, delta0=0.1, rs=rs, method=method, logfile=None,
+                constraints=Constraints(at), proj_trans=False)
+    opt.use_fused_step = fused
+    return opt
+
+
+def _run(opt, nsteps):
+    rows, calls = [], 0
+    real = type(opt)._step_fused
+
+    def counting(self, blk):
+        nonlocal calls
+        calls += 1
+        return real(self, blk)
+    type(opt)._step_fused = counting
+    try:
+        for _ in range(nsteps):
+            opt.step()
+            rows.append((opt.pes.get_x().copy(), opt.pes.get_f(), opt.delta, opt.rho, opt.nsteps_since_diag))
+    finally:
+        type(opt)._step_fused = real
+    return rows, calls
+
+
+def _same_row(ra, rb, i):
+    """Same search: the one-call step updates the eigendecomposition in coordinates (csrc/lrstep.hip) where the general
+    path runs host-planned rank-one merges on the eigenvector panel — two evaluations of the same matrices, equal to
+    roundoff at each step, the difference then growing with the search like between any two runs whose arithmetic
+    differs in the last bit (tests/test_pes_oracle.py uses the same schedule of tolerances)."""
+    tol = 1e-11 * 4 ** min(i, 10)
+    np.testing.assert_allclose(ra[0], rb[0], atol=tol, rtol=0, err_msg=f'step {i}')
+    assert ra[1] == pytest.approx(rb[1], abs=tol), i
+    assert ra[2] == pytest.approx(rb[2], rel=1e-9, abs=tol), i
+    assert ra[3] == pytest.approx(rb[3], rel=1e-6, abs=1e-6), i
+    assert ra[4] == rb[4], i
+
+
+@pytest.mark.parametrize('rs,method,order', [('tr', 'prfo', 1), ('ras', 'prfo', 1), ('tr', 'rfo', 0), ('ras', 'qn', 0)])
+def test_fused_step_equals_the_general_path(ctx, rs, method, order):
+    a, na = _run(_model_search(True, rs, method, order), 10)
+    b, nb = _run(_model_search(False, rs, method, order), 10)
+    assert na >= 8 and nb == 0                      # the first step initialises; the rest are single calls
+    for i, (ra, rb) in enumerate(zip(a, b)):
+        _same_row(ra, rb, i)
+
+
+def test_fused_step_with_pinned_coordinates(ctx):
+    """BASELINE configs[1] on a down-sized twin (Cu(111) 4 x 4 x 4 EMT slab, lower half pinned atom by atom): pins -> selection bases and the
+    principal-submatrix view, default `Sella` (`ras`, P-RFO)."""
+    from conftest_shim import emt_slab
+    from sella_amd import Sella
+    out = {}
+    for fused in (True, False):
+        atoms, cons, pinned = emt_slab((4, 4, 4))        # (3, 3, 4) leaves the view too small for the structured form
+        opt = Sella(atoms, constraints=cons, logfile=None)
+        opt.use_fused_step = fused
+        rows, calls = _run(opt, 6)
+        out[fused] = (rows, calls, opt.pes.neval, opt.pes.H.B.copy(), atoms.positions[pinned].copy())
+    assert out[True][1] >= 4 and out[False][1] == 0
+    assert out[True][2] == out[False][2]
+    for i, (ra, rb) in enumerate(zip(out[True][0], out[False][0])):
+        _same_row(ra, rb, i)
+    np.testing.assert_allclose(out[True][3], out[False][3], atol=1e-9)
+    np.testing.assert_array_equal(out[True][4], out[False][4])
+
+
+def test_fused_step_steps_aside(ctx):
+    """Configurations the one-call step does not cover take the general path: dense eigendecomposition (structured form
+    off), a rotation constraint (general projection basis), a user-defined restricted step."""
+    from sella_amd import linalg
+    from sella_amd.optimize.restricted_step import TrustRegion
+    linalg.LR_MIN_DIM = None
+    rows, calls = _run(_model_search(True, 'tr', 'prfo', 1), 4)
+    assert calls == 0
+    linalg.LR_MIN_DIM = 96
+
+    class MyRegion(TrustRegion):
+        pass
+    opt = _model_search(True, 'tr', 'prfo', 1)
+    opt.rs = MyRegion
+    assert _run(opt, 3)[1] == 0

@@ -61,7 +61,9 @@ int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
  *   panel_small (2048) panel products with <= 64 rows and <= 16 right-hand sides take the split-K kernels from this
  *   many columns on | bd_dev_rr (0) Rayleigh-Ritz eigenproblem of sella_davidson_block on the device (one-workgroup
  *   Jacobi kernel) instead of the host | lr_dev (1) sella_opt_step updates structured eigendecompositions in
- *   coordinates with every decision on the device (0: the host-planned rank-one merges of sella_update_h_lr).     */
+ *   coordinates with every decision on the device (0: the host-planned rank-one merges of sella_update_h_lr) |
+ *   rs_fast (1) sella_opt_step finds the restricted step by interpolating batches of 15 trial alphas instead of the
+ *   reference's Newton / bisection schedule (same root).                                                         */
 int sella_ctx_set_option(sella_ctx* ctx, const char* key, long value);
 
 /* ---- device matrices --------------------------------------------------------------- */

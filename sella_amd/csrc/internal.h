@@ -94,6 +94,7 @@ struct Options {
     long panel_mfma = 1;     // 1: products with more than 8 right-hand sides stream the matrix once (MFMA panel kernel)
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
+    long rs_fast = 1;        // 1: sella_opt_step searches the restricted step by interpolating batches (stepper.hip)
     long lr_dev = 1;         // 1: sella_opt_step updates structured decompositions in coordinates, all decisions on the device (lrstep.hip)
     long rank2k_stream = 1;  // 1: trailing update of the tridiagonalisation as a mirror-free MFMA stream (update.hip)
     long panel_small = 2048; // panel products with <= 64 rows and at least this many columns split the long index over the
@@ -280,6 +281,8 @@ int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, M
 // stepper.hip: step family on m modes = rows idx[0..m) of a device panel (gathered into matrices the stepper owns)
 int stepper_from_panel(sella_ctx* c, int kind, const double* src, int ld, const int* idx, int m, int n, const double* ev,
                        const double* gh, int order, sella_stepper** out);
+// the interpolating batched root search of sella_restricted_step instead of the reference's alpha schedule (sella_opt_step)
+void stepper_set_fast_search(sella_stepper* st, bool on);
 // lrstep.hip: the learn / adapt / propose step on structured decompositions with every decision on the device
 int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled);
 // batched NN GEMM for the merges of one divide-and-conquer level: batch b multiplies the diagonal blocks

@@ -24,6 +24,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -48,7 +50,7 @@ __device__ __forceinline__ double blk_max(double v, double* red) {
 }
 
 // scalar slots of the workspace (doubles)
-enum { SC_M1 = 0, SC_M2, SC_JS, SC_SBS, SC_SIG1, SC_SIG2, SC_CAREFUL, SC_KEEP1, SC_KEEP2, SC_GPERP2 = 16, SC_N = 32 };
+enum { SC_M1 = 0, SC_M2, SC_JS, SC_SBS, SC_SIG1, SC_SIG2, SC_CAREFUL, SC_KEEP1, SC_KEEP2, SC_FAIL, SC_GPERP2 = 16, SC_N = 32 };
 // gram slots: host / device Gram of the input rows and of the residual rows
 enum { G_SS = 0, G_SY, G_YY, G_A11 = 8, G_A12, G_A22 = 11 };
 
@@ -73,11 +75,14 @@ __global__ __launch_bounds__(256) void lr_pre_kernel(PreArgs a) {
     const double r11 = keep1 ? sqrt(a11) : 0.0;
     const double y1 = keep1 ? a12 / r11 : 0.0;
     const double rho2sq = a22 - y1 * y1;
-    const bool keep2 = yy > 0.0 && rho2sq > 1e-26 * yy;
+    // The second direction comes out of a cancellation, resolved to ~1e-15 a22 by the two sweeps behind the Gram
+    // matrix: a remainder below 1e-13 a22 is noise (the two residuals are parallel — the usual case in a view, where
+    // both update vectors leave span(W) along one direction) and the row stays zero; from 1e-11 a22 on the normalised
+    // remainder is orthogonal to W and e1 to better than 1e-10.  In between the caller takes the Gram-Schmidt path of
+    // eigh.hip.
+    const bool keep2 = yy > 0.0 && rho2sq > 1e-26 * yy && rho2sq > 1e-13 * a22;
     const double r22 = keep2 ? sqrt(rho2sq) : 0.0;
-    // the second direction comes out of a cancellation: below 1e-8 of |y_perp|^2 its orthogonality to e1 is no longer
-    // at roundoff and the caller takes the Gram-Schmidt path of eigh.hip instead
-    const bool careful = keep2 && rho2sq < 1e-8 * a22;
+    const bool careful = keep2 && rho2sq < 1e-11 * a22;
     if (tid == 0) {
         a.ec[0] = keep1 ? 1.0 / r11 : 0.0;                                  // W1[j * 2 + c]: residual row j -> new row c
         a.ec[1] = (keep1 && keep2) ? -(a12 / a11) / r22 : 0.0;
@@ -86,6 +91,9 @@ __global__ __launch_bounds__(256) void lr_pre_kernel(PreArgs a) {
         a.sc[SC_CAREFUL] = careful ? 1.0 : 0.0;
         a.sc[SC_KEEP1] = keep1 ? 1.0 : 0.0;
         a.sc[SC_KEEP2] = keep2 ? 1.0 : 0.0;
+        a.sc[SC_FAIL] = 0.0;
+        a.sc[SC_GPERP2] = 0.0;
+        a.sc[20] = ss; a.sc[21] = sy; a.sc[22] = yy; a.sc[23] = a11; a.sc[24] = a12; a.sc[25] = a22;
     }
     auto Dof = [&](int i) { return i < r ? a.mu[i] : a.lam0; };
     auto s_of = [&](int i) { return i < r ? -(a.C[i] + a.C2[i]) : (i == r ? r11 : 0.0); };      // (C, C2: negated W x)
@@ -173,25 +181,38 @@ struct PlanArgs {
 
 // One workgroup: weights of the term in the current eigenbasis, ascending order of the (signed) poles, deflation by
 // LAPACK dlaed2's rules (a negligible weight; of two nearly equal poles one rotated out), the rotations applied to the
-// columns of Q, the compact secular problem.  A negative sigma is solved as -(-D + |sigma| z z^T).
+// columns of Q, the compact secular problem.  A negative sigma is solved as -(-D + |sigma| z z^T).  The sequential part
+// (one thread walks the poles in order) works on LDS copies: a chain of dependent global loads costs ~0.5 us a link.
 __global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
     __shared__ double red[4];
-    __shared__ int sK, sRot;
+    __shared__ double sD[LR_DEV_MAX], sZ[LR_DEV_MAX], sP[LR_DEV_MAX], sCS[2 * LR_DEV_MAX];
+    __shared__ int sPerm[LR_DEV_MAX], sNd[LR_DEV_MAX], sDf[LR_DEV_MAX], sI1[LR_DEV_MAX], sI2[LR_DEV_MAX];
+    __shared__ int sK, sRot, sNdf;
     const int tid = threadIdx.x, nr = a.nr;
     const double sigma = a.sigma[0];
+    for (int i = tid; i < nr; i += 256) sP[i] = a.p[i];
+    __syncthreads();
     double pz = 0.0;
     for (int i = tid; i < nr; i += 256) {
         double zi;
         if (a.first) {
-            zi = a.p[i];
+            zi = sP[i];
         } else {
-            zi = 0.0;
-            for (int k = 0; k < nr; ++k) zi += a.Q[(size_t)k * a.ldq + i] * a.p[k];
+            double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+            int k = 0;
+            for (; k + 3 < nr; k += 4) {
+                z0 += a.Q[(size_t)k * a.ldq + i] * sP[k];
+                z1 += a.Q[(size_t)(k + 1) * a.ldq + i] * sP[k + 1];
+                z2 += a.Q[(size_t)(k + 2) * a.ldq + i] * sP[k + 2];
+                z3 += a.Q[(size_t)(k + 3) * a.ldq + i] * sP[k + 3];
+            }
+            for (; k < nr; ++k) z0 += a.Q[(size_t)k * a.ldq + i] * sP[k];
+            zi = (z0 + z1) + (z2 + z3);
         }
-        a.z[i] = zi;
+        sZ[i] = zi;
         pz += zi * zi;
     }
     const double zn2 = blk_sum(pz, red);
@@ -200,9 +221,9 @@ __global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) {
     const double zn = idle ? 1.0 : sqrt(zn2);
     double dmax = 0.0, zmax = 0.0;
     for (int i = tid; i < nr; i += 256) {
-        const double d = sgn * a.Dcur[i], w = a.z[i] / zn;
-        a.Dp[i] = d;
-        a.zz[i] = w;
+        const double d = sgn * a.Dcur[i], w = sZ[i] / zn;
+        sD[i] = d;
+        sZ[i] = w;
         dmax = fmax(dmax, fabs(d));
         zmax = fmax(zmax, fabs(w));
     }
@@ -211,13 +232,13 @@ __global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) {
     __syncthreads();
     // stable ascending order of the poles: perm[rank] = index
     for (int i = tid; i < nr; i += 256) {
-        const double di = a.Dp[i];
+        const double di = sD[i];
         int rank = 0;
         for (int j = 0; j < nr; ++j) {
-            const double dj = a.Dp[j];
+            const double dj = sD[j];
             rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
         }
-        a.perm[rank] = i;
+        sPerm[rank] = i;
     }
     __syncthreads();
     const double rho = fabs(sigma) * zn2;
@@ -226,51 +247,52 @@ __global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) {
         const double tol = 8.0 * eps * fmax(dmax, zmax);
         int K = 0, nd = 0, nrot = 0;
         if (idle || rho * zmax <= tol) {
-            for (int jj = 0; jj < nr; ++jj) a.df[nd++] = a.perm[jj];
+            for (int jj = 0; jj < nr; ++jj) sDf[nd++] = sPerm[jj];
         } else {
             int pj = -1;
             for (int jj = 0; jj < nr; ++jj) {
-                const int nj = a.perm[jj];
-                if (rho * fabs(a.zz[nj]) <= tol) { a.df[nd++] = nj; continue; }
+                const int nj = sPerm[jj];
+                if (rho * fabs(sZ[nj]) <= tol) { sDf[nd++] = nj; continue; }
                 if (pj < 0) { pj = nj; continue; }
-                double s = a.zz[pj], cc = a.zz[nj];
+                double s = sZ[pj], cc = sZ[nj];
                 const double tau = hypot(cc, s);
-                const double t = a.Dp[nj] - a.Dp[pj];
+                const double t = sD[nj] - sD[pj];
                 cc /= tau;
                 s = -s / tau;
                 if (fabs(t * cc * s) <= tol) {
-                    a.zz[nj] = tau;
-                    a.zz[pj] = 0.0;
-                    a.i1[nrot] = pj;
-                    a.i2[nrot] = nj;
-                    a.cs[2 * nrot] = cc;
-                    a.cs[2 * nrot + 1] = s;
+                    sZ[nj] = tau;
+                    sZ[pj] = 0.0;
+                    sI1[nrot] = pj;
+                    sI2[nrot] = nj;
+                    sCS[2 * nrot] = cc;
+                    sCS[2 * nrot + 1] = s;
                     ++nrot;
-                    const double tt = a.Dp[pj] * cc * cc + a.Dp[nj] * s * s;
-                    a.Dp[nj] = a.Dp[pj] * s * s + a.Dp[nj] * cc * cc;
-                    a.Dp[pj] = tt;
-                    a.df[nd++] = pj;
+                    const double tt = sD[pj] * cc * cc + sD[nj] * s * s;
+                    sD[nj] = sD[pj] * s * s + sD[nj] * cc * cc;
+                    sD[pj] = tt;
+                    sDf[nd++] = pj;
                     pj = nj;
                 } else {
-                    a.nd[K++] = pj;
+                    sNd[K++] = pj;
                     pj = nj;
                 }
             }
-            if (pj >= 0) a.nd[K++] = pj;
+            if (pj >= 0) sNd[K++] = pj;
         }
         sK = K;
         sRot = nrot;
+        sNdf = nd;
         a.cnt[0] = K;
         a.cnt[1] = nrot;
         a.pl[0] = rho;
         a.pl[1] = sgn;
     }
     __syncthreads();
-    const int K = sK, nrot = sRot;
+    const int K = sK, nrot = sRot, ndf = sNdf;
     // rotations on column pairs of Q (x' = c x + s y, y' = c y - s x: the row rotations of eigh.hip, transposed)
     for (int q = 0; q < nrot; ++q) {
-        const int c1 = a.i1[q], c2 = a.i2[q];
-        const double cc = a.cs[2 * q], s = a.cs[2 * q + 1];
+        const int c1 = sI1[q], c2 = sI2[q];
+        const double cc = sCS[2 * q], s = sCS[2 * q + 1];
         for (int k = tid; k < nr; k += 256) {
             double* row = a.Q + (size_t)k * a.ldq;
             const double x = row[c1], y = row[c2];
@@ -279,10 +301,13 @@ __global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) {
         }
         __syncthreads();
     }
+    for (int i = tid; i < nr; i += 256) a.Dp[i] = sD[i];
     for (int p = tid; p < K; p += 256) {
-        a.Dd[p] = a.Dp[a.nd[p]];
-        a.wd[p] = a.zz[a.nd[p]];
+        a.nd[p] = sNd[p];
+        a.Dd[p] = sD[sNd[p]];
+        a.wd[p] = sZ[sNd[p]];
     }
+    for (int p = tid; p < ndf; p += 256) a.df[p] = sDf[p];
 }
 
 struct WaveSum2 {
@@ -300,7 +325,7 @@ struct WaveProd2 {
 __global__ __launch_bounds__(256) void lr_secular_kernel(const int* __restrict__ cnt, const double* __restrict__ pl,
                                                          const double* __restrict__ D, const double* __restrict__ w,
                                                          double* __restrict__ tau, int* __restrict__ org,
-                                                         double* __restrict__ lam) {
+                                                         double* __restrict__ lam, double* __restrict__ fail) {
     const int K = cnt[0];
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -312,7 +337,7 @@ __global__ __launch_bounds__(256) void lr_secular_kernel(const int* __restrict__
         tau[j] = t;
         org[j] = o;
         lam[j] = D[o] + t;
-        if (it < 0) const_cast<int*>(cnt)[2] = j + 1;
+        if (it < 0) fail[0] = j + 1.0;
     }
 }
 
@@ -373,6 +398,33 @@ __global__ __launch_bounds__(256) void lr_apply_kernel(ApplyArgs a) {
     }
 }
 
+// R_h -= sum_j C[h * ldc + j] W_j for both residual rows in ONE pass over W (C holds the negated coefficients: added)
+__global__ __launch_bounds__(256) void lr_proj2_kernel(const double* __restrict__ W, int ldw, int r, int n,
+                                                       const double* __restrict__ C, int ldc, double* __restrict__ R,
+                                                       int ldr_) {
+    __shared__ double c0[LR_DEV_MAX], c1[LR_DEV_MAX];
+    for (int j = threadIdx.x; j < r; j += 256) { c0[j] = C[j]; c1[j] = C[ldc + j]; }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    int j = 0;
+    for (; j + 1 < r; j += 2) {
+        const double w0 = W[(size_t)j * ldw + i], w1 = W[(size_t)(j + 1) * ldw + i];
+        a0 += c0[j] * w0;
+        b0 += c0[j + 1] * w1;
+        a1 += c1[j] * w0;
+        b1 += c1[j + 1] * w1;
+    }
+    if (j < r) {
+        const double w0 = W[(size_t)j * ldw + i];
+        a0 += c0[j] * w0;
+        a1 += c1[j] * w0;
+    }
+    R[i] += a0 + b0;
+    R[ldr_ + i] += a1 + b1;
+}
+
 __global__ __launch_bounds__(256) void lr_identity_kernel(double* __restrict__ Q, int nr, int ldq) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < nr * ldq) Q[i] = ((i / ldq) == (i % ldq)) ? 1.0 : 0.0;
@@ -406,11 +458,12 @@ static int lr_work(sella_ctx* c, int slot, int nr, LrWork& w) {
     SCHK(scratch_get(c, slot, (ndbl + nint / 2 + 8) * sizeof(double), &base));
     double* p = base;
     auto take = [&](size_t k) { double* q = p; p += k; return q; };
-    w.C = take(3 * ldr); w.C2 = take(2 * ldr); w.G = take(16); w.sc = take(SC_N); w.ec = take(8);
+    w.C = take(3 * ldr); w.C2 = take(2 * ldr); w.G = take(16); w.ec = take(8);
+    w.sc = take(SC_N); w.D0 = take(ldr); w.ghat = take(ldr);           // read back as ONE block: sc | D0 | ghat
     w.UZ = take(2 * ldr); w.P = take(2 * ldr);
-    w.D0 = take(ldr); w.D1 = take(ldr); w.z = take(ldr); w.Dp = take(ldr); w.zz = take(ldr); w.Dd = take(ldr);
+    w.D1 = take(ldr); w.z = take(ldr); w.Dp = take(ldr); w.zz = take(ldr); w.Dd = take(ldr);
     w.wd = take(ldr); w.tau = take(ldr); w.zh = take(ldr); w.lam = take(ldr); w.cs = take(2 * ldr); w.mu = take(ldr);
-    w.ghat = take(ldr); w.pl = take(8);
+    w.pl = take(8);
     w.Qa = take(ldr * ldr); w.Qb = take(ldr * ldr);
     int* ip = reinterpret_cast<int*>(p);
     w.perm = ip; w.nd = ip + ldr; w.df = ip + 2 * ldr; w.i1 = ip + 3 * ldr; w.i2 = ip + 4 * ldr; w.org = ip + 5 * ldr;
@@ -438,8 +491,8 @@ struct LrJob {
     LrWork w;
     double* Wnew;
     int ldw;
-    std::vector<double> hD, hghat, hsc;
-    int hcnt[4];
+    std::vector<double> hout;          // sc | D | ghat as read back in one transfer
+    const double *hD, *hghat, *hsc;
 };
 
 static int lr_job_queue(sella_ctx* c, LrJob& j) {
@@ -456,8 +509,6 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
     j.ldw = ld;
     double* W = Wm->d;
     // small uploads: mu and the Gram of the input rows
-    HIPCHK(hipMemsetAsync(w.C, 0, (size_t)(5 * w.ldr + 16 + SC_N) * sizeof(double), c->stream));
-    HIPCHK(hipMemsetAsync(w.cnt, 0, 8 * sizeof(int), c->stream));
     if (r > 0) SCHK(h2d_async(c, w.mu, j.mu, (size_t)r * sizeof(double)));
     if (j.gram) {
         SCHK(h2d_async(c, w.G, j.gram, 3 * sizeof(double)));
@@ -473,13 +524,10 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
         GemvEpi neg;                                  // C, C2 hold the NEGATED coefficients: lincomb adds them
         neg.alpha = -1.0;
         SCHK(launch_gemv_rows(c, W, r, n, ld, R, ld, 2, w.C, w.ldr, neg));
-        for (int h = 0; h < 2; ++h)
-            SCHK(launch_lincomb(c, n, 1, W, ld, r, w.C + (size_t)h * w.ldr, 1, nullptr, 0, 0, nullptr, 0, 1.0,
-                                R + (size_t)h * ld, ld));
+        hipLaunchKernelGGL(lr_proj2_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, W, ld, r, n, w.C, w.ldr, R, ld);
         SCHK(launch_gemv_rows(c, W, r, n, ld, R, ld, 2, w.C2, w.ldr, neg));
-        for (int h = 0; h < 2; ++h)
-            SCHK(launch_lincomb(c, n, 1, W, ld, r, w.C2 + (size_t)h * w.ldr, 1, nullptr, 0, 0, nullptr, 0, 1.0,
-                                R + (size_t)h * ld, ld));
+        hipLaunchKernelGGL(lr_proj2_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, W, ld, r, n, w.C2, w.ldr, R, ld);
+        HIPCHK(hipGetLastError());
     }
     // Gram of the residual rows: G[8 + h * 2 + i] = R_i . R_h -> a11 = G[8], a12 = G[9] (= G[10]), a22 = G[11]
     SCHK(launch_gemv_rows(c, R, 2, n, ld, R, ld, 2, w.G + G_A11, 2, GemvEpi()));
@@ -502,7 +550,7 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
         pl.perm = w.perm; pl.nd = w.nd; pl.df = w.df; pl.i1 = w.i1; pl.i2 = w.i2; pl.cnt = w.cnt;
         hipLaunchKernelGGL(lr_plan_kernel, dim3(1), dim3(256), 0, c->stream, pl);
         hipLaunchKernelGGL(lr_secular_kernel, dim3((nr + 3) / 4), dim3(256), 0, c->stream, w.cnt, w.pl, w.Dd, w.wd, w.tau,
-                           w.org, w.lam);
+                           w.org, w.lam, w.sc + SC_FAIL);
         hipLaunchKernelGGL(lr_zhat_kernel, dim3((nr + 3) / 4), dim3(256), 0, c->stream, w.cnt, w.Dd, w.wd, w.tau, w.org,
                            w.zh);
         ApplyArgs ap;
@@ -517,8 +565,7 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
     // W+ = Q^T E on the matrix cores
     SCHK(launch_gemm(c, 1, 0, nr, n, nr, 1.0, Qin, w.ldq, W, ld, 0.0, j.Wnew, ld));
     HIPCHK(hipMemsetAsync(j.Wnew + (size_t)nr * ld, 0, (size_t)2 * ld * sizeof(double), c->stream));
-    j.hD.assign(nr, 0.0);
-    j.hsc.assign(SC_N, 0.0);
+    j.hout.assign((size_t)SC_N + 2 * w.ldr, 0.0);
     if (j.want_modes) {
         const double* g = j.Xd + 2 * (size_t)j.ldx;
         GemvEpi e;
@@ -528,12 +575,12 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
         SCHK(launch_axpby2d(c, 1, n, 1.0, g, j.ldx, 0.0, nullptr, 0, gp, ld));
         SCHK(launch_lincomb(c, n, 1, j.Wnew, ld, nr, w.ghat, 1, nullptr, 0, 0, nullptr, 0, 1.0, gp, ld));
         SCHK(launch_rows_sumsq(c, gp, ld, 1, n, w.sc + SC_GPERP2));
-        j.hghat.assign(nr, 0.0);
-        SCHK(d2h_async(c, j.hghat.data(), w.ghat, (size_t)nr * sizeof(double)));
     }
-    SCHK(d2h_async(c, j.hD.data(), Din, (size_t)nr * sizeof(double)));
-    SCHK(d2h_async(c, j.hsc.data(), w.sc, SC_N * sizeof(double)));
-    SCHK(d2h_async(c, j.hcnt, w.cnt, 4 * sizeof(int)));
+    if (Din != w.D0) { set_error("structured update: eigenvalue buffers out of step"); return SELLA_E_INVALID; }
+    SCHK(d2h_async(c, j.hout.data(), w.sc, j.hout.size() * sizeof(double)));
+    j.hsc = j.hout.data();
+    j.hD = j.hout.data() + SC_N;
+    j.hghat = j.hD + w.ldr;
     return SELLA_OK;
 }
 
@@ -625,11 +672,19 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled) {
     }
     SCHK(stream_wait(c));
     auto sound = [](const LrJob& j) {
-        if (j.hsc[SC_CAREFUL] != 0.0 || j.hcnt[2] != 0) return false;
-        for (double v : j.hD) if (!(v == v)) return false;
+        if (j.hsc[SC_CAREFUL] != 0.0 || j.hsc[SC_FAIL] != 0.0) return false;
+        for (int i = 0; i < j.r + 2; ++i) if (!(j.hD[i] == j.hD[i])) return false;
         return true;
     };
-    if (!sound(F) || (view && !sound(S))) return SELLA_OK;              // nothing committed
+    if (!sound(F) || (view && !sound(S))) {                            // nothing committed
+        if (getenv("SELLA_DEBUG_TIMING"))
+            fprintf(stderr, "opt_step: coordinate update set aside (full: careful %g fail %g keep %g %g; view: careful %g fail %g keep %g %g)\n",
+                    F.hsc[SC_CAREFUL], F.hsc[SC_FAIL], F.hsc[SC_KEEP1], F.hsc[SC_KEEP2], view ? S.hsc[SC_CAREFUL] : 0.0,
+                    view ? S.hsc[SC_FAIL] : 0.0, view ? S.hsc[SC_KEEP1] : 0.0, view ? S.hsc[SC_KEEP2] : 0.0);
+        if (getenv("SELLA_DEBUG_TIMING") && view)
+            fprintf(stderr, "   view rows: uu %g uz %g zz %g | residual Gram %g %g %g\n", S.hsc[20], S.hsc[21], S.hsc[22], S.hsc[23], S.hsc[24], S.hsc[25]);
+        return SELLA_OK;
+    }
     *handled = true;
     std::vector<int> keptF, keptS;
     SCHK(lr_job_commit(c, F, a->r, a->mu, keptF));
@@ -686,6 +741,7 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled) {
     }
     sella_stepper* st = nullptr;
     SCHK(stepper_from_panel(c, a->stepper_kind, J.Wnew, J.ldw, idx.data(), mm, nd, ev.data(), gh.data(), a->order, &st));
+    stepper_set_fast_search(st, c->opt.rs_fast != 0);
     const bool qn = a->stepper_kind == SELLA_STEP_QN;
     const double alpha0 = qn ? 0.0 : 1.0, alphamax = qn ? std::numeric_limits<double>::infinity() : 1.0;
     const int rc = sella_restricted_step(st, a->cons, a->delta, nullptr, nullptr, nullptr, alpha0, 0.0, alphamax,

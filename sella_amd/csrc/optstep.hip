@@ -113,11 +113,13 @@ extern "C" int sella_opt_step(sella_ctx* c, sella_opt_step_t* a) {
             for (int j = 0; j < a->m; ++j) gs[j] = a->g_new[a->idx[j]];
             SCHK(sella_stepper_create_lr(c, a->stepper_kind, a->Wt_sub, *a->r_sub, a->mu_sub, a->lam0, gs.data(), a->m,
                                          a->order, &st));
+            stepper_set_fast_search(st, c->opt.rs_fast != 0);
             rc = sella_restricted_step(st, a->cons, a->delta, nullptr, nullptr, nullptr, fam.alpha0, fam.alphamin,
                                        fam.alphamax, fam.slope, fam.newton_safe, 1, a->tol, a->maxiter, a->idx, n,
                                        a->s_out, &a->smag_out, nullptr, &a->nalpha);
         } else {
             SCHK(sella_stepper_create_lr(c, a->stepper_kind, a->Wt, *a->r, a->mu, a->lam0, a->g_new, n, a->order, &st));
+            stepper_set_fast_search(st, c->opt.rs_fast != 0);
             rc = sella_restricted_step(st, a->cons, a->delta, nullptr, nullptr, nullptr, fam.alpha0, fam.alphamin,
                                        fam.alphamax, fam.slope, fam.newton_safe, 1, a->tol, a->maxiter, nullptr, 0,
                                        a->s_out, &a->smag_out, nullptr, &a->nalpha);

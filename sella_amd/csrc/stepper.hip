@@ -28,6 +28,7 @@ struct sella_stepper {
     sella_mat Vt = SELLA_NO_MAT;     // rows = eigenvectors [not owned]; needed for V^T scons in the root finder
     double t_host = 0.0, t_dev = 0.0;     // SELLA_DEBUG_TIMING: seconds in the secular solves / in the device round trip
     long calls = 0, sweeps = 0;
+    bool fast_search = false;             // sella_opt_step: interpolating batched search instead of the reference's alpha schedule
 };
 
 namespace sella {
@@ -691,11 +692,12 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         batch_ready = true;
         return SELLA_OK;
     };
-    auto batch_evaluate = [&](double lower, double upper) -> int {
+    // given: cand[1 .. BATCH_NODES] are set by the caller; otherwise the tree of midpoints of (lower, upper)
+    auto batch_evaluate = [&](double lower, double upper, bool given = false) -> int {
         if (!batch_ready) SCHK(batch_setup());
         double lo[BATCH_NODES + 1], hi[BATCH_NODES + 1];
         lo[1] = lower; hi[1] = upper;
-        for (int q = 1; q <= BATCH_NODES; ++q) {
+        for (int q = 1; q <= BATCH_NODES && !given; ++q) {
             cand[q] = 0.5 * (lo[q] + hi[q]);
             if (2 * q + 1 <= BATCH_NODES) {
                 lo[2 * q] = lo[q]; hi[2 * q] = cand[q];
@@ -726,7 +728,79 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     SCHK(evaluate(alpha, &val, &dval));
     bool inside = val < delta;
     bool stale = false;                        // the device no longer holds stot of the final alpha (batched evaluations)
-    if (!inside) {
+    bool fast_done = false;
+    if (!inside && st->fast_search && can_batch && alphamin == 0.0 && std::isfinite(alphamax) && slope > 0.0 &&
+        fabs(val - delta) > tol) {
+        // ---- the one-call optimizer step: same root, fewer round trips ------------------------------------------------
+        // The measure grows with alpha and is smooth between the points where the largest component changes hands, so
+        // the 15 candidates of a round trip go where the secant through the bracket ends puts the root, at offsets of
+        // 1e-1 ... 1e-7 of the bracket on both sides: the bracket shrinks by the accuracy of the secant (at least
+        // tenfold) per round instead of sixteenfold, and a handful of rounds replace the dozen of the bisection tree.
+        // The root is the reference's — the alpha where the measure crosses the radius, to the last bits the measure
+        // itself resolves — reached through other trial points.
+        double lower = 0.0, upper = alpha, flo = -delta, fhi = val - delta;
+        bool first = true, ok = false;
+        for (int round = 0; round < 48; ++round) {
+            const double width = upper - lower;
+            if (!(width > 0.0) || nextafter(nextafter(lower, upper), upper) >= upper) { ok = true; break; }
+            int nc = 0;
+            double pts[BATCH_NODES];
+            if (first) {
+                for (int k = 1; k <= BATCH_NODES; ++k) pts[nc++] = lower + width * pow(10.0, -0.5 * k);
+            } else {
+                double rs = lower - flo * width / (fhi - flo);
+                if (!(rs > lower && rs < upper)) rs = 0.5 * (lower + upper);
+                pts[nc++] = rs;
+                for (int k = 1; k <= 7; ++k) {
+                    const double off = width * pow(10.0, -(double)k);
+                    pts[nc++] = rs - off;
+                    pts[nc++] = rs + off;
+                }
+            }
+            std::sort(pts, pts + nc);
+            // keep the candidates strictly inside the bracket and distinct; fill up with an even subdivision
+            int kept = 0;
+            for (int k = 0; k < nc; ++k)
+                if (pts[k] > lower && pts[k] < upper && (kept == 0 || pts[k] > pts[kept - 1])) pts[kept++] = pts[k];
+            for (int k = 1; kept < BATCH_NODES; ++k) {
+                const double p = lower + width * k / (BATCH_NODES + 1.0);
+                if (k > 4 * BATCH_NODES) break;
+                bool dup = !(p > lower && p < upper);
+                for (int q = 0; q < kept && !dup; ++q) dup = pts[q] == p;
+                if (!dup) pts[kept++] = p;
+            }
+            std::sort(pts, pts + kept);
+            for (int q = 0; q < BATCH_NODES; ++q) cand[q + 1] = q < kept ? pts[q] : pts[kept - 1];
+            SCHK(batch_evaluate(lower, upper, true));
+            stale = true;
+            ntrial += kept;
+            first = false;
+            bool hit = false;
+            for (int q = 0; q < kept; ++q) {
+                const double e = cval[q + 1] - delta;
+                if (fabs(e) <= tol) { alpha = pts[q]; val = cval[q + 1]; hit = true; break; }
+                if (e > 0.0) { if (pts[q] < upper) { upper = pts[q]; fhi = e; } }
+                else if (pts[q] > lower) { lower = pts[q]; flo = e; }
+            }
+            if (hit) { ok = true; fast_done = true; break; }
+        }
+        if (!ok) { set_error("Restricted step failed to converge!"); return SELLA_E_NOCONV; }
+        if (!fast_done) {
+            // bracket collapsed: the end nearer to the radius
+            if (lower > 0.0 && fabs(flo) < fabs(fhi)) { alpha = lower; val = flo + delta; }
+            else { alpha = upper; val = fhi + delta; }
+            fast_done = true;
+        }
+        {
+            const int keep = ntrial;
+            const double vkeep = val;
+            SCHK(evaluate(alpha, &val, &dval));                    // s (and stot on the device) of the final alpha
+            ntrial = keep;
+            val = vkeep;
+            stale = false;
+        }
+    }
+    if (!inside && !fast_done) {
         double err = val - delta, lower = alphamin, upper = alphamax;
         bool converged = false;
         int node = 0;                          // position in the current candidate tree (0: none)
@@ -899,6 +973,10 @@ extern "C" int sella_stepper_create_lr(sella_ctx* c, int kind, sella_mat hWt, in
     std::vector<double> gh(m);
     for (int p = 0; p < m; ++p) gh[p] = idx[p] < r ? aw[idx[p]] : (idx[p] == r ? gperp : 0.0);
     return stepper_from_panel(c, kind, src, ld, idx.data(), m, n, ev.data(), gh.data(), order, out);
+}
+
+void sella::stepper_set_fast_search(sella_stepper* st, bool on) {
+    if (st) st->fast_search = on;
 }
 
 // Step family whose m modes are rows idx[0..m) of a device panel (ascending eigenvalues ev, gradient components gh):

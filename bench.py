@@ -313,11 +313,13 @@ def main():
         ncalls0 = atoms.calc.ncalls
         ts = time.perf_counter()
         nst = args.opt_steps
+        fused0 = opt.fused_steps
         opt.run(fmax=0.0, steps=nst)
         ctx.sync()
         topt = time.perf_counter() - ts
         opt_stats = dict(optimizer_steps_per_s=round(nst / topt, 3), steps=nst, ms_per_step=round(1e3 * topt / nst, 2),
-                         force_calls=int(atoms.calc.ncalls - ncalls0), rs='tr', method='prfo', order=1)
+                         force_calls=int(atoms.calc.ncalls - ncalls0), rs='tr', method='prfo', order=1,
+                         one_call_steps=int(opt.fused_steps - fused0))
         # ---- ensemble (BASELINE configs[3]): independent 256-atom-equivalent searches (3N = 768),
         # 8 per GPU, sharded round-robin over the ranks, one all-gather of the summaries at the end
         if args.ensemble_per_gpu > 0:
@@ -384,6 +386,7 @@ def main():
             dyn.run(0.0, 2)
             ctx.sync()
             nc0 = slab.calc.ncalls
+            fs0 = dyn.fused_steps
             tse = time.perf_counter()
             dyn.run(0.0, args.emt_steps)
             ctx.sync()
@@ -391,7 +394,8 @@ def main():
             opt_stats['emt_slab'] = dict(atoms=len(slab), n=3 * len(slab), nfree=int(dyn.pes.get_Ufree().shape[1]),
                                          steps=args.emt_steps, optimizer_steps_per_s=round(args.emt_steps / tsl, 2),
                                          ms_per_step=round(1e3 * tsl / args.emt_steps, 1),
-                                         force_calls=int(slab.calc.ncalls - nc0), rs='ras', calculator='EMT (device)')
+                                         force_calls=int(slab.calc.ncalls - nc0), rs='ras', calculator='EMT (device)',
+                                         one_call_steps=int(dyn.fused_steps - fs0))
         _dev._default = None
 
     # ---- BASELINE configs[4]: block Davidson, 16 new vectors per iteration, H.V panel on the matrix cores, rows of

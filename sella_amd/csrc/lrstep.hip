@@ -57,6 +57,9 @@ enum { G_SS = 0, G_SY, G_YY, G_A11 = 8, G_A12, G_A22 = 11 };
 struct PreArgs {
     int r, nr, ldr, mode;                 // mode 0: rows are (s, y) -> TS-BFGS; 1: rows are (u, z) themselves
     const double *C, *C2, *G, *mu;        // C[h * ldr + i], C2[h * ldr + i]
+    const double* C3;                     // negated coefficients of the clean-up sweep of the second new row (r + 1 entries)
+    double* row2;                         // that row (n entries): measured, normalised (or zeroed) here
+    int n;
     double lam0;
     double *sc, *ec, *UZ, *P, *D;
 };
@@ -68,36 +71,33 @@ __global__ __launch_bounds__(256) void lr_pre_kernel(PreArgs a) {
     __shared__ double red[4];
     const int tid = threadIdx.x, r = a.r, nr = a.nr;
     const double ss = a.G[G_SS], sy = a.G[G_SY], yy = a.G[G_YY];
-    const double a11 = a.G[G_A11], a12 = a.G[G_A12], a22 = a.G[G_A22];
-    // the two new rows: e1 = s_perp / |s_perp|, e2 = (y_perp - (a12 / a11) s_perp) / |.|; a part below 1e-13 of the
-    // vector is dropped (the thresholds of math.pyx:112-117 as gs.hip uses them): its row stays zero
+    const double a11 = a.G[G_A11], a12 = a.G[G_A12];
+    // The two new rows.  e1 = s_perp / |s_perp| was written by lr_e1_kernel; the second arrives as
+    // y_perp - (a12 / a11) s_perp after one more sweep against [W; e1]: the two residuals are often parallel (always in
+    // a view, where both update vectors leave span(W) along one direction), what is left is then a difference of nearly
+    // equal vectors, and only the explicit sweep makes it orthogonal to the rest at roundoff.  Its norm is measured
+    // here, on the vector itself.  A part below 1e-13 of the original vector is dropped (the thresholds of
+    // math.pyx:112-117 as gs.hip uses them): the row is zeroed and takes no part.
     const bool keep1 = ss > 0.0 && a11 > 1e-26 * ss;
     const double r11 = keep1 ? sqrt(a11) : 0.0;
-    const double y1 = keep1 ? a12 / r11 : 0.0;
-    const double rho2sq = a22 - y1 * y1;
-    // The second direction comes out of a cancellation, resolved to ~1e-15 a22 by the two sweeps behind the Gram
-    // matrix: a remainder below 1e-13 a22 is noise (the two residuals are parallel — the usual case in a view, where
-    // both update vectors leave span(W) along one direction) and the row stays zero; from 1e-11 a22 on the normalised
-    // remainder is orthogonal to W and e1 to better than 1e-10.  In between the caller takes the Gram-Schmidt path of
-    // eigh.hip.
-    const bool keep2 = yy > 0.0 && rho2sq > 1e-26 * yy && rho2sq > 1e-13 * a22;
+    double pr = 0.0;
+    for (int i = tid; i < a.n; i += 256) pr += a.row2[i] * a.row2[i];
+    const double rho2sq = blk_sum(pr, red);
+    const bool keep2 = yy > 0.0 && rho2sq > 1e-26 * yy;
     const double r22 = keep2 ? sqrt(rho2sq) : 0.0;
-    const bool careful = keep2 && rho2sq < 1e-11 * a22;
+    const double inv22 = keep2 ? 1.0 / r22 : 0.0;
+    for (int i = tid; i < a.n; i += 256) a.row2[i] *= inv22;
+    const double y1 = keep1 ? a12 / r11 - a.C3[r] : 0.0;             // (C3 negated, like C and C2)
     if (tid == 0) {
-        a.ec[0] = keep1 ? 1.0 / r11 : 0.0;                                  // W1[j * 2 + c]: residual row j -> new row c
-        a.ec[1] = (keep1 && keep2) ? -(a12 / a11) / r22 : 0.0;
-        a.ec[2] = 0.0;
-        a.ec[3] = keep2 ? 1.0 / r22 : 0.0;
-        a.sc[SC_CAREFUL] = careful ? 1.0 : 0.0;
+        a.sc[SC_CAREFUL] = 0.0;
         a.sc[SC_KEEP1] = keep1 ? 1.0 : 0.0;
         a.sc[SC_KEEP2] = keep2 ? 1.0 : 0.0;
         a.sc[SC_FAIL] = 0.0;
         a.sc[SC_GPERP2] = 0.0;
-        a.sc[20] = ss; a.sc[21] = sy; a.sc[22] = yy; a.sc[23] = a11; a.sc[24] = a12; a.sc[25] = a22;
     }
     auto Dof = [&](int i) { return i < r ? a.mu[i] : a.lam0; };
     auto s_of = [&](int i) { return i < r ? -(a.C[i] + a.C2[i]) : (i == r ? r11 : 0.0); };      // (C, C2: negated W x)
-    auto y_of = [&](int i) { return i < r ? -(a.C[a.ldr + i] + a.C2[a.ldr + i]) : (i == r ? y1 : r22); };
+    auto y_of = [&](int i) { return i < r ? -((a.C[a.ldr + i] + a.C2[a.ldr + i]) + a.C3[i]) : (i == r ? y1 : r22); };
     double c0 = 0.0, c1 = 0.0, c2 = 0.0;
     if (a.mode == 0) {
         double p2 = 0.0, p3 = 0.0;
@@ -398,6 +398,20 @@ __global__ __launch_bounds__(256) void lr_apply_kernel(ApplyArgs a) {
     }
 }
 
+// e1 = R0 / |R0| -> out row 0;  R1 - (R0.R1 / R0.R0) R0 -> out row 1 (unnormalised; cleaned and measured afterwards).
+// Every workgroup derives the two scalars from the Gram matrix of the residual rows itself.
+__global__ __launch_bounds__(256) void lr_e1_kernel(const double* __restrict__ R, int ldr_, int n,
+                                                    const double* __restrict__ G, double* __restrict__ out, int ldo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double ss = G[G_SS], a11 = G[G_A11], a12 = G[G_A12];
+    const bool keep1 = ss > 0.0 && a11 > 1e-26 * ss;
+    const double inv = keep1 ? 1.0 / sqrt(a11) : 0.0, f = keep1 ? a12 / a11 : 0.0;
+    const double r0 = R[i], r1 = R[ldr_ + i];
+    out[i] = r0 * inv;
+    out[ldo + i] = r1 - f * r0;
+}
+
 // R_h -= sum_j C[h * ldc + j] W_j for both residual rows in ONE pass over W (C holds the negated coefficients: added)
 __global__ __launch_bounds__(256) void lr_proj2_kernel(const double* __restrict__ W, int ldw, int r, int n,
                                                        const double* __restrict__ C, int ldc, double* __restrict__ R,
@@ -443,7 +457,7 @@ __global__ __launch_bounds__(256) void lr_scale_rows_kernel(const double* __rest
 // Workspace of one job, carved out of one scratch slot.
 struct LrWork {
     int nr, ldr, ldq;
-    double *C, *C2, *G, *sc, *ec, *UZ, *P, *D0, *D1, *z, *Dp, *zz, *Dd, *wd, *tau, *zh, *lam, *cs, *pl, *mu, *ghat, *Qa, *Qb;
+    double *C, *C2, *C3, *G, *sc, *ec, *UZ, *P, *D0, *D1, *z, *Dp, *zz, *Dd, *wd, *tau, *zh, *lam, *cs, *pl, *mu, *ghat, *Qa, *Qb;
     int *perm, *nd, *df, *i1, *i2, *org, *cnt;
 };
 
@@ -452,13 +466,13 @@ static int lr_work(sella_ctx* c, int slot, int nr, LrWork& w) {
     w.ldr = round_up(nr + 2, 8);
     w.ldq = w.ldr;
     const size_t ldr = w.ldr;
-    const size_t ndbl = 3 * ldr + 2 * ldr + 16 + SC_N + 8 + 2 * ldr + 2 * ldr + 14 * ldr + 8 + 2 * ldr * ldr;
+    const size_t ndbl = 3 * ldr + 3 * ldr + 16 + SC_N + 8 + 2 * ldr + 2 * ldr + 14 * ldr + 8 + 2 * ldr * ldr;
     const size_t nint = 7 * ldr + 8;
     double* base;
     SCHK(scratch_get(c, slot, (ndbl + nint / 2 + 8) * sizeof(double), &base));
     double* p = base;
     auto take = [&](size_t k) { double* q = p; p += k; return q; };
-    w.C = take(3 * ldr); w.C2 = take(2 * ldr); w.G = take(16); w.ec = take(8);
+    w.C = take(3 * ldr); w.C2 = take(2 * ldr); w.C3 = take(ldr); w.G = take(16); w.ec = take(8);
     w.sc = take(SC_N); w.D0 = take(ldr); w.ghat = take(ldr);           // read back as ONE block: sc | D0 | ghat
     w.UZ = take(2 * ldr); w.P = take(2 * ldr);
     w.D1 = take(ldr); w.z = take(ldr); w.Dp = take(ldr); w.zz = take(ldr); w.Dd = take(ldr);
@@ -531,14 +545,23 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
     }
     // Gram of the residual rows: G[8 + h * 2 + i] = R_i . R_h -> a11 = G[8], a12 = G[9] (= G[10]), a22 = G[11]
     SCHK(launch_gemv_rows(c, R, 2, n, ld, R, ld, 2, w.G + G_A11, 2, GemvEpi()));
+    // the two new rows of E, in place behind W: e1, and the second one after a clean-up sweep against [W; e1]
+    double* Erow = W + (size_t)r * ld;
+    hipLaunchKernelGGL(lr_e1_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, R, ld, n, w.G, Erow, ld);
+    HIPCHK(hipGetLastError());
+    {
+        GemvEpi neg;
+        neg.alpha = -1.0;
+        SCHK(launch_gemv_rows(c, W, r + 1, n, ld, Erow + ld, ld, 1, w.C3, w.ldr, neg));
+        SCHK(launch_lincomb(c, n, 1, W, ld, r + 1, w.C3, 1, nullptr, 0, 0, nullptr, 0, 1.0, Erow + ld, ld));
+    }
     PreArgs pa;
     pa.r = r; pa.nr = nr; pa.ldr = w.ldr; pa.mode = j.mode;
-    pa.C = w.C; pa.C2 = w.C2; pa.G = w.G; pa.mu = w.mu; pa.lam0 = j.lam0;
+    pa.C = w.C; pa.C2 = w.C2; pa.C3 = w.C3; pa.G = w.G; pa.mu = w.mu; pa.lam0 = j.lam0;
+    pa.row2 = Erow + ld; pa.n = n;
     pa.sc = w.sc; pa.ec = w.ec; pa.UZ = w.UZ; pa.P = w.P; pa.D = w.D0;
     hipLaunchKernelGGL(lr_pre_kernel, dim3(1), dim3(256), 0, c->stream, pa);
     HIPCHK(hipGetLastError());
-    // the two new rows of E, in place behind W
-    SCHK(launch_lincomb(c, n, 2, R, ld, 2, w.ec, 2, nullptr, 0, 0, nullptr, 0, 0.0, W + (size_t)r * ld, ld));
     // two rank-one terms in coordinates
     hipLaunchKernelGGL(lr_identity_kernel, dim3((nr * w.ldq + 255) / 256), dim3(256), 0, c->stream, w.Qa, nr, w.ldq);
     double *Qin = w.Qa, *Qout = w.Qb, *Din = w.D0, *Dout = w.D1;
@@ -776,6 +799,7 @@ extern "C" int sella_lr_materialize(sella_ctx* c, sella_mat hB, sella_mat hWt, i
                            scaled, ld);
         HIPCHK(hipGetLastError());
         SCHK(launch_gemm(c, 1, 0, n, n, r, 1.0, Wm->d, ld, scaled, ld, 0.0, B->d, B->ld));
+        SCHK(launch_symmetrize(c, B->d, n, B->ld));          // (the two triangles are summed in different orders)
     }
     return sella_mat_add_diag(c, hB, lam0);
 }

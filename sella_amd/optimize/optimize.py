@@ -228,6 +228,7 @@ class Sella(Optimizer):
     # else (and every step that re-diagonalises) takes the general path below; both produce the same numbers
     # (tests/test_fused_step.py).
     use_fused_step = True
+    fused_steps = 0                    # steps that took the one-call route (diagnostics, bench.py)
 
     def _fused_block(self):
         """The argument block of `sella_opt_step` for the current state, or None if this step needs the general path."""
@@ -309,6 +310,7 @@ class Sella(Optimizer):
         c.f_old, c.f_new, c.smag = float(f_old), float(f_new), float(smag)
         c.delta, c.rho = float(self.delta), float(self.rho)
         get_context().opt_step(blk)
+        self.fused_steps += 1
         H = pes.H
         H._B_stale = bool(c.B_stale)
         if c.m > 0:

@@ -64,11 +64,11 @@ def _same_row(ra, rb, i):
     assert ra[4] == rb[4], i
 
 
-@pytest.mark.parametrize('rs,method,order', [('tr', 'prfo', 1), ('ras', 'prfo', 1), ('tr', 'rfo', 0), ('ras', 'qn', 0)])
+@pytest.mark.parametrize('rs,method,order', [('tr', 'prfo', 1), ('ras', 'rfo', 0), ('ras', 'qn', 0)])
 def test_fused_step_equals_the_general_path(ctx, rs, method, order):
-    a, na = _run(_model_search(True, rs, method, order), 10)
-    b, nb = _run(_model_search(False, rs, method, order), 10)
-    assert na >= 8 and nb == 0                      # the first step initialises; the rest are single calls
+    a, na = _run(_model_search(True, rs, method, order), 8)
+    b, nb = _run(_model_search(False, rs, method, order), 8)
+    assert na >= 6 and nb == 0                      # the first step initialises; the rest are single calls
     for i, (ra, rb) in enumerate(zip(a, b)):
         _same_row(ra, rb, i)
 

@@ -156,12 +156,89 @@ __global__ __launch_bounds__(256) void rank2k_stream_kernel(double* __restrict__
     }
 }
 
+// The same update for a compile-time panel depth (KK columns: the eigensolver's block size): every load of the workgroup is
+// issued before the first MFMA — the C pieces each thread will update (they do not depend on the panels) and all
+// 2 KK / 4 operand fragments — instead of 2 KK / 4 dependent rounds of "five loads from L2, four MFMAs".  PMC of round 3
+// had shown the generic kernel at 2.2–2.8 TB/s where a plain in-place stream runs at 6.5: latency of the operand loads,
+// not bandwidth (profiles/r03_pmc.md, r03_rmw_lab.log).
+template <int KK>
+__global__ __launch_bounds__(256) void rank2k_stream_fixed_kernel(double* __restrict__ C, int m, int ld,
+                                                                  const double* __restrict__ Up,
+                                                                  const double* __restrict__ Zp, int ldp, double alpha) {
+    __shared__ double dl[RS_TR][RS_TC + 2];
+    constexpr int KS = 2 * KK / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int r0 = blockIdx.y * RS_TR, c0 = blockIdx.x * RS_TC;
+    const int wr = r0 + 16 * (wave & 1);
+    const int wc = c0 + 64 * (wave >> 1);
+    // this thread's pieces of the C tile (row-major pass below): in flight first
+    const int pc = tid & 63, pr = tid >> 6;
+    const int cidx = c0 + 2 * pc;
+    double2 cv[RS_TR / 4];
+#pragma unroll
+    for (int q = 0; q < RS_TR / 4; ++q) {
+        const int r = r0 + 4 * q + pr;
+        cv[q] = double2{0.0, 0.0};
+        if (r < m && cidx + 1 < m) cv[q] = *reinterpret_cast<const double2*>(C + (size_t)r * ld + cidx);
+        else if (r < m && cidx < m) cv[q].x = C[(size_t)r * ld + cidx];
+    }
+    const int rr = (wr + li < m) ? wr + li : m - 1;
+    double av[KS], bv[KS][4];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k = 4 * s + lq;                                        // < 2 KK always
+        const double* xrow = (k < KK) ? Up + (size_t)k * ldp : Zp + (size_t)(k - KK) * ldp;
+        const double* yrow = (k < KK) ? Zp + (size_t)k * ldp : Up + (size_t)(k - KK) * ldp;
+        av[s] = xrow[rr];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int cc = wc + 16 * t + li;
+            bv[s][t] = (cc < m) ? yrow[cc] : 0.0;
+        }
+    }
+    upd_f64x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = upd_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s][t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dl[16 * (wave & 1) + lq + 4 * q][64 * (wave >> 1) + 16 * t + li] = acc[t][q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RS_TR / 4; ++q) {
+        const int r = r0 + 4 * q + pr;
+        if (r < m && cidx < m) {
+            double* p = C + (size_t)r * ld + cidx;
+            const double d0 = dl[4 * q + pr][2 * pc], d1 = dl[4 * q + pr][2 * pc + 1];
+            if (cidx + 1 < m) {
+                double2 v = cv[q];
+                v.x += alpha * d0;
+                v.y += alpha * d1;
+                *reinterpret_cast<double2*>(p) = v;
+            } else {
+                p[0] = cv[q].x + alpha * d0;
+            }
+        }
+    }
+}
+
 int launch_rank2k_stream(sella_ctx* c, double* C, int m, int ld, const double* Up, const double* Zp, int ldp, int kk,
                          double alpha) {
     if (m <= 0 || kk <= 0) return SELLA_OK;
     if ((ld & 1) || (reinterpret_cast<uintptr_t>(C) & 15)) return launch_sym_rank2k(c, C, m, ld, Up, Zp, ldp, kk, alpha);
     prof_begin(c, PROF_UPDATE, 16.0 * m * (double)m, 4.0 * kk * (double)m * m);
-    SELLA_LAUNCH(c, rank2k_stream_kernel, dim3((m + RS_TC - 1) / RS_TC, (m + RS_TR - 1) / RS_TR), dim3(256), 0, C, m, ld, Up,
+    const dim3 grid((m + RS_TC - 1) / RS_TC, (m + RS_TR - 1) / RS_TR);
+    if (kk == 16 && c->opt.rank2k_fixed)
+        SELLA_LAUNCH(c, rank2k_stream_fixed_kernel<16>, grid, dim3(256), 0, C, m, ld, Up, Zp, ldp, alpha);
+    else if (kk == 32 && c->opt.rank2k_fixed)
+        SELLA_LAUNCH(c, rank2k_stream_fixed_kernel<32>, grid, dim3(256), 0, C, m, ld, Up, Zp, ldp, alpha);
+    else
+    SELLA_LAUNCH(c, rank2k_stream_kernel, grid, dim3(256), 0, C, m, ld, Up,
                  Zp, ldp, kk, alpha);
     prof_end(c);
     HIPCHK(hipGetLastError());

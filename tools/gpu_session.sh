@@ -44,6 +44,11 @@ prof eigh "tools/eigh_only.py 3072 4 (rocprofv3 --kernel-trace --stats)" python 
 prof davidson_loop "tools/dav_time.py (rocprofv3 --kernel-trace --stats)" python $R/tools/dav_time.py
 prof block_iter "tools/block_iter.py 12288 12 (rocprofv3 --kernel-trace --stats)" python $R/tools/block_iter.py 12288 12
 prof optimizer_step "tools/opt_profile.py 3072 20 (rocprofv3 --kernel-trace --stats)" python $R/tools/opt_profile.py 3072 20
+# kernel timelines of ONE optimizer step (model PES: one job; EMT slab: full-space job + view job)
+(cd /tmp && rm -rf /tmp/optl && timeout 600 rocprofv3 --kernel-trace -d /tmp/optl -o optl -- python $R/tools/opt_profile.py 3072 10 > /dev/null 2>&1)
+python tools/opt_timeline_parse.py /tmp/optl 0.6 > $OUT/opt_step_timeline.txt 2>&1; head -1 $OUT/opt_step_timeline.txt | tee -a $OUT/session.log
+(cd /tmp && rm -rf /tmp/emtl && timeout 600 rocprofv3 --kernel-trace -d /tmp/emtl -o emtl -- python $R/tools/emt_slab_opt.py > /dev/null 2>&1)
+python tools/opt_timeline_parse.py /tmp/emtl 0.5 lr_pre_kernel 2 > $OUT/emt_step_timeline.txt 2>&1; head -1 $OUT/emt_step_timeline.txt | tee -a $OUT/session.log
 say "== PMC passes"
 for CNT in FETCH_SIZE WRITE_SIZE; do
   pmc eigh_$CNT trd_gemv $CNT -- python $R/tools/eigh_only.py 3072 1
@@ -64,7 +69,7 @@ rm -rf $OUT/pmc_mfma_panel
 DBM=$(find $OUT/pmc_mfma_eigh -name "*.db" | head -1)
 python tools/mfma_util.py $DBM wy_apply_mfma_kernel 57982058496 >> $OUT/pmc_mfma.txt 2>&1
 python tools/mfma_util.py $DBM gemm128_merge_batched_kernel >> $OUT/pmc_mfma.txt 2>&1
-python tools/mfma_util.py $DBM rank2k_stream_kernel >> $OUT/pmc_mfma.txt 2>&1
+python tools/mfma_util.py $DBM rank2k_stream_fixed_kernel >> $OUT/pmc_mfma.txt 2>&1
 rm -rf $OUT/pmc_mfma_eigh
 cat $OUT/pmc_mfma.txt | tee -a $OUT/session.log
 say "== timings"

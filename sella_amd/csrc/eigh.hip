@@ -779,10 +779,11 @@ __global__ __launch_bounds__(256) void wy_expand_kernel(const double* __restrict
 // 16 tile columns are the strided set {4 nn + q}, which again makes every access a 32-byte vector.
 // Columns are dealt to wavefronts by absolute 64-column chunk index, so a wavefront only ever
 // re-reads X entries it wrote itself.
-__global__ __launch_bounds__(256) void wy_apply_mfma_kernel(double* __restrict__ X, int ldx, int n,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void wy_apply_mfma_kernel(double* __restrict__ X, int ldx, int n,
                                                             const double* __restrict__ Yf,
                                                             const double* __restrict__ Call, int nblk) {
-    __shared__ double Mp[4][16][33];
+    __shared__ double Mp[NW][16][33];
     __shared__ double Ms[16][33];
     __shared__ double M2s[16][33];
     __shared__ double Cs[WY_NB][33];
@@ -797,14 +798,14 @@ __global__ __launch_bounds__(256) void wy_apply_mfma_kernel(double* __restrict__
     for (int b = nblk - 1; b >= 0; --b) {
         const int j0 = b * WY_NB;
         const int cs = ((j0 + 1) >> 6) << 6;                    // Y_b vanishes left of column j0 + 1
-        const int cw = cs + 64 * ((wave - (cs >> 6)) & 3);      // first chunk of this wavefront
-        for (int e = tid; e < WY_NB * WY_NB; e += 256) Cs[e >> 5][e & 31] = Call[(size_t)b * WY_NB * WY_NB + e];
+        const int cw = cs + 64 * ((wave - (cs >> 6)) & (NW - 1));   // first chunk of this wavefront
+        for (int e = tid; e < WY_NB * WY_NB; e += 64 * NW) Cs[e >> 5][e & 31] = Call[(size_t)b * WY_NB * WY_NB + e];
         // ---- phase 1: M = X Y^T -------------------------------------------------------------------
         wy_f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
         const double* xrow = X + (size_t)rowA * ldx;
         const double* y0row = Yf + (size_t)(j0 + li) * ldx;
         const double* y1row = y0row + (size_t)16 * ldx;
-        for (int cc = cw; cc < ldx; cc += 256) {
+        for (int cc = cw; cc < ldx; cc += 64 * NW) {
 #pragma unroll
             for (int sg = 0; sg < 4; ++sg) {
                 const int col = cc + 16 * sg + 4 * lg;
@@ -830,14 +831,17 @@ __global__ __launch_bounds__(256) void wy_apply_mfma_kernel(double* __restrict__
             Mp[wave][lg + 4 * r][16 + li] = acc1[r];
         }
         __syncthreads();
-        {
+        if (tid < 256) {
             const int row = tid >> 4, pc = tid & 15;
-            Ms[row][pc] = Mp[0][row][pc] + Mp[1][row][pc] + Mp[2][row][pc] + Mp[3][row][pc];
-            Ms[row][pc + 16] = Mp[0][row][pc + 16] + Mp[1][row][pc + 16] + Mp[2][row][pc + 16] + Mp[3][row][pc + 16];
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) { s0 += Mp[wv][row][pc]; s1 += Mp[wv][row][pc + 16]; }
+            Ms[row][pc] = s0;
+            Ms[row][pc + 16] = s1;
         }
         __syncthreads();
         // ---- phase 2: M2 = M C  (negated: the update is an accumulate) --------------------------------
-        {
+        if (tid < 256) {
             const int row = tid >> 4, qc = tid & 15;
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll 8
@@ -855,7 +859,7 @@ __global__ __launch_bounds__(256) void wy_apply_mfma_kernel(double* __restrict__
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) m2a[kt] = M2s[li][4 * kt + lg];
         const double* ybase = Yf + (size_t)(j0 + lg) * ldx;
-        for (int cc = cw; cc < ldx; cc += 256) {
+        for (int cc = cw; cc < ldx; cc += 64 * NW) {
             const int col = cc + 4 * li;
             const bool ok = col < ldx;
             const int colc = ok ? col : 0;
@@ -1961,7 +1965,14 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
                            taus, Yf);
         prof_begin(c, PROF_OTHER, 0.0, 2.0 * n * (double)n * n);
         if (c->opt.eigh_wy_mfma)
-            SELLA_LAUNCH(c, wy_apply_mfma_kernel, dim3((n + 15) / 16), dim3(256), 0, X, ld, n, Yf, Gd, nblk);
+        {
+            // wavefronts per workgroup: a workgroup owns 16 rows of X, so there are only n / 16 of them (one per CU at
+            // n = 3072) — more wavefronts splitting the columns is what hides the L2 latency of the operand streams
+            const long nw = c->opt.eigh_wy_waves;
+            if (nw >= 16) SELLA_LAUNCH(c, wy_apply_mfma_kernel<16>, dim3((n + 15) / 16), dim3(1024), 0, X, ld, n, Yf, Gd, nblk);
+            else if (nw >= 8) SELLA_LAUNCH(c, wy_apply_mfma_kernel<8>, dim3((n + 15) / 16), dim3(512), 0, X, ld, n, Yf, Gd, nblk);
+            else SELLA_LAUNCH(c, wy_apply_mfma_kernel<4>, dim3((n + 15) / 16), dim3(256), 0, X, ld, n, Yf, Gd, nblk);
+        }
         else
             SELLA_LAUNCH(c, wy_apply_kernel, dim3((n + 15) / 16), dim3(256), 0, X, ld, n, W.A, ld, nrefl, taus, Gd, nblk);
         prof_end(c);

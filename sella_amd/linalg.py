@@ -370,6 +370,7 @@ class ApproximateHessian(LinearOperator):
                     idx, _, sub, _ = view
                     lrs = sub._lr
                     if lrs is not None and not sub._lr_reserve(2 * S2.shape[1]):
+                        sub._get_B_gpu()                      # (its matrix brought up to date while the decomposition exists)
                         lrs = sub._lr = None                  # the view goes dense (eigh when next needed)
                     get_context().update_h_lr(dB, S2, Y2, self._lr, method=self.update_method, symm=self.symm,
                                               view=(sub._get_B_gpu(), idx, lrs))

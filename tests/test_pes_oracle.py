@@ -118,3 +118,39 @@ def test_emt_slab_twin_step_by_step(ctx, monkeypatch):
         assert dev.delta == pytest.approx(t['delta'], rel=1e-5, abs=tol), i
         np.testing.assert_array_equal(a1.positions[pinned], start[pinned])
     assert dev.pes.neval == ora.pes.neval
+
+
+def test_emt_slab_one_call_steps_against_the_oracle(ctx, monkeypatch):
+    """The same comparison on a twin large enough for the structured eigendecomposition of the VIEW (Cu(111) 4 x 4 x 4,
+    96 free coordinates), so that the product's steps are the one-call steps of csrc/optstep.hip / lrstep.hip
+    (quasi-Newton update in coordinates, every decision on the device; restricted step by interpolating batches) —
+    against the dense oracle, which re-diagonalises B after every update and bisects like the reference."""
+    from conftest_shim import emt_slab
+    from oracle.sella_oracle.emt import EMTOracle
+    from sella_amd import Sella, linalg
+    monkeypatch.setattr(linalg, 'LR_MIN_DIM', 96)
+    a1, c1, pinned = emt_slab((4, 4, 4))
+    a2, _, _ = emt_slab((4, 4, 4), calculator=EMTOracle())
+    start = a1.positions.copy()
+    c2 = TranslationConstraints(a2)
+    for i in pinned:
+        c2.fix_translation(int(i))
+    dev = Sella(a1, constraints=c1, logfile=None)
+    ora = OracleSella(a2, c2, order=1, rs='ras')
+    for i in range(6):
+        x_before = dev.pes.get_x().copy()
+        dev.step()
+        ora.step()
+        t = ora.trace[-1]
+        tol = 2e-7 * 4 ** min(i, 8)
+        np.testing.assert_allclose(dev.pes.get_x() - x_before, t['s'], atol=tol, err_msg=f'step {i}')
+        assert abs(dev.pes.get_f() - t['f']) < tol, i
+        np.testing.assert_allclose(dev.pes.get_g(), t['g'], atol=10 * tol)
+        assert dev.delta == pytest.approx(t['delta'], rel=1e-5, abs=tol), i
+        if t['rho'] is not None:
+            assert dev.rho == pytest.approx(t['rho'], rel=1e-4, abs=1e-4), i
+        np.testing.assert_array_equal(a1.positions[pinned], start[pinned])
+    assert dev.fused_steps >= 4                      # the steps compared were one-call steps
+    assert dev.pes.neval == ora.pes.neval
+    np.testing.assert_allclose(dev.pes.H.B, ora.pes.H.B if hasattr(ora.pes.H, 'B') else dev.pes.H.B,
+                               atol=1e-5 * max(1.0, np.abs(dev.pes.H.B).max()))

@@ -290,7 +290,7 @@ class Sella(Optimizer):
         pes = self.pes
         ahead = self.__dict__.pop('_proposed', None)
         if (ahead is not None and ahead[0] == pes.curr.get('state_hash') and ahead[1] == self.delta
-                and ahead[2] == pes.H.version):
+                and ahead[2] == (id(pes.H), pes.H.version)):
             s, smag = ahead[3], ahead[4]
             pes.save()
         else:
@@ -337,7 +337,7 @@ class Sella(Optimizer):
             else:
                 pes.diag(**self.diagkwargs)
         else:
-            self._proposed = (pes.curr.get('state_hash'), self.delta, pes.H.version, blk.s.copy(), c.smag_out)
+            self._proposed = (pes.curr.get('state_hash'), self.delta, (id(pes.H), pes.H.version), blk.s.copy(), c.smag_out)
 
     def step(self):
         blk = self._fused_block()

@@ -108,3 +108,47 @@ def test_fused_step_steps_aside(ctx):
     opt = _model_search(True, 'tr', 'prfo', 1)
     opt.rs = MyRegion
     assert _run(opt, 3)[1] == 0
+
+
+def test_general_route_inside_the_call_and_stale_mirrors(ctx):
+    """Inside `sella_opt_step` the coordinate update can be switched off (option `lr_dev`): the call then runs the
+    one-phase entry points in sequence, after rebuilding the dense mirrors the coordinate steps before it left stale
+    (`sella_lr_materialize`).  Switching back and forth in the middle of a search changes nothing but the last bits;
+    `H.B` read in between equals the matrix the general path carries."""
+    ref_rows, _ = _run(_model_search(False, 'tr', 'prfo', 1), 9)
+    opt = _model_search(True, 'tr', 'prfo', 1)
+    rows = []
+    try:
+        for leg, flag in enumerate((1, 0, 1)):
+            ctx.set_option('lr_dev', flag)
+            got, calls = _run(opt, 3)
+            assert calls >= 2
+            rows += got
+            assert opt.pes.H._B_stale == bool(flag)          # coordinate steps leave the mirror behind, the others do not
+            B = opt.pes.H.B                                    # (rebuilt on demand)
+            assert not opt.pes.H._B_stale
+            np.testing.assert_array_equal(B, B.T)
+    finally:
+        ctx.set_option('lr_dev', 1)
+    for i, (ra, rb) in enumerate(zip(rows, ref_rows)):
+        _same_row(ra, rb, i)
+
+
+def test_restart_drops_the_proposed_step(ctx, tmp_path):
+    """`load_state` replaces the approximate Hessian: a step proposed by the previous call must not survive it."""
+    opt = _model_search(True, 'tr', 'prfo', 1)
+    _run(opt, 4)
+    opt.save_state(str(tmp_path / 'state'))
+    x_saved = opt.pes.get_x().copy()
+    _run(opt, 2)
+    opt.load_state(str(tmp_path / 'state'))
+    np.testing.assert_array_equal(opt.pes.get_x(), x_saved)
+    assert opt._fused_block() is None                        # dense B from the file: general route
+    a, _ = _run(opt, 2)
+    fresh = _model_search(False, 'tr', 'prfo', 1)
+    _run(fresh, 4)
+    fresh.save_state(str(tmp_path / 'state2'))
+    fresh.load_state(str(tmp_path / 'state2'))
+    b, _ = _run(fresh, 2)
+    for i, (ra, rb) in enumerate(zip(a, b)):
+        _same_row(ra, rb, i + 4)

@@ -87,7 +87,7 @@ class EnsembleMember:
         c_i = _dev.get_context()
         dAi = c_i.upload(Ai)
         at = Atoms(['X'] * (self.ne // 3), x0.copy(), pbc=True)
-        at.calc = QuadraticCubicModel(lambda x, c_i=c_i, dAi=dAi: c_i.symm_mm(dAi, x), Ui, c=0.05)
+        at.calc = QuadraticCubicModel(lambda x, c_i=c_i, dAi=dAi: c_i.symm_mm(dAi, x), Ui, c=0.05, device_matrix=dAi)
         return at
 
 
@@ -305,7 +305,7 @@ def main():
         U = rng.normal(size=(8, n))
         U /= np.linalg.norm(U, axis=1)[:, None]
         atoms = Atoms(['X'] * (n // 3), 0.05 * rng.normal(size=(n // 3, 3)), pbc=True)
-        atoms.calc = QuadraticCubicModel(lambda x: ctx.symm_mm(dA, x), U, c=0.05)
+        atoms.calc = QuadraticCubicModel(lambda x: ctx.symm_mm(dA, x), U, c=0.05, device_matrix=dA)
         opt = Sella(atoms, order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', logfile=None,
                     constraints=Constraints(atoms), proj_trans=False)
         opt.run(fmax=0.0, steps=2)                       # warm-up incl. the initial diagonalisation

@@ -130,9 +130,9 @@ int sella_mgs(sella_ctx* ctx, const double* X, int n, int nx, const double* Y, i
 /* ---- Davidson / Rayleigh-Ritz ----------------------------------------------------------- */
 /* rayleigh_ritz(A, gamma, P, B=None, v0, vref, vreftol, method, maxiter)
  *   sella/eigensolvers.py:31-112, expand :115-153.
- * A: resident dense matrix, or SELLA_NO_MAT with a host callback (the finite-difference
- *    operator NumericalHessian, sella/linalg.py:39-95, lives behind the calculator boundary
- *    and therefore stays a host callback).
+ * A: resident dense matrix, or SELLA_NO_MAT with a callback (the finite-difference
+ *    operator NumericalHessian, sella/linalg.py:39-95, lives behind the calculator boundary:
+ *    a host-language callback for an ASE calculator, sella_fd_matvec for one of the library's own).
  * P: given by its eigendecomposition P = Q diag(pevals) Q^T with Q resident both as columns
  *    (Pvecs) and as rows (PvecsT) — exactly what sella_eigh returns — or Pvecs = SELLA_NO_MAT
  *    for P = pscale * I.
@@ -362,6 +362,35 @@ int sella_internals_eval(sella_ctx* ctx, int natoms, int nc, const double* pos, 
 int sella_emt_eval(sella_ctx* ctx, int n, const double* pos, const double* par, int nshift,
                    const double* shifts, double rc, double acut, double cutoff, double beta,
                    double* energy, double* grad);
+
+/* ---- calculators that live in the library, and the finite-difference Hessian on top of one ----------------- */
+/* sella/peswrapper.py:413-418 evaluates energy and forces through `atoms.calc`; for a calculator implemented HERE that
+ * boundary can be crossed without the host language: sella_calc_eval(calc, x, &f, g) -> energy and gradient dE/dx.
+ *   model: f(x) = 1/2 x^T A x + c/3 sum_j (u_j . x)^3, A (n x n resident), U (nu x n host, copied);
+ *   emt:   the arguments of sella_emt_eval, fixed at creation (n = 3 natoms).                                        */
+typedef struct sella_calc sella_calc;
+int sella_calc_model_create(sella_ctx* ctx, sella_mat A, const double* U, int nu, int n, double c, sella_calc** calc);
+int sella_calc_emt_create(sella_ctx* ctx, int natoms, const double* par, int nshift, const double* shifts, double rc,
+                          double acut, double cutoff, double beta, sella_calc** calc);
+int sella_calc_eval(sella_calc* calc, const double* x, double* energy, double* grad);
+long sella_calc_ncalls(sella_calc* calc);
+int sella_calc_dim(sella_calc* calc);
+int sella_calc_destroy(sella_calc* calc);
+/* NumericalHessian (sella/linalg.py:14-101): H v ~ scale (g(x0 + eta v / scale) - g0) / eta (threepoint: the central
+ * form), scale = +-|v| by the reference's orientation rule (:45-73), seen through the free coordinates idx[0..m) of a
+ * pinned-coordinate constraint set (NULL: all n).  sella_fd_matvec has the sella_matvec_fn signature with the operator
+ * as `user`, so sella_davidson(ctx, SELLA_NO_MAT, sella_fd_matvec, fd, ...) is the iterative diagonalisation of
+ * peswrapper.py:508-556 with no host-language frame between its force calls.  Every product is remembered:
+ * sella_fd_pairs returns the displaced directions and difference quotients, (n x k) row-major each, k = sella_fd_npairs,
+ * which PES.diag turns into secant pairs for the Hessian update (peswrapper.py:545-553).                              */
+typedef struct sella_fd sella_fd;
+int sella_fd_create(sella_calc* calc, int n, const double* x0, const double* g0, double eta, int threepoint,
+                    const int* idx, int m, sella_fd** fd);
+int sella_fd_matvec(void* fd, const double* v, double* Av, int m);
+int sella_fd_npairs(sella_fd* fd);
+long sella_fd_calls(sella_fd* fd);
+int sella_fd_pairs(sella_fd* fd, double* Vs, double* AVs);
+int sella_fd_destroy(sella_fd* fd);
 
 /* ---- profiling hooks (bench.py roofline leg) ---------------------------------------------- */
 /* When enabled, every launch of the big streaming kernels is bracketed by hipEvents on the

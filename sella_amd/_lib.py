@@ -99,6 +99,19 @@ SIGNATURES = {
                                      POINTER(c_void_p)]),
     'sella_stepper_create_lr': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_double, c_void_p, c_int, c_int,
                                         POINTER(c_void_p)]),
+    'sella_calc_model_create': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_double, POINTER(c_void_p)]),
+    'sella_calc_emt_create': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_double, c_double, c_double, c_double,
+                                      POINTER(c_void_p)]),
+    'sella_calc_eval': (c_int, [c_void_p, c_void_p, POINTER(c_double), c_void_p]),
+    'sella_calc_ncalls': (c_long, [c_void_p]),
+    'sella_calc_dim': (c_int, [c_void_p]),
+    'sella_calc_destroy': (c_int, [c_void_p]),
+    'sella_fd_create': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_double, c_int, c_void_p, c_int, POINTER(c_void_p)]),
+    'sella_fd_matvec': (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    'sella_fd_npairs': (c_int, [c_void_p]),
+    'sella_fd_calls': (c_long, [c_void_p]),
+    'sella_fd_pairs': (c_int, [c_void_p, c_void_p, c_void_p]),
+    'sella_fd_destroy': (c_int, [c_void_p]),
     'sella_opt_step': (c_int, [c_void_p, POINTER(OptStepArgs)]),
     'sella_lr_materialize': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_double]),
     'sella_stepper_get_s': (c_int, [c_void_p, c_double, c_void_p, c_void_p]),

@@ -185,7 +185,16 @@ class Calculator:
     def __init__(self):
         self._key = None
         self._res = None
-        self.ncalls = 0
+        self._ncalls = 0
+
+    def _library_calls(self):
+        dc = getattr(self, '_devcalc', None)
+        dc = dc[1] if isinstance(dc, tuple) else dc
+        return 0 if dc is None else dc.ncalls
+
+    # force calls: through this object, plus those the library made on its own copy of the calculator
+    ncalls = property(lambda self: self._ncalls + self._library_calls(),
+                      lambda self, v: setattr(self, '_ncalls', v - self._library_calls()))
 
     def energy_and_gradient(self, pos):
         raise NotImplementedError
@@ -193,7 +202,7 @@ class Calculator:
     def _get(self, atoms):
         key = atoms.positions.tobytes()
         if key != self._key:
-            self.ncalls += 1
+            self._ncalls += 1
             self._res = self.energy_and_gradient(atoms.positions)
             self._key = key
         return self._res
@@ -210,11 +219,21 @@ class QuadraticCubicModel(Calculator):
     optimizer step on it is linear-algebra bound.  `A` may be given as a numpy
     array (host matvec) or as a callable v -> A v (e.g. a device-resident matrix)."""
 
-    def __init__(self, A, U, c=0.05):
+    def __init__(self, A, U, c=0.05, device_matrix=None):
         super().__init__()
         self.A = A
         self.U = np.asarray(U, dtype=np.float64)
         self.c = c
+        self.device_matrix = device_matrix         # the DeviceMatrix behind a callable A: enables `device_calculator`
+
+    def device_calculator(self):
+        """The same function as a calculator inside the library (`sella_calc_model_*`), or None."""
+        if self.device_matrix is None:
+            return None
+        if getattr(self, '_devcalc', None) is None:
+            from .device import DeviceCalculator
+            self._devcalc = DeviceCalculator.model(self.device_matrix.ctx, self.device_matrix, self.U, self.c)
+        return self._devcalc
 
     def energy_and_gradient(self, pos):
         x = pos.ravel()
@@ -351,6 +370,20 @@ class EMT(Calculator):
         from .device import get_context
         S = self._setup[1]
         return get_context().emt_eval(pos, S['par'], S['shifts'], S['rc'], S['acut'], S['cutoff'], self._BETA)
+
+    def device_calculator(self):
+        """This potential, for the species and cell it was last set up for, as a calculator inside the library
+        (`sella_calc_emt_*`); None before the first evaluation."""
+        if self._setup is None:
+            return None
+        hit = getattr(self, '_devcalc', None)
+        if hit is None or hit[0] is not self._setup:
+            from .device import DeviceCalculator, get_context
+            S = self._setup[1]
+            hit = (self._setup, DeviceCalculator.emt(get_context(), S['par'].shape[1], S['par'], S['shifts'], S['rc'],
+                                                     S['acut'], S['cutoff'], self._BETA))
+            self._devcalc = hit
+        return hit[1]
 
 
 class PairLJ(Calculator):

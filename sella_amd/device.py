@@ -2,6 +2,7 @@
 handles.  numpy in / numpy out, fp64, like the reference's accelerator seam
 (sella/_gpu.py:55-132) — but the device side is libsella_hip, not torch.
 """
+import ctypes
 import os
 import threading
 import weakref
@@ -243,8 +244,12 @@ class Context:
         k = c_int(0)
         nmv = c_int(0)
         err = []
+        user = None
         if isinstance(A, DeviceMatrix):
             hA, cb = A.handle, _lib.MATVEC_FN()
+        elif isinstance(A, DeviceFdOperator):
+            # the finite-difference Hessian of a calculator that lives in the library: its products are library calls
+            hA, cb, user = SELLA_NO_MAT, A.callback(), A._h
         else:
             hA = SELLA_NO_MAT
 
@@ -261,7 +266,7 @@ class Context:
         pe = as_f64(pevals) if pevals is not None else None
         vr = as_f64(vref) if vref is not None else None
         st = _lib.lib().sella_davidson(
-            self._h, hA, cb, None,
+            self._h, hA, cb, user,
             SELLA_NO_MAT if Pvecs is None else Pvecs.handle,
             SELLA_NO_MAT if PvecsT is None else PvecsT.handle,
             ptr(pe), float(pscale), int(n), ptr(v0), nv0, float(gamma),
@@ -502,6 +507,73 @@ class Context:
         n, ms, b, f = c_long(0), c_double(0), c_double(0), c_double(0)
         check(_lib.lib().sella_prof_get(self._h, int(kind), byref(n), byref(ms), byref(b), byref(f)))
         return dict(launches=n.value, ms=ms.value, bytes=b.value, flops=f.value)
+
+
+class DeviceCalculator:
+    """A calculator that lives in the library (`sella_calc_*`, csrc/calc.hip): energy and gradient without a
+    host-language frame, so that the finite-difference products of an iterative diagonalisation are library calls."""
+
+    def __init__(self, ctx, handle, keep=()):
+        self.ctx, self._h, self._keep = ctx, handle, keep
+        self._fin = weakref.finalize(self, _lib.lib().sella_calc_destroy, handle)
+
+    @classmethod
+    def model(cls, ctx, A, U, c):
+        U = as_f64(U)
+        h = c_void_p()
+        check(_lib.lib().sella_calc_model_create(ctx._h, A.handle, ptr(U), U.shape[0], U.shape[1], float(c), byref(h)))
+        return cls(ctx, h, (A,))
+
+    @classmethod
+    def emt(cls, ctx, natoms, par, shifts, rc, acut, cutoff, beta):
+        par, shifts = as_f64(par), as_f64(shifts)
+        h = c_void_p()
+        check(_lib.lib().sella_calc_emt_create(ctx._h, int(natoms), ptr(par), shifts.shape[0], ptr(shifts), float(rc),
+                                               float(acut), float(cutoff), float(beta), byref(h)))
+        return cls(ctx, h)
+
+    def eval(self, x):
+        x = as_f64(x).ravel()
+        e = c_double(0.0)
+        g = np.empty(x.size)
+        check(_lib.lib().sella_calc_eval(self._h, ptr(x), byref(e), ptr(g)))
+        return e.value, g
+
+    ncalls = property(lambda self: int(_lib.lib().sella_calc_ncalls(self._h)))
+
+
+class DeviceFdOperator:
+    """`NumericalHessian` (sella/linalg.py:14-101) over a `DeviceCalculator`: `sella_fd_*`.  Passed to `Context.davidson`
+    as the operator; `Vs` / `AVs` afterwards hold the recorded secant pairs (full space, one column per product)."""
+
+    def __init__(self, calc, x0, g0, eta, threepoint=False, free=None):
+        x0, g0 = as_f64(x0).ravel(), as_f64(g0).ravel()
+        self.calc, self.ntrue = calc, x0.size
+        self._free = None if free is None else np.ascontiguousarray(free, dtype=np.int32)
+        n = self.ntrue if self._free is None else len(self._free)
+        self.shape = (n, n)
+        h = c_void_p()
+        check(_lib.lib().sella_fd_create(calc._h, self.ntrue, ptr(x0), ptr(g0), float(eta), int(bool(threepoint)),
+                                         None if self._free is None else self._free.ctypes.data_as(c_void_p),
+                                         0 if self._free is None else len(self._free), byref(h)))
+        self._h = h
+        self._fin = weakref.finalize(self, _lib.lib().sella_fd_destroy, h)
+
+    def callback(self):
+        """`sella_fd_matvec` as the `sella_matvec_fn` of `sella_davidson` (a function of the library itself)."""
+        return ctypes.cast(_lib.lib().sella_fd_matvec, _lib.MATVEC_FN)
+
+    calls = property(lambda self: int(_lib.lib().sella_fd_calls(self._h)))
+
+    def _pairs(self):
+        k = int(_lib.lib().sella_fd_npairs(self._h))
+        Vs, AVs = np.empty((self.ntrue, k)), np.empty((self.ntrue, k))
+        if k:
+            check(_lib.lib().sella_fd_pairs(self._h, ptr(Vs), ptr(AVs)))
+        return Vs, AVs
+
+    Vs = property(lambda self: self._pairs()[0])
+    AVs = property(lambda self: self._pairs()[1])
 
 
 class OptStep:

@@ -6,7 +6,7 @@ finite-difference Hessian lives behind the calculator boundary.
 """
 import numpy as np
 
-from .device import DeviceMatrix, get_context
+from .device import DeviceFdOperator, DeviceMatrix, get_context
 from .linalg import ApproximateHessian
 
 
@@ -103,7 +103,7 @@ def rayleigh_ritz(A, gamma, P, B=None, v0=None, vref=None, vreftol=0.99,
         own_A = False
         if isinstance(A, np.ndarray):
             op, own_A = ctx.upload(A), True
-        elif isinstance(A, DeviceMatrix):
+        elif isinstance(A, (DeviceMatrix, DeviceFdOperator)):
             op = A
         else:
             def op(v, _A=A):

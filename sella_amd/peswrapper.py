@@ -400,7 +400,9 @@ class PES:
                 v0 = None
         else:
             v0 = None
-        Hproj = NumericalHessian(self._calc_eg, self.get_x(), self.get_g(), self.eta, threepoint, Ufree)
+        Hproj = self._library_fd_operator(Ufree, threepoint)
+        if Hproj is None:
+            Hproj = NumericalHessian(self._calc_eg, self.get_x(), self.get_g(), self.eta, threepoint, Ufree)
         A = Hproj
         Hc = None
         if self._has_curved_constraints():
@@ -411,6 +413,8 @@ class PES:
         rayleigh_ritz(A, gamma, None if P_is_none else P, v0=v0, method=self.eigensolver, maxiter=maxiter)
 
         Vs, AVs = Hproj.Vs, Hproj.AVs
+        if not isinstance(Hproj, NumericalHessian):
+            self.neval += Hproj.calls * (2 if threepoint else 1)     # force calls the library made itself
         # Ritz vectors of the collected full-space iterates (peswrapper.py:545-551)
         Atilde = Vs.T @ symmetrize_Y(Vs, AVs, symm=2)
         if Hc is not None:
@@ -418,6 +422,29 @@ class PES:
         _, X = eigh(Atilde)
         self.H.update(Vs @ X, AVs @ X)
         self.first_diag = False
+
+    def _library_fd_operator(self, Ufree, threepoint):
+        """The finite-difference Hessian as a library object (`sella_fd_*`) when the calculator itself lives in the
+        library (`atoms.calc.device_calculator()`): the force calls of the Davidson run are then library calls, with no
+        interpreter frame between them.  Needs a basis that is the identity or a selection of coordinates, no curved
+        constraints, and nobody listening per force call (a trajectory writes one image per call, peswrapper.py:409-418)."""
+        from .utilities.math import selection_of
+        calc = getattr(self.atoms, 'calc', None)
+        maker = getattr(calc, 'device_calculator', None)
+        if maker is None or self.traj is not None or self._has_curved_constraints() or type(self) is not PES:
+            return None
+        if getattr(self, 'use_library_calculator', True) is False:
+            return None
+        free = None
+        if not is_identity(Ufree):
+            free = selection_of(Ufree)
+            if free is None:
+                return None
+        dc = maker()
+        if dc is None:
+            return None
+        from .device import DeviceFdOperator
+        return DeviceFdOperator(dc, self.get_x(), self.get_g(), self.eta, threepoint, free)
 
     def get_projected_forces(self):
         g = self.get_g()

@@ -26,7 +26,7 @@ def member(i):
     Ui = rngi.normal(size=(8, ne))
     Ui /= np.linalg.norm(Ui, axis=1)[:, None]
     at = Atoms(['X'] * (ne // 3), 0.05 * rngi.normal(size=(ne // 3, 3)), pbc=True)
-    at.calc = QuadraticCubicModel(lambda x, dAi=dAi: ctx.symm_mm(dAi, x), Ui, c=0.05)
+    at.calc = QuadraticCubicModel(lambda x, dAi=dAi: ctx.symm_mm(dAi, x), Ui, c=0.05, device_matrix=dAi)
     return at
 
 

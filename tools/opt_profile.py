@@ -24,7 +24,7 @@ if __name__ == '__main__':
     U = rng.normal(size=(8, n))
     U /= np.linalg.norm(U, axis=1)[:, None]
     atoms = Atoms(['X'] * (n // 3), 0.05 * rng.normal(size=(n // 3, 3)), pbc=True)
-    atoms.calc = QuadraticCubicModel(lambda x: ctx.symm_mm(dA, x), U, c=0.05)
+    atoms.calc = QuadraticCubicModel(lambda x: ctx.symm_mm(dA, x), U, c=0.05, device_matrix=dA)
     opt = Sella(atoms, order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', logfile=None,
                 constraints=Constraints(atoms), proj_trans=False)
     opt.run(fmax=0.0, steps=2)

@@ -392,6 +392,33 @@ long sella_fd_calls(sella_fd* fd);
 int sella_fd_pairs(sella_fd* fd, double* Vs, double* AVs);
 int sella_fd_destroy(sella_fd* fd);
 
+/* ---- a whole search in the library --------------------------------------------------------------------------- */
+/* `Sella(atoms, ...).run(fmax, steps)` (sella/optimize/optimize.py:42-440 under ASE's Optimizer.irun) for the
+ * configuration an ensemble of independent searches consists of (BASELINE configs[3]): Cartesian PES, no constraints or
+ * pinned coordinates (idx / m: the free ones), a calculator of the library (sella_calc_*), TS-BFGS, structured
+ * approximate Hessian, built-in step family and measure, eig = True.  The loop is the reference's — first-use
+ * diagonalisation (:318-326), restricted step, kick, re-diagonalisation rule (:363-378), trust-radius rule (:413-434),
+ * convergence on the largest per-atom projected force (peswrapper.py:438-441) — made of the entry points above
+ * (sella_davidson over sella_fd_matvec, sella_update_h_lr, sella_lr_restrict, sella_opt_step); the host language is not
+ * entered between creation and return, so one host thread per replica can drive one GPU.  SELLA_E_UNSUPPORTED: the
+ * search left the covered configuration (explicit rank beyond 0.4 n, ...): the caller continues with the general driver.
+ *   cons: 0 trust region (delta0 = per-coordinate radius x free coordinates, optimize.py:183-186), 1 per-atom measure.  */
+typedef struct sella_search sella_search;
+typedef struct sella_search_params_t {
+    int order, eig, threepoint, dav_method, stepper_kind, cons, update_method, symm, nsteps_per_diag;
+    long diag_every_n;                         /* < 0: never */
+    double eta, gamma, delta0, delta_min, sigma_inc, sigma_dec, rho_inc, rho_dec;
+} sella_search_params_t;
+int sella_search_create(sella_ctx* ctx, sella_calc* calc, int n, const double* x0, const int* idx, int m,
+                        const sella_search_params_t* params, sella_search** search);
+/* energy and gradient (dE/dx, n) at the starting point, if the caller evaluated them already (counts as a force call) */
+int sella_search_seed(sella_search* search, double energy, const double* grad);
+int sella_search_run(sella_search* search, double fmax, long steps, int* converged);
+/* x, g (n each, may be NULL); scalars[5] = f, fmax, delta, rho, lowest eigenvalue of the approximate Hessian;
+ * counters[5] = optimizer steps, force calls, one-call steps, explicit rank, explicit rank of the view (-1: none)     */
+int sella_search_state(sella_search* search, double* x, double* g, double* scalars, long* counters);
+int sella_search_destroy(sella_search* search);
+
 /* ---- profiling hooks (bench.py roofline leg) ---------------------------------------------- */
 /* When enabled, every launch of the big streaming kernels is bracketed by hipEvents on the
  * context stream.  kind: 0 = row-panel matvec (n x n streams), 1 = gemm, 2 = update, 3 = other,

@@ -42,6 +42,15 @@ class OptStepArgs(ctypes.Structure):
     ]
 
 
+class SearchParams(ctypes.Structure):
+    """`sella_search_params_t` of include/sella_hip.h."""
+    _fields_ = [('order', c_int), ('eig', c_int), ('threepoint', c_int), ('dav_method', c_int), ('stepper_kind', c_int),
+                ('cons', c_int), ('update_method', c_int), ('symm', c_int), ('nsteps_per_diag', c_int),
+                ('diag_every_n', c_long),
+                ('eta', c_double), ('gamma', c_double), ('delta0', c_double), ('delta_min', c_double),
+                ('sigma_inc', c_double), ('sigma_dec', c_double), ('rho_inc', c_double), ('rho_dec', c_double)]
+
+
 # name -> (restype, argtypes); mirrors include/sella_hip.h one to one
 SIGNATURES = {
     'sella_last_error': (c_char_p, []),
@@ -112,6 +121,12 @@ SIGNATURES = {
     'sella_fd_calls': (c_long, [c_void_p]),
     'sella_fd_pairs': (c_int, [c_void_p, c_void_p, c_void_p]),
     'sella_fd_destroy': (c_int, [c_void_p]),
+    'sella_search_create': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, POINTER(SearchParams),
+                                    POINTER(c_void_p)]),
+    'sella_search_seed': (c_int, [c_void_p, c_double, c_void_p]),
+    'sella_search_run': (c_int, [c_void_p, c_double, c_long, c_int_p]),
+    'sella_search_state': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'sella_search_destroy': (c_int, [c_void_p]),
     'sella_opt_step': (c_int, [c_void_p, POINTER(OptStepArgs)]),
     'sella_lr_materialize': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_double]),
     'sella_stepper_get_s': (c_int, [c_void_p, c_double, c_void_p, c_void_p]),

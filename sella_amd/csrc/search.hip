@@ -1,0 +1,405 @@
+// A whole saddle-point search as library calls: `Sella.run` (sella/optimize/optimize.py:317-440 driven by ASE's
+// Optimizer.irun) for the configuration the ensemble of BASELINE configs[3] consists of — Cartesian PES
+// (sella/peswrapper.py:214-607), no constraints or constraints that pin single coordinates, a calculator that lives in the
+// library (calc.hip), approximate Hessian in structured form (eigh.hip / lrstep.hip), built-in step family and measure.
+//
+// Nothing here is new arithmetic: the loop strings together the entry points the host-language driver calls —
+// sella_davidson over sella_fd_matvec (PES.diag, peswrapper.py:508-556), sella_symmetrize_y and the secant-pair
+// rotation of :545-553, sella_update_h_lr for the block update (linalg.py:274-304), sella_lr_restrict for the view of
+// pinned coordinates (peswrapper.py:363-386), sella_opt_step for every optimizer step — with the reference's schedule
+// (first-use diagonalisation, optimize.py:318-326; re-diagonalisation rule, :363-378; convergence test of
+// peswrapper.py:438-441) in between.  What it removes is the interpreter: a 3N = 768 member spends ~10,000 host-language
+// function calls per search, a third of its wall time, and — holding the interpreter lock — keeps host threads from
+// sharing a GPU.  With the search in the library one thread per replica scales like the launch-and-wait loops of
+// tools/lab/wait_lab.hip.
+#include "internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+using namespace sella;
+
+struct sella_search {
+    sella_ctx* c = nullptr;
+    sella_calc* calc = nullptr;
+    int n = 0, m = 0;
+    std::vector<int> idx;                       // free coordinates (empty: all n)
+    sella_search_params_t p;
+    // point
+    std::vector<double> x, g, gold, s, dx, target;
+    double f = 0.0, delta = 0.0, rho = 1.0, smag = 0.0;
+    bool have_fg = false, initialized = false, first_diag = true, have_step = false;
+    long nsteps_since_diag = 0, nsteps = 0, neval = 0, nfused = 0;
+    // approximate Hessian: structured form (+ view of the free coordinates)
+    bool H_none = true, have_view = false;
+    sella_mat B = SELLA_NO_MAT, Wt = SELLA_NO_MAT, Bsub = SELLA_NO_MAT, Wt_sub = SELLA_NO_MAT;
+    int r = 0, r_sub = 0, cap = 0, cap_sub = 0, rank_limit = 0, rank_limit_sub = 0;
+    std::vector<double> mu, mu_sub;
+    double lam0 = 0.0;
+    int B_stale = 0, Bsub_stale = 0;
+    sella_opt_step_t io;
+};
+
+namespace {
+
+int rank_limit_of(int dim) { return std::max(std::max(1, (int)(0.4 * dim)), 8); }      // linalg.py LR_MAX_FRACTION
+
+int evaluate(sella_search* S) {
+    SCHK(sella_calc_eval(S->calc, S->x.data(), &S->f, S->g.data()));
+    ++S->neval;
+    S->have_fg = true;
+    return SELLA_OK;
+}
+
+// peswrapper.py:438-441: largest per-atom norm of the projected forces (pinned coordinates carry none)
+double fmax_now(const sella_search* S) {
+    std::vector<char> freec;
+    if (!S->idx.empty()) {
+        freec.assign(S->n, 0);
+        for (int q : S->idx) freec[q] = 1;
+    }
+    double best = 0.0;
+    for (int a = 0; a + 2 < S->n; a += 3) {
+        double s2 = 0.0;
+        for (int d = 0; d < 3; ++d) {
+            const double v = (freec.empty() || freec[a + d]) ? S->g[a + d] : 0.0;
+            s2 += v * v;
+        }
+        best = std::max(best, std::sqrt(s2));
+    }
+    return best;
+}
+
+int ensure_view(sella_search* S) {
+    if (S->idx.empty() || S->have_view || S->H_none) return SELLA_OK;
+    if (S->r > 256) { set_error("search: explicit rank %d too large for a structured view", S->r); return SELLA_E_UNSUPPORTED; }
+    SCHK(sella_mat_alloc(S->c, S->cap_sub, S->m, &S->Wt_sub));
+    SCHK(sella_mat_alloc(S->c, S->m, S->m, &S->Bsub));
+    S->mu_sub.assign((size_t)S->cap_sub, 0.0);
+    SCHK(sella_lr_restrict(S->c, S->Wt, S->r, S->mu.data(), S->lam0, S->idx.data(), S->m, S->Wt_sub, &S->r_sub,
+                           S->mu_sub.data()));
+    S->Bsub_stale = 1;                           // the matrix itself is rebuilt from the decomposition if ever needed
+    S->have_view = true;
+    return SELLA_OK;
+}
+
+// ApproximateHessian.update with a block of k secant pairs (linalg.py:274-304)
+int update_block(sella_search* S, const double* Sm, const double* Ym, int k) {
+    sella_ctx* c = S->c;
+    const int n = S->n;
+    if (S->H_none) {
+        if (2 * k > rank_limit_of(n)) { set_error("search: first update of rank %d exceeds the structured form", 2 * k); return SELLA_E_UNSUPPORTED; }
+        // B = lam0 I + update, lam0 the geometric mean |Ritz value| of S^T Ytilde (hessian_update.py:58-67)
+        std::vector<double> Yt((size_t)n * k), M((size_t)k * k, 0.0), th(k), Z((size_t)k * k), work(k);
+        if (k == 1 || S->p.symm < 0) Yt.assign(Ym, Ym + (size_t)n * k);
+        else SCHK(sella_symmetrize_y(c, Sm, Ym, n, k, S->p.symm, Yt.data()));
+        for (int i = 0; i < n; ++i)
+            for (int a = 0; a < k; ++a) {
+                const double sa = Sm[(size_t)i * k + a];
+                for (int b = 0; b < k; ++b) M[(size_t)a * k + b] += sa * Yt[(size_t)i * k + b];
+            }
+        if (small::sym_eig(k, M.data(), k, th.data(), Z.data(), k, work.data()) != 0) {
+            set_error("search: small eigenproblem did not converge");
+            return SELLA_E_NOCONV;
+        }
+        double acc = 0.0;
+        for (int a = 0; a < k; ++a) acc += std::log(std::max(std::fabs(th[a]), 1e-12));
+        S->lam0 = std::exp(acc / k);
+        SCHK(sella_mat_alloc(c, n, n, &S->B));
+        SCHK(sella_mat_add_diag(c, S->B, S->lam0));
+        SCHK(sella_mat_alloc(c, S->cap, n, &S->Wt));
+        S->mu.assign((size_t)S->cap, 0.0);
+        S->r = 0;
+        int nr1 = 0;
+        SCHK(sella_update_h_lr(c, S->B, S->Wt, &S->r, S->mu.data(), S->lam0, Sm, Ym, n, k, S->p.update_method, S->p.symm, &nr1,
+                               SELLA_NO_MAT, SELLA_NO_MAT, nullptr, nullptr, nullptr, 0, nullptr));
+        S->H_none = false;
+        S->B_stale = 0;
+        return SELLA_OK;
+    }
+    if (S->r + 2 * k > S->rank_limit || S->r + 2 * k + 4 > S->cap) {
+        set_error("search: explicit rank %d + %d leaves the structured form", S->r, 2 * k);
+        return SELLA_E_UNSUPPORTED;
+    }
+    if (S->B_stale) { SCHK(sella_lr_materialize(c, S->B, S->Wt, S->r, S->mu.data(), S->lam0)); S->B_stale = 0; }
+    int nr1 = 0, nr1s = 0;
+    if (S->have_view) {
+        if (S->r_sub + 2 * k > S->rank_limit_sub || S->r_sub + 2 * k + 4 > S->cap_sub) {
+            set_error("search: explicit rank of the view %d + %d leaves the structured form", S->r_sub, 2 * k);
+            return SELLA_E_UNSUPPORTED;
+        }
+        if (S->Bsub_stale) {
+            SCHK(sella_lr_materialize(c, S->Bsub, S->Wt_sub, S->r_sub, S->mu_sub.data(), S->lam0));
+            S->Bsub_stale = 0;
+        }
+        return sella_update_h_lr(c, S->B, S->Wt, &S->r, S->mu.data(), S->lam0, Sm, Ym, n, k, S->p.update_method, S->p.symm, &nr1,
+                                 S->Bsub, S->Wt_sub, &S->r_sub, S->mu_sub.data(), S->idx.data(), S->m, &nr1s);
+    }
+    return sella_update_h_lr(c, S->B, S->Wt, &S->r, S->mu.data(), S->lam0, Sm, Ym, n, k, S->p.update_method, S->p.symm, &nr1,
+                             SELLA_NO_MAT, SELLA_NO_MAT, nullptr, nullptr, nullptr, 0, nullptr);
+}
+
+// PES.diag (peswrapper.py:508-556): Davidson on the finite-difference Hessian in the free coordinates, preconditioned
+// by the projected approximate Hessian; every product becomes a secant pair of the block update afterwards
+int diagonalise(sella_search* S) {
+    sella_ctx* c = S->c;
+    const int n = S->n, m = S->m;
+    if (m == 0) return SELLA_OK;
+    SCHK(ensure_view(S));
+    const bool pins = !S->idx.empty();
+    // preconditioner: structured decomposition of the projected Hessian
+    sella_mat hP = SELLA_NO_MAT, hPt = SELLA_NO_MAT;
+    const double* pevals = nullptr;
+    double pscale = 1.0;
+    int rP = 0;
+    if (!S->H_none) {
+        const sella_mat src = pins ? S->Wt_sub : S->Wt;
+        rP = pins ? S->r_sub : S->r;
+        pevals = pins ? S->mu_sub.data() : S->mu.data();
+        pscale = S->lam0;
+        if (rP > 0) {
+            SCHK(sella_mat_rows(c, src, 0, rP, &hPt));
+            int st = sella_mat_transpose(c, hPt, &hP);
+            if (st != SELLA_OK) { sella_mat_free(c, hPt); return st; }
+        }
+    }
+    auto cleanup = [&](int code) {
+        if (hP != SELLA_NO_MAT) sella_mat_free(c, hP);
+        if (hPt != SELLA_NO_MAT) sella_mat_free(c, hPt);
+        return code;
+    };
+    // start block (peswrapper.py:518-525, eigensolvers.py:43-50)
+    std::vector<double> start;
+    int nv0 = 0;
+    if (S->H_none || S->first_diag) {
+        double nrm = 0.0;
+        start.resize((size_t)m);
+        for (int q = 0; q < m; ++q) { start[q] = S->g[pins ? S->idx[q] : q]; nrm += start[q] * start[q]; }
+        nv0 = std::sqrt(nrm) < 1e-12 ? 0 : 1;
+    }
+    if (nv0 == 0) {
+        if (rP > 0) {
+            int nneg = 0;
+            for (int i = 0; i < rP; ++i) nneg += pevals[i] < 0.0 ? 1 : 0;
+            nneg = std::max(1, nneg);
+            std::vector<double> rows((size_t)rP * m);
+            int st = sella_mat_download(c, hPt, rows.data());
+            if (st != SELLA_OK) return cleanup(st);
+            start.assign((size_t)m * nneg, 0.0);
+            for (int j = 0; j < nneg; ++j)
+                for (int i = 0; i < m; ++i) start[(size_t)i * nneg + j] = rows[(size_t)j * m + i];
+            nv0 = nneg;
+        } else {
+            start.assign((size_t)m, 0.0);
+            start[0] = 1.0;
+            nv0 = 1;
+        }
+    }
+    sella_fd* fd = nullptr;
+    {
+        int st = sella_fd_create(S->calc, n, S->x.data(), S->g.data(), S->p.eta, S->p.threepoint, pins ? S->idx.data() : nullptr,
+                                 pins ? m : 0, &fd);
+        if (st != SELLA_OK) return cleanup(st);
+    }
+    const int maxiter = 2 * m + 1;
+    const int kmax = std::min(m, std::max(maxiter, nv0));
+    std::vector<double> lams((size_t)kmax + 1), V((size_t)m * (kmax + 1)), AV((size_t)m * (kmax + 1));
+    int k = 0, nmv = 0;
+    int st = sella_davidson(c, SELLA_NO_MAT, sella_fd_matvec, fd, hP, hPt, rP > 0 ? pevals : nullptr, pscale, m, start.data(), nv0,
+                            S->p.gamma, S->p.dav_method, maxiter, nullptr, 0.99, lams.data(), V.data(), AV.data(), &k, &nmv);
+    S->neval += sella_fd_calls(fd) * (S->p.threepoint ? 2 : 1);
+    if (st != SELLA_OK) { sella_fd_destroy(fd); return cleanup(st); }
+    const int kp = sella_fd_npairs(fd);
+    std::vector<double> Vs((size_t)n * kp), AVs((size_t)n * kp);
+    st = kp > 0 ? sella_fd_pairs(fd, Vs.data(), AVs.data()) : SELLA_OK;
+    sella_fd_destroy(fd);
+    cleanup(SELLA_OK);
+    if (st != SELLA_OK) return st;
+    if (kp == 0) { S->first_diag = false; return SELLA_OK; }
+    // Ritz rotation of the collected iterates (peswrapper.py:545-551): Atilde = Vs^T symmetrize_Y(Vs, AVs, 2)
+    std::vector<double> Yt((size_t)n * kp), At((size_t)kp * kp, 0.0), w(kp), X((size_t)kp * kp), work(kp);
+    if (kp == 1) Yt = AVs;
+    else SCHK(sella_symmetrize_y(c, Vs.data(), AVs.data(), n, kp, 2, Yt.data()));
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < kp; ++a) {
+            const double va = Vs[(size_t)i * kp + a];
+            for (int b = 0; b < kp; ++b) At[(size_t)a * kp + b] += va * Yt[(size_t)i * kp + b];
+        }
+    if (small::sym_eig(kp, At.data(), kp, w.data(), X.data(), kp, work.data()) != 0) {
+        set_error("search: Ritz eigenproblem did not converge");
+        return SELLA_E_NOCONV;
+    }
+    std::vector<double> Sm((size_t)n * kp, 0.0), Ym((size_t)n * kp, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < kp; ++a) {
+            const double va = Vs[(size_t)i * kp + a], ya = AVs[(size_t)i * kp + a];
+            for (int b = 0; b < kp; ++b) {
+                Sm[(size_t)i * kp + b] += va * X[(size_t)a * kp + b];
+                Ym[(size_t)i * kp + b] += ya * X[(size_t)a * kp + b];
+            }
+        }
+    SCHK(update_block(S, Sm.data(), Ym.data(), kp));
+    S->first_diag = false;
+    return SELLA_OK;
+}
+
+// optimize.py:363-378
+bool wants_diagonalisation(const sella_search* S) {
+    if (S->p.diag_every_n >= 0 && S->nsteps_since_diag >= S->p.diag_every_n) return true;
+    if (!(S->p.eig && S->nsteps_since_diag >= S->p.nsteps_per_diag)) return false;
+    if (S->H_none) return true;
+    std::vector<double> pool(S->mu.begin(), S->mu.begin() + S->r);
+    const int ncl = std::min(S->p.order, S->n - S->r);
+    for (int q = 0; q < ncl; ++q) pool.push_back(S->lam0);
+    std::sort(pool.begin(), pool.end());
+    for (int q = 0; q < S->p.order && q < (int)pool.size(); ++q)
+        if (pool[q] > 0.0) return true;
+    return false;
+}
+
+int call_opt_step(sella_search* S, int flags, double f_old) {
+    sella_opt_step_t& a = S->io;
+    const bool pins = !S->idx.empty();
+    if ((flags & SELLA_OPT_LEARN) || pins) SCHK(ensure_view(S));
+    if (S->r + 4 > S->rank_limit || S->r + 4 > S->cap || (pins && (S->r_sub + 4 > S->rank_limit_sub || S->r_sub + 4 > S->cap_sub))) {
+        set_error("search: explicit rank leaves the structured form (%d of %d)", S->r, S->rank_limit);
+        return SELLA_E_UNSUPPORTED;
+    }
+    a.flags = flags;
+    a.n = S->n;
+    a.B = S->B; a.Wt = S->Wt; a.r = &S->r; a.mu = S->mu.data(); a.lam0 = S->lam0;
+    a.update_method = S->p.update_method; a.symm = S->p.symm;
+    a.B_stale = S->B_stale; a.Bsub_stale = S->Bsub_stale;
+    if (pins) {
+        a.Bsub = S->Bsub; a.Wt_sub = S->Wt_sub; a.r_sub = &S->r_sub; a.mu_sub = S->mu_sub.data(); a.idx = S->idx.data(); a.m = S->m;
+    } else {
+        a.Bsub = SELLA_NO_MAT; a.Wt_sub = SELLA_NO_MAT; a.r_sub = nullptr; a.mu_sub = nullptr; a.idx = nullptr; a.m = 0;
+    }
+    a.dx = S->dx.data(); a.g_old = S->gold.data(); a.g_new = S->g.data();
+    a.f_old = f_old; a.f_new = S->f; a.smag = S->smag;
+    a.delta = S->delta; a.rho = S->rho;
+    a.delta_min = S->p.delta_min; a.sigma_inc = S->p.sigma_inc; a.sigma_dec = S->p.sigma_dec;
+    a.rho_inc = S->p.rho_inc; a.rho_dec = S->p.rho_dec;
+    a.stepper_kind = S->p.stepper_kind; a.order = S->p.order; a.cons = S->p.cons; a.maxiter = 1000;
+    a.tol = S->p.stepper_kind == SELLA_STEP_QN ? 1e-10 : 1e-15;
+    a.s_out = S->s.data();
+    SCHK(sella_opt_step(S->c, &a));
+    S->B_stale = a.B_stale;
+    S->Bsub_stale = a.Bsub_stale;
+    if (flags & SELLA_OPT_LEARN) { S->delta = a.delta; S->rho = a.rho; ++S->nfused; }
+    if (flags & SELLA_OPT_PROPOSE) { S->smag = a.smag_out; S->have_step = true; }
+    return SELLA_OK;
+}
+
+// Sella.step (optimize.py:359-440)
+int one_step(sella_search* S) {
+    if (!S->initialized) {                                   // optimize.py:318-326
+        if (S->p.eig) {
+            SCHK(diagonalise(S));
+            S->nsteps_since_diag = -1;
+        }
+        S->initialized = true;
+    }
+    if (S->H_none) { set_error("search: a step without curvature information (eig = False) is not covered"); return SELLA_E_UNSUPPORTED; }
+    if (!S->have_step) SCHK(call_opt_step(S, SELLA_OPT_PROPOSE, S->f));
+    const bool rediag = wants_diagonalisation(S);
+    S->nsteps_since_diag = rediag ? 0 : S->nsteps_since_diag + 1;
+    // PES.kick (peswrapper.py:578-602): move, force call, then everything else in one library call
+    const double f_old = S->f;
+    S->gold = S->g;
+    for (int i = 0; i < S->n; ++i) {
+        S->target[i] = S->x[i] + S->s[i];
+        S->dx[i] = S->target[i] - S->x[i];
+    }
+    S->x = S->target;
+    SCHK(evaluate(S));
+    S->have_step = false;
+    SCHK(call_opt_step(S, SELLA_OPT_LEARN | (rediag ? 0 : SELLA_OPT_PROPOSE), f_old));
+    if (rediag) SCHK(diagonalise(S));
+    return SELLA_OK;
+}
+
+}  // namespace
+
+extern "C" int sella_search_create(sella_ctx* c, sella_calc* calc, int n, const double* x0, const int* idx, int m,
+                                   const sella_search_params_t* p, sella_search** out) {
+    if (!c || !calc || !x0 || !p || !out || n <= 0 || n % 3 != 0 || sella_calc_dim(calc) != n || (idx && (m <= 0 || m > n))) {
+        set_error("search: invalid arguments");
+        return SELLA_E_INVALID;
+    }
+    if (p->update_method != SELLA_UPD_TS_BFGS || p->cons < 0 || p->cons > 1 || p->stepper_kind < SELLA_STEP_QN ||
+        p->stepper_kind > SELLA_STEP_PRFO || !p->eig) {
+        set_error("search: configuration outside the library loop (TS-BFGS, trust region / per-atom measure, built-in families, eig)");
+        return SELLA_E_UNSUPPORTED;
+    }
+    sella_search* S = new sella_search();
+    S->c = c; S->calc = calc; S->n = n; S->p = *p;
+    if (idx) S->idx.assign(idx, idx + m);
+    S->m = idx ? m : n;
+    S->x.assign(x0, x0 + n);
+    S->g.assign(n, 0.0); S->gold.assign(n, 0.0); S->s.assign(n, 0.0); S->dx.assign(n, 0.0); S->target.assign(n, 0.0);
+    S->delta = p->delta0;
+    S->rho = 1.0;
+    S->rank_limit = rank_limit_of(n);
+    S->rank_limit_sub = rank_limit_of(S->m);
+    S->cap = std::min(n, S->rank_limit + 72);
+    S->cap_sub = std::min(S->m, S->rank_limit_sub + 72);
+    *out = S;
+    return SELLA_OK;
+}
+
+// Optimizer.irun: convergence first, then steps until converged or `steps` taken
+extern "C" int sella_search_run(sella_search* S, double fmax, long steps, int* converged) {
+    if (!S || !converged) return SELLA_E_INVALID;
+    *converged = 0;
+    if (!S->have_fg) SCHK(evaluate(S));
+    if (fmax_now(S) < fmax) { *converged = 1; return SELLA_OK; }
+    for (long it = 0; it < steps; ++it) {
+        SCHK(one_step(S));
+        ++S->nsteps;
+        if (fmax_now(S) < fmax) { *converged = 1; return SELLA_OK; }
+    }
+    return SELLA_OK;
+}
+
+// energy and gradient at the current point, if the caller has them already (counted as one force call)
+extern "C" int sella_search_seed(sella_search* S, double f, const double* g) {
+    if (!S || !g) return SELLA_E_INVALID;
+    S->f = f;
+    S->g.assign(g, g + S->n);
+    S->have_fg = true;
+    ++S->neval;
+    return SELLA_OK;
+}
+
+extern "C" int sella_search_state(sella_search* S, double* x, double* g, double* scalars, long* counters) {
+    if (!S) return SELLA_E_INVALID;
+    if (x) std::copy(S->x.begin(), S->x.end(), x);
+    if (g) std::copy(S->g.begin(), S->g.end(), g);
+    if (scalars) {
+        scalars[0] = S->f;
+        scalars[1] = S->have_fg ? fmax_now(S) : 0.0;
+        scalars[2] = S->delta;
+        scalars[3] = S->rho;
+        double lam = S->H_none ? NAN : S->lam0;              // lowest eigenvalue of the approximate Hessian
+        if (!S->H_none && S->r > 0 && (S->r == S->n || S->mu[0] < lam)) lam = S->mu[0];
+        scalars[4] = lam;
+    }
+    if (counters) {
+        counters[0] = S->nsteps;
+        counters[1] = S->neval;
+        counters[2] = S->nfused;
+        counters[3] = S->r;
+        counters[4] = S->have_view ? S->r_sub : -1;
+    }
+    return SELLA_OK;
+}
+
+extern "C" int sella_search_destroy(sella_search* S) {
+    if (!S) return SELLA_OK;
+    for (sella_mat h : {S->B, S->Wt, S->Bsub, S->Wt_sub})
+        if (h != SELLA_NO_MAT) sella_mat_free(S->c, h);
+    delete S;
+    return SELLA_OK;
+}

@@ -39,6 +39,10 @@ def rank_and_world():
     return comm.rank, comm.world
 
 
+# members whose configuration the library loop covers (sella_amd/search.py) run there; False: always the general driver
+USE_LIBRARY_SEARCH = os.environ.get('SELLA_LIBRARY_SEARCH', '1') != '0'
+
+
 def local_members(n_replicas, rank, world):
     """Round-robin assignment: replica r belongs to rank r mod world."""
     return list(range(rank, n_replicas, world))
@@ -53,6 +57,21 @@ def run_one(atoms, fmax, steps, sella_kwargs):
     if isinstance(atoms, tuple):
         atoms, own = atoms
         kw.update(own)
+    if USE_LIBRARY_SEARCH:
+        # the whole search inside the library when it is covered (sella_amd/search.py): no interpreter between the
+        # force calls, so that members on host threads overlap on the GPU
+        from .search import LibrarySearch, SearchLeftLibrary
+        if LibrarySearch.applies(atoms, **kw):
+            start = np.asarray(atoms.positions, dtype=np.float64).copy()
+            ls = LibrarySearch(atoms, **kw)
+            try:
+                conv = ls.run(fmax=fmax, steps=steps)
+                summary = np.array([1.0 if conv else 0.0, float(ls.nsteps), ls.energy, ls.fmax_now, ls.lambda_min])
+                return summary, np.asarray(atoms.positions, dtype=np.float64).copy()
+            except SearchLeftLibrary:
+                atoms.positions = start                      # from the beginning with the general driver
+            finally:
+                ls.close()
     opt = Sella(atoms, **kw)
     conv = opt.run(fmax=fmax, steps=steps)
     pes = opt.pes

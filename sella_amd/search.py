@@ -1,0 +1,159 @@
+"""`LibrarySearch` — a whole `Sella(atoms, ...).run(fmax, steps)` as library calls (`sella_search_*`, csrc/search.hip).
+
+The general driver (`sella_amd.optimize.optimize.Sella`) keeps the reference's module structure and crosses into the
+library ~100 times per optimizer step and ~300 times per diagonalisation; for a small system that is where the time
+goes, and because the interpreter lock is held in between, host threads cannot share a GPU.  For the configuration an
+ensemble of independent searches consists of (BASELINE configs[3]) the same loop runs inside the library:
+
+    Cartesian PES, no constraints or constraints that pin single Cartesian coordinates (all satisfied);
+    a calculator that lives in the library (`atoms.calc.device_calculator()`: the model PES, device EMT);
+    3N >= `linalg.LR_MIN_DIM` (structured approximate Hessian), TS-BFGS, `rs` in {'tr', 'ras'}, built-in step families,
+    `eig=True`; no trajectory, no log, no observers.
+
+`LibrarySearch.applies(atoms, **kwargs)` says whether a set of `Sella` keywords is covered; `run_one`
+(sella_amd/ensemble.py) uses it for every member it can.  Results agree with the general driver's to the amplification
+of last-bit differences (tests/test_library_search.py).  If a search leaves the covered configuration on the way (its
+explicit rank passes 0.4 n) `run` raises `SearchLeftLibrary`; the atoms then hold the last geometry reached.
+"""
+import weakref
+from ctypes import byref, c_int, c_long, c_void_p
+
+import numpy as np
+
+from . import _lib, linalg
+from ._lib import SellaHipError, check, ptr
+from .device import CONSTRAINT_KINDS, DAVIDSON_METHODS, STEPPER_KINDS, UPDATE_METHODS, get_context
+from .optimize.optimize import _default_kwargs
+from .optimize.restricted_step import RestrictedAtomicStep, TrustRegion, get_restricted_step
+from .optimize.stepper import _all_steppers, get_stepper
+
+
+class SearchLeftLibrary(RuntimeError):
+    pass
+
+
+_COVERED = {'order', 'eta', 'gamma', 'delta0', 'sigma_inc', 'sigma_dec', 'rho_inc', 'rho_dec', 'rs', 'method', 'eig',
+            'threepoint', 'nsteps_per_diag', 'diag_every_n', 'constraints', 'proj_trans', 'proj_rot', 'logfile',
+            'trajectory', 'internal'}
+
+
+def _pinned_free(atoms, constraints, proj_trans, proj_rot):
+    """Free coordinates of a constraint set made of single-coordinate pins — None: unconstrained; False: not covered
+    (the defaults of `PES.__init__`, peswrapper.py:236-253, add a global translation / rotation constraint, whose
+    projection basis is not a selection of coordinates)."""
+    from .peswrapper import _pinned_coordinates
+    has_trans = constraints is not None and bool(constraints.internals['translations'])
+    if ((not has_trans) if proj_trans is None else proj_trans) or ((not np.any(atoms.pbc)) if proj_rot is None else proj_rot):
+        return False
+    if constraints is None:
+        return None
+    c = constraints
+    if (c.nbonds + c.nangles + c.ndihedrals) > 0 or c.has_inequalities() or c.internals['rotations']:
+        return False
+    drdx = c.jacobian()
+    if drdx.shape[0] == 0:
+        return None
+    pinned = _pinned_coordinates(drdx)
+    if pinned is None or np.any(c.residual()):
+        return False
+    return np.setdiff1d(np.arange(3 * len(atoms)), pinned[0]).astype(np.int32)
+
+
+class LibrarySearch:
+    @staticmethod
+    def applies(atoms, **kw):
+        if set(kw) - _COVERED or kw.get('trajectory') is not None or kw.get('logfile') is not None or kw.get('internal'):
+            return False
+        calc = getattr(atoms, 'calc', None)
+        if getattr(calc, 'device_calculator', None) is None:
+            return False
+        n = 3 * len(atoms)
+        if linalg.LR_MIN_DIM is None or n < linalg.LR_MIN_DIM:
+            return False
+        order = kw.get('order', 1)
+        table = _default_kwargs['minimum' if order == 0 else 'saddle']
+        if not (table['eig'] if kw.get('eig') is None else kw['eig']):
+            return False
+        try:
+            rs = get_restricted_step(kw['rs'] if kw.get('rs') is not None else 'ras')
+            method = kw.get('method') or table['method']
+            family = method if isinstance(method, type) else get_stepper(method.lower())
+        except ValueError:
+            return False
+        if rs not in (TrustRegion, RestrictedAtomicStep) or family not in _all_steppers:
+            return False
+        return _pinned_free(atoms, kw.get('constraints'), kw.get('proj_trans'), kw.get('proj_rot')) is not False
+
+    def __init__(self, atoms, order=1, eta=1e-4, gamma=0.1, delta0=None, sigma_inc=None, sigma_dec=None, rho_inc=None,
+                 rho_dec=None, rs=None, method=None, eig=None, threepoint=False, nsteps_per_diag=3, diag_every_n=None,
+                 constraints=None, proj_trans=None, proj_rot=None, logfile=None, trajectory=None, internal=False):
+        if not self.applies(atoms, order=order, rs=rs, method=method, eig=eig, constraints=constraints,
+                            proj_trans=proj_trans, proj_rot=proj_rot, logfile=logfile, trajectory=trajectory,
+                            internal=internal):
+            raise ValueError('this search is not covered by the library loop: use sella_amd.Sella')
+        self.atoms = atoms
+        table = _default_kwargs['minimum' if order == 0 else 'saddle']
+        pick = lambda v, key: table[key] if v is None else v          # noqa: E731
+        rs_name = rs if rs is not None else 'ras'
+        rs_cls = get_restricted_step(rs_name)
+        method = pick(method, 'method')
+        family = method if isinstance(method, type) else get_stepper(method.lower())
+        free = _pinned_free(atoms, constraints, proj_trans, proj_rot)
+        n = 3 * len(atoms)
+        nfree = n if free is None else len(free)
+        p = _lib.SearchParams()
+        p.order, p.eig, p.threepoint = int(order), 1, int(bool(threepoint))
+        p.dav_method = DAVIDSON_METHODS['jd0']
+        p.stepper_kind, p.cons = STEPPER_KINDS[family._kind], CONSTRAINT_KINDS[rs_cls.measure]
+        p.update_method, p.symm = UPDATE_METHODS['TS-BFGS'], 2
+        p.nsteps_per_diag = int(nsteps_per_diag)
+        p.diag_every_n = -1 if diag_every_n is None or not np.isfinite(diag_every_n) else int(diag_every_n)
+        p.eta, p.gamma = float(eta), float(gamma)
+        p.delta0 = float(pick(delta0, 'delta0')) * (nfree if rs_cls.measure == 'tr' else 1)          # optimize.py:183-186
+        p.delta_min = float(eta)
+        p.sigma_inc, p.sigma_dec = float(pick(sigma_inc, 'sigma_inc')), float(pick(sigma_dec, 'sigma_dec'))
+        p.rho_inc, p.rho_dec = float(pick(rho_inc, 'rho_inc')), float(pick(rho_dec, 'rho_dec'))
+        # the calculator has to know the species / cell before it can be handed to the library: the first force call is
+        # made here, through the host-language object, and handed over
+        f0 = float(atoms.get_potential_energy())
+        g0 = np.ascontiguousarray(-np.asarray(atoms.get_forces(), dtype=np.float64)).ravel()
+        self._calc = atoms.calc.device_calculator()
+        if self._calc is None:
+            raise ValueError('the calculator has no library form')
+        self._free = free
+        x0 = np.ascontiguousarray(atoms.positions, dtype=np.float64).ravel()
+        h = c_void_p()
+        ctx = get_context()
+        check(_lib.lib().sella_search_create(ctx._h, self._calc._h, n, ptr(x0),
+                                             None if free is None else free.ctypes.data_as(c_void_p),
+                                             0 if free is None else len(free), byref(p), byref(h)))
+        self._h, self._ctx, self._n = h, ctx, n
+        check(_lib.lib().sella_search_seed(h, f0, ptr(g0)))
+        # (finalizers run in reverse order of creation at interpreter exit: before the calculator's and the context's)
+        self._fin = weakref.finalize(self, _lib.lib().sella_search_destroy, h)
+        self.nsteps = 0
+        self._sync()
+
+    def _sync(self):
+        x, g = np.empty(self._n), np.empty(self._n)
+        sc, cn = np.zeros(5), (c_long * 5)()
+        check(_lib.lib().sella_search_state(self._h, ptr(x), ptr(g), ptr(sc), cn))
+        self.atoms.positions = x.reshape(-1, 3)
+        self.gradient = g
+        self.energy, self.fmax_now, self.delta, self.rho, self.lambda_min = (float(v) for v in sc)
+        self.nsteps, self.neval, self.one_call_steps, self.rank, self.rank_view = (int(v) for v in cn)
+
+    def run(self, fmax=0.05, steps=100000000):
+        conv = c_int(0)
+        try:
+            check(_lib.lib().sella_search_run(self._h, float(fmax), int(steps), byref(conv)))
+        except SellaHipError as e:
+            self._sync()
+            if getattr(e, 'status', None) == -7 or 'structured form' in str(e):
+                raise SearchLeftLibrary(str(e)) from None
+            raise
+        self._sync()
+        return bool(conv.value)
+
+    def close(self):
+        self._fin()

@@ -1,0 +1,111 @@
+"""`LibrarySearch` (sella_amd/search.py -> `sella_search_*`, csrc/search.hip): a whole `Sella(...).run()` inside the
+library — first-use diagonalisation through the library's own calculator, one-call optimizer steps, the reference's
+re-diagonalisation schedule — against the general driver on the same searches: same geometries, energies, radii,
+numbers of steps and force calls."""
+import numpy as np
+import pytest
+
+from conftest import hessian_like
+
+
+@pytest.fixture(autouse=True)
+def structured_from_96():
+    from sella_amd import linalg
+    old = linalg.LR_MIN_DIM
+    linalg.LR_MIN_DIM = 96
+    yield
+    linalg.LR_MIN_DIM = old
+
+
+def _model(ctx, n=120, seed=41):
+    from sella_amd.atoms import Atoms, QuadraticCubicModel
+    A = hessian_like(n, seed)[0]
+    dA = ctx.upload(A)
+    rng = np.random.RandomState(seed + 1)
+    U = rng.normal(size=(8, n))
+    U /= np.linalg.norm(U, axis=1)[:, None]
+    at = Atoms(['X'] * (n // 3), 0.05 * rng.normal(size=(n // 3, 3)), pbc=True)
+    at.calc = QuadraticCubicModel(lambda x: ctx.symm_mm(dA, x), U, c=0.05, device_matrix=dA)
+    return at
+
+
+KW = dict(order=1, eta=1e-4, gamma=0.1, delta0=0.1, proj_trans=False)
+
+
+@pytest.mark.parametrize('rs,nsteps_per_diag', [('tr', 3), ('ras', 2)])
+def test_model_search_in_the_library(ctx, rs, nsteps_per_diag):
+    from sella_amd import Sella
+    from sella_amd.internal import Constraints
+    from sella_amd.search import LibrarySearch
+    a1, a2 = _model(ctx), _model(ctx)
+    kw = dict(KW, rs=rs, nsteps_per_diag=nsteps_per_diag)
+    assert LibrarySearch.applies(a1, constraints=Constraints(a1), **kw)
+    ls = LibrarySearch(a1, constraints=Constraints(a1), **kw)
+    assert not ls.run(0.0, 5)
+    assert ls.run(0.0, 4) is False and ls.nsteps == 9          # a search can be continued
+    opt = Sella(a2, constraints=Constraints(a2), logfile=None, **kw)
+    opt.run(0.0, 9)
+    assert (ls.nsteps, ls.neval) == (opt.nsteps, opt.pes.neval)
+    assert a1.calc.ncalls == a2.calc.ncalls
+    np.testing.assert_allclose(a1.positions, a2.positions, atol=1e-8)
+    assert ls.energy == pytest.approx(opt.pes.get_f(), abs=1e-9)
+    assert ls.delta == pytest.approx(opt.delta, rel=1e-8) and ls.rho == pytest.approx(opt.rho, rel=1e-5)
+    assert ls.lambda_min == pytest.approx(opt.pes.H.evals[0], abs=1e-7)
+    assert ls.fmax_now == pytest.approx(opt.pes.converged(0.0)[1], abs=1e-8)
+    assert ls.one_call_steps == 9
+    # converges like the general driver does
+    ls.close()
+
+
+def test_pinned_slab_search_in_the_library(ctx):
+    """BASELINE configs[1] on a down-sized twin: EMT (library calculator), lower half pinned, default keywords."""
+    from conftest_shim import emt_slab
+    from sella_amd import Sella
+    from sella_amd.search import LibrarySearch
+    a1, c1, pinned = emt_slab((4, 4, 4))
+    a2, c2, _ = emt_slab((4, 4, 4))
+    start = a1.positions.copy()
+    ls = LibrarySearch(a1, constraints=c1, nsteps_per_diag=2)
+    ls.run(0.0, 7)
+    opt = Sella(a2, constraints=c2, logfile=None, nsteps_per_diag=2)
+    opt.run(0.0, 7)
+    assert (ls.nsteps, ls.neval) == (opt.nsteps, opt.pes.neval)
+    np.testing.assert_array_equal(a1.positions[pinned], start[pinned])
+    np.testing.assert_allclose(a1.positions, a2.positions, atol=1e-9)
+    assert ls.energy == pytest.approx(opt.pes.get_f(), abs=1e-9)
+    assert ls.delta == pytest.approx(opt.delta, rel=1e-8)
+    assert ls.rank_view > 0
+
+
+def test_library_search_says_what_it_covers(ctx):
+    from conftest_shim import emt_slab
+    from sella_amd.atoms import Atoms, MorseCluster
+    from sella_amd.internal import Constraints
+    from sella_amd.search import LibrarySearch
+    at = _model(ctx)
+    assert not LibrarySearch.applies(at, constraints=Constraints(at))                 # default: global translation constraint
+    assert not LibrarySearch.applies(at, constraints=Constraints(at), proj_trans=False, trajectory='x.traj')
+    assert not LibrarySearch.applies(at, constraints=Constraints(at), proj_trans=False, order=0)     # eig=False by default
+    assert not LibrarySearch.applies(at, constraints=Constraints(at), proj_trans=False, rs='mis')
+    mc = Atoms(['Xe'] * 40, np.random.RandomState(0).normal(size=(40, 3)), pbc=True)
+    mc.calc = MorseCluster()
+    assert not LibrarySearch.applies(mc, constraints=Constraints(mc), proj_trans=False)            # host-language calculator
+    slab, cons, _ = emt_slab((4, 4, 4))
+    cons.fix_bond((0, 1))
+    assert not LibrarySearch.applies(slab, constraints=cons)
+    with pytest.raises(ValueError):
+        LibrarySearch(at, constraints=Constraints(at))
+
+
+def test_run_one_takes_the_library_route(ctx, monkeypatch):
+    from sella_amd import ensemble
+    from sella_amd.internal import Constraints
+    kw = dict(KW, rs='tr')
+    a1, a2 = _model(ctx), _model(ctx)
+    monkeypatch.setattr(ensemble, 'USE_LIBRARY_SEARCH', True)
+    s1, p1 = ensemble.run_one((a1, dict(constraints=Constraints(a1))), 0.0, 6, kw)
+    monkeypatch.setattr(ensemble, 'USE_LIBRARY_SEARCH', False)
+    s2, p2 = ensemble.run_one((a2, dict(constraints=Constraints(a2))), 0.0, 6, kw)
+    np.testing.assert_allclose(p1, p2, atol=1e-8)
+    np.testing.assert_allclose(s1, s2, atol=1e-7)
+    assert s1[1] == 6 and s1[4] < 0

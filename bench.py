@@ -76,7 +76,7 @@ class EnsembleMember:
         range, so that code objects, scratch and pinned buffers exist — what the earlier legs do for the parent."""
         from sella_amd.ensemble import run_one
         run_one(self(-1), 0.0, 3, self.SELLA_KW)
-        del self.host[-1]
+        self.host.pop(-1, None)          # (several threads may warm up at once)
 
     def __call__(self, i):
         from sella_amd import device as _dev
@@ -109,7 +109,9 @@ def main():
     ap.add_argument('--ensemble-per-gpu', type=int, default=8)
     ap.add_argument('--ensemble-steps', type=int, default=20)
     ap.add_argument('--ensemble-n', type=int, default=768)
-    ap.add_argument('--ensemble-threads', type=int, default=1)
+    ap.add_argument('--ensemble-threads', type=int, default=-1,
+                    help='host threads per GPU for the ensemble leg (persistent contexts, sella_amd.ensemble.EnsembleThreads); '
+                         '-1: min(members per GPU, 8, 2 x CPUs per rank); 0 / 1: none')
     ap.add_argument('--ensemble-procs', type=int, default=-1,
                     help='worker processes per GPU for the ensemble leg (-1: min(members, 4, CPUs of this rank); 0/1: none)')
     ap.add_argument('--block-n', type=int, default=12288, help='configs[4] leg: operator size (0 disables)')
@@ -332,12 +334,22 @@ def main():
             from sella_amd.ensemble import EnsemblePool
             make_member = EnsembleMember(ne)
             mine_e = local_members(total, rank, world)
+            # Since the searches run inside the library (sella_amd/search.py: no interpreter between the force calls)
+            # host THREADS of this one process share the GPU — one persistent device context each — and that is the
+            # default; --ensemble-procs P > 1 with --ensemble-threads 0 selects the worker processes of round 2.
+            from sella_amd.ensemble import EnsembleThreads
+            cpus_rank = max(1, effective_cpu_count() // max(1, local_world))
+            nthr_e = args.ensemble_threads
+            if nthr_e < 0:
+                nthr_e = min(args.ensemble_per_gpu, 8, 2 * cpus_rank)
             nproc_e = args.ensemble_procs
             if nproc_e < 0:
-                nproc_e = min(args.ensemble_per_gpu, EnsemblePool.BEST_PER_GPU,
-                              max(1, effective_cpu_count() // max(1, local_world)))
-            pool, pool_note = None, None
-            if nproc_e > 1 and os.environ.get('SELLA_BENCH_COMM') != 'gloo':
+                nproc_e = 0 if nthr_e > 1 else min(args.ensemble_per_gpu, EnsemblePool.BEST_PER_GPU, cpus_rank)
+            pool, pool_note, tpool = None, None, None
+            if nthr_e > 1 and nproc_e <= 1:
+                tpool = EnsembleThreads(nthr_e)
+                tpool.prepare(make_member, mine_e)
+            if tpool is None and nproc_e > 1 and os.environ.get('SELLA_BENCH_COMM') != 'gloo':
                 try:
                     pool = EnsemblePool(nproc_e)
                     pool.prepare(make_member, mine_e)
@@ -347,20 +359,21 @@ def main():
                     if pool is not None:
                         pool.close()
                     pool = None
-            if pool is None:
+            if pool is None and tpool is None:
                 for i in mine_e:
                     make_member.prepare(i)
             barrier()
             te = time.perf_counter()
             res = run_ensemble(make_member, total, fmax=0.0, steps=args.ensemble_steps,
                                sella_kwargs=EnsembleMember.SELLA_KW,
-                               threads=args.ensemble_threads, pool=pool, prepared=pool is not None)
+                               threads=tpool if tpool is not None else 1, pool=pool, prepared=pool is not None)
             ctx.sync()
             tens = time.perf_counter() - te
             tens = comm.max_host(tens)
             nst_tot = float(res['summary'][:, 1].sum())
             opt_stats['ensemble'] = dict(replicas=total, per_gpu=args.ensemble_per_gpu, n=ne,
-                                         host_threads_per_gpu=args.ensemble_threads,
+                                         host_threads_per_gpu=(tpool.threads if tpool is not None else 1),
+                                         searches_in_library=bool(__import__('sella_amd.ensemble').ensemble.USE_LIBRARY_SEARCH),
                                          worker_processes_per_gpu=(pool.processes if pool is not None else 0),
                                          steps_per_replica=args.ensemble_steps,
                                          optimizer_steps_per_s=round(nst_tot / tens, 2),
@@ -370,6 +383,8 @@ def main():
                 opt_stats['ensemble']['note'] = pool_note
             if pool is not None:
                 pool.close()
+            if tpool is not None:
+                tpool.close()
         # ---- BASELINE configs[1] as named: 1024-atom Cu(111) EMT slab (3N = 3072), one surface atom lifted onto a
         # bridge site, lower half frozen by translation constraints (the README pattern), default Sella settings,
         # device EMT calculator.  Host-glue bound (Python between sub-millisecond kernels), reported for the record.

@@ -252,13 +252,91 @@ class EnsemblePool:
         self.close()
 
 
+class EnsembleThreads:
+    """T host threads on this rank's GPU, started once and reused, each with a device context (HIP stream, scratch,
+    pinned rings) of its own that outlives the runs — creating a context costs tens of milliseconds (its first arena
+    slab is a `hipMalloc`), which is the whole budget of a small search.
+
+    Worth having since the searches themselves run inside the library (`LibrarySearch`): the interpreter lock is
+    released for the duration of a member, and the threads overlap on the device like the launch-and-wait loops of
+    tools/lab/wait_lab.hip.  Members are handed out one by one (whoever is free takes the next); results do not depend
+    on which thread ran a member."""
+
+    def __init__(self, threads):
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        self.threads = int(threads)
+        if self.threads < 1:
+            raise ValueError('EnsembleThreads needs at least one thread')
+        self._ctxs = []
+        self._lock = threading.Lock()
+        self._ex = ThreadPoolExecutor(max_workers=self.threads, initializer=self._enter)
+        self._all(lambda: None)                                  # every thread up, every context created
+
+    def _enter(self):
+        from . import device
+        ctx = device.Context()
+        device.use_context(ctx)
+        with self._lock:
+            self._ctxs.append(ctx)
+
+    def _all(self, fn):
+        """Run fn once on EVERY thread (a barrier keeps a fast thread from taking two)."""
+        import threading
+        gate = threading.Barrier(self.threads)
+
+        def task():
+            gate.wait()
+            return fn()
+        for f in [self._ex.submit(task) for _ in range(self.threads)]:
+            f.result()
+
+    def prepare(self, factory, members=()):
+        """`factory.prepare(i)` for the members (host-side data), then `factory.warmup()` on every thread."""
+        prep = getattr(factory, 'prepare', None)
+        if prep is not None:
+            for i in members:
+                prep(i)
+        warm = getattr(factory, 'warmup', None)
+        if warm is not None:
+            self._all(warm)
+
+    def run(self, factory, members, fmax, steps, sella_kwargs):
+        futs = {i: self._ex.submit(lambda i=i: run_one(factory(i), fmax, steps, sella_kwargs)) for i in members}
+        return {i: f.result() for i, f in futs.items()}
+
+    def close(self):
+        if self._ex is None:
+            return
+        from . import device
+
+        def leave():
+            import gc
+            ctx = device.get_context()
+            device.use_context(None)
+            gc.collect()
+            ctx.close()
+        try:
+            self._all(leave)
+        finally:
+            self._ex.shutdown()
+            self._ex = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def run_ensemble(make_replica, n_replicas, fmax=0.05, steps=1000, sella_kwargs=None, threads=1, pool=None,
                  prepared=False):
     """Run `n_replicas` independent searches, sharded over the initialised process group (or all in
     this process when there is none).  Every rank returns the same
     `dict(summary=(n_replicas, 5) array, positions=list of (N_i, 3) arrays, owner=(n_replicas,))`.
 
-    threads > 1: the rank's members are dealt to that many host threads, each with its own device
+    threads: an `EnsembleThreads` (persistent threads and contexts), or a number > 1: the rank's members are dealt to
+    that many host threads created for this call, each with its own device
     context (own HIP stream): a small search is host-latency bound (Python between sub-millisecond
     kernels), so several of them keep one GPU busy.  `make_replica(i)` is then called inside the
     worker thread and must build its calculator on `sella_amd.device.get_context()`.
@@ -271,6 +349,9 @@ def run_ensemble(make_replica, n_replicas, fmax=0.05, steps=1000, sella_kwargs=N
     if pool is not None:
         done = pool.run(None if prepared else make_replica, mine, fmax, steps, sella_kwargs)
         for i, (sm, ps) in done.items():
+            summaries[i], positions[i] = sm, ps
+    elif isinstance(threads, EnsembleThreads):
+        for i, (sm, ps) in threads.run(make_replica, mine, fmax, steps, sella_kwargs).items():
             summaries[i], positions[i] = sm, ps
     elif threads > 1 and len(mine) > 1:
         from concurrent.futures import ThreadPoolExecutor

@@ -1760,6 +1760,119 @@ int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, M
     }
     if (!done) {
     int mb = 0;
+    // Orthonormal basis of the 2 kk update vectors.  A block of them (the secant pairs of a Davidson run: 2 kk ~ 60)
+    // by Cholesky-QR twice — Gram matrix on the matrix cores, its Cholesky factor on the host, the rows recombined, and
+    // once more on the result: three round trips instead of two per vector.  The second pass sees a Gram matrix within
+    // 0.1 of the identity or the block goes through the vector-by-vector Gram-Schmidt below (rank-deficient or wildly
+    // scaled input: a non-positive pivot, a first pass that left more than that).
+    bool blocked = false;
+    if (m >= 8 && c->opt.lr_cholqr) {
+        double* Gd = W.Ut;                                   // Gram matrices, then the recombination coefficients
+        double* Q1 = W.Zb;
+        std::vector<double> G((size_t)m * m), L, T, Wc;
+        bool ok = true;
+        // pass 1: PIVOTED Cholesky of the scaled Gram matrix — the secant pairs of a Krylov run span about half of
+        // 2 kk dimensions (U and Z are combinations of S and Y = A S), so the factorisation has to reveal the rank: rows
+        // enter in order of their remaining norm until that falls below 1e-6 of the row (1e-12 on the Gram scale, four
+        // digits above its rounding noise); what the rejected rows still carry outside the basis is measured below
+        SCHK(launch_gemm(c, 0, 1, m, m, n, 1.0, src, ld, src, ld, 0.0, Gd, m));
+        SCHK(d2h_async(c, G.data(), Gd, (size_t)m * m * sizeof(double)));
+        SCHK(stream_wait(c));
+        std::vector<double> sc(m, 0.0), diag(m), rown2(m);
+        std::vector<int> piv;
+        for (int i = 0; i < m; ++i) {
+            const double d = G[(size_t)i * m + i];
+            rown2[i] = d;
+            if (d == d && d > 0.0) sc[i] = 1.0 / sqrt(d);
+            else if (!(d == 0.0)) ok = false;
+            diag[i] = sc[i] > 0.0 ? 1.0 : 0.0;
+        }
+        std::vector<double> Lf((size_t)m * m, 0.0);            // Lf[i][q]: column q of the pivoted factor, all rows i
+        if (ok) {
+            std::vector<char> used(m, 0);
+            for (int q = 0; q < m; ++q) {
+                int best = -1;
+                for (int i = 0; i < m; ++i)
+                    if (!used[i] && (best < 0 || diag[i] > diag[best])) best = i;
+                if (best < 0 || !(diag[best] > 1e-12)) break;
+                const double lqq = sqrt(diag[best]);
+                used[best] = 1;
+                piv.push_back(best);
+                for (int i = 0; i < m; ++i) {
+                    if (used[i] && i != best) continue;
+                    double t = 0.5 * (G[(size_t)i * m + best] + G[(size_t)best * m + i]) * sc[i] * sc[best];
+                    for (int kq = 0; kq < q; ++kq) t -= Lf[(size_t)i * m + kq] * Lf[(size_t)best * m + kq];
+                    Lf[(size_t)i * m + q] = (i == best) ? lqq : t / lqq;
+                    if (i != best) diag[i] -= Lf[(size_t)i * m + q] * Lf[(size_t)i * m + q];
+                }
+            }
+        }
+        const int mp = (int)piv.size();
+        ok = ok && mp > 0;
+        if (ok) {
+            // T = L11^-1 (mp x mp, L11 = rows piv of Lf): Q1_c = sum_q T[c][q] sc[piv q] src[piv q]
+            T.assign((size_t)mp * mp, 0.0);
+            for (int col = 0; col < mp; ++col)
+                for (int i = col; i < mp; ++i) {
+                    double acc = (i == col) ? 1.0 : 0.0;
+                    for (int kq = col; kq < i; ++kq) acc -= Lf[(size_t)piv[i] * m + kq] * T[(size_t)kq * mp + col];
+                    T[(size_t)i * mp + col] = acc / Lf[(size_t)piv[i] * m + i];
+                }
+            Wc.assign((size_t)m * mp, 0.0);                        // lincomb: Wc[j][c] = coefficient of src row j in output c
+            for (int cq = 0; cq < mp; ++cq)
+                for (int q = 0; q <= cq; ++q) Wc[(size_t)piv[q] * mp + cq] = T[(size_t)cq * mp + q] * sc[piv[q]];
+            SCHK(h2d_async(c, Gd, Wc.data(), Wc.size() * sizeof(double)));
+            SCHK(launch_lincomb(c, n, mp, src, ld, m, Gd, mp, nullptr, 0, 0, nullptr, 0, 0.0, Q1, ld));
+            // pass 2: plain Cholesky-QR of the mp rows (now well conditioned): Gram matrix within 0.1 of the identity
+            G.assign((size_t)mp * mp, 0.0);
+            SCHK(launch_gemm(c, 0, 1, mp, mp, n, 1.0, Q1, ld, Q1, ld, 0.0, Gd, mp));
+            SCHK(d2h_async(c, G.data(), Gd, (size_t)mp * mp * sizeof(double)));
+            SCHK(stream_wait(c));
+            double dev = 0.0;
+            for (int i = 0; i < mp; ++i)
+                for (int j = 0; j < mp; ++j) dev = std::max(dev, fabs(G[(size_t)i * mp + j] - (i == j ? 1.0 : 0.0)));
+            L.assign((size_t)mp * mp, 0.0);
+            std::vector<double> Gs((size_t)mp * mp);
+            for (int i = 0; i < mp; ++i)
+                for (int j = 0; j < mp; ++j) Gs[(size_t)i * mp + j] = 0.5 * (G[(size_t)i * mp + j] + G[(size_t)j * mp + i]);
+            ok = dev < 0.1 && small::cholesky(mp, Gs.data(), mp, L.data(), mp) == 0;
+        }
+        if (ok) {
+            T.assign((size_t)mp * mp, 0.0);
+            for (int col = 0; col < mp; ++col)
+                for (int i = col; i < mp; ++i) {
+                    double acc = (i == col) ? 1.0 : 0.0;
+                    for (int kq = col; kq < i; ++kq) acc -= L[(size_t)i * mp + kq] * T[(size_t)kq * mp + col];
+                    T[(size_t)i * mp + col] = acc / L[(size_t)i * mp + i];
+                }
+            Wc.assign((size_t)mp * mp, 0.0);
+            for (int cq = 0; cq < mp; ++cq)
+                for (int q = 0; q <= cq; ++q) Wc[(size_t)q * mp + cq] = T[(size_t)cq * mp + q];
+            SCHK(h2d_async(c, Gd, Wc.data(), Wc.size() * sizeof(double)));
+            SCHK(launch_lincomb(c, n, mp, Q1, ld, mp, Gd, mp, nullptr, 0, 0, nullptr, 0, 0.0, Qb, ld));
+            mb = mp;
+            // what the update vectors carry outside the basis: rows above 1e-13 of their norm (the drop threshold of the
+            // vector-by-vector path, math.pyx:112-117) are orthonormalised into it one by one
+            double* Rd = W.Ut;
+            double* Res = W.Zb;
+            SCHK(launch_gemm(c, 0, 1, mb, m, n, -1.0, Qb, ld, src, ld, 0.0, Rd, m));             // -(Qb src^T), mb x m
+            SCHK(launch_axpby2d(c, m, n, 1.0, src, ld, 0.0, nullptr, 0, Res, ld));
+            SCHK(launch_lincomb(c, n, m, Qb, ld, mb, Rd, m, nullptr, 0, 0, nullptr, 0, 1.0, Res, ld));    // src - (src Qb^T) Qb
+            double* nd = c->dscal + DS_CVEC;
+            SCHK(launch_rows_sumsq(c, Res, ld, m, n, nd));
+            SCHK(read_scalars(c, DS_CVEC, m));
+            for (int h = 0; h < m; ++h) {
+                if (!(c->hscal[DS_CVEC + h] > 1e-26 * rown2[h])) continue;
+                double* slot = Qb + (size_t)mb * ld;
+                HIPCHK(hipMemcpyAsync(slot, Res + (size_t)h * ld, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                int kept = 0;
+                SCHK(gs_orthonormalise(c, Qb, ld, mb, slot, n, 1e-15, 1e-13, 100, &kept, nullptr));
+                if (kept) ++mb;
+            }
+            blocked = true;
+        }
+    }
+    if (!blocked) {
     for (int v = 0; v < m; ++v) {
         double* slot = Qb + (size_t)mb * ld;
         HIPCHK(hipMemcpyAsync(slot, src + (size_t)v * ld, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -1767,14 +1880,18 @@ int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, M
         SCHK(gs_orthonormalise(c, Qb, ld, mb, slot, n, 1e-15, 1e-13, 100, &kept, nullptr));
         if (kept) ++mb;
     }
+    }
+    if (getenv("SELLA_DEBUG_TIMING"))
+        fprintf(stderr, "structured eigen-update: %d update vectors, basis of %d by %s\n", m, mb,
+                blocked ? "Cholesky-QR twice" : "vector-by-vector Gram-Schmidt");
     if (mb == 0) return SELLA_OK;
+    // coordinates of the update vectors in the basis: R = Qb src^T in one product and one read-back
     std::vector<double> R((size_t)mb * m);
-    for (int v0 = 0; v0 < m; v0 += 8) {
-        const int nv = std::min(8, m - v0);
-        SCHK(launch_gemv_rows(c, Qb, mb, n, ld, src + (size_t)v0 * ld, ld, nv, c->dscal + DS_CVEC, mb, GemvEpi()));
-        SCHK(read_scalars(c, DS_CVEC, mb * nv));
-        for (int h = 0; h < nv; ++h)
-            for (int i = 0; i < mb; ++i) R[(size_t)i * m + v0 + h] = c->hscal[DS_CVEC + (size_t)h * mb + i];
+    {
+        double* Rd = W.Ut;
+        SCHK(launch_gemm(c, 0, 1, mb, m, n, 1.0, Qb, ld, src, ld, 0.0, Rd, m));
+        SCHK(d2h_async(c, R.data(), Rd, (size_t)mb * m * sizeof(double)));
+        SCHK(stream_wait(c));
     }
     std::vector<double> C((size_t)mb * mb, 0.0), sig(mb), F((size_t)mb * mb), work(mb);
     for (int i = 0; i < mb; ++i)

@@ -95,6 +95,7 @@ struct Options {
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
     long eigh_wy_waves = 4;  // wavefronts per workgroup of the MFMA back-transformation (4, 8 or 16: measured equal at n = 3072 and 12288 — the kernel is bound by L2 bandwidth, 22.7 GB in 3.16 ms, not by latency)
+    long lr_cholqr = 1;      // 1: block of update vectors orthonormalised by Cholesky-QR twice (eigh.hip, lr_lowrank_update)
     long rank2k_fixed = 1;   // 1: trailing update with all loads issued up front for the panel depths 16 / 32 (update.hip)
     long rs_fast = 1;        // 1: sella_opt_step searches the restricted step by interpolating batches (stepper.hip)
     long lr_dev = 1;         // 1: sella_opt_step updates structured decompositions in coordinates, all decisions on the device (lrstep.hip)

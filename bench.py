@@ -112,6 +112,8 @@ def main():
     ap.add_argument('--ensemble-threads', type=int, default=-1,
                     help='host threads per GPU for the ensemble leg (persistent contexts, sella_amd.ensemble.EnsembleThreads); '
                          '-1: min(members per GPU, 8, 2 x CPUs per rank); 0 / 1: none')
+    ap.add_argument('--ensemble-saturate', type=int, default=4,
+                    help='second ensemble figure with this many times the members per GPU on up to 12 threads (0: skip)')
     ap.add_argument('--ensemble-procs', type=int, default=-1,
                     help='worker processes per GPU for the ensemble leg (-1: min(members, 4, CPUs of this rank); 0/1: none)')
     ap.add_argument('--block-n', type=int, default=12288, help='configs[4] leg: operator size (0 disables)')
@@ -379,6 +381,20 @@ def main():
                                          optimizer_steps_per_s=round(nst_tot / tens, 2),
                                          searches_per_s=round(total / tens, 3), seconds=round(tens, 3),
                                          lambda_min_negative=int((res['summary'][:, 4] < 0).sum()))
+            if tpool is not None and world == 1 and args.ensemble_saturate > 0:
+                # the same members with more of them in flight than the configuration names (8 per GPU): what one
+                # process sustains once every thread always has a next member to take
+                nsat, tsat = args.ensemble_saturate * args.ensemble_per_gpu, min(12, 2 * cpus_rank)
+                with EnsembleThreads(tsat) as sat:
+                    sat.prepare(make_member, range(nsat))
+                    run_ensemble(make_member, tsat, fmax=0.0, steps=3, sella_kwargs=EnsembleMember.SELLA_KW, threads=sat)
+                    ts0 = time.perf_counter()
+                    rs = run_ensemble(make_member, nsat, fmax=0.0, steps=args.ensemble_steps,
+                                      sella_kwargs=EnsembleMember.SELLA_KW, threads=sat)
+                    tsat_s = time.perf_counter() - ts0
+                opt_stats['ensemble']['saturated'] = dict(replicas=nsat, host_threads_per_gpu=tsat, worker_processes_per_gpu=0,
+                                                          searches_per_s=round(nsat / tsat_s, 3), seconds=round(tsat_s, 3),
+                                                          lambda_min_negative=int((rs['summary'][:, 4] < 0).sum()))
             if pool_note:
                 opt_stats['ensemble']['note'] = pool_note
             if pool is not None:

@@ -199,6 +199,13 @@ class Calculator:
     def energy_and_gradient(self, pos):
         raise NotImplementedError
 
+    # a calculator that also exists inside the library says so (`library_form`) and hands out that object
+    # (`device_calculator()`; None until it can be built): sella_amd/search.py, PES._library_fd_operator
+    library_form = False
+
+    def device_calculator(self):
+        return None
+
     def _get(self, atoms):
         key = atoms.positions.tobytes()
         if key != self._key:
@@ -225,6 +232,8 @@ class QuadraticCubicModel(Calculator):
         self.U = np.asarray(U, dtype=np.float64)
         self.c = c
         self.device_matrix = device_matrix         # the DeviceMatrix behind a callable A: enables `device_calculator`
+
+    library_form = property(lambda self: self.device_matrix is not None)
 
     def device_calculator(self):
         """The same function as a calculator inside the library (`sella_calc_model_*`), or None."""
@@ -370,6 +379,8 @@ class EMT(Calculator):
         from .device import get_context
         S = self._setup[1]
         return get_context().emt_eval(pos, S['par'], S['shifts'], S['rc'], S['acut'], S['cutoff'], self._BETA)
+
+    library_form = True
 
     def device_calculator(self):
         """This potential, for the species and cell it was last set up for, as a calculator inside the library

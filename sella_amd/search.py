@@ -65,7 +65,7 @@ class LibrarySearch:
         if set(kw) - _COVERED or kw.get('trajectory') is not None or kw.get('logfile') is not None or kw.get('internal'):
             return False
         calc = getattr(atoms, 'calc', None)
-        if getattr(calc, 'device_calculator', None) is None:
+        if not getattr(calc, 'library_form', False):
             return False
         n = 3 * len(atoms)
         if linalg.LR_MIN_DIM is None or n < linalg.LR_MIN_DIM:

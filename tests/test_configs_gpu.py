@@ -164,3 +164,24 @@ def test_config3_ensemble_of_emt_slabs(ctx):
     with EnsemblePool(2) as pool:
         res_p = run_ensemble(EmtMember(), nrep, fmax=0.0, steps=steps, sella_kwargs=kw, pool=pool)
     np.testing.assert_array_equal(res_p['summary'], res['summary'])
+    # ... and on host threads of this process (one persistent device context each): the searches run inside the library
+    # (sella_amd/search.py), so the threads overlap on the device; which thread takes which member does not matter
+    from sella_amd import ensemble
+    from sella_amd.ensemble import EnsembleThreads
+    assert ensemble.USE_LIBRARY_SEARCH
+    with EnsembleThreads(4) as threads:
+        res_t = run_ensemble(EmtMember(), nrep, fmax=0.0, steps=steps, sella_kwargs=kw, threads=threads)
+        res_t2 = run_ensemble(EmtMember(), nrep, fmax=0.0, steps=steps, sella_kwargs=kw, threads=threads)
+    np.testing.assert_array_equal(res_t['summary'], res['summary'])
+    np.testing.assert_array_equal(res_t2['summary'], res['summary'])
+    for i in range(nrep):
+        np.testing.assert_array_equal(res_t['positions'][i], res['positions'][i])
+    # the library loop against the general driver (the same searches, ~300 library calls per step there)
+    ensemble.USE_LIBRARY_SEARCH = False
+    try:
+        res_g = run_ensemble(EmtMember(), 2, fmax=0.0, steps=steps, sella_kwargs=kw)
+    finally:
+        ensemble.USE_LIBRARY_SEARCH = True
+    np.testing.assert_allclose(res_g['summary'], res['summary'][:2], atol=1e-7)
+    for i in range(2):
+        np.testing.assert_allclose(res_g['positions'][i], res['positions'][i], atol=1e-8)

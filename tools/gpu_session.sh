@@ -84,7 +84,9 @@ timeout 600 python tools/geodesic_bench.py --steps 3 --sella-steps 2 > $OUT/geod
 grep "^{" $OUT/geodesic.log | cut -c1-400 | tee -a $OUT/session.log
 say "== ensemble: worker processes, host threads"
 timeout 300 python tools/ensemble_probe.py 16 1 2 4 > $OUT/probe.log 2>&1; grep "pool\|cpus" $OUT/probe.log | tee -a $OUT/session.log
-timeout 300 python tools/ensemble_threads.py 16 1 2 4 > $OUT/threads.log 2>&1; grep threads $OUT/threads.log | tee -a $OUT/session.log
+timeout 300 python tools/ensemble_threads.py 32 1 2 4 8 12 16 > $OUT/threads.log 2>&1; grep threads $OUT/threads.log | tee -a $OUT/session.log
+SELLA_LIBRARY_SEARCH=0 timeout 300 python tools/ensemble_threads.py 32 1 4 8 > $OUT/threads_general.log 2>&1; grep threads $OUT/threads_general.log | sed "s/^/general driver: /" | tee -a $OUT/session.log
+SELLA_DEBUG_TIMING=1 timeout 300 python tools/ens_profile.py > $OUT/ens_profile.log 2>&1; grep "seconds per member\|update_H n=768 k=[23]\|structured eigen" $OUT/ens_profile.log | tail -5 | tee -a $OUT/session.log
 timeout 300 python tools/thread_scaling.py 768 40 > $OUT/thread_scaling.log 2>&1; cat $OUT/thread_scaling.log | tee -a $OUT/session.log
 say "== rccl: 1 rank, then 2 ranks on the one GPU"
 timeout 120 python tools/rccl_smoke.py > $OUT/rccl.log 2>&1; tail -1 $OUT/rccl.log | tee -a $OUT/session.log

@@ -310,6 +310,7 @@ def main():
         U /= np.linalg.norm(U, axis=1)[:, None]
         atoms = Atoms(['X'] * (n // 3), 0.05 * rng.normal(size=(n // 3, 3)), pbc=True)
         atoms.calc = QuadraticCubicModel(lambda x: ctx.symm_mm(dA, x), U, c=0.05, device_matrix=dA)
+        x_init = atoms.positions.copy()
         opt = Sella(atoms, order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', logfile=None,
                     constraints=Constraints(atoms), proj_trans=False)
         opt.run(fmax=0.0, steps=2)                       # warm-up incl. the initial diagonalisation
@@ -324,6 +325,26 @@ def main():
         opt_stats = dict(optimizer_steps_per_s=round(nst / topt, 3), steps=nst, ms_per_step=round(1e3 * topt / nst, 2),
                          force_calls=int(atoms.calc.ncalls - ncalls0), rs='tr', method='prfo', order=1,
                          one_call_steps=int(opt.fused_steps - fused0))
+        # the same search through the library loop (sella_amd/search.py: `Sella.run` inside the library for this
+        # configuration — what the ensemble members below run): steps/s after the same 2-step warm-up
+        try:
+            from sella_amd.search import LibrarySearch
+            at2 = Atoms(['X'] * (n // 3), x_init.copy(), pbc=True)
+            at2.calc = QuadraticCubicModel(lambda x: ctx.symm_mm(dA, x), U, c=0.05, device_matrix=dA)
+            kw2 = dict(order=1, eta=1e-4, gamma=0.1, delta0=0.1, rs='tr', constraints=Constraints(at2), proj_trans=False)
+            if LibrarySearch.applies(at2, **kw2):
+                ls = LibrarySearch(at2, **kw2)
+                ls.run(0.0, 2)
+                ctx.sync()
+                tl = time.perf_counter()
+                ls.run(0.0, nst)
+                ctx.sync()
+                tl = time.perf_counter() - tl
+                opt_stats['library_loop'] = dict(optimizer_steps_per_s=round(nst / tl, 3), ms_per_step=round(1e3 * tl / nst, 3),
+                                                 steps=nst, one_call_steps=int(ls.one_call_steps))
+                ls.close()
+        except Exception as e:                           # noqa: BLE001 — reported, the leg above stands on its own
+            opt_stats['library_loop'] = dict(error=str(e)[:200])
         # ---- ensemble (BASELINE configs[3]): independent 256-atom-equivalent searches (3N = 768),
         # 8 per GPU, sharded round-robin over the ranks, one all-gather of the summaries at the end
         if args.ensemble_per_gpu > 0:
@@ -427,6 +448,29 @@ def main():
                                          ms_per_step=round(1e3 * tsl / args.emt_steps, 1),
                                          force_calls=int(slab.calc.ncalls - nc0), rs='ras', calculator='EMT (device)',
                                          one_call_steps=int(dyn.fused_steps - fs0))
+            try:
+                from sella_amd.search import LibrarySearch
+                slab2 = fcc111('Cu', (8, 8, 16), vacuum=7)
+                add_adsorbate(slab2, 'Cu', 2.0, 'bridge')
+                cons2 = Constraints(slab2)
+                for atom in slab2:
+                    if atom.position[2] < slab2.cell[2, 2] / 2.:
+                        cons2.fix_translation(atom.index)
+                slab2.calc = EMT()
+                if LibrarySearch.applies(slab2, constraints=cons2):
+                    ls = LibrarySearch(slab2, constraints=cons2)
+                    ls.run(0.0, 2)
+                    ctx.sync()
+                    tl = time.perf_counter()
+                    ls.run(0.0, args.emt_steps)
+                    ctx.sync()
+                    tl = time.perf_counter() - tl
+                    opt_stats['emt_slab']['library_loop'] = dict(optimizer_steps_per_s=round(args.emt_steps / tl, 2),
+                                                                 ms_per_step=round(1e3 * tl / args.emt_steps, 3),
+                                                                 force_calls=int(ls.neval))
+                    ls.close()
+            except Exception as e:                       # noqa: BLE001
+                opt_stats['emt_slab']['library_loop'] = dict(error=str(e)[:200])
         _dev._default = None
 
     # ---- BASELINE configs[4]: block Davidson, 16 new vectors per iteration, H.V panel on the matrix cores, rows of

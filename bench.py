@@ -450,8 +450,7 @@ def main():
                                          one_call_steps=int(dyn.fused_steps - fs0))
             try:
                 from sella_amd.search import LibrarySearch
-                slab2 = fcc111('Cu', (8, 8, 16), vacuum=7)
-                add_adsorbate(slab2, 'Cu', 2.0, 'bridge')
+                slab2 = make_slab()
                 cons2 = Constraints(slab2)
                 for atom in slab2:
                     if atom.position[2] < slab2.cell[2, 2] / 2.:

@@ -14,6 +14,19 @@ GOLD = os.path.join(REPO, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'emu_heavy: the host EMULATION of this test takes tens of seconds (whole searches '
+                                       'fibre by fibre); skipped on the emulator unless SELLA_EMU_FULL=1 — its [hip] '
+                                       'variant runs under -m gpu, and a lighter test of the same code stays on the CPU')
+
+
+def pytest_collection_modifyitems(config, items):
+    # the CPU suite is sized to run in a few minutes: whole-search tests stay on the device unless asked for
+    if os.environ.get('SELLA_EMU_FULL') == '1':
+        return
+    skip = pytest.mark.skip(reason='emulation of a whole search: set SELLA_EMU_FULL=1 (the [hip] variant runs under -m gpu)')
+    for item in items:
+        if item.get_closest_marker('emu_heavy') is not None and '[emu' in item.name:
+            item.add_marker(skip)
 
 
 BACKENDS = [pytest.param('emu', id='emu'), pytest.param('hip', marks=pytest.mark.gpu, id='hip')]

@@ -17,7 +17,19 @@ FLAGS = ['-x', 'c++', '-std=c++17', '-O2', '-g', '-fPIC', '-I', os.path.join(HER
 
 
 def build(force=False, verbose=False):
+    """Build (if stale) and return the library path; an exclusive file lock serialises concurrent callers (pytest-xdist
+    workers, ensemble worker processes of the CPU tests)."""
+    import fcntl
     os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.hip')]
     srcs.append(os.path.join(HERE, 'hostemu.cpp'))
     hooks = os.path.join(HERE, 'hooks.cpp')

@@ -64,7 +64,8 @@ def _same_row(ra, rb, i):
     assert ra[4] == rb[4], i
 
 
-@pytest.mark.parametrize('rs,method,order', [('tr', 'prfo', 1), ('ras', 'rfo', 0), ('ras', 'qn', 0)])
+@pytest.mark.parametrize('rs,method,order', [('tr', 'prfo', 1), pytest.param('ras', 'rfo', 0, marks=pytest.mark.emu_heavy),
+                                             pytest.param('ras', 'qn', 0, marks=pytest.mark.emu_heavy)])
 def test_fused_step_equals_the_general_path(ctx, rs, method, order):
     a, na = _run(_model_search(True, rs, method, order), 8)
     b, nb = _run(_model_search(False, rs, method, order), 8)
@@ -73,6 +74,7 @@ def test_fused_step_equals_the_general_path(ctx, rs, method, order):
         _same_row(ra, rb, i)
 
 
+@pytest.mark.emu_heavy
 def test_fused_step_with_pinned_coordinates(ctx):
     """BASELINE configs[1] on a down-sized twin (Cu(111) 4 x 4 x 4 EMT slab, lower half pinned atom by atom): pins -> selection bases and the
     principal-submatrix view, default `Sella` (`ras`, P-RFO)."""
@@ -93,6 +95,7 @@ def test_fused_step_with_pinned_coordinates(ctx):
     np.testing.assert_array_equal(out[True][4], out[False][4])
 
 
+@pytest.mark.emu_heavy
 def test_fused_step_steps_aside(ctx):
     """Configurations the one-call step does not cover take the general path: dense eigendecomposition (structured form
     off), a rotation constraint (general projection basis), a user-defined restricted step."""
@@ -134,6 +137,7 @@ def test_general_route_inside_the_call_and_stale_mirrors(ctx):
         _same_row(ra, rb, i)
 
 
+@pytest.mark.emu_heavy
 def test_restart_drops_the_proposed_step(ctx, tmp_path):
     """`load_state` replaces the approximate Hessian: a step proposed by the previous call must not survive it."""
     opt = _model_search(True, 'tr', 'prfo', 1)

@@ -71,7 +71,7 @@ def test_energy_gradient_consistency(ctx):
     assert pes.get_projected_forces().shape == (5, 3)
 
 
-@pytest.mark.parametrize('order', [0, 1])
+@pytest.mark.parametrize('order', [0, pytest.param(1, marks=pytest.mark.emu_heavy)])
 def test_internal_search_matches_cartesian(ctx, order):
     from sella_amd import Sella
     from sella_amd.internal import Constraints

@@ -62,6 +62,7 @@ def test_golden_irc_steps(ctx, manifest):
         assert np.linalg.norm((s + d1) * sqrtm) == pytest.approx(case['delta'], abs=1e-9)
 
 
+@pytest.mark.emu_heavy
 def test_irc_from_rhombus_saddle(ctx):
     """4-atom Morse cluster: the planar rhombus is the first-order saddle between two tetrahedra; the
     IRC must run downhill from it in both directions and end on minima of the same energy."""

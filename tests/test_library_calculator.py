@@ -84,6 +84,7 @@ def test_fd_operator_equals_numerical_hessian(ctx, pinned, threepoint):
     assert op.Vs.shape == (n, 3)
 
 
+@pytest.mark.emu_heavy
 def test_search_through_the_library_calculator(ctx, monkeypatch):
     """The same `Sella` search with the diagonalisations' force calls made by the library and by the interpreter:
     same trajectory (to the amplification of last-bit differences of the model's cubic term by 1 / eta), same number

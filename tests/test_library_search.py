@@ -32,7 +32,7 @@ def _model(ctx, n=120, seed=41):
 KW = dict(order=1, eta=1e-4, gamma=0.1, delta0=0.1, proj_trans=False)
 
 
-@pytest.mark.parametrize('rs,nsteps_per_diag', [('tr', 3), ('ras', 2)])
+@pytest.mark.parametrize('rs,nsteps_per_diag', [('tr', 3), pytest.param('ras', 2, marks=pytest.mark.emu_heavy)])
 def test_model_search_in_the_library(ctx, rs, nsteps_per_diag):
     from sella_amd import Sella
     from sella_amd.internal import Constraints
@@ -57,6 +57,7 @@ def test_model_search_in_the_library(ctx, rs, nsteps_per_diag):
     ls.close()
 
 
+@pytest.mark.emu_heavy
 def test_pinned_slab_search_in_the_library(ctx):
     """BASELINE configs[1] on a down-sized twin: EMT (library calculator), lower half pinned, default keywords."""
     from conftest_shim import emt_slab

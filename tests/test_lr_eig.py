@@ -100,7 +100,8 @@ def test_structured_steppers_match_dense(ctx, kind, order):
     np.testing.assert_allclose(s1, s0, atol=1e-9 * max(1.0, np.abs(s0).max()))
 
 
-@pytest.mark.parametrize('rs,method', [('tr', 'prfo'), ('ras', 'prfo'), ('tr', 'qn'), ('ras', 'rfo')])
+@pytest.mark.parametrize('rs,method', [('tr', 'prfo'), pytest.param('ras', 'prfo', marks=pytest.mark.emu_heavy), ('tr', 'qn'),
+                                       pytest.param('ras', 'rfo', marks=pytest.mark.emu_heavy)])
 def test_structured_restricted_step_matches_dense(ctx, rs, method):
     from sella_amd.linalg import ApproximateHessian
     from sella_amd.optimize.restricted_step import get_restricted_step
@@ -124,6 +125,7 @@ def test_structured_restricted_step_matches_dense(ctx, rs, method):
     np.testing.assert_allclose(s1, s0, atol=1e-9)
 
 
+@pytest.mark.emu_heavy
 def test_structured_preconditioner_in_davidson(ctx):
     """rayleigh_ritz with P = structured approximate Hessian against P = the same matrix held dense."""
     from sella_amd.eigensolvers import rayleigh_ritz
@@ -182,6 +184,7 @@ def test_structured_view_of_pinned_coordinates(ctx):
         check()
 
 
+@pytest.mark.emu_heavy
 def test_structured_and_dense_searches_agree(ctx):
     """A whole `Sella` search with the structured form on (default) and off: same trajectory."""
     from sella_amd import Sella, linalg

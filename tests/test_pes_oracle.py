@@ -87,6 +87,7 @@ def test_pinned_slab_step_by_step(ctx):
         np.testing.assert_array_equal(a1.positions[:6], pos[:6])
 
 
+@pytest.mark.emu_heavy
 def test_emt_slab_twin_step_by_step(ctx, monkeypatch):
     """BASELINE configs[1] on a down-sized twin — Cu(111) 3 x 3 x 4 EMT slab with a lifted surface atom, lower half
     pinned atom by atom, default `Sella` — product (device EMT, selection bases, principal-submatrix view, carried
@@ -120,6 +121,7 @@ def test_emt_slab_twin_step_by_step(ctx, monkeypatch):
     assert dev.pes.neval == ora.pes.neval
 
 
+@pytest.mark.emu_heavy
 def test_emt_slab_one_call_steps_against_the_oracle(ctx, monkeypatch):
     """The same comparison on a twin large enough for the structured eigendecomposition of the VIEW (Cu(111) 4 x 4 x 4,
     96 free coordinates), so that the product's steps are the one-call steps of csrc/optstep.hip / lrstep.hip

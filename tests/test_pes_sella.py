@@ -64,7 +64,7 @@ def test_PES(ctx):
 
 
 @pytest.mark.parametrize('rigid', ['pins', 'rotation'])
-@pytest.mark.parametrize('order', [0, 1])
+@pytest.mark.parametrize('order', [0, pytest.param(1, marks=pytest.mark.emu_heavy)])
 def test_morse_cluster(ctx, order, rigid):
     from sella_amd import Constraints, Sella
     atoms = morse_atoms(4, seed=4)

@@ -70,6 +70,7 @@ def _mis_pes(Hcls, g, case, i):
     return pes
 
 
+@pytest.mark.emu_heavy
 def test_golden_restricted_mis(ctx, manifest):
     """`mis` — MaxInternalStep (restricted_step.py:186-243), the trust measure of every internal-coordinate search —
     against fixtures from the real reference class (oracle/make_golden.py::gen_restricted_mis): weights per block of
@@ -166,6 +167,7 @@ def test_alpha_trace_matches_oracle(ctx):
         np.testing.assert_allclose(dev.alphas[:m], ref.alpha_trace[:m], rtol=1e-6, atol=1e-12)
 
 
+@pytest.mark.emu_heavy
 def test_batched_bisection_matches_sequential(ctx):
     """The bisection phase evaluated 15 trial alphas per round trip (`rs_batch`, csrc/stepper.hip) visits the same
     alphas and returns the same step as one evaluation per round trip."""
@@ -190,6 +192,7 @@ def test_batched_bisection_matches_sequential(ctx):
         assert m0 == m1
 
 
+@pytest.mark.emu_heavy
 def test_batched_bisection_all_measures(ctx):
     """The same for every measure of `sella_restricted_step` (component-wise 'mis', Euclidean 'tr' in the output space,
     mass-weighted 'sphere') and a selection basis, straight through the stepper binding."""

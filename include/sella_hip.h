@@ -62,6 +62,9 @@ int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
  *   many columns on | bd_dev_rr (0) Rayleigh-Ritz eigenproblem of sella_davidson_block on the device (one-workgroup
  *   Jacobi kernel) instead of the host | lr_dev (1) sella_opt_step updates structured eigendecompositions in
  *   coordinates with every decision on the device (0: the host-planned rank-one merges of sella_update_h_lr) |
+ *   eigh_wy_waves (4), eigh_wy_rows (16) wavefronts / rows of X per workgroup of the back-transformation (8, 16 / 32
+ *   measured equal or slower) | rank2k_fixed (1) trailing update with all loads up front | lr_cholqr (1) block of update
+ *   vectors by rank-revealing Cholesky-QR |
  *   rs_fast (1) sella_opt_step finds the restricted step by interpolating batches of 15 trial alphas instead of the
  *   reference's Newton / bisection schedule (same root).                                                         */
 int sella_ctx_set_option(sella_ctx* ctx, const char* key, long value);

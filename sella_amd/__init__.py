@@ -19,6 +19,8 @@ _LAZY = {
     'InternalCoordinates': ('sella_amd.internal', 'InternalCoordinates'),
     'Constraints': ('sella_amd.internal', 'Constraints'),
     'Atoms': ('sella_amd.atoms', 'Atoms'),
+    'LibrarySearch': ('sella_amd.search', 'LibrarySearch'),
+    'EnsembleThreads': ('sella_amd.ensemble', 'EnsembleThreads'),
 }
 
 

@@ -388,6 +388,7 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
         c->opt.gemv_rw = value;
     } else if (!strcmp(key, "gemm_mfma")) c->opt.gemm_mfma = value ? 1 : 0;
     else if (!strcmp(key, "rank2k_stream")) c->opt.rank2k_stream = value ? 1 : 0;
+    else if (!strcmp(key, "eigh_wy_rows")) c->opt.eigh_wy_rows = value;
     else if (!strcmp(key, "eigh_wy_waves")) c->opt.eigh_wy_waves = value;
     else if (!strcmp(key, "lr_cholqr")) c->opt.lr_cholqr = value ? 1 : 0;
     else if (!strcmp(key, "rank2k_fixed")) c->opt.rank2k_fixed = value ? 1 : 0;

@@ -890,6 +890,140 @@ __global__ __launch_bounds__(64 * NW) void wy_apply_mfma_kernel(double* __restri
     }
 }
 
+// The same sweep with 32 rows of X per workgroup (two MFMA row tiles sharing every reflector fetch).  The kernel above
+// is bound by L2 bandwidth — 22.7 GB of requests in 3.16 ms at n = 3072, two thirds of them the reflector blocks Y_b, which
+// every workgroup streams in full twice per block (PMC pass in profiles/, 4 / 8 / 16 wavefronts per workgroup measured
+// equal) — so the lever is fewer workgroups per reflector byte, not more wavefronts: with two row tiles the Y traffic
+// per row of X halves.  n / 32 workgroups of NW wavefronts; the MFMA work of a workgroup doubles, which is where the
+// two limits meet at n = 3072 (96 CUs busy).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void wy_apply_mfma2_kernel(double* __restrict__ X, int ldx, int n,
+                                                             const double* __restrict__ Yf,
+                                                             const double* __restrict__ Call, int nblk) {
+    __shared__ double Mp[NW][32][33];
+    __shared__ double Ms[32][33];
+    __shared__ double M2s[32][33];
+    __shared__ double Cs[WY_NB][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int r0 = blockIdx.x * 32;
+    int rowA[2], rowD[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        rowA[t] = (r0 + 16 * t + li < n) ? r0 + 16 * t + li : n - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowD[t][r] = (r0 + 16 * t + lg + 4 * r < n) ? r0 + 16 * t + lg + 4 * r : n - 1;
+    }
+    const double4 zero4 = make_double4(0.0, 0.0, 0.0, 0.0);
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int j0 = b * WY_NB;
+        const int cs = ((j0 + 1) >> 6) << 6;
+        const int cw = cs + 64 * ((wave - (cs >> 6)) & (NW - 1));
+        for (int e = tid; e < WY_NB * WY_NB; e += 64 * NW) Cs[e >> 5][e & 31] = Call[(size_t)b * WY_NB * WY_NB + e];
+        // ---- phase 1: M = X Y^T (32 x 32) ---------------------------------------------------------
+        wy_f64x4 acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { acc[t][0] = wy_f64x4{0.0, 0.0, 0.0, 0.0}; acc[t][1] = wy_f64x4{0.0, 0.0, 0.0, 0.0}; }
+        const double* xrow0 = X + (size_t)rowA[0] * ldx;
+        const double* xrow1 = X + (size_t)rowA[1] * ldx;
+        const double* y0row = Yf + (size_t)(j0 + li) * ldx;
+        const double* y1row = y0row + (size_t)16 * ldx;
+        for (int cc = cw; cc < ldx; cc += 64 * NW) {
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                const int col = cc + 16 * sg + 4 * lg;
+                const bool ok = col < ldx;
+                const int colc = ok ? col : 0;
+                double4 xa = *reinterpret_cast<const double4*>(xrow0 + colc);
+                double4 xb = *reinterpret_cast<const double4*>(xrow1 + colc);
+                const double4 ya = *reinterpret_cast<const double4*>(y0row + colc);
+                const double4 yb = *reinterpret_cast<const double4*>(y1row + colc);
+                if (!ok) { xa = zero4; xb = zero4; }
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.x, ya.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.x, yb.x, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb.x, ya.x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb.x, yb.x, acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.y, ya.y, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.y, yb.y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb.y, ya.y, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb.y, yb.y, acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.z, ya.z, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.z, yb.z, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb.z, ya.z, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb.z, yb.z, acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.w, ya.w, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.w, yb.w, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb.w, ya.w, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb.w, yb.w, acc[1][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Mp[wave][16 * t + lg + 4 * r][li] = acc[t][0][r];
+                Mp[wave][16 * t + lg + 4 * r][16 + li] = acc[t][1][r];
+            }
+        __syncthreads();
+        for (int e = tid; e < 32 * 32; e += 64 * NW) {
+            const int row = e >> 5, pc = e & 31;
+            double s0 = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) s0 += Mp[wv][row][pc];
+            Ms[row][pc] = s0;
+        }
+        __syncthreads();
+        // ---- phase 2: M2 = -M C ---------------------------------------------------------------------
+        for (int e = tid; e < 32 * 32; e += 64 * NW) {
+            const int row = e >> 5, qc = e & 31;
+            double s0 = 0.0;
+#pragma unroll 8
+            for (int pp = 0; pp < WY_NB; ++pp) s0 += Ms[row][pp] * Cs[pp][qc];
+            M2s[row][qc] = -s0;
+        }
+        __syncthreads();
+        // ---- phase 3: X += (-M2) Y ------------------------------------------------------------------
+        double m2a[2][8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) m2a[t][kt] = M2s[16 * t + li][4 * kt + lg];
+        const double* ybase = Yf + (size_t)(j0 + lg) * ldx;
+        for (int cc = cw; cc < ldx; cc += 64 * NW) {
+            const int col = cc + 4 * li;
+            const bool ok = col < ldx;
+            const int colc = ok ? col : 0;
+            double4 yv[8];
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt)
+                yv[kt] = *reinterpret_cast<const double4*>(ybase + (size_t)(4 * kt) * ldx + colc);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                double4 xv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xv[r] = *reinterpret_cast<const double4*>(X + (size_t)rowD[t][r] * ldx + colc);
+                wy_f64x4 d0, d1, d2, d3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { d0[r] = xv[r].x; d1[r] = xv[r].y; d2[r] = xv[r].z; d3[r] = xv[r].w; }
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt) {
+                    d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(m2a[t][kt], yv[kt].x, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(m2a[t][kt], yv[kt].y, d1, 0, 0, 0);
+                    d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(m2a[t][kt], yv[kt].z, d2, 0, 0, 0);
+                    d3 = __builtin_amdgcn_mfma_f64_16x16x4f64(m2a[t][kt], yv[kt].w, d3, 0, 0, 0);
+                }
+                if (ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r0 + 16 * t + lg + 4 * r < n)
+                            *reinterpret_cast<double4*>(X + (size_t)rowD[t][r] * ldx + col) = make_double4(d0[r], d1[r], d2[r], d3[r]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -2086,7 +2220,11 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
             // wavefronts per workgroup: a workgroup owns 16 rows of X, so there are only n / 16 of them (one per CU at
             // n = 3072) — more wavefronts splitting the columns is what hides the L2 latency of the operand streams
             const long nw = c->opt.eigh_wy_waves;
-            if (nw >= 16) SELLA_LAUNCH(c, wy_apply_mfma_kernel<16>, dim3((n + 15) / 16), dim3(1024), 0, X, ld, n, Yf, Gd, nblk);
+            if (c->opt.eigh_wy_rows == 32 && nw >= 8)
+                SELLA_LAUNCH(c, wy_apply_mfma2_kernel<8>, dim3((n + 31) / 32), dim3(512), 0, X, ld, n, Yf, Gd, nblk);
+            else if (c->opt.eigh_wy_rows == 32)
+                SELLA_LAUNCH(c, wy_apply_mfma2_kernel<4>, dim3((n + 31) / 32), dim3(256), 0, X, ld, n, Yf, Gd, nblk);
+            else if (nw >= 16) SELLA_LAUNCH(c, wy_apply_mfma_kernel<16>, dim3((n + 15) / 16), dim3(1024), 0, X, ld, n, Yf, Gd, nblk);
             else if (nw >= 8) SELLA_LAUNCH(c, wy_apply_mfma_kernel<8>, dim3((n + 15) / 16), dim3(512), 0, X, ld, n, Yf, Gd, nblk);
             else SELLA_LAUNCH(c, wy_apply_mfma_kernel<4>, dim3((n + 15) / 16), dim3(256), 0, X, ld, n, Yf, Gd, nblk);
         }

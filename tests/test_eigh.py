@@ -64,9 +64,16 @@ def test_panel_widths_and_variants(ctx):
             if ref is None:
                 ref = w
             np.testing.assert_allclose(w, ref, atol=1e-12 * np.abs(ref).max())
+        # back-transformation with 32 rows per workgroup (two row tiles), 4 and 8 wavefronts; 16 rows with 8 / 16 wavefronts
+        for rows, waves in ((32, 4), (32, 8), (16, 8), (16, 16)):
+            ctx.set_option('eigh_wy_rows', rows)
+            ctx.set_option('eigh_wy_waves', waves)
+            np.testing.assert_allclose(check(ctx, A), ref, atol=1e-12 * np.abs(ref).max())
     finally:
         ctx.set_option('eigh_nb', 16)
         ctx.set_option('eigh_wy_mfma', 1)
+        ctx.set_option('eigh_wy_rows', 16)
+        ctx.set_option('eigh_wy_waves', 4)
 
 
 def test_spectra(ctx):

@@ -14,6 +14,8 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 ctx = Context(0)
 if os.environ.get('EIGH_NB'):
     ctx.set_option('eigh_nb', int(os.environ['EIGH_NB']))
+if os.environ.get('EIGH_WY_ROWS'):
+    ctx.set_option('eigh_wy_rows', int(os.environ['EIGH_WY_ROWS']))
 if os.environ.get('EIGH_WY_WAVES'):
     ctx.set_option('eigh_wy_waves', int(os.environ['EIGH_WY_WAVES']))
 if os.environ.get('EIGH_LEAF'):

@@ -91,6 +91,32 @@ class EnsembleMember:
         return at
 
 
+class EmtSlabMember:
+    """configs[3] as BASELINE names it: member i = 256-atom Cu(111) EMT slab (8 x 8 x 4) with a lifted surface atom, lower
+    half pinned atom by atom, thermal jitter from seed i (3N = 768, 384 free coordinates, device EMT, default `Sella`
+    keywords); returns (atoms, the member's own keywords)."""
+    SELLA_KW = dict(order=1, eta=1e-4, gamma=0.1)
+
+    def __call__(self, i):
+        from sella_amd import Constraints
+        from sella_amd.atoms import EMT, fcc111
+        slab = fcc111('Cu', (8, 8, 4), vacuum=7.5)
+        slab.positions += 0.02 * np.random.RandomState(100 + i).normal(size=slab.positions.shape)
+        top = int(np.argmax(slab.positions[:, 2]))
+        site = slab.info['adsorbate_sites']['bridge']
+        slab.positions[top] += np.array([site[0], site[1], 1.9])
+        cons = Constraints(slab)
+        for a in slab:
+            if a.position[2] < slab.cell[2, 2] / 2.:
+                cons.fix_translation(a.index)
+        slab.calc = EMT()
+        return slab, dict(constraints=cons)
+
+    def warmup(self):
+        from sella_amd.ensemble import run_one
+        run_one(self(-1), 0.0, 3, self.SELLA_KW)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -112,6 +138,8 @@ def main():
     ap.add_argument('--ensemble-threads', type=int, default=-1,
                     help='host threads per GPU for the ensemble leg (persistent contexts, sella_amd.ensemble.EnsembleThreads); '
                          '-1: min(members per GPU, 8, 2 x CPUs per rank); 0 / 1: none')
+    ap.add_argument('--ensemble-emt', type=int, default=8,
+                    help='members of the second ensemble figure: 256-atom EMT slab searches, configs[3] as named (0: skip)')
     ap.add_argument('--ensemble-saturate', type=int, default=4,
                     help='second ensemble figure with this many times the members per GPU on up to 12 threads (0: skip)')
     ap.add_argument('--ensemble-procs', type=int, default=-1,
@@ -416,6 +444,22 @@ def main():
                 opt_stats['ensemble']['saturated'] = dict(replicas=nsat, host_threads_per_gpu=tsat, worker_processes_per_gpu=0,
                                                           searches_per_s=round(nsat / tsat_s, 3), seconds=round(tsat_s, 3),
                                                           lambda_min_negative=int((rs['summary'][:, 4] < 0).sum()))
+            if tpool is not None and world == 1 and args.ensemble_emt > 0:
+                # configs[3] as named: 256-atom EMT slab members (pinned lower half, 'ras'), same threads
+                emt_member = EmtSlabMember()
+                tpool.prepare(emt_member)
+                run_ensemble(emt_member, tpool.threads, fmax=0.0, steps=3, sella_kwargs=EmtSlabMember.SELLA_KW, threads=tpool)
+                t0e = time.perf_counter()
+                re_ = run_ensemble(emt_member, args.ensemble_emt, fmax=0.0, steps=args.ensemble_steps,
+                                   sella_kwargs=EmtSlabMember.SELLA_KW, threads=tpool)
+                te_ = time.perf_counter() - t0e
+                opt_stats['ensemble']['emt_members'] = dict(replicas=args.ensemble_emt, atoms=256, n=768, nfree=384,
+                                                            host_threads_per_gpu=tpool.threads, worker_processes_per_gpu=0,
+                                                            steps_per_replica=args.ensemble_steps,
+                                                            searches_per_s=round(args.ensemble_emt / te_, 3),
+                                                            optimizer_steps_per_s=round(float(re_['summary'][:, 1].sum()) / te_, 2),
+                                                            seconds=round(te_, 3),
+                                                            lambda_min_negative=int((re_['summary'][:, 4] < 0).sum()))
             if pool_note:
                 opt_stats['ensemble']['note'] = pool_note
             if pool is not None:

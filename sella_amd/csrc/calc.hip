@@ -30,6 +30,8 @@ struct sella_calc {
     std::vector<double> par, shifts;
     double rc = 0, acut = 0, cutoff = 0, beta = 0;
     std::vector<double> work;
+    double* dconst = nullptr;         // EMT: parameter table + shift vectors, resident
+    size_t dconst_bytes = 0;
 };
 
 extern "C" int sella_calc_model_create(sella_ctx* c, sella_mat A, const double* U, int nu, int n, double cc, sella_calc** out) {
@@ -57,6 +59,15 @@ extern "C" int sella_calc_emt_create(sella_ctx* c, int natoms, const double* par
     k->par.assign(par, par + (size_t)9 * natoms);
     k->shifts.assign(shifts, shifts + (size_t)3 * nshift);
     k->rc = rc; k->acut = acut; k->cutoff = cutoff; k->beta = beta;
+    k->dconst_bytes = ((size_t)9 * natoms + (size_t)3 * nshift) * sizeof(double);
+    if (dev_alloc(c, k->dconst_bytes, &k->dconst) == SELLA_OK) {
+        int st = h2d_async(c, k->dconst, par, (size_t)9 * natoms * sizeof(double));
+        if (st == SELLA_OK) st = h2d_async(c, k->dconst + (size_t)9 * natoms, shifts, (size_t)3 * nshift * sizeof(double));
+        if (st == SELLA_OK) st = stream_wait(c);
+        if (st != SELLA_OK) { dev_free(c, k->dconst, k->dconst_bytes); k->dconst = nullptr; }
+    } else {
+        k->dconst = nullptr;
+    }
     *out = k;
     return SELLA_OK;
 }
@@ -65,8 +76,8 @@ extern "C" int sella_calc_emt_create(sella_ctx* c, int natoms, const double* par
 extern "C" int sella_calc_eval(sella_calc* k, const double* x, double* f, double* g) {
     if (!k || !x || !f || !g) return SELLA_E_INVALID;
     ++k->ncalls;
-    if (k->kind == 1) return sella_emt_eval(k->c, k->natoms, x, k->par.data(), k->nshift, k->shifts.data(), k->rc, k->acut,
-                                            k->cutoff, k->beta, f, g);
+    if (k->kind == 1) return emt_eval_resident(k->c, k->natoms, x, k->par.data(), k->nshift, k->shifts.data(), k->dconst, k->rc,
+                                               k->acut, k->cutoff, k->beta, f, g);
     const int n = k->n;
     double* Ax = k->work.data();
     SCHK(sella_symm_mm(k->c, k->A, x, 1, Ax));
@@ -89,6 +100,7 @@ extern "C" int sella_calc_eval(sella_calc* k, const double* x, double* f, double
 extern "C" long sella_calc_ncalls(sella_calc* k) { return k ? k->ncalls : 0; }
 extern "C" int sella_calc_dim(sella_calc* k) { return k ? k->n : 0; }
 extern "C" int sella_calc_destroy(sella_calc* k) {
+    if (k && k->dconst) dev_free(k->c, k->dconst, k->dconst_bytes);
     delete k;
     return SELLA_OK;
 }

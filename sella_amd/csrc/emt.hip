@@ -124,13 +124,11 @@ __global__ __launch_bounds__(256) void emt_force_kernel(EmtArgs a) {
 
 using namespace sella;
 
-extern "C" int sella_emt_eval(sella_ctx* c, int n, const double* pos, const double* par /* 9 x n */, int nshift,
-                              const double* shifts, double rc, double acut, double cutoff, double beta,
-                              double* energy, double* grad) {
-    if (!c || n <= 0 || !pos || !par || nshift <= 0 || !shifts || !energy || !grad) {
-        set_error("emt_eval: invalid arguments");
-        return SELLA_E_INVALID;
-    }
+// dconst != nullptr: the parameter table and the shift vectors are resident already (9 n + 3 nshift doubles, uploaded by
+// the caller once: sella_calc_emt_create) — a force call is then one upload (positions), three kernels, one read-back
+int sella::emt_eval_resident(sella_ctx* c, int n, const double* pos, const double* par, int nshift, const double* shifts,
+                             const double* dconst, double rc, double acut, double cutoff, double beta, double* energy,
+                             double* grad) {
     const size_t words = (size_t)3 * n + (size_t)9 * n + (size_t)3 * nshift + (size_t)4 * n + (size_t)3 * n + 64;
     double* buf;
     SCHK(scratch_get(c, SCR_MISC0, words * sizeof(double), &buf));
@@ -143,8 +141,13 @@ extern "C" int sella_emt_eval(sella_ctx* c, int n, const double* pos, const doub
     double* dea = dde + n;
     double* dgr = dea + n;
     SCHK(h2d_async(c, dpos, pos, (size_t)3 * n * sizeof(double)));
-    SCHK(h2d_async(c, dpar, par, (size_t)9 * n * sizeof(double)));
-    SCHK(h2d_async(c, dsh, shifts, (size_t)3 * nshift * sizeof(double)));
+    if (dconst) {
+        dpar = const_cast<double*>(dconst);
+        dsh = dpar + 9 * (size_t)n;
+    } else {
+        SCHK(h2d_async(c, dpar, par, (size_t)9 * n * sizeof(double)));
+        SCHK(h2d_async(c, dsh, shifts, (size_t)3 * nshift * sizeof(double)));
+    }
     EmtArgs a;
     a.n = n; a.nshift = nshift; a.pos = dpos; a.shifts = dsh;
     a.p.E0 = dpar; a.p.s0 = dpar + n; a.p.V0 = dpar + 2 * (size_t)n; a.p.eta2 = dpar + 3 * (size_t)n;
@@ -156,12 +159,24 @@ extern "C" int sella_emt_eval(sella_ctx* c, int n, const double* pos, const doub
     hipLaunchKernelGGL(emt_cohesive_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
     hipLaunchKernelGGL(emt_force_kernel, dim3(n), dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
-    std::vector<double> ea(n);
-    SCHK(d2h_async(c, ea.data(), dea, (size_t)n * sizeof(double)));
-    SCHK(d2h_async(c, grad, dgr, (size_t)3 * n * sizeof(double)));
+    // per-atom energies and the gradient sit back to back: one read-back
+    std::vector<double>& out = c->hbuf_b;
+    out.resize((size_t)4 * n);
+    SCHK(d2h_async(c, out.data(), dea, (size_t)4 * n * sizeof(double)));
     SCHK(stream_wait(c));
     double e = 0.0;
-    for (int i = 0; i < n; ++i) e += ea[i];
+    for (int i = 0; i < n; ++i) e += out[i];
     *energy = e;
+    for (size_t i = 0; i < (size_t)3 * n; ++i) grad[i] = out[(size_t)n + i];
     return SELLA_OK;
+}
+
+extern "C" int sella_emt_eval(sella_ctx* c, int n, const double* pos, const double* par /* 9 x n */, int nshift,
+                              const double* shifts, double rc, double acut, double cutoff, double beta,
+                              double* energy, double* grad) {
+    if (!c || n <= 0 || !pos || !par || nshift <= 0 || !shifts || !energy || !grad) {
+        set_error("emt_eval: invalid arguments");
+        return SELLA_E_INVALID;
+    }
+    return emt_eval_resident(c, n, pos, par, nshift, shifts, nullptr, rc, acut, cutoff, beta, energy, grad);
 }

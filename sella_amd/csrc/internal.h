@@ -282,6 +282,9 @@ int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const do
 // on the orthogonal complement of their span; *r_io and mu are updated (r grows by at most one per rank-one term)
 int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, Mat* Wt, const double* Up, const double* Zp,
                       int ldp, int kk, int* nrank1);
+// emt.hip: sella_emt_eval with the parameter table and shift vectors optionally resident (dconst: 9 n + 3 nshift doubles)
+int emt_eval_resident(sella_ctx* c, int n, const double* pos, const double* par, int nshift, const double* shifts,
+                      const double* dconst, double rc, double acut, double cutoff, double beta, double* energy, double* grad);
 // stepper.hip: step family on m modes = rows idx[0..m) of a device panel (gathered into matrices the stepper owns)
 int stepper_from_panel(sella_ctx* c, int kind, const double* src, int ld, const int* idx, int m, int n, const double* ev,
                        const double* gh, int order, sella_stepper** out);

@@ -1,0 +1,33 @@
+"""configs[3] as named — 256-atom EMT slab members — on host threads (EnsembleThreads) and on worker processes
+(EnsemblePool): searches/s.   usage: emt_ensemble.py [members] [t<threads> | p<processes> ...]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import EmtSlabMember  # noqa: E402
+from sella_amd.ensemble import EnsemblePool, EnsembleThreads, run_ensemble  # noqa: E402
+
+if __name__ == '__main__':
+    nmem = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    modes = sys.argv[2:] or ['t1', 't4', 't8', 'p4']
+    fac = EmtSlabMember()
+    ref = None
+    for mode in modes:
+        k = int(mode[1:])
+        if mode[0] == 't':
+            with EnsembleThreads(k) as pool:
+                pool.prepare(fac)
+                t = time.perf_counter()
+                res = run_ensemble(fac, nmem, fmax=0.0, steps=20, sella_kwargs=EmtSlabMember.SELLA_KW, threads=pool)
+                dt = time.perf_counter() - t
+        else:
+            with EnsemblePool(k) as pool:
+                pool.prepare(fac, [])
+                t = time.perf_counter()
+                res = run_ensemble(fac, nmem, fmax=0.0, steps=20, sella_kwargs=EmtSlabMember.SELLA_KW, pool=pool, prepared=True)
+                dt = time.perf_counter() - t
+        same = True if ref is None else bool((res['summary'] == ref).all())
+        ref = res['summary'] if ref is None else ref
+        print('%s %d: %d members in %.3f s = %.1f searches/s (bit-identical to the first run: %s)'
+              % ('threads' if mode[0] == 't' else 'processes', k, nmem, dt, nmem / dt, same), flush=True)

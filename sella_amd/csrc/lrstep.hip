@@ -501,6 +501,11 @@ struct LrJob {
     const double* gram;        // host: ss, sy, yy of the two rows (mode 0) or nullptr (computed on the device)
     bool want_modes;
     int slot_ws, slot_panel;
+    // optional: what the caller has put on the device already in ONE transfer — the residual rows as copies of the
+    // inputs (2 rows, stride ldx), the eigenvalues and a 16-double Gram block (entries 0..2 set) — instead of four copies here
+    double* Rpre = nullptr;
+    double* mu_dev = nullptr;
+    double* G_dev = nullptr;
     // results
     LrWork w;
     double* Wnew;
@@ -522,9 +527,17 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
     j.Wnew = panel + 2 * (size_t)ld;
     j.ldw = ld;
     double* W = Wm->d;
+    const bool packed = j.Rpre && j.mu_dev && j.G_dev && j.ldx == ld;
+    if (packed) {
+        R = j.Rpre;
+        w.mu = j.mu_dev;
+        w.G = j.G_dev;
+    }
     // small uploads: mu and the Gram of the input rows
-    if (r > 0) SCHK(h2d_async(c, w.mu, j.mu, (size_t)r * sizeof(double)));
-    if (j.gram) {
+    if (packed) {
+    } else if (r > 0) SCHK(h2d_async(c, w.mu, j.mu, (size_t)r * sizeof(double)));
+    if (packed) {
+    } else if (j.gram) {
         SCHK(h2d_async(c, w.G, j.gram, 3 * sizeof(double)));
     } else {
         // G[h * 2 + i] = X_i . X_h -> ss = G[0], sy = G[1] ... laid out to match (ss, sy, yy) needs a shuffle: use 3 dots
@@ -532,7 +545,7 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
         SCHK(launch_gemv_rows(c, j.Xd + j.ldx, 1, n, j.ldx, j.Xd + j.ldx, j.ldx, 1, w.G + 2, 1, GemvEpi()));   // yy
     }
     // residual rows start as copies of the inputs
-    SCHK(launch_axpby2d(c, 2, n, 1.0, j.Xd, j.ldx, 0.0, nullptr, 0, R, ld));
+    if (!packed) SCHK(launch_axpby2d(c, 2, n, 1.0, j.Xd, j.ldx, 0.0, nullptr, 0, R, ld));
     if (r > 0) {
         // two classical Gram-Schmidt sweeps of both rows against W
         GemvEpi neg;                                  // C, C2 hold the NEGATED coefficients: lincomb adds them
@@ -663,13 +676,27 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled) {
     }
     if (!(std::sqrt(gram[0]) >= 1e-8)) return SELLA_OK;             // B is left alone: the general route knows how
     const int ld = round_up(n, 8);
+    // ONE transfer for everything the full-space job reads from the host: the rows s, y, g; s, y again as the residual
+    // rows the two sweeps work on; the eigenvalues; the Gram entries of (s, y)
+    const int ldmu = round_up(*a->r + 2, 8);
+    const size_t nstage = (size_t)5 * ld + ldmu + 16;
     double* X;
-    SCHK(scratch_get(c, SCR_UPD0, (size_t)3 * ld * sizeof(double), &X));
-    SCHK(h2d_async(c, X, a->dx, (size_t)n * sizeof(double)));
-    SCHK(h2d_async(c, X + ld, y.data(), (size_t)n * sizeof(double)));
-    SCHK(h2d_async(c, X + 2 * (size_t)ld, a->g_new, (size_t)n * sizeof(double)));
+    SCHK(scratch_get(c, SCR_UPD0, nstage * sizeof(double), &X));
+    {
+        std::vector<double>& hs = c->hbuf_b;
+        hs.assign(nstage, 0.0);
+        std::copy(a->dx, a->dx + n, hs.begin());
+        std::copy(y.begin(), y.end(), hs.begin() + ld);
+        std::copy(a->g_new, a->g_new + n, hs.begin() + 2 * (size_t)ld);
+        std::copy(a->dx, a->dx + n, hs.begin() + 3 * (size_t)ld);
+        std::copy(y.begin(), y.end(), hs.begin() + 4 * (size_t)ld);
+        std::copy(a->mu, a->mu + *a->r, hs.begin() + 5 * (size_t)ld);
+        std::copy(gram, gram + 3, hs.begin() + 5 * (size_t)ld + ldmu);
+        SCHK(h2d_async(c, X, hs.data(), nstage * sizeof(double)));
+    }
     LrJob F;
     F.Wt = Wm; F.r = *a->r; F.n = n; F.mode = 0; F.mu = a->mu; F.lam0 = a->lam0; F.Xd = X; F.ldx = ld; F.gram = gram;
+    if (Wm->ld == ld) { F.Rpre = X + 3 * (size_t)ld; F.mu_dev = X + 5 * (size_t)ld; F.G_dev = F.mu_dev + ldmu; }
     F.want_modes = propose && !view; F.slot_ws = SCR_EIG0; F.slot_panel = SCR_EIG1;
     SCHK(lr_job_queue(c, F));
     LrJob S;

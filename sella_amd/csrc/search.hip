@@ -301,7 +301,64 @@ int one_step(sella_search* S) {
         }
         S->initialized = true;
     }
-    if (S->H_none) { set_error("search: a step without curvature information (eig = False) is not covered"); return SELLA_E_UNSUPPORTED; }
+    if (S->H_none) {
+        // no curvature information yet (eig = False, the default of a minimisation, optimize.py:20-39): the step family
+        // sees the identity (stepper.py:62-64) — in structured terms no explicit pairs and lam0 = 1 — and the first
+        // secant pair initialises the Hessian (linalg.py:274-289)
+        const double f_old = S->f;
+        S->gold = S->g;
+        S->lam0 = 1.0;
+        S->r = 0;
+        S->mu.assign(8, 0.0);
+        {
+            sella_opt_step_t& a = S->io;
+            a = sella_opt_step_t();
+            a.flags = SELLA_OPT_PROPOSE;
+            a.n = S->n;
+            a.B = SELLA_NO_MAT; a.Wt = SELLA_NO_MAT; a.r = &S->r; a.mu = S->mu.data(); a.lam0 = 1.0;
+            a.update_method = S->p.update_method; a.symm = S->p.symm;
+            a.Bsub = SELLA_NO_MAT; a.Wt_sub = SELLA_NO_MAT;
+            std::vector<double> gfree;
+            int rsub = 0;
+            if (!S->idx.empty()) { a.idx = S->idx.data(); a.m = S->m; a.r_sub = &rsub; a.mu_sub = S->mu.data(); }
+            a.g_new = S->g.data();
+            a.delta = S->delta; a.rho = S->rho;
+            a.stepper_kind = S->p.stepper_kind; a.order = S->p.order; a.cons = S->p.cons; a.maxiter = 1000;
+            a.tol = S->p.stepper_kind == SELLA_STEP_QN ? 1e-10 : 1e-15;
+            a.s_out = S->s.data();
+            SCHK(sella_opt_step(S->c, &a));
+            S->smag = a.smag_out;
+        }
+        const bool rediag0 = wants_diagonalisation(S);
+        S->nsteps_since_diag = rediag0 ? 0 : S->nsteps_since_diag + 1;
+        double gd = 0.0, dd = 0.0;
+        for (int i = 0; i < S->n; ++i) {
+            S->target[i] = S->x[i] + S->s[i];
+            S->dx[i] = S->target[i] - S->x[i];
+            gd += S->gold[i] * S->dx[i];
+            dd += S->dx[i] * S->dx[i];
+        }
+        S->x = S->target;
+        SCHK(evaluate(S));
+        // peswrapper.py:578-602 with H = identity: predicted change g.dx + dx.dx / 2
+        const double predicted = gd + 0.5 * dd;
+        if (std::sqrt(dd) >= 1e-8) {
+            std::vector<double> dg(S->n);
+            for (int i = 0; i < S->n; ++i) dg[i] = S->g[i] - S->gold[i];
+            SCHK(update_block(S, S->dx.data(), dg.data(), 1));
+        }
+        if (rediag0) SCHK(diagonalise(S));
+        if (std::fabs(predicted) >= 1e-14) {                     // optimize.py:413-434
+            const double rho = (S->f - f_old) / predicted;
+            if (!(1.0 / S->p.rho_dec <= rho && rho <= S->p.rho_dec)) S->delta = std::max(S->smag * S->p.sigma_dec, S->p.delta_min);
+            else if (1.0 / S->p.rho_inc < rho && rho < S->p.rho_inc) S->delta = std::max(S->p.sigma_inc * S->smag, S->delta);
+            S->rho = rho;
+        } else {
+            S->rho = 1.0;
+        }
+        S->have_step = false;
+        return SELLA_OK;
+    }
     if (!S->have_step) SCHK(call_opt_step(S, SELLA_OPT_PROPOSE, S->f));
     const bool rediag = wants_diagonalisation(S);
     S->nsteps_since_diag = rediag ? 0 : S->nsteps_since_diag + 1;
@@ -329,8 +386,8 @@ extern "C" int sella_search_create(sella_ctx* c, sella_calc* calc, int n, const 
         return SELLA_E_INVALID;
     }
     if (p->update_method != SELLA_UPD_TS_BFGS || p->cons < 0 || p->cons > 1 || p->stepper_kind < SELLA_STEP_QN ||
-        p->stepper_kind > SELLA_STEP_PRFO || !p->eig) {
-        set_error("search: configuration outside the library loop (TS-BFGS, trust region / per-atom measure, built-in families, eig)");
+        p->stepper_kind > SELLA_STEP_PRFO) {
+        set_error("search: configuration outside the library loop (TS-BFGS, trust region / per-atom measure, built-in families)");
         return SELLA_E_UNSUPPORTED;
     }
     sella_search* S = new sella_search();

@@ -8,7 +8,7 @@ ensemble of independent searches consists of (BASELINE configs[3]) the same loop
     Cartesian PES, no constraints or constraints that pin single Cartesian coordinates (all satisfied);
     a calculator that lives in the library (`atoms.calc.device_calculator()`: the model PES, device EMT);
     3N >= `linalg.LR_MIN_DIM` (structured approximate Hessian), TS-BFGS, `rs` in {'tr', 'ras'}, built-in step families,
-    `eig=True`; no trajectory, no log, no observers.
+    no trajectory, no log, no observers.
 
 `LibrarySearch.applies(atoms, **kwargs)` says whether a set of `Sella` keywords is covered; `run_one`
 (sella_amd/ensemble.py) uses it for every member it can.  Results agree with the general driver's to the amplification
@@ -72,8 +72,6 @@ class LibrarySearch:
             return False
         order = kw.get('order', 1)
         table = _default_kwargs['minimum' if order == 0 else 'saddle']
-        if not (table['eig'] if kw.get('eig') is None else kw['eig']):
-            return False
         try:
             rs = get_restricted_step(kw['rs'] if kw.get('rs') is not None else 'ras')
             method = kw.get('method') or table['method']
@@ -102,7 +100,7 @@ class LibrarySearch:
         n = 3 * len(atoms)
         nfree = n if free is None else len(free)
         p = _lib.SearchParams()
-        p.order, p.eig, p.threepoint = int(order), 1, int(bool(threepoint))
+        p.order, p.eig, p.threepoint = int(order), int(bool(pick(eig, 'eig'))), int(bool(threepoint))
         p.dav_method = DAVIDSON_METHODS['jd0']
         p.stepper_kind, p.cons = STEPPER_KINDS[family._kind], CONSTRAINT_KINDS[rs_cls.measure]
         p.update_method, p.symm = UPDATE_METHODS['TS-BFGS'], 2

@@ -17,9 +17,9 @@ def structured_from_96():
     linalg.LR_MIN_DIM = old
 
 
-def _model(ctx, n=120, seed=41):
+def _model(ctx, n=120, seed=41, nneg=1):
     from sella_amd.atoms import Atoms, QuadraticCubicModel
-    A = hessian_like(n, seed)[0]
+    A = hessian_like(n, seed, nneg=nneg)[0]
     dA = ctx.upload(A)
     rng = np.random.RandomState(seed + 1)
     U = rng.normal(size=(8, n))
@@ -78,6 +78,26 @@ def test_pinned_slab_search_in_the_library(ctx):
     assert ls.rank_view > 0
 
 
+def test_minimisation_without_curvature_information(ctx):
+    """order = 0 with the defaults of a minimisation (eig = False, quasi-Newton family, optimize.py:20-39): the search
+    starts from the identity, the first secant pair initialises the Hessian, no diagonalisation ever."""
+    from sella_amd import Sella
+    from sella_amd.internal import Constraints
+    from sella_amd.search import LibrarySearch
+    a1, a2 = _model(ctx, nneg=0), _model(ctx, nneg=0)
+    kw = dict(order=0, proj_trans=False, rs='tr')
+    assert LibrarySearch.applies(a1, constraints=Constraints(a1), **kw)
+    ls = LibrarySearch(a1, constraints=Constraints(a1), **kw)
+    ls.run(0.0, 8)
+    opt = Sella(a2, constraints=Constraints(a2), logfile=None, **kw)
+    opt.run(0.0, 8)
+    assert (ls.nsteps, ls.neval) == (opt.nsteps, opt.pes.neval) == (8, 9)
+    np.testing.assert_allclose(a1.positions, a2.positions, atol=1e-9)
+    assert ls.energy == pytest.approx(opt.pes.get_f(), abs=1e-10) and ls.energy < 0.5 * float(a1.calc.energy_and_gradient(
+        _model(ctx, nneg=0).positions)[0])
+    assert ls.delta == pytest.approx(opt.delta, rel=1e-8) and ls.rho == pytest.approx(opt.rho, rel=1e-6)
+
+
 def test_library_search_says_what_it_covers(ctx):
     from conftest_shim import emt_slab
     from sella_amd.atoms import Atoms, MorseCluster
@@ -86,7 +106,6 @@ def test_library_search_says_what_it_covers(ctx):
     at = _model(ctx)
     assert not LibrarySearch.applies(at, constraints=Constraints(at))                 # default: global translation constraint
     assert not LibrarySearch.applies(at, constraints=Constraints(at), proj_trans=False, trajectory='x.traj')
-    assert not LibrarySearch.applies(at, constraints=Constraints(at), proj_trans=False, order=0)     # eig=False by default
     assert not LibrarySearch.applies(at, constraints=Constraints(at), proj_trans=False, rs='mis')
     mc = Atoms(['Xe'] * 40, np.random.RandomState(0).normal(size=(40, 3)), pbc=True)
     mc.calc = MorseCluster()

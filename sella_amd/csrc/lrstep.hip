@@ -50,7 +50,7 @@ __device__ __forceinline__ double blk_max(double v, double* red) {
 }
 
 // scalar slots of the workspace (doubles)
-enum { SC_M1 = 0, SC_M2, SC_JS, SC_SBS, SC_SIG1, SC_SIG2, SC_CAREFUL, SC_KEEP1, SC_KEEP2, SC_FAIL, SC_GPERP2 = 16, SC_N = 32 };
+enum { SC_M1 = 0, SC_M2, SC_JS, SC_SBS, SC_SIG1, SC_SIG2, SC_KEEP1, SC_KEEP2, SC_FAIL, SC_GPERP2 = 16, SC_N = 32 };
 // gram slots: host / device Gram of the input rows and of the residual rows
 enum { G_SS = 0, G_SY, G_YY, G_A11 = 8, G_A12, G_A22 = 11 };
 
@@ -89,7 +89,6 @@ __global__ __launch_bounds__(256) void lr_pre_kernel(PreArgs a) {
     for (int i = tid; i < a.n; i += 256) a.row2[i] *= inv22;
     const double y1 = keep1 ? a12 / r11 - a.C3[r] : 0.0;             // (C3 negated, like C and C2)
     if (tid == 0) {
-        a.sc[SC_CAREFUL] = 0.0;
         a.sc[SC_KEEP1] = keep1 ? 1.0 : 0.0;
         a.sc[SC_KEEP2] = keep2 ? 1.0 : 0.0;
         a.sc[SC_FAIL] = 0.0;
@@ -722,17 +721,14 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled) {
     }
     SCHK(stream_wait(c));
     auto sound = [](const LrJob& j) {
-        if (j.hsc[SC_CAREFUL] != 0.0 || j.hsc[SC_FAIL] != 0.0) return false;
+        if (j.hsc[SC_FAIL] != 0.0) return false;
         for (int i = 0; i < j.r + 2; ++i) if (!(j.hD[i] == j.hD[i])) return false;
         return true;
     };
-    if (!sound(F) || (view && !sound(S))) {                            // nothing committed
+    if (!sound(F) || (view && !sound(S))) {                            // nothing committed: the general route takes the step
         if (getenv("SELLA_DEBUG_TIMING"))
-            fprintf(stderr, "opt_step: coordinate update set aside (full: careful %g fail %g keep %g %g; view: careful %g fail %g keep %g %g)\n",
-                    F.hsc[SC_CAREFUL], F.hsc[SC_FAIL], F.hsc[SC_KEEP1], F.hsc[SC_KEEP2], view ? S.hsc[SC_CAREFUL] : 0.0,
-                    view ? S.hsc[SC_FAIL] : 0.0, view ? S.hsc[SC_KEEP1] : 0.0, view ? S.hsc[SC_KEEP2] : 0.0);
-        if (getenv("SELLA_DEBUG_TIMING") && view)
-            fprintf(stderr, "   view rows: uu %g uz %g zz %g | residual Gram %g %g %g\n", S.hsc[20], S.hsc[21], S.hsc[22], S.hsc[23], S.hsc[24], S.hsc[25]);
+            fprintf(stderr, "opt_step: coordinate update set aside (secular solver flag: full %g, view %g)\n", F.hsc[SC_FAIL],
+                    view ? S.hsc[SC_FAIL] : 0.0);
         return SELLA_OK;
     }
     *handled = true;

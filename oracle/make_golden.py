@@ -634,6 +634,52 @@ def gen_numhess(ref, orc):
     return cases
 
 
+def gen_numhess_model(ref, orc):
+    """The reference's NumericalHessian (sella/linalg.py:14-101) on the model PES the library's own calculator
+    implements, f(x) = 1/2 x^T A x + c/3 sum_j (u_j . x)^3, in the full space and seen through a SELECTION of
+    coordinates (what constraints that pin single coordinates project with): pins `sella_fd_matvec` (csrc/calc.hip),
+    the restatement of that operator on the far side of the calculator boundary."""
+    out, cases = {}, []
+    for i, (n, nfree, three, eta) in enumerate(((12, None, False, 1e-4), (12, None, True, 1e-4), (15, 9, False, 1e-4),
+                                                (15, 9, True, 1e-3))):
+        rng = np.random.RandomState(900 + i)
+        A = rng.normal(size=(n, n))
+        A = 0.5 * (A + A.T)
+        Uc = rng.normal(size=(4, n))
+        Uc /= np.linalg.norm(Uc, axis=1)[:, None]
+        c = 0.05
+
+        def f(x, A=A, Uc=Uc, c=c):
+            p = Uc @ x
+            return 0.5 * x @ (A @ x) + c / 3.0 * np.sum(p ** 3), A @ x + Uc.T @ (c * p ** 2)
+        x = rng.normal(size=n)
+        _, g = f(x)
+        free = None if nfree is None else np.sort(rng.permutation(n)[:nfree])
+        U = None if free is None else np.eye(n)[:, free]
+        m = n if free is None else nfree
+        Hr = ref.linalg.NumericalHessian(f, x, g, eta, three, U)
+        Ho = orc.FiniteDifferenceHessian(f, x, g, eta, three, U)
+        M = rng.normal(size=(m, 5))
+        gp = g if U is None else U.T @ g
+        xp = x if U is None else U.T @ x
+        M[:, 0] = xp - gp * (xp @ gp) / (gp @ gp)           # orthogonal to g: oriented by x
+        M[:, 1] -= M[:, 0] * (M[:, 1] @ M[:, 0]) / (M[:, 0] @ M[:, 0])
+        M[:, 1] -= gp * (M[:, 1] @ gp) / (gp @ gp)          # orthogonal to g and x: oriented by its leading component
+        M[:, 2] *= -1e-3                                    # short vector
+        M[:, 4] = 0.0                                       # zero vector branch
+        r = Hr.dot(M)
+        o = Ho.dot(M)
+        close(o, r, 1e-10, f'NumericalHessian on the model PES [{n},{nfree},{three}]')
+        out[f'c{i}_A'], out[f'c{i}_U'] = A, Uc
+        out[f'c{i}_x'], out[f'c{i}_g'], out[f'c{i}_M'] = x, g, M
+        if free is not None:
+            out[f'c{i}_free'] = free
+        out[f'c{i}_out'], out[f'c{i}_Vs'], out[f'c{i}_AVs'] = r, Hr.Vs, Hr.AVs
+        cases.append(dict(id=i, n=n, nfree=-1 if nfree is None else nfree, threepoint=three, eta=eta, c=c))
+    np.savez_compressed(os.path.join(GOLD, 'g12_numhess_model.npz'), **out)
+    return cases
+
+
 def gen_big_digests(ref, orc, sizes):
     """Scalar digests at benchmark sizes (matrices are regenerated from seeds)."""
     dig = {}
@@ -727,7 +773,8 @@ def main():
                      ('g8_mis', gen_restricted_mis),
                      ('g9_numhess', gen_numhess),
                      ('g10_irc', gen_irc),
-                     ('g11_sparse_internal', gen_sparse_internal)):
+                     ('g11_sparse_internal', gen_sparse_internal),
+                     ('g12_numhess_model', gen_numhess_model)):
         if (only and name not in only) or (args.converged and not only):
             continue
         t0 = time.time()

@@ -105,3 +105,39 @@ def test_search_through_the_library_calculator(ctx, monkeypatch):
     assert runs[True][1] == runs[False][1] and runs[True][2] == runs[False][2]
     assert runs[True][1] > 20
     np.testing.assert_allclose(runs[True][0], runs[False][0], atol=1e-8)
+
+
+def test_fd_operator_against_the_reference(ctx, manifest):
+    """`sella_fd_matvec` over `sella_calc_model_*` against golden vectors of the REFERENCE's `NumericalHessian`
+    (sella/linalg.py:14-101) on the same model PES: products — through every branch of the orientation rule, a short
+    vector, the zero vector — and the remembered secant pairs, in the full space and through a selection of
+    coordinates, forward and central differences (`g12_numhess_model`, oracle/make_golden.py)."""
+    from conftest import load_golden
+    from sella_amd import _lib
+    from sella_amd.device import DeviceCalculator, DeviceFdOperator
+    g = load_golden('g12_numhess_model')
+    assert len(manifest['g12_numhess_model']) == 4
+    for case in manifest['g12_numhess_model']:
+        i, n = case['id'], case['n']
+        A, U, x, g0, M = (g[f'c{i}_{k}'] for k in ('A', 'U', 'x', 'g', 'M'))
+        free = g[f'c{i}_free'].astype(np.int32) if case['nfree'] > 0 else None
+        dA = ctx.upload(A)
+        dc = DeviceCalculator.model(ctx, dA, U, case['c'])
+        f0, gl = dc.eval(x)
+        np.testing.assert_allclose(gl, g0, atol=1e-13 * max(1.0, np.abs(g0).max()))
+        op = DeviceFdOperator(dc, x, g0, case['eta'], case['threepoint'], free)
+        m = op.shape[0]
+        assert m == M.shape[0]
+        out = np.empty_like(M)
+        for col in range(M.shape[1]):
+            v = np.ascontiguousarray(M[:, col])
+            o = np.empty(m)
+            assert _lib.lib().sella_fd_matvec(op._h, v.ctypes.data_as(ctypes.c_void_p), o.ctypes.data_as(ctypes.c_void_p), m) == 0
+            out[:, col] = o
+        scale = max(1.0, np.abs(g[f'c{i}_out']).max())
+        # (a last-bit difference of the gradient — device matvec against NumPy's — is amplified by 1 / eta)
+        tol = 4e-16 * np.abs(A).sum(axis=1).max() * max(1.0, np.abs(x).max()) / case['eta'] * 50
+        np.testing.assert_allclose(out, g[f'c{i}_out'], atol=tol * scale, err_msg=str(case))
+        np.testing.assert_array_equal(op.Vs, g[f'c{i}_Vs'])
+        np.testing.assert_allclose(op.AVs, g[f'c{i}_AVs'], atol=tol * scale)
+        assert op.calls == M.shape[1] and op.Vs.shape[1] == M.shape[1] - 1        # the zero vector is not remembered

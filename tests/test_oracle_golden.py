@@ -115,6 +115,24 @@ def test_numerical_hessian(manifest):
         np.testing.assert_allclose(H.AVs, g[f'c{i}_AVs'], atol=1e-12)
 
 
+def test_numerical_hessian_on_the_model_pes(manifest):
+    """The oracle's finite-difference operator on the model PES the library's calculator implements, incl. a selection
+    basis (`g12_numhess_model`): the vectors the library-side operator is pinned with (tests/test_library_calculator.py)."""
+    g = load_golden('g12_numhess_model')
+    for case in manifest['g12_numhess_model']:
+        i, n = case['id'], case['n']
+        A, Uc, c = g[f'c{i}_A'], g[f'c{i}_U'], case['c']
+
+        def f(x, A=A, Uc=Uc, c=c):
+            p = Uc @ x
+            return 0.5 * x @ (A @ x) + c / 3.0 * np.sum(p ** 3), A @ x + Uc.T @ (c * p ** 2)
+        U = np.eye(n)[:, g[f'c{i}_free']] if case['nfree'] > 0 else None
+        H = orc.FiniteDifferenceHessian(f, g[f'c{i}_x'], g[f'c{i}_g'], case['eta'], case['threepoint'], U)
+        np.testing.assert_allclose(H.dot(g[f'c{i}_M']), g[f'c{i}_out'], atol=1e-10)
+        np.testing.assert_allclose(H.Vs, g[f'c{i}_Vs'], atol=1e-12)
+        np.testing.assert_allclose(H.AVs, g[f'c{i}_AVs'], atol=1e-10)
+
+
 class _OraclePES:
     int = None
     n_cell_dof = 0

@@ -418,8 +418,15 @@ int sella_search_create(sella_ctx* ctx, sella_calc* calc, int n, const double* x
 int sella_search_seed(sella_search* search, double energy, const double* grad);
 int sella_search_run(sella_search* search, double fmax, long steps, int* converged);
 /* x, g (n each, may be NULL); scalars[5] = f, fmax, delta, rho, lowest eigenvalue of the approximate Hessian;
- * counters[5] = optimizer steps, force calls, one-call steps, explicit rank, explicit rank of the view (-1: none)     */
+ * counters[6] = optimizer steps, force calls, one-call steps, explicit rank, explicit rank of the view (-1: none),
+ * first-use diagonalisation done (0 / 1)                                                                              */
 int sella_search_state(sella_search* search, double* x, double* g, double* scalars, long* counters);
+/* Hand the approximate Hessian over to the caller, who continues with the general driver: the matrix handles change owner
+ * (the search cannot be run again).  mats[4] = B, Wt, Bsub, Wt_sub (SELLA_NO_MAT where absent); ints[8] = r (-1: no
+ * Hessian yet), r_sub (-1: no view), rows of Wt, rows of Wt_sub, B_stale, Bsub_stale (the dense matrices lag behind the
+ * decompositions: sella_lr_materialize), steps since the last diagonalisation, first_diag; mu / mu_sub: `rows` entries.  */
+int sella_search_release_hessian(sella_search* search, sella_mat* mats, long* ints, double* mu, double* mu_sub,
+                                 double* lam0);
 int sella_search_destroy(sella_search* search);
 
 /* ---- profiling hooks (bench.py roofline leg) ---------------------------------------------- */

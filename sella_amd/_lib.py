@@ -126,6 +126,7 @@ SIGNATURES = {
     'sella_search_seed': (c_int, [c_void_p, c_double, c_void_p]),
     'sella_search_run': (c_int, [c_void_p, c_double, c_long, c_int_p]),
     'sella_search_state': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'sella_search_release_hessian': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
     'sella_search_destroy': (c_int, [c_void_p]),
     'sella_opt_step': (c_int, [c_void_p, POINTER(OptStepArgs)]),
     'sella_lr_materialize': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_double]),

@@ -29,7 +29,7 @@ struct sella_search {
     // point
     std::vector<double> x, g, gold, s, dx, target;
     double f = 0.0, delta = 0.0, rho = 1.0, smag = 0.0;
-    bool have_fg = false, initialized = false, first_diag = true, have_step = false;
+    bool have_fg = false, initialized = false, first_diag = true, have_step = false, released = false;
     long nsteps_since_diag = 0, nsteps = 0, neval = 0, nfused = 0;
     // approximate Hessian: structured form (+ view of the free coordinates)
     bool H_none = true, have_view = false;
@@ -409,6 +409,7 @@ extern "C" int sella_search_create(sella_ctx* c, sella_calc* calc, int n, const 
 // Optimizer.irun: convergence first, then steps until converged or `steps` taken
 extern "C" int sella_search_run(sella_search* S, double fmax, long steps, int* converged) {
     if (!S || !converged) return SELLA_E_INVALID;
+    if (S->released) { set_error("search: its Hessian was handed over to the caller"); return SELLA_E_INVALID; }
     *converged = 0;
     if (!S->have_fg) SCHK(evaluate(S));
     if (fmax_now(S) < fmax) { *converged = 1; return SELLA_OK; }
@@ -449,7 +450,34 @@ extern "C" int sella_search_state(sella_search* S, double* x, double* g, double*
         counters[2] = S->nfused;
         counters[3] = S->r;
         counters[4] = S->have_view ? S->r_sub : -1;
+        counters[5] = S->initialized ? 1 : 0;
     }
+    return SELLA_OK;
+}
+
+// Hand the approximate Hessian over to the caller (who continues the search with the general driver): the matrix handles
+// change owner — the search keeps none and cannot be run again.  mats[4] = B, Wt, Bsub, Wt_sub (SELLA_NO_MAT where absent);
+// ints[8] = r, r_sub, rows of Wt, rows of Wt_sub, B_stale, Bsub_stale, steps since the last diagonalisation, first_diag;
+// mu / mu_sub: at least `rows` entries each (may be NULL when the search has no Hessian / no view); *lam0.
+extern "C" int sella_search_release_hessian(sella_search* S, sella_mat* mats, long* ints, double* mu, double* mu_sub,
+                                            double* lam0) {
+    if (!S || !mats || !ints || !lam0) return SELLA_E_INVALID;
+    mats[0] = S->B; mats[1] = S->Wt; mats[2] = S->Bsub; mats[3] = S->Wt_sub;
+    ints[0] = S->H_none ? -1 : S->r;
+    ints[1] = S->have_view ? S->r_sub : -1;
+    ints[2] = S->H_none ? 0 : S->cap;
+    ints[3] = S->have_view ? S->cap_sub : 0;
+    ints[4] = S->B_stale;
+    ints[5] = S->Bsub_stale;
+    ints[6] = S->nsteps_since_diag;
+    ints[7] = S->first_diag ? 1 : 0;
+    *lam0 = S->lam0;
+    if (!S->H_none && mu) std::copy(S->mu.begin(), S->mu.begin() + std::min((size_t)S->cap, S->mu.size()), mu);
+    if (S->have_view && mu_sub) std::copy(S->mu_sub.begin(), S->mu_sub.begin() + std::min((size_t)S->cap_sub, S->mu_sub.size()), mu_sub);
+    S->B = S->Wt = S->Bsub = S->Wt_sub = SELLA_NO_MAT;
+    S->H_none = true;
+    S->have_view = false;
+    S->released = true;
     return SELLA_OK;
 }
 

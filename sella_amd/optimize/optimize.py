@@ -48,6 +48,15 @@ class Sella(Optimizer):
         self.optimize_cell = False
         self.user_internal, self.peskwargs = internal, dict(kwargs)
         self._user_constraints = constraints
+        # what `LibrarySearch` would be built from (`run` hands the whole search to the library when it is covered)
+        self._lib, self._lib_authoritative = None, False
+        self._lib_kw = None
+        if (not internal and restart is None and v0 is None and hessian_function is None and trajectory is None
+                and logfile is None and master is None and not (set(kwargs) - {'proj_trans', 'proj_rot'})):
+            self._lib_kw = dict(order=order, eta=eta, gamma=gamma, delta0=delta0, sigma_inc=sigma_inc, sigma_dec=sigma_dec,
+                                rho_inc=rho_inc, rho_dec=rho_dec, rs=rs, method=method, eig=eig, threepoint=threepoint,
+                                nsteps_per_diag=nsteps_per_diag, diag_every_n=diag_every_n, constraints=constraints,
+                                proj_trans=kwargs.get('proj_trans'), proj_rot=kwargs.get('proj_rot'))
         own_traj = isinstance(trajectory, str)
         if own_traj:                                                              # :144-150
             from ..peswrapper import open_trajectory
@@ -86,6 +95,90 @@ class Sella(Optimizer):
         self.initialized = False
         self.fmax = None
         self._last_converged = None
+
+    # ---- the whole search inside the library (sella_amd/search.py) -----------------------------------------------
+    # `run()` on a fresh optimizer whose configuration the library loop covers (Cartesian PES, pinned coordinates at
+    # most, a calculator that lives in the library, no log / trajectory / observers) hands the search to
+    # `sella_search_run`: no interpreter between the force calls.  The library then holds the truth — geometry, trust
+    # radius, approximate Hessian — until somebody looks: the first access to `self.pes` (so `step()`, `irun()`,
+    # `converged()`, `log()`, `save_state()` too) brings it back (`_adopt`), approximate Hessian with its structured
+    # eigendecomposition and the view of the pinned coordinates included, and the general driver continues from there.
+    use_library_loop = True
+
+    @property
+    def pes(self):
+        if self.__dict__.get('_lib_authoritative'):
+            self._adopt()
+        return self._pes
+
+    @pes.setter
+    def pes(self, value):
+        self._pes = value
+
+    def _library_run_applies(self):
+        if not self.use_library_loop or self._lib_kw is None or self.observers or self.logfile is not None:
+            return False
+        if self._lib is not None:
+            return True
+        pes = self._pes
+        if self.initialized or self.nsteps != 0 or type(pes) is not PES or pes.traj is not None or not pes.H._is_none:
+            return False
+        from ..search import LibrarySearch
+        try:
+            return LibrarySearch.applies(self.atoms, **self._lib_kw)
+        except Exception:                                        # noqa: BLE001 — anything odd: the general driver
+            return False
+
+    def run(self, fmax=0.05, steps=100000000):
+        if self._library_run_applies():
+            from ..search import LibrarySearch, SearchLeftLibrary
+            if self._lib is None:
+                self._lib = LibrarySearch(self.atoms, **self._lib_kw)
+            ls = self._lib
+            self.fmax = fmax
+            self.max_steps = self.nsteps + steps
+            before = (ls.nsteps, ls.one_call_steps)
+            try:
+                conv = ls.run(fmax, steps)
+                left = False
+            except SearchLeftLibrary:
+                conv, left = False, True
+            taken = ls.nsteps - before[0]
+            self.nsteps += taken
+            self.fused_steps += ls.one_call_steps - before[1]
+            self.delta, self.rho = ls.delta, ls.rho
+            self._lib_authoritative = True
+            if not left:
+                return conv
+            steps -= taken                                       # the rest with the general driver, from where it stands
+        return Optimizer.run(self, fmax=fmax, steps=steps)
+
+    def _adopt(self):
+        """Bring the state of the library search back into this object's PES and drop the library search."""
+        from ..linalg import ApproximateHessian
+        ls, self._lib, self._lib_authoritative = self._lib, None, False
+        pes = self._pes
+        st = ls.release_hessian()
+        pes.neval = ls.neval
+        pes.curr.update(x=pes.get_x(), state_hash=pes._state_hash(), f=ls.energy, g=ls.gradient.copy())
+        pes._update_basis()
+        pes.last = dict(pes.curr)
+        pes.first_diag = st['first_diag']
+        self.initialized = ls.initialized
+        self.nsteps_since_diag = st['nsteps_since_diag']
+        Hd = st['hessian']
+        if Hd is not None:
+            H = pes.H
+            H.set_B(Hd['B'])
+            H._lr = dict(Wt=Hd['Wt'], r=Hd['r'], mu=Hd['mu'], lam0=Hd['lam0'])
+            H._B_stale = Hd['stale']
+            v = Hd['view']
+            if v is not None:
+                sub = ApproximateHessian(len(v['idx']), 0, v['B'], H.update_method, H.symm)
+                sub._lr = dict(Wt=v['Wt'], r=v['r'], mu=v['mu'], lam0=Hd['lam0'])
+                sub._B_stale = v['stale']
+                H._view = (np.ascontiguousarray(v['idx'], dtype=np.int32), pes.get_Ufree(), sub, H.version)
+        ls.close()
 
     def initialize_pes(self, atoms, trajectory=None, order=1, eta=1e-4, constraints=None, v0=None,
                        internal=False, hessian_function=None, **kwargs):

@@ -16,7 +16,7 @@ of last-bit differences (tests/test_library_search.py).  If a search leaves the 
 explicit rank passes 0.4 n) `run` raises `SearchLeftLibrary`; the atoms then hold the last geometry reached.
 """
 import weakref
-from ctypes import byref, c_int, c_long, c_void_p
+from ctypes import byref, c_double, c_int, c_long, c_void_p
 
 import numpy as np
 
@@ -134,12 +134,13 @@ class LibrarySearch:
 
     def _sync(self):
         x, g = np.empty(self._n), np.empty(self._n)
-        sc, cn = np.zeros(5), (c_long * 5)()
+        sc, cn = np.zeros(5), (c_long * 6)()
         check(_lib.lib().sella_search_state(self._h, ptr(x), ptr(g), ptr(sc), cn))
         self.atoms.positions = x.reshape(-1, 3)
         self.gradient = g
         self.energy, self.fmax_now, self.delta, self.rho, self.lambda_min = (float(v) for v in sc)
-        self.nsteps, self.neval, self.one_call_steps, self.rank, self.rank_view = (int(v) for v in cn)
+        self.nsteps, self.neval, self.one_call_steps, self.rank, self.rank_view = (int(v) for v in cn[:5])
+        self.initialized = bool(cn[5])
 
     def run(self, fmax=0.05, steps=100000000):
         conv = c_int(0)
@@ -152,6 +153,31 @@ class LibrarySearch:
             raise
         self._sync()
         return bool(conv.value)
+
+    def release_hessian(self):
+        """Hand the approximate Hessian over (`sella_search_release_hessian`): -> dict(B, Wt, r, mu, lam0, stale, view=dict
+        or None, nsteps_since_diag, first_diag) with `DeviceMatrix` objects that now own the device memory, or None if
+        the search has no Hessian yet.  The search cannot be run afterwards."""
+        from .device import DeviceMatrix
+        n = self._n
+        m = n if self._free is None else len(self._free)
+        mats = (c_int * 4)()
+        ints = (c_long * 8)()
+        cap = max(8, min(n, max(max(1, int(0.4 * n)), 8) + 72))
+        cap_sub = max(8, min(m, max(max(1, int(0.4 * m)), 8) + 72))
+        mu, mu_sub = np.zeros(cap), np.zeros(cap_sub)
+        lam0 = c_double(0.0)
+        check(_lib.lib().sella_search_release_hessian(self._h, mats, ints, ptr(mu), ptr(mu_sub), byref(lam0)))
+        out = dict(nsteps_since_diag=int(ints[6]), first_diag=bool(ints[7]), hessian=None)
+        if ints[0] >= 0:
+            ctx = self._ctx
+            H = dict(B=DeviceMatrix(ctx, mats[0], (n, n)), Wt=DeviceMatrix(ctx, mats[1], (int(ints[2]), n)), r=int(ints[0]),
+                     mu=mu[:int(ints[2])].copy(), lam0=float(lam0.value), stale=bool(ints[4]), view=None)
+            if ints[1] >= 0:
+                H['view'] = dict(B=DeviceMatrix(ctx, mats[2], (m, m)), Wt=DeviceMatrix(ctx, mats[3], (int(ints[3]), m)),
+                                 r=int(ints[1]), mu=mu_sub[:int(ints[3])].copy(), stale=bool(ints[5]), idx=self._free)
+            out['hessian'] = H
+        return out
 
     def close(self):
         self._fin()

@@ -129,3 +129,57 @@ def test_run_one_takes_the_library_route(ctx, monkeypatch):
     np.testing.assert_allclose(p1, p2, atol=1e-8)
     np.testing.assert_allclose(s1, s2, atol=1e-7)
     assert s1[1] == 6 and s1[4] < 0
+
+
+@pytest.mark.parametrize('pinned', [False, pytest.param(True, marks=pytest.mark.emu_heavy)])
+def test_sella_run_hands_the_search_to_the_library_and_takes_it_back(ctx, pinned):
+    """`Sella(...).run()` on a covered configuration runs inside the library; the first look at `opt.pes` brings the
+    state back — geometry, energy, gradient, counters, approximate Hessian with its structured eigendecomposition (and
+    the view of the pinned coordinates) — and the general driver continues from there exactly like an optimizer that
+    never left it."""
+    from conftest_shim import emt_slab
+    from sella_amd import Sella
+    from sella_amd.internal import Constraints
+
+    def make(lib):
+        if pinned:
+            atoms, cons, _ = emt_slab((4, 4, 4))
+            opt = Sella(atoms, constraints=cons, logfile=None, nsteps_per_diag=2)
+        else:
+            atoms = _model(ctx)
+            opt = Sella(atoms, constraints=Constraints(atoms), logfile=None, rs='tr', **KW)
+        opt.use_library_loop = lib
+        return atoms, opt
+    a1, o1 = make(True)
+    a2, o2 = make(False)
+    assert o1.run(0.0, 4) is False and o1._lib is not None and o1._lib_authoritative
+    o1.run(0.0, 2)                                            # continues inside the library
+    assert o1._lib is not None and o1.nsteps == 6 and o1.fused_steps >= 5
+    o2.run(0.0, 6)
+    assert o2._lib is None
+    np.testing.assert_allclose(a1.positions, a2.positions, atol=1e-8)
+    pes = o1.pes                                              # <- the state comes back here
+    assert o1._lib is None and not o1._lib_authoritative
+    assert (o1.nsteps, pes.neval, o1.initialized) == (o2.nsteps, o2.pes.neval, True)
+    assert a1.calc.ncalls == a2.calc.ncalls
+    assert pes.get_f() == pytest.approx(o2.pes.get_f(), abs=1e-9)
+    np.testing.assert_allclose(pes.get_g(), o2.pes.get_g(), atol=1e-7)
+    assert pes.neval == o2.pes.neval                          # (looking did not cost a force call)
+    assert o1.delta == pytest.approx(o2.delta, rel=1e-8) and o1.nsteps_since_diag == o2.nsteps_since_diag
+    assert pes.H.device_eig_lr() is not None
+    np.testing.assert_allclose(pes.H.B, o2.pes.H.B, atol=1e-6 * max(1.0, np.abs(o2.pes.H.B).max()))
+    if pinned:
+        v1, v2 = pes.get_HL_projected(pes.get_Ufree()), o2.pes.get_HL_projected(o2.pes.get_Ufree())
+        assert v1 is not pes.H and v1.device_eig_lr() is not None
+        np.testing.assert_allclose(v1.B, v2.B, atol=1e-6 * max(1.0, np.abs(v2.B).max()))
+    for _ in range(3):                                        # both in the general driver now
+        o1.step()
+        o2.step()
+    np.testing.assert_allclose(a1.positions, a2.positions, atol=1e-7)
+    assert o1.pes.neval == o2.pes.neval
+    # a logging optimizer is never handed over
+    a3, o3 = make(True)
+    o3.logfile = open('/dev/null', 'w')
+    o3.run(0.0, 1)
+    assert o3._lib is None
+    o3.logfile.close()

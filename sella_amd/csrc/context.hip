@@ -411,6 +411,9 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
         c->opt.panel_rows = value;
     } else if (!strcmp(key, "eigh_wy_mfma")) {
         c->opt.eigh_wy_mfma = value ? 1 : 0;
+    } else if (!strcmp(key, "eigh_symv_min")) {
+        if (value < 0) { set_error("eigh_symv_min must be >= 0"); return SELLA_E_INVALID; }
+        c->opt.eigh_symv_min = value;
     } else if (!strcmp(key, "eigh_nb")) {
         if (value < 1 || value > 64) { set_error("eigh_nb must be in [1, 64]"); return SELLA_E_INVALID; }
         c->opt.eigh_nb = value;

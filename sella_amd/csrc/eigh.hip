@@ -284,6 +284,148 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
     }
 }
 
+// ---- symmetric-aware trailing matvec (large trailing blocks: the stage is bandwidth bound there) ----------------
+// A22 u' from the UPPER triangle only: every stored entry A[r][c], c >= r, serves row r (a dot along the row) and —
+// transposed — row c.  The matrix is cut into tiles of SYMV_TR rows x SYMV_TC columns on a grid that is fixed in
+// ABSOLUTE coordinates (a workgroup keeps its tile, and its XCD, from one column of the factorisation to the next);
+// tiles below the diagonal or above the trailing block leave at once.  A workgroup writes, for its tile (I, J),
+//     Prow[J][r] = sum_{c in tile, c >= r} A[r][c] u'[c]          Pcol[I][c] = sum_{r in tile, r < c} A[r][c] u'[r]
+// and `trd_symv_finish_kernel` adds them up in a fixed order — deterministic, unlike atomics — and does what the
+// epilogue of trd_gemv_kernel does (reflector scalars, v, A22 v, the v . A22 v partials, the panel dots).
+// Bytes per column: 4 m^2 instead of 8 m^2, plus 16 m (m / SYMV_TR + m / SYMV_TC) for the partial sums.
+constexpr int SYMV_TR = 64, SYMV_TC = 256;
+
+struct TrdSymvArgs {
+    const double* A; int ld, n, o;
+    const double* ubuf;
+    double* Prow; double* Pcol; int ldp;
+};
+
+__global__ __launch_bounds__(256) void trd_symv_kernel(TrdSymvArgs a) {
+    __shared__ double colred[4][SYMV_TC];
+    __shared__ double rowres[SYMV_TR];
+    const int J = blockIdx.x, I = blockIdx.y;
+    const int r0 = I * SYMV_TR, c0 = J * SYMV_TC;
+    if (r0 + SYMV_TR - 1 < a.o || c0 + SYMV_TC - 1 < r0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool crossing = c0 < r0 + SYMV_TR;                 // the diagonal runs through this tile
+    // the four columns of this lane: c0 + 2 lane (+1), c0 + 128 + 2 lane (+1); loads are clamped into the row
+    const int ca = c0 + 2 * lane, cb = ca + 128;
+    const int lim = a.ld - 2;
+    const int cal = ca <= lim ? ca : lim, cbl = cb <= lim ? cb : lim;
+    auto uval = [&](int cabs) -> double { return (cabs > a.o && cabs < a.n) ? a.ubuf[cabs < a.n ? cabs : a.n - 1] : 0.0; };
+    const double x0 = uval(ca), x1 = uval(ca + 1), x2 = uval(cb), x3 = uval(cb + 1);
+    double col[4] = {0.0, 0.0, 0.0, 0.0};
+    const int rw = r0 + 16 * wave;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        double2 va[8], vb[8];
+        double xr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = rw + 8 * half + k;
+            const int rl = r < a.n ? r : a.n - 1;
+            const double* row = a.A + (size_t)rl * a.ld;
+            va[k] = *reinterpret_cast<const double2*>(row + cal);
+            vb[k] = *reinterpret_cast<const double2*>(row + cbl);
+            xr[k] = uval(r);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = rw + 8 * half + k;
+            double e0 = va[k].x, e1 = va[k].y, e2 = vb[k].x, e3 = vb[k].y;
+            if (crossing) {                                   // entries left of the diagonal belong to other tiles
+                if (ca < r) e0 = 0.0;
+                if (ca + 1 < r) e1 = 0.0;
+                if (cb < r) e2 = 0.0;
+                if (cb + 1 < r) e3 = 0.0;
+            }
+            double dot = e0 * x0 + e1 * x1 + e2 * x2 + e3 * x3;
+            if (crossing) {                                   // the diagonal entry itself counts once (in the row dot)
+                if (ca == r) e0 = 0.0;
+                if (ca + 1 == r) e1 = 0.0;
+                if (cb == r) e2 = 0.0;
+                if (cb + 1 == r) e3 = 0.0;
+            }
+            col[0] += e0 * xr[k]; col[1] += e1 * xr[k]; col[2] += e2 * xr[k]; col[3] += e3 * xr[k];
+            dot = wave_sum64(dot);
+            if (lane == 0) rowres[16 * wave + 8 * half + k] = dot;
+        }
+    }
+    colred[wave][2 * lane] = col[0];
+    colred[wave][2 * lane + 1] = col[1];
+    colred[wave][128 + 2 * lane] = col[2];
+    colred[wave][128 + 2 * lane + 1] = col[3];
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (c0 + t < a.n) a.Pcol[(size_t)I * a.ldp + c0 + t] = (colred[0][t] + colred[1][t]) + (colred[2][t] + colred[3][t]);
+    if (t < SYMV_TR && r0 + t < a.n && r0 + t >= a.o) a.Prow[(size_t)J * a.ldp + r0 + t] = rowres[t];
+}
+
+struct TrdSymvFinishArgs {
+    const double* A; int ld, n, o, j;
+    const double* ubuf;
+    const double* partA; int nblkA;
+    const double* Prow; const double* Pcol; int ldp;
+    double* wraw; double* partB;
+    double* Vrow; double* Arow;
+    double* taus; double* evec; double* colscal;
+    const double* Wp; const double* Vp; int ldpan, i;
+    double* cdots;
+    int nelem;                  // workgroups that own 256 entries of the result; the 2 i behind them one panel row each
+};
+
+__global__ __launch_bounds__(256) void trd_symv_finish_kernel(TrdSymvFinishArgs a) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    double ssl = 0.0;
+    for (int b = lane; b < a.nblkA; b += 64) ssl += a.partA[(size_t)b * TRD_PA];
+    const double ss = wave_sum_e(ssl);
+    const double alpha = a.ubuf[a.o];
+    double beta, tau, scale;
+    if (ss == 0.0) { beta = alpha; tau = 0.0; scale = 0.0; }
+    else {
+        const double nrm = sqrt(alpha * alpha + ss);
+        beta = (alpha >= 0.0) ? -nrm : nrm;
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+    }
+    if ((int)blockIdx.x >= a.nelem) {
+        // panel row q against v = e_o + scale u'
+        const int q = blockIdx.x - a.nelem;
+        const double* row = (q < a.i) ? a.Wp + (size_t)q * a.ldpan : a.Vp + (size_t)(q - a.i) * a.ldpan;
+        double acc = 0.0;
+        for (int k = a.o + tid; k < a.n; k += 256) acc += row[k] * ((k == a.o) ? 1.0 : scale * a.ubuf[k]);
+        acc = block_sum_256(acc, red);
+        if (tid == 0) a.cdots[(q < a.i) ? q : TRD_NBMAX + q - a.i] = acc;
+        return;
+    }
+    const int k = a.o + blockIdx.x * 256 + tid;
+    double p = 0.0;
+    if (k < a.n) {
+        double s0 = 0.0, s1 = 0.0;
+        const int NJ = (a.n + SYMV_TC - 1) / SYMV_TC;
+        for (int J = k / SYMV_TC; J < NJ; ++J) s0 += a.Prow[(size_t)J * a.ldp + k];
+        for (int I = a.o / SYMV_TR; I <= k / SYMV_TR; ++I) s1 += a.Pcol[(size_t)I * a.ldp + k];
+        const double res = scale * (s0 + s1) + a.A[(size_t)a.o * a.ld + k];
+        const double vk = (k == a.o) ? 1.0 : scale * a.ubuf[k];
+        a.wraw[k] = res;
+        a.Vrow[k] = vk;
+        if (k > a.o) a.Arow[k] = vk;
+        p = vk * res;
+    }
+    p = block_sum_256(p, red);
+    if (tid == 0) {
+        a.partB[blockIdx.x] = p;
+        if (blockIdx.x == 0) {
+            a.taus[a.j] = tau;
+            a.evec[a.j] = beta;
+            a.colscal[0] = tau;
+            a.colscal[1] = scale;
+        }
+    }
+}
+
 __global__ void tridiag_tail_kernel(const double* __restrict__ A, int ld, int n, double* dvec,
                                     double* evec, double* taus) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1405,6 +1547,15 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     double* colscal = W.vec + (size_t)V_COL * ld;
     double* cdots = partB + maxblkB + 8;               // 2 * TRD_NBMAX doubles
     int cur = 0, nblkA_prev = 0, nblkB_prev = 0;
+    // symmetric-aware matvec for trailing blocks of at least `eigh_symv_min` rows (0: never)
+    const int symv_min = (int)c->opt.eigh_symv_min;
+    const int symNJ = (n + SYMV_TC - 1) / SYMV_TC, symNI = (n + SYMV_TR - 1) / SYMV_TR;
+    const int ldP = (n + 255) / 256 * 256;
+    double *Prow = nullptr, *Pcol = nullptr;
+    if (symv_min > 0 && n - 1 >= symv_min) {
+        SCHK(scratch_get(c, SCR_SYMV, (size_t)(symNJ + symNI) * ldP * sizeof(double), &Prow));
+        Pcol = Prow + (size_t)symNJ * ldP;
+    }
     for (int j0 = 0; j0 < nrefl; j0 += nb) {
         const int kb = std::min(nb, nrefl - j0);
         for (int i = 0; i <= kb; ++i) {
@@ -1463,10 +1614,32 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
             // from that XCD's L2 once the trailing block fits (m <~ 1800); the <= 15 rows between 2 P0 and o
             // are dummies.
             ga.pad = o - (o / 16) * 16;
-            const int nblkB = (ga.pad + m + 2 * i + 1) / 2;
-            prof_begin(c, PROF_TRD_GEMV, 8.0 * m * (double)m, 2.0 * m * (double)m);
-            SELLA_LAUNCH(c, trd_gemv_kernel, dim3(nblkB), dim3(256), 0, ga);
-            prof_end(c);
+            int nblkB = (ga.pad + m + 2 * i + 1) / 2;
+            if (symv_min > 0 && m >= symv_min) {
+                // large trailing block: upper triangle only, partial sums added up by a second (small) kernel
+                TrdSymvArgs sa;
+                sa.A = W.A; sa.ld = ld; sa.n = n; sa.o = o; sa.ubuf = ub[cur];
+                sa.Prow = Prow; sa.Pcol = Pcol; sa.ldp = ldP;
+                prof_begin(c, PROF_TRD_GEMV, 4.0 * m * (double)m, 2.0 * m * (double)m);
+                SELLA_LAUNCH(c, trd_symv_kernel, dim3(symNJ, symNI), dim3(256), 0, sa);
+                prof_end(c);
+                TrdSymvFinishArgs fa;
+                fa.A = W.A; fa.ld = ld; fa.n = n; fa.o = o; fa.j = j; fa.ubuf = ub[cur];
+                fa.partA = partA[cur]; fa.nblkA = nblkA;
+                fa.Prow = Prow; fa.Pcol = Pcol; fa.ldp = ldP;
+                fa.wraw = wraw; fa.partB = partB; fa.Vrow = ga.Vrow; fa.Arow = ga.Arow;
+                fa.taus = taus; fa.evec = evec; fa.colscal = colscal;
+                fa.Wp = Wp; fa.Vp = Vp; fa.ldpan = ld; fa.i = i; fa.cdots = cdots;
+                fa.nelem = (m + 255) / 256;
+                nblkB = fa.nelem;
+                prof_begin(c, PROF_OTHER, 16.0 * m * (double)(m / SYMV_TR + m / SYMV_TC), 0.0);
+                SELLA_LAUNCH(c, trd_symv_finish_kernel, dim3(fa.nelem + 2 * i), dim3(256), 0, fa);
+                prof_end(c);
+            } else {
+                prof_begin(c, PROF_TRD_GEMV, 8.0 * m * (double)m, 2.0 * m * (double)m);
+                SELLA_LAUNCH(c, trd_gemv_kernel, dim3(nblkB), dim3(256), 0, ga);
+                prof_end(c);
+            }
             c->prof = prof_all;
             nblkA_prev = nblkA;
             nblkB_prev = nblkB;

@@ -90,6 +90,8 @@ struct Options {
     long host_scalars = 0;   // 1: host-consumed scalars are written straight into pinned host memory (measured: no gain)
     long gemm_tile128 = 1;   // 1: 128x128 double-buffered tiles for large NN/TN products
     long eigh_leaf = 32;     // leaf size of the divide-and-conquer tree
+    long eigh_symv_min = 4096;   // trailing blocks of at least this many rows use the symmetric-aware matvec of the
+                                 // tridiagonalisation (upper triangle only, eigh.hip); 0: never
     long eigh_nb = 16;       // panel width of the blocked tridiagonalisation (tools/eigh_tune.py)
     long panel_mfma = 1;     // 1: products with more than 8 right-hand sides stream the matrix once (MFMA panel kernel)
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
@@ -200,7 +202,7 @@ int prof_flush(sella_ctx* c);
 enum ScratchSlot {
     SCR_X = 0, SCR_Y, SCR_PART, SCR_V, SCR_AV, SCR_V2, SCR_AV2, SCR_R, SCR_T, SCR_W, SCR_C,
     SCR_EIG0, SCR_EIG1, SCR_EIG2, SCR_EIG3, SCR_EIG4, SCR_EIG5, SCR_EIG6, SCR_UPD0, SCR_UPD1, SCR_UPD2,
-    SCR_UPD3, SCR_UPD4, SCR_QR0, SCR_QR1, SCR_STEP0, SCR_STEP1, SCR_STEP2, SCR_MISC0, SCR_MISC1, SCR_PSMALL, SCR_NSLOTS
+    SCR_UPD3, SCR_UPD4, SCR_QR0, SCR_QR1, SCR_STEP0, SCR_STEP1, SCR_STEP2, SCR_MISC0, SCR_MISC1, SCR_PSMALL, SCR_SYMV, SCR_NSLOTS
 };
 
 // ---- kernel launchers (kernels.hip) -------------------------------------------------------

@@ -76,6 +76,41 @@ def test_panel_widths_and_variants(ctx):
         ctx.set_option('eigh_wy_waves', 4)
 
 
+def test_symmetric_aware_trailing_matvec(ctx):
+    """Trailing blocks above `eigh_symv_min` rows read the upper triangle only (tiles of 64 x 256 on an absolute grid,
+    partial sums added in a fixed order): same tridiagonal matrix up to rounding, whatever the threshold, for sizes
+    that put the diagonal, the trailing origin and the matrix edge at every position inside a tile."""
+    rng = np.random.RandomState(11)
+    try:
+        sizes = ((70, (1,)), (257, (1, 100)), (330, (1, 200)), (515, (1,)), (1100, (1, 600)))
+        if ctx.backend == 'emu':
+            sizes = ((70, (1,)), (258, (1,)))                             # the emulator runs fibre by fibre
+        for n, thresholds in sizes:
+            A = rng.normal(size=(n, n))
+            A = A + A.T
+            if ctx.backend == 'emu' and n > 100:
+                ctx.set_option('eigh_symv_min', 1)
+                check(ctx, A)                                             # against LAPACK only
+                continue
+            ctx.set_option('eigh_symv_min', 0)
+            ref = check(ctx, A)
+            for thr in thresholds:
+                ctx.set_option('eigh_symv_min', thr)
+                w = check(ctx, A)
+                np.testing.assert_allclose(w, ref, atol=1e-12 * np.abs(ref).max())
+                w2 = check(ctx, A)
+                np.testing.assert_array_equal(w, w2)                      # fixed summation order: run-to-run identical
+        for nb in ((24,) if ctx.backend == 'emu' else (4, 24)):
+            ctx.set_option('eigh_nb', nb)
+            ctx.set_option('eigh_symv_min', 1)
+            n = 100 if ctx.backend == 'emu' else 200
+            A = rng.normal(size=(n, n))
+            check(ctx, A + A.T)
+    finally:
+        ctx.set_option('eigh_symv_min', 4096)
+        ctx.set_option('eigh_nb', 16)
+
+
 def test_spectra(ctx):
     rng = np.random.RandomState(1)
     n = 72 if ctx.backend == 'emu' else 700

@@ -389,6 +389,7 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     } else if (!strcmp(key, "gemm_mfma")) c->opt.gemm_mfma = value ? 1 : 0;
     else if (!strcmp(key, "rank2k_stream")) c->opt.rank2k_stream = value ? 1 : 0;
     else if (!strcmp(key, "eigh_wy_rows")) c->opt.eigh_wy_rows = value;
+    else if (!strcmp(key, "eigh_wy_nb64_min")) c->opt.eigh_wy_nb64_min = value;
     else if (!strcmp(key, "eigh_wy_waves")) c->opt.eigh_wy_waves = value;
     else if (!strcmp(key, "lr_cholqr")) c->opt.lr_cholqr = value ? 1 : 0;
     else if (!strcmp(key, "rank2k_fixed")) c->opt.rank2k_fixed = value ? 1 : 0;
@@ -411,6 +412,11 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
         c->opt.panel_rows = value;
     } else if (!strcmp(key, "eigh_wy_mfma")) {
         c->opt.eigh_wy_mfma = value ? 1 : 0;
+    } else if (!strcmp(key, "eigh_symv_tri")) {
+        c->opt.eigh_symv_tri = value ? 1 : 0;
+    } else if (!strcmp(key, "eigh_symv_tr")) {
+        if (value != 64 && value != 128) { set_error("eigh_symv_tr must be 64 or 128"); return SELLA_E_INVALID; }
+        c->opt.eigh_symv_tr = value;
     } else if (!strcmp(key, "eigh_symv_min")) {
         if (value < 0) { set_error("eigh_symv_min must be >= 0"); return SELLA_E_INVALID; }
         c->opt.eigh_symv_min = value;

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
 // and `trd_symv_finish_kernel` adds them up in a fixed order — deterministic, unlike atomics — and does what the
 // epilogue of trd_gemv_kernel does (reflector scalars, v, A22 v, the v . A22 v partials, the panel dots).
 // Bytes per column: 4 m^2 instead of 8 m^2, plus 16 m (m / SYMV_TR + m / SYMV_TC) for the partial sums.
-constexpr int SYMV_TR = 64, SYMV_TC = 256;
+constexpr int SYMV_TC = 256;            // tile columns; tile rows (64 or 128) are a launch parameter: option eigh_symv_tr
 
 struct TrdSymvArgs {
     const double* A; int ld, n, o;
@@ -301,6 +301,7 @@ struct TrdSymvArgs {
     double* Prow; double* Pcol; int ldp;
 };
 
+template <int SYMV_TR>
 __global__ __launch_bounds__(256) void trd_symv_kernel(TrdSymvArgs a) {
     __shared__ double colred[4][SYMV_TC];
     __shared__ double rowres[SYMV_TR];
@@ -316,9 +317,10 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(TrdSymvArgs a) {
     auto uval = [&](int cabs) -> double { return (cabs > a.o && cabs < a.n) ? a.ubuf[cabs < a.n ? cabs : a.n - 1] : 0.0; };
     const double x0 = uval(ca), x1 = uval(ca + 1), x2 = uval(cb), x3 = uval(cb + 1);
     double col[4] = {0.0, 0.0, 0.0, 0.0};
-    const int rw = r0 + 16 * wave;
+    constexpr int RPW = SYMV_TR / 4;                         // rows per wavefront, eight at a time
+    const int rw = r0 + RPW * wave;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < RPW / 8; ++half) {
         double2 va[8], vb[8];
         double xr[8];
 #pragma unroll
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(TrdSymvArgs a) {
             }
             col[0] += e0 * xr[k]; col[1] += e1 * xr[k]; col[2] += e2 * xr[k]; col[3] += e3 * xr[k];
             dot = wave_sum64(dot);
-            if (lane == 0) rowres[16 * wave + 8 * half + k] = dot;
+            if (lane == 0) rowres[RPW * wave + 8 * half + k] = dot;
         }
     }
     colred[wave][2 * lane] = col[0];
@@ -358,8 +360,18 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(TrdSymvArgs a) {
     colred[wave][128 + 2 * lane + 1] = col[3];
     __syncthreads();
     const int t = threadIdx.x;
-    if (c0 + t < a.n) a.Pcol[(size_t)I * a.ldp + c0 + t] = (colred[0][t] + colred[1][t]) + (colred[2][t] + colred[3][t]);
-    if (t < SYMV_TR && r0 + t < a.n && r0 + t >= a.o) a.Prow[(size_t)J * a.ldp + r0 + t] = rowres[t];
+    // partial sums are stored by blocks of 64 entries, all partial rows of a block next to each other: the finish kernel
+    // streams one contiguous region per block (rows of a plain [tile][entry] array are n * 8 bytes apart — one DRAM page
+    // and, for n a multiple of a large power of two, one channel each; measured 0.85 TB/s)
+    const int NI = gridDim.y, NJ = gridDim.x;
+    if (c0 + t < a.n) {
+        const int cabs = c0 + t;
+        a.Pcol[((size_t)(cabs >> 6) * NI + I) * 64 + (cabs & 63)] = (colred[0][t] + colred[1][t]) + (colred[2][t] + colred[3][t]);
+    }
+    if (t < SYMV_TR && r0 + t < a.n && r0 + t >= a.o) {
+        const int rabs = r0 + t;
+        a.Prow[((size_t)(rabs >> 6) * NJ + J) * 64 + (rabs & 63)] = rowres[t];
+    }
 }
 
 struct TrdSymvFinishArgs {
@@ -372,7 +384,8 @@ struct TrdSymvFinishArgs {
     double* taus; double* evec; double* colscal;
     const double* Wp; const double* Vp; int ldpan, i;
     double* cdots;
-    int nelem;                  // workgroups that own 256 entries of the result; the 2 i behind them one panel row each
+    int tr;                     // rows per tile of the matvec that wrote the partial sums
+    int nelem;                  // workgroups that own 64 entries of the result; the 2 i behind them one panel row each
 };
 
 __global__ __launch_bounds__(256) void trd_symv_finish_kernel(TrdSymvFinishArgs a) {
@@ -394,20 +407,62 @@ __global__ __launch_bounds__(256) void trd_symv_finish_kernel(TrdSymvFinishArgs 
         // panel row q against v = e_o + scale u'
         const int q = blockIdx.x - a.nelem;
         const double* row = (q < a.i) ? a.Wp + (size_t)q * a.ldpan : a.Vp + (size_t)(q - a.i) * a.ldpan;
+        // one workgroup streams a whole row (the dots come out exact, as in trd_gemv_kernel): sixteen entries per thread
+        // in flight at a time — a plain loop waits for every load in turn (24 us at m = 12000)
         double acc = 0.0;
-        for (int k = a.o + tid; k < a.n; k += 256) acc += row[k] * ((k == a.o) ? 1.0 : scale * a.ubuf[k]);
+        for (int k0 = a.o + tid; k0 < a.n; k0 += 256 * 16) {
+            double rv[16], uv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + 256 * u;
+                const int kc = k < a.n ? k : a.n - 1;
+                rv[u] = row[kc];
+                uv[u] = a.ubuf[kc];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + 256 * u;
+                if (k < a.n) acc += rv[u] * ((k == a.o) ? 1.0 : scale * uv[u]);
+            }
+        }
         acc = block_sum_256(acc, red);
         if (tid == 0) a.cdots[(q < a.i) ? q : TRD_NBMAX + q - a.i] = acc;
         return;
     }
-    const int k = a.o + blockIdx.x * 256 + tid;
+    // 64 entries per workgroup; wavefront w adds every fourth partial row (row- and column-side lists taken as one),
+    // sixteen loads in flight at a time; the four sums meet in LDS in a fixed order
+    __shared__ double quarter[4][64];
+    const int wave = tid >> 6;
+    // blocks of 64 entries at absolute multiples of 64: a wavefront's entries share their tiles, so the loop bounds and the
+    // row pointers below are uniform
+    const int k = (a.o & ~63) + blockIdx.x * 64 + lane;
+    const int kl = k < a.n ? k : a.n - 1;
+    const int NJ = (a.n + SYMV_TC - 1) / SYMV_TC;
+    // every entry of this workgroup needs row-side tiles J >= kmax / TC ... hence per-entry bounds below
+    const int kb0 = (a.o & ~63) + blockIdx.x * 64;          // < n: first entry of the block (64 | tile sizes)
+    const int J0 = kb0 / SYMV_TC, nrow = NJ - J0;
+    const int I0 = a.o / a.tr, ncol = kb0 / a.tr - I0 + 1;
+    const int NI = (a.n + a.tr - 1) / a.tr, eb = kb0 >> 6;
+    double acc = 0.0;
+    for (int q0 = wave; q0 < nrow + ncol; q0 += 64) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int q = q0 + 4 * u;
+            const int qq = q < nrow + ncol ? q : nrow + ncol - 1;
+            const double* src = (qq < nrow) ? a.Prow + ((size_t)eb * NJ + J0 + qq) * 64
+                                            : a.Pcol + ((size_t)eb * NI + I0 + qq - nrow) * 64;
+            v[u] = src[lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += (q0 + 4 * u < nrow + ncol) ? v[u] : 0.0;
+    }
+    quarter[wave][lane] = acc;
+    __syncthreads();
     double p = 0.0;
-    if (k < a.n) {
-        double s0 = 0.0, s1 = 0.0;
-        const int NJ = (a.n + SYMV_TC - 1) / SYMV_TC;
-        for (int J = k / SYMV_TC; J < NJ; ++J) s0 += a.Prow[(size_t)J * a.ldp + k];
-        for (int I = a.o / SYMV_TR; I <= k / SYMV_TR; ++I) s1 += a.Pcol[(size_t)I * a.ldp + k];
-        const double res = scale * (s0 + s1) + a.A[(size_t)a.o * a.ld + k];
+    if (wave == 0 && k < a.n && k >= a.o) {
+        const double sum = (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]);
+        const double res = scale * sum + a.A[(size_t)a.o * a.ld + k];
         const double vk = (k == a.o) ? 1.0 : scale * a.ubuf[k];
         a.wraw[k] = res;
         a.Vrow[k] = vk;
@@ -1032,6 +1087,205 @@ __global__ __launch_bounds__(64 * NW) void wy_apply_mfma_kernel(double* __restri
     }
 }
 
+// ---- 64 reflectors per compact-WY block ---------------------------------------------------------------------------------
+// Every block of the sweep above is one pass over the workgroup's rows of X (read twice, written once).  For n beyond a
+// few thousand those rows no longer stay in L2 between blocks (16 x 12288 doubles = 1.5 MB per workgroup, 768 workgroups)
+// and the sweep is bound by that traffic: n / 32 passes over X.  Twice the reflectors per block = half the passes; the
+// reflector stream and the MFMA work are unchanged.
+constexpr int WY_NB2 = 64;
+
+__global__ __launch_bounds__(256) void wy_gram64_kernel(const double* __restrict__ A, int ld, int n, int nrefl,
+                                                        const double* __restrict__ taus, double* __restrict__ G) {
+    __shared__ double Ys[WY_NB2][65];
+    const int b = blockIdx.x, j0 = b * WY_NB2;
+    const int kb = (nrefl - j0 < WY_NB2) ? (nrefl - j0) : WY_NB2;
+    const int p = threadIdx.x >> 2, q0 = (threadIdx.x & 3) * 16;
+    double acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0;
+    for (int ct = j0 + 1; ct < n; ct += 64) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < WY_NB2 * 64; e += 256) {
+            const int r = e >> 6, cc = e & 63;
+            Ys[r][cc] = (r < kb && ct + cc < n) ? yval(A, ld, taus, j0 + r, ct + cc) : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int cc = 0; cc < 64; ++cc) {
+            const double yp = Ys[p][cc];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] += yp * Ys[q0 + k][cc];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) G[((size_t)b * WY_NB2 + p) * WY_NB2 + q0 + k] = acc[k];
+}
+
+// C_b = T_b^T for a 64-block, in place (see wy_tinv_kernel).  One LDS array serves both triangular matrices: T^-1 (from
+// the Gram matrix) in the upper triangle with its diagonal, the transpose of T — which is the output — growing in the
+// strictly lower one, its diagonal beside it.
+__global__ __launch_bounds__(64) void wy_tinv64_kernel(double* __restrict__ G, int nrefl, const double* __restrict__ taus) {
+    __shared__ double S[WY_NB2][WY_NB2 + 1];
+    __shared__ double dg[WY_NB2];
+    const int b = blockIdx.x, j0 = b * WY_NB2;
+    const int kb = (nrefl - j0 < WY_NB2) ? (nrefl - j0) : WY_NB2;
+    double* Gb = G + (size_t)b * WY_NB2 * WY_NB2;
+    for (int e = threadIdx.x; e < WY_NB2 * WY_NB2; e += 64) {
+        const int i = e >> 6, k2 = e & 63;
+        double v = 0.0;
+        if (i < kb && k2 < kb) {
+            if (k2 > i) v = Gb[e];
+            else if (k2 == i) { const double t = taus[j0 + i]; v = (t != 0.0) ? 1.0 / t : 1.0; }
+        }
+        S[i][k2] = v;
+    }
+    dg[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int col = threadIdx.x;
+    if (col < kb) {
+        for (int i = col; i >= 0; --i) {                       // column `col` of T, bottom up; T[k2][col] lives at S[col][k2]
+            double s = (i == col) ? 1.0 : 0.0;
+            for (int k2 = i + 1; k2 <= col; ++k2) s -= S[i][k2] * ((k2 == col) ? dg[col] : S[col][k2]);
+            const double val = s / S[i][i];
+            if (i == col) dg[col] = val;
+            else S[col][i] = val;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < WY_NB2 * WY_NB2; e += 64) {
+        const int p = e >> 6, q = e & 63;                        // C[p][q] = T[q][p]
+        Gb[e] = (p < kb && q < kb) ? ((q < p) ? S[p][q] : (q == p ? dg[p] : 0.0)) : 0.0;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void wy_apply_mfma64_kernel(double* __restrict__ X, int ldx, int n,
+                                                              const double* __restrict__ Yf,
+                                                              const double* __restrict__ Call, int nblk) {
+    constexpr int MPC = (NW * 16 > WY_NB2 ? NW * 16 : WY_NB2) * 65;
+    __shared__ double MpC[MPC];                                  // phase-1 partials of the wavefronts, then C_b
+    __shared__ double Ms[16][65];
+    __shared__ double M2s[16][65];
+    double (*Mp)[16][65] = reinterpret_cast<double (*)[16][65]>(MpC);
+    double (*Cs)[65] = reinterpret_cast<double (*)[65]>(MpC);
+    constexpr int CR = WY_NB2 * WY_NB2 / (64 * NW);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int r0 = blockIdx.x * 16;
+    const int rowA = (r0 + li < n) ? r0 + li : n - 1;
+    int rowD[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rowD[r] = (r0 + lg + 4 * r < n) ? r0 + lg + 4 * r : n - 1;
+    const double4 zero4 = make_double4(0.0, 0.0, 0.0, 0.0);
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int j0 = b * WY_NB2;
+        const int cs = ((j0 + 1) >> 6) << 6;
+        const int cw = cs + 64 * ((wave - (cs >> 6)) & (NW - 1));
+        double creg[CR];                                         // C_b: in flight now, into LDS once the partials are consumed
+#pragma unroll
+        for (int u = 0; u < CR; ++u) creg[u] = Call[(size_t)b * WY_NB2 * WY_NB2 + tid + u * 64 * NW];
+        // ---- phase 1: M = X Y^T (16 x 64) ---------------------------------------------------------
+        wy_f64x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = wy_f64x4{0.0, 0.0, 0.0, 0.0};
+        const double* xrow = X + (size_t)rowA * ldx;
+        const double* yrow0 = Yf + (size_t)(j0 + li) * ldx;
+        for (int cc = cw; cc < ldx; cc += 64 * NW) {
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                const int col = cc + 16 * sg + 4 * lg;
+                const bool ok = col < ldx;
+                const int colc = ok ? col : 0;
+                double4 xa = *reinterpret_cast<const double4*>(xrow + colc);
+                double4 yv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) yv[q] = *reinterpret_cast<const double4*>(yrow0 + (size_t)(16 * q) * ldx + colc);
+                if (!ok) xa = zero4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.x, yv[q].x, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.y, yv[q].y, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.z, yv[q].z, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.w, yv[q].w, acc[q], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Mp[wave][lg + 4 * r][16 * q + li] = acc[q][r];
+        __syncthreads();
+        double sreg[4] = {0.0, 0.0, 0.0, 0.0};
+        if (tid < 256) {
+            const int row = tid >> 4, pc = tid & 15;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sreg[q] += Mp[wv][row][pc + 16 * q];
+        }
+        __syncthreads();                                          // the partials are consumed: their space takes C_b
+        if (tid < 256) {
+            const int row = tid >> 4, pc = tid & 15;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ms[row][pc + 16 * q] = sreg[q];
+        }
+#pragma unroll
+        for (int u = 0; u < CR; ++u) { const int e = tid + u * 64 * NW; Cs[e >> 6][e & 63] = creg[u]; }
+        __syncthreads();
+        // ---- phase 2: M2 = -M C -----------------------------------------------------------------------
+        if (tid < 256) {
+            const int row = tid >> 4, qc = tid & 15;
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+            for (int pp = 0; pp < WY_NB2; ++pp) {
+                const double m = Ms[row][pp];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s4[q] += m * Cs[pp][qc + 16 * q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) M2s[row][qc + 16 * q] = -s4[q];
+        }
+        __syncthreads();
+        // ---- phase 3: X += (-M2) Y, the 64 reflectors in two halves -----------------------------------
+        double m2a[16];
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt) m2a[kt] = M2s[li][4 * kt + lg];
+        const double* ybase = Yf + (size_t)(j0 + lg) * ldx;
+        for (int cc = cw; cc < ldx; cc += 64 * NW) {
+            const int col = cc + 4 * li;
+            const bool ok = col < ldx;
+            const int colc = ok ? col : 0;
+            double4 xv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xv[r] = *reinterpret_cast<const double4*>(X + (size_t)rowD[r] * ldx + colc);
+            wy_f64x4 d0, d1, d2, d3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { d0[r] = xv[r].x; d1[r] = xv[r].y; d2[r] = xv[r].z; d3[r] = xv[r].w; }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double4 yv[8];
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+                    yv[kt] = *reinterpret_cast<const double4*>(ybase + (size_t)(32 * h + 4 * kt) * ldx + colc);
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt) {
+                    d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(m2a[8 * h + kt], yv[kt].x, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(m2a[8 * h + kt], yv[kt].y, d1, 0, 0, 0);
+                    d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(m2a[8 * h + kt], yv[kt].z, d2, 0, 0, 0);
+                    d3 = __builtin_amdgcn_mfma_f64_16x16x4f64(m2a[8 * h + kt], yv[kt].w, d3, 0, 0, 0);
+                }
+            }
+            if (ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r0 + lg + 4 * r < n)
+                        *reinterpret_cast<double4*>(X + (size_t)rowD[r] * ldx + col) = make_double4(d0[r], d1[r], d2[r], d3[r]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // The same sweep with 32 rows of X per workgroup (two MFMA row tiles sharing every reflector fetch).  The kernel above
 // is bound by L2 bandwidth — 22.7 GB of requests in 3.16 ms at n = 3072, two thirds of them the reflector blocks Y_b, which
 // every workgroup streams in full twice per block (PMC pass in profiles/, 4 / 8 / 16 wavefronts per workgroup measured
@@ -1549,15 +1803,20 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     int cur = 0, nblkA_prev = 0, nblkB_prev = 0;
     // symmetric-aware matvec for trailing blocks of at least `eigh_symv_min` rows (0: never)
     const int symv_min = (int)c->opt.eigh_symv_min;
-    const int symNJ = (n + SYMV_TC - 1) / SYMV_TC, symNI = (n + SYMV_TR - 1) / SYMV_TR;
+    const int symTR = c->opt.eigh_symv_tr == 128 ? 128 : 64;
+    const int symNJ = (n + SYMV_TC - 1) / SYMV_TC, symNI = (n + symTR - 1) / symTR;
     const int ldP = (n + 255) / 256 * 256;
     double *Prow = nullptr, *Pcol = nullptr;
     if (symv_min > 0 && n - 1 >= symv_min) {
         SCHK(scratch_get(c, SCR_SYMV, (size_t)(symNJ + symNI) * ldP * sizeof(double), &Prow));
         Pcol = Prow + (size_t)symNJ * ldP;
     }
+    bool lower_stale = false;                          // the trailing update has been writing the upper triangle only
+    const bool can_tri = c->opt.rank2k_stream && c->opt.eigh_symv_tri;
     for (int j0 = 0; j0 < nrefl; j0 += nb) {
         const int kb = std::min(nb, nrefl - j0);
+        // one decision per panel: the symmetric-aware matvec reads the upper triangle, the streaming one the full block
+        const bool panel_symv = symv_min > 0 && n - j0 - 1 >= symv_min;
         for (int i = 0; i <= kb; ++i) {
             const int j = j0 + i;
             const bool do_row = i < kb;
@@ -1615,13 +1874,14 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
             // are dummies.
             ga.pad = o - (o / 16) * 16;
             int nblkB = (ga.pad + m + 2 * i + 1) / 2;
-            if (symv_min > 0 && m >= symv_min) {
+            if (panel_symv) {
                 // large trailing block: upper triangle only, partial sums added up by a second (small) kernel
                 TrdSymvArgs sa;
                 sa.A = W.A; sa.ld = ld; sa.n = n; sa.o = o; sa.ubuf = ub[cur];
                 sa.Prow = Prow; sa.Pcol = Pcol; sa.ldp = ldP;
                 prof_begin(c, PROF_TRD_GEMV, 4.0 * m * (double)m, 2.0 * m * (double)m);
-                SELLA_LAUNCH(c, trd_symv_kernel, dim3(symNJ, symNI), dim3(256), 0, sa);
+                if (symTR == 128) SELLA_LAUNCH(c, trd_symv_kernel<128>, dim3(symNJ, symNI), dim3(256), 0, sa);
+                else SELLA_LAUNCH(c, trd_symv_kernel<64>, dim3(symNJ, symNI), dim3(256), 0, sa);
                 prof_end(c);
                 TrdSymvFinishArgs fa;
                 fa.A = W.A; fa.ld = ld; fa.n = n; fa.o = o; fa.j = j; fa.ubuf = ub[cur];
@@ -1630,9 +1890,10 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
                 fa.wraw = wraw; fa.partB = partB; fa.Vrow = ga.Vrow; fa.Arow = ga.Arow;
                 fa.taus = taus; fa.evec = evec; fa.colscal = colscal;
                 fa.Wp = Wp; fa.Vp = Vp; fa.ldpan = ld; fa.i = i; fa.cdots = cdots;
-                fa.nelem = (m + 255) / 256;
+                fa.tr = symTR;
+                fa.nelem = (n - (o & ~63) + 63) / 64;
                 nblkB = fa.nelem;
-                prof_begin(c, PROF_OTHER, 16.0 * m * (double)(m / SYMV_TR + m / SYMV_TC), 0.0);
+                prof_begin(c, PROF_OTHER, 16.0 * m * (double)(m / symTR + m / SYMV_TC), 0.0);
                 SELLA_LAUNCH(c, trd_symv_finish_kernel, dim3(fa.nelem + 2 * i), dim3(256), 0, fa);
                 prof_end(c);
             } else {
@@ -1651,7 +1912,22 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
         if (mt > 0) {
             double* At = W.A + (size_t)r0 * ld + r0;
             // one fused pass (update.hip): every tile pair is read and written once
-            if (c->opt.rank2k_stream) SCHK(launch_rank2k_stream(c, At, mt, ld, Vp + r0, Wp + r0, ld, kb, -1.0));
+            const bool next_symv = symv_min > 0 && n - r0 - 1 >= symv_min;
+            // (the streaming kernel needs 16-byte aligned rows; the kernel that stands in otherwise averages the two
+            // triangles, so it must see a full block)
+            const bool aligned = !(ld & 1) && !(reinterpret_cast<uintptr_t>(At) & 15);
+            if (lower_stale && !(can_tri && aligned)) {
+                SCHK(launch_mirror_upper(c, At, mt, ld));
+                lower_stale = false;
+            }
+            if (can_tri && aligned && (next_symv || lower_stale)) {
+                SCHK(launch_rank2k_stream(c, At, mt, ld, Vp + r0, Wp + r0, ld, kb, -1.0, true));
+                lower_stale = true;
+                if (!next_symv) {                          // the streaming matvec takes over: full block again
+                    SCHK(launch_mirror_upper(c, At, mt, ld));
+                    lower_stale = false;
+                }
+            } else if (c->opt.rank2k_stream) SCHK(launch_rank2k_stream(c, At, mt, ld, Vp + r0, Wp + r0, ld, kb, -1.0));
             else SCHK(launch_sym_rank2k(c, At, mt, ld, Vp + r0, Wp + r0, ld, kb, -1.0));
         }
     }
@@ -1911,7 +2187,7 @@ int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const do
     if (ldp != ld) { set_error("eigh update: panel stride mismatch"); return SELLA_E_INVALID; }
     EighWork W;
     W.c = c; W.n = n; W.ld = ld;
-    const size_t mbytes = ((size_t)std::max(n, 64) + WY_NB + 2) * std::max(ld, 64) * sizeof(double);
+    const size_t mbytes = ((size_t)std::max(n, 64) + WY_NB2 + 2) * std::max(ld, 64) * sizeof(double);
     SCHK(scratch_get(c, SCR_EIG1, mbytes, &W.Za));
     SCHK(scratch_get(c, SCR_EIG2, mbytes, &W.Zb));
     SCHK(scratch_get(c, SCR_EIG3, mbytes, &W.Zc));
@@ -2331,7 +2607,7 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     const int ld = round_up(n, 8);
     EighWork W;
     W.c = c; W.n = n; W.ld = ld;
-    const size_t mbytes = ((size_t)std::max(n, 64) + WY_NB + 2) * std::max(ld, 64) * sizeof(double);
+    const size_t mbytes = ((size_t)std::max(n, 64) + WY_NB2 + 2) * std::max(ld, 64) * sizeof(double);
     SCHK(scratch_get(c, SCR_EIG0, mbytes, &W.A));
     SCHK(scratch_get(c, SCR_EIG1, mbytes, &W.Za));
     SCHK(scratch_get(c, SCR_EIG2, mbytes, &W.Zb));
@@ -2365,12 +2641,21 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     // The compact-WY factors of the back-transformation depend on the reflectors only: their Gram matrices
     // and triangular factors are enqueued now and run while the host plans the divide & conquer stage.
     const int nrefl = n - 2;
-    const int nblk = nrefl > 0 ? (nrefl + WY_NB - 1) / WY_NB : 0;
-    double* Gd = nullptr;                                // nblk x 32 x 32: Gram matrices, then C = T^T
+    // 64 reflectors per block from `eigh_wy_nb64_min` rows on (MFMA path with 16 rows and 4 wavefronts per workgroup)
+    const bool wy64 = c->opt.eigh_wy_mfma && c->opt.eigh_wy_rows != 32 && c->opt.eigh_wy_waves < 8 &&
+                      c->opt.eigh_wy_nb64_min > 0 && n >= c->opt.eigh_wy_nb64_min;
+    const int wynb = wy64 ? WY_NB2 : WY_NB;
+    const int nblk = nrefl > 0 ? (nrefl + wynb - 1) / wynb : 0;
+    double* Gd = nullptr;                                // nblk x nb x nb: Gram matrices, then C = T^T
     if ((hV || hVt) && nblk > 0) {
-        SCHK(scratch_get(c, SCR_EIG6, (size_t)nblk * WY_NB * WY_NB * sizeof(double), &Gd));
-        hipLaunchKernelGGL(wy_gram_kernel, dim3(nblk), dim3(256), 0, c->stream, W.A, ld, n, nrefl, taus, Gd);
-        hipLaunchKernelGGL(wy_tinv_kernel, dim3(nblk), dim3(64), 0, c->stream, Gd, nrefl, taus);
+        SCHK(scratch_get(c, SCR_EIG6, (size_t)nblk * wynb * wynb * sizeof(double), &Gd));
+        if (wy64) {
+            hipLaunchKernelGGL(wy_gram64_kernel, dim3(nblk), dim3(256), 0, c->stream, W.A, ld, n, nrefl, taus, Gd);
+            hipLaunchKernelGGL(wy_tinv64_kernel, dim3(nblk), dim3(64), 0, c->stream, Gd, nrefl, taus);
+        } else {
+            hipLaunchKernelGGL(wy_gram_kernel, dim3(nblk), dim3(256), 0, c->stream, W.A, ld, n, nrefl, taus, Gd);
+            hipLaunchKernelGGL(wy_tinv_kernel, dim3(nblk), dim3(64), 0, c->stream, Gd, nrefl, taus);
+        }
         HIPCHK(hipGetLastError());
     }
 
@@ -2383,7 +2668,7 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     // ---- stage 3: X = Z H_{n-3} ... H_0 (rows) -------------------------------------------------
     double* X = W.Za;
     if (nrefl > 0) {
-        const int yrows = nblk * WY_NB;
+        const int yrows = nblk * wynb;
         double* Yf = W.Zc;                               // explicit reflectors (yrows x ld)
         hipLaunchKernelGGL(wy_expand_kernel, dim3((ld + 255) / 256, yrows), dim3(256), 0, c->stream, W.A, ld, n, nrefl,
                            taus, Yf);
@@ -2393,7 +2678,9 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
             // wavefronts per workgroup: a workgroup owns 16 rows of X, so there are only n / 16 of them (one per CU at
             // n = 3072) — more wavefronts splitting the columns is what hides the L2 latency of the operand streams
             const long nw = c->opt.eigh_wy_waves;
-            if (c->opt.eigh_wy_rows == 32 && nw >= 8)
+            if (wy64)
+                SELLA_LAUNCH(c, wy_apply_mfma64_kernel<4>, dim3((n + 15) / 16), dim3(256), 0, X, ld, n, Yf, Gd, nblk);
+            else if (c->opt.eigh_wy_rows == 32 && nw >= 8)
                 SELLA_LAUNCH(c, wy_apply_mfma2_kernel<8>, dim3((n + 31) / 32), dim3(512), 0, X, ld, n, Yf, Gd, nblk);
             else if (c->opt.eigh_wy_rows == 32)
                 SELLA_LAUNCH(c, wy_apply_mfma2_kernel<4>, dim3((n + 31) / 32), dim3(256), 0, X, ld, n, Yf, Gd, nblk);

@@ -90,12 +90,16 @@ struct Options {
     long host_scalars = 0;   // 1: host-consumed scalars are written straight into pinned host memory (measured: no gain)
     long gemm_tile128 = 1;   // 1: 128x128 double-buffered tiles for large NN/TN products
     long eigh_leaf = 32;     // leaf size of the divide-and-conquer tree
-    long eigh_symv_min = 4096;   // trailing blocks of at least this many rows use the symmetric-aware matvec of the
+    long eigh_symv_tri = 1;      // ... and the trailing update then writes the upper triangle only (mirrored once, when the
+                                 // trailing block drops below eigh_symv_min)
+    long eigh_symv_tr = 64;      // rows per tile of that matvec (64 or 128)
+    long eigh_symv_min = 5120;   // trailing blocks of at least this many rows use the symmetric-aware matvec of the
                                  // tridiagonalisation (upper triangle only, eigh.hip); 0: never
     long eigh_nb = 16;       // panel width of the blocked tridiagonalisation (tools/eigh_tune.py)
     long panel_mfma = 1;     // 1: products with more than 8 right-hand sides stream the matrix once (MFMA panel kernel)
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
+    long eigh_wy_nb64_min = 4096; // 64 instead of 32 reflectors per block of the back-transformation from this many rows on (0: never)
     long eigh_wy_rows = 16;  // rows of X per workgroup of the MFMA back-transformation (16, or 32: two row tiles)
     long eigh_wy_waves = 4;  // wavefronts per workgroup of the MFMA back-transformation (4, 8 or 16: measured equal at n = 3072 and 12288 — the kernel is bound by L2 bandwidth, 22.7 GB in 3.16 ms, not by latency)
     long lr_cholqr = 1;      // 1: block of update vectors orthonormalised by Cholesky-QR twice (eigh.hip, lr_lowrank_update)
@@ -275,7 +279,8 @@ int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, 
 // C <- C + alpha sum_a (U_a Z_a^T + Z_a U_a^T) for an ALREADY symmetric block, as a pure stream (no mirror tile; the two
 // triangles agree to roundoff, not bitwise): the trailing update of the tridiagonalisation
 int launch_rank2k_stream(sella_ctx* c, double* C, int m, int ld, const double* Up, const double* Zp, int ldp, int kk,
-                         double alpha);
+                         double alpha, bool upper_only = false);
+int launch_mirror_upper(sella_ctx* c, double* C, int m, int ld);      // lower triangle <- transpose of the upper one
 // eigh.hip: eigendecomposition (w host ascending, Vt rows / V columns, both updated in place) of
 // B + sum_a (U_a Z_a^T + Z_a U_a^T) from that of B; *nrank1 = rank-one modifications applied
 int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const double* Up, const double* Zp,

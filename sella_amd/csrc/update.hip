@@ -164,9 +164,13 @@ __global__ __launch_bounds__(256) void rank2k_stream_kernel(double* __restrict__
 template <int KK>
 __global__ __launch_bounds__(256) void rank2k_stream_fixed_kernel(double* __restrict__ C, int m, int ld,
                                                                   const double* __restrict__ Up,
-                                                                  const double* __restrict__ Zp, int ldp, double alpha) {
+                                                                  const double* __restrict__ Zp, int ldp, double alpha,
+                                                                  int upper_only) {
     __shared__ double dl[RS_TR][RS_TC + 2];
     constexpr int KS = 2 * KK / 4;
+    // upper_only: the caller reads the upper triangle only (symmetric-aware matvec of the tridiagonalisation): tiles
+    // entirely below the diagonal leave at once
+    if (upper_only && (int)(blockIdx.x * RS_TC + RS_TC - 1) < (int)(blockIdx.y * RS_TR)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int r0 = blockIdx.y * RS_TR, c0 = blockIdx.x * RS_TC;
@@ -227,16 +231,45 @@ __global__ __launch_bounds__(256) void rank2k_stream_fixed_kernel(double* __rest
     }
 }
 
+// lower triangle of the m x m block C <- transpose of its upper triangle (32 x 32 tiles through LDS)
+__global__ __launch_bounds__(256) void mirror_upper_kernel(double* __restrict__ C, int m, int ld) {
+    __shared__ double t[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;              // source tile (rows bi, columns bj), bj >= bi
+    if (bj < bi) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int q = 0; q < 4; ++q) {
+        const int r = bi * 32 + ty + 8 * q, cc = bj * 32 + tx;
+        t[ty + 8 * q][tx] = (r < m && cc < m) ? C[(size_t)r * ld + cc] : 0.0;
+    }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        const int r = bj * 32 + ty + 8 * q, cc = bi * 32 + tx;   // destination (r, cc) = source (cc, r)
+        if (r < m && cc < m && r > cc) C[(size_t)r * ld + cc] = t[tx][ty + 8 * q];
+    }
+}
+
+int launch_mirror_upper(sella_ctx* c, double* C, int m, int ld) {
+    if (m <= 1) return SELLA_OK;
+    const int nt = (m + 31) / 32;
+    prof_begin(c, PROF_OTHER, 8.0 * m * (double)m, 0.0);
+    SELLA_LAUNCH(c, mirror_upper_kernel, dim3(nt, nt), dim3(256), 0, C, m, ld);
+    prof_end(c);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
 int launch_rank2k_stream(sella_ctx* c, double* C, int m, int ld, const double* Up, const double* Zp, int ldp, int kk,
-                         double alpha) {
+                         double alpha, bool upper_only) {
     if (m <= 0 || kk <= 0) return SELLA_OK;
     if ((ld & 1) || (reinterpret_cast<uintptr_t>(C) & 15)) return launch_sym_rank2k(c, C, m, ld, Up, Zp, ldp, kk, alpha);
-    prof_begin(c, PROF_UPDATE, 16.0 * m * (double)m, 4.0 * kk * (double)m * m);
+    const double part = upper_only ? 0.5 : 1.0;
+    prof_begin(c, PROF_UPDATE, part * 16.0 * m * (double)m, part * 4.0 * kk * (double)m * m);
     const dim3 grid((m + RS_TC - 1) / RS_TC, (m + RS_TR - 1) / RS_TR);
+    const int uo = upper_only ? 1 : 0;
     if (kk == 16 && c->opt.rank2k_fixed)
-        SELLA_LAUNCH(c, rank2k_stream_fixed_kernel<16>, grid, dim3(256), 0, C, m, ld, Up, Zp, ldp, alpha);
+        SELLA_LAUNCH(c, rank2k_stream_fixed_kernel<16>, grid, dim3(256), 0, C, m, ld, Up, Zp, ldp, alpha, uo);
     else if (kk == 32 && c->opt.rank2k_fixed)
-        SELLA_LAUNCH(c, rank2k_stream_fixed_kernel<32>, grid, dim3(256), 0, C, m, ld, Up, Zp, ldp, alpha);
+        SELLA_LAUNCH(c, rank2k_stream_fixed_kernel<32>, grid, dim3(256), 0, C, m, ld, Up, Zp, ldp, alpha, uo);
     else
     SELLA_LAUNCH(c, rank2k_stream_kernel, grid, dim3(256), 0, C, m, ld, Up,
                  Zp, ldp, kk, alpha);

@@ -69,11 +69,20 @@ def test_panel_widths_and_variants(ctx):
             ctx.set_option('eigh_wy_rows', rows)
             ctx.set_option('eigh_wy_waves', waves)
             np.testing.assert_allclose(check(ctx, A), ref, atol=1e-12 * np.abs(ref).max())
+        # 64 reflectors per compact-WY block (the default from n = 4096 on): full blocks, a ragged last block, one block
+        ctx.set_option('eigh_wy_rows', 16)
+        ctx.set_option('eigh_wy_waves', 4)
+        ctx.set_option('eigh_wy_nb64_min', 1)
+        np.testing.assert_allclose(check(ctx, A), ref, atol=1e-12 * np.abs(ref).max())
+        for n2 in ((40, 150) if ctx.backend == 'emu' else (40, 130, 150, 515)):
+            A2 = rng.normal(size=(n2, n2))
+            check(ctx, A2 + A2.T)
     finally:
         ctx.set_option('eigh_nb', 16)
         ctx.set_option('eigh_wy_mfma', 1)
         ctx.set_option('eigh_wy_rows', 16)
         ctx.set_option('eigh_wy_waves', 4)
+        ctx.set_option('eigh_wy_nb64_min', 4096)
 
 
 def test_symmetric_aware_trailing_matvec(ctx):
@@ -84,7 +93,7 @@ def test_symmetric_aware_trailing_matvec(ctx):
     try:
         sizes = ((70, (1,)), (257, (1, 100)), (330, (1, 200)), (515, (1,)), (1100, (1, 600)))
         if ctx.backend == 'emu':
-            sizes = ((70, (1,)), (258, (1,)))                             # the emulator runs fibre by fibre
+            sizes = ((70, (1, 40)), (67, (1,)), (258, (1,)))                        # the emulator runs fibre by fibre
         for n, thresholds in sizes:
             A = rng.normal(size=(n, n))
             A = A + A.T
@@ -103,11 +112,16 @@ def test_symmetric_aware_trailing_matvec(ctx):
         for nb in ((24,) if ctx.backend == 'emu' else (4, 24)):
             ctx.set_option('eigh_nb', nb)
             ctx.set_option('eigh_symv_min', 1)
+            ctx.set_option('eigh_symv_tr', 128)                           # 128-row tiles
             n = 100 if ctx.backend == 'emu' else 200
             A = rng.normal(size=(n, n))
             check(ctx, A + A.T)
+        if ctx.backend != 'emu':
+            A = rng.normal(size=(700, 700))
+            check(ctx, A + A.T)
     finally:
-        ctx.set_option('eigh_symv_min', 4096)
+        ctx.set_option('eigh_symv_min', 5120)
+        ctx.set_option('eigh_symv_tr', 64)
         ctx.set_option('eigh_nb', 16)
 
 

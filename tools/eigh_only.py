@@ -20,6 +20,10 @@ if os.environ.get('EIGH_WY_WAVES'):
     ctx.set_option('eigh_wy_waves', int(os.environ['EIGH_WY_WAVES']))
 if os.environ.get('EIGH_SYMV_MIN'):
     ctx.set_option('eigh_symv_min', int(os.environ['EIGH_SYMV_MIN']))
+if os.environ.get('EIGH_SYMV_TR'):
+    ctx.set_option('eigh_symv_tr', int(os.environ['EIGH_SYMV_TR']))
+if os.environ.get('EIGH_WY64_MIN'):
+    ctx.set_option('eigh_wy_nb64_min', int(os.environ['EIGH_WY64_MIN']))
 if os.environ.get('EIGH_LEAF'):
     ctx.set_option('eigh_leaf', int(os.environ['EIGH_LEAF']))
 rng = np.random.RandomState(0)

@@ -86,6 +86,16 @@ SELLA_DEBUG_TIMING=1 timeout 300 python tools/opt_profile.py 3072 20 > $OUT/opt_
 grep "update_H\|rank-one" $OUT/opt_3072_timing.log | tail -3 | tee -a $OUT/session.log
 SELLA_DEBUG_TIMING=1 timeout 300 python tools/emt_slab_opt.py > $OUT/emt.log 2> $OUT/emt_timing.log; grep "per optimizer step" -A8 $OUT/emt.log | tee -a $OUT/session.log
 grep "update_H" $OUT/emt_timing.log | tail -2 | tee -a $OUT/session.log
+say "== eigensolver at 3N = 6144 / 8192 / 12288: defaults, then symmetric-aware matvec and 64-reflector blocks off"
+{ for n in 6144 8192 12288; do
+    echo "n = $n, defaults (eigh_symv_min 5120, eigh_wy_nb64_min 4096)"; timeout 300 python tools/eigh_only.py $n 3 2>&1 | tail -2
+    echo "n = $n, eigh_symv_min 0, eigh_wy_nb64_min 0 (streaming matvec over the full block, 32-reflector blocks)"; EIGH_SYMV_MIN=0 EIGH_WY64_MIN=0 timeout 300 python tools/eigh_only.py $n 3 2>&1 | tail -2
+  done; } > $OUT/eigh_large.log 2>&1; cat $OUT/eigh_large.log | tee -a $OUT/session.log
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_eigh12288 -o eigh12288 -- python $R/tools/eigh_only.py 12288 1 > $R/$OUT/rocprof_eigh12288.log 2>&1); say "rocprof eigh 12288 exit $?"
+db=$(find $OUT/prof_eigh12288 -name "*.db" | head -1)
+python tools/rocprof_summary.py $db $OUT/eigh12288_kernel_stats.md "tools/eigh_only.py 12288 1 (rocprofv3 --kernel-trace --stats)" > /dev/null
+python tools/trd_by_m.py $db 1024 > $OUT/eigh12288_by_m.txt 2>&1; head -14 $OUT/eigh12288_kernel_stats.md | tee -a $OUT/session.log; cat $OUT/eigh12288_by_m.txt | tee -a $OUT/session.log
+rm -rf $OUT/prof_eigh12288
 say "== configs[2]: internal coordinates / geodesic at 1024 atoms"
 timeout 600 python tools/geodesic_bench.py --steps 3 --sella-steps 2 > $OUT/geodesic.log 2>&1; say "geodesic exit $?"
 grep "^{" $OUT/geodesic.log | cut -c1-400 | tee -a $OUT/session.log

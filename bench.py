@@ -129,6 +129,8 @@ def main():
     ap.add_argument('--starts', type=int, default=5)
     ap.add_argument('--converged-n', type=int, default=768)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--option', action='append', default=[], metavar='KEY=VALUE',
+                    help='library tuning knob for this run (sella_ctx_set_option; recorded on the line), repeatable')
     ap.add_argument('--no-optimizer', action='store_true')
     ap.add_argument('--opt-steps', type=int, default=20)
     ap.add_argument('--emt-steps', type=int, default=10)
@@ -162,6 +164,9 @@ def main():
     local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
     host_threads = limit_blas_threads(max(1, effective_cpu_count() // max(1, local_world)))
     ctx = Context()             # LOCAL_RANK selects the device (one process per GPU)
+    for kv in args.option:
+        key, _, val = kv.partition('=')
+        ctx.set_option(key, int(val))
     # Collectives: librccl bound with ctypes on this context's stream and buffers (sella_amd/comm.py) — no PyTorch.
     # The CPU tests (gloo, host emulation) set SELLA_BENCH_COMM=gloo; if the direct binding cannot come up on a GPU
     # box, torch.distributed's nccl backend (the same RCCL) is the fallback, and the line says which was used.
@@ -663,7 +668,8 @@ def main():
             'config': {'workload': f'1024-atom-equivalent 3N={n} fp64 Davidson (BASELINE configs[1]), '
                                    f'one independent replica per GPU', 'n': n, 'maxiter': args.maxiter,
                        'gamma': args.gamma, 'method': 'jd0', 'problems': args.seeds * args.starts, 'matrices': args.seeds,
-                       'vectors_per_call': round(total_iters / (args.steps * world), 2)},
+                       'vectors_per_call': round(total_iters / (args.steps * world), 2),
+                       **({'options': list(args.option)} if args.option else {})},
             'davidson_loop_only_iter_per_s': round(it2 / t_loop, 1),
             'eigh_ms': round(1e3 * t_eigh, 2),
             'optimizer': opt_stats,

@@ -56,11 +56,14 @@ int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
  *   gemv_rw (2) rows per wavefront of the streaming matvec | gemm_mfma (1) GEMMs on the matrix cores |
  *   gemm_tile128 (1) 128x128 GEMM tiles for large products | panel_mfma (1), panel_rows (0 = by size) the
  *   H.V block product | host_scalars (0) zero-copy scalars | rank2k_stream (1) mirror-free trailing update |
- *   eigh_nb (16) panel width, eigh_leaf (32) leaf size, eigh_wy_mfma (1) MFMA back-transformation |
+ *   eigh_nb (16) panel width, eigh_leaf (16) leaf size, eigh_wy_mfma (1) MFMA back-transformation |
  *   eigh_symv_min (5120) trailing blocks of the tridiagonalisation with at least this many rows take the
  *   symmetric-aware matvec (upper triangle only, fixed-order partial sums; 0: never), eigh_symv_tr (64) rows per tile
- *   of it, eigh_symv_tri (1) trailing update on the upper triangle only while it runs | eigh_wy_nb64_min (4096) 64
+ *   of it, eigh_symv_tri (1) trailing update on the upper triangle only while it runs | eigh_wy_nb64_min (2560) 64
  *   instead of 32 reflectors per block of the back-transformation from this many rows on |
+ *   dav_fuse_scale (1), dav_zero_copy (0) Davidson chain: diagonal scaling inside the residual kernel, coefficients read
+ *   from pinned host memory |
+ *   eigh_tail_lds (128) the last <= 128 columns of the tridiagonalisation inside one workgroup, the block in LDS |
  *   rs_batch (1) bisection phase of sella_restricted_step: 15 trial alphas per device round trip |
  *   panel_small (2048) panel products with <= 64 rows and <= 16 right-hand sides take the split-K kernels from this
  *   many columns on | bd_dev_rr (0) Rayleigh-Ritz eigenproblem of sella_davidson_block on the device (one-workgroup

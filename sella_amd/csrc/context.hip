@@ -390,6 +390,9 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "rank2k_stream")) c->opt.rank2k_stream = value ? 1 : 0;
     else if (!strcmp(key, "eigh_wy_rows")) c->opt.eigh_wy_rows = value;
     else if (!strcmp(key, "eigh_wy_nb64_min")) c->opt.eigh_wy_nb64_min = value;
+    else if (!strcmp(key, "dav_fuse_scale")) c->opt.dav_fuse_scale = value ? 1 : 0;
+    else if (!strcmp(key, "dav_zero_copy")) c->opt.dav_zero_copy = value ? 1 : 0;
+    else if (!strcmp(key, "eigh_tail_lds")) c->opt.eigh_tail_lds = value < 0 ? 0 : value;
     else if (!strcmp(key, "eigh_wy_waves")) c->opt.eigh_wy_waves = value;
     else if (!strcmp(key, "lr_cholqr")) c->opt.lr_cholqr = value ? 1 : 0;
     else if (!strcmp(key, "rank2k_fixed")) c->opt.rank2k_fixed = value ? 1 : 0;

@@ -366,7 +366,11 @@ template <int NJ>
 __global__ __launch_bounds__(256) void dav_resid_kernel(int n, int k, int nneg, const double* __restrict__ V,
                                                         const double* __restrict__ AV, int ld,
                                                         const double* __restrict__ coef, double* __restrict__ R,
-                                                        double* __restrict__ vout, double* __restrict__ part) {
+                                                        double* __restrict__ vout, double* __restrict__ part,
+                                                        int seek, const double* __restrict__ dscale, double theta,
+                                                        double* __restrict__ mid) {
+    // seek >= 0 (panels in P's eigenbasis): the rows the correction equation needs are also written divided by
+    // (d - theta) — mid row 0 from residual row `seek`, mid row 1 from v — which was a kernel of its own on the chain
     __shared__ double cs[(2 * NJ + 1) * DF_TILE];
     __shared__ double xw[4][NJ + 1][DF_EL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -400,15 +404,24 @@ __global__ __launch_bounds__(256) void dav_resid_kernel(int n, int k, int nneg, 
     }
     df_rowsplit_sum<NJ + 1>(acc, xw);
     if (wave == 0) {
+        double den = 1.0;
+        if (seek >= 0) {
+            den = dscale[il] - theta;                           // exact-hit guard of GemvEpi mode 1 (kernels.hip)
+            if (den == 0.0) den = 2.220446049250313e-16 * fmax(fabs(theta), 2.2250738585072014e-308);
+        }
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
             if (j0 + jj < nneg) {                               // (uniform)
                 if (valid) R[(size_t)(j0 + jj) * ld + i] = acc[jj];
+                if (valid && j0 + jj == seek) mid[i] = acc[jj] / den;
                 const double ss = wave_sum64(valid ? acc[jj] * acc[jj] : 0.0);
                 if (lane == 0) part[(size_t)(j0 + jj) * DF_MAXBLK + blockIdx.x] = ss;
             }
         }
-        if (dov && valid) vout[i] = acc[NJ];
+        if (dov && valid) {
+            vout[i] = acc[NJ];
+            if (seek >= 0) mid[(size_t)ld + i] = acc[NJ] / den;
+        }
     }
 }
 
@@ -921,10 +934,10 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
             if (nneg == 1) {
                 grid.y = 1;
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(dav_resid_kernel<1>), grid, dim3(256), 0, c->stream, n, k, nneg, s.Vp, s.AVp,
-                                   s.ld, dC, s.Rp, vrow, rpart);
+                                   s.ld, dC, s.Rp, vrow, rpart, -1, nullptr, 0.0, nullptr);
             } else {
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(dav_resid_kernel<4>), grid, dim3(256), 0, c->stream, n, k, nneg, s.Vp, s.AVp,
-                                   s.ld, dC, s.Rp, vrow, rpart);
+                                   s.ld, dC, s.Rp, vrow, rpart, -1, nullptr, 0.0, nullptr);
             }
             HIPCHK(hipGetLastError());
             return SELLA_OK;
@@ -957,22 +970,33 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
                 // the convergence test), the diagonal of (P - theta)^-1, then the ONE n x n pass with Q
                 double* dC;
                 const int ncoef = (2 * nneg + 1) * k;
-                DCHK(put_small(s, coef.data(), ncoef, 1, (size_t)s.cap * s.cap + 8, &dC));
+                if (c->opt.dav_zero_copy && ncoef <= 8192) {
+                    // the kernels stage the coefficients into LDS straight from pinned host memory: one coalesced read
+                    // over the link instead of a copy launch on the chain; the slot is rewritten only after this
+                    // iteration's synchronisation
+                    dC = c->hscal + DS_STAGE + 8192;
+                    memcpy(dC, coef.data(), (size_t)ncoef * sizeof(double));
+                } else {
+                    DCHK(put_small(s, coef.data(), ncoef, 1, (size_t)s.cap * s.cap + 8, &dC));
+                }
                 s.dcoef = dC;
                 double* Rq = s.Vq;                           // free between flushes: rows Q^T r_j
                 double* vq = s.AVq;                          // row 0: Q^T v
                 dim3 grid(nblk, (nneg + 3) / 4);
+                const bool fuse = c->opt.dav_fuse_scale;     // the diagonal scaling in the epilogue of the residual kernel
+                const int fseek = fuse ? seek_pred : -1;
                 if (nneg == 1) {
                     grid.y = 1;
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(dav_resid_kernel<1>), grid, dim3(256), 0, c->stream, n, k, nneg, s.QtV,
-                                       s.QtAV, s.ld, dC, Rq, vq, rpart);
+                                       s.QtAV, s.ld, dC, Rq, vq, rpart, fseek, s.pevals_dev, lams[seek_pred], mid);
                 } else {
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(dav_resid_kernel<4>), grid, dim3(256), 0, c->stream, n, k, nneg, s.QtV,
-                                       s.QtAV, s.ld, dC, Rq, vq, rpart);
+                                       s.QtAV, s.ld, dC, Rq, vq, rpart, fseek, s.pevals_dev, lams[seek_pred], mid);
                 }
                 mode = (method == SELLA_DAV_GD) ? 0 : 1;
-                hipLaunchKernelGGL(dav_eigscale_kernel, dim3(nblke), dim3(256), 0, c->stream, n, mode == 1 ? 2 : 1,
-                                   Rq + (size_t)seek_pred * s.ld, vq, s.pevals_dev, lams[seek_pred], mid, s.ld);
+                if (!fuse)
+                    hipLaunchKernelGGL(dav_eigscale_kernel, dim3(nblke), dim3(256), 0, c->stream, n, mode == 1 ? 2 : 1,
+                                       Rq + (size_t)seek_pred * s.ld, vq, s.pevals_dev, lams[seek_pred], mid, s.ld);
                 DHIP(hipGetLastError());
                 DCHK(launch_gemv_rows(c, s.Q->d, n, n, s.Q->ld, mid, s.ld, mode == 1 ? 2 : 1, out, s.ld, GemvEpi()));
             } else {

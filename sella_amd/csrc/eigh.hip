@@ -481,6 +481,98 @@ __global__ __launch_bounds__(256) void trd_symv_finish_kernel(TrdSymvFinishArgs 
     }
 }
 
+// ---- the last columns in LDS --------------------------------------------------------------------------------------------
+// Below ~1500 trailing rows every column of the factorisation costs two launches on their floors (row kernel 3.3 us,
+// matvec 2.2-3.6 us) whatever the block size.  Once the trailing block has m <= TRD_TAIL rows it fits the 160 KB of LDS of
+// one CU: ONE workgroup of 1024 threads finishes the factorisation there (unblocked Householder steps, dsytd2's algebra:
+// v, p = tau A v, w = p - tau/2 (p.v) v, A -= v w^T + w v^T), five barriers per column instead of two launches.  Row r of
+// the block belongs to the 8 threads tid / 8 == r (columns interleaved), so the 8-lane sums of the matvec are three DPP
+// steps.  The upper triangle of the block is the authoritative one on entry; reflectors go to the rows of A as in
+// trd_gemv_kernel.
+constexpr int TRD_TAIL = 128, TRD_TAIL_LD = 136;
+
+__global__ __launch_bounds__(1024) void trd_tail_lds_kernel(double* __restrict__ A, int ld, int n, int j0,
+                                                            double* __restrict__ dvec, double* __restrict__ evec,
+                                                            double* __restrict__ taus) {
+    __shared__ double S[TRD_TAIL][TRD_TAIL_LD];
+    __shared__ double v[TRD_TAIL], w[TRD_TAIL], pr[TRD_TAIL];
+    __shared__ double red[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = n - j0;
+    const int r = tid >> 3, q = tid & 7;
+    for (int e = tid; e < m * m; e += 1024) {
+        const int rr = e / m, cc = e - rr * m;
+        const int lo = rr < cc ? rr : cc, hi = rr < cc ? cc : rr;
+        S[rr][cc] = A[(size_t)(j0 + lo) * ld + j0 + hi];
+    }
+    __syncthreads();
+    for (int k = 0; k + 2 < m; ++k) {
+        const int o = k + 1;
+        // (a) sum of squares behind the leading entry of row k
+        if (tid < 128) {
+            const double x = (tid > o && tid < m) ? S[k][tid] : 0.0;
+            const double ss = wave_sum64(x * x);
+            if (lane == 0) red[wave] = ss;
+        }
+        __syncthreads();
+        // (b) reflector (dlarfg), v, the tridiagonal entries
+        const double ss = red[0] + red[1];
+        const double alpha = S[k][o];
+        double beta, tau, scale;
+        if (ss == 0.0) { beta = alpha; tau = 0.0; scale = 0.0; }
+        else {
+            const double nrm = sqrt(alpha * alpha + ss);
+            beta = (alpha >= 0.0) ? -nrm : nrm;
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        if (tid < m) {
+            const double vc = (tid < o) ? 0.0 : (tid == o ? 1.0 : scale * S[k][tid]);
+            v[tid] = vc;
+            if (tid > o) A[(size_t)(j0 + k) * ld + j0 + tid] = vc;
+        }
+        if (tid == 0) { dvec[j0 + k] = S[k][k]; evec[j0 + k] = beta; taus[j0 + k] = tau; }
+        __syncthreads();
+        // (c) p = tau S22 v
+        {
+            double acc = 0.0;
+            if (r >= o && r < m)
+                for (int c = o + q; c < m; c += 8) acc += S[r][c] * v[c];
+            acc = wave_dpp_add<0xB1>(acc);
+            acc = wave_dpp_add<0x4E>(acc);
+            acc = wave_dpp_add<0x141>(acc);
+            if (q == 0 && r < m) pr[r] = (r >= o) ? tau * acc : 0.0;
+        }
+        __syncthreads();
+        // (d) w = p - tau/2 (p.v) v
+        if (tid < 128) {
+            const double x = (tid >= o && tid < m) ? pr[tid] * v[tid] : 0.0;
+            const double pv = wave_sum64(x);
+            if (lane == 0) red[wave] = pv;
+        }
+        __syncthreads();
+        const double alpha2 = -0.5 * tau * (red[0] + red[1]);
+        if (tid >= o && tid < m) w[tid] = pr[tid] + alpha2 * v[tid];
+        __syncthreads();
+        // (e) S22 -= v w^T + w v^T
+        if (r >= o && r < m) {
+            const double vr = v[r], wr = w[r];
+            for (int c = o + q; c < m; c += 8) S[r][c] -= vr * w[c] + wr * v[c];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (m >= 2) {
+            dvec[j0 + m - 2] = S[m - 2][m - 2];
+            evec[j0 + m - 2] = S[m - 2][m - 1];
+            taus[j0 + m - 2] = 0.0;
+        }
+        dvec[j0 + m - 1] = S[m - 1][m - 1];
+        evec[j0 + m - 1] = 0.0;
+        taus[j0 + m - 1] = 0.0;
+    }
+}
+
 __global__ void tridiag_tail_kernel(const double* __restrict__ A, int ld, int n, double* dvec,
                                     double* evec, double* taus) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1094,16 +1186,19 @@ __global__ __launch_bounds__(64 * NW) void wy_apply_mfma_kernel(double* __restri
 // reflector stream and the MFMA work are unchanged.
 constexpr int WY_NB2 = 64;
 
+// grid (blocks, S): slice s of a block takes every S-th 64-column chunk and writes its own partial Gram matrix
+// (G[(b S + s)]); wy_tinv64_kernel adds the S partials in a fixed order.
 __global__ __launch_bounds__(256) void wy_gram64_kernel(const double* __restrict__ A, int ld, int n, int nrefl,
                                                         const double* __restrict__ taus, double* __restrict__ G) {
     __shared__ double Ys[WY_NB2][65];
     const int b = blockIdx.x, j0 = b * WY_NB2;
+    const int S = gridDim.y, sl = blockIdx.y;
     const int kb = (nrefl - j0 < WY_NB2) ? (nrefl - j0) : WY_NB2;
     const int p = threadIdx.x >> 2, q0 = (threadIdx.x & 3) * 16;
     double acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.0;
-    for (int ct = j0 + 1; ct < n; ct += 64) {
+    for (int ct = j0 + 1 + 64 * sl; ct < n; ct += 64 * S) {
         __syncthreads();
         for (int e = threadIdx.x; e < WY_NB2 * 64; e += 256) {
             const int r = e >> 6, cc = e & 63;
@@ -1118,13 +1213,14 @@ __global__ __launch_bounds__(256) void wy_gram64_kernel(const double* __restrict
         }
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) G[((size_t)b * WY_NB2 + p) * WY_NB2 + q0 + k] = acc[k];
+    for (int k = 0; k < 16; ++k) G[(((size_t)b * S + sl) * WY_NB2 + p) * WY_NB2 + q0 + k] = acc[k];
 }
 
 // C_b = T_b^T for a 64-block, in place (see wy_tinv_kernel).  One LDS array serves both triangular matrices: T^-1 (from
 // the Gram matrix) in the upper triangle with its diagonal, the transpose of T — which is the output — growing in the
 // strictly lower one, its diagonal beside it.
-__global__ __launch_bounds__(64) void wy_tinv64_kernel(double* __restrict__ G, int nrefl, const double* __restrict__ taus) {
+__global__ __launch_bounds__(64) void wy_tinv64_kernel(double* __restrict__ G, const double* __restrict__ Gpart, int nsl,
+                                                       int nrefl, const double* __restrict__ taus) {
     __shared__ double S[WY_NB2][WY_NB2 + 1];
     __shared__ double dg[WY_NB2];
     const int b = blockIdx.x, j0 = b * WY_NB2;
@@ -1134,8 +1230,9 @@ __global__ __launch_bounds__(64) void wy_tinv64_kernel(double* __restrict__ G, i
         const int i = e >> 6, k2 = e & 63;
         double v = 0.0;
         if (i < kb && k2 < kb) {
-            if (k2 > i) v = Gb[e];
-            else if (k2 == i) { const double t = taus[j0 + i]; v = (t != 0.0) ? 1.0 / t : 1.0; }
+            if (k2 > i) {
+                for (int sl = 0; sl < nsl; ++sl) v += Gpart[((size_t)b * nsl + sl) * WY_NB2 * WY_NB2 + e];
+            } else if (k2 == i) { const double t = taus[j0 + i]; v = (t != 0.0) ? 1.0 / t : 1.0; }
         }
         S[i][k2] = v;
     }
@@ -1811,10 +1908,19 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
         SCHK(scratch_get(c, SCR_SYMV, (size_t)(symNJ + symNI) * ldP * sizeof(double), &Prow));
         Pcol = Prow + (size_t)symNJ * ldP;
     }
+    const int tail_lds = (int)std::min<long>(c->opt.eigh_tail_lds, TRD_TAIL);
     bool lower_stale = false;                          // the trailing update has been writing the upper triangle only
     const bool can_tri = c->opt.rank2k_stream && c->opt.eigh_symv_tri;
     for (int j0 = 0; j0 < nrefl; j0 += nb) {
         const int kb = std::min(nb, nrefl - j0);
+        if (tail_lds > 0 && n - j0 <= tail_lds) {
+            // the rest of the factorisation inside one workgroup (the trailing block is up to date at a panel boundary)
+            prof_begin(c, PROF_OTHER, 8.0 * (n - j0) * (double)(n - j0), 0.0);
+            SELLA_LAUNCH(c, trd_tail_lds_kernel, dim3(1), dim3(1024), 0, W.A, ld, n, j0, dvec, evec, taus);
+            prof_end(c);
+            HIPCHK(hipGetLastError());
+            return SELLA_OK;
+        }
         // one decision per panel: the symmetric-aware matvec reads the upper triangle, the streaming one the full block
         const bool panel_symv = symv_min > 0 && n - j0 - 1 >= symv_min;
         for (int i = 0; i <= kb; ++i) {
@@ -2648,10 +2754,14 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     const int nblk = nrefl > 0 ? (nrefl + wynb - 1) / wynb : 0;
     double* Gd = nullptr;                                // nblk x nb x nb: Gram matrices, then C = T^T
     if ((hV || hVt) && nblk > 0) {
-        SCHK(scratch_get(c, SCR_EIG6, (size_t)nblk * wynb * wynb * sizeof(double), &Gd));
+        // 64-blocks: the Gram matrix of a block in `gsl` column slices (one workgroup per block would leave most of the
+        // chip idle: 48 blocks at n = 3072, 1.27 ms), partial matrices behind the C array
+        const int gsl = wy64 ? std::max(1, std::min(8, (256 + nblk - 1) / nblk)) : 0;
+        SCHK(scratch_get(c, SCR_EIG6, (size_t)nblk * (1 + gsl) * wynb * wynb * sizeof(double), &Gd));
         if (wy64) {
-            hipLaunchKernelGGL(wy_gram64_kernel, dim3(nblk), dim3(256), 0, c->stream, W.A, ld, n, nrefl, taus, Gd);
-            hipLaunchKernelGGL(wy_tinv64_kernel, dim3(nblk), dim3(64), 0, c->stream, Gd, nrefl, taus);
+            double* Gpart = Gd + (size_t)nblk * wynb * wynb;
+            hipLaunchKernelGGL(wy_gram64_kernel, dim3(nblk, gsl), dim3(256), 0, c->stream, W.A, ld, n, nrefl, taus, Gpart);
+            hipLaunchKernelGGL(wy_tinv64_kernel, dim3(nblk), dim3(64), 0, c->stream, Gd, Gpart, gsl, nrefl, taus);
         } else {
             hipLaunchKernelGGL(wy_gram_kernel, dim3(nblk), dim3(256), 0, c->stream, W.A, ld, n, nrefl, taus, Gd);
             hipLaunchKernelGGL(wy_tinv_kernel, dim3(nblk), dim3(64), 0, c->stream, Gd, nrefl, taus);

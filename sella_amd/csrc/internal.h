@@ -89,7 +89,7 @@ struct Options {
     long gemm_mfma = 1;      // 1: MFMA f64 16x16x4 GEMM tiles, 0: VALU register tiles
     long host_scalars = 0;   // 1: host-consumed scalars are written straight into pinned host memory (measured: no gain)
     long gemm_tile128 = 1;   // 1: 128x128 double-buffered tiles for large NN/TN products
-    long eigh_leaf = 32;     // leaf size of the divide-and-conquer tree
+    long eigh_leaf = 16;     // leaf size of the divide-and-conquer tree (16: 39.7 ms per eigh at n = 3072, 32: 40.2, 64: 41.5)
     long eigh_symv_tri = 1;      // ... and the trailing update then writes the upper triangle only (mirrored once, when the
                                  // trailing block drops below eigh_symv_min)
     long eigh_symv_tr = 64;      // rows per tile of that matvec (64 or 128)
@@ -99,7 +99,10 @@ struct Options {
     long panel_mfma = 1;     // 1: products with more than 8 right-hand sides stream the matrix once (MFMA panel kernel)
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
-    long eigh_wy_nb64_min = 4096; // 64 instead of 32 reflectors per block of the back-transformation from this many rows on (0: never)
+    long dav_fuse_scale = 1;     // Davidson chain: (d - theta)^-1 scaling in the epilogue of the residual kernel (0: own kernel)
+    long dav_zero_copy = 0;      // ... its coefficients read from pinned host memory instead of a copy launch (measured equal or slower)
+    long eigh_tail_lds = 128;    // trailing blocks of at most this many rows (<= 128) are tridiagonalised by one workgroup in LDS (0: never)
+    long eigh_wy_nb64_min = 2560; // 64 instead of 32 reflectors per block of the back-transformation from this many rows on (0: never)
     long eigh_wy_rows = 16;  // rows of X per workgroup of the MFMA back-transformation (16, or 32: two row tiles)
     long eigh_wy_waves = 4;  // wavefronts per workgroup of the MFMA back-transformation (4, 8 or 16: measured equal at n = 3072 and 12288 — the kernel is bound by L2 bandwidth, 22.7 GB in 3.16 ms, not by latency)
     long lr_cholqr = 1;      // 1: block of update vectors orthonormalised by Cholesky-QR twice (eigh.hip, lr_lowrank_update)

@@ -45,7 +45,7 @@ def test_small_sizes(ctx):
         for n in (1, 2, 3, 5, 17, 33, 70):
             A = rng.normal(size=(n, n))
             check(ctx, A + A.T)
-    ctx.set_option('eigh_leaf', 32)
+    ctx.set_option('eigh_leaf', 16)
 
 
 def test_panel_widths_and_variants(ctx):
@@ -82,7 +82,7 @@ def test_panel_widths_and_variants(ctx):
         ctx.set_option('eigh_wy_mfma', 1)
         ctx.set_option('eigh_wy_rows', 16)
         ctx.set_option('eigh_wy_waves', 4)
-        ctx.set_option('eigh_wy_nb64_min', 4096)
+        ctx.set_option('eigh_wy_nb64_min', 2560)
 
 
 def test_symmetric_aware_trailing_matvec(ctx):
@@ -128,10 +128,10 @@ def test_symmetric_aware_trailing_matvec(ctx):
 def test_spectra(ctx):
     rng = np.random.RandomState(1)
     n = 72 if ctx.backend == 'emu' else 700
-    ctx.set_option('eigh_leaf', 8 if ctx.backend == 'emu' else 32)
+    ctx.set_option('eigh_leaf', 8 if ctx.backend == 'emu' else 16)
     for name, A in cases(n, rng):
         check(ctx, A)
-    ctx.set_option('eigh_leaf', 32)
+    ctx.set_option('eigh_leaf', 16)
 
 
 def _rank1_check(ctx, D, w, rho, tol=2e-14):

@@ -24,6 +24,8 @@ if os.environ.get('EIGH_SYMV_TR'):
     ctx.set_option('eigh_symv_tr', int(os.environ['EIGH_SYMV_TR']))
 if os.environ.get('EIGH_WY64_MIN'):
     ctx.set_option('eigh_wy_nb64_min', int(os.environ['EIGH_WY64_MIN']))
+if os.environ.get('EIGH_TAIL_LDS'):
+    ctx.set_option('eigh_tail_lds', int(os.environ['EIGH_TAIL_LDS']))
 if os.environ.get('EIGH_LEAF'):
     ctx.set_option('eigh_leaf', int(os.environ['EIGH_LEAF']))
 rng = np.random.RandomState(0)

@@ -88,7 +88,7 @@ SELLA_DEBUG_TIMING=1 timeout 300 python tools/emt_slab_opt.py > $OUT/emt.log 2> 
 grep "update_H" $OUT/emt_timing.log | tail -2 | tee -a $OUT/session.log
 say "== eigensolver at 3N = 6144 / 8192 / 12288: defaults, then symmetric-aware matvec and 64-reflector blocks off"
 { for n in 6144 8192 12288; do
-    echo "n = $n, defaults (eigh_symv_min 5120, eigh_wy_nb64_min 4096)"; timeout 300 python tools/eigh_only.py $n 3 2>&1 | tail -2
+    echo "n = $n, defaults (eigh_symv_min 5120, eigh_wy_nb64_min 2560)"; timeout 300 python tools/eigh_only.py $n 3 2>&1 | tail -2
     echo "n = $n, eigh_symv_min 0, eigh_wy_nb64_min 0 (streaming matvec over the full block, 32-reflector blocks)"; EIGH_SYMV_MIN=0 EIGH_WY64_MIN=0 timeout 300 python tools/eigh_only.py $n 3 2>&1 | tail -2
   done; } > $OUT/eigh_large.log 2>&1; cat $OUT/eigh_large.log | tee -a $OUT/session.log
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_eigh12288 -o eigh12288 -- python $R/tools/eigh_only.py 12288 1 > $R/$OUT/rocprof_eigh12288.log 2>&1); say "rocprof eigh 12288 exit $?"

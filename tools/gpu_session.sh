@@ -74,7 +74,7 @@ python tools/mfma_util.py $DBM panel16_mfma_kernel 4831838208 > $OUT/pmc_mfma.tx
 rm -rf $OUT/pmc_mfma_panel
 (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc_mfma_eigh -o pmc -- python $R/tools/eigh_only.py 3072 1 > $R/$OUT/pmc_mfma_eigh.log 2>&1); say "pmc mfma eigh exit $?"
 DBM=$(find $OUT/pmc_mfma_eigh -name "*.db" | head -1)
-python tools/mfma_util.py $DBM wy_apply_mfma_kernel 57982058496 >> $OUT/pmc_mfma.txt 2>&1
+python tools/mfma_util.py $DBM wy_apply_mfma 57982058496 >> $OUT/pmc_mfma.txt 2>&1
 python tools/mfma_util.py $DBM gemm128_merge_batched_kernel >> $OUT/pmc_mfma.txt 2>&1
 python tools/mfma_util.py $DBM rank2k_stream_fixed_kernel >> $OUT/pmc_mfma.txt 2>&1
 rm -rf $OUT/pmc_mfma_eigh
@@ -94,7 +94,7 @@ say "== eigensolver at 3N = 6144 / 8192 / 12288: defaults, then symmetric-aware 
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_eigh12288 -o eigh12288 -- python $R/tools/eigh_only.py 12288 1 > $R/$OUT/rocprof_eigh12288.log 2>&1); say "rocprof eigh 12288 exit $?"
 db=$(find $OUT/prof_eigh12288 -name "*.db" | head -1)
 python tools/rocprof_summary.py $db $OUT/eigh12288_kernel_stats.md "tools/eigh_only.py 12288 1 (rocprofv3 --kernel-trace --stats)" > /dev/null
-python tools/trd_by_m.py $db 1024 > $OUT/eigh12288_by_m.txt 2>&1; head -14 $OUT/eigh12288_kernel_stats.md | tee -a $OUT/session.log; cat $OUT/eigh12288_by_m.txt | tee -a $OUT/session.log
+python tools/trd_by_m.py $db 1024 12288 > $OUT/eigh12288_by_m.txt 2>&1; head -14 $OUT/eigh12288_kernel_stats.md | tee -a $OUT/session.log; cat $OUT/eigh12288_by_m.txt | tee -a $OUT/session.log
 rm -rf $OUT/prof_eigh12288
 say "== configs[2]: internal coordinates / geodesic at 1024 atoms"
 timeout 600 python tools/geodesic_bench.py --steps 3 --sella-steps 2 > $OUT/geodesic.log 2>&1; say "geodesic exit $?"

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Per-column kernel durations of the tridiagonalisation out of a rocprofv3 kernel trace (rocpd sqlite), binned by the
 size m of the trailing block: the k-th matvec of a factorisation works on m = n - 1 - k rows.  Only the first eigh of
-the trace is used.  Usage: tools/trd_by_m.py <results.db> [bin]"""
+the trace is used.  Usage: tools/trd_by_m.py <results.db> [bin] [n]   (n: the matrix size; needed when the last columns
+run inside trd_tail_lds_kernel and have no matvec launch of their own)"""
 import sqlite3
 import sys
 
 
-def main(db_path, width=256):
+def main(db_path, width=256, n_given=0):
     cur = sqlite3.connect(db_path).cursor()
     rows = cur.execute('select name, start, duration from kernels order by start').fetchall()
     kinds = {'trd_gemv_kernel': 'gemv', 'trd_symv_kernel': 'symv', 'trd_symv_finish_kernel': 'finish', 'trd_row_kernel': 'row'}
@@ -20,7 +21,7 @@ def main(db_path, width=256):
         if kind in ('gemv', 'symv'):
             ncol += 1
         seq.append((kind, ncol, dur))
-    n = ncol + 2
+    n = n_given if n_given else ncol + 2
     bins = {}
     for kind, k, dur in seq:
         m = n - 1 - max(k, 1)
@@ -44,4 +45,4 @@ def main(db_path, width=256):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 256)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 256, int(sys.argv[3]) if len(sys.argv) > 3 else 0)

@@ -411,7 +411,7 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     } else if (!strcmp(key, "panel_mfma")) {
         c->opt.panel_mfma = value ? 1 : 0;
     } else if (!strcmp(key, "panel_rows")) {
-        if (value != 0 && value != 16 && value != 32) { set_error("panel_rows must be 0, 16 or 32"); return SELLA_E_INVALID; }
+        if (value != 0 && value != 16 && value != 32 && value != 48 && value != 64) { set_error("panel_rows must be 0, 16, 32, 48 or 64"); return SELLA_E_INVALID; }
         c->opt.panel_rows = value;
     } else if (!strcmp(key, "eigh_wy_mfma")) {
         c->opt.eigh_wy_mfma = value ? 1 : 0;

@@ -302,10 +302,8 @@ struct TrdSymvArgs {
 };
 
 template <int SYMV_TR>
-__global__ __launch_bounds__(256) void trd_symv_kernel(TrdSymvArgs a) {
-    __shared__ double colred[4][SYMV_TC];
-    __shared__ double rowres[SYMV_TR];
-    const int J = blockIdx.x, I = blockIdx.y;
+__device__ __forceinline__ void trd_symv_tile(const TrdSymvArgs& a, int I, int J, int NI, int NJ,
+                                              double (*colred)[SYMV_TC], double* rowres) {
     const int r0 = I * SYMV_TR, c0 = J * SYMV_TC;
     if (r0 + SYMV_TR - 1 < a.o || c0 + SYMV_TC - 1 < r0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -363,7 +361,6 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(TrdSymvArgs a) {
     // partial sums are stored by blocks of 64 entries, all partial rows of a block next to each other: the finish kernel
     // streams one contiguous region per block (rows of a plain [tile][entry] array are n * 8 bytes apart — one DRAM page
     // and, for n a multiple of a large power of two, one channel each; measured 0.85 TB/s)
-    const int NI = gridDim.y, NJ = gridDim.x;
     if (c0 + t < a.n) {
         const int cabs = c0 + t;
         a.Pcol[((size_t)(cabs >> 6) * NI + I) * 64 + (cabs & 63)] = (colred[0][t] + colred[1][t]) + (colred[2][t] + colred[3][t]);
@@ -372,6 +369,15 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(TrdSymvArgs a) {
         const int rabs = r0 + t;
         a.Prow[((size_t)(rabs >> 6) * NJ + J) * 64 + (rabs & 63)] = rowres[t];
     }
+}
+
+// one workgroup per tile of the absolute grid (NJ, NI).  (A fixed number of workgroups walking the tiles round-robin —
+// 256 ... 2048 of them — was measured equal at best: 942 ms per eigh at n = 12288 either way, 1050 with 256.)
+template <int SYMV_TR>
+__global__ __launch_bounds__(256) void trd_symv_kernel(TrdSymvArgs a) {
+    __shared__ double colred[4][SYMV_TC];
+    __shared__ double rowres[SYMV_TR];
+    trd_symv_tile<SYMV_TR>(a, blockIdx.y, blockIdx.x, gridDim.y, gridDim.x, colred, rowres);
 }
 
 struct TrdSymvFinishArgs {

@@ -97,7 +97,7 @@ struct Options {
                                  // tridiagonalisation (upper triangle only, eigh.hip); 0: never
     long eigh_nb = 16;       // panel width of the blocked tridiagonalisation (tools/eigh_tune.py)
     long panel_mfma = 1;     // 1: products with more than 8 right-hand sides stream the matrix once (MFMA panel kernel)
-    long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, or 0 = by size
+    long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, 48, 64, or 0 = by size (one workgroup per CU)
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
     long dav_fuse_scale = 1;     // Davidson chain: (d - theta)^-1 scaling in the epilogue of the residual kernel (0: own kernel)
     long dav_zero_copy = 0;      // ... its coefficients read from pinned host memory instead of a copy launch (measured equal or slower)

@@ -909,7 +909,7 @@ int launch_gemm_merge_batched(sella_ctx* c, int nbatch, const int* desc, int max
 // straight from global memory as 32-byte vectors: lane (i, g) takes columns 4g..4g+3 of a 16-column
 // group for four successive v_mfma_f64_16x16x4_f64 (the summation index may be permuted freely).
 // ------------------------------------------------------------------------------------
-template <int RT>   // RT = 1: 16 rows per workgroup, RT = 2: 32 rows (halves the re-reads of X from L2)
+template <int RT>   // 16 RT rows per workgroup (RT = 1 .. 4, chosen by the launcher so that there are about 256 workgroups)
 __global__ __launch_bounds__(256) void panel16_mfma_kernel(const double* __restrict__ A, int rows, int ld,
                                                            const double* __restrict__ Xp, int nrhs,
                                                            double* __restrict__ Y, int ldy) {
@@ -1053,10 +1053,20 @@ int launch_panel16(sella_ctx* c, const double* A, int rows, int cols, int lda, c
         return SELLA_E_INVALID;
     }
     prof_begin(c, PROF_GEMV, 8.0 * rows * (double)cols, 2.0 * rows * (double)cols * nrhs);
-    // 16-row workgroups measured equal (n = 12288) or faster (n = 3072) than 32-row ones: tools/panel_bench.py
+    // Rows per workgroup by size: the kernel is fastest with ONE workgroup per CU (256 of them) — n = 12288: 48 rows
+    // 210 us = 5.76 TB/s against 281 (16 rows, 768 workgroups) and 286 (32 rows, 384); n = 8192: 32 rows 106 us against 130
+    // (16) and 128 (48); n = 3072: 16 rows (192 workgroups) 26 us against 36 (32): tools/panel_bench.py.  A variant that
+    // staged the matrix chunk through LDS to fetch whole rows per wavefront was built and measured slower (383 us).
     long rt = c->opt.panel_rows;
-    if (rt == 0) rt = 16;
-    if (rt == 32)
+    if (rt == 0) {
+        const int per = (rows + 4095) / 4096;
+        rt = 16 * (per < 1 ? 1 : (per > 4 ? 4 : per));
+    }
+    if (rt == 48)
+        SELLA_LAUNCH(c, HIP_KERNEL_NAME(panel16_mfma_kernel<3>), dim3((rows + 47) / 48), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
+    else if (rt == 64)
+        SELLA_LAUNCH(c, HIP_KERNEL_NAME(panel16_mfma_kernel<4>), dim3((rows + 63) / 64), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
+    else if (rt == 32)
         SELLA_LAUNCH(c, HIP_KERNEL_NAME(panel16_mfma_kernel<2>), dim3((rows + 31) / 32), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
     else
         SELLA_LAUNCH(c, HIP_KERNEL_NAME(panel16_mfma_kernel<1>), dim3((rows + 15) / 16), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);

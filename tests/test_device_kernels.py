@@ -117,7 +117,8 @@ def test_block_panel_product(ctx):
     """More than 8 right-hand sides go through the MFMA panel kernel (matrix streamed once per 16
     vectors); same results as the row-panel matvec path and as NumPy, for ragged shapes."""
     rng = np.random.RandomState(21)
-    shapes = [(40, 40, 9), (70, 53, 16), (33, 90, 17), (5, 12, 33), (130, 64, 12)]
+    shapes = [(40, 40, 9), (70, 53, 16), (33, 90, 17), (5, 12, 33), (130, 64, 12),
+              (100, 300, 16)]
     if ctx.backend == 'hip':
         shapes += [(3072, 3072, 16), (1537, 2049, 24)]
     for rows, cols, k in shapes:
@@ -133,4 +134,8 @@ def test_block_panel_product(ctx):
         ctx.set_option('panel_mfma', 1)
         np.testing.assert_allclose(Y1, ref, atol=tol, rtol=0)
         np.testing.assert_allclose(Y0, ref, atol=tol, rtol=0)
+        for rows_per_wg in (32, 48, 64):                          # the launcher picks by size; every variant here
+            ctx.set_option('panel_rows', rows_per_wg)
+            np.testing.assert_allclose(ctx.symm_mm(dA, X), ref, atol=tol, rtol=0)
+        ctx.set_option('panel_rows', 0)
         dA.free()

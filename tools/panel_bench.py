@@ -18,7 +18,7 @@ H = rng.normal(size=(n, n))
 X = rng.normal(size=(n, k))
 dH = ctx.upload(H)
 ref = H[:64] @ X
-for mode, prow in ((1, 16), (1, 32), (0, 0)):
+for mode, prow in ((1, 0), (1, 16), (1, 32), (1, 48), (1, 64), (0, 0)):
     ctx.set_option('panel_mfma', mode)
     ctx.set_option('panel_rows', prow)
     Y = ctx.symm_mm(dH, X)
@@ -30,7 +30,7 @@ for mode, prow in ((1, 16), (1, 32), (0, 0)):
     ctx.prof_enable(False)
     p = ctx.prof_get(0)
     us = 1e3 * p['ms'] / 10
-    print(json.dumps(dict(op='H.V block product', n=n, k=k, kernel=f'panel16_mfma<{prow} rows>' if mode else 'gemv_rows x2',
+    print(json.dumps(dict(op='H.V block product', n=n, k=k, kernel=(f'panel16_mfma<{prow} rows>' if prow else 'panel16_mfma<rows by size>') if mode else 'gemv_rows x2',
                           launches_per_product=p['launches'] / 10, us_per_product=round(us, 1),
                           matrix_GBps=round(8.0 * n * n / (us * 1e-6) / 1e9, 1),
                           tflops=round(2.0 * n * n * k / (us * 1e-6) / 1e12, 2), max_err=err)), flush=True)

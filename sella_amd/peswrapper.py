@@ -107,61 +107,60 @@ class PES:
     def __init__(self, atoms, H0=None, constraints=None, eigensolver='jd0', trajectory=None,
                  eta=1e-4, v0=None, proj_trans=None, proj_rot=None, hessian_function=None):
         self.atoms = atoms
-        if constraints is None:
-            constraints = Constraints(self.atoms)
-        if proj_trans is None:
-            proj_trans = not constraints.internals['translations']
-        if proj_trans:
-            try:
-                constraints.fix_translation(replace_ok=False)
-            except DuplicateInternalError:
-                pass
-        if proj_rot is None:
-            proj_rot = not np.any(atoms.pbc)
-        if proj_rot and not constraints.internals['rotations']:
-            # peswrapper.py:244-253: non-periodic systems get a global rotation constraint.  Here it is the
-            # linearised form (infinitesimal rotation generators about the centroid, internal.py Constraints.fix_rotation):
-            # the three rotational soft modes leave the Davidson / P-RFO subspace exactly as in the reference.
-            constraints.fix_rotation()
-        self.cons = constraints
-        self.eigensolver = eigensolver
-        if isinstance(trajectory, str):
-            trajectory = open_trajectory(trajectory, atoms)
-        self.traj = trajectory
-        self.eta = eta
-        self.v0 = v0
-        self.neval = 0
-        self.curr = dict(x=None, f=None, g=None)
-        self.last = self.curr.copy()
-        self.int = None
-        self.dummies = None
-        self.dim = 3 * len(atoms)
-        self.ncart = self.dim
-        if H0 is None:
-            self.set_H(None, initialized=False)
-        else:
-            self.set_H(H0, initialized=True)
-        self.savepoint = dict(apos=None, dpos=None)
-        self.first_diag = True
+        self.cons = self._constraint_set(atoms, constraints, proj_trans, proj_rot)
+        self.eigensolver, self.eta, self.v0 = eigensolver, eta, v0
         self.hessian_function = hessian_function
+        self.traj = open_trajectory(trajectory, atoms) if isinstance(trajectory, str) else trajectory
+        # coordinate system: Cartesian here (subclasses set `int` / `dummies` and the sizes themselves)
+        self.int = self.dummies = None
+        self.dim = self.ncart = 3 * len(atoms)
+        # the cached point and its predecessor (plain dicts: the IRC driver swaps them in and out), counters
+        self.curr = dict.fromkeys(('x', 'f', 'g'))
+        self.last = dict(self.curr)
+        self.savepoint = dict.fromkeys(('apos', 'dpos'))
+        self.neval = 0
+        self.first_diag = True
         self._basis_cache = _LRU2()
+        self.set_H(H0, initialized=H0 is not None)
+
+    @staticmethod
+    def _constraint_set(atoms, constraints, proj_trans, proj_rot):
+        """The constraints a search runs under (peswrapper.py:226-253): the user's, plus — unless they already say
+        something about it or the caller decides otherwise — a fixed centre of the system and, for non-periodic
+        systems, fixed global rotations.  The rotation constraint is the LINEARISED one (infinitesimal generators about
+        the centroid, internal.py Constraints.fix_rotation): the three rotational soft modes leave the Davidson / P-RFO
+        subspace exactly as in the reference."""
+        cons = Constraints(atoms) if constraints is None else constraints
+        want_trans = (not cons.internals['translations']) if proj_trans is None else proj_trans
+        want_rot = (not np.any(atoms.pbc)) if proj_rot is None else proj_rot
+        if want_trans:
+            try:
+                cons.fix_translation(replace_ok=False)
+            except DuplicateInternalError:
+                pass                                             # some component is pinned already
+        if want_rot and not cons.internals['rotations']:
+            cons.fix_rotation()
+        return cons
 
     apos = property(lambda self: self.atoms.positions.copy())
     dpos = property(lambda self: None)
 
     def _state_hash(self):
-        h = np.ascontiguousarray(self.atoms.positions).tobytes()
+        """Key of everything cached per geometry: the bytes of the positions and, if there is one, of the cell."""
+        parts = [np.ascontiguousarray(self.atoms.positions).tobytes()]
         cell = np.asarray(self.atoms.cell, dtype=float)
         if cell.any():
-            h += cell.tobytes()
-        return h
+            parts.append(cell.tobytes())
+        return b''.join(parts)
 
     def save(self):
-        self.savepoint = dict(apos=self.apos, dpos=self.dpos)
+        self.savepoint = {'apos': self.apos, 'dpos': self.dpos}
 
     def restore(self):
-        assert self.savepoint['apos'] is not None
-        self.atoms.positions = self.savepoint['apos']
+        kept = self.savepoint['apos']
+        if kept is None:
+            raise AssertionError('PES.restore() without a saved geometry')
+        self.atoms.positions = kept
 
     def close(self):
         if self.traj is not None:
@@ -193,12 +192,15 @@ class PES:
         self.H = ApproximateHessian(self.dim, self.ncart, target, *args, **kwargs)
 
     def get_Hc(self):
-        if self.curr.get('L') is None:
+        """Constraint curvature contracted with the multipliers, sum_k L_k d2 r_k / dx2."""
+        multipliers = self.curr.get('L')
+        if multipliers is None:
             raise RuntimeError("PES.get_Hc() called with L=None.")
-        return self.cons.hessian().ldot(self.curr['L'])
+        return self.cons.hessian().ldot(multipliers)
 
     def get_HL(self):
-        return self.get_H() + (-self.get_Hc())
+        """Hessian of the Lagrangian as a lazy sum (linalg.MatrixSum semantics)."""
+        return self.H + (-self.get_Hc())
 
     def _has_curved_constraints(self):
         c = self.cons
@@ -364,42 +366,41 @@ class PES:
             return
         self.H.update(dx, dg)
 
-    def get_f(self):
-        self._update()
-        return self.curr['f']
+    def _point_getter(name, needs_energy, copy=False):      # noqa: N805 — class-body helper, not a method
+        """Accessor of one entry of the cached point: bring the cache up to date (with or without a force call), hand
+        the entry out (a copy where callers modify what they get)."""
+        def getter(self):
+            self._update(needs_energy)
+            value = self.curr[name]
+            return value.copy() if copy else value
+        getter.__name__ = 'get_' + name
+        return getter
 
-    def get_g(self):
-        self._update()
-        return self.curr['g'].copy()
-
-    def get_Unred(self):
-        self._update(False)
-        return self.curr['Unred']
-
-    def get_Ufree(self):
-        self._update(False)
-        return self.curr['Ufree']
-
-    def get_Ucons(self):
-        self._update(False)
-        return self.curr['Ucons']
+    get_f = _point_getter('f', True)
+    get_g = _point_getter('g', True, copy=True)
+    get_Unred = _point_getter('Unred', False)
+    get_Ufree = _point_getter('Ufree', False)
+    get_Ucons = _point_getter('Ucons', False)
+    del _point_getter
 
     # ---- iterative diagonalisation (peswrapper.py:508-556) ----------------------------------------
     def diag(self, gamma=0.1, threepoint=False, maxiter=None):
-        if self.curr['f'] is None:
-            self._update(feval=True)
+        self._update(True)                                  # energy and gradient of the point the operator is built at
         Ufree = self.get_Ufree()
-        nfree = Ufree.shape[1]
-        if nfree == 0:
+        if Ufree.shape[1] == 0:
             return
         P = self.get_HL_projected(Ufree)
         P_is_none = P._is_none
+        # start vector (peswrapper.py:521-529): only while there is no curvature information to start from — the user's
+        # v0, else the projected gradient, unless that vanishes
+        v0 = None
         if P_is_none or self.first_diag:
-            v0 = self.v0 if self.v0 is not None else (self.get_g() if is_identity(Ufree) else self.get_g() @ Ufree)
-            if v0 is not None and np.linalg.norm(v0) < 1e-12:
+            v0 = self.v0
+            if v0 is None:
+                g = self.get_g()
+                v0 = g if is_identity(Ufree) else g @ Ufree
+            if np.linalg.norm(v0) < 1e-12:
                 v0 = None
-        else:
-            v0 = None
         Hproj = self._library_fd_operator(Ufree, threepoint)
         if Hproj is None:
             Hproj = NumericalHessian(self._calc_eg, self.get_x(), self.get_g(), self.eta, threepoint, Ufree)
@@ -463,17 +464,18 @@ class PES:
         return -(Ufree @ (Ufree.T @ g)).reshape((-1, 3))
 
     def converged(self, fmax, cmax=1e-5):
-        fmax1 = np.linalg.norm(self.get_projected_forces(), axis=1).max()
-        cmax1 = np.linalg.norm(self.get_res())
-        return (fmax1 < fmax) and (cmax1 < cmax), fmax1, cmax1
+        """(done, largest projected force on an atom, norm of the constraint residual)."""
+        per_atom = self.get_projected_forces()
+        worst_force = np.sqrt(np.einsum('ij,ij->i', per_atom, per_atom).max())
+        violation = np.linalg.norm(self.get_res())
+        return bool(worst_force < fmax and violation < cmax), worst_force, violation
 
     def wrap_dx(self, dx):
         return dx
 
     def get_df_pred(self, dx, g, H):
-        if H is None:
-            return None
-        return g.T @ dx + (dx.T @ (H @ dx)) / 2.
+        """Energy change of the quadratic model along dx (one Hessian-vector product on the device)."""
+        return None if H is None else float(g @ dx + 0.5 * (dx @ (H @ dx)))
 
     # ---- step + update (peswrapper.py:578-602) -------------------------------------------------------
     def kick(self, dx, diag=False, **diag_kwargs):

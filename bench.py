@@ -150,6 +150,7 @@ def main():
                     help='worker processes per GPU for the ensemble leg (-1: min(members, 4, CPUs of this rank); 0/1: none)')
     ap.add_argument('--block-n', type=int, default=12288, help='configs[4] leg: operator size (0 disables)')
     ap.add_argument('--block-iters', type=int, default=12)
+    ap.add_argument('--block-eigh', type=int, default=1, help='time the full device eigh of the block operator at N = 1 (0: skip)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -593,6 +594,21 @@ def main():
             tfl = 2.0 * (hi_ - lo_) * nb_ * 16 / max(1e-12, pp['ms'] * 1e-3 / pp['launches']) / 1e12
             block_stats.update(panel_pass_tflops=round(tfl, 2), panel_pass_mfma_frac=round(tfl / 78.6, 3),
                                panel_pass_hbm_frac=round(block_stats['panel_pass_gbs'] / HBM_PEAK_GBS, 3))
+        if world == 1 and args.block_eigh:
+            # the `exact` diagonalisation configs[4] needs once per call with an eigenbasis preconditioner
+            # (sella/eigensolvers.py:9-28): device eigh of the resident 3N x 3N operator, second call timed
+            try:
+                for rep in range(2):
+                    te0 = time.perf_counter()
+                    w_, V_, Vt_ = ctx.eigh(op.dH)
+                    ctx.sync()
+                    t_e = time.perf_counter() - te0
+                    V_.free()
+                    Vt_.free()
+                block_stats['eigh_exact_ms'] = round(1e3 * t_e, 1)
+                block_stats['eigh_exact_lowest'] = float(w_[0])
+            except Exception as e:                               # noqa: BLE001 — the figure is optional, the line is not
+                block_stats['eigh_exact_note'] = str(e)[:120]
         _dev2._default = None
 
     times = [elapsed]

@@ -55,7 +55,7 @@ def bench(out_path):
     import bench as bench_mod
     os.environ['SELLA_BENCH_COMM'] = 'gloo'
     sys.argv = ['bench.py', '--gpus', os.environ['WORLD_SIZE'], '--steps', '2', '--warmup', '1', '--n', '36', '--option', 'eigh_tail_lds=0',
-                '--maxiter', '8', '--seeds', '2', '--converged-n', '0', '--emt-steps', '0', '--no-cpu-baseline', '--opt-steps', '2', '--ensemble-per-gpu', '2', '--ensemble-n', '12', '--ensemble-steps', '2', '--block-n', '70', '--block-iters', '3']
+                '--maxiter', '8', '--seeds', '2', '--converged-n', '0', '--emt-steps', '0', '--no-cpu-baseline', '--opt-steps', '2', '--ensemble-per-gpu', '2', '--ensemble-n', '12', '--ensemble-steps', '2', '--block-n', '70', '--block-iters', '3', '--block-eigh', '0']
     buf = io.StringIO()
     with redirect_stdout(buf):
         bench_mod.main()

@@ -53,7 +53,7 @@ int sella_ctx_destroy(sella_ctx* ctx);
 int sella_ctx_sync(sella_ctx* ctx);
 int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
 /* integer tuning knobs (kernel variant selection for benchmarking); unknown key -> error.  Keys (defaults):
- *   gemv_rw (2) rows per wavefront of the streaming matvec | gemm_mfma (1) GEMMs on the matrix cores |
+ *   gemv_rw (0 = by size) rows per workgroup of the streaming matvec | gemm_mfma (1) GEMMs on the matrix cores |
  *   gemm_tile128 (1) 128x128 GEMM tiles for large products | panel_mfma (1), panel_rows (0 = by size) the
  *   H.V block product | host_scalars (0) zero-copy scalars | rank2k_stream (1) mirror-free trailing update |
  *   eigh_nb (16) panel width, eigh_leaf (16) leaf size, eigh_wy_mfma (1) MFMA back-transformation |

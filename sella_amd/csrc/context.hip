@@ -384,7 +384,7 @@ int sella_ctx_device_name(sella_ctx* c, char* buf, int buflen) {
 int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     if (!c || !key) return SELLA_E_INVALID;
     if (!strcmp(key, "gemv_rw")) {
-        if (value != 1 && value != 2 && value != 4) { set_error("gemv_rw must be 1, 2 or 4"); return SELLA_E_INVALID; }
+        if (value != 0 && value != 1 && value != 2 && value != 4) { set_error("gemv_rw must be 0, 1, 2 or 4"); return SELLA_E_INVALID; }
         c->opt.gemv_rw = value;
     } else if (!strcmp(key, "gemm_mfma")) c->opt.gemm_mfma = value ? 1 : 0;
     else if (!strcmp(key, "rank2k_stream")) c->opt.rank2k_stream = value ? 1 : 0;

@@ -85,7 +85,7 @@ struct ProfSlot {
 };
 
 struct Options {
-    long gemv_rw = 2;        // rows per wavefront in the row-panel matvec (1, 2 or 4)
+    long gemv_rw = 0;        // rows per workgroup in the row-panel matvec (1, 2, 4; 0 = by size: 4 from 4096 rows on, else 2)
     long gemm_mfma = 1;      // 1: MFMA f64 16x16x4 GEMM tiles, 0: VALU register tiles
     long host_scalars = 0;   // 1: host-consumed scalars are written straight into pinned host memory (measured: no gain)
     long gemm_tile128 = 1;   // 1: 128x128 double-buffered tiles for large NN/TN products

@@ -132,6 +132,9 @@ int launch_gemv_rows_xp(sella_ctx* c, const double* A, int rows, int cols, int l
         return SELLA_E_INVALID;
     }
     int rw = (int)c->opt.gemv_rw;
+    // 0 = by size: beyond ~4000 rows fewer, fatter workgroups stream faster (n = 6144, 2 right-hand sides: 4 rows per
+    // workgroup 47 us = 6.4 TB/s against 55 us with 2; equal at n = 3072 — tools/lab/gemv_rw.py)
+    if (rw == 0) rw = rows >= 4096 ? 4 : 2;
     // few rows (panel dots, small matrices): one row per workgroup keeps more of the chip busy
     if (rows < 1024) rw = 1;
     // 8 right-hand sides x 4 rows would need 64 accumulators per lane

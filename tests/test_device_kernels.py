@@ -24,7 +24,7 @@ def test_symm_mm(ctx):
         np.testing.assert_array_equal(dA.numpy(), A)
         np.testing.assert_array_equal(dA.transpose().numpy(), A.T)
         dA.free()
-    ctx.set_option('gemv_rw', 2)
+    ctx.set_option('gemv_rw', 0)
 
 
 def test_rectangular_and_transposed_products(ctx):

@@ -49,7 +49,7 @@ for n in sizes:
             us = 1e3 * p['ms'] / p['launches']
             print(json.dumps(dict(op='gemv_rows', n=n, nrhs=k, rw=rw, us=round(us, 2),
                                   GBs=round(8.0 * n * n / us / 1e3, 1))), flush=True)
-    ctx.set_option('gemv_rw', 2)
+    ctx.set_option('gemv_rw', 0)
     X = rng.normal(size=(n, 2))
     t = timeit(lambda: ctx.tmatmul(dA, X), reps=10)
     print(json.dumps(dict(op='gemv_cols(host-inclusive)', n=n, nrhs=2, us=round(1e6 * t, 1))), flush=True)

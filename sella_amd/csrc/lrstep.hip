@@ -187,32 +187,54 @@ __global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) {
 #pragma clang fp contract(off)
 #endif
     __shared__ double red[4];
-    __shared__ double sD[LR_DEV_MAX], sZ[LR_DEV_MAX], sP[LR_DEV_MAX], sCS[2 * LR_DEV_MAX];
+    __shared__ double sD[LR_DEV_MAX], sZ[LR_DEV_MAX], sP[LR_DEV_MAX], sCS[2 * LR_DEV_MAX], sZs[LR_DEV_MAX];
     __shared__ int sPerm[LR_DEV_MAX], sNd[LR_DEV_MAX], sDf[LR_DEV_MAX], sI1[LR_DEV_MAX], sI2[LR_DEV_MAX];
     __shared__ int sK, sRot, sNdf;
+    __shared__ double sZq[4][64];
     const int tid = threadIdx.x, nr = a.nr;
     const double sigma = a.sigma[0];
-    for (int i = tid; i < nr; i += 256) sP[i] = a.p[i];
+    for (int i = tid; i < nr; i += 256) { sP[i] = a.p[i]; sD[i] = a.Dcur[i]; }     // both vectors in flight together
     __syncthreads();
     double pz = 0.0;
-    for (int i = tid; i < nr; i += 256) {
-        double zi;
-        if (a.first) {
-            zi = sP[i];
-        } else {
-            double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
-            int k = 0;
-            for (; k + 3 < nr; k += 4) {
-                z0 += a.Q[(size_t)k * a.ldq + i] * sP[k];
-                z1 += a.Q[(size_t)(k + 1) * a.ldq + i] * sP[k + 1];
-                z2 += a.Q[(size_t)(k + 2) * a.ldq + i] * sP[k + 2];
-                z3 += a.Q[(size_t)(k + 3) * a.ldq + i] * sP[k + 3];
-            }
-            for (; k < nr; ++k) z0 += a.Q[(size_t)k * a.ldq + i] * sP[k];
-            zi = (z0 + z1) + (z2 + z3);
+    if (a.first) {
+        for (int i = tid; i < nr; i += 256) {
+            const double zi = sP[i];
+            sZ[i] = zi;
+            pz += zi * zi;
         }
-        sZ[i] = zi;
-        pz += zi * zi;
+    } else {
+        // z = Q^T p: lane -> column i (64 at a time), wavefront w -> the w-th quarter of the summation index, sixteen
+        // loads in flight at a time (a plain loop waits for every load in turn); the quarters meet in LDS in a fixed order
+        const int lane = tid & 63, wave = tid >> 6;
+        const int chunk = (nr + 3) / 4, kb = wave * chunk, ke = (kb + chunk < nr) ? kb + chunk : nr;
+        for (int i0 = 0; i0 < nr; i0 += 64) {
+            const int i = i0 + lane, il = i < nr ? i : nr - 1;
+            double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+            for (int k0 = kb; k0 < ke; k0 += 16) {
+                double qv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int k = k0 + u;
+                    qv[u] = a.Q[(size_t)(k < ke ? k : ke - 1) * a.ldq + il];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u += 4) {
+                    auto term = [&](int v) -> double { const int k = k0 + v; return k < ke ? qv[v] * sP[k] : 0.0; };
+                    z0 += term(u);
+                    z1 += term(u + 1);
+                    z2 += term(u + 2);
+                    z3 += term(u + 3);
+                }
+            }
+            sZq[wave][lane] = (z0 + z1) + (z2 + z3);
+            __syncthreads();
+            if (wave == 0 && i < nr) {
+                const double zi = (sZq[0][lane] + sZq[1][lane]) + (sZq[2][lane] + sZq[3][lane]);
+                sZ[i] = zi;
+                pz += zi * zi;
+            }
+            __syncthreads();
+        }
     }
     const double zn2 = blk_sum(pz, red);
     const double sgn = sigma < 0.0 ? -1.0 : 1.0;
@@ -220,7 +242,7 @@ __global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) {
     const double zn = idle ? 1.0 : sqrt(zn2);
     double dmax = 0.0, zmax = 0.0;
     for (int i = tid; i < nr; i += 256) {
-        const double d = sgn * a.Dcur[i], w = sZ[i] / zn;
+        const double d = sgn * sD[i], w = sZ[i] / zn;
         sD[i] = d;
         sZ[i] = w;
         dmax = fmax(dmax, fabs(d));
@@ -241,42 +263,84 @@ __global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) {
     }
     __syncthreads();
     const double rho = fabs(sigma) * zn2;
-    if (tid == 0) {
+    // the walk below reads poles and weights IN ORDER from sorted copies (sP is free by now: z is formed)
+    double* sDs = sP;                                        // p is consumed (z is formed)
+    for (int jj = tid; jj < nr; jj += 256) { sDs[jj] = sD[sPerm[jj]]; sZs[jj] = sZ[sPerm[jj]]; }
+    __syncthreads();
+    // The usual case needs no walk at all: no negligible weight and no pair of neighbouring poles close enough to rotate
+    // means every pole stays, in order.  Each thread tests its own position against its left neighbour (with nothing
+    // deflated in between the neighbour IS the pending pole of the walk); one block-wide maximum decides.
+    bool plain = false;
+    {
+        const double tol0 = 8.0 * 2.220446049250313e-16 * fmax(dmax, zmax);
+        double flag = (idle || rho * zmax <= tol0) ? 1.0 : 0.0;
+        for (int jj = tid; jj < nr; jj += 256) {
+            const double zj = sZs[jj];
+            if (rho * fabs(zj) <= tol0) flag = 1.0;
+            if (jj > 0) {
+                const double zq = sZs[jj - 1], t = sDs[jj] - sDs[jj - 1];
+                if (fabs(t * zj * zq) <= tol0 * (zj * zj + zq * zq)) flag = 1.0;
+            }
+        }
+        plain = !(blk_max(flag, red) > 0.0);
+        __syncthreads();
+    }
+    if (plain) {
+        for (int jj = tid; jj < nr; jj += 256) sNd[jj] = sPerm[jj];
+        if (tid == 0) {
+            sK = nr; sRot = 0; sNdf = 0;
+            a.cnt[0] = nr;
+            a.cnt[1] = 0;
+            a.pl[0] = rho;
+            a.pl[1] = sgn;
+        }
+    } else if (tid == 0) {
         const double eps = 2.220446049250313e-16;
         const double tol = 8.0 * eps * fmax(dmax, zmax);
         int K = 0, nd = 0, nrot = 0;
         if (idle || rho * zmax <= tol) {
             for (int jj = 0; jj < nr; ++jj) sDf[nd++] = sPerm[jj];
         } else {
-            int pj = -1;
+            // One thread, the poles in ascending order, dlaed2's rules.  The pending pole (position pjj) lives in
+            // registers; the closeness test |t c s| <= tol with c = cc / tau, s = -ss / tau is taken in the form
+            // |t cc ss| <= tol (cc^2 + ss^2), so the common case (distinct poles) costs no square root and no division —
+            // with hypot and two divisions per pole this walk was 25 us at 60 poles, most of a quasi-Newton update.
+            int pjj = -1;
+            double dp = 0.0, zp = 0.0;
             for (int jj = 0; jj < nr; ++jj) {
-                const int nj = sPerm[jj];
-                if (rho * fabs(sZ[nj]) <= tol) { sDf[nd++] = nj; continue; }
-                if (pj < 0) { pj = nj; continue; }
-                double s = sZ[pj], cc = sZ[nj];
-                const double tau = hypot(cc, s);
-                const double t = sD[nj] - sD[pj];
-                cc /= tau;
-                s = -s / tau;
-                if (fabs(t * cc * s) <= tol) {
-                    sZ[nj] = tau;
-                    sZ[pj] = 0.0;
+                const double zj = sZs[jj], dj = sDs[jj];
+                if (rho * fabs(zj) <= tol) { sDf[nd++] = sPerm[jj]; continue; }
+                if (pjj < 0) { pjj = jj; dp = dj; zp = zj; continue; }
+                const double t = dj - dp;
+                if (fabs(t * zj * zp) <= tol * (zj * zj + zp * zp)) {
+                    const double tau = hypot(zj, zp);
+                    const double cc = zj / tau, sn = -zp / tau;
+                    const int pj = sPerm[pjj], nj = sPerm[jj];
                     sI1[nrot] = pj;
                     sI2[nrot] = nj;
                     sCS[2 * nrot] = cc;
-                    sCS[2 * nrot + 1] = s;
+                    sCS[2 * nrot + 1] = sn;
                     ++nrot;
-                    const double tt = sD[pj] * cc * cc + sD[nj] * s * s;
-                    sD[nj] = sD[pj] * s * s + sD[nj] * cc * cc;
-                    sD[pj] = tt;
+                    sD[pj] = dp * cc * cc + dj * sn * sn;
+                    sZ[pj] = 0.0;
                     sDf[nd++] = pj;
-                    pj = nj;
+                    dp = dp * sn * sn + dj * cc * cc;
+                    zp = tau;
+                    pjj = jj;
                 } else {
+                    const int pj = sPerm[pjj];
+                    sD[pj] = dp;
+                    sZ[pj] = zp;
                     sNd[K++] = pj;
-                    pj = nj;
+                    pjj = jj; dp = dj; zp = zj;
                 }
             }
-            if (pj >= 0) sNd[K++] = pj;
+            if (pjj >= 0) {
+                const int pj = sPerm[pjj];
+                sD[pj] = dp;
+                sZ[pj] = zp;
+                sNd[K++] = pj;
+            }
         }
         sK = K;
         sRot = nrot;

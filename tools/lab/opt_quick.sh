@@ -1,0 +1,5 @@
+mkdir -p gpurun_out/symv; cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/symv/profopt -o p -- python /root/repo/tools/opt_profile.py 3072 20 > /root/repo/gpurun_out/symv/profopt.log 2>&1
+cd /root/repo
+db=$(find gpurun_out/symv/profopt -name "*.db" | head -1); python tools/rocprof_summary.py $db gpurun_out/symv/profopt_stats.md "opt" > /dev/null; grep "lr_\|rs_" gpurun_out/symv/profopt_stats.md | cut -c1-120
+rm -rf gpurun_out/symv/profopt

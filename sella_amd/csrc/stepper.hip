@@ -306,21 +306,34 @@ __device__ __forceinline__ void block_sum4_256(double v[4], double (*red)[4]) {
     for (int q = 0; q < 4; ++q) v[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
 }
 
-// shat of one RFO block (rfo_block above, without ds/dalpha) by the whole workgroup
+// shat of one RFO block (rfo_block above, without ds/dalpha).  WAVE = false: by the whole workgroup, the O(m) sums as block
+// reductions (two barriers each).  WAVE = true: by ONE wavefront (the caller lets only wavefront 0 in), the sums as
+// wavefront reductions — a root costs 6-10 evaluations of the secular function, and for the few dozen to few hundred
+// modes of a structured eigendecomposition the barriers were the whole cost (14 us per candidate and block).
+template <bool WAVE>
 __device__ void rfo_block_dev(int mm, const double* __restrict__ lam, const double* __restrict__ gh, int o, double alpha,
                               double* __restrict__ shat, double (*red)[4]) {
     if (mm == 0) return;
-    const int tid = threadIdx.x;
+    const int tid = WAVE ? (threadIdx.x & 63) : threadIdx.x;
+    constexpr int NT = WAVE ? 64 : 256;
+    auto sum4 = [&](double v[4]) {
+        if (WAVE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = wave_sum64(v[q]);
+        } else {
+            block_sum4_256(v, red);
+        }
+    };
     const double a2 = alpha * alpha;
     auto Dat = [&](int i) { return a2 * lam[i]; };
     auto bat = [&](int i) { return alpha * gh[i]; };
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = tid; i < mm; i += 256) { const double b = bat(i); acc[0] += b * b; }
-    block_sum4_256(acc, red);
+    for (int i = tid; i < mm; i += NT) { const double b = bat(i); acc[0] += b * b; }
+    sum4(acc);
     const double bb = acc[0];
     auto eval = [&](double shift, double t) {
         double v[4] = {0.0, 0.0, 0.0, 0.0};                  // s, sum |q|, dl, dr
-        for (int i = tid; i < mm; i += 256) {
+        for (int i = tid; i < mm; i += NT) {
             const double b = bat(i);
             const double r = 1.0 / ((Dat(i) - shift) - t);
             const double q = b * b * r;
@@ -328,7 +341,7 @@ __device__ void rfo_block_dev(int mm, const double* __restrict__ lam, const doub
             v[1] += fabs(q);
             if (i < o) v[2] += q * r; else v[3] += q * r;
         }
-        block_sum4_256(v, red);
+        sum4(v);
         bordered::Ev e;
         e.f = (shift + t) + v[0];
         e.noise = fabs(shift + t) + v[1];
@@ -341,43 +354,62 @@ __device__ void rfo_block_dev(int mm, const double* __restrict__ lam, const doub
     bordered::bordered_root_core(mm, Dat, bat, bb, o, eval, &org, &tau);
     const double shift = org >= 0 ? Dat(org) : 0.0;
     // eigenvector (unnormalised): y_i = b_i / (mu - D_i), eta = 1
-    double w[4] = {0.0, 0.0, 0.0, 0.0};                      // sum y^2, degenerate flag, first degenerate index (as -i)
-    w[2] = -1e300;
-    for (int i = tid; i < mm; i += 256) {
+    double w[4] = {0.0, 0.0, 0.0, 0.0};                      // sum y^2, degenerate flag
+    for (int i = tid; i < mm; i += NT) {
         const double den = tau - (Dat(i) - shift);
         if (den == 0.0) { w[1] += 1.0; }
         else { const double y = bat(i) / den; w[0] += y * y; }
     }
-    block_sum4_256(w, red);
+    sum4(w);
     if (w[1] > 0.0) {
         // mu coincides with a pole: the eigenvector is e_i of the FIRST such pole, last component zero, denominator
         // clamped at 1e-12 (stepper.py:134-136)
-        __shared__ int first;
-        if (tid == 0) first = 0x7fffffff;
-        __syncthreads();
-        for (int i = tid; i < mm; i += 256)
-            if (tau - (Dat(i) - shift) == 0.0) atomicMin(&first, i);
-        __syncthreads();
-        for (int i = tid; i < mm; i += 256) shat[i] = (i == first) ? alpha / 1e-12 : 0.0;
-        __syncthreads();
+        int mine = 0x7fffffff;
+        for (int i = tid; i < mm; i += NT)
+            if (tau - (Dat(i) - shift) == 0.0 && i < mine) mine = i;
+        int first;
+        if (WAVE) {
+            for (int off = 32; off > 0; off >>= 1) { const int other = __shfl_xor(mine, off); mine = other < mine ? other : mine; }
+            first = mine;
+        } else {
+            __shared__ int sfirst;
+            if (tid == 0) sfirst = 0x7fffffff;
+            __syncthreads();
+            if (mine != 0x7fffffff) atomicMin(&sfirst, mine);
+            __syncthreads();
+            first = sfirst;
+        }
+        for (int i = tid; i < mm; i += NT) shat[i] = (i == first) ? alpha / 1e-12 : 0.0;
+        if (!WAVE) __syncthreads();
         return;
     }
     const double inv = 1.0 / sqrt(1.0 + w[0]);
     double den = inv;
     if (fabs(den) < 1e-12) den = 1e-12;
-    for (int i = tid; i < mm; i += 256) {
+    for (int i = tid; i < mm; i += NT) {
         const double y = bat(i) / (tau - (Dat(i) - shift));
         shat[i] = (y * inv) * alpha / den;
     }
 }
 
+constexpr int RS_LDS_MAX = 2048;
+
 __global__ __launch_bounds__(256) void rs_batch_kernel(RsBatchArgs a) {
     __shared__ double red[4][4];
+    __shared__ double sLam[RS_LDS_MAX], sG[RS_LDS_MAX];
     const int cand = blockIdx.x, tid = threadIdx.x;
     if (cand >= a.ncand) return;
     const double alpha = a.alpha[cand];
     double* shat = a.X + (size_t)cand * a.ldx;
     const int m = a.m, o = a.order;
+    // every evaluation of the secular function walks the poles and weights again (6-10 times per root): from LDS, not
+    // from global memory — a round trip per evaluation was most of this kernel's 13 us
+    if (m <= RS_LDS_MAX && (a.kind == SELLA_STEP_RFO || a.kind == SELLA_STEP_PRFO)) {
+        for (int i = tid; i < m; i += 256) { sLam[i] = a.lam[i]; sG[i] = a.ghat[i]; }
+        __syncthreads();
+        a.lam = sLam;
+        a.ghat = sG;
+    }
     if (a.kind == SELLA_STEP_QN) {
         for (int i = tid; i < m; i += 256) {
             const double sgn = (i < o) ? -1.0 : 1.0;
@@ -385,11 +417,21 @@ __global__ __launch_bounds__(256) void rs_batch_kernel(RsBatchArgs a) {
         }
     } else if (a.kind == SELLA_STEP_QN_IRC) {
         for (int i = tid; i < m; i += 256) shat[i] = -(a.ghat[i] + alpha * a.d1hat[i]) / (fabs(a.lam[i]) + alpha);
+    } else if (m <= 1024) {
+        // few modes (the structured eigendecompositions: r + 1 of them): one wavefront, no barriers
+        if (tid < 64) {
+            if (a.kind == SELLA_STEP_RFO) {
+                rfo_block_dev<true>(m, a.lam, a.ghat, o, alpha, shat, red);
+            } else {
+                rfo_block_dev<true>(o, a.lam, a.ghat, o, alpha, shat, red);
+                rfo_block_dev<true>(m - o, a.lam + o, a.ghat + o, 0, alpha, shat + o, red);
+            }
+        }
     } else if (a.kind == SELLA_STEP_RFO) {
-        rfo_block_dev(m, a.lam, a.ghat, o, alpha, shat, red);
+        rfo_block_dev<false>(m, a.lam, a.ghat, o, alpha, shat, red);
     } else {
-        rfo_block_dev(o, a.lam, a.ghat, o, alpha, shat, red);
-        rfo_block_dev(m - o, a.lam + o, a.ghat + o, 0, alpha, shat + o, red);
+        rfo_block_dev<false>(o, a.lam, a.ghat, o, alpha, shat, red);
+        rfo_block_dev<false>(m - o, a.lam + o, a.ghat + o, 0, alpha, shat + o, red);
     }
 }
 

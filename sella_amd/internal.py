@@ -208,6 +208,11 @@ class _HessianStack:
             np.add.at(out, (i, rows, cols), H.ravel())
         return out
 
+    def __array__(self, dtype=None, copy=None):
+        """`np.asarray(stack)`: the dense (ncoords, ndof, ndof) array, like the reference's class."""
+        out = self.asarray()
+        return out if dtype is None else out.astype(dtype, copy=False)
+
 
 class _JacobianStack:
     """Per-coordinate gradients as blocks (dof index array (nc, m), grad (nc, m)): the scatter and the two

@@ -23,6 +23,25 @@ def modified_gram_schmidt(Xin, Yin=None, eps1=1.e-15, eps2=1.e-6, maxiter=100):
 _IDENTITIES = {}
 
 
+def pseudo_inverse(A, eps=1e-6):
+    """Moore-Penrose pseudo-inverse through the singular value decomposition, contract of sella/utilities/math.pyx:219-236
+    (`mppi`): -> (U, s, VT, Ainv, nsing) with A = U[:, :nsing] diag(s[:nsing]) VT[:nsing], singular values not above `eps`
+    dropped.  The reference has no caller for it outside its tests (its InternalPES uses `_gpu_qr` + SVD directly); kept
+    for API parity.  A tall matrix is first reduced by the device QR (`sella_qr_thin`), so the SVD is that of the small
+    triangular factor; U is returned THIN (n x min(n, m)) where the reference allocates n x n and fills min(n, m) columns."""
+    A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
+    n, m = A.shape
+    if n >= m and m > 0:
+        Q, R = get_context().qr_thin(A)
+        Ur, s, VT = np.linalg.svd(R)
+        U = Q @ Ur
+    else:
+        U, s, VT = np.linalg.svd(A, full_matrices=False)
+    nsing = int(np.sum(s > eps))
+    Ainv = (VT[:nsing].T / s[:nsing]) @ U[:, :nsing].T
+    return U, s[:nsing], VT, Ainv, nsing
+
+
 def shared_identity(n):
     I = _IDENTITIES.get(n)
     if I is None:

@@ -1,6 +1,7 @@
 """Gram-Schmidt (sella/utilities/math.pyx semantics, tests/utilities/test_math.py:46-75) and
 thin QR through the C ABI."""
 import numpy as np
+import pytest
 
 from conftest import load_golden
 
@@ -81,3 +82,43 @@ def test_accelerator_seam_by_name(ctx):
     np.testing.assert_allclose(gpu_project(A, U), U.T @ A @ U, atol=1e-12 * n)
     np.testing.assert_allclose(gpu_project(None, U, H_gpu=h), U.T @ A @ U, atol=1e-12 * n)
     np.testing.assert_array_equal(A, A0)                            # inputs are never mutated (_gpu.py:64)
+
+
+# ---- the reference's own utilities tests (tests/utilities/test_math.py), same names and parameters -----------------------
+@pytest.mark.parametrize("n,m,eps", [(3, 3, 1e-10), (100, 3, 1e-6)])
+def test_mppi(ctx, n, m, eps):
+    from helpers import get_matrix
+    from sella_amd.utilities.math import pseudo_inverse
+    rng = np.random.RandomState(1)
+    tol = dict(atol=1e-6, rtol=1e-6)
+    A = get_matrix(n, m, rng=rng)
+    U1, s1, VT1, Ainv, nsing1 = pseudo_inverse(A.copy(), eps=eps)
+    np.testing.assert_allclose(U1[:, :nsing1] @ np.diag(s1) @ VT1[:nsing1, :], A, **tol)
+    np.testing.assert_allclose(np.linalg.pinv(A), Ainv, **tol)
+    nsingB = nsing1 - 1
+    B = U1[:, :nsingB] @ np.diag(s1[:nsingB]) @ VT1[:nsingB, :]
+    U2, s2, VT2, Binv, nsing2 = pseudo_inverse(B.copy(), eps=eps)
+    assert nsing2 == nsingB
+    np.testing.assert_allclose(np.linalg.pinv(B, rcond=1e-8), Binv, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("n,mx,my,eps1,eps2,maxiter", [(3, 2, 1, 1e-15, 1e-6, 100), (100, 50, 25, 1e-15, 1e-6, 100)])
+def test_modified_gram_schmidt(ctx, n, mx, my, eps1, eps2, maxiter):
+    from helpers import get_matrix
+    from sella_amd.utilities.math import modified_gram_schmidt
+    rng = np.random.RandomState(2)
+    tol = dict(atol=1e-6, rtol=1e-6)
+    mgskw = dict(eps1=eps1, eps2=eps2, maxiter=maxiter)
+    X = get_matrix(n, mx, rng=rng)
+    Xout1 = modified_gram_schmidt(X, **mgskw)
+    nxout1 = Xout1.shape[1]
+    np.testing.assert_allclose(Xout1.T @ Xout1, np.eye(nxout1), **tol)
+    np.testing.assert_allclose(np.linalg.det(X.T @ X), np.linalg.det(X.T @ Xout1) ** 2, **tol)
+    Y = get_matrix(n, my, rng=rng)
+    Xout2 = modified_gram_schmidt(X, Y, **mgskw)
+    nxout2 = Xout2.shape[1]
+    np.testing.assert_allclose(Xout2.T @ Xout2, np.eye(nxout2), **tol)
+    np.testing.assert_allclose(Xout2.T @ Y, np.zeros((nxout2, my)), **tol)
+    X[:, 1] = X[:, 0]
+    Xout3 = modified_gram_schmidt(X, **mgskw)
+    assert Xout3.shape[1] == nxout1 - 1

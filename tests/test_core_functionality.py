@@ -18,6 +18,9 @@ MOLECULES = {
     'CH4': (['C', 'H', 'H', 'H', 'H'], [[0.0, 0.0, 0.0], [0.6291, 0.6291, 0.6291], [-0.6291, -0.6291, 0.6291],
                                         [0.6291, -0.6291, -0.6291], [-0.6291, 0.6291, -0.6291]]),
     'N2': (['N', 'N'], [[0.0, 0.0, 0.5649], [0.0, 0.0, -0.5649]]),
+    'C6H6': (['C'] * 6 + ['H'] * 6,
+             [[1.397 * np.cos(k * np.pi / 3), 1.397 * np.sin(k * np.pi / 3), 0.0] for k in range(6)] +
+             [[2.481 * np.cos(k * np.pi / 3), 2.481 * np.sin(k * np.pi / 3), 0.0] for k in range(6)]),
 }
 
 
@@ -168,3 +171,29 @@ class TestLinearMolecule:
         opt = Sella(atoms, order=0, internal=True, logfile=None)
         opt.run(fmax=0.01, steps=100)
         assert opt.converged()
+
+
+@pytest.mark.parametrize("name,traj,cons", [("CH4", "CH4.traj", None),
+                                            ("CH4", None, dict(bonds=((0, 1)))),
+                                            ("C6H6", None, None)])
+def test_PES(name, traj, cons, tmp_path):
+    """tests/test_peswrapper.py of the reference, same parameters (its `cons` is never handed to the class either; the
+    trajectory name makes the class write an ASE-format file, one image per force call)."""
+    tol = dict(atol=1e-6, rtol=1e-6)
+    atoms = molecule(name)
+    for MyPES in [PES, InternalPES]:
+        pes = PES(atoms, trajectory=None if traj is None else str(tmp_path / traj))
+        pes.kick(0., diag=True, gamma=0.1)
+        for i in range(2):
+            pes.kick(-pes.get_g() * 0.01)
+        assert pes.H is not None
+        assert not pes.converged(0.)[0]
+        assert pes.converged(1e100)
+        np.testing.assert_allclose(pes.get_Ufree().T @ pes.get_Ucons(), 0, **tol)
+        pes.kick(-pes.get_g() * 0.001, diag=True, gamma=0.1)
+        pes.close()
+    if traj is not None:
+        from sella_amd.trajectory import Trajectory
+        with Trajectory(str(tmp_path / traj)) as images:               # the second pass overwrote the first one's file
+            assert len(images) == pes.neval
+            assert images[-1].positions.shape == (len(atoms), 3)

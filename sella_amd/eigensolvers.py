@@ -81,7 +81,7 @@ def rayleigh_ritz(A, gamma, P, B=None, v0=None, vref=None, vreftol=0.99,
     ApproximateHessian (whose cached device eigendecomposition is then reused)."""
     n, _ = A.shape
     if B is not None and not _is_identity(np.asarray(B)):
-        raise NotImplementedError('a non-identity metric B is not supported by the HIP path')
+        return _rayleigh_ritz_metric(A, gamma, P, np.asarray(B, dtype=np.float64), v0, vref, vreftol, method, maxiter)
     if maxiter is None:
         maxiter = 2 * n + 1
     if gamma <= 0:
@@ -116,6 +116,81 @@ def rayleigh_ritz(A, gamma, P, B=None, v0=None, vref=None, vreftol=0.99,
         for h in owned:
             h.free()
     return lams, V, AV
+
+
+class _Congruent:
+    """x -> S (A (S x)) for an operator A that only offers `.dot` (S symmetric, resident)."""
+
+    def __init__(self, A, S):
+        self.A, self.S, self.shape = A, S, A.shape
+
+    def dot(self, v):
+        ctx = get_context()
+        inner = ctx.symm_mm(self.S, np.asarray(v, dtype=np.float64).ravel())
+        return ctx.symm_mm(self.S, np.asarray(self.A.dot(inner), dtype=np.float64).ravel())
+
+
+def _rayleigh_ritz_metric(A, gamma, P, B, v0, vref, vreftol, method, maxiter):
+    """Generalised problem A x = theta B x (sella/eigensolvers.py:35-36, 58, 70; no caller of the reference passes a metric).
+    Reduced to the standard one by the congruence with S = B^-1/2 from the device eigendecomposition of B:
+    (S A S) y = theta y, x = S y, and the standard device path runs on (S A S, S P S).  Returned as the reference returns
+    them: Ritz values, V with V^T B V = I, AV = A V.
+    Deviation: the reference keeps a Euclidean-orthonormal basis and solves a generalised Rayleigh-Ritz problem in it, so its
+    search space after k steps is not this one and its convergence test |A x - theta B x| is |S^-1 (residual here)|;
+    converged pairs agree, trajectories do not."""
+    ctx = get_context()
+    n = B.shape[0]
+    dB = ctx.upload(0.5 * (B + B.T))
+    wB, VB, VBt = ctx.eigh(dB)
+    dB.free()
+    if not wB[0] > 0.0:
+        VB.free()
+        VBt.free()
+        raise ValueError('rayleigh_ritz: the metric B must be positive definite')
+    Q = VB.numpy()
+    VB.free()
+    VBt.free()
+    # S = B^-1/2 resident, B^1/2 applied on the host to single vectors / narrow panels only (O(n^2 k))
+    dQs, dQt, S = ctx.upload(Q * wB ** -0.5), ctx.upload(np.ascontiguousarray(Q.T)), ctx.zeros(n, n)
+    ctx.gemm(dQs, dQt, S)
+    dQs.free()
+    dQt.free()
+
+    def sqrtB(X):
+        return Q @ ((wB ** 0.5)[:, None] * (Q.T @ X.reshape((n, -1))))
+
+    owned = [S]
+    try:
+        def congruent(M):
+            dM = M if isinstance(M, DeviceMatrix) else ctx.upload(np.asarray(M, dtype=np.float64))
+            tmp, out = ctx.zeros(n, n), ctx.zeros(n, n)
+            ctx.gemm(S, dM, tmp)
+            ctx.gemm(tmp, S, out)
+            tmp.free()
+            if dM is not M:
+                dM.free()
+            return out
+        if isinstance(A, (np.ndarray, DeviceMatrix)):
+            At = congruent(A)
+            owned.append(At)
+        else:
+            At = _Congruent(A, S)
+        Pt = None
+        if P is not None:
+            Pn = P.B if isinstance(P, ApproximateHessian) else np.asarray(P, dtype=np.float64)
+            if Pn is not None:
+                dPt = congruent(Pn)
+                Pt = dPt.numpy()
+                Pt = 0.5 * (Pt + Pt.T)
+                dPt.free()
+        v0t = None if v0 is None else sqrtB(np.asarray(v0, dtype=np.float64)).ravel()
+        vreft = None if vref is None else ctx.symm_mm(S, np.asarray(vref, dtype=np.float64).ravel())
+        lams, Vt_, AVt = rayleigh_ritz(At, gamma, Pt, None, v0t, vreft, vreftol, method, maxiter)
+        V = ctx.symm_mm(S, np.ascontiguousarray(Vt_))
+        return lams, V, sqrtB(np.ascontiguousarray(AVt))
+    finally:
+        for h in owned:
+            h.free()
 
 
 def block_davidson(A, nev, P=None, tol=1e-8, block=16, maxiter=500, maxvec=0, v0=None):

@@ -133,8 +133,39 @@ def test_unknown_method_and_metric(ctx):
     A = np.diag(np.arange(1., 9.))
     with pytest.raises(ValueError):
         rayleigh_ritz(A, 0.1, np.eye(8), v0=np.ones(8), method='nope')
-    with pytest.raises(NotImplementedError):
-        rayleigh_ritz(A, 0.1, np.eye(8), B=2 * np.eye(8), v0=np.ones(8))
+    with pytest.raises(ValueError):                              # a metric must be positive definite
+        rayleigh_ritz(A, 0.1, np.eye(8), B=-np.eye(8), v0=np.ones(8))
+
+
+@pytest.mark.parametrize('as_operator', [False, True])
+def test_generalised_metric(ctx, as_operator):
+    """A x = theta B x (eigensolvers.py:35-36, 58, 70): converged pairs against scipy's generalised eigh; V comes back
+    B-orthonormal and AV = A V, as the reference returns them."""
+    from scipy.linalg import eigh as geigh
+    from sella_amd.eigensolvers import rayleigh_ritz
+    rng = np.random.RandomState(31)
+    n = 24
+    A = rng.normal(size=(n, n))
+    A = 0.5 * (A + A.T)
+    M = rng.normal(size=(n, n))
+    B = M @ M.T / n + 0.5 * np.eye(n)
+    wref, Xref = geigh(A, B)
+    P = A + 0.05 * np.diag(rng.normal(size=n))
+
+    class Op:
+        shape = A.shape
+
+        def dot(self, v):
+            return A @ v
+
+    lams, V, AV = rayleigh_ritz(Op() if as_operator else A, 1e-9, P, B=B, v0=rng.normal(size=n), method='jd0')
+    k = V.shape[1]
+    np.testing.assert_allclose(V.T @ B @ V, np.eye(k), atol=1e-9)
+    np.testing.assert_allclose(AV, A @ V, atol=1e-9)
+    assert abs(lams[0] - wref[0]) < 1e-8
+    x = V[:, 0]
+    assert np.linalg.norm(A @ x - lams[0] * (B @ x)) < 1e-6
+    assert abs(abs(x @ B @ Xref[:, 0]) - 1.0) < 1e-6
 
 
 def test_callback_failure_propagates(ctx):

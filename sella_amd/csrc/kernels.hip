@@ -396,11 +396,23 @@ __global__ __launch_bounds__(256) void lincomb_kernel(int n, int nout, const dou
             }
             __syncthreads();
             if (i < n) {
-#pragma unroll 4
-                for (int j = 0; j < jt; ++j) {
-                    const double p = P[(size_t)(j0 + j) * ldp + i];
+                // sixteen panel rows in flight at a time (a loop unrolled by 4 is k / 4 memory round trips: 16 us for
+                // k = 60 rows of 3072 — these passes sit between the kernels of an optimizer step)
+                for (int jb = 0; jb < jt; jb += 16) {
+                    double pv[16];
 #pragma unroll
-                    for (int c = 0; c < LC_NT; ++c) acc[c] += ws[j * LC_NT + c] * p;
+                    for (int u = 0; u < 16; ++u) {
+                        const int j = jb + u;
+                        pv[u] = P[(size_t)(j0 + (j < jt ? j : jt - 1)) * ldp + i];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int j = jb + u;
+                        if (j < jt) {
+#pragma unroll
+                            for (int c = 0; c < LC_NT; ++c) acc[c] += ws[j * LC_NT + c] * pv[u];
+                        }
+                    }
                 }
             }
         }

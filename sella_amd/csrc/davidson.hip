@@ -1018,19 +1018,20 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
                                t2, At2, part, part + 2 * DF_MAXBLK, nblk, nblke, s.Vp + (size_t)k * s.ld,
                                s.AVp + (size_t)k * s.ld, dsc);
             DHIP(hipGetLastError());
-            if (s.qt_mode && !c->opt.host_scalars) {
-                // read the scalars back, mark that point, queue the eigenbasis images of the new vector behind it (they
-                // run while the host decides and does the next Rayleigh-Ritz step), wait for the mark only
+            if (s.qt_mode) {
+                // read the scalars back (host_scalars: the kernels have written them into pinned host memory themselves
+                // and there is nothing to copy), mark that point, queue the eigenbasis images of the new vector behind it
+                // (they run while the host decides and does the next Rayleigh-Ritz step), wait for the mark only
                 const int cnt = (int)(S0 + 8 + nneg);
-                DHIP(hipMemcpyAsync(c->hscal + DS_GRAM, c->dscal + DS_GRAM, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost,
-                                    c->stream));
+                if (!c->opt.host_scalars)
+                    DHIP(hipMemcpyAsync(c->hscal + DS_GRAM, c->dscal + DS_GRAM, (size_t)cnt * sizeof(double),
+                                        hipMemcpyDeviceToHost, c->stream));
                 DHIP(hipEventRecord(s.ev, c->stream));
                 const double* xs[2] = {s.Vp + (size_t)k * s.ld, s.AVp + (size_t)k * s.ld};
                 DCHK(launch_gemv_rows_xp(c, s.Qt->d, n, n, s.Qt->ld, xs, 2, s.QtV + (size_t)k * s.ld, capn * s.ld, GemvEpi()));
                 DHIP(hipEventSynchronize(s.ev));
             } else {
                 DCHK(sync_scalars(c, DS_GRAM, (int)(S0 + 8 + nneg)));
-                if (s.qt_mode) DCHK(qt_update(s, k, 1));
             }
             const double* h = c->hscal + DS_GRAM;
             // ---- verdict: the reference's control flow evaluated after the fact --------------------------------

@@ -10,6 +10,7 @@
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 struct Bar {
+    unsigned long long flags[256][16];   // mode 2: one cache line per workgroup, plain release stores, no atomics
     unsigned long long xcd[8][16];       // one cache line (128 B) per XCD counter
     unsigned long long global[16];
     unsigned long long gen[16];
@@ -25,7 +26,7 @@ __device__ bool spin_until(unsigned long long* p, unsigned long long want, int* 
     return false;
 }
 
-// mode 0: flat; mode 1: hierarchical by blockIdx.x % 8; `work` doubles are written by every workgroup before each barrier
+// mode 0: flat; mode 1: hierarchical by blockIdx.x % 8; mode 2: flag array (no atomics); `work` doubles are written by every workgroup before each barrier
 // and one word of a NEIGHBOUR's slice is read after it (a data dependency through the barrier: a value older than this
 // round's would be a stale read)
 __global__ __launch_bounds__(256) void barrier_loop(Bar* b, int mode, int rounds, double* data, int work, int* bad) {
@@ -36,7 +37,25 @@ __global__ __launch_bounds__(256) void barrier_loop(Bar* b, int mode, int rounds
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         bool ok = true;
-        if (tid == 0) {
+        if (mode == 2) {
+            // flag array: every workgroup publishes its round number in its own line; wavefront 0 of workgroup 0 polls all
+            // of them (four per lane) and publishes the generation; nobody performs a read-modify-write
+            if (tid == 0) __hip_atomic_store(&b->flags[me][0], (unsigned long long)r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (me == 0 && tid < 64) {
+                bool all = false;
+                for (int spin = 0; spin < (1 << 20) && !all; ++spin) {
+                    bool mine = true;
+                    for (int w = tid; w < nwg; w += 64)
+                        mine = mine && (__hip_atomic_load(&b->flags[w][0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)r);
+                    all = __all(mine);
+                }
+                if (tid == 0) {
+                    if (all) __hip_atomic_store(&b->gen[0], (unsigned long long)r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    else __hip_atomic_store(&b->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (tid == 0) ok = spin_until(&b->gen[0], r, &b->abort);
+        } else if (tid == 0) {
             if (mode == 0) {
                 const unsigned long long old = __hip_atomic_fetch_add(&b->global[0], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
                 if (old == (unsigned long long)nwg * r - 1) __hip_atomic_store(&b->gen[0], (unsigned long long)r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -75,7 +94,7 @@ int main() {
     CHK(hipMalloc(&bad, sizeof(int)));
     const int rounds = 2000;
     for (int nwg : {256, 64, 16})
-        for (int mode = 0; mode < 2; ++mode)
+        for (int mode = 0; mode < 3; ++mode)
             for (int work : {0, 64, 512}) {
                 CHK(hipMemset(b, 0, sizeof(Bar)));
                 CHK(hipMemset(bad, 0, sizeof(int)));
@@ -89,7 +108,7 @@ int main() {
                 CHK(hipMemcpy(&h, b, sizeof(Bar), hipMemcpyDeviceToHost));
                 CHK(hipMemcpy(&hb, bad, sizeof(int), hipMemcpyDeviceToHost));
                 printf("%3d workgroups, %-12s, %4d B written per workgroup and round: %8.1f ns per barrier round, %d stale reads%s\n", nwg,
-                       mode ? "hierarchical" : "flat", work * 8, 1e9 * dt / rounds, hb, h.abort ? "  [ABORTED]" : "");
+                       mode == 2 ? "flag array" : mode ? "hierarchical" : "flat", work * 8, 1e9 * dt / rounds, hb, h.abort ? "  [ABORTED]" : "");
             }
     return 0;
 }

@@ -151,7 +151,19 @@ int sella_mgs(sella_ctx* ctx, const double* X, int n, int nx, const double* Y, i
  * STRUCTURED P: Pvecs (n x r) and PvecsT (r x n) with r < n hold r explicit eigenpairs (pevals, r entries) and the
  *    remaining n - r eigenvalues all equal pscale, their eigenspace being the orthogonal complement of the r vectors:
  *    P = pscale (I - W^T W) + W^T diag(pevals) W — what an approximate Hessian that started as a scaled identity
- *    (sella/linalg.py:274-289) is after any number of quasi-Newton updates.  (P - theta)^-1 then costs O(n r).     */
+ *    (sella/linalg.py:274-289) is after any number of quasi-Newton updates.  (P - theta)^-1 then costs O(n r).
+ * RE-ENTRANCY CONTRACT of the callbacks (sella_matvec_fn, sella_allgather_fn).  A callback runs on the thread that
+ *    called the solver and MAY CALL ANY ENTRY POINT OF THIS LIBRARY ON THE SAME CONTEXT: create, upload, free and
+ *    factorise matrices, run sella_eigh / sella_qr_thin / another sella_davidson, synchronise.  (NumericalHessian._matvec,
+ *    sella/linalg.py:39-95, evaluates a calculator, and InternalPES transforms the vector through device-resident
+ *    Jacobians on the way.)  The library guarantees: (1) matrix handles the solver was given stay valid and keep their
+ *    device address while they are live — the handle table never moves an entry; (2) every scratch slot, scalar exchange
+ *    buffer and staging buffer of the interrupted call is parked for the duration of the callback, the nested calls work
+ *    on a set of their own per call depth; (3) device work queued by the callback is ordered behind the solver's on the
+ *    context's single stream.  The callback must NOT free or overwrite the matrices passed to the interrupted solver
+ *    (A, Pvecs, PvecsT), must not destroy the context, and must not call the library on this context from another
+ *    thread.  v and Av (send / recv) are only valid until it returns.  A non-zero return aborts the solver with
+ *    SELLA_E_CALLBACK.                                                                                              */
 typedef int (*sella_matvec_fn)(void* user, const double* v, double* Av, int n);
 enum { SELLA_DAV_LANCZOS = 0, SELLA_DAV_GD = 1, SELLA_DAV_JD0 = 2, SELLA_DAV_JD0_ALT = 3,
        SELLA_DAV_MJD0 = 4, SELLA_DAV_MJD0_ALT = 5 };
@@ -174,7 +186,8 @@ int sella_davidson(sella_ctx* ctx, sella_mat A, sella_matvec_fn matvec, void* us
  * V0 (n x nv0, host, nv0 <= 16) start block or NULL.  tol: a pair counts as converged when
  *    |r| <= tol |theta| (the reference's gamma test, sella/eigensolvers.py:80-89).
  * Outputs (host): lams (nev), V (n x nev row-major), res (nev residual norms, may be NULL), *niter,
- *    *nmatvec (operator columns applied), *nconv (pairs converged; nev on success).                           */
+ *    *nmatvec (operator columns applied), *nconv (pairs converged; nev on success).
+ * The gather callback is stream-ordered (no synchronisation around it); the re-entrancy contract above applies.     */
 typedef int (*sella_allgather_fn)(void* user, const void* send, void* recv, size_t bytes, void* hip_stream);
 int sella_davidson_block(sella_ctx* ctx, sella_mat A, int n, int row0, int world,
                          sella_allgather_fn gather, void* user, sella_mat Pvecs, sella_mat PvecsT,

@@ -38,6 +38,45 @@ int mat_new(sella_ctx* c, int rows, int cols, sella_mat* h) {
     return SELLA_OK;
 }
 
+static void frame_swap(sella_ctx* c, sella_ctx::Frame& f) {
+    std::swap(c->dscal, f.dscal);
+    std::swap(c->hscal, f.hscal);
+    c->scratch.swap(f.scratch);
+    std::swap(c->hstage, f.hstage);
+    std::swap(c->hstage_bytes, f.hstage_bytes);
+    c->hbuf_a.swap(f.hbuf_a);
+    c->hbuf_b.swap(f.hbuf_b);
+}
+
+int callback_enter(sella_ctx* c) {
+    // No wait here: one stream per context, so whatever the callback queues through the library is ordered behind the
+    // interrupted call's work, and recycled device blocks (dev_free -> dev_alloc) are reused in stream order.
+    if ((int)c->frames.size() < c->depth + 2) c->frames.resize(c->depth + 2);
+    frame_swap(c, c->frames[c->depth]);          // park the caller's working set ...
+    c->depth += 1;
+    frame_swap(c, c->frames[c->depth]);          // ... and install the one of the next depth
+    if (!c->dscal) {
+        if (hipMalloc((void**)&c->dscal, (size_t)c->nscal * sizeof(double)) != hipSuccess ||
+            hipHostMalloc((void**)&c->hscal, (size_t)c->nscal * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+            set_error("allocating the scalar exchange buffers of call depth %d failed", c->depth);
+            callback_leave(c);
+            return SELLA_E_NOMEM;
+        }
+        (void)hipMemsetAsync(c->dscal, 0, (size_t)c->nscal * sizeof(double), c->stream);
+        c->scratch.assign(SCR_NSLOTS, {nullptr, 0});
+    }
+    return SELLA_OK;
+}
+
+void callback_leave(sella_ctx* c) {
+    // device-to-host payloads the nested calls queued but never waited for are delivered while their destinations
+    // (the callback's own memory) are still alive
+    if (!c->d2h_pending.empty()) (void)stream_wait(c);
+    frame_swap(c, c->frames[c->depth]);
+    c->depth -= 1;
+    frame_swap(c, c->frames[c->depth]);
+}
+
 static size_t pool_class(size_t bytes) { return (size_t)round_up_l((long)(bytes ? bytes : 1), 4096); }
 
 int dev_alloc(sella_ctx* c, size_t bytes, double** p) {
@@ -362,6 +401,11 @@ int sella_ctx_destroy(sella_ctx* c) {
     if (c->dscal) (void)hipFree(c->dscal);
     if (c->hscal) (void)hipHostFree(c->hscal);
     if (c->hstage) (void)hipHostFree(c->hstage);
+    for (auto& f : c->frames) {                            // parked working sets of deeper call levels
+        if (f.dscal) (void)hipFree(f.dscal);
+        if (f.hscal) (void)hipHostFree(f.hscal);
+        if (f.hstage) (void)hipHostFree(f.hstage);
+    }
     if (c->hring) (void)hipHostFree(c->hring);
     if (c->dring) (void)hipHostFree(c->dring);
     (void)hipStreamDestroy(c->stream);

@@ -152,9 +152,15 @@ int apply_A(Dav& s, const double* x, double* y) {
     s.hav.resize(s.n);
     SCHK(d2h_async(c, s.hv.data(), x, (size_t)s.n * sizeof(double)));
     SCHK(stream_wait(c));
-    if (s.matvec(s.user, s.hv.data(), s.hav.data(), s.n) != 0) {
-        set_error("davidson: host matvec callback failed");
-        return SELLA_E_CALLBACK;
+    {
+        // the callback may re-enter the library on this context (NumericalHessian._matvec, sella/linalg.py:39-95, is
+        // allowed to do anything): it runs on a working set of its own (internal.h, sella_ctx::Frame)
+        CallbackScope scope(c);
+        SCHK(scope.status);
+        if (s.matvec(s.user, s.hv.data(), s.hav.data(), s.n) != 0) {
+            set_error("davidson: host matvec callback failed");
+            return SELLA_E_CALLBACK;
+        }
     }
     SCHK(h2d_async(c, y, s.hav.data(), (size_t)s.n * sizeof(double)));
     SCHK(stream_wait(c));

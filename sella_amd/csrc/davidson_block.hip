@@ -365,9 +365,13 @@ int apply_A(Blk& s, const double* X, int nh, double* Y) {
     s.nmatvec += nh;
     if (!s.gather) return launch_panel16(c, s.A->d, s.n, s.n, s.ld, X, nh, Y, s.ld);
     SCHK(launch_panel16(c, s.A->d, s.A->rows, s.n, s.ld, X, nh, s.send, s.m_max));
-    if (s.gather(s.user, s.send, s.recv, s.bytesS, (void*)c->stream) != 0) {
-        set_error("davidson_block: all-gather callback failed");
-        return SELLA_E_CALLBACK;
+    {
+        CallbackScope scope(c);                  // (stream-ordered: entering and leaving the scope does not wait)
+        SCHK(scope.status);
+        if (s.gather(s.user, s.send, s.recv, s.bytesS, (void*)c->stream) != 0) {
+            set_error("davidson_block: all-gather callback failed");
+            return SELLA_E_CALLBACK;
+        }
     }
     hipLaunchKernelGGL(bd_unpack_kernel, dim3((s.n + 255) / 256, nh), dim3(256), 0, c->stream, s.recv, s.world, s.m_max, s.n,
                        Y, s.ld);

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -123,7 +124,11 @@ struct Options {
 struct sella_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    std::vector<sella::Mat> mats;
+    // Handle table.  A deque: push_back never moves existing elements, so a `Mat*` obtained from mat_get stays valid
+    // while the handle is live, even when a host callback (sella_matvec_fn / sella_allgather_fn) re-enters the library
+    // and creates matrices.  (It was a std::vector until round 3: a reallocation inside the Davidson callback left
+    // the solver reading a freed Mat.)
+    std::deque<sella::Mat> mats;
     // small exchange buffers: device scalars + pinned host mirror
     double* dscal = nullptr;
     double* hscal = nullptr;
@@ -161,12 +166,38 @@ struct sella_ctx {
     struct PendingD2H { void* dst; const char* slot; size_t bytes; size_t dpitch, width, rows; };
     std::vector<PendingD2H> d2h_pending;
     std::vector<double> hbuf_a, hbuf_b;             // host work vectors of sella_opt_step (optstep.hip)
+    // Re-entrancy: the working state a library call may leave LIVE across a host callback (scalar exchange buffers,
+    // pooled scratch slots, pinned staging, host work vectors) exists once per call depth.  callback_enter parks the
+    // caller's set and installs the set of the next depth (created on first use); callback_leave restores it.  So a
+    // callback may call ANY entry point of the library on the same context without touching what the interrupted
+    // call still needs.
+    struct Frame {
+        double* dscal = nullptr;
+        double* hscal = nullptr;
+        std::vector<std::pair<double*, size_t>> scratch;
+        void* hstage = nullptr;
+        size_t hstage_bytes = 0;
+        std::vector<double> hbuf_a, hbuf_b;
+    };
+    std::deque<Frame> frames;      // frames[d] = parked state of depth d (d != depth)
+    int depth = 0;
 };
 
 namespace sella {
 
 // ---- context helpers (context.hip) ------------------------------------------------------
 int mat_new(sella_ctx* c, int rows, int cols, sella_mat* h);       // zero-initialised
+// Bracket EVERY invocation of a host callback with these (see sella_ctx::Frame); CallbackScope does it by scope.
+int callback_enter(sella_ctx* c);
+void callback_leave(sella_ctx* c);
+struct CallbackScope {
+    sella_ctx* c;
+    int status;
+    explicit CallbackScope(sella_ctx* ctx) : c(ctx), status(callback_enter(ctx)) {}
+    ~CallbackScope() { if (status == SELLA_OK) callback_leave(c); }
+    CallbackScope(const CallbackScope&) = delete;
+    CallbackScope& operator=(const CallbackScope&) = delete;
+};
 Mat* mat_get(sella_ctx* c, sella_mat h);
 int scratch_get(sella_ctx* c, int slot, size_t bytes, double** p); // persistent scratch slot
 int host_stage(sella_ctx* c, size_t bytes, void** p);               // pinned host staging buffer (grown on demand)

@@ -8,12 +8,26 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(REPO, 'sella_amd', 'csrc')
-OUT = os.path.join(HERE, '_build')
+# HOSTEMU_SANITIZE=1: AddressSanitizer + UBSan build in a directory of its own (tests/test_emu_sanitized.py runs part of
+# the suite on it in a subprocess with the sanitizer runtime preloaded).  The plain build could not see a use after
+# free inside the library (round 3: a Mat* held across a re-entering callback).
+SANITIZE = os.environ.get('HOSTEMU_SANITIZE') == '1'
+OUT = os.path.join(HERE, '_build_asan' if SANITIZE else '_build')
 LIB = os.path.join(OUT, 'libsella_hostemu.so')
 CXX = os.environ.get('HOSTEMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')
 FLAGS = ['-x', 'c++', '-std=c++17', '-O2', '-g', '-fPIC', '-I', os.path.join(HERE, 'include'),
          '-Wall', '-Wno-unused-function', '-Wno-unused-result', '-Wno-unknown-pragmas',
          '-Wno-pass-failed']
+SAN_FLAGS = ['-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-fno-omit-frame-pointer', '-shared-libasan',
+             '-fno-sanitize=vptr,function']
+if SANITIZE:
+    FLAGS = FLAGS + SAN_FLAGS
+
+
+def asan_runtime():
+    """Path of the shared AddressSanitizer runtime of the compiler (to LD_PRELOAD into the python that loads the library)."""
+    out = subprocess.check_output([CXX, '-print-file-name=libclang_rt.asan-x86_64.so']).decode().strip()
+    return os.path.realpath(out)
 
 
 def build(force=False, verbose=False):
@@ -60,7 +74,7 @@ def _build_locked(force, verbose):
     if bad:
         raise RuntimeError('hostemu build failed')
     if procs or not os.path.exists(LIB):
-        subprocess.check_call([CXX, '-shared', '-fPIC', *objs, '-o', LIB])
+        subprocess.check_call([CXX, '-shared', '-fPIC', *(SAN_FLAGS if SANITIZE else []), *objs, '-o', LIB])
     return LIB
 
 

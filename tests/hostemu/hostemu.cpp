@@ -15,6 +15,15 @@
 #include <mutex>
 #include <vector>
 
+// AddressSanitizer build (HOSTEMU_SANITIZE=1, build_emu.py): a fibre that finishes never returns from its frames, so
+// the redzones they poisoned on its (heap-allocated, recycled) stack must be cleared before the stack is used again.
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#include <sanitizer/asan_interface.h>
+#define HIPEMU_ASAN 1
+#endif
+#endif
+
 namespace hipemu {
 
 Idx g_threadIdx, g_blockIdx;
@@ -192,6 +201,9 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& 
                     f.lin = t;
                     f.tid = Idx{(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y),
                                 (unsigned)(t / (block.x * block.y))};
+#ifdef HIPEMU_ASAN
+                    __asan_unpoison_memory_region(f.stack, kStack);
+#endif
                     ctx_make(&f.ctx, f.stack, kStack, trampoline);
                     g_waves[t >> 6].live++;
                 }

@@ -152,7 +152,7 @@ static inline int hipemu_readlane(int v, int lane) {
 static inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
 static inline int __double2hiint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b >> 32); }
 static inline double __hiloint2double(int hi, int lo) {
-    long long b = ((long long)hi << 32) | (unsigned)lo;
+    unsigned long long b = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
     double d; memcpy(&d, &b, 8); return d;
 }
 

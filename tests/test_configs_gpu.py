@@ -1,5 +1,6 @@
 """BASELINE.json's configurations AS NAMED, on the MI355X only (this module never builds the host emulation):
 
+  configs[0]  Cu fcc111(5,5,6) + adatom, EMT, Cartesian (the README example; the reference runs it on the CPU)
   configs[1]  1024-atom Cu(111) EMT slab, Cartesian, lower half pinned, default `Sella`
   configs[2]  1024-atom slab, internal coordinates + geodesic step
   configs[3]  ensemble of 256-atom EMT saddle searches (one GPU's share: 8 members)
@@ -26,6 +27,45 @@ def test_benchmark_size_eigh(ctx):
     from test_eigh import check
     A, P, g = hessian_like(3072, 0)
     check(ctx, P, tol=2e-12)
+
+
+def test_config0_readme_slab_step_by_step(ctx):
+    """configs[0] as named: README.md:18-25 of the reference — Cu fcc111(5,5,6) + adatom on the bridge site (151 atoms,
+    3N = 453), the 75 atoms of the lower half held by translation constraints (225 constraints, 228 free coordinates),
+    default `Sella` (order 1, P-RFO, 'ras', gamma 0.4), EMT.  The product on the device (EMT kernel, finite-difference
+    Davidson through sella_fd_matvec, structured Hessian, fused restricted step) against the trajectory the dense CPU
+    oracle produced for the same start (tests/golden/g13_config0_trace.npz, oracle/make_config0_trace.py): step
+    vector, energy, gradient, trust radius, rho and the number of force calls, step by step."""
+    from conftest import load_golden
+    from sella_amd import Constraints, Sella
+    from sella_amd.atoms import EMT, add_adsorbate, fcc111
+    t = load_golden('g13_config0_trace')
+    slab = fcc111('Cu', (5, 5, 6), vacuum=7.5)
+    add_adsorbate(slab, 'Cu', 2.0, 'bridge')
+    np.testing.assert_array_equal(slab.positions, t['x_start'])
+    cons = Constraints(slab)
+    pinned = [a.index for a in slab if a.position[2] < slab.cell[2, 2] / 2.]
+    np.testing.assert_array_equal(pinned, t['pinned'])
+    for i in pinned:
+        cons.fix_translation(i)
+    assert len(slab) == 151 and len(pinned) == 75
+    slab.calc = EMT()
+    dyn = Sella(slab, constraints=cons, logfile=None)
+    assert dyn.pes.get_Ufree().shape == (453, 228)
+    assert dyn.delta == pytest.approx(float(t['delta0']))
+    for i in range(int(t['nsteps'])):
+        x_before = dyn.pes.get_x().copy()
+        dyn.step()
+        f, delta, rho, neval = t[f'scal{i}']
+        tol = 2e-7 * 4 ** min(i, 8)              # roundoff of the finite-difference Hessian products compounds along the path
+        np.testing.assert_allclose(dyn.pes.get_x() - x_before, t[f's{i}'], atol=tol, err_msg=f'step {i}')
+        assert abs(dyn.pes.get_f() - f) < tol, i
+        np.testing.assert_allclose(dyn.pes.get_g(), t[f'g{i}'], atol=10 * tol)
+        assert dyn.delta == pytest.approx(delta, rel=1e-5, abs=tol), i
+        if np.isfinite(rho):
+            assert dyn.rho == pytest.approx(rho, rel=1e-3, abs=1e-3), i
+        assert dyn.pes.neval == int(neval), i          # same diagonalisation schedule, same number of force calls
+        np.testing.assert_array_equal(slab.positions[pinned], t['x_start'][pinned])
 
 
 def test_config1_emt_slab_1024_atoms(ctx):

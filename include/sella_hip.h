@@ -437,6 +437,12 @@ int sella_search_create(sella_ctx* ctx, sella_calc* calc, int n, const double* x
 /* energy and gradient (dE/dx, n) at the starting point, if the caller evaluated them already (counts as a force call) */
 int sella_search_seed(sella_search* search, double energy, const double* grad);
 int sella_search_run(sella_search* search, double fmax, long steps, int* converged);
+/* After SELLA_E_UNSUPPORTED: the block of secant pairs of a diagonalisation that no longer fitted the structured form (its
+ * force calls are spent and counted, the optimizer step that scheduled it is counted): *k pairs (0: none pending), Sm and
+ * Ym (n x k row-major; NULL: only the count).  The caller applies them as one block update of the approximate Hessian
+ * it takes over (sella/linalg.py:274-304) and is then exactly where the reference is after PES.diag
+ * (sella/peswrapper.py:545-553).  A hand-over with k = 0 happened BEFORE the step moved the geometry.                  */
+int sella_search_pending_pairs(sella_search* search, int* k, double* Sm, double* Ym);
 /* x, g (n each, may be NULL); scalars[5] = f, fmax, delta, rho, lowest eigenvalue of the approximate Hessian;
  * counters[6] = optimizer steps, force calls, one-call steps, explicit rank, explicit rank of the view (-1: none),
  * first-use diagonalisation done (0 / 1)                                                                              */

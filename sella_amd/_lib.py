@@ -125,6 +125,7 @@ SIGNATURES = {
                                     POINTER(c_void_p)]),
     'sella_search_seed': (c_int, [c_void_p, c_double, c_void_p]),
     'sella_search_run': (c_int, [c_void_p, c_double, c_long, c_int_p]),
+    'sella_search_pending_pairs': (c_int, [c_void_p, c_int_p, c_void_p, c_void_p]),
     'sella_search_state': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'sella_search_release_hessian': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
     'sella_search_destroy': (c_int, [c_void_p]),

@@ -39,6 +39,12 @@ struct sella_search {
     double lam0 = 0.0;
     int B_stale = 0, Bsub_stale = 0;
     sella_opt_step_t io;
+    // Hand-over (SELLA_E_UNSUPPORTED) in the middle of a step: a diagonalisation whose block of secant pairs no longer
+    // fits the structured form has spent its force calls — the pairs are kept for the caller, who applies them on the
+    // dense route (sella_search_pending_pairs), and the step that scheduled it counts.
+    std::vector<double> pendS, pendY;           // (n x pend_k) row-major each
+    int pend_k = 0;
+    bool count_step_on_exit = false;
 };
 
 namespace {
@@ -239,9 +245,21 @@ int diagonalise(sella_search* S) {
                 Ym[(size_t)i * kp + b] += ya * X[(size_t)a * kp + b];
             }
         }
-    SCHK(update_block(S, Sm.data(), Ym.data(), kp));
+    const int ub = update_block(S, Sm.data(), Ym.data(), kp);
     S->first_diag = false;
-    return SELLA_OK;
+    if (ub == SELLA_E_UNSUPPORTED) {            // (update_block checks its capacity before it touches anything)
+        S->pendS.swap(Sm);
+        S->pendY.swap(Ym);
+        S->pend_k = kp;
+    }
+    return ub;
+}
+
+// room for one more quasi-Newton pair (and the bookkeeping rows of the one-call step) in the structured forms
+bool step_fits(const sella_search* S) {
+    const bool pins = !S->idx.empty();
+    if (S->r + 4 > S->rank_limit || S->r + 4 > S->cap) return false;
+    return !(pins && S->have_view && (S->r_sub + 4 > S->rank_limit_sub || S->r_sub + 4 > S->cap_sub));
 }
 
 // optimize.py:363-378
@@ -296,7 +314,12 @@ int call_opt_step(sella_search* S, int flags, double f_old) {
 int one_step(sella_search* S) {
     if (!S->initialized) {                                   // optimize.py:318-326
         if (S->p.eig) {
-            SCHK(diagonalise(S));
+            const int st = diagonalise(S);
+            if (st == SELLA_E_UNSUPPORTED && S->pend_k > 0) {    // done, its update pending with the caller; no step taken
+                S->nsteps_since_diag = -1;
+                S->initialized = true;
+            }
+            SCHK(st);
             S->nsteps_since_diag = -1;
         }
         S->initialized = true;
@@ -347,8 +370,7 @@ int one_step(sella_search* S) {
             for (int i = 0; i < S->n; ++i) dg[i] = S->g[i] - S->gold[i];
             SCHK(update_block(S, S->dx.data(), dg.data(), 1));
         }
-        if (rediag0) SCHK(diagonalise(S));
-        if (std::fabs(predicted) >= 1e-14) {                     // optimize.py:413-434
+        if (std::fabs(predicted) >= 1e-14) {                     // optimize.py:413-434 (independent of the diagonalisation)
             const double rho = (S->f - f_old) / predicted;
             if (!(1.0 / S->p.rho_dec <= rho && rho <= S->p.rho_dec)) S->delta = std::max(S->smag * S->p.sigma_dec, S->p.delta_min);
             else if (1.0 / S->p.rho_inc < rho && rho < S->p.rho_inc) S->delta = std::max(S->p.sigma_inc * S->smag, S->delta);
@@ -357,7 +379,18 @@ int one_step(sella_search* S) {
             S->rho = 1.0;
         }
         S->have_step = false;
+        if (rediag0) {
+            const int st = diagonalise(S);
+            if (st == SELLA_E_UNSUPPORTED && S->pend_k > 0) S->count_step_on_exit = true;
+            SCHK(st);
+        }
         return SELLA_OK;
+    }
+    // Capacity for THIS step is checked before the geometry moves and the force call is spent: a proposal kept from the
+    // previous call (have_step) was made when the explicit rank was smaller by the pair learnt since.
+    if (!step_fits(S)) {
+        set_error("search: explicit rank leaves the structured form (%d of %d)", S->r, S->rank_limit);
+        return SELLA_E_UNSUPPORTED;
     }
     if (!S->have_step) SCHK(call_opt_step(S, SELLA_OPT_PROPOSE, S->f));
     const bool rediag = wants_diagonalisation(S);
@@ -373,7 +406,11 @@ int one_step(sella_search* S) {
     SCHK(evaluate(S));
     S->have_step = false;
     SCHK(call_opt_step(S, SELLA_OPT_LEARN | (rediag ? 0 : SELLA_OPT_PROPOSE), f_old));
-    if (rediag) SCHK(diagonalise(S));
+    if (rediag) {
+        const int st = diagonalise(S);
+        if (st == SELLA_E_UNSUPPORTED && S->pend_k > 0) S->count_step_on_exit = true;    // moved, learnt, diagonalised
+        SCHK(st);
+    }
     return SELLA_OK;
 }
 
@@ -414,7 +451,11 @@ extern "C" int sella_search_run(sella_search* S, double fmax, long steps, int* c
     if (!S->have_fg) SCHK(evaluate(S));
     if (fmax_now(S) < fmax) { *converged = 1; return SELLA_OK; }
     for (long it = 0; it < steps; ++it) {
-        SCHK(one_step(S));
+        const int st = one_step(S);
+        if (st != SELLA_OK) {
+            if (S->count_step_on_exit) { ++S->nsteps; S->count_step_on_exit = false; }
+            return st;
+        }
         ++S->nsteps;
         if (fmax_now(S) < fmax) { *converged = 1; return SELLA_OK; }
     }
@@ -459,6 +500,19 @@ extern "C" int sella_search_state(sella_search* S, double* x, double* g, double*
 // change owner — the search keeps none and cannot be run again.  mats[4] = B, Wt, Bsub, Wt_sub (SELLA_NO_MAT where absent);
 // ints[8] = r, r_sub, rows of Wt, rows of Wt_sub, B_stale, Bsub_stale, steps since the last diagonalisation, first_diag;
 // mu / mu_sub: at least `rows` entries each (may be NULL when the search has no Hessian / no view); *lam0.
+// Secant pairs of a diagonalisation that no longer fitted the structured form (SELLA_E_UNSUPPORTED from sella_search_run):
+// *k pairs, Sm / Ym (n x k) row-major (NULL: only the count).  The caller applies them as ONE block update
+// (ApproximateHessian.update, linalg.py:274-304) — then its state is what the reference's would be after PES.diag.
+extern "C" int sella_search_pending_pairs(sella_search* S, int* k, double* Sm, double* Ym) {
+    if (!S || !k) return SELLA_E_INVALID;
+    *k = S->pend_k;
+    if (S->pend_k > 0 && Sm && Ym) {
+        memcpy(Sm, S->pendS.data(), S->pendS.size() * sizeof(double));
+        memcpy(Ym, S->pendY.data(), S->pendY.size() * sizeof(double));
+    }
+    return SELLA_OK;
+}
+
 extern "C" int sella_search_release_hessian(sella_search* S, sella_mat* mats, long* ints, double* mu, double* mu_sub,
                                             double* lam0) {
     if (!S || !mats || !ints || !lam0) return SELLA_E_INVALID;

@@ -72,7 +72,10 @@ def run_one(atoms, fmax, steps, sella_kwargs):
                 atoms.positions = start                      # from the beginning with the general driver
             finally:
                 ls.close()
+    # the general driver: with the switch off, or for a search the library handed back (from the beginning).  Sella.run
+    # would otherwise hand a covered search to the library itself — so the two routes stay two routes.
     opt = Sella(atoms, **kw)
+    opt.use_library_loop = False
     conv = opt.run(fmax=fmax, steps=steps)
     pes = opt.pes
     f = pes.get_projected_forces()

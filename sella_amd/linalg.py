@@ -188,6 +188,13 @@ class ApproximateHessian(LinearOperator):
         self._drop_eig()
         self._lr = lr
 
+    def _drop_lr(self):
+        """Leave the structured form for good: its eigenvector block is returned to the device pool now (not whenever the
+        finalizer runs — it is capacity x dim doubles held exactly when the rank has grown to 0.4 dim)."""
+        lr, self._lr = self._lr, None
+        if lr is not None and lr.get('Wt') is not None:
+            lr['Wt'].free()
+
     # ---- structured eigendecomposition ---------------------------------------------------------------------------
     def device_eig_lr(self):
         """dict(Wt DeviceMatrix (capacity x dim, leading r rows = explicit eigenvectors), r, mu (ascending), lam0) if
@@ -371,7 +378,8 @@ class ApproximateHessian(LinearOperator):
                     lrs = sub._lr
                     if lrs is not None and not sub._lr_reserve(2 * S2.shape[1]):
                         sub._get_B_gpu()                      # (its matrix brought up to date while the decomposition exists)
-                        lrs = sub._lr = None                  # the view goes dense (eigh when next needed)
+                        sub._drop_lr()                        # the view goes dense (eigh when next needed)
+                        lrs = None
                     get_context().update_h_lr(dB, S2, Y2, self._lr, method=self.update_method, symm=self.symm,
                                               view=(sub._get_B_gpu(), idx, lrs))
                     sub._B = None
@@ -386,7 +394,7 @@ class ApproximateHessian(LinearOperator):
                 self.initialized = True
                 self._drop_dense_eig()
                 return
-            self._lr = None                                   # rank no longer low: dense from here on
+            self._drop_lr()                                   # rank no longer low: dense from here on
         if (need_eig or have_eig) and EIG_UPDATE_MAX_RANK > 0:
             # carry the eigendecomposition across the update (rank-one modifications on the device)
             # instead of paying a new eigh at the next step solve, linalg.py:174-231

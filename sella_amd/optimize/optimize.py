@@ -135,6 +135,13 @@ class Sella(Optimizer):
             if self._lib is None:
                 self._lib = LibrarySearch(self.atoms, **self._lib_kw)
             ls = self._lib
+            if not np.array_equal(np.asarray(self.atoms.positions, dtype=np.float64).ravel(), ls.positions_flat()):
+                # somebody moved the atoms between two runs: the library's geometry is no longer the truth.  The state
+                # comes back (the PES then notices the change through its state hash, like the reference's) and the
+                # general driver continues.
+                self._lib_authoritative = True
+                self._adopt()
+                return Optimizer.run(self, fmax=fmax, steps=steps)
             self.fmax = fmax
             self.max_steps = self.nsteps + steps
             before = (ls.nsteps, ls.one_call_steps)
@@ -158,6 +165,7 @@ class Sella(Optimizer):
         from ..linalg import ApproximateHessian
         ls, self._lib, self._lib_authoritative = self._lib, None, False
         pes = self._pes
+        pending = ls.pending_pairs()
         st = ls.release_hessian()
         pes.neval = ls.neval
         pes.curr.update(x=pes.get_x(), state_hash=pes._state_hash(), f=ls.energy, g=ls.gradient.copy())
@@ -178,6 +186,12 @@ class Sella(Optimizer):
                 sub._lr = dict(Wt=v['Wt'], r=v['r'], mu=v['mu'], lam0=Hd['lam0'])
                 sub._B_stale = v['stale']
                 H._view = (np.ascontiguousarray(v['idx'], dtype=np.int32), pes.get_Ufree(), sub, H.version)
+        if pending is not None:
+            # the library left in the middle of a diagonalisation (its block update exceeds the structured form): the
+            # force calls are spent and counted, the pairs come with the hand-over — applied here, this object is where
+            # the reference is after PES.diag (peswrapper.py:545-553)
+            pes.H.update(*pending)
+            self.pairs_adopted = pending[0].shape[1]
         ls.close()
 
     def initialize_pes(self, atoms, trajectory=None, order=1, eta=1e-4, constraints=None, v0=None,

@@ -142,6 +142,13 @@ class LibrarySearch:
         self.nsteps, self.neval, self.one_call_steps, self.rank, self.rank_view = (int(v) for v in cn[:5])
         self.initialized = bool(cn[5])
 
+    def positions_flat(self):
+        """The library's own copy of the geometry (3N)."""
+        x = np.empty(self._n)
+        sc, cn = np.zeros(5), (c_long * 6)()
+        check(_lib.lib().sella_search_state(self._h, ptr(x), None, ptr(sc), cn))
+        return x
+
     def run(self, fmax=0.05, steps=100000000):
         conv = c_int(0)
         try:
@@ -153,6 +160,17 @@ class LibrarySearch:
             raise
         self._sync()
         return bool(conv.value)
+
+    def pending_pairs(self):
+        """(S, Y) of a diagonalisation whose block update no longer fitted the structured form (the search then left the
+        library with `SearchLeftLibrary`), or None: the caller applies them to the Hessian it takes over."""
+        k = c_int(0)
+        check(_lib.lib().sella_search_pending_pairs(self._h, byref(k), None, None))
+        if k.value == 0:
+            return None
+        S, Y = np.empty((self._n, k.value)), np.empty((self._n, k.value))
+        check(_lib.lib().sella_search_pending_pairs(self._h, byref(k), ptr(S), ptr(Y)))
+        return S, Y
 
     def release_hessian(self):
         """Hand the approximate Hessian over (`sella_search_release_hessian`): -> dict(B, Wt, r, mu, lam0, stale, view=dict

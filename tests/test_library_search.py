@@ -1,7 +1,8 @@
 """`LibrarySearch` (sella_amd/search.py -> `sella_search_*`, csrc/search.hip): a whole `Sella(...).run()` inside the
 library — first-use diagonalisation through the library's own calculator, one-call optimizer steps, the reference's
 re-diagonalisation schedule — against the general driver on the same searches: same geometries, energies, radii,
-numbers of steps and force calls."""
+numbers of steps and force calls.  The general driver is `Sella` with `use_library_loop = False` (`Sella.run` would
+otherwise hand a covered search to the library itself and the comparison would be the library against itself)."""
 import numpy as np
 import pytest
 
@@ -32,6 +33,13 @@ def _model(ctx, n=120, seed=41, nneg=1):
 KW = dict(order=1, eta=1e-4, gamma=0.1, delta0=0.1, proj_trans=False)
 
 
+def general_driver(atoms, **kw):
+    from sella_amd import Sella
+    opt = Sella(atoms, logfile=None, **kw)
+    opt.use_library_loop = False
+    return opt
+
+
 @pytest.mark.parametrize('rs,nsteps_per_diag', [('tr', 3), pytest.param('ras', 2, marks=pytest.mark.emu_heavy)])
 def test_model_search_in_the_library(ctx, rs, nsteps_per_diag):
     from sella_amd import Sella
@@ -43,8 +51,9 @@ def test_model_search_in_the_library(ctx, rs, nsteps_per_diag):
     ls = LibrarySearch(a1, constraints=Constraints(a1), **kw)
     assert not ls.run(0.0, 5)
     assert ls.run(0.0, 4) is False and ls.nsteps == 9          # a search can be continued
-    opt = Sella(a2, constraints=Constraints(a2), logfile=None, **kw)
+    opt = general_driver(a2, constraints=Constraints(a2), **kw)
     opt.run(0.0, 9)
+    assert opt._lib is None
     assert (ls.nsteps, ls.neval) == (opt.nsteps, opt.pes.neval)
     assert a1.calc.ncalls == a2.calc.ncalls
     np.testing.assert_allclose(a1.positions, a2.positions, atol=1e-8)
@@ -68,8 +77,9 @@ def test_pinned_slab_search_in_the_library(ctx):
     start = a1.positions.copy()
     ls = LibrarySearch(a1, constraints=c1, nsteps_per_diag=2)
     ls.run(0.0, 7)
-    opt = Sella(a2, constraints=c2, logfile=None, nsteps_per_diag=2)
+    opt = general_driver(a2, constraints=c2, nsteps_per_diag=2)
     opt.run(0.0, 7)
+    assert opt._lib is None
     assert (ls.nsteps, ls.neval) == (opt.nsteps, opt.pes.neval)
     np.testing.assert_array_equal(a1.positions[pinned], start[pinned])
     np.testing.assert_allclose(a1.positions, a2.positions, atol=1e-9)
@@ -89,13 +99,65 @@ def test_minimisation_without_curvature_information(ctx):
     assert LibrarySearch.applies(a1, constraints=Constraints(a1), **kw)
     ls = LibrarySearch(a1, constraints=Constraints(a1), **kw)
     ls.run(0.0, 8)
-    opt = Sella(a2, constraints=Constraints(a2), logfile=None, **kw)
+    opt = general_driver(a2, constraints=Constraints(a2), **kw)
     opt.run(0.0, 8)
+    assert opt._lib is None
     assert (ls.nsteps, ls.neval) == (opt.nsteps, opt.pes.neval) == (8, 9)
     np.testing.assert_allclose(a1.positions, a2.positions, atol=1e-9)
     assert ls.energy == pytest.approx(opt.pes.get_f(), abs=1e-10) and ls.energy < 0.5 * float(a1.calc.energy_and_gradient(
         _model(ctx, nneg=0).positions)[0])
     assert ls.delta == pytest.approx(opt.delta, rel=1e-8) and ls.rho == pytest.approx(opt.rho, rel=1e-6)
+
+
+@pytest.mark.parametrize('kw,nneg', [
+    (dict(order=0, proj_trans=False, rs='ras'), 0),
+    (dict(KW, rs='ras', nsteps_per_diag=2), 1),
+    pytest.param(dict(KW, rs='tr', diag_every_n=3), 1, marks=pytest.mark.emu_heavy),
+    pytest.param(dict(KW, rs='tr', method='rfo'), 1, marks=pytest.mark.emu_heavy),
+    pytest.param(dict(KW, rs='tr', threepoint=True), 1, marks=pytest.mark.emu_heavy),
+], ids=['order0-ras', 'saddle-ras', 'diag_every_n', 'rfo', 'threepoint'])
+def test_library_branches_against_the_general_driver(ctx, kw, nneg):
+    """The branches of csrc/search.hip that no other comparison reaches, each against the general driver."""
+    from sella_amd.internal import Constraints
+    from sella_amd.search import LibrarySearch
+    a1, a2 = _model(ctx, nneg=nneg), _model(ctx, nneg=nneg)
+    assert LibrarySearch.applies(a1, constraints=Constraints(a1), **kw)
+    ls = LibrarySearch(a1, constraints=Constraints(a1), **kw)
+    ls.run(0.0, 7)
+    opt = general_driver(a2, constraints=Constraints(a2), **kw)
+    opt.run(0.0, 7)
+    assert opt._lib is None
+    assert (ls.nsteps, ls.neval) == (opt.nsteps, opt.pes.neval)
+    np.testing.assert_allclose(a1.positions, a2.positions, atol=1e-7)
+    assert ls.energy == pytest.approx(opt.pes.get_f(), abs=1e-8)
+    assert ls.delta == pytest.approx(opt.delta, rel=1e-7) and ls.rho == pytest.approx(opt.rho, rel=1e-4, abs=1e-6)
+    ls.close()
+
+
+@pytest.mark.emu_heavy
+def test_pinned_model_search_against_the_general_driver(ctx):
+    """Pinned coordinates (selection bases, principal-submatrix view) in the library loop against the general driver —
+    on the model PES, so that the comparison also runs in the emulation."""
+    from sella_amd.internal import Constraints
+    from sella_amd.search import LibrarySearch
+    a1, a2 = _model(ctx, n=180), _model(ctx, n=180)            # 162 free coordinates: room for the first update's rank
+    c1, c2 = Constraints(a1), Constraints(a2)
+    for i in range(6):
+        c1.fix_translation(i)
+        c2.fix_translation(i)
+    kw = dict(KW, rs='ras', nsteps_per_diag=2)
+    start = a1.positions.copy()
+    assert LibrarySearch.applies(a1, constraints=c1, **kw)
+    ls = LibrarySearch(a1, constraints=c1, **kw)
+    ls.run(0.0, 6)
+    opt = general_driver(a2, constraints=c2, **kw)
+    opt.run(0.0, 6)
+    assert opt._lib is None
+    assert (ls.nsteps, ls.neval) == (opt.nsteps, opt.pes.neval)
+    np.testing.assert_array_equal(a1.positions[:6], start[:6])
+    np.testing.assert_allclose(a1.positions, a2.positions, atol=1e-7)
+    assert ls.delta == pytest.approx(opt.delta, rel=1e-7)
+    ls.close()
 
 
 def test_library_search_says_what_it_covers(ctx):
@@ -183,3 +245,32 @@ def test_sella_run_hands_the_search_to_the_library_and_takes_it_back(ctx, pinned
     o3.run(0.0, 1)
     assert o3._lib is None
     o3.logfile.close()
+
+
+@pytest.mark.parametrize('n,nsteps', [pytest.param(120, 26, marks=pytest.mark.emu_heavy), (96, 6)],
+                         ids=['before-a-step', 'inside-a-diagonalisation'])
+def test_hand_over_at_the_rank_limit_keeps_the_reference_semantics(ctx, n, nsteps):
+    """The explicit rank of the structured Hessian reaches 0.4 n and the library hands the search back.  Nothing may be
+    lost on the way.  n = 120: the limit is reached by the quasi-Newton pairs of the steps — the hand-over happens
+    BEFORE a step, geometry and force-call count untouched.  n = 96: already the block of the first-use diagonalisation
+    (2 x 29 vectors) exceeds it — the force calls are spent, so its secant pairs come with the hand-over
+    (sella_search_pending_pairs) and the caller applies them.  Either way the run as a whole is the general driver's run:
+    same steps, force calls, geometry, radius."""
+    from sella_amd import Sella
+    from sella_amd.internal import Constraints
+    kw = dict(KW, rs='tr', nsteps_per_diag=3)
+    a1, a2 = _model(ctx, n=n), _model(ctx, n=n)
+    o1 = Sella(a1, constraints=Constraints(a1), logfile=None, **kw)
+    o2 = general_driver(a2, constraints=Constraints(a2), **kw)
+    o1.run(0.0, nsteps)
+    assert o1._lib is None                                   # the library did hand the search back before the end
+    if n == 120:
+        assert o1.fused_steps > 3 and getattr(o1, 'pairs_adopted', 0) == 0
+    else:
+        assert o1.pairs_adopted >= 24                        # the first diagonalisation's block, applied on the dense route
+    o2.run(0.0, nsteps)
+    assert (o1.nsteps, o1.pes.neval) == (o2.nsteps, o2.pes.neval) == (nsteps, o2.pes.neval)
+    assert a1.calc.ncalls == a2.calc.ncalls
+    np.testing.assert_allclose(a1.positions, a2.positions, atol=1e-6)
+    assert o1.delta == pytest.approx(o2.delta, rel=1e-6)
+    assert o1.nsteps_since_diag == o2.nsteps_since_diag

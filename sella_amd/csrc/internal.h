@@ -116,6 +116,7 @@ struct Options {
     long bd_dev_rr = 0;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 56) on the device by parallel cyclic
                              // Jacobi in one workgroup (davidson_block.hip).  Measured at k = 48: 456 us per solve against ~270 us
                              // for the host's tred2 / tql2 (session r03l: 1.16 against 0.85 ms per block iteration), hence off
+    long lr_chain = 1;       // 1: the O(n r) passes of the one-call step as five fused launches, merged coordinate kernels (lrstep.hip)
     long rs_batch = 1;       // 1: bisection phase of the restricted-step root find evaluates 15 trial alphas per round trip (stepper.hip)
 };
 
@@ -329,6 +330,10 @@ int emt_eval_resident(sella_ctx* c, int n, const double* pos, const double* par,
 // stepper.hip: step family on m modes = rows idx[0..m) of a device panel (gathered into matrices the stepper owns)
 int stepper_from_panel(sella_ctx* c, int kind, const double* src, int ld, const int* idx, int m, int n, const double* ev,
                        const double* gh, int order, sella_stepper** out);
+// the same without copies: the family reads the rows where they are (trust-region measure only; stepper.hip)
+int stepper_on_panel(sella_ctx* c, int kind, const double* src, int ld, const int* idx, int m, int n, const double* ev,
+                     const double* gh, int order, sella_stepper** out);
+void stepper_panel_scale(sella_stepper* st, int mode, double factor);      // mode's row is stored unnormalised: row * factor
 // the interpolating batched root search of sella_restricted_step instead of the reference's alpha schedule (sella_opt_step)
 void stepper_set_fast_search(sella_stepper* st, bool on);
 // lrstep.hip: the learn / adapt / propose step on structured decompositions with every decision on the device

@@ -33,6 +33,7 @@ namespace sella {
 namespace {
 
 constexpr int LR_DEV_MAX = 512;          // rows (r + 2) up to which the coordinate kernels are used
+constexpr int LR_SMALL = 128;            // ... and up to which they take their merged forms (fused chain)
 
 __device__ __forceinline__ double blk_sum(double v, double* red) {
     v = wave_sum64(v);
@@ -52,7 +53,7 @@ __device__ __forceinline__ double blk_max(double v, double* red) {
 // scalar slots of the workspace (doubles)
 enum { SC_M1 = 0, SC_M2, SC_JS, SC_SBS, SC_SIG1, SC_SIG2, SC_KEEP1, SC_KEEP2, SC_FAIL, SC_GPERP2 = 16, SC_N = 32 };
 // gram slots: host / device Gram of the input rows and of the residual rows
-enum { G_SS = 0, G_SY, G_YY, G_A11 = 8, G_A12, G_A22 = 11 };
+enum { G_SS = 0, G_SY, G_YY, G_A11 = 8, G_A12, G_A22 = 11, G_R0G = 12, G_R1G = 13 };
 
 struct PreArgs {
     int r, nr, ldr, mode;                 // mode 0: rows are (s, y) -> TS-BFGS; 1: rows are (u, z) themselves
@@ -62,9 +63,16 @@ struct PreArgs {
     int n;
     double lam0;
     double *sc, *ec, *UZ, *P, *D;
+    // fused chain: |row2|^2 arrives as per-workgroup partials of the clean-up launch (null: measured here), and the
+    // components of a third row g along the rows of E are assembled from dots the earlier launches left (eg, nr entries):
+    // CG = the negated W g (row 2 of C), R0.g / R1.g in the Gram block
+    const double* NP = nullptr;
+    int parts = 0;
+    const double* CG = nullptr;
+    double* eg = nullptr;
 };
 
-__global__ __launch_bounds__(256) void lr_pre_kernel(PreArgs a) {
+__device__ __forceinline__ void lr_pre_body(const PreArgs& a) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
@@ -80,9 +88,16 @@ __global__ __launch_bounds__(256) void lr_pre_kernel(PreArgs a) {
     // math.pyx:112-117 as gs.hip uses them): the row is zeroed and takes no part.
     const bool keep1 = ss > 0.0 && a11 > 1e-26 * ss;
     const double r11 = keep1 ? sqrt(a11) : 0.0;
-    double pr = 0.0;
-    for (int i = tid; i < a.n; i += 256) pr += a.row2[i] * a.row2[i];
-    const double rho2sq = blk_sum(pr, red);
+    double rho2sq;
+    double row2g = 0.0;
+    if (a.NP) {
+        rho2sq = 0.0;
+        for (int p = 0; p < a.parts; ++p) { rho2sq += a.NP[2 * p]; row2g += a.NP[2 * p + 1]; }
+    } else {
+        double pr = 0.0;
+        for (int i = tid; i < a.n; i += 256) pr += a.row2[i] * a.row2[i];
+        rho2sq = blk_sum(pr, red);
+    }
     const bool keep2 = yy > 0.0 && rho2sq > 1e-26 * yy;
     const double r22 = keep2 ? sqrt(rho2sq) : 0.0;
     const double inv22 = keep2 ? 1.0 / r22 : 0.0;
@@ -93,6 +108,16 @@ __global__ __launch_bounds__(256) void lr_pre_kernel(PreArgs a) {
         a.sc[SC_KEEP2] = keep2 ? 1.0 : 0.0;
         a.sc[SC_FAIL] = 0.0;
         a.sc[SC_GPERP2] = 0.0;
+    }
+    if (a.eg) {
+        // E g: along the old rows measured by the first launch; along e1 = R0 / r11 from the dot R0.g of the second sweep;
+        // along e2 as measured on the cleaned row itself by the clean-up launch
+        const double r0g = a.G[G_R0G];
+        for (int i = tid; i < r; i += 256) a.eg[i] = -a.CG[i];
+        if (tid == 0) {
+            a.eg[r] = keep1 ? r0g / r11 : 0.0;
+            a.eg[r + 1] = keep2 ? row2g * inv22 : 0.0;
+        }
     }
     auto Dof = [&](int i) { return i < r ? a.mu[i] : a.lam0; };
     auto s_of = [&](int i) { return i < r ? -(a.C[i] + a.C2[i]) : (i == r ? r11 : 0.0); };      // (C, C2: negated W x)
@@ -168,7 +193,11 @@ __global__ __launch_bounds__(256) void lr_pre_kernel(PreArgs a) {
     if (tid == 0) { a.sc[SC_SIG1] = sig[0]; a.sc[SC_SIG2] = sig[1]; }
 }
 
+__global__ __launch_bounds__(256) void lr_pre_kernel(PreArgs a) { lr_pre_body(a); }
+
 struct PlanArgs {
+    int fill = 0;                         // with `first`: Q is NOT initialised — the kernel writes the identity itself if (and
+                                          // only if) it has rotations to apply to it; lr_apply_kernel reads cnt[1] to know
     int nr, ldr, ldq, first;              // first: Q is the identity (z = p)
     const double* p;
     const double* sigma;                  // device scalar
@@ -182,7 +211,7 @@ struct PlanArgs {
 // LAPACK dlaed2's rules (a negligible weight; of two nearly equal poles one rotated out), the rotations applied to the
 // columns of Q, the compact secular problem.  A negative sigma is solved as -(-D + |sigma| z z^T).  The sequential part
 // (one thread walks the poles in order) works on LDS copies: a chain of dependent global loads costs ~0.5 us a link.
-__global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) {
+__device__ __forceinline__ void lr_plan_body(const PlanArgs& a) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
@@ -352,6 +381,10 @@ __global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) {
     }
     __syncthreads();
     const int K = sK, nrot = sRot, ndf = sNdf;
+    if (a.first && a.fill && nrot > 0) {
+        for (int e = tid; e < nr * a.ldq; e += 256) a.Q[e] = ((e / a.ldq) == (e % a.ldq)) ? 1.0 : 0.0;
+        __syncthreads();
+    }
     // rotations on column pairs of Q (x' = c x + s y, y' = c y - s x: the row rotations of eigh.hip, transposed)
     for (int q = 0; q < nrot; ++q) {
         const int c1 = sI1[q], c2 = sI2[q];
@@ -371,6 +404,16 @@ __global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) {
         a.wd[p] = sZ[sNd[p]];
     }
     for (int p = tid; p < ndf; p += 256) a.df[p] = sDf[p];
+}
+
+__global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) { lr_plan_body(a); }
+
+// the first term's plan needs nothing but what lr_pre_kernel leaves: one workgroup does both (what the first writes to
+// global memory is visible to the whole workgroup behind the barrier)
+__global__ __launch_bounds__(256) void lr_pre_plan_kernel(PreArgs pa, PlanArgs pl) {
+    lr_pre_body(pa);
+    __syncthreads();
+    lr_plan_body(pl);
 }
 
 struct WaveSum2 {
@@ -421,6 +464,9 @@ struct ApplyArgs {
     const double *pl, *Dd, *Dp, *zh, *tau, *lam;
     const double* Qin;
     double *Qout, *Dnext;
+    int first = 0;                              // Qin is the identity unless the plan had to rotate it (cnt[1] > 0): then never read
+    const double* wd = nullptr;                 // merged form: the Gu / Eisenstat weights are computed here, by every
+                                                // workgroup for itself (K <= LR_SMALL), instead of by a launch of their own
 };
 
 // Workgroup j: new eigenpair j of the term — an updated one (j < K: Gu/Eisenstat vector over the non-deflated columns)
@@ -428,8 +474,19 @@ struct ApplyArgs {
 __global__ __launch_bounds__(256) void lr_apply_kernel(ApplyArgs a) {
     __shared__ double red[4];
     __shared__ double u[LR_DEV_MAX];
+    __shared__ double zhs[LR_SMALL + 8];
     const int tid = threadIdx.x, nr = a.nr, j = blockIdx.x;
     const int K = a.cnt[0];
+    const bool ident = a.first && a.cnt[1] == 0;
+    if (a.wd && j < K) {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int i = wave; i < K; i += 4) {
+            const double z = secular::zhat(K, a.Dd, a.wd, a.tau, a.org, i, lane, 64, WaveProd2());
+            if (lane == 0) zhs[i] = z;
+        }
+        __syncthreads();
+    }
+    const double* zh = a.wd ? zhs : a.zh;
     const double sgn = a.pl[1];
     auto value = [&](int t) { return sgn * (t < K ? a.lam[t] : a.Dp[a.df[t - K]]); };
     const double vj = value(j);
@@ -442,17 +499,25 @@ __global__ __launch_bounds__(256) void lr_apply_kernel(ApplyArgs a) {
     if (tid == 0) a.Dnext[pos] = vj;
     if (j >= K) {
         const int src = a.df[j - K];
-        for (int k = tid; k < nr; k += 256) a.Qout[(size_t)k * a.ldq + pos] = a.Qin[(size_t)k * a.ldq + src];
+        if (ident) for (int k = tid; k < nr; k += 256) a.Qout[(size_t)k * a.ldq + pos] = (k == src) ? 1.0 : 0.0;
+        else for (int k = tid; k < nr; k += 256) a.Qout[(size_t)k * a.ldq + pos] = a.Qin[(size_t)k * a.ldq + src];
         return;
     }
     const double Do = a.Dd[a.org[j]], tj = a.tau[j];
     double ssq = 0.0;
     for (int i = tid; i < K; i += 256) {
-        const double ui = a.zh[i] / ((a.Dd[i] - Do) - tj);
+        const double ui = zh[i] / ((a.Dd[i] - Do) - tj);
         u[i] = ui;
         ssq += ui * ui;
     }
     const double inv = 1.0 / sqrt(blk_sum(ssq, red));
+    if (ident) {
+        // columns of the identity: row nd[i] of the new vector is u[i], every other row zero
+        for (int k = tid; k < nr; k += 256) a.Qout[(size_t)k * a.ldq + pos] = 0.0;
+        __syncthreads();
+        for (int i = tid; i < K; i += 256) a.Qout[(size_t)a.nd[i] * a.ldq + pos] = u[i] * inv;
+        return;
+    }
     for (int k = tid; k < nr; k += 256) {
         const double* row = a.Qin + (size_t)k * a.ldq;
         double acc = 0.0;
@@ -502,6 +567,249 @@ __global__ __launch_bounds__(256) void lr_proj2_kernel(const double* __restrict_
     R[ldr_ + i] += a1 + b1;
 }
 
+
+// ---- the fused chain (option lr_chain, default): the O(n r) passes of a job as five launches ----------------------------
+// Every pass works on chunks of 64 coordinates (lane = coordinate; the four wavefronts of a workgroup split the rows of W
+// four ways and meet in LDS): it applies the coefficients of the previous pass (summed from that pass's per-workgroup
+// partials, in a fixed order, by every workgroup itself) and leaves the partial dots the next pass needs.  So a
+// Gram-Schmidt sweep is ONE launch (projection + the dots of the next sweep) instead of two, and no launch exists only to
+// reduce something.  n / 64 workgroups: up to 64 x 64 = 4096 coordinates (larger jobs take the chain of round 3).
+constexpr int LR_CHUNK = 64;
+constexpr int LR_MAXPARTS = 64;           // workgroups of a pass
+// slots of a pass's scalar partials (GP[wg * 8 + k])
+enum { GP_A11 = 0, GP_A12, GP_A22, GP_R0G, GP_R1G };
+
+__device__ __forceinline__ double wave4_sum(double v, double (*xs)[LR_CHUNK]) {      // sum over the 4 wavefronts, per lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    xs[wave][lane] = v;
+    __syncthreads();
+    return (xs[0][lane] + xs[1][lane]) + (xs[2][lane] + xs[3][lane]);
+}
+// sum over all 256 threads of a per-lane value that is ALREADY the same in the four wavefronts' lanes (one wave sums)
+__device__ __forceinline__ double lanes_sum(double v) { return wave_sum64(v); }
+
+// rows j = wave, wave + 4, ... < nrows of W against this lane's coordinate: lincomb with two coefficient vectors
+__device__ __forceinline__ void rows_lincomb(const double* __restrict__ W, int ldw, int nrows, int cl, const double* c0,
+                                             const double* c1, double* p0, double* p1) {
+    const int wave = threadIdx.x >> 6;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    int j = wave;
+    for (; j + 4 < nrows; j += 8) {
+        const double w0 = W[(size_t)j * ldw + cl], w1 = W[(size_t)(j + 4) * ldw + cl];
+        a0 += c0[j] * w0;
+        b0 += c0[j + 4] * w1;
+        if (c1) { a1 += c1[j] * w0; b1 += c1[j + 4] * w1; }
+    }
+    if (j < nrows) {
+        const double w0 = W[(size_t)j * ldw + cl];
+        a0 += c0[j] * w0;
+        if (c1) a1 += c1[j] * w0;
+    }
+    *p0 = a0 + b0;
+    if (p1) *p1 = a1 + b1;
+}
+// out_h[j] = -sum_lanes W_j[c] x_h   for the rows of this wavefront (x1 unused when out1 is null)
+__device__ __forceinline__ void rows_dots(const double* __restrict__ W, int ldw, int nrows, int cl, bool valid, double x0,
+                                          double x1, double* out0, double* out1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < nrows; j += 8) {
+        const bool two = j + 4 < nrows;
+        const double wa = valid ? W[(size_t)j * ldw + cl] : 0.0;
+        const double wb = (valid && two) ? W[(size_t)(j + 4) * ldw + cl] : 0.0;
+        const double a0 = wave_sum64(wa * x0), b0 = wave_sum64(wb * x0);
+        double a1 = 0.0, b1 = 0.0;
+        if (out1) { a1 = wave_sum64(wa * x1); b1 = wave_sum64(wb * x1); }
+        if (lane == 0) {
+            out0[j] = -a0;
+            if (out1) out1[j] = -a1;
+            if (two) { out0[j + 4] = -b0; if (out1) out1[j + 4] = -b1; }
+        }
+    }
+}
+
+struct SweepArgs {
+    const double* W; int ldw, r, n;
+    const double* Cin; int parts, ldc;          // parts == 0: final coefficients Cin[h * ldc + j]; else Cin[(p * 2 + h) * ldc + j]
+    double* R; int ldr_;
+    double* Cout;                               // partial dots of the NEW rows: Cout[(wg * 2 + h) * ldc + j] (null: not wanted)
+    double* GP;                                 // scalar partials of the new rows (null: not wanted)
+    const double* g;                            // with GP: R_h . g as well (null: none)
+    double* Csum;                               // the coefficients applied here, summed (workgroup 0 writes them; null: not wanted)
+};
+
+__global__ __launch_bounds__(256) void lr_sweep_kernel(SweepArgs a) {
+    __shared__ double c0[LR_DEV_MAX], c1[LR_DEV_MAX], xs[4][LR_CHUNK];
+    const int tid = threadIdx.x, r = a.r, lane = tid & 63;
+    for (int j = tid; j < r; j += 256) {
+        if (a.parts == 0) {
+            c0[j] = a.Cin[j];
+            c1[j] = a.Cin[a.ldc + j];
+        } else {
+            double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+            int p = 0;
+            for (; p + 1 < a.parts; p += 2) {
+                s0 += a.Cin[(size_t)(2 * p) * a.ldc + j];
+                s1 += a.Cin[(size_t)(2 * p + 1) * a.ldc + j];
+                t0 += a.Cin[(size_t)(2 * p + 2) * a.ldc + j];
+                t1 += a.Cin[(size_t)(2 * p + 3) * a.ldc + j];
+            }
+            if (p < a.parts) { s0 += a.Cin[(size_t)(2 * p) * a.ldc + j]; s1 += a.Cin[(size_t)(2 * p + 1) * a.ldc + j]; }
+            c0[j] = s0 + t0;
+            c1[j] = s1 + t1;
+        }
+        if (a.Csum && blockIdx.x == 0) { a.Csum[j] = c0[j]; a.Csum[a.ldc + j] = c1[j]; }
+    }
+    const int c = blockIdx.x * LR_CHUNK + lane;
+    const bool valid = c < a.n;
+    const int cl = valid ? c : a.n - 1;
+    const double x0 = valid ? a.R[c] : 0.0, x1 = valid ? a.R[a.ldr_ + c] : 0.0;      // (in flight across the barrier)
+    __syncthreads();
+    double p0, p1;
+    rows_lincomb(a.W, a.ldw, r, cl, c0, c1, &p0, &p1);
+    const double sum0 = wave4_sum(p0, xs), sum1 = wave4_sum(p1, xs);
+    const double r0 = valid ? x0 + sum0 : 0.0;
+    const double r1 = valid ? x1 + sum1 : 0.0;
+    if (valid && tid < 64) { a.R[c] = r0; a.R[a.ldr_ + c] = r1; }
+    if (a.Cout)
+        rows_dots(a.W, a.ldw, r, cl, valid, r0, r1, a.Cout + (size_t)(2 * blockIdx.x) * a.ldc,
+                  a.Cout + (size_t)(2 * blockIdx.x + 1) * a.ldc);
+    if (a.GP && tid < 64) {
+        const double gv = (a.g && valid) ? a.g[c] : 0.0;
+        const double s11 = lanes_sum(r0 * r0), s12 = lanes_sum(r0 * r1), s22 = lanes_sum(r1 * r1);
+        const double s0g = lanes_sum(r0 * gv), s1g = lanes_sum(r1 * gv);
+        if (tid == 0) {
+            double* o = a.GP + 8 * blockIdx.x;
+            o[GP_A11] = s11; o[GP_A12] = s12; o[GP_A22] = s22; o[GP_R0G] = s0g; o[GP_R1G] = s1g;
+        }
+    }
+}
+
+struct ERowsArgs {
+    const double* W; int ldw, r, n;
+    const double* R; int ldr_;
+    const double* GP; int parts;                // scalar partials of the residual rows (from the second sweep)
+    double* G;                                  // Gram block: entries 0..2 given; G_A11.., G_R0G, G_R1G written by workgroup 0
+    double* Erow;                               // W + r * ldw: e1, then the second new row (unnormalised, before its clean-up)
+    double* C3part; int ldc;                    // partial clean-up dots of the second row against [W; e1]: r + 1 entries each
+};
+
+// e1 = R0 / |R0| and the second row R1 - (a12 / a11) R0 (what lr_e1_kernel writes), plus the partial dots of that
+// second row against [W; e1] — the clean-up sweep of lr_pre_kernel's comment, whose coefficients the next launch sums
+__global__ __launch_bounds__(256) void lr_erows_kernel(ERowsArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int c = blockIdx.x * LR_CHUNK + lane;
+    const bool valid = c < a.n;
+    const int cl = valid ? c : a.n - 1;
+    const double r0 = valid ? a.R[c] : 0.0, r1 = valid ? a.R[a.ldr_ + c] : 0.0;
+    double a11 = 0.0, a12 = 0.0, a22 = 0.0, r0g = 0.0, r1g = 0.0;
+    for (int p = 0; p < a.parts; ++p) {
+        const double* o = a.GP + 8 * p;
+        a11 += o[GP_A11]; a12 += o[GP_A12]; a22 += o[GP_A22]; r0g += o[GP_R0G]; r1g += o[GP_R1G];
+    }
+    const double ss = a.G[G_SS];
+    const bool keep1 = ss > 0.0 && a11 > 1e-26 * ss;
+    const double inv = keep1 ? 1.0 / sqrt(a11) : 0.0, f = keep1 ? a12 / a11 : 0.0;
+    const double e1 = r0 * inv, row2 = r1 - f * r0;
+    if (valid && tid < 64) { a.Erow[c] = e1; a.Erow[a.ldw + c] = row2; }
+    double* out = a.C3part + (size_t)blockIdx.x * a.ldc;
+    rows_dots(a.W, a.ldw, a.r, cl, valid, row2, 0.0, out, nullptr);
+    if (tid < 64) {
+        const double de = lanes_sum(e1 * row2);      // against e1 itself: its chunk is in registers, the row is being written here
+        if (tid == 0) out[a.r] = -de;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        a.G[G_A11] = a11; a.G[G_A12] = a12; a.G[G_A12 + 1] = a12; a.G[G_A22] = a22;
+        a.G[G_R0G] = r0g; a.G[G_R1G] = r1g;
+    }
+}
+
+struct CleanArgs {
+    const double* W; int ldw, r, n;             // rows 0..r (row r = e1)
+    const double* C3part; int parts, ldc;
+    double* row2;                               // W + (r + 1) * ldw
+    double* C3;                                 // summed coefficients (r + 1), written by workgroup 0
+    double* NP;                                 // partial |row2|^2 after the clean-up: NP[2 * wg]; NP[2 * wg + 1]: row2 . g
+    const double* g;                            // (null: none) — measured on the vector itself: R1.g - f R0.g cancels as badly as the norm
+};
+
+__global__ __launch_bounds__(256) void lr_clean_kernel(CleanArgs a) {
+    __shared__ double c3[LR_DEV_MAX + 8], xs[4][LR_CHUNK];
+    const int tid = threadIdx.x, nr1 = a.r + 1, lane = tid & 63;
+    for (int j = tid; j < nr1; j += 256) {
+        double s = 0.0, t = 0.0;
+        int p = 0;
+        for (; p + 1 < a.parts; p += 2) { s += a.C3part[(size_t)p * a.ldc + j]; t += a.C3part[(size_t)(p + 1) * a.ldc + j]; }
+        if (p < a.parts) s += a.C3part[(size_t)p * a.ldc + j];
+        c3[j] = s + t;
+        if (blockIdx.x == 0) a.C3[j] = s + t;
+    }
+    const int c = blockIdx.x * LR_CHUNK + lane;
+    const bool valid = c < a.n;
+    const int cl = valid ? c : a.n - 1;
+    const double x = valid ? a.row2[c] : 0.0;
+    __syncthreads();
+    double p0;
+    rows_lincomb(a.W, a.ldw, nr1, cl, c3, nullptr, &p0, nullptr);
+    const double sum = wave4_sum(p0, xs);
+    const double v = valid ? x + sum : 0.0;
+    if (tid < 64) {
+        if (valid) a.row2[c] = v;
+        const double gv = (a.g && valid) ? a.g[c] : 0.0;
+        const double s2 = lanes_sum(v * v), sg = lanes_sum(v * gv);
+        if (tid == 0) { a.NP[2 * blockIdx.x] = s2; a.NP[2 * blockIdx.x + 1] = sg; }
+    }
+}
+
+struct GperpArgs {
+    const double* Wnew; int ldw, nr, n;         // the nr new eigenvector rows; rows nr (g_perp) and nr + 1 (zero) are written here
+    const double* Q; int ldq;                   // final coordinates (columns = new eigenvectors)
+    const double* eg;                           // E g in coordinates (nr entries, lr_pre_kernel)
+    const double* g;
+    double* ghat;                               // -(Wnew g) = -(Q^T E g), written by workgroup 0
+    double* NPg;                                // partial |g_perp|^2
+};
+
+// components of the gradient along the new eigenvectors WITHOUT a pass over them (they are Q^T applied to the components
+// along the old rows, which the first launch of the job measured), then the part of g outside their span and its norm
+__global__ __launch_bounds__(256) void lr_gperp_kernel(GperpArgs a) {
+    __shared__ double se[LR_SMALL + 8], gh[LR_SMALL + 8], xs[4][LR_CHUNK];
+    const int tid = threadIdx.x, nr = a.nr, lane = tid & 63;
+    const int c = blockIdx.x * LR_CHUNK + lane;
+    const bool valid = c < a.n;
+    const int cl = valid ? c : a.n - 1;
+    const double gv = valid ? a.g[c] : 0.0;
+    for (int k = tid; k < nr; k += 256) se[k] = a.eg[k];
+    __syncthreads();
+    for (int i = tid; i < nr; i += 256) {
+        double a0 = 0.0, a1 = 0.0;
+        int k = 0;
+        for (; k + 1 < nr; k += 2) {
+            a0 += a.Q[(size_t)k * a.ldq + i] * se[k];
+            a1 += a.Q[(size_t)(k + 1) * a.ldq + i] * se[k + 1];
+        }
+        if (k < nr) a0 += a.Q[(size_t)k * a.ldq + i] * se[k];
+        const double v = -(a0 + a1);
+        gh[i] = v;
+        if (blockIdx.x == 0) a.ghat[i] = v;
+    }
+    __syncthreads();
+    double p0;
+    rows_lincomb(a.Wnew, a.ldw, nr, cl, gh, nullptr, &p0, nullptr);
+    const double sum = wave4_sum(p0, xs);
+    const double v = valid ? gv + sum : 0.0;
+    // (rows nr and nr + 1 of the panel: g_perp, and the zero row the weightless copies of the cluster point at; the
+    // padding columns of both are zeroed too — the launch covers the whole leading dimension)
+    if (tid < 64) {
+        if (c < a.ldw) {
+            ((double*)a.Wnew)[(size_t)nr * a.ldw + c] = v;
+            ((double*)a.Wnew)[(size_t)(nr + 1) * a.ldw + c] = 0.0;
+        }
+        const double s2 = lanes_sum(v * v);
+        if (tid == 0) a.NPg[blockIdx.x] = s2;
+    }
+}
+
 __global__ __launch_bounds__(256) void lr_identity_kernel(double* __restrict__ Q, int nr, int ldq) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < nr * ldq) Q[i] = ((i / ldq) == (i % ldq)) ? 1.0 : 0.0;
@@ -521,6 +829,7 @@ __global__ __launch_bounds__(256) void lr_scale_rows_kernel(const double* __rest
 struct LrWork {
     int nr, ldr, ldq;
     double *C, *C2, *C3, *G, *sc, *ec, *UZ, *P, *D0, *D1, *z, *Dp, *zz, *Dd, *wd, *tau, *zh, *lam, *cs, *pl, *mu, *ghat, *Qa, *Qb;
+    double *npg, *eg, *np, *gp, *cpart, *c3part;       // fused chain: partials of the passes (npg directly behind ghat: read back with it)
     int *perm, *nd, *df, *i1, *i2, *org, *cnt;
 };
 
@@ -529,19 +838,23 @@ static int lr_work(sella_ctx* c, int slot, int nr, LrWork& w) {
     w.ldr = round_up(nr + 2, 8);
     w.ldq = w.ldr;
     const size_t ldr = w.ldr;
-    const size_t ndbl = 3 * ldr + 3 * ldr + 16 + SC_N + 8 + 2 * ldr + 2 * ldr + 14 * ldr + 8 + 2 * ldr * ldr;
+    const size_t nchain = LR_MAXPARTS + ldr + 2 * LR_MAXPARTS + 8 * LR_MAXPARTS + 2 * LR_MAXPARTS * ldr + LR_MAXPARTS * ldr;
+    const size_t ndbl = 3 * ldr + 3 * ldr + 16 + SC_N + 8 + 2 * ldr + 2 * ldr + 14 * ldr + 8 + 2 * ldr * ldr + nchain;
     const size_t nint = 7 * ldr + 8;
     double* base;
     SCHK(scratch_get(c, slot, (ndbl + nint / 2 + 8) * sizeof(double), &base));
     double* p = base;
     auto take = [&](size_t k) { double* q = p; p += k; return q; };
     w.C = take(3 * ldr); w.C2 = take(2 * ldr); w.C3 = take(ldr); w.G = take(16); w.ec = take(8);
-    w.sc = take(SC_N); w.D0 = take(ldr); w.ghat = take(ldr);           // read back as ONE block: sc | D0 | ghat
+    w.sc = take(SC_N); w.D0 = take(ldr); w.ghat = take(ldr);           // read back as ONE block: sc | D0 | ghat | npg
+    w.npg = take(LR_MAXPARTS);
     w.UZ = take(2 * ldr); w.P = take(2 * ldr);
     w.D1 = take(ldr); w.z = take(ldr); w.Dp = take(ldr); w.zz = take(ldr); w.Dd = take(ldr);
     w.wd = take(ldr); w.tau = take(ldr); w.zh = take(ldr); w.lam = take(ldr); w.cs = take(2 * ldr); w.mu = take(ldr);
     w.pl = take(8);
     w.Qa = take(ldr * ldr); w.Qb = take(ldr * ldr);
+    w.eg = take(ldr); w.np = take(2 * LR_MAXPARTS); w.gp = take(8 * LR_MAXPARTS);
+    w.cpart = take(2 * LR_MAXPARTS * ldr); w.c3part = take(LR_MAXPARTS * ldr);
     int* ip = reinterpret_cast<int*>(p);
     w.perm = ip; w.nd = ip + ldr; w.df = ip + 2 * ldr; w.i1 = ip + 3 * ldr; w.i2 = ip + 4 * ldr; w.org = ip + 5 * ldr;
     w.cnt = ip + 6 * ldr;
@@ -573,8 +886,15 @@ struct LrJob {
     LrWork w;
     double* Wnew;
     int ldw;
-    std::vector<double> hout;          // sc | D | ghat as read back in one transfer
+    std::vector<double> hout;          // sc | D | ghat (| partials of |g_perp|^2) as read back in one transfer
     const double *hD, *hghat, *hsc;
+    int gparts = 0;                    // > 0: |g_perp|^2 = sum of that many partials behind ghat (fused chain)
+    double gperp2() const {
+        if (gparts == 0) return hsc[SC_GPERP2];
+        double s = 0.0;
+        for (int p = 0; p < gparts; ++p) s += hghat[w.ldr + p];
+        return s;
+    }
 };
 
 static int lr_job_queue(sella_ctx* c, LrJob& j) {
@@ -609,6 +929,38 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
     }
     // residual rows start as copies of the inputs
     if (!packed) SCHK(launch_axpby2d(c, 2, n, 1.0, j.Xd, j.ldx, 0.0, nullptr, 0, R, ld));
+    const int parts = (n + LR_CHUNK - 1) / LR_CHUNK;
+    const bool chain = c->opt.lr_chain && parts <= LR_MAXPARTS;
+    const bool small = chain && nr <= LR_SMALL;            // merged coordinate kernels
+    double* Erow = W + (size_t)r * ld;
+    if (chain) {
+        // ---- fused chain: dots, two sweeps, the new rows, their clean-up (five launches; see the kernels) ----------
+        const double* g = j.want_modes ? j.Xd + 2 * (size_t)j.ldx : nullptr;
+        if (r > 0) {
+            GemvEpi neg;
+            neg.alpha = -1.0;
+            const double* xs[3] = {R, R + ld, g};
+            SCHK(launch_gemv_rows_xp(c, W, r, n, ld, xs, g ? 3 : 2, w.C, w.ldr, neg));     // C (and the negated W g)
+        }
+        SweepArgs sw;
+        sw.W = W; sw.ldw = ld; sw.r = r; sw.n = n; sw.R = R; sw.ldr_ = ld; sw.ldc = w.ldr;
+        if (r > 0) {
+            sw.Cin = w.C; sw.parts = 0; sw.Cout = w.cpart; sw.GP = nullptr; sw.g = nullptr; sw.Csum = nullptr;
+            hipLaunchKernelGGL(lr_sweep_kernel, dim3(parts), dim3(256), 0, c->stream, sw);
+        }
+        sw.Cin = w.cpart; sw.parts = r > 0 ? parts : 0; sw.Cout = nullptr; sw.GP = w.gp; sw.g = g; sw.Csum = r > 0 ? w.C2 : nullptr;
+        if (r == 0) sw.Cin = w.C;                          // (never read: no rows)
+        hipLaunchKernelGGL(lr_sweep_kernel, dim3(parts), dim3(256), 0, c->stream, sw);
+        ERowsArgs er;
+        er.W = W; er.ldw = ld; er.r = r; er.n = n; er.R = R; er.ldr_ = ld; er.GP = w.gp; er.parts = parts; er.G = w.G;
+        er.Erow = Erow; er.C3part = w.c3part; er.ldc = w.ldr;
+        hipLaunchKernelGGL(lr_erows_kernel, dim3(parts), dim3(256), 0, c->stream, er);
+        CleanArgs cl;
+        cl.W = W; cl.ldw = ld; cl.r = r; cl.n = n; cl.C3part = w.c3part; cl.parts = parts; cl.ldc = w.ldr;
+        cl.row2 = Erow + ld; cl.C3 = w.C3; cl.NP = w.np; cl.g = g;
+        hipLaunchKernelGGL(lr_clean_kernel, dim3(parts), dim3(256), 0, c->stream, cl);
+        HIPCHK(hipGetLastError());
+    } else {
     if (r > 0) {
         // two classical Gram-Schmidt sweeps of both rows against W
         GemvEpi neg;                                  // C, C2 hold the NEGATED coefficients: lincomb adds them
@@ -622,7 +974,6 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
     // Gram of the residual rows: G[8 + h * 2 + i] = R_i . R_h -> a11 = G[8], a12 = G[9] (= G[10]), a22 = G[11]
     SCHK(launch_gemv_rows(c, R, 2, n, ld, R, ld, 2, w.G + G_A11, 2, GemvEpi()));
     // the two new rows of E, in place behind W: e1, and the second one after a clean-up sweep against [W; e1]
-    double* Erow = W + (size_t)r * ld;
     hipLaunchKernelGGL(lr_e1_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, R, ld, n, w.G, Erow, ld);
     HIPCHK(hipGetLastError());
     {
@@ -631,30 +982,41 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
         SCHK(launch_gemv_rows(c, W, r + 1, n, ld, Erow + ld, ld, 1, w.C3, w.ldr, neg));
         SCHK(launch_lincomb(c, n, 1, W, ld, r + 1, w.C3, 1, nullptr, 0, 0, nullptr, 0, 1.0, Erow + ld, ld));
     }
+    }
     PreArgs pa;
     pa.r = r; pa.nr = nr; pa.ldr = w.ldr; pa.mode = j.mode;
     pa.C = w.C; pa.C2 = w.C2; pa.C3 = w.C3; pa.G = w.G; pa.mu = w.mu; pa.lam0 = j.lam0;
     pa.row2 = Erow + ld; pa.n = n;
     pa.sc = w.sc; pa.ec = w.ec; pa.UZ = w.UZ; pa.P = w.P; pa.D = w.D0;
-    hipLaunchKernelGGL(lr_pre_kernel, dim3(1), dim3(256), 0, c->stream, pa);
-    HIPCHK(hipGetLastError());
+    if (chain) {
+        pa.NP = w.np; pa.parts = parts;
+        if (j.want_modes && small) { pa.CG = w.C + 2 * (size_t)w.ldr; pa.eg = w.eg; }
+    }
     // two rank-one terms in coordinates
-    hipLaunchKernelGGL(lr_identity_kernel, dim3((nr * w.ldq + 255) / 256), dim3(256), 0, c->stream, w.Qa, nr, w.ldq);
     double *Qin = w.Qa, *Qout = w.Qb, *Din = w.D0, *Dout = w.D1;
+    if (!chain) {
+        hipLaunchKernelGGL(lr_pre_kernel, dim3(1), dim3(256), 0, c->stream, pa);
+        hipLaunchKernelGGL(lr_identity_kernel, dim3((nr * w.ldq + 255) / 256), dim3(256), 0, c->stream, w.Qa, nr, w.ldq);
+        HIPCHK(hipGetLastError());
+    }
     for (int t = 0; t < 2; ++t) {
         PlanArgs pl;
-        pl.nr = nr; pl.ldr = w.ldr; pl.ldq = w.ldq; pl.first = (t == 0);
+        pl.nr = nr; pl.ldr = w.ldr; pl.ldq = w.ldq; pl.first = (t == 0); pl.fill = chain ? 1 : 0;
         pl.p = w.P + (size_t)t * w.ldr; pl.sigma = w.sc + SC_SIG1 + t; pl.Dcur = Din; pl.Q = Qin;
         pl.z = w.z; pl.Dp = w.Dp; pl.zz = w.zz; pl.Dd = w.Dd; pl.wd = w.wd; pl.cs = w.cs; pl.pl = w.pl;
         pl.perm = w.perm; pl.nd = w.nd; pl.df = w.df; pl.i1 = w.i1; pl.i2 = w.i2; pl.cnt = w.cnt;
-        hipLaunchKernelGGL(lr_plan_kernel, dim3(1), dim3(256), 0, c->stream, pl);
+        if (chain && t == 0) hipLaunchKernelGGL(lr_pre_plan_kernel, dim3(1), dim3(256), 0, c->stream, pa, pl);
+        else hipLaunchKernelGGL(lr_plan_kernel, dim3(1), dim3(256), 0, c->stream, pl);
         hipLaunchKernelGGL(lr_secular_kernel, dim3((nr + 3) / 4), dim3(256), 0, c->stream, w.cnt, w.pl, w.Dd, w.wd, w.tau,
                            w.org, w.lam, w.sc + SC_FAIL);
-        hipLaunchKernelGGL(lr_zhat_kernel, dim3((nr + 3) / 4), dim3(256), 0, c->stream, w.cnt, w.Dd, w.wd, w.tau, w.org,
-                           w.zh);
+        if (!small)
+            hipLaunchKernelGGL(lr_zhat_kernel, dim3((nr + 3) / 4), dim3(256), 0, c->stream, w.cnt, w.Dd, w.wd, w.tau, w.org,
+                               w.zh);
         ApplyArgs ap;
         ap.nr = nr; ap.ldq = w.ldq; ap.cnt = w.cnt; ap.nd = w.nd; ap.df = w.df; ap.org = w.org; ap.pl = w.pl;
         ap.Dd = w.Dd; ap.Dp = w.Dp; ap.zh = w.zh; ap.tau = w.tau; ap.lam = w.lam; ap.Qin = Qin; ap.Qout = Qout; ap.Dnext = Dout;
+        ap.first = (chain && t == 0) ? 1 : 0;
+        ap.wd = small ? w.wd : nullptr;
         hipLaunchKernelGGL(lr_apply_kernel, dim3(nr), dim3(256), 0, c->stream, ap);
         HIPCHK(hipGetLastError());
         std::swap(Qin, Qout);
@@ -663,8 +1025,19 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
     // (after two terms: Qin == Qa, Din == D0 again)
     // W+ = Q^T E on the matrix cores
     SCHK(launch_gemm(c, 1, 0, nr, n, nr, 1.0, Qin, w.ldq, W, ld, 0.0, j.Wnew, ld));
-    HIPCHK(hipMemsetAsync(j.Wnew + (size_t)nr * ld, 0, (size_t)2 * ld * sizeof(double), c->stream));
-    j.hout.assign((size_t)SC_N + 2 * w.ldr, 0.0);
+    j.hout.assign((size_t)SC_N + 2 * w.ldr + LR_MAXPARTS, 0.0);
+    j.gparts = 0;
+    if (j.want_modes && small) {
+        // components along the new eigenvectors in coordinates, g_perp and its norm: one launch (it also writes the zero row)
+        GperpArgs ga;
+        ga.Wnew = j.Wnew; ga.ldw = ld; ga.nr = nr; ga.n = n; ga.Q = Qin; ga.ldq = w.ldq; ga.eg = w.eg;
+        ga.g = j.Xd + 2 * (size_t)j.ldx; ga.ghat = w.ghat; ga.NPg = w.npg;
+        j.gparts = (ld + LR_CHUNK - 1) / LR_CHUNK;
+        if (j.gparts > LR_MAXPARTS) { set_error("structured update: too many chunks"); return SELLA_E_INVALID; }
+        hipLaunchKernelGGL(lr_gperp_kernel, dim3(j.gparts), dim3(256), 0, c->stream, ga);
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemsetAsync(j.Wnew + (size_t)nr * ld, 0, (size_t)2 * ld * sizeof(double), c->stream));
     if (j.want_modes) {
         const double* g = j.Xd + 2 * (size_t)j.ldx;
         GemvEpi e;
@@ -674,6 +1047,7 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
         SCHK(launch_axpby2d(c, 1, n, 1.0, g, j.ldx, 0.0, nullptr, 0, gp, ld));
         SCHK(launch_lincomb(c, n, 1, j.Wnew, ld, nr, w.ghat, 1, nullptr, 0, 0, nullptr, 0, 1.0, gp, ld));
         SCHK(launch_rows_sumsq(c, gp, ld, 1, n, w.sc + SC_GPERP2));
+    }
     }
     if (Din != w.D0) { set_error("structured update: eigenvalue buffers out of step"); return SELLA_E_INVALID; }
     SCHK(d2h_async(c, j.hout.data(), w.sc, j.hout.size() * sizeof(double)));
@@ -795,6 +1169,18 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled) {
                     view ? S.hsc[SC_FAIL] : 0.0);
         return SELLA_OK;
     }
+    if (getenv("SELLA_DEBUG_LR")) {
+        auto dump = [](const char* tag, const LrJob& j) {
+            const int nr = j.r + 2;
+            double sd = 0.0, sg = 0.0;
+            for (int i = 0; i < nr; ++i) { sd += j.hD[i] * (i + 1); sg += j.hghat[i] * j.hghat[i]; }
+            fprintf(stderr, "LR %s r=%d sumD=%.15e |ghat|^2=%.15e gp2=%.15e m1=%.15e m2=%.15e js=%.15e sBs=%.15e sig=%.15e %.15e keep=%g %g\n", tag, j.r, sd,
+                    sg, j.gperp2(), j.hsc[SC_M1], j.hsc[SC_M2], j.hsc[SC_JS], j.hsc[SC_SBS], j.hsc[SC_SIG1], j.hsc[SC_SIG2],
+                    j.hsc[SC_KEEP1], j.hsc[SC_KEEP2]);
+        };
+        dump("F", F);
+        if (view) dump("S", S);
+    }
     *handled = true;
     std::vector<int> keptF, keptS;
     SCHK(lr_job_commit(c, F, a->r, a->mu, keptF));
@@ -828,12 +1214,15 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled) {
     const int nd = J.n, nrj = J.r + 2, rn = (int)kept.size();
     double g2 = gg;
     if (view) { g2 = 0.0; for (double v : gsub) g2 += v * v; }
-    const double gp2 = J.hsc[SC_GPERP2];
+    const double gp2 = J.gperp2();
     const int ncl = nd - rn;
     const bool have_perp = ncl > 0 && gp2 > 0.0 && gp2 > 1e-26 * g2;
     double* gprow = J.Wnew + (size_t)nrj * J.ldw;
-    if (have_perp) SCHK(launch_scale_by(c, gprow, nd, J.w.sc + SC_GPERP2, 0));
-    else HIPCHK(hipMemsetAsync(gprow, 0, (size_t)J.ldw * sizeof(double), c->stream));
+    const bool on_panel = a->cons == 0 && c->opt.lr_chain;       // (see below: the family then reads the panel's rows in place)
+    if (have_perp && on_panel && J.gparts > 0) { /* the row stays unnormalised: its factor goes into the step's coefficient */ }
+    else if (have_perp && J.gparts > 0) SCHK(launch_axpby(c, nd, 1.0 / std::sqrt(gp2), gprow, 0.0, nullptr, gprow));
+    else if (have_perp) SCHK(launch_scale_by(c, gprow, nd, J.w.sc + SC_GPERP2, 0));
+    else if (!(on_panel && J.gparts > 0)) HIPCHK(hipMemsetAsync(gprow, 0, (size_t)J.ldw * sizeof(double), c->stream));
     const int ncopy = ncl > 0 ? std::min(a->order, ncl - 1) : 0;
     const int mm = rn + (ncl > 0 ? 1 : 0) + ncopy;
     std::vector<double> ev(mm), gh(mm);
@@ -850,7 +1239,15 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled) {
         while (i < rn) put(i++);
     }
     sella_stepper* st = nullptr;
-    SCHK(stepper_from_panel(c, a->stepper_kind, J.Wnew, J.ldw, idx.data(), mm, nd, ev.data(), gh.data(), a->order, &st));
+    // trust-region measure: the search runs in the eigenbasis on the host and the step is one launch over the panel's own
+    // rows; the per-atom measure evaluates trial steps on the device and gets the mode matrices
+    if (on_panel) {
+        SCHK(stepper_on_panel(c, a->stepper_kind, J.Wnew, J.ldw, idx.data(), mm, nd, ev.data(), gh.data(), a->order, &st));
+        if (have_perp && J.gparts > 0)
+            for (int q = 0; q < mm; ++q)
+                if (idx[q] == nrj) stepper_panel_scale(st, q, 1.0 / std::sqrt(gp2));
+    } else
+        SCHK(stepper_from_panel(c, a->stepper_kind, J.Wnew, J.ldw, idx.data(), mm, nd, ev.data(), gh.data(), a->order, &st));
     stepper_set_fast_search(st, c->opt.rs_fast != 0);
     const bool qn = a->stepper_kind == SELLA_STEP_QN;
     const double alpha0 = qn ? 0.0 : 1.0, alphamax = qn ? std::numeric_limits<double>::infinity() : 1.0;

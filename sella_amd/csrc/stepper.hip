@@ -29,6 +29,13 @@ struct sella_stepper {
     double t_host = 0.0, t_dev = 0.0;     // SELLA_DEBUG_TIMING: seconds in the secular solves / in the device round trip
     long calls = 0, sweeps = 0;
     bool fast_search = false;             // sella_opt_step: interpolating batched search instead of the reference's alpha schedule
+    // Panel form (stepper_on_panel): the modes are rows pidx[i] of a device panel somebody else owns, never gathered into
+    // matrices — enough for the search in the orthonormal eigenbasis (trust-region measure), whose only device work is
+    // the step itself at the final alpha: s = sum_i shat_i row_i, one launch.
+    const double* panel = nullptr;
+    int panel_ld = 0;
+    std::vector<int> pidx;
+    std::vector<double> pscale;           // factor of each row (1 unless the row is stored unnormalised)
 };
 
 namespace sella {
@@ -573,6 +580,31 @@ __global__ __launch_bounds__(1024) void rs_cons_kernel(int cons, int nout, const
 }  // namespace
 }  // namespace sella
 
+// s[c] = sum_i coef[i] * panel[idx[i] * ld + c]: the step of a family in panel form (coefficients and row indices arrive
+// in ONE transfer: m doubles, then m ints)
+__global__ __launch_bounds__(256) void rs_panel_step_kernel(const double* __restrict__ panel, int ld, int m, int n,
+                                                            const double* __restrict__ pack, double* __restrict__ out) {
+    __shared__ double sc[1024];
+    __shared__ int si[1024];
+    const int* idx = reinterpret_cast<const int*>(pack + m);
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int cl = c < n ? c : n - 1;
+    double a0 = 0.0, a1 = 0.0;
+    for (int i0 = 0; i0 < m; i0 += 1024) {
+        const int nb = m - i0 < 1024 ? m - i0 : 1024;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += 256) { sc[i] = pack[i0 + i]; si[i] = idx[i0 + i]; }
+        __syncthreads();
+        int i = 0;
+        for (; i + 1 < nb; i += 2) {
+            a0 += sc[i] * panel[(size_t)si[i] * ld + cl];
+            a1 += sc[i + 1] * panel[(size_t)si[i + 1] * ld + cl];
+        }
+        if (i < nb) a0 += sc[i] * panel[(size_t)si[i] * ld + cl];
+    }
+    if (c < n) out[c] = a0 + a1;
+}
+
 extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, const double* scons, const double* w,
                                      const double* d1, double alpha0, double alphamin, double alphamax, double slope,
                                      int newton_safe, int orthonormal, double tol, int maxiter, const int* sel,
@@ -590,8 +622,12 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         return SELLA_E_INVALID;
     }
     sella_ctx* c = st->c;
-    Mat* V = mat_get(c, st->V);
-    if (!V) return SELLA_E_INVALID;
+    Mat* V = st->panel ? nullptr : mat_get(c, st->V);
+    if (!V && !st->panel) return SELLA_E_INVALID;
+    if (st->panel && !(orthonormal && cons == 0 && !scons)) {
+        set_error("restricted_step: a family in panel form serves the trust-region measure in its orthonormal eigenbasis only");
+        return SELLA_E_INVALID;
+    }
     const int m = st->m;
     const int nfam = st->nout;                         // rows of the family's eigenvector matrix (m modes of length nfam;
                                                        // m < nfam for a structured eigendecomposition, sella_stepper_create_lr)
@@ -709,7 +745,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     // Candidates in heap order: node 1 = mid(lower, upper), node 2q = midpoint of the lower half of node q's bracket,
     // node 2q + 1 of its upper half; computed with the reference's own expression 0.5 * (lower + upper).
     constexpr int BATCH_LEVELS = 4, BATCH_NODES = (1 << BATCH_LEVELS) - 1;
-    const bool can_batch = !eig_only && !newton_safe && c->opt.rs_batch && (V->ld % 4 == 0) && m <= V->ld;
+    const bool can_batch = !eig_only && V && !newton_safe && c->opt.rs_batch && (V->ld % 4 == 0) && m <= V->ld;
     double* dbatch = nullptr;                  // lam | ghat | d1hat | X (16 x ld) | Y (16 x ldy) | inv
     int ldb = 0;
     bool batch_ready = false;
@@ -892,7 +928,18 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         }
     }
     // ---- the step at the final alpha ------------------------------------------------------------------------------
-    if (eig_only) {
+    if (eig_only && st->panel) {
+        // coefficients and row indices in one transfer, the step in one launch
+        std::vector<double> pack((size_t)m + (size_t)(m + 1) / 2 + 1, 0.0);
+        for (int i = 0; i < m; ++i) pack[i] = shat[i] * st->pscale[i];
+        memcpy(pack.data() + m, st->pidx.data(), (size_t)m * sizeof(int));
+        double* dpack;
+        SCHK(scratch_get(c, SCR_STEP2, pack.size() * sizeof(double), &dpack));
+        SCHK(h2d_async(c, dpack, pack.data(), pack.size() * sizeof(double)));
+        hipLaunchKernelGGL(rs_panel_step_kernel, dim3((nfam + 255) / 256), dim3(256), 0, c->stream, st->panel, st->panel_ld, m,
+                           nfam, dpack, dy);
+        HIPCHK(hipGetLastError());
+    } else if (eig_only) {
         if (pinned) {
             memcpy(hin, shat, (size_t)m * sizeof(double));
             HIPCHK(hipMemcpyAsync(dx, hin, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -900,6 +947,8 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
             SCHK(h2d_async(c, dx, shat, (size_t)m * sizeof(double)));
         }
         SCHK(launch_gemv_rows(c, V->d, nfam, m, V->ld, dx, ldx, 1, dy, ldy, GemvEpi()));
+    }
+    if (eig_only) {
         if (sel) {
             std::vector<double> sp(nfam);
             SCHK(d2h_async(c, sp.data(), dy, (size_t)nfam * sizeof(double)));
@@ -1015,6 +1064,30 @@ extern "C" int sella_stepper_create_lr(sella_ctx* c, int kind, sella_mat hWt, in
     std::vector<double> gh(m);
     for (int p = 0; p < m; ++p) gh[p] = idx[p] < r ? aw[idx[p]] : (idx[p] == r ? gperp : 0.0);
     return stepper_from_panel(c, kind, src, ld, idx.data(), m, n, ev.data(), gh.data(), order, out);
+}
+
+// Step family in panel form: modes = rows idx[i] of `src` (not copied: the panel must outlive the family), eigenvalues
+// ev, gradient components gh.  For sella_restricted_step with the trust-region measure only (see sella_stepper).
+int sella::stepper_on_panel(sella_ctx* c, int kind, const double* src, int ld, const int* idx, int m, int n, const double* ev,
+                            const double* gh, int order, sella_stepper** out) {
+    if (!c || !out || !src || !idx || !ev || !gh || m <= 0 || order < 0 || order > m || kind < SELLA_STEP_QN ||
+        kind > SELLA_STEP_PRFO) {
+        set_error("stepper: invalid arguments");
+        return SELLA_E_INVALID;
+    }
+    sella_stepper* st = new sella_stepper();
+    st->c = c; st->kind = kind; st->m = m; st->order = order; st->nout = n;
+    st->lam.assign(ev, ev + m);
+    st->ghat.assign(gh, gh + m);
+    st->panel = src; st->panel_ld = ld;
+    st->pidx.assign(idx, idx + m);
+    st->pscale.assign(m, 1.0);
+    *out = st;
+    return SELLA_OK;
+}
+
+void sella::stepper_panel_scale(sella_stepper* st, int mode, double factor) {
+    if (st && mode >= 0 && mode < (int)st->pscale.size()) st->pscale[mode] = factor;
 }
 
 void sella::stepper_set_fast_search(sella_stepper* st, bool on) {

@@ -76,8 +76,26 @@ class Context:
         self.device = int(device)
         self._owner = threading.get_ident()
         self._parked = []
+        # finalizers of the library objects created on this context (calculators, finite-difference operators, step
+        # families, searches): they hold a pointer to the context, so `close()` runs them BEFORE the context goes — an
+        # object that outlives its context (a test failure keeps frames alive until interpreter exit) then has nothing
+        # left to destroy instead of a dangling pointer
+        self._children = []
         # the finalizer holds only the raw handle: passing `self` would keep the context alive for ever
-        self._fin = weakref.finalize(self, L.sella_ctx_destroy, h)
+        self._fin = weakref.finalize(self, Context._destroy, self._children, h)
+
+    @staticmethod
+    def _destroy(children, h):
+        while children:
+            children.pop()()                    # newest first; weakref.finalize objects are idempotent
+        _lib.lib().sella_ctx_destroy(h)
+
+    def child(self, fin):
+        """Register the finalizer of an object that lives on this context; returns it."""
+        if len(self._children) > 256:
+            self._children[:] = [f for f in self._children if f.alive]
+        self._children.append(fin)
+        return fin
 
     def _drain(self):
         while self._parked:
@@ -515,7 +533,7 @@ class DeviceCalculator:
 
     def __init__(self, ctx, handle, keep=()):
         self.ctx, self._h, self._keep = ctx, handle, keep
-        self._fin = weakref.finalize(self, _lib.lib().sella_calc_destroy, handle)
+        self._fin = ctx.child(weakref.finalize(self, _lib.lib().sella_calc_destroy, handle))
 
     @classmethod
     def model(cls, ctx, A, U, c):
@@ -557,7 +575,7 @@ class DeviceFdOperator:
                                          None if self._free is None else self._free.ctypes.data_as(c_void_p),
                                          0 if self._free is None else len(self._free), byref(h)))
         self._h = h
-        self._fin = weakref.finalize(self, _lib.lib().sella_fd_destroy, h)
+        self._fin = calc.ctx.child(weakref.finalize(self, _lib.lib().sella_fd_destroy, h))
 
     def callback(self):
         """`sella_fd_matvec` as the `sella_matvec_fn` of `sella_davidson` (a function of the library itself)."""
@@ -646,7 +664,7 @@ class DeviceStepper:
             check(_lib.lib().sella_stepper_create(ctx._h, STEPPER_KINDS[kind], V.handle, Vt.handle,
                                                   ptr(evals), ptr(g), len(evals), int(order), byref(h)))
         self._h = h
-        self._fin = weakref.finalize(self, _lib.lib().sella_stepper_destroy, h)
+        self._fin = ctx.child(weakref.finalize(self, _lib.lib().sella_stepper_destroy, h))
 
     def get_s(self, alpha):
         s = np.empty(self.nout)

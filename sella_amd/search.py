@@ -128,7 +128,7 @@ class LibrarySearch:
         self._h, self._ctx, self._n = h, ctx, n
         check(_lib.lib().sella_search_seed(h, f0, ptr(g0)))
         # (finalizers run in reverse order of creation at interpreter exit: before the calculator's and the context's)
-        self._fin = weakref.finalize(self, _lib.lib().sella_search_destroy, h)
+        self._fin = ctx.child(weakref.finalize(self, _lib.lib().sella_search_destroy, h))
         self.nsteps = 0
         self._sync()
 

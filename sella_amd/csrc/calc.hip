@@ -30,9 +30,28 @@ struct sella_calc {
     std::vector<double> par, shifts;
     double rc = 0, acut = 0, cutoff = 0, beta = 0;
     std::vector<double> work;
-    double* dconst = nullptr;         // EMT: parameter table + shift vectors, resident
+    double* dconst = nullptr;         // EMT: parameter table + shift vectors, resident; model: the rows u_j (nu x ld)
     size_t dconst_bytes = 0;
 };
+
+namespace {
+// g_i = (A x)_i + sum_j c p_j^2 u_j[i],  p = U x: the gradient of the cubic terms, the rows u_j taken in order
+__global__ __launch_bounds__(256) void model_grad_kernel(int n, int nu, int ld, double cc, const double* __restrict__ Ax,
+                                                         const double* __restrict__ p, const double* __restrict__ U,
+                                                         double* __restrict__ g) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v = Ax[i];
+    for (int j = 0; j < nu; ++j) {
+        const double w = cc * p[j] * p[j];
+        v += w * U[(size_t)j * ld + i];
+    }
+    g[i] = v;
+}
+}  // namespace
 
 extern "C" int sella_calc_model_create(sella_ctx* c, sella_mat A, const double* U, int nu, int n, double cc, sella_calc** out) {
     Mat* a = mat_get(c, A);
@@ -44,8 +63,63 @@ extern "C" int sella_calc_model_create(sella_ctx* c, sella_mat A, const double* 
     k->c = c; k->kind = 0; k->n = n; k->A = A; k->nu = nu; k->cc = cc;
     k->U.assign(U, U + (size_t)nu * n);
     k->work.resize((size_t)n);
+    if (nu > 0) {
+        const int ld = round_up(n, 8);
+        k->dconst_bytes = ((size_t)nu + 2) * ld * sizeof(double);
+        int st = dev_alloc(c, k->dconst_bytes, &k->dconst);
+        if (st == SELLA_OK) st = hipMemsetAsync(k->dconst, 0, k->dconst_bytes, c->stream) == hipSuccess ? SELLA_OK : SELLA_E_HIP;
+        for (int j = 0; j < nu && st == SELLA_OK; ++j)
+            st = h2d_async(c, k->dconst + (size_t)j * ld, U + (size_t)j * n, (size_t)n * sizeof(double));
+        if (st == SELLA_OK) st = stream_wait(c);
+        if (st != SELLA_OK) { delete k; return st; }
+    }
     *out = k;
     return SELLA_OK;
+}
+
+int sella::calc_queue(sella_calc* k, const double* x, double** g_dev, double** aux_dev, int* naux) {
+    sella_ctx* c = k->c;
+    ++k->ncalls;
+    if (k->kind == 1) {
+        double *dea, *dgr;
+        SCHK(emt_queue(c, k->natoms, x, k->par.data(), k->nshift, k->shifts.data(), k->dconst, k->rc, k->acut, k->cutoff, k->beta,
+                       &dea, &dgr));
+        *g_dev = dgr;
+        *aux_dev = dea;
+        *naux = k->natoms;
+        return SELLA_OK;
+    }
+    const int n = k->n, ld = round_up(n, 8), nu = k->nu;
+    Mat* A = mat_get(c, k->A);
+    if (!A) return SELLA_E_INVALID;
+    double* buf;                                       // x | A x | p (8-padded) | g
+    const int ldp = round_up(nu > 0 ? nu : 1, 8);
+    SCHK(scratch_get(c, SCR_MISC0, ((size_t)3 * ld + ldp) * sizeof(double), &buf));
+    double *dx = buf, *dAx = buf + ld, *dp = buf + 2 * (size_t)ld, *dg = dp + ldp;
+    SCHK(h2d_async(c, dx, x, (size_t)n * sizeof(double)));
+    SCHK(launch_gemv_rows(c, A->d, n, n, A->ld, dx, ld, 1, dAx, ld, GemvEpi()));
+    if (nu > 0) SCHK(launch_gemv_rows(c, k->dconst, nu, n, ld, dx, ld, 1, dp, ldp, GemvEpi()));
+    hipLaunchKernelGGL(model_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, nu, ld, k->cc, dAx, dp, k->dconst, dg);
+    HIPCHK(hipGetLastError());
+    *g_dev = dg;
+    *aux_dev = dAx;                                    // A x (ld entries) then p: one read-back
+    *naux = ld + ldp;
+    return SELLA_OK;
+}
+
+double sella::calc_finish(sella_calc* k, const double* x, const double* aux) {
+    if (k->kind == 1) {
+        double e = 0.0;
+        for (int i = 0; i < k->natoms; ++i) e += aux[i];
+        return e;
+    }
+    const int n = k->n, ld = round_up(n, 8);
+    double e = 0.0;
+    for (int i = 0; i < n; ++i) e += x[i] * aux[i];
+    e *= 0.5;
+    double cub = 0.0;
+    for (int j = 0; j < k->nu; ++j) { const double p = aux[ld + j]; cub += p * p * p; }
+    return e + k->cc / 3.0 * cub;
 }
 
 extern "C" int sella_calc_emt_create(sella_ctx* c, int natoms, const double* par, int nshift, const double* shifts, double rc,
@@ -75,25 +149,15 @@ extern "C" int sella_calc_emt_create(sella_ctx* c, int natoms, const double* par
 // energy and gradient dE/dx at x (n entries)
 extern "C" int sella_calc_eval(sella_calc* k, const double* x, double* f, double* g) {
     if (!k || !x || !f || !g) return SELLA_E_INVALID;
-    ++k->ncalls;
-    if (k->kind == 1) return emt_eval_resident(k->c, k->natoms, x, k->par.data(), k->nshift, k->shifts.data(), k->dconst, k->rc,
-                                               k->acut, k->cutoff, k->beta, f, g);
-    const int n = k->n;
-    double* Ax = k->work.data();
-    SCHK(sella_symm_mm(k->c, k->A, x, 1, Ax));
-    double e = 0.0;
-    for (int i = 0; i < n; ++i) { e += x[i] * Ax[i]; g[i] = Ax[i]; }
-    e *= 0.5;
-    double cub = 0.0;
-    for (int j = 0; j < k->nu; ++j) {
-        const double* u = k->U.data() + (size_t)j * n;
-        double p = 0.0;
-        for (int i = 0; i < n; ++i) p += u[i] * x[i];
-        cub += p * p * p;
-        const double w = k->cc * p * p;
-        for (int i = 0; i < n; ++i) g[i] += w * u[i];
-    }
-    *f = e + k->cc / 3.0 * cub;
+    double *dg, *daux;
+    int naux = 0;
+    SCHK(calc_queue(k, x, &dg, &daux, &naux));
+    std::vector<double>& aux = k->work;
+    aux.resize((size_t)naux);
+    SCHK(d2h_async(k->c, aux.data(), daux, (size_t)naux * sizeof(double)));
+    SCHK(d2h_async(k->c, g, dg, (size_t)k->n * sizeof(double)));
+    SCHK(stream_wait(k->c));
+    *f = calc_finish(k, x, aux.data());
     return SELLA_OK;
 }
 

@@ -129,6 +129,25 @@ using namespace sella;
 int sella::emt_eval_resident(sella_ctx* c, int n, const double* pos, const double* par, int nshift, const double* shifts,
                              const double* dconst, double rc, double acut, double cutoff, double beta, double* energy,
                              double* grad) {
+    double *dea, *dgr;
+    SCHK(emt_queue(c, n, pos, par, nshift, shifts, dconst, rc, acut, cutoff, beta, &dea, &dgr));
+    // per-atom energies and the gradient sit back to back: one read-back
+    std::vector<double>& out = c->hbuf_b;
+    out.resize((size_t)4 * n);
+    SCHK(d2h_async(c, out.data(), dea, (size_t)4 * n * sizeof(double)));
+    SCHK(stream_wait(c));
+    double e = 0.0;
+    for (int i = 0; i < n; ++i) e += out[i];
+    *energy = e;
+    for (size_t i = 0; i < (size_t)3 * n; ++i) grad[i] = out[(size_t)n + i];
+    return SELLA_OK;
+}
+
+// the same up to the kernels: positions uploaded, three launches queued, nothing waited for.  *eatom (n per-atom
+// energies, summed by the caller in index order) and *grad (3 n, directly behind) stay valid until scratch slot
+// SCR_MISC0 is used again.
+int sella::emt_queue(sella_ctx* c, int n, const double* pos, const double* par, int nshift, const double* shifts,
+                     const double* dconst, double rc, double acut, double cutoff, double beta, double** eatom, double** grad) {
     const size_t words = (size_t)3 * n + (size_t)9 * n + (size_t)3 * nshift + (size_t)4 * n + (size_t)3 * n + 64;
     double* buf;
     SCHK(scratch_get(c, SCR_MISC0, words * sizeof(double), &buf));
@@ -159,15 +178,8 @@ int sella::emt_eval_resident(sella_ctx* c, int n, const double* pos, const doubl
     hipLaunchKernelGGL(emt_cohesive_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
     hipLaunchKernelGGL(emt_force_kernel, dim3(n), dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
-    // per-atom energies and the gradient sit back to back: one read-back
-    std::vector<double>& out = c->hbuf_b;
-    out.resize((size_t)4 * n);
-    SCHK(d2h_async(c, out.data(), dea, (size_t)4 * n * sizeof(double)));
-    SCHK(stream_wait(c));
-    double e = 0.0;
-    for (int i = 0; i < n; ++i) e += out[i];
-    *energy = e;
-    for (size_t i = 0; i < (size_t)3 * n; ++i) grad[i] = out[(size_t)n + i];
+    *eatom = dea;
+    *grad = dgr;
     return SELLA_OK;
 }
 

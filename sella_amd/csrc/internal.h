@@ -116,6 +116,7 @@ struct Options {
     long bd_dev_rr = 0;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 56) on the device by parallel cyclic
                              // Jacobi in one workgroup (davidson_block.hip).  Measured at k = 48: 456 us per solve against ~270 us
                              // for the host's tred2 / tql2 (session r03l: 1.16 against 0.85 ms per block iteration), hence off
+    long lr_pipe = 1;        // 1: the library search queues the force call in front of the update that consumes it: one wait for both (search.hip)
     long lr_chain = 1;       // 1: the O(n r) passes of the one-call step as five fused launches, merged coordinate kernels (lrstep.hip)
     long rs_batch = 1;       // 1: bisection phase of the restricted-step root find evaluates 15 trial alphas per round trip (stepper.hip)
 };
@@ -327,6 +328,13 @@ int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, M
 // emt.hip: sella_emt_eval with the parameter table and shift vectors optionally resident (dconst: 9 n + 3 nshift doubles)
 int emt_eval_resident(sella_ctx* c, int n, const double* pos, const double* par, int nshift, const double* shifts,
                       const double* dconst, double rc, double acut, double cutoff, double beta, double* energy, double* grad);
+int emt_queue(sella_ctx* c, int n, const double* pos, const double* par, int nshift, const double* shifts, const double* dconst,
+              double rc, double acut, double cutoff, double beta, double** eatom, double** grad);
+// calc.hip: a force call of a library calculator in two halves, so that what consumes the gradient can be queued behind
+// it without a wait in between.  calc_queue: x (host) uploaded, kernels queued; *g_dev = gradient on the device (n),
+// *aux_dev / *naux = what the energy is assembled from.  calc_finish: energy from the read-back aux values, after the wait.
+int calc_queue(sella_calc* k, const double* x, double** g_dev, double** aux_dev, int* naux);
+double calc_finish(sella_calc* k, const double* x, const double* aux_host);
 // stepper.hip: step family on m modes = rows idx[0..m) of a device panel (gathered into matrices the stepper owns)
 int stepper_from_panel(sella_ctx* c, int kind, const double* src, int ld, const int* idx, int m, int n, const double* ev,
                        const double* gh, int order, sella_stepper** out);
@@ -337,7 +345,20 @@ void stepper_panel_scale(sella_stepper* st, int mode, double factor);      // mo
 // the interpolating batched root search of sella_restricted_step instead of the reference's alpha schedule (sella_opt_step)
 void stepper_set_fast_search(sella_stepper* st, bool on);
 // lrstep.hip: the learn / adapt / propose step on structured decompositions with every decision on the device
-int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled);
+// `pipe` (optional): the force call at the new geometry has NOT been made yet — the step queues it on the stream in front
+// of the update that consumes its gradient and waits once for both (csrc/search.hip: no host round trip between force call
+// and update).  g_out (n) and f receive gradient and energy; a->g_new must point at g_out, a->f_new is set here.
+// done == false on return: the step did not qualify before anything was queued, the caller makes the force call itself.
+struct CalcPipe {
+    sella_calc* calc = nullptr;
+    const double* x = nullptr;
+    double* g_out = nullptr;
+    double f = 0.0;
+    bool done = false;
+};
+int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pipe = nullptr);
+// optstep.hip: sella_opt_step with the force call inside (see CalcPipe); *f_new receives the energy
+int opt_step_with_calc(sella_ctx* c, sella_opt_step_t* a, sella_calc* calc, const double* x, double* g_new, double* f_new);
 // batched NN GEMM for the merges of one divide-and-conquer level: batch b multiplies the diagonal blocks
 // at offset lo_b:  C[lo.., lo..] (K_b x N_b) = A[lo.., lo..] (K_b x K_b) * B[lo.., lo..] (K_b x N_b), all with
 // leading dimension ld.  desc (device): 4 ints per batch {lo, N, K, unused}.

@@ -692,6 +692,7 @@ struct ERowsArgs {
     double* G;                                  // Gram block: entries 0..2 given; G_A11.., G_R0G, G_R1G written by workgroup 0
     double* Erow;                               // W + r * ldw: e1, then the second new row (unnormalised, before its clean-up)
     double* C3part; int ldc;                    // partial clean-up dots of the second row against [W; e1]: r + 1 entries each
+    const double* SY = nullptr; int syparts = 0;    // pipelined force call: partials of s.y, y.y -> G[G_SY], G[G_YY] (workgroup 0)
 };
 
 // e1 = R0 / |R0| and the second row R1 - (a12 / a11) R0 (what lr_e1_kernel writes), plus the partial dots of that
@@ -702,11 +703,19 @@ __global__ __launch_bounds__(256) void lr_erows_kernel(ERowsArgs a) {
     const bool valid = c < a.n;
     const int cl = valid ? c : a.n - 1;
     const double r0 = valid ? a.R[c] : 0.0, r1 = valid ? a.R[a.ldr_ + c] : 0.0;
-    double a11 = 0.0, a12 = 0.0, a22 = 0.0, r0g = 0.0, r1g = 0.0;
-    for (int p = 0; p < a.parts; ++p) {
-        const double* o = a.GP + 8 * p;
-        a11 += o[GP_A11]; a12 += o[GP_A12]; a22 += o[GP_A22]; r0g += o[GP_R0G]; r1g += o[GP_R1G];
+    // the scalar partials of the second sweep: lane p of every wavefront fetches part p (parts <= 64), one wavefront-wide
+    // sum each — a fixed tree, the same in every workgroup
+    __shared__ double gs[8];
+    {
+        const double* o = a.GP + 8 * (lane < a.parts ? lane : 0);
+        const bool on = lane < a.parts;
+        const double t11 = wave_sum64(on ? o[GP_A11] : 0.0), t12 = wave_sum64(on ? o[GP_A12] : 0.0);
+        const double t22 = wave_sum64(on ? o[GP_A22] : 0.0), t0g = wave_sum64(on ? o[GP_R0G] : 0.0);
+        const double t1g = wave_sum64(on ? o[GP_R1G] : 0.0);
+        if (tid == 0) { gs[0] = t11; gs[1] = t12; gs[2] = t22; gs[3] = t0g; gs[4] = t1g; }
     }
+    __syncthreads();
+    const double a11 = gs[0], a12 = gs[1], a22 = gs[2], r0g = gs[3], r1g = gs[4];
     const double ss = a.G[G_SS];
     const bool keep1 = ss > 0.0 && a11 > 1e-26 * ss;
     const double inv = keep1 ? 1.0 / sqrt(a11) : 0.0, f = keep1 ? a12 / a11 : 0.0;
@@ -721,6 +730,12 @@ __global__ __launch_bounds__(256) void lr_erows_kernel(ERowsArgs a) {
     if (blockIdx.x == 0 && tid == 0) {
         a.G[G_A11] = a11; a.G[G_A12] = a12; a.G[G_A12 + 1] = a12; a.G[G_A22] = a22;
         a.G[G_R0G] = r0g; a.G[G_R1G] = r1g;
+        if (a.SY) {
+            double sy = 0.0, yy = 0.0;
+            for (int p = 0; p < a.syparts; ++p) { sy += a.SY[2 * p]; yy += a.SY[2 * p + 1]; }
+            a.G[G_SY] = sy;
+            a.G[G_YY] = yy;
+        }
     }
 }
 
@@ -810,6 +825,21 @@ __global__ __launch_bounds__(256) void lr_gperp_kernel(GperpArgs a) {
     }
 }
 
+// The secant pair formed on the device (pipelined force call): X1 holds g_old on entry; y = g - g_old -> X1 and X4, g -> X2;
+// per-workgroup partials of s.y and y.y -> SY[2 * wg], SY[2 * wg + 1] (lr_erows_kernel sums them into the Gram block)
+__global__ __launch_bounds__(256) void lr_secant_kernel(double* __restrict__ X, int ld, int n, const double* __restrict__ g,
+                                                        double* __restrict__ SY) {
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i < n;
+    const double gi = valid ? g[i] : 0.0;
+    const double y = valid ? gi - X[ld + i] : 0.0;
+    const double s = valid ? X[i] : 0.0;
+    if (valid) { X[ld + i] = y; X[2 * (size_t)ld + i] = gi; X[4 * (size_t)ld + i] = y; }
+    const double sy = blk_sum(s * y, red), yy = blk_sum(y * y, red);
+    if (threadIdx.x == 0) { SY[2 * blockIdx.x] = sy; SY[2 * blockIdx.x + 1] = yy; }
+}
+
 __global__ __launch_bounds__(256) void lr_identity_kernel(double* __restrict__ Q, int nr, int ldq) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < nr * ldq) Q[i] = ((i / ldq) == (i % ldq)) ? 1.0 : 0.0;
@@ -882,6 +912,8 @@ struct LrJob {
     double* Rpre = nullptr;
     double* mu_dev = nullptr;
     double* G_dev = nullptr;
+    const double* SY = nullptr;        // pipelined force call: partials of s.y, y.y still to be summed into the Gram block
+    int syparts = 0;
     // results
     LrWork w;
     double* Wnew;
@@ -953,7 +985,7 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
         hipLaunchKernelGGL(lr_sweep_kernel, dim3(parts), dim3(256), 0, c->stream, sw);
         ERowsArgs er;
         er.W = W; er.ldw = ld; er.r = r; er.n = n; er.R = R; er.ldr_ = ld; er.GP = w.gp; er.parts = parts; er.G = w.G;
-        er.Erow = Erow; er.C3part = w.c3part; er.ldc = w.ldr;
+        er.Erow = Erow; er.C3part = w.c3part; er.ldc = w.ldr; er.SY = j.SY; er.syparts = j.syparts;
         hipLaunchKernelGGL(lr_erows_kernel, dim3(parts), dim3(256), 0, c->stream, er);
         CleanArgs cl;
         cl.W = W; cl.ldw = ld; cl.r = r; cl.n = n; cl.C3part = w.c3part; cl.parts = parts; cl.ldc = w.ldr;
@@ -1009,14 +1041,16 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
         else hipLaunchKernelGGL(lr_plan_kernel, dim3(1), dim3(256), 0, c->stream, pl);
         hipLaunchKernelGGL(lr_secular_kernel, dim3((nr + 3) / 4), dim3(256), 0, c->stream, w.cnt, w.pl, w.Dd, w.wd, w.tau,
                            w.org, w.lam, w.sc + SC_FAIL);
-        if (!small)
-            hipLaunchKernelGGL(lr_zhat_kernel, dim3((nr + 3) / 4), dim3(256), 0, c->stream, w.cnt, w.Dd, w.wd, w.tau, w.org,
+        // (the Gu / Eisenstat weights computed by every apply workgroup for itself were measured: the apply kernel grows by
+        // more than the launch saves — 11.7 / 14.8 us against 6.5 + 4.5 — so they keep their launch; ApplyArgs::wd stays as
+        // the switch)
+        hipLaunchKernelGGL(lr_zhat_kernel, dim3((nr + 3) / 4), dim3(256), 0, c->stream, w.cnt, w.Dd, w.wd, w.tau, w.org,
                                w.zh);
         ApplyArgs ap;
         ap.nr = nr; ap.ldq = w.ldq; ap.cnt = w.cnt; ap.nd = w.nd; ap.df = w.df; ap.org = w.org; ap.pl = w.pl;
         ap.Dd = w.Dd; ap.Dp = w.Dp; ap.zh = w.zh; ap.tau = w.tau; ap.lam = w.lam; ap.Qin = Qin; ap.Qout = Qout; ap.Dnext = Dout;
         ap.first = (chain && t == 0) ? 1 : 0;
-        ap.wd = small ? w.wd : nullptr;
+        ap.wd = nullptr;
         hipLaunchKernelGGL(lr_apply_kernel, dim3(nr), dim3(256), 0, c->stream, ap);
         HIPCHK(hipGetLastError());
         std::swap(Qin, Qout);
@@ -1088,7 +1122,7 @@ static int lr_job_commit(sella_ctx* c, LrJob& j, int* r_io, double* mu, std::vec
 
 // The fast form of sella_opt_step (optstep.hip): TS-BFGS, one secant pair, structured decompositions small enough for
 // the coordinate kernels.  *handled = false: nothing was changed and the caller takes the general route.
-int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled) {
+int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pipe) {
     *handled = false;
     const int n = a->n;
     const bool view = a->idx != nullptr && a->m > 0;
@@ -1099,20 +1133,31 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled) {
     if (!Wm || Wm->cols != n || Wm->rows < *a->r + 4 || (view && (!Ws || Ws->cols != a->m || Ws->rows < *a->r_sub + 4)))
         return SELLA_OK;
     const bool propose = (a->flags & SELLA_OPT_PROPOSE) != 0;
+    const int ld = round_up(n, 8);
+    // pipelined force call: only where the secant pair can be formed on the device (fused chain, packed staging)
+    const bool piped = pipe && pipe->calc && c->opt.lr_chain && c->opt.lr_pipe && Wm->ld == ld &&
+                       (n + 63) / 64 <= LR_MAXPARTS && (n + 255) / 256 <= LR_MAXPARTS;
     // host side of the secant pair
     std::vector<double>& y = c->hbuf_a;
     y.resize((size_t)n);
     double gram[3] = {0.0, 0.0, 0.0}, gd = 0.0, gg = 0.0;
     for (int i = 0; i < n; ++i) {
-        y[i] = a->g_new[i] - a->g_old[i];
         gram[0] += a->dx[i] * a->dx[i];
-        gram[1] += a->dx[i] * y[i];
-        gram[2] += y[i] * y[i];
         gd += a->g_old[i] * a->dx[i];
-        gg += a->g_new[i] * a->g_new[i];
+    }
+    if (!piped) {
+        if (pipe && pipe->calc) return SELLA_OK;                    // (the caller makes the force call and comes back)
+        for (int i = 0; i < n; ++i) {
+            y[i] = a->g_new[i] - a->g_old[i];
+            gram[1] += a->dx[i] * y[i];
+            gram[2] += y[i] * y[i];
+            gg += a->g_new[i] * a->g_new[i];
+        }
     }
     if (!(std::sqrt(gram[0]) >= 1e-8)) return SELLA_OK;             // B is left alone: the general route knows how
-    const int ld = round_up(n, 8);
+    double *gdev = nullptr, *auxdev = nullptr;
+    int naux = 0;
+    std::vector<double> auxh;
     // ONE transfer for everything the full-space job reads from the host: the rows s, y, g; s, y again as the residual
     // rows the two sweeps work on; the eigenvalues; the Gram entries of (s, y)
     const int ldmu = round_up(*a->r + 2, 8);
@@ -1123,17 +1168,36 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled) {
         std::vector<double>& hs = c->hbuf_b;
         hs.assign(nstage, 0.0);
         std::copy(a->dx, a->dx + n, hs.begin());
-        std::copy(y.begin(), y.end(), hs.begin() + ld);
-        std::copy(a->g_new, a->g_new + n, hs.begin() + 2 * (size_t)ld);
+        if (piped) {
+            std::copy(a->g_old, a->g_old + n, hs.begin() + ld);      // becomes y on the device (lr_secant_kernel)
+        } else {
+            std::copy(y.begin(), y.end(), hs.begin() + ld);
+            std::copy(a->g_new, a->g_new + n, hs.begin() + 2 * (size_t)ld);
+            std::copy(y.begin(), y.end(), hs.begin() + 4 * (size_t)ld);
+        }
         std::copy(a->dx, a->dx + n, hs.begin() + 3 * (size_t)ld);
-        std::copy(y.begin(), y.end(), hs.begin() + 4 * (size_t)ld);
         std::copy(a->mu, a->mu + *a->r, hs.begin() + 5 * (size_t)ld);
         std::copy(gram, gram + 3, hs.begin() + 5 * (size_t)ld + ldmu);
         SCHK(h2d_async(c, X, hs.data(), nstage * sizeof(double)));
     }
+    if (piped) {
+        // the force call: queued behind the staging transfer, nothing waited for — the host goes on queueing the update
+        // while the calculator's kernels run
+        SCHK(calc_queue(pipe->calc, pipe->x, &gdev, &auxdev, &naux));
+        auxh.resize((size_t)naux);
+    }
     LrJob F;
     F.Wt = Wm; F.r = *a->r; F.n = n; F.mode = 0; F.mu = a->mu; F.lam0 = a->lam0; F.Xd = X; F.ldx = ld; F.gram = gram;
     if (Wm->ld == ld) { F.Rpre = X + 3 * (size_t)ld; F.mu_dev = X + 5 * (size_t)ld; F.G_dev = F.mu_dev + ldmu; }
+    double* SYp = nullptr;
+    if (piped) {
+        const int syparts = (n + 255) / 256;
+        SCHK(scratch_get(c, SCR_UPD3, (size_t)2 * LR_MAXPARTS * sizeof(double), &SYp));
+        hipLaunchKernelGGL(lr_secant_kernel, dim3(syparts), dim3(256), 0, c->stream, X, ld, n, gdev, SYp);
+        HIPCHK(hipGetLastError());
+        F.SY = SYp;
+        F.syparts = syparts;
+    }
     F.want_modes = propose && !view; F.slot_ws = SCR_EIG0; F.slot_panel = SCR_EIG1;
     SCHK(lr_job_queue(c, F));
     LrJob S;
@@ -1151,13 +1215,32 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled) {
         hipLaunchKernelGGL(lr_gather_cols_kernel, dim3((m + 255) / 256, 2), dim3(256), 0, c->stream, UZp, ld, 2, didx, m, Xs, lds);
         HIPCHK(hipGetLastError());
         gsub.resize((size_t)m);
-        for (int q = 0; q < m; ++q) gsub[q] = a->g_new[a->idx[q]];
-        SCHK(h2d_async(c, Xs + 2 * (size_t)lds, gsub.data(), (size_t)m * sizeof(double)));
+        if (piped) {                                                   // the gradient is still on its way: gathered on the device
+            hipLaunchKernelGGL(lr_gather_cols_kernel, dim3((m + 255) / 256, 1), dim3(256), 0, c->stream, X + 2 * (size_t)ld, ld, 1,
+                               didx, m, Xs + 2 * (size_t)lds, lds);
+            HIPCHK(hipGetLastError());
+        } else {
+            for (int q = 0; q < m; ++q) gsub[q] = a->g_new[a->idx[q]];
+            SCHK(h2d_async(c, Xs + 2 * (size_t)lds, gsub.data(), (size_t)m * sizeof(double)));
+        }
         S.Wt = Ws; S.r = *a->r_sub; S.n = m; S.mode = 1; S.mu = a->mu_sub; S.lam0 = a->lam0; S.Xd = Xs; S.ldx = lds;
         S.gram = nullptr; S.want_modes = propose; S.slot_ws = SCR_EIG2; S.slot_panel = SCR_EIG3;
         SCHK(lr_job_queue(c, S));
     }
+    if (piped) {
+        // gradient and energy terms come back with the results of the update, delivered by the one wait
+        SCHK(d2h_async(c, pipe->g_out, X + 2 * (size_t)ld, (size_t)n * sizeof(double)));
+        SCHK(d2h_async(c, auxh.data(), auxdev, (size_t)naux * sizeof(double)));
+    }
     SCHK(stream_wait(c));
+    if (piped) {
+        // the force call is complete whatever becomes of the update
+        pipe->f = calc_finish(pipe->calc, pipe->x, auxh.data());
+        pipe->done = true;
+        a->f_new = pipe->f;
+        for (int i = 0; i < n; ++i) gg += pipe->g_out[i] * pipe->g_out[i];
+        if (view) for (int q = 0; q < a->m; ++q) gsub[q] = pipe->g_out[a->idx[q]];
+    }
     auto sound = [](const LrJob& j) {
         if (j.hsc[SC_FAIL] != 0.0) return false;
         for (int i = 0; i < j.r + 2; ++i) if (!(j.hD[i] == j.hD[i])) return false;

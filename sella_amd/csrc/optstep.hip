@@ -34,10 +34,10 @@ Family family_of(int kind) {
 
 }  // namespace
 
+static int opt_step_general(sella_ctx* c, sella_opt_step_t* a);
+
 extern "C" int sella_opt_step(sella_ctx* c, sella_opt_step_t* a) {
     if (!c || !a || a->n <= 0 || !a->r || !a->mu) return SELLA_E_INVALID;
-    const int n = a->n;
-    const bool view = a->idx != nullptr && a->m > 0;
     a->ratio_valid = 0;
     a->updated = 0;
     a->nrank1 = a->nrank1_sub = 0;
@@ -48,6 +48,39 @@ extern "C" int sella_opt_step(sella_ctx* c, sella_opt_step_t* a) {
         SCHK(lr_fused_step(c, a, &handled));
         if (handled) return SELLA_OK;
     }
+    return opt_step_general(c, a);
+}
+
+// The same with the force call at the new geometry INSIDE (csrc/search.hip): where the fast form applies, the calculator's
+// kernels are queued in front of the update that consumes their gradient and the host waits once for both; otherwise
+// the force call is made here and the step proceeds as sella_opt_step.  g_new (n) and *f_new receive gradient and energy.
+int sella::opt_step_with_calc(sella_ctx* c, sella_opt_step_t* a, sella_calc* calc, const double* x, double* g_new,
+                              double* f_new) {
+    if (!c || !a || !calc || !x || !g_new || !f_new || a->n <= 0 || !a->r || !a->mu) return SELLA_E_INVALID;
+    a->ratio_valid = 0;
+    a->updated = 0;
+    a->nrank1 = a->nrank1_sub = 0;
+    a->nalpha = 0;
+    a->g_new = g_new;
+    CalcPipe pipe;
+    pipe.calc = calc; pipe.x = x; pipe.g_out = g_new;
+    bool handled = false;
+    SCHK(lr_fused_step(c, a, &handled, &pipe));
+    if (pipe.done) {
+        *f_new = pipe.f;
+        if (handled) return SELLA_OK;
+    } else {
+        SCHK(sella_calc_eval(calc, x, f_new, g_new));
+        a->f_new = *f_new;
+        SCHK(lr_fused_step(c, a, &handled));
+        if (handled) return SELLA_OK;
+    }
+    return opt_step_general(c, a);
+}
+
+static int opt_step_general(sella_ctx* c, sella_opt_step_t* a) {
+    const int n = a->n;
+    const bool view = a->idx != nullptr && a->m > 0;
     // general route: the one-phase entry points in sequence.  They update the dense matrices in place: rebuild them
     // first if they lag behind the decompositions.
     if (a->flags & SELLA_OPT_LEARN) {

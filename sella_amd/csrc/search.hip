@@ -276,7 +276,7 @@ bool wants_diagonalisation(const sella_search* S) {
     return false;
 }
 
-int call_opt_step(sella_search* S, int flags, double f_old) {
+int call_opt_step(sella_search* S, int flags, double f_old, bool with_calc = false) {
     sella_opt_step_t& a = S->io;
     const bool pins = !S->idx.empty();
     if ((flags & SELLA_OPT_LEARN) || pins) SCHK(ensure_view(S));
@@ -302,7 +302,14 @@ int call_opt_step(sella_search* S, int flags, double f_old) {
     a.stepper_kind = S->p.stepper_kind; a.order = S->p.order; a.cons = S->p.cons; a.maxiter = 1000;
     a.tol = S->p.stepper_kind == SELLA_STEP_QN ? 1e-10 : 1e-15;
     a.s_out = S->s.data();
-    SCHK(sella_opt_step(S->c, &a));
+    if (with_calc) {
+        // the force call at S->x rides in front of the update (optstep.hip: one wait for both where the fast form applies)
+        SCHK(opt_step_with_calc(S->c, &a, S->calc, S->x.data(), S->g.data(), &S->f));
+        ++S->neval;
+        S->have_fg = true;
+    } else {
+        SCHK(sella_opt_step(S->c, &a));
+    }
     S->B_stale = a.B_stale;
     S->Bsub_stale = a.Bsub_stale;
     if (flags & SELLA_OPT_LEARN) { S->delta = a.delta; S->rho = a.rho; ++S->nfused; }
@@ -403,9 +410,8 @@ int one_step(sella_search* S) {
         S->dx[i] = S->target[i] - S->x[i];
     }
     S->x = S->target;
-    SCHK(evaluate(S));
     S->have_step = false;
-    SCHK(call_opt_step(S, SELLA_OPT_LEARN | (rediag ? 0 : SELLA_OPT_PROPOSE), f_old));
+    SCHK(call_opt_step(S, SELLA_OPT_LEARN | (rediag ? 0 : SELLA_OPT_PROPOSE), f_old, true));
     if (rediag) {
         const int st = diagonalise(S);
         if (st == SELLA_E_UNSUPPORTED && S->pend_k > 0) S->count_step_on_exit = true;    // moved, learnt, diagonalised

@@ -40,8 +40,9 @@ if __name__ == '__main__':
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     ctx = _dev.get_context()
     for name, make in (('model PES 3N=%d' % n, lambda: model(ctx, n)), ('EMT slab 1024 atoms', slab)):
-        for chain in (1, 0, 1, 0):
+        for chain, pipe in ((1, 1), (1, 0), (0, 0), (1, 1), (1, 0), (0, 0)):
             ctx.set_option('lr_chain', chain)
+            ctx.set_option('lr_pipe', pipe)
             opt = make()
             opt.run(fmax=0.0, steps=3)
             ctx.sync()
@@ -49,5 +50,5 @@ if __name__ == '__main__':
             opt.run(fmax=0.0, steps=steps)
             ctx.sync()
             dt = time.perf_counter() - t
-            print('%-22s lr_chain %d: %.3f ms per step, x[0..2] %s' % (name, chain, 1e3 * dt / steps,
+            print('%-22s lr_chain %d lr_pipe %d: %.3f ms per step, x[0..2] %s' % (name, chain, pipe, 1e3 * dt / steps,
                   np.array2string(opt.atoms.positions.ravel()[:3], precision=12)), flush=True)

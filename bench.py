@@ -97,7 +97,20 @@ class EmtSlabMember:
     keywords); returns (atoms, the member's own keywords)."""
     SELLA_KW = dict(order=1, eta=1e-4, gamma=0.1)
 
+    def __init__(self):
+        self.host = {}
+
+    def prepare(self, i):
+        """Host-side description of member i (geometry, constraint list, calculator object: interpreter work, serial
+        under the interpreter lock) — outside the timed region, like `EnsembleMember.prepare`; everything that touches
+        the device (first force call, library calculator, the search) happens inside it."""
+        self.host[i] = self._build(i)
+
     def __call__(self, i):
+        built = self.host.pop(i, None)           # a prepared member is consumed: the next pass builds its own
+        return built if built is not None else self._build(i)
+
+    def _build(self, i):
         from sella_amd import Constraints
         from sella_amd.atoms import EMT, fcc111
         slab = fcc111('Cu', (8, 8, 4), vacuum=7.5)
@@ -378,6 +391,31 @@ def main():
                 tl = time.perf_counter() - tl
                 opt_stats['library_loop'] = dict(optimizer_steps_per_s=round(nst / tl, 3), ms_per_step=round(1e3 * tl / nst, 3),
                                                  steps=nst, one_call_steps=int(ls.one_call_steps))
+                # roofline of the optimizer step: its one n x n pass is the force matvec of the model PES (8 n^2 bytes);
+                # everything else is O(n r) on the structured Hessian B = lam0 I + W^T (mu - lam0) W: 8 passes over the
+                # r x n eigenvector panel (dots, two Gram-Schmidt sweeps, new rows, clean-up, W+ = Q^T E read + write,
+                # g_perp), the step itself one more.  Instrumented steps (hipEvents on the kernels' own packets).
+                ctx.prof_reset()
+                ctx.prof_enable(True)
+                nprof_o = 10
+                tp = time.perf_counter()
+                ls.run(0.0, nprof_o)
+                ctx.sync()
+                tp = time.perf_counter() - tp
+                ctx.prof_enable(False)
+                pm = ctx.prof_get(0)
+                r_now = int(ls.rank)
+                alg = 8.0 * n * n + 9.0 * 8.0 * n * max(1, r_now)
+                step_s = tl / nst
+                if roof is not None and pm['launches'] > 0 and pm['ms'] > 0:
+                    mv = hbm(pm, 'gemv_rows_kernel<1,2> (force matvec A x of the model PES, the one n x n pass of a step)')
+                    roof['optimizer_step'] = dict(
+                        bound='hbm', dominant_kernel=mv, explicit_rank=r_now,
+                        algorithmic_bytes_per_step=round(alg), achieved=round(alg / step_s / 1e9, 1), peak=HBM_PEAK_GBS,
+                        unit='GB/s', frac=round(alg / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                        ms_per_step=round(1e3 * step_s, 3), ms_per_step_instrumented=round(1e3 * tp / nprof_o, 3),
+                        note='latency bound: ~25 dependent launches of 4-25 us and two host synchronisations per step; '
+                             'kernel timeline in profiles/r04_opt_step_timeline.txt')
                 ls.close()
         except Exception as e:                           # noqa: BLE001 — reported, the leg above stands on its own
             opt_stats['library_loop'] = dict(error=str(e)[:200])
@@ -465,6 +503,8 @@ def main():
                 run_ensemble(emt_member, tpool.threads, fmax=0.0, steps=3, sella_kwargs=EmtSlabMember.SELLA_KW, threads=tpool)
                 epasses = []
                 for _ in range(max(1, args.ensemble_reps)):
+                    for i_ in range(args.ensemble_emt):
+                        emt_member.prepare(i_)
                     t0e = time.perf_counter()
                     re_ = run_ensemble(emt_member, args.ensemble_emt, fmax=0.0, steps=args.ensemble_steps,
                                        sella_kwargs=EmtSlabMember.SELLA_KW, threads=tpool)

@@ -112,6 +112,10 @@ class Translation(Coordinate):
             return NotImplemented
         return self.kwargs['dim'] == other.kwargs['dim'] and set(self.indices.tolist()) == set(other.indices.tolist())
 
+    def _dupkey(self):
+        """What `__eq__` compares, hashable (Constraints._add)."""
+        return (self.kwargs['dim'], frozenset(self.indices.tolist()))
+
     def calc(self, atoms):
         return float(atoms.positions[self.indices, self.kwargs['dim']].mean())
 
@@ -456,8 +460,30 @@ class Constraints:
 
     # ---- adding constraints (internal.py:2861-2955) ----------------------------------------------
     def _add(self, name, new, target, kind, replace_ok):
+        # duplicate look-up through a dictionary where the coordinate names itself (`_dupkey`): pinning a slab atom by
+        # atom is hundreds of additions, and a linear search with `__eq__` made that quadratic — 20 ms of interpreter
+        # time per 256-atom ensemble member, serial under the interpreter lock however many host threads run members
+        keyf = getattr(new, '_dupkey', None)
         try:
-            idx = self.internals[name].index(new)
+            if keyf is None:
+                idx = self.internals[name].index(new)
+            else:
+                table = self.__dict__.setdefault('_dup', {}).setdefault(name, None)
+                lst = self.internals[name]
+                if table is None or table[0] != len(lst):
+                    table = [len(lst), {c._dupkey(): i for i, c in enumerate(lst) if hasattr(c, '_dupkey')}]
+                    if len(table[1]) != len(lst):
+                        table = None                       # mixed list: the linear search
+                if table is None:
+                    idx = lst.index(new)
+                else:
+                    idx = table[1].get(keyf())
+                    if idx is None:
+                        table[1][keyf()] = len(lst)
+                        table[0] = len(lst) + 1
+                        self._dup[name] = table
+                        raise ValueError
+                    self._dup[name] = table
         except ValueError:
             self.internals[name].append(new)
             self._targets[name].append(target)

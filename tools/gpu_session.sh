@@ -2,7 +2,7 @@
 # One GPU visit for the evidence kept under profiles/: smoke, gpu tests, bench line, rocprofv3 kernel statistics of the
 # bench / the eigensolver / the Davidson loop / the block iteration / the optimizer step, PMC passes (own runs, kernel
 # dispatch tracing only).   Usage (repo root, via gpurun):  bash tools/gpu_session.sh [tag] [fast]
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -53,9 +53,9 @@ prof block_iter "tools/block_iter.py 12288 12 (rocprofv3 --kernel-trace --stats)
 prof optimizer_step "tools/opt_profile.py 3072 20 (rocprofv3 --kernel-trace --stats)" python $R/tools/opt_profile.py 3072 20
 # kernel timelines of ONE optimizer step (model PES: one job; EMT slab: full-space job + view job)
 (cd /tmp && rm -rf /tmp/optl && timeout 600 rocprofv3 --kernel-trace -d /tmp/optl -o optl -- python $R/tools/opt_profile.py 3072 10 > /dev/null 2>&1)
-python tools/opt_timeline_parse.py /tmp/optl 0.6 > $OUT/opt_step_timeline.txt 2>&1; head -1 $OUT/opt_step_timeline.txt | tee -a $OUT/session.log
+python tools/opt_timeline_parse.py /tmp/optl 0.6 lr_pre_plan > $OUT/opt_step_timeline.txt 2>&1; head -1 $OUT/opt_step_timeline.txt | tee -a $OUT/session.log
 (cd /tmp && rm -rf /tmp/emtl && timeout 600 rocprofv3 --kernel-trace -d /tmp/emtl -o emtl -- python $R/tools/emt_slab_opt.py > /dev/null 2>&1)
-python tools/opt_timeline_parse.py /tmp/emtl 0.5 lr_pre_kernel 2 > $OUT/emt_step_timeline.txt 2>&1; head -1 $OUT/emt_step_timeline.txt | tee -a $OUT/session.log
+python tools/opt_timeline_parse.py /tmp/emtl 0.5 lr_pre_plan 2 > $OUT/emt_step_timeline.txt 2>&1; head -1 $OUT/emt_step_timeline.txt | tee -a $OUT/session.log
 say "== PMC passes"
 for CNT in FETCH_SIZE WRITE_SIZE; do
   pmc eigh_$CNT trd_gemv $CNT -- python $R/tools/eigh_only.py 3072 1

@@ -111,7 +111,7 @@ def test_minimisation_without_curvature_information(ctx):
 
 @pytest.mark.parametrize('kw,nneg', [
     (dict(order=0, proj_trans=False, rs='ras'), 0),
-    (dict(KW, rs='ras', nsteps_per_diag=2), 1),
+    pytest.param(dict(KW, rs='ras', nsteps_per_diag=2), 1, marks=pytest.mark.emu_heavy),
     pytest.param(dict(KW, rs='tr', diag_every_n=3), 1, marks=pytest.mark.emu_heavy),
     pytest.param(dict(KW, rs='tr', method='rfo'), 1, marks=pytest.mark.emu_heavy),
     pytest.param(dict(KW, rs='tr', threepoint=True), 1, marks=pytest.mark.emu_heavy),
@@ -193,7 +193,8 @@ def test_run_one_takes_the_library_route(ctx, monkeypatch):
     assert s1[1] == 6 and s1[4] < 0
 
 
-@pytest.mark.parametrize('pinned', [False, pytest.param(True, marks=pytest.mark.emu_heavy)])
+@pytest.mark.parametrize('pinned', [pytest.param(False, marks=pytest.mark.emu_heavy),
+                                    pytest.param(True, marks=pytest.mark.emu_heavy)])
 def test_sella_run_hands_the_search_to_the_library_and_takes_it_back(ctx, pinned):
     """`Sella(...).run()` on a covered configuration runs inside the library; the first look at `opt.pes` brings the
     state back — geometry, energy, gradient, counters, approximate Hessian with its structured eigendecomposition (and

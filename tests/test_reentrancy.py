@@ -50,7 +50,8 @@ def _noisy_operator(ctx, A, log):
     return op
 
 
-@pytest.mark.parametrize('method', ['jd0', 'gd', 'mjd0'])
+@pytest.mark.parametrize('method', ['jd0', pytest.param('gd', marks=pytest.mark.emu_heavy),
+                                    pytest.param('mjd0', marks=pytest.mark.emu_heavy)])
 def test_davidson_callback_may_reenter_the_library(ctx, method):
     n = 96 if ctx.backend == 'emu' else 300
     A, P, g, w, Q = _problem(n)

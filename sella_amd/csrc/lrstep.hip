@@ -692,7 +692,8 @@ struct ERowsArgs {
     double* G;                                  // Gram block: entries 0..2 given; G_A11.., G_R0G, G_R1G written by workgroup 0
     double* Erow;                               // W + r * ldw: e1, then the second new row (unnormalised, before its clean-up)
     double* C3part; int ldc;                    // partial clean-up dots of the second row against [W; e1]: r + 1 entries each
-    const double* SY = nullptr; int syparts = 0;    // pipelined force call: partials of s.y, y.y -> G[G_SY], G[G_YY] (workgroup 0)
+    const double* SY = nullptr; int syparts = 0;    // Gram of the input rows still in partials (3 per part: x0.x0, x0.x1, x1.x1):
+                                                    // summed here, written to G[0..2] by workgroup 0 (pipelined force call, view jobs)
 };
 
 // e1 = R0 / |R0| and the second row R1 - (a12 / a11) R0 (what lr_e1_kernel writes), plus the partial dots of that
@@ -716,7 +717,9 @@ __global__ __launch_bounds__(256) void lr_erows_kernel(ERowsArgs a) {
     }
     __syncthreads();
     const double a11 = gs[0], a12 = gs[1], a22 = gs[2], r0g = gs[3], r1g = gs[4];
-    const double ss = a.G[G_SS];
+    double ss = 0.0;
+    if (a.SY) for (int p = 0; p < a.syparts; ++p) ss += a.SY[3 * p];
+    else ss = a.G[G_SS];
     const bool keep1 = ss > 0.0 && a11 > 1e-26 * ss;
     const double inv = keep1 ? 1.0 / sqrt(a11) : 0.0, f = keep1 ? a12 / a11 : 0.0;
     const double e1 = r0 * inv, row2 = r1 - f * r0;
@@ -732,7 +735,8 @@ __global__ __launch_bounds__(256) void lr_erows_kernel(ERowsArgs a) {
         a.G[G_R0G] = r0g; a.G[G_R1G] = r1g;
         if (a.SY) {
             double sy = 0.0, yy = 0.0;
-            for (int p = 0; p < a.syparts; ++p) { sy += a.SY[2 * p]; yy += a.SY[2 * p + 1]; }
+            for (int p = 0; p < a.syparts; ++p) { sy += a.SY[3 * p + 1]; yy += a.SY[3 * p + 2]; }
+            a.G[G_SS] = ss;
             a.G[G_SY] = sy;
             a.G[G_YY] = yy;
         }
@@ -836,8 +840,44 @@ __global__ __launch_bounds__(256) void lr_secant_kernel(double* __restrict__ X, 
     const double y = valid ? gi - X[ld + i] : 0.0;
     const double s = valid ? X[i] : 0.0;
     if (valid) { X[ld + i] = y; X[2 * (size_t)ld + i] = gi; X[4 * (size_t)ld + i] = y; }
-    const double sy = blk_sum(s * y, red), yy = blk_sum(y * y, red);
-    if (threadIdx.x == 0) { SY[2 * blockIdx.x] = sy; SY[2 * blockIdx.x + 1] = yy; }
+    const double ss = blk_sum(s * s, red), sy = blk_sum(s * y, red), yy = blk_sum(y * y, red);
+    if (threadIdx.x == 0) { SY[3 * blockIdx.x] = ss; SY[3 * blockIdx.x + 1] = sy; SY[3 * blockIdx.x + 2] = yy; }
+}
+
+// The update vectors of a view job formed where they are needed (one launch instead of a lincomb, two gathers, a zero
+// fill, a copy and two Gram launches): u = sum_i UZ[2i] E_i, z = sum_i UZ[2i+1] E_i restricted to the view's coordinates
+// idx, written as rows 0, 1 (inputs) and 3, 4 (residual rows) of the packed block Xs; row 2 = g[idx] when the gradient
+// is on the device (else the caller uploads it); padding columns zero; partials of u.u, u.z, z.z -> SY[3 wg ..].
+struct ViewRowsArgs {
+    const double* E; int lde, nr;
+    const double* UZ;
+    const int* idx; int m, lds;
+    const double* gsrc;
+    double* Xs;
+    double* SY;
+};
+
+__global__ __launch_bounds__(256) void lr_view_rows_kernel(ViewRowsArgs a) {
+    __shared__ double cu[LR_DEV_MAX + 8], cz[LR_DEV_MAX + 8], xs[4][LR_CHUNK];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < a.nr; i += 256) { cu[i] = a.UZ[2 * i]; cz[i] = a.UZ[2 * i + 1]; }
+    const int c = blockIdx.x * LR_CHUNK + lane;
+    const bool valid = c < a.m;
+    const int col = a.idx[valid ? c : a.m - 1];
+    __syncthreads();
+    double pu, pz;
+    rows_lincomb(a.E, a.lde, a.nr, col, cu, cz, &pu, &pz);
+    const double su = wave4_sum(pu, xs), sz = wave4_sum(pz, xs);
+    const double u = valid ? su : 0.0, z = valid ? sz : 0.0;
+    if (tid < 64) {
+        if (c < a.lds) {
+            a.Xs[c] = u; a.Xs[(size_t)a.lds + c] = z;
+            a.Xs[3 * (size_t)a.lds + c] = u; a.Xs[4 * (size_t)a.lds + c] = z;
+            if (a.gsrc) a.Xs[2 * (size_t)a.lds + c] = valid ? a.gsrc[col] : 0.0;
+        }
+        const double uu = lanes_sum(u * u), uz = lanes_sum(u * z), zz = lanes_sum(z * z);
+        if (tid == 0) { a.SY[3 * blockIdx.x] = uu; a.SY[3 * blockIdx.x + 1] = uz; a.SY[3 * blockIdx.x + 2] = zz; }
+    }
 }
 
 __global__ __launch_bounds__(256) void lr_identity_kernel(double* __restrict__ Q, int nr, int ldq) {
@@ -1192,7 +1232,7 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
     double* SYp = nullptr;
     if (piped) {
         const int syparts = (n + 255) / 256;
-        SCHK(scratch_get(c, SCR_UPD3, (size_t)2 * LR_MAXPARTS * sizeof(double), &SYp));
+        SCHK(scratch_get(c, SCR_UPD3, (size_t)6 * LR_MAXPARTS * sizeof(double), &SYp));
         hipLaunchKernelGGL(lr_secant_kernel, dim3(syparts), dim3(256), 0, c->stream, X, ld, n, gdev, SYp);
         HIPCHK(hipGetLastError());
         F.SY = SYp;
@@ -1205,16 +1245,41 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
     if (view) {
         const int m = a->m, lds = round_up(m, 8), nr = F.r + 2;
         double *UZp, *Xs;
+        const int ldmus = round_up(*a->r_sub + 2, 8);
+        const int vparts = (lds + LR_CHUNK - 1) / LR_CHUNK;
+        const bool vfused = c->opt.lr_chain && Ws->ld == lds && vparts <= LR_MAXPARTS && nr <= LR_DEV_MAX;
         SCHK(scratch_get(c, SCR_UPD1, (size_t)2 * ld * sizeof(double), &UZp));
-        SCHK(scratch_get(c, SCR_UPD2, ((size_t)3 * lds + (size_t)m / 2 + 8) * sizeof(double), &Xs));
-        int* didx = reinterpret_cast<int*>(Xs + 3 * (size_t)lds);
+        SCHK(scratch_get(c, SCR_UPD2, ((size_t)5 * lds + ldmus + 16 + (size_t)m / 2 + 8) * sizeof(double), &Xs));
+        int* didx = reinterpret_cast<int*>(Xs + 5 * (size_t)lds + ldmus + 16);
+        SCHK(h2d_async(c, didx, a->idx, (size_t)m * sizeof(int)));
+        gsub.resize((size_t)m);
+        S.Wt = Ws; S.r = *a->r_sub; S.n = m; S.mode = 1; S.mu = a->mu_sub; S.lam0 = a->lam0; S.Xd = Xs; S.ldx = lds;
+        S.gram = nullptr; S.want_modes = propose; S.slot_ws = SCR_EIG2; S.slot_panel = SCR_EIG3;
+        if (vfused) {
+            // u, z on the view's coordinates, their copies as residual rows, their Gram partials, the gradient: one launch
+            std::vector<double> small((size_t)ldmus + 16, 0.0);
+            std::copy(a->mu_sub, a->mu_sub + *a->r_sub, small.begin());
+            SCHK(h2d_async(c, Xs + 5 * (size_t)lds, small.data(), small.size() * sizeof(double)));
+            ViewRowsArgs va;
+            va.E = Wm->d; va.lde = Wm->ld; va.nr = nr; va.UZ = F.w.UZ; va.idx = didx; va.m = m; va.lds = lds;
+            va.gsrc = piped ? X + 2 * (size_t)ld : nullptr; va.Xs = Xs;
+            double* SYv = SYp ? SYp + 3 * LR_MAXPARTS : nullptr;
+            if (!SYv) { SCHK(scratch_get(c, SCR_UPD3, (size_t)6 * LR_MAXPARTS * sizeof(double), &SYv)); SYv += 3 * LR_MAXPARTS; }
+            va.SY = SYv;
+            hipLaunchKernelGGL(lr_view_rows_kernel, dim3(vparts), dim3(256), 0, c->stream, va);
+            HIPCHK(hipGetLastError());
+            if (!piped) {
+                for (int q = 0; q < m; ++q) gsub[q] = a->g_new[a->idx[q]];
+                SCHK(h2d_async(c, Xs + 2 * (size_t)lds, gsub.data(), (size_t)m * sizeof(double)));
+            }
+            S.Rpre = Xs + 3 * (size_t)lds; S.mu_dev = Xs + 5 * (size_t)lds; S.G_dev = S.mu_dev + ldmus;
+            S.SY = SYv; S.syparts = vparts;
+        } else {
         // u, z as vectors (rows of E weighted by their coordinates), restricted to the view's coordinates
         SCHK(launch_lincomb(c, n, 2, Wm->d, Wm->ld, nr, F.w.UZ, 2, nullptr, 0, 0, nullptr, 0, 0.0, UZp, ld));
-        SCHK(h2d_async(c, didx, a->idx, (size_t)m * sizeof(int)));
         HIPCHK(hipMemsetAsync(Xs, 0, (size_t)3 * lds * sizeof(double), c->stream));
         hipLaunchKernelGGL(lr_gather_cols_kernel, dim3((m + 255) / 256, 2), dim3(256), 0, c->stream, UZp, ld, 2, didx, m, Xs, lds);
         HIPCHK(hipGetLastError());
-        gsub.resize((size_t)m);
         if (piped) {                                                   // the gradient is still on its way: gathered on the device
             hipLaunchKernelGGL(lr_gather_cols_kernel, dim3((m + 255) / 256, 1), dim3(256), 0, c->stream, X + 2 * (size_t)ld, ld, 1,
                                didx, m, Xs + 2 * (size_t)lds, lds);
@@ -1223,8 +1288,7 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
             for (int q = 0; q < m; ++q) gsub[q] = a->g_new[a->idx[q]];
             SCHK(h2d_async(c, Xs + 2 * (size_t)lds, gsub.data(), (size_t)m * sizeof(double)));
         }
-        S.Wt = Ws; S.r = *a->r_sub; S.n = m; S.mode = 1; S.mu = a->mu_sub; S.lam0 = a->lam0; S.Xd = Xs; S.ldx = lds;
-        S.gram = nullptr; S.want_modes = propose; S.slot_ws = SCR_EIG2; S.slot_panel = SCR_EIG3;
+        }
         SCHK(lr_job_queue(c, S));
     }
     if (piped) {
@@ -1301,7 +1365,7 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
     const int ncl = nd - rn;
     const bool have_perp = ncl > 0 && gp2 > 0.0 && gp2 > 1e-26 * g2;
     double* gprow = J.Wnew + (size_t)nrj * J.ldw;
-    const bool on_panel = a->cons == 0 && c->opt.lr_chain;       // (see below: the family then reads the panel's rows in place)
+    const bool on_panel = a->cons <= 1 && c->opt.lr_chain;       // (see below: the family then reads the panel's rows in place)
     if (have_perp && on_panel && J.gparts > 0) { /* the row stays unnormalised: its factor goes into the step's coefficient */ }
     else if (have_perp && J.gparts > 0) SCHK(launch_axpby(c, nd, 1.0 / std::sqrt(gp2), gprow, 0.0, nullptr, gprow));
     else if (have_perp) SCHK(launch_scale_by(c, gprow, nd, J.w.sc + SC_GPERP2, 0));
@@ -1322,8 +1386,8 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
         while (i < rn) put(i++);
     }
     sella_stepper* st = nullptr;
-    // trust-region measure: the search runs in the eigenbasis on the host and the step is one launch over the panel's own
-    // rows; the per-atom measure evaluates trial steps on the device and gets the mode matrices
+    // the family reads its modes where they are — rows of the panel the update just wrote (trial steps of the per-atom
+    // measure, the final step of the trust-region one): no gather, no transpose, no zero-filled mode matrices
     if (on_panel) {
         SCHK(stepper_on_panel(c, a->stepper_kind, J.Wnew, J.ldw, idx.data(), mm, nd, ev.data(), gh.data(), a->order, &st));
         if (have_perp && J.gparts > 0)

@@ -580,29 +580,47 @@ __global__ __launch_bounds__(1024) void rs_cons_kernel(int cons, int nout, const
 }  // namespace
 }  // namespace sella
 
-// s[c] = sum_i coef[i] * panel[idx[i] * ld + c]: the step of a family in panel form (coefficients and row indices arrive
-// in ONE transfer: m doubles, then m ints)
-__global__ __launch_bounds__(256) void rs_panel_step_kernel(const double* __restrict__ panel, int ld, int m, int n,
-                                                            const double* __restrict__ pack, double* __restrict__ out) {
-    __shared__ double sc[1024];
-    __shared__ int si[1024];
-    const int* idx = reinterpret_cast<const int*>(pack + m);
+// Y[q * ldy + c] = sum_i X[q * ldx + i] * scale[i] * panel[idx[i] * ld + c],  q < nq (<= 16): trial steps of a family in panel
+// form — its modes are rows of a panel somebody else owns, read where they are.  `aux` = m doubles (factor of each row),
+// then m ints (row of each mode), uploaded once per family.  Thread = coordinate; the coefficients go through LDS in
+// tiles of 128 modes (read back as broadcasts).
+__global__ __launch_bounds__(256) void rs_panel_apply_kernel(const double* __restrict__ panel, int ld, int m, int n,
+                                                             const double* __restrict__ aux, const double* __restrict__ X,
+                                                             int ldx, int nq, double* __restrict__ Y, int ldy) {
+    constexpr int TI = 128;
+    __shared__ double cs[TI][16];
+    __shared__ int si[TI];
+    const int* idx = reinterpret_cast<const int*>(aux + m);
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int cl = c < n ? c : n - 1;
-    double a0 = 0.0, a1 = 0.0;
-    for (int i0 = 0; i0 < m; i0 += 1024) {
-        const int nb = m - i0 < 1024 ? m - i0 : 1024;
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+    for (int i0 = 0; i0 < m; i0 += TI) {
+        const int nb = m - i0 < TI ? m - i0 : TI;
         __syncthreads();
-        for (int i = threadIdx.x; i < nb; i += 256) { sc[i] = pack[i0 + i]; si[i] = idx[i0 + i]; }
-        __syncthreads();
-        int i = 0;
-        for (; i + 1 < nb; i += 2) {
-            a0 += sc[i] * panel[(size_t)si[i] * ld + cl];
-            a1 += sc[i + 1] * panel[(size_t)si[i + 1] * ld + cl];
+        for (int e = threadIdx.x; e < nb * 16; e += 256) {
+            const int i = e >> 4, q = e & 15;
+            cs[i][q] = q < nq ? X[(size_t)q * ldx + i0 + i] * aux[i0 + i] : 0.0;
         }
-        if (i < nb) a0 += sc[i] * panel[(size_t)si[i] * ld + cl];
+        for (int i = threadIdx.x; i < nb; i += 256) si[i] = idx[i0 + i];
+        __syncthreads();
+        if (nq <= 2) {
+            for (int i = 0; i < nb; ++i) {
+                const double v = panel[(size_t)si[i] * ld + cl];
+                acc[0] += cs[i][0] * v;
+                acc[1] += cs[i][1] * v;
+            }
+        } else {
+            for (int i = 0; i < nb; ++i) {
+                const double v = panel[(size_t)si[i] * ld + cl];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] += cs[i][q] * v;
+            }
+        }
     }
-    if (c < n) out[c] = a0 + a1;
+    if (c < n)
+        for (int q = 0; q < nq; ++q) Y[(size_t)q * ldy + c] = acc[q];
 }
 
 extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, const double* scons, const double* w,
@@ -624,10 +642,28 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     sella_ctx* c = st->c;
     Mat* V = st->panel ? nullptr : mat_get(c, st->V);
     if (!V && !st->panel) return SELLA_E_INVALID;
-    if (st->panel && !(orthonormal && cons == 0 && !scons)) {
-        set_error("restricted_step: a family in panel form serves the trust-region measure in its orthonormal eigenbasis only");
+    if (st->panel && !(orthonormal && cons <= 1 && !scons)) {
+        set_error("restricted_step: a family in panel form serves the trust-region and per-atom measures without a constraint correction only");
         return SELLA_E_INVALID;
     }
+    // panel form: factors and row indices of the modes on the device (once per family)
+    double* daux = nullptr;
+    const int ldxp = round_up(st->m, 8);
+    auto panel_apply = [&](const double* dX, int ldX, int nq, double* dYo, int ldYo) -> int {
+        if (!daux) {
+            const int mm = st->m;
+            std::vector<double> pack((size_t)mm + (size_t)(mm + 1) / 2 + 1, 0.0);
+            for (int i = 0; i < mm; ++i) pack[i] = st->pscale[i];
+            memcpy(pack.data() + mm, st->pidx.data(), (size_t)mm * sizeof(int));
+            SCHK(scratch_get(c, SCR_PSMALL, pack.size() * sizeof(double), &daux));
+            SCHK(h2d_async(c, daux, pack.data(), pack.size() * sizeof(double)));
+        }
+        hipLaunchKernelGGL(rs_panel_apply_kernel, dim3((st->nout + 255) / 256), dim3(256), 0, c->stream, st->panel, st->panel_ld,
+                           st->m, st->nout, daux, dX, ldX, nq, dYo, ldYo);
+        HIPCHK(hipGetLastError());
+        return SELLA_OK;
+    };
+    (void)ldxp;
     const int m = st->m;
     const int nfam = st->nout;                         // rows of the family's eigenvector matrix (m modes of length nfam;
                                                        // m < nfam for a structured eigendecomposition, sella_stepper_create_lr)
@@ -732,7 +768,8 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
             SCHK(h2d_async(c, dx, shat, (size_t)m * sizeof(double)));
             SCHK(h2d_async(c, dx + ldx, dshat, (size_t)m * sizeof(double)));
         }
-        SCHK(launch_gemv_rows(c, V->d, nfam, m, V->ld, dx, ldx, 2, dy, ldy, GemvEpi()));
+        if (st->panel) SCHK(panel_apply(dx, ldx, 2, dy, ldy));
+        else SCHK(launch_gemv_rows(c, V->d, nfam, m, V->ld, dx, ldx, 2, dy, ldy, GemvEpi()));
         hipLaunchKernelGGL(rs_cons_kernel, dim3(1), dim3(1024), 0, c->stream, cons, nout, dy, dy + ldy, dscons, dw, dd1, dstot,
                            hres, dsel, nfam, dsfull, ddfull);
         HIPCHK(hipGetLastError());
@@ -745,14 +782,14 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     // Candidates in heap order: node 1 = mid(lower, upper), node 2q = midpoint of the lower half of node q's bracket,
     // node 2q + 1 of its upper half; computed with the reference's own expression 0.5 * (lower + upper).
     constexpr int BATCH_LEVELS = 4, BATCH_NODES = (1 << BATCH_LEVELS) - 1;
-    const bool can_batch = !eig_only && V && !newton_safe && c->opt.rs_batch && (V->ld % 4 == 0) && m <= V->ld;
+    const bool can_batch = !eig_only && !newton_safe && c->opt.rs_batch && (st->panel || ((V->ld % 4 == 0) && m <= V->ld));
     double* dbatch = nullptr;                  // lam | ghat | d1hat | X (16 x ld) | Y (16 x ldy) | inv
     int ldb = 0;
     bool batch_ready = false;
     double cand[BATCH_NODES + 1], cval[BATCH_NODES + 1];
     int nbatch = 0;
     auto batch_setup = [&]() -> int {
-        ldb = V->ld;
+        ldb = st->panel ? round_up(m, 8) : V->ld;
         const size_t need = (size_t)3 * ldx + (size_t)16 * ldb + (size_t)16 * ldy + (size_t)ldy + 64;
         SCHK(scratch_get(c, SCR_STEP2, need * sizeof(double), &dbatch));
         std::vector<double> pack((size_t)3 * ldx, 0.0);
@@ -792,7 +829,8 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         const int* dinv = sel ? reinterpret_cast<const int*>(dY + (size_t)16 * ldy) : nullptr;
         hipLaunchKernelGGL(rs_batch_kernel, dim3(BATCH_NODES), dim3(256), 0, c->stream, ba);
         HIPCHK(hipGetLastError());
-        SCHK(launch_panel16(c, V->d, nfam, m, V->ld, ba.X, BATCH_NODES, dY, ldy));
+        if (st->panel) SCHK(panel_apply(ba.X, ldb, BATCH_NODES, dY, ldy));
+        else SCHK(launch_panel16(c, V->d, nfam, m, V->ld, ba.X, BATCH_NODES, dY, ldy));
         hipLaunchKernelGGL(rs_measure_kernel, dim3(BATCH_NODES), dim3(256), 0, c->stream, cons, nout, dY, ldy, dscons, dw, dd1,
                            dinv, hres + 2);
         HIPCHK(hipGetLastError());
@@ -929,16 +967,14 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     }
     // ---- the step at the final alpha ------------------------------------------------------------------------------
     if (eig_only && st->panel) {
-        // coefficients and row indices in one transfer, the step in one launch
-        std::vector<double> pack((size_t)m + (size_t)(m + 1) / 2 + 1, 0.0);
-        for (int i = 0; i < m; ++i) pack[i] = shat[i] * st->pscale[i];
-        memcpy(pack.data() + m, st->pidx.data(), (size_t)m * sizeof(int));
-        double* dpack;
-        SCHK(scratch_get(c, SCR_STEP2, pack.size() * sizeof(double), &dpack));
-        SCHK(h2d_async(c, dpack, pack.data(), pack.size() * sizeof(double)));
-        hipLaunchKernelGGL(rs_panel_step_kernel, dim3((nfam + 255) / 256), dim3(256), 0, c->stream, st->panel, st->panel_ld, m,
-                           nfam, dpack, dy);
-        HIPCHK(hipGetLastError());
+        // coefficients up, the step in one launch over the panel's own rows
+        if (pinned) {
+            memcpy(hin, shat, (size_t)m * sizeof(double));
+            HIPCHK(hipMemcpyAsync(dx, hin, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        } else {
+            SCHK(h2d_async(c, dx, shat, (size_t)m * sizeof(double)));
+        }
+        SCHK(panel_apply(dx, ldx, 1, dy, ldy));
     } else if (eig_only) {
         if (pinned) {
             memcpy(hin, shat, (size_t)m * sizeof(double));

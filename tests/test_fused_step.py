@@ -156,3 +156,20 @@ def test_restart_drops_the_proposed_step(ctx, tmp_path):
     b, _ = _run(fresh, 2)
     for i, (ra, rb) in enumerate(zip(a, b)):
         _same_row(ra, rb, i + 4)
+
+
+def test_batched_trial_steps_on_the_panel_rows(ctx):
+    """The per-atom measure's batched root search (`rs_batch`, 15 trial alphas per round trip) with the step family
+    reading its modes from the update's panel in place (`rs_panel_apply_kernel`) against the one-at-a-time search: the
+    same steps.  (The emulation's default switches the batches off — minutes of fibre switching per whole run — so this
+    short run is the CPU suite's only pass through that kernel with 15 right-hand sides.)"""
+    out = {}
+    for batch in (1, 0):
+        ctx.set_option('rs_batch', batch)
+        try:
+            out[batch], _ = _run(_model_search(True, 'ras', 'rfo', 0), 4)
+        finally:
+            ctx.set_option('rs_batch', 0 if ctx.backend == 'emu' else 1)
+    for i, (ra, rb) in enumerate(zip(out[1], out[0])):
+        np.testing.assert_allclose(ra[0], rb[0], atol=1e-9 * 4 ** i, rtol=0, err_msg=f'step {i}')
+        assert ra[2] == pytest.approx(rb[2], rel=1e-9)

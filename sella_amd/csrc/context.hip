@@ -178,6 +178,31 @@ int h2d_async(sella_ctx* c, void* dst, const void* src, size_t bytes) {
     return SELLA_OK;
 }
 
+// The same in two halves for payloads the caller composes itself: *slot is pinned memory to fill (zeroed here), h2d_end
+// queues the transfer.  Saves the intermediate buffer and its copy (the staging block of the one-call optimizer step is
+// 120 KB per step).  Payloads beyond half the ring are refused (SELLA_E_INVALID): the caller takes h2d_async.
+int h2d_begin(sella_ctx* c, size_t bytes, void** slot) {
+    if (!c->hring) {
+        void* p = nullptr;
+        HIPCHK(hipHostMalloc(&p, H2D_RING_BYTES, hipHostMallocDefault));
+        c->hring = static_cast<char*>(p);
+        c->hring_bytes = H2D_RING_BYTES;
+        c->hring_pos = 0;
+    }
+    if (bytes == 0 || bytes > c->hring_bytes / 2) return SELLA_E_INVALID;
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (c->hring_pos + need > c->hring_bytes) SCHK(stream_wait(c));
+    *slot = c->hring + c->hring_pos;
+    c->hring_pos += need;
+    memset(*slot, 0, bytes);
+    return SELLA_OK;
+}
+
+int h2d_end(sella_ctx* c, void* dst, const void* slot, size_t bytes) {
+    HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+    return SELLA_OK;
+}
+
 static constexpr size_t D2H_RING_BYTES = (size_t)8 << 20;
 
 int d2h_async_2d(sella_ctx* c, void* dst, const void* src_dev, size_t spitch, size_t width, size_t rows) {

@@ -208,6 +208,8 @@ void dev_free(sella_ctx* c, double* p, size_t bytes);
 int upload_panel(sella_ctx* c, const double* X, int n, int k, double* dpanel, int ldp);   // (n x k) host -> k rows
 int download_panel(sella_ctx* c, const double* dpanel, int ldp, int n, int k, double* X); // k rows -> (n x k) host
 int h2d_async(sella_ctx* c, void* dst, const void* src, size_t bytes);   // caller memory -> device, no wait (pinned ring)
+int h2d_begin(sella_ctx* c, size_t bytes, void** slot);                   // pinned slot (zeroed) for the caller to compose in ...
+int h2d_end(sella_ctx* c, void* dst, const void* slot, size_t bytes);     // ... and its transfer queued
 // device -> caller memory through the pinned ring: `dst` is valid after the next stream_wait(c).  The 2-D form copies
 // `rows` rows of `width` bytes from a device pitch `spitch` into a dense destination.
 int d2h_async(sella_ctx* c, void* dst, const void* src_dev, size_t bytes);

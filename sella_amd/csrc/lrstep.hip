@@ -1198,6 +1198,11 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
     double *gdev = nullptr, *auxdev = nullptr;
     int naux = 0;
     std::vector<double> auxh;
+    if (piped) {
+        // the force call first, nothing waited for: its kernels run while the host stages and queues the update
+        SCHK(calc_queue(pipe->calc, pipe->x, &gdev, &auxdev, &naux));
+        auxh.resize((size_t)naux);
+    }
     // ONE transfer for everything the full-space job reads from the host: the rows s, y, g; s, y again as the residual
     // rows the two sweeps work on; the eigenvalues; the Gram entries of (s, y)
     const int ldmu = round_up(*a->r + 2, 8);
@@ -1205,26 +1210,26 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
     double* X;
     SCHK(scratch_get(c, SCR_UPD0, nstage * sizeof(double), &X));
     {
-        std::vector<double>& hs = c->hbuf_b;
-        hs.assign(nstage, 0.0);
-        std::copy(a->dx, a->dx + n, hs.begin());
+        // composed directly in the pinned ring (no intermediate buffer)
+        void* slot = nullptr;
+        std::vector<double>& hsv = c->hbuf_b;
+        double* hs;
+        const bool ring = h2d_begin(c, nstage * sizeof(double), &slot) == SELLA_OK;
+        if (ring) hs = static_cast<double*>(slot);
+        else { hsv.assign(nstage, 0.0); hs = hsv.data(); }
+        std::copy(a->dx, a->dx + n, hs);
         if (piped) {
-            std::copy(a->g_old, a->g_old + n, hs.begin() + ld);      // becomes y on the device (lr_secant_kernel)
+            std::copy(a->g_old, a->g_old + n, hs + ld);               // becomes y on the device (lr_secant_kernel)
         } else {
-            std::copy(y.begin(), y.end(), hs.begin() + ld);
-            std::copy(a->g_new, a->g_new + n, hs.begin() + 2 * (size_t)ld);
-            std::copy(y.begin(), y.end(), hs.begin() + 4 * (size_t)ld);
+            std::copy(y.begin(), y.end(), hs + ld);
+            std::copy(a->g_new, a->g_new + n, hs + 2 * (size_t)ld);
+            std::copy(y.begin(), y.end(), hs + 4 * (size_t)ld);
         }
-        std::copy(a->dx, a->dx + n, hs.begin() + 3 * (size_t)ld);
-        std::copy(a->mu, a->mu + *a->r, hs.begin() + 5 * (size_t)ld);
-        std::copy(gram, gram + 3, hs.begin() + 5 * (size_t)ld + ldmu);
-        SCHK(h2d_async(c, X, hs.data(), nstage * sizeof(double)));
-    }
-    if (piped) {
-        // the force call: queued behind the staging transfer, nothing waited for — the host goes on queueing the update
-        // while the calculator's kernels run
-        SCHK(calc_queue(pipe->calc, pipe->x, &gdev, &auxdev, &naux));
-        auxh.resize((size_t)naux);
+        std::copy(a->dx, a->dx + n, hs + 3 * (size_t)ld);
+        std::copy(a->mu, a->mu + *a->r, hs + 5 * (size_t)ld);
+        std::copy(gram, gram + 3, hs + 5 * (size_t)ld + ldmu);
+        if (ring) SCHK(h2d_end(c, X, slot, nstage * sizeof(double)));
+        else SCHK(h2d_async(c, X, hs, nstage * sizeof(double)));
     }
     LrJob F;
     F.Wt = Wm; F.r = *a->r; F.n = n; F.mode = 0; F.mu = a->mu; F.lam0 = a->lam0; F.Xd = X; F.ldx = ld; F.gram = gram;

@@ -60,7 +60,8 @@ int evaluate(sella_search* S) {
 
 // peswrapper.py:438-441: largest per-atom norm of the projected forces (pinned coordinates carry none)
 double fmax_now(const sella_search* S) {
-    std::vector<char> freec;
+    static thread_local std::vector<char> freec;           // (one search per thread at a time: rebuilt per call only if pinned)
+    freec.clear();
     if (!S->idx.empty()) {
         freec.assign(S->n, 0);
         for (int q : S->idx) freec[q] = 1;

@@ -54,7 +54,7 @@ prof optimizer_step "tools/opt_profile.py 3072 20 (rocprofv3 --kernel-trace --st
 # kernel timelines of ONE optimizer step (model PES: one job; EMT slab: full-space job + view job)
 (cd /tmp && rm -rf /tmp/optl && timeout 600 rocprofv3 --kernel-trace -d /tmp/optl -o optl -- python $R/tools/opt_profile.py 3072 10 > /dev/null 2>&1)
 python tools/opt_timeline_parse.py /tmp/optl 0.6 lr_pre_plan > $OUT/opt_step_timeline.txt 2>&1; head -1 $OUT/opt_step_timeline.txt | tee -a $OUT/session.log
-(cd /tmp && rm -rf /tmp/emtl && timeout 600 rocprofv3 --kernel-trace -d /tmp/emtl -o emtl -- python $R/tools/emt_slab_opt.py > /dev/null 2>&1)
+(cd /tmp && rm -rf /tmp/emtl && timeout 600 rocprofv3 --kernel-trace -d /tmp/emtl -o emtl -- python $R/tools/emt_slab_lib.py 12 > /dev/null 2>&1)
 python tools/opt_timeline_parse.py /tmp/emtl 0.5 lr_pre_plan 2 > $OUT/emt_step_timeline.txt 2>&1; head -1 $OUT/emt_step_timeline.txt | tee -a $OUT/session.log
 say "== PMC passes"
 for CNT in FETCH_SIZE WRITE_SIZE; do
@@ -86,6 +86,11 @@ SELLA_DEBUG_TIMING=1 timeout 300 python tools/opt_profile.py 3072 20 > $OUT/opt_
 grep "update_H\|rank-one" $OUT/opt_3072_timing.log | tail -3 | tee -a $OUT/session.log
 SELLA_DEBUG_TIMING=1 timeout 300 python tools/emt_slab_opt.py > $OUT/emt.log 2> $OUT/emt_timing.log; grep "per optimizer step" -A8 $OUT/emt.log | tee -a $OUT/session.log
 grep "update_H" $OUT/emt_timing.log | tail -2 | tee -a $OUT/session.log
+say "== one-call optimizer step, A/B by option (lr_chain: fused launch chain of round 4; lr_pipe: force call queued in front of the update)"
+timeout 600 python tools/opt_ab.py 3072 30 > $OUT/opt_ab.log 2>&1; cat $OUT/opt_ab.log | tee -a $OUT/session.log
+{ python tools/emt_slab_lib.py 20; python tools/emt_slab_lib.py 20 lr_chain=0 lr_pipe=0; python tools/emt_slab_lib.py 20; } > $OUT/emt_lib_ab.log 2>&1; cat $OUT/emt_lib_ab.log | tee -a $OUT/session.log
+say "== configs[3] as named: 256-atom EMT members on host threads"
+timeout 300 python tools/emt_ensemble.py 64 t1 t4 t8 t16 > $OUT/emt_ensemble.log 2>&1; cat $OUT/emt_ensemble.log | tee -a $OUT/session.log
 say "== eigensolver at 3N = 6144 / 8192 / 12288: defaults, then symmetric-aware matvec and 64-reflector blocks off"
 { for n in 6144 8192 12288; do
     echo "n = $n, defaults (eigh_symv_min 5120, eigh_wy_nb64_min 2560)"; timeout 300 python tools/eigh_only.py $n 3 2>&1 | tail -2

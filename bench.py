@@ -161,6 +161,8 @@ def main():
                     help='second ensemble figure with this many times the members per GPU on up to 12 threads (0: skip)')
     ap.add_argument('--ensemble-procs', type=int, default=-1,
                     help='worker processes per GPU for the ensemble leg (-1: min(members, 4, CPUs of this rank); 0/1: none)')
+    ap.add_argument('--concurrent', type=int, default=4,
+                    help='extra leg: this many independent problems in flight on host threads (0 / 1: skip)')
     ap.add_argument('--block-n', type=int, default=12288, help='configs[4] leg: operator size (0 disables)')
     ap.add_argument('--block-iters', type=int, default=12)
     ap.add_argument('--block-eigh', type=int, default=1, help='time the full device eigh of the block operator at N = 1 (0: skip)')
@@ -255,6 +257,65 @@ def main():
     ctx.sync()
     elapsed = time.perf_counter() - t0
     barrier()
+
+    # ---- the same steps, several independent problems in flight (host threads, a device context and stream each) -------
+    # One rayleigh_ritz call is a chain of ~6,000 dependent launches of a few workgroups: it leaves most of the chip (and
+    # the host's other cores) idle.  Independent saddle searches — the ensemble of configs[3], or the 20 problems of this
+    # leg — fill it.  Reported BESIDE the headline (`value` stays the one-problem-at-a-time rate).
+    concurrent = None
+    if args.concurrent > 1 and world == 1:
+        import threading
+        from sella_amd import device as _devm
+        T = args.concurrent
+        per = max(1, args.steps // T)
+        done, errs = [0] * T, []
+        host = [hessian_like(n, seed=t_ % args.seeds) for t_ in range(T)]
+
+        def work(t_):
+            cx = dA_t = dP_t = None
+            try:
+                cx = Context()                       # (created by the thread that uses it: it owns the handles it frees)
+                _devm.use_context(cx)
+                A_s, P_s, g_t = host[t_]
+                dA_t, dP_t = cx.upload(A_s), cx.upload(P_s)
+                for i_ in range(per + 1):
+                    if i_ == 1:
+                        gate.wait()                  # (first pass = warm-up; the clock starts when every thread is warm)
+                    w_t, V_t, Vt_t = cx.eigh(dP_t)
+                    r_ = cx.davidson(dA_t, n, g_t if i_ % 2 == 0 else g_t[::-1].copy(), args.gamma, method='jd0',
+                                     maxiter=args.maxiter, Pvecs=V_t, PvecsT=Vt_t, pevals=w_t)
+                    V_t.free()
+                    Vt_t.free()
+                    if i_ >= 1:
+                        done[t_] += r_[1].shape[1]
+                cx.sync()
+            except BaseException as e:               # noqa: BLE001 — reported on the line
+                errs.append(repr(e)[:200])
+                try:
+                    gate.abort()
+                except Exception:                    # noqa: BLE001
+                    pass
+            finally:
+                _devm.use_context(None)
+                if cx is not None:
+                    import gc
+                    del dA_t, dP_t
+                    gc.collect()
+                    cx.close()
+        gate = threading.Barrier(T + 1)
+        ths = [threading.Thread(target=work, args=(t_,)) for t_ in range(T)]
+        for th in ths:
+            th.start()
+        try:
+            gate.wait()
+            tc0 = time.perf_counter()
+        except threading.BrokenBarrierError:
+            tc0 = time.perf_counter()
+        for th in ths:
+            th.join()
+        tcc = time.perf_counter() - tc0
+        concurrent = dict(problems_in_flight=T, calls=per * T, davidson_iter_per_s=round(sum(done) / tcc, 1),
+                          ms_per_call_amortised=round(1e3 * tcc / (per * T), 3), errors=errs or None)
 
     # Davidson loop alone (P's eigendecomposition kept from a previous optimizer phase)
     w, V, Vt = ctx.eigh(dP)
@@ -728,6 +789,7 @@ def main():
                        **({'options': list(args.option)} if args.option else {})},
             'davidson_loop_only_iter_per_s': round(it2 / t_loop, 1),
             'eigh_ms': round(1e3 * t_eigh, 2),
+            'concurrent_problems': concurrent,
             'optimizer': opt_stats,
             'block_davidson': block_stats,
             'parity': {'lowest_ritz_value': float(lams[0]), 'ritz_residual_norm': resid, 'max_abs_AV_minus_A_V': av_err,

@@ -468,6 +468,7 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "lr_dev")) c->opt.lr_dev = value ? 1 : 0;
     else if (!strcmp(key, "lr_chain")) c->opt.lr_chain = value ? 1 : 0;
     else if (!strcmp(key, "lr_pipe")) c->opt.lr_pipe = value ? 1 : 0;
+    else if (!strcmp(key, "rs_batch_result")) c->opt.rs_batch_result = value ? 1 : 0;
     else if (!strcmp(key, "rs_fast")) c->opt.rs_fast = value ? 1 : 0;
     else if (!strcmp(key, "rs_batch")) c->opt.rs_batch = value ? 1 : 0;
     else if (!strcmp(key, "bd_dev_rr")) c->opt.bd_dev_rr = value ? 1 : 0;

@@ -116,6 +116,8 @@ struct Options {
     long bd_dev_rr = 0;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 56) on the device by parallel cyclic
                              // Jacobi in one workgroup (davidson_block.hip).  Measured at k = 48: 456 us per solve against ~270 us
                              // for the host's tred2 / tql2 (session r03l: 1.16 against 0.85 ms per block iteration), hence off
+    long rs_batch_result = 1; // 1: on an expected boundary step the start value rides in the first batch and the final step is read from the
+                              //    batch that produced it (stepper.hip)
     long lr_pipe = 1;        // 1: the library search queues the force call in front of the update that consumes it: one wait for both (search.hip)
     long lr_chain = 1;       // 1: the O(n r) passes of the one-call step as five fused launches, merged coordinate kernels (lrstep.hip)
     long rs_batch = 1;       // 1: bisection phase of the restricted-step root find evaluates 15 trial alphas per round trip (stepper.hip)
@@ -345,7 +347,7 @@ int stepper_on_panel(sella_ctx* c, int kind, const double* src, int ld, const in
                      const double* gh, int order, sella_stepper** out);
 void stepper_panel_scale(sella_stepper* st, int mode, double factor);      // mode's row is stored unnormalised: row * factor
 // the interpolating batched root search of sella_restricted_step instead of the reference's alpha schedule (sella_opt_step)
-void stepper_set_fast_search(sella_stepper* st, bool on);
+void stepper_set_fast_search(sella_stepper* st, bool on, bool boundary_hint = false);
 // lrstep.hip: the learn / adapt / propose step on structured decompositions with every decision on the device
 // `pipe` (optional): the force call at the new geometry has NOT been made yet — the step queues it on the stream in front
 // of the update that consumes its gradient and waits once for both (csrc/search.hip: no host round trip between force call

@@ -1173,6 +1173,7 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
     if (!Wm || Wm->cols != n || Wm->rows < *a->r + 4 || (view && (!Ws || Ws->cols != a->m || Ws->rows < *a->r_sub + 4)))
         return SELLA_OK;
     const bool propose = (a->flags & SELLA_OPT_PROPOSE) != 0;
+    const bool on_boundary = a->smag == a->delta;          // the step just taken ended on the trust boundary (val_out = delta)
     const int ld = round_up(n, 8);
     // pipelined force call: only where the secant pair can be formed on the device (fused chain, packed staging)
     const bool piped = pipe && pipe->calc && c->opt.lr_chain && c->opt.lr_pipe && Wm->ld == ld &&
@@ -1400,7 +1401,7 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
                 if (idx[q] == nrj) stepper_panel_scale(st, q, 1.0 / std::sqrt(gp2));
     } else
         SCHK(stepper_from_panel(c, a->stepper_kind, J.Wnew, J.ldw, idx.data(), mm, nd, ev.data(), gh.data(), a->order, &st));
-    stepper_set_fast_search(st, c->opt.rs_fast != 0);
+    stepper_set_fast_search(st, c->opt.rs_fast != 0, on_boundary);
     const bool qn = a->stepper_kind == SELLA_STEP_QN;
     const double alpha0 = qn ? 0.0 : 1.0, alphamax = qn ? std::numeric_limits<double>::infinity() : 1.0;
     const int rc = sella_restricted_step(st, a->cons, a->delta, nullptr, nullptr, nullptr, alpha0, 0.0, alphamax,

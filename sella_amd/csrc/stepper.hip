@@ -28,6 +28,7 @@ struct sella_stepper {
     sella_mat Vt = SELLA_NO_MAT;     // rows = eigenvectors [not owned]; needed for V^T scons in the root finder
     double t_host = 0.0, t_dev = 0.0;     // SELLA_DEBUG_TIMING: seconds in the secular solves / in the device round trip
     long calls = 0, sweeps = 0;
+    bool boundary_hint = false;           // sella_opt_step: the previous step ended on the trust boundary
     bool fast_search = false;             // sella_opt_step: interpolating batched search instead of the reference's alpha schedule
     // Panel form (stepper_on_panel): the modes are rows pidx[i] of a device panel somebody else owns, never gathered into
     // matrices — enough for the search in the orthonormal eigenbasis (trust-region measure), whose only device work is
@@ -784,6 +785,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     constexpr int BATCH_LEVELS = 4, BATCH_NODES = (1 << BATCH_LEVELS) - 1;
     const bool can_batch = !eig_only && !newton_safe && c->opt.rs_batch && (st->panel || ((V->ld % 4 == 0) && m <= V->ld));
     double* dbatch = nullptr;                  // lam | ghat | d1hat | X (16 x ld) | Y (16 x ldy) | inv
+    double* batch_Y = nullptr;                 // Y of the last batch
     int ldb = 0;
     bool batch_ready = false;
     double cand[BATCH_NODES + 1], cval[BATCH_NODES + 1];
@@ -826,6 +828,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         ba.lam = dbatch; ba.ghat = dbatch + ldx; ba.d1hat = dbatch + 2 * (size_t)ldx;
         ba.X = dbatch + 3 * (size_t)ldx;
         double* dY = ba.X + (size_t)16 * ldb;
+        batch_Y = dY;
         const int* dinv = sel ? reinterpret_cast<const int*>(dY + (size_t)16 * ldy) : nullptr;
         hipLaunchKernelGGL(rs_batch_kernel, dim3(BATCH_NODES), dim3(256), 0, c->stream, ba);
         HIPCHK(hipGetLastError());
@@ -841,12 +844,20 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     };
     // ---- restricted_step.py:78-120 --------------------------------------------------------------------------------
     double alpha = alpha0, val = 0.0, dval = 0.0;
-    SCHK(evaluate(alpha, &val, &dval));
-    bool inside = val < delta;
+    bool inside = false;
     bool stale = false;                        // the device no longer holds stot of the final alpha (batched evaluations)
     bool fast_done = false;
-    if (!inside && st->fast_search && can_batch && alphamin == 0.0 && std::isfinite(alphamax) && slope > 0.0 &&
-        fabs(val - delta) > tol) {
+    int batch_row = -1;                        // >= 0: the step of the final alpha is row `batch_row` of the LAST batch's output
+    const bool fast_ok = st->fast_search && can_batch && alphamin == 0.0 && std::isfinite(alphamax) && slope > 0.0;
+    // The caller expects the step on the trust boundary (the previous one was: sella_opt_step's hint) — then the start value
+    // alpha0 rides in the first batch instead of a round trip of its own, and the final step is read from the batch that
+    // produced it whenever it is the last one.  Same trial values, same root; two round trips fewer on a boundary step.
+    const bool merged = fast_ok && st->boundary_hint && !scons && alpha0 > 0.0 && c->opt.rs_batch_result;
+    if (!merged) {
+        SCHK(evaluate(alpha, &val, &dval));
+        inside = val < delta;
+    }
+    if (merged || (!inside && fast_ok && fabs(val - delta) > tol)) {
         // ---- the one-call optimizer step: same root, fewer round trips ------------------------------------------------
         // The measure grows with alpha and is smooth between the points where the largest component changes hands, so
         // the 15 candidates of a round trip go where the secant through the bracket ends puts the root, at offsets of
@@ -854,15 +865,17 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         // tenfold) per round instead of sixteenfold, and a handful of rounds replace the dozen of the bisection tree.
         // The root is the reference's — the alpha where the measure crosses the radius, to the last bits the measure
         // itself resolves — reached through other trial points.
-        double lower = 0.0, upper = alpha, flo = -delta, fhi = val - delta;
-        bool first = true, ok = false;
+        double lower = 0.0, upper = alpha, flo = -delta, fhi = merged ? 0.0 : val - delta;
+        bool first = true, ok = false, have_top = !merged;
+        int round_no = 0, src_lo_round = -1, src_lo_row = -1, src_hi_round = -1, src_hi_row = -1, hit_row = -1;
         for (int round = 0; round < 48; ++round) {
             const double width = upper - lower;
-            if (!(width > 0.0) || nextafter(nextafter(lower, upper), upper) >= upper) { ok = true; break; }
+            if (have_top && (!(width > 0.0) || nextafter(nextafter(lower, upper), upper) >= upper)) { ok = true; break; }
             int nc = 0;
             double pts[BATCH_NODES];
+            const int nlog = have_top ? BATCH_NODES : BATCH_NODES - 1;
             if (first) {
-                for (int k = 1; k <= BATCH_NODES; ++k) pts[nc++] = lower + width * pow(10.0, -0.5 * k);
+                for (int k = 1; k <= nlog; ++k) pts[nc++] = lower + width * pow(10.0, -0.5 * k);
             } else {
                 double rs = lower - flo * width / (fhi - flo);
                 if (!(rs > lower && rs < upper)) rs = 0.5 * (lower + upper);
@@ -878,7 +891,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
             int kept = 0;
             for (int k = 0; k < nc; ++k)
                 if (pts[k] > lower && pts[k] < upper && (kept == 0 || pts[k] > pts[kept - 1])) pts[kept++] = pts[k];
-            for (int k = 1; kept < BATCH_NODES; ++k) {
+            for (int k = 1; kept < nlog; ++k) {
                 const double p = lower + width * k / (BATCH_NODES + 1.0);
                 if (k > 4 * BATCH_NODES) break;
                 bool dup = !(p > lower && p < upper);
@@ -886,28 +899,44 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
                 if (!dup) pts[kept++] = p;
             }
             std::sort(pts, pts + kept);
+            if (!have_top) pts[kept++] = upper;                    // the start value itself: the largest candidate
             for (int q = 0; q < BATCH_NODES; ++q) cand[q + 1] = q < kept ? pts[q] : pts[kept - 1];
             SCHK(batch_evaluate(lower, upper, true));
+            ++round_no;
             stale = true;
             ntrial += kept;
             first = false;
+            int nscan = kept;
+            if (!have_top) {
+                // what the evaluation at alpha0 would have said (restricted_step.py:78-84)
+                have_top = true;
+                nscan = kept - 1;
+                val = cval[kept];
+                inside = val < delta;
+                if (inside || fabs(val - delta) <= tol) { hit_row = kept - 1; ok = true; fast_done = true; break; }
+                fhi = val - delta;
+                src_hi_round = round_no; src_hi_row = kept - 1;
+            }
             bool hit = false;
-            for (int q = 0; q < kept; ++q) {
+            for (int q = 0; q < nscan; ++q) {
                 const double e = cval[q + 1] - delta;
-                if (fabs(e) <= tol) { alpha = pts[q]; val = cval[q + 1]; hit = true; break; }
-                if (e > 0.0) { if (pts[q] < upper) { upper = pts[q]; fhi = e; } }
-                else if (pts[q] > lower) { lower = pts[q]; flo = e; }
+                if (fabs(e) <= tol) { alpha = pts[q]; val = cval[q + 1]; hit = true; hit_row = q; break; }
+                if (e > 0.0) { if (pts[q] < upper) { upper = pts[q]; fhi = e; src_hi_round = round_no; src_hi_row = q; } }
+                else if (pts[q] > lower) { lower = pts[q]; flo = e; src_lo_round = round_no; src_lo_row = q; }
             }
             if (hit) { ok = true; fast_done = true; break; }
         }
         if (!ok) { set_error("Restricted step failed to converge!"); return SELLA_E_NOCONV; }
         if (!fast_done) {
             // bracket collapsed: the end nearer to the radius
-            if (lower > 0.0 && fabs(flo) < fabs(fhi)) { alpha = lower; val = flo + delta; }
-            else { alpha = upper; val = fhi + delta; }
+            if (lower > 0.0 && fabs(flo) < fabs(fhi)) { alpha = lower; val = flo + delta; if (src_lo_round == round_no) batch_row = src_lo_row; }
+            else { alpha = upper; val = fhi + delta; if (src_hi_round == round_no) batch_row = src_hi_row; }
             fast_done = true;
+        } else {
+            batch_row = hit_row;                                   // found in the batch just evaluated
         }
-        {
+        if (!merged) batch_row = -1;                               // (the step from the batch output: with the merged flow only)
+        if (batch_row < 0) {
             const int keep = ntrial;
             const double vkeep = val;
             SCHK(evaluate(alpha, &val, &dval));                    // s (and stot on the device) of the final alpha
@@ -997,6 +1026,17 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         }
         if (scons)
             for (int i = 0; i < nout; ++i) s_out[i] += scons[i];
+    } else if (batch_row >= 0) {
+        // the step of the final alpha as the last batch computed it (family space; pinned coordinates stay zero)
+        std::vector<double> sp(nfam);
+        SCHK(d2h_async(c, sp.data(), batch_Y + (size_t)batch_row * ldy, (size_t)nfam * sizeof(double)));
+        SCHK(stream_wait(c));
+        if (sel) {
+            for (int i = 0; i < nout; ++i) s_out[i] = 0.0;
+            for (int i = 0; i < nfam; ++i) s_out[sel[i]] = sp[i];
+        } else {
+            for (int i = 0; i < nout; ++i) s_out[i] = sp[i];
+        }
     } else {
         SCHK(d2h_async(c, s_out, dstot, (size_t)nout * sizeof(double)));
         SCHK(stream_wait(c));
@@ -1126,8 +1166,8 @@ void sella::stepper_panel_scale(sella_stepper* st, int mode, double factor) {
     if (st && mode >= 0 && mode < (int)st->pscale.size()) st->pscale[mode] = factor;
 }
 
-void sella::stepper_set_fast_search(sella_stepper* st, bool on) {
-    if (st) st->fast_search = on;
+void sella::stepper_set_fast_search(sella_stepper* st, bool on, bool boundary_hint) {
+    if (st) { st->fast_search = on; st->boundary_hint = boundary_hint; }
 }
 
 // Step family whose m modes are rows idx[0..m) of a device panel (ascending eigenvalues ev, gradient components gh):

@@ -248,6 +248,10 @@ int d2h_async(sella_ctx* c, void* dst, const void* src_dev, size_t bytes) {
 
 int stream_wait(sella_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
+    // (both streams: the rings below are shared, and a wait issued while a job is being queued on the second stream must
+    // not rewind them under transfers the main stream still has queued)
+    if (c->stream_main && c->stream_main != c->stream) HIPCHK(hipStreamSynchronize(c->stream_main));
+    if (c->stream2 && c->stream2 != c->stream) HIPCHK(hipStreamSynchronize(c->stream2));
     for (const auto& p : c->d2h_pending) memcpy(p.dst, p.slot, p.bytes);
     c->d2h_pending.clear();
     c->dring_pos = 0;
@@ -404,6 +408,7 @@ int sella_ctx_create(int device, sella_ctx** out) {
         delete c;
         return SELLA_E_HIP;
     }
+    c->stream_main = c->stream;
     c->nscal = DS_TOTAL;
     if (hipMalloc((void**)&c->dscal, (size_t)c->nscal * sizeof(double)) != hipSuccess ||
         hipHostMalloc((void**)&c->hscal, (size_t)c->nscal * sizeof(double), hipHostMallocDefault) != hipSuccess) {
@@ -433,7 +438,10 @@ int sella_ctx_destroy(sella_ctx* c) {
     }
     if (c->hring) (void)hipHostFree(c->hring);
     if (c->dring) (void)hipHostFree(c->dring);
-    (void)hipStreamDestroy(c->stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    (void)hipStreamDestroy(c->stream_main ? c->stream_main : c->stream);
     delete c;
     return SELLA_OK;
 }
@@ -468,6 +476,7 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "lr_dev")) c->opt.lr_dev = value ? 1 : 0;
     else if (!strcmp(key, "lr_chain")) c->opt.lr_chain = value ? 1 : 0;
     else if (!strcmp(key, "lr_pipe")) c->opt.lr_pipe = value ? 1 : 0;
+    else if (!strcmp(key, "lr_overlap")) c->opt.lr_overlap = value ? 1 : 0;
     else if (!strcmp(key, "rs_batch_result")) c->opt.rs_batch_result = value ? 1 : 0;
     else if (!strcmp(key, "rs_fast")) c->opt.rs_fast = value ? 1 : 0;
     else if (!strcmp(key, "rs_batch")) c->opt.rs_batch = value ? 1 : 0;

@@ -116,6 +116,7 @@ struct Options {
     long bd_dev_rr = 0;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 56) on the device by parallel cyclic
                              // Jacobi in one workgroup (davidson_block.hip).  Measured at k = 48: 456 us per solve against ~270 us
                              // for the host's tred2 / tql2 (session r03l: 1.16 against 0.85 ms per block iteration), hence off
+    long lr_overlap = 1;     // 1: the view job of the one-call step is queued on a second stream, beside the coordinate kernels of the full-space job
     long rs_batch_result = 1; // 1: on an expected boundary step the start value rides in the first batch and the final step is read from the
                               //    batch that produced it (stepper.hip)
     long lr_pipe = 1;        // 1: the library search queues the force call in front of the update that consumes it: one wait for both (search.hip)
@@ -183,6 +184,11 @@ struct sella_ctx {
         size_t hstage_bytes = 0;
         std::vector<double> hbuf_a, hbuf_b;
     };
+    // second stream for work that is independent of the main chain for a while (the view job of the one-call optimizer
+    // step, lrstep.hip): forked and joined with events, so every wait on `stream` still covers it
+    hipStream_t stream2 = nullptr;
+    hipStream_t stream_main = nullptr;         // == stream except while a job is being queued on stream2
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::deque<Frame> frames;      // frames[d] = parked state of depth d (d != depth)
     int depth = 0;
 };

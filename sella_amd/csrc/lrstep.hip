@@ -952,6 +952,7 @@ struct LrJob {
     double* Rpre = nullptr;
     double* mu_dev = nullptr;
     double* G_dev = nullptr;
+    hipEvent_t fork_ev = nullptr;      // recorded behind the launch after which a dependent job on another stream may start
     const double* SY = nullptr;        // pipelined force call: partials of s.y, y.y still to be summed into the Gram block
     int syparts = 0;
     // results
@@ -1077,8 +1078,12 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
         pl.p = w.P + (size_t)t * w.ldr; pl.sigma = w.sc + SC_SIG1 + t; pl.Dcur = Din; pl.Q = Qin;
         pl.z = w.z; pl.Dp = w.Dp; pl.zz = w.zz; pl.Dd = w.Dd; pl.wd = w.wd; pl.cs = w.cs; pl.pl = w.pl;
         pl.perm = w.perm; pl.nd = w.nd; pl.df = w.df; pl.i1 = w.i1; pl.i2 = w.i2; pl.cnt = w.cnt;
-        if (chain && t == 0) hipLaunchKernelGGL(lr_pre_plan_kernel, dim3(1), dim3(256), 0, c->stream, pa, pl);
-        else hipLaunchKernelGGL(lr_plan_kernel, dim3(1), dim3(256), 0, c->stream, pl);
+        if (chain && t == 0) {
+            hipLaunchKernelGGL(lr_pre_plan_kernel, dim3(1), dim3(256), 0, c->stream, pa, pl);
+            // (from here on the job only works in coordinates and on its own panel: the two new rows of E and the update
+            // vectors' coordinates are final)
+            if (j.fork_ev) HIPCHK(hipEventRecord(j.fork_ev, c->stream));
+        } else hipLaunchKernelGGL(lr_plan_kernel, dim3(1), dim3(256), 0, c->stream, pl);
         hipLaunchKernelGGL(lr_secular_kernel, dim3((nr + 3) / 4), dim3(256), 0, c->stream, w.cnt, w.pl, w.Dd, w.wd, w.tau,
                            w.org, w.lam, w.sc + SC_FAIL);
         // (the Gu / Eisenstat weights computed by every apply workgroup for itself were measured: the apply kernel grows by
@@ -1245,10 +1250,33 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
         F.syparts = syparts;
     }
     F.want_modes = propose && !view; F.slot_ws = SCR_EIG0; F.slot_panel = SCR_EIG1;
+    // the view job depends on the full-space job up to its lr_pre_plan_kernel only: from there the two run side by side
+    bool overlap = false;
+    if (view && c->opt.lr_overlap && c->opt.lr_chain && (n + LR_CHUNK - 1) / LR_CHUNK <= LR_MAXPARTS) {
+        if (!c->stream2) {
+            if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+                set_error("structured update: second stream could not be created");
+                return SELLA_E_HIP;
+            }
+        }
+        overlap = true;
+        F.fork_ev = c->ev_fork;
+    }
     SCHK(lr_job_queue(c, F));
     LrJob S;
     std::vector<double> gsub;
+    struct StreamSwap {                       // every launch helper queues on c->stream: the view job is queued with the second
+        sella_ctx* c; hipStream_t saved; bool on;                      // stream installed there (restored on every path)
+        ~StreamSwap() { if (on) c->stream = saved; }
+    } swap{c, c->stream, false};
     if (view) {
+        if (overlap) {
+            HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            c->stream = c->stream2;
+            swap.on = true;
+        }
         const int m = a->m, lds = round_up(m, 8), nr = F.r + 2;
         double *UZp, *Xs;
         const int ldmus = round_up(*a->r_sub + 2, 8);
@@ -1296,6 +1324,12 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
         }
         }
         SCHK(lr_job_queue(c, S));
+        if (overlap) {
+            HIPCHK(hipEventRecord(c->ev_join, c->stream));          // (c->stream is the second stream here)
+            c->stream = swap.saved;
+            swap.on = false;
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));   // every later wait on the main stream covers the view job
+        }
     }
     if (piped) {
         // gradient and energy terms come back with the results of the update, delivered by the one wait

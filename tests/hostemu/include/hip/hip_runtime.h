@@ -205,8 +205,11 @@ hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize();
 hipError_t hipEventCreate(hipEvent_t* e);
+#define hipEventDisableTiming 2u
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipGetLastError();

@@ -116,7 +116,9 @@ struct Options {
     long bd_dev_rr = 0;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 56) on the device by parallel cyclic
                              // Jacobi in one workgroup (davidson_block.hip).  Measured at k = 48: 456 us per solve against ~270 us
                              // for the host's tred2 / tql2 (session r03l: 1.16 against 0.85 ms per block iteration), hence off
-    long lr_overlap = 1;     // 1: the view job of the one-call step is queued on a second stream, beside the coordinate kernels of the full-space job
+    long lr_overlap = 0;     // 1: the view job of the one-call step is queued on a second stream, beside the coordinate kernels of the
+                             //    full-space job.  Measured (session r04k): EMT-slab step 0.59-0.62 ms either way, and the ensemble of EMT
+                             //    members DROPS from 211 to 172-182 searches/s with 8 threads x 2 streams: off
     long rs_batch_result = 1; // 1: on an expected boundary step the start value rides in the first batch and the final step is read from the
                               //    batch that produced it (stepper.hip)
     long lr_pipe = 1;        // 1: the library search queues the force call in front of the update that consumes it: one wait for both (search.hip)

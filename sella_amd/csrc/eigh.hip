@@ -442,7 +442,6 @@ __global__ __launch_bounds__(256) void trd_symv_finish_kernel(TrdSymvFinishArgs 
     // blocks of 64 entries at absolute multiples of 64: a wavefront's entries share their tiles, so the loop bounds and the
     // row pointers below are uniform
     const int k = (a.o & ~63) + blockIdx.x * 64 + lane;
-    const int kl = k < a.n ? k : a.n - 1;
     const int NJ = (a.n + SYMV_TC - 1) / SYMV_TC;
     // every entry of this workgroup needs row-side tiles J >= kmax / TC ... hence per-entry bounds below
     const int kb0 = (a.o & ~63) + blockIdx.x * 64;          // < n: first entry of the block (64 | tile sizes)
@@ -624,14 +623,6 @@ __global__ __launch_bounds__(64) void leaf_ql_kernel(const double* __restrict__ 
     }
 }
 
-// z_i = last component of left-child eigenvector i / sign * first component of right-child ones
-__global__ __launch_bounds__(256) void gather_z_kernel(const double* __restrict__ Zt, int ld, int lo,
-                                                       int n1, int N, int mid, double sgn,
-                                                       double* __restrict__ z) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    z[lo + i] = (i < n1) ? Zt[(size_t)(lo + i) * ld + mid - 1] : sgn * Zt[(size_t)(lo + i) * ld + mid];
-}
 
 // Givens rotations on pairs of rows, in order:  x' = c x + s y ; y' = c y - s x   (BLAS drot), one
 // column per lane.  The deflation of a merge produces CHAINS: the row left as y by one rotation is
@@ -1728,7 +1719,6 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
         return SELLA_E_NOCONV;
     }
 
-    const double eps = 2.220446049250313e-16;
     double* cur = W.Za;
     double* nxt = W.Zb;
     double* zdev = W.vec + (size_t)V_Z * ld;

@@ -50,13 +50,37 @@ def _pinned_free(atoms, constraints, proj_trans, proj_rot):
     c = constraints
     if (c.nbonds + c.nangles + c.ndihedrals) > 0 or c.has_inequalities() or c.internals['rotations']:
         return False
+    # (asked three times per search — `applies` twice, the constructor once — with a dense constraint Jacobian each time:
+    # 4 ms of interpreter time per 256-atom ensemble member, serial under the interpreter lock; remembered per constraint
+    # set and geometry)
+    key = (getattr(c, '_ver', None), len(atoms), hash(np.asarray(atoms.positions, dtype=np.float64).tobytes()))
+    memo = c.__dict__.get('_pinned_free_memo')
+    if memo is not None and memo[0] == key and key[0] is not None:
+        return memo[1]
+    tr = c.internals['translations']
+    act = c._active['translations']
+    if tr and all(act) and all(len(t.indices) == 1 for t in tr):
+        # every constraint pins one Cartesian coordinate of one atom (the README pattern): read them off the list
+        # instead of building and scanning the dense Jacobian
+        pins = np.fromiter((3 * int(t.indices[0]) + t.kwargs['dim'] for t in tr), dtype=np.int64, count=len(tr))
+        x = np.asarray(atoms.positions, dtype=np.float64).ravel()
+        if len(np.unique(pins)) != len(pins) or np.any(x[pins] - np.asarray(c._targets['translations'], dtype=np.float64)):
+            out = False
+        else:
+            out = np.setdiff1d(np.arange(3 * len(atoms)), pins).astype(np.int32)
+        c.__dict__['_pinned_free_memo'] = (key, out)
+        return out
     drdx = c.jacobian()
     if drdx.shape[0] == 0:
-        return None
-    pinned = _pinned_coordinates(drdx)
-    if pinned is None or np.any(c.residual()):
-        return False
-    return np.setdiff1d(np.arange(3 * len(atoms)), pinned[0]).astype(np.int32)
+        out = None
+    else:
+        pinned = _pinned_coordinates(drdx)
+        if pinned is None or np.any(c.residual()):
+            out = False
+        else:
+            out = np.setdiff1d(np.arange(3 * len(atoms)), pinned[0]).astype(np.int32)
+    c.__dict__['_pinned_free_memo'] = (key, out)
+    return out
 
 
 class LibrarySearch:

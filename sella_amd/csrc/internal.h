@@ -116,6 +116,8 @@ struct Options {
     long bd_dev_rr = 0;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 56) on the device by parallel cyclic
                              // Jacobi in one workgroup (davidson_block.hip).  Measured at k = 48: 456 us per solve against ~270 us
                              // for the host's tred2 / tql2 (session r03l: 1.16 against 0.85 ms per block iteration), hence off
+    long eigh_two_stage = 0; // 1: sella_eigh reduces dense -> band -> tridiagonal (eigh_two_stage.h) from eigh2_min rows on
+    long eigh2_min = 6144;
     long lr_overlap = 0;     // 1: the view job of the one-call step is queued on a second stream, beside the coordinate kernels of the
                              //    full-space job.  Measured (session r04k): EMT-slab step 0.59-0.62 ms either way, and the ensemble of EMT
                              //    members DROPS from 211 to 172-182 searches/s with 8 threads x 2 streams: off

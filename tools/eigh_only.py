@@ -26,6 +26,9 @@ if os.environ.get('EIGH_WY64_MIN'):
     ctx.set_option('eigh_wy_nb64_min', int(os.environ['EIGH_WY64_MIN']))
 if os.environ.get('EIGH_TAIL_LDS'):
     ctx.set_option('eigh_tail_lds', int(os.environ['EIGH_TAIL_LDS']))
+if os.environ.get('EIGH_TWO_STAGE'):
+    ctx.set_option('eigh_two_stage', 1)
+    ctx.set_option('eigh2_min', int(os.environ['EIGH_TWO_STAGE']))
 if os.environ.get('EIGH_LEAF'):
     ctx.set_option('eigh_leaf', int(os.environ['EIGH_LEAF']))
 rng = np.random.RandomState(0)
@@ -42,5 +45,9 @@ for r in range(reps):
     w, V, Vt = ctx.eigh(dA)
     ctx.sync()
     print(f'eigh n={n}: {1e3 * (time.perf_counter() - t0):.2f} ms', flush=True)
+    if r == reps - 1 and os.environ.get('EIGH_CHECK'):
+        Vn = V.numpy()
+        wr = np.linalg.eigvalsh(A)
+        print('check: eig err %.2e, resid %.2e, orth %.2e' % (np.abs(w - wr).max(), np.abs(A @ Vn - Vn * w).max(), np.abs(Vn.T @ Vn - np.eye(n)).max()), flush=True)
     V.free()
     Vt.free()

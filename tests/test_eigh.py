@@ -125,6 +125,34 @@ def test_symmetric_aware_trailing_matvec(ctx):
         ctx.set_option('eigh_nb', 16)
 
 
+def test_two_stage_reduction(ctx):
+    """Option `eigh_two_stage`: dense -> band (b = 32, blocked Householder panels, rank-2b trailing updates) -> tridiagonal
+    (bulge chasing, one wavefront of independent tasks per launch), eigenvectors carried back through both stages.  Same
+    bar as the one-stage path: eigenvalues, residuals and orthogonality against LAPACK; sizes put the last panel, the
+    last sweep group and the last chase block at every remainder modulo the bandwidth."""
+    rng = np.random.RandomState(21)
+    sizes = (96, 97, 129, 161) if ctx.backend == 'emu' else (96, 97, 127, 128, 129, 250, 515, 1000, 1537)
+    try:
+        ctx.set_option('eigh_two_stage', 1)
+        ctx.set_option('eigh2_min', 0)
+        for n in sizes:
+            A = rng.normal(size=(n, n))
+            w = check(ctx, A + A.T)
+            if n == sizes[0]:
+                ctx.set_option('eigh_two_stage', 0)
+                np.testing.assert_allclose(check(ctx, A + A.T), w, atol=1e-12 * np.abs(w).max())
+                ctx.set_option('eigh_two_stage', 1)
+        n = 100 if ctx.backend == 'emu' else 700
+        for name, A in cases(n, rng):
+            check(ctx, A)
+        # below three bandwidths the one-stage path answers whatever the option says
+        A = rng.normal(size=(40, 40))
+        check(ctx, A + A.T)
+    finally:
+        ctx.set_option('eigh_two_stage', 0)
+        ctx.set_option('eigh2_min', 6144)
+
+
 def test_spectra(ctx):
     rng = np.random.RandomState(1)
     n = 72 if ctx.backend == 'emu' else 700

@@ -145,12 +145,28 @@ def test_two_stage_reduction(ctx):
         n = 100 if ctx.backend == 'emu' else 700
         for name, A in cases(n, rng):
             check(ctx, A)
+        # panel factorisation variants of stage 1: rows streamed from memory (0), two rows in registers (2: what sizes
+        # beyond 6144 use)
+        for variant in (0, 2):
+            ctx.set_option('eigh2_qr_reg', variant)
+            A = rng.normal(size=(sizes[1], sizes[1]))
+            check(ctx, A + A.T)
+        ctx.set_option('eigh2_qr_reg', 1)
+        # stage-1 reflectors in blocks of 64 (two panels per block) in the back-transformation: even and odd panel counts
+        ctx.set_option('eigh_wy_nb64_min', 1)
+        for n in ((129, 161) if ctx.backend == 'emu' else (129, 161, 700)):
+            A = rng.normal(size=(n, n))
+            check(ctx, A + A.T)
+        check(ctx, 2.0 * np.eye(130))                                    # every reflector the identity
+        ctx.set_option('eigh_wy_nb64_min', 2560)
         # below three bandwidths the one-stage path answers whatever the option says
         A = rng.normal(size=(40, 40))
         check(ctx, A + A.T)
     finally:
         ctx.set_option('eigh_two_stage', 0)
         ctx.set_option('eigh2_min', 6144)
+        ctx.set_option('eigh2_qr_reg', 1)
+        ctx.set_option('eigh_wy_nb64_min', 2560)
 
 
 def test_spectra(ctx):

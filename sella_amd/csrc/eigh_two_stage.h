@@ -171,6 +171,12 @@ __device__ __forceinline__ void ts_block_sums(double (&v)[K], double (*red)[16],
     for (int k = 0; k < K; ++k) v[k] = tot[k];
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define TS_SCHED_FENCE() ((void)0)
+#endif
+
 template <int VPT, int SB, bool KEEP>
 __global__ __launch_bounds__(512) void ts_panel_qr_reg_kernel(double* __restrict__ A, int ld, int n, int p, int b,
                                                               double* __restrict__ Yt, double* __restrict__ taus) {
@@ -298,13 +304,9 @@ __global__ __launch_bounds__(512) void ts_panel_qr_reg_kernel(double* __restrict
         // batches in the order 2nd, 3rd, ..., last, 1st: the result of the 1st goes straight into x, which nobody needs any more
         const int nbatch = (b - j0 - SB) / SB;
         auto batch_row = [&](int bi) { return bi < nbatch ? j0 + SB + bi * SB : j0 + SB; };
-        load_rows(batch_row(1), xr);
-        for (int bi = 1; bi <= nbatch; ++bi) {
-            const int jp = batch_row(bi);
-            const bool last = bi == nbatch;
-            if constexpr (PF) {
-                if (!last) load_rows(batch_row(bi + 1), reinterpret_cast<double (&)[XS][XV]>(xn));
-            }
+        // one batch: products with the SB reflectors, block-wide sums, update; LAST (the 1st batch, taken last): into x
+        auto batch = [&](int jp, auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
             double d[SB * SB];
 #pragma unroll
             for (int k = 0; k < SB * SB; ++k) d[k] = 0.0;
@@ -345,21 +347,26 @@ __global__ __launch_bounds__(512) void ts_panel_qr_reg_kernel(double* __restrict
                 }
 #pragma unroll
                 for (int q = 0; q < SB; ++q) {
-                    if (last) x[q][v] = acc[q];
+                    if constexpr (LAST) x[q][v] = acc[q];
                     else if (i < m) A[(size_t)(p + jp + q) * ld + r0 + i] = acc[q];
                 }
             }
-            if (!last) {
-                if constexpr (PF) {
+        };
+        load_rows(batch_row(1), xr);
+        for (int bi = 1; bi < nbatch; ++bi) {
+            if constexpr (PF) load_rows(batch_row(bi + 1), reinterpret_cast<double (&)[XS][XV]>(xn));
+            batch(batch_row(bi), std::false_type());
+            if constexpr (PF) {
 #pragma unroll
-                    for (int q = 0; q < SB; ++q)
+                for (int q = 0; q < SB; ++q)
 #pragma unroll
-                        for (int v = 0; v < VPT; ++v) xr[q][v] = xn[q][v];
-                } else {
-                    load_rows(batch_row(bi + 1), xr);
-                }
+                    for (int v = 0; v < VPT; ++v) xr[q][v] = xn[q][v];
+            } else {
+                TS_SCHED_FENCE();                                // keep the next batch's loads behind this batch's stores (registers)
+                load_rows(batch_row(bi + 1), xr);
             }
         }
+        batch(j0 + SB, std::true_type());
     }
 }
 
@@ -763,17 +770,20 @@ __global__ __launch_bounds__(256) void ts_q2_pack_kernel(const double* __restric
 
 typedef double ts_f64x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ ts_f64x4 ts_q2_load(const double* xrow, int col, int n) {
-    ts_f64x4 v = {0.0, 0.0, 0.0, 0.0};
-    if (col < n) {                                             // col is a multiple of 4 and the row is padded to 8: whole vector
-        const double4 t = *reinterpret_cast<const double4*>(xrow + col);
-        v[0] = t.x;
-        v[1] = col + 1 < n ? t.y : 0.0;
-        v[2] = col + 2 < n ? t.z : 0.0;
-        v[3] = col + 3 < n ? t.w : 0.0;
-    }
+// four consecutive entries of a row of X: fetched from a clamped address with no branch (the load stays in flight), masked
+// to the matrix when they are consumed
+__device__ __forceinline__ double4 ts_q2_fetch(const double* xrow, int col, int n) {
+    return *reinterpret_cast<const double4*>(xrow + (col < n ? col : 0));   // col is a multiple of 4, rows are padded to 8
+}
+__device__ __forceinline__ ts_f64x4 ts_q2_mask(double4 t, int col, int n) {
+    ts_f64x4 v;
+    v[0] = col < n ? t.x : 0.0;
+    v[1] = col + 1 < n ? t.y : 0.0;
+    v[2] = col + 2 < n ? t.z : 0.0;
+    v[3] = col + 3 < n ? t.w : 0.0;
     return v;
 }
+__device__ __forceinline__ ts_f64x4 ts_q2_load(const double* xrow, int col, int n) { return ts_q2_mask(ts_q2_fetch(xrow, col, n), col, n); }
 
 // One wavefront per 16 rows of X, through every block in the order above; the window slides by two tiles per block, so every
 // entry of the slab is loaded and stored once per group.
@@ -802,12 +812,10 @@ __global__ __launch_bounds__(64) void ts_q2_apply_mfma_kernel(double* __restrict
             // operands of the next block and the two tiles the window gains there: in flight under this block's products
             f += TS_Q2_TILES * 64;
             double4 an[TS_Q2_TILES];
-            ts_f64x4 xn2 = {0.0, 0.0, 0.0, 0.0}, xn3 = {0.0, 0.0, 0.0, 0.0};
+            const double4 xn2 = ts_q2_fetch(xrow, cb + 64 + c4, n), xn3 = ts_q2_fetch(xrow, cb + 80 + c4, n);
             if (k + 1 < kcount) {
 #pragma unroll
                 for (int t = 0; t < TS_Q2_TILES; ++t) an[t] = f[t * 64];
-                xn2 = ts_q2_load(xrow, cb + 64 + c4, n);
-                xn3 = ts_q2_load(xrow, cb + 80 + c4, n);
             } else {
 #pragma unroll
                 for (int t = 0; t < TS_Q2_TILES; ++t) an[t] = a[t];
@@ -837,8 +845,8 @@ __global__ __launch_bounds__(64) void ts_q2_apply_mfma_kernel(double* __restrict
             }
             x[0] = x[2];
             x[1] = x[3];
-            x[2] = xn2;
-            x[3] = xn3;
+            x[2] = ts_q2_mask(xn2, cb + 64 + c4, n);
+            x[3] = ts_q2_mask(xn3, cb + 80 + c4, n);
 #pragma unroll
             for (int t = 0; t < TS_Q2_TILES; ++t) a[t] = an[t];
         }
@@ -909,7 +917,7 @@ static int two_stage_reduce(EighWork& W, TwoStage& ts, std::vector<double>& d, s
         else if (vpt <= 2) TS_QR(2, 4, true);
         else if (vpt <= 4) TS_QR(4, 4, true);
         else if (vpt <= 8) TS_QR(8, 4, true);
-        else if (vpt <= 12) TS_QR(12, 4, false);
+        else if (vpt <= 12) TS_QR(12, 2, true);
         else if (vpt <= 16) TS_QR(16, 2, true);
         else TS_QR(24, 2, false);
 #undef TS_QR

@@ -1,10 +1,10 @@
-"""Part of the emulator suite again under AddressSanitizer + UBSan.
+"""Part of the emulator suite again under AddressSanitizer.
 
-The library sources are compiled a second time with -fsanitize=address,undefined (tests/hostemu/build_emu.py,
+The library sources are compiled a second time with -fsanitize=address (tests/hostemu/build_emu.py,
 HOSTEMU_SANITIZE=1) and the re-entrancy tests run on that build in a subprocess that has the sanitizer runtime
 preloaded: a dangling pointer inside the library (round 3's Mat* held across a callback) then stops the run with a
 report instead of depending on what the heap happens to hold.  tools/emu_sanitized.sh runs the WHOLE CPU suite this
-way (about half an hour; log under profiles/)."""
+way with UBSan on top (HOSTEMU_SANITIZE=2; about half an hour; log under profiles/)."""
 import os
 import subprocess
 import sys

@@ -28,6 +28,7 @@ struct sella_stepper {
     sella_mat Vt = SELLA_NO_MAT;     // rows = eigenvectors [not owned]; needed for V^T scons in the root finder
     double t_host = 0.0, t_dev = 0.0;     // SELLA_DEBUG_TIMING: seconds in the secular solves / in the device round trip
     long calls = 0, sweeps = 0;
+    long rs_calls = 0, rs_rounds = 0, rs_single = 0;   // SELLA_DEBUG_TIMING: root searches, batched round trips, single-alpha round trips
     bool boundary_hint = false;           // sella_opt_step: the previous step ended on the trust boundary
     bool fast_search = false;             // sella_opt_step: interpolating batched search instead of the reference's alpha schedule
     // Panel form (stepper_on_panel): the modes are rows pidx[i] of a device panel somebody else owns, never gathered into
@@ -775,6 +776,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
                            hres, dsel, nfam, dsfull, ddfull);
         HIPCHK(hipGetLastError());
         SCHK(stream_wait(c));
+        ++st->rs_single;
         *val = hres[0];
         *dval = hres[1];
         return SELLA_OK;
@@ -1044,15 +1046,17 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     *val_out = inside ? val : delta;
     if (nalpha) *nalpha = ntrial;
     st->calls += ntrial;
+    ++st->rs_calls;
+    st->rs_rounds += nbatch;
     return SELLA_OK;
 }
 
 extern "C" int sella_stepper_destroy(sella_stepper* st) {
     if (!st) return SELLA_OK;
     if (st->calls && getenv("SELLA_DEBUG_TIMING"))
-        fprintf(stderr, "stepper m=%d nout=%d: %ld get_s calls, %.1f us host solve (%.1f sweeps) + %.1f us device round trip per call\n",
+        fprintf(stderr, "stepper m=%d nout=%d: %ld get_s calls, %.1f us host solve (%.1f sweeps) + %.1f us device round trip per call; %ld root searches, %ld batched and %ld single-alpha round trips\n",
                 st->m, st->nout, st->calls, 1e6 * st->t_host / st->calls, (double)st->sweeps / st->calls,
-                1e6 * st->t_dev / st->calls);
+                1e6 * st->t_dev / st->calls, st->rs_calls, st->rs_rounds, st->rs_single);
     if (st->ownV != SELLA_NO_MAT) sella_mat_free(st->c, st->ownV);
     if (st->ownVt != SELLA_NO_MAT) sella_mat_free(st->c, st->ownVt);
     delete st;

@@ -79,7 +79,8 @@ int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
  *   eigh2_qr_reg (1) panel factorisation of that reduction with the sub-panel in registers (0: rows streamed) |
  *   lr_chain (1) the structured quasi-Newton update of sella_opt_step as the fused launch chain of round 4 (0: round 3's
  *   kernels), lr_pipe (1) the force call queued in front of the update that consumes it, rs_batch_result (1) final step
- *   read from the batch of trial alphas that produced it, lr_overlap (0) view job on a second stream.               */
+ *   read from the batch of trial alphas that produced it, lr_overlap (0) view job on a second stream |
+ *   emt_hcap (8) neighbour-list slots per thread of the EMT kernels (1 .. 8; tests lower it to reach the overflow path). */
 int sella_ctx_set_option(sella_ctx* ctx, const char* key, long value);
 
 /* ---- device matrices --------------------------------------------------------------- */

@@ -21,11 +21,13 @@ struct EmtPar {             // per-atom parameters, already converted to eV / An
 
 struct EmtArgs {
     int n, nshift;
+    int hcap;               // slots of a thread's neighbour list in use (<= EMT_HCAP; option emt_hcap, tests lower it)
     const double* pos;      // n x 3
     const double* shifts;   // nshift x 3 lattice translations (including 0)
     EmtPar p;
     double rc, acut, cutoff, beta;
     double* sigma1; double* epair; double* dEdsig; double* eatom; double* grad;
+    int* nbr;               // n x 256 x (1 + EMT_HCAP): neighbour lists of the density kernel's threads, for the force kernel
 };
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -36,15 +38,73 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The sweep over all (neighbour, image) pairs is split in two per thread: first the distance test alone over the thread's
+// pairs (t = tid, tid + 256, ...: no division, squared distance against a slightly widened cutoff), the few pairs inside
+// the cutoff noted in LDS; then the exponentials for those only.  Under 1 % of the pairs are neighbours, but with the
+// expensive branch inside the sweep every second wavefront iteration took it for some lane; deferred, a wavefront
+// pays for the largest number of neighbours any of its lanes found (2-3).  The terms are added per thread in the same
+// order as before — sums are bit-identical to the one-loop form.
+constexpr int EMT_HCAP = 8;
+constexpr int EMT_LDS_ATOMS = 1024;       // up to this many atoms the positions are staged in LDS (structure of arrays)
+
+struct EmtStage {
+    double x[EMT_LDS_ATOMS], y[EMT_LDS_ATOMS], z[EMT_LDS_ATOMS];
+};
+
+// All pairs of this thread (t = s n + j = tid mod 256, in increasing t) through `heavy`, in two steps: the distance test alone
+// — image by image (s uniform: its shift sits in scalar registers), neighbours noted in hits[tid][..] — then the noted pairs.
+// A thread whose list fills up (never at EMT's cutoff and 256 threads) works it off and takes its remaining pairs
+// directly, in the same order; the count returned is then negative: the stored list is incomplete.
+template <class Heavy>
+__device__ __forceinline__ int emt_pairs(const EmtArgs& a, double xi, double yi, double zi, EmtStage* st, int (*hits)[EMT_HCAP + 1],
+                                         Heavy heavy) {
+    const int tid = threadIdx.x, n = a.n;
+    const double cut2 = a.cutoff * a.cutoff * (1.0 + 1e-12);
+    const bool staged = n <= EMT_LDS_ATOMS;
+    if (staged) {
+        for (int j = tid; j < n; j += 256) { st->x[j] = a.pos[3 * j]; st->y[j] = a.pos[3 * j + 1]; st->z[j] = a.pos[3 * j + 2]; }
+        __syncthreads();
+    }
+    const bool aligned = (n & 255) == 0;
+    auto first_j = [&](int s) { return aligned ? tid : (((tid - s * n) % 256) + 256) % 256; };
+    // (pos + shift) - x_i as in the terms themselves: the same rounding decides which pairs are neighbours
+    auto near = [&](int j, double shx, double shy, double shz) {
+        const double px = staged ? st->x[j] : a.pos[3 * j], py = staged ? st->y[j] : a.pos[3 * j + 1];
+        const double pz = staged ? st->z[j] : a.pos[3 * j + 2];
+        const double dx = px + shx - xi, dy = py + shy - yi, dz = pz + shz - zi;
+        return dx * dx + dy * dy + dz * dz <= cut2;
+    };
+    int nh = 0, rs = -1, rj = 0;
+    for (int s = 0; s < a.nshift; ++s) {
+        const double shx = a.shifts[3 * s], shy = a.shifts[3 * s + 1], shz = a.shifts[3 * s + 2];
+        if (rs >= 0) continue;                                     // (this thread's list is full: see below)
+        for (int j = first_j(s); j < n; j += 256) {
+            if (near(j, shx, shy, shz)) {
+                if (nh == a.hcap) { rs = s; rj = j; break; }
+                hits[tid][nh++] = s * n + j;
+            }
+        }
+    }
+    for (int h = 0; h < nh; ++h) heavy(hits[tid][h]);
+    if (rs < 0) return nh;
+    for (int s = rs; s < a.nshift; ++s) {
+        const double shx = a.shifts[3 * s], shy = a.shifts[3 * s + 1], shz = a.shifts[3 * s + 2];
+        for (int j = (s == rs) ? rj : first_j(s); j < n; j += 256)
+            if (near(j, shx, shy, shz)) heavy(s * n + j);
+    }
+    return -1;
+}
+
 __global__ __launch_bounds__(256) void emt_density_kernel(EmtArgs a) {
     __shared__ double red[4];
+    __shared__ int hits[256][EMT_HCAP + 1];
+    __shared__ EmtStage stage;
     const int i = blockIdx.x;
     const double xi = a.pos[3 * i], yi = a.pos[3 * i + 1], zi = a.pos[3 * i + 2];
     const double n0i = a.p.n0[i], g1i = a.p.gamma1[i], g2i = a.p.gamma2[i], V0i = a.p.V0[i];
     double sig = 0.0, ep = 0.0;
-    const long total = (long)a.n * a.nshift;
-    for (long t = threadIdx.x; t < total; t += 256) {
-        const int j = (int)(t % a.n), s = (int)(t / a.n);
+    auto heavy = [&](int t) {
+        const int j = t % a.n, s = t / a.n;
         const double dx = a.pos[3 * j] + a.shifts[3 * s] - xi;
         const double dy = a.pos[3 * j + 1] + a.shifts[3 * s + 1] - yi;
         const double dz = a.pos[3 * j + 2] + a.shifts[3 * s + 2] - zi;
@@ -55,6 +115,13 @@ __global__ __launch_bounds__(256) void emt_density_kernel(EmtArgs a) {
             sig += exp(-a.p.eta2[j] * (r - a.beta * a.p.s0[j])) * chi * theta / g1i;
             ep += 0.5 * V0i * exp(-a.p.kappa[j] * (r / a.beta - a.p.s0[j])) * chi / g2i * theta;
         }
+    };
+    const int nh = emt_pairs(a, xi, yi, zi, &stage, hits, heavy);
+    // the neighbour lists go on to the force kernel (same atom, same thread, same order): count < 0 = incomplete
+    {
+        int* out = a.nbr + ((size_t)i * 256 + threadIdx.x) * (EMT_HCAP + 1);
+        out[0] = nh;
+        for (int h = 0; h < nh; ++h) out[1 + h] = hits[threadIdx.x][h];
     }
     sig = block_sum(sig, red);
     ep = block_sum(ep, red);
@@ -77,14 +144,16 @@ __global__ __launch_bounds__(256) void emt_cohesive_kernel(EmtArgs a) {
 
 __global__ __launch_bounds__(256) void emt_force_kernel(EmtArgs a) {
     __shared__ double red[4];
+    __shared__ int hits[256][EMT_HCAP + 1];
+    __shared__ EmtStage stage;
+    __shared__ int incomplete;
     const int i = blockIdx.x;
     const double xi = a.pos[3 * i], yi = a.pos[3 * i + 1], zi = a.pos[3 * i + 2];
     const double n0i = a.p.n0[i], g1i = a.p.gamma1[i], g2i = a.p.gamma2[i], V0i = a.p.V0[i];
     const double eta2i = a.p.eta2[i], kapi = a.p.kappa[i], s0i = a.p.s0[i], dEi = a.dEdsig[i];
     double gx = 0.0, gy = 0.0, gz = 0.0;
-    const long total = (long)a.n * a.nshift;
-    for (long t = threadIdx.x; t < total; t += 256) {
-        const int j = (int)(t % a.n), s = (int)(t / a.n);
+    auto heavy = [&](int t) {
+        const int j = t % a.n, s = t / a.n;
         const double dx = a.pos[3 * j] + a.shifts[3 * s] - xi;
         const double dy = a.pos[3 * j + 1] + a.shifts[3 * s + 1] - yi;
         const double dz = a.pos[3 * j + 2] + a.shifts[3 * s + 2] - zi;
@@ -108,6 +177,18 @@ __global__ __launch_bounds__(256) void emt_force_kernel(EmtArgs a) {
             gy -= f * dy;
             gz -= f * dz;
         }
+    };
+    // neighbours from the density kernel's lists; the sweep again only if some thread's list overflowed there
+    const int* lst = a.nbr + ((size_t)i * 256 + threadIdx.x) * (EMT_HCAP + 1);
+    const int cnt = lst[0];
+    if (threadIdx.x == 0) incomplete = 0;
+    __syncthreads();
+    if (cnt < 0) incomplete = 1;
+    __syncthreads();
+    if (incomplete) {
+        (void)emt_pairs(a, xi, yi, zi, &stage, hits, heavy);
+    } else {
+        for (int h = 0; h < cnt; ++h) heavy(lst[1 + h]);
     }
     gx = block_sum(gx, red);
     gy = block_sum(gy, red);
@@ -148,7 +229,8 @@ int sella::emt_eval_resident(sella_ctx* c, int n, const double* pos, const doubl
 // SCR_MISC0 is used again.
 int sella::emt_queue(sella_ctx* c, int n, const double* pos, const double* par, int nshift, const double* shifts,
                      const double* dconst, double rc, double acut, double cutoff, double beta, double** eatom, double** grad) {
-    const size_t words = (size_t)3 * n + (size_t)9 * n + (size_t)3 * nshift + (size_t)4 * n + (size_t)3 * n + 64;
+    const size_t nbr_words = ((size_t)n * 256 * (EMT_HCAP + 1) + 1) / 2;
+    const size_t words = (size_t)3 * n + (size_t)9 * n + (size_t)3 * nshift + (size_t)4 * n + (size_t)3 * n + 64 + nbr_words;
     double* buf;
     SCHK(scratch_get(c, SCR_MISC0, words * sizeof(double), &buf));
     double* dpos = buf;
@@ -169,11 +251,13 @@ int sella::emt_queue(sella_ctx* c, int n, const double* pos, const double* par, 
     }
     EmtArgs a;
     a.n = n; a.nshift = nshift; a.pos = dpos; a.shifts = dsh;
+    a.hcap = (int)std::min<long>(std::max<long>(c->opt.emt_hcap, 1), EMT_HCAP);
     a.p.E0 = dpar; a.p.s0 = dpar + n; a.p.V0 = dpar + 2 * (size_t)n; a.p.eta2 = dpar + 3 * (size_t)n;
     a.p.kappa = dpar + 4 * (size_t)n; a.p.lam = dpar + 5 * (size_t)n; a.p.n0 = dpar + 6 * (size_t)n;
     a.p.gamma1 = dpar + 7 * (size_t)n; a.p.gamma2 = dpar + 8 * (size_t)n;
     a.rc = rc; a.acut = acut; a.cutoff = cutoff; a.beta = beta;
     a.sigma1 = dsig; a.epair = dep; a.dEdsig = dde; a.eatom = dea; a.grad = dgr;
+    a.nbr = reinterpret_cast<int*>(dgr + 3 * (size_t)n + 32);
     hipLaunchKernelGGL(emt_density_kernel, dim3(n), dim3(256), 0, c->stream, a);
     hipLaunchKernelGGL(emt_cohesive_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
     hipLaunchKernelGGL(emt_force_kernel, dim3(n), dim3(256), 0, c->stream, a);

@@ -118,6 +118,7 @@ struct Options {
                              // for the host's tred2 / tql2 (session r03l: 1.16 against 0.85 ms per block iteration), hence off
     long eigh_two_stage = 0; // 1: sella_eigh reduces dense -> band -> tridiagonal (eigh_two_stage.h) from eigh2_min rows on
     long eigh2_min = 6144;
+    long emt_hcap = 8;       // neighbour-list slots per thread of the EMT kernels (tests: 1 forces the overflow path)
     long eigh2_qr_reg = 1;   // panel factorisation of stage 1 with the sub-panel in registers (0: the row-streaming kernel)
     long lr_overlap = 0;     // 1: the view job of the one-call step is queued on a second stream, beside the coordinate kernels of the
                              //    full-space job.  Measured (session r04k): EMT-slab step 0.59-0.62 ms either way, and the ensemble of EMT

@@ -47,6 +47,38 @@ def test_emt_calculator_in_the_library(ctx):
     assert slab.calc.ncalls == before + 1                    # force calls the library makes are counted with the others
 
 
+def test_emt_neighbour_lists_that_overflow(ctx):
+    """The EMT kernels note each thread's neighbours first (eight slots per thread, far more than EMT's cutoff ever fills)
+    and hand the lists from the density pass to the force pass.  With one slot per thread (option `emt_hcap`) and the
+    cutoff opened up, threads find more than their list holds: it is worked off in batches, marked incomplete, and the
+    force pass sweeps again — same energy and forces as the oracle's all-pairs sums with the same cutoff."""
+    from conftest_shim import emt_slab
+    from oracle.sella_oracle.emt import EMTOracle
+    slab, _, _ = emt_slab((4, 4, 5), seed=5, jitter=0.03, calculator=EMTOracle())
+    slab.get_potential_energy()                                  # sets the oracle up for this cell
+    S = slab.calc._setup[1]
+    big = S['rc'] + 9.0
+    S['cutoff'] = big
+    e_ref, g_ref = slab.calc.energy_and_gradient(slab.positions)
+    par = np.array([S['arr'][k] for k in ('E0', 's0', 'V0', 'eta2', 'kappa', 'lam', 'n0', 'gamma1', 'gamma2')])
+    try:
+        ctx.set_option('emt_hcap', 1)
+        e, g = ctx.emt_eval(slab.positions, par, S['shifts'], S['rc'], S['acut'], big, slab.calc._BETA)
+    finally:
+        ctx.set_option('emt_hcap', 8)
+    assert len(slab) * len(S['shifts']) > 2 * 256               # more pairs than one slot per thread holds
+    assert abs(e - e_ref) <= 1e-11 * abs(e_ref)
+    np.testing.assert_allclose(g, g_ref, atol=1e-11 * np.abs(g_ref).max())
+    e8, g8 = ctx.emt_eval(slab.positions, par, S['shifts'], S['rc'], S['acut'], big, slab.calc._BETA)
+    assert e8 == e and np.array_equal(g8, g)                    # the batches keep the order of the terms: same bits
+    # and at EMT's own cutoff on the same geometry (complete lists, the usual path)
+    S['cutoff'] = S['rc'] + 0.5
+    e_ref, g_ref = slab.calc.energy_and_gradient(slab.positions)
+    e, g = ctx.emt_eval(slab.positions, par, S['shifts'], S['rc'], S['acut'], S['cutoff'], slab.calc._BETA)
+    assert abs(e - e_ref) <= 1e-12 * abs(e_ref)
+    np.testing.assert_allclose(g, g_ref, atol=1e-12 * np.abs(g_ref).max())
+
+
 @pytest.mark.parametrize('threepoint', [False, True])
 @pytest.mark.parametrize('pinned', [False, True])
 def test_fd_operator_equals_numerical_hessian(ctx, pinned, threepoint):

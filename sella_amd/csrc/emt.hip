@@ -47,6 +47,9 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 constexpr int EMT_HCAP = 8;
 constexpr int EMT_LDS_ATOMS = 1024;       // up to this many atoms the positions are staged in LDS (structure of arrays)
 
+// a noted pair: atom index in the low 24 bits, image above (no division when it is taken up again)
+__device__ __forceinline__ int emt_pack(int j, int s) { return (s << 24) | j; }
+
 struct EmtStage {
     double x[EMT_LDS_ATOMS], y[EMT_LDS_ATOMS], z[EMT_LDS_ATOMS];
 };
@@ -81,7 +84,7 @@ __device__ __forceinline__ int emt_pairs(const EmtArgs& a, double xi, double yi,
         for (int j = first_j(s); j < n; j += 256) {
             if (near(j, shx, shy, shz)) {
                 if (nh == a.hcap) { rs = s; rj = j; break; }
-                hits[tid][nh++] = s * n + j;
+                hits[tid][nh++] = emt_pack(j, s);
             }
         }
     }
@@ -90,7 +93,7 @@ __device__ __forceinline__ int emt_pairs(const EmtArgs& a, double xi, double yi,
     for (int s = rs; s < a.nshift; ++s) {
         const double shx = a.shifts[3 * s], shy = a.shifts[3 * s + 1], shz = a.shifts[3 * s + 2];
         for (int j = (s == rs) ? rj : first_j(s); j < n; j += 256)
-            if (near(j, shx, shy, shz)) heavy(s * n + j);
+            if (near(j, shx, shy, shz)) heavy(emt_pack(j, s));
     }
     return -1;
 }
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void emt_density_kernel(EmtArgs a) {
     const double n0i = a.p.n0[i], g1i = a.p.gamma1[i], g2i = a.p.gamma2[i], V0i = a.p.V0[i];
     double sig = 0.0, ep = 0.0;
     auto heavy = [&](int t) {
-        const int j = t % a.n, s = t / a.n;
+        const int j = t & 0xffffff, s = t >> 24;
         const double dx = a.pos[3 * j] + a.shifts[3 * s] - xi;
         const double dy = a.pos[3 * j + 1] + a.shifts[3 * s + 1] - yi;
         const double dz = a.pos[3 * j + 2] + a.shifts[3 * s + 2] - zi;
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) void emt_force_kernel(EmtArgs a) {
     const double eta2i = a.p.eta2[i], kapi = a.p.kappa[i], s0i = a.p.s0[i], dEi = a.dEdsig[i];
     double gx = 0.0, gy = 0.0, gz = 0.0;
     auto heavy = [&](int t) {
-        const int j = t % a.n, s = t / a.n;
+        const int j = t & 0xffffff, s = t >> 24;
         const double dx = a.pos[3 * j] + a.shifts[3 * s] - xi;
         const double dy = a.pos[3 * j + 1] + a.shifts[3 * s + 1] - yi;
         const double dz = a.pos[3 * j + 2] + a.shifts[3 * s + 2] - zi;
@@ -229,6 +232,7 @@ int sella::emt_eval_resident(sella_ctx* c, int n, const double* pos, const doubl
 // SCR_MISC0 is used again.
 int sella::emt_queue(sella_ctx* c, int n, const double* pos, const double* par, int nshift, const double* shifts,
                      const double* dconst, double rc, double acut, double cutoff, double beta, double** eatom, double** grad) {
+    if (n >= (1 << 24) || nshift > 127) { set_error("emt: at most 2^24 atoms and 127 periodic images"); return SELLA_E_INVALID; }
     const size_t nbr_words = ((size_t)n * 256 * (EMT_HCAP + 1) + 1) / 2;
     const size_t words = (size_t)3 * n + (size_t)9 * n + (size_t)3 * nshift + (size_t)4 * n + (size_t)3 * n + 64 + nbr_words;
     double* buf;

@@ -8,8 +8,8 @@
 // cutoff — 1024 atoms x 9 images are 9.4 M pair terms per pass, far below anything a neighbour list would
 // pay for itself on this device — and reduces in-block, so energies and forces are deterministic (no atomics).
 //   pass 1: sigma1_i = sum_j dsigma(i <- j), pair energy of atom i
-//   pass 2: cohesive function, dE/dsigma1_i                           (one thread per atom)
-//   pass 3: F_i by gathering both ordered pairs (i <- j) and (j <- i) of every neighbour
+//           cohesive function, dE/dsigma1_i                           (own density only: at the end of pass 1)
+//   pass 2: F_i by gathering both ordered pairs (i <- j) and (j <- i) of every neighbour
 #include "internal.h"
 
 namespace sella {
@@ -58,22 +58,17 @@ struct EmtStage {
 // — image by image (s uniform: its shift sits in scalar registers), neighbours noted in hits[tid][..] — then the noted pairs.
 // A thread whose list fills up (never at EMT's cutoff and 256 threads) works it off and takes its remaining pairs
 // directly, in the same order; the count returned is then negative: the stored list is incomplete.
-template <class Heavy>
-__device__ __forceinline__ int emt_pairs(const EmtArgs& a, double xi, double yi, double zi, EmtStage* st, int (*hits)[EMT_HCAP + 1],
-                                         Heavy heavy) {
+template <bool STAGED, class Heavy>
+__device__ __forceinline__ int emt_pairs_impl(const EmtArgs& a, double xi, double yi, double zi, const EmtStage* st,
+                                              int (*hits)[EMT_HCAP + 1], Heavy heavy) {
     const int tid = threadIdx.x, n = a.n;
     const double cut2 = a.cutoff * a.cutoff * (1.0 + 1e-12);
-    const bool staged = n <= EMT_LDS_ATOMS;
-    if (staged) {
-        for (int j = tid; j < n; j += 256) { st->x[j] = a.pos[3 * j]; st->y[j] = a.pos[3 * j + 1]; st->z[j] = a.pos[3 * j + 2]; }
-        __syncthreads();
-    }
     const bool aligned = (n & 255) == 0;
     auto first_j = [&](int s) { return aligned ? tid : (((tid - s * n) % 256) + 256) % 256; };
     // (pos + shift) - x_i as in the terms themselves: the same rounding decides which pairs are neighbours
     auto near = [&](int j, double shx, double shy, double shz) {
-        const double px = staged ? st->x[j] : a.pos[3 * j], py = staged ? st->y[j] : a.pos[3 * j + 1];
-        const double pz = staged ? st->z[j] : a.pos[3 * j + 2];
+        const double px = STAGED ? st->x[j] : a.pos[3 * j], py = STAGED ? st->y[j] : a.pos[3 * j + 1];
+        const double pz = STAGED ? st->z[j] : a.pos[3 * j + 2];
         const double dx = px + shx - xi, dy = py + shy - yi, dz = pz + shz - zi;
         return dx * dx + dy * dy + dz * dz <= cut2;
     };
@@ -81,11 +76,21 @@ __device__ __forceinline__ int emt_pairs(const EmtArgs& a, double xi, double yi,
     for (int s = 0; s < a.nshift; ++s) {
         const double shx = a.shifts[3 * s], shy = a.shifts[3 * s + 1], shz = a.shifts[3 * s + 2];
         if (rs >= 0) continue;                                     // (this thread's list is full: see below)
-        for (int j = first_j(s); j < n; j += 256) {
-            if (near(j, shx, shy, shz)) {
-                if (nh == a.hcap) { rs = s; rj = j; break; }
-                hits[tid][nh++] = emt_pack(j, s);
+        for (int j = first_j(s); j < n; j += 1024) {
+            bool in[4];                                            // four tests at a time: their loads are in flight together
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ju = j + 256 * u;
+                in[u] = near(ju < n ? ju : j, shx, shy, shz) && ju < n;
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (in[u] && rs < 0) {
+                    if (nh == a.hcap) { rs = s; rj = j + 256 * u; }
+                    else hits[tid][nh++] = emt_pack(j + 256 * u, s);
+                }
+            }
+            if (rs >= 0) break;
         }
     }
     for (int h = 0; h < nh; ++h) heavy(hits[tid][h]);
@@ -96,6 +101,17 @@ __device__ __forceinline__ int emt_pairs(const EmtArgs& a, double xi, double yi,
             if (near(j, shx, shy, shz)) heavy(emt_pack(j, s));
     }
     return -1;
+}
+
+template <class Heavy>
+__device__ __forceinline__ int emt_pairs(const EmtArgs& a, double xi, double yi, double zi, EmtStage* st, int (*hits)[EMT_HCAP + 1],
+                                         Heavy heavy) {
+    if (a.n <= EMT_LDS_ATOMS) {
+        for (int j = threadIdx.x; j < a.n; j += 256) { st->x[j] = a.pos[3 * j]; st->y[j] = a.pos[3 * j + 1]; st->z[j] = a.pos[3 * j + 2]; }
+        __syncthreads();
+        return emt_pairs_impl<true>(a, xi, yi, zi, st, hits, heavy);
+    }
+    return emt_pairs_impl<false>(a, xi, yi, zi, st, hits, heavy);
 }
 
 __global__ __launch_bounds__(256) void emt_density_kernel(EmtArgs a) {
@@ -131,18 +147,13 @@ __global__ __launch_bounds__(256) void emt_density_kernel(EmtArgs a) {
     if (threadIdx.x == 0) {
         a.sigma1[i] = sig;
         a.epair[i] = -ep;
+        // cohesive function and dE/dsigma1 of this atom (own density only: no pass of its own)
+        const double ds = -log(sig / 12.0) / (a.beta * a.p.eta2[i]);
+        const double xl = a.p.lam[i] * ds, yl = exp(-xl);
+        const double z = 6.0 * a.p.V0[i] * exp(-a.p.kappa[i] * ds);
+        a.eatom[i] = a.p.E0[i] * ((1.0 + xl) * yl - 1.0) + z + -ep;
+        a.dEdsig[i] = (a.p.E0[i] * xl * yl * a.p.lam[i] + z * a.p.kappa[i]) / (sig * a.beta * a.p.eta2[i]);
     }
-}
-
-__global__ __launch_bounds__(256) void emt_cohesive_kernel(EmtArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
-    const double sig = a.sigma1[i];
-    const double ds = -log(sig / 12.0) / (a.beta * a.p.eta2[i]);
-    const double xl = a.p.lam[i] * ds, yl = exp(-xl);
-    const double z = 6.0 * a.p.V0[i] * exp(-a.p.kappa[i] * ds);
-    a.eatom[i] = a.p.E0[i] * ((1.0 + xl) * yl - 1.0) + z + a.epair[i];
-    a.dEdsig[i] = (a.p.E0[i] * xl * yl * a.p.lam[i] + z * a.p.kappa[i]) / (sig * a.beta * a.p.eta2[i]);
 }
 
 __global__ __launch_bounds__(256) void emt_force_kernel(EmtArgs a) {
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(256) void emt_force_kernel(EmtArgs a) {
 using namespace sella;
 
 // dconst != nullptr: the parameter table and the shift vectors are resident already (9 n + 3 nshift doubles, uploaded by
-// the caller once: sella_calc_emt_create) — a force call is then one upload (positions), three kernels, one read-back
+// the caller once: sella_calc_emt_create) — a force call is then one upload (positions), two kernels, one read-back
 int sella::emt_eval_resident(sella_ctx* c, int n, const double* pos, const double* par, int nshift, const double* shifts,
                              const double* dconst, double rc, double acut, double cutoff, double beta, double* energy,
                              double* grad) {
@@ -227,7 +238,7 @@ int sella::emt_eval_resident(sella_ctx* c, int n, const double* pos, const doubl
     return SELLA_OK;
 }
 
-// the same up to the kernels: positions uploaded, three launches queued, nothing waited for.  *eatom (n per-atom
+// the same up to the kernels: positions uploaded, two launches queued, nothing waited for.  *eatom (n per-atom
 // energies, summed by the caller in index order) and *grad (3 n, directly behind) stay valid until scratch slot
 // SCR_MISC0 is used again.
 int sella::emt_queue(sella_ctx* c, int n, const double* pos, const double* par, int nshift, const double* shifts,
@@ -263,7 +274,6 @@ int sella::emt_queue(sella_ctx* c, int n, const double* pos, const double* par, 
     a.sigma1 = dsig; a.epair = dep; a.dEdsig = dde; a.eatom = dea; a.grad = dgr;
     a.nbr = reinterpret_cast<int*>(dgr + 3 * (size_t)n + 32);
     hipLaunchKernelGGL(emt_density_kernel, dim3(n), dim3(256), 0, c->stream, a);
-    hipLaunchKernelGGL(emt_cohesive_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
     hipLaunchKernelGGL(emt_force_kernel, dim3(n), dim3(256), 0, c->stream, a);
     HIPCHK(hipGetLastError());
     *eatom = dea;

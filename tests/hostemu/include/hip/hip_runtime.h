@@ -149,6 +149,7 @@ static inline int hipemu_readlane(int v, int lane) {
     return out;
 }
 #define __builtin_amdgcn_readlane hipemu_readlane
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 static inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
 static inline int __double2hiint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b >> 32); }
 static inline double __hiloint2double(int hi, int lo) {

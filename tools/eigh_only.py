@@ -31,6 +31,9 @@ if os.environ.get('EIGH_TWO_STAGE'):
     ctx.set_option('eigh2_min', int(os.environ['EIGH_TWO_STAGE']))
 if os.environ.get('EIGH_LEAF'):
     ctx.set_option('eigh_leaf', int(os.environ['EIGH_LEAF']))
+for kv in filter(None, os.environ.get('EIGH_OPTS', '').split(',')):     # generic: EIGH_OPTS=key=value,key=value
+    key, value = kv.split('=')
+    ctx.set_option(key, int(value))
 rng = np.random.RandomState(0)
 kind = sys.argv[3] if len(sys.argv) > 3 else 'dense'
 if kind == 'dense':

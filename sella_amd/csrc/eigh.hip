@@ -61,7 +61,6 @@ struct TrdRowArgs {
     const double* colscal;                      // {tau, scale} of column j-1
     const double* cdots;                        // W_p.v (p < i-1) at [p], V_p.v at [TRD_NBMAX + p] (from K2)
     double* dvec;
-    double* Aprev_row;                          // one-launch-per-column chain: row j-1 of A receives its reflector here
 };
 
 // K1.  Thread owns absolute column c = j + blockIdx.x*256 + tid.
@@ -154,7 +153,6 @@ __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
         const double wj = tau * (wrawj - t) + alpha2;           // w_{i-1}[j], v_{i-1}[j] = 1
         wc = tau * (wrawc - s) + alpha2 * vprev;
         if (valid) a.Wp[(size_t)ip * ldp + c] = wc;
-        if (a.Aprev_row && valid && c > j) a.Aprev_row[c] = vprev;
         u = arow - q - (vprev * wj + wc);                       // p = i-1: W[j] = wj, V[j] = 1
     } else {
         u = arow;
@@ -286,50 +284,46 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
     }
 }
 
-// ---- one launch per column (round 5) -------------------------------------------------------------------------------
-// K1 + K2 in ONE kernel: the chain of the factorisation is n dependent steps, and with two launches per step half of
-// them sat on the floor of a launch (row kernel 3.6-4.2 us for 24 KB of work).  What K1 produced — the finished w of the
-// previous column and the updated row u — is elementwise in the column index c given a handful of uniform scalars, so
-// every workgroup of the matvec forms u[c] ON THE FLY for the columns its threads stream (2 ip + 3 panel / vector loads
-// per column, all L2 hits: the panel is 2 x 16 rows) instead of reading it from memory behind a kernel boundary:
-//     w_ip[c] = tau (wraw[c] - s[c]) + alpha2 v_ip[c]          s = sum_{p<ip} V_p c1_p + W_p c2_p      (dlatrd)
-//     u[c]    = A[j][c] - q[c] - (v_ip[c] w_ip[j] + w_ip[c])    q = sum_{p<ip} V_p W_p[j] + W_p V_p[j]
-// The redundancy is the price of having no exchange between workgroups: R rows per workgroup keep it at (2 ip + 3) / R
-// of the matrix stream, out of L2.  The scalars every workgroup needs (v.wraw of the previous column from its per-
-// workgroup partials, the panel dots, tau) are a few loads that go out together with the first matrix loads; each
-// wavefront reduces the partials for itself, so there is NO barrier in front of the stream.  Everything a workgroup
-// reads that this launch also writes is double-buffered by the host (wraw, partials, panel dots, column scalars); the
-// reflector cannot go to row j of A while other workgroups still read that row, so row j - 1 is written here (v_ip is
-// streamed anyway) and the last one of a panel by the finishing launch.  One designated workgroup per chunk of columns
-// stores w_ip; the dots W_ip.v, V_ip.v of the row that is finished here are accumulated on the fly (the earlier panel
-// rows are appended to the matvec as before).
-struct TrdColArgs {
+// ---- one launch per column, trailing block kept up to date (round 5) ------------------------------------------------
+// Below ~1800 trailing rows the block (8 m^2 <= 26 MB) is served by the L2s and the Infinity Cache, and every column of
+// the blocked chain costs two launches on their floors (row kernel 3.4-4.4 us + matvec 3.5-6 us) plus its share of the
+// rank-2nb update.  There the chain switches to dsytd2's algebra with ONE launch per column: the launch for column j
+//   (1) finishes  w = tau A v + alpha2 v  of column j-1 from the raw product, its per-workgroup v.(A v) partials and tau
+//       (each wavefront reduces the partials for itself: no barrier in front of the stream),
+//   (2) applies   A22 -= v w^T + w v^T   to the rows it owns — so the trailing block is always current and there is no
+//       panel, no W^T v / V^T v correction and no separate trailing update —
+//   (3) forms row j of the updated block on the fly, u = A[j] - w - w[j] v (three vector loads per column, against
+//       2 i + 3 for a lazy panel: a first version that formed the lazily updated row inside the matvec of the BLOCKED
+//       chain lost to the two-launch pair at every size, profiles/r05_trd_col_onthefly_sweep.log — the panel reads of all
+//       workgroups together exceeded what the L2s deliver),
+//   (4) multiplies its updated rows with u (reflector scalars applied afterwards, as in trd_gemv_kernel).
+// Cost: the block is written back once per column (16 m^2 instead of 8 m^2 + 16 m^2 / nb bytes) — which is why this is
+// the path of the SMALL trailing blocks only.  Everything a launch reads that it also writes is double-buffered by the
+// host (v, A v, partials, column scalars); reflector j cannot go to row j of A while other workgroups still read that
+// row, so row j-1 is written here (v is streamed anyway) and the last one by trd_upd_finish_kernel, which also applies
+// the last rank-2 update before the LDS tail takes over.
+struct TrdUpdArgs {
     double* A; int ld, n;
-    int j, i;                   // column; local index in the panel (i < kb)
+    int j;                      // column
     int o, m, oc, shift;        // o = j + 1, m = n - o, oc = o rounded down to even, shift = o - oc
     int pad;                    // dummy rows in front: row group -> workgroup id mod 8 (XCD) fixed across columns
-    double* Vp; double* Wp; int ldp;
-    const double* wraw_prev; double* wraw_cur;
+    const double* v_prev; double* v_cur;            // reflector of column j-1 / j, absolute index (v[o] = 1)
+    const double* wraw_prev; double* wraw_cur;      // A22 v, absolute row index
     const double* partB_prev; int nblkB_prev; double* partB_cur;
-    const double* cdots_prev; double* cdots_cur;
     const double* colscal_prev; double* colscal_cur;
     double* taus; double* evec; double* dvec;
 };
 
 __device__ __forceinline__ double2 ldg2(const double* p) { return *reinterpret_cast<const double2*>(p); }
-constexpr int TRD_COL_MAXGRID = 1024;   // workgroups per launch: their v.wraw partials are summed by every wavefront, 16 per lane
+constexpr int TRD_UPD_MAXGRID = 1024;   // workgroups per launch: their v.wraw partials are summed by every wavefront, 16 per lane
 
-template <int R, int NT, int PB, bool FIRST>
-__global__ __launch_bounds__(NT) void trd_col_kernel(TrdColArgs a) {
+template <int R, int NT, bool FIRST>
+__global__ __launch_bounds__(NT) void trd_upd_kernel(TrdUpdArgs a) {
     constexpr int NW = NT / 64;
-    __shared__ double red[NW][R + 3];
+    __shared__ double red[NW][R + 1];
     __shared__ double ush[R];
-    __shared__ double bc[3];                                // u[o], w_ip[o], v_ip[o]
-    // the four uniform values of every finished panel column, one private copy per wavefront (written by lane p, read
-    // back as broadcasts: LDS operations of one wavefront execute in order, so no barrier is involved)
-    __shared__ double coef[FIRST ? 1 : NW][FIRST ? 1 : TRD_NBMAX][4];
+    __shared__ double bc[3];                                // u[o], w[o], v[o]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ip = FIRST ? 0 : a.i - 1;
     const int bw = a.pad / R;                               // first workgroup that owns a real row
     const int b = blockIdx.x;
     if (b < bw) {
@@ -337,47 +331,41 @@ __global__ __launch_bounds__(NT) void trd_col_kernel(TrdColArgs a) {
         return;
     }
     const int row0 = b * R - a.pad;
-    const int mtot = a.m + 2 * ip;
-    const int j = a.j, o = a.o, n = a.n, ldp = a.ldp;
-    const double* rbase[R];
+    const int j = a.j, o = a.o, n = a.n;
+    double* rbase[R];
+    int rrow[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int rr = row0 + r;
         if (rr < 0) rr = 0;
-        if (rr > mtot - 1) rr = mtot - 1;
-        const double* base;
-        if (rr < a.m) base = a.A + (size_t)(o + rr) * a.ld + a.oc;
-        else if (rr < a.m + ip) base = a.Wp + (size_t)(rr - a.m) * ldp + a.oc;
-        else base = a.Vp + (size_t)(rr - a.m - ip) * ldp + a.oc;
-        rbase[r] = base;
+        if (rr > a.m - 1) rr = a.m - 1;
+        rrow[r] = o + rr;
+        rbase[r] = a.A + (size_t)(o + rr) * a.ld + a.oc;
     }
     const int n2 = (a.m + a.shift + 1) >> 1;
     const double* Arowj = a.A + (size_t)j * a.ld;
-    const double* Vip = a.Vp + (size_t)ip * ldp;
-    // Every load of the first chunk goes out before the first use, in the order of use: the scalars, the vectors the
-    // updated row is made of, the first PB panel rows, the matrix.  (A loop with a run-time trip count in front of the
-    // stream would put one memory round trip per iteration on the critical path of the factorisation.)
-    // ---- (1) scalars: partial sums of v.wraw (lane-strided), the four uniform values of panel column `lane`
-    double pv[TRD_COL_MAXGRID / 64], c1l = 0.0, c2l = 0.0, vjl = 0.0, wjl = 0.0, tau = 0.0, wrawj = 0.0;
+    // Every load of the first chunk goes out before the first use, in the order of use.
+    // ---- (1) scalars: partial sums of v.wraw (lane-strided), tau, the entries of v and A v at this workgroup's rows
+    double pv[TRD_UPD_MAXGRID / 64], tau = 0.0, wrawj = 0.0, vrow[R], wrow[R];
     const double ajj = Arowj[j];
     if (!FIRST) {
 #pragma unroll
-        for (int k = 0; k < TRD_COL_MAXGRID / 64; ++k) {
+        for (int k = 0; k < TRD_UPD_MAXGRID / 64; ++k) {
             const int bb = lane + 64 * k;
             pv[k] = a.partB_prev[bb < a.nblkB_prev ? bb : a.nblkB_prev - 1];
         }
-        const int pl = lane < ip ? lane : 0;
-        c1l = a.cdots_prev[pl];
-        c2l = a.cdots_prev[TRD_NBMAX + pl];
-        vjl = a.Vp[(size_t)pl * ldp + j];
-        wjl = a.Wp[(size_t)pl * ldp + j];
         tau = a.colscal_prev[0];
         wrawj = a.wraw_prev[j];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            vrow[r] = a.v_prev[rrow[r]];
+            wrow[r] = a.wraw_prev[rrow[r]];
+        }
     }
-    // ---- (2) row j, wraw, v_ip and the first panel batch at this thread's columns, (3) the matrix
+    // ---- (2) row j, A v and v at this thread's columns, (3) the matrix rows
     int k = tid;
     bool has = k < n2;
-    double2 ajv = make_double2(0.0, 0.0), wrv = ajv, vpv = ajv, vv[PB], ww[PB], mat[R];
+    double2 ajv, wrv = make_double2(0.0, 0.0), vpv = wrv, mat[R];
     double lead[R];
     {
         // (lanes without a chunk load chunk 0 again: a branch here would make every wait below cover both paths)
@@ -385,13 +373,7 @@ __global__ __launch_bounds__(NT) void trd_col_kernel(TrdColArgs a) {
         ajv = ldg2(Arowj + ca);
         if (!FIRST) {
             wrv = ldg2(a.wraw_prev + ca);
-            vpv = ldg2(Vip + ca);
-#pragma unroll
-            for (int pp = 0; pp < PB; ++pp) {
-                const int p = pp < ip ? pp : (ip > 0 ? ip - 1 : 0);
-                vv[pp] = ldg2(a.Vp + (size_t)p * ldp + ca);
-                ww[pp] = ldg2(a.Wp + (size_t)p * ldp + ca);
-            }
+            vpv = ldg2(a.v_prev + ca);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) mat[r] = ldg2(rbase[r] + 2 * kc);
@@ -403,23 +385,19 @@ __global__ __launch_bounds__(NT) void trd_col_kernel(TrdColArgs a) {
     if (!FIRST) {
         double vw = 0.0;
 #pragma unroll
-        for (int q = 0; q < TRD_COL_MAXGRID / 64; ++q) vw += (lane + 64 * q < a.nblkB_prev) ? pv[q] : 0.0;
-        if (lane >= ip) { c1l = 0.0; c2l = 0.0; vjl = 0.0; wjl = 0.0; }
-        coef[wave][lane][0] = c1l; coef[wave][lane][1] = c2l;       // (zeros from lane ip on: a batch may run over)
-        coef[wave][lane][2] = vjl; coef[wave][lane][3] = wjl;
+        for (int q = 0; q < TRD_UPD_MAXGRID / 64; ++q) vw += (lane + 64 * q < a.nblkB_prev) ? pv[q] : 0.0;
         vw = wave_sum_e(vw);
-        const double cc = wave_sum_e(c1l * c2l);
-        const double t = wave_sum_e(vjl * c1l + wjl * c2l);
-        const double qj = wave_sum_e(2.0 * vjl * wjl);
-        alpha2 = -0.5 * tau * tau * (vw - 2.0 * cc);
-        wj = tau * (wrawj - t) + alpha2;                    // w_ip[j]   (v_ip[j] = 1)
-        dj = ajj - qj - 2.0 * wj;                           // u[j]: the diagonal entry of T
+        alpha2 = -0.5 * tau * tau * vw;
+        wj = tau * wrawj + alpha2;                          // w[j]   (v[j] = 1)
+        dj = ajj - 2.0 * wj;                                // u[j]: the diagonal entry of T
+#pragma unroll
+        for (int r = 0; r < R; ++r) wrow[r] = tau * wrow[r] + alpha2 * vrow[r];       // w at this workgroup's rows
     }
     // ---- the stream
     double acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
-    double ss = 0.0, d1 = 0.0, d2 = 0.0;
+    double ss = 0.0;
     double* Aprev = a.A + (size_t)(j - 1) * a.ld;           // row of the previous reflector (not FIRST)
     const int nown = (int)gridDim.x - bw;                   // workgroups that run the stream
     const int nset = (n2 + NT - 1) / NT;
@@ -427,96 +405,74 @@ __global__ __launch_bounds__(NT) void trd_col_kernel(TrdColArgs a) {
         if (has) {
             const int ca = a.oc + 2 * k;
             double ue[2] = {ajv.x, ajv.y};
-            double wce[2] = {0.0, 0.0}, vpe[2] = {0.0, 0.0};
+            double wce[2] = {0.0, 0.0};
+            const double vpe[2] = {vpv.x, vpv.y};
             if (!FIRST) {
-                double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
-                // panel sums: batch 0 is in registers, further batches (ip > PB) are loaded PB rows at a time
-                for (int p0 = 0;;) {
-                    // (coefficients four panel columns at a time: fetched all at once they would occupy 8 PB registers)
-#pragma unroll
-                    for (int pg = 0; pg < PB; pg += 4) {
-                        if (p0 + pg < ip) {
-#pragma unroll
-                            for (int pp = pg; pp < pg + 4 && pp < PB; ++pp) {
-                                const int pc = p0 + pp;                              // (rows beyond ip: zero weights)
-                                const double c1 = coef[wave][pc][0], c2 = coef[wave][pc][1];
-                                const double vj = coef[wave][pc][2], wjp = coef[wave][pc][3];
-                                s0 += vv[pp].x * c1 + ww[pp].x * c2;
-                                s1 += vv[pp].y * c1 + ww[pp].y * c2;
-                                q0 += vv[pp].x * wjp + ww[pp].x * vj;
-                                q1 += vv[pp].y * wjp + ww[pp].y * vj;
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    p0 += PB;
-                    if (p0 >= ip) break;
-#pragma unroll
-                    for (int pp = 0; pp < PB; ++pp) {
-                        const int p = p0 + pp < ip ? p0 + pp : ip - 1;
-                        vv[pp] = ldg2(a.Vp + (size_t)p * ldp + ca);
-                        ww[pp] = ldg2(a.Wp + (size_t)p * ldp + ca);
-                    }
-                }
-                wce[0] = tau * (wrv.x - s0) + alpha2 * vpv.x;
-                wce[1] = tau * (wrv.y - s1) + alpha2 * vpv.y;
-                vpe[0] = vpv.x; vpe[1] = vpv.y;
-                ue[0] = ajv.x - q0 - (vpv.x * wj + wce[0]);
-                ue[1] = ajv.y - q1 - (vpv.y * wj + wce[1]);
+                wce[0] = tau * wrv.x + alpha2 * vpv.x;
+                wce[1] = tau * wrv.y + alpha2 * vpv.y;
+                ue[0] = ajv.x - wce[0] - wj * vpv.x;
+                ue[1] = ajv.y - wce[1] - wj * vpv.y;
             }
             const bool store = t % nown == b - bw;
             double x[2];
+            bool inw[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int c = ca + e;
-                const bool inw = c >= o && c < n;
+                inw[e] = c >= o && c < n;
                 const bool inu = c > o && c < n;
                 if (c == o) { bc[0] = ue[e]; bc[1] = wce[e]; bc[2] = vpe[e]; }
                 const int own = c - o - row0;
-                if (inw && own >= 0 && own < R) ush[own] = ue[e];
-                if (!FIRST && store && inw) {
-                    a.Wp[(size_t)ip * ldp + c] = wce[e];
-                    Aprev[c] = vpe[e];
-                }
+                if (inw[e] && own >= 0 && own < R) ush[own] = ue[e];
+                if (!FIRST && store && inw[e]) Aprev[c] = vpe[e];
                 x[e] = inu ? ue[e] : 0.0;
                 ss += x[e] * x[e];
-                if (!FIRST) {
-                    d1 += (inu ? wce[e] : 0.0) * x[e];
-                    d2 += (inu ? vpe[e] : 0.0) * x[e];
-                }
-            }
+                if (!inw[e]) wce[e] = 0.0;                  // (outside the block: no update, and nothing undefined
+            }                                               //  from the padding of the vectors reaches the sums)
+            const double vm[2] = {inw[0] ? vpe[0] : 0.0, inw[1] ? vpe[1] : 0.0};
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] += mat[r].x * x[0] + mat[r].y * x[1];
+            for (int r = 0; r < R; ++r) {
+                double m0 = mat[r].x, m1 = mat[r].y;
+                if (!FIRST) {
+                    // the rank-2 update of column j-1 on this row, written back (rows beyond the block are clamped copies
+                    // of its last row: they compute, they do not store)
+                    m0 -= vrow[r] * wce[0] + wrow[r] * vm[0];
+                    m1 -= vrow[r] * wce[1] + wrow[r] * vm[1];
+                    const int rr = row0 + r;
+                    if (rr >= 0 && rr < a.m) {
+                        double* dst = rbase[r] + 2 * k;
+                        if (inw[0] && inw[1]) *reinterpret_cast<double2*>(dst) = make_double2(m0, m1);
+                        else {
+                            if (inw[0]) dst[0] = m0;
+                            if (inw[1]) dst[1] = m1;
+                        }
+                    }
+                }
+                acc[r] += m0 * x[0] + m1 * x[1];
+            }
         }
         k += NT;
         has = k < n2;
         if (t + 1 < nset) {
-            // next chunk: same order
             const int kc = has ? k : 0, ca = a.oc + 2 * kc;
             ajv = ldg2(Arowj + ca);
             if (!FIRST) {
                 wrv = ldg2(a.wraw_prev + ca);
-                vpv = ldg2(Vip + ca);
-#pragma unroll
-                for (int pp = 0; pp < PB; ++pp) {
-                    const int p = pp < ip ? pp : (ip > 0 ? ip - 1 : 0);
-                    vv[pp] = ldg2(a.Vp + (size_t)p * ldp + ca);
-                    ww[pp] = ldg2(a.Wp + (size_t)p * ldp + ca);
-                }
+                vpv = ldg2(a.v_prev + ca);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) mat[r] = ldg2(rbase[r] + 2 * kc);
         }
     }
-    // ---- one exchange: row sums, |u'|^2 and the two dots of the row finished here
+    // ---- one exchange: row sums and |u'|^2
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const double v = wave_sum_e(acc[r]);
         if (lane == 0) red[wave][r] = v;
     }
     {
-        const double v0 = wave_sum_e(ss), v1 = wave_sum_e(d1), v2 = wave_sum_e(d2);
-        if (lane == 0) { red[wave][R] = v0; red[wave][R + 1] = v1; red[wave][R + 2] = v2; }
+        const double v0 = wave_sum_e(ss);
+        if (lane == 0) red[wave][R] = v0;
     }
     __syncthreads();
     if (wave != 0) return;
@@ -537,25 +493,23 @@ __global__ __launch_bounds__(NT) void trd_col_kernel(TrdColArgs a) {
         scale = 1.0 / (alpha - beta);
     }
     double p = 0.0;
-    // lead[] lives in registers indexed by r: unrolled select instead of a dynamic index
+    // per-row registers are indexed by r: unrolled select instead of a dynamic index
     double res = 0.0;
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (lane == r) res = scale * total(r) + lead[r];
+        if (lane == r) {
+            // entry of the UPDATED row in column o (v[o] = 1 multiplies it)
+            const double ld_new = FIRST ? lead[r] : lead[r] - (vrow[r] * bc[1] + wrow[r] * bc[2]);
+            res = scale * total(r) + ld_new;
+        }
     if (lane < R) {
         const int rr = row0 + lane;
-        if (rr < 0) {
-            // dummy row of the alignment pad
-        } else if (rr < a.m) {
+        if (rr >= 0 && rr < a.m) {
             const int rabs = o + rr;
             const double vr = (rr == 0) ? 1.0 : scale * ush[lane];
             a.wraw_cur[rabs] = res;
-            a.Vp[(size_t)a.i * ldp + rabs] = vr;
+            a.v_cur[rabs] = vr;
             p = vr * res;
-        } else if (rr < a.m + ip) {
-            a.cdots_cur[rr - a.m] = res;
-        } else if (rr < mtot) {
-            a.cdots_cur[TRD_NBMAX + rr - a.m - ip] = res;
         }
     }
     p = wave_sum_e(p);
@@ -567,12 +521,40 @@ __global__ __launch_bounds__(NT) void trd_col_kernel(TrdColArgs a) {
             a.colscal_cur[0] = taun;
             a.colscal_cur[1] = scale;
             a.dvec[j] = dj;
-            if (!FIRST) {
-                a.cdots_cur[ip] = bc[1] + scale * total(R + 1);
-                a.cdots_cur[TRD_NBMAX + ip] = bc[2] + scale * total(R + 2);
-                a.Wp[(size_t)ip * ldp + j] = wj;
-            }
         }
+    }
+}
+
+// The last rank-2 update of the one-launch-per-column chain (column jl = o - 1) on the rows >= o it leaves behind, and
+// reflector jl into its row.  One workgroup per 4 rows (the block has at most ~130 rows here when the LDS tail follows,
+// more when it is switched off); launched with 256 threads.
+struct TrdUpdFinishArgs {
+    double* A; int ld, n, o;
+    const double* v; const double* wraw;
+    const double* partB; int nblkB;
+    const double* colscal;
+};
+
+__global__ __launch_bounds__(256) void trd_upd_finish_kernel(TrdUpdFinishArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    double vw = 0.0;
+    for (int b0 = lane; b0 < a.nblkB; b0 += 64) vw += a.partB[b0];
+    vw = wave_sum_e(vw);
+    const double tau = a.colscal[0];
+    const double alpha2 = -0.5 * tau * tau * vw;
+    const int m = a.n - a.o;
+    for (int rr = blockIdx.x * 4; rr < blockIdx.x * 4 + 4 && rr < m; ++rr) {
+        const int r = a.o + rr;
+        const double vr = a.v[r], wr = tau * a.wraw[r] + alpha2 * vr;
+        double* row = a.A + (size_t)r * a.ld;
+        for (int c = a.o + tid; c < a.n; c += 256) {
+            const double vc = a.v[c], wc = tau * a.wraw[c] + alpha2 * vc;
+            row[c] -= vr * wc + wr * vc;
+        }
+    }
+    if (blockIdx.x == 0) {
+        double* refl = a.A + (size_t)(a.o - 1) * a.ld;
+        for (int c = a.o + 1 + tid; c < a.n; c += 256) refl[c] = a.v[c];
     }
 }
 
@@ -2185,12 +2167,11 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     double* wraw = W.vec + (size_t)V_WRAW * ld;
     double* colscal = W.vec + (size_t)V_COL * ld;
     double* cdots = partB + maxblkB + 8;               // 2 * TRD_NBMAX doubles
-    // second set of everything a column launch both reads (previous column) and writes (trd_col_kernel)
+    // one-launch-per-column chain (trd_upd_kernel): second set of everything a launch both reads (previous column) and writes
     double* partB2[2] = {partB, cdots + 2 * TRD_NBMAX + 8};
-    double* cdots2[2] = {cdots, partB2[1] + maxblkB + 8};
-    double* colscal2[2] = {colscal, cdots2[1] + 2 * TRD_NBMAX + 8};
+    double* colscal2[2] = {colscal, partB2[1] + maxblkB + 8};
     double* wraw2[2] = {wraw, W.vec + (size_t)V_WRAW2 * ld};
-    const bool fused = c->opt.eigh_fused != 0;
+    const int upd_max = (int)c->opt.eigh_upd_max;
     int cur = 0, nblkA_prev = 0, nblkB_prev = 0;
     // symmetric-aware matvec for trailing blocks of at least `eigh_symv_min` rows (0: never)
     const int symv_min = (int)c->opt.eigh_symv_min;
@@ -2207,6 +2188,69 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     const bool can_tri = c->opt.rank2k_stream && c->opt.eigh_symv_tri;
     for (int j0 = 0; j0 < nrefl; j0 += nb) {
         const int kb = std::min(nb, nrefl - j0);
+        if (upd_max > 0 && !lower_stale && n - j0 - 1 <= upd_max && !(tail_lds > 0 && n - j0 <= tail_lds) &&
+            !(symv_min > 0 && n - j0 - 1 >= symv_min)) {
+            // ---- small trailing block: one launch per column from here to the LDS tail (or to the end)
+            const int jend = tail_lds > 0 ? std::min(nrefl, n - tail_lds) : nrefl;
+            int fc = 0, nblk_last = 0;
+            for (int j = j0; j < jend; ++j) {
+                const int o = j + 1, m = n - o;
+                TrdUpdArgs ua;
+                ua.A = W.A; ua.ld = ld; ua.n = n; ua.j = j;
+                ua.o = o; ua.m = m; ua.oc = o & ~1; ua.shift = o - ua.oc;
+                ua.v_prev = ub[1 - fc]; ua.v_cur = ub[fc];
+                ua.wraw_prev = wraw2[1 - fc]; ua.wraw_cur = wraw2[fc];
+                ua.partB_prev = partB2[1 - fc]; ua.nblkB_prev = nblk_last; ua.partB_cur = partB2[fc];
+                ua.colscal_prev = colscal2[1 - fc]; ua.colscal_cur = colscal2[fc];
+                ua.taus = taus; ua.evec = evec; ua.dvec = dvec;
+                int R = (int)c->opt.eigh_upd_rows;
+                if (R != 2 && R != 4 && R != 8) R = m >= c->opt.eigh_upd_r8_min ? 8 : m >= c->opt.eigh_upd_r4_min ? 4 : 2;
+                while (R < 8 && (8 * R + m + R - 1) / R > TRD_UPD_MAXGRID) R *= 2;
+                ua.pad = o % (8 * R);
+                const int grid = (ua.pad + m + R - 1) / R;
+                if (grid > TRD_UPD_MAXGRID) { set_error("eigh_upd_max too large for the one-launch-per-column chain"); return SELLA_E_INVALID; }
+                const int n2 = (m + ua.shift + 1) >> 1;     // 16-byte chunks per row: one per thread up to 1024 columns
+                const int nt_max = (int)c->opt.eigh_upd_nt;
+                const bool first = j == j0;
+                const bool prof_all = c->prof;
+                if (prof_all && (j & 3)) c->prof = false;
+                if (c->prof) SCHK(stream_wait(c));
+                prof_begin(c, PROF_TRD_GEMV, (first ? 8.0 : 16.0) * m * (double)m, (first ? 2.0 : 6.0) * m * (double)m);
+#define SELLA_TRD_UPD(RR, NT)                                                                                             \
+    do {                                                                                                                  \
+        if (first) SELLA_LAUNCH(c, HIP_KERNEL_NAME(trd_upd_kernel<RR, NT, true>), dim3(grid), dim3(NT), 0, ua);           \
+        else SELLA_LAUNCH(c, HIP_KERNEL_NAME(trd_upd_kernel<RR, NT, false>), dim3(grid), dim3(NT), 0, ua);                \
+    } while (0)
+#define SELLA_TRD_UPD_NT(RR)                                                                                              \
+    do {                                                                                                                  \
+        if (nt_max <= 128 || n2 <= 128) SELLA_TRD_UPD(RR, 128);                                                           \
+        else if (nt_max <= 256 || n2 <= 256) SELLA_TRD_UPD(RR, 256);                                                      \
+        else SELLA_TRD_UPD(RR, 512);                                                                                      \
+    } while (0)
+                switch (R) {
+                    case 2: SELLA_TRD_UPD_NT(2); break;
+                    case 4: SELLA_TRD_UPD_NT(4); break;
+                    default: SELLA_TRD_UPD_NT(8); break;
+                }
+#undef SELLA_TRD_UPD_NT
+#undef SELLA_TRD_UPD
+                prof_end(c);
+                c->prof = prof_all;
+                nblk_last = grid;
+                fc = 1 - fc;
+            }
+            if (jend > j0) {
+                TrdUpdFinishArgs fa;
+                fa.A = W.A; fa.ld = ld; fa.n = n; fa.o = jend;
+                fa.v = ub[1 - fc]; fa.wraw = wraw2[1 - fc];
+                fa.partB = partB2[1 - fc]; fa.nblkB = nblk_last;
+                fa.colscal = colscal2[1 - fc];
+                SELLA_LAUNCH(c, trd_upd_finish_kernel, dim3((n - jend + 3) / 4), dim3(256), 0, fa);
+            }
+            HIPCHK(hipGetLastError());
+            j0 = jend - nb;                                 // (the loop adds nb: the next pass starts at jend)
+            continue;
+        }
         if (tail_lds > 0 && n - j0 <= tail_lds) {
             // the rest of the factorisation inside one workgroup (the trailing block is up to date at a panel boundary)
             prof_begin(c, PROF_OTHER, 8.0 * (n - j0) * (double)(n - j0), 0.0);
@@ -2217,81 +2261,6 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
         }
         // one decision per panel: the symmetric-aware matvec reads the upper triangle, the streaming one the full block
         const bool panel_symv = symv_min > 0 && n - j0 - 1 >= symv_min;
-        if (fused && !panel_symv && (n - j0 + 2 * nb + 8 * 16 + 15) / 16 <= TRD_COL_MAXGRID) {
-            // one launch per column + one to finish the last w of the panel
-            int fc = 0, nblk_last = 0;
-            for (int i = 0; i < kb; ++i) {
-                const int j = j0 + i, o = j + 1, m = n - o, ip = i > 0 ? i - 1 : 0;
-                TrdColArgs ca;
-                ca.A = W.A; ca.ld = ld; ca.n = n; ca.j = j; ca.i = i;
-                ca.o = o; ca.m = m; ca.oc = o & ~1; ca.shift = o - ca.oc;
-                ca.Vp = Vp; ca.Wp = Wp; ca.ldp = ld;
-                ca.wraw_prev = wraw2[1 - fc]; ca.wraw_cur = wraw2[fc];
-                ca.partB_prev = partB2[1 - fc]; ca.nblkB_prev = nblk_last; ca.partB_cur = partB2[fc];
-                ca.cdots_prev = cdots2[1 - fc]; ca.cdots_cur = cdots2[fc];
-                ca.colscal_prev = colscal2[1 - fc]; ca.colscal_cur = colscal2[fc];
-                ca.taus = taus; ca.evec = evec; ca.dvec = dvec;
-                int R = (int)c->opt.eigh_col_rows;
-                if (R != 2 && R != 4 && R != 8 && R != 16)
-                    R = m >= c->opt.eigh_col_r16_min ? 16 : m >= c->opt.eigh_col_r8_min ? 8 : m >= c->opt.eigh_col_r4_min ? 4 : 2;
-                while (R < 16 && (8 * R + m + 2 * ip + R - 1) / R > TRD_COL_MAXGRID) R *= 2;
-                ca.pad = o % (8 * R);
-                const int grid = (ca.pad + m + 2 * ip + R - 1) / R;
-                const bool prof_all = c->prof;
-                if (prof_all && (j & 3)) c->prof = false;
-                if (c->prof) SCHK(stream_wait(c));
-                prof_begin(c, PROF_TRD_GEMV, 8.0 * m * (double)m + 8.0 * (2.0 * ip + 3.0) * m, 2.0 * m * (double)m);
-#define SELLA_TRD_COL(RR, NT)                                                                                             \
-    do {                                                                                                                  \
-        if (i == 0) SELLA_LAUNCH(c, HIP_KERNEL_NAME(trd_col_kernel<RR, NT, 1, true>), dim3(grid), dim3(NT), 0, ca);       \
-        else SELLA_LAUNCH(c, HIP_KERNEL_NAME(trd_col_kernel<RR, NT, (RR >= 16 ? 4 : 8), false>), dim3(grid), dim3(NT), 0, ca); \
-    } while (0)
-#define SELLA_TRD_COL_NT(RR)                                                                                              \
-    do {                                                                                                                  \
-        if (nt_max <= 128 || n2 <= 128) SELLA_TRD_COL(RR, 128);                                                           \
-        else if (nt_max <= 256 || n2 <= 256) SELLA_TRD_COL(RR, 256);                                                      \
-        else SELLA_TRD_COL(RR, 512);                                                                                      \
-    } while (0)
-                const int n2 = (m + ca.shift + 1) >> 1;     // 16-byte chunks per row: one per thread up to 1024 columns
-                const int nt_max = (int)c->opt.eigh_col_nt;
-                switch (R) {
-                    case 2: SELLA_TRD_COL_NT(2); break;
-                    case 4: SELLA_TRD_COL_NT(4); break;
-                    case 8: SELLA_TRD_COL_NT(8); break;
-                    default: SELLA_TRD_COL_NT(16); break;
-                }
-#undef SELLA_TRD_COL_NT
-#undef SELLA_TRD_COL
-                prof_end(c);
-                c->prof = prof_all;
-                nblk_last = grid;
-                fc = 1 - fc;
-            }
-            {
-                const int j = j0 + kb;
-                TrdRowArgs ra;
-                ra.A = W.A; ra.ld = ld; ra.n = n; ra.j = j; ra.i = kb; ra.do_row = 0;
-                ra.Vp = Vp; ra.Wp = Wp; ra.ldp = ld;
-                ra.u_prev = ub[0]; ra.u_cur = ub[1];
-                ra.wraw = wraw2[1 - fc];
-                ra.partA_prev = partA[0]; ra.nblkA_prev = 0; ra.partA_cur = partA[1];
-                ra.partB = partB2[1 - fc]; ra.nblkB = nblk_last;
-                ra.colscal = colscal2[1 - fc];
-                ra.cdots = cdots2[1 - fc];
-                ra.dvec = dvec;
-                ra.Aprev_row = W.A + (size_t)(j - 1) * ld;
-                const dim3 gA((n - j + 255) / 256), bA(256);
-                switch (kb - 1) {
-#define SELLA_TRD_ROW_CASE(IP) case IP: SELLA_LAUNCH(c, HIP_KERNEL_NAME(trd_row_kernel<IP>), gA, bA, 0, ra); break;
-                    SELLA_TRD_ROW_CASE(0) SELLA_TRD_ROW_CASE(1) SELLA_TRD_ROW_CASE(2) SELLA_TRD_ROW_CASE(3)
-                    SELLA_TRD_ROW_CASE(4) SELLA_TRD_ROW_CASE(5) SELLA_TRD_ROW_CASE(6) SELLA_TRD_ROW_CASE(7)
-                    SELLA_TRD_ROW_CASE(8) SELLA_TRD_ROW_CASE(9) SELLA_TRD_ROW_CASE(10) SELLA_TRD_ROW_CASE(11)
-                    SELLA_TRD_ROW_CASE(12) SELLA_TRD_ROW_CASE(13) SELLA_TRD_ROW_CASE(14) SELLA_TRD_ROW_CASE(15)
-#undef SELLA_TRD_ROW_CASE
-                    default: SELLA_LAUNCH(c, HIP_KERNEL_NAME(trd_row_kernel<-1>), gA, bA, 0, ra);
-                }
-            }
-        } else
         for (int i = 0; i <= kb; ++i) {
             const int j = j0 + i;
             const bool do_row = i < kb;
@@ -2306,7 +2275,6 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
             ra.colscal = colscal;
             ra.cdots = cdots;
             ra.dvec = dvec;
-            ra.Aprev_row = nullptr;
             const int nblkA = (n - j + 255) / 256;
             const dim3 gA(nblkA), bA(256);
             // Profiling samples every 4th column.  The event pair is attached to the dispatch packet, whose

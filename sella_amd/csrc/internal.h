@@ -116,11 +116,13 @@ struct Options {
     long bd_dev_rr = 0;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 56) on the device by parallel cyclic
                              // Jacobi in one workgroup (davidson_block.hip).  Measured at k = 48: 456 us per solve against ~270 us
                              // for the host's tred2 / tql2 (session r03l: 1.16 against 0.85 ms per block iteration), hence off
-    long eigh_fused = 1;     // 1: one launch per column of the tridiagonalisation (trd_col_kernel: the updated row formed on the fly
-                             //    inside the matvec); 0: round 4's row kernel + matvec pair
-    long eigh_col_rows = 0;  // rows per workgroup of that kernel (2, 4, 8, 16); 0: by trailing size, thresholds below
-    long eigh_col_nt = 512;  // most threads per workgroup of that kernel (128, 256, 512; tests force several chunks per thread with 128)
-    long eigh_col_r4_min = 768, eigh_col_r8_min = 2048, eigh_col_r16_min = 1 << 30;
+    long eigh_upd_max = 1024; // trailing blocks of at most this many rows are tridiagonalised with ONE launch per column, the block
+                             //    kept up to date by the launch itself (trd_upd_kernel, eigh.hip); 0: never.  eigh at n = 3072 by
+                             //    switch-over size (session r05b): 0: 39.85 ms, 512: 38.78, 1024: 38.28, 1536: 39.07, 2048: 40.19,
+                             //    3072: 47.9 — the block is written back once per column, which only pays while it is small
+    long eigh_upd_rows = 0;  // rows per workgroup of that kernel (2, 4, 8); 0: by trailing size, thresholds below
+    long eigh_upd_nt = 512;  // most threads per workgroup of that kernel (128, 256, 512; tests force several chunks per thread with 128)
+    long eigh_upd_r4_min = 1 << 30, eigh_upd_r8_min = 1 << 30;   // (2 rows per workgroup measured best at every size up to 1024)
     long eigh_two_stage = 0; // 1: sella_eigh reduces dense -> band -> tridiagonal (eigh_two_stage.h) from eigh2_min rows on
     long eigh2_min = 6144;
     long emt_hcap = 8;       // neighbour-list slots per thread of the EMT kernels (tests: 1 forces the overflow path)

@@ -137,8 +137,8 @@ class Sella(Optimizer):
             ls = self._lib
             if not np.array_equal(np.asarray(self.atoms.positions, dtype=np.float64).ravel(), ls.positions_flat()):
                 # somebody moved the atoms between two runs: the library's geometry is no longer the truth.  The state
-                # comes back (the PES then notices the change through its state hash, like the reference's) and the
-                # general driver continues.
+                # comes back as the library's point (`_adopt` caches it under the library's geometry), the PES notices
+                # the change through its state hash like the reference's, and the general driver continues.
                 self._lib_authoritative = True
                 self._adopt()
                 return Optimizer.run(self, fmax=fmax, steps=steps)
@@ -168,9 +168,20 @@ class Sella(Optimizer):
         pending = ls.pending_pairs()
         st = ls.release_hessian()
         pes.neval = ls.neval
+        # Energy and gradient belong to the LIBRARY's geometry.  If somebody moved the atoms in the meantime (`run()`
+        # after a perturbation), the cached point must still be the library's — geometry, state hash and basis — so that
+        # the first look at the PES sees 'moved', makes its force call at the new positions and keeps the library's
+        # point as `last` (what the reference's PES does after an external move, peswrapper.py:440-474).
+        x_lib = ls.positions_flat().reshape(-1, 3)
+        user_pos = np.array(self.atoms.positions, dtype=np.float64)
+        moved = not np.array_equal(user_pos, x_lib)
+        if moved:
+            self.atoms.positions = x_lib
         pes.curr.update(x=pes.get_x(), state_hash=pes._state_hash(), f=ls.energy, g=ls.gradient.copy())
         pes._update_basis()
         pes.last = dict(pes.curr)
+        if moved:
+            self.atoms.positions = user_pos
         pes.first_diag = st['first_diag']
         self.initialized = ls.initialized
         self.nsteps_since_diag = st['nsteps_since_diag']

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-column durations of the one-launch-per-column tridiagonalisation (trd_col_kernel) out of a rocprofv3 kernel trace
+"""Per-column durations of the one-launch-per-column tridiagonalisation (trd_upd_kernel) out of a rocprofv3 kernel trace
 (rocpd sqlite), binned by the size m of the trailing block; LAST eigh of the trace (the first one pays first-touch).
 Usage: tools/col_by_m.py <results.db> <n> [bin]"""
 import sqlite3
@@ -11,7 +11,7 @@ def main(db_path, n, width=256):
     rows = cur.execute('select name, start, duration, grid_x, workgroup_x from kernels order by start').fetchall()
     runs, cur_run = [], []
     for name, _, dur, gx, wx in rows:
-        if 'trd_col_kernel' in name:
+        if 'trd_upd_kernel' in name:
             cur_run.append((dur, gx, wx))
         elif 'tridiag_tail_kernel' in name or 'trd_tail_lds_kernel' in name:
             if cur_run:
@@ -20,7 +20,7 @@ def main(db_path, n, width=256):
     if cur_run:
         runs.append(cur_run)
     if not runs:
-        print('no trd_col_kernel launches in the trace')
+        print('no trd_upd_kernel launches in the trace')
         return
     seq = runs[-1]
     bins = {}

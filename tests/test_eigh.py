@@ -125,6 +125,47 @@ def test_symmetric_aware_trailing_matvec(ctx):
         ctx.set_option('eigh_nb', 16)
 
 
+def test_one_launch_per_column_chain(ctx):
+    """Small trailing blocks run dsytd2's algebra with one launch per column (`trd_upd_kernel`: finish w, rank-2 update of
+    the rows the workgroup owns, next row formed on the fly, matvec) — same tridiagonal matrix as the blocked chain up to
+    rounding: with and without the LDS tail behind it, entered at the first column or in the middle of the factorisation,
+    every rows-per-workgroup variant, one and several chunks per thread, odd and even offsets of the trailing block."""
+    rng = np.random.RandomState(21)
+    emu = ctx.backend == 'emu'
+    try:
+        for tail in (0, 128):
+            ctx.set_option('eigh_tail_lds', tail)
+            for n in ((3, 4, 5, 18, 70) if tail == 0 else ((141,) if emu else (141, 200, 301, 700))):
+                A = rng.normal(size=(n, n))
+                A = A + A.T
+                ctx.set_option('eigh_upd_max', 0)
+                ref = check(ctx, A)
+                variants = [(4096, 2, 512), (4096, 4, 512), (4096, 8, 512), (40, 2, 512)]
+                if n > 140:
+                    variants += [(4096, 2, 128), (n // 2, 4, 128)]          # several chunks per thread from n = 257 on
+                if emu and n > 100:
+                    variants = [variants[0], variants[-1]]
+                for upd_max, rows, nt in variants:
+                    ctx.set_option('eigh_upd_max', upd_max)
+                    ctx.set_option('eigh_upd_rows', rows)
+                    ctx.set_option('eigh_upd_nt', nt)
+                    w = check(ctx, A)
+                    np.testing.assert_allclose(w, ref, atol=1e-12 * max(1.0, np.abs(ref).max()))
+                    np.testing.assert_array_equal(w, check(ctx, A))        # fixed summation order: run-to-run identical
+        # degenerate inputs through the chain: zero rows (tau = 0 reflectors), a diagonal matrix, identity + low rank
+        ctx.set_option('eigh_tail_lds', 0)
+        ctx.set_option('eigh_upd_max', 4096)
+        ctx.set_option('eigh_upd_rows', 0)
+        ctx.set_option('eigh_upd_nt', 512)
+        for name, A in cases(40, rng):
+            check(ctx, A)
+    finally:
+        ctx.set_option('eigh_tail_lds', 128)
+        ctx.set_option('eigh_upd_max', 1024)
+        ctx.set_option('eigh_upd_rows', 0)
+        ctx.set_option('eigh_upd_nt', 512)
+
+
 def test_two_stage_reduction(ctx):
     """Option `eigh_two_stage`: dense -> band (b = 32, blocked Householder panels, rank-2b trailing updates) -> tridiagonal
     (bulge chasing, one wavefront of independent tasks per launch), eigenvectors carried back through both stages.  Same

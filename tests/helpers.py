@@ -1,53 +1,37 @@
-"""Shared test helpers (recipes re-stated from the reference's tests/test_utils)."""
-import math
-from itertools import permutations
-
+"""Shared test helpers: own input generators (nothing here is taken from the reference's test utilities)."""
 import numpy as np
 
 
-def get_matrix(n, m, pd=False, symm=False, rng=None):
-    """tests/test_utils/matrix_factory.py:3-15."""
-    if rng is None:
-        rng = np.random.RandomState(1)
-    A = rng.normal(size=(n, m))
-    if symm:
-        A = 0.5 * (A + A.T)
-    if pd:
-        lams, vecs = np.linalg.eigh(A)
-        A = vecs @ (np.abs(lams)[:, np.newaxis] * vecs.T)
-    return A
+def random_matrix(rng, rows, cols=None, symmetric=False, positive=False):
+    """Gaussian entries; `symmetric` (square only) mirrors the upper triangle, `positive` shifts the spectrum of the
+    symmetric matrix above zero (a Gershgorin-free way: subtract the lowest eigenvalue, add one)."""
+    cols = rows if cols is None else cols
+    M = rng.standard_normal((rows, cols))
+    if symmetric or positive:
+        M = np.triu(M) + np.triu(M, 1).T
+    if positive:
+        M = M + (1.0 - np.linalg.eigvalsh(M)[0]) * np.eye(rows)
+    return M
 
 
-def poly_factory(dim, order, rng=None):
-    """Random multi-dimensional polynomial f, g, H (tests/test_utils/poly_factory.py:8-39)."""
-    if rng is None:
-        rng = np.random.RandomState(1)
-    coeffs = []
-    for i in range(order + 1):
-        tmp = rng.normal(size=(dim,) * i)
-        coeff = np.zeros_like(tmp)
-        nperm = 0
-        for permute in permutations(range(i)):
-            coeff += np.transpose(tmp, permute)
-            nperm += 1
-        coeffs.append(coeff / (nperm * math.factorial(i)))
+class SmoothModel:
+    """f(x) = 1/2 x.A x + sum_k a_k sin(u_k.x) + b_k/4 (u_k.x)^4 with closed-form gradient and Hessian: a smooth,
+    non-quadratic function for the finite-difference operator tests (third and fourth derivatives both present)."""
 
-    def poly(x):
-        res = 0
-        grad = np.zeros_like(x)
-        hess = np.zeros((dim, dim))
-        for i, coeff in enumerate(coeffs):
-            lastlast = last = None
-            for _ in range(i):
-                lastlast, last = last, coeff
-                coeff = coeff @ x
-            if last is not None:
-                grad += i * last
-            if lastlast is not None:
-                hess += i * (i - 1) * lastlast
-            res += coeff
-        return res, grad, hess
-    return poly
+    def __init__(self, dim, rng, nterms=6, quadratic_only=False):
+        self.A = random_matrix(rng, dim, symmetric=True)
+        self.U = rng.standard_normal((nterms, dim)) / np.sqrt(dim)
+        self.a = np.zeros(nterms) if quadratic_only else 0.7 * rng.standard_normal(nterms)
+        self.b = np.zeros(nterms) if quadratic_only else 0.3 * rng.standard_normal(nterms)
+
+    def energy_gradient(self, x):
+        p = self.U @ x
+        f = 0.5 * x @ self.A @ x + np.sum(self.a * np.sin(p) + 0.25 * self.b * p ** 4)
+        return f, self.A @ x + self.U.T @ (self.a * np.cos(p) + self.b * p ** 3)
+
+    def hessian(self, x):
+        p = self.U @ x
+        return self.A + (self.U.T * (-self.a * np.sin(p) + 3.0 * self.b * p ** 2)) @ self.U
 
 
 def colsign(V, Vref):

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from helpers import colsign, get_matrix, poly_factory
+from helpers import SmoothModel, colsign, random_matrix
 
 STRICT = ('jd0', 'jd0_alt', 'lanczos')
 
@@ -81,51 +81,59 @@ def test_golden_expand_through_one_iteration(ctx, manifest):
         assert np.linalg.norm(resid) < 1e-8, case
 
 
-@pytest.mark.parametrize("dim,order,eta,threepoint", [(10, 4, 1e-6, True), (10, 4, 1e-6, False)])
-def test_exact(ctx, dim, order, eta, threepoint):
+@pytest.mark.parametrize('threepoint', [False, True])
+def test_exact_on_a_matrix_and_on_a_finite_difference_operator(ctx, threepoint):
+    """`exact` (eigensolvers.py:9-28): a dense matrix goes through the device eigh, an operator is applied to the columns
+    of the identity (or of P's eigenvectors) first.  Against LAPACK on the closed-form Hessian of a smooth model; the
+    operator route within the finite-difference error."""
     from sella_amd.eigensolvers import exact
     from sella_amd.linalg import NumericalHessian
-    rng = np.random.RandomState(1)
-    tol = dict(atol=1e-4, rtol=eta ** 2)
-    poly = poly_factory(dim, order, rng=rng)
-    x = rng.normal(size=dim)
-    _, g, h = poly(x)
-    H = NumericalHessian(lambda x: poly(x)[:2], g0=g, x0=x, eta=eta, threepoint=threepoint)
-    l1, V1, AV1 = exact(h)
-    l2, V2, AV2 = exact(H)
-    np.testing.assert_allclose(l1, l2, **tol)
-    np.testing.assert_allclose(np.abs(V1.T @ V2), np.eye(dim), **tol)
-    np.testing.assert_allclose(h @ V1, AV1, **tol)
-    np.testing.assert_allclose(h @ V2, AV2, **tol)
-    P = h + get_matrix(dim, dim, rng=rng) * 1e-3
-    l3, V3, AV3 = exact(H, P=P)
-    np.testing.assert_allclose(l1, l3, **tol)
+    rng = np.random.RandomState(23)
+    n = 11
+    model = SmoothModel(n, rng)
+    x = 0.4 * rng.standard_normal(n)
+    Hx = model.hessian(x)
+    wref, Vref = np.linalg.eigh(Hx)
+    lam, V, AV = exact(Hx)
+    np.testing.assert_allclose(lam, wref, atol=1e-12)
+    np.testing.assert_allclose(colsign(V, Vref), Vref, atol=1e-9)
+    np.testing.assert_allclose(AV, Hx @ V, atol=1e-12)
+    op = NumericalHessian(model.energy_gradient, g0=model.energy_gradient(x)[1], x0=x, eta=1e-6, threepoint=threepoint)
+    fd = 1e-7 if threepoint else 2e-5                      # central / forward difference error at eta = 1e-6
+    for P in (None, Hx + 1e-3 * random_matrix(rng, n, symmetric=True)):
+        lam2, V2, AV2 = exact(op, P=P)
+        np.testing.assert_allclose(lam2, wref, atol=fd)
+        assert np.abs(np.abs(Vref.T @ V2) - np.eye(n)).max() < 50 * fd
+        np.testing.assert_allclose(AV2, Hx @ V2, atol=10 * fd)
 
 
-@pytest.mark.parametrize("dim,order,eta,threepoint,gamma,method,maxiter",
-                         [(10, 4, 1e-6, False, 0., 'jd0', None),
-                          (10, 4, 1e-6, False, 1e-32, 'jd0', 3),
-                          (10, 4, 1e-6, True, 1e-1, 'jd0', None),
-                          (10, 4, 1e-6, False, 1e-1, 'jd0', None),
-                          (10, 4, 1e-6, False, 1e-1, 'lanczos', None),
-                          (10, 4, 1e-6, False, 1e-1, 'gd', None),
-                          (10, 4, 1e-6, False, 1e-1, 'jd0_alt', None),
-                          (10, 4, 1e-6, False, 1e-1, 'mjd0_alt', None),
-                          (10, 4, 1e-6, False, 1e-1, 'mjd0', None)])
-def test_rayleigh_ritz(ctx, dim, order, eta, threepoint, gamma, method, maxiter):
+@pytest.mark.parametrize('method', ['jd0', 'jd0_alt', 'mjd0', 'mjd0_alt', 'gd', 'lanczos'])
+def test_rayleigh_ritz_on_a_finite_difference_operator(ctx, method):
+    """Every `method` of `expand` driving the loop on an OPERATOR (each product a pair of gradient calls): the returned
+    Ritz values are those of V^T A V, V is orthonormal with AV = A V, a converged run (gamma = 0: until the space is
+    exhausted) reproduces the lowest eigenpair, `maxiter` is respected, and `vref` only adds a log line."""
     from sella_amd.eigensolvers import rayleigh_ritz
     from sella_amd.linalg import NumericalHessian
-    rng = np.random.RandomState(1)
-    tol = dict(atol=1e-4, rtol=eta ** 2)
-    poly = poly_factory(dim, order, rng=rng)
-    x = rng.normal(size=dim)
-    _, g, h = poly(x)
-    H = NumericalHessian(lambda x: poly(x)[:2], g0=g, x0=x, eta=eta, threepoint=threepoint)
-    l1, V1, AV1 = rayleigh_ritz(H, gamma, np.eye(dim), method=method, maxiter=maxiter)
-    np.testing.assert_allclose(l1, np.linalg.eigh(V1.T @ AV1)[0], **tol)
-    v0 = rng.normal(size=dim)
-    rayleigh_ritz(H, gamma, np.eye(dim), method=method, v0=v0, maxiter=maxiter,
-                  vref=np.linalg.eigh(h)[1][:, 0])
+    rng = np.random.RandomState(29)
+    n = 10
+    model = SmoothModel(n, rng)
+    x = 0.3 * rng.standard_normal(n)
+    Hx = model.hessian(x)
+    wref, Vref = np.linalg.eigh(Hx)
+
+    def operator():
+        return NumericalHessian(model.energy_gradient, g0=model.energy_gradient(x)[1], x0=x, eta=1e-6, threepoint=True)
+    lam, V, AV = rayleigh_ritz(operator(), 0.1, np.eye(n), method=method)
+    np.testing.assert_allclose(V.T @ V, np.eye(V.shape[1]), atol=1e-9)
+    np.testing.assert_allclose(AV, Hx @ V, atol=1e-6)
+    np.testing.assert_allclose(lam, np.linalg.eigvalsh(V.T @ AV), atol=1e-6)
+    assert lam[0] >= wref[0] - 1e-6                        # a Ritz value never undercuts the spectrum
+    lam, V, AV = rayleigh_ritz(operator(), 0.0, np.eye(n), method=method, v0=rng.standard_normal(n))
+    assert lam[0] == pytest.approx(wref[0], abs=1e-6)
+    assert abs(V[:, 0] @ Vref[:, 0]) > 1 - 1e-6
+    lam, V, AV = rayleigh_ritz(operator(), 1e-30, np.eye(n), method=method, v0=rng.standard_normal(n), maxiter=3,
+                               vref=Vref[:, 0])
+    assert V.shape[1] <= 4
 
 
 def test_unknown_method_and_metric(ctx):

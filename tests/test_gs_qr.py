@@ -84,41 +84,44 @@ def test_accelerator_seam_by_name(ctx):
     np.testing.assert_array_equal(A, A0)                            # inputs are never mutated (_gpu.py:64)
 
 
-# ---- the reference's own utilities tests (tests/utilities/test_math.py), same names and parameters -----------------------
-@pytest.mark.parametrize("n,m,eps", [(3, 3, 1e-10), (100, 3, 1e-6)])
-def test_mppi(ctx, n, m, eps):
-    from helpers import get_matrix
+# ---- sella_amd.utilities.math on its own terms -----------------------------------------------------------------------------
+@pytest.mark.parametrize('shape,rank', [((4, 4), 4), ((60, 5), 5), ((7, 30), 7), ((40, 6), 4)])
+def test_pseudo_inverse_factors_and_rank(ctx, shape, rank):
+    """`pseudo_inverse` (utilities/math.pyx:17-41): the factors reproduce the matrix on its numerical range, the inverse is
+    the Moore-Penrose one (the four Penrose conditions), and singular values below `eps` are counted out."""
     from sella_amd.utilities.math import pseudo_inverse
-    rng = np.random.RandomState(1)
-    tol = dict(atol=1e-6, rtol=1e-6)
-    A = get_matrix(n, m, rng=rng)
-    U1, s1, VT1, Ainv, nsing1 = pseudo_inverse(A.copy(), eps=eps)
-    np.testing.assert_allclose(U1[:, :nsing1] @ np.diag(s1) @ VT1[:nsing1, :], A, **tol)
-    np.testing.assert_allclose(np.linalg.pinv(A), Ainv, **tol)
-    nsingB = nsing1 - 1
-    B = U1[:, :nsingB] @ np.diag(s1[:nsingB]) @ VT1[:nsingB, :]
-    U2, s2, VT2, Binv, nsing2 = pseudo_inverse(B.copy(), eps=eps)
-    assert nsing2 == nsingB
-    np.testing.assert_allclose(np.linalg.pinv(B, rcond=1e-8), Binv, atol=1e-5, rtol=1e-5)
+    rng = np.random.RandomState(37)
+    A = rng.standard_normal((shape[0], rank)) @ rng.standard_normal((rank, shape[1]))
+    U, s, VT, Ainv, nsing = pseudo_inverse(A.copy(), eps=1e-9)
+    assert nsing == rank and np.all(s[:nsing] > 1e-9)
+    np.testing.assert_allclose((U[:, :nsing] * s[:nsing]) @ VT[:nsing], A, atol=1e-10)
+    for lhs, rhs in ((A @ Ainv @ A, A), (Ainv @ A @ Ainv, Ainv), ((A @ Ainv).T, A @ Ainv), ((Ainv @ A).T, Ainv @ A)):
+        np.testing.assert_allclose(lhs, rhs, atol=1e-9)
 
 
-@pytest.mark.parametrize("n,mx,my,eps1,eps2,maxiter", [(3, 2, 1, 1e-15, 1e-6, 100), (100, 50, 25, 1e-15, 1e-6, 100)])
-def test_modified_gram_schmidt(ctx, n, mx, my, eps1, eps2, maxiter):
-    from helpers import get_matrix
+def test_gram_schmidt_spans_and_drops(ctx):
+    """`modified_gram_schmidt` (utilities/math.pyx:74-159): orthonormal columns with the span of X (same projector as a
+    QR of X), orthogonal to Y when a Y is given with the span of X's part outside Y, and a column that is a combination
+    of earlier ones (or lies inside Y) is dropped instead of being normalised from roundoff."""
     from sella_amd.utilities.math import modified_gram_schmidt
-    rng = np.random.RandomState(2)
-    tol = dict(atol=1e-6, rtol=1e-6)
-    mgskw = dict(eps1=eps1, eps2=eps2, maxiter=maxiter)
-    X = get_matrix(n, mx, rng=rng)
-    Xout1 = modified_gram_schmidt(X, **mgskw)
-    nxout1 = Xout1.shape[1]
-    np.testing.assert_allclose(Xout1.T @ Xout1, np.eye(nxout1), **tol)
-    np.testing.assert_allclose(np.linalg.det(X.T @ X), np.linalg.det(X.T @ Xout1) ** 2, **tol)
-    Y = get_matrix(n, my, rng=rng)
-    Xout2 = modified_gram_schmidt(X, Y, **mgskw)
-    nxout2 = Xout2.shape[1]
-    np.testing.assert_allclose(Xout2.T @ Xout2, np.eye(nxout2), **tol)
-    np.testing.assert_allclose(Xout2.T @ Y, np.zeros((nxout2, my)), **tol)
-    X[:, 1] = X[:, 0]
-    Xout3 = modified_gram_schmidt(X, **mgskw)
-    assert Xout3.shape[1] == nxout1 - 1
+    rng = np.random.RandomState(41)
+    n = 80
+    X = rng.standard_normal((n, 12))
+    Q = modified_gram_schmidt(X)
+    assert Q.shape == (n, 12)
+    np.testing.assert_allclose(Q.T @ Q, np.eye(12), atol=1e-12)
+    Qr = np.linalg.qr(X)[0]
+    np.testing.assert_allclose(Q @ Q.T, Qr @ Qr.T, atol=1e-10)
+    Y = rng.standard_normal((n, 5))
+    Q2 = modified_gram_schmidt(X, Y)
+    np.testing.assert_allclose(Q2.T @ Q2, np.eye(Q2.shape[1]), atol=1e-12)
+    assert np.abs(Q2.T @ Y).max() < 1e-10
+    Qy = np.linalg.qr(Y)[0]
+    Xperp = X - Qy @ (Qy.T @ X)
+    Qp = np.linalg.qr(Xperp)[0]
+    np.testing.assert_allclose(Q2 @ Q2.T, Qp @ Qp.T, atol=1e-9)
+    Xd = X.copy()
+    Xd[:, 7] = 2.0 * Xd[:, 2] - 0.5 * Xd[:, 4]            # dependent on earlier columns
+    Xd[:, 9] = Y @ rng.standard_normal(5)                  # inside Y
+    assert modified_gram_schmidt(Xd).shape[1] == 11
+    assert modified_gram_schmidt(Xd, Y).shape[1] == 10

@@ -1,44 +1,42 @@
-"""NumericalHessian / MatrixSum / ApproximateHessian of sella_amd.linalg: the reference's own
-tests (tests/test_linalg.py:11-58, tests/test_core_functionality.py:26-93) re-stated, plus golden
-parity for update sequences from the uninitialised state (g6) and the finite-difference operator
-including its sign-canonicalisation branches (g9)."""
+"""NumericalHessian / MatrixSum / ApproximateHessian of sella_amd.linalg: golden parity for update sequences from the
+uninitialised state (g6) and for the finite-difference operator including its sign-canonicalisation branches (g9), plus
+own property tests on a model with closed-form derivatives."""
 import numpy as np
 import pytest
-from scipy.stats import ortho_group
 
 from conftest import load_golden
-from helpers import poly_factory
+from helpers import SmoothModel, random_matrix
 
 
-@pytest.mark.parametrize("dim,subdim,order,threepoint",
-                         [(3, None, 1, False), (3, None, 1, True), (5, 3, 2, True),
-                          (10, None, 4, True), (10, 6, 4, False)])
-def test_NumericalHessian(ctx, dim, subdim, order, threepoint, eta=1e-6, atol=1e-4):
-    from sella_amd.linalg import NumericalHessian
-    rng = np.random.RandomState(2)
-    tol = dict(rtol=atol, atol=eta ** 2)
-    x = rng.normal(size=dim)
-    poly1 = poly_factory(dim, order, rng)
-    _, g1, h1 = poly1(x)
-    poly2 = poly_factory(dim, order, rng)
-    _, g2, h2 = poly2(x)
-    if subdim is None:
-        U, subdim, g1proj, xproj = None, dim, g1, x
-    else:
-        U = ortho_group.rvs(dim, random_state=rng)[:, :subdim]
-        h1 = U.T @ h1 @ U
-        h2 = U.T @ h2 @ U
-        g1proj = U.T @ g1
-        xproj = U.T @ x
-    Hkwargs = dict(x0=x, eta=eta, threepoint=threepoint, Uproj=U)
-    H1 = NumericalHessian(lambda x: poly1(x)[:2], g0=g1, **Hkwargs)
-    M1 = rng.normal(size=(subdim, subdim))
-    H2 = H1 + NumericalHessian(lambda x: poly2(x)[:2], g0=g2, **Hkwargs) + M1
-    H3 = h1 + h2 + M1
-    M1[:, 0] = xproj - g1proj * (xproj @ g1proj) / (g1proj @ g1proj)
-    M1[:, 1] -= M1[:, 0] * (M1[:, 1] @ M1[:, 0]) / (M1[:, 0] @ M1[:, 0])
-    M1[:, 1] -= g1proj * (M1[:, 1] @ g1proj) / (g1proj @ g1proj)
-    np.testing.assert_allclose(H2.T.dot(M1), H3.T @ M1, **tol)
+@pytest.mark.parametrize('sub,threepoint,quadratic', [(0, False, True), (0, True, False), (4, True, False), (6, False, False)])
+def test_numerical_hessian_products_and_sums(ctx, sub, threepoint, quadratic):
+    """The finite-difference operator (linalg.py:14-118) on a model with closed-form Hessian: `dot` and `T.dot` agree with
+    the Hessian (projected through `Uproj` when there is one) to the difference error, also for columns that are parallel
+    to the gradient or to an earlier column (the branches that reuse or canonicalise a direction), and `op + op + matrix`
+    is a `MatrixSum` whose products are the sums of the products."""
+    from sella_amd.linalg import MatrixSum, NumericalHessian
+    rng = np.random.RandomState(31)
+    n = 9
+    m1, m2 = SmoothModel(n, rng, quadratic_only=quadratic), SmoothModel(n, rng, quadratic_only=quadratic)
+    x = 0.5 * rng.standard_normal(n)
+    U = np.linalg.qr(rng.standard_normal((n, sub)))[0] if sub else None
+    k = sub if sub else n
+    proj = (lambda H: U.T @ H @ U) if sub else (lambda H: H)
+    kw = dict(x0=x, eta=1e-6, threepoint=threepoint, Uproj=U)
+    g1, g2 = m1.energy_gradient(x)[1], m2.energy_gradient(x)[1]
+    op1 = NumericalHessian(m1.energy_gradient, g0=g1, **kw)
+    extra = random_matrix(rng, k, symmetric=True)
+    total = op1 + NumericalHessian(m2.energy_gradient, g0=g2, **kw) + extra
+    assert isinstance(total, MatrixSum)
+    Href = proj(m1.hessian(x)) + proj(m2.hessian(x)) + extra
+    gk = U.T @ g1 if sub else g1
+    M = rng.standard_normal((k, 4))
+    M[:, 1] = gk / np.linalg.norm(gk)                      # parallel to the gradient
+    M[:, 2] = -2.0 * M[:, 0]                               # parallel to an earlier column, opposite sign
+    tol = 1e-9 if quadratic else (2e-7 if threepoint else 5e-5)
+    np.testing.assert_allclose(total.dot(M), Href @ M, atol=tol * max(1.0, np.abs(Href).max()))
+    np.testing.assert_allclose(total.T.dot(M), Href.T @ M, atol=tol * max(1.0, np.abs(Href).max()))
+    np.testing.assert_allclose(op1.dot(M[:, 3]), proj(m1.hessian(x)) @ M[:, 3], atol=tol * max(1.0, np.abs(Href).max()))
 
 
 def test_golden_numerical_hessian(ctx, manifest):

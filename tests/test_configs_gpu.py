@@ -57,13 +57,17 @@ def test_config0_readme_slab_step_by_step(ctx):
         x_before = dyn.pes.get_x().copy()
         dyn.step()
         f, delta, rho, neval = t[f'scal{i}']
-        tol = 2e-7 * 4 ** min(i, 8)              # roundoff of the finite-difference Hessian products compounds along the path
+        # Measured on MI355X (tools/config0_deviation.py, session r05c): the step vectors agree to 4e-12 ... 4e-11 at all
+        # eight steps, energies to 2e-12, gradients to 1e-10.  The bound is flat and far below every step of the trace
+        # (the last one is 9.5e-5 long): a tolerance that grows along the path would end up larger than the step itself.
+        tol = 1e-9
+        assert tol <= 1e-4 * np.abs(t[f's{i}']).max(), i
         np.testing.assert_allclose(dyn.pes.get_x() - x_before, t[f's{i}'], atol=tol, err_msg=f'step {i}')
         assert abs(dyn.pes.get_f() - f) < tol, i
-        np.testing.assert_allclose(dyn.pes.get_g(), t[f'g{i}'], atol=10 * tol)
-        assert dyn.delta == pytest.approx(delta, rel=1e-5, abs=tol), i
+        np.testing.assert_allclose(dyn.pes.get_g(), t[f'g{i}'], atol=2 * tol)
+        assert dyn.delta == pytest.approx(delta, rel=1e-8, abs=tol), i
         if np.isfinite(rho):
-            assert dyn.rho == pytest.approx(rho, rel=1e-3, abs=1e-3), i
+            assert dyn.rho == pytest.approx(rho, rel=1e-5, abs=1e-6), i
         assert dyn.pes.neval == int(neval), i          # same diagonalisation schedule, same number of force calls
         np.testing.assert_array_equal(slab.positions[pinned], t['x_start'][pinned])
 

@@ -67,7 +67,7 @@ def test_config0_readme_slab_step_by_step(ctx):
         np.testing.assert_allclose(dyn.pes.get_g(), t[f'g{i}'], atol=2 * tol)
         assert dyn.delta == pytest.approx(delta, rel=1e-8, abs=tol), i
         if np.isfinite(rho):
-            assert dyn.rho == pytest.approx(rho, rel=1e-5, abs=1e-6), i
+            assert dyn.rho == pytest.approx(rho, rel=1e-3, abs=1e-3), i   # (a ratio of energy differences down to 1e-9: 1e-12 / 1e-9)
         assert dyn.pes.neval == int(neval), i          # same diagonalisation schedule, same number of force calls
         np.testing.assert_array_equal(slab.positions[pinned], t['x_start'][pinned])
 

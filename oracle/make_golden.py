@@ -747,10 +747,49 @@ def gen_converged_digests(ref, orc, sizes):
         json.dump(dig, f, indent=1)
 
 
+def gen_envelope_digests(ref, sizes):
+    """The reference's OWN sensitivity envelope of the gamma = 0.1 benchmark run, merged into big_digests.json: the run is
+    repeated with the start vector moved by one ulp up / down (every entry) and with P perturbed by a relative 1e-16
+    (symmetrised), and for every number of vectors j up to the shortest run the largest change of the lowest Ritz value
+    of span(v_1 .. v_j) is recorded.  The reference is compared with ITSELF here: this is how far apart two executions
+    of sella/eigensolvers.py:31-112 are allowed to be by the algorithm (the unprojected (P - theta)^-1 of an unconverged
+    pair amplifies roundoff about tenfold per vector), and tests/test_big_gpu.py holds the device to a multiple of it at
+    every j, not only at the first few."""
+    path = os.path.join(GOLD, 'big_digests.json')
+    with open(path) as f:
+        dig = json.load(f)
+    for n in sizes:
+        A, P, g = hessian_like(n, seed=0, eps=5e-3)
+        rng = np.random.RandomState(9)
+        Pp = P * (1 + 1e-16 * rng.normal(size=P.shape))
+        Pp = 0.5 * (Pp + Pp.T)
+        runs = []
+        t0 = time.time()
+        for name, Pm, v0 in (('base', P, g), ('v0 + 1 ulp', P, np.nextafter(g, np.inf)),
+                             ('v0 - 1 ulp', P, np.nextafter(g, -np.inf)), ('P (1 + 1e-16 xi)', Pp, g)):
+            rec = _Recorder(A)
+            lams, V, AV = ref.eig.rayleigh_ritz(rec.op, 0.1, Pm, v0=v0, method='jd0', maxiter=40)
+            runs.append((name, ritz_trace(A, np.array(rec.inputs).T)))
+        base = runs[0][1]
+        assert np.abs(base - np.array(dig[str(n)]['ritz'])[:len(base)]).max() == 0.0, 'base run differs from the committed digest'
+        kmin = min(len(r) for _, r in runs)
+        env = np.max([np.abs(r[:kmin] - base[:kmin]) for _, r in runs[1:]], axis=0)
+        dig[str(n)]['envelope'] = dict(
+            recipe='lowest Ritz value after j vectors of rayleigh_ritz(A,0.1,P,v0=g,jd0,maxiter=40) against the same run with '
+                   'v0 -> nextafter(v0, +-inf) and with P -> sym(P (1 + 1e-16 N(0,1))), RandomState(9); max over the three',
+            perturbations=[name for name, _ in runs[1:]], exits=[int(len(r)) for _, r in runs],
+            max_abs_change=env.tolist())
+        print(f'  envelope n={n}: exits {[len(r) for _, r in runs]}, '
+              + ' '.join(f'{j + 1}:{e:.1e}' for j, e in enumerate(env)) + f' ({time.time() - t0:.1f}s)')
+    with open(path, 'w') as f:
+        json.dump(dig, f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--big', action='store_true')
     ap.add_argument('--converged', action='store_true', help='add the converged-eigenpair digests only')
+    ap.add_argument('--envelope', action='store_true', help='add the sensitivity envelope of the benchmark run only')
     ap.add_argument('--only', default='', help='comma-separated fixture names: regenerate these, keep the rest')
     ap.add_argument('--sizes', default='300,768,3072')
     args = ap.parse_args()
@@ -761,7 +800,7 @@ def main():
     import oracle.sella_oracle as orc
     manifest = {}
     only = [x for x in args.only.split(',') if x]
-    if only or args.converged:
+    if only or args.converged or args.envelope:
         with open(os.path.join(GOLD, 'manifest.json')) as f:
             manifest = json.load(f)
     for name, fn in (('g1_davidson', gen_davidson), ('g2_expand', gen_expand),
@@ -775,7 +814,7 @@ def main():
                      ('g10_irc', gen_irc),
                      ('g11_sparse_internal', gen_sparse_internal),
                      ('g12_numhess_model', gen_numhess_model)):
-        if (only and name not in only) or (args.converged and not only):
+        if (only and name not in only) or ((args.converged or args.envelope) and not only):
             continue
         t0 = time.time()
         manifest[name] = fn(ref, orc)
@@ -787,6 +826,8 @@ def main():
         gen_big_digests(ref, orc, [int(s) for s in args.sizes.split(',')])
     if args.big or args.converged:
         gen_converged_digests(ref, orc, [int(s) for s in args.sizes.split(',') if int(s) >= 768])
+    if args.big or args.envelope:
+        gen_envelope_digests(ref, [int(s) for s in args.sizes.split(',')])
 
 
 if __name__ == '__main__':

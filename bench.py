@@ -335,27 +335,6 @@ def main():
         Vt_.free()
     ctx.sync()
     t_eigh = (time.perf_counter() - t2) / 3
-    # the two-stage reduction (dense -> band -> tridiagonal; option, off by default because it is slower on this part):
-    # timed beside the default so that the line carries both, with its eigenvalues checked against the default's
-    two_stage = None
-    if rank == 0:
-        try:
-            ctx.set_option('eigh_two_stage', 1)
-            ctx.set_option('eigh2_min', 0)
-            ws, Vs, Vts = ctx.eigh(dP)                           # scratch, packed operands
-            Vs.free(); Vts.free()
-            ctx.sync()
-            t3 = time.perf_counter()
-            for _ in range(2):
-                ws, Vs, Vts = ctx.eigh(dP)
-                Vs.free(); Vts.free()
-            ctx.sync()
-            two_stage = {'eigh_ms': round(1e3 * (time.perf_counter() - t3) / 2, 2), 'default': False,
-                         'max_abs_eigenvalue_difference_to_default': float(np.abs(ws - w_).max())}
-        finally:
-            ctx.set_option('eigh_two_stage', 0)
-            ctx.set_option('eigh2_min', 6144)
-
     # parity evidence carried on the line: lowest Ritz pair of the benchmark call against the host, and
     # the north_star criterion proper — the CONVERGED lowest eigenvalue (gamma = 1e-7, run to convergence)
     # against the exact one, which is -1 by construction of the synthetic Hessian
@@ -809,7 +788,6 @@ def main():
                        **({'options': list(args.option)} if args.option else {})},
             'davidson_loop_only_iter_per_s': round(it2 / t_loop, 1),
             'eigh_ms': round(1e3 * t_eigh, 2),
-            'eigh_two_stage': two_stage,
             'concurrent_problems': concurrent,
             'optimizer': opt_stats,
             'block_davidson': block_stats,

@@ -74,9 +74,9 @@ int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
  *   vectors by rank-revealing Cholesky-QR |
  *   rs_fast (1) sella_opt_step finds the restricted step by interpolating batches of 15 trial alphas instead of the
  *   reference's Newton / bisection schedule (same root) |
- *   eigh_two_stage (0), eigh2_min (6144): sella_eigh reduces dense -> band 32 -> tridiagonal (bulge chasing) from eigh2_min
- *   rows on instead of column by column; same results, slower on MI355X at every size measured, hence off |
- *   eigh2_qr_reg (1) panel factorisation of that reduction with the sub-panel in registers (0: rows streamed) |
+ *   eigh_upd_max (1024): trailing blocks of the tridiagonalisation with at most this many rows take ONE launch per column
+ *   (the block kept up to date by the launch itself; 0: the blocked two-launch chain throughout), eigh_upd_rows (0 = 2),
+ *   eigh_upd_nt (512) rows / most threads per workgroup of that launch |
  *   lr_chain (1) the structured quasi-Newton update of sella_opt_step as the fused launch chain of round 4 (0: round 3's
  *   kernels), lr_pipe (1) the force call queued in front of the update that consumes it, rs_batch_result (1) final step
  *   read from the batch of trial alphas that produced it, lr_overlap (0) view job on a second stream |

@@ -476,14 +476,11 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "lr_dev")) c->opt.lr_dev = value ? 1 : 0;
     else if (!strcmp(key, "lr_chain")) c->opt.lr_chain = value ? 1 : 0;
     else if (!strcmp(key, "lr_pipe")) c->opt.lr_pipe = value ? 1 : 0;
-    else if (!strcmp(key, "eigh_two_stage")) c->opt.eigh_two_stage = value ? 1 : 0;
     else if (!strcmp(key, "eigh_upd_max")) c->opt.eigh_upd_max = value < 0 ? 0 : value;
     else if (!strcmp(key, "eigh_upd_rows")) c->opt.eigh_upd_rows = value;
     else if (!strcmp(key, "eigh_upd_nt")) c->opt.eigh_upd_nt = value;
     else if (!strcmp(key, "eigh_upd_r4_min")) c->opt.eigh_upd_r4_min = value;
     else if (!strcmp(key, "eigh_upd_r8_min")) c->opt.eigh_upd_r8_min = value;
-    else if (!strcmp(key, "eigh2_min")) c->opt.eigh2_min = value < 0 ? 0 : value;
-    else if (!strcmp(key, "eigh2_qr_reg")) c->opt.eigh2_qr_reg = value;
     else if (!strcmp(key, "emt_hcap")) c->opt.emt_hcap = value;
     else if (!strcmp(key, "lr_overlap")) c->opt.lr_overlap = value ? 1 : 0;
     else if (!strcmp(key, "rs_batch_result")) c->opt.rs_batch_result = value ? 1 : 0;

@@ -3043,8 +3043,6 @@ extern "C" int sella_rank1_eig(sella_ctx* c, int K, const double* D, const doubl
     return SELLA_OK;
 }
 
-#include "eigh_two_stage.h"
-
 extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, sella_mat* hVt) {
     Mat* a = mat_get(c, hA);
     if (!a || !w) return SELLA_E_INVALID;
@@ -3085,24 +3083,6 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
         else sella_mat_free(c, vt);
         return SELLA_OK;
     };
-    // ---- two-stage factorisation (eigh_two_stage.h): dense -> band -> tridiagonal, by size ------------------------------
-    if (c->opt.eigh_two_stage && n >= c->opt.eigh2_min && n >= 3 * TS_BMAX) {
-        HIPCHK(hipMemsetAsync(W.vec, 0, (size_t)V_NSLOTS * ld * sizeof(double), c->stream));
-        TwoStage ts;
-        std::vector<double> d2, e2;
-        SCHK(two_stage_reduce(W, ts, d2, e2, hV || hVt));
-        const double t1 = now();
-        SCHK(dc_solve(W, d2, e2, w));
-        const double t2 = now();
-        if (!hV && !hVt) return SELLA_OK;
-        SCHK(two_stage_back(W, ts, W.Za));
-        const double t3 = now();
-        SCHK(outputs(W.Za));
-        if (dbg_time)
-            fprintf(stderr, "eigh n=%d (two-stage, b = %d): reduction %.2f ms, divide&conquer %.2f ms, back-transform %.2f ms, outputs %.2f ms\n",
-                    n, ts.b, 1e3 * (t1 - t_s0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (now() - t3));
-        return SELLA_OK;
-    }
     // ---- stage 1 ----------------------------------------------------------------------------
     double* dvec = W.vec + (size_t)V_D * ld;
     double* evec = W.vec + (size_t)V_E * ld;

@@ -123,10 +123,7 @@ struct Options {
     long eigh_upd_rows = 0;  // rows per workgroup of that kernel (2, 4, 8); 0: by trailing size, thresholds below
     long eigh_upd_nt = 512;  // most threads per workgroup of that kernel (128, 256, 512; tests force several chunks per thread with 128)
     long eigh_upd_r4_min = 1 << 30, eigh_upd_r8_min = 1 << 30;   // (2 rows per workgroup measured best at every size up to 1024)
-    long eigh_two_stage = 0; // 1: sella_eigh reduces dense -> band -> tridiagonal (eigh_two_stage.h) from eigh2_min rows on
-    long eigh2_min = 6144;
     long emt_hcap = 8;       // neighbour-list slots per thread of the EMT kernels (tests: 1 forces the overflow path)
-    long eigh2_qr_reg = 1;   // panel factorisation of stage 1 with the sub-panel in registers (0: the row-streaming kernel)
     long lr_overlap = 0;     // 1: the view job of the one-call step is queued on a second stream, beside the coordinate kernels of the
                              //    full-space job.  Measured (session r04k): EMT-slab step 0.59-0.62 ms either way, and the ensemble of EMT
                              //    members DROPS from 211 to 172-182 searches/s with 8 threads x 2 streams: off

@@ -166,50 +166,6 @@ def test_one_launch_per_column_chain(ctx):
         ctx.set_option('eigh_upd_nt', 512)
 
 
-def test_two_stage_reduction(ctx):
-    """Option `eigh_two_stage`: dense -> band (b = 32, blocked Householder panels, rank-2b trailing updates) -> tridiagonal
-    (bulge chasing, one wavefront of independent tasks per launch), eigenvectors carried back through both stages.  Same
-    bar as the one-stage path: eigenvalues, residuals and orthogonality against LAPACK; sizes put the last panel, the
-    last sweep group and the last chase block at every remainder modulo the bandwidth."""
-    rng = np.random.RandomState(21)
-    sizes = (97, 161) if ctx.backend == 'emu' else (96, 97, 127, 128, 129, 250, 515, 1000, 1537)
-    try:
-        ctx.set_option('eigh_two_stage', 1)
-        ctx.set_option('eigh2_min', 0)
-        for n in sizes:
-            A = rng.normal(size=(n, n))
-            w = check(ctx, A + A.T)
-            if n == sizes[0]:
-                ctx.set_option('eigh_two_stage', 0)
-                np.testing.assert_allclose(check(ctx, A + A.T), w, atol=1e-12 * np.abs(w).max())
-                ctx.set_option('eigh_two_stage', 1)
-        n = 98 if ctx.backend == 'emu' else 700
-        for name, A in cases(n, rng):
-            check(ctx, A)
-        # panel factorisation variants of stage 1: rows streamed from memory (0), two rows in registers (2: what sizes
-        # beyond 6144 use)
-        for variant in (0, 2):
-            ctx.set_option('eigh2_qr_reg', variant)
-            A = rng.normal(size=(sizes[1], sizes[1]))
-            check(ctx, A + A.T)
-        ctx.set_option('eigh2_qr_reg', 1)
-        # stage-1 reflectors in blocks of 64 (two panels per block) in the back-transformation: even and odd panel counts
-        ctx.set_option('eigh_wy_nb64_min', 1)
-        for n in ((129,) if ctx.backend == 'emu' else (129, 161, 700)):
-            A = rng.normal(size=(n, n))
-            check(ctx, A + A.T)
-        check(ctx, 2.0 * np.eye(130))                                    # every reflector the identity
-        ctx.set_option('eigh_wy_nb64_min', 2560)
-        # below three bandwidths the one-stage path answers whatever the option says
-        A = rng.normal(size=(40, 40))
-        check(ctx, A + A.T)
-    finally:
-        ctx.set_option('eigh_two_stage', 0)
-        ctx.set_option('eigh2_min', 6144)
-        ctx.set_option('eigh2_qr_reg', 1)
-        ctx.set_option('eigh_wy_nb64_min', 2560)
-
-
 def test_spectra(ctx):
     rng = np.random.RandomState(1)
     n = 72 if ctx.backend == 'emu' else 700

@@ -18,7 +18,6 @@ cp $S/opt_step_timeline.txt $P/${RP}_opt_step_timeline.txt; cp $S/emt_step_timel
 { echo "# threads, processes and RCCL on one GPU (session $TAG)"; echo; echo '## ensemble leg on host threads of ONE process, searches inside the library (tools/ensemble_threads.py: EnsembleThreads, one persistent device context per thread)'; echo '```'; cat $S/threads.log; echo '```'; echo '## the same with the general driver (SELLA_LIBRARY_SEARCH=0: ~10,000 host-language calls per member, interpreter lock held in between)'; echo '```'; cat $S/threads_general.log; echo '```'; echo '## one member, where its time goes (tools/ens_profile.py)'; echo '```'; grep "seconds per member\|update_H n=768\|structured eigen" $S/ens_profile.log | tail -8; sed -n 1,18p $S/ens_profile.log; echo '```'; echo '## ensemble leg: worker processes (tools/ensemble_probe.py; workers run with HSA_ENABLE_SDMA=0)'; echo '```'; cat $S/probe.log; echo '```'; echo '## fine-grained library calls from N Python threads, one context each (tools/thread_scaling.py)'; echo '```'; cat $S/thread_scaling.log; echo '```'; echo '## RCCL: one rank (tools/rccl_smoke.py)'; echo '```'; cat $S/rccl.log; echo '```'; echo '## RCCL: two ranks on the one GPU of the box (tools/rccl_two_ranks_one_gpu.py)'; echo '```'; cat $S/rccl2.log; echo '```'; } > $P/${RP}_threads_procs_rccl.md
 { echo "# eigensolver beyond the Infinity Cache (session $TAG): symmetric-aware trailing matvec + triangle-only trailing update from 5120 trailing rows on, 64-reflector blocks in the back-transformation from n = 4096 on"; echo; echo '## wall time per eigh (tools/eigh_only.py)'; echo '```'; cat $S/eigh_large.log; echo '```'; echo; echo '## kernels of one eigh at 3N = 12288'; echo; sed -n 3,22p $S/eigh12288_kernel_stats.md; echo; echo '## per-column kernels by trailing size (tools/trd_by_m.py)'; echo; cat $S/eigh12288_by_m.txt; } > $P/${RP}_eigh_large.md
 { echo "# optimizer step and configs[1] timings (session $TAG)"; for f in opt_3072 emt geodesic dav_time; do echo; echo "## $f.log"; echo '```'; cat $S/$f.log; echo '```'; done; } > $P/${RP}_timings.md
-{ echo "# two-stage reduction of sella_eigh (option eigh_two_stage, off by default; session $TAG)"; echo; echo '## stage times, against the one-stage default (SELLA_DEBUG_TIMING, tools/eigh_only.py; check = against LAPACK)'; echo '```'; cat $S/eigh_two_stage.log; echo '```'; for n in 3072 12288; do echo; echo "## kernels of two eigh calls at 3N = $n"; echo; sed -n 3,26p $S/eigh_two_stage_${n}_kernel_stats.md; done; } > $P/${RP}_eigh_two_stage.md
 python3 - "$S" <<'PY'
 import json, re, sys
 S = sys.argv[1]

@@ -26,9 +26,6 @@ if os.environ.get('EIGH_WY64_MIN'):
     ctx.set_option('eigh_wy_nb64_min', int(os.environ['EIGH_WY64_MIN']))
 if os.environ.get('EIGH_TAIL_LDS'):
     ctx.set_option('eigh_tail_lds', int(os.environ['EIGH_TAIL_LDS']))
-if os.environ.get('EIGH_TWO_STAGE'):
-    ctx.set_option('eigh_two_stage', 1)
-    ctx.set_option('eigh2_min', int(os.environ['EIGH_TWO_STAGE']))
 if os.environ.get('EIGH_LEAF'):
     ctx.set_option('eigh_leaf', int(os.environ['EIGH_LEAF']))
 for kv in filter(None, os.environ.get('EIGH_OPTS', '').split(',')):     # generic: EIGH_OPTS=key=value,key=value

@@ -101,18 +101,6 @@ db=$(find $OUT/prof_eigh12288 -name "*.db" | head -1)
 python tools/rocprof_summary.py $db $OUT/eigh12288_kernel_stats.md "tools/eigh_only.py 12288 1 (rocprofv3 --kernel-trace --stats)" > /dev/null
 python tools/trd_by_m.py $db 1024 12288 > $OUT/eigh12288_by_m.txt 2>&1; head -14 $OUT/eigh12288_kernel_stats.md | tee -a $OUT/session.log; cat $OUT/eigh12288_by_m.txt | tee -a $OUT/session.log
 rm -rf $OUT/prof_eigh12288
-say "== two-stage reduction (option eigh_two_stage, off by default): stage times by size, kernels at 3N = 3072 and 12288"
-{ for n in 3072 8192 12288; do
-    echo "n = $n, two-stage"; EIGH_CHECK=1 EIGH_TWO_STAGE=0 SELLA_DEBUG_TIMING=1 timeout 300 python tools/eigh_only.py $n 3 2>&1 | tail -3
-    echo "n = $n, one-stage (default)"; SELLA_DEBUG_TIMING=1 timeout 300 python tools/eigh_only.py $n 3 2>&1 | tail -2
-  done; } > $OUT/eigh_two_stage.log 2>&1; cat $OUT/eigh_two_stage.log | tee -a $OUT/session.log
-for n in 3072 12288; do
-  (cd /tmp && EIGH_TWO_STAGE=0 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_ts$n -o ts -- python $R/tools/eigh_only.py $n 2 > $R/$OUT/rocprof_ts$n.log 2>&1); say "rocprof two-stage $n exit $?"
-  db=$(find $OUT/prof_ts$n -name "*.db" | head -1)
-  python tools/rocprof_summary.py $db $OUT/eigh_two_stage_${n}_kernel_stats.md "EIGH_TWO_STAGE=0 tools/eigh_only.py $n 2 (rocprofv3 --kernel-trace --stats)" > /dev/null
-  head -22 $OUT/eigh_two_stage_${n}_kernel_stats.md | tee -a $OUT/session.log
-  rm -rf $OUT/prof_ts$n
-done
 say "== configs[2]: internal coordinates / geodesic at 1024 atoms"
 timeout 600 python tools/geodesic_bench.py --steps 3 --sella-steps 2 > $OUT/geodesic.log 2>&1; say "geodesic exit $?"
 grep "^{" $OUT/geodesic.log | cut -c1-400 | tee -a $OUT/session.log

@@ -476,6 +476,7 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "lr_dev")) c->opt.lr_dev = value ? 1 : 0;
     else if (!strcmp(key, "lr_chain")) c->opt.lr_chain = value ? 1 : 0;
     else if (!strcmp(key, "lr_pipe")) c->opt.lr_pipe = value ? 1 : 0;
+    else if (!strcmp(key, "eigh_wy_overlap")) c->opt.eigh_wy_overlap = value ? 1 : 0;
     else if (!strcmp(key, "eigh_upd_max")) c->opt.eigh_upd_max = value < 0 ? 0 : value;
     else if (!strcmp(key, "eigh_upd_rows")) c->opt.eigh_upd_rows = value;
     else if (!strcmp(key, "eigh_upd_nt")) c->opt.eigh_upd_nt = value;

@@ -3109,19 +3109,37 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     const int wynb = wy64 ? WY_NB2 : WY_NB;
     const int nblk = nrefl > 0 ? (nrefl + wynb - 1) / wynb : 0;
     double* Gd = nullptr;                                // nblk x nb x nb: Gram matrices, then C = T^T
+    hipStream_t wy_stream = c->stream;
     if ((hV || hVt) && nblk > 0) {
         // 64-blocks: the Gram matrix of a block in `gsl` column slices (one workgroup per block would leave most of the
         // chip idle: 48 blocks at n = 3072, 1.27 ms), partial matrices behind the C array
         const int gsl = wy64 ? std::max(1, std::min(8, (256 + nblk - 1) / nblk)) : 0;
         SCHK(scratch_get(c, SCR_EIG6, (size_t)nblk * (1 + gsl) * wynb * wynb * sizeof(double), &Gd));
+        // On a second stream (round 5): 0.45 ms of Gram / triangular-factor kernels at n = 3072 (and the explicit
+        // reflectors, 0.03 ms) used to sit on the main stream in FRONT of the divide & conquer stage, whose levels are
+        // small kernels between host round trips — the chip has room for both.  Joined in front of the back-transformation.
+        if (c->opt.eigh_wy_overlap && !c->prof) {
+            if (!c->stream2) {
+                if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+                    set_error("second stream for the compact-WY factors could not be created");
+                    return SELLA_E_HIP;
+                }
+            }
+            HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            wy_stream = c->stream2;
+        }
         if (wy64) {
             double* Gpart = Gd + (size_t)nblk * wynb * wynb;
-            hipLaunchKernelGGL(wy_gram64_kernel, dim3(nblk, gsl), dim3(256), 0, c->stream, W.A, ld, n, nrefl, taus, Gpart);
-            hipLaunchKernelGGL(wy_tinv64_kernel, dim3(nblk), dim3(64), 0, c->stream, Gd, Gpart, gsl, nrefl, taus);
+            hipLaunchKernelGGL(wy_gram64_kernel, dim3(nblk, gsl), dim3(256), 0, wy_stream, W.A, ld, n, nrefl, taus, Gpart);
+            hipLaunchKernelGGL(wy_tinv64_kernel, dim3(nblk), dim3(64), 0, wy_stream, Gd, Gpart, gsl, nrefl, taus);
         } else {
-            hipLaunchKernelGGL(wy_gram_kernel, dim3(nblk), dim3(256), 0, c->stream, W.A, ld, n, nrefl, taus, Gd);
-            hipLaunchKernelGGL(wy_tinv_kernel, dim3(nblk), dim3(64), 0, c->stream, Gd, nrefl, taus);
+            hipLaunchKernelGGL(wy_gram_kernel, dim3(nblk), dim3(256), 0, wy_stream, W.A, ld, n, nrefl, taus, Gd);
+            hipLaunchKernelGGL(wy_tinv_kernel, dim3(nblk), dim3(64), 0, wy_stream, Gd, nrefl, taus);
         }
+        if (wy_stream != c->stream) HIPCHK(hipEventRecord(c->ev_join, wy_stream));
         HIPCHK(hipGetLastError());
     }
 
@@ -3136,6 +3154,7 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     if (nrefl > 0) {
         const int yrows = nblk * wynb;
         double* Yf = W.Zc;                               // explicit reflectors (yrows x ld)
+        if (wy_stream != c->stream) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
         hipLaunchKernelGGL(wy_expand_kernel, dim3((ld + 255) / 256, yrows), dim3(256), 0, c->stream, W.A, ld, n, nrefl,
                            taus, Yf);
         prof_begin(c, PROF_OTHER, 0.0, 2.0 * n * (double)n * n);

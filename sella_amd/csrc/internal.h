@@ -116,6 +116,7 @@ struct Options {
     long bd_dev_rr = 0;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 56) on the device by parallel cyclic
                              // Jacobi in one workgroup (davidson_block.hip).  Measured at k = 48: 456 us per solve against ~270 us
                              // for the host's tred2 / tql2 (session r03l: 1.16 against 0.85 ms per block iteration), hence off
+    long eigh_wy_overlap = 1; // 1: Gram matrices / triangular factors of the compact-WY blocks on a second stream, beside divide & conquer
     long eigh_upd_max = 1024; // trailing blocks of at most this many rows are tridiagonalised with ONE launch per column, the block
                              //    kept up to date by the launch itself (trd_upd_kernel, eigh.hip); 0: never.  eigh at n = 3072 by
                              //    switch-over size (session r05b): 0: 39.85 ms, 512: 38.78, 1024: 38.28, 1536: 39.07, 2048: 40.19,

@@ -249,9 +249,9 @@ def test_sella_run_hands_the_search_to_the_library_and_takes_it_back(ctx, pinned
 
 
 def test_atoms_moved_between_two_runs(ctx):
-    """Converge inside the library, perturb the atoms, `run()` again: the cached energy and gradient belong to the
-    library's geometry, so the second run must make a force call at the new positions (not report convergence from the
-    stale gradient) and then walk exactly like the general driver put through the same sequence."""
+    """A run inside the library, then somebody moves the atoms, then `run()` again: the energy and gradient the library
+    holds belong to ITS geometry, so the second run must make a force call at the new positions (not carry the stale
+    gradient over as if it belonged there) and then walk exactly like the general driver put through the same sequence."""
     from sella_amd import Sella
     from sella_amd.internal import Constraints
 
@@ -262,17 +262,18 @@ def test_atoms_moved_between_two_runs(ctx):
         return atoms, opt
     a1, o1 = make(True)
     a2, o2 = make(False)
-    assert o1.run(1e-3, 60) and o2.run(1e-3, 60)
-    assert o1._lib is not None and o1.nsteps == o2.nsteps
+    o1.run(0.0, 6)
+    o2.run(0.0, 6)
+    assert o1._lib is not None and o1._lib_authoritative and o1.nsteps == o2.nsteps == 6
     kick = 0.02 * np.random.RandomState(7).normal(size=a1.positions.shape)
     a1.positions = a1.positions + kick
     a2.positions = a2.positions + kick
     calls = a1.calc.ncalls
-    conv1 = o1.run(1e-3, 3)
-    conv2 = o2.run(1e-3, 3)
+    o1.run(0.0, 3)
+    o2.run(0.0, 3)
     assert o1._lib is None                                    # the state came back, the general driver continued
-    assert a1.calc.ncalls > calls                             # ... with a force call at the perturbed geometry
-    assert conv1 == conv2 and o1.nsteps == o2.nsteps and o1.pes.neval == o2.pes.neval
+    assert a1.calc.ncalls > calls + 3                         # ... with a force call at the perturbed geometry on top of the steps'
+    assert o1.nsteps == o2.nsteps and o1.pes.neval == o2.pes.neval and a1.calc.ncalls == a2.calc.ncalls
     np.testing.assert_allclose(a1.positions, a2.positions, atol=1e-7)
     assert o1.pes.get_f() == pytest.approx(o2.pes.get_f(), abs=1e-9)
     np.testing.assert_allclose(o1.pes.get_g(), o2.pes.get_g(), atol=1e-7)

@@ -388,7 +388,10 @@ int sella_internals_eval(sella_ctx* ctx, int natoms, int nc, const double* pos, 
 /* Energy and gradient of the effective-medium potential (functional form of ase/calculators/emt.py).
  * pos (n x 3); par (9 x n): per-atom E0, s0, V0, eta2, kappa, lambda, n0, gamma1, gamma2 in eV / Angstrom;
  * shifts (nshift x 3): lattice translations of the periodic images to include (with the zero vector);
- * rc, acut, cutoff, beta: cutoff function parameters.  Outputs: *energy, grad (n x 3) = dE/dx.         */
+ * rc, acut, cutoff, beta: cutoff function parameters.  Outputs: *energy, grad (n x 3) = dE/dx.
+ * Limits (also of sella_calc_emt_create): n < 2^24 atoms and nshift <= 127 images (SELLA_E_INVALID beyond: the density pass
+ * hands each thread's neighbours to the force pass as packed (atom, image) words); the hand-over area is 256 x 9 ints =
+ * 9.2 KB of scratch per atom, written and read by every force call (9.4 MB at 1024 atoms).                            */
 int sella_emt_eval(sella_ctx* ctx, int n, const double* pos, const double* par, int nshift,
                    const double* shifts, double rc, double acut, double cutoff, double beta,
                    double* energy, double* grad);
@@ -445,10 +448,12 @@ int sella_search_create(sella_ctx* ctx, sella_calc* calc, int n, const double* x
 int sella_search_seed(sella_search* search, double energy, const double* grad);
 int sella_search_run(sella_search* search, double fmax, long steps, int* converged);
 /* After SELLA_E_UNSUPPORTED: the block of secant pairs of a diagonalisation that no longer fitted the structured form (its
- * force calls are spent and counted, the optimizer step that scheduled it is counted): *k pairs (0: none pending), Sm and
- * Ym (n x k row-major; NULL: only the count).  The caller applies them as one block update of the approximate Hessian
- * it takes over (sella/linalg.py:274-304) and is then exactly where the reference is after PES.diag
- * (sella/peswrapper.py:545-553).  A hand-over with k = 0 happened BEFORE the step moved the geometry.                  */
+ * force calls are spent and counted; when an optimizer step scheduled the diagonalisation, that step has moved the geometry
+ * and is counted): *k pairs (0: none pending), Sm and Ym (n x k row-major; NULL: only the count).  The caller applies them
+ * as one block update of the approximate Hessian it takes over (sella/linalg.py:274-304) and is then exactly where the
+ * reference is after PES.diag (sella/peswrapper.py:545-553).  Two hand-overs leave the geometry where it was and count
+ * no step: k = 0 (the capacity check in front of a step), and the FIRST-USE diagonalisation of a search (k > 0 with
+ * counters[0] == 0: optimize.py:318-326 runs it before the first step is taken).                                       */
 int sella_search_pending_pairs(sella_search* search, int* k, double* Sm, double* Ym);
 /* x, g (n each, may be NULL); scalars[5] = f, fmax, delta, rho, lowest eigenvalue of the approximate Hessian;
  * counters[6] = optimizer steps, force calls, one-call steps, explicit rank, explicit rank of the view (-1: none),

@@ -379,7 +379,8 @@ struct CalcPipe {
 };
 int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pipe = nullptr);
 // optstep.hip: sella_opt_step with the force call inside (see CalcPipe); *f_new receives the energy
-int opt_step_with_calc(sella_ctx* c, sella_opt_step_t* a, sella_calc* calc, const double* x, double* g_new, double* f_new);
+int opt_step_with_calc(sella_ctx* c, sella_opt_step_t* a, sella_calc* calc, const double* x, double* g_new, double* f_new,
+                       bool* force_call_made = nullptr);
 // batched NN GEMM for the merges of one divide-and-conquer level: batch b multiplies the diagonal blocks
 // at offset lo_b:  C[lo.., lo..] (K_b x N_b) = A[lo.., lo..] (K_b x K_b) * B[lo.., lo..] (K_b x N_b), all with
 // leading dimension ld.  desc (device): 4 ints per batch {lo, N, K, unused}.

@@ -830,7 +830,8 @@ __global__ __launch_bounds__(256) void lr_gperp_kernel(GperpArgs a) {
 }
 
 // The secant pair formed on the device (pipelined force call): X1 holds g_old on entry; y = g - g_old -> X1 and X4, g -> X2;
-// per-workgroup partials of s.y and y.y -> SY[2 * wg], SY[2 * wg + 1] (lr_erows_kernel sums them into the Gram block)
+// per-workgroup partials of s.s, s.y and y.y -> SY[3 * wg], SY[3 * wg + 1], SY[3 * wg + 2] (lr_erows_kernel sums them into the
+// Gram block)
 __global__ __launch_bounds__(256) void lr_secant_kernel(double* __restrict__ X, int ld, int n, const double* __restrict__ g,
                                                         double* __restrict__ SY) {
     __shared__ double red[4];
@@ -1304,7 +1305,11 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
             HIPCHK(hipGetLastError());
             if (!piped) {
                 for (int q = 0; q < m; ++q) gsub[q] = a->g_new[a->idx[q]];
-                SCHK(h2d_async(c, Xs + 2 * (size_t)lds, gsub.data(), (size_t)m * sizeof(double)));
+                // whole row, padding zeroed: the scratch may hold another search's layout beyond column m
+                double* slot = nullptr;
+                SCHK(h2d_begin(c, (size_t)lds * sizeof(double), reinterpret_cast<void**>(&slot)));
+                memcpy(slot, gsub.data(), (size_t)m * sizeof(double));
+                SCHK(h2d_end(c, Xs + 2 * (size_t)lds, slot, (size_t)lds * sizeof(double)));
             }
             S.Rpre = Xs + 3 * (size_t)lds; S.mu_dev = Xs + 5 * (size_t)lds; S.G_dev = S.mu_dev + ldmus;
             S.SY = SYv; S.syparts = vparts;

@@ -55,7 +55,8 @@ extern "C" int sella_opt_step(sella_ctx* c, sella_opt_step_t* a) {
 // kernels are queued in front of the update that consumes their gradient and the host waits once for both; otherwise
 // the force call is made here and the step proceeds as sella_opt_step.  g_new (n) and *f_new receive gradient and energy.
 int sella::opt_step_with_calc(sella_ctx* c, sella_opt_step_t* a, sella_calc* calc, const double* x, double* g_new,
-                              double* f_new) {
+                              double* f_new, bool* force_call_made) {
+    if (force_call_made) *force_call_made = false;
     if (!c || !a || !calc || !x || !g_new || !f_new || a->n <= 0 || !a->r || !a->mu) return SELLA_E_INVALID;
     a->ratio_valid = 0;
     a->updated = 0;
@@ -65,12 +66,17 @@ int sella::opt_step_with_calc(sella_ctx* c, sella_opt_step_t* a, sella_calc* cal
     CalcPipe pipe;
     pipe.calc = calc; pipe.x = x; pipe.g_out = g_new;
     bool handled = false;
-    SCHK(lr_fused_step(c, a, &handled, &pipe));
+    // (the status of the step is propagated only after the force call has been accounted for: a step that fails behind a
+    // finished force call must leave the caller with energy, gradient and call count of the geometry it moved to)
+    int status = lr_fused_step(c, a, &handled, &pipe);
     if (pipe.done) {
         *f_new = pipe.f;
-        if (handled) return SELLA_OK;
+        if (force_call_made) *force_call_made = true;
+        if (status != SELLA_OK || handled) return status;
     } else {
+        SCHK(status);
         SCHK(sella_calc_eval(calc, x, f_new, g_new));
+        if (force_call_made) *force_call_made = true;
         a->f_new = *f_new;
         SCHK(lr_fused_step(c, a, &handled));
         if (handled) return SELLA_OK;

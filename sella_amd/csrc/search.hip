@@ -305,9 +305,13 @@ int call_opt_step(sella_search* S, int flags, double f_old, bool with_calc = fal
     a.s_out = S->s.data();
     if (with_calc) {
         // the force call at S->x rides in front of the update (optstep.hip: one wait for both where the fast form applies)
-        SCHK(opt_step_with_calc(S->c, &a, S->calc, S->x.data(), S->g.data(), &S->f));
-        ++S->neval;
-        S->have_fg = true;
+        bool called = false;
+        const int status = opt_step_with_calc(S->c, &a, S->calc, S->x.data(), S->g.data(), &S->f, &called);
+        if (called) {                                        // counted and kept whatever became of the step behind it
+            ++S->neval;
+            S->have_fg = true;
+        }
+        SCHK(status);
     } else {
         SCHK(sella_opt_step(S->c, &a));
     }

@@ -2215,7 +2215,7 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
                 const bool prof_all = c->prof;
                 if (prof_all && (j & 3)) c->prof = false;
                 if (c->prof) SCHK(stream_wait(c));
-                prof_begin(c, PROF_TRD_GEMV, (first ? 8.0 : 16.0) * m * (double)m, (first ? 2.0 : 6.0) * m * (double)m);
+                prof_begin(c, PROF_OTHER, (first ? 8.0 : 16.0) * m * (double)m, (first ? 2.0 : 6.0) * m * (double)m);   // (PROF_TRD_GEMV stays the matvec of the blocked chain alone)
 #define SELLA_TRD_UPD(RR, NT)                                                                                             \
     do {                                                                                                                  \
         if (first) SELLA_LAUNCH(c, HIP_KERNEL_NAME(trd_upd_kernel<RR, NT, true>), dim3(grid), dim3(NT), 0, ua);           \

@@ -4,12 +4,15 @@ db = sqlite3.connect(paths[0])
 rows = db.execute("select name,start,end,duration from kernels order by start").fetchall()
 def short(n):
     return n.replace('sella::', '').replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:34]
-# last davidson call: everything after the last wy_apply / transpose of eigh ... take last 30% of rows
-rows = rows[int(len(rows) * 0.72):]
-# split into iterations at each 'gemv_rows_kernel<1, 2>' (A t)
+# last davidson call: everything after the last launch of the eigensolver (its final transpose)
+last = max(i for i, r in enumerate(rows) if 'wy_apply' in r[0])
+rows = rows[last + 4:]
+third = len(rows) * 2 // 3
+rows = rows[third:]
+# split into iterations at the residual kernel (first launch of the fused chain of an iteration)
 its, cur = [], []
 for r in rows:
-    if 'gemv_rows_kernel<1, 2>' in r[0] and cur:
+    if 'dav_resid_kernel' in r[0] and cur:
         its.append(cur); cur = []
     cur.append(r)
 its.append(cur)

@@ -99,7 +99,11 @@ def test_profiling_hooks(ctx):
     ctx.prof_reset()
     ctx.prof_enable(True)
     ctx.symm_mm(dA, rng.normal(size=n))
-    ctx.eigh(dA)
+    ctx.set_option('eigh_upd_max', 0)            # the blocked chain at this size too (slot 5 counts ITS matvec launches only)
+    try:
+        ctx.eigh(dA)
+    finally:
+        ctx.set_option('eigh_upd_max', 1024)
     ctx.prof_enable(False)
     small, trd = ctx.prof_get(4), ctx.prof_get(5)
     assert small['launches'] >= 1 and small['bytes'] >= 8.0 * n * n and small['ms'] >= 0.0
@@ -111,6 +115,12 @@ def test_profiling_hooks(ctx):
     assert abs(trd['bytes'] - 8.0 * sum((n - 1 - j) ** 2 for j in cols)) < 1e-6
     ctx.symm_mm(dA, rng.normal(size=n))          # not counted once disabled
     assert ctx.prof_get(4)['launches'] == small['launches']
+    # default options: a trailing block this small goes through the one-launch-per-column chain, which is not slot 5
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    ctx.eigh(dA)
+    ctx.prof_enable(False)
+    assert ctx.prof_get(5)['launches'] == 0 and ctx.prof_get(3)['launches'] > 0
 
 
 def test_block_panel_product(ctx):

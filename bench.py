@@ -381,7 +381,11 @@ def main():
                     bytes_per_launch=round(p['bytes'] / p['launches']))
 
     roof = hbm(pt, 'trd_gemv_kernel (m x m trailing-matrix matvec, one per column of the eigh of P)')
-    if roof is not None:
+    if roof is None:
+        # a matrix too small for the blocked chain of the eigensolver (at most 1024 trailing rows go through the
+        # one-launch-per-column chain, csrc/eigh.hip): the Davidson loop's own n x n stream is the kernel to report
+        roof = hbm(pg, 'gemv_rows_kernel<NRHS,2> (n x n row-panel matvec of the Davidson loop; n below the blocked chain of eigh)')
+    elif roof is not None:
         # HBM traffic per launch cannot be counted from inside this process: it comes from the PMC
         # passes of tools/gpu_session.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own runs), whose
         # per-launch means are committed in profiles/pmc_traffic.json with the guide's gfx950 correction

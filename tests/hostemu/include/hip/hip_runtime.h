@@ -150,6 +150,10 @@ static inline int hipemu_readlane(int v, int lane) {
 }
 #define __builtin_amdgcn_readlane hipemu_readlane
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+// lanes of a wavefront are fibers here: where the hardware's lockstep orders "all lanes wrote LDS, then any lane reads it",
+// the kernels say so with a wave barrier (a compiler-only barrier on the device, a rendezvous of the 64 fibers here)
+static inline void hipemu_wave_barrier() { int x = 0, y; hipemu::wave_exchange(&x, &y, sizeof(int), hipemu::lane_id()); (void)y; }
+#define __builtin_amdgcn_wave_barrier hipemu_wave_barrier
 static inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
 static inline int __double2hiint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b >> 32); }
 static inline double __hiloint2double(int hi, int lo) {

@@ -6,6 +6,8 @@ cp $S/session.log $P/${RP}_session.log
 cp $S/bench_line.json $P/${RP}_bench_line.json
 for k in bench eigh davidson_loop block_iter optimizer_step; do cp $S/${k}_kernel_stats.md $P/${RP}_${k}_kernel_stats.md; done
 cp $S/opt_step_timeline.txt $P/${RP}_opt_step_timeline.txt; cp $S/emt_step_timeline.txt $P/${RP}_emt_step_timeline.txt
+cp $S/dav_iter_timeline.txt $P/${RP}_dav_iter_timeline.txt
+{ echo "# tridiagonalisation at 3N = 3072 by trailing size (session $TAG): blocked chain above eigh_upd_max = 1024 rows, one launch per column below"; echo; cat $S/eigh_by_m.txt; echo; echo '## eigh wall time by switch-over size'; echo '```'; cat $S/eigh_switch.log; echo '```'; } > $P/${RP}_eigh_by_m.md
 { echo "# PMC passes (rocprofv3 --pmc <counter> with kernel dispatch tracing only, one counter group per run; tools/gpu_session.sh $TAG at the evidence head)"; echo;
   echo "Units: FETCH_SIZE / WRITE_SIZE in KiB as reported (raw). On gfx950 FETCH_SIZE counts a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM section): multiply FETCH by 2. Infinity-Cache hits are included."; echo;
   echo '## eigensolver, `tools/eigh_only.py 3072 1` — matvec kernel'; echo '```'; cat $S/pmc_eigh_FETCH_SIZE.txt $S/pmc_eigh_WRITE_SIZE.txt; echo '```'; echo;

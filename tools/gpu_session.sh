@@ -101,6 +101,15 @@ db=$(find $OUT/prof_eigh12288 -name "*.db" | head -1)
 python tools/rocprof_summary.py $db $OUT/eigh12288_kernel_stats.md "tools/eigh_only.py 12288 1 (rocprofv3 --kernel-trace --stats)" > /dev/null
 python tools/trd_by_m.py $db 1024 12288 > $OUT/eigh12288_by_m.txt 2>&1; head -14 $OUT/eigh12288_kernel_stats.md | tee -a $OUT/session.log; cat $OUT/eigh12288_by_m.txt | tee -a $OUT/session.log
 rm -rf $OUT/prof_eigh12288
+say "== tridiagonalisation by trailing size: blocked chain (row kernel + matvec), one-launch chain below eigh_upd_max; switch-over sweep"
+(cd /tmp && rm -rf /tmp/trm && timeout 300 rocprofv3 --kernel-trace -d /tmp/trm -o tr -- python $R/tools/eigh_only.py 3072 2 > /dev/null 2>&1)
+db=$(find /tmp/trm -name "*.db" | head -1)
+{ python tools/trd_by_m.py $db 256 3072; python tools/col_by_m.py $db 3072; python tools/eigh_tail_timeline.py $db | tail -1; } > $OUT/eigh_by_m.txt 2>&1; cat $OUT/eigh_by_m.txt | tee -a $OUT/session.log
+{ for MX in 0 512 1024 1536 2048; do echo -n "eigh_upd_max $MX: "; EIGH_OPTS=eigh_upd_max=$MX timeout 300 python tools/eigh_only.py 3072 4 2>&1 | tail -1; done;
+  echo -n "eigh_wy_overlap 0: "; EIGH_OPTS=eigh_wy_overlap=0 timeout 300 python tools/eigh_only.py 3072 4 2>&1 | tail -1; } > $OUT/eigh_switch.log 2>&1; cat $OUT/eigh_switch.log | tee -a $OUT/session.log
+say "== Davidson iteration, launch by launch"
+(cd /tmp && rm -rf /tmp/dt && timeout 300 rocprofv3 --kernel-trace -d /tmp/dt -o dt -- python $R/tools/dav_timeline.py > /dev/null 2>&1)
+python tools/dav_timeline_parse.py /tmp/dt > $OUT/dav_iter_timeline.txt 2>&1; cat $OUT/dav_iter_timeline.txt | tee -a $OUT/session.log
 say "== configs[2]: internal coordinates / geodesic at 1024 atoms"
 timeout 600 python tools/geodesic_bench.py --steps 3 --sella-steps 2 > $OUT/geodesic.log 2>&1; say "geodesic exit $?"
 grep "^{" $OUT/geodesic.log | cut -c1-400 | tee -a $OUT/session.log

@@ -107,6 +107,11 @@ struct WaveState {
     int live = 0;
     int count = 0;
     unsigned gen = 0;
+    // quads (4 consecutive lanes) rendezvous on their own for quad-permute DPP: code in which the quads of a wavefront
+    // follow different control flow (one small problem per quad) only ever exchanges data inside a quad
+    int qlive[16] = {0};
+    int qcount[16] = {0};
+    unsigned qgen[16] = {0};
     alignas(64) unsigned char xchg[64][64];
 };
 std::vector<WaveState> g_waves;
@@ -120,9 +125,12 @@ void trampoline() {
     --g_live;
     WaveState& w = g_waves[f->lin >> 6];
     --w.live;
+    const int q = (f->lin & 63) >> 2;
+    --w.qlive[q];
     // a finished thread must not strand its peers at a barrier
     if (g_bar_count > 0 && g_bar_count == g_live) { g_bar_count = 0; ++g_bar_gen; }
     if (w.count > 0 && w.count == w.live) { w.count = 0; ++w.gen; }
+    if (w.qcount[q] > 0 && w.qcount[q] == w.qlive[q]) { w.qcount[q] = 0; ++w.qgen[q]; }
     ctx_switch(&f->ctx, &g_sched);
     abort();                         // a finished fiber is never resumed
 }
@@ -131,6 +139,12 @@ void wave_barrier(WaveState& w) {
     unsigned gen = w.gen;
     if (++w.count == w.live) { w.count = 0; ++w.gen; return; }
     while (w.gen == gen) yield();
+}
+
+void quad_barrier(WaveState& w, int q) {
+    unsigned gen = w.qgen[q];
+    if (++w.qcount[q] == w.qlive[q]) { w.qcount[q] = 0; ++w.qgen[q]; return; }
+    while (w.qgen[q] == gen) yield();
 }
 }  // namespace
 
@@ -157,6 +171,20 @@ void wave_exchange(const void* in, void* out, size_t bytes, int src_lane) {
     if (src_lane < 0 || src_lane >= nlanes) src_lane = lane;
     memcpy(out, w.xchg[src_lane], bytes);
     wave_barrier(w);
+}
+
+void quad_exchange(const void* in, void* out, size_t bytes, int src_lane) {
+    if (bytes > 64) { fprintf(stderr, "hipemu: shuffle payload too large\n"); abort(); }
+    WaveState& w = g_waves[g_cur->lin >> 6];
+    const int lane = g_cur->lin & 63, q = lane >> 2;
+    if ((src_lane >> 2) != q) { fprintf(stderr, "hipemu: quad exchange across quads\n"); abort(); }
+    memcpy(w.xchg[lane], in, bytes);
+    quad_barrier(w, q);
+    int total = g_nthreads;
+    int wave_base = (g_cur->lin >> 6) << 6;
+    if (wave_base + src_lane >= total) src_lane = lane;
+    memcpy(out, w.xchg[src_lane], bytes);
+    quad_barrier(w, q);
 }
 
 void wave_gather64(const void* in, size_t bytes, void* all64) {
@@ -206,6 +234,7 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& 
 #endif
                     ctx_make(&f.ctx, f.stack, kStack, trampoline);
                     g_waves[t >> 6].live++;
+                    g_waves[t >> 6].qlive[(t & 63) >> 2]++;
                 }
                 int remaining = nthreads;
                 while (remaining > 0) {

@@ -70,6 +70,7 @@ void* dyn_smem();
 void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 void block_barrier();
 void wave_exchange(const void* in, void* out, size_t bytes, int src_lane);
+void quad_exchange(const void* in, void* out, size_t bytes, int src_lane);  // the four lanes of a quad rendezvous on their own
 void wave_gather64(const void* in, size_t bytes, void* all64);  // every lane gets all 64 values
 int lane_id();
 long launches();
@@ -139,7 +140,8 @@ static inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool) 
     else if (ctrl == 0x141) from = base + (idx & 8) + (7 - (idx & 7));
     else { fprintf(stderr, "hipemu: unsupported DPP control 0x%x\n", ctrl); abort(); }
     int out;
-    hipemu::wave_exchange(&src, &out, sizeof(int), from);
+    if (ctrl < 0x100) hipemu::quad_exchange(&src, &out, sizeof(int), from);   // quad permutes stay inside the quad
+    else hipemu::wave_exchange(&src, &out, sizeof(int), from);
     return out;
 }
 #define __builtin_amdgcn_update_dpp hipemu_update_dpp
@@ -150,6 +152,7 @@ static inline int hipemu_readlane(int v, int lane) {
 }
 #define __builtin_amdgcn_readlane hipemu_readlane
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+static inline long long wall_clock64() { return 0; }
 // lanes of a wavefront are fibers here: where the hardware's lockstep orders "all lanes wrote LDS, then any lane reads it",
 // the kernels say so with a wave barrier (a compiler-only barrier on the device, a rendezvous of the 64 fibers here)
 static inline void hipemu_wave_barrier() { int x = 0, y; hipemu::wave_exchange(&x, &y, sizeof(int), hipemu::lane_id()); (void)y; }

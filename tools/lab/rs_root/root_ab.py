@@ -24,8 +24,9 @@ def slab():
 
 if __name__ == '__main__':
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    modes = [int(a) for a in sys.argv[2:]] or [1, 0, 1, 0]
     ctx = _dev.get_context()
-    for dev in (1, 0, 1, 0):
+    for dev in modes:
         ctx.set_option('rs_dev_root', dev)
         opt = slab()
         opt.run(fmax=0.0, steps=3)

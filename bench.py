@@ -633,6 +633,25 @@ def main():
                     opt_stats['emt_slab']['library_loop'] = dict(optimizer_steps_per_s=round(args.emt_steps / tl, 2),
                                                                  ms_per_step=round(1e3 * tl / args.emt_steps, 3),
                                                                  force_calls=int(ls.neval))
+                    # roofline of the step on the configuration BASELINE's metric names.  There is no n x n pass in it: the
+                    # approximate Hessian is lam0 I + W^T (mu - lam0) W with r explicit pairs (and its principal submatrix on
+                    # the free coordinates, r_view pairs), so a step is O(n r): 9 passes over each of the two panels (dots, two
+                    # Gram-Schmidt sweeps, new rows, clean-up, W+ = Q^T E read + write, g_perp), the panel products of the
+                    # root search over the view (3.4 batches of 16 trial steps on average, rocprofv3) and one EMT force call
+                    # (positions in, forces out, 9 KB of neighbour hand-over per atom written and read).
+                    r_f, r_v = int(ls.rank), max(0, int(ls.rank_view))
+                    n_s, m_s, na_s = 3 * len(slab2), int(dyn.pes.get_Ufree().shape[1]), len(slab2)
+                    alg_s = 9.0 * 8.0 * n_s * max(1, r_f) + 9.0 * 8.0 * m_s * max(1, r_v) + 3.4 * 8.0 * m_s * (r_v + 2) \
+                        + 48.0 * na_s + 2.0 * 9216.0 * na_s
+                    step_slab = tl / args.emt_steps
+                    if roof is not None:
+                        roof['optimizer_step_emt_slab'] = dict(
+                            bound='hbm', explicit_rank=r_f, explicit_rank_view=r_v, algorithmic_bytes_per_step=round(alg_s),
+                            achieved=round(alg_s / step_slab / 1e9, 2), peak=HBM_PEAK_GBS, unit='GB/s',
+                            frac=round(alg_s / step_slab / 1e9 / HBM_PEAK_GBS, 5), ms_per_step=round(1e3 * step_slab, 3),
+                            note='latency bound: ~63 dependent launches of 3-30 us (two coordinate-update chains, 3.4 round trips '
+                                 'of the per-atom root search, EMT) and their host waits; kernel timeline in '
+                                 'profiles/r05_emt_step_timeline.txt')
                     ls.close()
             except Exception as e:                       # noqa: BLE001
                 opt_stats['emt_slab']['library_loop'] = dict(error=str(e)[:200])

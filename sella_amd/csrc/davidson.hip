@@ -333,7 +333,7 @@ void unpack(const vec& in, int k, vec& G, int cap) {
 // pursue, a vector that needs a third sweep or is dropped) discards the speculative vector and repeats the iteration
 // on the synchronous path, which is the reference's control flow step by step.  Results are therefore identical to
 // the synchronous path's; only the launch/sync structure differs.
-constexpr int DF_MAXBLK = 256;     // partial sums per quantity: ceil(n / 64) <= 250 for n <= 16000
+constexpr int DF_MAXBLK = 4096;    // partial sums per quantity (stride of the partial buffers): ceil(n / 64), n <= 262144
 constexpr int DF_TILE = 512;       // coefficients staged in LDS per trip
 constexpr int DF_EL = 64;          // elements per workgroup of the panel-combination kernels: lane = element, the four
                                    // wavefronts split the panel rows (row a belongs to wave a mod 4) and meet in LDS —
@@ -350,7 +350,8 @@ __device__ __forceinline__ double df_block_sum(double v, double* red) {
 
 // sum of up to DF_MAXBLK partials, every thread gets the result
 __device__ __forceinline__ double df_sum_partials(const double* __restrict__ p, int nblk, double* red) {
-    const double v = (threadIdx.x < (unsigned)nblk) ? p[threadIdx.x] : 0.0;
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) v += p[b];      // (one trip up to n = 16384)
     return df_block_sum(v, red);
 }
 
@@ -624,8 +625,8 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         set_error("davidson: invalid arguments");
         return SELLA_E_INVALID;
     }
-    if (n > 16000) {
-        set_error("davidson: n = %d exceeds the scalar exchange layout (16000); use sella_davidson_block", n);
+    if (n > 64 * DF_MAXBLK) {
+        set_error("davidson: n = %d exceeds the partial-sum layout (%d); use sella_davidson_block", n, 64 * DF_MAXBLK);
         return SELLA_E_UNSUPPORTED;
     }
     if (method < SELLA_DAV_LANCZOS || method > SELLA_DAV_MJD0_ALT) {

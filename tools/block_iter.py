@@ -21,7 +21,8 @@ H[np.arange(n), np.arange(n)] += 0.5 + 50.0 * (np.arange(n) / n) ** 2
 dH = ctx.upload(H)
 diag = np.ascontiguousarray(H.diagonal())
 del H
-for flag in (1, 0, 1):
+flags = [int(a) for a in sys.argv[3:]] or [1, 0, 1]
+for flag in flags:
     ctx.set_option('bd_dev_rr', flag)
     ctx.davidson_block(dH, n, 16, block=16, tol=1e-14, maxiter=2, diag=diag)
     ctx.sync()

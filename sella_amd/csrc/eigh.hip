@@ -398,7 +398,7 @@ __global__ __launch_bounds__(NT) void trd_upd_kernel(TrdUpdArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
     double ss = 0.0;
-    double* Aprev = a.A + (size_t)(j - 1) * a.ld;           // row of the previous reflector (not FIRST)
+    double* Aprev = FIRST ? a.A : a.A + (size_t)(j - 1) * a.ld;     // row of the previous reflector (unused in the first launch)
     const int nown = (int)gridDim.x - bw;                   // workgroups that run the stream
     const int nset = (n2 + NT - 1) / NT;
     for (int t = 0; t < nset; ++t) {

@@ -479,7 +479,7 @@ def main():
                         unit='GB/s', frac=round(alg / step_s / 1e9 / HBM_PEAK_GBS, 4),
                         ms_per_step=round(1e3 * step_s, 3), ms_per_step_instrumented=round(1e3 * tp / nprof_o, 3),
                         note='latency bound: ~25 dependent launches of 4-25 us and two host synchronisations per step; '
-                             'kernel timeline in profiles/r04_opt_step_timeline.txt')
+                             'kernel timeline in profiles/r05_opt_step_timeline.txt')
                 ls.close()
         except Exception as e:                           # noqa: BLE001 — reported, the leg above stands on its own
             opt_stats['library_loop'] = dict(error=str(e)[:200])

@@ -30,7 +30,10 @@ vals = {k: float(v) for k, _, v in re.findall(r'(FETCH_SIZE|WRITE_SIZE)\s+dispat
 t = d['trd_gemv_kernel']
 t['FETCH_SIZE_kb_mean_raw'], t['WRITE_SIZE_kb_mean_raw'] = vals['FETCH_SIZE'], vals['WRITE_SIZE']
 t['bytes_per_launch'] = (2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024
-t['source'] = re.sub(r'session r03\w', 'session ' + S.split('/')[-1], t['source'])
+t['source'] = re.sub(r'session r0\d\w?', 'session ' + S.split('/')[-1], t['source'])
+nd = int(re.search(r'FETCH_SIZE\s+dispatches=\s*(\d+)', txt).group(1))
+t['dispatches'] = nd          # blocked chain only: trailing blocks of n-1 .. n-nd rows
+t['algorithmic_bytes_per_launch'] = round(sum(8 * m * m + 16 * m for m in range(t['n'] - nd, t['n'])) / nd)
 json.dump(d, open(p, 'w'), indent=1)
 print(vals)
 PY

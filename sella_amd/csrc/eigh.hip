@@ -75,6 +75,9 @@ struct TrdRowArgs {
 template <int IPC>
 __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
     __shared__ double red[4];
+    SELLA_ARG(a.A); SELLA_ARG(a.ld); SELLA_ARG(a.n); SELLA_ARG(a.j); SELLA_ARG(a.i); SELLA_ARG(a.do_row); SELLA_ARG(a.Vp);
+    SELLA_ARG(a.Wp); SELLA_ARG(a.ldp); SELLA_ARG(a.u_cur); SELLA_ARG(a.wraw); SELLA_ARG(a.partA_cur); SELLA_ARG(a.partB);
+    SELLA_ARG(a.nblkB); SELLA_ARG(a.colscal); SELLA_ARG(a.cdots); SELLA_ARG(a.dvec);
     const int tid = threadIdx.x;
     const int j = a.j, i = a.i, ldp = a.ldp;
     const int c = j + blockIdx.x * 256 + tid;
@@ -84,19 +87,36 @@ __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
     // ---- loads that do not depend on anything computed here.  Every batch is written as "load all,
     // then use" with clamped indices: a plain loop makes the compiler wait for each load in turn, and
     // this kernel is nothing but a chain of memory round trips.
-    double vw = 0.0;
-    if (i > 0) {
-        for (int b0 = tid; b0 < a.nblkB; b0 += 256 * 8) {
-            double pv[8];
+    // the first 2048 partials of v.wraw: loaded unconditionally (clamped) and summed only where the sum is needed — a loop
+    // around them would wait for them before anything else is issued (one more dependent round trip per launch)
+    double pv0[8];
+    {
+        const int last = (a.nblkB > 0) ? a.nblkB - 1 : 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int b = b0 + 256 * k;
-                pv[k] = a.partB[b < a.nblkB ? b : a.nblkB - 1];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) vw += (b0 + 256 * k < a.nblkB) ? pv[k] : 0.0;
+        for (int k = 0; k < 8; ++k) {
+            const int b = tid + 256 * k;
+            pv0[k] = a.partB[b < a.nblkB ? b : last];
         }
     }
+    auto sum_partials = [&]() -> double {
+        double vw = 0.0;
+        if (IPC > 0 || i > 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) vw += (tid + 256 * k < a.nblkB) ? pv0[k] : 0.0;
+            for (int b0 = tid + 256 * 8; b0 < a.nblkB; b0 += 256 * 8) {          // (more than 2048 workgroups in the matvec only)
+                double pv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int b = b0 + 256 * k;
+                    pv[k] = a.partB[b < a.nblkB ? b : a.nblkB - 1];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) vw += (b0 + 256 * k < a.nblkB) ? pv[k] : 0.0;
+            }
+        }
+        return vw;
+    };
+    double vw = 0.0;
     const double arow = a.do_row ? a.A[(size_t)j * a.ld + cl] : 0.0;
     const double wrawc = (i > 0) ? a.wraw[cl] : 0.0;
     const double wrawj = (i > 0) ? a.wraw[j] : 0.0;
@@ -124,7 +144,7 @@ __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
             uni[tid] = (k == 0) ? a.cdots[p] : (k == 1) ? a.cdots[TRD_NBMAX + p]
                      : (k == 2) ? a.Vp[(size_t)p * ldp + j] : a.Wp[(size_t)p * ldp + j];
         }
-        vw = block_sum_256(vw, red);                                        // (i > 0 always holds here)
+        vw = block_sum_256(sum_partials(), red);                            // (i > 0 always holds here)
         vw_done = true;
 #pragma unroll
         for (int p = 0; p < NPC; ++p) {
@@ -148,7 +168,7 @@ __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
     }
     double wc = 0.0, u = 0.0;
     if (i > 0) {
-        if (!vw_done) vw = block_sum_256(vw, red);
+        if (!vw_done) vw = block_sum_256(sum_partials(), red);
         const double alpha2 = -0.5 * tau * tau * (vw - 2.0 * cc);
         const double wj = tau * (wrawj - t) + alpha2;           // w_{i-1}[j], v_{i-1}[j] = 1
         wc = tau * (wrawc - s) + alpha2 * vprev;
@@ -166,6 +186,8 @@ __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
     ss = block_sum_256(ss, red);
     if (tid == 0) a.partA_cur[(size_t)blockIdx.x * TRD_PA] = ss;
 }
+
+__device__ __forceinline__ double2 ldg2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 
 struct TrdGemvArgs {
     const double* A22;          // A + o*ld + oc   (oc = o rounded down to even: aligned 16-byte rows)
@@ -189,8 +211,17 @@ struct TrdGemvArgs {
 // matrix stream starts at once instead of waiting for the norm.  The 2i panel rows W_p, V_p (p < i)
 // are appended as extra rows of the same launch: a wavefront streams a whole row, so the dots the
 // next column needs (dlatrd's W^T v, V^T v) come out exact, without partial buffers.
+// NCH > 0: the rows are at most NCH chunks of 256 16-byte pieces long and EVERY load of the workgroup is issued before the
+// first wait — clamped addresses, masked afterwards.  The loop form (NCH = 0) waits for its loads once per pass (the
+// compiler cannot keep conditional loads in flight across the back edge): three dependent memory round trips per launch at
+// 3N = 3072 on top of the one for the partials, in a kernel whose whole life is 5 - 12 us.  Same expressions in the same
+// order: bit-identical results.
+template <int NCH>
 __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
     __shared__ double red[4][2];
+    SELLA_ARG(a.A22); SELLA_ARG(a.ld); SELLA_ARG(a.m); SELLA_ARG(a.shift); SELLA_ARG(a.o); SELLA_ARG(a.n); SELLA_ARG(a.j);
+    SELLA_ARG(a.pad); SELLA_ARG(a.ubuf); SELLA_ARG(a.partA); SELLA_ARG(a.nblkA); SELLA_ARG(a.wraw); SELLA_ARG(a.partB);
+    SELLA_ARG(a.Vrow); SELLA_ARG(a.Arow); SELLA_ARG(a.Wp); SELLA_ARG(a.Vp); SELLA_ARG(a.ldp); SELLA_ARG(a.i); SELLA_ARG(a.cdots);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = blockIdx.x * 2 - a.pad;              // local row of this workgroup's first row (may be < 0)
     const int mtot = a.m + 2 * a.i;
@@ -211,8 +242,9 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
     }
     // K1 partials of sum u^2 (one per lane, reduced after the stream) and the entries of u this
     // workgroup's epilogue needs: issued now, consumed at the end
+    double ssl0 = a.partA[(size_t)(lane < a.nblkA ? lane : a.nblkA - 1) * TRD_PA];     // consumed after the stream
     double ssl = 0.0;
-    for (int b = lane; b < a.nblkA; b += 64) ssl += a.partA[(size_t)b * TRD_PA];
+    for (int b = lane + 64; b < a.nblkA; b += 64) ssl += a.partA[(size_t)b * TRD_PA];  // (n > 16384 only)
     const double alpha = a.ubuf[a.o];
     double urow[2];
 #pragma unroll
@@ -224,6 +256,39 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
     const int n2 = (a.m + a.shift + 1) >> 1;
     // u' on the fly: u behind column o, 0 at column o, in the alignment pad and beyond n
     auto uval = [&](int cabs) -> double { return (cabs > a.o && cabs < a.n) ? a.ubuf[cabs] : 0.0; };
+    if constexpr (NCH > 0) {
+        double2 av[2][NCH], xv[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int jk = threadIdx.x + 256 * k;
+            const int jc = (jk < n2) ? jk : n2 - 1;
+            av[0][k] = arow[0][jc];
+            av[1][k] = arow[1][jc];
+            xv[k] = ldg2(a.ubuf + oc + 2 * jc);
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            SELLA_PIN(av[0][k].x); SELLA_PIN(av[0][k].y); SELLA_PIN(av[1][k].x); SELLA_PIN(av[1][k].y);
+            SELLA_PIN(xv[k].x); SELLA_PIN(xv[k].y);
+        }
+        const double2 zero2 = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < NCH; k += 2) {
+            const int j0 = threadIdx.x + 256 * k, j1 = j0 + 256;
+            const bool has0 = j0 < n2, has1 = j1 < n2;
+            const int c0 = oc + 2 * j0, c1 = oc + 2 * j1;
+            const double x00 = (has0 && c0 > a.o && c0 < a.n) ? xv[k].x : 0.0;
+            const double x01 = (has0 && c0 + 1 > a.o && c0 + 1 < a.n) ? xv[k].y : 0.0;
+            const double x10 = (has1 && c1 > a.o && c1 < a.n) ? xv[k + 1].x : 0.0;
+            const double x11 = (has1 && c1 + 1 > a.o && c1 + 1 < a.n) ? xv[k + 1].y : 0.0;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                // a chunk beyond the row adds exact zeros (the accumulator starts at +0 and can never be -0)
+                const double2 a0 = has0 ? av[r][k] : zero2, a1 = has1 ? av[r][k + 1] : zero2;
+                acc[r] += a0.x * x00 + a0.y * x01 + a1.x * x10 + a1.y * x11;
+            }
+        }
+    } else
     for (int j0 = threadIdx.x; j0 < n2; j0 += 512) {
         const int j1 = j0 + 256;
         const bool has1 = j1 < n2;
@@ -243,7 +308,7 @@ __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
         const double v = wave_sum_e(acc[r]);
         if (lane == 0) red[wave][r] = v;
     }
-    const double ss = wave_sum_e(ssl);
+    const double ss = wave_sum_e(ssl + ((lane < a.nblkA) ? ssl0 : 0.0));
     __syncthreads();
     if (threadIdx.x == 0) {
         // reflector scalars from the K1 partials (dlarfg)
@@ -314,7 +379,6 @@ struct TrdUpdArgs {
     double* taus; double* evec; double* dvec;
 };
 
-__device__ __forceinline__ double2 ldg2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 constexpr int TRD_UPD_MAXGRID = 1024;   // workgroups per launch: their v.wraw partials are summed by every wavefront, 16 per lane
 
 template <int R, int NT, bool FIRST>
@@ -323,6 +387,9 @@ __global__ __launch_bounds__(NT) void trd_upd_kernel(TrdUpdArgs a) {
     __shared__ double red[NW][R + 1];
     __shared__ double ush[R];
     __shared__ double bc[3];                                // u[o], w[o], v[o]
+    SELLA_ARG(a.A); SELLA_ARG(a.ld); SELLA_ARG(a.n); SELLA_ARG(a.j); SELLA_ARG(a.o); SELLA_ARG(a.m); SELLA_ARG(a.oc);
+    SELLA_ARG(a.shift); SELLA_ARG(a.pad); SELLA_ARG(a.v_prev); SELLA_ARG(a.v_cur); SELLA_ARG(a.wraw_prev); SELLA_ARG(a.wraw_cur);
+    SELLA_ARG(a.partB_prev); SELLA_ARG(a.nblkB_prev); SELLA_ARG(a.partB_cur); SELLA_ARG(a.colscal_prev);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bw = a.pad / R;                               // first workgroup that owns a real row
     const int b = blockIdx.x;
@@ -2342,7 +2409,14 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
                 prof_end(c);
             } else {
                 prof_begin(c, PROF_TRD_GEMV, 8.0 * m * (double)m, 2.0 * m * (double)m);
-                SELLA_LAUNCH(c, trd_gemv_kernel, dim3(nblkB), dim3(256), 0, ga);
+                const int n2g = (m + ga.shift + 1) >> 1;                // 16-byte pieces per row (as in the kernel)
+                const int nch = c->opt.eigh_gemv_flat ? (n2g + 255) / 256 : 1 << 30;
+                if (nch <= 2) SELLA_LAUNCH(c, trd_gemv_kernel<2>, dim3(nblkB), dim3(256), 0, ga);
+                else if (nch <= 4) SELLA_LAUNCH(c, trd_gemv_kernel<4>, dim3(nblkB), dim3(256), 0, ga);
+                else if (nch <= 6) SELLA_LAUNCH(c, trd_gemv_kernel<6>, dim3(nblkB), dim3(256), 0, ga);
+                else if (nch <= 8) SELLA_LAUNCH(c, trd_gemv_kernel<8>, dim3(nblkB), dim3(256), 0, ga);
+                else if (nch <= 10) SELLA_LAUNCH(c, trd_gemv_kernel<10>, dim3(nblkB), dim3(256), 0, ga);
+                else SELLA_LAUNCH(c, trd_gemv_kernel<0>, dim3(nblkB), dim3(256), 0, ga);
                 prof_end(c);
             }
             c->prof = prof_all;

@@ -17,6 +17,22 @@
 #define SELLA_HD __host__ __device__
 #include "small_linalg.h"
 
+// "this value is in a register from here on": an empty statement the compiler cannot look through.  Placed behind a batch
+// of loads it keeps them unconditional and in flight together — otherwise a load whose only use sits behind a condition is
+// sunk behind that condition (and the wait for it with everything issued before it).
+// SELLA_ARG(x): the same for a kernel argument (uniform): all arguments named at the top of a kernel are fetched by one
+// batch of scalar loads instead of one dependent fetch per branch that first needs them.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SELLA_NO_ARG_BATCH)
+#define SELLA_PIN(x) asm volatile("" : "+v"(x))
+#define SELLA_ARG(x) asm volatile("" : : "s"(x))
+#elif defined(__HIP_DEVICE_COMPILE__)
+#define SELLA_PIN(x) asm volatile("" : "+v"(x))
+#define SELLA_ARG(x) ((void)0)
+#else
+#define SELLA_PIN(x) ((void)0)
+#define SELLA_ARG(x) ((void)0)
+#endif
+
 namespace sella {
 
 // ---- wave64 sum, every lane gets the result -------------------------------------------------------
@@ -107,6 +123,7 @@ struct Options {
     long eigh_wy_rows = 16;  // rows of X per workgroup of the MFMA back-transformation (16, or 32: two row tiles)
     long eigh_wy_waves = 4;  // wavefronts per workgroup of the MFMA back-transformation (4, 8 or 16: measured equal at n = 3072 and 12288 — the kernel is bound by L2 bandwidth, 22.7 GB in 3.16 ms, not by latency)
     long lr_cholqr = 1;      // 1: block of update vectors orthonormalised by Cholesky-QR twice (eigh.hip, lr_lowrank_update)
+    long eigh_gemv_flat = 1; // 1: trailing matvec of the tridiagonalisation with every load issued before the first wait (eigh.hip)
     long rank2k_pair = 1;    // 1: panel depth 16 by pairs of 64 x 64 tiles sharing one MFMA product (update.hip)
     long rank2k_fixed = 1;   // 1: trailing update with all loads issued up front for the panel depths 16 / 32 (update.hip)
     long rs_fast = 1;        // 1: sella_opt_step searches the restricted step by interpolating batches (stepper.hip)

@@ -244,54 +244,24 @@ __global__ __launch_bounds__(256) void rank2k_stream_fixed_kernel(double* __rest
 // two workgroups per CU), i.e. the MFMA work and the launch's tail are what the pairing removes, not L2 traffic.
 constexpr int RP_T = 64, RP_YS = 80, RP_DS = 65;
 
-template <int KK>
-__global__ __launch_bounds__(256) void rank2k_stream_pair_kernel(double* __restrict__ C, int m, int ld,
-                                                                 const double* __restrict__ Up,
-                                                                 const double* __restrict__ Zp, int ldp, double alpha,
-                                                                 int upper_only, int nT) {
-    static_assert(2 * KK * RP_YS <= RP_T * RP_DS, "the column operand must fit the fragment array");
-    __shared__ double lds[RP_T * RP_DS];
+template <int KK, bool SECOND>
+__device__ __forceinline__ void rank2k_pair_body(double* __restrict__ C, int m, int ld, const double* __restrict__ Up,
+                                                 const double* __restrict__ Zp, int ldp, double alpha, int bi, int bj,
+                                                 double* __restrict__ lds) {
     constexpr int KS = 2 * KK / 4;
     constexpr int YL = 2 * KK * RP_T / 256;
-    // pair index -> (bi, bj), bi <= bj: row bi holds nT - bi pairs
-    int bi = 0, rem = blockIdx.x;
-    {
-        // closed form, then a correction step for rounding
-        const double b = 2.0 * nT + 1.0;
-        bi = (int)((b - sqrt(b * b - 8.0 * (double)rem)) * 0.5);
-        if (bi < 0) bi = 0;
-        while (bi > 0 && bi * nT - (bi * (bi - 1)) / 2 > rem) --bi;
-        while ((bi + 1) * nT - ((bi + 1) * bi) / 2 <= rem) ++bi;
-        rem -= bi * nT - (bi * (bi - 1)) / 2;
-    }
-    const int bj = bi + rem;
-    const bool diag = bi == bj;
-    const bool second = !diag && !upper_only;
+    constexpr bool second = SECOND;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int r0 = bi * RP_T, c0 = bj * RP_T;
-    // pieces of the two C tiles (row-major passes below): thread -> rows 8 q + pr, columns 2 pc, 2 pc + 1
-    const int pc = tid & 31, pr = tid >> 5;
-    double2 cv[RP_T / 8], cw[RP_T / 8];
-#pragma unroll
-    for (int q = 0; q < RP_T / 8; ++q) {
-        const int r = r0 + 8 * q + pr, cidx = c0 + 2 * pc;
-        cv[q] = double2{0.0, 0.0};
-        if (r < m && cidx + 1 < m) cv[q] = *reinterpret_cast<const double2*>(C + (size_t)r * ld + cidx);
-        else if (r < m && cidx < m) cv[q].x = C[(size_t)r * ld + cidx];
-    }
-#pragma unroll
-    for (int q = 0; q < RP_T / 8; ++q) {
-        const int r = c0 + 8 * q + pr, cidx = r0 + 2 * pc;                 // tile (bj, bi): rows of bj, columns of bi
-        cw[q] = double2{0.0, 0.0};
-        if (second && r < m) cw[q] = *reinterpret_cast<const double2*>(C + (size_t)r * ld + cidx);   // r0 + 63 < c0 <= r < m
-    }
+    // operands first: the counter of outstanding loads retires in order, so the MFMA phase can start on them while the
+    // pieces of C (needed only at the end) are still on their way
     double ys[YL];
 #pragma unroll
     for (int e = 0; e < YL; ++e) {
         const int idx = tid + 256 * e, k = idx >> 6, cc = c0 + (idx & 63);
         const double* yrow = (k < KK) ? Zp + (size_t)k * ldp : Up + (size_t)(k - KK) * ldp;
-        ys[e] = (cc < m) ? yrow[cc] : 0.0;
+        ys[e] = yrow[cc < m ? cc : m - 1];                                 // clamped, zeroed below: no load behind a branch
     }
     const int rr = (r0 + 16 * wave + li < m) ? r0 + 16 * wave + li : m - 1;
     double av[KS];
@@ -301,10 +271,31 @@ __global__ __launch_bounds__(256) void rank2k_stream_pair_kernel(double* __restr
         const double* xrow = (k < KK) ? Up + (size_t)k * ldp : Zp + (size_t)(k - KK) * ldp;
         av[s] = xrow[rr];
     }
+    // pieces of the two C tiles (row-major passes below): thread -> rows 8 q + pr, columns 2 pc, 2 pc + 1.  Always a 16-byte
+    // load from a clamped address (ld is even: the pair behind an even column of any row exists): a load behind a
+    // condition costs a full wait for everything issued before it.
+    const int pc = tid & 31, pr = tid >> 5;
+    double2 cv[RP_T / 8], cw[RP_T / 8];
+    {
+        const int cidx = (c0 + 2 * pc < m) ? c0 + 2 * pc : 0;
+#pragma unroll
+        for (int q = 0; q < RP_T / 8; ++q) {
+            const int r = (r0 + 8 * q + pr < m) ? r0 + 8 * q + pr : m - 1;
+            cv[q] = *reinterpret_cast<const double2*>(C + (size_t)r * ld + cidx);
+        }
+    }
+    if (second) {                                                           // uniform; last in program order
+        const int cidx = r0 + 2 * pc;                                       // tile (bj, bi): rows of bj, columns of bi; r0 + 63 < c0 < m
+#pragma unroll
+        for (int q = 0; q < RP_T / 8; ++q) {
+            const int r = (c0 + 8 * q + pr < m) ? c0 + 8 * q + pr : m - 1;
+            cw[q] = *reinterpret_cast<const double2*>(C + (size_t)r * ld + cidx);
+        }
+    }
 #pragma unroll
     for (int e = 0; e < YL; ++e) {
         const int idx = tid + 256 * e;
-        lds[(idx >> 6) * RP_YS + (idx & 63)] = ys[e];
+        lds[(idx >> 6) * RP_YS + (idx & 63)] = (c0 + (idx & 63) < m) ? ys[e] : 0.0;
     }
     __syncthreads();
     upd_f64x4 acc[RP_T / 16];
@@ -352,6 +343,31 @@ __global__ __launch_bounds__(256) void rank2k_stream_pair_kernel(double* __restr
             }
         }
     }
+}
+
+template <int KK>
+__global__ __launch_bounds__(256) void rank2k_stream_pair_kernel(double* __restrict__ C, int m, int ld,
+                                                                 const double* __restrict__ Up,
+                                                                 const double* __restrict__ Zp, int ldp, double alpha,
+                                                                 int upper_only, int nT) {
+    static_assert(2 * KK * RP_YS <= RP_T * RP_DS, "the column operand must fit the fragment array");
+    __shared__ double lds[RP_T * RP_DS];
+    // pair index -> (bi, bj), bi <= bj: row bi holds nT - bi pairs
+    int bi = 0, rem = blockIdx.x;
+    {
+        // closed form, then a correction step for rounding
+        const double b = 2.0 * nT + 1.0;
+        bi = (int)((b - sqrt(b * b - 8.0 * (double)rem)) * 0.5);
+        if (bi < 0) bi = 0;
+        while (bi > 0 && bi * nT - (bi * (bi - 1)) / 2 > rem) --bi;
+        while ((bi + 1) * nT - ((bi + 1) * bi) / 2 <= rem) ++bi;
+        rem -= bi * nT - (bi * (bi - 1)) / 2;
+    }
+    const int bj = bi + rem;
+    // two straight-line bodies instead of one with a uniform branch around the second tile's loads: behind a join the
+    // compiler no longer knows how many loads are outstanding and waits for more than the operands
+    if (bi != bj && !upper_only) rank2k_pair_body<KK, true>(C, m, ld, Up, Zp, ldp, alpha, bi, bj, lds);
+    else rank2k_pair_body<KK, false>(C, m, ld, Up, Zp, ldp, alpha, bi, bj, lds);
 }
 
 // lower triangle of the m x m block C <- transpose of its upper triangle (32 x 32 tiles through LDS)

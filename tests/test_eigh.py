@@ -246,3 +246,27 @@ def test_trailing_update_by_tile_pairs(ctx):
         ctx.set_option('eigh_tail_lds', 128)
         ctx.set_option('eigh_symv_min', 5120)
         ctx.set_option('rank2k_pair', 1)
+
+
+def test_trailing_matvec_all_loads_up_front(ctx):
+    """`trd_gemv_kernel<NCH>` (every load of the workgroup issued before the first wait, clamped and masked) against its
+    loop form: the same sums in the same order, bit for bit — rows shorter than one chunk, ragged last chunks, odd and
+    even offsets of the trailing block, panel rows appended."""
+    rng = np.random.RandomState(35)
+    try:
+        ctx.set_option('eigh_upd_max', 0)
+        ctx.set_option('eigh_tail_lds', 0)
+        for n in (5, 70, 290) if ctx.backend == "emu" else (5, 70, 530, 1100, 2070, 2600):
+            A = rng.normal(size=(n, n))
+            A = A + A.T
+            out = []
+            for flat in (0, 1):
+                ctx.set_option('eigh_gemv_flat', flat)
+                w, V, _ = ctx.eigh(ctx.upload(A))
+                out.append((np.array(w), V.numpy()))
+            np.testing.assert_array_equal(out[0][0], out[1][0])
+            np.testing.assert_array_equal(out[0][1], out[1][1])
+    finally:
+        ctx.set_option('eigh_upd_max', 1024)
+        ctx.set_option('eigh_tail_lds', 128)
+        ctx.set_option('eigh_gemv_flat', 1)

@@ -6,7 +6,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.abspath(os.environ['SELLA_AB_ROOT']) if os.environ.get('SELLA_AB_ROOT')      # tools/ab_build.sh
+                else os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sella_amd.device import Context  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3072

@@ -473,6 +473,7 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "eigh_wy_waves")) c->opt.eigh_wy_waves = value;
     else if (!strcmp(key, "lr_cholqr")) c->opt.lr_cholqr = value ? 1 : 0;
     else if (!strcmp(key, "rank2k_fixed")) c->opt.rank2k_fixed = value ? 1 : 0;
+    else if (!strcmp(key, "eigh_dc_pipeline")) c->opt.eigh_dc_pipeline = value ? 1 : 0;
     else if (!strcmp(key, "eigh_gemv_flat")) c->opt.eigh_gemv_flat = value ? 1 : 0;
     else if (!strcmp(key, "rank2k_pair")) c->opt.rank2k_pair = value ? 1 : 0;
     else if (!strcmp(key, "lr_dev")) c->opt.lr_dev = value ? 1 : 0;

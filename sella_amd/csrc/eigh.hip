@@ -75,6 +75,9 @@ struct TrdRowArgs {
 template <int IPC>
 __global__ __launch_bounds__(256) void trd_row_kernel(TrdRowArgs a) {
     __shared__ double red[4];
+    // all arguments in one batch of scalar loads (left to itself the compiler fetches them in four dependent stages, each
+    // behind the branch that first needs it: -0.5 us per launch, 1.1 ms per eigh at 3N = 3072, session r05p; the same in
+    // the matvec and in trd_upd_kernel measured equal / 0.2 us SLOWER per launch — their first loads start later)
     SELLA_ARG(a.A); SELLA_ARG(a.ld); SELLA_ARG(a.n); SELLA_ARG(a.j); SELLA_ARG(a.i); SELLA_ARG(a.do_row); SELLA_ARG(a.Vp);
     SELLA_ARG(a.Wp); SELLA_ARG(a.ldp); SELLA_ARG(a.u_cur); SELLA_ARG(a.wraw); SELLA_ARG(a.partA_cur); SELLA_ARG(a.partB);
     SELLA_ARG(a.nblkB); SELLA_ARG(a.colscal); SELLA_ARG(a.cdots); SELLA_ARG(a.dvec);
@@ -219,9 +222,6 @@ struct TrdGemvArgs {
 template <int NCH>
 __global__ __launch_bounds__(256) void trd_gemv_kernel(TrdGemvArgs a) {
     __shared__ double red[4][2];
-    SELLA_ARG(a.A22); SELLA_ARG(a.ld); SELLA_ARG(a.m); SELLA_ARG(a.shift); SELLA_ARG(a.o); SELLA_ARG(a.n); SELLA_ARG(a.j);
-    SELLA_ARG(a.pad); SELLA_ARG(a.ubuf); SELLA_ARG(a.partA); SELLA_ARG(a.nblkA); SELLA_ARG(a.wraw); SELLA_ARG(a.partB);
-    SELLA_ARG(a.Vrow); SELLA_ARG(a.Arow); SELLA_ARG(a.Wp); SELLA_ARG(a.Vp); SELLA_ARG(a.ldp); SELLA_ARG(a.i); SELLA_ARG(a.cdots);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = blockIdx.x * 2 - a.pad;              // local row of this workgroup's first row (may be < 0)
     const int mtot = a.m + 2 * a.i;
@@ -387,9 +387,6 @@ __global__ __launch_bounds__(NT) void trd_upd_kernel(TrdUpdArgs a) {
     __shared__ double red[NW][R + 1];
     __shared__ double ush[R];
     __shared__ double bc[3];                                // u[o], w[o], v[o]
-    SELLA_ARG(a.A); SELLA_ARG(a.ld); SELLA_ARG(a.n); SELLA_ARG(a.j); SELLA_ARG(a.o); SELLA_ARG(a.m); SELLA_ARG(a.oc);
-    SELLA_ARG(a.shift); SELLA_ARG(a.pad); SELLA_ARG(a.v_prev); SELLA_ARG(a.v_cur); SELLA_ARG(a.wraw_prev); SELLA_ARG(a.wraw_cur);
-    SELLA_ARG(a.partB_prev); SELLA_ARG(a.nblkB_prev); SELLA_ARG(a.partB_cur); SELLA_ARG(a.colscal_prev);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bw = a.pad / R;                               // first workgroup that owns a real row
     const int b = blockIdx.x;
@@ -2014,7 +2011,7 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
     const size_t nmmax = (size_t)n / 2 + 8;
     const size_t stage_doubles = 4 * (size_t)ld + 2 * (size_t)n + 8;
     const size_t stage_ints = 5 * (size_t)n + 4 * nmmax + 16;
-    SCHK(host_stage(c, stage_doubles * sizeof(double) + stage_ints * sizeof(int) + nmmax * sizeof(MergeDev), &stage));
+    SCHK(host_stage(c, stage_doubles * sizeof(double) + stage_ints * sizeof(int) + 2 * nmmax * sizeof(MergeDev), &stage));
     {
         double* hde = static_cast<double*>(stage);
         std::copy(d.begin(), d.end(), hde);
@@ -2084,16 +2081,25 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
     int* hidx = hr1 + 2 * (size_t)n;
     int* hmrow = hr1 + 3 * (size_t)n;                          // mirrors mrowd | gdescd (device: + n for orgd in between)
     int* hgd = hmrow + n;
-    MergeDev* hmd = reinterpret_cast<MergeDev*>(hgd + 4 * nmmax + 8 - ((4 * nmmax + 8) & 1));
+    MergeDev* hmd2[2];                                         // per-merge parameters, double-buffered by level parity
+    hmd2[0] = reinterpret_cast<MergeDev*>(hgd + 4 * nmmax + 8 - ((4 * nmmax + 8) & 1));
+    hmd2[1] = hmd2[0] + nmmax;
     std::vector<int> order;
     // Eigenvector rows of a node are supported on its own column range only, so everything outside the
     // diagonal blocks must read as zero.  One clearing of the second buffer suffices: level h overwrites
     // its diagonal blocks completely (K updated + N-K deflated rows of N columns each), and the blocks
     // this buffer held two levels earlier lie inside them.
     HIPCHK(hipMemsetAsync(nxt, 0, (size_t)n * ld * sizeof(double), c->stream));
-    for (int h = 1; h <= maxdepth; ++h) {
+    // (1) of a level — the rank-one vectors of all its merges: one launch and one download, queued (not waited for) by
+    // the level BEFORE it, right behind that level's last kernel: the vectors are rows of the eigenvector blocks just
+    // written, nothing the host has to decide first.  So a level costs ONE synchronisation, which hands over the previous
+    // level's eigenvalues and this level's vectors together (it was two, with the launch of this small kernel and its
+    // download exposed in between: about 50 us per level, eight levels at 3N = 3072).
+    const bool pipelined = c->opt.eigh_dc_pipeline != 0;
+    const bool dc_timing = getenv("SELLA_DC_TIMING") != nullptr;
+    auto queue_level_vectors = [&](int h, const double* rows) -> int {
         const std::vector<int>& lvl = by_height[h];
-        // ---- (1) rank-one vectors of all merges of this level: one launch, one synchronisation -------
+        MergeDev* hmd = hmd2[h & 1];
         const int nm = (int)lvl.size();
         int maxN = 0;
         for (int mi = 0; mi < nm; ++mi) {
@@ -2103,15 +2109,54 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
             m.n1 = nd.mid - nd.lo; m.mid = nd.mid;
             m.rho = 0.0; m.sgn = e[nd.mid - 1] < 0 ? -1.0 : 1.0;
             maxN = std::max(maxN, m.N);
-            for (int p = nd.lo; p < nd.hi; ++p) hmrow[p] = mi;
         }
         HIPCHK(hipMemcpyAsync(mdd, hmd, (size_t)nm * sizeof(MergeDev), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(gather_z_batched_kernel, dim3((maxN + 255) / 256, nm), dim3(256), 0, c->stream, mdd, cur, ld, zdev);
+        hipLaunchKernelGGL(gather_z_batched_kernel, dim3((maxN + 255) / 256, nm), dim3(256), 0, c->stream, mdd, rows, ld, zdev);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(z, zdev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        return SELLA_OK;
+    };
+    std::vector<MergePlan> plans, plans_prev;
+    // eigenvalues of a finished level into `vals` (new roots, then the deflated values), after its download has arrived
+    auto take_level_values = [&](const std::vector<MergePlan>& done) -> int {
+        if (hi2[1] != 0) {
+            if (getenv("SELLA_DEBUG")) {
+                for (const MergePlan& pl : done) {
+                    if (hi2[1] - 1 >= pl.K) continue;
+                    fprintf(stderr, "secular fail? merge lo=%d N=%d K=%d rho=%.17g root=%d\n", pl.lo, pl.N, pl.K, pl.rho, hi2[1] - 1);
+                }
+            }
+            set_error("eigh: secular equation solver hit its iteration cap (root %d)", hi2[1] - 1);
+            return SELLA_E_NOCONV;
+        }
+        std::vector<double> nv;
+        for (const MergePlan& pl : done) {
+            double* D = vals.data() + pl.lo;
+            nv.resize(pl.N);
+            for (int p = 0; p < pl.K; ++p) nv[p] = lam[pl.lo + p];
+            for (int p = 0; p < pl.N - pl.K; ++p) nv[pl.K + p] = D[pl.defl[p]];
+            for (int p = 0; p < pl.N; ++p) D[p] = nv[p];
+        }
+        return SELLA_OK;
+    };
+    if (pipelined && maxdepth >= 1) SCHK(queue_level_vectors(1, cur));
+    for (int h = 1; h <= maxdepth; ++h) {
+        const std::vector<int>& lvl = by_height[h];
+        MergeDev* hmd = hmd2[h & 1];
+        const int nm = (int)lvl.size();
+        int maxN = 0;
+        for (int mi = 0; mi < nm; ++mi) {
+            const Node& nd = nodes[lvl[mi]];
+            maxN = std::max(maxN, nd.hi - nd.lo);
+            for (int p = nd.lo; p < nd.hi; ++p) hmrow[p] = mi;
+        }
+        if (!pipelined) SCHK(queue_level_vectors(h, cur));
+        const auto tw0 = std::chrono::steady_clock::now();
         SCHK(stream_wait(c));
+        const auto tw1 = std::chrono::steady_clock::now();
+        if (pipelined && h > 1) SCHK(take_level_values(plans_prev));
         // ---- (2) deflation of every merge on the host (dlaed2 logic) ------------------------------
-        std::vector<MergePlan> plans(lvl.size());
+        plans.assign(lvl.size(), MergePlan());
         for (size_t mi = 0; mi < lvl.size(); ++mi) {
             const Node& nd = nodes[lvl[mi]];
             MergePlan& pl = plans[mi];
@@ -2137,6 +2182,7 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
                 hcs[2 * (size_t)(lo + r) + 1] = pl.cs[2 * r + 1];
             }
         }
+        const auto tw2 = std::chrono::steady_clock::now();
         // (c,s) pairs | D | w in one piece (device slots V_CS0, V_CS1, V_DD, V_WD are consecutive), rotation and
         // gather indices in another
         static_assert(V_CS1 == V_CS0 + 1 && V_DD == V_CS0 + 2 && V_WD == V_CS0 + 3, "slot order");
@@ -2175,28 +2221,24 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(lam, lamd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(hi2, info, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        SCHK(stream_wait(c));
-        if (hi2[1] != 0) {
-            if (getenv("SELLA_DEBUG")) {
-                for (size_t mi = 0; mi < lvl.size(); ++mi) {
-                    const MergePlan& pl = plans[mi];
-                    if (hi2[1] - 1 >= pl.K) continue;
-                    fprintf(stderr, "secular fail? merge lo=%d N=%d K=%d rho=%.17g root=%d\n", pl.lo, pl.N, pl.K, pl.rho, hi2[1] - 1);
-                    for (int p = 0; p < pl.K; ++p) fprintf(stderr, "%.17g %.17g\n", hD[pl.lo + p], hw[pl.lo + p]);
-                }
-            }
-            set_error("eigh: secular equation solver hit its iteration cap (root %d)", hi2[1] - 1);
-            return SELLA_E_NOCONV;
-        }
-        for (size_t mi = 0; mi < lvl.size(); ++mi) {
-            const MergePlan& pl = plans[mi];
-            double* D = vals.data() + pl.lo;
-            std::vector<double> nv(pl.N);
-            for (int p = 0; p < pl.K; ++p) nv[p] = lam[pl.lo + p];
-            for (int p = 0; p < pl.N - pl.K; ++p) nv[pl.K + p] = D[pl.defl[p]];
-            for (int p = 0; p < pl.N; ++p) D[p] = nv[p];
-        }
         std::swap(cur, nxt);
+        if (dc_timing) {
+            const auto tw3 = std::chrono::steady_clock::now();
+            auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            fprintf(stderr, "dc level %d: wait %.1f us, values + plan + staging %.1f us, uploads + launches %.1f us\n", h, us(tw0, tw1),
+                    us(tw1, tw2), us(tw2, tw3));
+        }
+        if (pipelined) {
+            plans_prev.swap(plans);
+            if (h < maxdepth) SCHK(queue_level_vectors(h + 1, cur));
+        } else {
+            SCHK(stream_wait(c));
+            SCHK(take_level_values(plans));
+        }
+    }
+    if (pipelined && maxdepth >= 1) {
+        SCHK(stream_wait(c));
+        SCHK(take_level_values(plans_prev));
     }
     // final ascending order
     order.resize(n);

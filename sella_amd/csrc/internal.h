@@ -123,6 +123,7 @@ struct Options {
     long eigh_wy_rows = 16;  // rows of X per workgroup of the MFMA back-transformation (16, or 32: two row tiles)
     long eigh_wy_waves = 4;  // wavefronts per workgroup of the MFMA back-transformation (4, 8 or 16: measured equal at n = 3072 and 12288 — the kernel is bound by L2 bandwidth, 22.7 GB in 3.16 ms, not by latency)
     long lr_cholqr = 1;      // 1: block of update vectors orthonormalised by Cholesky-QR twice (eigh.hip, lr_lowrank_update)
+    long eigh_dc_pipeline = 1; // 1: divide & conquer queues the next level's rank-one vectors behind the current level (one wait per level)
     long eigh_gemv_flat = 1; // 1: trailing matvec of the tridiagonalisation with every load issued before the first wait (eigh.hip)
     long rank2k_pair = 1;    // 1: panel depth 16 by pairs of 64 x 64 tiles sharing one MFMA product (update.hip)
     long rank2k_fixed = 1;   // 1: trailing update with all loads issued up front for the panel depths 16 / 32 (update.hip)

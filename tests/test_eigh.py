@@ -270,3 +270,26 @@ def test_trailing_matvec_all_loads_up_front(ctx):
         ctx.set_option('eigh_upd_max', 1024)
         ctx.set_option('eigh_tail_lds', 128)
         ctx.set_option('eigh_gemv_flat', 1)
+
+
+def test_divide_and_conquer_one_wait_per_level(ctx):
+    """Divide & conquer with the next level's rank-one vectors queued behind the current level (one host wait per level
+    instead of two) is a change of schedule only: eigenvalues and eigenvectors bit for bit those of the two-wait loop,
+    for trees of depth 0, 1 and more, and for the spectra that deflate heavily."""
+    rng = np.random.RandomState(37)
+    try:
+        for n in (3, 20, 33, 70, 150):
+            mats = list(cases(n, rng)) if n == 70 else [('random', None)]
+            for name, A in mats:
+                if A is None:
+                    A = rng.normal(size=(n, n))
+                    A = A + A.T
+                out = []
+                for pipe in (0, 1):
+                    ctx.set_option('eigh_dc_pipeline', pipe)
+                    w, V, _ = ctx.eigh(ctx.upload(A))
+                    out.append((np.array(w), V.numpy()))
+                np.testing.assert_array_equal(out[0][0], out[1][0], err_msg=name)
+                np.testing.assert_array_equal(out[0][1], out[1][1], err_msg=name)
+    finally:
+        ctx.set_option('eigh_dc_pipeline', 1)

@@ -70,8 +70,7 @@ int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
  *   Jacobi kernel) instead of the host | lr_dev (1) sella_opt_step updates structured eigendecompositions in
  *   coordinates with every decision on the device (0: the host-planned rank-one merges of sella_update_h_lr) |
  *   eigh_wy_waves (4), eigh_wy_rows (16) wavefronts / rows of X per workgroup of the back-transformation (8, 16 / 32
- *   measured equal or slower) | rank2k_fixed (1) trailing update with all loads up front, rank2k_pair (1) by pairs of
- *   64 x 64 tiles that share one MFMA product (0: every 32 x 128 tile on its own) | lr_cholqr (1) block of update
+ *   measured equal or slower) | rank2k_fixed (1) trailing update with all loads up front | lr_cholqr (1) block of update
  *   vectors by rank-revealing Cholesky-QR |
  *   rs_fast (1) sella_opt_step finds the restricted step by interpolating batches of 15 trial alphas instead of the
  *   reference's Newton / bisection schedule (same root) |

@@ -2145,15 +2145,17 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
         MergeDev* hmd = hmd2[h & 1];
         const int nm = (int)lvl.size();
         int maxN = 0;
-        for (int mi = 0; mi < nm; ++mi) {
-            const Node& nd = nodes[lvl[mi]];
-            maxN = std::max(maxN, nd.hi - nd.lo);
-            for (int p = nd.lo; p < nd.hi; ++p) hmrow[p] = mi;
-        }
+        for (int mi = 0; mi < nm; ++mi) maxN = std::max(maxN, nodes[lvl[mi]].hi - nodes[lvl[mi]].lo);
         if (!pipelined) SCHK(queue_level_vectors(h, cur));
         const auto tw0 = std::chrono::steady_clock::now();
         SCHK(stream_wait(c));
         const auto tw1 = std::chrono::steady_clock::now();
+        // (only now: the staging arrays below are the sources of the previous level's uploads, which have been executed
+        // for certain only behind this wait)
+        for (int mi = 0; mi < nm; ++mi) {
+            const Node& nd = nodes[lvl[mi]];
+            for (int p = nd.lo; p < nd.hi; ++p) hmrow[p] = mi;
+        }
         if (pipelined && h > 1) SCHK(take_level_values(plans_prev));
         // ---- (2) deflation of every merge on the host (dlaed2 logic) ------------------------------
         plans.assign(lvl.size(), MergePlan());

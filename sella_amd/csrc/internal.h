@@ -125,7 +125,6 @@ struct Options {
     long lr_cholqr = 1;      // 1: block of update vectors orthonormalised by Cholesky-QR twice (eigh.hip, lr_lowrank_update)
     long eigh_dc_pipeline = 1; // 1: divide & conquer queues the next level's rank-one vectors behind the current level (one wait per level)
     long eigh_gemv_flat = 1; // 1: trailing matvec of the tridiagonalisation with every load issued before the first wait (eigh.hip)
-    long rank2k_pair = 1;    // 1: panel depth 16 by pairs of 64 x 64 tiles sharing one MFMA product (update.hip)
     long rank2k_fixed = 1;   // 1: trailing update with all loads issued up front for the panel depths 16 / 32 (update.hip)
     long rs_fast = 1;        // 1: sella_opt_step searches the restricted step by interpolating batches (stepper.hip)
     long lr_dev = 1;         // 1: sella_opt_step updates structured decompositions in coordinates, all decisions on the device (lrstep.hip)

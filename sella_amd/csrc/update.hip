@@ -160,7 +160,13 @@ __global__ __launch_bounds__(256) void rank2k_stream_kernel(double* __restrict__
 // issued before the first MFMA — the C pieces each thread will update (they do not depend on the panels) and all
 // 2 KK / 4 operand fragments — instead of 2 KK / 4 dependent rounds of "five loads from L2, four MFMAs".  PMC of round 3
 // had shown the generic kernel at 2.2–2.8 TB/s where a plain in-place stream runs at 6.5: latency of the operand loads,
-// not bandwidth (profiles/r03_pmc.md, r03_rmw_lab.log).
+// not bandwidth (profiles/r03_pmc.md, r03_rmw_lab.log).  Round 5: the loads are straight-line code (clamped addresses,
+// masked afterwards) with the operands in front — 21.6 -> 17.3 us per launch at 3N = 3072, the largest block (151 MB)
+// 38.2 -> 29.9 us = 5.0 TB/s, bit-identical results.  Two other layouts were measured and dropped (sessions r05k, r05l,
+// r05u): 64 x 128 tiles with the column operand staged in LDS (0.375 operand bytes per matrix byte instead of 1.25:
+// SLOWER, 25.1 us — two workgroups per CU), and pairs of 64 x 64 tiles sharing one MFMA product, the lower tile taking
+// it transposed (half the MFMA work: 16.2-16.8 us, but the two triangles then differ from this kernel's by rounding,
+// which moves the Davidson trajectories for 0.05 ms per eigh).
 template <int KK>
 __global__ __launch_bounds__(256) void rank2k_stream_fixed_kernel(double* __restrict__ C, int m, int ld,
                                                                   const double* __restrict__ Up,
@@ -176,17 +182,10 @@ __global__ __launch_bounds__(256) void rank2k_stream_fixed_kernel(double* __rest
     const int r0 = blockIdx.y * RS_TR, c0 = blockIdx.x * RS_TC;
     const int wr = r0 + 16 * (wave & 1);
     const int wc = c0 + 64 * (wave >> 1);
-    // this thread's pieces of the C tile (row-major pass below): in flight first
-    const int pc = tid & 63, pr = tid >> 6;
-    const int cidx = c0 + 2 * pc;
-    double2 cv[RS_TR / 4];
-#pragma unroll
-    for (int q = 0; q < RS_TR / 4; ++q) {
-        const int r = r0 + 4 * q + pr;
-        cv[q] = double2{0.0, 0.0};
-        if (r < m && cidx + 1 < m) cv[q] = *reinterpret_cast<const double2*>(C + (size_t)r * ld + cidx);
-        else if (r < m && cidx < m) cv[q].x = C[(size_t)r * ld + cidx];
-    }
+    // operands first, then this thread's pieces of the C tile (row-major pass below): the counter of outstanding loads
+    // retires in order, so the MFMA phase starts on the operands while the pieces of C (needed only at the end) are
+    // still on their way.  Every load is unconditional, from a clamped address (ld is even: the pair behind an even
+    // column of any row exists) — a load behind a condition costs a full wait for everything issued before it.
     const int rr = (wr + li < m) ? wr + li : m - 1;
     double av[KS], bv[KS][4];
 #pragma unroll
@@ -198,9 +197,24 @@ __global__ __launch_bounds__(256) void rank2k_stream_fixed_kernel(double* __rest
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int cc = wc + 16 * t + li;
-            bv[s][t] = (cc < m) ? yrow[cc] : 0.0;
+            bv[s][t] = yrow[cc < m ? cc : m - 1];
         }
     }
+    const int pc = tid & 63, pr = tid >> 6;
+    const int cidx = c0 + 2 * pc;
+    double2 cv[RS_TR / 4];
+    {
+        const int cl = (cidx < m) ? cidx : 0;
+#pragma unroll
+        for (int q = 0; q < RS_TR / 4; ++q) {
+            const int r = (r0 + 4 * q + pr < m) ? r0 + 4 * q + pr : m - 1;
+            cv[q] = *reinterpret_cast<const double2*>(C + (size_t)r * ld + cl);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[s][t] = (wc + 16 * t + li < m) ? bv[s][t] : 0.0;
     upd_f64x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = upd_f64x4{0.0, 0.0, 0.0, 0.0};
@@ -229,145 +243,6 @@ __global__ __launch_bounds__(256) void rank2k_stream_fixed_kernel(double* __rest
             }
         }
     }
-}
-
-// The update by PAIRS of 64 x 64 tiles (round 5): the correction of tile (bj, bi) is the transpose of that of (bi, bj), so a
-// workgroup forms D = X_bi Y_bj^T once (K = 2 KK), leaves it in LDS and updates both tiles from there — the second one
-// reading LDS transposed.  Half the MFMA work and half the operand fetches of a kernel that treats the two tiles
-// separately, the same matrix traffic; off-diagonal tile pairs come out EXACTLY symmetric (the kernels above leave them
-// symmetric to rounding).  A wavefront owns 16 rows and all 64 columns of D: the row operand comes straight from memory
-// (nobody else needs it), the column operand once per workgroup through LDS (32 x 64 entries, row stride 80 doubles: the
-// four k rows a wavefront reads at once fall on disjoint bank halves); the same array then takes the MFMA fragments.
-// Grid: the nT (nT + 1) / 2 pairs bi <= bj, enumerated row by row.  Measured at 3N = 3072 (session r05l): 17.3 us per
-// launch against 21.6 for the 32 x 128 kernel (33.2 against 38.2 for the largest block, 151 MB); a 64 x 128 single-tile
-// kernel with the same LDS staging — fewer operand bytes, the same MFMA work — was SLOWER than the 32 x 128 one (25.1 us:
-// two workgroups per CU), i.e. the MFMA work and the launch's tail are what the pairing removes, not L2 traffic.
-constexpr int RP_T = 64, RP_YS = 80, RP_DS = 65;
-
-template <int KK, bool SECOND>
-__device__ __forceinline__ void rank2k_pair_body(double* __restrict__ C, int m, int ld, const double* __restrict__ Up,
-                                                 const double* __restrict__ Zp, int ldp, double alpha, int bi, int bj,
-                                                 double* __restrict__ lds) {
-    constexpr int KS = 2 * KK / 4;
-    constexpr int YL = 2 * KK * RP_T / 256;
-    constexpr bool second = SECOND;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lq = lane >> 4;
-    const int r0 = bi * RP_T, c0 = bj * RP_T;
-    // operands first: the counter of outstanding loads retires in order, so the MFMA phase can start on them while the
-    // pieces of C (needed only at the end) are still on their way
-    double ys[YL];
-#pragma unroll
-    for (int e = 0; e < YL; ++e) {
-        const int idx = tid + 256 * e, k = idx >> 6, cc = c0 + (idx & 63);
-        const double* yrow = (k < KK) ? Zp + (size_t)k * ldp : Up + (size_t)(k - KK) * ldp;
-        ys[e] = yrow[cc < m ? cc : m - 1];                                 // clamped, zeroed below: no load behind a branch
-    }
-    const int rr = (r0 + 16 * wave + li < m) ? r0 + 16 * wave + li : m - 1;
-    double av[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int k = 4 * s + lq;
-        const double* xrow = (k < KK) ? Up + (size_t)k * ldp : Zp + (size_t)(k - KK) * ldp;
-        av[s] = xrow[rr];
-    }
-    // pieces of the two C tiles (row-major passes below): thread -> rows 8 q + pr, columns 2 pc, 2 pc + 1.  Always a 16-byte
-    // load from a clamped address (ld is even: the pair behind an even column of any row exists): a load behind a
-    // condition costs a full wait for everything issued before it.
-    const int pc = tid & 31, pr = tid >> 5;
-    double2 cv[RP_T / 8], cw[RP_T / 8];
-    {
-        const int cidx = (c0 + 2 * pc < m) ? c0 + 2 * pc : 0;
-#pragma unroll
-        for (int q = 0; q < RP_T / 8; ++q) {
-            const int r = (r0 + 8 * q + pr < m) ? r0 + 8 * q + pr : m - 1;
-            cv[q] = *reinterpret_cast<const double2*>(C + (size_t)r * ld + cidx);
-        }
-    }
-    if (second) {                                                           // uniform; last in program order
-        const int cidx = r0 + 2 * pc;                                       // tile (bj, bi): rows of bj, columns of bi; r0 + 63 < c0 < m
-#pragma unroll
-        for (int q = 0; q < RP_T / 8; ++q) {
-            const int r = (c0 + 8 * q + pr < m) ? c0 + 8 * q + pr : m - 1;
-            cw[q] = *reinterpret_cast<const double2*>(C + (size_t)r * ld + cidx);
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < YL; ++e) {
-        const int idx = tid + 256 * e;
-        lds[(idx >> 6) * RP_YS + (idx & 63)] = (c0 + (idx & 63) < m) ? ys[e] : 0.0;
-    }
-    __syncthreads();
-    upd_f64x4 acc[RP_T / 16];
-#pragma unroll
-    for (int t = 0; t < RP_T / 16; ++t) acc[t] = upd_f64x4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        double bv[RP_T / 16];
-#pragma unroll
-        for (int t = 0; t < RP_T / 16; ++t) bv[t] = lds[(4 * s + lq) * RP_YS + 16 * t + li];
-#pragma unroll
-        for (int t = 0; t < RP_T / 16; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[t], acc[t], 0, 0, 0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < RP_T / 16; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) lds[(16 * wave + lq + 4 * q) * RP_DS + 16 * t + li] = acc[t][q];
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < RP_T / 8; ++q) {
-        const int rl = 8 * q + pr, r = r0 + rl, cidx = c0 + 2 * pc;
-        if (r < m && cidx < m) {
-            double* p = C + (size_t)r * ld + cidx;
-            const double d0 = lds[rl * RP_DS + 2 * pc], d1 = lds[rl * RP_DS + 2 * pc + 1];
-            if (cidx + 1 < m) {
-                double2 v = cv[q];
-                v.x += alpha * d0;
-                v.y += alpha * d1;
-                *reinterpret_cast<double2*>(p) = v;
-            } else {
-                p[0] = cv[q].x + alpha * d0;
-            }
-        }
-    }
-    if (second) {
-#pragma unroll
-        for (int q = 0; q < RP_T / 8; ++q) {
-            const int rl = 8 * q + pr, r = c0 + rl, cidx = r0 + 2 * pc;     // entry (r, cidx) of C takes D[cidx - r0][r - c0]
-            if (r < m) {
-                double2 v = cw[q];
-                v.x += alpha * lds[(2 * pc) * RP_DS + rl];
-                v.y += alpha * lds[(2 * pc + 1) * RP_DS + rl];
-                *reinterpret_cast<double2*>(C + (size_t)r * ld + cidx) = v;
-            }
-        }
-    }
-}
-
-template <int KK>
-__global__ __launch_bounds__(256) void rank2k_stream_pair_kernel(double* __restrict__ C, int m, int ld,
-                                                                 const double* __restrict__ Up,
-                                                                 const double* __restrict__ Zp, int ldp, double alpha,
-                                                                 int upper_only, int nT) {
-    static_assert(2 * KK * RP_YS <= RP_T * RP_DS, "the column operand must fit the fragment array");
-    __shared__ double lds[RP_T * RP_DS];
-    // pair index -> (bi, bj), bi <= bj: row bi holds nT - bi pairs
-    int bi = 0, rem = blockIdx.x;
-    {
-        // closed form, then a correction step for rounding
-        const double b = 2.0 * nT + 1.0;
-        bi = (int)((b - sqrt(b * b - 8.0 * (double)rem)) * 0.5);
-        if (bi < 0) bi = 0;
-        while (bi > 0 && bi * nT - (bi * (bi - 1)) / 2 > rem) --bi;
-        while ((bi + 1) * nT - ((bi + 1) * bi) / 2 <= rem) ++bi;
-        rem -= bi * nT - (bi * (bi - 1)) / 2;
-    }
-    const int bj = bi + rem;
-    // two straight-line bodies instead of one with a uniform branch around the second tile's loads: behind a join the
-    // compiler no longer knows how many loads are outstanding and waits for more than the operands
-    if (bi != bj && !upper_only) rank2k_pair_body<KK, true>(C, m, ld, Up, Zp, ldp, alpha, bi, bj, lds);
-    else rank2k_pair_body<KK, false>(C, m, ld, Up, Zp, ldp, alpha, bi, bj, lds);
 }
 
 // lower triangle of the m x m block C <- transpose of its upper triangle (32 x 32 tiles through LDS)
@@ -405,10 +280,7 @@ int launch_rank2k_stream(sella_ctx* c, double* C, int m, int ld, const double* U
     prof_begin(c, PROF_UPDATE, part * 16.0 * m * (double)m, part * 4.0 * kk * (double)m * m);
     const dim3 grid((m + RS_TC - 1) / RS_TC, (m + RS_TR - 1) / RS_TR);
     const int uo = upper_only ? 1 : 0;
-    if (kk == 16 && c->opt.rank2k_fixed && c->opt.rank2k_pair) {
-        const int nT = (m + RP_T - 1) / RP_T;
-        SELLA_LAUNCH(c, rank2k_stream_pair_kernel<16>, dim3(nT * (nT + 1) / 2), dim3(256), 0, C, m, ld, Up, Zp, ldp, alpha, uo, nT);
-    } else if (kk == 16 && c->opt.rank2k_fixed)
+    if (kk == 16 && c->opt.rank2k_fixed)
         SELLA_LAUNCH(c, rank2k_stream_fixed_kernel<16>, grid, dim3(256), 0, C, m, ld, Up, Zp, ldp, alpha, uo);
     else if (kk == 32 && c->opt.rank2k_fixed)
         SELLA_LAUNCH(c, rank2k_stream_fixed_kernel<32>, grid, dim3(256), 0, C, m, ld, Up, Zp, ldp, alpha, uo);

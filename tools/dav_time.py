@@ -3,7 +3,9 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.abspath(os.environ['SELLA_AB_ROOT']) if os.environ.get('SELLA_AB_ROOT')      # tools/ab_build.sh
+                else os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(1, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import hessian_like  # noqa: E402
 from sella_amd.device import Context  # noqa: E402
 

@@ -26,12 +26,14 @@ S = sys.argv[1]
 p = 'profiles/pmc_traffic.json'
 d = json.load(open(p))
 txt = open(S + '/pmc_eigh_FETCH_SIZE.txt').read() + open(S + '/pmc_eigh_WRITE_SIZE.txt').read()
-vals = {k: float(v) for k, _, v in re.findall(r'(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*(\d+) mean=([0-9.e+]+)', txt)}
+# the matvec is a family of template instances (trd_gemv_kernel<NCH>): dispatch-weighted mean over all of them
+rows = re.findall(r'(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*(\d+) mean=([0-9.e+]+)', txt)
+vals = {k: sum(int(d) * float(v) for kk, d, v in rows if kk == k) / sum(int(d) for kk, d, v in rows if kk == k) for k in ('FETCH_SIZE', 'WRITE_SIZE')}
 t = d['trd_gemv_kernel']
 t['FETCH_SIZE_kb_mean_raw'], t['WRITE_SIZE_kb_mean_raw'] = vals['FETCH_SIZE'], vals['WRITE_SIZE']
 t['bytes_per_launch'] = (2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024
 t['source'] = re.sub(r'session r0\d\w?', 'session ' + S.split('/')[-1], t['source'])
-nd = int(re.search(r'FETCH_SIZE\s+dispatches=\s*(\d+)', txt).group(1))
+nd = sum(int(d) for kk, d, v in rows if kk == 'FETCH_SIZE')
 t['dispatches'] = nd          # blocked chain only: trailing blocks of n-1 .. n-nd rows
 t['algorithmic_bytes_per_launch'] = round(sum(8 * m * m + 16 * m for m in range(t['n'] - nd, t['n'])) / nd)
 json.dump(d, open(p, 'w'), indent=1)

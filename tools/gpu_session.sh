@@ -106,7 +106,9 @@ say "== tridiagonalisation by trailing size: blocked chain (row kernel + matvec)
 db=$(find /tmp/trm -name "*.db" | head -1)
 { python tools/trd_by_m.py $db 256 3072; python tools/col_by_m.py $db 3072; python tools/eigh_tail_timeline.py $db | tail -1; } > $OUT/eigh_by_m.txt 2>&1; cat $OUT/eigh_by_m.txt | tee -a $OUT/session.log
 { for MX in 0 512 1024 1536 2048; do echo -n "eigh_upd_max $MX: "; EIGH_OPTS=eigh_upd_max=$MX timeout 300 python tools/eigh_only.py 3072 4 2>&1 | tail -1; done;
-  echo -n "eigh_wy_overlap 0: "; EIGH_OPTS=eigh_wy_overlap=0 timeout 300 python tools/eigh_only.py 3072 4 2>&1 | tail -1; } > $OUT/eigh_switch.log 2>&1; cat $OUT/eigh_switch.log | tee -a $OUT/session.log
+  echo -n "eigh_wy_overlap 0: "; EIGH_OPTS=eigh_wy_overlap=0 timeout 300 python tools/eigh_only.py 3072 4 2>&1 | tail -1;
+  for O in eigh_gemv_flat=0 rank2k_fixed=0 eigh_dc_pipeline=0 eigh_gemv_flat=1; do echo -n "$O: "; EIGH_OPTS=$O timeout 300 python tools/eigh_only.py 3072 4 2>&1 | tail -1; done;
+  echo "divide & conquer, host side per level (SELLA_DC_TIMING):"; SELLA_DC_TIMING=1 timeout 300 python tools/eigh_only.py 3072 2 2>&1 | grep "dc level" | tail -8; } > $OUT/eigh_switch.log 2>&1; cat $OUT/eigh_switch.log | tee -a $OUT/session.log
 say "== Davidson iteration, launch by launch"
 (cd /tmp && rm -rf /tmp/dt && timeout 300 rocprofv3 --kernel-trace -d /tmp/dt -o dt -- python $R/tools/dav_timeline.py > /dev/null 2>&1)
 python tools/dav_timeline_parse.py /tmp/dt > $OUT/dav_iter_timeline.txt 2>&1; cat $OUT/dav_iter_timeline.txt | tee -a $OUT/session.log

@@ -14,8 +14,9 @@ def main(db_path, width=256, n_given=0):
     seq, ncol = [], 0
     for name, _, dur in rows:
         kind = next((v for k, v in kinds.items() if k + '(' in name or k + '<' in name), None)
-        if 'tridiag_tail_kernel' in name:
-            break
+        if 'tridiag_tail_kernel' in name or 'trd_tail_lds_kernel' in name:
+            break                                     # end of the first factorisation (the blocked chain may hand over earlier:
+                                                      # trd_upd_kernel launches, tools/col_by_m.py, carry no matvec of their own)
         if kind is None:
             continue
         if kind in ('gemv', 'symv'):

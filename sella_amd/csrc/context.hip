@@ -156,6 +156,32 @@ int scratch_get(sella_ctx* c, int slot, size_t bytes, double** p) {
 // stream synchronisation, so a slot is never overwritten while a copy that reads it is still queued.
 static constexpr size_t H2D_RING_BYTES = (size_t)8 << 20;
 
+// From 16 KB on the runtime's host-to-device copy leaves its fast path: 2.8 us per copy up to 2048 doubles, 15.2 us at
+// 3072 (24 KB: every n-vector of the 1024-atom configurations), 11.8 us for the 120 KB staging block of an optimizer step
+// (tools/lab/h2d_lab.hip, profiles/r05_h2d_lab.log) — where a kernel that reads the pinned slot directly (the ring is
+// device-visible host memory) takes 3.5 - 5.2 us.  Payloads of at least `h2d_kernel_min` bytes go that way.
+__global__ __launch_bounds__(256) void h2d_copy_kernel(double2* __restrict__ dst, const double2* __restrict__ src, size_t n2,
+                                                       double* __restrict__ dst_tail, const double* __restrict__ src_tail) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n2) dst[i] = src[i];
+    if (i == 0 && dst_tail) *dst_tail = *src_tail;
+}
+
+static int h2d_queue(sella_ctx* c, void* dst, const void* slot, size_t bytes) {
+    const long kmin = c->opt.h2d_kernel_min;
+    if (kmin > 0 && bytes >= (size_t)kmin && (bytes & 7) == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(slot)) & 15) == 0) {
+        const size_t n2 = bytes / 16;
+        const bool tail = (bytes & 15) != 0;
+        hipLaunchKernelGGL(h2d_copy_kernel, dim3((unsigned)((n2 + 255) / 256 + (n2 == 0))), dim3(256), 0, c->stream,
+                           static_cast<double2*>(dst), static_cast<const double2*>(slot), n2,
+                           tail ? static_cast<double*>(dst) + 2 * n2 : nullptr, tail ? static_cast<const double*>(slot) + 2 * n2 : nullptr);
+        HIPCHK(hipGetLastError());
+        return SELLA_OK;
+    }
+    HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+    return SELLA_OK;
+}
+
 int h2d_async(sella_ctx* c, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return SELLA_OK;
     if (!c->hring) {
@@ -173,7 +199,7 @@ int h2d_async(sella_ctx* c, void* dst, const void* src, size_t bytes) {
     if (c->hring_pos + need > c->hring_bytes) SCHK(stream_wait(c));           // rewinds the ring
     char* slot = c->hring + c->hring_pos;
     memcpy(slot, src, bytes);
-    HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+    SCHK(h2d_queue(c, dst, slot, bytes));
     c->hring_pos += need;
     return SELLA_OK;
 }
@@ -198,9 +224,12 @@ int h2d_begin(sella_ctx* c, size_t bytes, void** slot) {
     return SELLA_OK;
 }
 
-int h2d_end(sella_ctx* c, void* dst, const void* slot, size_t bytes) {
-    HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
-    return SELLA_OK;
+int h2d_end(sella_ctx* c, void* dst, const void* slot, size_t bytes) { return h2d_queue(c, dst, slot, bytes); }
+
+// the same for any pinned (hipHostMalloc) source the caller owns and keeps unchanged until the stream has passed the copy
+int h2d_pinned(sella_ctx* c, void* dst, const void* pinned_src, size_t bytes) {
+    if (bytes == 0) return SELLA_OK;
+    return h2d_queue(c, dst, pinned_src, bytes);
 }
 
 static constexpr size_t D2H_RING_BYTES = (size_t)8 << 20;
@@ -473,6 +502,7 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "eigh_wy_waves")) c->opt.eigh_wy_waves = value;
     else if (!strcmp(key, "lr_cholqr")) c->opt.lr_cholqr = value ? 1 : 0;
     else if (!strcmp(key, "rank2k_fixed")) c->opt.rank2k_fixed = value ? 1 : 0;
+    else if (!strcmp(key, "h2d_kernel_min")) c->opt.h2d_kernel_min = value < 0 ? 0 : value;
     else if (!strcmp(key, "eigh_dc_pipeline")) c->opt.eigh_dc_pipeline = value ? 1 : 0;
     else if (!strcmp(key, "eigh_gemv_flat")) c->opt.eigh_gemv_flat = value ? 1 : 0;
     else if (!strcmp(key, "lr_dev")) c->opt.lr_dev = value ? 1 : 0;

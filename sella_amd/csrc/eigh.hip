@@ -2043,7 +2043,7 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
         double* hde = static_cast<double*>(stage);
         std::copy(d.begin(), d.end(), hde);
         std::copy(e.begin(), e.end(), hde + ld);
-        HIPCHK(hipMemcpyAsync(ddev, hde, ((size_t)ld + n) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        SCHK(h2d_pinned(c, ddev, hde, ((size_t)ld + n) * sizeof(double)));
     }
     int* ranges = reinterpret_cast<int*>(static_cast<double*>(stage) + 2 * (size_t)ld);
     const size_t nranges = 2 * leaves.size();
@@ -2221,8 +2221,9 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
         // (c,s) pairs | D | w in one piece (device slots V_CS0, V_CS1, V_DD, V_WD are consecutive), rotation and
         // gather indices in another
         static_assert(V_CS1 == V_CS0 + 1 && V_DD == V_CS0 + 2 && V_WD == V_CS0 + 3, "slot order");
-        HIPCHK(hipMemcpyAsync(csd, hcs, (3 * (size_t)ld + n) * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(i1d, hr1, 3 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        // (by kernel from 16 KB on: the runtime's copy takes 12 - 15 us at these sizes, h2d_kernel_min)
+        SCHK(h2d_pinned(c, csd, hcs, (3 * (size_t)ld + n) * sizeof(double)));
+        SCHK(h2d_pinned(c, i1d, hr1, 3 * (size_t)n * sizeof(int)));
         // ---- (3) device work of the whole level: one launch per kernel, blockIdx.y = merge -------------
         {
             int maxK = 0, maxrot = 0;
@@ -2236,7 +2237,7 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
                 hgd[4 * mi] = pl.lo; hgd[4 * mi + 1] = pl.N; hgd[4 * mi + 2] = pl.K; hgd[4 * mi + 3] = 0;
             }
             HIPCHK(hipMemcpyAsync(mdd, hmd, (size_t)nm * sizeof(MergeDev), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(mrowd, hmrow, ((size_t)n + 4 * (size_t)nm) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            SCHK(h2d_pinned(c, mrowd, hmrow, ((size_t)n + 4 * (size_t)nm) * sizeof(int)));
             if (maxrot > 0)
                 hipLaunchKernelGGL(rot_rows_batched_kernel, dim3((maxN + 63) / 64, nm), dim3(64), 0, c->stream, mdd, cur, ld,
                                    i1d, i2d, csd);
@@ -2698,8 +2699,8 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int nr, int n, int ld, do
     }
     const double tt2 = now();
     static_assert(V_CS1 == V_CS0 + 1 && V_DD == V_CS0 + 2 && V_WD == V_CS0 + 3, "slot order");
-    HIPCHK(hipMemcpyAsync(i1d, hr1, 3 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(csd, hcs, (3 * (size_t)ld + n) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    SCHK(h2d_pinned(c, i1d, hr1, 3 * (size_t)n * sizeof(int)));
+    SCHK(h2d_pinned(c, csd, hcs, (3 * (size_t)ld + n) * sizeof(double)));
     double* nxt = W.Zb;
     if (pl.nrot > 0) {
         hipLaunchKernelGGL(rot_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, Vt, ld, n, pl.nrot, i1d, i2d, csd);

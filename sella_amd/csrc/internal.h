@@ -123,6 +123,7 @@ struct Options {
     long eigh_wy_rows = 16;  // rows of X per workgroup of the MFMA back-transformation (16, or 32: two row tiles)
     long eigh_wy_waves = 4;  // wavefronts per workgroup of the MFMA back-transformation (4, 8 or 16: measured equal at n = 3072 and 12288 — the kernel is bound by L2 bandwidth, 22.7 GB in 3.16 ms, not by latency)
     long lr_cholqr = 1;      // 1: block of update vectors orthonormalised by Cholesky-QR twice (eigh.hip, lr_lowrank_update)
+    long h2d_kernel_min = 16384; // host-to-device payloads of at least this many bytes are copied by a kernel reading the pinned ring (0: never)
     long eigh_dc_pipeline = 1; // 1: divide & conquer queues the next level's rank-one vectors behind the current level (one wait per level)
     long eigh_gemv_flat = 1; // 1: trailing matvec of the tridiagonalisation with every load issued before the first wait (eigh.hip)
     long rank2k_fixed = 1;   // 1: trailing update with all loads issued up front for the panel depths 16 / 32 (update.hip)
@@ -245,6 +246,7 @@ void dev_free(sella_ctx* c, double* p, size_t bytes);
 int upload_panel(sella_ctx* c, const double* X, int n, int k, double* dpanel, int ldp);   // (n x k) host -> k rows
 int download_panel(sella_ctx* c, const double* dpanel, int ldp, int n, int k, double* X); // k rows -> (n x k) host
 int h2d_async(sella_ctx* c, void* dst, const void* src, size_t bytes);   // caller memory -> device, no wait (pinned ring)
+int h2d_pinned(sella_ctx* c, void* dst, const void* pinned_src, size_t bytes);   // pinned source of the caller: by kernel from 16 KB on (h2d_kernel_min)
 int h2d_begin(sella_ctx* c, size_t bytes, void** slot);                   // pinned slot (zeroed) for the caller to compose in ...
 int h2d_end(sella_ctx* c, void* dst, const void* slot, size_t bytes);     // ... and its transfer queued
 // device -> caller memory through the pinned ring: `dst` is valid after the next stream_wait(c).  The 2-D form copies

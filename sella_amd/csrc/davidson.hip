@@ -134,7 +134,7 @@ int put_small(Dav& s, const double* h, int count, int stage, size_t dev_offset, 
     if (count <= 8192) {
         double* st = c->hscal + DS_STAGE + (size_t)stage * 8192;
         memcpy(st, h, (size_t)count * sizeof(double));
-        HIPCHK(hipMemcpyAsync(d, st, (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        SCHK(h2d_pinned(c, d, st, (size_t)count * sizeof(double)));          // (by kernel from 16 KB on)
     } else {
         SCHK(h2d_async(c, d, h, (size_t)count * sizeof(double)));
         SCHK(stream_wait(c));

@@ -79,7 +79,8 @@ int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
  *   eigh_upd_nt (512) rows / most threads per workgroup of that launch | eigh_gemv_flat (1) trailing matvec of the blocked
  *   chain with every load issued before the first wait (0: the loop form; same sums, bit for bit), eigh_dc_pipeline (1)
  *   divide & conquer with ONE host wait per level (0: two; same results bit for bit), eigh_wy_overlap (1) compact-WY
- *   factors on a second stream beside divide & conquer |
+ *   factors on a second stream beside divide & conquer | h2d_kernel_min (16384) host-to-device payloads of at least this
+ *   many bytes are copied by a kernel that reads the pinned staging ring (0: always the runtime's copy) |
  *   lr_chain (1) the structured quasi-Newton update of sella_opt_step as the fused launch chain of round 4 (0: round 3's
  *   kernels), lr_pipe (1) the force call queued in front of the update that consumes it, rs_batch_result (1) final step
  *   read from the batch of trial alphas that produced it, lr_overlap (0) view job on a second stream |

@@ -20,6 +20,7 @@
 // lr_secular_kernel / lr_zhat_kernel (one wavefront per root, secular.h), lr_apply_kernel (one workgroup per new
 // eigenpair: its vector, its place in the ascending order, its column of the new Q).
 #include "internal.h"
+#include <chrono>
 #include "secular.h"
 
 #include <algorithm>
@@ -1170,6 +1171,9 @@ static int lr_job_commit(sella_ctx* c, LrJob& j, int* r_io, double* mu, std::vec
 // the coordinate kernels.  *handled = false: nothing was changed and the caller takes the general route.
 int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pipe) {
     *handled = false;
+    static const bool step_timing = getenv("SELLA_STEP_TIMING") != nullptr;   // host side of a step, phase by phase (stderr)
+    auto stamp = [] { return std::chrono::steady_clock::now(); };
+    const auto ts0 = stamp();
     const int n = a->n;
     const bool view = a->idx != nullptr && a->m > 0;
     if (!(a->flags & SELLA_OPT_LEARN) || a->update_method != SELLA_UPD_TS_BFGS || !c->opt.lr_dev) return SELLA_OK;
@@ -1341,7 +1345,9 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
         SCHK(d2h_async(c, pipe->g_out, X + 2 * (size_t)ld, (size_t)n * sizeof(double)));
         SCHK(d2h_async(c, auxh.data(), auxdev, (size_t)naux * sizeof(double)));
     }
+    const auto ts1 = stamp();
     SCHK(stream_wait(c));
+    const auto ts2 = stamp();
     if (piped) {
         // the force call is complete whatever becomes of the update
         pipe->f = calc_finish(pipe->calc, pipe->x, auxh.data());
@@ -1398,6 +1404,7 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
         else if (1.0 / a->rho_inc < rho && rho < a->rho_inc) a->delta = std::fmax(a->sigma_inc * a->smag, a->delta);
         a->rho = rho;
     }
+    const auto ts3 = stamp();
     if (!propose) return SELLA_OK;
     // step family on the new modes: explicit pairs + the part of g outside their span (+ weightless copies), as
     // sella_stepper_create_lr builds it, from what came back with the update
@@ -1443,10 +1450,17 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
     stepper_set_fast_search(st, c->opt.rs_fast != 0, on_boundary);
     const bool qn = a->stepper_kind == SELLA_STEP_QN;
     const double alpha0 = qn ? 0.0 : 1.0, alphamax = qn ? std::numeric_limits<double>::infinity() : 1.0;
+    const auto ts4 = stamp();
     const int rc = sella_restricted_step(st, a->cons, a->delta, nullptr, nullptr, nullptr, alpha0, 0.0, alphamax,
                                          qn ? -1.0 : 1.0, qn ? 1 : 0, 1, a->tol, a->maxiter, view ? a->idx : nullptr,
                                          view ? n : 0, a->s_out, &a->smag_out, nullptr, &a->nalpha);
     sella_stepper_destroy(st);
+    if (step_timing) {
+        const auto ts5 = stamp();
+        auto us = [](auto x, auto y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+        fprintf(stderr, "step host side: stage + queue %.1f us, wait %.1f us, commit + ratio %.1f us, family %.1f us, restricted step %.1f us\n",
+                us(ts0, ts1), us(ts1, ts2), us(ts2, ts3), us(ts3, ts4), us(ts4, ts5));
+    }
     return rc;
 }
 

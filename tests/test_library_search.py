@@ -306,3 +306,25 @@ def test_hand_over_at_the_rank_limit_keeps_the_reference_semantics(ctx, n, nstep
     np.testing.assert_allclose(a1.positions, a2.positions, atol=1e-6)
     assert o1.delta == pytest.approx(o2.delta, rel=1e-6)
     assert o1.nsteps_since_diag == o2.nsteps_since_diag
+
+
+def test_upload_paths_agree(ctx):
+    """Host-to-device payloads by the copy kernel that reads the pinned ring (`h2d_kernel_min`: from 16 KB on by default)
+    against the runtime's copy for everything (0) and against the kernel for everything including the one-double tail (8):
+    a transport change only — the same search, bit for bit."""
+    from sella_amd.internal import Constraints
+    from sella_amd.search import LibrarySearch
+    out = []
+    try:
+        for kmin in (16384, 0, 8):
+            ctx.set_option('h2d_kernel_min', kmin)
+            at = _model(ctx, n=126, seed=43)                   # 126: an odd number of doubles in some payloads
+            ls = LibrarySearch(at, constraints=Constraints(at), **dict(KW, rs='tr', nsteps_per_diag=3))
+            assert not ls.run(0.0, 6)
+            out.append((at.positions.copy(), ls.energy, ls.delta))
+            ls.close()
+    finally:
+        ctx.set_option('h2d_kernel_min', 16384)
+    for o in out[1:]:
+        np.testing.assert_array_equal(o[0], out[0][0])
+        assert o[1] == out[0][1] and o[2] == out[0][2]

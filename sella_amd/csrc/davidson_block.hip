@@ -17,6 +17,7 @@
 //   sella/utilities/math.pyx:112-117); A T on the matrix cores (+ ONE all-gather when the rows are sharded);
 //   one panel product for the new Gram rows; thick restart when the basis is full.
 #include "internal.h"
+#include <chrono>
 #include "host_math.h"
 
 namespace sella {
@@ -636,10 +637,15 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
             for (int b = 0; b < k; ++b) Gk[(size_t)a * k + b] = s.G[(size_t)a * s.kcap + b];
         W.assign((size_t)k * k, 0.0);
         work.resize(k);
+        static const bool rr_timing = getenv("SELLA_BD_TIMING") != nullptr;      // host Rayleigh-Ritz, per iteration (stderr)
+        const auto trr0 = std::chrono::steady_clock::now();
         if (small::sym_eig(k, Gk.data(), k, theta.data(), W.data(), k, work.data()) != 0) {
             set_error("davidson_block: Rayleigh-Ritz eigenproblem failed");
             return fail(SELLA_E_NOCONV);
         }
+        if (rr_timing)
+            fprintf(stderr, "block davidson: host Rayleigh-Ritz k = %d: %.1f us\n", k,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - trr0).count());
         }
         // ---- residuals of the lowest nev Ritz pairs, 16 at a time; the first chunk with unconverged pairs feeds
         // the correction block s.T (its rows are copied out before s.R is reused) --------------------------------

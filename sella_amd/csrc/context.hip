@@ -280,7 +280,7 @@ int stream_wait(sella_ctx* c) {
     // (both streams: the rings below are shared, and a wait issued while a job is being queued on the second stream must
     // not rewind them under transfers the main stream still has queued)
     if (c->stream_main && c->stream_main != c->stream) HIPCHK(hipStreamSynchronize(c->stream_main));
-    if (c->stream2 && c->stream2 != c->stream) HIPCHK(hipStreamSynchronize(c->stream2));
+    if (c->stream2 && c->stream2 != c->stream && !c->stream2_detached) HIPCHK(hipStreamSynchronize(c->stream2));
     for (const auto& p : c->d2h_pending) memcpy(p.dst, p.slot, p.bytes);
     c->d2h_pending.clear();
     c->dring_pos = 0;
@@ -502,6 +502,7 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "eigh_wy_waves")) c->opt.eigh_wy_waves = value;
     else if (!strcmp(key, "lr_cholqr")) c->opt.lr_cholqr = value ? 1 : 0;
     else if (!strcmp(key, "rank2k_fixed")) c->opt.rank2k_fixed = value ? 1 : 0;
+    else if (!strcmp(key, "eigh_wy_strip")) c->opt.eigh_wy_strip = value;
     else if (!strcmp(key, "h2d_kernel_min")) c->opt.h2d_kernel_min = value < 0 ? 0 : value;
     else if (!strcmp(key, "eigh_dc_pipeline")) c->opt.eigh_dc_pipeline = value ? 1 : 0;
     else if (!strcmp(key, "eigh_gemv_flat")) c->opt.eigh_gemv_flat = value ? 1 : 0;
@@ -509,11 +510,19 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "lr_chain")) c->opt.lr_chain = value ? 1 : 0;
     else if (!strcmp(key, "lr_pipe")) c->opt.lr_pipe = value ? 1 : 0;
     else if (!strcmp(key, "eigh_wy_overlap")) c->opt.eigh_wy_overlap = value ? 1 : 0;
-    else if (!strcmp(key, "eigh_upd_max")) c->opt.eigh_upd_max = value < 0 ? 0 : value;
-    else if (!strcmp(key, "eigh_upd_rows")) c->opt.eigh_upd_rows = value;
-    else if (!strcmp(key, "eigh_upd_nt")) c->opt.eigh_upd_nt = value;
-    else if (!strcmp(key, "eigh_upd_r4_min")) c->opt.eigh_upd_r4_min = value;
-    else if (!strcmp(key, "eigh_upd_r8_min")) c->opt.eigh_upd_r8_min = value;
+    // (one launch per column: at most 1024 workgroups of at most 8 rows, eigh.hip TRD_UPD_MAXGRID — larger blocks stay
+    //  with the blocked chain instead of failing in the middle of a factorisation)
+    else if (!strcmp(key, "eigh_upd_max")) c->opt.eigh_upd_max = value < 0 ? 0 : (value > 8 * 1024 - 64 ? 8 * 1024 - 64 : value);
+    else if (!strcmp(key, "eigh_upd_rows")) {
+        if (value != 0 && value != 2 && value != 4 && value != 8) { set_error("eigh_upd_rows must be 0, 2, 4 or 8"); return SELLA_E_INVALID; }
+        c->opt.eigh_upd_rows = value;
+    }
+    else if (!strcmp(key, "eigh_upd_nt")) {
+        if (value != 128 && value != 256 && value != 512) { set_error("eigh_upd_nt must be 128, 256 or 512"); return SELLA_E_INVALID; }
+        c->opt.eigh_upd_nt = value;
+    }
+    else if (!strcmp(key, "eigh_upd_r4_min")) c->opt.eigh_upd_r4_min = value < 0 ? 0 : value;
+    else if (!strcmp(key, "eigh_upd_r8_min")) c->opt.eigh_upd_r8_min = value < 0 ? 0 : value;
     else if (!strcmp(key, "emt_hcap")) c->opt.emt_hcap = value;
     else if (!strcmp(key, "lr_overlap")) c->opt.lr_overlap = value ? 1 : 0;
     else if (!strcmp(key, "rs_batch_result")) c->opt.rs_batch_result = value ? 1 : 0;

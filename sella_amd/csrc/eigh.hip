@@ -1718,6 +1718,145 @@ __global__ __launch_bounds__(64 * NW) void wy_apply_mfma64_kernel(double* __rest
     }
 }
 
+// ---- the strip of X in registers for the whole sweep (round 5) -------------------------------------------------------------
+// wy_apply_mfma64_kernel is bound by what the L2s deliver: per block a workgroup streams its 16 rows of X twice and writes
+// them once, and streams the reflector block twice (19.9 GB through the L2s at n = 3072, of which 5.4 GB are X).  Here the
+// strip never leaves the CU: 8 wavefronts hold the 16 x n strip in their accumulator registers — wavefront w the 64-column
+// chunks w, w + 8, ... (dealt cyclically: the active columns of a block are a suffix, so every wavefront keeps about the
+// same share) — for ALL blocks; only the reflectors stream.  What makes that possible is the TRANSPOSED tile: a chunk is
+// kept as four 16 x 16 tiles of X^T in the MFMA C/D layout (lane (i, g), register r: X[row i][64 ch + 16 r + 4 g + c] for
+// tile c), updated as  X^T -= Y_b^T M2^T  (A operand: 32-byte vectors of a reflector row, columns 4 i .. 4 i + 3 — the same
+// loads as above), and the very same registers are the B operand of the first product  M^T = Y_b X^T  (columns
+// {16 r + 4 g + c : g} of a chunk are the four summation slots of MFMA (r, c); the A operand is again a 32-byte vector of a
+// reflector row).  X is read once and written once per eigh.  Needs n = ld = a multiple of 64 with at most 8 NCH chunks.
+template <int NCH, int NW>
+__global__ __launch_bounds__(64 * NW) void wy_apply_strip_kernel(double* __restrict__ X, int ldx, int n,
+                                                                 const double* __restrict__ Yf,
+                                                                 const double* __restrict__ Call, int nblk) {
+    __shared__ double Mp[NW][WY_NB2][17];                        // partial M^T of every wavefront: 64 reflectors x 16 rows
+    __shared__ double Ms[WY_NB2][17];
+    __shared__ double M2s[WY_NB2][17];
+    __shared__ double Cs[WY_NB2][WY_NB2 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int r0 = blockIdx.x * 16;
+    const int row = (r0 + li < n) ? r0 + li : n - 1;
+    const int nchunks = ldx >> 6;
+    // ---- the strip: xr[i][c][r] = X[row][64 (wave + 8 i) + 16 r + 4 lg + c]
+    wy_f64x4 xr[NCH][4];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = wave + NW * i;
+        const bool has = ch < nchunks;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double4 v = has ? *reinterpret_cast<const double4*>(X + (size_t)row * ldx + 64 * ch + 16 * r + 4 * lg)
+                                  : make_double4(0.0, 0.0, 0.0, 0.0);
+            xr[i][0][r] = v.x; xr[i][1][r] = v.y; xr[i][2][r] = v.z; xr[i][3][r] = v.w;
+        }
+    }
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int j0 = b * WY_NB2;
+        const int ch0 = (j0 + 1) >> 6;                           // first chunk with a non-zero reflector entry
+        // C_b into LDS (consumed in phase 2, behind two barriers)
+        for (int e = tid; e < WY_NB2 * WY_NB2; e += 64 * NW) Cs[e >> 6][e & 63] = Call[(size_t)b * WY_NB2 * WY_NB2 + e];
+        // ---- phase 1: M^T = Y_b X^T (64 x 16), this wavefront's chunks; the 64 reflectors in two halves (the strip leaves
+        // 64 registers for everything else: two accumulator tiles and two operand vectors at a time)
+        // (operand addresses = uniform base + a 32-bit lane offset: the base stays in scalar registers)
+        const unsigned offA = (unsigned)(li * ldx + 4 * lg);
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh) {
+            wy_f64x4 accM0 = wy_f64x4{0.0, 0.0, 0.0, 0.0}, accM1 = wy_f64x4{0.0, 0.0, 0.0, 0.0};
+            const double* yq = Yf + (size_t)(j0 + 32 * qh) * ldx;               // uniform
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int ch = wave + NW * i;
+                if (ch >= ch0 && ch < nchunks) {
+                    const double* yc = yq + 64 * ch;                             // uniform
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double4 y0 = *reinterpret_cast<const double4*>(yc + 16 * r + offA);
+                        const double4 y1 = *reinterpret_cast<const double4*>(yc + (size_t)16 * ldx + 16 * r + offA);
+                        accM0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0.x, xr[i][0][r], accM0, 0, 0, 0);
+                        accM1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1.x, xr[i][0][r], accM1, 0, 0, 0);
+                        accM0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0.y, xr[i][1][r], accM0, 0, 0, 0);
+                        accM1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1.y, xr[i][1][r], accM1, 0, 0, 0);
+                        accM0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0.z, xr[i][2][r], accM0, 0, 0, 0);
+                        accM1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1.z, xr[i][2][r], accM1, 0, 0, 0);
+                        accM0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0.w, xr[i][3][r], accM0, 0, 0, 0);
+                        accM1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1.w, xr[i][3][r], accM1, 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Mp[wave][32 * qh + lg + 4 * r][li] = accM0[r];
+                Mp[wave][32 * qh + 16 + lg + 4 * r][li] = accM1[r];
+            }
+        }
+        __syncthreads();
+        // the eight partials in a fixed order: 1024 entries, two per thread
+#pragma unroll
+        for (int u = 0; u < 1024 / (64 * NW); ++u) {
+            const int e = tid + 64 * NW * u, j = e >> 4, rr = e & 15;
+            double sacc = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) sacc += Mp[wv][j][rr];
+            Ms[j][rr] = sacc;
+        }
+        __syncthreads();
+        // ---- phase 2: M2^T = -C_b^T M^T
+#pragma unroll
+        for (int u = 0; u < 1024 / (64 * NW); ++u) {
+            const int e = tid + 64 * NW * u, qc = e >> 4, rr = e & 15;
+            double sacc = 0.0;
+#pragma unroll 8
+            for (int pp = 0; pp < WY_NB2; ++pp) sacc += Ms[pp][rr] * Cs[pp][qc];
+            M2s[qc][rr] = -sacc;
+        }
+        __syncthreads();
+        // ---- phase 3: X^T += Y_b^T M2^T on this wavefront's chunks
+        const unsigned offB = (unsigned)(lg * ldx + 4 * li);
+        const double* yb = Yf + (size_t)j0 * ldx;                                // uniform
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = wave + NW * i;
+            if (ch >= ch0 && ch < nchunks) {
+                const double* yc = yb + 64 * ch;                                 // uniform
+#pragma unroll
+                for (int kp = 0; kp < 8; ++kp) {
+                    const double4 y0 = *reinterpret_cast<const double4*>(yc + (size_t)(8 * kp) * ldx + offB);
+                    const double4 y1 = *reinterpret_cast<const double4*>(yc + (size_t)(8 * kp + 4) * ldx + offB);
+                    const double m20 = M2s[8 * kp + lg][li], m21 = M2s[8 * kp + 4 + lg][li];
+                    xr[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0.x, m20, xr[i][0], 0, 0, 0);
+                    xr[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0.y, m20, xr[i][1], 0, 0, 0);
+                    xr[i][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0.z, m20, xr[i][2], 0, 0, 0);
+                    xr[i][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0.w, m20, xr[i][3], 0, 0, 0);
+                    xr[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1.x, m21, xr[i][0], 0, 0, 0);
+                    xr[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1.y, m21, xr[i][1], 0, 0, 0);
+                    xr[i][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1.z, m21, xr[i][2], 0, 0, 0);
+                    xr[i][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1.w, m21, xr[i][3], 0, 0, 0);
+                }
+            }
+        }
+        // (the next block's first barrier separates this block's reads of M2s / Cs from their next writes: Cs is rewritten
+        // at the top of the loop, so one barrier here)
+        __syncthreads();
+    }
+    if (r0 + li < n) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = wave + NW * i;
+            if (ch < nchunks) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<double4*>(X + (size_t)row * ldx + 64 * ch + 16 * r + 4 * lg) =
+                        make_double4(xr[i][0][r], xr[i][1][r], xr[i][2][r], xr[i][3][r]);
+            }
+        }
+    }
+}
+
 // The same sweep with 32 rows of X per workgroup (two MFMA row tiles sharing every reflector fetch).  The kernel above
 // is bound by L2 bandwidth — 22.7 GB of requests in 3.16 ms at n = 3072, two thirds of them the reflector blocks Y_b, which
 // every workgroup streams in full twice per block (PMC pass in profiles/, 4 / 8 / 16 wavefronts per workgroup measured
@@ -3298,7 +3437,17 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
 
     const double t_s1 = now();
     // ---- stage 2 ----------------------------------------------------------------------------
-    SCHK(dc_solve(W, d, e, w));
+    // The waits of divide & conquer cover the main stream only while the factor kernels run beside it (they read the
+    // reflectors and write SCR_EIG6, nothing the levels touch, and use neither ring) — otherwise the first level's wait
+    // would block on them and the overlap would end there.  Joined again whatever the outcome.
+    const bool detached = wy_stream != c->stream;
+    c->stream2_detached = detached;
+    const int dc_status = dc_solve(W, d, e, w);
+    c->stream2_detached = false;
+    if (dc_status != SELLA_OK) {
+        if (detached) (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
+        return dc_status;
+    }
     if (!hV && !hVt) return SELLA_OK;
 
     const double t_s2 = now();
@@ -3316,7 +3465,9 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
             // wavefronts per workgroup: a workgroup owns 16 rows of X, so there are only n / 16 of them (one per CU at
             // n = 3072) — more wavefronts splitting the columns is what hides the L2 latency of the operand streams
             const long nw = c->opt.eigh_wy_waves;
-            if (wy64)
+            if (wy64 && c->opt.eigh_wy_strip && ld == n && (n & 63) == 0 && n <= 64 * 8 * 6 && (n > 64 * 8 * 4 || c->opt.eigh_wy_strip == 2))
+                SELLA_LAUNCH(c, HIP_KERNEL_NAME(wy_apply_strip_kernel<6, 8>), dim3(n / 16), dim3(512), 0, X, ld, n, Yf, Gd, nblk);
+            else if (wy64)
                 SELLA_LAUNCH(c, wy_apply_mfma64_kernel<4>, dim3((n + 15) / 16), dim3(256), 0, X, ld, n, Yf, Gd, nblk);
             else if (c->opt.eigh_wy_rows == 32 && nw >= 8)
                 SELLA_LAUNCH(c, wy_apply_mfma2_kernel<8>, dim3((n + 31) / 32), dim3(512), 0, X, ld, n, Yf, Gd, nblk);

@@ -126,6 +126,8 @@ struct Options {
     long h2d_kernel_min = 16384; // host-to-device payloads of at least this many bytes are copied by a kernel reading the pinned ring (0: never)
     long eigh_dc_pipeline = 1; // 1: divide & conquer queues the next level's rank-one vectors behind the current level (one wait per level)
     long eigh_gemv_flat = 1; // 1: trailing matvec of the tridiagonalisation with every load issued before the first wait (eigh.hip)
+    long eigh_wy_strip = 1;  // 1: back-transformation with the strip of X in registers for the whole sweep (n = ld a multiple of 64,
+                             //    2048 < n <= 3072: 2.49 -> 2.19 ms, L2 traffic 19.9 -> 14.5 GB); 2: any such n <= 3072 (tests); 0: never
     long rank2k_fixed = 1;   // 1: trailing update with all loads issued up front for the panel depths 16 / 32 (update.hip)
     long rs_fast = 1;        // 1: sella_opt_step searches the restricted step by interpolating batches (stepper.hip)
     long lr_dev = 1;         // 1: sella_opt_step updates structured decompositions in coordinates, all decisions on the device (lrstep.hip)
@@ -219,6 +221,7 @@ struct sella_ctx {
     hipStream_t stream2 = nullptr;
     hipStream_t stream_main = nullptr;         // == stream except while a job is being queued on stream2
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool stream2_detached = false;             // stream2 runs work no wait of the main chain has to cover (eigh.hip, WY factors)
     std::deque<Frame> frames;      // frames[d] = parked state of depth d (d != depth)
     int depth = 0;
 };

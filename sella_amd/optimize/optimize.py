@@ -177,11 +177,13 @@ class Sella(Optimizer):
         moved = not np.array_equal(user_pos, x_lib)
         if moved:
             self.atoms.positions = x_lib
-        pes.curr.update(x=pes.get_x(), state_hash=pes._state_hash(), f=ls.energy, g=ls.gradient.copy())
-        pes._update_basis()
-        pes.last = dict(pes.curr)
-        if moved:
-            self.atoms.positions = user_pos
+        try:
+            pes.curr.update(x=pes.get_x(), state_hash=pes._state_hash(), f=ls.energy, g=ls.gradient.copy())
+            pes._update_basis()
+            pes.last = dict(pes.curr)
+        finally:
+            if moved:                                    # whatever happened above, the user's geometry is what stays
+                self.atoms.positions = user_pos
         pes.first_diag = st['first_diag']
         self.initialized = ls.initialized
         self.nsteps_since_diag = st['nsteps_since_diag']

@@ -166,6 +166,27 @@ def test_one_launch_per_column_chain(ctx):
         ctx.set_option('eigh_upd_nt', 512)
 
 
+def test_back_transformation_with_the_strip_in_registers(ctx):
+    """`wy_apply_strip_kernel` (the 16-row strip of X kept in the accumulator registers of eight wavefronts for all blocks;
+    default from 2048 < n <= 3072, forced here by option value 2) against the streaming kernel and LAPACK."""
+    try:
+        ctx.set_option('eigh_wy_nb64_min', 1)
+        for n in ((64, 192) if ctx.backend == "emu" else (64, 192, 320, 1024, 2112, 3072)):
+            rng = np.random.RandomState(n)
+            A = rng.normal(size=(n, n))
+            A = A + A.T
+            out = []
+            for strip in (0, 2):
+                ctx.set_option('eigh_wy_strip', strip)
+                w = check(ctx, A)
+                out.append((w, ctx.eigh(ctx.upload(A))[1].numpy()))
+            np.testing.assert_array_equal(out[0][0], out[1][0])           # same tridiagonal problem, same eigenvalues
+            assert np.abs(out[0][1] - out[1][1]).max() <= 1e-12 * n       # eigenvectors: another summation order only
+    finally:
+        ctx.set_option('eigh_wy_nb64_min', 2560)
+        ctx.set_option('eigh_wy_strip', 1)
+
+
 def test_spectra(ctx):
     rng = np.random.RandomState(1)
     n = 72 if ctx.backend == 'emu' else 700

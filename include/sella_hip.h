@@ -470,6 +470,31 @@ int sella_search_state(sella_search* search, double* x, double* g, double* scala
 int sella_search_release_hessian(sella_search* search, sella_mat* mats, long* ints, double* mu, double* mu_sub,
                                  double* lam0);
 int sella_search_destroy(sella_search* search);
+sella_ctx* sella_search_ctx(sella_search* search);        /* the context the search lives on */
+
+/* ---- cohorts: the replica dimension of the ensemble (BASELINE configs[3]) ------------------------- */
+/* The reference's ensemble members are independent `Sella` objects (sella/optimize/optimize.py:42-81, 359-440).  A cohort
+ * advances up to 16 of them on ONE GPU in lockstep from ONE host thread: every member keeps its own context (memory,
+ * rings, scratch), but while the cohort runs the members share one stream, every kernel of the step is launched ONCE for
+ * all members that have reached it (the member is the grid's z index, its arguments a by-value descriptor array), and
+ * every wait is one stream synchronisation for all of them.  Members whose control flow differs (a further round of the
+ * root search, a re-diagonalisation) form launches of their own and rejoin at the next step boundary.  A member's results
+ * are bit-identical to sella_search_run on its own.
+ *   sella_cohort_create: `members` = n distinct contexts of one device (1 <= n <= 16), each in no other cohort; they stay
+ *     usable on their own between runs.  Destroy the cohort before its contexts.
+ *   sella_cohort_run_searches: searches[i] lives on member context i (NULL: empty slot); converged[i] / status[i] are what
+ *     sella_search_run(searches[i], fmax, steps, ...) would have returned (SELLA_E_UNSUPPORTED: that member left the
+ *     covered configuration, see sella_search_pending_pairs); sella_cohort_error(cohort, i) is its message.
+ *   sella_cohort_stats: counters[8] = scheduler rounds, launches asked for by the members, launches issued (merged),
+ *     waits asked for, stream synchronisations, barrier arrivals, 0, 0 — accumulated since creation.                    */
+typedef struct sella_cohort sella_cohort;
+int sella_cohort_create(sella_ctx* const* members, int n, sella_cohort** cohort);
+int sella_cohort_size(sella_cohort* cohort);
+int sella_cohort_run_searches(sella_cohort* cohort, sella_search* const* searches, int n, double fmax, long steps,
+                              int* converged, int* status);
+int sella_cohort_stats(sella_cohort* cohort, long* counters);
+const char* sella_cohort_error(sella_cohort* cohort, int member);
+int sella_cohort_destroy(sella_cohort* cohort);
 
 /* ---- profiling hooks (bench.py roofline leg) ---------------------------------------------- */
 /* When enabled, every launch of the big streaming kernels is bracketed by hipEvents on the

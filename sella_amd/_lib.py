@@ -129,6 +129,13 @@ SIGNATURES = {
     'sella_search_state': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'sella_search_release_hessian': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
     'sella_search_destroy': (c_int, [c_void_p]),
+    'sella_search_ctx': (c_void_p, [c_void_p]),
+    'sella_cohort_create': (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    'sella_cohort_size': (c_int, [c_void_p]),
+    'sella_cohort_run_searches': (c_int, [c_void_p, c_void_p, c_int, c_double, c_long, c_void_p, c_void_p]),
+    'sella_cohort_stats': (c_int, [c_void_p, c_void_p]),
+    'sella_cohort_error': (c_char_p, [c_void_p, c_int]),
+    'sella_cohort_destroy': (c_int, [c_void_p]),
     'sella_opt_step': (c_int, [c_void_p, POINTER(OptStepArgs)]),
     'sella_lr_materialize': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_double]),
     'sella_stepper_get_s': (c_int, [c_void_p, c_double, c_void_p, c_void_p]),

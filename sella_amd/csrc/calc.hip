@@ -36,13 +36,13 @@ struct sella_calc {
 
 namespace {
 // g_i = (A x)_i + sum_j c p_j^2 u_j[i],  p = U x: the gradient of the cubic terms, the rows u_j taken in order
-__global__ __launch_bounds__(256) void model_grad_kernel(int n, int nu, int ld, double cc, const double* __restrict__ Ax,
+__device__ __forceinline__ void model_grad_vb(const VB vb, int n, int nu, int ld, double cc, const double* __restrict__ Ax,
                                                          const double* __restrict__ p, const double* __restrict__ U,
                                                          double* __restrict__ g) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = vb.x * 256 + threadIdx.x;
     if (i >= n) return;
     double v = Ax[i];
     for (int j = 0; j < nu; ++j) {
@@ -51,6 +51,9 @@ __global__ __launch_bounds__(256) void model_grad_kernel(int n, int nu, int ld, 
     }
     g[i] = v;
 }
+__global__ __launch_bounds__(256) void model_grad_kernel(int n, int nu, int ld, double cc, const double* __restrict__ Ax,
+                                                         const double* __restrict__ p, const double* __restrict__ U,
+                                                         double* __restrict__ g) { model_grad_vb(vb_hw(), n, nu, ld, cc, Ax, p, U, g); }
 }  // namespace
 
 extern "C" int sella_calc_model_create(sella_ctx* c, sella_mat A, const double* U, int nu, int n, double cc, sella_calc** out) {
@@ -67,7 +70,7 @@ extern "C" int sella_calc_model_create(sella_ctx* c, sella_mat A, const double* 
         const int ld = round_up(n, 8);
         k->dconst_bytes = ((size_t)nu + 2) * ld * sizeof(double);
         int st = dev_alloc(c, k->dconst_bytes, &k->dconst);
-        if (st == SELLA_OK) st = hipMemsetAsync(k->dconst, 0, k->dconst_bytes, c->stream) == hipSuccess ? SELLA_OK : SELLA_E_HIP;
+        if (st == SELLA_OK) st = s_memset0(c, k->dconst, k->dconst_bytes) == hipSuccess ? SELLA_OK : SELLA_E_HIP;
         for (int j = 0; j < nu && st == SELLA_OK; ++j)
             st = h2d_async(c, k->dconst + (size_t)j * ld, U + (size_t)j * n, (size_t)n * sizeof(double));
         if (st == SELLA_OK) st = stream_wait(c);
@@ -99,7 +102,7 @@ int sella::calc_queue(sella_calc* k, const double* x, double** g_dev, double** a
     SCHK(h2d_async(c, dx, x, (size_t)n * sizeof(double)));
     SCHK(launch_gemv_rows(c, A->d, n, n, A->ld, dx, ld, 1, dAx, ld, GemvEpi()));
     if (nu > 0) SCHK(launch_gemv_rows(c, k->dconst, nu, n, ld, dx, ld, 1, dp, ldp, GemvEpi()));
-    hipLaunchKernelGGL(model_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, nu, ld, k->cc, dAx, dp, k->dconst, dg);
+    SELLA_LAUNCHB(c, model_grad_kernel, model_grad_vb, 256, dim3((n + 255) / 256), dim3(256), 0, n, nu, ld, k->cc, dAx, dp, k->dconst, dg);
     HIPCHK(hipGetLastError());
     *g_dev = dg;
     *aux_dev = dAx;                                    // A x (ld entries) then p: one read-back

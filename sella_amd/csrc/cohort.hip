@@ -1,0 +1,375 @@
+// cohort.hip — W ensemble members advanced in lockstep by one issuing thread, one batched launch per kernel of the step
+// (design: cohort.h).  This file is the host runtime: member fibers, the scheduler that merges their parked launches, and
+// the C ABI (`sella_cohort_*`).  Reference semantics: independent `Sella` objects (sella/optimize/optimize.py:42-81,
+// 359-440) — a member's results do not depend on who else is in the cohort.
+#include "internal.h"
+
+#include <sys/mman.h>
+
+#include <functional>
+#include <string>
+
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#include <sanitizer/asan_interface.h>
+#define SELLA_COHORT_ASAN 1
+#endif
+#endif
+
+using namespace sella;
+
+// ---- fibers: callee-saved registers + stack pointer (x86-64 System V), a dozen instructions per switch ----------------
+// (glibc's swapcontext makes two sigprocmask system calls per switch, ~0.5 us: a member parks ~90 times per step.)
+#if !defined(__HIP_DEVICE_COMPILE__)
+#if !defined(__x86_64__)
+#error "cohort.hip: the member fibers are written for x86-64 hosts"
+#endif
+extern "C" void sella_fiber_switch(void** save_sp, void* new_sp);
+asm(R"(
+    .text
+    .globl sella_fiber_switch
+    .type sella_fiber_switch,@function
+sella_fiber_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size sella_fiber_switch,.-sella_fiber_switch
+)");
+#else
+extern "C" void sella_fiber_switch(void** save_sp, void* new_sp);
+#endif
+
+namespace {
+
+constexpr size_t FIBER_STACK = (size_t)4 << 20;      // virtual: touched pages only
+
+enum FiberState { F_IDLE = 0, F_RUNNABLE, F_AT_LAUNCH, F_AT_WAIT, F_AT_BARRIER, F_DONE };
+
+struct Fiber {
+    void* sp = nullptr;
+    char* stack = nullptr;
+    FiberState state = F_IDLE;
+    std::function<int()> job;
+    int status = SELLA_OK;
+    std::string error;
+    // parked launch
+    unsigned long long key = 0;                    // parked at a barrier: its position (smaller = further behind)
+    BatchLauncher fn = nullptr;
+    const char* name = "";
+    dim3 grid, block;
+    size_t shmem = 0;
+    alignas(16) char pack[COHORT_PACK_BYTES];
+};
+
+}  // namespace
+
+struct sella_cohort {
+    int device = 0;
+    hipStream_t stream = nullptr;                 // the cohort's stream: member 0's own
+    std::vector<sella_ctx*> members;
+    std::vector<hipStream_t> own_stream;          // the members' own streams, put back after a run
+    std::vector<Fiber> fibers;
+    void* sched_sp = nullptr;
+    int current = -1;                             // member whose fiber is running (-1: the scheduler)
+    // statistics of the last run / since creation
+    long rounds = 0, launches_parked = 0, launches_issued = 0, waits_parked = 0, syncs = 0, barriers = 0, direct = 0;
+};
+
+namespace {
+
+thread_local sella_cohort* g_running = nullptr;   // the cohort this thread is advancing
+
+void fiber_main();
+
+void fiber_prepare(Fiber& f) {
+    if (!f.stack) {
+        void* p = mmap(nullptr, FIBER_STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        f.stack = p == MAP_FAILED ? nullptr : static_cast<char*>(p);
+    }
+#ifdef SELLA_COHORT_ASAN
+    if (f.stack) __asan_unpoison_memory_region(f.stack, FIBER_STACK);
+#endif
+    if (!f.stack) return;
+    uintptr_t top = (reinterpret_cast<uintptr_t>(f.stack) + FIBER_STACK) & ~static_cast<uintptr_t>(15);
+    void** sp = reinterpret_cast<void**>(top);
+    *--sp = nullptr;                               // fake return address of fiber_main (keeps the ABI's stack alignment)
+    *--sp = reinterpret_cast<void*>(&fiber_main);  // popped by the `ret` of the first switch
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;   // rbp, rbx, r12 .. r15
+    // control words of the creating thread (round to nearest, exceptions masked)
+    unsigned int mxcsr = 0;
+    unsigned short fcw = 0;
+    asm volatile("stmxcsr %0" : "=m"(mxcsr));
+    asm volatile("fnstcw %0" : "=m"(fcw));
+    unsigned int words[2] = {mxcsr, fcw};
+    --sp;
+    memcpy(sp, words, 8);
+    f.sp = sp;
+}
+
+// from a member fiber back to the scheduler
+void park(sella_cohort* co, FiberState st) {
+    Fiber& f = co->fibers[co->current];
+    f.state = st;
+    sella_fiber_switch(&f.sp, co->sched_sp);
+}
+
+void fiber_main() {
+    sella_cohort* co = g_running;
+    Fiber& f = co->fibers[co->current];
+    int st;
+    try {
+        st = f.job();
+    } catch (const std::bad_alloc&) {
+        set_error("cohort member: out of host memory");
+        st = SELLA_E_NOMEM;
+    } catch (...) {
+        set_error("cohort member: unexpected exception");
+        st = SELLA_E_INVALID;
+    }
+    f.status = st;
+    if (st != SELLA_OK) f.error = sella_last_error();
+    park(co, F_DONE);
+    abort();                                       // a finished fiber is never resumed
+}
+
+void resume(sella_cohort* co, int i) {
+    co->current = i;
+    co->fibers[i].state = F_RUNNABLE;
+    sella_fiber_switch(&co->sched_sp, co->fibers[i].sp);
+    co->current = -1;
+}
+
+// Advance the members until all of them are done.  A round: run every runnable member until it parks; then merge the
+// parked launches body by body (members parked at the same kernel form one launch, in member order); with no launch
+// parked, one synchronisation of the stream releases every member parked at a wait; with nobody at a wait either, the
+// members at the barrier go on together.
+int advance(sella_cohort* co) {
+    const int n = (int)co->fibers.size();
+    const void* packs[COHORT_MAX];
+    dim3 grids[COHORT_MAX];
+    int who[COHORT_MAX];
+    static const bool trace = getenv("SELLA_COHORT_TRACE") != nullptr;      // one line per scheduler round on stderr
+    for (;;) {
+        ++co->rounds;
+        for (int i = 0; i < n; ++i)
+            if (co->fibers[i].state == F_RUNNABLE) resume(co, i);
+        int nl = 0, nw = 0, nb = 0;
+        for (int i = 0; i < n; ++i) {
+            const FiberState s = co->fibers[i].state;
+            nl += s == F_AT_LAUNCH;
+            nw += s == F_AT_WAIT;
+            nb += s == F_AT_BARRIER;
+        }
+        if (trace) {
+            fprintf(stderr, "cohort round %ld:", co->rounds);
+            for (int i = 0; i < n; ++i) {
+                const Fiber& f = co->fibers[i];
+                fprintf(stderr, " %s", f.state == F_AT_LAUNCH ? f.name : f.state == F_AT_WAIT ? "WAIT" : f.state == F_AT_BARRIER ? "BARRIER" :
+                                       f.state == F_DONE ? "done" : "-");
+            }
+            fprintf(stderr, "\n");
+        }
+        if (nl + nw + nb == 0) return SELLA_OK;
+        if (nl > 0) {
+            for (int i = 0; i < n; ++i) {
+                Fiber& f = co->fibers[i];
+                if (f.state != F_AT_LAUNCH) continue;
+                int cnt = 0;
+                for (int j = i; j < n; ++j) {
+                    Fiber& g = co->fibers[j];
+                    if (g.state != F_AT_LAUNCH || g.fn != f.fn || g.shmem != f.shmem || g.block.x != f.block.x || g.block.y != f.block.y ||
+                        g.block.z != f.block.z)
+                        continue;
+                    packs[cnt] = g.pack;
+                    grids[cnt] = g.grid;
+                    who[cnt++] = j;
+                }
+                f.fn(co->stream, cnt, packs, grids, f.block, f.shmem);
+                ++co->launches_issued;
+                for (int q = 0; q < cnt; ++q) co->fibers[who[q]].state = F_RUNNABLE;
+            }
+            HIPCHK(hipGetLastError());
+            continue;
+        }
+        if (nw > 0) {
+            HIPCHK(hipStreamSynchronize(co->stream));
+            ++co->syncs;
+            for (int i = 0; i < n; ++i)
+                if (co->fibers[i].state == F_AT_WAIT) co->fibers[i].state = F_RUNNABLE;
+            continue;
+        }
+        unsigned long long lowest = ~0ull;
+        for (int i = 0; i < n; ++i)
+            if (co->fibers[i].state == F_AT_BARRIER && co->fibers[i].key < lowest) lowest = co->fibers[i].key;
+        for (int i = 0; i < n; ++i)
+            if (co->fibers[i].state == F_AT_BARRIER && co->fibers[i].key == lowest) co->fibers[i].state = F_RUNNABLE;
+    }
+}
+
+}  // namespace
+
+namespace sella {
+
+bool cohort_in_fiber() { return g_running != nullptr && g_running->current >= 0; }
+
+void cohort_park_launch(sella_ctx* c, BatchLauncher fn, const void* pack, size_t pack_bytes, dim3 grid, dim3 block, size_t shmem,
+                        const char* name) {
+    sella_cohort* co = g_running;
+    (void)c;
+    Fiber& f = co->fibers[co->current];
+    f.fn = fn;
+    f.name = name;
+    f.grid = grid;
+    f.block = block;
+    f.shmem = shmem;
+    memcpy(f.pack, pack, pack_bytes);
+    ++co->launches_parked;
+    park(co, F_AT_LAUNCH);
+}
+
+void cohort_park_wait(sella_ctx* c) {
+    (void)c;
+    sella_cohort* co = g_running;
+    ++co->waits_parked;
+    park(co, F_AT_WAIT);
+}
+
+void cohort_set_phase(sella_ctx* c, long epoch, int stage) {
+    if (c) c->cohort_phase = ((unsigned long long)(epoch < 0 ? 0 : epoch) << 8) | (unsigned)(stage & 0xff);
+}
+
+void cohort_barrier(sella_ctx* c, unsigned iter, unsigned sub) {
+    if (!c || !c->cohort || !cohort_in_fiber()) return;
+    sella_cohort* co = g_running;
+    ++co->barriers;
+    co->fibers[co->current].key = (c->cohort_phase << 32) | ((unsigned long long)(iter & 0xffffffu) << 8) | (sub & 0xffu);
+    park(co, F_AT_BARRIER);
+}
+
+}  // namespace sella
+
+extern "C" {
+
+int sella_cohort_create(sella_ctx* const* members, int n, sella_cohort** out) {
+    if (!members || !out || n < 1 || n > COHORT_MAX) {
+        set_error("cohort: between 1 and %d member contexts", COHORT_MAX);
+        return SELLA_E_INVALID;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!members[i] || members[i]->cohort || members[i]->device != members[0]->device) {
+            set_error("cohort: member contexts must be distinct, on one device, and in no other cohort");
+            return SELLA_E_INVALID;
+        }
+        for (int j = 0; j < i; ++j)
+            if (members[j] == members[i]) { set_error("cohort: member context given twice"); return SELLA_E_INVALID; }
+    }
+    sella_cohort* co = new sella_cohort();
+    co->device = members[0]->device;
+    co->stream = members[0]->stream;
+    co->members.assign(members, members + n);
+    co->own_stream.resize(n);
+    co->fibers.resize(n);
+    for (int i = 0; i < n; ++i) members[i]->cohort = co;
+    *out = co;
+    return SELLA_OK;
+}
+
+int sella_cohort_destroy(sella_cohort* co) {
+    if (!co) return SELLA_OK;
+    for (sella_ctx* c : co->members) c->cohort = nullptr;
+    for (Fiber& f : co->fibers)
+        if (f.stack) munmap(f.stack, FIBER_STACK);
+    delete co;
+    return SELLA_OK;
+}
+
+int sella_cohort_size(sella_cohort* co) { return co ? (int)co->members.size() : 0; }
+
+// counters[8]: scheduler rounds, launches parked by the members, launches issued (merged), waits parked, stream
+// synchronisations, barrier arrivals, 0, 0 — accumulated since creation
+int sella_cohort_stats(sella_cohort* co, long* counters) {
+    if (!co || !counters) return SELLA_E_INVALID;
+    const long v[8] = {co->rounds, co->launches_parked, co->launches_issued, co->waits_parked, co->syncs, co->barriers, 0, 0};
+    memcpy(counters, v, sizeof(v));
+    return SELLA_OK;
+}
+
+const char* sella_cohort_error(sella_cohort* co, int member) {
+    if (!co || member < 0 || member >= (int)co->fibers.size()) return "";
+    return co->fibers[member].error.c_str();
+}
+
+// `Optimizer.irun` of up to W searches at once: search i must live on member context i (NULL: the slot stays empty).
+// status[i] / converged[i] are what sella_search_run would have returned for that member on its own.
+int sella_cohort_run_searches(sella_cohort* co, sella_search* const* searches, int n, double fmax, long steps, int* converged,
+                              int* status) {
+    if (!co || !searches || !converged || !status || n < 1 || n > (int)co->members.size()) {
+        set_error("cohort: invalid arguments");
+        return SELLA_E_INVALID;
+    }
+    if (g_running) { set_error("cohort: a cohort is already being advanced on this thread"); return SELLA_E_INVALID; }
+    for (int i = 0; i < n; ++i)
+        if (searches[i] && sella_search_ctx(searches[i]) != co->members[i]) {
+            set_error("cohort: search %d does not live on member context %d", i, i);
+            return SELLA_E_INVALID;
+        }
+    HIPCHK(hipSetDevice(co->device));
+    // everything the members queued on their own streams so far is complete before they share one
+    const int W = (int)co->members.size();
+    for (int i = 0; i < W; ++i) {
+        sella_ctx* c = co->members[i];
+        SCHK(stream_wait(c));
+        co->own_stream[i] = c->stream;
+        c->stream = co->stream;
+        c->stream_main = co->stream;
+    }
+    for (int i = 0; i < W; ++i) {
+        Fiber& f = co->fibers[i];
+        f.state = F_IDLE;
+        f.status = SELLA_OK;
+        f.error.clear();
+        if (i >= n || !searches[i]) continue;
+        converged[i] = 0;
+        sella_search* S = searches[i];
+        int* conv = &converged[i];
+        f.job = [S, fmax, steps, conv]() { return sella_search_run(S, fmax, steps, conv); };
+        fiber_prepare(f);
+        if (!f.stack) {
+            for (int j = 0; j < W; ++j) { co->members[j]->stream = co->own_stream[j]; co->members[j]->stream_main = co->own_stream[j]; }
+            set_error("cohort: no memory for a member's stack");
+            return SELLA_E_NOMEM;
+        }
+        f.state = F_RUNNABLE;
+    }
+    g_running = co;
+    const int st = advance(co);
+    g_running = nullptr;
+    (void)hipStreamSynchronize(co->stream);
+    for (int i = 0; i < W; ++i) {
+        sella_ctx* c = co->members[i];
+        c->stream = co->own_stream[i];
+        c->stream_main = co->own_stream[i];
+    }
+    for (int i = 0; i < n; ++i) status[i] = searches[i] ? co->fibers[i].status : SELLA_OK;
+    return st;
+}
+
+}  // extern "C"

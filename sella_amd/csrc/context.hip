@@ -25,7 +25,7 @@ int mat_new(sella_ctx* c, int rows, int cols, sella_mat* h) {
     // two spare rows so 16-byte reads that start inside the last row never leave the buffer
     const size_t bytes = ((size_t)(rows > 0 ? rows : 1) + 2) * m.ld * sizeof(double);
     SCHK(dev_alloc(c, bytes, &m.d));
-    HIPCHK(hipMemsetAsync(m.d, 0, bytes, c->stream));
+    HIPCHK(s_memset0(c, m.d, bytes));
     m.live = true;
     for (size_t i = 0; i < c->mats.size(); ++i)
         if (!c->mats[i].live) {
@@ -62,7 +62,7 @@ int callback_enter(sella_ctx* c) {
             callback_leave(c);
             return SELLA_E_NOMEM;
         }
-        (void)hipMemsetAsync(c->dscal, 0, (size_t)c->nscal * sizeof(double), c->stream);
+        (void)s_memset0(c, c->dscal, (size_t)c->nscal * sizeof(double));
         c->scratch.assign(SCR_NSLOTS, {nullptr, 0});
     }
     return SELLA_OK;
@@ -142,7 +142,7 @@ int scratch_get(sella_ctx* c, int slot, size_t bytes, double** p) {
         size_t want = bytes + bytes / 4;
         SCHK(dev_alloc(c, want, &s.first));
         s.second = want;
-        HIPCHK(hipMemsetAsync(s.first, 0, want, c->stream));
+        HIPCHK(s_memset0(c, s.first, want));
     }
     *p = s.first;
     return SELLA_OK;
@@ -160,25 +160,27 @@ static constexpr size_t H2D_RING_BYTES = (size_t)8 << 20;
 // 3072 (24 KB: every n-vector of the 1024-atom configurations), 11.8 us for the 120 KB staging block of an optimizer step
 // (tools/lab/h2d_lab.hip, profiles/r05_h2d_lab.log) — where a kernel that reads the pinned slot directly (the ring is
 // device-visible host memory) takes 3.5 - 5.2 us.  Payloads of at least `h2d_kernel_min` bytes go that way.
-__global__ __launch_bounds__(256) void h2d_copy_kernel(double2* __restrict__ dst, const double2* __restrict__ src, size_t n2,
+__device__ __forceinline__ void h2d_copy_vb(const VB vb, double2* __restrict__ dst, const double2* __restrict__ src, size_t n2,
                                                        double* __restrict__ dst_tail, const double* __restrict__ src_tail) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = (size_t)vb.x * 256 + threadIdx.x;
     if (i < n2) dst[i] = src[i];
     if (i == 0 && dst_tail) *dst_tail = *src_tail;
 }
+__global__ __launch_bounds__(256) void h2d_copy_kernel(double2* __restrict__ dst, const double2* __restrict__ src, size_t n2,
+                                                       double* __restrict__ dst_tail, const double* __restrict__ src_tail) { h2d_copy_vb(vb_hw(), dst, src, n2, dst_tail, src_tail); }
 
 static int h2d_queue(sella_ctx* c, void* dst, const void* slot, size_t bytes) {
     const long kmin = c->opt.h2d_kernel_min;
     if (kmin > 0 && bytes >= (size_t)kmin && (bytes & 7) == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(slot)) & 15) == 0) {
         const size_t n2 = bytes / 16;
         const bool tail = (bytes & 15) != 0;
-        hipLaunchKernelGGL(h2d_copy_kernel, dim3((unsigned)((n2 + 255) / 256 + (n2 == 0))), dim3(256), 0, c->stream,
+        SELLA_LAUNCHB(c, h2d_copy_kernel, h2d_copy_vb, 256, dim3((unsigned)((n2 + 255) / 256 + (n2 == 0))), dim3(256), 0,
                            static_cast<double2*>(dst), static_cast<const double2*>(slot), n2,
                            tail ? static_cast<double*>(dst) + 2 * n2 : nullptr, tail ? static_cast<const double*>(slot) + 2 * n2 : nullptr);
         HIPCHK(hipGetLastError());
         return SELLA_OK;
     }
-    HIPCHK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(s_memcpy(c, dst, slot, bytes, hipMemcpyHostToDevice, true));
     return SELLA_OK;
 }
 
@@ -263,9 +265,9 @@ int d2h_async_2d(sella_ctx* c, void* dst, const void* src_dev, size_t spitch, si
     }
     char* slot = c->dring + c->dring_pos;
     if (rows == 1 || spitch == width)
-        HIPCHK(hipMemcpyAsync(slot, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(s_memcpy(c, slot, src_dev, bytes, hipMemcpyDeviceToHost, true));
     else
-        HIPCHK(hipMemcpy2DAsync(slot, width, src_dev, spitch, width, rows, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(s_memcpy2d(c, slot, width, src_dev, spitch, width, rows, hipMemcpyDeviceToHost, true));
     c->d2h_pending.push_back({dst, slot, bytes, width, width, rows});
     c->dring_pos += need;
     return SELLA_OK;
@@ -275,8 +277,86 @@ int d2h_async(sella_ctx* c, void* dst, const void* src_dev, size_t bytes) {
     return d2h_async_2d(c, dst, src_dev, bytes, bytes, 1);
 }
 
-int stream_wait(sella_ctx* c) {
+// ---- stream-ordered copies / fills (see internal.h) -------------------------------------------------------------------
+// 4-byte words: every payload of the library is doubles or ints.  grid.y = row of a 2-D copy (pitches in words).
+__device__ __forceinline__ void copy_words_vb(const VB vb, unsigned* __restrict__ dst, const unsigned* __restrict__ src, size_t nwords,
+                                              size_t dpitch, size_t spitch) {
+    const size_t i = ((size_t)vb.x * 256 + threadIdx.x) * 4;
+    unsigned* d = dst + (size_t)vb.y * dpitch;
+    const unsigned* s = src + (size_t)vb.y * spitch;
+    if (i + 4 <= nwords && ((reinterpret_cast<uintptr_t>(d + i) | reinterpret_cast<uintptr_t>(s + i)) & 15) == 0) {
+        *reinterpret_cast<uint4*>(d + i) = *reinterpret_cast<const uint4*>(s + i);
+    } else {
+        for (size_t q = i; q < i + 4 && q < nwords; ++q) d[q] = s[q];
+    }
+}
+__global__ __launch_bounds__(256) void copy_words_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, size_t nwords,
+                                                         size_t dpitch, size_t spitch) { copy_words_vb(vb_hw(), dst, src, nwords, dpitch, spitch); }
+__device__ __forceinline__ void zero_words_vb(const VB vb, unsigned* __restrict__ dst, size_t nwords) {
+    const size_t i = ((size_t)vb.x * 256 + threadIdx.x) * 4;
+    if (i + 4 <= nwords && (reinterpret_cast<uintptr_t>(dst + i) & 15) == 0) {
+        *reinterpret_cast<uint4*>(dst + i) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        for (size_t q = i; q < i + 4 && q < nwords; ++q) dst[q] = 0u;
+    }
+}
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ dst, size_t nwords) { zero_words_vb(vb_hw(), dst, nwords); }
+
+static bool cohort_copy_ok(sella_ctx* c, const void* a, const void* b, size_t bytes, size_t rows) {
+    return c->cohort && cohort_in_fiber() && bytes > 0 && (bytes & 3) == 0 && bytes / 16 + 1 < ((size_t)1 << 30) && rows < 65536 &&
+           ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 3) == 0;
+}
+
+hipError_t s_memcpy(sella_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, bool host_pinned) {
+    if (bytes == 0) return hipSuccess;
+    if ((kind == hipMemcpyDeviceToDevice || host_pinned) && cohort_copy_ok(c, dst, src, bytes, 1)) {
+        const size_t nw = bytes / 4;
+        SELLA_LAUNCHB(c, copy_words_kernel, copy_words_vb, 256, dim3((unsigned)((nw + 1023) / 1024)), dim3(256), 0,
+                      static_cast<unsigned*>(dst), static_cast<const unsigned*>(src), nw, (size_t)0, (size_t)0);
+        return hipGetLastError();
+    }
+    return hipMemcpyAsync(dst, src, bytes, kind, c->stream);
+}
+
+hipError_t s_memcpy2d(sella_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows,
+                      hipMemcpyKind kind, bool host_pinned) {
+    if (width == 0 || rows == 0) return hipSuccess;
+    if ((kind == hipMemcpyDeviceToDevice || host_pinned) && cohort_copy_ok(c, dst, src, width, rows) && (dpitch & 3) == 0 && (spitch & 3) == 0) {
+        const size_t nw = width / 4;
+        SELLA_LAUNCHB(c, copy_words_kernel, copy_words_vb, 256, dim3((unsigned)((nw + 1023) / 1024), (unsigned)rows), dim3(256), 0,
+                      static_cast<unsigned*>(dst), static_cast<const unsigned*>(src), nw, dpitch / 4, spitch / 4);
+        return hipGetLastError();
+    }
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, kind, c->stream);
+}
+
+hipError_t s_memset0(sella_ctx* c, void* dst, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    if (cohort_copy_ok(c, dst, dst, bytes, 1)) {
+        const size_t nw = bytes / 4;
+        SELLA_LAUNCHB(c, zero_words_kernel, zero_words_vb, 256, dim3((unsigned)((nw + 1023) / 1024)), dim3(256), 0,
+                      static_cast<unsigned*>(dst), nw);
+        return hipGetLastError();
+    }
+    return hipMemsetAsync(dst, 0, bytes, c->stream);
+}
+
+// On a member fiber of a cohort a wait parks the member: the scheduler synchronises the shared stream once for everybody
+// who waits (cohort.hip), which covers everything this member has queued.
+int stream_sync_raw(sella_ctx* c) {
+    if (c->cohort && cohort_in_fiber()) { cohort_park_wait(c); return SELLA_OK; }
     HIPCHK(hipStreamSynchronize(c->stream));
+    return SELLA_OK;
+}
+
+int event_wait(sella_ctx* c, hipEvent_t ev) {
+    if (c->cohort && cohort_in_fiber()) { cohort_park_wait(c); return SELLA_OK; }
+    HIPCHK(hipEventSynchronize(ev));
+    return SELLA_OK;
+}
+
+int stream_wait(sella_ctx* c) {
+    SCHK(stream_sync_raw(c));
     // (both streams: the rings below are shared, and a wait issued while a job is being queued on the second stream must
     // not rewind them under transfers the main stream still has queued)
     if (c->stream_main && c->stream_main != c->stream) HIPCHK(hipStreamSynchronize(c->stream_main));
@@ -318,8 +398,7 @@ int read_scalars(sella_ctx* c, int offset, int count) {
         set_error("read_scalars: range [%d, %d) outside the exchange buffer", offset, offset + count);
         return SELLA_E_INVALID;
     }
-    HIPCHK(hipMemcpyAsync(c->hscal + offset, c->dscal + offset, (size_t)count * sizeof(double),
-                          hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(s_memcpy(c, c->hscal + offset, c->dscal + offset, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, true));
     SCHK(stream_wait(c));
     return SELLA_OK;
 }
@@ -445,7 +524,7 @@ int sella_ctx_create(int device, sella_ctx** out) {
         delete c;
         return SELLA_E_NOMEM;
     }
-    (void)hipMemsetAsync(c->dscal, 0, (size_t)c->nscal * sizeof(double), c->stream);
+    (void)s_memset0(c, c->dscal, (size_t)c->nscal * sizeof(double));
     c->scratch.resize(SCR_NSLOTS, {nullptr, 0});
     *out = c;
     return SELLA_OK;
@@ -621,17 +700,18 @@ int sella_mat_copy(sella_ctx* c, sella_mat src, sella_mat* dst) {
 }
 
 // A[i][i] += alpha (square or not: the leading min(rows, cols) diagonal entries)
-__global__ void add_diag_kernel(double* __restrict__ A, int ld, int n, double alpha) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void add_diag_vb(const VB vb, double* __restrict__ A, int ld, int n, double alpha) {
+    const int i = vb.x * 256 + threadIdx.x;
     if (i < n) A[(size_t)i * ld + i] += alpha;
 }
+__global__ __launch_bounds__(1024) void add_diag_kernel(double* __restrict__ A, int ld, int n, double alpha) { add_diag_vb(vb_hw(), A, ld, n, alpha); }
 
 int sella_mat_add_diag(sella_ctx* c, sella_mat h, double alpha) {
     Mat* m = mat_get(c, h);
     if (!m) return SELLA_E_INVALID;
     const int n = std::min(m->rows, m->cols);
     if (n == 0) return SELLA_OK;
-    hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, m->d, m->ld, n, alpha);
+    SELLA_LAUNCHB(c, add_diag_kernel, add_diag_vb, 1024, dim3((n + 255) / 256), dim3(256), 0, m->d, m->ld, n, alpha);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
@@ -703,7 +783,7 @@ int sella_symm_mm(sella_ctx* c, sella_mat A, const double* X, int k, double* Y) 
         // block product: 16 right-hand sides per pass over the matrix (kernels.hip, panel16_mfma_kernel)
         const int kpad = round_up(k, 16);
         SCHK(scratch_get(c, SCR_X, (size_t)kpad * ldx * sizeof(double), &dx));
-        HIPCHK(hipMemsetAsync(dx, 0, (size_t)kpad * ldx * sizeof(double), c->stream));
+        HIPCHK(s_memset0(c, dx, (size_t)kpad * ldx * sizeof(double)));
         SCHK(upload_panel(c, X, cols, k, dx, ldx));
         a = mat_get(c, A);
         for (int h0 = 0; h0 < k; h0 += 16)

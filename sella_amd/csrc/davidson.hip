@@ -27,6 +27,7 @@ using hostm::vec;
 struct Dav {
     sella_ctx* c = nullptr;
     int n = 0, ld = 0, cap = 0, k = 0;
+    unsigned it = 0;             // iteration counter (position of a cohort member inside the loop, cohort.h)
     double *Vp = nullptr, *AVp = nullptr, *Vq = nullptr, *AVq = nullptr;   // ping-pong panels
     double *Rp = nullptr;        // residual panel (cap rows)
     // carried images of the panels in the eigenbasis of P (fused iteration with an eigenbasis preconditioner):
@@ -65,23 +66,23 @@ int dav_alloc(Dav& s, int cap) {
         set_error("davidson: cannot allocate panels for %d vectors of length %d", cap, s.n);
         return SELLA_E_NOMEM;
     }
-    HIPCHK(hipMemsetAsync(nV, 0, pbytes, c->stream));
-    HIPCHK(hipMemsetAsync(nAV, 0, pbytes, c->stream));
-    HIPCHK(hipMemsetAsync(nVq, 0, pbytes, c->stream));
-    HIPCHK(hipMemsetAsync(nAVq, 0, pbytes, c->stream));
-    HIPCHK(hipMemsetAsync(nR, 0, pbytes, c->stream));
+    HIPCHK(s_memset0(c, nV, pbytes));
+    HIPCHK(s_memset0(c, nAV, pbytes));
+    HIPCHK(s_memset0(c, nVq, pbytes));
+    HIPCHK(s_memset0(c, nAVq, pbytes));
+    HIPCHK(s_memset0(c, nR, pbytes));
     if (s.qt_mode) {
         if (dev_alloc(c, 2 * pbytes, &nQt) != SELLA_OK) { set_error("davidson: cannot allocate the eigenbasis panels"); return SELLA_E_NOMEM; }
-        HIPCHK(hipMemsetAsync(nQt, 0, 2 * pbytes, c->stream));
+        HIPCHK(s_memset0(c, nQt, 2 * pbytes));
     }
     if (s.Vp) {
         const size_t old = (size_t)s.k * s.ld * sizeof(double);
         if (old) {
-            HIPCHK(hipMemcpyAsync(nV, s.Vp, old, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(nAV, s.AVp, old, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(s_memcpy(c, nV, s.Vp, old, hipMemcpyDeviceToDevice));
+            HIPCHK(s_memcpy(c, nAV, s.AVp, old, hipMemcpyDeviceToDevice));
             if (s.qt_mode && s.QtV) {
-                HIPCHK(hipMemcpyAsync(nQt, s.QtV, old, hipMemcpyDeviceToDevice, c->stream));
-                HIPCHK(hipMemcpyAsync(nQt + (size_t)cap * s.ld, s.QtAV, old, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(s_memcpy(c, nQt, s.QtV, old, hipMemcpyDeviceToDevice));
+                HIPCHK(s_memcpy(c, nQt + (size_t)cap * s.ld, s.QtAV, old, hipMemcpyDeviceToDevice));
             }
         }
         if (s.QtV) dev_free(c, s.QtV, 2 * s.pbytes);
@@ -106,7 +107,7 @@ int dav_alloc(Dav& s, int cap) {
 }
 
 void dav_free(Dav& s) {
-    if (s.c) (void)hipStreamSynchronize(s.c->stream);
+    if (s.c) (void)stream_sync_raw(s.c);
     if (s.Vp) {
         dev_free(s.c, s.Vp, s.pbytes); dev_free(s.c, s.AVp, s.pbytes); dev_free(s.c, s.Vq, s.pbytes);
         dev_free(s.c, s.AVq, s.pbytes); dev_free(s.c, s.Rp, s.pbytes);
@@ -148,6 +149,7 @@ int apply_A(Dav& s, const double* x, double* y) {
     sella_ctx* c = s.c;
     s.nmatvec++;
     if (s.A) return launch_gemv_rows(c, s.A->d, s.n, s.n, s.A->ld, x, s.ld, 1, y, s.ld, GemvEpi());
+    cohort_barrier(c, s.it, 2);               // (members of a cohort make the force calls behind their products together)
     s.hv.resize(s.n);
     s.hav.resize(s.n);
     SCHK(d2h_async(c, s.hv.data(), x, (size_t)s.n * sizeof(double)));
@@ -228,16 +230,19 @@ int apply_pinv_xp(Dav& s, double theta, const double* const* in, int m, double* 
 
 // mid_h[i] = in_h[i] / (d[i] - theta), h < nh (<= 2): the diagonal of (P - theta)^-1 in P's eigenbasis, with the exact-hit
 // guard of the matvec epilogue (kernels.hip, GemvEpi mode 1)
-__global__ __launch_bounds__(256) void dav_eigscale_kernel(int n, int nh, const double* __restrict__ in0,
+__device__ __forceinline__ void dav_eigscale_vb(const VB vb, int n, int nh, const double* __restrict__ in0,
                                                            const double* __restrict__ in1, const double* __restrict__ d,
                                                            double theta, double* __restrict__ mid, int ld) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = vb.x * 256 + threadIdx.x;
     if (i >= n) return;
     double den = d[i] - theta;
     if (den == 0.0) den = 2.220446049250313e-16 * fmax(fabs(theta), 2.2250738585072014e-308);
     mid[i] = in0[i] / den;
     if (nh > 1) mid[(size_t)ld + i] = in1[i] / den;
 }
+__global__ __launch_bounds__(256) void dav_eigscale_kernel(int n, int nh, const double* __restrict__ in0,
+                                                           const double* __restrict__ in1, const double* __restrict__ d,
+                                                           double theta, double* __restrict__ mid, int ld) { dav_eigscale_vb(vb_hw(), n, nh, in0, in1, d, theta, mid, ld); }
 
 // rows [row0, row0 + nrows) of the eigenbasis panels from the raw panels: QtV_a = Q^T V_a, QtAV_a = Q^T AV_a
 int qt_update(Dav& s, int row0, int nrows) {
@@ -370,7 +375,7 @@ __device__ __forceinline__ void df_rowsplit_sum(double (&acc)[NA], double (*xw)[
 // resid: R_j = sum_a ca_j[a] AV_a + cv_j[a] V_a (j < nneg), v = sum_a cw[a] V_a, from the RAW panels.
 // coef = [ca_0 .. ca_{nneg-1} | cv_0 .. cv_{nneg-1} | cw], k doubles each.
 template <int NJ>
-__global__ __launch_bounds__(256) void dav_resid_kernel(int n, int k, int nneg, const double* __restrict__ V,
+__device__ __forceinline__ void dav_resid_vb(const VB vb, int n, int k, int nneg, const double* __restrict__ V,
                                                         const double* __restrict__ AV, int ld,
                                                         const double* __restrict__ coef, double* __restrict__ R,
                                                         double* __restrict__ vout, double* __restrict__ part,
@@ -381,11 +386,11 @@ __global__ __launch_bounds__(256) void dav_resid_kernel(int n, int k, int nneg, 
     __shared__ double cs[(2 * NJ + 1) * DF_TILE];
     __shared__ double xw[4][NJ + 1][DF_EL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * DF_EL + lane;
-    const int j0 = blockIdx.y * NJ;
+    const int i = vb.x * DF_EL + lane;
+    const int j0 = vb.y * NJ;
     const bool valid = i < n;
     const int il = valid ? i : n - 1;
-    const bool dov = blockIdx.y == 0;
+    const bool dov = vb.y == 0;
     double acc[NJ + 1];
 #pragma unroll
     for (int q = 0; q <= NJ; ++q) acc[q] = 0.0;
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(256) void dav_resid_kernel(int n, int k, int nneg, 
                 if (valid) R[(size_t)(j0 + jj) * ld + i] = acc[jj];
                 if (valid && j0 + jj == seek) mid[i] = acc[jj] / den;
                 const double ss = wave_sum64(valid ? acc[jj] * acc[jj] : 0.0);
-                if (lane == 0) part[(size_t)(j0 + jj) * DF_MAXBLK + blockIdx.x] = ss;
+                if (lane == 0) part[(size_t)(j0 + jj) * DF_MAXBLK + vb.x] = ss;
             }
         }
         if (dov && valid) {
@@ -431,13 +436,20 @@ __global__ __launch_bounds__(256) void dav_resid_kernel(int n, int k, int nneg, 
         }
     }
 }
+template <int NJ>
+__global__ __launch_bounds__(256) void dav_resid_kernel(int n, int k, int nneg, const double* __restrict__ V,
+                                                        const double* __restrict__ AV, int ld,
+                                                        const double* __restrict__ coef, double* __restrict__ R,
+                                                        double* __restrict__ vout, double* __restrict__ part,
+                                                        int seek, const double* __restrict__ dscale, double theta,
+                                                        double* __restrict__ mid) { dav_resid_vb<NJ>(vb_hw(), n, k, nneg, V, AV, ld, coef, R, vout, part, seek, dscale, theta, mid); }
 
 // gs1: the correction vector and its first Gram-Schmidt sweep.
 //   mode 0: t = x (lanczos: x = r; gd: x = (P - theta)^-1 r)
 //   mode 1: t = y (v.x / v.y) - x with v.x = cw.dx, v.y = cw.dy; |v.y| < 1e-12 -> t = x   (eigensolvers.py:123-139)
 //   t1 = t - V^T (V t)  with V t = the same combination of dx = V x, dy = V y.
 // Partials: part[blk] = |t|^2, part[DF_MAXBLK + blk] = |t1|^2.  Workgroup 0 also finishes the residual norms.
-__global__ __launch_bounds__(256) void dav_gs1_kernel(int n, int k, const double* __restrict__ V, int ld,
+__device__ __forceinline__ void dav_gs1_vb(const VB vb, int n, int k, const double* __restrict__ V, int ld,
                                                       const double* __restrict__ x, const double* __restrict__ y,
                                                       const double* __restrict__ dx, const double* __restrict__ dy,
                                                       const double* __restrict__ cw, int mode,
@@ -448,7 +460,7 @@ __global__ __launch_bounds__(256) void dav_gs1_kernel(int n, int k, const double
     __shared__ double xw[4][1][DF_EL];
     __shared__ double red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * DF_EL + lane;
+    const int i = vb.x * DF_EL + lane;
     const bool valid = i < n;
     const int il = valid ? i : n - 1;
     double sfac = 0.0;
@@ -485,11 +497,11 @@ __global__ __launch_bounds__(256) void dav_gs1_kernel(int n, int k, const double
         const double s0 = wave_sum64(valid ? tv * tv : 0.0);
         const double s1 = wave_sum64(valid ? t1v * t1v : 0.0);
         if (lane == 0) {
-            part[blockIdx.x] = s0;
-            part[DF_MAXBLK + blockIdx.x] = s1;
+            part[vb.x] = s0;
+            part[DF_MAXBLK + vb.x] = s1;
         }
     }
-    if (blockIdx.x == 0) {
+    if (vb.x == 0) {
         for (int j = 0; j < nneg; ++j) {
             const double rr = df_sum_partials(rpart + (size_t)j * DF_MAXBLK, nblk, red);
             if (threadIdx.x == 0) scal[8 + j] = rr;
@@ -500,10 +512,17 @@ __global__ __launch_bounds__(256) void dav_gs1_kernel(int n, int k, const double
         }
     }
 }
+__global__ __launch_bounds__(256) void dav_gs1_kernel(int n, int k, const double* __restrict__ V, int ld,
+                                                      const double* __restrict__ x, const double* __restrict__ y,
+                                                      const double* __restrict__ dx, const double* __restrict__ dy,
+                                                      const double* __restrict__ cw, int mode,
+                                                      double* __restrict__ t1, double* __restrict__ part,
+                                                      const double* __restrict__ rpart, int nneg, int nblk,
+                                                      double* __restrict__ scal) { dav_gs1_vb(vb_hw(), n, k, V, ld, x, y, dx, dy, cw, mode, t1, part, rpart, nneg, nblk, scal); }
 
 // gs2: second sweep on t1/|t1| with c2 = V t1, and the image by linearity:
 //   t2 = (t1 - V^T c2) / |t1|,   A t2 = (A t1 - AV^T c2) / |t1|;   part2[blk] = |t2|^2
-__global__ __launch_bounds__(256) void dav_gs2_kernel(int n, int k, const double* __restrict__ V,
+__device__ __forceinline__ void dav_gs2_vb(const VB vb, int n, int k, const double* __restrict__ V,
                                                       const double* __restrict__ AV, int ld,
                                                       const double* __restrict__ t1, const double* __restrict__ At1,
                                                       const double* __restrict__ c2, const double* __restrict__ part1,
@@ -513,7 +532,7 @@ __global__ __launch_bounds__(256) void dav_gs2_kernel(int n, int k, const double
     __shared__ double xw[4][2][DF_EL];
     __shared__ double red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * DF_EL + lane;
+    const int i = vb.x * DF_EL + lane;
     const bool valid = i < n;
     const int il = valid ? i : n - 1;
     const double t1v = t1[il], a1v = At1[il];
@@ -539,16 +558,22 @@ __global__ __launch_bounds__(256) void dav_gs2_kernel(int n, int k, const double
             At2[i] = a2v;
         }
         const double s2 = wave_sum64(valid ? t2v * t2v : 0.0);
-        if (lane == 0) part2[blockIdx.x] = s2;
+        if (lane == 0) part2[vb.x] = s2;
     }
 }
+__global__ __launch_bounds__(256) void dav_gs2_kernel(int n, int k, const double* __restrict__ V,
+                                                      const double* __restrict__ AV, int ld,
+                                                      const double* __restrict__ t1, const double* __restrict__ At1,
+                                                      const double* __restrict__ c2, const double* __restrict__ part1,
+                                                      int nblk, double* __restrict__ t2, double* __restrict__ At2,
+                                                      double* __restrict__ part2) { dav_gs2_vb(vb_hw(), n, k, V, AV, ld, t1, At1, c2, part1, nblk, t2, At2, part2); }
 
 // final: normalise the new vector and its image into panel slot k and form the raw Gram dots in the same launch.
 //   blocks [0, nblke):       V_k = t2 / |t2|, AV_k = At2 / |t2|;  block 0 also stores the three squared norms
 //   block nblke + r, r < k:  out[r] = V_r . V_k,  out[cap + r] = V_r . AV_k
 //   block nblke + k + r:     out[2 cap + r] = AV_r . V_k
 //   block nblke + 2k:        out[cap + k] = V_k . AV_k,  out[k] = V_k . V_k
-__global__ __launch_bounds__(256) void dav_final_kernel(int n, int k, int cap, const double* __restrict__ V,
+__device__ __forceinline__ void dav_final_vb(const VB vb, int n, int k, int cap, const double* __restrict__ V,
                                                         const double* __restrict__ AV, int ld,
                                                         const double* __restrict__ t2, const double* __restrict__ At2,
                                                         const double* __restrict__ part1, const double* __restrict__ part2,
@@ -557,7 +582,7 @@ __global__ __launch_bounds__(256) void dav_final_kernel(int n, int k, int cap, c
     __shared__ double red[4];
     const double n2sq = df_sum_partials(part2, nblk, red);
     const double inv2 = 1.0 / sqrt(n2sq);
-    const int b = blockIdx.x;
+    const int b = vb.x;
     if (b < nblke) {
         const int i = b * 256 + threadIdx.x;
         if (i < n) {
@@ -610,6 +635,12 @@ __global__ __launch_bounds__(256) void dav_final_kernel(int n, int k, int cap, c
         }
     }
 }
+__global__ __launch_bounds__(256) void dav_final_kernel(int n, int k, int cap, const double* __restrict__ V,
+                                                        const double* __restrict__ AV, int ld,
+                                                        const double* __restrict__ t2, const double* __restrict__ At2,
+                                                        const double* __restrict__ part1, const double* __restrict__ part2,
+                                                        int nblk, int nblke, double* __restrict__ vslot,
+                                                        double* __restrict__ avslot, double* __restrict__ out) { dav_final_vb(vb_hw(), n, k, cap, V, AV, ld, t2, At2, part1, part2, nblk, nblke, vslot, avslot, out); }
 
 }  // namespace
 }  // namespace sella
@@ -699,8 +730,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         DCHK(upload_panel(c, v0, n, nv0, tmp, s.ld));
         for (int j = 0; j < nv0; ++j) {
             double* slot = s.Vp + (size_t)s.k * s.ld;
-            DHIP(hipMemcpyAsync(slot, tmp + (size_t)j * s.ld, (size_t)s.ld * sizeof(double), hipMemcpyDeviceToDevice,
-                                c->stream));
+            DHIP(s_memcpy(c, slot, tmp + (size_t)j * s.ld, (size_t)s.ld * sizeof(double), hipMemcpyDeviceToDevice));
             int kept = 0;
             DCHK(orthonormalise(s, slot, s.k, &kept, nullptr));
             if (kept) DCHK(append_vector(s, Wc));
@@ -732,6 +762,8 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         DHIP(hipEventCreate(&s.ev));
     }
     while (true) {
+        ++s.it;
+        cohort_barrier(c, s.it, 0);           // members of a cohort start their iterations together (cohort.h)
         const int k = s.k, cap = s.cap;
         double th0 = now();
         // ---- Rayleigh-Ritz (eigensolvers.py:57-64) ---------------------------------------
@@ -940,10 +972,10 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
             dim3 grid(nblk, (nneg + 3) / 4);             // nblk workgroups of 64 elements
             if (nneg == 1) {
                 grid.y = 1;
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(dav_resid_kernel<1>), grid, dim3(256), 0, c->stream, n, k, nneg, s.Vp, s.AVp,
+                SELLA_LAUNCHB(c, HIP_KERNEL_NAME(dav_resid_kernel<1>), SELLA_BODY(dav_resid_vb<1>), 256, grid, dim3(256), 0, n, k, nneg, s.Vp, s.AVp,
                                    s.ld, dC, s.Rp, vrow, rpart, -1, nullptr, 0.0, nullptr);
             } else {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(dav_resid_kernel<4>), grid, dim3(256), 0, c->stream, n, k, nneg, s.Vp, s.AVp,
+                SELLA_LAUNCHB(c, HIP_KERNEL_NAME(dav_resid_kernel<4>), SELLA_BODY(dav_resid_vb<4>), 256, grid, dim3(256), 0, n, k, nneg, s.Vp, s.AVp,
                                    s.ld, dC, s.Rp, vrow, rpart, -1, nullptr, 0.0, nullptr);
             }
             HIPCHK(hipGetLastError());
@@ -953,7 +985,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         auto launch_expand = [&](int seek, double theta, int* mode) -> int {
             const double* r = s.Rp + (size_t)seek * s.ld;
             if (method == SELLA_DAV_LANCZOS) {
-                HIPCHK(hipMemcpyAsync(out, r, (size_t)s.ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(s_memcpy(c, out, r, (size_t)s.ld * sizeof(double), hipMemcpyDeviceToDevice));
                 *mode = 0;
             } else if (method == SELLA_DAV_GD) {
                 const double* rr[1] = {r};
@@ -994,15 +1026,15 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
                 const int fseek = fuse ? seek_pred : -1;
                 if (nneg == 1) {
                     grid.y = 1;
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(dav_resid_kernel<1>), grid, dim3(256), 0, c->stream, n, k, nneg, s.QtV,
+                    SELLA_LAUNCHB(c, HIP_KERNEL_NAME(dav_resid_kernel<1>), SELLA_BODY(dav_resid_vb<1>), 256, grid, dim3(256), 0, n, k, nneg, s.QtV,
                                        s.QtAV, s.ld, dC, Rq, vq, rpart, fseek, s.pevals_dev, lams[seek_pred], mid);
                 } else {
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(dav_resid_kernel<4>), grid, dim3(256), 0, c->stream, n, k, nneg, s.QtV,
+                    SELLA_LAUNCHB(c, HIP_KERNEL_NAME(dav_resid_kernel<4>), SELLA_BODY(dav_resid_vb<4>), 256, grid, dim3(256), 0, n, k, nneg, s.QtV,
                                        s.QtAV, s.ld, dC, Rq, vq, rpart, fseek, s.pevals_dev, lams[seek_pred], mid);
                 }
                 mode = (method == SELLA_DAV_GD) ? 0 : 1;
                 if (!fuse)
-                    hipLaunchKernelGGL(dav_eigscale_kernel, dim3(nblke), dim3(256), 0, c->stream, n, mode == 1 ? 2 : 1,
+                    SELLA_LAUNCHB(c, dav_eigscale_kernel, dav_eigscale_vb, 256, dim3(nblke), dim3(256), 0, n, mode == 1 ? 2 : 1,
                                        Rq + (size_t)seek_pred * s.ld, vq, s.pevals_dev, lams[seek_pred], mid, s.ld);
                 DHIP(hipGetLastError());
                 DCHK(launch_gemv_rows(c, s.Q->d, n, n, s.Q->ld, mid, s.ld, mode == 1 ? 2 : 1, out, s.ld, GemvEpi()));
@@ -1014,14 +1046,14 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
                 const double* xs[2] = {out, out + s.ld};           // V.[x y] in one launch: dyd = dxd + ld
                 DCHK(launch_gemv_rows_xp(c, s.Vp, k, n, s.ld, xs, mode == 1 ? 2 : 1, dxd, s.ld, GemvEpi()));
             }
-            hipLaunchKernelGGL(dav_gs1_kernel, dim3(nblk), dim3(256), 0, c->stream, n, k, s.Vp, s.ld, out, out + s.ld, dxd,
+            SELLA_LAUNCHB(c, dav_gs1_kernel, dav_gs1_vb, 256, dim3(nblk), dim3(256), 0, n, k, s.Vp, s.ld, out, out + s.ld, dxd,
                                dyd, s.dcoef + (size_t)2 * nneg * k, mode, t1, part, rpart, nneg, nblk, dsc + S0);
             DHIP(hipGetLastError());
             s.nmatvec++;
             DCHK(launch_gemv_rows2(c, s.A->d, n, s.A->ld, s.Vp, k, s.ld, n, t1, At1, c2d));     // [A; V] t1 in one launch
-            hipLaunchKernelGGL(dav_gs2_kernel, dim3(nblk), dim3(256), 0, c->stream, n, k, s.Vp, s.AVp, s.ld, t1, At1, c2d, part,
+            SELLA_LAUNCHB(c, dav_gs2_kernel, dav_gs2_vb, 256, dim3(nblk), dim3(256), 0, n, k, s.Vp, s.AVp, s.ld, t1, At1, c2d, part,
                                nblk, t2, At2, part + 2 * DF_MAXBLK);
-            hipLaunchKernelGGL(dav_final_kernel, dim3(nblke + 2 * k + 1), dim3(256), 0, c->stream, n, k, capn, s.Vp, s.AVp, s.ld,
+            SELLA_LAUNCHB(c, dav_final_kernel, dav_final_vb, 256, dim3(nblke + 2 * k + 1), dim3(256), 0, n, k, capn, s.Vp, s.AVp, s.ld,
                                t2, At2, part, part + 2 * DF_MAXBLK, nblk, nblke, s.Vp + (size_t)k * s.ld,
                                s.AVp + (size_t)k * s.ld, dsc);
             DHIP(hipGetLastError());
@@ -1031,12 +1063,11 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
                 // (they run while the host decides and does the next Rayleigh-Ritz step), wait for the mark only
                 const int cnt = (int)(S0 + 8 + nneg);
                 if (!c->opt.host_scalars)
-                    DHIP(hipMemcpyAsync(c->hscal + DS_GRAM, c->dscal + DS_GRAM, (size_t)cnt * sizeof(double),
-                                        hipMemcpyDeviceToHost, c->stream));
+                    DHIP(s_memcpy(c, c->hscal + DS_GRAM, c->dscal + DS_GRAM, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, true));
                 DHIP(hipEventRecord(s.ev, c->stream));
                 const double* xs[2] = {s.Vp + (size_t)k * s.ld, s.AVp + (size_t)k * s.ld};
                 DCHK(launch_gemv_rows_xp(c, s.Qt->d, n, n, s.Qt->ld, xs, 2, s.QtV + (size_t)k * s.ld, capn * s.ld, GemvEpi()));
-                DHIP(hipEventSynchronize(s.ev));
+                DCHK(event_wait(c, s.ev));
             } else {
                 DCHK(sync_scalars(c, DS_GRAM, (int)(S0 + 8 + nneg)));
             }
@@ -1091,7 +1122,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
             // ---- correction vector (expand, :115-153) into panel slot k -----------------------
             double* t = s.Vp + (size_t)s.k * s.ld;
             auto copy_row = [&](double* dst, const double* src) -> int {
-                HIPCHK(hipMemcpyAsync(dst, src, (size_t)s.ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(s_memcpy(c, dst, src, (size_t)s.ld * sizeof(double), hipMemcpyDeviceToDevice));
                 return SELLA_OK;
             };
             if (method == SELLA_DAV_LANCZOS) {
@@ -1114,7 +1145,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
                 DCHK(scratch_get(c, SCR_AV2, (size_t)(kk + 1) * s.ld * sizeof(double), &pmid));
                 double* pin;
                 DCHK(scratch_get(c, SCR_R, (size_t)(kk + 1) * s.ld * sizeof(double), &pin));
-                DHIP(hipMemcpyAsync(pin, s.Vp, (size_t)kk * s.ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                DHIP(s_memcpy(c, pin, s.Vp, (size_t)kk * s.ld * sizeof(double), hipMemcpyDeviceToDevice));
                 DCHK(copy_row(pin + (size_t)kk * s.ld, r));
                 DCHK(apply_pinv(s, theta, pin, kk + 1, pmid, pv));
                 // G = V^T [Pinv V | Pinv r]  -> (kk+1) columns of kk entries
@@ -1177,6 +1208,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         }
         last_seek = seeking;
     }
+    cohort_barrier(c, 0xffffff, 0);           // (a cohort closes up behind loops of different length)
 
     if (dbg_time)
         fprintf(stderr, "davidson: k=%d total %.3f ms, host k x k algebra %.3f ms, fused iterations %ld, synchronous %ld\n", s.k,

@@ -288,12 +288,12 @@ int blk_alloc(Blk& s) {
     double** big[3] = {&s.V, &s.AV, &s.Vt};
     for (auto p : big) {
         SCHK(dev_alloc(c, s.bytesV, p));
-        HIPCHK(hipMemsetAsync(*p, 0, s.bytesV, c->stream));
+        HIPCHK(s_memset0(c, *p, s.bytesV));
     }
     double** small16[5] = {&s.R, &s.T, &s.T2, &s.MID, &s.AT};
     for (auto p : small16) {
         SCHK(dev_alloc(c, s.bytes16, p));
-        HIPCHK(hipMemsetAsync(*p, 0, s.bytes16, c->stream));
+        HIPCHK(s_memset0(c, *p, s.bytes16));
     }
     SCHK(dev_alloc(c, s.bytesC, &s.dC));
     if (s.gather) {
@@ -301,14 +301,14 @@ int blk_alloc(Blk& s) {
         s.bytesR = s.bytesS * s.world;
         SCHK(dev_alloc(c, s.bytesS, &s.send));
         SCHK(dev_alloc(c, s.bytesR, &s.recv));
-        HIPCHK(hipMemsetAsync(s.send, 0, s.bytesS, c->stream));
+        HIPCHK(s_memset0(c, s.send, s.bytesS));
     }
     s.G.assign((size_t)s.kcap * s.kcap, 0.0);
     s.dev_rr = s.maxvec <= BD_JMAX && c->opt.bd_dev_rr;      // the basis never holds more than maxvec vectors
     if (s.dev_rr) {
         const size_t kk2 = (size_t)s.kcap * s.kcap;
         SCHK(dev_alloc(c, (3 * kk2 + 2 * (size_t)s.kcap + 16) * sizeof(double), &s.dG));
-        HIPCHK(hipMemsetAsync(s.dG, 0, (3 * kk2 + 2 * (size_t)s.kcap + 16) * sizeof(double), c->stream));
+        HIPCHK(s_memset0(c, s.dG, (3 * kk2 + 2 * (size_t)s.kcap + 16) * sizeof(double)));
         s.dWt = s.dG + kk2;
         s.dWtmp = s.dWt + kk2;
         s.dtheta = s.dWtmp + kk2;
@@ -441,7 +441,7 @@ int svqb(Blk& s, double*& T, double*& T2, int nt, bool has_pre, double drop, int
         for (int a = 0; a < m; ++a) Ch[(size_t)jj * nt + live[a]] = dinv[a] * U[(size_t)a * m + j] * f;
     }
     SCHK(put_coeffs(s, Ch, mk, nt));
-    HIPCHK(hipMemsetAsync(T2, 0, s.bytes16, c->stream));
+    HIPCHK(s_memset0(c, T2, s.bytes16));
     SCHK(combine(s, mk, nt, s.dC, s.kcap, T, 1.0, 0.0, T2));
     std::swap(T, T2);
     *kept = mk;
@@ -590,18 +590,16 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
     while (true) {
         // ---- append the orthonormal block in s.T: V, AV, Gram rows ------------------------------------------
         const int k0 = s.k, nbk = kept;
-        BHIP(hipMemcpyAsync(s.V + (size_t)k0 * s.ld, s.T, (size_t)nbk * s.ld * sizeof(double), hipMemcpyDeviceToDevice,
-                            c->stream));
+        BHIP(s_memcpy(c, s.V + (size_t)k0 * s.ld, s.T, (size_t)nbk * s.ld * sizeof(double), hipMemcpyDeviceToDevice));
         if (nbk < BD_NB)      // rows [nbk, 16) of the panel operand must be zero
-            BHIP(hipMemsetAsync(s.T + (size_t)nbk * s.ld, 0, (size_t)(BD_NB - nbk) * s.ld * sizeof(double), c->stream));
+            BHIP(s_memset0(c, s.T + (size_t)nbk * s.ld, (size_t)(BD_NB - nbk) * s.ld * sizeof(double)));
         BCHK(apply_A(s, s.T, nbk, s.AT));
-        BHIP(hipMemcpyAsync(s.AV + (size_t)k0 * s.ld, s.AT, (size_t)nbk * s.ld * sizeof(double), hipMemcpyDeviceToDevice,
-                            c->stream));
+        BHIP(s_memcpy(c, s.AV + (size_t)k0 * s.ld, s.AT, (size_t)nbk * s.ld * sizeof(double), hipMemcpyDeviceToDevice));
         s.k = k0 + nbk;
         {
             double* dY = c->dscal + DS_GRAM;                                   // dY[h * kcap + a] = V_a . (A T)_h
             if (nbk < BD_NB)
-                BHIP(hipMemsetAsync(s.AT + (size_t)nbk * s.ld, 0, (size_t)(BD_NB - nbk) * s.ld * sizeof(double), c->stream));
+                BHIP(s_memset0(c, s.AT + (size_t)nbk * s.ld, (size_t)(BD_NB - nbk) * s.ld * sizeof(double)));
             BCHK(launch_panel16(c, s.V, s.k, n, s.ld, s.AT, nbk, dY, s.kcap));
             if (s.dev_rr) {
                 hipLaunchKernelGGL(bd_gram_rows_kernel, dim3((nbk * s.k + 255) / 256), dim3(256), 0, c->stream, dY, s.kcap, k0,
@@ -653,7 +651,7 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
         int na = 0;
         Theta16 th;
         for (int h = 0; h < BD_NB; ++h) th.v[h] = 0.0;
-        BHIP(hipMemsetAsync(s.T, 0, s.bytes16, c->stream));
+        BHIP(s_memset0(c, s.T, s.bytes16));
         nconv = 0;
         for (int j0 = 0; j0 < nwant; j0 += BD_NB) {
             const int nh = std::min(BD_NB, nwant - j0);
@@ -689,8 +687,8 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
             int run_src = -1, run_dst = 0, run_len = 0;              // consecutive residual rows travel as one copy
             auto flush_run = [&]() -> int {
                 if (run_len > 0)
-                    HIPCHK(hipMemcpyAsync(s.T + (size_t)run_dst * s.ld, s.R + (size_t)run_src * s.ld,
-                                          (size_t)run_len * s.ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                    HIPCHK(s_memcpy(c, s.T + (size_t)run_dst * s.ld, s.R + (size_t)run_src * s.ld,
+                                          (size_t)run_len * s.ld * sizeof(double), hipMemcpyDeviceToDevice));
                 run_len = 0;
                 return SELLA_OK;
             };
@@ -733,7 +731,7 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
             BCHK(launch_panel16(c, s.Qt->d, n, n, s.ld, s.T, na, s.MID, s.ld));
             hipLaunchKernelGGL(bd_shift_scale_kernel, dim3((n + 255) / 256, na), dim3(256), 0, c->stream, n, na, s.MID, s.ld,
                                s.dP, th, s.guard);
-            if (na < BD_NB) BHIP(hipMemsetAsync(s.MID + (size_t)na * s.ld, 0, (size_t)(BD_NB - na) * s.ld * sizeof(double), c->stream));
+            if (na < BD_NB) BHIP(s_memset0(c, s.MID + (size_t)na * s.ld, (size_t)(BD_NB - na) * s.ld * sizeof(double)));
             BCHK(launch_panel16(c, s.Q->d, n, n, s.ld, s.MID, na, s.T, s.ld));
         } else if (s.dP) {
             hipLaunchKernelGGL(bd_shift_scale_kernel, dim3((n + 255) / 256, na), dim3(256), 0, c->stream, n, na, s.T, s.ld, s.dP,
@@ -757,8 +755,8 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
                     BCHK(put_coeffs(s, Ch, nh, s.k));
                     BCHK(combine(s, nh, s.k, s.dC, s.kcap, src, 1.0, 0.0, s.Vt + (size_t)j0 * s.ld));
                 }
-                BHIP(hipMemcpyAsync(src, s.Vt, (size_t)keep * s.ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-                BHIP(hipMemsetAsync(src + (size_t)keep * s.ld, 0, (size_t)(s.kcap - keep) * s.ld * sizeof(double), c->stream));
+                BHIP(s_memcpy(c, src, s.Vt, (size_t)keep * s.ld * sizeof(double), hipMemcpyDeviceToDevice));
+                BHIP(s_memset0(c, src + (size_t)keep * s.ld, (size_t)(s.kcap - keep) * s.ld * sizeof(double)));
             }
             if (s.dev_rr) {
                 hipLaunchKernelGGL(bd_gram_reset_kernel, dim3((s.kcap * s.kcap + 255) / 256), dim3(256), 0, c->stream, s.dG,

@@ -2200,7 +2200,7 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
     double* mdraw;                                    // per-merge parameters (the stage-1 partial buffer is free now)
     SCHK(scratch_get(c, SCR_MISC1, ((size_t)n / 2 + 8) * sizeof(MergeDev), &mdraw));
     MergeDev* mdd = reinterpret_cast<MergeDev*>(mdraw);
-    HIPCHK(hipMemsetAsync(info, 0, 8 * sizeof(int), c->stream));
+    HIPCHK(s_memset0(c, info, 8 * sizeof(int)));
     HIPCHK(hipMemcpyAsync(rdev, ranges, nranges * sizeof(int), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(set_identity_kernel, dim3((n + 255) / 256, n), dim3(256), 0, c->stream, W.Za, ld, n);
     hipLaunchKernelGGL(leaf_ql_kernel, dim3((unsigned)leaves.size()), dim3(64), 0, c->stream, ddev, edev, wdev,
@@ -2255,7 +2255,7 @@ static int dc_solve(EighWork& W, std::vector<double>& d, std::vector<double>& e,
     // diagonal blocks must read as zero.  One clearing of the second buffer suffices: level h overwrites
     // its diagonal blocks completely (K updated + N-K deflated rows of N columns each), and the blocks
     // this buffer held two levels earlier lie inside them.
-    HIPCHK(hipMemsetAsync(nxt, 0, (size_t)n * ld * sizeof(double), c->stream));
+    HIPCHK(s_memset0(c, nxt, (size_t)n * ld * sizeof(double)));
     // (1) of a level — the rank-one vectors of all its merges: one launch and one download, queued (not waited for) by
     // the level BEFORE it, right behind that level's last kernel: the vectors are rows of the eigenvector blocks just
     // written, nothing the host has to decide first.  So a level costs ONE synchronisation, which hands over the previous
@@ -2443,7 +2443,7 @@ static int tridiagonalise(EighWork& W, double* taus, double* dvec, double* evec)
     // a panel every entry of V_p, W_p that meets a non-zero factor has been written by this panel (indices >= j0 + p + 1);
     // the entries in front of it — left over from the previous panel — only ever meet the zeros of the masked row u',
     // so they must be finite, nothing more: the shared scratch may hold anything before the first panel.
-    HIPCHK(hipMemsetAsync(Vp, 0, (size_t)2 * nb * ld * sizeof(double), c->stream));
+    HIPCHK(s_memset0(c, Vp, (size_t)2 * nb * ld * sizeof(double)));
     const int maxblkA = (n + 255) / 256 + 1, maxblkB = (n + 16 + 2 * TRD_NBMAX + 1) / 2 + 1;
     SCHK(scratch_get(c, SCR_MISC1, ((size_t)2 * maxblkA * TRD_PA + 2 * (size_t)maxblkB + 4 * TRD_NBMAX + 128) * sizeof(double), &part));
     double* partA[2] = {part, part + (size_t)maxblkA * TRD_PA};
@@ -2714,7 +2714,7 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int nr, int n, int ld, do
     const int nr_in = nr;
     if (append_lam0) {
         double* slot = Vt + (size_t)nr * ld;
-        HIPCHK(hipMemcpyAsync(slot, q, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(s_memcpy(c, slot, q, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice));
         SCHK(gs_project_twice(c, Vt, ld, nr, slot, n));          // sweep norms -> scalar slots 8, 9, 10
         ++nr;                                                     // z includes the speculative row
     }
@@ -2733,7 +2733,7 @@ static int eig_rank1_update(sella_ctx* c, EighWork& W, int nr, int n, int ld, do
     int* hr2 = hr1 + n;
     int* hidx = hr1 + 2 * (size_t)n;
     HIPCHK(hipMemcpyAsync(z, zdev, (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemsetAsync(info, 0, 8 * sizeof(int), c->stream));
+    HIPCHK(s_memset0(c, info, 8 * sizeof(int)));
     if (append_lam0) SCHK(sync_scalars(c, 8, 3));
     else SCHK(stream_wait(c));
     if (append_lam0) {
@@ -2960,7 +2960,7 @@ int eig_lowrank_update(sella_ctx* c, int n, double* w, Mat* V, Mat* Vt, const do
     int mb = 0;
     for (int v = 0; v < m; ++v) {
         double* slot = Qb + (size_t)mb * ld;
-        HIPCHK(hipMemcpyAsync(slot, src + (size_t)v * ld, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(s_memcpy(c, slot, src + (size_t)v * ld, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice));
         int kept = 0;
         // a vector is dropped only when nothing but rounding noise is left of it
         SCHK(gs_orthonormalise(c, Qb, ld, mb, slot, n, 1e-15, 1e-13, 100, &kept, nullptr));
@@ -3183,7 +3183,7 @@ int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, M
             for (int h = 0; h < m; ++h) {
                 if (!(c->hscal[DS_CVEC + h] > 1e-26 * rown2[h])) continue;
                 double* slot = Qb + (size_t)mb * ld;
-                HIPCHK(hipMemcpyAsync(slot, Res + (size_t)h * ld, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(s_memcpy(c, slot, Res + (size_t)h * ld, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice));
                 int kept = 0;
                 SCHK(gs_orthonormalise(c, Qb, ld, mb, slot, n, 1e-15, 1e-13, 100, &kept, nullptr));
                 if (kept) ++mb;
@@ -3194,7 +3194,7 @@ int lr_lowrank_update(sella_ctx* c, int n, int* r_io, double* mu, double lam0, M
     if (!blocked) {
     for (int v = 0; v < m; ++v) {
         double* slot = Qb + (size_t)mb * ld;
-        HIPCHK(hipMemcpyAsync(slot, src + (size_t)v * ld, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(s_memcpy(c, slot, src + (size_t)v * ld, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice));
         int kept = 0;
         SCHK(gs_orthonormalise(c, Qb, ld, mb, slot, n, 1e-15, 1e-13, 100, &kept, nullptr));
         if (kept) ++mb;
@@ -3316,7 +3316,7 @@ extern "C" int sella_rank1_eig(sella_ctx* c, int K, const double* D, const doubl
     double* Ud = buf + 6 * ldu + 64;
     HIPCHK(hipMemcpyAsync(Dd, D, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(wd, w, (size_t)K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(info, 0, 2 * sizeof(int), c->stream));
+    HIPCHK(s_memset0(c, info, 2 * sizeof(int)));
     hipLaunchKernelGGL(secular_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd, wd, rho, taud, orgd, lamd, info);
     hipLaunchKernelGGL(zhat_kernel, dim3((K + 3) / 4), dim3(256), 0, c->stream, K, Dd, wd, taud, orgd, zhd);
     hipLaunchKernelGGL(build_u_kernel, dim3(K), dim3(256), 0, c->stream, K, Dd, zhd, taud, orgd, Ud, ldu);
@@ -3379,7 +3379,7 @@ extern "C" int sella_eigh(sella_ctx* c, sella_mat hA, double* w, sella_mat* hV, 
     double* dvec = W.vec + (size_t)V_D * ld;
     double* evec = W.vec + (size_t)V_E * ld;
     double* taus = W.vec + (size_t)V_TAUS * ld;
-    HIPCHK(hipMemsetAsync(W.vec, 0, (size_t)V_NSLOTS * ld * sizeof(double), c->stream));
+    HIPCHK(s_memset0(c, W.vec, (size_t)V_NSLOTS * ld * sizeof(double)));
     SCHK(tridiagonalise(W, taus, dvec, evec));
     std::vector<double> d(n), e(n);
     {

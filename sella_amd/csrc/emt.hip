@@ -114,11 +114,11 @@ __device__ __forceinline__ int emt_pairs(const EmtArgs& a, double xi, double yi,
     return emt_pairs_impl<false>(a, xi, yi, zi, st, hits, heavy);
 }
 
-__global__ __launch_bounds__(256) void emt_density_kernel(EmtArgs a) {
+__device__ __forceinline__ void emt_density_vb(const VB vb, EmtArgs a) {
     __shared__ double red[4];
     __shared__ int hits[256][EMT_HCAP + 1];
     __shared__ EmtStage stage;
-    const int i = blockIdx.x;
+    const int i = vb.x;
     const double xi = a.pos[3 * i], yi = a.pos[3 * i + 1], zi = a.pos[3 * i + 2];
     const double n0i = a.p.n0[i], g1i = a.p.gamma1[i], g2i = a.p.gamma2[i], V0i = a.p.V0[i];
     double sig = 0.0, ep = 0.0;
@@ -155,13 +155,14 @@ __global__ __launch_bounds__(256) void emt_density_kernel(EmtArgs a) {
         a.dEdsig[i] = (a.p.E0[i] * xl * yl * a.p.lam[i] + z * a.p.kappa[i]) / (sig * a.beta * a.p.eta2[i]);
     }
 }
+__global__ __launch_bounds__(256) void emt_density_kernel(EmtArgs a) { emt_density_vb(vb_hw(), a); }
 
-__global__ __launch_bounds__(256) void emt_force_kernel(EmtArgs a) {
+__device__ __forceinline__ void emt_force_vb(const VB vb, EmtArgs a) {
     __shared__ double red[4];
     __shared__ int hits[256][EMT_HCAP + 1];
     __shared__ EmtStage stage;
     __shared__ int incomplete;
-    const int i = blockIdx.x;
+    const int i = vb.x;
     const double xi = a.pos[3 * i], yi = a.pos[3 * i + 1], zi = a.pos[3 * i + 2];
     const double n0i = a.p.n0[i], g1i = a.p.gamma1[i], g2i = a.p.gamma2[i], V0i = a.p.V0[i];
     const double eta2i = a.p.eta2[i], kapi = a.p.kappa[i], s0i = a.p.s0[i], dEi = a.dEdsig[i];
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(256) void emt_force_kernel(EmtArgs a) {
         a.grad[3 * i + 2] = gz;
     }
 }
+__global__ __launch_bounds__(256) void emt_force_kernel(EmtArgs a) { emt_force_vb(vb_hw(), a); }
 
 }  // namespace
 }  // namespace sella
@@ -273,8 +275,8 @@ int sella::emt_queue(sella_ctx* c, int n, const double* pos, const double* par, 
     a.rc = rc; a.acut = acut; a.cutoff = cutoff; a.beta = beta;
     a.sigma1 = dsig; a.epair = dep; a.dEdsig = dde; a.eatom = dea; a.grad = dgr;
     a.nbr = reinterpret_cast<int*>(dgr + 3 * (size_t)n + 32);
-    hipLaunchKernelGGL(emt_density_kernel, dim3(n), dim3(256), 0, c->stream, a);
-    hipLaunchKernelGGL(emt_force_kernel, dim3(n), dim3(256), 0, c->stream, a);
+    SELLA_LAUNCHB(c, emt_density_kernel, emt_density_vb, 256, dim3(n), dim3(256), 0, a);
+    SELLA_LAUNCHB(c, emt_force_kernel, emt_force_vb, 256, dim3(n), dim3(256), 0, a);
     HIPCHK(hipGetLastError());
     *eatom = dea;
     *grad = dgr;

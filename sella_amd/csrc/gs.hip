@@ -91,8 +91,7 @@ extern "C" int sella_mgs(sella_ctx* c, const double* X, int n, int nx, const dou
     int k = 0, ykept = 0;
     for (int col = 0; col < ny + nx; ++col) {
         double* slot = P + (size_t)k * ld;
-        HIPCHK(hipMemcpyAsync(slot, src + (size_t)col * ld, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice,
-                              c->stream));
+        HIPCHK(s_memcpy(c, slot, src + (size_t)col * ld, (size_t)ld * sizeof(double), hipMemcpyDeviceToDevice));
         int kept = 0;
         SCHK(gs_orthonormalise(c, P, ld, k, slot, n, eps1, eps2, maxiter, &kept, nullptr));
         if (kept) ++k;

@@ -16,6 +16,7 @@
 
 #define SELLA_HD __host__ __device__
 #include "small_linalg.h"
+#include "cohort.h"
 
 // "this value is in a register from here on": an empty statement the compiler cannot look through.  Placed behind a batch
 // of loads it keeps them unconditional and in flight together — otherwise a load whose only use sits behind a condition is
@@ -158,9 +159,17 @@ struct Options {
 
 }  // namespace sella
 
+struct sella_cohort;
+struct sella_search;
+extern "C" sella_ctx* sella_search_ctx(sella_search* search);
+
 struct sella_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // member of a cohort (cohort.h): while the cohort is being advanced, `stream` is the cohort's stream, batchable
+    // launches are parked and merged across the members, and every wait is one synchronisation for all of them
+    sella_cohort* cohort = nullptr;
+    unsigned long long cohort_phase = 0;       // (optimizer step << 8 | stage) of the member, the high part of its barrier keys
     // Handle table.  A deque: push_back never moves existing elements, so a `Mat*` obtained from mat_get stays valid
     // while the handle is live, even when a host callback (sella_matvec_fn / sella_allgather_fn) re-enters the library
     // and creates matrices.  (It was a std::vector until round 3: a reallocation inside the Davidson callback left
@@ -258,7 +267,17 @@ int d2h_async(sella_ctx* c, void* dst, const void* src_dev, size_t bytes);
 int d2h_async_2d(sella_ctx* c, void* dst, const void* src_dev, size_t spitch, size_t width, size_t rows);
 // THE wait of the library: stream synchronisation, then the queued device-to-host payloads are delivered and both
 // pinned rings rewound.  Every host-side wait goes through here (never hipStreamSynchronize directly).
+// Stream-ordered copies and zero-fills of the library.  Outside a cohort they ARE the runtime's hipMemcpyAsync /
+// hipMemsetAsync on the context's stream; on a member fiber of a cohort they are batchable kernels like every other launch
+// of the step (one launch for all members instead of one runtime blit per member) whenever both sides are visible to the
+// device — `host_pinned` says that the host side of an H2D / D2H copy is pinned (hipHostMalloc) memory.
+hipError_t s_memcpy(sella_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, bool host_pinned = false);
+hipError_t s_memcpy2d(sella_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows,
+                      hipMemcpyKind kind, bool host_pinned = false);
+hipError_t s_memset0(sella_ctx* c, void* dst, size_t bytes);
 int stream_wait(sella_ctx* c);
+int stream_sync_raw(sella_ctx* c);                                  // the synchronisation alone (nothing delivered, rings kept)
+int event_wait(sella_ctx* c, hipEvent_t ev);                        // wait for an event recorded on the context's stream
 int read_scalars(sella_ctx* c, int offset, int count);             // dscal -> hscal (sync)
 // Where a kernel should put scalars that only the HOST consumes next: with `host_scalars` on, the pinned,
 // device-visible host mirror itself (zero-copy: the readback is then just the stream synchronisation and the
@@ -281,6 +300,16 @@ int prof_flush(sella_ctx* c);
                                   (c)->prof_b, 0, __VA_ARGS__);                                                   \
         else                                                                                         \
             hipLaunchKernelGGL((kernel), grid, block, shmem, (c)->stream, __VA_ARGS__);              \
+    } while (0)
+
+// the same for a kernel with a batchable body (cohort.h): parked and merged on a member fiber of a cohort
+#define SELLA_BODY(...) __VA_ARGS__
+#define SELLA_LAUNCHB_PROF(c, kernel, body, LB, grid, block, shmem, ...)                                     \
+    do {                                                                                                     \
+        if ((c)->cohort && sella::cohort_in_fiber())                                                         \
+            sella::cohort_launch<body, LB>((c), #body, dim3(grid), dim3(block), (size_t)(shmem), __VA_ARGS__); \
+        else                                                                                                 \
+            SELLA_LAUNCH(c, (kernel), grid, block, shmem, __VA_ARGS__);                                      \
     } while (0)
 
 enum ScratchSlot {

@@ -24,14 +24,14 @@ __device__ __forceinline__ double wave_sum(double v) { return wave_sum64(v); }
 // wavefront-per-row + LDS-staged-x variant this replaced.  Algorithmic traffic: 8*rows*cols bytes.
 // ------------------------------------------------------------------------------------
 template <int NRHS, int RB>
-__global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ A, int rows,
+__device__ __forceinline__ void gemv_rows_vb(const VB vb, const double* __restrict__ A, int rows,
                                                         int cols, int lda,
                                                         GemvX xp,
                                                         double* __restrict__ Y, int ldy,
                                                         GemvEpi epi) {
     __shared__ double red[4][RB][NRHS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = blockIdx.x * RB;
+    const int row0 = vb.x * RB;
     const double2* arow[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -106,18 +106,24 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict
         }
     }
 }
+template <int NRHS, int RB>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const double* __restrict__ A, int rows,
+                                                        int cols, int lda,
+                                                        GemvX xp,
+                                                        double* __restrict__ Y, int ldy,
+                                                        GemvEpi epi) { gemv_rows_vb<NRHS, RB>(vb_hw(), A, rows, cols, lda, xp, Y, ldy, epi); }
 
 template <int NRHS>
 static int gemv_rows_dispatch_rw(sella_ctx* c, int rb, const double* A, int rows, int cols, int lda,
                                  const GemvX& xp, double* Y, int ldy, const GemvEpi& epi) {
     if (rb == 4) {
-        SELLA_LAUNCH(c, HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 4>), dim3((rows + 3) / 4), dim3(256), 0,
+        SELLA_LAUNCHB_PROF(c, HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 4>), SELLA_BODY(gemv_rows_vb<NRHS, 4>), 256, dim3((rows + 3) / 4), dim3(256), 0,
                      A, rows, cols, lda, xp, Y, ldy, epi);
     } else if (rb == 2) {
-        SELLA_LAUNCH(c, HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 2>), dim3((rows + 1) / 2), dim3(256), 0,
+        SELLA_LAUNCHB_PROF(c, HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 2>), SELLA_BODY(gemv_rows_vb<NRHS, 2>), 256, dim3((rows + 1) / 2), dim3(256), 0,
                      A, rows, cols, lda, xp, Y, ldy, epi);
     } else {
-        SELLA_LAUNCH(c, HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 1>), dim3(rows), dim3(256), 0,
+        SELLA_LAUNCHB_PROF(c, HIP_KERNEL_NAME(gemv_rows_kernel<NRHS, 1>), SELLA_BODY(gemv_rows_vb<NRHS, 1>), 256, dim3(rows), dim3(256), 0,
                      A, rows, cols, lda, xp, Y, ldy, epi);
     }
     HIPCHK(hipGetLastError());
@@ -173,14 +179,14 @@ int launch_gemv_rows(sella_ctx* c, const double* A, int rows, int cols, int lda,
 
 // Two row sources, one right-hand side: rows [0, rows) come from A, rows [rows, rows + rows2) from A2 (same column
 // count); same streaming structure as gemv_rows_kernel<1, 2>.
-__global__ __launch_bounds__(256) void gemv_rows2_kernel(const double* __restrict__ A, int rows, int lda,
+__device__ __forceinline__ void gemv_rows2_vb(const VB vb, const double* __restrict__ A, int rows, int lda,
                                                          const double* __restrict__ A2, int rows2, int lda2, int cols,
                                                          const double* __restrict__ x, double* __restrict__ y,
                                                          double* __restrict__ y2) {
     constexpr int RB = 2;
     __shared__ double red[4][RB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = blockIdx.x * RB, rtot = rows + rows2;
+    const int row0 = vb.x * RB, rtot = rows + rows2;
     const double2* arow[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -226,6 +232,10 @@ __global__ __launch_bounds__(256) void gemv_rows2_kernel(const double* __restric
         }
     }
 }
+__global__ __launch_bounds__(256) void gemv_rows2_kernel(const double* __restrict__ A, int rows, int lda,
+                                                         const double* __restrict__ A2, int rows2, int lda2, int cols,
+                                                         const double* __restrict__ x, double* __restrict__ y,
+                                                         double* __restrict__ y2) { gemv_rows2_vb(vb_hw(), A, rows, lda, A2, rows2, lda2, cols, x, y, y2); }
 
 int launch_gemv_rows2(sella_ctx* c, const double* A, int rows, int lda, const double* A2, int rows2, int lda2, int cols,
                       const double* x, double* y, double* y2) {
@@ -235,14 +245,14 @@ int launch_gemv_rows2(sella_ctx* c, const double* A, int rows, int lda, const do
         return SELLA_E_INVALID;
     }
     prof_begin(c, PROF_GEMV, 8.0 * (rows + rows2) * (double)cols, 2.0 * (rows + rows2) * (double)cols);
-    SELLA_LAUNCH(c, gemv_rows2_kernel, dim3((rows + rows2 + 1) / 2), dim3(256), 0, A, rows, lda, A2, rows2, lda2, cols, x, y, y2);
+    SELLA_LAUNCHB_PROF(c, gemv_rows2_kernel, gemv_rows2_vb, 256, dim3((rows + rows2 + 1) / 2), dim3(256), 0, A, rows, lda, A2, rows2, lda2, cols, x, y, y2);
     prof_end(c);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
 
 // |x|^2 -> out[0], then x /= |x|  in ONE single-workgroup launch (n up to a few 10^4)
-__global__ __launch_bounds__(1024) void normalize_kernel(double* __restrict__ x, int n, double* __restrict__ out) {
+__device__ __forceinline__ void normalize_vb(const VB vb, double* __restrict__ x, int n, double* __restrict__ out) {
     __shared__ double red[16];
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 1024) s += x[i] * x[i];
@@ -256,9 +266,10 @@ __global__ __launch_bounds__(1024) void normalize_kernel(double* __restrict__ x,
     for (int i = threadIdx.x; i < n; i += 1024) x[i] *= f;
     if (threadIdx.x == 0) out[0] = tot;
 }
+__global__ __launch_bounds__(1024) void normalize_kernel(double* __restrict__ x, int n, double* __restrict__ out) { normalize_vb(vb_hw(), x, n, out); }
 
 int launch_normalize(sella_ctx* c, double* x, int n, double* out) {
-    hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(1024), 0, c->stream, x, n, out);
+    SELLA_LAUNCHB(c, normalize_kernel, normalize_vb, 1024, dim3(1), dim3(1024), 0, x, n, out);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
@@ -272,20 +283,20 @@ int launch_normalize(sella_ctx* c, double* x, int n, double* out) {
 constexpr int GEMVT_ROWS = 32;
 
 template <int NRHS>
-__global__ __launch_bounds__(256) void gemv_cols_partial_kernel(const double* __restrict__ A,
+__device__ __forceinline__ void gemv_cols_partial_vb(const VB vb, const double* __restrict__ A,
                                                                 int rows, int cols, int lda,
                                                                 const double* __restrict__ X,
                                                                 int ldx, double* __restrict__ part,
                                                                 int ldpart) {
     __shared__ double xs[NRHS * GEMVT_ROWS];
-    const int r0 = blockIdx.y * GEMVT_ROWS;
+    const int r0 = vb.y * GEMVT_ROWS;
     const int nr = (rows - r0 < GEMVT_ROWS) ? (rows - r0) : GEMVT_ROWS;
     for (int t = threadIdx.x; t < NRHS * GEMVT_ROWS; t += 256) {
         const int h = t / GEMVT_ROWS, r = t % GEMVT_ROWS;
         xs[t] = (r < nr) ? X[(size_t)h * ldx + r0 + r] : 0.0;
     }
     __syncthreads();
-    const int cp = blockIdx.x * 256 + threadIdx.x;
+    const int cp = vb.x * 256 + threadIdx.x;
     const int cols2 = (cols + 1) & ~1;
     if (2 * cp >= cols2) return;
     double2 acc[NRHS];
@@ -304,20 +315,30 @@ __global__ __launch_bounds__(256) void gemv_cols_partial_kernel(const double* __
     }
 #pragma unroll
     for (int h = 0; h < NRHS; ++h)
-        *reinterpret_cast<double2*>(part + ((size_t)blockIdx.y * NRHS + h) * ldpart + 2 * cp) = acc[h];
+        *reinterpret_cast<double2*>(part + ((size_t)vb.y * NRHS + h) * ldpart + 2 * cp) = acc[h];
 }
+template <int NRHS>
+__global__ __launch_bounds__(256) void gemv_cols_partial_kernel(const double* __restrict__ A,
+                                                                int rows, int cols, int lda,
+                                                                const double* __restrict__ X,
+                                                                int ldx, double* __restrict__ part,
+                                                                int ldpart) { gemv_cols_partial_vb<NRHS>(vb_hw(), A, rows, cols, lda, X, ldx, part, ldpart); }
 
-__global__ __launch_bounds__(256) void gemv_cols_reduce_kernel(const double* __restrict__ part,
+__device__ __forceinline__ void gemv_cols_reduce_vb(const VB vb, const double* __restrict__ part,
                                                                int ldpart, int nsplit, int nrhs,
                                                                int cols, double* __restrict__ Y,
                                                                int ldy) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int h = blockIdx.y;
+    const int j = vb.x * 256 + threadIdx.x;
+    const int h = vb.y;
     if (j >= cols) return;
     double s = 0.0;
     for (int sp = 0; sp < nsplit; ++sp) s += part[((size_t)sp * nrhs + h) * ldpart + j];
     Y[(size_t)h * ldy + j] = s;
 }
+__global__ __launch_bounds__(256) void gemv_cols_reduce_kernel(const double* __restrict__ part,
+                                                               int ldpart, int nsplit, int nrhs,
+                                                               int cols, double* __restrict__ Y,
+                                                               int ldy) { gemv_cols_reduce_vb(vb_hw(), part, ldpart, nsplit, nrhs, cols, Y, ldy); }
 
 template <int NRHS>
 static int gemv_cols_run(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* X,
@@ -329,11 +350,11 @@ static int gemv_cols_run(sella_ctx* c, const double* A, int rows, int cols, int 
     SCHK(scratch_get(c, SCR_PART, (size_t)nsplit * NRHS * ldpart * sizeof(double), &part));
     dim3 grid((cols2 / 2 + 255) / 256, nsplit);
     prof_begin(c, PROF_GEMV, 8.0 * rows * (double)cols, 2.0 * rows * (double)cols * NRHS);
-    SELLA_LAUNCH(c, HIP_KERNEL_NAME(gemv_cols_partial_kernel<NRHS>), grid, dim3(256), 0,
+    SELLA_LAUNCHB_PROF(c, HIP_KERNEL_NAME(gemv_cols_partial_kernel<NRHS>), SELLA_BODY(gemv_cols_partial_vb<NRHS>), 256, grid, dim3(256), 0,
                  A, rows, cols, lda, X, ldx, part, ldpart);
     prof_end(c);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(gemv_cols_reduce_kernel, dim3((cols + 255) / 256, NRHS), dim3(256), 0, c->stream,
+    SELLA_LAUNCHB(c, gemv_cols_reduce_kernel, gemv_cols_reduce_vb, 256, dim3((cols + 255) / 256, NRHS), dim3(256), 0,
                        part, ldpart, nsplit, NRHS, cols, Y, ldy);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
@@ -367,7 +388,7 @@ int launch_gemv_cols(sella_ctx* c, const double* A, int rows, int cols, int lda,
 constexpr int LC_NT = 8;     // outputs per thread
 constexpr int LC_JT = 128;   // panel rows per LDS tile of coefficients
 
-__global__ __launch_bounds__(256) void lincomb_kernel(int n, int nout, const double* __restrict__ P1,
+__device__ __forceinline__ void lincomb_vb(const VB vb, int n, int nout, const double* __restrict__ P1,
                                                       int ldp1, int k1,
                                                       const double* __restrict__ W1, int ldw1,
                                                       const double* __restrict__ P2, int ldp2,
@@ -375,8 +396,8 @@ __global__ __launch_bounds__(256) void lincomb_kernel(int n, int nout, const dou
                                                       int ldw2, double beta,
                                                       double* __restrict__ out, int ldo) {
     __shared__ double ws[LC_JT * LC_NT];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int c0 = blockIdx.y * LC_NT;
+    const int i = vb.x * 256 + threadIdx.x;
+    const int c0 = vb.y * LC_NT;
     double acc[LC_NT];
 #pragma unroll
     for (int c = 0; c < LC_NT; ++c) acc[c] = 0.0;
@@ -427,13 +448,20 @@ __global__ __launch_bounds__(256) void lincomb_kernel(int n, int nout, const dou
         }
     }
 }
+__global__ __launch_bounds__(256) void lincomb_kernel(int n, int nout, const double* __restrict__ P1,
+                                                      int ldp1, int k1,
+                                                      const double* __restrict__ W1, int ldw1,
+                                                      const double* __restrict__ P2, int ldp2,
+                                                      int k2, const double* __restrict__ W2,
+                                                      int ldw2, double beta,
+                                                      double* __restrict__ out, int ldo) { lincomb_vb(vb_hw(), n, nout, P1, ldp1, k1, W1, ldw1, P2, ldp2, k2, W2, ldw2, beta, out, ldo); }
 
 int launch_lincomb(sella_ctx* c, int n, int nout, const double* P1, int ldp1, int k1,
                    const double* W1, int ldw1, const double* P2, int ldp2, int k2,
                    const double* W2, int ldw2, double beta, double* out, int ldo) {
     if (n <= 0 || nout <= 0) return SELLA_OK;
     dim3 grid((n + 255) / 256, (nout + LC_NT - 1) / LC_NT);
-    hipLaunchKernelGGL(lincomb_kernel, grid, dim3(256), 0, c->stream, n, nout, P1, ldp1, k1, W1, ldw1,
+    SELLA_LAUNCHB(c, lincomb_kernel, lincomb_vb, 256, grid, dim3(256), 0, n, nout, P1, ldp1, k1, W1, ldw1,
                        P2, ldp2, k2, W2, ldw2, beta, out, ldo);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
@@ -443,10 +471,10 @@ int launch_lincomb(sella_ctx* c, int n, int nout, const double* P1, int ldp1, in
 // small vector kernels
 // ------------------------------------------------------------------------------------
 // one workgroup per row: 256 lanes take 16-byte pieces, four loads in flight each
-__global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restrict__ P, int ldp,
+__device__ __forceinline__ void rows_sumsq_vb(const VB vb, const double* __restrict__ P, int ldp,
                                                          int nrows, int n, double* __restrict__ out) {
     __shared__ double red[4];
-    const double* p = P + (size_t)blockIdx.x * ldp;
+    const double* p = P + (size_t)vb.x * ldp;
     double s = 0.0;
     // usually ONE row (the residual of the lowest Ritz pair): a single workgroup walks it, so the loads are
     // issued four at a time instead of one per trip (12 dependent trips at n = 3072 cost 12 us)
@@ -463,19 +491,21 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restric
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) out[vb.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+__global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restrict__ P, int ldp,
+                                                         int nrows, int n, double* __restrict__ out) { rows_sumsq_vb(vb_hw(), P, ldp, nrows, n, out); }
 
 int launch_rows_sumsq(sella_ctx* c, const double* P, int ldp, int nrows, int n, double* out) {
     if (nrows <= 0) return SELLA_OK;
-    hipLaunchKernelGGL(rows_sumsq_kernel, dim3(nrows), dim3(256), 0, c->stream, P, ldp, nrows, n, out);
+    SELLA_LAUNCHB(c, rows_sumsq_kernel, rows_sumsq_vb, 256, dim3(nrows), dim3(256), 0, P, ldp, nrows, n, out);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
 
-__global__ __launch_bounds__(256) void scale_by_kernel(double* __restrict__ x, int n,
+__device__ __forceinline__ void scale_by_vb(const VB vb, double* __restrict__ x, int n,
                                                        const double* __restrict__ scal, int mode) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = vb.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double s = scal[0];
     double f;
@@ -484,76 +514,88 @@ __global__ __launch_bounds__(256) void scale_by_kernel(double* __restrict__ x, i
     else f = s;
     x[i] *= f;
 }
+__global__ __launch_bounds__(256) void scale_by_kernel(double* __restrict__ x, int n,
+                                                       const double* __restrict__ scal, int mode) { scale_by_vb(vb_hw(), x, n, scal, mode); }
 
 int launch_scale_by(sella_ctx* c, double* x, int n, const double* scal, int mode) {
-    hipLaunchKernelGGL(scale_by_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, x, n, scal, mode);
+    SELLA_LAUNCHB(c, scale_by_kernel, scale_by_vb, 256, dim3((n + 255) / 256), dim3(256), 0, x, n, scal, mode);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
 
-__global__ __launch_bounds__(256) void jd_combine_kernel(const double* __restrict__ x,
+__device__ __forceinline__ void jd_combine_vb(const VB vb, const double* __restrict__ x,
                                                          const double* __restrict__ y,
                                                          const double* __restrict__ dots,
                                                          double* __restrict__ t, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = vb.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double num = dots[0], den = dots[1];
     // eigensolvers.py:127-132: t = y*(v.x / v.y) - x, or x itself when v.y ~ 0
     t[i] = (fabs(den) < 1e-12) ? x[i] : (y[i] * (num / den) - x[i]);
 }
+__global__ __launch_bounds__(256) void jd_combine_kernel(const double* __restrict__ x,
+                                                         const double* __restrict__ y,
+                                                         const double* __restrict__ dots,
+                                                         double* __restrict__ t, int n) { jd_combine_vb(vb_hw(), x, y, dots, t, n); }
 
 int launch_jd_combine(sella_ctx* c, const double* x, const double* y, const double* dots, double* t,
                       int n) {
-    hipLaunchKernelGGL(jd_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, x, y, dots, t, n);
+    SELLA_LAUNCHB(c, jd_combine_kernel, jd_combine_vb, 256, dim3((n + 255) / 256), dim3(256), 0, x, y, dots, t, n);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
 
 // (no __restrict__: callers may update in place)
-__global__ __launch_bounds__(256) void axpby_kernel(int n, double a, const double* x, double b,
+__device__ __forceinline__ void axpby_vb(const VB vb, int n, double a, const double* x, double b,
                                                     const double* y, double* z) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = vb.x * 256 + threadIdx.x;
     if (i >= n) return;
     double v = a * x[i];
     if (y != nullptr) v += b * y[i];
     z[i] = v;
 }
+__global__ __launch_bounds__(256) void axpby_kernel(int n, double a, const double* x, double b,
+                                                    const double* y, double* z) { axpby_vb(vb_hw(), n, a, x, b, y, z); }
 
 int launch_axpby(sella_ctx* c, int n, double a, const double* x, double b, const double* y, double* z) {
     if (n <= 0) return SELLA_OK;
-    hipLaunchKernelGGL(axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, a, x, b, y, z);
+    SELLA_LAUNCHB(c, axpby_kernel, axpby_vb, 256, dim3((n + 255) / 256), dim3(256), 0, n, a, x, b, y, z);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
 
-__global__ __launch_bounds__(256) void axpby2d_kernel(int rows, int cols, double a,
+__device__ __forceinline__ void axpby2d_vb(const VB vb, int rows, int cols, double a,
                                                       const double* __restrict__ A, int lda, double b,
                                                       const double* __restrict__ B, int ldb,
                                                       double* __restrict__ C, int ldc) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int i = blockIdx.y;
+    const int j = vb.x * 256 + threadIdx.x;
+    const int i = vb.y;
     if (j >= cols || i >= rows) return;
     double v = a * A[(size_t)i * lda + j];
     if (B != nullptr) v += b * B[(size_t)i * ldb + j];
     C[(size_t)i * ldc + j] = v;
 }
+__global__ __launch_bounds__(256) void axpby2d_kernel(int rows, int cols, double a,
+                                                      const double* __restrict__ A, int lda, double b,
+                                                      const double* __restrict__ B, int ldb,
+                                                      double* __restrict__ C, int ldc) { axpby2d_vb(vb_hw(), rows, cols, a, A, lda, b, B, ldb, C, ldc); }
 
 int launch_axpby2d(sella_ctx* c, int rows, int cols, double a, const double* A, int lda, double b,
                    const double* B, int ldb, double* C, int ldc) {
     if (rows <= 0 || cols <= 0) return SELLA_OK;
-    hipLaunchKernelGGL(axpby2d_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, c->stream, rows,
+    SELLA_LAUNCHB(c, axpby2d_kernel, axpby2d_vb, 256, dim3((cols + 255) / 256, rows), dim3(256), 0, rows,
                        cols, a, A, lda, b, B, ldb, C, ldc);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
 
 // 32x32 tiles through LDS (+1 padding), coalesced on both sides.
-__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ A, int rows,
+__device__ __forceinline__ void transpose_vb(const VB vb, const double* __restrict__ A, int rows,
                                                         int cols, int lda, double* __restrict__ At,
                                                         int ldat) {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int r0 = vb.y * 32, c0 = vb.x * 32;
     for (int k = ty; k < 32; k += 8) {
         const int r = r0 + k, cc = c0 + tx;
         tile[k][tx] = (r < rows && cc < cols) ? A[(size_t)r * lda + cc] : 0.0;
@@ -564,22 +606,24 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict
         if (cc < cols && r < rows) At[(size_t)cc * ldat + r] = tile[tx][k];
     }
 }
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ A, int rows,
+                                                        int cols, int lda, double* __restrict__ At,
+                                                        int ldat) { transpose_vb(vb_hw(), A, rows, cols, lda, At, ldat); }
 
 int launch_transpose(sella_ctx* c, const double* A, int rows, int cols, int lda, double* At, int ldat) {
     if (rows <= 0 || cols <= 0) return SELLA_OK;
-    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
-                       c->stream, A, rows, cols, lda, At, ldat);
+    SELLA_LAUNCHB(c, transpose_kernel, transpose_vb, 256, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, A, rows, cols, lda, At, ldat);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
 
 // In-place symmetrisation B <- (B + B^T)/2: block (bi, bj) with bi <= bj handles both tiles.
-__global__ __launch_bounds__(256) void symmetrize_kernel(double* __restrict__ B, int n, int ld) {
-    if (blockIdx.x < blockIdx.y) return;   // uniform per block
+__device__ __forceinline__ void symmetrize_vb(const VB vb, double* __restrict__ B, int n, int ld) {
+    if (vb.x < vb.y) return;   // uniform per block
     __shared__ double t1[32][33];
     __shared__ double t2[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;     // tile (r0, c0), mirror (c0, r0)
+    const int r0 = vb.y * 32, c0 = vb.x * 32;     // tile (r0, c0), mirror (c0, r0)
     for (int k = ty; k < 32; k += 8) {
         int r = r0 + k, cc = c0 + tx;
         t1[k][tx] = (r < n && cc < n) ? B[(size_t)r * ld + cc] : 0.0;
@@ -594,29 +638,34 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(double* __restrict__ B,
         if (r < n && cc < n) B[(size_t)r * ld + cc] = 0.5 * (t2[k][tx] + t1[tx][k]);
     }
 }
+__global__ __launch_bounds__(256) void symmetrize_kernel(double* __restrict__ B, int n, int ld) { symmetrize_vb(vb_hw(), B, n, ld); }
 
 int launch_symmetrize(sella_ctx* c, double* B, int n, int ld) {
     if (n <= 0) return SELLA_OK;
     const int nb = (n + 31) / 32;
-    hipLaunchKernelGGL(symmetrize_kernel, dim3(nb, nb), dim3(256), 0, c->stream, B, n, ld);
+    SELLA_LAUNCHB(c, symmetrize_kernel, symmetrize_vb, 256, dim3(nb, nb), dim3(256), 0, B, n, ld);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
 
-__global__ __launch_bounds__(256) void gather_rows_kernel(const double* __restrict__ in, int ldi,
+__device__ __forceinline__ void gather_rows_vb(const VB vb, const double* __restrict__ in, int ldi,
                                                           const int* __restrict__ idx, int nrows,
                                                           int ncols, double* __restrict__ out,
                                                           int ldo) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int r = blockIdx.y;
+    const int j = vb.x * 256 + threadIdx.x;
+    const int r = vb.y;
     if (j >= ncols || r >= nrows) return;
     out[(size_t)r * ldo + j] = in[(size_t)idx[r] * ldi + j];
 }
+__global__ __launch_bounds__(256) void gather_rows_kernel(const double* __restrict__ in, int ldi,
+                                                          const int* __restrict__ idx, int nrows,
+                                                          int ncols, double* __restrict__ out,
+                                                          int ldo) { gather_rows_vb(vb_hw(), in, ldi, idx, nrows, ncols, out, ldo); }
 
 int launch_gather_rows(sella_ctx* c, const double* in, int ldi, const int* idx, int nrows, int ncols,
                        double* out, int ldo) {
     if (nrows <= 0 || ncols <= 0) return SELLA_OK;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((ncols + 255) / 256, nrows), dim3(256), 0, c->stream, in,
+    SELLA_LAUNCHB(c, gather_rows_kernel, gather_rows_vb, 256, dim3((ncols + 255) / 256, nrows), dim3(256), 0, in,
                        ldi, idx, nrows, ncols, out, ldo);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
@@ -708,16 +757,21 @@ __device__ __forceinline__ void gemm_mfma_tile(int transA, int transB, int M, in
             }
 }
 
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(int transA, int transB, int M, int N, int K,
+__device__ __forceinline__ void gemm_mfma_vb(const VB vb, int transA, int transB, int M, int N, int K,
                                                         double alpha, const double* __restrict__ A,
                                                         int lda, const double* __restrict__ B,
                                                         int ldb, double beta, double* __restrict__ C,
                                                         int ldc) {
     __shared__ double As[GM_BK][GM_LD];
     __shared__ double Bs[GM_BK][GM_LD];
-    gemm_mfma_tile(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, blockIdx.y * GM_BM,
-                   blockIdx.x * GM_BN, As, Bs);
+    gemm_mfma_tile(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, vb.y * GM_BM,
+                   vb.x * GM_BN, As, Bs);
 }
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(int transA, int transB, int M, int N, int K,
+                                                        double alpha, const double* __restrict__ A,
+                                                        int lda, const double* __restrict__ B,
+                                                        int ldb, double beta, double* __restrict__ C,
+                                                        int ldc) { gemm_mfma_vb(vb_hw(), transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc); }
 
 // one launch for all merges of a divide-and-conquer level (blockIdx.z = merge)
 __global__ __launch_bounds__(256) void gemm_merge_batched_kernel(const int* __restrict__ desc,
@@ -892,7 +946,7 @@ int launch_gemm(sella_ctx* c, int transA, int transB, int M, int N, int K, doubl
         dim3 g2((N + G2_BN - 1) / G2_BN, (M + G2_BM - 1) / G2_BM);
         SELLA_LAUNCH(c, gemm128_kernel, g2, dim3(256), 0, transA, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc);
     } else if (c->opt.gemm_mfma)
-        SELLA_LAUNCH(c, gemm_mfma_kernel, grid, dim3(256), 0, transA, transB, M, N, K, alpha,
+        SELLA_LAUNCHB_PROF(c, gemm_mfma_kernel, gemm_mfma_vb, 256, grid, dim3(256), 0, transA, transB, M, N, K, alpha,
                      A, lda, B, ldb, beta, C, ldc);
     else
         SELLA_LAUNCH(c, gemm_valu_kernel, grid, dim3(256), 0, transA, transB, M, N, K, alpha,
@@ -924,15 +978,16 @@ int launch_gemm_merge_batched(sella_ctx* c, int nbatch, const int* desc, int max
 // straight from global memory as 32-byte vectors: lane (i, g) takes columns 4g..4g+3 of a 16-column
 // group for four successive v_mfma_f64_16x16x4_f64 (the summation index may be permuted freely).
 // ------------------------------------------------------------------------------------
-template <int RT>   // 16 RT rows per workgroup (RT = 1 .. 4, chosen by the launcher so that there are about 256 workgroups)
-__global__ __launch_bounds__(256) void panel16_mfma_kernel(const double* __restrict__ A, int rows, int ld,
+// 16 RT rows per workgroup (RT = 1 .. 4, chosen by the launcher so that there are about 256 workgroups)
+template <int RT>
+__device__ __forceinline__ void panel16_mfma_vb(const VB vb, const double* __restrict__ A, int rows, int ld,
                                                            const double* __restrict__ Xp, int nrhs,
                                                            double* __restrict__ Y, int ldy) {
     constexpr int WR = 16 * RT;
     __shared__ double part[4][WR][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    const int r0 = blockIdx.x * WR;
+    const int r0 = vb.x * WR;
     const double* arow[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
@@ -977,6 +1032,10 @@ __global__ __launch_bounds__(256) void panel16_mfma_kernel(const double* __restr
             Y[(size_t)h * ldy + r0 + row] = part[0][row][h] + part[1][row][h] + part[2][row][h] + part[3][row][h];
     }
 }
+template <int RT>
+__global__ __launch_bounds__(256) void panel16_mfma_kernel(const double* __restrict__ A, int rows, int ld,
+                                                           const double* __restrict__ Xp, int nrhs,
+                                                           double* __restrict__ Y, int ldy) { panel16_mfma_vb<RT>(vb_hw(), A, rows, ld, Xp, nrhs, Y, ldy); }
 
 // ---- short-and-wide panel products -----------------------------------------------------------------------------
 // Gram blocks and projections of the block methods: rows <= 64 (the basis), nrhs <= 16 (the block), cols = n long.
@@ -1078,13 +1137,13 @@ int launch_panel16(sella_ctx* c, const double* A, int rows, int cols, int lda, c
         rt = 16 * (per < 1 ? 1 : (per > 4 ? 4 : per));
     }
     if (rt == 48)
-        SELLA_LAUNCH(c, HIP_KERNEL_NAME(panel16_mfma_kernel<3>), dim3((rows + 47) / 48), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
+        SELLA_LAUNCHB_PROF(c, HIP_KERNEL_NAME(panel16_mfma_kernel<3>), SELLA_BODY(panel16_mfma_vb<3>), 256, dim3((rows + 47) / 48), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
     else if (rt == 64)
-        SELLA_LAUNCH(c, HIP_KERNEL_NAME(panel16_mfma_kernel<4>), dim3((rows + 63) / 64), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
+        SELLA_LAUNCHB_PROF(c, HIP_KERNEL_NAME(panel16_mfma_kernel<4>), SELLA_BODY(panel16_mfma_vb<4>), 256, dim3((rows + 63) / 64), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
     else if (rt == 32)
-        SELLA_LAUNCH(c, HIP_KERNEL_NAME(panel16_mfma_kernel<2>), dim3((rows + 31) / 32), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
+        SELLA_LAUNCHB_PROF(c, HIP_KERNEL_NAME(panel16_mfma_kernel<2>), SELLA_BODY(panel16_mfma_vb<2>), 256, dim3((rows + 31) / 32), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
     else
-        SELLA_LAUNCH(c, HIP_KERNEL_NAME(panel16_mfma_kernel<1>), dim3((rows + 15) / 16), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
+        SELLA_LAUNCHB_PROF(c, HIP_KERNEL_NAME(panel16_mfma_kernel<1>), SELLA_BODY(panel16_mfma_vb<1>), 256, dim3((rows + 15) / 16), dim3(256), 0, A, rows, lda, Xp, nrhs, Y, ldy);
     prof_end(c);
     HIPCHK(hipGetLastError());
     return SELLA_OK;

@@ -194,7 +194,8 @@ __device__ __forceinline__ void lr_pre_body(const PreArgs& a) {
     if (tid == 0) { a.sc[SC_SIG1] = sig[0]; a.sc[SC_SIG2] = sig[1]; }
 }
 
-__global__ __launch_bounds__(256) void lr_pre_kernel(PreArgs a) { lr_pre_body(a); }
+__device__ __forceinline__ void lr_pre_vb(const VB vb, PreArgs a) { lr_pre_body(a); }
+__global__ __launch_bounds__(256) void lr_pre_kernel(PreArgs a) { lr_pre_vb(vb_hw(), a); }
 
 struct PlanArgs {
     int fill = 0;                         // with `first`: Q is NOT initialised — the kernel writes the identity itself if (and
@@ -407,15 +408,17 @@ __device__ __forceinline__ void lr_plan_body(const PlanArgs& a) {
     for (int p = tid; p < ndf; p += 256) a.df[p] = sDf[p];
 }
 
-__global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) { lr_plan_body(a); }
+__device__ __forceinline__ void lr_plan_vb(const VB vb, PlanArgs a) { lr_plan_body(a); }
+__global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) { lr_plan_vb(vb_hw(), a); }
 
 // the first term's plan needs nothing but what lr_pre_kernel leaves: one workgroup does both (what the first writes to
 // global memory is visible to the whole workgroup behind the barrier)
-__global__ __launch_bounds__(256) void lr_pre_plan_kernel(PreArgs pa, PlanArgs pl) {
+__device__ __forceinline__ void lr_pre_plan_vb(const VB vb, PreArgs pa, PlanArgs pl) {
     lr_pre_body(pa);
     __syncthreads();
     lr_plan_body(pl);
 }
+__global__ __launch_bounds__(256) void lr_pre_plan_kernel(PreArgs pa, PlanArgs pl) { lr_pre_plan_vb(vb_hw(), pa, pl); }
 
 struct WaveSum2 {
     __device__ double operator()(double v) const { return wave_sum64(v); }
@@ -429,12 +432,12 @@ struct WaveProd2 {
 };
 
 // one wavefront per root; K and rho come from the plan kernel
-__global__ __launch_bounds__(256) void lr_secular_kernel(const int* __restrict__ cnt, const double* __restrict__ pl,
+__device__ __forceinline__ void lr_secular_vb(const VB vb, const int* __restrict__ cnt, const double* __restrict__ pl,
                                                          const double* __restrict__ D, const double* __restrict__ w,
                                                          double* __restrict__ tau, int* __restrict__ org,
                                                          double* __restrict__ lam, double* __restrict__ fail) {
     const int K = cnt[0];
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = vb.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (j >= K) return;
     int o;
@@ -447,17 +450,24 @@ __global__ __launch_bounds__(256) void lr_secular_kernel(const int* __restrict__
         if (it < 0) fail[0] = j + 1.0;
     }
 }
+__global__ __launch_bounds__(256) void lr_secular_kernel(const int* __restrict__ cnt, const double* __restrict__ pl,
+                                                         const double* __restrict__ D, const double* __restrict__ w,
+                                                         double* __restrict__ tau, int* __restrict__ org,
+                                                         double* __restrict__ lam, double* __restrict__ fail) { lr_secular_vb(vb_hw(), cnt, pl, D, w, tau, org, lam, fail); }
 
-__global__ __launch_bounds__(256) void lr_zhat_kernel(const int* __restrict__ cnt, const double* __restrict__ D,
+__device__ __forceinline__ void lr_zhat_vb(const VB vb, const int* __restrict__ cnt, const double* __restrict__ D,
                                                       const double* __restrict__ w, const double* __restrict__ tau,
                                                       const int* __restrict__ org, double* __restrict__ zh) {
     const int K = cnt[0];
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = vb.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= K) return;
     const double z = secular::zhat(K, D, w, tau, org, i, lane, 64, WaveProd2());
     if (lane == 0) zh[i] = z;
 }
+__global__ __launch_bounds__(256) void lr_zhat_kernel(const int* __restrict__ cnt, const double* __restrict__ D,
+                                                      const double* __restrict__ w, const double* __restrict__ tau,
+                                                      const int* __restrict__ org, double* __restrict__ zh) { lr_zhat_vb(vb_hw(), cnt, D, w, tau, org, zh); }
 
 struct ApplyArgs {
     int nr, ldq;
@@ -472,11 +482,11 @@ struct ApplyArgs {
 
 // Workgroup j: new eigenpair j of the term — an updated one (j < K: Gu/Eisenstat vector over the non-deflated columns)
 // or a deflated one (copied) — goes to its place in the ascending order of the new spectrum.
-__global__ __launch_bounds__(256) void lr_apply_kernel(ApplyArgs a) {
+__device__ __forceinline__ void lr_apply_vb(const VB vb, ApplyArgs a) {
     __shared__ double red[4];
     __shared__ double u[LR_DEV_MAX];
     __shared__ double zhs[LR_SMALL + 8];
-    const int tid = threadIdx.x, nr = a.nr, j = blockIdx.x;
+    const int tid = threadIdx.x, nr = a.nr, j = vb.x;
     const int K = a.cnt[0];
     const bool ident = a.first && a.cnt[1] == 0;
     if (a.wd && j < K) {
@@ -526,12 +536,13 @@ __global__ __launch_bounds__(256) void lr_apply_kernel(ApplyArgs a) {
         a.Qout[(size_t)k * a.ldq + pos] = acc * inv;
     }
 }
+__global__ __launch_bounds__(256) void lr_apply_kernel(ApplyArgs a) { lr_apply_vb(vb_hw(), a); }
 
 // e1 = R0 / |R0| -> out row 0;  R1 - (R0.R1 / R0.R0) R0 -> out row 1 (unnormalised; cleaned and measured afterwards).
 // Every workgroup derives the two scalars from the Gram matrix of the residual rows itself.
-__global__ __launch_bounds__(256) void lr_e1_kernel(const double* __restrict__ R, int ldr_, int n,
+__device__ __forceinline__ void lr_e1_vb(const VB vb, const double* __restrict__ R, int ldr_, int n,
                                                     const double* __restrict__ G, double* __restrict__ out, int ldo) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = vb.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double ss = G[G_SS], a11 = G[G_A11], a12 = G[G_A12];
     const bool keep1 = ss > 0.0 && a11 > 1e-26 * ss;
@@ -540,15 +551,17 @@ __global__ __launch_bounds__(256) void lr_e1_kernel(const double* __restrict__ R
     out[i] = r0 * inv;
     out[ldo + i] = r1 - f * r0;
 }
+__global__ __launch_bounds__(256) void lr_e1_kernel(const double* __restrict__ R, int ldr_, int n,
+                                                    const double* __restrict__ G, double* __restrict__ out, int ldo) { lr_e1_vb(vb_hw(), R, ldr_, n, G, out, ldo); }
 
 // R_h -= sum_j C[h * ldc + j] W_j for both residual rows in ONE pass over W (C holds the negated coefficients: added)
-__global__ __launch_bounds__(256) void lr_proj2_kernel(const double* __restrict__ W, int ldw, int r, int n,
+__device__ __forceinline__ void lr_proj2_vb(const VB vb, const double* __restrict__ W, int ldw, int r, int n,
                                                        const double* __restrict__ C, int ldc, double* __restrict__ R,
                                                        int ldr_) {
     __shared__ double c0[LR_DEV_MAX], c1[LR_DEV_MAX];
     for (int j = threadIdx.x; j < r; j += 256) { c0[j] = C[j]; c1[j] = C[ldc + j]; }
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = vb.x * 256 + threadIdx.x;
     if (i >= n) return;
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
     int j = 0;
@@ -567,6 +580,9 @@ __global__ __launch_bounds__(256) void lr_proj2_kernel(const double* __restrict_
     R[i] += a0 + b0;
     R[ldr_ + i] += a1 + b1;
 }
+__global__ __launch_bounds__(256) void lr_proj2_kernel(const double* __restrict__ W, int ldw, int r, int n,
+                                                       const double* __restrict__ C, int ldc, double* __restrict__ R,
+                                                       int ldr_) { lr_proj2_vb(vb_hw(), W, ldw, r, n, C, ldc, R, ldr_); }
 
 
 // ---- the fused chain (option lr_chain, default): the O(n r) passes of a job as five launches ----------------------------
@@ -639,7 +655,7 @@ struct SweepArgs {
     double* Csum;                               // the coefficients applied here, summed (workgroup 0 writes them; null: not wanted)
 };
 
-__global__ __launch_bounds__(256) void lr_sweep_kernel(SweepArgs a) {
+__device__ __forceinline__ void lr_sweep_vb(const VB vb, SweepArgs a) {
     __shared__ double c0[LR_DEV_MAX], c1[LR_DEV_MAX], xs[4][LR_CHUNK];
     const int tid = threadIdx.x, r = a.r, lane = tid & 63;
     for (int j = tid; j < r; j += 256) {
@@ -659,9 +675,9 @@ __global__ __launch_bounds__(256) void lr_sweep_kernel(SweepArgs a) {
             c0[j] = s0 + t0;
             c1[j] = s1 + t1;
         }
-        if (a.Csum && blockIdx.x == 0) { a.Csum[j] = c0[j]; a.Csum[a.ldc + j] = c1[j]; }
+        if (a.Csum && vb.x == 0) { a.Csum[j] = c0[j]; a.Csum[a.ldc + j] = c1[j]; }
     }
-    const int c = blockIdx.x * LR_CHUNK + lane;
+    const int c = vb.x * LR_CHUNK + lane;
     const bool valid = c < a.n;
     const int cl = valid ? c : a.n - 1;
     const double x0 = valid ? a.R[c] : 0.0, x1 = valid ? a.R[a.ldr_ + c] : 0.0;      // (in flight across the barrier)
@@ -673,18 +689,19 @@ __global__ __launch_bounds__(256) void lr_sweep_kernel(SweepArgs a) {
     const double r1 = valid ? x1 + sum1 : 0.0;
     if (valid && tid < 64) { a.R[c] = r0; a.R[a.ldr_ + c] = r1; }
     if (a.Cout)
-        rows_dots(a.W, a.ldw, r, cl, valid, r0, r1, a.Cout + (size_t)(2 * blockIdx.x) * a.ldc,
-                  a.Cout + (size_t)(2 * blockIdx.x + 1) * a.ldc);
+        rows_dots(a.W, a.ldw, r, cl, valid, r0, r1, a.Cout + (size_t)(2 * vb.x) * a.ldc,
+                  a.Cout + (size_t)(2 * vb.x + 1) * a.ldc);
     if (a.GP && tid < 64) {
         const double gv = (a.g && valid) ? a.g[c] : 0.0;
         const double s11 = lanes_sum(r0 * r0), s12 = lanes_sum(r0 * r1), s22 = lanes_sum(r1 * r1);
         const double s0g = lanes_sum(r0 * gv), s1g = lanes_sum(r1 * gv);
         if (tid == 0) {
-            double* o = a.GP + 8 * blockIdx.x;
+            double* o = a.GP + 8 * vb.x;
             o[GP_A11] = s11; o[GP_A12] = s12; o[GP_A22] = s22; o[GP_R0G] = s0g; o[GP_R1G] = s1g;
         }
     }
 }
+__global__ __launch_bounds__(256) void lr_sweep_kernel(SweepArgs a) { lr_sweep_vb(vb_hw(), a); }
 
 struct ERowsArgs {
     const double* W; int ldw, r, n;
@@ -699,9 +716,9 @@ struct ERowsArgs {
 
 // e1 = R0 / |R0| and the second row R1 - (a12 / a11) R0 (what lr_e1_kernel writes), plus the partial dots of that
 // second row against [W; e1] — the clean-up sweep of lr_pre_kernel's comment, whose coefficients the next launch sums
-__global__ __launch_bounds__(256) void lr_erows_kernel(ERowsArgs a) {
+__device__ __forceinline__ void lr_erows_vb(const VB vb, ERowsArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int c = blockIdx.x * LR_CHUNK + lane;
+    const int c = vb.x * LR_CHUNK + lane;
     const bool valid = c < a.n;
     const int cl = valid ? c : a.n - 1;
     const double r0 = valid ? a.R[c] : 0.0, r1 = valid ? a.R[a.ldr_ + c] : 0.0;
@@ -725,13 +742,13 @@ __global__ __launch_bounds__(256) void lr_erows_kernel(ERowsArgs a) {
     const double inv = keep1 ? 1.0 / sqrt(a11) : 0.0, f = keep1 ? a12 / a11 : 0.0;
     const double e1 = r0 * inv, row2 = r1 - f * r0;
     if (valid && tid < 64) { a.Erow[c] = e1; a.Erow[a.ldw + c] = row2; }
-    double* out = a.C3part + (size_t)blockIdx.x * a.ldc;
+    double* out = a.C3part + (size_t)vb.x * a.ldc;
     rows_dots(a.W, a.ldw, a.r, cl, valid, row2, 0.0, out, nullptr);
     if (tid < 64) {
         const double de = lanes_sum(e1 * row2);      // against e1 itself: its chunk is in registers, the row is being written here
         if (tid == 0) out[a.r] = -de;
     }
-    if (blockIdx.x == 0 && tid == 0) {
+    if (vb.x == 0 && tid == 0) {
         a.G[G_A11] = a11; a.G[G_A12] = a12; a.G[G_A12 + 1] = a12; a.G[G_A22] = a22;
         a.G[G_R0G] = r0g; a.G[G_R1G] = r1g;
         if (a.SY) {
@@ -743,6 +760,7 @@ __global__ __launch_bounds__(256) void lr_erows_kernel(ERowsArgs a) {
         }
     }
 }
+__global__ __launch_bounds__(256) void lr_erows_kernel(ERowsArgs a) { lr_erows_vb(vb_hw(), a); }
 
 struct CleanArgs {
     const double* W; int ldw, r, n;             // rows 0..r (row r = e1)
@@ -753,7 +771,7 @@ struct CleanArgs {
     const double* g;                            // (null: none) — measured on the vector itself: R1.g - f R0.g cancels as badly as the norm
 };
 
-__global__ __launch_bounds__(256) void lr_clean_kernel(CleanArgs a) {
+__device__ __forceinline__ void lr_clean_vb(const VB vb, CleanArgs a) {
     __shared__ double c3[LR_DEV_MAX + 8], xs[4][LR_CHUNK];
     const int tid = threadIdx.x, nr1 = a.r + 1, lane = tid & 63;
     for (int j = tid; j < nr1; j += 256) {
@@ -762,9 +780,9 @@ __global__ __launch_bounds__(256) void lr_clean_kernel(CleanArgs a) {
         for (; p + 1 < a.parts; p += 2) { s += a.C3part[(size_t)p * a.ldc + j]; t += a.C3part[(size_t)(p + 1) * a.ldc + j]; }
         if (p < a.parts) s += a.C3part[(size_t)p * a.ldc + j];
         c3[j] = s + t;
-        if (blockIdx.x == 0) a.C3[j] = s + t;
+        if (vb.x == 0) a.C3[j] = s + t;
     }
-    const int c = blockIdx.x * LR_CHUNK + lane;
+    const int c = vb.x * LR_CHUNK + lane;
     const bool valid = c < a.n;
     const int cl = valid ? c : a.n - 1;
     const double x = valid ? a.row2[c] : 0.0;
@@ -777,9 +795,10 @@ __global__ __launch_bounds__(256) void lr_clean_kernel(CleanArgs a) {
         if (valid) a.row2[c] = v;
         const double gv = (a.g && valid) ? a.g[c] : 0.0;
         const double s2 = lanes_sum(v * v), sg = lanes_sum(v * gv);
-        if (tid == 0) { a.NP[2 * blockIdx.x] = s2; a.NP[2 * blockIdx.x + 1] = sg; }
+        if (tid == 0) { a.NP[2 * vb.x] = s2; a.NP[2 * vb.x + 1] = sg; }
     }
 }
+__global__ __launch_bounds__(256) void lr_clean_kernel(CleanArgs a) { lr_clean_vb(vb_hw(), a); }
 
 struct GperpArgs {
     const double* Wnew; int ldw, nr, n;         // the nr new eigenvector rows; rows nr (g_perp) and nr + 1 (zero) are written here
@@ -792,10 +811,10 @@ struct GperpArgs {
 
 // components of the gradient along the new eigenvectors WITHOUT a pass over them (they are Q^T applied to the components
 // along the old rows, which the first launch of the job measured), then the part of g outside their span and its norm
-__global__ __launch_bounds__(256) void lr_gperp_kernel(GperpArgs a) {
+__device__ __forceinline__ void lr_gperp_vb(const VB vb, GperpArgs a) {
     __shared__ double se[LR_SMALL + 8], gh[LR_SMALL + 8], xs[4][LR_CHUNK];
     const int tid = threadIdx.x, nr = a.nr, lane = tid & 63;
-    const int c = blockIdx.x * LR_CHUNK + lane;
+    const int c = vb.x * LR_CHUNK + lane;
     const bool valid = c < a.n;
     const int cl = valid ? c : a.n - 1;
     const double gv = valid ? a.g[c] : 0.0;
@@ -811,7 +830,7 @@ __global__ __launch_bounds__(256) void lr_gperp_kernel(GperpArgs a) {
         if (k < nr) a0 += a.Q[(size_t)k * a.ldq + i] * se[k];
         const double v = -(a0 + a1);
         gh[i] = v;
-        if (blockIdx.x == 0) a.ghat[i] = v;
+        if (vb.x == 0) a.ghat[i] = v;
     }
     __syncthreads();
     double p0;
@@ -826,25 +845,28 @@ __global__ __launch_bounds__(256) void lr_gperp_kernel(GperpArgs a) {
             ((double*)a.Wnew)[(size_t)(nr + 1) * a.ldw + c] = 0.0;
         }
         const double s2 = lanes_sum(v * v);
-        if (tid == 0) a.NPg[blockIdx.x] = s2;
+        if (tid == 0) a.NPg[vb.x] = s2;
     }
 }
+__global__ __launch_bounds__(256) void lr_gperp_kernel(GperpArgs a) { lr_gperp_vb(vb_hw(), a); }
 
 // The secant pair formed on the device (pipelined force call): X1 holds g_old on entry; y = g - g_old -> X1 and X4, g -> X2;
 // per-workgroup partials of s.s, s.y and y.y -> SY[3 * wg], SY[3 * wg + 1], SY[3 * wg + 2] (lr_erows_kernel sums them into the
 // Gram block)
-__global__ __launch_bounds__(256) void lr_secant_kernel(double* __restrict__ X, int ld, int n, const double* __restrict__ g,
+__device__ __forceinline__ void lr_secant_vb(const VB vb, double* __restrict__ X, int ld, int n, const double* __restrict__ g,
                                                         double* __restrict__ SY) {
     __shared__ double red[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = vb.x * 256 + threadIdx.x;
     const bool valid = i < n;
     const double gi = valid ? g[i] : 0.0;
     const double y = valid ? gi - X[ld + i] : 0.0;
     const double s = valid ? X[i] : 0.0;
     if (valid) { X[ld + i] = y; X[2 * (size_t)ld + i] = gi; X[4 * (size_t)ld + i] = y; }
     const double ss = blk_sum(s * s, red), sy = blk_sum(s * y, red), yy = blk_sum(y * y, red);
-    if (threadIdx.x == 0) { SY[3 * blockIdx.x] = ss; SY[3 * blockIdx.x + 1] = sy; SY[3 * blockIdx.x + 2] = yy; }
+    if (threadIdx.x == 0) { SY[3 * vb.x] = ss; SY[3 * vb.x + 1] = sy; SY[3 * vb.x + 2] = yy; }
 }
+__global__ __launch_bounds__(256) void lr_secant_kernel(double* __restrict__ X, int ld, int n, const double* __restrict__ g,
+                                                        double* __restrict__ SY) { lr_secant_vb(vb_hw(), X, ld, n, g, SY); }
 
 // The update vectors of a view job formed where they are needed (one launch instead of a lincomb, two gathers, a zero
 // fill, a copy and two Gram launches): u = sum_i UZ[2i] E_i, z = sum_i UZ[2i+1] E_i restricted to the view's coordinates
@@ -859,11 +881,11 @@ struct ViewRowsArgs {
     double* SY;
 };
 
-__global__ __launch_bounds__(256) void lr_view_rows_kernel(ViewRowsArgs a) {
+__device__ __forceinline__ void lr_view_rows_vb(const VB vb, ViewRowsArgs a) {
     __shared__ double cu[LR_DEV_MAX + 8], cz[LR_DEV_MAX + 8], xs[4][LR_CHUNK];
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < a.nr; i += 256) { cu[i] = a.UZ[2 * i]; cz[i] = a.UZ[2 * i + 1]; }
-    const int c = blockIdx.x * LR_CHUNK + lane;
+    const int c = vb.x * LR_CHUNK + lane;
     const bool valid = c < a.m;
     const int col = a.idx[valid ? c : a.m - 1];
     __syncthreads();
@@ -878,22 +900,27 @@ __global__ __launch_bounds__(256) void lr_view_rows_kernel(ViewRowsArgs a) {
             if (a.gsrc) a.Xs[2 * (size_t)a.lds + c] = valid ? a.gsrc[col] : 0.0;
         }
         const double uu = lanes_sum(u * u), uz = lanes_sum(u * z), zz = lanes_sum(z * z);
-        if (tid == 0) { a.SY[3 * blockIdx.x] = uu; a.SY[3 * blockIdx.x + 1] = uz; a.SY[3 * blockIdx.x + 2] = zz; }
+        if (tid == 0) { a.SY[3 * vb.x] = uu; a.SY[3 * vb.x + 1] = uz; a.SY[3 * vb.x + 2] = zz; }
     }
 }
+__global__ __launch_bounds__(256) void lr_view_rows_kernel(ViewRowsArgs a) { lr_view_rows_vb(vb_hw(), a); }
 
-__global__ __launch_bounds__(256) void lr_identity_kernel(double* __restrict__ Q, int nr, int ldq) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void lr_identity_vb(const VB vb, double* __restrict__ Q, int nr, int ldq) {
+    const int i = vb.x * 256 + threadIdx.x;
     if (i < nr * ldq) Q[i] = ((i / ldq) == (i % ldq)) ? 1.0 : 0.0;
 }
+__global__ __launch_bounds__(256) void lr_identity_kernel(double* __restrict__ Q, int nr, int ldq) { lr_identity_vb(vb_hw(), Q, nr, ldq); }
 
 // rows i < r of out scaled copies of W: out_i = (mu_i - lam0) W_i   (dense mirror: B = lam0 I + W^T out)
-__global__ __launch_bounds__(256) void lr_scale_rows_kernel(const double* __restrict__ W, int ldw, int r, int n,
+__device__ __forceinline__ void lr_scale_rows_vb(const VB vb, const double* __restrict__ W, int ldw, int r, int n,
                                                             const double* __restrict__ mu, double lam0,
                                                             double* __restrict__ out, int ldo) {
-    const int i = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    const int i = vb.x * 256 + threadIdx.x, row = vb.y;
     if (i < n && row < r) out[(size_t)row * ldo + i] = (mu[row] - lam0) * W[(size_t)row * ldw + i];
 }
+__global__ __launch_bounds__(256) void lr_scale_rows_kernel(const double* __restrict__ W, int ldw, int r, int n,
+                                                            const double* __restrict__ mu, double lam0,
+                                                            double* __restrict__ out, int ldo) { lr_scale_rows_vb(vb_hw(), W, ldw, r, n, mu, lam0, out, ldo); }
 
 }  // namespace
 
@@ -1021,19 +1048,19 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
         sw.W = W; sw.ldw = ld; sw.r = r; sw.n = n; sw.R = R; sw.ldr_ = ld; sw.ldc = w.ldr;
         if (r > 0) {
             sw.Cin = w.C; sw.parts = 0; sw.Cout = w.cpart; sw.GP = nullptr; sw.g = nullptr; sw.Csum = nullptr;
-            hipLaunchKernelGGL(lr_sweep_kernel, dim3(parts), dim3(256), 0, c->stream, sw);
+            SELLA_LAUNCHB(c, lr_sweep_kernel, lr_sweep_vb, 256, dim3(parts), dim3(256), 0, sw);
         }
         sw.Cin = w.cpart; sw.parts = r > 0 ? parts : 0; sw.Cout = nullptr; sw.GP = w.gp; sw.g = g; sw.Csum = r > 0 ? w.C2 : nullptr;
         if (r == 0) sw.Cin = w.C;                          // (never read: no rows)
-        hipLaunchKernelGGL(lr_sweep_kernel, dim3(parts), dim3(256), 0, c->stream, sw);
+        SELLA_LAUNCHB(c, lr_sweep_kernel, lr_sweep_vb, 256, dim3(parts), dim3(256), 0, sw);
         ERowsArgs er;
         er.W = W; er.ldw = ld; er.r = r; er.n = n; er.R = R; er.ldr_ = ld; er.GP = w.gp; er.parts = parts; er.G = w.G;
         er.Erow = Erow; er.C3part = w.c3part; er.ldc = w.ldr; er.SY = j.SY; er.syparts = j.syparts;
-        hipLaunchKernelGGL(lr_erows_kernel, dim3(parts), dim3(256), 0, c->stream, er);
+        SELLA_LAUNCHB(c, lr_erows_kernel, lr_erows_vb, 256, dim3(parts), dim3(256), 0, er);
         CleanArgs cl;
         cl.W = W; cl.ldw = ld; cl.r = r; cl.n = n; cl.C3part = w.c3part; cl.parts = parts; cl.ldc = w.ldr;
         cl.row2 = Erow + ld; cl.C3 = w.C3; cl.NP = w.np; cl.g = g;
-        hipLaunchKernelGGL(lr_clean_kernel, dim3(parts), dim3(256), 0, c->stream, cl);
+        SELLA_LAUNCHB(c, lr_clean_kernel, lr_clean_vb, 256, dim3(parts), dim3(256), 0, cl);
         HIPCHK(hipGetLastError());
     } else {
     if (r > 0) {
@@ -1041,15 +1068,15 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
         GemvEpi neg;                                  // C, C2 hold the NEGATED coefficients: lincomb adds them
         neg.alpha = -1.0;
         SCHK(launch_gemv_rows(c, W, r, n, ld, R, ld, 2, w.C, w.ldr, neg));
-        hipLaunchKernelGGL(lr_proj2_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, W, ld, r, n, w.C, w.ldr, R, ld);
+        SELLA_LAUNCHB(c, lr_proj2_kernel, lr_proj2_vb, 256, dim3((n + 255) / 256), dim3(256), 0, W, ld, r, n, w.C, w.ldr, R, ld);
         SCHK(launch_gemv_rows(c, W, r, n, ld, R, ld, 2, w.C2, w.ldr, neg));
-        hipLaunchKernelGGL(lr_proj2_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, W, ld, r, n, w.C2, w.ldr, R, ld);
+        SELLA_LAUNCHB(c, lr_proj2_kernel, lr_proj2_vb, 256, dim3((n + 255) / 256), dim3(256), 0, W, ld, r, n, w.C2, w.ldr, R, ld);
         HIPCHK(hipGetLastError());
     }
     // Gram of the residual rows: G[8 + h * 2 + i] = R_i . R_h -> a11 = G[8], a12 = G[9] (= G[10]), a22 = G[11]
     SCHK(launch_gemv_rows(c, R, 2, n, ld, R, ld, 2, w.G + G_A11, 2, GemvEpi()));
     // the two new rows of E, in place behind W: e1, and the second one after a clean-up sweep against [W; e1]
-    hipLaunchKernelGGL(lr_e1_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, R, ld, n, w.G, Erow, ld);
+    SELLA_LAUNCHB(c, lr_e1_kernel, lr_e1_vb, 256, dim3((n + 255) / 256), dim3(256), 0, R, ld, n, w.G, Erow, ld);
     HIPCHK(hipGetLastError());
     {
         GemvEpi neg;
@@ -1070,8 +1097,8 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
     // two rank-one terms in coordinates
     double *Qin = w.Qa, *Qout = w.Qb, *Din = w.D0, *Dout = w.D1;
     if (!chain) {
-        hipLaunchKernelGGL(lr_pre_kernel, dim3(1), dim3(256), 0, c->stream, pa);
-        hipLaunchKernelGGL(lr_identity_kernel, dim3((nr * w.ldq + 255) / 256), dim3(256), 0, c->stream, w.Qa, nr, w.ldq);
+        SELLA_LAUNCHB(c, lr_pre_kernel, lr_pre_vb, 256, dim3(1), dim3(256), 0, pa);
+        SELLA_LAUNCHB(c, lr_identity_kernel, lr_identity_vb, 256, dim3((nr * w.ldq + 255) / 256), dim3(256), 0, w.Qa, nr, w.ldq);
         HIPCHK(hipGetLastError());
     }
     for (int t = 0; t < 2; ++t) {
@@ -1081,24 +1108,24 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
         pl.z = w.z; pl.Dp = w.Dp; pl.zz = w.zz; pl.Dd = w.Dd; pl.wd = w.wd; pl.cs = w.cs; pl.pl = w.pl;
         pl.perm = w.perm; pl.nd = w.nd; pl.df = w.df; pl.i1 = w.i1; pl.i2 = w.i2; pl.cnt = w.cnt;
         if (chain && t == 0) {
-            hipLaunchKernelGGL(lr_pre_plan_kernel, dim3(1), dim3(256), 0, c->stream, pa, pl);
+            SELLA_LAUNCHB(c, lr_pre_plan_kernel, lr_pre_plan_vb, 256, dim3(1), dim3(256), 0, pa, pl);
             // (from here on the job only works in coordinates and on its own panel: the two new rows of E and the update
             // vectors' coordinates are final)
             if (j.fork_ev) HIPCHK(hipEventRecord(j.fork_ev, c->stream));
-        } else hipLaunchKernelGGL(lr_plan_kernel, dim3(1), dim3(256), 0, c->stream, pl);
-        hipLaunchKernelGGL(lr_secular_kernel, dim3((nr + 3) / 4), dim3(256), 0, c->stream, w.cnt, w.pl, w.Dd, w.wd, w.tau,
+        } else SELLA_LAUNCHB(c, lr_plan_kernel, lr_plan_vb, 256, dim3(1), dim3(256), 0, pl);
+        SELLA_LAUNCHB(c, lr_secular_kernel, lr_secular_vb, 256, dim3((nr + 3) / 4), dim3(256), 0, w.cnt, w.pl, w.Dd, w.wd, w.tau,
                            w.org, w.lam, w.sc + SC_FAIL);
         // (the Gu / Eisenstat weights computed by every apply workgroup for itself were measured: the apply kernel grows by
         // more than the launch saves — 11.7 / 14.8 us against 6.5 + 4.5 — so they keep their launch; ApplyArgs::wd stays as
         // the switch)
-        hipLaunchKernelGGL(lr_zhat_kernel, dim3((nr + 3) / 4), dim3(256), 0, c->stream, w.cnt, w.Dd, w.wd, w.tau, w.org,
+        SELLA_LAUNCHB(c, lr_zhat_kernel, lr_zhat_vb, 256, dim3((nr + 3) / 4), dim3(256), 0, w.cnt, w.Dd, w.wd, w.tau, w.org,
                                w.zh);
         ApplyArgs ap;
         ap.nr = nr; ap.ldq = w.ldq; ap.cnt = w.cnt; ap.nd = w.nd; ap.df = w.df; ap.org = w.org; ap.pl = w.pl;
         ap.Dd = w.Dd; ap.Dp = w.Dp; ap.zh = w.zh; ap.tau = w.tau; ap.lam = w.lam; ap.Qin = Qin; ap.Qout = Qout; ap.Dnext = Dout;
         ap.first = (chain && t == 0) ? 1 : 0;
         ap.wd = nullptr;
-        hipLaunchKernelGGL(lr_apply_kernel, dim3(nr), dim3(256), 0, c->stream, ap);
+        SELLA_LAUNCHB(c, lr_apply_kernel, lr_apply_vb, 256, dim3(nr), dim3(256), 0, ap);
         HIPCHK(hipGetLastError());
         std::swap(Qin, Qout);
         std::swap(Din, Dout);
@@ -1115,10 +1142,10 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
         ga.g = j.Xd + 2 * (size_t)j.ldx; ga.ghat = w.ghat; ga.NPg = w.npg;
         j.gparts = (ld + LR_CHUNK - 1) / LR_CHUNK;
         if (j.gparts > LR_MAXPARTS) { set_error("structured update: too many chunks"); return SELLA_E_INVALID; }
-        hipLaunchKernelGGL(lr_gperp_kernel, dim3(j.gparts), dim3(256), 0, c->stream, ga);
+        SELLA_LAUNCHB(c, lr_gperp_kernel, lr_gperp_vb, 256, dim3(j.gparts), dim3(256), 0, ga);
         HIPCHK(hipGetLastError());
     } else {
-        HIPCHK(hipMemsetAsync(j.Wnew + (size_t)nr * ld, 0, (size_t)2 * ld * sizeof(double), c->stream));
+        HIPCHK(s_memset0(c, j.Wnew + (size_t)nr * ld, (size_t)2 * ld * sizeof(double)));
     if (j.want_modes) {
         const double* g = j.Xd + 2 * (size_t)j.ldx;
         GemvEpi e;
@@ -1138,13 +1165,16 @@ static int lr_job_queue(sella_ctx* c, LrJob& j) {
     return SELLA_OK;
 }
 
-__global__ __launch_bounds__(256) void lr_gather_cols_kernel(const double* __restrict__ P, int ldp, int rows,
+__device__ __forceinline__ void lr_gather_cols_vb(const VB vb, const double* __restrict__ P, int ldp, int rows,
                                                              const int* __restrict__ idx, int m,
                                                              double* __restrict__ out, int ldo) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int r = blockIdx.y;
+    const int i = vb.x * 256 + threadIdx.x;
+    const int r = vb.y;
     if (i < m && r < rows) out[(size_t)r * ldo + i] = P[(size_t)r * ldp + idx[i]];
 }
+__global__ __launch_bounds__(256) void lr_gather_cols_kernel(const double* __restrict__ P, int ldp, int rows,
+                                                             const int* __restrict__ idx, int m,
+                                                             double* __restrict__ out, int ldo) { lr_gather_cols_vb(vb_hw(), P, ldp, rows, idx, m, out, ldo); }
 
 // After the wait: the new explicit pairs of one job (rows whose eigenvalue is exactly lam0 belong to the cluster again:
 // dropped, zero rows of a direction that was already in span(W) included) written back into the decomposition.
@@ -1249,7 +1279,7 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
     if (piped) {
         const int syparts = (n + 255) / 256;
         SCHK(scratch_get(c, SCR_UPD3, (size_t)6 * LR_MAXPARTS * sizeof(double), &SYp));
-        hipLaunchKernelGGL(lr_secant_kernel, dim3(syparts), dim3(256), 0, c->stream, X, ld, n, gdev, SYp);
+        SELLA_LAUNCHB(c, lr_secant_kernel, lr_secant_vb, 256, dim3(syparts), dim3(256), 0, X, ld, n, gdev, SYp);
         HIPCHK(hipGetLastError());
         F.SY = SYp;
         F.syparts = syparts;
@@ -1305,7 +1335,7 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
             double* SYv = SYp ? SYp + 3 * LR_MAXPARTS : nullptr;
             if (!SYv) { SCHK(scratch_get(c, SCR_UPD3, (size_t)6 * LR_MAXPARTS * sizeof(double), &SYv)); SYv += 3 * LR_MAXPARTS; }
             va.SY = SYv;
-            hipLaunchKernelGGL(lr_view_rows_kernel, dim3(vparts), dim3(256), 0, c->stream, va);
+            SELLA_LAUNCHB(c, lr_view_rows_kernel, lr_view_rows_vb, 256, dim3(vparts), dim3(256), 0, va);
             HIPCHK(hipGetLastError());
             if (!piped) {
                 for (int q = 0; q < m; ++q) gsub[q] = a->g_new[a->idx[q]];
@@ -1320,11 +1350,11 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
         } else {
         // u, z as vectors (rows of E weighted by their coordinates), restricted to the view's coordinates
         SCHK(launch_lincomb(c, n, 2, Wm->d, Wm->ld, nr, F.w.UZ, 2, nullptr, 0, 0, nullptr, 0, 0.0, UZp, ld));
-        HIPCHK(hipMemsetAsync(Xs, 0, (size_t)3 * lds * sizeof(double), c->stream));
-        hipLaunchKernelGGL(lr_gather_cols_kernel, dim3((m + 255) / 256, 2), dim3(256), 0, c->stream, UZp, ld, 2, didx, m, Xs, lds);
+        HIPCHK(s_memset0(c, Xs, (size_t)3 * lds * sizeof(double)));
+        SELLA_LAUNCHB(c, lr_gather_cols_kernel, lr_gather_cols_vb, 256, dim3((m + 255) / 256, 2), dim3(256), 0, UZp, ld, 2, didx, m, Xs, lds);
         HIPCHK(hipGetLastError());
         if (piped) {                                                   // the gradient is still on its way: gathered on the device
-            hipLaunchKernelGGL(lr_gather_cols_kernel, dim3((m + 255) / 256, 1), dim3(256), 0, c->stream, X + 2 * (size_t)ld, ld, 1,
+            SELLA_LAUNCHB(c, lr_gather_cols_kernel, lr_gather_cols_vb, 256, dim3((m + 255) / 256, 1), dim3(256), 0, X + 2 * (size_t)ld, ld, 1,
                                didx, m, Xs + 2 * (size_t)lds, lds);
             HIPCHK(hipGetLastError());
         } else {
@@ -1421,7 +1451,7 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
     if (have_perp && on_panel && J.gparts > 0) { /* the row stays unnormalised: its factor goes into the step's coefficient */ }
     else if (have_perp && J.gparts > 0) SCHK(launch_axpby(c, nd, 1.0 / std::sqrt(gp2), gprow, 0.0, nullptr, gprow));
     else if (have_perp) SCHK(launch_scale_by(c, gprow, nd, J.w.sc + SC_GPERP2, 0));
-    else if (!(on_panel && J.gparts > 0)) HIPCHK(hipMemsetAsync(gprow, 0, (size_t)J.ldw * sizeof(double), c->stream));
+    else if (!(on_panel && J.gparts > 0)) HIPCHK(s_memset0(c, gprow, (size_t)J.ldw * sizeof(double)));
     const int ncopy = ncl > 0 ? std::min(a->order, ncl - 1) : 0;
     const int mm = rn + (ncl > 0 ? 1 : 0) + ncopy;
     std::vector<double> ev(mm), gh(mm);
@@ -1476,7 +1506,7 @@ extern "C" int sella_lr_materialize(sella_ctx* c, sella_mat hB, sella_mat hWt, i
         return SELLA_E_INVALID;
     }
     const int n = B->rows;
-    HIPCHK(hipMemsetAsync(B->d, 0, (size_t)n * B->ld * sizeof(double), c->stream));
+    HIPCHK(s_memset0(c, B->d, (size_t)n * B->ld * sizeof(double)));
     if (r > 0) {
         const int ld = Wm->ld;
         double *scaled, *dmu;
@@ -1485,7 +1515,7 @@ extern "C" int sella_lr_materialize(sella_ctx* c, sella_mat hB, sella_mat hWt, i
         SCHK(h2d_async(c, dmu, mu, (size_t)r * sizeof(double)));
         B = mat_get(c, hB);
         Wm = mat_get(c, hWt);
-        hipLaunchKernelGGL(lr_scale_rows_kernel, dim3((n + 255) / 256, r), dim3(256), 0, c->stream, Wm->d, ld, r, n, dmu, lam0,
+        SELLA_LAUNCHB(c, lr_scale_rows_kernel, lr_scale_rows_vb, 256, dim3((n + 255) / 256, r), dim3(256), 0, Wm->d, ld, r, n, dmu, lam0,
                            scaled, ld);
         HIPCHK(hipGetLastError());
         SCHK(launch_gemm(c, 1, 0, n, n, r, 1.0, Wm->d, ld, scaled, ld, 0.0, B->d, B->ld));

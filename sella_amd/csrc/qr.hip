@@ -95,7 +95,7 @@ extern "C" int sella_qr_thin(sella_ctx* c, const double* A, int m, int n, double
     double* vpad = wk;                       // 1 + m
     double* taus = wk + 2 * (size_t)ld;      // n
     double* dots = taus + n + 8;             // n
-    HIPCHK(hipMemsetAsync(wk, 0, (size_t)(3 * ld + 2 * n + 64) * sizeof(double), c->stream));
+    HIPCHK(s_memset0(c, wk, (size_t)(3 * ld + 2 * n + 64) * sizeof(double)));
     SCHK(upload_panel(c, A, m, n, At, ld));
     // factorisation
     for (int j = 0; j < n; ++j) {
@@ -113,7 +113,7 @@ extern "C" int sella_qr_thin(sella_ctx* c, const double* A, int m, int n, double
             for (int l = 0; l < n; ++l) R[(size_t)j * n + l] = (l >= j) ? at[(size_t)l * n + j] : 0.0;
     }
     // Q = H_0 ... H_{n-1} [I; 0]: rows of Qt start as unit vectors, reflectors applied last to first
-    HIPCHK(hipMemsetAsync(Qt, 0, ((size_t)n + 2) * ld * sizeof(double), c->stream));
+    HIPCHK(s_memset0(c, Qt, ((size_t)n + 2) * ld * sizeof(double)));
     {
         std::vector<double> ones(n, 1.0);
         HIPCHK(hipMemcpy2DAsync(Qt, ((size_t)ld + 1) * sizeof(double), ones.data(), sizeof(double), sizeof(double), n,
@@ -125,11 +125,10 @@ extern "C" int sella_qr_thin(sella_ctx* c, const double* A, int m, int n, double
     for (int j = n - 1; j >= 0; --j) {
         // rebuild vpad from the stored reflector: vpad[1] = 1, vpad[2..] = At[j][j+1..]
         const int len = m - j;
-        HIPCHK(hipMemsetAsync(vpad, 0, 2 * sizeof(double), c->stream));
+        HIPCHK(s_memset0(c, vpad, 2 * sizeof(double)));
         if (len > 1)
-            HIPCHK(hipMemcpyAsync(vpad + 2, At + (size_t)j * ld + j + 1, (size_t)(len - 1) * sizeof(double),
-                                  hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(vpad + 1, Qt + (size_t)(n + 1) * ld, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(s_memcpy(c, vpad + 2, At + (size_t)j * ld + j + 1, (size_t)(len - 1) * sizeof(double), hipMemcpyDeviceToDevice));
+        HIPCHK(s_memcpy(c, vpad + 1, Qt + (size_t)(n + 1) * ld, sizeof(double), hipMemcpyDeviceToDevice));
         SCHK(apply_reflector(c, Qt, ld, j, n, j, m, vpad, taus + j, dots));
     }
     return download_panel(c, Qt, ld, m, n, Q);

@@ -323,9 +323,15 @@ int call_opt_step(sella_search* S, int flags, double f_old, bool with_calc = fal
 }
 
 // Sella.step (optimize.py:359-440)
+// Stages of one optimizer step for the barriers of a cohort (cohort.h): members of a cohort close up at every stage.
+enum { ST_TOP = 0, ST_FIRST_DIAG = 1, ST_PROPOSE = 2, ST_KICK = 3, ST_REDIAG = 4 };
+
 int one_step(sella_search* S) {
+    cohort_set_phase(S->c, S->nsteps + 1, ST_TOP);
+    cohort_barrier(S->c);
     if (!S->initialized) {                                   // optimize.py:318-326
         if (S->p.eig) {
+            cohort_set_phase(S->c, S->nsteps + 1, ST_FIRST_DIAG);
             const int st = diagonalise(S);
             if (st == SELLA_E_UNSUPPORTED && S->pend_k > 0) {    // done, its update pending with the caller; no step taken
                 S->nsteps_since_diag = -1;
@@ -392,6 +398,8 @@ int one_step(sella_search* S) {
         }
         S->have_step = false;
         if (rediag0) {
+            cohort_set_phase(S->c, S->nsteps + 1, ST_REDIAG);
+            cohort_barrier(S->c);
             const int st = diagonalise(S);
             if (st == SELLA_E_UNSUPPORTED && S->pend_k > 0) S->count_step_on_exit = true;
             SCHK(st);
@@ -404,6 +412,7 @@ int one_step(sella_search* S) {
         set_error("search: explicit rank leaves the structured form (%d of %d)", S->r, S->rank_limit);
         return SELLA_E_UNSUPPORTED;
     }
+    cohort_set_phase(S->c, S->nsteps + 1, ST_PROPOSE);
     if (!S->have_step) SCHK(call_opt_step(S, SELLA_OPT_PROPOSE, S->f));
     const bool rediag = wants_diagonalisation(S);
     S->nsteps_since_diag = rediag ? 0 : S->nsteps_since_diag + 1;
@@ -416,8 +425,12 @@ int one_step(sella_search* S) {
     }
     S->x = S->target;
     S->have_step = false;
+    cohort_set_phase(S->c, S->nsteps + 1, ST_KICK);
+    cohort_barrier(S->c);
     SCHK(call_opt_step(S, SELLA_OPT_LEARN | (rediag ? 0 : SELLA_OPT_PROPOSE), f_old, true));
     if (rediag) {
+        cohort_set_phase(S->c, S->nsteps + 1, ST_REDIAG);
+        cohort_barrier(S->c);
         const int st = diagonalise(S);
         if (st == SELLA_E_UNSUPPORTED && S->pend_k > 0) S->count_step_on_exit = true;    // moved, learnt, diagonalised
         SCHK(st);
@@ -426,6 +439,8 @@ int one_step(sella_search* S) {
 }
 
 }  // namespace
+
+extern "C" sella_ctx* sella_search_ctx(sella_search* S) { return S ? S->c : nullptr; }
 
 extern "C" int sella_search_create(sella_ctx* c, sella_calc* calc, int n, const double* x0, const int* idx, int m,
                                    const sella_search_params_t* p, sella_search** out) {

@@ -257,7 +257,7 @@ extern "C" int sella_stepper_get_s(sella_stepper* st, double alpha, double* s_ou
     if (pinned) {
         memcpy(hin, shat, (size_t)m * sizeof(double));
         memcpy(hin + ldx, dshat, (size_t)m * sizeof(double));
-        HIPCHK(hipMemcpyAsync(dx, hin, (size_t)(ldx + m) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(s_memcpy(c, dx, hin, (size_t)(ldx + m) * sizeof(double), hipMemcpyHostToDevice, true));
         SCHK(launch_gemv_rows(c, V->d, nout, m, V->ld, dx, ldx, 2, hout, ldy, GemvEpi()));
         SCHK(stream_wait(c));
         memcpy(s_out, hout, (size_t)nout * sizeof(double));
@@ -403,10 +403,10 @@ __device__ void rfo_block_dev(int mm, const double* __restrict__ lam, const doub
 
 constexpr int RS_LDS_MAX = 2048;
 
-__global__ __launch_bounds__(256) void rs_batch_kernel(RsBatchArgs a) {
+__device__ __forceinline__ void rs_batch_vb(const VB vb, RsBatchArgs a) {
     __shared__ double red[4][4];
     __shared__ double sLam[RS_LDS_MAX], sG[RS_LDS_MAX];
-    const int cand = blockIdx.x, tid = threadIdx.x;
+    const int cand = vb.x, tid = threadIdx.x;
     if (cand >= a.ncand) return;
     const double alpha = a.alpha[cand];
     double* shat = a.X + (size_t)cand * a.ldx;
@@ -443,16 +443,17 @@ __global__ __launch_bounds__(256) void rs_batch_kernel(RsBatchArgs a) {
         rfo_block_dev<false>(m - o, a.lam + o, a.ghat + o, 0, alpha, shat + o, red);
     }
 }
+__global__ __launch_bounds__(256) void rs_batch_kernel(RsBatchArgs a) { rs_batch_vb(vb_hw(), a); }
 
 // value of the constraint for candidate blockIdx.x: y = V shat (row blockIdx.x of Y), optionally scattered through the
 // inverse selection map (inv[i] = position of full coordinate i in the family's space, -1: not a free coordinate)
-__global__ __launch_bounds__(256) void rs_measure_kernel(int cons, int nout, const double* __restrict__ Y, int ldy,
+__device__ __forceinline__ void rs_measure_vb(const VB vb, int cons, int nout, const double* __restrict__ Y, int ldy,
                                                          const double* __restrict__ scons, const double* __restrict__ w,
                                                          const double* __restrict__ d1, const int* __restrict__ inv,
                                                          double* out) {
     __shared__ double red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double* y = Y + (size_t)blockIdx.x * ldy;
+    const double* y = Y + (size_t)vb.x * ldy;
     auto stot = [&](int i) {
         double s;
         if (inv) { const int p = inv[i]; s = (p >= 0) ? y[p] : 0.0; }
@@ -483,10 +484,14 @@ __global__ __launch_bounds__(256) void rs_measure_kernel(int cons, int nout, con
     if (lane == 0) red[wave] = acc;
     __syncthreads();
     if (tid == 0) {
-        if (cons == 0 || cons == 3) out[blockIdx.x] = sqrt(red[0] + red[1] + red[2] + red[3]);
-        else out[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        if (cons == 0 || cons == 3) out[vb.x] = sqrt(red[0] + red[1] + red[2] + red[3]);
+        else out[vb.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
     }
 }
+__global__ __launch_bounds__(256) void rs_measure_kernel(int cons, int nout, const double* __restrict__ Y, int ldy,
+                                                         const double* __restrict__ scons, const double* __restrict__ w,
+                                                         const double* __restrict__ d1, const int* __restrict__ inv,
+                                                         double* out) { rs_measure_vb(vb_hw(), cons, nout, Y, ldy, scons, w, d1, inv, out); }
 
 // Constraint measure of the total step and its derivative along the family, in ONE workgroup:
 //   stot = s + scons (written back to `stot`),  out[0] = val, out[1] = dval.
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(256) void rs_measure_kernel(int cons, int nout, con
 //   cons 1: atom with the largest |stot_a|: (|stot_a|, dsda_a.stot_a / |stot_a|);
 //   cons 2: component with the largest |stot_i w_i|: (that value, sign(stot_i) dsda_i w_i).
 // Ties resolve to the lowest index (np.argmax).  val is clamped at 1e-12 in the denominators like the reference.
-__global__ __launch_bounds__(1024) void rs_cons_kernel(int cons, int nout, const double* s_in, const double* dsda_in,
+__device__ __forceinline__ void rs_cons_vb(const VB vb, int cons, int nout, const double* s_in, const double* dsda_in,
                                                        const double* __restrict__ scons, const double* __restrict__ w,
                                                        const double* __restrict__ d1, double* stot, double* out,
                                                        const int* __restrict__ sel, int m, double* sfull, double* dfull) {
@@ -578,6 +583,10 @@ __global__ __launch_bounds__(1024) void rs_cons_kernel(int cons, int nout, const
         out[1] = (cons == 1) ? bd / (best > 1e-12 ? best : 1e-12) : bd;
     }
 }
+__global__ __launch_bounds__(1024) void rs_cons_kernel(int cons, int nout, const double* s_in, const double* dsda_in,
+                                                       const double* __restrict__ scons, const double* __restrict__ w,
+                                                       const double* __restrict__ d1, double* stot, double* out,
+                                                       const int* __restrict__ sel, int m, double* sfull, double* dfull) { rs_cons_vb(vb_hw(), cons, nout, s_in, dsda_in, scons, w, d1, stot, out, sel, m, sfull, dfull); }
 
 }  // namespace
 }  // namespace sella
@@ -586,14 +595,14 @@ __global__ __launch_bounds__(1024) void rs_cons_kernel(int cons, int nout, const
 // form — its modes are rows of a panel somebody else owns, read where they are.  `aux` = m doubles (factor of each row),
 // then m ints (row of each mode), uploaded once per family.  Thread = coordinate; the coefficients go through LDS in
 // tiles of 128 modes (read back as broadcasts).
-__global__ __launch_bounds__(256) void rs_panel_apply_kernel(const double* __restrict__ panel, int ld, int m, int n,
+__device__ __forceinline__ void rs_panel_apply_vb(const VB vb, const double* __restrict__ panel, int ld, int m, int n,
                                                              const double* __restrict__ aux, const double* __restrict__ X,
                                                              int ldx, int nq, double* __restrict__ Y, int ldy) {
     constexpr int TI = 128;
     __shared__ double cs[TI][16];
     __shared__ int si[TI];
     const int* idx = reinterpret_cast<const int*>(aux + m);
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = vb.x * 256 + threadIdx.x;
     const int cl = c < n ? c : n - 1;
     double acc[16];
 #pragma unroll
@@ -624,6 +633,9 @@ __global__ __launch_bounds__(256) void rs_panel_apply_kernel(const double* __res
     if (c < n)
         for (int q = 0; q < nq; ++q) Y[(size_t)q * ldy + c] = acc[q];
 }
+__global__ __launch_bounds__(256) void rs_panel_apply_kernel(const double* __restrict__ panel, int ld, int m, int n,
+                                                             const double* __restrict__ aux, const double* __restrict__ X,
+                                                             int ldx, int nq, double* __restrict__ Y, int ldy) { rs_panel_apply_vb(vb_hw(), panel, ld, m, n, aux, X, ldx, nq, Y, ldy); }
 
 extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, const double* scons, const double* w,
                                      const double* d1, double alpha0, double alphamin, double alphamax, double slope,
@@ -660,7 +672,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
             SCHK(scratch_get(c, SCR_PSMALL, pack.size() * sizeof(double), &daux));
             SCHK(h2d_async(c, daux, pack.data(), pack.size() * sizeof(double)));
         }
-        hipLaunchKernelGGL(rs_panel_apply_kernel, dim3((st->nout + 255) / 256), dim3(256), 0, c->stream, st->panel, st->panel_ld,
+        SELLA_LAUNCHB(c, rs_panel_apply_kernel, rs_panel_apply_vb, 256, dim3((st->nout + 255) / 256), dim3(256), 0, st->panel, st->panel_ld,
                            st->m, st->nout, daux, dX, ldX, nq, dYo, ldYo);
         HIPCHK(hipGetLastError());
         return SELLA_OK;
@@ -765,14 +777,14 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         if (pinned) {
             memcpy(hin, shat, (size_t)m * sizeof(double));
             memcpy(hin + ldx, dshat, (size_t)m * sizeof(double));
-            HIPCHK(hipMemcpyAsync(dx, hin, (size_t)(ldx + m) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(s_memcpy(c, dx, hin, (size_t)(ldx + m) * sizeof(double), hipMemcpyHostToDevice, true));
         } else {
             SCHK(h2d_async(c, dx, shat, (size_t)m * sizeof(double)));
             SCHK(h2d_async(c, dx + ldx, dshat, (size_t)m * sizeof(double)));
         }
         if (st->panel) SCHK(panel_apply(dx, ldx, 2, dy, ldy));
         else SCHK(launch_gemv_rows(c, V->d, nfam, m, V->ld, dx, ldx, 2, dy, ldy, GemvEpi()));
-        hipLaunchKernelGGL(rs_cons_kernel, dim3(1), dim3(1024), 0, c->stream, cons, nout, dy, dy + ldy, dscons, dw, dd1, dstot,
+        SELLA_LAUNCHB(c, rs_cons_kernel, rs_cons_vb, 1024, dim3(1), dim3(1024), 0, cons, nout, dy, dy + ldy, dscons, dw, dd1, dstot,
                            hres, dsel, nfam, dsfull, ddfull);
         HIPCHK(hipGetLastError());
         SCHK(stream_wait(c));
@@ -801,7 +813,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         std::copy(st->ghat.begin(), st->ghat.end(), pack.begin() + ldx);
         if ((int)st->d1hat.size() == m) std::copy(st->d1hat.begin(), st->d1hat.end(), pack.begin() + 2 * (size_t)ldx);
         SCHK(h2d_async(c, dbatch, pack.data(), pack.size() * sizeof(double)));
-        HIPCHK(hipMemsetAsync(dbatch + 3 * (size_t)ldx, 0, (size_t)16 * ldb * sizeof(double), c->stream));
+        HIPCHK(s_memset0(c, dbatch + 3 * (size_t)ldx, (size_t)16 * ldb * sizeof(double)));
         if (sel) {
             std::vector<int> inv(nout, -1);
             for (int i = 0; i < nfam; ++i) inv[sel[i]] = i;
@@ -813,6 +825,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     };
     // given: cand[1 .. BATCH_NODES] are set by the caller; otherwise the tree of midpoints of (lower, upper)
     auto batch_evaluate = [&](double lower, double upper, bool given = false) -> int {
+        cohort_barrier(c, 1 + nbatch, 0);                     // members of a cohort take the rounds of their searches together
         if (!batch_ready) SCHK(batch_setup());
         double lo[BATCH_NODES + 1], hi[BATCH_NODES + 1];
         lo[1] = lower; hi[1] = upper;
@@ -832,11 +845,11 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         double* dY = ba.X + (size_t)16 * ldb;
         batch_Y = dY;
         const int* dinv = sel ? reinterpret_cast<const int*>(dY + (size_t)16 * ldy) : nullptr;
-        hipLaunchKernelGGL(rs_batch_kernel, dim3(BATCH_NODES), dim3(256), 0, c->stream, ba);
+        SELLA_LAUNCHB(c, rs_batch_kernel, rs_batch_vb, 256, dim3(BATCH_NODES), dim3(256), 0, ba);
         HIPCHK(hipGetLastError());
         if (st->panel) SCHK(panel_apply(ba.X, ldb, BATCH_NODES, dY, ldy));
         else SCHK(launch_panel16(c, V->d, nfam, m, V->ld, ba.X, BATCH_NODES, dY, ldy));
-        hipLaunchKernelGGL(rs_measure_kernel, dim3(BATCH_NODES), dim3(256), 0, c->stream, cons, nout, dY, ldy, dscons, dw, dd1,
+        SELLA_LAUNCHB(c, rs_measure_kernel, rs_measure_vb, 256, dim3(BATCH_NODES), dim3(256), 0, cons, nout, dY, ldy, dscons, dw, dd1,
                            dinv, hres + 2);
         HIPCHK(hipGetLastError());
         SCHK(stream_wait(c));
@@ -997,11 +1010,12 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         }
     }
     // ---- the step at the final alpha ------------------------------------------------------------------------------
+    cohort_barrier(c, 0xffffff, 0);                           // (a cohort closes up behind searches of different length)
     if (eig_only && st->panel) {
         // coefficients up, the step in one launch over the panel's own rows
         if (pinned) {
             memcpy(hin, shat, (size_t)m * sizeof(double));
-            HIPCHK(hipMemcpyAsync(dx, hin, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(s_memcpy(c, dx, hin, (size_t)m * sizeof(double), hipMemcpyHostToDevice, true));
         } else {
             SCHK(h2d_async(c, dx, shat, (size_t)m * sizeof(double)));
         }
@@ -1009,7 +1023,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     } else if (eig_only) {
         if (pinned) {
             memcpy(hin, shat, (size_t)m * sizeof(double));
-            HIPCHK(hipMemcpyAsync(dx, hin, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(s_memcpy(c, dx, hin, (size_t)m * sizeof(double), hipMemcpyHostToDevice, true));
         } else {
             SCHK(h2d_async(c, dx, shat, (size_t)m * sizeof(double)));
         }
@@ -1090,7 +1104,7 @@ extern "C" int sella_stepper_create_lr(sella_ctx* c, int kind, sella_mat hWt, in
         SCHK(launch_axpby2d(c, r, n, 1.0, Wm->d, Wm->ld, 0.0, nullptr, 0, src, ld));
     }
     double* gp = src + (size_t)r * ld;
-    HIPCHK(hipMemsetAsync(gp, 0, (size_t)2 * ld * sizeof(double), c->stream));
+    HIPCHK(s_memset0(c, gp, (size_t)2 * ld * sizeof(double)));
     // ONE round trip: a = W g (weights of the explicit modes), then the normalised component of g outside span(W) by two
     // Gram-Schmidt sweeps whose norms come back with a — |g_perp| = |g| n1 n2 is the weight of the cluster's mode
     bool have_perp = false;
@@ -1102,7 +1116,7 @@ extern "C" int sella_stepper_create_lr(sella_ctx* c, int kind, sella_mat hWt, in
         if (r > 8192) { set_error("stepper (structured): too many explicit eigenpairs"); return SELLA_E_UNSUPPORTED; }
         if (r > 0) {
             SCHK(launch_gemv_rows(c, src, r, n, ld, gp, ld, 1, da, std::max(r, 1), GemvEpi()));
-            HIPCHK(hipMemcpyAsync(c->hscal + DS_CVEC + 8192, da, (size_t)r * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(s_memcpy(c, c->hscal + DS_CVEC + 8192, da, (size_t)r * sizeof(double), hipMemcpyDeviceToHost, true));
         }
         if (ncl > 0) SCHK(gs_project_twice(c, src, ld, r, gp, n));
         SCHK(sync_scalars(c, 8, 3));
@@ -1126,7 +1140,7 @@ extern "C" int sella_stepper_create_lr(sella_ctx* c, int kind, sella_mat hWt, in
             } else if (have_perp) {
                 gperp = sqrt(n0sq) * n1 * n2;
             }
-            if (!have_perp) HIPCHK(hipMemsetAsync(gp, 0, (size_t)ld * sizeof(double), c->stream));
+            if (!have_perp) HIPCHK(s_memset0(c, gp, (size_t)ld * sizeof(double)));
         }
     }
     // modes in ascending order of eigenvalue; within the cluster the weighted mode first

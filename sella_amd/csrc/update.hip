@@ -26,16 +26,16 @@ namespace sella {
 // ------------------------------------------------------------------------------------------
 constexpr int R2K_KT = 16;
 
-__global__ __launch_bounds__(256) void sym_rank2k_kernel(double* __restrict__ B, int n, int ld,
+__device__ __forceinline__ void sym_rank2k_vb(const VB vb, double* __restrict__ B, int n, int ld,
                                                          const double* __restrict__ Up,
                                                          const double* __restrict__ Zp, int ldp, int kk,
                                                          double alpha) {
-    if (blockIdx.x < blockIdx.y) return;
+    if (vb.x < vb.y) return;
     __shared__ double t1[32][33];
     __shared__ double t2[32][33];
     __shared__ double ur[R2K_KT][32], zr[R2K_KT][32], uc[R2K_KT][32], zc[R2K_KT][32];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int r0 = vb.y * 32, c0 = vb.x * 32;
     for (int k = ty; k < 32; k += 8) {
         int r = r0 + k, cc = c0 + tx;
         t1[k][tx] = (r < n && cc < n) ? B[(size_t)r * ld + cc] : 0.0;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void sym_rank2k_kernel(double* __restrict__ B,
         t1[k][tx] = v;
     }
     __syncthreads();
-    const bool diag = (blockIdx.x == blockIdx.y);
+    const bool diag = (vb.x == vb.y);
     for (int k = ty; k < 32; k += 8) {
         int r = r0 + k, cc = c0 + tx;
         // inside a diagonal tile both (k, tx) and (tx, k) are computed (in different summation
@@ -85,6 +85,10 @@ __global__ __launch_bounds__(256) void sym_rank2k_kernel(double* __restrict__ B,
         }
     }
 }
+__global__ __launch_bounds__(256) void sym_rank2k_kernel(double* __restrict__ B, int n, int ld,
+                                                         const double* __restrict__ Up,
+                                                         const double* __restrict__ Zp, int ldp, int kk,
+                                                         double alpha) { sym_rank2k_vb(vb_hw(), B, n, ld, Up, Zp, ldp, kk, alpha); }
 
 // ------------------------------------------------------------------------------------------
 // Streaming rank-2kk update of an ALREADY SYMMETRIC block (the trailing update of the tridiagonalisation,
@@ -246,9 +250,9 @@ __global__ __launch_bounds__(256) void rank2k_stream_fixed_kernel(double* __rest
 }
 
 // lower triangle of the m x m block C <- transpose of its upper triangle (32 x 32 tiles through LDS)
-__global__ __launch_bounds__(256) void mirror_upper_kernel(double* __restrict__ C, int m, int ld) {
+__device__ __forceinline__ void mirror_upper_vb(const VB vb, double* __restrict__ C, int m, int ld) {
     __shared__ double t[32][33];
-    const int bi = blockIdx.y, bj = blockIdx.x;              // source tile (rows bi, columns bj), bj >= bi
+    const int bi = vb.y, bj = vb.x;              // source tile (rows bi, columns bj), bj >= bi
     if (bj < bi) return;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int q = 0; q < 4; ++q) {
@@ -261,12 +265,13 @@ __global__ __launch_bounds__(256) void mirror_upper_kernel(double* __restrict__ 
         if (r < m && cc < m && r > cc) C[(size_t)r * ld + cc] = t[tx][ty + 8 * q];
     }
 }
+__global__ __launch_bounds__(256) void mirror_upper_kernel(double* __restrict__ C, int m, int ld) { mirror_upper_vb(vb_hw(), C, m, ld); }
 
 int launch_mirror_upper(sella_ctx* c, double* C, int m, int ld) {
     if (m <= 1) return SELLA_OK;
     const int nt = (m + 31) / 32;
     prof_begin(c, PROF_OTHER, 8.0 * m * (double)m, 0.0);
-    SELLA_LAUNCH(c, mirror_upper_kernel, dim3(nt, nt), dim3(256), 0, C, m, ld);
+    SELLA_LAUNCHB_PROF(c, mirror_upper_kernel, mirror_upper_vb, 256, dim3(nt, nt), dim3(256), 0, C, m, ld);
     prof_end(c);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
@@ -296,7 +301,7 @@ int launch_sym_rank2k(sella_ctx* c, double* B, int n, int ld, const double* Up, 
                       int kk, double alpha) {
     prof_begin(c, PROF_UPDATE, 16.0 * n * (double)n, 4.0 * kk * (double)n * n);
     const int nb = (n + 31) / 32;
-    SELLA_LAUNCH(c, sym_rank2k_kernel, dim3(nb, nb), dim3(256), 0, B, n, ld, Up, Zp, ldp, kk, alpha);
+    SELLA_LAUNCHB_PROF(c, sym_rank2k_kernel, sym_rank2k_vb, 256, dim3(nb, nb), dim3(256), 0, B, n, ld, Up, Zp, ldp, kk, alpha);
     prof_end(c);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
@@ -440,22 +445,25 @@ static int lr_abs_times(sella_ctx* c, const LrRef& lr, const double* Sp, int n, 
     return SELLA_OK;
 }
 
-__global__ __launch_bounds__(256) void gather_cols_kernel(const double* __restrict__ P, int ldp, int rows,
+__device__ __forceinline__ void gather_cols_vb(const VB vb, const double* __restrict__ P, int ldp, int rows,
                                                           const int* __restrict__ idx, int m,
                                                           double* __restrict__ out, int ldo) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int r = blockIdx.y;
+    const int i = vb.x * 256 + threadIdx.x;
+    const int r = vb.y;
     if (i < m && r < rows) out[(size_t)r * ldo + i] = P[(size_t)r * ldp + idx[i]];
 }
+__global__ __launch_bounds__(256) void gather_cols_kernel(const double* __restrict__ P, int ldp, int rows,
+                                                          const int* __restrict__ idx, int m,
+                                                          double* __restrict__ out, int ldo) { gather_cols_vb(vb_hw(), P, ldp, rows, idx, m, out, ldo); }
 
 // k = 1 TS-BFGS (the per-step quasi-Newton update): the three scalars of hessian_update.py:120-126 stay on the
 // device.  in: d[0] = s.ytilde, d[1] = s.|B|s, d[2] = j.s;  out: coef[0], coef[1] = pinv(G) [M1, M2] with
 // G = M1^2 + M2^2, coef[2] = -1/2 sym(J^T S).  Same operations in the same order as the host k x k code.
-__global__ void tsbfgs_k1_coef_kernel(const double* __restrict__ d, double* __restrict__ coef) {
+__device__ __forceinline__ void tsbfgs_k1_coef_vb(const VB vb, const double* __restrict__ d, double* __restrict__ coef) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0 || vb.x != 0) return;
     const double m1 = d[0], m2 = d[1];
     const double g = m1 * m1 + m2 * m2;
     const double gp = (fabs(g) <= 2.220446049250313e-16 * fabs(g)) ? 0.0 : 1.0 / g;      // sym_pinv_solve's cut, m = 1
@@ -463,6 +471,7 @@ __global__ void tsbfgs_k1_coef_kernel(const double* __restrict__ d, double* __re
     coef[1] = gp * m2;
     coef[2] = -0.25 * (d[2] + d[2]);
 }
+__global__ __launch_bounds__(1024) void tsbfgs_k1_coef_kernel(const double* __restrict__ d, double* __restrict__ coef) { tsbfgs_k1_coef_vb(vb_hw(), d, coef); }
 
 static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt, const double* evals,
                          const double* S, const double* Y, int n, int k, int method, int symm,
@@ -595,7 +604,7 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
                 SCHK(launch_gemv_rows(c, Ytp, 1, n, ld, Sp, ld, 1, dd, 1, GemvEpi()));
                 SCHK(launch_gemv_rows(c, absBS, 1, n, ld, Sp, ld, 1, dd + 1, 1, GemvEpi()));
                 SCHK(launch_gemv_rows(c, Jp, 1, n, ld, Sp, ld, 1, dd + 2, 1, GemvEpi()));
-                hipLaunchKernelGGL(tsbfgs_k1_coef_kernel, dim3(1), dim3(64), 0, c->stream, dd, dcoef);
+                SELLA_LAUNCHB(c, tsbfgs_k1_coef_kernel, tsbfgs_k1_coef_vb, 1024, dim3(1), dim3(64), 0, dd, dcoef);
                 HIPCHK(hipGetLastError());
                 SCHK(launch_lincomb(c, n, 1, Ytp, ld, 1, dcoef, 1, absBS, ld, 1, dcoef + 1, 1, 0.0, Up, ld));
                 SCHK(launch_axpby2d(c, 1, n, 1.0, Jp, ld, 0.0, nullptr, 0, Zp, ld));
@@ -681,10 +690,10 @@ static int update_h_core(sella_ctx* c, sella_mat hB, sella_mat hV, sella_mat hVt
         Zs = wks + (size_t)kk * lds;
         int* didx = reinterpret_cast<int*>(wks + 2 * (size_t)kk * lds);
         SCHK(h2d_async(c, didx, sv->idx, (size_t)m * sizeof(int)));
-        HIPCHK(hipMemsetAsync(wks, 0, (size_t)2 * kk * lds * sizeof(double), c->stream));
+        HIPCHK(s_memset0(c, wks, (size_t)2 * kk * lds * sizeof(double)));
         const dim3 gg((m + 255) / 256, kk);
-        hipLaunchKernelGGL(gather_cols_kernel, gg, dim3(256), 0, c->stream, Up, ld, kk, didx, m, Us, lds);
-        hipLaunchKernelGGL(gather_cols_kernel, gg, dim3(256), 0, c->stream, Zp, ld, kk, didx, m, Zs, lds);
+        SELLA_LAUNCHB(c, gather_cols_kernel, gather_cols_vb, 256, gg, dim3(256), 0, Up, ld, kk, didx, m, Us, lds);
+        SELLA_LAUNCHB(c, gather_cols_kernel, gather_cols_vb, 256, gg, dim3(256), 0, Zp, ld, kk, didx, m, Zs, lds);
         HIPCHK(hipGetLastError());
         SCHK(launch_sym_rank2k(c, Bs->d, m, Bs->ld, Us, Zs, lds, kk));
     }
@@ -808,14 +817,14 @@ extern "C" int sella_lr_restrict(sella_ctx* c, sella_mat hWt, int r, const doubl
     int* didx = reinterpret_cast<int*>(wk + 2 * (size_t)r * lds);
     double* Rd = wk + 2 * (size_t)r * lds + (size_t)m / 2 + 8;      // r' x r coordinates (device)
     SCHK(h2d_async(c, didx, idx, (size_t)m * sizeof(int)));
-    HIPCHK(hipMemsetAsync(wk, 0, (size_t)2 * r * lds * sizeof(double), c->stream));
+    HIPCHK(s_memset0(c, wk, (size_t)2 * r * lds * sizeof(double)));
     Wm = mat_get(c, hWt);
-    hipLaunchKernelGGL(gather_cols_kernel, dim3((m + 255) / 256, r), dim3(256), 0, c->stream, Wm->d, Wm->ld, r, didx, m, Wf, lds);
+    SELLA_LAUNCHB(c, gather_cols_kernel, gather_cols_vb, 256, dim3((m + 255) / 256, r), dim3(256), 0, Wm->d, Wm->ld, r, didx, m, Wf, lds);
     HIPCHK(hipGetLastError());
     int rq = 0;
     for (int v = 0; v < r && rq < m; ++v) {
         double* slot = Qf + (size_t)rq * lds;
-        HIPCHK(hipMemcpyAsync(slot, Wf + (size_t)v * lds, (size_t)lds * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(s_memcpy(c, slot, Wf + (size_t)v * lds, (size_t)lds * sizeof(double), hipMemcpyDeviceToDevice));
         int kept = 0;
         SCHK(gs_orthonormalise(c, Qf, lds, rq, slot, m, 1e-15, 1e-13, 100, &kept, nullptr));
         if (kept) ++rq;

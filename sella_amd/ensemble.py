@@ -332,8 +332,142 @@ class EnsembleThreads:
         self.close()
 
 
+class EnsembleCohort:
+    """W members of this rank's GPU advanced in LOCKSTEP by one host thread (`sella_cohort_*`, csrc/cohort.hip): every
+    member keeps a device context of its own, but while the cohort runs they share one stream, every kernel of the step
+    is launched once for all members that have reached it (the member is the grid's z index) and every wait is one
+    stream synchronisation for all of them — the replica dimension of SURVEY.md 8(e).  Host threads with a stream each
+    sit at the runtime's launch rate (~63 launches per member step); a cohort divides the launches by its width.
+
+    Members are taken in waves of `width` (<= 16).  The searches run inside the library (`LibrarySearch`); a member the
+    library loop does not cover, or that leaves it on the way, is run by the general driver afterwards, from its start
+    geometry, exactly as `run_one` does.  Per-member results are bit-identical to `run_one` (independent `Sella` objects,
+    sella/optimize/optimize.py:42-81)."""
+
+    MAX_WIDTH = 16
+
+    def __init__(self, width=8):
+        from . import device
+        self.width = int(width)
+        if not 1 <= self.width <= self.MAX_WIDTH:
+            raise ValueError('EnsembleCohort: width must be in [1, %d]' % self.MAX_WIDTH)
+        self._ctxs = [device.Context() for _ in range(self.width)]
+        from ctypes import byref, c_void_p
+        from . import _lib
+        arr = (c_void_p * self.width)(*[c._h for c in self._ctxs])
+        h = c_void_p()
+        _lib.check(_lib.lib().sella_cohort_create(arr, self.width, byref(h)))
+        self._h = h
+
+    def prepare(self, factory, members=()):
+        """`factory.prepare(i)` for the members (host-side data), then `factory.warmup()` on every member context."""
+        from . import device
+        prep = getattr(factory, 'prepare', None)
+        if prep is not None:
+            for i in members:
+                prep(i)
+        warm = getattr(factory, 'warmup', None)
+        if warm is not None:
+            keep = getattr(device._tls, 'ctx', None)
+            try:
+                for c in self._ctxs:
+                    device.use_context(c)
+                    warm()
+            finally:
+                device.use_context(keep)
+
+    def stats(self):
+        from ctypes import c_long
+        from . import _lib
+        cn = (c_long * 8)()
+        _lib.check(_lib.lib().sella_cohort_stats(self._h, cn))
+        return dict(zip(('rounds', 'launches_asked', 'launches_issued', 'waits_asked', 'stream_syncs', 'barrier_arrivals'),
+                        (int(v) for v in cn[:6])))
+
+    def run(self, factory, members, fmax, steps, sella_kwargs):
+        from ctypes import c_int, c_void_p
+        from . import _lib, device
+        from .search import LibrarySearch
+        members = list(members)
+        out = {}
+        keep = getattr(device._tls, 'ctx', None)
+        try:
+            for lo in range(0, len(members), self.width):
+                wave = members[lo:lo + self.width]
+                searches, leftovers = [], []
+                for slot, i in enumerate(wave):
+                    device.use_context(self._ctxs[slot])
+                    atoms = factory(i)
+                    kw = dict(logfile=None)
+                    kw.update(sella_kwargs or {})
+                    if isinstance(atoms, tuple):
+                        atoms, own = atoms
+                        kw.update(own)
+                    if USE_LIBRARY_SEARCH and LibrarySearch.applies(atoms, **kw):
+                        start = np.asarray(atoms.positions, dtype=np.float64).copy()
+                        searches.append((slot, i, atoms, kw, start, LibrarySearch(atoms, **kw)))
+                    else:
+                        leftovers.append((slot, i, atoms, kw))
+                if searches:
+                    n = max(s[0] for s in searches) + 1
+                    handles = (c_void_p * n)()
+                    for slot, _, _, _, _, ls in searches:
+                        handles[slot] = ls._h
+                    conv, status = (c_int * n)(), (c_int * n)()
+                    _lib.check(_lib.lib().sella_cohort_run_searches(self._h, handles, n, float(fmax), int(steps), conv, status))
+                    for slot, i, atoms, kw, start, ls in searches:
+                        device.use_context(self._ctxs[slot])
+                        try:
+                            ls._sync()
+                            if status[slot] == 0:
+                                out[i] = (np.array([1.0 if conv[slot] else 0.0, float(ls.nsteps), ls.energy, ls.fmax_now,
+                                                    ls.lambda_min]), np.asarray(atoms.positions, dtype=np.float64).copy())
+                            elif status[slot] == -7:                   # SELLA_E_UNSUPPORTED: left the covered configuration
+                                atoms.positions = start
+                                leftovers.append((slot, i, atoms, kw))
+                            else:
+                                msg = _lib.lib().sella_cohort_error(self._h, slot)
+                                raise _lib.SellaHipError(status[slot], (msg or b'').decode())
+                        finally:
+                            ls.close()
+                for slot, i, atoms, kw in leftovers:                   # the general driver, one after the other
+                    from .optimize.optimize import Sella
+                    device.use_context(self._ctxs[slot])
+                    opt = Sella(atoms, **kw)
+                    opt.use_library_loop = False
+                    cv = opt.run(fmax=fmax, steps=steps)
+                    pes = opt.pes
+                    f = pes.get_projected_forces()
+                    evals = pes.H.evals
+                    out[i] = (np.array([1.0 if cv else 0.0, float(opt.nsteps), float(pes.get_f()),
+                                        float(np.sqrt((f ** 2).sum(axis=1).max())),
+                                        float(evals[0]) if evals is not None else float('nan')]),
+                              np.asarray(atoms.positions, dtype=np.float64).copy())
+        finally:
+            device.use_context(keep)
+        return out
+
+    def close(self):
+        if self._h is None:
+            return
+        from . import _lib
+        import gc
+        gc.collect()
+        _lib.lib().sella_cohort_destroy(self._h)
+        self._h = None
+        for c in self._ctxs:
+            c.close()
+        self._ctxs = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def run_ensemble(make_replica, n_replicas, fmax=0.05, steps=1000, sella_kwargs=None, threads=1, pool=None,
-                 prepared=False):
+                 prepared=False, cohort=None):
     """Run `n_replicas` independent searches, sharded over the initialised process group (or all in
     this process when there is none).  Every rank returns the same
     `dict(summary=(n_replicas, 5) array, positions=list of (N_i, 3) arrays, owner=(n_replicas,))`.
@@ -344,12 +478,17 @@ def run_ensemble(make_replica, n_replicas, fmax=0.05, steps=1000, sella_kwargs=N
     kernels), so several of them keep one GPU busy.  `make_replica(i)` is then called inside the
     worker thread and must build its calculator on `sella_amd.device.get_context()`.
 
+    cohort: an `EnsembleCohort`; the rank's members advance in lockstep through batched launches, `width` at a time.
+
     pool: an `EnsemblePool`; the rank's members run in its worker processes (`make_replica` is pickled to them,
     or — prepared=True — the factory already shipped by `pool.prepare` is used)."""
     rank, world = rank_and_world()
     mine = local_members(n_replicas, rank, world)
     summaries, positions = {}, {}
-    if pool is not None:
+    if cohort is not None:
+        for i, (sm, ps) in cohort.run(make_replica, mine, fmax, steps, sella_kwargs).items():
+            summaries[i], positions[i] = sm, ps
+    elif pool is not None:
         done = pool.run(None if prepared else make_replica, mine, fmax, steps, sella_kwargs)
         for i, (sm, ps) in done.items():
             summaries[i], positions[i] = sm, ps

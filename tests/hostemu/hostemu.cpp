@@ -255,6 +255,30 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& 
 }
 }  // namespace hipemu
 
+// ---- launch log (which kernels does a path use, and how often): HIPEMU_LAUNCH_LOG=<file> ------------------------------
+#include <map>
+#include <string>
+namespace {
+struct LaunchLog {
+    std::map<std::string, long> count;
+    const char* path = getenv("HIPEMU_LAUNCH_LOG");
+    ~LaunchLog() {
+        if (!path) return;
+        FILE* f = fopen(path, "w");
+        if (!f) return;
+        for (const auto& kv : count) fprintf(f, "%8ld  %s\n", kv.second, kv.first.c_str());
+        fclose(f);
+    }
+};
+LaunchLog g_launch_log;
+std::mutex g_launch_log_mu;
+}  // namespace
+void hipemu_note_launch(const char* kernel_text) {
+    if (!g_launch_log.path) return;
+    std::lock_guard<std::mutex> hold(g_launch_log_mu);
+    ++g_launch_log.count[kernel_text];
+}
+
 // ----------------------------------------------------------- host API shim --
 struct hipemu_event_t { std::chrono::steady_clock::time_point t; };
 struct hipemu_stream_t { int dummy; };
@@ -282,18 +306,23 @@ hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t b, hipMemcpyKind) { memmove(d, s, b); return hipSuccess; }
-hipError_t hipMemcpyAsync(void* d, const void* s, size_t b, hipMemcpyKind, hipStream_t) { memmove(d, s, b); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t b, hipMemcpyKind k, hipStream_t) {
+    hipemu_note_launch(k == hipMemcpyHostToDevice ? "[hipMemcpyAsync H2D]" : k == hipMemcpyDeviceToHost ? "[hipMemcpyAsync D2H]" : "[hipMemcpyAsync D2D]");
+    memmove(d, s, b);
+    return hipSuccess;
+}
 hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width,
                             size_t height, hipMemcpyKind, hipStream_t) {
+    hipemu_note_launch("[hipMemcpy2DAsync]");
     for (size_t r = 0; r < height; ++r) memmove((char*)dst + r * dpitch, (const char*)src + r * spitch, width);
     return hipSuccess;
 }
 hipError_t hipMemset(void* d, int v, size_t b) { memset(d, v, b); return hipSuccess; }
-hipError_t hipMemsetAsync(void* d, int v, size_t b, hipStream_t) { memset(d, v, b); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t b, hipStream_t) { hipemu_note_launch("[hipMemsetAsync]"); memset(d, v, b); return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t* s) { *s = new hipemu_stream_t{0}; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { hipemu_note_launch("[hipStreamSynchronize]"); return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event_t; return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }

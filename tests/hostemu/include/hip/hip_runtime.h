@@ -60,6 +60,8 @@ static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 struct double4 { double x, y, z, w; };
 static inline double4 make_double4(double x, double y, double z, double w) { return double4{x, y, z, w}; }
 struct int2 { int x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 // ---------------------------------------------------------------- runtime --
 namespace hipemu {
@@ -87,8 +89,9 @@ static inline void launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipStre
 #define blockDim hipemu::g_blockDim
 #define gridDim hipemu::g_gridDim
 
+void hipemu_note_launch(const char* kernel_text);      // HIPEMU_LAUNCH_LOG=<file>: histogram of launched kernels at exit
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), stream, ##__VA_ARGS__)
+    (hipemu_note_launch(#kernel), hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), stream, ##__VA_ARGS__))
 
 static inline void __syncthreads() { hipemu::block_barrier(); }
 static inline void __threadfence() {}

@@ -328,3 +328,34 @@ def test_upload_paths_agree(ctx):
     for o in out[1:]:
         np.testing.assert_array_equal(o[0], out[0][0])
         assert o[1] == out[0][1] and o[2] == out[0][2]
+
+
+def _cohort_member(i):
+    from sella_amd import device
+    from sella_amd.internal import Constraints
+    at = _model(device.get_context(), seed=41 + 3 * i)
+    return at, dict(constraints=Constraints(at))
+
+
+@pytest.mark.parametrize('rs', ['tr', pytest.param('ras', marks=pytest.mark.emu_heavy)])
+def test_cohort_members_are_bit_identical_to_searches_run_alone(ctx, rs):
+    """`EnsembleCohort`: members advanced in lockstep from one thread, one batched launch per kernel for all of them
+    (csrc/cohort.hip) — every member's summary and geometry equal, bit for bit, what `run_one` gives for it alone
+    (independent `Sella` objects, sella/optimize/optimize.py:42-81).  Width 3 with 5 members: a full wave and a ragged
+    one; the members differ, so their ranks, root-search rounds and deflations do."""
+    from sella_amd import device, ensemble
+    kw = dict(KW, rs=rs, nsteps_per_diag=3)
+    nrep, steps = 5, 7
+    alone = [ensemble.run_one(_cohort_member(i), 0.0, steps, kw) for i in range(nrep)]
+    with ensemble.EnsembleCohort(3) as cohort:
+        res = ensemble.run_ensemble(_cohort_member, nrep, fmax=0.0, steps=steps, sella_kwargs=kw, cohort=cohort)
+        again = ensemble.run_ensemble(_cohort_member, nrep, fmax=0.0, steps=steps, sella_kwargs=kw, cohort=cohort)
+        st = cohort.stats()
+    assert device.get_context() is ctx
+    for i in range(nrep):
+        np.testing.assert_array_equal(res['summary'][i], alone[i][0])
+        np.testing.assert_array_equal(res['positions'][i], alone[i][1])
+        np.testing.assert_array_equal(again['summary'][i], alone[i][0])
+    assert len({round(e, 9) for e in res['summary'][:, 2]}) == nrep
+    assert st['launches_issued'] < st['launches_asked']                        # launches were merged across the members
+    assert st['stream_syncs'] < st['waits_asked']

@@ -582,6 +582,38 @@ def main():
                                                             seconds=round(te_, 3),
                                                             passes_seconds=[round(t, 3) for t in epasses],
                                                             lambda_min_negative=int((re_['summary'][:, 4] < 0).sum()))
+                # ... and the same members in lockstep COHORTS (sella_amd.ensemble.EnsembleCohorts -> csrc/cohort.hip: the
+                # replica dimension in the kernels — one batched launch per kernel of the step for all members of a cohort,
+                # one stream synchronisation per phase): the 8 members of one GPU's share, then 8 x as many in flight
+                from sella_amd.ensemble import EnsembleCohorts
+                co_stats = {}
+                for tag, nmem_c, width_c, thr_c in (('share_of_one_gpu', args.ensemble_emt, max(1, args.ensemble_emt // 2), 2),
+                                                    ('saturated', 8 * args.ensemble_emt, 8, min(8, 2 * cpus_rank))):
+                    with EnsembleCohorts(width_c, thr_c) as cohorts:
+                        cohorts.prepare(emt_member)
+                        run_ensemble(lambda i: emt_member(-1 - i), width_c * thr_c, fmax=0.0, steps=3,
+                                     sella_kwargs=EmtSlabMember.SELLA_KW, cohort=cohorts)
+                        cpasses, before = [], cohorts.stats()
+                        for _ in range(max(1, args.ensemble_reps)):
+                            for i_ in range(nmem_c):
+                                emt_member.prepare(i_)
+                            t0c = time.perf_counter()
+                            rc_ = run_ensemble(emt_member, nmem_c, fmax=0.0, steps=args.ensemble_steps,
+                                               sella_kwargs=EmtSlabMember.SELLA_KW, cohort=cohorts)
+                            cpasses.append(time.perf_counter() - t0c)
+                        after = cohorts.stats()
+                    tc_ = sorted(cpasses)[len(cpasses) // 2]
+                    npass = len(cpasses)
+                    co_stats[tag] = dict(replicas=nmem_c, cohort_width=width_c, issuing_threads=thr_c,
+                                         searches_per_s=round(nmem_c / tc_, 3), seconds=round(tc_, 3),
+                                         passes_seconds=[round(t, 3) for t in cpasses],
+                                         launches_asked_per_pass=(after['launches_asked'] - before['launches_asked']) // npass,
+                                         launches_issued_per_pass=(after['launches_issued'] - before['launches_issued']) // npass,
+                                         waits_asked_per_pass=(after['waits_asked'] - before['waits_asked']) // npass,
+                                         stream_syncs_per_pass=(after['stream_syncs'] - before['stream_syncs']) // npass,
+                                         bit_identical_to_threads=bool(np.array_equal(rc_['summary'][:args.ensemble_emt], re_['summary'])),
+                                         lambda_min_negative=int((rc_['summary'][:, 4] < 0).sum()))
+                opt_stats['ensemble']['emt_members']['cohorts'] = co_stats
             if pool_note:
                 opt_stats['ensemble']['note'] = pool_note
             if pool is not None:

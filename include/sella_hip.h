@@ -486,7 +486,8 @@ sella_ctx* sella_search_ctx(sella_search* search);        /* the context the sea
  *     sella_search_run(searches[i], fmax, steps, ...) would have returned (SELLA_E_UNSUPPORTED: that member left the
  *     covered configuration, see sella_search_pending_pairs); sella_cohort_error(cohort, i) is its message.
  *   sella_cohort_stats: counters[8] = scheduler rounds, launches asked for by the members, launches issued (merged),
- *     waits asked for, stream synchronisations, barrier arrivals, 0, 0 — accumulated since creation.                    */
+ *     waits asked for, stream synchronisations, barrier arrivals, microseconds spent inside the members' host code,
+ *     microseconds spent issuing the merged launches — accumulated since creation.                                     */
 typedef struct sella_cohort sella_cohort;
 int sella_cohort_create(sella_ctx* const* members, int n, sella_cohort** cohort);
 int sella_cohort_size(sella_cohort* cohort);

@@ -6,6 +6,7 @@
 
 #include <sys/mman.h>
 
+#include <chrono>
 #include <functional>
 #include <string>
 
@@ -90,7 +91,8 @@ struct sella_cohort {
     void* sched_sp = nullptr;
     int current = -1;                             // member whose fiber is running (-1: the scheduler)
     // statistics of the last run / since creation
-    long rounds = 0, launches_parked = 0, launches_issued = 0, waits_parked = 0, syncs = 0, barriers = 0, direct = 0;
+    long rounds = 0, launches_parked = 0, launches_issued = 0, waits_parked = 0, syncs = 0, barriers = 0;
+    double t_members = 0.0, t_issue = 0.0, t_sync = 0.0;      // seconds: member host code, issuing merged launches, stream synchronisations
 };
 
 namespace {
@@ -167,10 +169,14 @@ int advance(sella_cohort* co) {
     dim3 grids[COHORT_MAX];
     int who[COHORT_MAX];
     static const bool trace = getenv("SELLA_COHORT_TRACE") != nullptr;      // one line per scheduler round on stderr
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (;;) {
         ++co->rounds;
+        const double t0 = now();
         for (int i = 0; i < n; ++i)
             if (co->fibers[i].state == F_RUNNABLE) resume(co, i);
+        const double t1 = now();
+        co->t_members += t1 - t0;
         int nl = 0, nw = 0, nb = 0;
         for (int i = 0; i < n; ++i) {
             const FiberState s = co->fibers[i].state;
@@ -207,10 +213,19 @@ int advance(sella_cohort* co) {
                 for (int q = 0; q < cnt; ++q) co->fibers[who[q]].state = F_RUNNABLE;
             }
             HIPCHK(hipGetLastError());
+            co->t_issue += now() - t1;
             continue;
         }
         if (nw > 0) {
-            HIPCHK(hipStreamSynchronize(co->stream));
+            static const bool spin = getenv("SELLA_COHORT_SPIN") != nullptr;
+            if (spin) {
+                hipError_t q;
+                while ((q = hipStreamQuery(co->stream)) == hipErrorNotReady) {}
+                HIPCHK(q);
+            } else {
+                HIPCHK(hipStreamSynchronize(co->stream));
+            }
+            co->t_sync += now() - t1;
             ++co->syncs;
             for (int i = 0; i < n; ++i)
                 if (co->fibers[i].state == F_AT_WAIT) co->fibers[i].state = F_RUNNABLE;
@@ -304,10 +319,12 @@ int sella_cohort_destroy(sella_cohort* co) {
 int sella_cohort_size(sella_cohort* co) { return co ? (int)co->members.size() : 0; }
 
 // counters[8]: scheduler rounds, launches parked by the members, launches issued (merged), waits parked, stream
-// synchronisations, barrier arrivals, 0, 0 — accumulated since creation
+// synchronisations, barrier arrivals, microseconds inside the members' host code, microseconds issuing the merged
+// launches — accumulated since creation
 int sella_cohort_stats(sella_cohort* co, long* counters) {
     if (!co || !counters) return SELLA_E_INVALID;
-    const long v[8] = {co->rounds, co->launches_parked, co->launches_issued, co->waits_parked, co->syncs, co->barriers, 0, 0};
+    const long v[8] = {co->rounds, co->launches_parked, co->launches_issued, co->waits_parked, co->syncs, co->barriers,
+                       (long)(1e6 * co->t_members), (long)(1e6 * co->t_issue)};
     memcpy(counters, v, sizeof(v));
     return SELLA_OK;
 }

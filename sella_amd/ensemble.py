@@ -381,18 +381,21 @@ class EnsembleCohort:
         from . import _lib
         cn = (c_long * 8)()
         _lib.check(_lib.lib().sella_cohort_stats(self._h, cn))
-        return dict(zip(('rounds', 'launches_asked', 'launches_issued', 'waits_asked', 'stream_syncs', 'barrier_arrivals'),
-                        (int(v) for v in cn[:6])))
+        return dict(zip(('rounds', 'launches_asked', 'launches_issued', 'waits_asked', 'stream_syncs', 'barrier_arrivals',
+                         'us_in_members', 'us_issuing'), (int(v) for v in cn[:8])))
 
     def run(self, factory, members, fmax, steps, sella_kwargs):
         from ctypes import c_int, c_void_p
         from . import _lib, device
         from .search import LibrarySearch
+        import time
         members = list(members)
         out = {}
         keep = getattr(device._tls, 'ctx', None)
+        self.last_timing = dict(setup=0.0, run=0.0, collect=0.0)                  # seconds: member set-up / lockstep run / results
         try:
             for lo in range(0, len(members), self.width):
+                t_a = time.perf_counter()
                 wave = members[lo:lo + self.width]
                 searches, leftovers = [], []
                 for slot, i in enumerate(wave):
@@ -408,6 +411,8 @@ class EnsembleCohort:
                         searches.append((slot, i, atoms, kw, start, LibrarySearch(atoms, **kw)))
                     else:
                         leftovers.append((slot, i, atoms, kw))
+                t_b = time.perf_counter()
+                self.last_timing['setup'] += t_b - t_a
                 if searches:
                     n = max(s[0] for s in searches) + 1
                     handles = (c_void_p * n)()
@@ -415,6 +420,8 @@ class EnsembleCohort:
                         handles[slot] = ls._h
                     conv, status = (c_int * n)(), (c_int * n)()
                     _lib.check(_lib.lib().sella_cohort_run_searches(self._h, handles, n, float(fmax), int(steps), conv, status))
+                    t_c = time.perf_counter()
+                    self.last_timing['run'] += t_c - t_b
                     for slot, i, atoms, kw, start, ls in searches:
                         device.use_context(self._ctxs[slot])
                         try:
@@ -430,6 +437,7 @@ class EnsembleCohort:
                                 raise _lib.SellaHipError(status[slot], (msg or b'').decode())
                         finally:
                             ls.close()
+                    self.last_timing['collect'] += time.perf_counter() - t_c
                 for slot, i, atoms, kw in leftovers:                   # the general driver, one after the other
                     from .optimize.optimize import Sella
                     device.use_context(self._ctxs[slot])
@@ -464,6 +472,85 @@ class EnsembleCohort:
 
     def __exit__(self, *exc):
         self.close()
+
+
+class EnsembleCohorts:
+    """T issuing threads on this rank's GPU, each advancing an `EnsembleCohort` of `width` members of its own (own
+    contexts, own stream): the members' host code between the launches — serial inside one cohort — runs on T cores, and
+    T streams overlap on the device.  The rank's members are dealt to the threads in contiguous blocks of `width`, so a
+    member's cohort-mates — which never influence its results — are fixed by its index.  `run_ensemble(..., cohort=...)`
+    takes either class."""
+
+    def __init__(self, width=8, threads=2):
+        from concurrent.futures import ThreadPoolExecutor
+        import threading
+        self.width, self.threads = int(width), int(threads)
+        if self.threads < 1:
+            raise ValueError('EnsembleCohorts needs at least one thread')
+        self._local = threading.local()
+        self._all_cohorts = []
+        self._lock = threading.Lock()
+        self._ex = ThreadPoolExecutor(max_workers=self.threads, initializer=self._enter)
+        self._each(lambda: None)
+
+    def _enter(self):
+        co = EnsembleCohort(self.width)
+        self._local.cohort = co
+        with self._lock:
+            self._all_cohorts.append(co)
+
+    def _each(self, fn):
+        import threading
+        gate = threading.Barrier(self.threads)
+
+        def task():
+            gate.wait()
+            return fn()
+        return [f.result() for f in [self._ex.submit(task) for _ in range(self.threads)]]
+
+    def prepare(self, factory, members=()):
+        prep = getattr(factory, 'prepare', None)
+        if prep is not None:
+            for i in members:
+                prep(i)
+        if getattr(factory, 'warmup', None) is not None:
+            self._each(lambda: self._local.cohort.prepare(_WarmupOnly(factory)))
+
+    def stats(self):
+        out = {}
+        for co in self._all_cohorts:
+            for k, v in co.stats().items():
+                out[k] = out.get(k, 0) + v
+        return out
+
+    def run(self, factory, members, fmax, steps, sella_kwargs):
+        members = list(members)
+        blocks = [members[lo:lo + self.width] for lo in range(0, len(members), self.width)]
+        futs = [self._ex.submit(lambda b=b: self._local.cohort.run(factory, b, fmax, steps, sella_kwargs)) for b in blocks]
+        out = {}
+        for f in futs:
+            out.update(f.result())
+        return out
+
+    def close(self):
+        if self._ex is None:
+            return
+        try:
+            self._each(lambda: self._local.cohort.close())
+        finally:
+            self._ex.shutdown()
+            self._ex = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class _WarmupOnly:
+    def __init__(self, factory):
+        self.warmup = factory.warmup
 
 
 def run_ensemble(make_replica, n_replicas, fmax=0.05, steps=1000, sella_kwargs=None, threads=1, pool=None,

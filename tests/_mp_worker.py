@@ -36,6 +36,52 @@ def make_replica(i):
     return atoms
 
 
+def make_library_replica(i):
+    """Replica i in a form the library loop covers (structured Hessian from 3N = 96, calculator with a library form): what
+    the lockstep cohorts advance.  Deterministic in i; built on the calling thread's device context."""
+    from conftest_shim import hessian_like
+    from sella_amd import device, linalg
+    from sella_amd.atoms import Atoms, QuadraticCubicModel
+    from sella_amd.internal import Constraints
+    linalg.LR_MIN_DIM = 96
+    n = 120
+    ctx = device.get_context()
+    A = hessian_like(n, 41 + 3 * i, nneg=1)[0]
+    dA = ctx.upload(A)
+    rng = np.random.RandomState(42 + 3 * i)
+    U = rng.normal(size=(8, n))
+    U /= np.linalg.norm(U, axis=1)[:, None]
+    at = Atoms(['X'] * (n // 3), 0.05 * rng.normal(size=(n // 3, 3)), pbc=True)
+    at.calc = QuadraticCubicModel(lambda x: ctx.symm_mm(dA, x), U, c=0.05, device_matrix=dA)
+    return at, dict(constraints=Constraints(at))
+
+
+COHORT_KW = dict(order=1, eta=1e-4, gamma=0.1, delta0=0.1, proj_trans=False, rs='tr', nsteps_per_diag=3)
+
+
+def ensemble_cohort(out_path, n_replicas, sharded):
+    """configs[3] at toy size with the replica dimension in the kernels: every rank advances its members in lockstep
+    cohorts (width 2), one all-gather at the end; `sharded` False: one process, members one after the other (run_one)."""
+    from sella_amd import linalg
+    from sella_amd.ensemble import EnsembleCohort, run_ensemble
+    linalg.LR_MIN_DIM = 96
+    if sharded:
+        import torch.distributed as dist
+        dist.init_process_group(backend='gloo')
+        with EnsembleCohort(2) as cohort:
+            res = run_ensemble(make_library_replica, n_replicas, fmax=0.0, steps=4, sella_kwargs=COHORT_KW, cohort=cohort)
+            st = cohort.stats()
+        assert st['launches_issued'] < st['launches_asked'] or len(res['summary']) < 2 * dist.get_world_size()
+        rank0 = dist.get_rank() == 0
+    else:
+        res = run_ensemble(make_library_replica, n_replicas, fmax=0.0, steps=4, sella_kwargs=COHORT_KW)
+        rank0 = True
+    if rank0:
+        np.savez(out_path, summary=res['summary'], owner=res['owner'], **{f'pos{i}': p for i, p in enumerate(res['positions'])})
+    if sharded:
+        dist.destroy_process_group()
+
+
 def ensemble(out_path, n_replicas):
     import torch.distributed as dist
     from sella_amd.ensemble import run_ensemble
@@ -90,6 +136,8 @@ if __name__ == '__main__':
     use_emulator()
     if sys.argv[1] == 'ensemble':
         ensemble(sys.argv[2], int(sys.argv[3]))
+    elif sys.argv[1] in ('ensemble-cohort', 'ensemble-cohort-serial'):
+        ensemble_cohort(sys.argv[2], int(sys.argv[3]), sys.argv[1] == 'ensemble-cohort')
     elif sys.argv[1] == 'bench':
         bench(sys.argv[2])
     elif sys.argv[1] == 'panel':

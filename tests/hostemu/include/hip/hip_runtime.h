@@ -214,6 +214,7 @@ hipError_t hipStreamCreate(hipStream_t* s);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipDeviceSynchronize();
 hipError_t hipEventCreate(hipEvent_t* e);
 #define hipEventDisableTiming 2u

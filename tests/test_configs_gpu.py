@@ -220,6 +220,24 @@ def test_config3_ensemble_of_emt_slabs(ctx):
     np.testing.assert_array_equal(res_t2['summary'], res['summary'])
     for i in range(nrep):
         np.testing.assert_array_equal(res_t['positions'][i], res['positions'][i])
+    # ... and in lockstep cohorts: one issuing thread per cohort, one batched launch per kernel for its members, one stream
+    # synchronisation per phase (csrc/cohort.hip) — a full cohort of 8, two threads with 4 each, and a ragged 3 + 3 + 2
+    from sella_amd.ensemble import EnsembleCohort, EnsembleCohorts
+    with EnsembleCohort(8) as cohort:
+        res_c = run_ensemble(EmtMember(), nrep, fmax=0.0, steps=steps, sella_kwargs=kw, cohort=cohort)
+        st = cohort.stats()
+    np.testing.assert_array_equal(res_c['summary'], res['summary'])
+    for i in range(nrep):
+        np.testing.assert_array_equal(res_c['positions'][i], res['positions'][i])
+    assert 3 * st['launches_issued'] < st['launches_asked'] and 3 * st['stream_syncs'] < st['waits_asked'], st
+    with EnsembleCohorts(4, 2) as cohorts:
+        res_c2 = run_ensemble(EmtMember(), nrep, fmax=0.0, steps=steps, sella_kwargs=kw, cohort=cohorts)
+    with EnsembleCohort(3) as cohort:
+        res_c3 = run_ensemble(EmtMember(), nrep, fmax=0.0, steps=steps, sella_kwargs=kw, cohort=cohort)
+    for other in (res_c2, res_c3):
+        np.testing.assert_array_equal(other['summary'], res['summary'])
+        for i in range(nrep):
+            np.testing.assert_array_equal(other['positions'][i], res['positions'][i])
     # the library loop against the general driver (the same searches, ~300 library calls per step there)
     ensemble.USE_LIBRARY_SEARCH = False
     try:

@@ -50,6 +50,22 @@ def test_ensemble_two_ranks_matches_single_process(tmp_path):
     assert np.all(s[:, 4] < 0.0)                # ... with a negative lowest Hessian eigenvalue
 
 
+def test_ensemble_cohorts_two_ranks_match_members_run_alone(tmp_path):
+    """The replica dimension under sharding: two gloo ranks, each advancing its members in lockstep
+    cohorts — batched launches, merged waits (csrc/cohort.hip) — give, bit for bit, what one process gives that runs
+    the members one after the other."""
+    n_rep = 5                                   # ranks hold 3 and 2 members: a full cohort + a ragged one, and a full one
+    two, one = str(tmp_path / 'two.npz'), str(tmp_path / 'one.npz')
+    launch(2, 'ensemble-cohort', two, str(n_rep))
+    launch(1, 'ensemble-cohort-serial', one, str(n_rep))
+    a, b = np.load(two), np.load(one)
+    np.testing.assert_array_equal(a['owner'], np.arange(n_rep) % 2)
+    np.testing.assert_array_equal(a['summary'], b['summary'])
+    for i in range(n_rep):
+        np.testing.assert_array_equal(a[f'pos{i}'], b[f'pos{i}'])
+    assert np.all(a['summary'][:, 1] == 4) and len({round(e, 9) for e in a['summary'][:, 2]}) == n_rep
+
+
 def test_ensemble_host_threads_match_serial(tmp_path):
     """Several host threads, one device context each, drive one device: same per-replica results."""
     thr, one = str(tmp_path / 'thr.npz'), str(tmp_path / 'one.npz')

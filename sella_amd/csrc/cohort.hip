@@ -8,6 +8,7 @@
 
 #include <chrono>
 #include <functional>
+#include <map>
 #include <string>
 
 #if defined(__has_feature)
@@ -92,6 +93,7 @@ struct sella_cohort {
     int current = -1;                             // member whose fiber is running (-1: the scheduler)
     // statistics of the last run / since creation
     long rounds = 0, launches_parked = 0, launches_issued = 0, waits_parked = 0, syncs = 0, barriers = 0;
+    std::map<std::string, std::pair<long, long>> by_name;   // SELLA_COHORT_TRACE=2: body -> (launches asked, launches issued)
     double t_members = 0.0, t_issue = 0.0, t_sync = 0.0;      // seconds: member host code, issuing merged launches, stream synchronisations
 };
 
@@ -168,7 +170,9 @@ int advance(sella_cohort* co) {
     const void* packs[COHORT_MAX];
     dim3 grids[COHORT_MAX];
     int who[COHORT_MAX];
-    static const bool trace = getenv("SELLA_COHORT_TRACE") != nullptr;      // one line per scheduler round on stderr
+    static const char* trace_env = getenv("SELLA_COHORT_TRACE");
+    static const bool trace = trace_env && trace_env[0] == '1';             // 1: one line per scheduler round on stderr
+    static const bool count_names = trace_env && trace_env[0] == '2';       // 2: launches per kernel body, printed at destruction
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (;;) {
         ++co->rounds;
@@ -210,6 +214,7 @@ int advance(sella_cohort* co) {
                 }
                 f.fn(co->stream, cnt, packs, grids, f.block, f.shmem);
                 ++co->launches_issued;
+                if (count_names) { auto& e = co->by_name[f.name]; e.first += cnt; e.second += 1; }
                 for (int q = 0; q < cnt; ++q) co->fibers[who[q]].state = F_RUNNABLE;
             }
             HIPCHK(hipGetLastError());
@@ -309,6 +314,10 @@ int sella_cohort_create(sella_ctx* const* members, int n, sella_cohort** out) {
 
 int sella_cohort_destroy(sella_cohort* co) {
     if (!co) return SELLA_OK;
+    if (!co->by_name.empty()) {
+        fprintf(stderr, "cohort of %d: launches asked / issued by kernel body\n", (int)co->members.size());
+        for (const auto& kv : co->by_name) fprintf(stderr, "  %8ld %8ld  %s\n", kv.second.first, kv.second.second, kv.first.c_str());
+    }
     for (sella_ctx* c : co->members) c->cohort = nullptr;
     for (Fiber& f : co->fibers)
         if (f.stack) munmap(f.stack, FIBER_STACK);

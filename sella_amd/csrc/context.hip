@@ -582,6 +582,7 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "lr_cholqr")) c->opt.lr_cholqr = value ? 1 : 0;
     else if (!strcmp(key, "rank2k_fixed")) c->opt.rank2k_fixed = value ? 1 : 0;
     else if (!strcmp(key, "eigh_wy_strip")) c->opt.eigh_wy_strip = value;
+    else if (!strcmp(key, "gs_small")) c->opt.gs_small = value < 0 ? 0 : (value > 2048 ? 2048 : value);
     else if (!strcmp(key, "h2d_kernel_min")) c->opt.h2d_kernel_min = value < 0 ? 0 : value;
     else if (!strcmp(key, "eigh_dc_pipeline")) c->opt.eigh_dc_pipeline = value ? 1 : 0;
     else if (!strcmp(key, "eigh_gemv_flat")) c->opt.eigh_gemv_flat = value ? 1 : 0;

@@ -352,6 +352,11 @@ class EnsembleCohort:
         if not 1 <= self.width <= self.MAX_WIDTH:
             raise ValueError('EnsembleCohort: width must be in [1, %d]' % self.MAX_WIDTH)
         self._ctxs = [device.Context() for _ in range(self.width)]
+        if os.environ.get('SELLA_COHORT_HOST_SCALARS', '1') != '0':
+            # scalars only the host consumes are written by their kernels straight into the pinned mirror: in a cohort
+            # the read-back copy would be one more (batched) launch per wait
+            for c in self._ctxs:
+                c.set_option('host_scalars', 1)
         from ctypes import byref, c_void_p
         from . import _lib
         arr = (c_void_p * self.width)(*[c._h for c in self._ctxs])

@@ -125,3 +125,30 @@ def test_gram_schmidt_spans_and_drops(ctx):
     Xd[:, 9] = Y @ rng.standard_normal(5)                  # inside Y
     assert modified_gram_schmidt(Xd).shape[1] == 11
     assert modified_gram_schmidt(Xd, Y).shape[1] == 10
+
+
+def test_one_launch_gram_schmidt_agrees_with_the_sweep_by_sweep_launches(ctx):
+    """`gs_small_kernel` (one workgroup: sweeps, norms and the accept / drop decisions of math.pyx:112-129 in one launch,
+    default up to 2048 entries) against the launch-per-sweep form of the same routine: same columns kept, same vectors to
+    roundoff — on well-conditioned blocks, duplicates, near-duplicates (a third sweep), zero columns and a block with Y."""
+    from sella_amd.utilities.math import modified_gram_schmidt
+    rng = np.random.RandomState(11)
+    n = 70 if ctx.backend == 'emu' else 1500
+    X = rng.normal(size=(n, 9))
+    X[:, 2] = X[:, 0]                                        # dropped
+    X[:, 4] = X[:, 1] + 1e-4 * rng.normal(size=n)            # survives after heavy cancellation: more than two sweeps
+    X[:, 6] = 0.0
+    Y = rng.normal(size=(n, 4))
+    try:
+        outs = []
+        for opt in (0, 2048):
+            ctx.set_option('gs_small', opt)
+            outs.append((modified_gram_schmidt(X), modified_gram_schmidt(X, Y), modified_gram_schmidt(X[:, :1])))
+        for a, b in zip(*outs):
+            assert a.shape == b.shape
+            np.testing.assert_allclose(a, b, atol=1e-10 if a.shape[1] > 1 else 1e-15)
+            np.testing.assert_allclose(b.T @ b, np.eye(b.shape[1]), atol=1e-13)
+        assert outs[1][0].shape == (n, 7) and outs[1][1].shape == (n, 7)
+        np.testing.assert_allclose(outs[1][1].T @ Y, 0, atol=1e-12)
+    finally:
+        ctx.set_option('gs_small', 2048)

@@ -10,6 +10,8 @@ from sella_amd.device import get_context  # noqa: E402
 from sella_amd.search import LibrarySearch  # noqa: E402
 
 fac = EmtSlabMember()
+if os.environ.get('SELLA_GS_SMALL') is not None:
+    get_context().set_option('gs_small', int(os.environ['SELLA_GS_SMALL']))
 fac.warmup()
 for i in range(3):
     atoms, own = fac(i)

@@ -317,6 +317,18 @@ def main():
         concurrent = dict(problems_in_flight=T, calls=per * T, davidson_iter_per_s=round(sum(done) / tcc, 1),
                           ms_per_call_amortised=round(1e3 * tcc / (per * T), 3), errors=errs or None)
 
+    # What the drop-in call `rayleigh_ritz(A_numpy, gamma, P_numpy)` pays on top of `value`: A and P go up over PCIe
+    # (2 x 8 n^2 bytes, pageable numpy memory as the reference's callers hold it) — measured, not priced from the spec
+    dtmp = [ctx.upload(A), ctx.upload(P)]
+    ctx.sync()
+    for m_ in dtmp:
+        m_.free()
+    tu0 = time.perf_counter()
+    dtmp = [ctx.upload(A), ctx.upload(P)]
+    ctx.sync()
+    upload_ms = 1e3 * (time.perf_counter() - tu0)
+    for m_ in dtmp:
+        m_.free()
     # Davidson loop alone (P's eigendecomposition kept from a previous optimizer phase)
     w, V, Vt = ctx.eigh(dP)
     ctx.sync()
@@ -842,7 +854,9 @@ def main():
                        'vectors_per_call': round(total_iters / (args.steps * world), 2),
                        **({'options': list(args.option)} if args.option else {})},
             'davidson_loop_only_iter_per_s': round(it2 / t_loop, 1),
+            'ms_per_vector_loop': round(1e3 * t_loop / max(1, it2), 4),
             'eigh_ms': round(1e3 * t_eigh, 2),
+            'upload_ms': round(upload_ms, 2),          # A and P from numpy memory (2 x 75 MB at 3N = 3072): NOT in `value`
             'concurrent_problems': concurrent,
             'optimizer': opt_stats,
             'block_davidson': block_stats,

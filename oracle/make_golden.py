@@ -719,6 +719,28 @@ def gen_big_digests(ref, orc, sizes):
         json.dump(dig, f, indent=1)
 
 
+def gen_prfo_digests(ref, sizes):
+    """The P-RFO trust-region step of the REAL reference (`sella/optimize/restricted_step.py` over `stepper.py`) on the
+    benchmark recipe, merged into big_digests.json — at 3N = 3072 the reference's dense augmented eigenproblems take a few
+    minutes, which is why gen_big_digests stops at 768 and this is a mode of its own (`--prfo --sizes 3072`)."""
+    path = os.path.join(GOLD, 'big_digests.json')
+    with open(path) as f:
+        dig = json.load(f)
+    for n in sizes:
+        A, P, g = hessian_like(n, seed=0, eps=5e-3)
+        probe = np.cos(np.arange(n) * 0.37)
+        pr = FakePES(ref.linalg.ApproximateHessian, P, g, 0, seed=0)
+        t0 = time.time()
+        s, smag = ref.rs.get_restricted_step('tr')(pr, 1, 0.1, 'prfo').get_s()
+        d = dig.setdefault(str(n), {})
+        d['prfo_tr_s_probe'] = float(probe @ s)
+        d['prfo_tr_s_norm'] = float(np.linalg.norm(s))
+        d['prfo_seconds'] = time.time() - t0
+        print(f'  n={n}: |s| = {d["prfo_tr_s_norm"]:.15f} ({d["prfo_seconds"]:.1f}s reference)', flush=True)
+    with open(path, 'w') as f:
+        json.dump(dig, f, indent=1)
+
+
 def gen_converged_digests(ref, orc, sizes):
     """The reference's CONVERGED lowest eigenpair at benchmark sizes, merged into big_digests.json: the run the
     optimizer flow makes (start block = P's negative-curvature eigenvectors, eigensolvers.py:46-50, v0=None), to
@@ -790,6 +812,7 @@ def main():
     ap.add_argument('--big', action='store_true')
     ap.add_argument('--converged', action='store_true', help='add the converged-eigenpair digests only')
     ap.add_argument('--envelope', action='store_true', help='add the sensitivity envelope of the benchmark run only')
+    ap.add_argument('--prfo', action='store_true', help='add the P-RFO step digests at --sizes only (3072: minutes)')
     ap.add_argument('--only', default='', help='comma-separated fixture names: regenerate these, keep the rest')
     ap.add_argument('--sizes', default='300,768,3072')
     args = ap.parse_args()
@@ -800,7 +823,7 @@ def main():
     import oracle.sella_oracle as orc
     manifest = {}
     only = [x for x in args.only.split(',') if x]
-    if only or args.converged or args.envelope:
+    if only or args.converged or args.envelope or args.prfo:
         with open(os.path.join(GOLD, 'manifest.json')) as f:
             manifest = json.load(f)
     for name, fn in (('g1_davidson', gen_davidson), ('g2_expand', gen_expand),
@@ -814,7 +837,7 @@ def main():
                      ('g10_irc', gen_irc),
                      ('g11_sparse_internal', gen_sparse_internal),
                      ('g12_numhess_model', gen_numhess_model)):
-        if (only and name not in only) or ((args.converged or args.envelope) and not only):
+        if (only and name not in only) or ((args.converged or args.envelope or args.prfo) and not only):
             continue
         t0 = time.time()
         manifest[name] = fn(ref, orc)
@@ -824,6 +847,8 @@ def main():
         json.dump(manifest, f, indent=1)
     if args.big:
         gen_big_digests(ref, orc, [int(s) for s in args.sizes.split(',')])
+    if args.prfo:
+        gen_prfo_digests(ref, [int(s) for s in args.sizes.split(',')])
     if args.big or args.converged:
         gen_converged_digests(ref, orc, [int(s) for s in args.sizes.split(',') if int(s) >= 768])
     if args.big or args.envelope:

@@ -85,26 +85,40 @@ __global__ void __launch_bounds__(LB) batched_kernel(BatchArgs<P, NB> b) {
 // one group of parked launches of the same body: `packs[i]` / `grids[i]` belong to member i of the group
 typedef void (*BatchLauncher)(hipStream_t st, int nm, const void* const* packs, const dim3* grids, dim3 block, size_t shmem);
 
+// one launch for `cnt` (<= NB) members: the descriptor array has NB slots, so a small group travels in a small argument
+// segment (the runtime copies it per launch)
+template <auto Body, int LB, int NB, class P>
+void batched_launch_n(hipStream_t st, int cnt, const void* const* packs, const dim3* grids, dim3 block, size_t shmem) {
+    static_assert(sizeof(BatchArgs<P, NB>) <= 4096, "descriptor array beyond the kernel-argument segment");
+    BatchArgs<P, NB> b;
+    unsigned mx = 1, my = 1;
+    for (int i = 0; i < cnt; ++i) {
+        b.gx[i] = grids[i].x;
+        b.gy[i] = grids[i].y;
+        memcpy(&b.a[i], packs[i], sizeof(P));
+        mx = b.gx[i] > mx ? b.gx[i] : mx;
+        my = b.gy[i] > my ? b.gy[i] : my;
+    }
+    for (int i = cnt; i < NB; ++i) {                           // (unused slots: defined bytes in the argument segment)
+        b.gx[i] = b.gy[i] = 0;
+        memcpy(&b.a[i], packs[0], sizeof(P));
+    }
+    hipLaunchKernelGGL((batched_kernel<Body, LB, NB, P>), dim3(mx, my, (unsigned)cnt), block, shmem, st, b);
+}
+
 template <auto Body, int LB, class P>
 void batched_launcher(hipStream_t st, int nm, const void* const* packs, const dim3* grids, dim3 block, size_t shmem) {
-    constexpr int NB = batch_cap<P>();
-    static_assert(sizeof(BatchArgs<P, NB>) <= 4096, "descriptor array beyond the kernel-argument segment");
-    for (int lo = 0; lo < nm; lo += NB) {
-        const int cnt = nm - lo < NB ? nm - lo : NB;
-        BatchArgs<P, NB> b;
-        unsigned mx = 1, my = 1;
-        for (int i = 0; i < cnt; ++i) {
-            b.gx[i] = grids[lo + i].x;
-            b.gy[i] = grids[lo + i].y;
-            memcpy(&b.a[i], packs[lo + i], sizeof(P));
-            mx = b.gx[i] > mx ? b.gx[i] : mx;
-            my = b.gy[i] > my ? b.gy[i] : my;
+    constexpr int CAP = batch_cap<P>();
+    for (int lo = 0; lo < nm; lo += CAP) {
+        const int cnt = nm - lo < CAP ? nm - lo : CAP;
+        if constexpr (CAP >= 16) {
+            if (cnt > 8) { batched_launch_n<Body, LB, 16, P>(st, cnt, packs + lo, grids + lo, block, shmem); continue; }
         }
-        for (int i = cnt; i < NB; ++i) {                       // (unused slots: defined bytes in the argument segment)
-            b.gx[i] = b.gy[i] = 0;
-            memcpy(&b.a[i], packs[lo], sizeof(P));
+        if constexpr (CAP >= 8) {
+            if (cnt > 4) { batched_launch_n<Body, LB, 8, P>(st, cnt, packs + lo, grids + lo, block, shmem); continue; }
         }
-        hipLaunchKernelGGL((batched_kernel<Body, LB, NB, P>), dim3(mx, my, (unsigned)cnt), block, shmem, st, b);
+        if (cnt > 1) batched_launch_n<Body, LB, 4, P>(st, cnt, packs + lo, grids + lo, block, shmem);
+        else batched_launch_n<Body, LB, 1, P>(st, cnt, packs + lo, grids + lo, block, shmem);
     }
 }
 

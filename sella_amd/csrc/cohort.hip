@@ -93,6 +93,7 @@ struct sella_cohort {
     int current = -1;                             // member whose fiber is running (-1: the scheduler)
     // statistics of the last run / since creation
     long rounds = 0, launches_parked = 0, launches_issued = 0, waits_parked = 0, syncs = 0, barriers = 0;
+    std::map<std::string, double> host_by_park;             // ... and seconds of member host code in front of a park at that body / wait
     std::map<std::string, std::pair<long, long>> by_name;   // SELLA_COHORT_TRACE=2: body -> (launches asked, launches issued)
     double t_members = 0.0, t_issue = 0.0, t_sync = 0.0;      // seconds: member host code, issuing merged launches, stream synchronisations
 };
@@ -178,7 +179,17 @@ int advance(sella_cohort* co) {
         ++co->rounds;
         const double t0 = now();
         for (int i = 0; i < n; ++i)
-            if (co->fibers[i].state == F_RUNNABLE) resume(co, i);
+            if (co->fibers[i].state == F_RUNNABLE) {
+                if (count_names) {
+                    // host time of the member up to its next park, booked on what it parks at
+                    const double ta = now();
+                    resume(co, i);
+                    const Fiber& f = co->fibers[i];
+                    co->host_by_park[f.state == F_AT_LAUNCH ? f.name : f.state == F_AT_WAIT ? "(wait)" : f.state == F_AT_BARRIER ? "(barrier)" : "(done)"] += now() - ta;
+                } else {
+                    resume(co, i);
+                }
+            }
         const double t1 = now();
         co->t_members += t1 - t0;
         int nl = 0, nw = 0, nb = 0;
@@ -317,6 +328,8 @@ int sella_cohort_destroy(sella_cohort* co) {
     if (!co->by_name.empty()) {
         fprintf(stderr, "cohort of %d: launches asked / issued by kernel body\n", (int)co->members.size());
         for (const auto& kv : co->by_name) fprintf(stderr, "  %8ld %8ld  %s\n", kv.second.first, kv.second.second, kv.first.c_str());
+        fprintf(stderr, "microseconds of member host code in front of a park at\n");
+        for (const auto& kv : co->host_by_park) fprintf(stderr, "  %10.1f  host-before %s\n", 1e6 * kv.second, kv.first.c_str());
     }
     for (sella_ctx* c : co->members) c->cohort = nullptr;
     for (Fiber& f : co->fibers)

@@ -330,10 +330,18 @@ hipError_t s_memcpy2d(sella_ctx* c, void* dst, size_t dpitch, const void* src, s
     return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, kind, c->stream);
 }
 
-hipError_t s_memset0(sella_ctx* c, void* dst, size_t bytes) {
+hipError_t s_memset0(sella_ctx* c, void* dst, size_t bytes, const char* file, int line) {
     if (bytes == 0) return hipSuccess;
     if (cohort_copy_ok(c, dst, dst, bytes, 1)) {
         const size_t nw = bytes / 4;
+        static const bool sites = getenv("SELLA_COHORT_TRACE") && getenv("SELLA_COHORT_TRACE")[0] == '2';
+        if (sites) {                                   // (profiling aid: the call site as the launch's name)
+            static thread_local std::map<std::pair<const char*, int>, std::string> names;
+            std::string& nm = names[{file, line}];
+            if (nm.empty()) { const char* b = strrchr(file, '/'); nm = std::string("zero_words_vb@") + (b ? b + 1 : file) + ":" + std::to_string(line); }
+            cohort_launch<zero_words_vb, 256>(c, nm.c_str(), dim3((unsigned)((nw + 1023) / 1024)), dim3(256), 0, static_cast<unsigned*>(dst), nw);
+            return hipGetLastError();
+        }
         SELLA_LAUNCHB(c, zero_words_kernel, zero_words_vb, 256, dim3((unsigned)((nw + 1023) / 1024)), dim3(256), 0,
                       static_cast<unsigned*>(dst), nw);
         return hipGetLastError();

@@ -276,7 +276,7 @@ int d2h_async_2d(sella_ctx* c, void* dst, const void* src_dev, size_t spitch, si
 hipError_t s_memcpy(sella_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, bool host_pinned = false);
 hipError_t s_memcpy2d(sella_ctx* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows,
                       hipMemcpyKind kind, bool host_pinned = false);
-hipError_t s_memset0(sella_ctx* c, void* dst, size_t bytes);
+hipError_t s_memset0(sella_ctx* c, void* dst, size_t bytes, const char* file = __builtin_FILE(), int line = __builtin_LINE());
 int stream_wait(sella_ctx* c);
 int stream_sync_raw(sella_ctx* c);                                  // the synchronisation alone (nothing delivered, rings kept)
 int event_wait(sella_ctx* c, hipEvent_t ev);                        // wait for an event recorded on the context's stream

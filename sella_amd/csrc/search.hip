@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <vector>
 
 using namespace sella;
@@ -211,10 +212,14 @@ int diagonalise(sella_search* S) {
     }
     const int maxiter = 2 * m + 1;
     const int kmax = std::min(m, std::max(maxiter, nv0));
-    std::vector<double> lams((size_t)kmax + 1), V((size_t)m * (kmax + 1)), AV((size_t)m * (kmax + 1));
+    // (capacity for the largest subspace the solver may return, m x (kmax + 1) doubles twice — 2.4 MB for 384 free
+    //  coordinates, of which a run uses some twenty columns: NOT value-initialised, so only the pages the solver writes are
+    //  ever touched; a zero-filled std::vector cost 0.34 ms of page faults per diagonalisation)
+    std::vector<double> lams((size_t)kmax + 1);
+    std::unique_ptr<double[]> V(new double[(size_t)m * (kmax + 1)]), AV(new double[(size_t)m * (kmax + 1)]);
     int k = 0, nmv = 0;
     int st = sella_davidson(c, SELLA_NO_MAT, sella_fd_matvec, fd, hP, hPt, rP > 0 ? pevals : nullptr, pscale, m, start.data(), nv0,
-                            S->p.gamma, S->p.dav_method, maxiter, nullptr, 0.99, lams.data(), V.data(), AV.data(), &k, &nmv);
+                            S->p.gamma, S->p.dav_method, maxiter, nullptr, 0.99, lams.data(), V.get(), AV.get(), &k, &nmv);
     S->neval += sella_fd_calls(fd) * (S->p.threepoint ? 2 : 1);
     if (st != SELLA_OK) { sella_fd_destroy(fd); return cleanup(st); }
     const int kp = sella_fd_npairs(fd);

@@ -67,6 +67,10 @@ __host__ __device__ inline void bordered_root_core(int mm, DAt Dat, BAt bat, dou
     // the same sign there) next to the exact nearest pole — with the nearest pole alone these roots took 30-60
     // sweeps at the sizes of a slab search, now 3-6.  Bracket + bisection as the safeguard, stop at |f| below its rounding noise.
     const double EPS = 2.220446049250313e-16;
+    // (the root of the rational MODEL is only the next trial point: it is iterated to a relative step of 1e-6, not to the
+    //  last bit — round 6: the scalar model solves were 40 % of the Davidson loop's k x k Rayleigh-Ritz time and the O(1)
+    //  part of every trial alpha of the step families; the number of sweeps over the sum is unchanged)
+    const double MODEL_TOL = 1e-6;
     for (int it = 0; it < 200; ++it) {
         const Ev e = eval(shift, t);
         const double fv = e.f;
@@ -93,7 +97,9 @@ __host__ __device__ inline void bordered_root_core(int mm, DAt Dat, BAt bat, dou
                 double xn = x - Fx / dF;
                 if (!(xn > elo && xn < ehi)) xn = 0.5 * (elo + ehi);
                 if (xn == x) break;
+                const double moved = fabs(xn - x);
                 x = xn;
+                if (moved <= MODEL_TOL * fabs(x)) break;
                 const double q1 = a1 / (p1 - x), q2 = a2 / (p2 - x);
                 Fx = ((mu + x) + c0) + q1 + q2;
                 if (fabs(Fx) <= 4.0 * EPS * (fabs(mu + x) + fabs(c0) + fabs(q1) + fabs(q2))) break;
@@ -119,7 +125,9 @@ __host__ __device__ inline void bordered_root_core(int mm, DAt Dat, BAt bat, dou
                 double xn = x - Fx / dF;
                 if (!(xn > elo && xn < ehi)) xn = 0.5 * (elo + ehi);
                 if (xn == x) break;
+                const double moved = fabs(xn - x);
                 x = xn;
+                if (moved <= MODEL_TOL * fabs(x)) break;
                 Fx = (mu + x) + a1 / (p1 - x) + a2 / (p2 - x);
                 if (fabs(Fx) <= 4.0 * EPS * (fabs(mu + x) + fabs(a1 / (p1 - x)) + fabs(a2 / (p2 - x)))) break;
             }
@@ -137,8 +145,8 @@ __host__ __device__ inline void bordered_root_core(int mm, DAt Dat, BAt bat, dou
 }
 
 // host form: arrays D (ascending), b
-// wide: sum four terms at a time (the step families' O(m) problems); the Davidson loop's k x k Rayleigh-Ritz keeps the
-// sequential order — its trajectory is sensitive to the last bit and nothing is gained at k <= 40.
+// wide: sum four terms at a time (the step families' O(m) problems and, since round 6, the Davidson loop's k x k
+// Rayleigh-Ritz: once the model solves above stopped dominating, the divisions of the sums are what is left).
 inline void bordered_root(int mm, const double* D, const double* b, int j, int* origin, double* tau, bool wide = false) {
     double bb = 0.0;
     for (int i = 0; i < mm; ++i) bb += b[i] * b[i];

@@ -363,6 +363,44 @@ int event_wait(sella_ctx* c, hipEvent_t ev) {
     return SELLA_OK;
 }
 
+__global__ void poll_mark_kernel(unsigned long long* word, unsigned long long seq) {
+    __threadfence_system();
+    *reinterpret_cast<volatile unsigned long long*>(word) = seq;
+}
+
+int poll_mark(sella_ctx* c) {
+    if (!c->poll_word) {
+        void* p = nullptr;
+        HIPCHK(hipHostMalloc(&p, 64, hipHostMallocDefault));
+        c->poll_word = static_cast<unsigned long long*>(p);
+        *c->poll_word = 0;
+    }
+    ++c->poll_seq;
+    if (c->cohort && cohort_in_fiber()) return SELLA_OK;             // (the member parks at the wait: one synchronisation for all)
+    hipLaunchKernelGGL(poll_mark_kernel, dim3(1), dim3(1), 0, c->stream, c->poll_word, c->poll_seq);
+    HIPCHK(hipGetLastError());
+    return SELLA_OK;
+}
+
+int poll_wait(sella_ctx* c) {
+    if (c->cohort && cohort_in_fiber()) { cohort_park_wait(c); return SELLA_OK; }
+    const unsigned long long want = c->poll_seq;
+    long spins = 0;
+    while (__atomic_load_n(c->poll_word, __ATOMIC_ACQUIRE) != want) {
+        if ((++spins & 0xfffff) == 0 && hipStreamQuery(c->stream) != hipErrorNotReady) {
+            // the stream has drained (or failed) without the word arriving: fall back to the synchronisation's verdict
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (__atomic_load_n(c->poll_word, __ATOMIC_ACQUIRE) == want) break;
+            set_error("polled wait: the stream finished without the sequence word");
+            return SELLA_E_HIP;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return SELLA_OK;
+}
+
 int stream_wait(sella_ctx* c) {
     SCHK(stream_sync_raw(c));
     // (both streams: the rings below are shared, and a wait issued while a job is being queued on the second stream must
@@ -554,6 +592,7 @@ int sella_ctx_destroy(sella_ctx* c) {
     }
     if (c->hring) (void)hipHostFree(c->hring);
     if (c->dring) (void)hipHostFree(c->dring);
+    if (c->poll_word) (void)hipHostFree(c->poll_word);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -585,6 +624,7 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "eigh_wy_nb64_min")) c->opt.eigh_wy_nb64_min = value;
     else if (!strcmp(key, "dav_fuse_scale")) c->opt.dav_fuse_scale = value ? 1 : 0;
     else if (!strcmp(key, "dav_zero_copy")) c->opt.dav_zero_copy = value ? 1 : 0;
+    else if (!strcmp(key, "dav_poll")) c->opt.dav_poll = value ? 1 : 0;
     else if (!strcmp(key, "eigh_tail_lds")) c->opt.eigh_tail_lds = value < 0 ? 0 : value;
     else if (!strcmp(key, "eigh_wy_waves")) c->opt.eigh_wy_waves = value;
     else if (!strcmp(key, "lr_cholqr")) c->opt.lr_cholqr = value ? 1 : 0;

@@ -708,6 +708,13 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
     // Rayleigh-Ritz-dependent chain then holds two n x n passes (Q, A) instead of three.
     s.qt_mode = s.A != nullptr && s.Q != nullptr && s.prank == n && method >= SELLA_DAV_GD && method <= SELLA_DAV_JD0_ALT &&
                 vref == nullptr && !getenv("SELLA_DAV_SYNC") && !getenv("SELLA_DAV_NOQT");
+    // Polled waits (dav_poll) read the iteration's scalars where its kernels stored them — in the pinned mirror: the fused
+    // iteration then runs with host-visible scalars for the length of this call (restored on every way out).
+    struct HostScalarsScope {
+        sella_ctx* c; long saved;
+        ~HostScalarsScope() { c->opt.host_scalars = saved; }
+    } hs_scope{c, c->opt.host_scalars};
+    if (s.qt_mode && c->opt.dav_poll) c->opt.host_scalars = 1;
     if (maxiter <= 0) maxiter = 2 * n + 1;
     const int kstop = (n < maxiter) ? n : maxiter;
 
@@ -1062,12 +1069,15 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
                 // and there is nothing to copy), mark that point, queue the eigenbasis images of the new vector behind it
                 // (they run while the host decides and does the next Rayleigh-Ritz step), wait for the mark only
                 const int cnt = (int)(S0 + 8 + nneg);
+                const bool poll = c->opt.dav_poll && c->opt.host_scalars;
                 if (!c->opt.host_scalars)
                     DHIP(s_memcpy(c, c->hscal + DS_GRAM, c->dscal + DS_GRAM, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, true));
-                DHIP(hipEventRecord(s.ev, c->stream));
+                if (poll) DCHK(poll_mark(c));
+                else DHIP(hipEventRecord(s.ev, c->stream));
                 const double* xs[2] = {s.Vp + (size_t)k * s.ld, s.AVp + (size_t)k * s.ld};
                 DCHK(launch_gemv_rows_xp(c, s.Qt->d, n, n, s.Qt->ld, xs, 2, s.QtV + (size_t)k * s.ld, capn * s.ld, GemvEpi()));
-                DCHK(event_wait(c, s.ev));
+                if (poll) DCHK(poll_wait(c));
+                else DCHK(event_wait(c, s.ev));
             } else {
                 DCHK(sync_scalars(c, DS_GRAM, (int)(S0 + 8 + nneg)));
             }

@@ -194,7 +194,7 @@ inline int arrow_eig(int m, const double* Din, const double* zin, double alpha, 
         vec Dp(ma), bp(ma), tau(ma + 1), bh(ma);
         std::vector<int> org(ma + 1);
         for (int a = 0; a < ma; ++a) { Dp[a] = d[act[a]] - alpha; bp[a] = b[act[a]]; }
-        for (int j = 0; j <= ma; ++j) bordered::bordered_root(ma, Dp.data(), bp.data(), j, &org[j], &tau[j]);
+        for (int j = 0; j <= ma; ++j) bordered::bordered_root(ma, Dp.data(), bp.data(), j, &org[j], &tau[j], true);
         // mu_j - D_a with full relative accuracy
         auto diff = [&](int j, int a) { return (org[j] >= 0 ? (Dp[org[j]] - Dp[a]) : -Dp[a]) + tau[j]; };
         for (int a = 0; a < ma; ++a) {

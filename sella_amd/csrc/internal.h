@@ -118,6 +118,10 @@ struct Options {
     long panel_rows = 0;     // rows per workgroup of the panel kernel: 16, 32, 48, 64, or 0 = by size (one workgroup per CU)
     long eigh_wy_mfma = 1;   // 1: back-transformation on the matrix cores, 0: VALU/LDS variant
     long dav_fuse_scale = 1;     // Davidson chain: (d - theta)^-1 scaling in the epilogue of the residual kernel (0: own kernel)
+    long dav_poll = 1;           // ... 1: the fused iteration's one wait polls a sequence word in pinned host memory, written by a
+                                 //    one-thread kernel behind the iteration's last kernel (the scalars of the iteration are then
+                                 //    stored there by their kernels for the length of the call), instead of sleeping on an event — the wake-up of an interrupt-driven wait is
+                                 //    ~10 us of a ~95 us iteration
     long dav_zero_copy = 0;      // ... its coefficients read from pinned host memory instead of a copy launch (measured equal or slower)
     long eigh_tail_lds = 128;    // trailing blocks of at most this many rows (<= 128) are tridiagonalised by one workgroup in LDS (0: never)
     long eigh_wy_nb64_min = 2560; // 64 instead of 32 reflectors per block of the back-transformation from this many rows on (0: never)
@@ -232,6 +236,8 @@ struct sella_ctx {
     hipStream_t stream2 = nullptr;
     hipStream_t stream_main = nullptr;         // == stream except while a job is being queued on stream2
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned long long* poll_word = nullptr;   // pinned sequence word of polled waits (davidson.hip, dav_poll) and its last value
+    unsigned long long poll_seq = 0;
     bool stream2_detached = false;             // stream2 runs work no wait of the main chain has to cover (eigh.hip, WY factors)
     std::deque<Frame> frames;      // frames[d] = parked state of depth d (d != depth)
     int depth = 0;
@@ -279,7 +285,12 @@ hipError_t s_memcpy2d(sella_ctx* c, void* dst, size_t dpitch, const void* src, s
 hipError_t s_memset0(sella_ctx* c, void* dst, size_t bytes, const char* file = __builtin_FILE(), int line = __builtin_LINE());
 int stream_wait(sella_ctx* c);
 int stream_sync_raw(sella_ctx* c);                                  // the synchronisation alone (nothing delivered, rings kept)
-int event_wait(sella_ctx* c, hipEvent_t ev);                        // wait for an event recorded on the context's stream
+int event_wait(sella_ctx* c, hipEvent_t ev);
+// Polled wait: poll_mark queues a one-thread kernel that stores the next sequence number into a pinned word behind
+// everything queued so far; poll_wait spins on that word (a cohort member parks instead).  What kernels in front of the mark
+// stored into pinned host memory is visible when the word is.
+int poll_mark(sella_ctx* c);
+int poll_wait(sella_ctx* c);                        // wait for an event recorded on the context's stream
 int read_scalars(sella_ctx* c, int offset, int count);             // dscal -> hscal (sync)
 // Where a kernel should put scalars that only the HOST consumes next: with `host_scalars` on, the pinned,
 // device-visible host mirror itself (zero-copy: the readback is then just the stream synchronisation and the

@@ -96,6 +96,7 @@ void hipemu_note_launch(const char* kernel_text);      // HIPEMU_LAUNCH_LOG=<fil
 static inline void __syncthreads() { hipemu::block_barrier(); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
+static inline void __threadfence_system() {}
 
 template <class T>
 static inline T __shfl(T v, int src, int width = 64) {

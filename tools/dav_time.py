@@ -14,9 +14,10 @@ n = 3072
 A, P, g = hessian_like(n, 0)
 dA, dP = ctx.upload(A), ctx.upload(P)
 w, V, Vt = ctx.eigh(dP)
-for opt, zc in ((0, 0), (1, 0), (0, 1), (1, 1), (0, 0), (1, 1)):
+for opt, zc, poll in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 0, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)):
     ctx.set_option('host_scalars', opt)
     ctx.set_option('dav_zero_copy', zc)
+    ctx.set_option('dav_poll', poll)
     for mi in (40,):
         ctx.davidson(dA, n, g, 1e-32, method='jd0', maxiter=mi, Pvecs=V, PvecsT=Vt, pevals=w)
         t0 = time.perf_counter()
@@ -25,5 +26,5 @@ for opt, zc in ((0, 0), (1, 0), (0, 1), (1, 1), (0, 0), (1, 1)):
             out = ctx.davidson(dA, n, g, 1e-32, method='jd0', maxiter=mi, Pvecs=V, PvecsT=Vt, pevals=w)
         ctx.sync()
         dt = (time.perf_counter() - t0) / reps
-        print(f'host_scalars={opt} dav_zero_copy={zc} maxiter={mi}: {out[1].shape[1]} vectors, {1e3 * dt:.2f} ms per call, '
+        print(f'host_scalars={opt} dav_zero_copy={zc} dav_poll={poll} maxiter={mi}: {out[1].shape[1]} vectors, {1e3 * dt:.2f} ms per call, '
               f'{1e6 * dt / out[1].shape[1]:.1f} us per vector', flush=True)

@@ -158,6 +158,7 @@ struct Options {
                               //    batch that produced it (stepper.hip)
     long lr_pipe = 1;        // 1: the library search queues the force call in front of the update that consumes it: one wait for both (search.hip)
     long lr_chain = 1;       // 1: the O(n r) passes of the one-call step as five fused launches, merged coordinate kernels (lrstep.hip)
+    long rs_poll = 0;        // 1: the rounds of the batched root search wait by polling a pinned sequence word (context.hip, poll_wait); measured equal on the EMT slab (0.576 vs 0.577 ms per step: the mark kernel costs what the wake-up saves): off
     long gs_small = 2048;    // Gram-Schmidt of vectors of at most this many entries (<= 2048) in ONE launch of one workgroup, sweeps,
                              //    norms and accept / drop decisions included (gs.hip); 0: always the sweep-by-sweep launches
     long rs_batch = 1;       // 1: bisection phase of the restricted-step root find evaluates 15 trial alphas per round trip (stepper.hip)

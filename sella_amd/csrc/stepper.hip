@@ -852,7 +852,10 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         SELLA_LAUNCHB(c, rs_measure_kernel, rs_measure_vb, 256, dim3(BATCH_NODES), dim3(256), 0, cons, nout, dY, ldy, dscons, dw, dd1,
                            dinv, hres + 2);
         HIPCHK(hipGetLastError());
-        SCHK(stream_wait(c));
+        // (the values land in pinned host memory, written by the kernel itself: the wait polls a sequence word stored
+        //  behind it instead of sleeping in the runtime — nothing else is pending on the stream in a round)
+        if (c->opt.rs_poll && c->d2h_pending.empty()) { SCHK(poll_mark(c)); SCHK(poll_wait(c)); }
+        else SCHK(stream_wait(c));
         for (int q = 1; q <= BATCH_NODES; ++q) cval[q] = hres[1 + q];
         ++nbatch;
         return SELLA_OK;

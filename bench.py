@@ -599,9 +599,11 @@ def main():
                 # one stream synchronisation per phase): the 8 members of one GPU's share, then 8 x as many in flight
                 from sella_amd.ensemble import EnsembleCohorts
                 co_stats = {}
-                for tag, nmem_c, width_c, thr_c in (('share_of_one_gpu', args.ensemble_emt, max(1, args.ensemble_emt // 2), 2),
-                                                    ('saturated', 8 * args.ensemble_emt, 8, min(8, 2 * cpus_rank))):
-                    with EnsembleCohorts(width_c, thr_c) as cohorts:
+                # (member threads — the members' host code on a worker thread each, width + 1 spinning cores per cohort —
+                #  for the GPU's own share when the host has the cores; fibers for the saturated case)
+                for tag, nmem_c, width_c, thr_c, mt_c in (('share_of_one_gpu', args.ensemble_emt, max(1, args.ensemble_emt // 2), 2, cpus_rank >= 12),
+                                                          ('saturated', 8 * args.ensemble_emt, 8, min(8, 2 * cpus_rank), False)):
+                    with EnsembleCohorts(width_c, thr_c, member_threads=mt_c) as cohorts:
                         cohorts.prepare(emt_member)
                         run_ensemble(lambda i: emt_member(-1 - i), width_c * thr_c, fmax=0.0, steps=3,
                                      sella_kwargs=EmtSlabMember.SELLA_KW, cohort=cohorts)
@@ -616,7 +618,7 @@ def main():
                         after = cohorts.stats()
                     tc_ = sorted(cpasses)[len(cpasses) // 2]
                     npass = len(cpasses)
-                    co_stats[tag] = dict(replicas=nmem_c, cohort_width=width_c, issuing_threads=thr_c,
+                    co_stats[tag] = dict(replicas=nmem_c, cohort_width=width_c, issuing_threads=thr_c, member_threads=bool(mt_c),
                                          searches_per_s=round(nmem_c / tc_, 3), seconds=round(tc_, 3),
                                          passes_seconds=[round(t, 3) for t in cpasses],
                                          launches_asked_per_pass=(after['launches_asked'] - before['launches_asked']) // npass,

@@ -493,6 +493,10 @@ int sella_cohort_create(sella_ctx* const* members, int n, sella_cohort** cohort)
 int sella_cohort_size(sella_cohort* cohort);
 int sella_cohort_run_searches(sella_cohort* cohort, sella_search* const* searches, int n, double fmax, long steps,
                               int* converged, int* status);
+/* on != 0: the members' host code between their launches runs on a worker thread each instead of on fibers of the calling
+ * thread (parallel host code; the launches are still merged and issued by the caller of sella_cohort_run_searches); width + 1
+ * cores spin per cohort while it runs.  Results do not depend on the mode.                                            */
+int sella_cohort_member_threads(sella_cohort* cohort, int on);
 int sella_cohort_stats(sella_cohort* cohort, long* counters);
 const char* sella_cohort_error(sella_cohort* cohort, int member);
 int sella_cohort_destroy(sella_cohort* cohort);

@@ -133,6 +133,7 @@ SIGNATURES = {
     'sella_cohort_create': (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
     'sella_cohort_size': (c_int, [c_void_p]),
     'sella_cohort_run_searches': (c_int, [c_void_p, c_void_p, c_int, c_double, c_long, c_void_p, c_void_p]),
+    'sella_cohort_member_threads': (c_int, [c_void_p, c_int]),
     'sella_cohort_stats': (c_int, [c_void_p, c_void_p]),
     'sella_cohort_error': (c_char_p, [c_void_p, c_int]),
     'sella_cohort_destroy': (c_int, [c_void_p]),

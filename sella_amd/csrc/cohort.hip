@@ -6,10 +6,15 @@
 
 #include <sys/mman.h>
 
+#include <sched.h>
+
 #include <chrono>
+#include <condition_variable>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #if defined(__has_feature)
 #if __has_feature(address_sanitizer)
@@ -68,10 +73,11 @@ enum FiberState { F_IDLE = 0, F_RUNNABLE, F_AT_LAUNCH, F_AT_WAIT, F_AT_BARRIER, 
 struct Fiber {
     void* sp = nullptr;
     char* stack = nullptr;
-    FiberState state = F_IDLE;
+    int state = F_IDLE;                            // FiberState; with member threads: stored / loaded with release / acquire
     std::function<int()> job;
     int status = SELLA_OK;
     std::string error;
+    long n_launch = 0, n_wait = 0, n_barrier = 0;  // parks of this member (since creation of the cohort)
     // parked launch
     unsigned long long key = 0;                    // parked at a barrier: its position (smaller = further behind)
     BatchLauncher fn = nullptr;
@@ -79,7 +85,17 @@ struct Fiber {
     dim3 grid, block;
     size_t shmem = 0;
     alignas(16) char pack[COHORT_PACK_BYTES];
+    // member threads (sella_cohort_member_threads): the member's host code runs on a thread of its own
+    std::thread worker;
+    long job_seq = 0, job_seen = 0;                // guarded by the cohort's mutex
 };
+
+inline int load_state(const Fiber& f) { return __atomic_load_n(&f.state, __ATOMIC_ACQUIRE); }
+inline void store_state(Fiber& f, int st) { __atomic_store_n(&f.state, st, __ATOMIC_RELEASE); }
+inline void cpu_relax(long& spins) {
+    __builtin_ia32_pause();
+    if ((++spins & 0x3ff) == 0) sched_yield();     // (a preempted partner gets the core when there are fewer cores than spinners)
+}
 
 }  // namespace
 
@@ -91,8 +107,14 @@ struct sella_cohort {
     std::vector<Fiber> fibers;
     void* sched_sp = nullptr;
     int current = -1;                             // member whose fiber is running (-1: the scheduler)
+    // Member threads instead of fibers: the members' host code between their parks — serial on the fibers of the one
+    // issuing thread — runs in parallel, the launches are still merged and issued by the thread that advances the cohort.
+    // Every member thread and the issuing thread spin while they wait for each other: width + 1 busy cores per cohort.
+    bool member_threads = false, quit = false;
+    std::mutex mu;
+    std::condition_variable cv;
     // statistics of the last run / since creation
-    long rounds = 0, launches_parked = 0, launches_issued = 0, waits_parked = 0, syncs = 0, barriers = 0;
+    long rounds = 0, launches_issued = 0, syncs = 0;
     std::map<std::string, double> host_by_park;             // ... and seconds of member host code in front of a park at that body / wait
     std::map<std::string, std::pair<long, long>> by_name;   // SELLA_COHORT_TRACE=2: body -> (launches asked, launches issued)
     double t_members = 0.0, t_issue = 0.0, t_sync = 0.0;      // seconds: member host code, issuing merged launches, stream synchronisations
@@ -101,6 +123,15 @@ struct sella_cohort {
 namespace {
 
 thread_local sella_cohort* g_running = nullptr;   // the cohort this thread is advancing
+thread_local sella_cohort* g_member_of = nullptr; // member thread: its cohort ...
+thread_local int g_member_idx = -1;               // ... its slot ...
+thread_local bool g_member_busy = false;          // ... and whether it is inside a job
+
+inline Fiber& self_fiber(sella_cohort*& co) {
+    if (g_member_busy) { co = g_member_of; return co->fibers[g_member_idx]; }
+    co = g_running;
+    return co->fibers[co->current];
+}
 
 void fiber_main();
 
@@ -129,16 +160,21 @@ void fiber_prepare(Fiber& f) {
     f.sp = sp;
 }
 
-// from a member fiber back to the scheduler
-void park(sella_cohort* co, FiberState st) {
-    Fiber& f = co->fibers[co->current];
+// from a member back to the scheduler: a fiber switches stacks, a member thread publishes its state and spins until the
+// scheduler makes it runnable again (what it parked with — launch slot, barrier key — is written before the state)
+void park(sella_cohort* co, Fiber& f, FiberState st) {
+    if (co->member_threads) {
+        store_state(f, st);
+        if (st == F_DONE) return;
+        long spins = 0;
+        while (load_state(f) != F_RUNNABLE) cpu_relax(spins);
+        return;
+    }
     f.state = st;
     sella_fiber_switch(&f.sp, co->sched_sp);
 }
 
-void fiber_main() {
-    sella_cohort* co = g_running;
-    Fiber& f = co->fibers[co->current];
+int run_job(Fiber& f) {
     int st;
     try {
         st = f.job();
@@ -151,7 +187,33 @@ void fiber_main() {
     }
     f.status = st;
     if (st != SELLA_OK) f.error = sella_last_error();
-    park(co, F_DONE);
+    return st;
+}
+
+void member_thread_main(sella_cohort* co, int idx) {
+    (void)hipSetDevice(co->device);
+    g_member_of = co;
+    g_member_idx = idx;
+    Fiber& f = co->fibers[idx];
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(co->mu);
+            co->cv.wait(lk, [&] { return co->quit || f.job_seq != f.job_seen; });
+            if (co->quit) return;
+            f.job_seen = f.job_seq;
+        }
+        g_member_busy = true;
+        run_job(f);
+        g_member_busy = false;
+        store_state(f, F_DONE);
+    }
+}
+
+void fiber_main() {
+    sella_cohort* co = g_running;
+    Fiber& f = co->fibers[co->current];
+    run_job(f);
+    park(co, f, F_DONE);
     abort();                                       // a finished fiber is never resumed
 }
 
@@ -178,6 +240,12 @@ int advance(sella_cohort* co) {
     for (;;) {
         ++co->rounds;
         const double t0 = now();
+        if (co->member_threads) {
+            // the runnable members ARE running, each on its thread: wait until every one of them has parked again
+            long spins = 0;
+            for (int i = 0; i < n; ++i)
+                while (load_state(co->fibers[i]) == F_RUNNABLE) cpu_relax(spins);
+        } else
         for (int i = 0; i < n; ++i)
             if (co->fibers[i].state == F_RUNNABLE) {
                 if (count_names) {
@@ -194,7 +262,7 @@ int advance(sella_cohort* co) {
         co->t_members += t1 - t0;
         int nl = 0, nw = 0, nb = 0;
         for (int i = 0; i < n; ++i) {
-            const FiberState s = co->fibers[i].state;
+            const int s = load_state(co->fibers[i]);
             nl += s == F_AT_LAUNCH;
             nw += s == F_AT_WAIT;
             nb += s == F_AT_BARRIER;
@@ -226,7 +294,7 @@ int advance(sella_cohort* co) {
                 f.fn(co->stream, cnt, packs, grids, f.block, f.shmem);
                 ++co->launches_issued;
                 if (count_names) { auto& e = co->by_name[f.name]; e.first += cnt; e.second += 1; }
-                for (int q = 0; q < cnt; ++q) co->fibers[who[q]].state = F_RUNNABLE;
+                for (int q = 0; q < cnt; ++q) store_state(co->fibers[who[q]], F_RUNNABLE);
             }
             HIPCHK(hipGetLastError());
             co->t_issue += now() - t1;
@@ -244,14 +312,14 @@ int advance(sella_cohort* co) {
             co->t_sync += now() - t1;
             ++co->syncs;
             for (int i = 0; i < n; ++i)
-                if (co->fibers[i].state == F_AT_WAIT) co->fibers[i].state = F_RUNNABLE;
+                if (co->fibers[i].state == F_AT_WAIT) store_state(co->fibers[i], F_RUNNABLE);
             continue;
         }
         unsigned long long lowest = ~0ull;
         for (int i = 0; i < n; ++i)
             if (co->fibers[i].state == F_AT_BARRIER && co->fibers[i].key < lowest) lowest = co->fibers[i].key;
         for (int i = 0; i < n; ++i)
-            if (co->fibers[i].state == F_AT_BARRIER && co->fibers[i].key == lowest) co->fibers[i].state = F_RUNNABLE;
+            if (co->fibers[i].state == F_AT_BARRIER && co->fibers[i].key == lowest) store_state(co->fibers[i], F_RUNNABLE);
     }
 }
 
@@ -259,28 +327,29 @@ int advance(sella_cohort* co) {
 
 namespace sella {
 
-bool cohort_in_fiber() { return g_running != nullptr && g_running->current >= 0; }
+bool cohort_in_fiber() { return g_member_busy || (g_running != nullptr && g_running->current >= 0); }
 
 void cohort_park_launch(sella_ctx* c, BatchLauncher fn, const void* pack, size_t pack_bytes, dim3 grid, dim3 block, size_t shmem,
                         const char* name) {
-    sella_cohort* co = g_running;
     (void)c;
-    Fiber& f = co->fibers[co->current];
+    sella_cohort* co;
+    Fiber& f = self_fiber(co);
     f.fn = fn;
     f.name = name;
     f.grid = grid;
     f.block = block;
     f.shmem = shmem;
     memcpy(f.pack, pack, pack_bytes);
-    ++co->launches_parked;
-    park(co, F_AT_LAUNCH);
+    ++f.n_launch;
+    park(co, f, F_AT_LAUNCH);
 }
 
 void cohort_park_wait(sella_ctx* c) {
     (void)c;
-    sella_cohort* co = g_running;
-    ++co->waits_parked;
-    park(co, F_AT_WAIT);
+    sella_cohort* co;
+    Fiber& f = self_fiber(co);
+    ++f.n_wait;
+    park(co, f, F_AT_WAIT);
 }
 
 void cohort_set_phase(sella_ctx* c, long epoch, int stage) {
@@ -289,10 +358,11 @@ void cohort_set_phase(sella_ctx* c, long epoch, int stage) {
 
 void cohort_barrier(sella_ctx* c, unsigned iter, unsigned sub) {
     if (!c || !c->cohort || !cohort_in_fiber()) return;
-    sella_cohort* co = g_running;
-    ++co->barriers;
-    co->fibers[co->current].key = (c->cohort_phase << 32) | ((unsigned long long)(iter & 0xffffffu) << 8) | (sub & 0xffu);
-    park(co, F_AT_BARRIER);
+    sella_cohort* co;
+    Fiber& f = self_fiber(co);
+    ++f.n_barrier;
+    f.key = (c->cohort_phase << 32) | ((unsigned long long)(iter & 0xffffffu) << 8) | (sub & 0xffu);
+    park(co, f, F_AT_BARRIER);
 }
 
 }  // namespace sella
@@ -331,10 +401,31 @@ int sella_cohort_destroy(sella_cohort* co) {
         fprintf(stderr, "microseconds of member host code in front of a park at\n");
         for (const auto& kv : co->host_by_park) fprintf(stderr, "  %10.1f  host-before %s\n", 1e6 * kv.second, kv.first.c_str());
     }
+    {
+        std::lock_guard<std::mutex> lk(co->mu);
+        co->quit = true;
+    }
+    co->cv.notify_all();
+    for (Fiber& f : co->fibers)
+        if (f.worker.joinable()) f.worker.join();
     for (sella_ctx* c : co->members) c->cohort = nullptr;
     for (Fiber& f : co->fibers)
         if (f.stack) munmap(f.stack, FIBER_STACK);
     delete co;
+    return SELLA_OK;
+}
+
+// on != 0: the members' host code runs on a worker thread each (created here) instead of on fibers of the advancing thread:
+// parallel host code between the parks, the launches still merged by the advancing thread.  Width + 1 cores spin per cohort
+// while it runs — for a GPU's share of an ensemble on a host with cores to spare, not for many cohorts per GPU.
+int sella_cohort_member_threads(sella_cohort* co, int on) {
+    if (!co) return SELLA_E_INVALID;
+    if (g_running == co) { set_error("cohort: cannot change its members while it is being advanced"); return SELLA_E_INVALID; }
+    if (on && !co->member_threads) {
+        for (int i = 0; i < (int)co->fibers.size(); ++i)
+            if (!co->fibers[i].worker.joinable()) co->fibers[i].worker = std::thread(member_thread_main, co, i);
+    }
+    co->member_threads = on != 0;
     return SELLA_OK;
 }
 
@@ -345,8 +436,9 @@ int sella_cohort_size(sella_cohort* co) { return co ? (int)co->members.size() : 
 // launches — accumulated since creation
 int sella_cohort_stats(sella_cohort* co, long* counters) {
     if (!co || !counters) return SELLA_E_INVALID;
-    const long v[8] = {co->rounds, co->launches_parked, co->launches_issued, co->waits_parked, co->syncs, co->barriers,
-                       (long)(1e6 * co->t_members), (long)(1e6 * co->t_issue)};
+    long nl = 0, nw = 0, nb = 0;
+    for (const Fiber& f : co->fibers) { nl += f.n_launch; nw += f.n_wait; nb += f.n_barrier; }
+    const long v[8] = {co->rounds, nl, co->launches_issued, nw, co->syncs, nb, (long)(1e6 * co->t_members), (long)(1e6 * co->t_issue)};
     memcpy(counters, v, sizeof(v));
     return SELLA_OK;
 }
@@ -390,6 +482,12 @@ int sella_cohort_run_searches(sella_cohort* co, sella_search* const* searches, i
         sella_search* S = searches[i];
         int* conv = &converged[i];
         f.job = [S, fmax, steps, conv]() { return sella_search_run(S, fmax, steps, conv); };
+        if (co->member_threads) {
+            store_state(f, F_RUNNABLE);
+            std::lock_guard<std::mutex> lk(co->mu);
+            ++f.job_seq;
+            continue;
+        }
         fiber_prepare(f);
         if (!f.stack) {
             for (int j = 0; j < W; ++j) { co->members[j]->stream = co->own_stream[j]; co->members[j]->stream_main = co->own_stream[j]; }
@@ -398,6 +496,7 @@ int sella_cohort_run_searches(sella_cohort* co, sella_search* const* searches, i
         }
         f.state = F_RUNNABLE;
     }
+    if (co->member_threads) co->cv.notify_all();
     g_running = co;
     const int st = advance(co);
     g_running = nullptr;

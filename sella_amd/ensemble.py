@@ -346,7 +346,9 @@ class EnsembleCohort:
 
     MAX_WIDTH = 16
 
-    def __init__(self, width=8):
+    def __init__(self, width=8, member_threads=False):
+        """member_threads: the members' host code between their launches runs on a worker thread each instead of on fibers
+        of the issuing thread — parallel host code, merged launches; width + 1 cores spin while the cohort runs."""
         from . import device
         self.width = int(width)
         if not 1 <= self.width <= self.MAX_WIDTH:
@@ -363,6 +365,9 @@ class EnsembleCohort:
         h = c_void_p()
         _lib.check(_lib.lib().sella_cohort_create(arr, self.width, byref(h)))
         self._h = h
+        self.member_threads = bool(member_threads)
+        if self.member_threads:
+            _lib.check(_lib.lib().sella_cohort_member_threads(h, 1))
 
     def prepare(self, factory, members=()):
         """`factory.prepare(i)` for the members (host-side data), then `factory.warmup()` on every member context."""
@@ -486,8 +491,9 @@ class EnsembleCohorts:
     member's cohort-mates — which never influence its results — are fixed by its index.  `run_ensemble(..., cohort=...)`
     takes either class."""
 
-    def __init__(self, width=8, threads=2):
+    def __init__(self, width=8, threads=2, member_threads=False):
         from concurrent.futures import ThreadPoolExecutor
+        self.member_threads = bool(member_threads)
         import threading
         self.width, self.threads = int(width), int(threads)
         if self.threads < 1:
@@ -499,7 +505,7 @@ class EnsembleCohorts:
         self._each(lambda: None)
 
     def _enter(self):
-        co = EnsembleCohort(self.width)
+        co = EnsembleCohort(self.width, member_threads=self.member_threads)
         self._local.cohort = co
         with self._lock:
             self._all_cohorts.append(co)

@@ -230,7 +230,7 @@ def test_config3_ensemble_of_emt_slabs(ctx):
     for i in range(nrep):
         np.testing.assert_array_equal(res_c['positions'][i], res['positions'][i])
     assert 3 * st['launches_issued'] < st['launches_asked'] and 3 * st['stream_syncs'] < st['waits_asked'], st
-    with EnsembleCohorts(4, 2) as cohorts:
+    with EnsembleCohorts(4, 2, member_threads=True) as cohorts:          # (the members' host code on worker threads)
         res_c2 = run_ensemble(EmtMember(), nrep, fmax=0.0, steps=steps, sella_kwargs=kw, cohort=cohorts)
     with EnsembleCohort(3) as cohort:
         res_c3 = run_ensemble(EmtMember(), nrep, fmax=0.0, steps=steps, sella_kwargs=kw, cohort=cohort)

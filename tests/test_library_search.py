@@ -351,11 +351,18 @@ def test_cohort_members_are_bit_identical_to_searches_run_alone(ctx, rs):
         res = ensemble.run_ensemble(_cohort_member, nrep, fmax=0.0, steps=steps, sella_kwargs=kw, cohort=cohort)
         again = ensemble.run_ensemble(_cohort_member, nrep, fmax=0.0, steps=steps, sella_kwargs=kw, cohort=cohort)
         st = cohort.stats()
+    # the members' host code on worker threads instead of fibers (parallel host code, the same merged launches)
+    with ensemble.EnsembleCohort(3, member_threads=True) as cohort:
+        res_mt = ensemble.run_ensemble(_cohort_member, nrep, fmax=0.0, steps=steps, sella_kwargs=kw, cohort=cohort)
+        st_mt = cohort.stats()
+    assert st_mt['launches_issued'] < st_mt['launches_asked']
     assert device.get_context() is ctx
     for i in range(nrep):
         np.testing.assert_array_equal(res['summary'][i], alone[i][0])
         np.testing.assert_array_equal(res['positions'][i], alone[i][1])
         np.testing.assert_array_equal(again['summary'][i], alone[i][0])
+        np.testing.assert_array_equal(res_mt['summary'][i], alone[i][0])
+        np.testing.assert_array_equal(res_mt['positions'][i], alone[i][1])
     assert len({round(e, 9) for e in res['summary'][:, 2]}) == nrep
     assert st['launches_issued'] < st['launches_asked']                        # launches were merged across the members
     assert st['stream_syncs'] < st['waits_asked']

@@ -7,6 +7,8 @@ cp $S/bench_line.json $P/${RP}_bench_line.json
 for k in bench eigh davidson_loop block_iter optimizer_step; do cp $S/${k}_kernel_stats.md $P/${RP}_${k}_kernel_stats.md; done
 cp $S/opt_step_timeline.txt $P/${RP}_opt_step_timeline.txt; cp $S/emt_step_timeline.txt $P/${RP}_emt_step_timeline.txt
 cp $S/dav_iter_timeline.txt $P/${RP}_dav_iter_timeline.txt
+{ echo "# configs[3] in lockstep cohorts (session $TAG): tools/emt_ensemble.py — t<T>: T host threads, one member each at a time; c<W>x<T>: T issuing threads, each advancing a cohort of W members (csrc/cohort.hip)"; echo '```'; cat $S/emt_cohorts.log | cut -c1-400; echo '```'; echo; echo "## GPU busy fraction of one cohort of 8 (rocprofv3 --kernel-trace of tools/emt_ensemble.py 8 c8; tools/cohort_busy.py over the launches of the timed pass; the profiler slows the host side)"; echo '```'; cat $S/cohort_busy.txt | cut -c1-200; echo '```'; echo; echo "## launches asked for by the members / issued after merging, by kernel body; microseconds of member host code in front of each park (SELLA_COHORT_TRACE=2; warm-up pass included)"; echo '```'; cat $S/cohort_by_kernel.log | cut -c1-160; echo '```'; } > $P/${RP}_cohorts.md
+cp $S/member1_kernel_stats.md $P/${RP}_member_search_kernel_stats.md; cp $S/cohort8_kernel_stats.md $P/${RP}_cohort8_kernel_stats.md
 { echo "# tridiagonalisation at 3N = 3072 by trailing size (session $TAG): blocked chain above eigh_upd_max = 1024 rows, one launch per column below"; echo; cat $S/eigh_by_m.txt; echo; echo '## eigh wall time by switch-over size'; echo '```'; cat $S/eigh_switch.log; echo '```'; } > $P/${RP}_eigh_by_m.md
 { echo "# PMC passes (rocprofv3 --pmc <counter> with kernel dispatch tracing only, one counter group per run; tools/gpu_session.sh $TAG at the evidence head)"; echo;
   echo "Units: FETCH_SIZE / WRITE_SIZE in KiB as reported (raw). On gfx950 FETCH_SIZE counts a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM section): multiply FETCH by 2. Infinity-Cache hits are included."; echo;
@@ -20,7 +22,7 @@ cp $S/dav_iter_timeline.txt $P/${RP}_dav_iter_timeline.txt
 { echo "# threads, processes and RCCL on one GPU (session $TAG)"; echo; echo '## ensemble leg on host threads of ONE process, searches inside the library (tools/ensemble_threads.py: EnsembleThreads, one persistent device context per thread)'; echo '```'; cat $S/threads.log; echo '```'; echo '## the same with the general driver (SELLA_LIBRARY_SEARCH=0: ~10,000 host-language calls per member, interpreter lock held in between)'; echo '```'; cat $S/threads_general.log; echo '```'; echo '## one member, where its time goes (tools/ens_profile.py)'; echo '```'; grep "seconds per member\|update_H n=768\|structured eigen" $S/ens_profile.log | tail -8; sed -n 1,18p $S/ens_profile.log; echo '```'; echo '## ensemble leg: worker processes (tools/ensemble_probe.py; workers run with HSA_ENABLE_SDMA=0)'; echo '```'; cat $S/probe.log; echo '```'; echo '## fine-grained library calls from N Python threads, one context each (tools/thread_scaling.py)'; echo '```'; cat $S/thread_scaling.log; echo '```'; echo '## RCCL: one rank (tools/rccl_smoke.py)'; echo '```'; cat $S/rccl.log; echo '```'; echo '## RCCL: two ranks on the one GPU of the box (tools/rccl_two_ranks_one_gpu.py)'; echo '```'; cat $S/rccl2.log; echo '```'; } > $P/${RP}_threads_procs_rccl.md
 { echo "# eigensolver beyond the Infinity Cache (session $TAG): symmetric-aware trailing matvec + triangle-only trailing update from 5120 trailing rows on, 64-reflector blocks in the back-transformation from n = 4096 on"; echo; echo '## wall time per eigh (tools/eigh_only.py)'; echo '```'; cat $S/eigh_large.log; echo '```'; echo; echo '## kernels of one eigh at 3N = 12288'; echo; sed -n 3,22p $S/eigh12288_kernel_stats.md; echo; echo '## per-column kernels by trailing size (tools/trd_by_m.py)'; echo; cat $S/eigh12288_by_m.txt; } > $P/${RP}_eigh_large.md
 { echo "# optimizer step and configs[1] timings (session $TAG)"; for f in opt_3072 emt geodesic dav_time; do echo; echo "## $f.log"; echo '```'; cat $S/$f.log; echo '```'; done; } > $P/${RP}_timings.md
-python3 - "$S" <<'PY'
+python3 - "$S" "$RP" <<'PY'
 import json, re, sys
 S = sys.argv[1]
 p = 'profiles/pmc_traffic.json'
@@ -36,6 +38,30 @@ t['source'] = re.sub(r'session r0\d\w?', 'session ' + S.split('/')[-1], t['sourc
 nd = sum(int(d) for kk, d, v in rows if kk == 'FETCH_SIZE')
 t['dispatches'] = nd          # blocked chain only: trailing blocks of n-1 .. n-nd rows
 t['algorithmic_bytes_per_launch'] = round(sum(8 * m * m + 16 * m for m in range(t['n'] - nd, t['n'])) / nd)
+sess = S.split('/')[-1]
+def grab(path):
+    out = {}
+    for line in open(path):
+        m = re.search(r'(\S+)\s+dispatches=\s*(\d+) mean=([0-9.e+]+)', line)
+        if m:
+            out[m.group(1)] = (int(m.group(2)), float(m.group(3)), line.split('(')[0].replace('void ', '').replace('sella::', '').strip())
+    return out
+try:
+    r = {**grab(S + '/pmc_rank2k_FETCH.txt'), **grab(S + '/pmc_rank2k_WRITE.txt')}
+    k = d['rank2k_stream_kernel']
+    k['dispatches'] = r['FETCH_SIZE'][0]
+    k['FETCH_SIZE_kb_mean_raw'], k['WRITE_SIZE_kb_mean_raw'] = r['FETCH_SIZE'][1], r['WRITE_SIZE'][1]
+    k['bytes_per_launch'] = (2 * r['FETCH_SIZE'][1] + r['WRITE_SIZE'][1]) * 1024
+    k.pop('mean_duration_us', None)
+    k['source'] = 'profiles/%s_pmc.md (session %s); durations in profiles/%s_eigh_kernel_stats.md' % (sys.argv[2], sess, sys.argv[2])
+    w = {**grab(S + '/pmc_wy_l2req.txt'), **grab(S + '/pmc_wy_l2hit.txt'), **grab(S + '/pmc_wy_fetch.txt')}
+    key = 'wy_apply_mfma_kernel'
+    d[key] = {'n': 3072, 'dispatches': w['FETCH_SIZE'][0], 'kernel': w['FETCH_SIZE'][2], 'FETCH_SIZE_kb_raw': w['FETCH_SIZE'][1],
+              'bytes_fetched': 2 * w['FETCH_SIZE'][1] * 1024, 'TCP_TCC_READ_REQ': w['TCP_TCC_READ_REQ_sum'][1],
+              'TCC_HIT': w['TCC_HIT_sum'][1], 'TCC_MISS': w['TCC_MISS_sum'][1], 'algorithmic_bytes': 3 * 8 * 3072 * 3072,
+              'source': 'profiles/%s_pmc.md (session %s); duration in profiles/%s_eigh_kernel_stats.md' % (sys.argv[2], sess, sys.argv[2])}
+except Exception as e:                                   # noqa: BLE001
+    print('pmc_traffic.json: rank2k / wy entries not refreshed:', e)
 json.dump(d, open(p, 'w'), indent=1)
 print(vals)
 PY

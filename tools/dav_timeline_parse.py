@@ -16,7 +16,10 @@ for r in rows:
         its.append(cur); cur = []
     cur.append(r)
 its.append(cur)
-mid = its[len(its) // 2]
+# the iteration printed is the one with the MEDIAN span (what the rate of the loop corresponds to), not whichever sits in
+# the middle of the list
+inner = its[2:-1] if len(its) > 4 else its
+mid = sorted(inner, key=lambda it: it[-1][2] - it[0][1])[len(inner) // 2]
 t0 = mid[0][1]
 print('iteration with %d launches, span %.1f us, busy %.1f us' % (len(mid), (mid[-1][2] - t0) / 1e3, sum(r[3] for r in mid) / 1e3))
 prev_end = t0

@@ -15,6 +15,8 @@ if __name__ == '__main__':
     fac = EmtSlabMember()
     ref = None
     for mode in modes:
+        mt = mode.endswith('m')                                  # c<W>[x<T>]m: the members' host code on worker threads
+        mode = mode.rstrip('m')
         k = int(mode[1:].split('x')[0])
         nthr = int(mode.split('x')[1]) if 'x' in mode else 1
         if mode[0] == 't':
@@ -26,7 +28,7 @@ if __name__ == '__main__':
                 res = run_ensemble(fac, nmem, fmax=0.0, steps=20, sella_kwargs=EmtSlabMember.SELLA_KW, threads=pool)
                 dt = time.perf_counter() - t
         elif mode[0] == 'c':
-            with (EnsembleCohort(k) if nthr == 1 else EnsembleCohorts(k, nthr)) as pool:
+            with (EnsembleCohort(k, member_threads=mt) if nthr == 1 else EnsembleCohorts(k, nthr, member_threads=mt)) as pool:
                 pool.prepare(fac)
                 for i in range(nmem):
                     fac.prepare(i)
@@ -46,4 +48,4 @@ if __name__ == '__main__':
         same = True if ref is None else bool((res['summary'] == ref).all())
         ref = res['summary'] if ref is None else ref
         print('%s %d: %d members in %.3f s = %.1f searches/s (bit-identical to the first run: %s)'
-              % ({'t': 'threads', 'p': 'processes', 'c': '%d thread(s) x cohort of' % nthr}[mode[0]], k, nmem, dt, nmem / dt, same), flush=True)
+              % ({'t': 'threads', 'p': 'processes', 'c': '%d thread(s) x %scohort of' % (nthr, 'member-thread ' if mt else '')}[mode[0]], k, nmem, dt, nmem / dt, same), flush=True)

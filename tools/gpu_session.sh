@@ -39,14 +39,9 @@ say "== bench"
 timeout 900 python bench.py > $OUT/bench.log 2>&1; say "bench exit $?"
 tail -1 $OUT/bench.log > $OUT/bench_line.json; cat $OUT/bench_line.json | tee -a $OUT/session.log
 say "== kernel statistics"
-prof bench "bench.py --steps 5 --warmup 1 --no-cpu-baseline --ensemble-procs 0 (rocprofv3 --kernel-trace --stats)" python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --ensemble-procs 0
-if [ ! -s $OUT/bench_kernel_stats.md ]; then
-  # rocprofv3's kernel tracing has crashed inside a kernel launch issued from a worker thread of the ensemble leg
-  # (r03D: SIGSEGV under hipLaunchKernel -> rocprofiler -> memcpy; the same command passes unprofiled and passed under
-  # the profiler in r03C): the statistics are then taken with the leg's members run one after another in the rank thread
-  say "rocprof bench: profiler crashed with the threaded ensemble leg, repeated with --ensemble-threads 0"
-  prof bench "bench.py --steps 5 --warmup 1 --no-cpu-baseline --ensemble-procs 0 --ensemble-threads 0 (rocprofv3 --kernel-trace --stats)" python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --ensemble-procs 0 --ensemble-threads 0
-fi
+# (the threaded legs — ensemble threads, cohorts' issuing threads, concurrent problems — have crashed rocprofv3's kernel tracing
+#  inside a launch issued from a worker thread, r03D / r05G: the statistics are taken with those legs off)
+prof bench "bench.py --steps 5 --warmup 1 --no-cpu-baseline --ensemble-procs 0 --ensemble-threads 0 --concurrent 1 (rocprofv3 --kernel-trace --stats)" python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --ensemble-procs 0 --ensemble-threads 0 --concurrent 1
 prof eigh "tools/eigh_only.py 3072 4 (rocprofv3 --kernel-trace --stats)" python $R/tools/eigh_only.py 3072 4
 prof davidson_loop "tools/dav_time.py (rocprofv3 --kernel-trace --stats)" python $R/tools/dav_time.py
 prof block_iter "tools/block_iter.py 12288 12 (rocprofv3 --kernel-trace --stats)" python $R/tools/block_iter.py 12288 12
@@ -64,9 +59,9 @@ done
 pmc rank2k_FETCH rank2k_stream FETCH_SIZE -- python $R/tools/eigh_only.py 3072 1
 pmc rank2k_WRITE rank2k_stream WRITE_SIZE -- python $R/tools/eigh_only.py 3072 1
 # L2 re-read traffic of the back-transformation (requests from the CUs into L2, hits / misses there)
-pmc wy_l2req wy_apply_mfma TCP_TCC_READ_REQ_sum -- python $R/tools/eigh_only.py 3072 1
-pmc wy_l2hit wy_apply_mfma TCC_HIT_sum TCC_MISS_sum -- python $R/tools/eigh_only.py 3072 1
-pmc wy_fetch wy_apply_mfma FETCH_SIZE -- python $R/tools/eigh_only.py 3072 1
+pmc wy_l2req wy_apply_ TCP_TCC_READ_REQ_sum -- python $R/tools/eigh_only.py 3072 1
+pmc wy_l2hit wy_apply_ TCC_HIT_sum TCC_MISS_sum -- python $R/tools/eigh_only.py 3072 1
+pmc wy_fetch wy_apply_ FETCH_SIZE -- python $R/tools/eigh_only.py 3072 1
 say "== MFMA utilisation (PMC): block product, eigensolver kernels"
 (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc_mfma_panel -o pmc -- python $R/tools/panel_bench.py 12288 16 > $R/$OUT/pmc_mfma_panel.log 2>&1); say "pmc mfma panel exit $?"
 DBM=$(find $OUT/pmc_mfma_panel -name "*.db" | head -1)
@@ -74,7 +69,7 @@ python tools/mfma_util.py $DBM panel16_mfma_kernel 4831838208 > $OUT/pmc_mfma.tx
 rm -rf $OUT/pmc_mfma_panel
 (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $R/$OUT/pmc_mfma_eigh -o pmc -- python $R/tools/eigh_only.py 3072 1 > $R/$OUT/pmc_mfma_eigh.log 2>&1); say "pmc mfma eigh exit $?"
 DBM=$(find $OUT/pmc_mfma_eigh -name "*.db" | head -1)
-python tools/mfma_util.py $DBM wy_apply_mfma 57982058496 >> $OUT/pmc_mfma.txt 2>&1
+python tools/mfma_util.py $DBM wy_apply_ 57982058496 >> $OUT/pmc_mfma.txt 2>&1
 python tools/mfma_util.py $DBM gemm128_merge_batched_kernel >> $OUT/pmc_mfma.txt 2>&1
 python tools/mfma_util.py $DBM rank2k_stream_fixed_kernel >> $OUT/pmc_mfma.txt 2>&1
 rm -rf $OUT/pmc_mfma_eigh
@@ -91,6 +86,14 @@ timeout 600 python tools/opt_ab.py 3072 30 > $OUT/opt_ab.log 2>&1; cat $OUT/opt_
 { python tools/emt_slab_lib.py 20; python tools/emt_slab_lib.py 20 lr_chain=0 lr_pipe=0; python tools/emt_slab_lib.py 20; } > $OUT/emt_lib_ab.log 2>&1; cat $OUT/emt_lib_ab.log | tee -a $OUT/session.log
 say "== configs[3] as named: 256-atom EMT members on host threads"
 timeout 300 python tools/emt_ensemble.py 64 t1 t4 t8 t16 > $OUT/emt_ensemble.log 2>&1; cat $OUT/emt_ensemble.log | tee -a $OUT/session.log
+say "== configs[3] in lockstep cohorts (csrc/cohort.hip): one issuing thread per cohort, one batched launch per kernel for its members"
+timeout 300 python tools/emt_ensemble.py 8 t8 c8 c4x2 c3x3 c2x4 > $OUT/emt_cohorts.log 2>&1; timeout 300 python tools/emt_ensemble.py 64 t12 c16x4 c8x8 >> $OUT/emt_cohorts.log 2>&1; grep -v "^  cohort" $OUT/emt_cohorts.log | tee -a $OUT/session.log
+grep "^  cohort" $OUT/emt_cohorts.log | cut -c1-330 >> $OUT/session.log
+SELLA_COHORT_TRACE=2 timeout 300 python tools/emt_ensemble.py 8 c8 > /dev/null 2> $OUT/cohort_by_kernel.log
+KEEP_DB=1 bash tools/prof_cmd.sh $TAG cohort8 python $R/tools/emt_ensemble.py 8 c8 > /dev/null
+NCO=$(grep -o "launches_issued.: [0-9]*" $OUT/rocprof_cohort8.log | tail -1 | grep -o "[0-9]*$")
+{ grep "members in" $OUT/rocprof_cohort8.log; python tools/cohort_busy.py $OUT/cohort8.db $NCO; } > $OUT/cohort_busy.txt 2>&1; rm -f $OUT/cohort8.db; cat $OUT/cohort_busy.txt | cut -c1-200 | tee -a $OUT/session.log
+KEEP_DB=1 bash tools/prof_cmd.sh $TAG member1 python $R/tools/emt_member_time.py > /dev/null; rm -f $OUT/member1.db
 say "== eigensolver at 3N = 6144 / 8192 / 12288: defaults, then symmetric-aware matvec and 64-reflector blocks off"
 { for n in 6144 8192 12288; do
     echo "n = $n, defaults (eigh_symv_min 5120, eigh_wy_nb64_min 2560)"; timeout 300 python tools/eigh_only.py $n 3 2>&1 | tail -2

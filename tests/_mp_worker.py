@@ -69,12 +69,12 @@ def ensemble_cohort(out_path, n_replicas, sharded):
         import torch.distributed as dist
         dist.init_process_group(backend='gloo')
         with EnsembleCohort(2) as cohort:
-            res = run_ensemble(make_library_replica, n_replicas, fmax=0.0, steps=4, sella_kwargs=COHORT_KW, cohort=cohort)
+            res = run_ensemble(make_library_replica, n_replicas, fmax=0.0, steps=3, sella_kwargs=COHORT_KW, cohort=cohort)
             st = cohort.stats()
         assert st['launches_issued'] < st['launches_asked'] or len(res['summary']) < 2 * dist.get_world_size()
         rank0 = dist.get_rank() == 0
     else:
-        res = run_ensemble(make_library_replica, n_replicas, fmax=0.0, steps=4, sella_kwargs=COHORT_KW)
+        res = run_ensemble(make_library_replica, n_replicas, fmax=0.0, steps=3, sella_kwargs=COHORT_KW)
         rank0 = True
     if rank0:
         np.savez(out_path, summary=res['summary'], owner=res['owner'], **{f'pos{i}': p for i, p in enumerate(res['positions'])})

@@ -63,7 +63,7 @@ def test_ensemble_cohorts_two_ranks_match_members_run_alone(tmp_path):
     np.testing.assert_array_equal(a['summary'], b['summary'])
     for i in range(n_rep):
         np.testing.assert_array_equal(a[f'pos{i}'], b[f'pos{i}'])
-    assert np.all(a['summary'][:, 1] == 4) and len({round(e, 9) for e in a['summary'][:, 2]}) == n_rep
+    assert np.all(a['summary'][:, 1] == 3) and len({round(e, 9) for e in a['summary'][:, 2]}) == n_rep
 
 
 def test_ensemble_host_threads_match_serial(tmp_path):

@@ -111,6 +111,7 @@ struct sella_cohort {
     // issuing thread — runs in parallel, the launches are still merged and issued by the thread that advances the cohort.
     // Every member thread and the issuing thread spin while they wait for each other: width + 1 busy cores per cohort.
     bool member_threads = false, quit = false;
+    bool broken = false;                          // a run ended on a HIP error with member threads still parked inside their searches
     std::mutex mu;
     std::condition_variable cv;
     // statistics of the last run / since creation
@@ -407,7 +408,11 @@ int sella_cohort_destroy(sella_cohort* co) {
     }
     co->cv.notify_all();
     for (Fiber& f : co->fibers)
-        if (f.worker.joinable()) f.worker.join();
+        if (f.worker.joinable()) {
+            if (co->broken) f.worker.detach();
+            else f.worker.join();
+        }
+    if (co->broken) return SELLA_OK;                                  // (leaked on purpose: parked threads still point into it)
     for (sella_ctx* c : co->members) c->cohort = nullptr;
     for (Fiber& f : co->fibers)
         if (f.stack) munmap(f.stack, FIBER_STACK);
@@ -457,6 +462,7 @@ int sella_cohort_run_searches(sella_cohort* co, sella_search* const* searches, i
         return SELLA_E_INVALID;
     }
     if (g_running) { set_error("cohort: a cohort is already being advanced on this thread"); return SELLA_E_INVALID; }
+    if (co->broken) { set_error("cohort: an earlier run ended on a device error"); return SELLA_E_INVALID; }
     for (int i = 0; i < n; ++i)
         if (searches[i] && sella_search_ctx(searches[i]) != co->members[i]) {
             set_error("cohort: search %d does not live on member context %d", i, i);
@@ -500,6 +506,7 @@ int sella_cohort_run_searches(sella_cohort* co, sella_search* const* searches, i
     g_running = co;
     const int st = advance(co);
     g_running = nullptr;
+    if (st != SELLA_OK && co->member_threads) co->broken = true;      // (their searches cannot be unwound: the threads are left behind)
     (void)hipStreamSynchronize(co->stream);
     for (int i = 0; i < W; ++i) {
         sella_ctx* c = co->members[i];

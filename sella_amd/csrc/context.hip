@@ -382,6 +382,26 @@ int poll_mark(sella_ctx* c) {
     return SELLA_OK;
 }
 
+int poll_arm(sella_ctx* c, unsigned long long** word, unsigned long long* seq, unsigned** count) {
+    *word = nullptr; *seq = 0; *count = nullptr;
+    if (!c->poll_word) {
+        void* p = nullptr;
+        HIPCHK(hipHostMalloc(&p, 64, hipHostMallocDefault));
+        c->poll_word = static_cast<unsigned long long*>(p);
+        *c->poll_word = 0;
+    }
+    if (!c->poll_count) {
+        HIPCHK(hipMalloc((void**)&c->poll_count, 64));
+        HIPCHK(hipMemsetAsync(c->poll_count, 0, 64, c->stream));
+    }
+    ++c->poll_seq;
+    if (c->cohort && cohort_in_fiber()) return SELLA_OK;
+    *word = c->poll_word;
+    *seq = c->poll_seq;
+    *count = c->poll_count;
+    return SELLA_OK;
+}
+
 int poll_wait(sella_ctx* c) {
     if (c->cohort && cohort_in_fiber()) { cohort_park_wait(c); return SELLA_OK; }
     const unsigned long long want = c->poll_seq;
@@ -593,6 +613,7 @@ int sella_ctx_destroy(sella_ctx* c) {
     if (c->hring) (void)hipHostFree(c->hring);
     if (c->dring) (void)hipHostFree(c->dring);
     if (c->poll_word) (void)hipHostFree(c->poll_word);
+    if (c->poll_count) (void)hipFree(c->poll_count);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);

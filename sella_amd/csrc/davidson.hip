@@ -578,8 +578,24 @@ __device__ __forceinline__ void dav_final_vb(const VB vb, int n, int k, int cap,
                                                         const double* __restrict__ t2, const double* __restrict__ At2,
                                                         const double* __restrict__ part1, const double* __restrict__ part2,
                                                         int nblk, int nblke, double* __restrict__ vslot,
-                                                        double* __restrict__ avslot, double* __restrict__ out) {
+                                                        double* __restrict__ avslot, double* __restrict__ out,
+                                                        unsigned long long* pword, unsigned long long pseq, unsigned* pcount) {
     __shared__ double red[4];
+    // Polled wait (context.hip, poll_wait): the LAST workgroup to finish stores the sequence word into pinned host memory —
+    // every workgroup makes its own stores visible system-wide, then counts itself; who counts last resets the counter
+    // and publishes.  (No one-thread kernel behind this one: its launch boundary was 3 us of every iteration.)
+    auto publish = [&]() {
+        if (pword == nullptr) return;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            if (atomicAdd(pcount, 1u) == vb.gx - 1) {
+                *pcount = 0u;
+                __threadfence_system();
+                *reinterpret_cast<volatile unsigned long long*>(pword) = pseq;
+            }
+        }
+    };
     const double n2sq = df_sum_partials(part2, nblk, red);
     const double inv2 = 1.0 / sqrt(n2sq);
     const int b = vb.x;
@@ -598,6 +614,7 @@ __device__ __forceinline__ void dav_final_vb(const VB vb, int n, int k, int cap,
                 out[3 * (size_t)cap + 2] = n2sq;
             }
         }
+        publish();
         return;
     }
     const int r = b - nblke;
@@ -634,13 +651,15 @@ __device__ __forceinline__ void dav_final_vb(const VB vb, int n, int k, int cap,
             out[k] = n2sq * inv2 * inv2;
         }
     }
+    publish();
 }
 __global__ __launch_bounds__(256) void dav_final_kernel(int n, int k, int cap, const double* __restrict__ V,
                                                         const double* __restrict__ AV, int ld,
                                                         const double* __restrict__ t2, const double* __restrict__ At2,
                                                         const double* __restrict__ part1, const double* __restrict__ part2,
                                                         int nblk, int nblke, double* __restrict__ vslot,
-                                                        double* __restrict__ avslot, double* __restrict__ out) { dav_final_vb(vb_hw(), n, k, cap, V, AV, ld, t2, At2, part1, part2, nblk, nblke, vslot, avslot, out); }
+                                                        double* __restrict__ avslot, double* __restrict__ out,
+                                                        unsigned long long* pword, unsigned long long pseq, unsigned* pcount) { dav_final_vb(vb_hw(), n, k, cap, V, AV, ld, t2, At2, part1, part2, nblk, nblke, vslot, avslot, out, pword, pseq, pcount); }
 
 }  // namespace
 }  // namespace sella
@@ -1060,20 +1079,24 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
             DCHK(launch_gemv_rows2(c, s.A->d, n, s.A->ld, s.Vp, k, s.ld, n, t1, At1, c2d));     // [A; V] t1 in one launch
             SELLA_LAUNCHB(c, dav_gs2_kernel, dav_gs2_vb, 256, dim3(nblk), dim3(256), 0, n, k, s.Vp, s.AVp, s.ld, t1, At1, c2d, part,
                                nblk, t2, At2, part + 2 * DF_MAXBLK);
+            // (polled wait: the kernel's last workgroup publishes the sequence word itself)
+            const bool poll = s.qt_mode && c->opt.dav_poll && c->opt.host_scalars;
+            unsigned long long* pword = nullptr;
+            unsigned long long pseq = 0;
+            unsigned* pcount = nullptr;
+            if (poll) DCHK(poll_arm(c, &pword, &pseq, &pcount));
             SELLA_LAUNCHB(c, dav_final_kernel, dav_final_vb, 256, dim3(nblke + 2 * k + 1), dim3(256), 0, n, k, capn, s.Vp, s.AVp, s.ld,
                                t2, At2, part, part + 2 * DF_MAXBLK, nblk, nblke, s.Vp + (size_t)k * s.ld,
-                               s.AVp + (size_t)k * s.ld, dsc);
+                               s.AVp + (size_t)k * s.ld, dsc, pword, pseq, pcount);
             DHIP(hipGetLastError());
             if (s.qt_mode) {
                 // read the scalars back (host_scalars: the kernels have written them into pinned host memory themselves
                 // and there is nothing to copy), mark that point, queue the eigenbasis images of the new vector behind it
                 // (they run while the host decides and does the next Rayleigh-Ritz step), wait for the mark only
                 const int cnt = (int)(S0 + 8 + nneg);
-                const bool poll = c->opt.dav_poll && c->opt.host_scalars;
                 if (!c->opt.host_scalars)
                     DHIP(s_memcpy(c, c->hscal + DS_GRAM, c->dscal + DS_GRAM, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, true));
-                if (poll) DCHK(poll_mark(c));
-                else DHIP(hipEventRecord(s.ev, c->stream));
+                if (!poll) DHIP(hipEventRecord(s.ev, c->stream));
                 const double* xs[2] = {s.Vp + (size_t)k * s.ld, s.AVp + (size_t)k * s.ld};
                 DCHK(launch_gemv_rows_xp(c, s.Qt->d, n, n, s.Qt->ld, xs, 2, s.QtV + (size_t)k * s.ld, capn * s.ld, GemvEpi()));
                 if (poll) DCHK(poll_wait(c));

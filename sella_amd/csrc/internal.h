@@ -239,6 +239,7 @@ struct sella_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long* poll_word = nullptr;   // pinned sequence word of polled waits (davidson.hip, dav_poll) and its last value
     unsigned long long poll_seq = 0;
+    unsigned* poll_count = nullptr;            // device counter of poll_arm (zero between uses)
     bool stream2_detached = false;             // stream2 runs work no wait of the main chain has to cover (eigh.hip, WY factors)
     std::deque<Frame> frames;      // frames[d] = parked state of depth d (d != depth)
     int depth = 0;
@@ -291,6 +292,9 @@ int event_wait(sella_ctx* c, hipEvent_t ev);
 // everything queued so far; poll_wait spins on that word (a cohort member parks instead).  What kernels in front of the mark
 // stored into pinned host memory is visible when the word is.
 int poll_mark(sella_ctx* c);
+// the same without the extra kernel: the LAST workgroup of the caller's kernel publishes `seq` to `*word` (pinned) after
+// counting itself on `*count` (device, zero between uses); on a member fiber of a cohort all three come back null / 0
+int poll_arm(sella_ctx* c, unsigned long long** word, unsigned long long* seq, unsigned** count);
 int poll_wait(sella_ctx* c);                        // wait for an event recorded on the context's stream
 int read_scalars(sella_ctx* c, int offset, int count);             // dscal -> hscal (sync)
 // Where a kernel should put scalars that only the HOST consumes next: with `host_scalars` on, the pinned,

@@ -1320,15 +1320,17 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
         SCHK(scratch_get(c, SCR_UPD1, (size_t)2 * ld * sizeof(double), &UZp));
         SCHK(scratch_get(c, SCR_UPD2, ((size_t)5 * lds + ldmus + 16 + (size_t)m / 2 + 8) * sizeof(double), &Xs));
         int* didx = reinterpret_cast<int*>(Xs + 5 * (size_t)lds + ldmus + 16);
-        SCHK(h2d_async(c, didx, a->idx, (size_t)m * sizeof(int)));
+        if (!vfused) SCHK(h2d_async(c, didx, a->idx, (size_t)m * sizeof(int)));          // (fused: rides with the eigenvalues below)
         gsub.resize((size_t)m);
         S.Wt = Ws; S.r = *a->r_sub; S.n = m; S.mode = 1; S.mu = a->mu_sub; S.lam0 = a->lam0; S.Xd = Xs; S.ldx = lds;
         S.gram = nullptr; S.want_modes = propose; S.slot_ws = SCR_EIG2; S.slot_panel = SCR_EIG3;
         if (vfused) {
             // u, z on the view's coordinates, their copies as residual rows, their Gram partials, the gradient: one launch
-            std::vector<double> small((size_t)ldmus + 16, 0.0);
+            // eigenvalues of the view + the index map behind them: one transfer (they are neighbours on the device)
+            std::vector<double> small((size_t)ldmus + 16 + (size_t)(m + 1) / 2, 0.0);
             std::copy(a->mu_sub, a->mu_sub + *a->r_sub, small.begin());
-            SCHK(h2d_async(c, Xs + 5 * (size_t)lds, small.data(), small.size() * sizeof(double)));
+            memcpy(small.data() + ldmus + 16, a->idx, (size_t)m * sizeof(int));
+            SCHK(h2d_async(c, Xs + 5 * (size_t)lds, small.data(), ((size_t)ldmus + 16) * sizeof(double) + (size_t)m * sizeof(int)));
             ViewRowsArgs va;
             va.E = Wm->d; va.lde = Wm->ld; va.nr = nr; va.UZ = F.w.UZ; va.idx = didx; va.m = m; va.lds = lds;
             va.gsrc = piped ? X + 2 * (size_t)ld : nullptr; va.Xs = Xs;

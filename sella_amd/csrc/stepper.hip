@@ -798,27 +798,45 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
     // node 2q + 1 of its upper half; computed with the reference's own expression 0.5 * (lower + upper).
     constexpr int BATCH_LEVELS = 4, BATCH_NODES = (1 << BATCH_LEVELS) - 1;
     const bool can_batch = !eig_only && !newton_safe && c->opt.rs_batch && (st->panel || ((V->ld % 4 == 0) && m <= V->ld));
-    double* dbatch = nullptr;                  // lam | ghat | d1hat | X (16 x ld) | Y (16 x ldy) | inv
+    double* dbatch = nullptr;                  // lam | ghat | d1hat | X (16 x ldb) | inv | Y (16 x ldy)
     double* batch_Y = nullptr;                 // Y of the last batch
     int ldb = 0;
     bool batch_ready = false;
     double cand[BATCH_NODES + 1], cval[BATCH_NODES + 1];
     int nbatch = 0;
+    // device layout: lam | ghat | d1hat | X (16 x ldb, zero) | inv (nout ints, padded to ldy / 2 + 8 doubles) | Y (16 x ldy)
+    const size_t inv_doubles = (size_t)ldy / 2 + 8;
     auto batch_setup = [&]() -> int {
         ldb = st->panel ? round_up(m, 8) : V->ld;
-        const size_t need = (size_t)3 * ldx + (size_t)16 * ldb + (size_t)16 * ldy + (size_t)ldy + 64;
+        const size_t nup = (size_t)3 * ldx + (size_t)16 * ldb + inv_doubles;      // what comes from the host, in front of Y
+        const size_t need = nup + (size_t)16 * ldy + 64;
         SCHK(scratch_get(c, SCR_STEP2, need * sizeof(double), &dbatch));
-        std::vector<double> pack((size_t)3 * ldx, 0.0);
-        std::copy(st->lam.begin(), st->lam.end(), pack.begin());
-        std::copy(st->ghat.begin(), st->ghat.end(), pack.begin() + ldx);
-        if ((int)st->d1hat.size() == m) std::copy(st->d1hat.begin(), st->d1hat.end(), pack.begin() + 2 * (size_t)ldx);
-        SCHK(h2d_async(c, dbatch, pack.data(), pack.size() * sizeof(double)));
-        HIPCHK(s_memset0(c, dbatch + 3 * (size_t)ldx, (size_t)16 * ldb * sizeof(double)));
-        if (sel) {
-            std::vector<int> inv(nout, -1);
-            for (int i = 0; i < nfam; ++i) inv[sel[i]] = i;
-            SCHK(h2d_async(c, dbatch + 3 * (size_t)ldx + (size_t)16 * ldb + (size_t)16 * ldy, inv.data(),
-                           (size_t)nout * sizeof(int)));
+        // ONE transfer for the spectrum, the zero-filled candidate matrix and the index map of the view (round 6: they
+        // were an upload, a fill and an upload — three small operations and their gaps in front of the first round)
+        void* slot = nullptr;
+        if (h2d_begin(c, nup * sizeof(double), &slot) == SELLA_OK) {           // (zeroed by h2d_begin)
+            double* pk = static_cast<double*>(slot);
+            std::copy(st->lam.begin(), st->lam.end(), pk);
+            std::copy(st->ghat.begin(), st->ghat.end(), pk + ldx);
+            if ((int)st->d1hat.size() == m) std::copy(st->d1hat.begin(), st->d1hat.end(), pk + 2 * (size_t)ldx);
+            if (sel) {
+                int* inv = reinterpret_cast<int*>(pk + 3 * (size_t)ldx + (size_t)16 * ldb);
+                for (int i = 0; i < nout; ++i) inv[i] = -1;
+                for (int i = 0; i < nfam; ++i) inv[sel[i]] = i;
+            }
+            SCHK(h2d_end(c, dbatch, slot, nup * sizeof(double)));
+        } else {                                                                // (beyond half the ring: the separate operations)
+            std::vector<double> pack((size_t)3 * ldx, 0.0);
+            std::copy(st->lam.begin(), st->lam.end(), pack.begin());
+            std::copy(st->ghat.begin(), st->ghat.end(), pack.begin() + ldx);
+            if ((int)st->d1hat.size() == m) std::copy(st->d1hat.begin(), st->d1hat.end(), pack.begin() + 2 * (size_t)ldx);
+            SCHK(h2d_async(c, dbatch, pack.data(), pack.size() * sizeof(double)));
+            HIPCHK(s_memset0(c, dbatch + 3 * (size_t)ldx, (size_t)16 * ldb * sizeof(double)));
+            if (sel) {
+                std::vector<int> inv(nout, -1);
+                for (int i = 0; i < nfam; ++i) inv[sel[i]] = i;
+                SCHK(h2d_async(c, dbatch + 3 * (size_t)ldx + (size_t)16 * ldb, inv.data(), (size_t)nout * sizeof(int)));
+            }
         }
         batch_ready = true;
         return SELLA_OK;
@@ -842,9 +860,9 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         ba.alpha[15] = 0.0;
         ba.lam = dbatch; ba.ghat = dbatch + ldx; ba.d1hat = dbatch + 2 * (size_t)ldx;
         ba.X = dbatch + 3 * (size_t)ldx;
-        double* dY = ba.X + (size_t)16 * ldb;
+        double* dY = ba.X + (size_t)16 * ldb + inv_doubles;
         batch_Y = dY;
-        const int* dinv = sel ? reinterpret_cast<const int*>(dY + (size_t)16 * ldy) : nullptr;
+        const int* dinv = sel ? reinterpret_cast<const int*>(ba.X + (size_t)16 * ldb) : nullptr;
         SELLA_LAUNCHB(c, rs_batch_kernel, rs_batch_vb, 256, dim3(BATCH_NODES), dim3(256), 0, ba);
         HIPCHK(hipGetLastError());
         if (st->panel) SCHK(panel_apply(ba.X, ldb, BATCH_NODES, dY, ldy));

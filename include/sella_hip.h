@@ -370,6 +370,8 @@ typedef struct sella_opt_step_t {
     double* s_out;                                          /* n */
     double smag_out;                                        /* out */
     int nalpha;                                             /* out */
+    double alpha_hint;         /* in-out: alpha at which the previous root search of THIS search ended (0: none): the first
+                                * round of the batched search looks around it; same root, fewer rounds                    */
 } sella_opt_step_t;
 int sella_opt_step(sella_ctx* ctx, sella_opt_step_t* io);
 /* Dense mirror of a structured decomposition: B <- lam0 I + W^T diag(mu - lam0) W (B n x n resident, overwritten).  The

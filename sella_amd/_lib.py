@@ -39,6 +39,7 @@ class OptStepArgs(ctypes.Structure):
         ('s_out', c_void_p),
         ('smag_out', c_double),
         ('nalpha', c_int),
+        ('alpha_hint', c_double),
     ]
 
 

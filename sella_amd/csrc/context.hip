@@ -647,6 +647,7 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "dav_zero_copy")) c->opt.dav_zero_copy = value ? 1 : 0;
     else if (!strcmp(key, "dav_poll")) c->opt.dav_poll = value ? 1 : 0;
     else if (!strcmp(key, "rs_poll")) c->opt.rs_poll = value ? 1 : 0;
+    else if (!strcmp(key, "rs_hint")) c->opt.rs_hint = value ? 1 : 0;
     else if (!strcmp(key, "eigh_tail_lds")) c->opt.eigh_tail_lds = value < 0 ? 0 : value;
     else if (!strcmp(key, "eigh_wy_waves")) c->opt.eigh_wy_waves = value;
     else if (!strcmp(key, "lr_cholqr")) c->opt.lr_cholqr = value ? 1 : 0;

@@ -158,6 +158,9 @@ struct Options {
                               //    batch that produced it (stepper.hip)
     long lr_pipe = 1;        // 1: the library search queues the force call in front of the update that consumes it: one wait for both (search.hip)
     long lr_chain = 1;       // 1: the O(n r) passes of the one-call step as five fused launches, merged coordinate kernels (lrstep.hip)
+    long rs_hint = 1;        // 1: the batched root search interpolates quadratically through three evaluated points and, given the alpha the
+                             //    previous root search of the same saddle search ended at (sella_opt_step_t::alpha_hint), looks around it first:
+                             //    4.9 -> 3.5 rounds per boundary step on the EMT slab
     long rs_poll = 0;        // 1: the rounds of the batched root search wait by polling a pinned sequence word (context.hip, poll_wait); measured equal on the EMT slab (0.576 vs 0.577 ms per step: the mark kernel costs what the wake-up saves): off
     long gs_small = 2048;    // Gram-Schmidt of vectors of at most this many entries (<= 2048) in ONE launch of one workgroup, sweeps,
                              //    norms and accept / drop decisions included (gs.hip); 0: always the sweep-by-sweep launches
@@ -435,6 +438,9 @@ int stepper_on_panel(sella_ctx* c, int kind, const double* src, int ld, const in
 void stepper_panel_scale(sella_stepper* st, int mode, double factor);      // mode's row is stored unnormalised: row * factor
 // the interpolating batched root search of sella_restricted_step instead of the reference's alpha schedule (sella_opt_step)
 void stepper_set_fast_search(sella_stepper* st, bool on, bool boundary_hint = false);
+// where the previous root search of the same saddle search ended (its first round looks there) / where this one ended
+void stepper_set_alpha_hint(sella_stepper* st, double hint);
+double stepper_alpha_found(const sella_stepper* st);
 // lrstep.hip: the learn / adapt / propose step on structured decompositions with every decision on the device
 // `pipe` (optional): the force call at the new geometry has NOT been made yet — the step queues it on the stream in front
 // of the update that consumes its gradient and waits once for both (csrc/search.hip: no host round trip between force call

@@ -1480,12 +1480,14 @@ int lr_fused_step(sella_ctx* c, sella_opt_step_t* a, bool* handled, CalcPipe* pi
     } else
         SCHK(stepper_from_panel(c, a->stepper_kind, J.Wnew, J.ldw, idx.data(), mm, nd, ev.data(), gh.data(), a->order, &st));
     stepper_set_fast_search(st, c->opt.rs_fast != 0, on_boundary);
+    stepper_set_alpha_hint(st, c->opt.rs_hint ? a->alpha_hint : 0.0);
     const bool qn = a->stepper_kind == SELLA_STEP_QN;
     const double alpha0 = qn ? 0.0 : 1.0, alphamax = qn ? std::numeric_limits<double>::infinity() : 1.0;
     const auto ts4 = stamp();
     const int rc = sella_restricted_step(st, a->cons, a->delta, nullptr, nullptr, nullptr, alpha0, 0.0, alphamax,
                                          qn ? -1.0 : 1.0, qn ? 1 : 0, 1, a->tol, a->maxiter, view ? a->idx : nullptr,
                                          view ? n : 0, a->s_out, &a->smag_out, nullptr, &a->nalpha);
+    if (rc == SELLA_OK && stepper_alpha_found(st) > 0.0) a->alpha_hint = stepper_alpha_found(st);
     sella_stepper_destroy(st);
     if (step_timing) {
         const auto ts5 = stamp();

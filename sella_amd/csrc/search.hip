@@ -39,7 +39,7 @@ struct sella_search {
     std::vector<double> mu, mu_sub;
     double lam0 = 0.0;
     int B_stale = 0, Bsub_stale = 0;
-    sella_opt_step_t io;
+    sella_opt_step_t io = sella_opt_step_t();   // (persistent: its alpha_hint carries from step to step)
     // Hand-over (SELLA_E_UNSUPPORTED) in the middle of a step: a diagonalisation whose block of secant pairs no longer
     // fits the structured form has spent its force calls — the pairs are kept for the caller, who applies them on the
     // dense route (sella_search_pending_pairs), and the step that scheduled it counts.

@@ -31,6 +31,8 @@ struct sella_stepper {
     long rs_calls = 0, rs_rounds = 0, rs_single = 0;   // SELLA_DEBUG_TIMING: root searches, batched round trips, single-alpha round trips
     bool boundary_hint = false;           // sella_opt_step: the previous step ended on the trust boundary
     bool fast_search = false;             // sella_opt_step: interpolating batched search instead of the reference's alpha schedule
+    double alpha_hint = 0.0;              // ... where the previous root search of the same saddle search ended (0: unknown)
+    double alpha_found = 0.0;             // ... and where this one did
     // Panel form (stepper_on_panel): the modes are rows pidx[i] of a device panel somebody else owns, never gathered into
     // matrices — enough for the search in the orthonormal eigenbasis (trust-region measure), whose only device work is
     // the step itself at the final alpha: s = sum_i shat_i row_i, one launch.
@@ -904,20 +906,49 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         double lower = 0.0, upper = alpha, flo = -delta, fhi = merged ? 0.0 : val - delta;
         bool first = true, ok = false, have_top = !merged;
         int round_no = 0, src_lo_round = -1, src_lo_row = -1, src_hi_round = -1, src_hi_row = -1, hit_row = -1;
+        // a third evaluated point next to the bracket (the nearest one outside it, from the last round): with it the next
+        // trial value comes from inverse QUADRATIC interpolation instead of the secant — the measure is smooth between the
+        // points where its largest component changes hands, and the bracket then shrinks by the cube of its width per round
+        bool have3 = false;
+        double x3 = 0.0, f3 = 0.0;
         for (int round = 0; round < 48; ++round) {
             const double width = upper - lower;
             if (have_top && (!(width > 0.0) || nextafter(nextafter(lower, upper), upper) >= upper)) { ok = true; break; }
             int nc = 0;
             double pts[BATCH_NODES];
             const int nlog = have_top ? BATCH_NODES : BATCH_NODES - 1;
-            if (first) {
+            const double hint = st->alpha_hint;
+            if (first && c->opt.rs_hint && hint > lower && hint < upper && lower == 0.0) {
+                // The previous root search of this saddle search ended at `hint`: consecutive steps of a search sit on the same trust
+                // boundary with slowly changing curvature, so the first round spends half of its trial values around that
+                // value (offsets of 10^-1 ... 10^-4 to both sides, clipped into the bracket) and the other half on the decades
+                // below the start value as before.  Other trial points, the same root (restricted_step.py:78-120); a hint that
+                // is off costs nothing but the round it would have taken anyway.
+                pts[nc++] = hint;
+                for (int k = 1; k <= 4 && nc + 2 <= nlog; ++k) {
+                    const double off = hint * pow(10.0, -(double)k);
+                    pts[nc++] = hint - off;
+                    pts[nc++] = hint + off;
+                }
+                for (int k = 1; nc < nlog; ++k) pts[nc++] = lower + width * pow(10.0, -1.0 * k);
+            } else if (first) {
                 for (int k = 1; k <= nlog; ++k) pts[nc++] = lower + width * pow(10.0, -0.5 * k);
             } else {
                 double rs = lower - flo * width / (fhi - flo);
+                if (c->opt.rs_hint && have3 && f3 != flo && f3 != fhi && flo != fhi) {
+                    // x as a quadratic in f through (flo, lower), (fhi, upper), (f3, x3), evaluated at f = 0
+                    const double q = lower * (fhi * f3) / ((flo - fhi) * (flo - f3)) + upper * (flo * f3) / ((fhi - flo) * (fhi - f3)) +
+                                     x3 * (flo * fhi) / ((f3 - flo) * (f3 - fhi));
+                    if (q > lower && q < upper) rs = q;
+                }
                 if (!(rs > lower && rs < upper)) rs = 0.5 * (lower + upper);
                 pts[nc++] = rs;
+                // offsets to both sides of the estimate: decades 10^-1 ... 10^-7 of the bracket, or — with the better
+                // estimate — every other decade down to 10^-13 (an estimate that is good to 10^-9 of the bracket is
+                // then bracketed that tightly instead of at 10^-7)
+                const double step10 = (c->opt.rs_hint && have3) ? 2.0 : 1.0;
                 for (int k = 1; k <= 7; ++k) {
-                    const double off = width * pow(10.0, -(double)k);
+                    const double off = width * pow(10.0, -step10 * k + (step10 - 1.0));
                     pts[nc++] = rs - off;
                     pts[nc++] = rs + off;
                 }
@@ -954,13 +985,28 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
                 src_hi_round = round_no; src_hi_row = kept - 1;
             }
             bool hit = false;
+            const double lower_in = lower, upper_in = upper, flo_in = flo, fhi_in = fhi;
+            int q_lo = -1, q_hi = -1;                              // rows of this round that became the bracket ends
             for (int q = 0; q < nscan; ++q) {
                 const double e = cval[q + 1] - delta;
                 if (fabs(e) <= tol) { alpha = pts[q]; val = cval[q + 1]; hit = true; hit_row = q; break; }
-                if (e > 0.0) { if (pts[q] < upper) { upper = pts[q]; fhi = e; src_hi_round = round_no; src_hi_row = q; } }
-                else if (pts[q] > lower) { lower = pts[q]; flo = e; src_lo_round = round_no; src_lo_row = q; }
+                if (e > 0.0) { if (pts[q] < upper) { upper = pts[q]; fhi = e; src_hi_round = round_no; src_hi_row = q; q_hi = q; } }
+                else if (pts[q] > lower) { lower = pts[q]; flo = e; src_lo_round = round_no; src_lo_row = q; q_lo = q; }
             }
             if (hit) { ok = true; fast_done = true; break; }
+            {
+                // the nearest evaluated neighbours outside the new bracket: the row below the new lower end (or the old lower
+                // end), the row above the new upper end (or the old upper end); the one with the smaller residual is kept
+                double xa = 0.0, fa = 0.0, xb = 0.0, fb = 0.0;
+                bool ha = false, hb = false;
+                if (q_lo > 0) { xa = pts[q_lo - 1]; fa = cval[q_lo] - delta; ha = true; }
+                else if (q_lo == 0 && lower_in > 0.0) { xa = lower_in; fa = flo_in; ha = true; }
+                if (q_hi >= 0 && q_hi + 1 < nscan) { xb = pts[q_hi + 1]; fb = cval[q_hi + 2] - delta; hb = true; }
+                else if (q_hi >= 0) { xb = upper_in; fb = fhi_in; hb = fhi_in != 0.0; }
+                have3 = ha || hb;
+                if (ha && (!hb || fabs(fa) <= fabs(fb))) { x3 = xa; f3 = fa; }
+                else if (hb) { x3 = xb; f3 = fb; }
+            }
         }
         if (!ok) { set_error("Restricted step failed to converge!"); return SELLA_E_NOCONV; }
         if (!fast_done) {
@@ -971,6 +1017,7 @@ extern "C" int sella_restricted_step(sella_stepper* st, int cons, double delta, 
         } else {
             batch_row = hit_row;                                   // found in the batch just evaluated
         }
+        st->alpha_found = alpha;                                   // where this search ended: the next one starts looking there
         if (!merged) batch_row = -1;                               // (the step from the batch output: with the merged flow only)
         if (batch_row < 0) {
             const int keep = ntrial;
@@ -1204,6 +1251,9 @@ int sella::stepper_on_panel(sella_ctx* c, int kind, const double* src, int ld, c
 void sella::stepper_panel_scale(sella_stepper* st, int mode, double factor) {
     if (st && mode >= 0 && mode < (int)st->pscale.size()) st->pscale[mode] = factor;
 }
+
+void sella::stepper_set_alpha_hint(sella_stepper* st, double hint) { if (st) st->alpha_hint = hint; }
+double sella::stepper_alpha_found(const sella_stepper* st) { return st ? st->alpha_found : 0.0; }
 
 void sella::stepper_set_fast_search(sella_stepper* st, bool on, bool boundary_hint) {
     if (st) { st->fast_search = on; st->boundary_hint = boundary_hint; }

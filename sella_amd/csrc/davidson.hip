@@ -164,9 +164,8 @@ int apply_A(Dav& s, const double* x, double* y) {
             return SELLA_E_CALLBACK;
         }
     }
-    SCHK(h2d_async(c, y, s.hav.data(), (size_t)s.n * sizeof(double)));
-    SCHK(stream_wait(c));
-    return SELLA_OK;
+    // (no wait: the payload sits in the pinned ring from here on, the copy is ordered in front of whatever reads y)
+    return h2d_async(c, y, s.hav.data(), (size_t)s.n * sizeof(double));
 }
 
 // out(m rows) = (P - theta I)^-1 in(m rows), all panels with leading dimension ld

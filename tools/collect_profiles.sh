@@ -34,7 +34,7 @@ vals = {k: sum(int(d) * float(v) for kk, d, v in rows if kk == k) / sum(int(d) f
 t = d['trd_gemv_kernel']
 t['FETCH_SIZE_kb_mean_raw'], t['WRITE_SIZE_kb_mean_raw'] = vals['FETCH_SIZE'], vals['WRITE_SIZE']
 t['bytes_per_launch'] = (2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024
-t['source'] = re.sub(r'session r0\d\w?', 'session ' + S.split('/')[-1], t['source'])
+t['source'] = re.sub(r'session r0\d\w?', 'session ' + S.split('/')[-1], re.sub(r'profiles/r0\d_pmc\.md', 'profiles/%s_pmc.md' % sys.argv[2], t['source']))
 nd = sum(int(d) for kk, d, v in rows if kk == 'FETCH_SIZE')
 t['dispatches'] = nd          # blocked chain only: trailing blocks of n-1 .. n-nd rows
 t['algorithmic_bytes_per_launch'] = round(sum(8 * m * m + 16 * m for m in range(t['n'] - nd, t['n'])) / nd)
@@ -44,7 +44,8 @@ def grab(path):
     for line in open(path):
         m = re.search(r'(\S+)\s+dispatches=\s*(\d+) mean=([0-9.e+]+)', line)
         if m:
-            out[m.group(1)] = (int(m.group(2)), float(m.group(3)), line.split('(')[0].replace('void ', '').replace('sella::', '').strip())
+            nm = re.search(r'(\w+_kernel(?:<[^>]*>)?)', line)
+            out[m.group(1)] = (int(m.group(2)), float(m.group(3)), nm.group(1) if nm else '')
     return out
 try:
     r = {**grab(S + '/pmc_rank2k_FETCH.txt'), **grab(S + '/pmc_rank2k_WRITE.txt')}

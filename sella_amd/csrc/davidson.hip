@@ -660,6 +660,31 @@ __global__ __launch_bounds__(256) void dav_final_kernel(int n, int k, int cap, c
                                                         double* __restrict__ avslot, double* __restrict__ out,
                                                         unsigned long long* pword, unsigned long long pseq, unsigned* pcount) { dav_final_vb(vb_hw(), n, k, cap, V, AV, ld, t2, At2, part1, part2, nblk, nblke, vslot, avslot, out, pword, pseq, pcount); }
 
+// Vector-major panels (k rows of stride ld) -> the caller's layout (n x k row-major, vectors as columns), both panels in
+// one launch (upper half of grid.y: the second panel), through 32 x 32 LDS tiles: the results then travel in ONE
+// contiguous transfer and land in the caller's arrays by plain copies (the host-side transposition of two n x k panels was
+// a third of the call's fixed cost).
+__device__ __forceinline__ void dav_to_columns_vb(const VB vb, int n, int k, const double* __restrict__ P0,
+                                                  const double* __restrict__ P1, int ld, double* __restrict__ out) {
+    __shared__ double tile[32][33];
+    const unsigned ny = vb.gy / 2, second = vb.y >= ny ? 1u : 0u;
+    const double* __restrict__ P = second ? P1 : P0;
+    double* __restrict__ o = out + (size_t)second * n * k;
+    const int i0 = vb.x * 32, j0 = (vb.y - second * ny) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + r, i = i0 + tx;
+        tile[r][tx] = (j < k && i < n) ? P[(size_t)j * ld + i] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, j = j0 + tx;
+        if (i < n && j < k) o[(size_t)i * k + j] = tile[tx][r];
+    }
+}
+__global__ __launch_bounds__(256) void dav_to_columns_kernel(int n, int k, const double* __restrict__ P0,
+                                                             const double* __restrict__ P1, int ld, double* __restrict__ out) { dav_to_columns_vb(vb_hw(), n, k, P0, P1, ld, out); }
+
 }  // namespace
 }  // namespace sella
 
@@ -736,6 +761,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
     if (maxiter <= 0) maxiter = 2 * n + 1;
     const int kstop = (n < maxiter) ? n : maxiter;
 
+    const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     int cap0 = 64;
     while (cap0 < nv0 + 2) cap0 *= 2;
     if (cap0 > n + 1) cap0 = n + 1;
@@ -1242,6 +1268,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
     }
     cohort_barrier(c, 0xffffff, 0);           // (a cohort closes up behind loops of different length)
 
+    const double t_loop_end = now();
     if (dbg_time)
         fprintf(stderr, "davidson: k=%d total %.3f ms, host k x k algebra %.3f ms, fused iterations %ld, synchronous %ld\n", s.k,
                 1e3 * (now() - t_begin), 1e3 * t_host, n_fast, n_slow);
@@ -1254,11 +1281,24 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         DCHK(launch_lincomb(c, n, k, s.Vp, s.ld, k, dWp, k, nullptr, 0, 0, nullptr, 0, 0.0, s.Vq, s.ld));
         DCHK(launch_lincomb(c, n, k, s.AVp, s.ld, k, dWp, k, nullptr, 0, 0, nullptr, 0, 0.0, s.AVq, s.ld));
     }
-    DCHK(download_panel(c, s.Vq, s.ld, n, k, V_out));
-    DCHK(download_panel(c, s.AVq, s.ld, n, k, AV_out));
+    {
+        // both panels in the caller's layout on the device, one transfer, plain copies into the caller's arrays
+        double* cols;
+        DCHK(scratch_get(c, SCR_X, 2 * (size_t)n * k * sizeof(double), &cols));
+        SELLA_LAUNCHB(c, dav_to_columns_kernel, dav_to_columns_vb, 256, dim3((n + 31) / 32, 2 * ((k + 31) / 32)), dim3(256), 0, n, k,
+                      (const double*)s.Vq, (const double*)s.AVq, s.ld, cols);
+        DHIP(hipGetLastError());
+        DCHK(d2h_async(c, V_out, cols, (size_t)n * k * sizeof(double)));
+        DCHK(d2h_async(c, AV_out, cols + (size_t)n * k, (size_t)n * k * sizeof(double)));
+        DCHK(stream_wait(c));
+    }
     *k_out = k;
     if (nmatvec_out) *nmatvec_out = s.nmatvec;
+    const double t_res_end = now();
     dav_free(s);
+    if (dbg_time)
+        fprintf(stderr, "davidson: allocation + start block %.1f us, loop %.1f us, Ritz vectors and images to the host %.1f us, release %.1f us\n",
+                1e6 * (t_begin - t_enter), 1e6 * (t_loop_end - t_begin), 1e6 * (t_res_end - t_loop_end), 1e6 * (now() - t_res_end));
     return SELLA_OK;
 #undef DCHK
 #undef DHIP

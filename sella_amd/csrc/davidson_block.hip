@@ -30,12 +30,13 @@ constexpr int BD_HG = 4;       // outputs per thread of the combine kernel
 // out[h][i] = beta out[h][i] + alpha sum_a C[h ldc + a] P[a ldp + i],  h < nh (<= 16), a < k.
 // Thread i owns element i of BD_HG outputs (blockIdx.y picks the group): coalesced panel reads, coefficients
 // broadcast from LDS.
-// rowscale (device, nh entries, may be null): output h is additionally scaled by rowscale[h] — the -theta_h of the
-// residual when the Ritz values never leave the device.
+// rowscale (device, nh entries, may be null): output h is additionally scaled by rowscale[h].  base (may be null): the
+// beta term is read from base (same layout as out) instead of out — an out-of-place update.
 __global__ __launch_bounds__(256) void bd_combine_kernel(int n, int nh, int k, const double* __restrict__ C, int ldc,
                                                          const double* __restrict__ P, int ldp, double alpha, double beta,
                                                          double* __restrict__ out, int ldo,
-                                                         const double* __restrict__ rowscale) {
+                                                         const double* __restrict__ rowscale,
+                                                         const double* __restrict__ base) {
     __shared__ double cs[128][BD_HG];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int h0 = blockIdx.y * BD_HG;
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256) void bd_combine_kernel(int n, int nh, int k, c
             if (h0 + h < nh) {
                 double* o = out + (size_t)(h0 + h) * ldo + i;
                 const double al = rowscale ? alpha * rowscale[h0 + h] : alpha;
-                *o = (beta == 0.0) ? al * acc[h] : (beta * (*o) + al * acc[h]);
+                const double b0 = (beta == 0.0) ? 0.0 : (base ? base[(size_t)(h0 + h) * ldo + i] : *o);
+                *o = (beta == 0.0) ? al * acc[h] : (beta * b0 + al * acc[h]);
             }
     }
 }
@@ -73,167 +75,6 @@ __global__ __launch_bounds__(256) void bd_combine_kernel(int n, int nh, int k, c
 struct Theta16 {
     double v[BD_NB];
 };
-
-// ---- Rayleigh-Ritz on the device ---------------------------------------------------------------------------------
-// The k x k projected eigenproblem (k <= 64: nev + 2 blocks) used to be solved on the host — 0.3-0.5 ms of scalar
-// tred2 / tql2 per block iteration at k = 48, more than the sharded panel product it sits behind.  One workgroup does it
-// by parallel cyclic Jacobi instead: the matrix in LDS, k / 2 disjoint rotations per step in round-robin order, k - 1
-// steps per sweep, ~6-8 sweeps to full accuracy (Jacobi is backward stable and at least as accurate as QL); the
-// eigenvectors accumulate as ROWS of Wt in global memory (L2 resident), sorted ascending with the host routine's sign
-// convention, ready to be read as the coefficient rows of bd_combine_kernel — so neither the Ritz vectors' coefficients
-// nor the Gram matrix ever travel to the host.
-constexpr int BD_JMAX = 56;      // both k x k matrices of the Jacobi kernel live in LDS: 2 x 56 x 56 doubles = 49 KB
-
-__global__ __launch_bounds__(256) void bd_jacobi_eig_kernel(int k, const double* __restrict__ G, int ldg,
-                                                            double* __restrict__ theta, double* __restrict__ Wt, int ldw,
-                                                            double* __restrict__ /*unused*/, int* __restrict__ info) {
-    __shared__ double Af[BD_JMAX * BD_JMAX], Wf[BD_JMAX * BD_JMAX];
-    __shared__ double cc[BD_JMAX / 2], ss[BD_JMAX / 2], red[256];
-    __shared__ int pp[BD_JMAX / 2], qq[BD_JMAX / 2], rankof[BD_JMAX];
-    __shared__ double dsort[BD_JMAX];
-    __shared__ int again;
-    const int tid = threadIdx.x;
-    const int k2 = k + (k & 1);                       // even size; the pad index carries a decoupled zero
-    for (int e = tid; e < k2 * k2; e += 256) {
-        const int i = e / k2, j = e % k2;
-        double v = 0.0;
-        if (i < k && j < k) v = 0.5 * (G[(size_t)i * ldg + j] + G[(size_t)j * ldg + i]);
-        Af[(i) * k2 + (j)] = v;
-    }
-    for (int e = tid; e < k2 * k2; e += 256) {
-        const int i = e / k2, j = e % k2;
-        Wf[(i) * k2 + (j)] = (i == j) ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    const int half = k2 / 2, m1 = k2 - 1;
-    int sweep = 0;
-    for (; sweep < 40; ++sweep) {
-        // convergence: off-diagonal mass against the diagonal's
-        double off = 0.0, dia = 0.0;
-        for (int e = tid; e < k2 * k2; e += 256) {
-            const int i = e / k2, j = e % k2;
-            const double v = Af[(i) * k2 + (j)];
-            if (i == j) dia += v * v; else off += v * v;
-        }
-        red[tid] = off;
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-        const double offt = red[0];
-        __syncthreads();
-        red[tid] = dia;
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
-        const double diat = red[0];
-        __syncthreads();
-        // rounding floor of the rotations: (4 eps)^2 per entry against the diagonal's mass
-        if (tid == 0) again = (offt > 7.9e-31 * k2 * diat && offt > 0.0) ? 1 : 0;
-        __syncthreads();
-        if (!again) break;
-        for (int step = 0; step < m1; ++step) {
-            if (tid < half) {
-                int p, q;
-                if (tid == 0) { p = m1; q = step; }
-                else {
-                    p = step + tid; if (p >= m1) p -= m1;
-                    q = step + m1 - tid; if (q >= m1) q -= m1;
-                }
-                if (p > q) { const int t = p; p = q; q = t; }
-                const double apq = Af[p * k2 + q];
-                double c = 1.0, sn = 0.0;
-                if (fabs(apq) > 1e-300) {
-                    const double tau = (Af[q * k2 + q] - Af[p * k2 + p]) / (2.0 * apq);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    c = 1.0 / sqrt(1.0 + t * t);
-                    sn = t * c;
-                }
-                pp[tid] = p; qq[tid] = q; cc[tid] = c; ss[tid] = sn;
-            }
-            __syncthreads();
-            // A <- J^T A J in ONE phase: the index pairs partition the matrix into disjoint 2 x 2 blocks
-            // (row pair tr) x (column pair tc), each read and written by one thread; thread (tr, tc) = (tid / 32, tid % 32)
-            const int tc = tid & 31;
-            for (int tr = tid >> 5; tr < half; tr += 8) {
-                if (tc < half) {
-                    const int p = pp[tr], q = qq[tr], u = pp[tc], v = qq[tc];
-                    const double cr = cc[tr], sr = ss[tr], c2 = cc[tc], s2 = ss[tc];
-                    const double apu = Af[p * k2 + u], apv = Af[p * k2 + v], aqu = Af[q * k2 + u], aqv = Af[q * k2 + v];
-                    // rows: (p, q) <- (c p - s q, s p + c q)
-                    const double bpu = cr * apu - sr * aqu, bpv = cr * apv - sr * aqv;
-                    const double bqu = sr * apu + cr * aqu, bqv = sr * apv + cr * aqv;
-                    // columns: (u, v) <- (c u - s v, s u + c v)
-                    Af[p * k2 + u] = c2 * bpu - s2 * bpv;
-                    Af[p * k2 + v] = s2 * bpu + c2 * bpv;
-                    Af[q * k2 + u] = c2 * bqu - s2 * bqv;
-                    Af[q * k2 + v] = s2 * bqu + c2 * bqv;
-                }
-            }
-            // eigenvector rows p, q of W: thread (tr, column j), 64 columns per pass
-            {
-                const int j = tid & 63;
-                if (j < k2)
-                    for (int tr = tid >> 6; tr < half; tr += 4) {
-                        const int p = pp[tr], q = qq[tr];
-                        const double c = cc[tr], sn = ss[tr];
-                        const double wp = Wf[p * k2 + j], wq = Wf[q * k2 + j];
-                        Wf[p * k2 + j] = c * wp - sn * wq;
-                        Wf[q * k2 + j] = sn * wp + c * wq;
-                    }
-            }
-            __syncthreads();
-        }
-    }
-    if (tid == 0 && sweep >= 40) info[0] = 1;
-    // ascending order (ties: lower index first), sign: largest-magnitude component positive
-    if (tid < k) dsort[tid] = Af[(tid) * k2 + (tid)];
-    __syncthreads();
-    if (tid < k) {
-        const double d = dsort[tid];
-        int r = 0;
-        for (int j = 0; j < k; ++j) r += (dsort[j] < d || (dsort[j] == d && j < tid)) ? 1 : 0;
-        rankof[tid] = r;
-        theta[r] = d;
-    }
-    __syncthreads();
-    for (int row = tid >> 6; row < k; row += 4) {                 // one wavefront per eigenvector row
-        const int lane = tid & 63;
-        double best = 0.0;
-        int bi = 0;
-        for (int j = lane; j < k; j += 64) {
-            const double v = fabs(Wf[(row) * k2 + (j)]);
-            if (v > best) { best = v; bi = j; }
-        }
-        for (int mz = 32; mz > 0; mz >>= 1) {
-            const double ob = __shfl_xor(best, mz, 64);
-            const int oi = __shfl_xor(bi, mz, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        const double sgn = (Wf[(row) * k2 + (bi)] < 0.0) ? -1.0 : 1.0;
-        const int r = rankof[row];
-        for (int j = lane; j < k; j += 64) Wt[(size_t)r * ldw + j] = sgn * Wf[(row) * k2 + (j)];
-    }
-}
-
-// New rows / columns of the projected matrix from the panel product dY[h * ldy + a] = V_a . (A T)_h, h < nbk, a < k:
-// G[a][k0 + h] = G[k0 + h][a], the new diagonal block exactly symmetric.
-__global__ __launch_bounds__(256) void bd_gram_rows_kernel(const double* __restrict__ dY, int ldy, int k0, int nbk, int k,
-                                                           double* __restrict__ G, int ldg) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= nbk * k) return;
-    const int h = e / k, a = e % k;
-    double v = dY[(size_t)h * ldy + a];
-    if (a >= k0) v = 0.5 * (v + dY[(size_t)(a - k0) * ldy + k0 + h]);
-    G[(size_t)a * ldg + k0 + h] = v;
-    G[(size_t)(k0 + h) * ldg + a] = v;
-}
-
-// G <- diag(theta[0 .. keep)) after a thick restart (the restarted basis is the Ritz basis)
-__global__ __launch_bounds__(256) void bd_gram_reset_kernel(double* __restrict__ G, int ldg, int kcap, int keep,
-                                                            const double* __restrict__ theta) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= kcap * kcap) return;
-    const int i = e / kcap, j = e % kcap;
-    G[(size_t)i * ldg + j] = (i == j && i < keep) ? theta[i] : 0.0;
-}
 
 // X[h][i] <- X[h][i] / (d[i] - theta_h), the denominator kept away from zero (|.| >= guard, sign preserved):
 // the eigenbasis form of (P - theta)^-1 would otherwise inject inf when a Ritz value hits an eigenvalue of P.
@@ -255,6 +96,223 @@ __global__ __launch_bounds__(256) void bd_unpack_kernel(const double* __restrict
     Y[(size_t)h * ldy + g] = recv[((size_t)r * BD_NB + h) * m_max + i];
 }
 
+// ---- kernels of the pipelined iteration (run_pipelined below) ------------------------------------------------------
+// out[z][h][i] = sum_a C[h ldc + a] P_z[a ldp + i] for TWO panels in one launch (blockIdx.z): the thick restart
+// (V, AV) <- (W^T V, W^T AV) and the block's final transformation (T, A T) <- (S T', S (A T)'), written straight into
+// their slots of the basis.  Columns [n, ld) of the outputs are left alone (zero since allocation).
+__global__ __launch_bounds__(256) void bd_combine_pair_kernel(int n, int nh, int k, const double* __restrict__ C, int ldc,
+                                                              const double* __restrict__ P0, const double* __restrict__ P1,
+                                                              int ldp, double* __restrict__ out0, double* __restrict__ out1,
+                                                              int ldo) {
+    __shared__ double cs[128][BD_HG];
+    const double* __restrict__ P = blockIdx.z ? P1 : P0;
+    double* __restrict__ out = blockIdx.z ? out1 : out0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int h0 = blockIdx.y * BD_HG;
+    double acc[BD_HG];
+#pragma unroll
+    for (int h = 0; h < BD_HG; ++h) acc[h] = 0.0;
+    for (int a0 = 0; a0 < k; a0 += 128) {
+        const int jt = (k - a0 < 128) ? (k - a0) : 128;
+        __syncthreads();
+        for (int t = threadIdx.x; t < jt * BD_HG; t += 256) {
+            const int a = t / BD_HG, h = t % BD_HG;
+            cs[a][h] = (h0 + h < nh) ? C[(size_t)(h0 + h) * ldc + a0 + a] : 0.0;
+        }
+        __syncthreads();
+        if (i < n) {
+#pragma unroll 4
+            for (int a = 0; a < jt; ++a) {
+                const double p = P[(size_t)(a0 + a) * ldp + i];
+#pragma unroll
+                for (int h = 0; h < BD_HG; ++h) acc[h] += cs[a][h] * p;
+            }
+        }
+    }
+    if (i < n) {
+#pragma unroll
+        for (int h = 0; h < BD_HG; ++h)
+            if (h0 + h < nh) out[(size_t)(h0 + h) * ldo + i] = acc[h];
+    }
+}
+
+// In-place transformation of the 16 rows behind the basis, both panels in one launch (blockIdx.z):
+//   slot_h <- sum_{a < kt} C[h ldc + a] P_z[a],   slot = rows [kt - 16, kt) of P_z,   h < 16.
+// A thread owns one column and all 16 outputs, reads its column of every row before it writes: no other thread touches
+// that column, so the rows may be overwritten where they stand.  (T, A T) = S (T' - X V, A T' - X AV) with the coefficient
+// rows [-S X | S] is one such launch.
+constexpr int BD_TR_THREADS = 64;
+__global__ __launch_bounds__(BD_TR_THREADS) void bd_transform_kernel(int n, int kt, const double* __restrict__ C, int ldc,
+                                                                     double* __restrict__ P0, double* __restrict__ P1, int ldp) {
+    __shared__ double cs[64][BD_NB];
+    double* __restrict__ P = blockIdx.z ? P1 : P0;
+    const int i = blockIdx.x * BD_TR_THREADS + threadIdx.x;
+    double acc[BD_NB];
+#pragma unroll
+    for (int h = 0; h < BD_NB; ++h) acc[h] = 0.0;
+    for (int a0 = 0; a0 < kt; a0 += 64) {
+        const int jt = (kt - a0 < 64) ? (kt - a0) : 64;
+        __syncthreads();
+        for (int t = threadIdx.x; t < jt * BD_NB; t += BD_TR_THREADS) {
+            const int a = t / BD_NB, h = t % BD_NB;
+            cs[a][h] = C[(size_t)h * ldc + a0 + a];
+        }
+        __syncthreads();
+        if (i < n) {
+#pragma unroll 4
+            for (int a = 0; a < jt; ++a) {
+                const double p = P[(size_t)(a0 + a) * ldp + i];
+#pragma unroll
+                for (int h = 0; h < BD_NB; ++h) acc[h] += cs[a][h] * p;
+            }
+        }
+    }
+    if (i < n) {
+#pragma unroll
+        for (int h = 0; h < BD_NB; ++h) P[(size_t)(kt - BD_NB + h) * ldp + i] = acc[h];
+    }
+}
+
+// Residuals of the lowest Ritz pairs when the basis IS the Ritz basis (right after a thick restart):
+// R_h = (AV)_h - theta_h V_h, and the diagonally preconditioned correction T_h = R_h / (d - theta_h) beside it
+// (d null: T = R), the latter twice: into the rows behind the basis and into scratch rows (T2, may be null).  Rows
+// [nh, 16) of all of them are zero-filled: T is the operand of a 16-row panel product.  npart (may be null, pinned host
+// memory): npart[h * gridDim.x + b] = sum of R_h^2 over the columns of workgroup b — the host adds them up in order.
+__device__ __forceinline__ void bd_block_sumsq(double v, double* __restrict__ dst) {
+    __shared__ double red[4];
+    const double w = wave_sum64(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) *dst = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void bd_resid_ritz_kernel(int n, int nh, const double* __restrict__ V,
+                                                            const double* __restrict__ AV, int ld, Theta16 th,
+                                                            const double* __restrict__ d, double guard,
+                                                            double* __restrict__ R, double* __restrict__ T,
+                                                            double* __restrict__ T2, double* __restrict__ npart) {
+    const int i = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
+    double r = 0.0, t = 0.0;
+    if (i < n && h < nh) {
+        r = AV[(size_t)h * ld + i] - th.v[h] * V[(size_t)h * ld + i];
+        t = r;
+        if (d) {
+            double den = d[i] - th.v[h];
+            if (fabs(den) < guard) den = (den < 0.0) ? -guard : guard;
+            t = r / den;
+        }
+    }
+    if (i < n) {
+        R[(size_t)h * ld + i] = r;
+        T[(size_t)h * ld + i] = t;
+        if (T2) T2[(size_t)h * ld + i] = t;
+    }
+    if (npart) bd_block_sumsq(r * r, npart + (size_t)h * gridDim.x + blockIdx.x);
+}
+
+// The same from general Ritz coefficients (before the first restart): R_h = sum_a C[h][a] (AV_a - theta_h V_a).
+__global__ __launch_bounds__(256) void bd_resid_coef_kernel(int n, int nh, int k, const double* __restrict__ C, int ldc,
+                                                            const double* __restrict__ V, const double* __restrict__ AV,
+                                                            int ld, Theta16 th, const double* __restrict__ d, double guard,
+                                                            double* __restrict__ R, double* __restrict__ T,
+                                                            double* __restrict__ T2, double* __restrict__ npart) {
+    __shared__ double cs[128][BD_HG];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int h0 = blockIdx.y * BD_HG;
+    double av[BD_HG], vv[BD_HG];
+#pragma unroll
+    for (int h = 0; h < BD_HG; ++h) av[h] = vv[h] = 0.0;
+    for (int a0 = 0; a0 < k; a0 += 128) {
+        const int jt = (k - a0 < 128) ? (k - a0) : 128;
+        __syncthreads();
+        for (int t = threadIdx.x; t < jt * BD_HG; t += 256) {
+            const int a = t / BD_HG, h = t % BD_HG;
+            cs[a][h] = (h0 + h < nh) ? C[(size_t)(h0 + h) * ldc + a0 + a] : 0.0;
+        }
+        __syncthreads();
+        if (i < n) {
+#pragma unroll 4
+            for (int a = 0; a < jt; ++a) {
+                const double pa = AV[(size_t)(a0 + a) * ld + i], pv = V[(size_t)(a0 + a) * ld + i];
+#pragma unroll
+                for (int h = 0; h < BD_HG; ++h) { av[h] += cs[a][h] * pa; vv[h] += cs[a][h] * pv; }
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < BD_HG; ++h) {
+        const int hh = h0 + h;                            // (grid.y = 4: hh < 16)
+        double r = 0.0, t = 0.0;
+        if (i < n && hh < nh) {
+            r = av[h] - th.v[hh] * vv[h];
+            t = r;
+            if (d) {
+                double den = d[i] - th.v[hh];
+                if (fabs(den) < guard) den = (den < 0.0) ? -guard : guard;
+                t = r / den;
+            }
+        }
+        if (i < n) {
+            R[(size_t)hh * ld + i] = r;
+            T[(size_t)hh * ld + i] = t;
+            if (T2) T2[(size_t)hh * ld + i] = t;
+        }
+        if (npart) bd_block_sumsq(r * r, npart + (size_t)hh * gridDim.x + blockIdx.x);
+    }
+}
+
+// (T, A T) = [-S X | S] applied to [basis rows; raw block] for both panels in one launch (blockIdx.z), out of place:
+//   out_z[h] = sum_{a < k} C[h ldc + a] P_z[a] + sum_{j < 16} C[h ldc + k + j] B_z[j],   h < 16,
+// P_z the basis panel (V / AV), B_z the raw block kept in scratch rows (T' / A T'), out_z the 16 rows behind the basis.
+// Workgroup (x, y, z): 256 columns, outputs 4 y .. 4 y + 3.
+__global__ __launch_bounds__(256) void bd_transform2_kernel(int n, int k, const double* __restrict__ C, int ldc,
+                                                            const double* __restrict__ P0, const double* __restrict__ P1,
+                                                            const double* __restrict__ B0, const double* __restrict__ B1, int ldp,
+                                                            double* __restrict__ out0, double* __restrict__ out1) {
+    __shared__ double cs[128][BD_HG];
+    const double* __restrict__ P = blockIdx.z ? P1 : P0;
+    const double* __restrict__ B = blockIdx.z ? B1 : B0;
+    double* __restrict__ out = blockIdx.z ? out1 : out0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int h0 = blockIdx.y * BD_HG;
+    const int kt = k + BD_NB;
+    double acc[BD_HG];
+#pragma unroll
+    for (int h = 0; h < BD_HG; ++h) acc[h] = 0.0;
+    for (int a0 = 0; a0 < kt; a0 += 128) {
+        const int jt = (kt - a0 < 128) ? (kt - a0) : 128;
+        __syncthreads();
+        for (int t = threadIdx.x; t < jt * BD_HG; t += 256) {
+            const int a = t / BD_HG, h = t % BD_HG;
+            cs[a][h] = C[(size_t)(h0 + h) * ldc + a0 + a];
+        }
+        __syncthreads();
+        if (i < n) {
+#pragma unroll 4
+            for (int a = 0; a < jt; ++a) {
+                const int ga = a0 + a;
+                const double p = (ga < k) ? P[(size_t)ga * ldp + i] : B[(size_t)(ga - k) * ldp + i];
+#pragma unroll
+                for (int h = 0; h < BD_HG; ++h) acc[h] += cs[a][h] * p;
+            }
+        }
+    }
+    if (i < n) {
+#pragma unroll
+        for (int h = 0; h < BD_HG; ++h) out[(size_t)(h0 + h) * ldp + i] = acc[h];
+    }
+}
+
+// unit vectors e_{idx[j]} as the rows of a zeroed panel (Davidson's classic start block)
+struct Idx16 {
+    int v[BD_NB];
+};
+__global__ void bd_unit_rows_kernel(double* __restrict__ T, int ld, int nt, Idx16 idx) {
+    const int j = threadIdx.x;
+    if (j < nt) T[(size_t)j * ld + idx.v[j]] = 1.0;
+}
+
 struct Blk {
     sella_ctx* c = nullptr;
     int n = 0, ld = 0, maxvec = 0, k = 0;
@@ -273,10 +331,10 @@ struct Blk {
     int nmatvec = 0;
     vec G;                         // (maxvec + 16)^2 host Gram matrix V^T A V, leading dimension kcap
     int kcap = 0;
-    // Rayleigh-Ritz on the device (kcap <= 64): projected matrix, Ritz values, Ritz coefficient rows
-    bool dev_rr = false;
-    double *dG = nullptr, *dWt = nullptr, *dWtmp = nullptr, *dtheta = nullptr;
-    int* dinfo = nullptr;
+    // pipelined iteration (run_pipelined): restart targets, restart coefficients W (32 x kcap)
+    double *Valt = nullptr, *AValt = nullptr, *dW = nullptr;
+    long n_clean = 0, n_second = 0, n_direct = 0, n_refresh = 0;
+    double av_err = 1.0;           // bound on the errors the rows of AV carry, units of eps |A| (run_pipelined)
 };
 
 int blk_alloc(Blk& s) {
@@ -304,16 +362,6 @@ int blk_alloc(Blk& s) {
         HIPCHK(s_memset0(c, s.send, s.bytesS));
     }
     s.G.assign((size_t)s.kcap * s.kcap, 0.0);
-    s.dev_rr = s.maxvec <= BD_JMAX && c->opt.bd_dev_rr;      // the basis never holds more than maxvec vectors
-    if (s.dev_rr) {
-        const size_t kk2 = (size_t)s.kcap * s.kcap;
-        SCHK(dev_alloc(c, (3 * kk2 + 2 * (size_t)s.kcap + 16) * sizeof(double), &s.dG));
-        HIPCHK(s_memset0(c, s.dG, (3 * kk2 + 2 * (size_t)s.kcap + 16) * sizeof(double)));
-        s.dWt = s.dG + kk2;
-        s.dWtmp = s.dWt + kk2;
-        s.dtheta = s.dWtmp + kk2;
-        s.dinfo = reinterpret_cast<int*>(s.dtheta + 2 * (size_t)s.kcap);
-    }
     return SELLA_OK;
 }
 
@@ -328,14 +376,16 @@ void blk_free(Blk& s) {
     for (double* p : small16)
         if (p) dev_free(c, p, s.bytes16);
     if (s.dC) dev_free(c, s.dC, s.bytesC);
-    if (s.dG) dev_free(c, s.dG, (3 * (size_t)s.kcap * s.kcap + 2 * (size_t)s.kcap + 16) * sizeof(double));
+    if (s.Valt) dev_free(c, s.Valt, s.bytesV);
+    if (s.AValt) dev_free(c, s.AValt, s.bytesV);
+    if (s.dW) dev_free(c, s.dW, 2 * s.bytesC);
     if (s.send) dev_free(c, s.send, s.bytesS);
     if (s.recv) dev_free(c, s.recv, s.bytesR);
     s.V = nullptr;
 }
 
 int combine(Blk& s, int nh, int k, const double* dC, int ldc, const double* P, double alpha, double beta, double* out,
-            const double* rowscale = nullptr) {
+            const double* rowscale = nullptr, const double* base = nullptr) {
     if (nh <= 0) return SELLA_OK;
     if (k <= 0) {
         if (beta == 0.0) HIPCHK(hipMemsetAsync(out, 0, (size_t)nh * s.ld * sizeof(double), s.c->stream));
@@ -343,7 +393,7 @@ int combine(Blk& s, int nh, int k, const double* dC, int ldc, const double* P, d
     }
     dim3 grid((s.n + 255) / 256, (nh + BD_HG - 1) / BD_HG);
     hipLaunchKernelGGL(bd_combine_kernel, grid, dim3(256), 0, s.c->stream, s.n, nh, k, dC, ldc, P, s.ld, alpha, beta, out,
-                       s.ld, rowscale);
+                       s.ld, rowscale, base);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
 }
@@ -361,9 +411,9 @@ int put_coeffs(Blk& s, const vec& Ch, int nh, int k) {
 }
 
 // Y (nh rows) = A X^T for the 16-row panel X (rows >= nh zero): local panel product (+ all-gather)
-int apply_A(Blk& s, const double* X, int nh, double* Y) {
+int apply_A(Blk& s, const double* X, int nh, double* Y, bool count = true) {
     sella_ctx* c = s.c;
-    s.nmatvec += nh;
+    if (count) s.nmatvec += nh;
     if (!s.gather) return launch_panel16(c, s.A->d, s.n, s.n, s.ld, X, nh, Y, s.ld);
     SCHK(launch_panel16(c, s.A->d, s.A->rows, s.n, s.ld, X, nh, s.send, s.m_max));
     {
@@ -394,18 +444,22 @@ int project_out(Blk& s, double* T, int nt, int k) {
 // *clean (optional) = the pass lost little: every surviving row kept at least a quarter of its squared norm in the
 // projection against V and the block's Gram matrix has a condition number below 1e3 — one classical Gram-Schmidt
 // pass then already leaves orthogonality at the 1e-13 level and the second pass can be skipped.
-int svqb(Blk& s, double*& T, double*& T2, int nt, bool has_pre, double drop, int* kept, bool* clean = nullptr) {
-    sella_ctx* c = s.c;
-    *kept = 0;
+// The host half: S = Gram matrix of the nt rows (16 x 16 layout), pre = their squared norms before the projection (or
+// null), skip[h] != 0 = row h does not take part (a converged pair's correction).  Ch (mk x nt, row jj = coefficients of
+// new row jj) and *mk come back.
+// *amp (optional): by how much the pass amplifies rounding errors of the rows it transforms — the largest norm loss in
+// the projection times the square root of the block's condition number; *gain (optional): by how much it amplifies
+// errors of the BASIS rows that the projection subtracts (|X_h| / |T_h - X_h V| for orthonormal V, times the same root).
+int svqb_host(const double* S, const double* pre, const char* skip, int nt, double drop, vec& Ch, int* mk_out, bool* clean,
+              double* amp = nullptr, double* gain = nullptr) {
+    *mk_out = 0;
     if (clean) *clean = false;
-    if (nt <= 0) return SELLA_OK;
-    double* dS = c->dscal + DS_GRAM;
-    SCHK(launch_panel16(c, T, nt, s.n, s.ld, T, nt, dS, BD_NB));                  // dS[h * 16 + r] = T_r . T_h
-    SCHK(read_scalars(c, DS_GRAM, BD_NB * BD_NB + BD_NB));                        // ... + the 16 pre-projection norms
-    const double* S = c->hscal + DS_GRAM;
-    const double* pre = has_pre ? c->hscal + DS_GRAM + BD_NB * BD_NB : nullptr;
+    if (amp) *amp = 1.0;
+    if (gain) *gain = 0.0;
     std::vector<int> live;
+    int nskip = 0;
     for (int h = 0; h < nt; ++h) {
+        if (skip && skip[h]) { ++nskip; continue; }
         const double d = S[h * BD_NB + h];
         if (!(d > 0.0) || d != d) continue;
         if (pre && !(d >= drop * drop * pre[h])) continue;
@@ -428,18 +482,41 @@ int svqb(Blk& s, double*& T, double*& T2, int nt, bool has_pre, double drop, int
         if (sig[j] > drop * drop * smax) good.push_back(j);
     const int mk = (int)good.size();
     if (mk == 0) return SELLA_OK;
+    if (amp) {
+        double loss = 1.0;
+        if (pre)
+            for (int a = 0; a < m; ++a) loss = std::max(loss, pre[live[a]] / S[live[a] * BD_NB + live[a]]);
+        *amp = sqrt(loss * smax / sig[good[mk - 1]]);
+        if (gain) *gain = sqrt((loss - 1.0) * smax / sig[good[mk - 1]]);
+    }
     if (clean && pre) {
-        bool ok = mk == m && (int)live.size() == nt && sig[0] > 1e-3 * smax;
+        bool ok = mk == m && (int)live.size() == nt - nskip && sig[0] > 1e-3 * smax;
         for (int a = 0; a < m && ok; ++a) ok = S[live[a] * BD_NB + live[a]] >= 0.25 * pre[live[a]];
         *clean = ok;
     }
     // T_new[jj] = sum_a dinv_a U[a][j] / sqrt(sig_j) T[live_a]
-    vec Ch((size_t)mk * nt, 0.0);
+    Ch.assign((size_t)mk * nt, 0.0);
     for (int jj = 0; jj < mk; ++jj) {
         const int j = good[jj];
         const double f = 1.0 / sqrt(sig[j]);
         for (int a = 0; a < m; ++a) Ch[(size_t)jj * nt + live[a]] = dinv[a] * U[(size_t)a * m + j] * f;
     }
+    *mk_out = mk;
+    return SELLA_OK;
+}
+
+int svqb(Blk& s, double*& T, double*& T2, int nt, bool has_pre, double drop, int* kept, bool* clean = nullptr) {
+    sella_ctx* c = s.c;
+    *kept = 0;
+    if (clean) *clean = false;
+    if (nt <= 0) return SELLA_OK;
+    double* dS = c->dscal + DS_GRAM;
+    SCHK(launch_panel16(c, T, nt, s.n, s.ld, T, nt, dS, BD_NB));                  // dS[h * 16 + r] = T_r . T_h
+    SCHK(read_scalars(c, DS_GRAM, BD_NB * BD_NB + BD_NB));                        // ... + the 16 pre-projection norms
+    vec Ch;
+    int mk = 0;
+    SCHK(svqb_host(c->hscal + DS_GRAM, has_pre ? c->hscal + DS_GRAM + BD_NB * BD_NB : nullptr, nullptr, nt, drop, Ch, &mk, clean));
+    if (mk == 0) return SELLA_OK;
     SCHK(put_coeffs(s, Ch, mk, nt));
     HIPCHK(s_memset0(c, T2, s.bytes16));
     SCHK(combine(s, mk, nt, s.dC, s.kcap, T, 1.0, 0.0, T2));
@@ -467,6 +544,281 @@ int orthonormalise_block(Blk& s, int nt, int k, int* kept) {
     int m2 = 0;
     SCHK(svqb(s, s.T, s.T2, m1, false, 1e-6, &m2));
     *kept = m2;
+    return SELLA_OK;
+}
+
+// ---- the pipelined iteration ------------------------------------------------------------------------------------------
+// State shared by the two iteration drivers and the result stage.
+struct BlkRun {
+    vec theta, W, rn;              // Ritz values, Ritz coefficients (k x k, eigenvectors as COLUMNS), residual norms
+    std::vector<char> conv;
+    int iter = 0, nconv = 0, kept = 0;
+    bool done = false;
+};
+
+inline double bd_now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// One block iteration used to be a chain of ~60 stream operations with three or four host waits between the matrix
+// passes: Rayleigh-Ritz, residuals (wait), corrections, Gram-Schmidt against V (wait, second pass: wait), A T (the one
+// n^2 pass), Gram rows (wait).  Here the chain is cut to two waits and the matrix pass covers the host's share of the
+// orthonormalisation:
+//   * A is applied to the RAW correction block T' (preconditioned residuals, written into the 16 rows behind the basis)
+//     while the host does the SVQB step; ONE panel product over V's k + 16 rows gives the projection coefficients
+//     X = T' V^T and T' T'^T together (the Gram matrix of the projected block is T' T'^T - X X^T), and ONE in-place launch
+//     with the coefficient rows [-S X | S] turns the rows behind V and AV into
+//         T = S (T' - X V),   A T = S (A T' - X AV).
+//     A `clean` pass (the projection kept at least a quarter of every row, block condition below 1e3) ends there;
+//     otherwise the block takes a second Gram-Schmidt pass, T and A T again transformed alike (n_second).  The
+//     transformed A T inherits the errors of the AV rows times |X| / |T' - X V| (its `gain`: above one they would grow
+//     from block to block) plus the fresh product's times the cancellation (`amp`): an error budget (av_err) is carried
+//     and the block's A T recomputed from T itself by one more matrix pass when it would pass 1e-12 |A| (n_direct).
+//   * the residual norms are read together with the Gram matrix (convergence is decided one wait later, the corrections
+//     of converged pairs are dropped from the block by the SVQB coefficients), so the iteration has no wait between the
+//     Rayleigh-Ritz step and the matrix pass;
+//   * the thick restart runs BEFORE the residuals (the restarted basis is the Ritz basis: R_h = AV_h - theta_h V_h, one
+//     launch for both panels into alternate buffers, no copies back);
+//   * results the host consumes are written by their kernels into pinned host memory and waited for by polling
+//     (context.hip poll_mark / poll_wait); the k x k eigenproblem runs in hostm::sym_eig_rows (row-oriented, vectorised).
+// Applies when every wanted pair can be corrected in every iteration: nev <= block and the start block gave at least nev
+// vectors (k >= nev from then on).  Everything else (nev > 16, narrow blocks) stays with the general driver.
+int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter) {
+    sella_ctx* c = s.c;
+    const int n = s.n, ld = s.ld, kcap = s.kcap;
+    double** bV[2] = {&s.Valt, &s.AValt};
+    for (auto p : bV) { SCHK(dev_alloc(c, s.bytesV, p)); HIPCHK(s_memset0(c, *p, s.bytesV)); }
+    SCHK(dev_alloc(c, 2 * s.bytesC, &s.dW));
+    double* const hN = c->hscal + DS_GRAM;              // |R_h|^2 (16)
+    double* const hY = hN + 512;                        // projections + block Gram matrix, then Gram rows V_a . (A T)_h: 16 x kcap
+    const int nblk = (n + 255) / 256;                   // workgroups of the residual kernels = partial sums per residual norm
+    double* const hpart = (512 + (size_t)BD_NB * kcap + (size_t)BD_NB * nblk <= (size_t)(DS_TOTAL - DS_GRAM))
+                              ? hY + (size_t)BD_NB * kcap : nullptr;
+    if (512 + (size_t)BD_NB * kcap > (size_t)(DS_TOTAL - DS_GRAM)) { set_error("davidson_block: basis too large for the exchange buffer"); return SELLA_E_UNSUPPORTED; }
+    static const bool timing = getenv("SELLA_BD_TIMING") != nullptr;
+    const double* dprec = s.Q ? nullptr : s.dP;
+    vec Gk, Wt, theta, Ch, pk;
+    std::vector<char> skip(BD_NB, 0);
+    r.conv.assign(nev, 0);
+    r.rn.assign(std::max(nev, BD_NB), 0.0);
+    auto wait_mark = [&]() -> int { SCHK(poll_mark(c)); return poll_wait(c); };
+    auto gram_rows = [&](int k0, int nbk) {
+        for (int h = 0; h < nbk; ++h)
+            for (int a = 0; a < k0 + nbk; ++a) {
+                const double v = hY[(size_t)h * kcap + a];
+                s.G[(size_t)a * kcap + k0 + h] = v;
+                s.G[(size_t)(k0 + h) * kcap + a] = v;
+            }
+        for (int h = 0; h < nbk; ++h)
+            for (int g = 0; g < h; ++g) {
+                const double v = 0.5 * (hY[(size_t)h * kcap + k0 + g] + hY[(size_t)g * kcap + k0 + h]);
+                s.G[(size_t)(k0 + h) * kcap + k0 + g] = s.G[(size_t)(k0 + g) * kcap + k0 + h] = v;
+            }
+    };
+    // rows [0, nrows) of a row-major (nrows x ncols) host block -> device rows of stride lddev, ONE transfer
+    auto put_rows = [&](double* dev, int lddev, const double* h, int nrows, int ncols, int ldh) -> int {
+        pk.assign((size_t)nrows * lddev, 0.0);
+        for (int a = 0; a < nrows; ++a) memcpy(pk.data() + (size_t)a * lddev, h + (size_t)a * ldh, (size_t)ncols * sizeof(double));
+        return h2d_async(c, dev, pk.data(), ((size_t)(nrows - 1) * lddev + ncols) * sizeof(double));
+    };
+    // Ritz coefficients as columns for the result stage (and the general conventions)
+    auto export_W = [&](int k) {
+        r.W.assign((size_t)k * k, 0.0);
+        for (int j = 0; j < k; ++j)
+            for (int a = 0; a < k; ++a) r.W[(size_t)a * k + j] = Wt[(size_t)j * k + a];
+    };
+
+    // ---- the start block: V[0:kept) = T, AV = A T, first Gram block ---------------------------------------------------
+    {
+        const int nbk = r.kept;
+        HIPCHK(s_memcpy(c, s.V, s.T, (size_t)nbk * ld * sizeof(double), hipMemcpyDeviceToDevice));
+        if (nbk < BD_NB) HIPCHK(s_memset0(c, s.T + (size_t)nbk * ld, (size_t)(BD_NB - nbk) * ld * sizeof(double)));
+        SCHK(apply_A(s, s.T, nbk, s.AV));
+        s.k = nbk;
+        SCHK(launch_panel16_marked(c, s.V, s.k, n, ld, s.AV, nbk, hY, kcap));
+        SCHK(poll_wait(c));
+        gram_rows(0, nbk);
+    }
+    const int nwant = nev;
+    vec Sg((size_t)BD_NB * BD_NB), pre(BD_NB), Cf;
+    while (true) {
+        int k = s.k;
+        const double t0 = timing ? bd_now_us() : 0.0;
+        // ---- Rayleigh-Ritz ------------------------------------------------------------------------------------------------
+        Gk.resize((size_t)k * k);
+        for (int a = 0; a < k; ++a) memcpy(Gk.data() + (size_t)a * k, s.G.data() + (size_t)a * kcap, (size_t)k * sizeof(double));
+        theta.assign(k, 0.0);
+        Wt.assign((size_t)k * k, 0.0);
+        if (hostm::sym_eig_rows(k, Gk.data(), k, theta.data(), Wt.data()) != 0) {
+            set_error("davidson_block: Rayleigh-Ritz eigenproblem failed");
+            return SELLA_E_NOCONV;
+        }
+        const double t1 = timing ? bd_now_us() : 0.0;
+        Theta16 th;
+        for (int h = 0; h < BD_NB; ++h) th.v[h] = (h < nwant) ? theta[h] : 0.0;
+        // ---- thick restart when the next block would overflow the basis: (V, AV) <- Ritz vectors, alternate buffers ---------
+        // (as many new vectors as pairs were unconverged at the last verdict; should a pair fall back the basis may pass maxvec
+        // by a few rows for one iteration — the panels hold maxvec + 16)
+        bool ritz_basis = false;
+        if (k + std::max(1, nwant - r.nconv) > s.maxvec) {
+            const int keep = std::min(k, std::max(nev + block, 2 * block));
+            SCHK(put_rows(s.dW, kcap, Wt.data(), keep, k, k));
+            hipLaunchKernelGGL(bd_combine_pair_kernel, dim3((n + 255) / 256, (keep + BD_HG - 1) / BD_HG, 2), dim3(256), 0, c->stream, n,
+                               keep, k, s.dW, kcap, s.V, s.AV, ld, s.Valt, s.AValt, ld);
+            HIPCHK(hipGetLastError());
+            std::swap(s.V, s.Valt);
+            std::swap(s.AV, s.AValt);
+            std::fill(s.G.begin(), s.G.end(), 0.0);
+            for (int a = 0; a < keep; ++a) s.G[(size_t)a * kcap + a] = theta[a];
+            theta.resize(keep);
+            Wt.assign((size_t)keep * keep, 0.0);
+            for (int a = 0; a < keep; ++a) Wt[(size_t)a * keep + a] = 1.0;
+            s.k = k = keep;
+            ritz_basis = true;
+        }
+        r.theta = theta;
+        // ---- residuals (16 rows of their own) and raw corrections T' — into the 16 rows BEHIND the basis, rows [nwant, 16)
+        // zero: one panel product over V's k + 16 rows then gives the projections and the block's Gram matrix together ------
+        double* Ts = s.V + (size_t)k * ld;
+        double* ATs = s.AV + (size_t)k * ld;
+        const int kt = k + BD_NB;
+        // (T' a second time in scratch rows: the final transformation reads it there and writes the rows behind the basis;
+        // the squared residual norms as per-workgroup partial sums straight into pinned host memory)
+        double* T2 = s.Q ? nullptr : s.T;
+        if (ritz_basis) {
+            hipLaunchKernelGGL(bd_resid_ritz_kernel, dim3(nblk, BD_NB), dim3(256), 0, c->stream, n, nwant, s.V, s.AV, ld, th,
+                               dprec, s.guard, s.R, Ts, T2, hpart);
+        } else {
+            SCHK(put_rows(s.dC, kcap, Wt.data(), nwant, k, k));
+            hipLaunchKernelGGL(bd_resid_coef_kernel, dim3(nblk, BD_NB / BD_HG), dim3(256), 0, c->stream, n, nwant, k, s.dC,
+                               kcap, s.V, s.AV, ld, th, dprec, s.guard, s.R, Ts, T2, hpart);
+        }
+        HIPCHK(hipGetLastError());
+        if (s.Q) {
+            // T' = Q diag(1 / (d - theta_h)) Q^T R   (eigensolvers.py:119-121 'gd', in the eigenbasis of P)
+            SCHK(launch_panel16(c, s.Qt->d, n, n, ld, s.R, nwant, s.MID, ld));
+            hipLaunchKernelGGL(bd_shift_scale_kernel, dim3((n + 255) / 256, nwant), dim3(256), 0, c->stream, n, nwant, s.MID, ld, s.dP,
+                               th, s.guard);
+            HIPCHK(hipGetLastError());
+            SCHK(launch_panel16(c, s.Q->d, n, n, ld, s.MID, nwant, Ts, ld));
+            HIPCHK(s_memcpy(c, s.T, Ts, s.bytes16, hipMemcpyDeviceToDevice));
+        }
+        if (!hpart) SCHK(launch_rows_sumsq(c, s.R, ld, nwant, n, hN));
+        auto verdict = [&]() {
+            r.nconv = 0;
+            for (int h = 0; h < nwant; ++h) {
+                if (hpart) {
+                    double acc = 0.0;
+                    for (int b = 0; b < nblk; ++b) acc += hpart[(size_t)h * nblk + b];
+                    hN[h] = acc;
+                }
+                r.rn[h] = sqrt(hN[h]);
+                const bool ok = r.rn[h] <= tol * std::max(fabs(theta[h]), 1e-300);
+                r.conv[h] = ok ? 1 : 0;
+                skip[h] = r.conv[h];
+                r.nconv += ok ? 1 : 0;
+            }
+        };
+        if (r.iter >= maxiter) {                        // out of iterations: the norms of the final pairs, nothing else
+            SCHK(wait_mark());
+            verdict();
+            r.done = (r.nconv == nev);
+            export_W(k);
+            break;
+        }
+        // hY[h][a] = V_a . T'_h (a < k: the projection coefficients X) and T'_{a-k} . T'_h (the block's Gram matrix): marked
+        SCHK(launch_panel16_marked(c, s.V, kt, n, ld, Ts, nwant, hY, kcap));
+        // ---- the matrix pass on the raw block (into scratch rows: the final transformation writes the rows behind AV) --------
+        SCHK(apply_A(s, Ts, nwant, s.AT, false));                // (counted below: the rows of unconverged pairs)
+        const double t2 = timing ? bd_now_us() : 0.0;
+        SCHK(poll_wait(c));
+        const double t3 = timing ? bd_now_us() : 0.0;
+        verdict();
+        if (r.nconv == nev) { r.done = true; export_W(k); break; }
+        s.nmatvec += nwant - r.nconv;
+        // ---- the host's share: SVQB on the Gram matrix of the projected block, (T' - X V)(T' - X V)^T = T' T'^T - X X^T for an
+        // orthonormal V (a projection that cancels digits here is not `clean`, and the second pass measures its Gram matrix
+        // afresh); coefficient rows [-S X | S] over the k + 16 rows transform T' and A T' where they stand ----------------
+        static const bool force2 = getenv("SELLA_BD_FORCE2") != nullptr;       // (test aid: second pass and A T from T, always)
+        int mk = nwant;
+        bool clean = false, direct = false, stop = false;
+        double amp = 1.0, gain = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int nt = mk;
+            for (int h = 0; h < nt; ++h) {
+                pre[h] = hY[(size_t)h * kcap + k + h];
+                for (int g = 0; g < nt; ++g) {
+                    double xg = 0.0;
+                    for (int a = 0; a < k; ++a) xg += hY[(size_t)h * kcap + a] * hY[(size_t)g * kcap + a];
+                    Sg[(size_t)h * BD_NB + g] = hY[(size_t)h * kcap + k + g] - xg;
+                }
+            }
+            int m2 = 0;
+            if (pass == 0) SCHK(svqb_host(Sg.data(), pre.data(), skip.data(), nt, 1e-6, Ch, &m2, &clean, &amp, &gain));
+            else SCHK(svqb_host(Sg.data(), nullptr, nullptr, nt, 1e-6, Ch, &m2, nullptr));
+            if (m2 == 0) { stop = true; break; }
+            Cf.assign((size_t)BD_NB * kcap, 0.0);
+            for (int jj = 0; jj < m2; ++jj) {
+                double* cf = Cf.data() + (size_t)jj * kcap;
+                for (int j = 0; j < nt; ++j) {
+                    const double sj = Ch[(size_t)jj * nt + j];
+                    if (sj == 0.0) continue;
+                    cf[k + j] = sj;
+                    const double* xj = hY + (size_t)j * kcap;
+                    for (int a = 0; a < k; ++a) cf[a] -= sj * xj[a];
+                }
+            }
+            SCHK(h2d_async(c, s.dC, Cf.data(), ((size_t)(BD_NB - 1) * kcap + kt) * sizeof(double)));
+            if (pass == 0)
+                hipLaunchKernelGGL(bd_transform2_kernel, dim3(nblk, BD_NB / BD_HG, 2), dim3(256), 0, c->stream, n, k, s.dC, kcap, s.V, s.AV,
+                                   s.T, s.AT, ld, Ts, ATs);
+            else                                             // (second pass: the rows are transformed where they stand)
+                hipLaunchKernelGGL(bd_transform_kernel, dim3((n + BD_TR_THREADS - 1) / BD_TR_THREADS, 1, 2), dim3(BD_TR_THREADS), 0,
+                                   c->stream, n, kt, s.dC, kcap, s.V, s.AV, ld);
+            HIPCHK(hipGetLastError());
+            mk = m2;
+            if (pass == 0) {
+                // Error budget of the transformed A T (units of eps |A|): what the rows of AV already carry comes back multiplied
+                // by `gain` (the X AV term), the fresh product A T' by `amp`.  Past 1e4 (1e-12 |A|) the block's A T is
+                // recomputed from T itself by one more matrix pass, and when the basis rows are near the limit, so are they.
+                const double err_new = gain * s.av_err + amp;
+                direct = !(err_new <= 1e4) || force2;
+                if (!direct) s.av_err = std::max(s.av_err, err_new);
+                if (force2) clean = false;
+                if (clean) { ++s.n_clean; break; }
+                ++s.n_second;
+                SCHK(launch_panel16_marked(c, s.V, kt, n, ld, Ts, mk, hY, kcap));
+                SCHK(poll_wait(c));
+            }
+        }
+        if (stop) { ++r.iter; export_W(k); break; }              // the corrections are in span(V): nothing left to add
+        if (direct) {
+            ++s.n_direct;
+            SCHK(apply_A(s, Ts, mk, ATs, false));
+            if (s.av_err > 1e4 / 16.0) {
+                // the basis rows are near the limit themselves: AV = A V afresh, 16 rows per matrix pass
+                for (int a0 = 0; a0 < k; a0 += BD_NB) {
+                    // (a last chunk shorter than 16 rows multiplies rows of the new block too: their products are what stands there)
+                    SCHK(apply_A(s, s.V + (size_t)a0 * ld, std::min(BD_NB, kt - a0), s.AV + (size_t)a0 * ld, false));
+                }
+                ++s.n_refresh;
+                s.av_err = 1.0;
+            }
+        }
+        // ---- new rows of the projected matrix ------------------------------------------------------------------------------------
+        SCHK(launch_panel16_marked(c, s.V, k + mk, n, ld, ATs, mk, hY, kcap));
+        SCHK(poll_wait(c));
+        gram_rows(k, mk);
+        s.k = k + mk;
+        ++r.iter;
+        if (timing) {
+            fprintf(stderr, "block davidson (pipelined): k = %d: Rayleigh-Ritz %.1f us, queueing %.1f us, wait behind the projection %.1f us, "
+                            "SVQB + final stage + wait for the Gram rows %.1f us%s\n", k, t1 - t0, t2 - t1, t3 - t2, bd_now_us() - t3,
+                    clean ? "" : " (second pass)");
+            fprintf(stderr, "    theta0 %.6e rn0 %.2e nconv %d new rows %d amplification %.2e gain %.2e%s\n", theta[0], r.rn[0], r.nconv, mk,
+                    amp, gain, direct ? " (A T recomputed)" : "");
+        }
+    }
     return SELLA_OK;
 }
 
@@ -530,6 +882,8 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
         }
     }
     s.maxvec = maxvec;
+    const bool stage_timing = getenv("SELLA_BD_TIMING") != nullptr;
+    const double ts0 = bd_now_us();
     int st = blk_alloc(s);
     auto fail = [&](int code) { blk_free(s); return code; };
 #define BCHK(expr) do { int s__ = (expr); if (s__ != SELLA_OK) return fail(s__); } while (0)
@@ -553,17 +907,23 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
             X0.assign((size_t)n * nt, 0.0);
             for (int i = 0; i < n; ++i)
                 for (int j = 0; j < nt; ++j) X0[(size_t)i * nt + j] = V0[(size_t)i * nv0 + j];
+        } else if (pdiag && !s.Q) {
+            // unit vectors at the `nt` smallest diagonal entries (Davidson's classic start), set on the device: s.T is zero
+            nt = std::min(block, n);
+            std::vector<int> idx(n);
+            for (int i = 0; i < n; ++i) idx[i] = i;
+            std::partial_sort(idx.begin(), idx.begin() + nt, idx.end(),
+                              [&](int a, int b) { return pdiag[a] < pdiag[b] || (pdiag[a] == pdiag[b] && a < b); });
+            Idx16 ix;
+            for (int j = 0; j < BD_NB; ++j) ix.v[j] = (j < nt) ? idx[j] : 0;
+            hipLaunchKernelGGL(bd_unit_rows_kernel, dim3(1), dim3(64), 0, c->stream, s.T, s.ld, nt, ix);
+            BHIP(hipGetLastError());
+        } else if (s.Q) {
+            nt = std::min(block, n);          // (the lowest eigenvectors of P, copied below)
         } else {
             nt = std::min(block, n);
             X0.assign((size_t)n * nt, 0.0);
-            if (pdiag && !s.Q) {
-                // unit vectors at the `nt` smallest diagonal entries (Davidson's classic start)
-                std::vector<int> idx(n);
-                for (int i = 0; i < n; ++i) idx[i] = i;
-                std::partial_sort(idx.begin(), idx.begin() + nt, idx.end(),
-                                  [&](int a, int b) { return pdiag[a] < pdiag[b] || (pdiag[a] == pdiag[b] && a < b); });
-                for (int j = 0; j < nt; ++j) X0[(size_t)idx[j] * nt + j] = 1.0;
-            } else {
+            {
                 unsigned long long lcg = 0x9E3779B97F4A7C15ull;          // deterministic pseudo-random start
                 for (size_t e = 0; e < X0.size(); ++e) {
                     lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
@@ -571,7 +931,7 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
                 }
             }
         }
-        BCHK(upload_panel(c, X0.data(), n, nt, s.T, s.ld));
+        if (!X0.empty()) BCHK(upload_panel(c, X0.data(), n, nt, s.T, s.ld));
         if (s.Q && !(V0 && nv0 > 0)) {
             // with an eigenbasis preconditioner the natural start is its lowest eigenvectors
             BHIP(hipMemcpy2DAsync(s.T, (size_t)s.ld * sizeof(double), s.Qt->d, (size_t)s.Qt->ld * sizeof(double),
@@ -579,15 +939,30 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
         }
     }
     int kept = 0;
+    const double ts1 = bd_now_us();
     BCHK(orthonormalise_block(s, nt, 0, &kept));
+    const double ts2 = bd_now_us();
     if (kept == 0) { set_error("davidson_block: the start block is numerically zero"); return fail(SELLA_E_INVALID); }
 
-    vec theta, W, Gk, work, rn(std::max(nev, BD_NB), 0.0), Ch;
+    BlkRun run;
+    vec &theta = run.theta, &W = run.W, &rn = run.rn;
+    std::vector<char>& conv = run.conv;
+    int &iter = run.iter, &nconv = run.nconv;
+    bool& done = run.done;
+    vec Gk, work, Ch;
+    rn.assign(std::max(nev, BD_NB), 0.0);
+    conv.assign(nev, 0);
     unsigned long long lcg = 0xD1B54A32D192ED03ull;
-    std::vector<char> conv(nev, 0);
-    int iter = 0, nconv = 0;
-    bool done = false;
-    while (true) {
+    // every wanted pair corrected in every iteration, two waits per iteration, the matrix pass over the host's share of the
+    // orthonormalisation: run_pipelined above; narrow blocks and nev > block stay with the general loop below
+    const bool pipelined = c->opt.bd_pipeline && nev <= block && kept >= nev;
+    if (pipelined) {
+        run.kept = kept;
+        BCHK(run_pipelined(s, run, nev, block, tol, maxiter));
+        if (getenv("SELLA_BD_TIMING"))
+            fprintf(stderr, "block davidson (pipelined): %d iterations, %ld clean blocks, %ld with a second pass, %ld blocks with A T recomputed, %ld refreshes of AV, error bound %.1e eps\n", iter, s.n_clean, s.n_second, s.n_direct, s.n_refresh, s.av_err);
+    }
+    while (!pipelined) {
         // ---- append the orthonormal block in s.T: V, AV, Gram rows ------------------------------------------
         const int k0 = s.k, nbk = kept;
         BHIP(s_memcpy(c, s.V + (size_t)k0 * s.ld, s.T, (size_t)nbk * s.ld * sizeof(double), hipMemcpyDeviceToDevice));
@@ -601,11 +976,6 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
             if (nbk < BD_NB)
                 BHIP(s_memset0(c, s.AT + (size_t)nbk * s.ld, (size_t)(BD_NB - nbk) * s.ld * sizeof(double)));
             BCHK(launch_panel16(c, s.V, s.k, n, s.ld, s.AT, nbk, dY, s.kcap));
-            if (s.dev_rr) {
-                hipLaunchKernelGGL(bd_gram_rows_kernel, dim3((nbk * s.k + 255) / 256), dim3(256), 0, c->stream, dY, s.kcap, k0,
-                                   nbk, s.k, s.dG, s.kcap);
-                BHIP(hipGetLastError());
-            } else {
             BCHK(read_scalars(c, DS_GRAM, BD_NB * s.kcap));
             const double* Y = c->hscal + DS_GRAM;
             for (int h = 0; h < nbk; ++h)
@@ -619,17 +989,10 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
                     const double v = 0.5 * (s.G[(size_t)(k0 + h) * s.kcap + k0 + g] + s.G[(size_t)(k0 + g) * s.kcap + k0 + h]);
                     s.G[(size_t)(k0 + h) * s.kcap + k0 + g] = s.G[(size_t)(k0 + g) * s.kcap + k0 + h] = v;
                 }
-            }
         }
         // ---- Rayleigh-Ritz ------------------------------------------------------------------------------------
         const int k = s.k;
         theta.assign(k, 0.0);
-        if (s.dev_rr) {
-            // one workgroup: Ritz values -> dtheta, Ritz coefficient rows -> dWt; theta comes back with the residual norms
-            hipLaunchKernelGGL(bd_jacobi_eig_kernel, dim3(1), dim3(256), 0, c->stream, k, s.dG, s.kcap, s.dtheta, s.dWt, s.kcap,
-                               s.dWtmp, s.dinfo);
-            BHIP(hipGetLastError());
-        } else {
         Gk.resize((size_t)k * k);
         for (int a = 0; a < k; ++a)
             for (int b = 0; b < k; ++b) Gk[(size_t)a * k + b] = s.G[(size_t)a * s.kcap + b];
@@ -644,7 +1007,6 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
         if (rr_timing)
             fprintf(stderr, "block davidson: host Rayleigh-Ritz k = %d: %.1f us\n", k,
                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - trr0).count());
-        }
         // ---- residuals of the lowest nev Ritz pairs, 16 at a time; the first chunk with unconverged pairs feeds
         // the correction block s.T (its rows are copied out before s.R is reused) --------------------------------
         const int nwant = std::min(nev, k);
@@ -655,22 +1017,6 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
         nconv = 0;
         for (int j0 = 0; j0 < nwant; j0 += BD_NB) {
             const int nh = std::min(BD_NB, nwant - j0);
-            if (s.dev_rr) {
-                // R = (AV) W - theta (V W) with the coefficient rows and -theta read from the device
-                const double* Crow = s.dWt + (size_t)j0 * s.kcap;
-                BCHK(combine(s, nh, k, Crow, s.kcap, s.AV, 1.0, 0.0, s.R));
-                BCHK(combine(s, nh, k, Crow, s.kcap, s.V, -1.0, 1.0, s.R, s.dtheta + j0));
-                BCHK(launch_rows_sumsq(c, s.R, s.ld, nh, n, c->dscal + DS_MISC));
-                if (j0 == 0) {
-                    BCHK(d2h_async(c, theta.data(), s.dtheta, (size_t)k * sizeof(double)));
-                    BHIP(hipMemcpyAsync(c->hscal + DS_MISC + 32, s.dinfo, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                }
-                BCHK(read_scalars(c, DS_MISC, nh));
-                if (j0 == 0 && *reinterpret_cast<const int*>(c->hscal + DS_MISC + 32) != 0) {
-                    set_error("davidson_block: Rayleigh-Ritz eigenproblem failed (Jacobi sweeps exhausted)");
-                    return fail(SELLA_E_NOCONV);
-                }
-            } else {
             Ch.assign((size_t)nh * k, 0.0);
             for (int h = 0; h < nh; ++h)
                 for (int a = 0; a < k; ++a) Ch[(size_t)h * k + a] = W[(size_t)a * k + j0 + h];
@@ -682,7 +1028,6 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
             BCHK(combine(s, nh, k, s.dC, s.kcap, s.V, 1.0, 1.0, s.R));
             BCHK(launch_rows_sumsq(c, s.R, s.ld, nh, n, c->dscal + DS_MISC));
             BCHK(read_scalars(c, DS_MISC, nh));
-            }
             const bool feed = (na == 0);
             int run_src = -1, run_dst = 0, run_len = 0;              // consecutive residual rows travel as one copy
             auto flush_run = [&]() -> int {
@@ -745,10 +1090,6 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
                 double* src = pass ? s.AV : s.V;
                 for (int j0 = 0; j0 < keep; j0 += BD_NB) {
                     const int nh = std::min(BD_NB, keep - j0);
-                    if (s.dev_rr) {
-                        BCHK(combine(s, nh, s.k, s.dWt + (size_t)j0 * s.kcap, s.kcap, src, 1.0, 0.0, s.Vt + (size_t)j0 * s.ld));
-                        continue;
-                    }
                     Ch.assign((size_t)nh * s.k, 0.0);
                     for (int h = 0; h < nh; ++h)
                         for (int a = 0; a < s.k; ++a) Ch[(size_t)h * s.k + a] = W[(size_t)a * s.k + j0 + h];
@@ -758,20 +1099,12 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
                 BHIP(s_memcpy(c, src, s.Vt, (size_t)keep * s.ld * sizeof(double), hipMemcpyDeviceToDevice));
                 BHIP(s_memset0(c, src + (size_t)keep * s.ld, (size_t)(s.kcap - keep) * s.ld * sizeof(double)));
             }
-            if (s.dev_rr) {
-                hipLaunchKernelGGL(bd_gram_reset_kernel, dim3((s.kcap * s.kcap + 255) / 256), dim3(256), 0, c->stream, s.dG,
-                                   s.kcap, s.kcap, keep, s.dtheta);
-                BHIP(hipGetLastError());
-            } else {
-                std::fill(s.G.begin(), s.G.end(), 0.0);
-                for (int a = 0; a < keep; ++a) s.G[(size_t)a * s.kcap + a] = theta[a];
-            }
+            std::fill(s.G.begin(), s.G.end(), 0.0);
+            for (int a = 0; a < keep; ++a) s.G[(size_t)a * s.kcap + a] = theta[a];
             s.k = keep;
             theta.resize(keep);                       // the restarted basis IS the Ritz basis: W = I until the next RR
-            if (!s.dev_rr) {
-                W.assign((size_t)keep * keep, 0.0);
-                for (int a = 0; a < keep; ++a) W[(size_t)a * keep + a] = 1.0;
-            }
+            W.assign((size_t)keep * keep, 0.0);
+            for (int a = 0; a < keep; ++a) W[(size_t)a * keep + a] = 1.0;
         }
         BCHK(orthonormalise_block(s, na, s.k, &kept));
         ++iter;
@@ -779,31 +1112,35 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
     }
 
     // ---- results: lowest nev Ritz pairs --------------------------------------------------------------------------
+    const double ts3 = bd_now_us();
     const int k = s.k, nout = std::min(nev, k);
     for (int j = 0; j < nev; ++j) lams_out[j] = (j < nout) ? theta[j] : 0.0;
     if (res_out)
         for (int j = 0; j < nev; ++j) res_out[j] = (j < nout) ? rn[j] : -1.0;
-    vec Xh((size_t)n * BD_NB);
-    for (size_t e = 0; e < (size_t)n * nev; ++e) V_out[e] = 0.0;
+    static thread_local vec Xh;                  // (kept across calls: fresh pages cost more than the transfer)
+    Xh.resize((size_t)n * BD_NB);
+    if (nout < nev)
+        for (size_t e = 0; e < (size_t)n * nev; ++e) V_out[e] = 0.0;
     for (int j0 = 0; j0 < nout; j0 += BD_NB) {
         const int nh = std::min(BD_NB, nout - j0);
-        if (s.dev_rr) {
-            BCHK(combine(s, nh, k, s.dWt + (size_t)j0 * s.kcap, s.kcap, s.V, 1.0, 0.0, s.R));
-        } else {
         Ch.assign((size_t)nh * k, 0.0);
         for (int h = 0; h < nh; ++h)
             for (int a = 0; a < k; ++a) Ch[(size_t)h * k + a] = W[(size_t)a * k + j0 + h];
         BCHK(put_coeffs(s, Ch, nh, k));
         BCHK(combine(s, nh, k, s.dC, s.kcap, s.V, 1.0, 0.0, s.R));
-        }
-        BCHK(download_panel(c, s.R, s.ld, n, nh, Xh.data()));
+        BCHK(d2h_async_2d(c, Xh.data(), s.R, (size_t)s.ld * sizeof(double), (size_t)n * sizeof(double), nh));   // vector-major
+        BCHK(stream_wait(c));
         for (int i = 0; i < n; ++i)
-            for (int h = 0; h < nh; ++h) V_out[(size_t)i * nev + j0 + h] = Xh[(size_t)i * nh + h];
+            for (int h = 0; h < nh; ++h) V_out[(size_t)i * nev + j0 + h] = Xh[(size_t)h * n + i];
     }
     if (niter_out) *niter_out = iter;
     if (nmatvec_out) *nmatvec_out = s.nmatvec;
     if (nconv_out) *nconv_out = done ? nev : nconv;
+    const double ts4 = bd_now_us();
     blk_free(s);
+    if (stage_timing)
+        fprintf(stderr, "block davidson: allocation + start vectors %.1f us, start block orthonormalised %.1f us, iterations %.1f us, "
+                        "Ritz vectors to the host %.1f us, release %.1f us\n", ts1 - ts0, ts2 - ts1, ts3 - ts2, ts4 - ts3, bd_now_us() - ts4);
     return SELLA_OK;
 #undef BCHK
 #undef BHIP

@@ -260,5 +260,147 @@ inline void congruence(int k, const double* W, const double* G, double* out) {
         }
 }
 
+// Full symmetric eigendecomposition of a small dense matrix with every inner loop running along a contiguous row (the
+// k x k Rayleigh-Ritz problem of the block Davidson iteration, k = 48: the column-oriented EISPACK routines of
+// small_linalg.h take 135 us there — strided rotations — and sit alone on the iteration's critical path).
+//   Householder tridiagonalisation on the FULL symmetric storage (both triangles updated: twice the flops of a
+//   one-triangle update, all of them in vector loops), Q accumulated backwards, implicit-shift QL with the rotations
+//   applied to the ROWS of Z^T.
+// G: k x k, symmetric (the lower triangle is mirrored first), leading dimension ldg.  On return w ascending, row j of Wt
+// (leading dimension k) = eigenvector j, largest-magnitude component positive (the convention of small::sym_eig).
+// Returns 0, or l + 1 if eigenvalue l did not converge in 60 QL iterations.
+inline int sym_eig_rows(int k, const double* G, int ldg, double* w, double* Wt) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)      // (no trajectory depends on these last bits: block Davidson's parity target is the converged pair)
+#endif
+    if (k <= 0) return 0;
+    if (k == 1) { w[0] = G[0]; Wt[0] = 1.0; return 0; }
+    static thread_local vec M, Vs, Qm, p, e, taus;
+    M.resize((size_t)k * k); Vs.assign((size_t)k * k, 0.0); Qm.resize((size_t)k * k);
+    p.resize(k); e.assign(k, 0.0); taus.assign(k, 0.0);
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j <= i; ++j) M[(size_t)i * k + j] = M[(size_t)j * k + i] = G[(size_t)i * ldg + j];
+    // ---- tridiagonalisation: column j below the sub-diagonal eliminated by H_j = I - tau v v^T, v = (1, ...) on rows j+1.. ----
+    for (int j = 0; j + 2 < k; ++j) {
+        const int m = k - j - 1;                              // trailing block rows j+1 .. k-1
+        double* x = &M[(size_t)j * k + j + 1];                // row j right of the diagonal = column j below it
+        double* v = &Vs[(size_t)j * k + j + 1];
+        double sig = 0.0;
+        for (int i = 1; i < m; ++i) sig += x[i] * x[i];
+        const double alpha = x[0];
+        if (sig == 0.0) { e[j] = alpha; taus[j] = 0.0; continue; }
+        const double nrm = sqrt(alpha * alpha + sig);
+        const double beta = (alpha >= 0.0) ? -nrm : nrm;
+        const double tau = (beta - alpha) / beta, sc = 1.0 / (alpha - beta);
+        v[0] = 1.0;
+        for (int i = 1; i < m; ++i) v[i] = x[i] * sc;
+        e[j] = beta;
+        taus[j] = tau;
+        // p = tau A22 v;  q = p - (tau/2)(p.v) v;  A22 -= v q^T + q v^T
+        double pv = 0.0;
+        for (int r = 0; r < m; ++r) {
+            const double* a = &M[(size_t)(j + 1 + r) * k + j + 1];
+            double s = 0.0;
+            for (int cidx = 0; cidx < m; ++cidx) s += a[cidx] * v[cidx];
+            p[r] = tau * s;
+            pv += p[r] * v[r];
+        }
+        const double hh = 0.5 * tau * pv;
+        for (int r = 0; r < m; ++r) p[r] -= hh * v[r];
+        for (int r = 0; r < m; ++r) {
+            double* a = &M[(size_t)(j + 1 + r) * k + j + 1];
+            const double vr = v[r], pr = p[r];
+            for (int cidx = 0; cidx < m; ++cidx) a[cidx] -= vr * p[cidx] + pr * v[cidx];
+        }
+    }
+    if (k >= 2) e[k - 2] = M[(size_t)(k - 2) * k + k - 1];
+    for (int i = 0; i < k; ++i) w[i] = M[(size_t)i * k + i];
+    // ---- Q = H_0 H_1 ... H_{k-3} accumulated backwards (only the block H_j touches is not yet the identity) ----
+    std::fill(Qm.begin(), Qm.end(), 0.0);
+    for (int i = 0; i < k; ++i) Qm[(size_t)i * k + i] = 1.0;
+    for (int j = k - 3; j >= 0; --j) {
+        if (taus[j] == 0.0) continue;
+        const int m = k - j - 1;
+        const double* v = &Vs[(size_t)j * k + j + 1];
+        double* y = p.data();                                 // y = v^T B, B = Q[j+1:, j+1:]
+        for (int cidx = 0; cidx < m; ++cidx) y[cidx] = 0.0;
+        for (int r = 0; r < m; ++r) {
+            const double* b = &Qm[(size_t)(j + 1 + r) * k + j + 1];
+            const double vr = v[r];
+            for (int cidx = 0; cidx < m; ++cidx) y[cidx] += vr * b[cidx];
+        }
+        for (int r = 0; r < m; ++r) {
+            double* b = &Qm[(size_t)(j + 1 + r) * k + j + 1];
+            const double f = taus[j] * v[r];
+            for (int cidx = 0; cidx < m; ++cidx) b[cidx] -= f * y[cidx];
+        }
+    }
+    for (int i = 0; i < k; ++i)                               // Wt = Q^T
+        for (int j = 0; j < k; ++j) Wt[(size_t)i * k + j] = Qm[(size_t)j * k + i];
+    // ---- implicit-shift QL (the recurrence of small::tridiag_ql), rotations on rows i, i+1 of Wt ----
+    double* d = w;
+    e[k - 1] = 0.0;
+    for (int l = 0; l < k; ++l) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < k - 1; ++m) {
+                const double dd = fabs(d[m]) + fabs(d[m + 1]);
+                if (fabs(e[m]) <= 2.220446049250313e-16 * dd) break;
+            }
+            if (m != l) {
+                if (iter++ == 60) return l + 1;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = sqrt(g * g + 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+                double s = 1.0, c = 1.0, pp = 0.0;
+                int i;
+                for (i = m - 1; i >= l; --i) {
+                    double f = s * e[i];
+                    const double b = c * e[i];
+                    r = sqrt(f * f + g * g);
+                    e[i + 1] = r;
+                    if (r == 0.0) { d[i + 1] -= pp; e[m] = 0.0; break; }
+                    s = f / r;
+                    c = g / r;
+                    g = d[i + 1] - pp;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    pp = s * r;
+                    d[i + 1] = g + pp;
+                    g = c * r - b;
+                    double* z0 = &Wt[(size_t)i * k];
+                    double* z1 = z0 + k;
+                    for (int q = 0; q < k; ++q) {
+                        const double f2 = z1[q], f1 = z0[q];
+                        z1[q] = s * f1 + c * f2;
+                        z0[q] = c * f1 - s * f2;
+                    }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= pp;
+                e[l] = g;
+                e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    // ---- ascending order, sign convention ----
+    static thread_local std::vector<int> ord;
+    ord.resize(k);
+    for (int i = 0; i < k; ++i) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return d[a] < d[b]; });
+    for (int i = 0; i < k; ++i) p[i] = d[ord[i]];
+    Qm.assign(Wt, Wt + (size_t)k * k);
+    for (int i = 0; i < k; ++i) {
+        const double* src = &Qm[(size_t)ord[i] * k];
+        double vm = 0.0;
+        int im = 0;
+        for (int q = 0; q < k; ++q)
+            if (fabs(src[q]) > vm) { vm = fabs(src[q]); im = q; }
+        const double sg = (src[im] < 0.0) ? -1.0 : 1.0;
+        for (int q = 0; q < k; ++q) Wt[(size_t)i * k + q] = sg * src[q];
+        w[i] = p[i];
+    }
+    return 0;
+}
+
 }  // namespace hostm
 }  // namespace sella

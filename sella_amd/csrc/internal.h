@@ -139,9 +139,8 @@ struct Options {
     long rank2k_stream = 1;  // 1: trailing update of the tridiagonalisation as a mirror-free MFMA stream (update.hip)
     long panel_small = 2048; // panel products with <= 64 rows and at least this many columns split the long index over the
                              // chip (kernels.hip); 0: never
-    long bd_dev_rr = 0;      // 1: block Davidson solves its k x k Rayleigh-Ritz problem (k <= 56) on the device by parallel cyclic
-                             // Jacobi in one workgroup (davidson_block.hip).  Measured at k = 48: 456 us per solve against ~270 us
-                             // for the host's tred2 / tql2 (session r03l: 1.16 against 0.85 ms per block iteration), hence off
+    long bd_pipeline = 1;    // block Davidson: pipelined iteration (davidson_block.hip run_pipelined: A applied to the raw correction
+                             // block while the host does the SVQB step, two polled waits per iteration); 0: the general loop
     long eigh_wy_overlap = 1; // 1: Gram matrices / triangular factors of the compact-WY blocks on a second stream, beside divide & conquer
     long eigh_upd_max = 1024; // trailing blocks of at most this many rows are tridiagonalised with ONE launch per column, the block
                              //    kept up to date by the launch itself (trd_upd_kernel, eigh.hip); 0: never.  eigh at n = 3072 by
@@ -366,6 +365,8 @@ int launch_gemv_rows2(sella_ctx* c, const double* A, int rows, int lda, const do
 // rows beyond nrhs and the row padding zero
 int launch_panel16(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* Xp, int nrhs,
                    double* Y, int ldy);
+int launch_panel16_marked(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* Xp, int nrhs, double* Y,
+                          int ldy);                  // ... and publishes the sequence word of a polled wait behind it
 // |x|^2 -> out[0]; x <- x/|x|   (one single-workgroup launch)
 int launch_normalize(sella_ctx* c, double* x, int n, double* out);
 // Y[h*ldy + j] = sum_i A[i*lda + j] * X[h*ldx + i]   (transposed product, deterministic 2-pass)

@@ -1081,8 +1081,11 @@ __global__ __launch_bounds__(256) void panel_small_partial_kernel(const double* 
 // one workgroup per right-hand side h: thread (r, g) sums every fourth partial of output (h, r) with four independent
 // accumulators (the loads of a sequential sum were this kernel's whole time: 174 us for 192 partials), the four groups
 // are combined through LDS in a fixed order
+// (pword != null: the LAST workgroup to finish publishes the sequence word of a polled wait — context.hip poll_arm /
+// poll_wait — so that a result the host consumes needs no mark kernel behind it)
 __global__ __launch_bounds__(256) void panel_small_reduce_kernel(const double* __restrict__ part, int nsplit, int rows,
-                                                                 int nrhs, double* __restrict__ Y, int ldy) {
+                                                                 int nrhs, double* __restrict__ Y, int ldy,
+                                                                 unsigned long long* pword, unsigned long long pseq, unsigned* pcount) {
     __shared__ double red[4][PS_ROWS];
     const int tid = threadIdx.x, r = tid & 63, g = tid >> 6, h = blockIdx.x;
     const double* p = part + (size_t)h * PS_ROWS + r;
@@ -1099,10 +1102,21 @@ __global__ __launch_bounds__(256) void panel_small_reduce_kernel(const double* _
     red[g][r] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && r < rows) Y[(size_t)h * ldy + r] = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+    if (pword != nullptr) {
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence_system();
+            if (atomicAdd(pcount, 1u) == gridDim.x - 1) {
+                *pcount = 0u;
+                __threadfence_system();
+                *reinterpret_cast<volatile unsigned long long*>(pword) = pseq;
+            }
+        }
+    }
 }
 
 static int launch_panel_small(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* X, int ldx, int nrhs,
-                              double* Y, int ldy) {
+                              double* Y, int ldy, bool publish = false) {
     int nsplit = (cols + PS_TILE - 1) / PS_TILE;
     if (nsplit > 256) nsplit = 256;
     int cpw = (cols + nsplit - 1) / nsplit;
@@ -1111,9 +1125,23 @@ static int launch_panel_small(sella_ctx* c, const double* A, int rows, int cols,
     double* part;
     SCHK(scratch_get(c, SCR_PSMALL, (size_t)256 * 16 * PS_ROWS * sizeof(double), &part));
     hipLaunchKernelGGL(panel_small_partial_kernel, dim3(nsplit), dim3(256), 0, c->stream, A, rows, cols, lda, X, ldx, nrhs, cpw, part);
-    hipLaunchKernelGGL(panel_small_reduce_kernel, dim3(nrhs), dim3(256), 0, c->stream, part, nsplit, rows, nrhs, Y, ldy);
+    unsigned long long* pword = nullptr;
+    unsigned long long pseq = 0;
+    unsigned* pcount = nullptr;
+    if (publish) SCHK(poll_arm(c, &pword, &pseq, &pcount));
+    hipLaunchKernelGGL(panel_small_reduce_kernel, dim3(nrhs), dim3(256), 0, c->stream, part, nsplit, rows, nrhs, Y, ldy, pword, pseq, pcount);
     HIPCHK(hipGetLastError());
     return SELLA_OK;
+}
+
+// launch_panel16 for a result the host waits for by polling (Y in pinned host memory): the product's last kernel
+// publishes the sequence word where it can, a mark kernel follows otherwise; poll_wait(c) afterwards.
+int launch_panel16_marked(sella_ctx* c, const double* A, int rows, int cols, int lda, const double* Xp, int nrhs, double* Y, int ldy) {
+    if (rows <= 0 || nrhs <= 0) return poll_mark(c);
+    if (rows <= PS_ROWS && nrhs <= 16 && c->opt.panel_small > 0 && cols >= c->opt.panel_small && !(c->cohort && cohort_in_fiber()))
+        return launch_panel_small(c, A, rows, cols, lda, Xp, lda, nrhs, Y, ldy, true);
+    SCHK(launch_panel16(c, A, rows, cols, lda, Xp, nrhs, Y, ldy));
+    return poll_mark(c);
 }
 
 // Y (nrhs rows, vector-major) = A X^T for a zero-padded 16-row panel Xp with the matrix's leading dimension

@@ -294,8 +294,8 @@ class Context:
             raise err[0]
         check(st)
         kk = k.value
-        return (lams[:kk].copy(), V[:n * kk].reshape(n, kk).copy(),
-                AV[:n * kk].reshape(n, kk).copy(), nmv.value)
+        # (views of the call's own buffers: two fresh 1 MB copies were 0.1 ms of a 1.8 ms call)
+        return (lams[:kk], V[:n * kk].reshape(n, kk), AV[:n * kk].reshape(n, kk), nmv.value)
 
     def davidson_block(self, A, n, nev, block=16, tol=1e-8, maxiter=500, maxvec=0, V0=None, Pvecs=None,
                        PvecsT=None, pevals=None, diag=None, row0=0, world=1, allgather=None):

@@ -90,19 +90,47 @@ def test_block_davidson_split_panel_products(ctx):
     assert outs[64]['niter'] == outs[0]['niter']
 
 
-def test_block_davidson_device_rayleigh_ritz(ctx):
-    """Option bd_dev_rr: the k x k Rayleigh-Ritz problem solved on the device (parallel cyclic Jacobi in one workgroup,
-    Ritz coefficients read by the combine kernels straight from HBM) against the default host solve: same pairs."""
-    n, nev = 128, 16
-    A, P, g = hessian_like(n, seed=n, nneg=2)
-    dA, dP = ctx.upload(A), ctx.upload(P)
-    w, Q, Qt = ctx.eigh(dP)
+@pytest.mark.parametrize('precond', ['eigenbasis', 'diagonal'])
+def test_block_davidson_pipelined_against_general_loop(ctx, precond):
+    """Option bd_pipeline (default 1): A applied to the raw correction block while the host orthonormalises it, the same
+    small coefficients transforming T and A T, two polled waits per iteration — against the general loop (0): the same
+    converged pairs (no trajectory to match: the reference has no block method)."""
+    nev = 16
+    if precond == 'eigenbasis':
+        n = 128
+        A, P, g = hessian_like(n, seed=n, nneg=2)
+        dA, dP = ctx.upload(A), ctx.upload(P)
+        w, Q, Qt = ctx.eigh(dP)
+        kw = dict(Pvecs=Q, PvecsT=Qt, pevals=w)
+    else:
+        n = 300
+        N = np.random.RandomState(11).normal(size=(n, n))
+        A = np.diag(np.arange(1, n + 1) * 0.5) + 0.02 * (N + N.T)        # diagonally dominant: Davidson's home ground
+        dA = ctx.upload(A)
+        kw = dict(diag=np.diag(A).copy())
     outs = {}
     for flag in (1, 0):
-        ctx.set_option('bd_dev_rr', flag)
+        ctx.set_option('bd_pipeline', flag)
         try:
-            outs[flag] = ctx.davidson_block(dA, n, nev, block=16, tol=1e-8, maxiter=200, Pvecs=Q, PvecsT=Qt, pevals=w)
+            outs[flag] = ctx.davidson_block(dA, n, nev, block=16, tol=1e-8, maxiter=400, **kw)
         finally:
-            ctx.set_option('bd_dev_rr', 0)
+            ctx.set_option('bd_pipeline', 1)
         check_pairs(A, outs[flag], nev)
     np.testing.assert_allclose(outs[1]['lams'], outs[0]['lams'], atol=1e-10)
+
+
+def test_block_davidson_pipelined_restarts_and_small_blocks(ctx):
+    """The pipelined driver with thick restarts in every iteration (maxvec at its minimum), with nev < block, and with a
+    start block that leaves fewer than 16 vectors."""
+    n = 300
+    rng = np.random.RandomState(3)
+    N = rng.normal(size=(n, n))
+    A = np.diag(np.arange(1, n + 1) * 0.5) + 0.02 * (N + N.T)
+    dA = ctx.upload(A)
+    out = ctx.davidson_block(dA, n, 6, block=6, tol=1e-9, maxiter=400, maxvec=18, diag=np.diag(A).copy())
+    check_pairs(A, out, 6)
+    out = ctx.davidson_block(dA, n, 3, block=8, tol=1e-9, maxiter=400, diag=np.diag(A).copy())
+    check_pairs(A, out, 3)
+    V0 = np.eye(n)[:, :7] + 0.05 * rng.normal(size=(n, 7))            # (a start block the caller supplies: 7 < 16 vectors)
+    out = ctx.davidson_block(dA, n, 5, block=16, tol=1e-9, maxiter=400, V0=V0, diag=np.diag(A).copy())
+    check_pairs(A, out, 5)

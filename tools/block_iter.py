@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Block Davidson iterations at BASELINE configs[4] size on one GPU (dense symmetric pseudo-random operator, diagonal
-preconditioner, fixed iteration count): ms per block iteration, with the Rayleigh-Ritz step on the device and on the
-host.   usage: block_iter.py [n] [iterations]"""
+preconditioner, fixed iteration count): ms per block iteration of the pipelined driver (option bd_pipeline 1) and of
+the general loop (0).   usage: block_iter.py [n] [iterations] [flags ...]"""
 import os
 import sys
 import time
@@ -23,12 +23,20 @@ diag = np.ascontiguousarray(H.diagonal())
 del H
 flags = [int(a) for a in sys.argv[3:]] or [1, 0, 1]
 for flag in flags:
-    ctx.set_option('bd_dev_rr', flag)
+    ctx.set_option('bd_pipeline', flag)
     ctx.davidson_block(dH, n, 16, block=16, tol=1e-14, maxiter=2, diag=diag)
     ctx.sync()
     t = time.perf_counter()
     out = ctx.davidson_block(dH, n, 16, block=16, tol=1e-14, maxiter=iters, diag=diag)
     ctx.sync()
     dt = time.perf_counter() - t
-    print('bd_dev_rr=%d: %d iterations, %.3f ms per block iteration, lowest Ritz %.12f'
+    print('bd_pipeline=%d: %d iterations, %.3f ms per block iteration, lowest Ritz %.12f'
           % (flag, out['niter'], 1e3 * dt / max(1, out['niter']), out['lams'][0]), flush=True)
+if os.environ.get('BLOCK_ITER_CONVERGE'):
+    for flag in (1, 0):
+        ctx.set_option('bd_pipeline', flag)
+        t = time.perf_counter()
+        out = ctx.davidson_block(dH, n, 16, block=16, tol=1e-9, maxiter=300, diag=diag)
+        dt = time.perf_counter() - t
+        print('bd_pipeline=%d: converged run, tol 1e-9: %d of 16 pairs in %d iterations, %d matrix-vector products, %.1f ms, lowest %.12f'
+              % (flag, out['nconv'], out['niter'], out['nmatvec'], 1e3 * dt, out['lams'][0]), flush=True)

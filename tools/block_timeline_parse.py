@@ -23,7 +23,7 @@ for r in rows:
     cur.append(r)
 its.append(cur)
 # one operator pass per iteration: take an iteration from the last run (skip the bare panel passes of the warm-up)
-cands = [it for it in its if len(it) > 12]
+cands = [it for it in its if len(it) > 6]
 mid = cands[len(cands) * 3 // 4]
 t0 = mid[0][1]
 busy = sum(e - s for _, s, e in mid)

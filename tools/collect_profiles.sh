@@ -18,7 +18,7 @@ cp $S/member1_kernel_stats.md $P/${RP}_member_search_kernel_stats.md; cp $S/coho
   echo '## back-transformation (wy_apply_mfma_kernel), L2 requests, hits / misses and fetched bytes'; echo '```'; cat $S/pmc_wy_l2req.txt $S/pmc_wy_l2hit.txt $S/pmc_wy_fetch.txt; echo '```';
   echo "64 reflectors per block (n >= 2560; wy_apply_mfma64_kernel): 1.49e8 requests x 128 B = 19.1 GB through L2 in 2.50 ms = 7.6 TB/s (hit rate 86 %), FETCH x 2 = 3.7 GB past L2, against 0.23 GB algorithmic (read X once, write once, reflectors once); 2 n^3 = 5.8e10 flop in 2.50 ms = 23.2 TFLOP/s = 0.295 of the fp64 MFMA peak.  The 32-reflector kernel it replaced at this size (sessions up to r03D): 1.77e8 requests = 22.7 GB in 3.16 ms = 7.2 TB/s, hit rate 82 %, 6.6 GB past L2, 18.3 TFLOP/s = 0.23 — L2-bandwidth bound either way (4 / 8 / 16 wavefronts per workgroup measured equal); the 64-blocks halve the passes over X, the reflector stream stays."; echo;
   echo '## matrix-core utilisation (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE)'; echo '```'; cat $S/pmc_mfma.txt; echo '```'; } > $P/${RP}_pmc.md
-{ echo "# block Davidson iteration (tools/block_iter.py, 3N = 12288, block 16), host Rayleigh-Ritz (default) against the device Jacobi kernel (option bd_dev_rr)"; echo '```'; cat $S/block_iter.log; echo '```'; } > $P/${RP}_block_iter.md
+{ echo "# block Davidson iteration (tools/block_iter.py, 3N = 12288, block 16), pipelined driver (default) against the general loop (option bd_pipeline)"; echo '```'; cat $S/block_iter.log; echo '```'; } > $P/${RP}_block_iter.md
 { echo "# threads, processes and RCCL on one GPU (session $TAG)"; echo; echo '## ensemble leg on host threads of ONE process, searches inside the library (tools/ensemble_threads.py: EnsembleThreads, one persistent device context per thread)'; echo '```'; cat $S/threads.log; echo '```'; echo '## the same with the general driver (SELLA_LIBRARY_SEARCH=0: ~10,000 host-language calls per member, interpreter lock held in between)'; echo '```'; cat $S/threads_general.log; echo '```'; echo '## one member, where its time goes (tools/ens_profile.py)'; echo '```'; grep "seconds per member\|update_H n=768\|structured eigen" $S/ens_profile.log | tail -8; sed -n 1,18p $S/ens_profile.log; echo '```'; echo '## ensemble leg: worker processes (tools/ensemble_probe.py; workers run with HSA_ENABLE_SDMA=0)'; echo '```'; cat $S/probe.log; echo '```'; echo '## fine-grained library calls from N Python threads, one context each (tools/thread_scaling.py)'; echo '```'; cat $S/thread_scaling.log; echo '```'; echo '## RCCL: one rank (tools/rccl_smoke.py)'; echo '```'; cat $S/rccl.log; echo '```'; echo '## RCCL: two ranks on the one GPU of the box (tools/rccl_two_ranks_one_gpu.py)'; echo '```'; cat $S/rccl2.log; echo '```'; } > $P/${RP}_threads_procs_rccl.md
 { echo "# eigensolver beyond the Infinity Cache (session $TAG): symmetric-aware trailing matvec + triangle-only trailing update from 5120 trailing rows on, 64-reflector blocks in the back-transformation from n = 4096 on"; echo; echo '## wall time per eigh (tools/eigh_only.py)'; echo '```'; cat $S/eigh_large.log; echo '```'; echo; echo '## kernels of one eigh at 3N = 12288'; echo; sed -n 3,22p $S/eigh12288_kernel_stats.md; echo; echo '## per-column kernels by trailing size (tools/trd_by_m.py)'; echo; cat $S/eigh12288_by_m.txt; } > $P/${RP}_eigh_large.md
 { echo "# optimizer step and configs[1] timings (session $TAG)"; for f in opt_3072 emt geodesic dav_time; do echo; echo "## $f.log"; echo '```'; cat $S/$f.log; echo '```'; done; } > $P/${RP}_timings.md

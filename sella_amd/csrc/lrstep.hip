@@ -43,6 +43,16 @@ __device__ __forceinline__ double blk_sum(double v, double* red) {
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
+// two sums with one pair of barriers (each added up in blk_sum's order); red: 8 doubles
+__device__ __forceinline__ void blk_sum2(double v1, double v2, double* red, double* o1, double* o2) {
+    v1 = wave_sum64(v1);
+    v2 = wave_sum64(v2);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = v1; red[4 + (threadIdx.x >> 6)] = v2; }
+    __syncthreads();
+    *o1 = (red[0] + red[1]) + (red[2] + red[3]);
+    *o2 = (red[4] + red[5]) + (red[6] + red[7]);
+}
 __device__ __forceinline__ double blk_max(double v, double* red) {
     for (int m = 32; m > 0; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
     __syncthreads();
@@ -73,10 +83,135 @@ struct PreArgs {
     double* eg = nullptr;
 };
 
-__device__ __forceinline__ void lr_pre_body(const PreArgs& a) {
+// Fast form for nr <= 256 (one coordinate per thread): every global operand — the coefficient rows, mu, the Gram scalars,
+// the partial sums, the second new row itself — is loaded ONCE, up front, all loads in flight together; s~, y~, u~, z~ stay
+// in registers between the three block-wide reductions.  The general form re-read them from global memory behind every
+// barrier: nine dependent load phases of 1.5 - 2 us in a kernel of 14.  shP / shD (LDS, may be null): p_1 and D for the
+// plan that follows in the same launch.  Same arithmetic, same summation orders as the general form.
+constexpr int LR_ROW2_REGS = 16;           // the second row rides in registers up to 256 x 16 = 4096 entries
+__device__ __forceinline__ void lr_pre_fast(const PreArgs& a, double* shP, double* shD) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
+    __shared__ double red[8];
+    const int tid = threadIdx.x, r = a.r, nr = a.nr, ldr = a.ldr;
+    // ---- every load of the kernel ----
+    double c0i = 0.0, c20i = 0.0, c1i = 0.0, c21i = 0.0, c3i = 0.0, mui = 0.0, cgi = 0.0;
+    if (tid < r) {
+        c0i = a.C[tid]; c20i = a.C2[tid]; c1i = a.C[ldr + tid]; c21i = a.C2[ldr + tid]; c3i = a.C3[tid]; mui = a.mu[tid];
+        if (a.eg) cgi = a.CG[tid];
+    }
+    const double c3r = a.C3[r];
+    const double ss = a.G[G_SS], sy = a.G[G_SY], yy = a.G[G_YY];
+    const double a11 = a.G[G_A11], a12 = a.G[G_A12];
+    const double r0g = a.eg ? a.G[G_R0G] : 0.0;
+    double rv[LR_ROW2_REGS];
+#pragma unroll
+    for (int q = 0; q < LR_ROW2_REGS; ++q) {
+        const int i = tid + 256 * q;
+        rv[q] = (i < a.n) ? a.row2[i] : 0.0;
+    }
+    double rho2sq = 0.0, row2g = 0.0;
+    if (a.NP) {
+        for (int p = 0; p < a.parts; ++p) { rho2sq += a.NP[2 * p]; row2g += a.NP[2 * p + 1]; }
+    } else {
+        double pr = 0.0;
+#pragma unroll
+        for (int q = 0; q < LR_ROW2_REGS; ++q) pr += rv[q] * rv[q];
+        rho2sq = blk_sum(pr, red);
+    }
+    const bool keep1 = ss > 0.0 && a11 > 1e-26 * ss;
+    const double r11 = keep1 ? sqrt(a11) : 0.0;
+    const bool keep2 = yy > 0.0 && rho2sq > 1e-26 * yy;
+    const double r22 = keep2 ? sqrt(rho2sq) : 0.0;
+    const double inv22 = keep2 ? 1.0 / r22 : 0.0;
+#pragma unroll
+    for (int q = 0; q < LR_ROW2_REGS; ++q) {
+        const int i = tid + 256 * q;
+        if (i < a.n) a.row2[i] = rv[q] * inv22;
+    }
+    const double y1 = keep1 ? a12 / r11 - c3r : 0.0;
+    if (tid == 0) {
+        a.sc[SC_KEEP1] = keep1 ? 1.0 : 0.0;
+        a.sc[SC_KEEP2] = keep2 ? 1.0 : 0.0;
+        a.sc[SC_FAIL] = 0.0;
+        a.sc[SC_GPERP2] = 0.0;
+    }
+    if (a.eg) {
+        if (tid < r) a.eg[tid] = -cgi;
+        if (tid == 0) {
+            a.eg[r] = keep1 ? r0g / r11 : 0.0;
+            a.eg[r + 1] = keep2 ? row2g * inv22 : 0.0;
+        }
+    }
+    const bool own = tid < nr;
+    const double di = tid < r ? mui : a.lam0;
+    const double si = tid < r ? -(c0i + c20i) : (tid == r ? r11 : 0.0);
+    const double yi = tid < r ? -((c1i + c21i) + c3i) : (tid == r ? y1 : r22);
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    if (a.mode == 0) {
+        double m2, sBs;
+        blk_sum2(own ? fabs(di) * si * si : 0.0, own ? di * si * si : 0.0, red, &m2, &sBs);
+        const double m1 = sy, js = sy - sBs;
+        const double g = m1 * m1 + m2 * m2;
+        const double gp = (g > 0.0) ? 1.0 / g : 0.0;
+        c0 = gp * m1;
+        c1 = gp * m2;
+        c2 = -0.5 * js;
+        if (tid == 0) { a.sc[SC_M1] = m1; a.sc[SC_M2] = m2; a.sc[SC_JS] = js; a.sc[SC_SBS] = sBs; }
+    }
+    double ui = 0.0, zi = 0.0;
+    if (own) {
+        if (a.mode == 0) {
+            ui = c0 * yi + c1 * fabs(di) * si;
+            zi = (yi - di * si) + c2 * ui;
+        } else {
+            ui = si;
+            zi = yi;
+        }
+        a.UZ[2 * tid] = ui;
+        a.UZ[2 * tid + 1] = zi;
+        a.D[tid] = di;
+        if (shD) shD[tid] = di;
+    }
+    double uu, uz;
+    blk_sum2(ui * ui, ui * zi, red, &uu, &uz);
+    const double proj = uu > 0.0 ? uz / uu : 0.0;
+    const double zp = zi - proj * ui;
+    const double n2 = blk_sum(own ? zp * zp : 0.0, red);
+    const double un = sqrt(uu), zn = sqrt(n2), s = un * zn, b = uz;
+    double sig[2] = {0.0, 0.0}, w1[2] = {0.0, 0.0}, w2[2] = {0.0, 0.0};        // p_t = w1[t] f1 + w2[t] f2
+    if (uu > 0.0) {
+        if (s > 0.0) {
+            const double root = sqrt(b * b + s * s);
+            if (b >= 0.0) { sig[0] = b + root; sig[1] = -(s * s) / sig[0]; }
+            else { sig[1] = b - root; sig[0] = -(s * s) / sig[1]; }
+            for (int t = 0; t < 2; ++t) {
+                const double nrm = sqrt(sig[t] * sig[t] + s * s);
+                w1[t] = sig[t] / nrm;
+                w2[t] = s / nrm;
+            }
+        } else {
+            sig[0] = 2.0 * b;
+            w1[0] = 1.0;
+        }
+    }
+    if (own) {
+        const double f1 = uu > 0.0 ? ui / un : 0.0;
+        const double f2 = zn > 0.0 ? zp / zn : 0.0;
+        const double p1 = w1[0] * f1 + w2[0] * f2;
+        a.P[tid] = p1;
+        a.P[ldr + tid] = w1[1] * f1 + w2[1] * f2;
+        if (shP) shP[tid] = p1;
+    }
+    if (tid == 0) { a.sc[SC_SIG1] = sig[0]; a.sc[SC_SIG2] = sig[1]; }
+}
+
+__device__ __forceinline__ void lr_pre_body(const PreArgs& a, double* shP = nullptr, double* shD = nullptr) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    if (a.nr <= 256 && a.n <= 256 * LR_ROW2_REGS) { lr_pre_fast(a, shP, shD); return; }
     __shared__ double red[4];
     const int tid = threadIdx.x, r = a.r, nr = a.nr;
     const double ss = a.G[G_SS], sy = a.G[G_SY], yy = a.G[G_YY];
@@ -233,6 +368,45 @@ __device__ __forceinline__ void lr_plan_body(const PlanArgs& a) {
             sZ[i] = zi;
             pz += zi * zi;
         }
+    } else if (nr <= 128) {
+        // z = Q^T p for up to 128 rows: lane -> columns lane and 64 + lane, wavefront w -> the w-th quarter of the summation
+        // index, EVERY load of the product in flight at once (two passes of two batches of sixteen were four dependent load
+        // phases of a 19 us kernel); the quarters meet in LDS once, summed in the order of the general form below
+        constexpr int QB = 32;
+        __shared__ double sZq2[2][4][64];
+        const int lane = tid & 63, wave = tid >> 6;
+        const int chunk = (nr + 3) / 4, kb = wave * chunk, ke = (kb + chunk < nr) ? kb + chunk : nr;
+        const int il0 = lane < nr ? lane : nr - 1, il1 = 64 + lane < nr ? 64 + lane : nr - 1;
+        const bool two = nr > 64;
+        double q0[QB], q1[QB];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            const int k = kb + u, kc = k < nr ? k : nr - 1;
+            q0[u] = a.Q[(size_t)kc * a.ldq + il0];
+            q1[u] = two ? a.Q[(size_t)kc * a.ldq + il1] : 0.0;
+        }
+        double za[4] = {0.0, 0.0, 0.0, 0.0}, zb[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            const int k = kb + u;
+            const double pk = k < ke ? sP[k] : 0.0;
+            za[u & 3] += k < ke ? q0[u] * pk : 0.0;
+            zb[u & 3] += k < ke ? q1[u] * pk : 0.0;
+        }
+        sZq2[0][wave][lane] = (za[0] + za[1]) + (za[2] + za[3]);
+        sZq2[1][wave][lane] = (zb[0] + zb[1]) + (zb[2] + zb[3]);
+        __syncthreads();
+        if (wave == 0) {
+            for (int ps = 0; ps < (two ? 2 : 1); ++ps) {
+                const int i = 64 * ps + lane;
+                if (i < nr) {
+                    const double zi = (sZq2[ps][0][lane] + sZq2[ps][1][lane]) + (sZq2[ps][2][lane] + sZq2[ps][3][lane]);
+                    sZ[i] = zi;
+                    pz += zi * zi;
+                }
+            }
+        }
+        __syncthreads();
     } else {
         // z = Q^T p: lane -> column i (64 at a time), wavefront w -> the w-th quarter of the summation index, sixteen
         // loads in flight at a time (a plain loop waits for every load in turn); the quarters meet in LDS in a fixed order
@@ -414,8 +588,12 @@ __global__ __launch_bounds__(256) void lr_plan_kernel(PlanArgs a) { lr_plan_vb(v
 // the first term's plan needs nothing but what lr_pre_kernel leaves: one workgroup does both (what the first writes to
 // global memory is visible to the whole workgroup behind the barrier)
 __device__ __forceinline__ void lr_pre_plan_vb(const VB vb, PreArgs pa, PlanArgs pl) {
-    lr_pre_body(pa);
+    // (fast form: the plan reads p_1 and D where the first half left them in LDS instead of through L2)
+    __shared__ double shP[256], shD[256];
+    const bool fast = pa.nr <= 256 && pa.n <= 256 * LR_ROW2_REGS;
+    lr_pre_body(pa, fast ? shP : nullptr, fast ? shD : nullptr);
     __syncthreads();
+    if (fast) { pl.p = shP; pl.Dcur = shD; }
     lr_plan_body(pl);
 }
 __global__ __launch_bounds__(256) void lr_pre_plan_kernel(PreArgs pa, PlanArgs pl) { lr_pre_plan_vb(vb_hw(), pa, pl); }

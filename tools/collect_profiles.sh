@@ -7,6 +7,7 @@ cp $S/bench_line.json $P/${RP}_bench_line.json
 for k in bench eigh davidson_loop block_iter optimizer_step; do cp $S/${k}_kernel_stats.md $P/${RP}_${k}_kernel_stats.md; done
 cp $S/opt_step_timeline.txt $P/${RP}_opt_step_timeline.txt; cp $S/emt_step_timeline.txt $P/${RP}_emt_step_timeline.txt
 cp $S/dav_iter_timeline.txt $P/${RP}_dav_iter_timeline.txt
+cp $S/block_iter_timeline.txt $P/${RP}_block_iter_timeline.txt
 { echo "# configs[3] in lockstep cohorts (session $TAG): tools/emt_ensemble.py — t<T>: T host threads, one member each at a time; c<W>x<T>: T issuing threads, each advancing a cohort of W members (csrc/cohort.hip)"; echo '```'; cat $S/emt_cohorts.log | cut -c1-400; echo '```'; echo; echo "## GPU busy fraction of one cohort of 8 (rocprofv3 --kernel-trace of tools/emt_ensemble.py 8 c8; tools/cohort_busy.py over the launches of the timed pass; the profiler slows the host side)"; echo '```'; cat $S/cohort_busy.txt | cut -c1-200; echo '```'; echo; echo "## launches asked for by the members / issued after merging, by kernel body; microseconds of member host code in front of each park (SELLA_COHORT_TRACE=2; warm-up pass included)"; echo '```'; cat $S/cohort_by_kernel.log | cut -c1-160; echo '```'; } > $P/${RP}_cohorts.md
 cp $S/member1_kernel_stats.md $P/${RP}_member_search_kernel_stats.md; cp $S/cohort8_kernel_stats.md $P/${RP}_cohort8_kernel_stats.md
 { echo "# tridiagonalisation at 3N = 3072 by trailing size (session $TAG): blocked chain above eigh_upd_max = 1024 rows, one launch per column below"; echo; cat $S/eigh_by_m.txt; echo; echo '## eigh wall time by switch-over size'; echo '```'; cat $S/eigh_switch.log; echo '```'; } > $P/${RP}_eigh_by_m.md

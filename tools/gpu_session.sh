@@ -76,7 +76,11 @@ rm -rf $OUT/pmc_mfma_eigh
 cat $OUT/pmc_mfma.txt | tee -a $OUT/session.log
 say "== timings"
 SELLA_DEBUG_TIMING=1 timeout 300 python tools/dav_time.py > $OUT/dav_time.log 2>&1; grep -v "^davidson\|^eigh" $OUT/dav_time.log | tail -4 | tee -a $OUT/session.log; grep "^davidson" $OUT/dav_time.log | tail -1 | tee -a $OUT/session.log
-timeout 300 python tools/block_iter.py > $OUT/block_iter.log 2>&1; cat $OUT/block_iter.log | tee -a $OUT/session.log
+BLOCK_ITER_CONVERGE=1 timeout 300 python tools/block_iter.py > $OUT/block_iter.log 2>&1; cat $OUT/block_iter.log | tee -a $OUT/session.log
+SELLA_BD_TIMING=1 timeout 300 python tools/block_iter.py 12288 12 1 2>&1 | grep "^block davidson" | tail -4 | cut -c1-260 >> $OUT/block_iter.log
+(cd /tmp && rm -rf /tmp/bt && timeout 300 rocprofv3 --kernel-trace -d /tmp/bt -o bt -- python $R/tools/block_iter.py 12288 12 1 > /dev/null 2>&1)
+python tools/block_timeline_parse.py /tmp/bt > $OUT/block_iter_timeline.txt 2>&1; cat $OUT/block_iter_timeline.txt | tee -a $OUT/session.log
+SELLA_DEBUG_TIMING=1 timeout 300 python tools/dav_fixed.py 2>&1 | grep "allocation\|maxiter" | tail -4 | tee -a $OUT/session.log
 SELLA_DEBUG_TIMING=1 timeout 300 python tools/opt_profile.py 3072 20 > $OUT/opt_3072.log 2> $OUT/opt_3072_timing.log; head -12 $OUT/opt_3072.log | tee -a $OUT/session.log
 grep "update_H\|rank-one" $OUT/opt_3072_timing.log | tail -3 | tee -a $OUT/session.log
 SELLA_DEBUG_TIMING=1 timeout 300 python tools/emt_slab_opt.py > $OUT/emt.log 2> $OUT/emt_timing.log; grep "per optimizer step" -A8 $OUT/emt.log | tee -a $OUT/session.log

@@ -707,7 +707,9 @@ def main():
     # H sharded over the ranks (strong scaling: the operator is fixed, every rank streams n / N rows of it and ONE
     # all-gather per block iteration assembles H V).  The operator is a dense symmetric pseudo-random matrix built
     # panel by panel from an integer hash (no rank ever holds more than its rows); the iteration count is fixed,
-    # so the figure is time per block iteration, not convergence (that is tests/test_big_gpu.py).
+    # so the figure is time per block iteration, not convergence (that is tests/test_big_gpu.py).  The tolerance is the
+    # parity tests' (1e-10: no pair reaches it in 12 iterations, residuals are ~0.1); rounds 1-5 passed 1e-14, which no
+    # path can meet and which makes the pipelined driver (round 6) hold A T to 4 eps |A| by taking its matrix pass late.
     block_stats = None
     if args.block_n > 0 and args.block_iters > 0:
         from sella_amd import device as _dev2
@@ -727,7 +729,7 @@ def main():
         dg_all = comm.allgather_host(dgl).sum(axis=0) if world > 1 else dgl
         op = RowShardedOperator(Hloc, lo_, nb_)
         del Hloc, hsh, a_, b_
-        op.block_davidson(16, block=16, tol=1e-14, maxiter=2, diag=dg_all)          # warm-up
+        op.block_davidson(16, block=16, tol=1e-10, maxiter=2, diag=dg_all)          # warm-up
         # one panel pass alone (the roofline-relevant part of the iteration): 8 * rows * n bytes
         Xp = np.random.RandomState(1).standard_normal((nb_, 16))
         op.local_matmat(Xp)
@@ -739,7 +741,7 @@ def main():
         pp = ctx.prof_get(0)
         barrier()
         tb = time.perf_counter()
-        outb = op.block_davidson(16, block=16, tol=1e-14, maxiter=args.block_iters, diag=dg_all)
+        outb = op.block_davidson(16, block=16, tol=1e-10, maxiter=args.block_iters, diag=dg_all)
         ctx.sync()
         tblk = comm.max_host(time.perf_counter() - tb)
         nit = max(1, outb['niter'])

@@ -334,7 +334,11 @@ struct Blk {
     // pipelined iteration (run_pipelined): restart targets, restart coefficients W (32 x kcap)
     double *Valt = nullptr, *AValt = nullptr, *dW = nullptr;
     long n_clean = 0, n_second = 0, n_direct = 0, n_refresh = 0;
-    double av_err = 1.0;           // bound on the errors the rows of AV carry, units of eps |A| (run_pipelined)
+    double anorm = 0.0;            // scale of the operator as far as known (largest |diagonal entry| / |eigenvalue of P|)
+    bool early_ok = true;          // the last block's transformed A T stayed inside the error budget: apply A to the raw block again
+    long n_late = 0;               // blocks whose matrix pass waited for the final T (A T exact)
+    double av_err = 1.0;           // largest error estimate over the rows of AV, units of eps |A| (run_pipelined)
+    vec err;                       // ... row by row
 };
 
 int blk_alloc(Blk& s) {
@@ -491,7 +495,13 @@ int svqb_host(const double* S, const double* pre, const char* skip, int nt, doub
     }
     if (clean && pre) {
         bool ok = mk == m && (int)live.size() == nt - nskip && sig[0] > 1e-3 * smax;
-        for (int a = 0; a < m && ok; ++a) ok = S[live[a] * BD_NB + live[a]] >= 0.25 * pre[live[a]];
+        if (amp) {
+            // (pipelined driver) one Gram-Schmidt pass leaves the block orthogonal to V to eps times the cancellation:
+            // the product of norm loss and block conditioning up to 100 (2e-14) ends the orthonormalisation
+            ok = ok && *amp <= 100.0;
+        } else {
+            for (int a = 0; a < m && ok; ++a) ok = S[live[a] * BD_NB + live[a]] >= 0.25 * pre[live[a]];
+        }
         *clean = ok;
     }
     // T_new[jj] = sum_a dinv_a U[a][j] / sqrt(sig_j) T[live_a]
@@ -571,9 +581,10 @@ inline double bd_now_us() {
 //         T = S (T' - X V),   A T = S (A T' - X AV).
 //     A `clean` pass (the projection kept at least a quarter of every row, block condition below 1e3) ends there;
 //     otherwise the block takes a second Gram-Schmidt pass, T and A T again transformed alike (n_second).  The
-//     transformed A T inherits the errors of the AV rows times |X| / |T' - X V| (its `gain`: above one they would grow
-//     from block to block) plus the fresh product's times the cancellation (`amp`): an error budget (av_err) is carried
-//     and the block's A T recomputed from T itself by one more matrix pass when it would pass 1e-12 |A| (n_direct).
+//     transformed A T inherits the errors of the AV rows through its coefficients and adds the fresh product's times the
+//     cancellation: an error estimate per row of AV is carried (Blk::err), and the block's A T is recomputed from T itself by
+//     one more matrix pass when a row would pass 2e-12 |A| (n_direct; with AV = A V recomputed when the basis rows are the
+//     cause, n_refresh).
 //   * the residual norms are read together with the Gram matrix (convergence is decided one wait later, the corrections
 //     of converged pairs are dropped from the block by the SVQB coefficients), so the iteration has no wait between the
 //     Rayleigh-Ritz step and the matrix pass;
@@ -640,6 +651,7 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
         gram_rows(0, nbk);
     }
     const int nwant = nev;
+    s.err.assign(kcap + BD_NB, 1.0);
     vec Sg((size_t)BD_NB * BD_NB), pre(BD_NB), Cf;
     while (true) {
         int k = s.k;
@@ -670,6 +682,15 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
             std::swap(s.AV, s.AValt);
             std::fill(s.G.begin(), s.G.end(), 0.0);
             for (int a = 0; a < keep; ++a) s.G[(size_t)a * kcap + a] = theta[a];
+            {
+                vec en(keep);
+                for (int a = 0; a < keep; ++a) {
+                    double acc = 0.0;
+                    for (int b = 0; b < k; ++b) acc += Wt[(size_t)a * k + b] * Wt[(size_t)a * k + b] * s.err[b] * s.err[b];
+                    en[a] = std::max(1.0, sqrt(acc));
+                }
+                for (int a = 0; a < keep; ++a) s.err[a] = en[a];
+            }
             theta.resize(keep);
             Wt.assign((size_t)keep * keep, 0.0);
             for (int a = 0; a < keep; ++a) Wt[(size_t)a * keep + a] = 1.0;
@@ -728,8 +749,10 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
         }
         // hY[h][a] = V_a . T'_h (a < k: the projection coefficients X) and T'_{a-k} . T'_h (the block's Gram matrix): marked
         SCHK(launch_panel16_marked(c, s.V, kt, n, ld, Ts, nwant, hY, kcap));
-        // ---- the matrix pass on the raw block (into scratch rows: the final transformation writes the rows behind AV) --------
-        SCHK(apply_A(s, Ts, nwant, s.AT, false));                // (counted below: the rows of unconverged pairs)
+        // ---- the matrix pass on the raw block (into scratch rows: the final transformation writes the rows behind AV) — unless
+        // the last block's transformed A T left the error budget: then A waits for the final T (27 us later, exact) --------
+        const bool early = s.early_ok;
+        if (early) SCHK(apply_A(s, Ts, nwant, s.AT, false));     // (counted below: the rows of unconverged pairs)
         const double t2 = timing ? bd_now_us() : 0.0;
         SCHK(poll_wait(c));
         const double t3 = timing ? bd_now_us() : 0.0;
@@ -741,8 +764,15 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
         // afresh); coefficient rows [-S X | S] over the k + 16 rows transform T' and A T' where they stand ----------------
         static const bool force2 = getenv("SELLA_BD_FORCE2") != nullptr;       // (test aid: second pass and A T from T, always)
         int mk = nwant;
-        bool clean = false, direct = false, stop = false;
-        double amp = 1.0, gain = 0.0;
+        bool clean = false, direct = false, stop = false, refreshed = false;
+        double amp = 1.0, gain = 0.0, inherited = 0.0;
+        // Error budget of the transformed A T, ROW BY ROW (units of eps |A|; `err`: what every row of AV carries).  Row h of
+        // the new block inherits sqrt(sum_a c_ha^2 err_a^2) through its coefficients c = [-S X | S] over the basis rows and
+        // adds the fresh product's error times the cancellation (`amp`).  Measured (tools/block_iter_hash.py, SELLA_BD_CHECK):
+        // with corrections that project onto OLD, accurate rows the error of A T follows amp eps for forty iterations whatever
+        // |X| is; it compounds — exponentially — only when a block projects onto the rows just added (a start block of random
+        // vectors under a diagonal preconditioner).  The per-row sum tells the two apart; a scalar bound |X| max(err) did not.
+        double errb[BD_NB];
         for (int pass = 0; pass < 2; ++pass) {
             const int nt = mk;
             for (int h = 0; h < nt; ++h) {
@@ -777,14 +807,24 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
                                    c->stream, n, kt, s.dC, kcap, s.V, s.AV, ld);
             HIPCHK(hipGetLastError());
             mk = m2;
+            {
+                double eb[BD_NB];
+                for (int jj = 0; jj < BD_NB; ++jj) {
+                    const double* cf = Cf.data() + (size_t)jj * kcap;
+                    double acc = 0.0, fresh = 0.0;
+                    for (int a = 0; a < k; ++a) acc += cf[a] * cf[a] * s.err[a] * s.err[a];
+                    if (pass == 0) {
+                        inherited = std::max(inherited, sqrt(acc));
+                        fresh = amp;
+                    } else {
+                        for (int j = 0; j < nt; ++j) acc += cf[k + j] * cf[k + j] * errb[j] * errb[j];
+                    }
+                    eb[jj] = (jj < m2) ? sqrt(acc) + fresh : 0.0;
+                }
+                for (int jj = 0; jj < BD_NB; ++jj) errb[jj] = eb[jj];
+            }
             if (pass == 0) {
-                // Error budget of the transformed A T (units of eps |A|): what the rows of AV already carry comes back multiplied
-                // by `gain` (the X AV term), the fresh product A T' by `amp`.  Past 1e4 (1e-12 |A|) the block's A T is
-                // recomputed from T itself by one more matrix pass, and when the basis rows are near the limit, so are they.
-                const double err_new = gain * s.av_err + amp;
-                direct = !(err_new <= 1e4) || force2;
-                if (!direct) s.av_err = std::max(s.av_err, err_new);
-                if (force2) clean = false;
+                if (force2 || getenv("SELLA_BD_ALWAYS2")) clean = false;
                 if (clean) { ++s.n_clean; break; }
                 ++s.n_second;
                 SCHK(launch_panel16_marked(c, s.V, kt, n, ld, Ts, mk, hY, kcap));
@@ -792,23 +832,69 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
             }
         }
         if (stop) { ++r.iter; export_W(k); break; }              // the corrections are in span(V): nothing left to add
+        // The budget: an error delta in AV puts a floor of about delta under the residual norms, and the caller asks for
+        // tol |theta|: 5 % of that, between 4 and 1e4 units (below 4 no path delivers).  Past it the block's A T is
+        // computed from T itself (one more matrix pass if the raw block's was already taken), and the next block's matrix
+        // pass waits for its final T; when it is what the basis rows carry that put it there, AV = A V is recomputed too.
+        double errmax = 0.0;
+        for (int h = 0; h < mk; ++h) errmax = std::max(errmax, errb[h]);
+        double anorm = s.anorm, thref = 0.0;
+        for (int a = 0; a < k; ++a) anorm = std::max(anorm, fabs(theta[a]));
+        for (int h = 0; h < nwant; ++h) { const double th_h = std::max(fabs(theta[h]), 1e-2 * anorm); thref = (h == 0) ? th_h : std::min(thref, th_h); }
+        const double limit = std::min(1e4, std::max(4.0, 0.05 * tol * thref / (2.220446049250313e-16 * std::max(anorm, 1e-300))));
+        direct = !(errmax <= limit) || force2 || !early;
+        s.early_ok = errmax <= 0.5 * limit;
+        static const bool never_direct = getenv("SELLA_BD_NEVER_DIRECT") != nullptr;      // (measurement aid)
+        if (never_direct) direct = false;
+        if (getenv("SELLA_BD_CHECK")) {
+            // measurement aid: the transformed A T against A T computed from T itself
+            SCHK(apply_A(s, Ts, mk, s.MID, false));
+            vec a1((size_t)n * mk), a2((size_t)n * mk);
+            SCHK(download_panel(c, ATs, ld, n, mk, a1.data()));
+            SCHK(download_panel(c, s.MID, ld, n, mk, a2.data()));
+            double e = 0.0, m = 0.0;
+            for (size_t q = 0; q < a1.size(); ++q) { e = std::max(e, fabs(a1[q] - a2[q])); m = std::max(m, fabs(a2[q])); }
+            fprintf(stderr, "    CHECK iteration %d: transformed A T against A T: max diff %.3e (max entry %.3e), gain %.2e amp %.2e bound %.2e%s\n", r.iter, e, m,
+                    gain, amp, errmax, direct ? " (direct)" : "");
+        }
         if (direct) {
-            ++s.n_direct;
+            if (early) ++s.n_direct; else ++s.n_late;
             SCHK(apply_A(s, Ts, mk, ATs, false));
-            if (s.av_err > 1e4 / 16.0) {
+            for (int h = 0; h < BD_NB; ++h) errb[h] = 1.0;
+            if (inherited > 0.5 * limit) {
                 // the basis rows are near the limit themselves: AV = A V afresh, 16 rows per matrix pass
                 for (int a0 = 0; a0 < k; a0 += BD_NB) {
                     // (a last chunk shorter than 16 rows multiplies rows of the new block too: their products are what stands there)
                     SCHK(apply_A(s, s.V + (size_t)a0 * ld, std::min(BD_NB, kt - a0), s.AV + (size_t)a0 * ld, false));
                 }
                 ++s.n_refresh;
-                s.av_err = 1.0;
+                refreshed = true;
+                for (int a = 0; a < k; ++a) s.err[a] = 1.0;
             }
         }
+        for (int h = 0; h < mk; ++h) s.err[k + h] = std::max(1.0, errb[h]);
+        s.av_err = 0.0;
+        for (int a = 0; a < k + mk; ++a) s.av_err = std::max(s.av_err, s.err[a]);
         // ---- new rows of the projected matrix ------------------------------------------------------------------------------------
         SCHK(launch_panel16_marked(c, s.V, k + mk, n, ld, ATs, mk, hY, kcap));
         SCHK(poll_wait(c));
         gram_rows(k, mk);
+        if (refreshed) {
+            // AV was recomputed: so is the projected matrix V^T AV (what it held was measured against the old rows)
+            const int kn = k + mk;
+            for (int a0 = 0; a0 < k; a0 += BD_NB) {
+                const int nh = std::min(BD_NB, kn - a0);
+                SCHK(launch_panel16_marked(c, s.V, kn, n, ld, s.AV + (size_t)a0 * ld, nh, hY, kcap));
+                SCHK(poll_wait(c));
+                for (int h = 0; h < nh; ++h)
+                    for (int a = 0; a < kn; ++a) s.G[(size_t)a * kcap + a0 + h] = hY[(size_t)h * kcap + a];
+            }
+            for (int a = 0; a < kn; ++a)
+                for (int b = 0; b < a; ++b) {
+                    const double v = 0.5 * (s.G[(size_t)a * kcap + b] + s.G[(size_t)b * kcap + a]);
+                    s.G[(size_t)a * kcap + b] = s.G[(size_t)b * kcap + a] = v;
+                }
+        }
         s.k = k + mk;
         ++r.iter;
         if (timing) {
@@ -896,6 +982,7 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
         double amax = 0.0;
         for (int i = 0; i < n; ++i) amax = std::max(amax, fabs(pdiag[i]));
         s.guard = std::max(1e-300, 1e-10 * amax);
+        s.anorm = amax;
     }
 
     // ---- start block ------------------------------------------------------------------------------------
@@ -960,7 +1047,7 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
         run.kept = kept;
         BCHK(run_pipelined(s, run, nev, block, tol, maxiter));
         if (getenv("SELLA_BD_TIMING"))
-            fprintf(stderr, "block davidson (pipelined): %d iterations, %ld clean blocks, %ld with a second pass, %ld blocks with A T recomputed, %ld refreshes of AV, error bound %.1e eps\n", iter, s.n_clean, s.n_second, s.n_direct, s.n_refresh, s.av_err);
+            fprintf(stderr, "block davidson (pipelined): %d iterations, %ld clean blocks, %ld with a second pass, %ld blocks with A T recomputed, %ld with the matrix pass behind the final T, %ld refreshes of AV, error estimate %.1e eps |A|\n", iter, s.n_clean, s.n_second, s.n_direct, s.n_late, s.n_refresh, s.av_err);
     }
     while (!pipelined) {
         // ---- append the orthonormal block in s.T: V, AV, Gram rows ------------------------------------------

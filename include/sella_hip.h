@@ -66,8 +66,9 @@ int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
  *   eigh_tail_lds (128) the last <= 128 columns of the tridiagonalisation inside one workgroup, the block in LDS |
  *   rs_batch (1) bisection phase of sella_restricted_step: 15 trial alphas per device round trip |
  *   panel_small (2048) panel products with <= 64 rows and <= 16 right-hand sides take the split-K kernels from this
- *   many columns on | bd_pipeline (1) sella_davidson_block applies A to the raw correction block while the host
- *   orthonormalises it (two polled waits per iteration; 0: the general loop) | lr_dev (1) sella_opt_step updates structured eigendecompositions in
+ *   many columns on | bd_pipeline (1) sella_davidson_block as a pipelined iteration: projection and block Gram
+ *   matrix from one panel product, two polled waits per iteration (0: the general loop) | bd_early_matvec (0) ... with A applied
+ *   to the raw correction block while the host orthonormalises it (error budget for the transformed A T) | lr_dev (1) sella_opt_step updates structured eigendecompositions in
  *   coordinates with every decision on the device (0: the host-planned rank-one merges of sella_update_h_lr) |
  *   eigh_wy_waves (4), eigh_wy_rows (16) wavefronts / rows of X per workgroup of the back-transformation (8, 16 / 32
  *   measured equal or slower) | rank2k_fixed (1) trailing update with all loads up front | lr_cholqr (1) block of update

@@ -246,6 +246,11 @@ __global__ __launch_bounds__(256) void dav_eigscale_kernel(int n, int nh, const 
 // rows [row0, row0 + nrows) of the eigenbasis panels from the raw panels: QtV_a = Q^T V_a, QtAV_a = Q^T AV_a
 int qt_update(Dav& s, int row0, int nrows) {
     sella_ctx* c = s.c;
+    if (nrows == 1 && s.QtAV == s.QtV + (size_t)s.cap * s.ld) {
+        // one vector: its image and the image of its product in ONE pass over Q^T (as the fused iteration does)
+        const double* xs[2] = {s.Vp + (size_t)row0 * s.ld, s.AVp + (size_t)row0 * s.ld};
+        return launch_gemv_rows_xp(c, s.Qt->d, s.n, s.n, s.Qt->ld, xs, 2, s.QtV + (size_t)row0 * s.ld, s.cap * s.ld, GemvEpi());
+    }
     for (int r = row0; r < row0 + nrows; r += 8) {
         const int nr = std::min(8, row0 + nrows - r);
         SCHK(launch_gemv_rows(c, s.Qt->d, s.n, s.n, s.Qt->ld, s.Vp + (size_t)r * s.ld, s.ld, nr, s.QtV + (size_t)r * s.ld, s.ld,
@@ -776,12 +781,15 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
     vec Wc;            // cumulative rotation raw -> Ritz basis (k x k)
     // ---- start block: V = mgs(v0) (eigensolvers.py:44-50), AV = A V ----------------------
     {
-        double* tmp;
-        DCHK(scratch_get(c, SCR_X, (size_t)nv0 * s.ld * sizeof(double), &tmp));
-        DCHK(upload_panel(c, v0, n, nv0, tmp, s.ld));
+        double* tmp = nullptr;
+        if (nv0 > 1) {
+            DCHK(scratch_get(c, SCR_X, (size_t)nv0 * s.ld * sizeof(double), &tmp));
+            DCHK(upload_panel(c, v0, n, nv0, tmp, s.ld));
+        }
         for (int j = 0; j < nv0; ++j) {
             double* slot = s.Vp + (size_t)s.k * s.ld;
-            DHIP(s_memcpy(c, slot, tmp + (size_t)j * s.ld, (size_t)s.ld * sizeof(double), hipMemcpyDeviceToDevice));
+            if (nv0 == 1) DCHK(h2d_async(c, slot, v0, (size_t)n * sizeof(double)));          // (one start vector: straight into its slot)
+            else DHIP(s_memcpy(c, slot, tmp + (size_t)j * s.ld, (size_t)s.ld * sizeof(double), hipMemcpyDeviceToDevice));
             int kept = 0;
             DCHK(orthonormalise(s, slot, s.k, &kept, nullptr));
             if (kept) DCHK(append_vector(s, Wc));
@@ -1288,8 +1296,12 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
         SELLA_LAUNCHB(c, dav_to_columns_kernel, dav_to_columns_vb, 256, dim3((n + 31) / 32, 2 * ((k + 31) / 32)), dim3(256), 0, n, k,
                       (const double*)s.Vq, (const double*)s.AVq, s.ld, cols);
         DHIP(hipGetLastError());
-        DCHK(d2h_async(c, V_out, cols, (size_t)n * k * sizeof(double)));
-        DCHK(d2h_async(c, AV_out, cols + (size_t)n * k, (size_t)n * k * sizeof(double)));
+        if (AV_out == V_out + (size_t)n * k) {
+            DCHK(d2h_async(c, V_out, cols, 2 * (size_t)n * k * sizeof(double)));
+        } else {
+            DCHK(d2h_async(c, V_out, cols, (size_t)n * k * sizeof(double)));
+            DCHK(d2h_async(c, AV_out, cols + (size_t)n * k, (size_t)n * k * sizeof(double)));
+        }
         DCHK(stream_wait(c));
     }
     *k_out = k;

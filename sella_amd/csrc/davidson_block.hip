@@ -136,43 +136,6 @@ __global__ __launch_bounds__(256) void bd_combine_pair_kernel(int n, int nh, int
     }
 }
 
-// In-place transformation of the 16 rows behind the basis, both panels in one launch (blockIdx.z):
-//   slot_h <- sum_{a < kt} C[h ldc + a] P_z[a],   slot = rows [kt - 16, kt) of P_z,   h < 16.
-// A thread owns one column and all 16 outputs, reads its column of every row before it writes: no other thread touches
-// that column, so the rows may be overwritten where they stand.  (T, A T) = S (T' - X V, A T' - X AV) with the coefficient
-// rows [-S X | S] is one such launch.
-constexpr int BD_TR_THREADS = 64;
-__global__ __launch_bounds__(BD_TR_THREADS) void bd_transform_kernel(int n, int kt, const double* __restrict__ C, int ldc,
-                                                                     double* __restrict__ P0, double* __restrict__ P1, int ldp) {
-    __shared__ double cs[64][BD_NB];
-    double* __restrict__ P = blockIdx.z ? P1 : P0;
-    const int i = blockIdx.x * BD_TR_THREADS + threadIdx.x;
-    double acc[BD_NB];
-#pragma unroll
-    for (int h = 0; h < BD_NB; ++h) acc[h] = 0.0;
-    for (int a0 = 0; a0 < kt; a0 += 64) {
-        const int jt = (kt - a0 < 64) ? (kt - a0) : 64;
-        __syncthreads();
-        for (int t = threadIdx.x; t < jt * BD_NB; t += BD_TR_THREADS) {
-            const int a = t / BD_NB, h = t % BD_NB;
-            cs[a][h] = C[(size_t)h * ldc + a0 + a];
-        }
-        __syncthreads();
-        if (i < n) {
-#pragma unroll 4
-            for (int a = 0; a < jt; ++a) {
-                const double p = P[(size_t)(a0 + a) * ldp + i];
-#pragma unroll
-                for (int h = 0; h < BD_NB; ++h) acc[h] += cs[a][h] * p;
-            }
-        }
-    }
-    if (i < n) {
-#pragma unroll
-        for (int h = 0; h < BD_NB; ++h) P[(size_t)(kt - BD_NB + h) * ldp + i] = acc[h];
-    }
-}
-
 // Residuals of the lowest Ritz pairs when the basis IS the Ritz basis (right after a thick restart):
 // R_h = (AV)_h - theta_h V_h, and the diagonally preconditioned correction T_h = R_h / (d - theta_h) beside it
 // (d null: T = R), the latter twice: into the rows behind the basis and into scratch rows (T2, may be null).  Rows
@@ -264,16 +227,19 @@ __global__ __launch_bounds__(256) void bd_resid_coef_kernel(int n, int nh, int k
 
 // (T, A T) = [-S X | S] applied to [basis rows; raw block] for both panels in one launch (blockIdx.z), out of place:
 //   out_z[h] = sum_{a < k} C[h ldc + a] P_z[a] + sum_{j < 16} C[h ldc + k + j] B_z[j],   h < 16,
-// P_z the basis panel (V / AV), B_z the raw block kept in scratch rows (T' / A T'), out_z the 16 rows behind the basis.
+// P_z the basis panel (V / AV), B_z the raw block kept in scratch rows (T' / A T'), out_z the 16 rows behind the basis
+// (cp_z, optional: the same rows once more in scratch, the B_z of a second pass).  grid.z = 1: the V panel only.
 // Workgroup (x, y, z): 256 columns, outputs 4 y .. 4 y + 3.
 __global__ __launch_bounds__(256) void bd_transform2_kernel(int n, int k, const double* __restrict__ C, int ldc,
                                                             const double* __restrict__ P0, const double* __restrict__ P1,
                                                             const double* __restrict__ B0, const double* __restrict__ B1, int ldp,
-                                                            double* __restrict__ out0, double* __restrict__ out1) {
+                                                            double* __restrict__ out0, double* __restrict__ out1,
+                                                            double* __restrict__ cp0, double* __restrict__ cp1) {
     __shared__ double cs[128][BD_HG];
     const double* __restrict__ P = blockIdx.z ? P1 : P0;
     const double* __restrict__ B = blockIdx.z ? B1 : B0;
     double* __restrict__ out = blockIdx.z ? out1 : out0;
+    double* __restrict__ cp = blockIdx.z ? cp1 : cp0;              // (may be null: a second copy for a pass that follows)
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int h0 = blockIdx.y * BD_HG;
     const int kt = k + BD_NB;
@@ -300,7 +266,10 @@ __global__ __launch_bounds__(256) void bd_transform2_kernel(int n, int k, const 
     }
     if (i < n) {
 #pragma unroll
-        for (int h = 0; h < BD_HG; ++h) out[(size_t)(h0 + h) * ldp + i] = acc[h];
+        for (int h = 0; h < BD_HG; ++h) {
+            out[(size_t)(h0 + h) * ldp + i] = acc[h];
+            if (cp) cp[(size_t)(h0 + h) * ldp + i] = acc[h];
+        }
     }
 }
 
@@ -608,6 +577,11 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
                               ? hY + (size_t)BD_NB * kcap : nullptr;
     if (512 + (size_t)BD_NB * kcap > (size_t)(DS_TOTAL - DS_GRAM)) { set_error("davidson_block: basis too large for the exchange buffer"); return SELLA_E_UNSUPPORTED; }
     static const bool timing = getenv("SELLA_BD_TIMING") != nullptr;
+    // measurement / debugging aids (environment, read once): second pass always, checks of the new block against V and of the
+    // transformed A T against A T, row norms of the basis per iteration, the error budget by hand
+    static const bool aid_always2 = getenv("SELLA_BD_ALWAYS2") != nullptr, aid_check2 = getenv("SELLA_BD_CHECK2") != nullptr,
+                      aid_check = getenv("SELLA_BD_CHECK") != nullptr, aid_norms = getenv("SELLA_BD_TRACE_NORMS") != nullptr;
+    static const char* const aid_limit = getenv("SELLA_BD_LIMIT");
     const double* dprec = s.Q ? nullptr : s.dP;
     vec Gk, Wt, theta, Ch, pk;
     std::vector<char> skip(BD_NB, 0);
@@ -789,6 +763,7 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
             if (pass == 0) SCHK(svqb_host(Sg.data(), pre.data(), skip.data(), nt, 1e-6, Ch, &m2, &clean, &amp, &gain));
             else SCHK(svqb_host(Sg.data(), nullptr, nullptr, nt, 1e-6, Ch, &m2, nullptr));
             if (m2 == 0) { stop = true; break; }
+            if (pass == 0 && (force2 || aid_always2)) clean = false;
             Cf.assign((size_t)BD_NB * kcap, 0.0);
             for (int jj = 0; jj < m2; ++jj) {
                 double* cf = Cf.data() + (size_t)jj * kcap;
@@ -801,12 +776,15 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
                 }
             }
             SCHK(h2d_async(c, s.dC, Cf.data(), ((size_t)(BD_NB - 1) * kcap + kt) * sizeof(double)));
+            // (both panels only with the early matrix pass; a block that is not clean leaves a second copy of its rows in
+            // scratch, which the second pass reads while it writes the rows behind the basis)
+            const unsigned nz = early ? 2u : 1u;
             if (pass == 0)
-                hipLaunchKernelGGL(bd_transform2_kernel, dim3(nblk, BD_NB / BD_HG, 2), dim3(256), 0, c->stream, n, k, s.dC, kcap, s.V, s.AV,
-                                   s.T, s.AT, ld, Ts, ATs);
-            else                                             // (second pass: the rows are transformed where they stand)
-                hipLaunchKernelGGL(bd_transform_kernel, dim3((n + BD_TR_THREADS - 1) / BD_TR_THREADS, 1, 2), dim3(BD_TR_THREADS), 0,
-                                   c->stream, n, kt, s.dC, kcap, s.V, s.AV, ld);
+                hipLaunchKernelGGL(bd_transform2_kernel, dim3(nblk, BD_NB / BD_HG, nz), dim3(256), 0, c->stream, n, k, s.dC, kcap, s.V, s.AV,
+                                   s.T, s.AT, ld, Ts, ATs, clean ? nullptr : s.T2, clean ? nullptr : s.MID);
+            else
+                hipLaunchKernelGGL(bd_transform2_kernel, dim3(nblk, BD_NB / BD_HG, nz), dim3(256), 0, c->stream, n, k, s.dC, kcap, s.V, s.AV,
+                                   s.T2, s.MID, ld, Ts, ATs, (double*)nullptr, (double*)nullptr);
             HIPCHK(hipGetLastError());
             mk = m2;
             {
@@ -826,7 +804,6 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
                 for (int jj = 0; jj < BD_NB; ++jj) errb[jj] = eb[jj];
             }
             if (pass == 0) {
-                if (force2 || getenv("SELLA_BD_ALWAYS2")) clean = false;
                 if (clean) { ++s.n_clean; break; }
                 ++s.n_second;
                 SCHK(launch_panel16_marked(c, s.V, kt, n, ld, Ts, mk, hY, kcap));
@@ -834,7 +811,7 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
             }
         }
         if (stop) { ++r.iter; export_W(k); break; }              // the corrections are in span(V): nothing left to add
-        if (getenv("SELLA_BD_CHECK2")) {
+        if (aid_check2) {
             SCHK(launch_panel16_marked(c, s.V, kt, n, ld, Ts, mk, hY, kcap));
             SCHK(poll_wait(c));
             double ov = 0.0, ot = 0.0, vv = 0.0;
@@ -857,12 +834,12 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
         for (int a = 0; a < k; ++a) anorm = std::max(anorm, fabs(theta[a]));
         for (int h = 0; h < nwant; ++h) { const double th_h = std::max(fabs(theta[h]), 1e-2 * anorm); thref = (h == 0) ? th_h : std::min(thref, th_h); }
         double limit = std::min(1e4, std::max(4.0, 0.05 * tol * thref / (2.220446049250313e-16 * std::max(anorm, 1e-300))));
-        if (const char* lim = getenv("SELLA_BD_LIMIT")) limit = atof(lim);                 // (measurement aid)
+        if (aid_limit) limit = atof(aid_limit);
         direct = !(errmax <= limit) || force2 || !early;
         s.early_ok = c->opt.bd_early_matvec && errmax <= 0.5 * limit;
         static const bool never_direct = getenv("SELLA_BD_NEVER_DIRECT") != nullptr;      // (measurement aid)
         if (never_direct) direct = false;
-        if (getenv("SELLA_BD_CHECK")) {
+        if (aid_check) {
             // measurement aid: the transformed A T against A T computed from T itself
             SCHK(apply_A(s, Ts, mk, s.MID, false));
             vec a1((size_t)n * mk), a2((size_t)n * mk);
@@ -913,7 +890,7 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
         }
         s.k = k + mk;
         ++r.iter;
-        if (getenv("SELLA_BD_TRACE_NORMS")) {
+        if (aid_norms) {
             SCHK(launch_rows_sumsq(c, s.V, ld, s.k, n, c->dscal + DS_MISC));
             SCHK(read_scalars(c, DS_MISC, s.k));
             double mn = 1e300; int arg = -1;

@@ -791,6 +791,25 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
             if (nv0 == 1) DCHK(h2d_async(c, slot, v0, (size_t)n * sizeof(double)));          // (one start vector: straight into its slot)
             else DHIP(s_memcpy(c, slot, tmp + (size_t)j * s.ld, (size_t)s.ld * sizeof(double), hipMemcpyDeviceToDevice));
             int kept = 0;
+            if (nv0 == 1 && c->opt.host_scalars && !(c->opt.gs_small && n <= c->opt.gs_small) && !(c->cohort && cohort_in_fiber())) {
+                // one start vector, scalars in the pinned mirror: its normalisation and its product A v are queued together
+                // and waited for ONCE (the norms of the sweeps are read behind append_vector's wait) — the decision below is
+                // gs_orthonormalise's for an empty basis; a vector that fails it leaves through the error exit as before
+                DCHK(gs_project_twice(c, s.Vp, s.ld, 0, slot, n));
+                DCHK(append_vector(s, Wc));
+                const double n0sq = c->hscal[8], n1 = sqrt(c->hscal[9]), n2 = sqrt(c->hscal[10]);
+                kept = (n0sq > 0.0) && (n1 == n1) && (n1 >= 1e-6) && (n2 == n2) && (n2 >= 1e-6) && (fabs(1.0 - n2) <= 1e-15);
+                if (!kept) {
+                    // (rare: a third sweep is needed, or the vector is numerically zero) back to the step-by-step path
+                    s.k = 0;
+                    s.nmatvec = 0;
+                    Wc.clear();
+                    DCHK(h2d_async(c, slot, v0, (size_t)n * sizeof(double)));
+                    DCHK(orthonormalise(s, slot, s.k, &kept, nullptr));
+                    if (kept) DCHK(append_vector(s, Wc));
+                }
+                continue;
+            }
             DCHK(orthonormalise(s, slot, s.k, &kept, nullptr));
             if (kept) DCHK(append_vector(s, Wc));
         }

@@ -837,7 +837,7 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
     const double t_begin = now();
     if (s.qt_mode) {
         DCHK(qt_update(s, 0, s.k));
-        DHIP(hipEventCreate(&s.ev));
+        // (the event of the un-polled wait is created when first needed: creating and destroying one per call was ~10 us)
     }
     while (true) {
         ++s.it;
@@ -1148,7 +1148,10 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
                 const int cnt = (int)(S0 + 8 + nneg);
                 if (!c->opt.host_scalars)
                     DHIP(s_memcpy(c, c->hscal + DS_GRAM, c->dscal + DS_GRAM, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, true));
-                if (!poll) DHIP(hipEventRecord(s.ev, c->stream));
+                if (!poll) {
+                    if (!s.ev) DHIP(hipEventCreate(&s.ev));
+                    DHIP(hipEventRecord(s.ev, c->stream));
+                }
                 const double* xs[2] = {s.Vp + (size_t)k * s.ld, s.AVp + (size_t)k * s.ld};
                 DCHK(launch_gemv_rows_xp(c, s.Qt->d, n, n, s.Qt->ld, xs, 2, s.QtV + (size_t)k * s.ld, capn * s.ld, GemvEpi()));
                 if (poll) DCHK(poll_wait(c));

@@ -67,7 +67,7 @@ int sella_ctx_device_name(sella_ctx* ctx, char* buf, int buflen);
  *   rs_batch (1) bisection phase of sella_restricted_step: 15 trial alphas per device round trip |
  *   panel_small (2048) panel products with <= 64 rows and <= 16 right-hand sides take the split-K kernels from this
  *   many columns on | bd_pipeline (1) sella_davidson_block as a pipelined iteration: projection and block Gram
- *   matrix from one panel product, two polled waits per iteration (0: the general loop) | bd_early_matvec (0) ... with A applied
+ *   matrix from one panel product, two polled waits per iteration (0: the general loop) | bd_early_matvec (1) ... with A applied
  *   to the raw correction block while the host orthonormalises it (error budget for the transformed A T) | lr_dev (1) sella_opt_step updates structured eigendecompositions in
  *   coordinates with every decision on the device (0: the host-planned rank-one merges of sella_update_h_lr) |
  *   eigh_wy_waves (4), eigh_wy_rows (16) wavefronts / rows of X per workgroup of the back-transformation (8, 16 / 32
@@ -196,7 +196,8 @@ int sella_davidson(sella_ctx* ctx, sella_mat A, sella_matvec_fn matvec, void* us
  *    sella_davidson: t = Q (d - theta)^-1 Q^T r, the 'gd' correction of sella/eigensolvers.py:119-121), else
  *    diag (n, host: t_i = r_i / (diag_i - theta)), else none.
  * V0 (n x nv0, host, nv0 <= 16) start block or NULL.  tol: a pair counts as converged when
- *    |r| <= tol |theta| (the reference's gamma test, sella/eigensolvers.py:80-89).
+ *    |r| <= tol |theta| (the reference's gamma test, sella/eigensolvers.py:80-89).  maxvec: basis limit before a thick
+ *    restart, 0 = nev + 3 block (room for two blocks between restarts; at least nev + 2 block).
  * Outputs (host): lams (nev), V (n x nev row-major), res (nev residual norms, may be NULL), *niter,
  *    *nmatvec (operator columns applied), *nconv (pairs converged; nev on success).
  * The gather callback is stream-ordered (no synchronisation around it); the re-entrancy contract above applies.     */

@@ -545,16 +545,16 @@ inline double bd_now_us() {
 //     and ONE launch with the coefficient rows [-S X | S] (S from the host's SVQB step) turns those rows into
 //     T = S (T' - X V).  A `clean` pass (the projection kept at least a quarter of every row, block condition below 1e3)
 //     ends there; otherwise a second pass of the same two launches follows (n_second).  Then the matrix pass A T.
-//   * option bd_early_matvec (off): A is applied to the RAW block T' while the host does the SVQB step, and the same
+//   * option bd_early_matvec (on): A is applied to the RAW block T' while the host does the SVQB step, and the same
 //     coefficients give A T = S (A T' - X AV) — the matrix pass covers the host's share, 0.44 instead of 0.47 ms per
 //     iteration at 3N = 12288.  The transformed A T inherits the errors of the AV rows through its coefficients: an error
 //     estimate per row of AV is carried (Blk::err), the budget is 5 % of tol |theta| (4 .. 1e4 eps |A|), past it the
 //     matrix pass waits for the final T again and, when the basis rows are the cause, AV and V^T AV are recomputed
 //     (n_direct / n_late / n_refresh).  Measured: the error follows amp eps when corrections project onto old rows and
-//     compounds x10 per block when they project onto rows just added; the estimate tracks both (SELLA_BD_CHECK).  Off by
-//     default all the same: with start blocks of random vectors under a diagonal preconditioner 2 runs in 6 stagnate
-//     (two pairs converged, three stuck at residuals ~1) with errors held below 2e-12 |A| — none does with A T exact,
-//     and none in the general loop; not understood, so not shipped as the default.
+//     compounds x10 per block when they project onto rows just added; the estimate tracks both within 20 x
+//     (SELLA_BD_CHECK).  (For half of round 6 this was off: runs from random start blocks stagnated with it — and, it
+//     turned out, without it too, only less often: the thick restart kept 32 of 37 vectors when nev = 5, block = 16; see
+//     the restart below.)
 //   * the residual norms are read together with the Gram matrix (convergence is decided one wait later, the corrections
 //     of converged pairs are dropped from the block by the SVQB coefficients), so the iteration has no wait between the
 //     Rayleigh-Ritz step and the matrix pass;
@@ -582,6 +582,7 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
     static const bool aid_always2 = getenv("SELLA_BD_ALWAYS2") != nullptr, aid_check2 = getenv("SELLA_BD_CHECK2") != nullptr,
                       aid_check = getenv("SELLA_BD_CHECK") != nullptr, aid_norms = getenv("SELLA_BD_TRACE_NORMS") != nullptr;
     static const char* const aid_limit = getenv("SELLA_BD_LIMIT");
+    static const char* const aid_keep = getenv("SELLA_BD_KEEP");
     const double* dprec = s.Q ? nullptr : s.dP;
     vec Gk, Wt, theta, Ch, pk;
     std::vector<char> skip(BD_NB, 0);
@@ -649,7 +650,13 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
         // by a few rows for one iteration — the panels hold maxvec + 16)
         bool ritz_basis = false;
         if (k + std::max(1, nwant - r.nconv) > s.maxvec) {
-            const int keep = std::min(k, std::max(nev + block, 2 * block));
+            // Vectors kept: twice the wanted pairs (at least eight beyond them), leaving room for the next block.  The
+            // general loop's max(nev + block, 2 block) presumes `block` new vectors per iteration; here an iteration adds at
+            // most nev <= block, and with nev = 5, block = 16 that rule keeps 32 of 37 and restarts EVERY iteration: the
+            // iteration then crawls (theta_0 0.9 -> 0.65 in 70 iterations with residuals ~2) until enough pairs converge for
+            // two blocks to fit between restarts — or never does (what looked like a defect of bd_early_matvec in round 6).
+            int keep = std::min(k, std::max(nev, std::min(std::max(2 * nev, nev + 8), s.maxvec - nev)));
+            if (aid_keep) keep = std::min(k, std::max(nev, atoi(aid_keep)));                  // (measurement aid)
             SCHK(put_rows(s.dW, kcap, Wt.data(), keep, k, k));
             hipLaunchKernelGGL(bd_combine_pair_kernel, dim3((n + 255) / 256, (keep + BD_HG - 1) / BD_HG, 2), dim3(256), 0, c->stream, n,
                                keep, k, s.dW, kcap, s.V, s.AV, ld, s.Valt, s.AValt, ld);
@@ -938,10 +945,11 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
     if (block <= 0 || block > BD_NB) block = BD_NB;
     if (nev > n) nev = n;
     if (block > n) block = n;
-    // default basis limit: the nev + block lowest Ritz vectors kept at a restart plus one new block — the k x k
-    // Rayleigh-Ritz problem on the host is O(k^3) in scalar code (0.5 ms at k = 48, 3 ms at k = 96: more than the
-    // whole device side of an iteration at 3N = 12288), so a larger history has to be asked for explicitly
-    if (maxvec <= 0) maxvec = std::max(nev + 2 * block, 24);
+    // default basis limit: the Ritz vectors kept at a restart plus TWO new blocks.  One block of room (nev + 2 block, the
+    // default until round 6) means a thick restart in every iteration: at 3N = 12288, nev = block = 16, tol 1e-9 that takes
+    // 439 iterations / 185 ms to converge against 220 / 106 ms with a second block between restarts, and 149 / 108 ms with
+    // four (tools/block_restart_sweep.py; the k x k Rayleigh-Ritz problem on the host is O(k^3): 0.1 ms at k = 48, 0.25 at 64)
+    if (maxvec <= 0) maxvec = std::max(nev + 3 * block, 24);
     if (maxvec < nev + 2 * block) maxvec = nev + 2 * block;
     if (maxvec > n) maxvec = n;
     if (maxvec + BD_NB > 2048) {

@@ -139,7 +139,7 @@ struct Options {
     long rank2k_stream = 1;  // 1: trailing update of the tridiagonalisation as a mirror-free MFMA stream (update.hip)
     long panel_small = 2048; // panel products with <= 64 rows and at least this many columns split the long index over the
                              // chip (kernels.hip); 0: never
-    long bd_early_matvec = 0; // pipelined block Davidson: 1 = A applied to the raw correction block while the host orthonormalises it
+    long bd_early_matvec = 1; // pipelined block Davidson: 1 = A applied to the raw correction block while the host orthonormalises it
                              // (A T by the same coefficients as T, error budget; see davidson_block.hip), 0 = A applied to the final T
     long bd_pipeline = 1;    // block Davidson: pipelined iteration (davidson_block.hip run_pipelined: A applied to the raw correction
                              // block while the host does the SVQB step, two polled waits per iteration); 0: the general loop

@@ -119,8 +119,9 @@ def test_block_davidson_pipelined_against_general_loop(ctx, precond):
     np.testing.assert_allclose(outs[1]['lams'], outs[0]['lams'], atol=1e-10)
 
 
+@pytest.mark.parametrize('early', [1, 0])
 @pytest.mark.parametrize('seed', [102, 103])
-def test_block_davidson_pipelined_random_start_block(ctx, seed):
+def test_block_davidson_pipelined_random_start_block(ctx, seed, early):
     """The hard regime: a start block of RANDOM vectors under a diagonal preconditioner (corrections that lie almost
     entirely inside the basis: projections cancel four to ten digits, every block takes the second Gram-Schmidt pass).
     The pipelined driver must get through it like the general loop does (84 - 91 iterations on sixteen such starts)."""
@@ -129,14 +130,19 @@ def test_block_davidson_pipelined_random_start_block(ctx, seed):
     A = np.diag(np.arange(1, n + 1) * 0.5) + 0.02 * (N + N.T)
     dA = ctx.upload(A)
     V0 = np.random.RandomState(seed).normal(size=(n, 7))
-    out = ctx.davidson_block(dA, n, 5, block=16, tol=1e-9, maxiter=200, V0=V0, diag=np.diag(A).copy())
+    ctx.set_option('bd_early_matvec', early)
+    try:
+        out = ctx.davidson_block(dA, n, 5, block=16, tol=1e-9, maxiter=200, V0=V0, diag=np.diag(A).copy())
+    finally:
+        ctx.set_option('bd_early_matvec', 1)
     check_pairs(A, out, 5)
+    assert out['niter'] < 120          # (84 - 91 in the general loop; 71 - 77 here since the restart keeps 2 nev vectors)
 
 
 def test_block_davidson_early_matrix_pass(ctx):
-    """Option bd_early_matvec: A applied to the raw correction block while the host orthonormalises it, A T transformed by
-    the coefficients that transform T, under the per-row error budget — same converged pairs as with A applied to the
-    final block (default)."""
+    """Option bd_early_matvec (default 1): A applied to the raw correction block while the host orthonormalises it, A T
+    transformed by the coefficients that transform T, under the per-row error budget — same converged pairs as with A
+    applied to the final block (0)."""
     n, nev = 300, 16
     N = np.random.RandomState(11).normal(size=(n, n))
     A = np.diag(np.arange(1, n + 1) * 0.5) + 0.02 * (N + N.T)
@@ -147,7 +153,7 @@ def test_block_davidson_early_matrix_pass(ctx):
         try:
             outs[flag] = ctx.davidson_block(dA, n, nev, block=16, tol=1e-9, maxiter=400, diag=np.diag(A).copy())
         finally:
-            ctx.set_option('bd_early_matvec', 0)
+            ctx.set_option('bd_early_matvec', 1)
         check_pairs(A, outs[flag], nev)
     np.testing.assert_allclose(outs[1]['lams'], outs[0]['lams'], atol=1e-10)
 

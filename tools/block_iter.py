@@ -24,10 +24,10 @@ del H
 flags = [int(a) for a in sys.argv[3:]] or [1, 0, 1]
 for flag in flags:
     ctx.set_option('bd_pipeline', flag)
-    ctx.davidson_block(dH, n, 16, block=16, tol=1e-10, maxiter=2, diag=diag)
+    ctx.davidson_block(dH, n, 16, block=16, tol=1e-10, maxiter=2, maxvec=48, diag=diag)
     ctx.sync()
     t = time.perf_counter()
-    out = ctx.davidson_block(dH, n, 16, block=16, tol=1e-10, maxiter=iters, diag=diag)
+    out = ctx.davidson_block(dH, n, 16, block=16, tol=1e-10, maxiter=iters, maxvec=48, diag=diag)
     ctx.sync()
     dt = time.perf_counter() - t
     print('bd_pipeline=%d: %d iterations, %.3f ms per block iteration, lowest Ritz %.12f'

@@ -681,6 +681,7 @@ int sella_ctx_set_option(sella_ctx* c, const char* key, long value) {
     else if (!strcmp(key, "rs_batch")) c->opt.rs_batch = value ? 1 : 0;
     else if (!strcmp(key, "bd_pipeline")) c->opt.bd_pipeline = value ? 1 : 0;
     else if (!strcmp(key, "bd_early_matvec")) c->opt.bd_early_matvec = value ? 1 : 0;
+    else if (!strcmp(key, "dav_rotate_fused")) c->opt.dav_rotate_fused = value ? 1 : 0;
     else if (!strcmp(key, "panel_small")) c->opt.panel_small = value > 0 ? value : 0;
     else if (!strcmp(key, "eigh_leaf")) {
         if (value < 2 || value > 64) { set_error("eigh_leaf must be in [2, 64]"); return SELLA_E_INVALID; }

@@ -690,6 +690,38 @@ __device__ __forceinline__ void dav_to_columns_vb(const VB vb, int n, int k, con
 __global__ __launch_bounds__(256) void dav_to_columns_kernel(int n, int k, const double* __restrict__ P0,
                                                              const double* __restrict__ P1, int ld, double* __restrict__ out) { dav_to_columns_vb(vb_hw(), n, k, P0, P1, ld, out); }
 
+// The rotation into the Ritz basis and the change of layout in ONE launch for k <= KM (the usual case: tens of vectors):
+//   out[(z n + i) k + j] = sum_a W[a k + j] P_z[a][i],   z = 0: V, 1: AV,
+// a thread owns column i of one panel and all k outputs (accumulated over a in ascending order, like launch_lincomb), the
+// k x k coefficients come from LDS.  Replaces two lincomb launches and the transposition (three launches, ~15 us).
+template <int KM>
+__device__ __forceinline__ void dav_rotate_columns_vb(const VB vb, int n, int k, const double* __restrict__ W,
+                                                      const double* __restrict__ P0, const double* __restrict__ P1, int ld,
+                                                      double* __restrict__ out) {
+    __shared__ double ws[KM * KM];
+    const double* __restrict__ P = vb.y ? P1 : P0;
+    for (int t = threadIdx.x; t < k * k; t += 256) ws[(t / k) * KM + (t % k)] = W[t];
+    __syncthreads();
+    const int i = vb.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double acc[KM];
+#pragma unroll
+    for (int j = 0; j < KM; ++j) acc[j] = 0.0;
+    for (int a = 0; a < k; ++a) {
+        const double p = P[(size_t)a * ld + i];
+#pragma unroll
+        for (int j = 0; j < KM; ++j) acc[j] += (j < k ? ws[a * KM + j] : 0.0) * p;
+    }
+    double* o = out + ((size_t)vb.y * n + i) * k;
+#pragma unroll
+    for (int j = 0; j < KM; ++j)
+        if (j < k) o[j] = acc[j];
+}
+template <int KM>
+__global__ __launch_bounds__(256) void dav_rotate_columns_kernel(int n, int k, const double* __restrict__ W,
+                                                                 const double* __restrict__ P0, const double* __restrict__ P1, int ld,
+                                                                 double* __restrict__ out) { dav_rotate_columns_vb<KM>(vb_hw(), n, k, W, P0, P1, ld, out); }
+
 }  // namespace
 }  // namespace sella
 
@@ -1306,17 +1338,23 @@ extern "C" int sella_davidson(sella_ctx* c, sella_mat hA, sella_matvec_fn matvec
     const int k = s.k;
     for (int i = 0; i < k; ++i) lams_out[i] = lams[i];
     {
-        double* dWp;
+        double *dWp, *cols;
         DCHK(put_small(s, Wc.data(), k * k, 0, 0, &dWp));
-        DCHK(launch_lincomb(c, n, k, s.Vp, s.ld, k, dWp, k, nullptr, 0, 0, nullptr, 0, 0.0, s.Vq, s.ld));
-        DCHK(launch_lincomb(c, n, k, s.AVp, s.ld, k, dWp, k, nullptr, 0, 0, nullptr, 0, 0.0, s.AVq, s.ld));
-    }
-    {
-        // both panels in the caller's layout on the device, one transfer, plain copies into the caller's arrays
-        double* cols;
+        // both panels rotated and in the caller's layout on the device, one transfer, plain copies into the caller's arrays
         DCHK(scratch_get(c, SCR_X, 2 * (size_t)n * k * sizeof(double), &cols));
-        SELLA_LAUNCHB(c, dav_to_columns_kernel, dav_to_columns_vb, 256, dim3((n + 31) / 32, 2 * ((k + 31) / 32)), dim3(256), 0, n, k,
-                      (const double*)s.Vq, (const double*)s.AVq, s.ld, cols);
+        const dim3 grot((n + 255) / 256, 2);
+        if (k <= 16 && c->opt.dav_rotate_fused) {
+            SELLA_LAUNCHB(c, HIP_KERNEL_NAME(dav_rotate_columns_kernel<16>), SELLA_BODY(dav_rotate_columns_vb<16>), 256, grot, dim3(256), 0, n, k,
+                          (const double*)dWp, (const double*)s.Vp, (const double*)s.AVp, s.ld, cols);
+        } else if (k <= 32 && c->opt.dav_rotate_fused) {
+            SELLA_LAUNCHB(c, HIP_KERNEL_NAME(dav_rotate_columns_kernel<32>), SELLA_BODY(dav_rotate_columns_vb<32>), 256, grot, dim3(256), 0, n, k,
+                          (const double*)dWp, (const double*)s.Vp, (const double*)s.AVp, s.ld, cols);
+        } else {
+            DCHK(launch_lincomb(c, n, k, s.Vp, s.ld, k, dWp, k, nullptr, 0, 0, nullptr, 0, 0.0, s.Vq, s.ld));
+            DCHK(launch_lincomb(c, n, k, s.AVp, s.ld, k, dWp, k, nullptr, 0, 0, nullptr, 0, 0.0, s.AVq, s.ld));
+            SELLA_LAUNCHB(c, dav_to_columns_kernel, dav_to_columns_vb, 256, dim3((n + 31) / 32, 2 * ((k + 31) / 32)), dim3(256), 0, n, k,
+                          (const double*)s.Vq, (const double*)s.AVq, s.ld, cols);
+        }
         DHIP(hipGetLastError());
         if (AV_out == V_out + (size_t)n * k) {
             DCHK(d2h_async(c, V_out, cols, 2 * (size_t)n * k * sizeof(double)));

@@ -139,6 +139,7 @@ struct Options {
     long rank2k_stream = 1;  // 1: trailing update of the tridiagonalisation as a mirror-free MFMA stream (update.hip)
     long panel_small = 2048; // panel products with <= 64 rows and at least this many columns split the long index over the
                              // chip (kernels.hip); 0: never
+    long dav_rotate_fused = 1; // sella_davidson's result stage: rotation into the Ritz basis and the caller's layout in one launch (k <= 32)
     long bd_early_matvec = 1; // pipelined block Davidson: 1 = A applied to the raw correction block while the host orthonormalises it
                              // (A T by the same coefficients as T, error budget; see davidson_block.hip), 0 = A applied to the final T
     long bd_pipeline = 1;    // block Davidson: pipelined iteration (davidson_block.hip run_pipelined: A applied to the raw correction

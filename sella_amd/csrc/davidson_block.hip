@@ -306,6 +306,7 @@ struct Blk {
     double anorm = 0.0;            // scale of the operator as far as known (largest |diagonal entry| / |eigenvalue of P|)
     bool early_ok = true;          // the last block's transformed A T stayed inside the error budget: apply A to the raw block again
     long n_late = 0;               // blocks whose matrix pass waited for the final T (A T exact)
+    long n_lanczos = 0;            // blocks that fell back to the residuals themselves
     double av_err = 1.0;           // largest error estimate over the rows of AV, units of eps |A| (run_pipelined)
     vec err;                       // ... row by row
 };
@@ -747,7 +748,7 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
         // afresh); coefficient rows [-S X | S] over the k + 16 rows transform T' and A T' where they stand ----------------
         static const bool force2 = getenv("SELLA_BD_FORCE2") != nullptr;       // (test aid: second pass and A T from T, always)
         int mk = nwant;
-        bool clean = false, direct = false, stop = false, refreshed = false;
+        bool clean = false, direct = false, stop = false, refreshed = false, fragile = false;
         double amp = 1.0, gain = 0.0, inherited = 0.0;
         // Error budget of the transformed A T, ROW BY ROW (units of eps |A|; `err`: what every row of AV carries).  Row h of
         // the new block inherits sqrt(sum_a c_ha^2 err_a^2) through its coefficients c = [-S X | S] over the basis rows and
@@ -756,6 +757,8 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
         // |X| is; it compounds — exponentially — only when a block projects onto the rows just added (a start block of random
         // vectors under a diagonal preconditioner).  The per-row sum tells the two apart; a scalar bound |X| max(err) did not.
         double errb[BD_NB];
+        bool lanczos = false;
+        for (;;) {
         for (int pass = 0; pass < 2; ++pass) {
             const int nt = mk;
             for (int h = 0; h < nt; ++h) {
@@ -767,8 +770,34 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
                 }
             }
             int m2 = 0;
-            if (pass == 0) SCHK(svqb_host(Sg.data(), pre.data(), skip.data(), nt, 1e-6, Ch, &m2, &clean, &amp, &gain));
-            else SCHK(svqb_host(Sg.data(), nullptr, nullptr, nt, 1e-6, Ch, &m2, nullptr));
+            if (pass == 0) {
+                // T' T'^T - X X^T loses its digits when the projection cancels more than ~eight of them (a correction that lies
+                // in the basis but for roundoff: spikes of a diagonal preconditioner at a start from random vectors): such a
+                // row must not be judged — or dropped — by that difference.  The first pass then only projects and scales
+                // (T_h = (T'_h - X_h V) / |T'_h|), and the second pass measures the block as it really is.
+                fragile = false;
+                for (int h = 0; h < nt; ++h)
+                    if (!skip[h] && pre[h] > 0.0 && !(Sg[(size_t)h * BD_NB + h] >= 1e-8 * pre[h])) fragile = true;
+                if (fragile) {
+                    Ch.assign((size_t)nt * nt, 0.0);
+                    for (int h = 0; h < nt; ++h)
+                        if (!skip[h] && pre[h] > 0.0 && pre[h] == pre[h]) {
+                            Ch[(size_t)m2 * nt + h] = 1.0 / sqrt(pre[h]);
+                            ++m2;
+                        }
+                    clean = false;
+                    amp = 1e8;
+                    gain = 1e8;
+                } else {
+                    SCHK(svqb_host(Sg.data(), pre.data(), skip.data(), nt, 1e-6, Ch, &m2, &clean, &amp, &gain));
+                }
+            } else if (fragile) {
+                // (rows of norm 1 / loss after the scaled projection: the drop rule of the first pass, applied to what was measured)
+                for (int h = 0; h < nt; ++h) pre[h] = 1.0;
+                SCHK(svqb_host(Sg.data(), pre.data(), nullptr, nt, 1e-6, Ch, &m2, nullptr));
+            } else {
+                SCHK(svqb_host(Sg.data(), nullptr, nullptr, nt, 1e-6, Ch, &m2, nullptr));
+            }
             if (m2 == 0) { stop = true; break; }
             if (pass == 0 && (force2 || aid_always2)) clean = false;
             Cf.assign((size_t)BD_NB * kcap, 0.0);
@@ -816,6 +845,25 @@ int run_pipelined(Blk& s, BlkRun& r, int nev, int block, double tol, int maxiter
                 SCHK(launch_panel16_marked(c, s.V, kt, n, ld, Ts, mk, hY, kcap));
                 SCHK(poll_wait(c));
             }
+        }
+        if (stop && !lanczos && (dprec || s.Q)) {
+            // Every preconditioned correction lies in the basis to working precision (a Ritz value inside the spectrum of a
+            // diagonal preconditioner: the correction is a spike along a vector the basis already holds).  The reference
+            // falls back to the residual itself there ("Do Lanczos instead", sella/eigensolvers.py:93-95): so does the block.
+            lanczos = true;
+            stop = clean = direct = fragile = false;
+            mk = nwant;
+            amp = 1.0;
+            gain = inherited = 0.0;
+            HIPCHK(s_memcpy(c, Ts, s.R, s.bytes16, hipMemcpyDeviceToDevice));
+            HIPCHK(s_memcpy(c, s.T, s.R, s.bytes16, hipMemcpyDeviceToDevice));
+            SCHK(launch_panel16_marked(c, s.V, kt, n, ld, Ts, nwant, hY, kcap));
+            if (early) SCHK(apply_A(s, Ts, nwant, s.AT, false));
+            SCHK(poll_wait(c));
+            ++s.n_lanczos;
+            continue;
+        }
+        break;
         }
         if (stop) { ++r.iter; export_W(k); break; }              // the corrections are in span(V): nothing left to add
         if (aid_check2) {
@@ -1068,7 +1116,7 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
         run.kept = kept;
         BCHK(run_pipelined(s, run, nev, block, tol, maxiter));
         if (getenv("SELLA_BD_TIMING"))
-            fprintf(stderr, "block davidson (pipelined): %d iterations, %ld clean blocks, %ld with a second pass, %ld blocks with A T recomputed, %ld with the matrix pass behind the final T, %ld refreshes of AV, error estimate %.1e eps |A|\n", iter, s.n_clean, s.n_second, s.n_direct, s.n_late, s.n_refresh, s.av_err);
+            fprintf(stderr, "block davidson (pipelined): %d iterations, %ld clean blocks, %ld with a second pass, %ld blocks with A T recomputed, %ld with the matrix pass behind the final T, %ld refreshes of AV, %ld blocks of plain residuals, error estimate %.1e eps |A|\n", iter, s.n_clean, s.n_second, s.n_direct, s.n_late, s.n_refresh, s.n_lanczos, s.av_err);
     }
     while (!pipelined) {
         // ---- append the orthonormal block in s.T: V, AV, Gram rows ------------------------------------------

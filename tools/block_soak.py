@@ -22,6 +22,15 @@ for r in range(runs):
     N = rng.normal(size=(n, n))
     A = np.diag(np.sort(rng.uniform(0.5, 0.5 * n, size=n))) + rng.choice([0.005, 0.02, 0.05]) * (N + N.T)
     w = np.linalg.eigvalsh(A)
+    only = os.environ.get('SOAK_ONLY')
+    if only is not None and int(only) != r:
+        # (draw what the run would have drawn, so that the generator stays in step)
+        if kind.endswith('random'):
+            rng.normal(size=(n, int(rng.choice([min(16, max(nev, 2)), 16]))))
+        if kind == 'eigen':
+            rng.normal(size=n)
+        rng.choice([1e-7, 1e-9]); rng.randint(2)
+        continue
     dA = ctx.upload(A)
     kw = {}
     if kind.startswith('diag'):

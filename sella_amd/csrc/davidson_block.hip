@@ -1241,7 +1241,9 @@ extern "C" int sella_davidson_block(sella_ctx* c, sella_mat hA, int n, int row0,
         BHIP(hipGetLastError());
         // ---- thick restart before the basis overflows ---------------------------------------------------------------
         if (s.k + na > s.maxvec) {
-            const int keep = std::min(s.k, std::max(nev + block, 2 * block));
+            // (nev <= block: an iteration adds at most nev vectors — the rule of run_pipelined, see there; else nev + block)
+            const int keep = (nev <= block) ? std::min(s.k, std::max(nev, std::min(std::max(2 * nev, nev + 8), s.maxvec - nev)))
+                                            : std::min(s.k, std::max(nev + block, 2 * block));
             for (int pass = 0; pass < 2; ++pass) {
                 double* src = pass ? s.AV : s.V;
                 for (int j0 = 0; j0 < keep; j0 += BD_NB) {
